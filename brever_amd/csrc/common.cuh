@@ -1,0 +1,104 @@
+// Shared device helpers for the brever_amd HIP kernels (gfx950 / CDNA4 only).
+//
+// Conventions used by every kernel in this directory:
+//  * activations are channels-last: [batch][frame t][channel], bf16, channel
+//    count padded to a multiple of 64 (padding columns hold exact zeros);
+//  * one wavefront = 64 lanes; workgroups are 256 threads (4 waves);
+//  * reductions that feed normalisation statistics accumulate in fp64 so the
+//    result does not depend on the (unordered) arrival of the partial sums.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace brv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+typedef uint16_t bf16_t;   // storage type of a bf16 element
+
+constexpr int kWave = 64;
+constexpr int kThreads = 256;
+
+// ---- bf16 <-> f32 ---------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 and keeps NaNs
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& q, float (&f)[8]) {
+  f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
+  f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xffff0000u);
+  f[4] = __uint_as_float(q.z << 16); f[5] = __uint_as_float(q.z & 0xffff0000u);
+  f[6] = __uint_as_float(q.w << 16); f[7] = __uint_as_float(q.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 q;
+  q.x = pack2(f[0], f[1]); q.y = pack2(f[2], f[3]);
+  q.z = pack2(f[4], f[5]); q.w = pack2(f[6], f[7]);
+  return q;
+}
+// value a bf16 store would hold, as f32
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ float prelu(float v, float a) {
+  return v > 0.f ? v : a*v;
+}
+
+// ---- reductions -----------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Sum over the 256 threads of a workgroup; result valid in thread 0.
+// `scratch` must hold >= 4 elements of T and is reusable after the call.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  T r = T(0);
+  if (threadIdx.x == 0) r = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+  return r;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- global layer norm statistics ----------------------------------------
+// stats[b] = {sum, sum of squares} over the (frames x true channels) of item b.
+struct NormStat { float mean, rstd; };
+__device__ __forceinline__ NormStat norm_stat(const double* stats, int b,
+                                              double inv_n, float eps) {
+  const double s = stats[2*b], ss = stats[2*b + 1];
+  const double mean = s*inv_n;
+  double var = ss*inv_n - mean*mean;      // biased variance, as nn.GroupNorm
+  if (var < 0.0) var = 0.0;
+  NormStat r;
+  r.mean = (float)mean;
+  r.rstd = (float)(1.0/sqrt(var + (double)eps));
+  return r;
+}
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1)/m*m; }
+__host__ __device__ inline int ceil_div(int x, int m) { return (x + m - 1)/m; }
+
+}  // namespace brv

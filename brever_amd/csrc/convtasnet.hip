@@ -1,0 +1,601 @@
+// Conv-TasNet forward / backward orchestration + C ABI (include/brever_hip.h).
+//
+// Reference being replaced: brever/models/convtasnet/convtasnet.py:66-72 (forward),
+// :100-260 (Encoder / Decoder / TCN / Conv1DBlock) and their autograd. The kernel
+// sequence and the saved-activation plan are described in DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/brever_hip.h"
+#include "gemm_rows.cuh"
+#include "gemm_wgrad.cuh"
+#include "prep.cuh"
+#include "tcn_kernels.cuh"
+
+using namespace brv;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_OK(expr)                                                        \
+  do {                                                                      \
+    hipError_t e_ = (expr);                                                 \
+    if (e_ != hipSuccess)                                                   \
+      return fail((int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+inline long long align_up(long long x, long long a) { return (x + a - 1)/a*a; }
+
+struct BlockOff {
+  long long conv_w, conv_b, dconv_w, dconv_b, res_w, res_b, skip_w, skip_b,
+      n1_g, n1_b, n2_g, n2_b, prelu1, prelu2;
+  long long p_c1_f, p_c1_b, p_rs_f, p_rs_b;     // prepared (bf16 elements)
+};
+
+struct Layout {
+  int N, K, Bn, H, Sc, P, nb, S, hop;
+  int Np, Kfp, Bnp, Hp, Scp;
+  long long enc_w, dec_w, ln_g, ln_b, bott_w, bott_b, tcn_prelu, out_w, out_b, n_params;
+  long long p_enc, p_dec_f, p_dec_b, p_bott_f, p_bott_b, p_out_f, p_out_b, n_prepared;
+  std::vector<BlockOff> blk;
+  std::vector<long long> tensor_offsets;
+
+  int init(const brv_ctn_config* c) {
+    if (!c) return fail(-1, "null config");
+    if (c->causal) return fail(-2, "causal=True (cLN) is not built yet in the HIP path");
+    if (c->filters < 1 || c->filter_length < 2 || c->bottleneck_channels < 1 ||
+        c->hidden_channels < 1 || c->skip_channels < 1 || c->layers < 1 ||
+        c->repeats < 1 || c->output_sources < 1)
+      return fail(-1, "invalid Conv-TasNet hyper-parameters");
+    if (c->kernel_size < 1 || c->kernel_size > 5)
+      return fail(-2, "kernel_size must be in [1, 5] in the HIP path");
+    N = c->filters; K = c->filter_length; Bn = c->bottleneck_channels;
+    H = c->hidden_channels; Sc = c->skip_channels; P = c->kernel_size;
+    nb = c->layers*c->repeats; S = c->output_sources; hop = K/2;
+    Np = round_up(N, 64); Kfp = round_up(K, 64); Bnp = round_up(Bn, 64);
+    Hp = round_up(H, 64); Scp = round_up(Sc, 64);
+    long long o = 0;
+    auto take = [&](long long n) { tensor_offsets.push_back(o); long long r = o; o += n; return r; };
+    enc_w = take((long long)N*K);
+    dec_w = take((long long)N*K);
+    ln_g = take(N); ln_b = take(N);
+    bott_w = take((long long)Bn*N); bott_b = take(Bn);
+    blk.resize(nb);
+    for (int i = 0; i < nb; ++i) {
+      BlockOff& b = blk[i];
+      b.conv_w = take((long long)H*Bn); b.conv_b = take(H);
+      b.dconv_w = take((long long)H*P); b.dconv_b = take(H);
+      if (i < nb - 1) { b.res_w = take((long long)Bn*H); b.res_b = take(Bn); }
+      else { b.res_w = -1; b.res_b = -1; }
+      b.skip_w = take((long long)Sc*H); b.skip_b = take(Sc);
+      b.n1_g = take(H); b.n1_b = take(H); b.n2_g = take(H); b.n2_b = take(H);
+      b.prelu1 = take(1); b.prelu2 = take(1);
+    }
+    tcn_prelu = take(1);
+    out_w = take((long long)S*N*Sc); out_b = take((long long)S*N);
+    n_params = o;
+    // prepared bf16 operands
+    long long q = 0;
+    auto ptake = [&](long long n) { long long r = q; q += align_up(n, 128); return r; };
+    p_enc = ptake((long long)Np*Kfp);
+    p_dec_f = ptake((long long)Kfp*Np);
+    p_dec_b = ptake((long long)Np*Kfp);
+    p_bott_f = ptake((long long)Bnp*Np);
+    p_bott_b = ptake((long long)Np*Bnp);
+    for (int i = 0; i < nb; ++i) {
+      const int rs = (i < nb - 1 ? Bnp : 0) + Scp;
+      blk[i].p_c1_f = ptake((long long)Hp*Bnp);
+      blk[i].p_c1_b = ptake((long long)Bnp*Hp);
+      blk[i].p_rs_f = ptake((long long)rs*Hp);
+      blk[i].p_rs_b = ptake((long long)Hp*rs);
+    }
+    p_out_f = ptake((long long)S*Np*Scp);
+    p_out_b = ptake((long long)Scp*S*Np);
+    n_prepared = q;
+    return 0;
+  }
+
+  long long frames(long long L) const {
+    long long pad = ((K - L) % hop + hop) % hop;      // Python modulo
+    long long Lp = L + pad;
+    if (Lp < K) return 0;
+    return (Lp - K)/hop + 1;
+  }
+};
+
+struct Workspace {
+  long long w, x, z1, z2, skip, m, y, stats, sums, dpre, dw1, gskip, gout, eA, eB,
+      e0, dwt, total;
+  long long x_stride, z_stride;       // bytes between consecutive blocks' buffers
+  long long stats_bytes;
+  void init(const Layout& l, long long B, long long T) {
+    long long o = 0;
+    auto take = [&](long long bytes) { long long r = o; o += align_up(bytes, 256); return r; };
+    const long long BT = B*T;
+    w = take(BT*l.Np*2);
+    x_stride = align_up(BT*l.Bnp*2, 256);
+    x = take(x_stride*l.nb);
+    z_stride = align_up(BT*l.Hp*2, 256);
+    z1 = take(z_stride*l.nb);
+    z2 = take(z_stride*l.nb);
+    skip = take(BT*l.Scp*4);
+    m = take(BT*l.S*l.Np*2);
+    y = take(BT*l.S*l.Np*2);
+    stats_bytes = (long long)(1 + 2*l.nb)*B*2*8;
+    stats = take(stats_bytes);
+    sums = take(stats_bytes);
+    dpre = take(BT*l.S*l.Np*2);
+    dw1 = take(BT*l.S*l.Np*2);
+    gskip = take(BT*l.Scp*2);
+    gout = take(BT*l.Bnp*2);
+    eA = take(BT*l.Hp*2);
+    eB = take(BT*l.Hp*2);
+    e0 = take(BT*l.Np*2);
+    dwt = take(BT*l.Np*2);
+    total = o;
+  }
+};
+
+// ---------------------------------------------------------------------------
+template <int BN, int AK, int EM>
+int launch_gemm_rows_t(const GemmRowsParams& p, int batch, hipStream_t st) {
+  dim3 grid(ceil_div(p.T, GR_BM), ceil_div(p.Np, BN), batch);
+  hipLaunchKernelGGL((gemm_rows_kernel<BN, AK, EM>), grid, dim3(256), 0, st, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template <int AK, int EM>
+int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st) {
+  if (p.T <= 0 || batch <= 0) return 0;
+  if (p.Kp % GR_BK != 0 || p.Np % 64 != 0) return fail(-1, "gemm_rows: unpadded dims");
+  if (p.Np % 128 == 0) return launch_gemm_rows_t<128, AK, EM>(p, batch, st);
+  return launch_gemm_rows_t<64, AK, EM>(p, batch, st);
+}
+
+template <int BH, int HK>
+int launch_wgrad_t(WgradParams& p, hipStream_t st) {
+  const int tiles = ceil_div(p.Gp, WG_BG)*(p.Hp/BH);
+  const int total = p.B*ceil_div(p.T, WG_BT);
+  int ns = ceil_div(768, tiles);
+  if (ns > total) ns = total;
+  if (ns < 1) ns = 1;
+  p.nsplit = ns;
+  dim3 grid(tiles, ns);
+  hipLaunchKernelGGL((gemm_wgrad_kernel<BH, HK>), grid, dim3(256), 0, st, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+template <int HK>
+int launch_wgrad(WgradParams& p, hipStream_t st) {
+  if (p.T <= 0 || p.B <= 0) return 0;
+  if (p.Hp % 64 != 0) return fail(-1, "wgrad: unpadded dims");
+  if (p.Hp % 128 == 0) return launch_wgrad_t<128, HK>(p, st);
+  return launch_wgrad_t<64, HK>(p, st);
+}
+
+template <template <int> class F, typename... Args>
+int dispatch_p(int P, Args&&... args) {
+  switch (P) {
+    case 1: return F<1>::run(args...);
+    case 2: return F<2>::run(args...);
+    case 3: return F<3>::run(args...);
+    case 4: return F<4>::run(args...);
+    case 5: return F<5>::run(args...);
+  }
+  return fail(-2, "unsupported kernel_size");
+}
+template <int P> struct DwFwd {
+  static int run(const DwParams& p, hipStream_t st) {
+    dim3 grid(ceil_div(p.T, DW_TT), p.Cp/64, p.B);
+    hipLaunchKernelGGL((dwconv_fwd_kernel<P>), grid, dim3(256), 0, st, p);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+};
+template <int P> struct DwBwd {
+  static int run(const DwParams& p, hipStream_t st) {
+    dim3 grid(ceil_div(p.T, DW_TT), p.Cp/64, p.B);
+    hipLaunchKernelGGL((dwconv_bwd_kernel<P>), grid, dim3(256), 0, st, p);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+};
+
+int launch_dz(const DzParams& p, hipStream_t st) {
+  const long long per_item = (long long)p.T*(p.Cp/8);
+  int gx = (int)((per_item + 256*4 - 1)/(256*4));
+  if (gx > 2048) gx = 2048;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(dz_kernel, dim3(gx, p.B), dim3(256), 0, st, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+ASpec rows_bf16(const void* ptr, int ld, long long T) {
+  ASpec a; memset(&a, 0, sizeof(a));
+  a.p0 = ptr; a.ld0 = ld; a.bs0 = T*ld; a.K0 = 1 << 30; a.nsrc = 1;
+  return a;
+}
+void set_affine(ASpec& a, const double* stats, const float* g, const float* b, int C,
+                long long T) {
+  a.stats = stats; a.gamma = g; a.beta = b; a.C = C;
+  a.inv_n = 1.0/((double)T*(double)C); a.eps = 1e-8f;
+}
+ASpec frames_of(const float* wav, long long L, int hop, int K) {
+  ASpec a; memset(&a, 0, sizeof(a));
+  a.p0 = wav; a.hop = hop; a.Kf = K; a.wav_stride = L; a.wav_len = (int)L;
+  a.K0 = 1 << 30; a.nsrc = 1;
+  return a;
+}
+
+struct PrepBatch { PrepJob jobs[64]; int n; };
+__global__ __launch_bounds__(256) void prep_weights_kernel(const float* params,
+                                                           bf16_t* prepped,
+                                                           const PrepBatch pb) {
+  prep_job_run(params, prepped, pb.jobs[blockIdx.y], blockIdx.x, gridDim.x);
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+int brv_version(void) { return 100; }
+const char* brv_last_error(void) { return g_err.c_str(); }
+
+int64_t brv_ctn_param_count(const brv_ctn_config* cfg) {
+  Layout l; if (l.init(cfg)) return -1; return l.n_params;
+}
+int64_t brv_ctn_param_tensors(const brv_ctn_config* cfg) {
+  Layout l; if (l.init(cfg)) return -1; return (int64_t)l.tensor_offsets.size();
+}
+int64_t brv_ctn_param_offset(const brv_ctn_config* cfg, int64_t index) {
+  Layout l; if (l.init(cfg)) return -1;
+  if (index < 0 || index >= (int64_t)l.tensor_offsets.size()) return -1;
+  return l.tensor_offsets[index];
+}
+int64_t brv_ctn_frames(const brv_ctn_config* cfg, int64_t length) {
+  Layout l; if (l.init(cfg)) return -1; return l.frames(length);
+}
+int64_t brv_ctn_prepared_bytes(const brv_ctn_config* cfg) {
+  Layout l; if (l.init(cfg)) return -1; return l.n_prepared*2;
+}
+int64_t brv_ctn_workspace_bytes(const brv_ctn_config* cfg, int64_t batch, int64_t length) {
+  Layout l; if (l.init(cfg)) return -1;
+  Workspace ws; ws.init(l, batch, l.frames(length));
+  return ws.total;
+}
+int64_t brv_ctn_workspace_offset(const brv_ctn_config* cfg, int64_t batch, int64_t length,
+                                 const char* name, int64_t index) {
+  Layout l; if (l.init(cfg)) return -1;
+  Workspace ws; ws.init(l, batch, l.frames(length));
+  const std::string n(name);
+  if (n == "w") return ws.w;
+  if (n == "x") return ws.x + ws.x_stride*index;
+  if (n == "z1") return ws.z1 + ws.z_stride*index;
+  if (n == "z2") return ws.z2 + ws.z_stride*index;
+  if (n == "skip") return ws.skip;
+  if (n == "m") return ws.m;
+  if (n == "y") return ws.y;
+  if (n == "stats") return ws.stats + index*batch*16;
+  if (n == "sums") return ws.sums + index*batch*16;
+  if (n == "dpre") return ws.dpre;
+  if (n == "gskip") return ws.gskip;
+  if (n == "gout") return ws.gout;
+  if (n == "dwt") return ws.dwt;
+  fail(-1, "unknown workspace tensor " + n);
+  return -1;
+}
+
+int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepared,
+                    brv_stream_t stream) {
+  Layout l; if (int r = l.init(cfg)) return r;
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<PrepJob> jobs;
+  auto add = [&](long long src, long long dst, int R, int C, int rows, int cols, int ld,
+                 int tr) {
+    PrepJob j; j.src_off = src; j.dst_off = dst; j.R = R; j.C = C; j.rows = rows;
+    j.cols = cols; j.dst_ld = ld; j.tr = tr; jobs.push_back(j);
+  };
+  add(l.enc_w, l.p_enc, l.N, l.K, l.Np, l.Kfp, l.Kfp, 0);
+  add(l.dec_w, l.p_dec_f, l.N, l.K, l.Kfp, l.Np, l.Np, 1);
+  add(l.dec_w, l.p_dec_b, l.N, l.K, l.Np, l.Kfp, l.Kfp, 0);
+  add(l.bott_w, l.p_bott_f, l.Bn, l.N, l.Bnp, l.Np, l.Np, 0);
+  add(l.bott_w, l.p_bott_b, l.Bn, l.N, l.Np, l.Bnp, l.Bnp, 1);
+  for (int i = 0; i < l.nb; ++i) {
+    const BlockOff& b = l.blk[i];
+    const bool has_res = i < l.nb - 1;
+    const int rs0 = has_res ? l.Bnp : 0, rs = rs0 + l.Scp;
+    add(b.conv_w, b.p_c1_f, l.H, l.Bn, l.Hp, l.Bnp, l.Bnp, 0);
+    add(b.conv_w, b.p_c1_b, l.H, l.Bn, l.Bnp, l.Hp, l.Hp, 1);
+    if (has_res) {
+      add(b.res_w, b.p_rs_f, l.Bn, l.H, l.Bnp, l.Hp, l.Hp, 0);
+      add(b.res_w, b.p_rs_b, l.Bn, l.H, l.Hp, l.Bnp, rs, 1);
+    }
+    add(b.skip_w, b.p_rs_f + (long long)rs0*l.Hp, l.Sc, l.H, l.Scp, l.Hp, l.Hp, 0);
+    add(b.skip_w, b.p_rs_b + rs0, l.Sc, l.H, l.Hp, l.Scp, rs, 1);
+  }
+  for (int s = 0; s < l.S; ++s) {
+    add(l.out_w + (long long)s*l.N*l.Sc, l.p_out_f + (long long)s*l.Np*l.Scp,
+        l.N, l.Sc, l.Np, l.Scp, l.Scp, 0);
+    add(l.out_w + (long long)s*l.N*l.Sc, l.p_out_b + (long long)s*l.Np,
+        l.N, l.Sc, l.Scp, l.Np, l.S*l.Np, 1);
+  }
+  for (size_t i = 0; i < jobs.size(); i += 64) {
+    PrepBatch pb;
+    pb.n = (int)std::min<size_t>(64, jobs.size() - i);
+    for (int k = 0; k < pb.n; ++k) pb.jobs[k] = jobs[i + k];
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(8, pb.n), dim3(256), 0, st, params,
+                       (bf16_t*)prepared, pb);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* prepared,
+                    void* workspace, const float* wave, float* out, int64_t batch,
+                    int64_t length, brv_stream_t stream) {
+  Layout l; if (int r = l.init(cfg)) return r;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = (int)batch; const long long L = length;
+  const long long T = l.frames(L);
+  if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
+  Workspace ws; ws.init(l, B, T);
+  char* base = (char*)workspace;
+  const bf16_t* prep = (const bf16_t*)prepared;
+  double* stats = (double*)(base + ws.stats);
+  auto stat = [&](int i) { return stats + (long long)i*B*2; };
+  bf16_t* w = (bf16_t*)(base + ws.w);
+  auto xbuf = [&](int i) { return (bf16_t*)(base + ws.x + ws.x_stride*i); };
+  auto z1buf = [&](int i) { return (bf16_t*)(base + ws.z1 + ws.z_stride*i); };
+  auto z2buf = [&](int i) { return (bf16_t*)(base + ws.z2 + ws.z_stride*i); };
+  float* skip = (float*)(base + ws.skip);
+  bf16_t* m = (bf16_t*)(base + ws.m);
+  bf16_t* y = (bf16_t*)(base + ws.y);
+
+  HIP_OK(hipMemsetAsync(stats, 0, ws.stats_bytes, st));
+  HIP_OK(hipMemsetAsync(out, 0, (size_t)B*l.S*L*sizeof(float), st));
+
+  GemmRowsParams g;
+  // encoder: framed filterbank analysis, statistics for the first gLN
+  memset(&g, 0, sizeof(g));
+  g.a = frames_of(wave, L, l.hop, l.K);
+  g.W = prep + l.p_enc; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
+  g.e.out = w; g.e.ldo = l.Np; g.e.N = l.N; g.e.stats_out = stat(0);
+  if (int r = launch_gemm_rows<A_FRAMES, E_STORE>(g, B, st)) return r;
+  // bottleneck 1x1 conv on gLN(w)
+  memset(&g, 0, sizeof(g));
+  g.a = rows_bf16(w, l.Np, T);
+  set_affine(g.a, stat(0), params + l.ln_g, params + l.ln_b, l.N, T);
+  g.W = prep + l.p_bott_f; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Np;
+  g.e.out = xbuf(0); g.e.ldo = l.Bnp; g.e.bias = params + l.bott_b; g.e.N = l.Bn;
+  if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st)) return r;
+
+  for (int i = 0; i < l.nb; ++i) {
+    const BlockOff& b = l.blk[i];
+    const bool has_res = i < l.nb - 1;
+    const int dil = 1 << (i % cfg->layers);
+    // 1x1 conv Bn -> H (+ statistics of prelu_1 output)
+    memset(&g, 0, sizeof(g));
+    g.a = rows_bf16(xbuf(i), l.Bnp, T);
+    g.W = prep + b.p_c1_f; g.T = (int)T; g.Np = l.Hp; g.Kp = l.Bnp;
+    g.e.out = z1buf(i); g.e.ldo = l.Hp; g.e.bias = params + b.conv_b; g.e.N = l.H;
+    g.e.stats_out = stat(1 + 2*i); g.e.stats_slope = params + b.prelu1;
+    if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st)) return r;
+    // prelu_1 -> gLN -> depthwise dilated conv (+ statistics of prelu_2 output)
+    DwParams d; memset(&d, 0, sizeof(d));
+    d.z1 = z1buf(i); d.z2 = z2buf(i); d.B = B; d.T = (int)T; d.Cp = l.Hp; d.C = l.H;
+    d.slope1 = params + b.prelu1; d.stats1 = stat(1 + 2*i);
+    d.gamma1 = params + b.n1_g; d.beta1 = params + b.n1_b;
+    d.inv_n = 1.0/((double)T*l.H); d.eps = 1e-8f;
+    d.taps = params + b.dconv_w; d.bias = params + b.dconv_b;
+    d.dil = dil; d.left = ((l.P - 1)*dil)/2;
+    d.stats2 = stat(2 + 2*i); d.slope2 = params + b.prelu2;
+    if (int r = dispatch_p<DwFwd>(l.P, d, st)) return r;
+    // prelu_2 -> gLN -> [res | skip] 1x1 convs, residual add, skip accumulation
+    memset(&g, 0, sizeof(g));
+    g.a = rows_bf16(z2buf(i), l.Hp, T);
+    g.a.slope = params + b.prelu2;
+    set_affine(g.a, stat(2 + 2*i), params + b.n2_g, params + b.n2_b, l.H, T);
+    const int rs0 = has_res ? l.Bnp : 0;
+    g.W = prep + b.p_rs_f; g.T = (int)T; g.Np = rs0 + l.Scp; g.Kp = l.Hp;
+    g.e.out = has_res ? xbuf(i + 1) : nullptr; g.e.ldo = l.Bnp;
+    g.e.bias = has_res ? params + b.res_b : nullptr; g.e.N = has_res ? l.Bn : 0;
+    g.e.Nsplit = rs0; g.e.bias2 = params + b.skip_b; g.e.N2 = l.Sc;
+    g.e.res_in = xbuf(i); g.e.ld_res = l.Bnp;
+    g.e.skip = skip; g.e.ld_skip = l.Scp; g.e.skip_init = (i == 0);
+    if (int r = launch_gemm_rows<A_BF16, E_RES_SKIP>(g, B, st)) return r;
+  }
+  // prelu -> output 1x1 conv -> sigmoid -> mask * encoder output
+  memset(&g, 0, sizeof(g));
+  g.a = rows_bf16(skip, l.Scp, T);
+  g.a.slope = params + l.tcn_prelu;
+  g.W = prep + l.p_out_f; g.T = (int)T; g.Np = l.S*l.Np; g.Kp = l.Scp;
+  g.e.out = y; g.e.ldo = l.Np; g.e.bias = params + l.out_b; g.e.N = l.N;
+  g.e.w_in = w; g.e.ld_w = l.Np; g.e.m_out = m; g.e.S = l.S; g.e.Np_src = l.Np;
+  if (int r = launch_gemm_rows<A_F32, E_MASK>(g, B, st)) return r;
+  // decoder: synthesis filterbank + overlap-add, cropped to the input length
+  memset(&g, 0, sizeof(g));
+  g.a = rows_bf16(y, l.Np, T);
+  g.W = prep + l.p_dec_f; g.T = (int)T; g.Np = l.Kfp; g.Kp = l.Np;
+  g.e.wave_out = out; g.e.hop = l.hop; g.e.Kf = l.K; g.e.wave_stride = L;
+  g.e.wave_len = (int)L;
+  if (int r = launch_gemm_rows<A_BF16, E_OLA>(g, B*l.S, st)) return r;
+  return 0;
+}
+
+int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void* prepared,
+                     void* workspace, const float* wave, const float* d_out, float* grads,
+                     int64_t batch, int64_t length, brv_stream_t stream) {
+  Layout l; if (int r = l.init(cfg)) return r;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = (int)batch; const long long L = length;
+  const long long T = l.frames(L);
+  if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
+  Workspace ws; ws.init(l, B, T);
+  char* base = (char*)workspace;
+  const bf16_t* prep = (const bf16_t*)prepared;
+  double* stats = (double*)(base + ws.stats);
+  double* sums = (double*)(base + ws.sums);
+  auto stat = [&](int i) { return stats + (long long)i*B*2; };
+  auto sum = [&](int i) { return sums + (long long)i*B*2; };
+  bf16_t* w = (bf16_t*)(base + ws.w);
+  auto xbuf = [&](int i) { return (bf16_t*)(base + ws.x + ws.x_stride*i); };
+  auto z1buf = [&](int i) { return (bf16_t*)(base + ws.z1 + ws.z_stride*i); };
+  auto z2buf = [&](int i) { return (bf16_t*)(base + ws.z2 + ws.z_stride*i); };
+  float* skip = (float*)(base + ws.skip);
+  bf16_t* m = (bf16_t*)(base + ws.m);
+  bf16_t* y = (bf16_t*)(base + ws.y);
+  bf16_t* dpre = (bf16_t*)(base + ws.dpre);
+  bf16_t* dw1 = (bf16_t*)(base + ws.dw1);
+  bf16_t* gskip = (bf16_t*)(base + ws.gskip);
+  bf16_t* gout = (bf16_t*)(base + ws.gout);
+  bf16_t* eA = (bf16_t*)(base + ws.eA);
+  bf16_t* eB = (bf16_t*)(base + ws.eB);
+  bf16_t* e0 = (bf16_t*)(base + ws.e0);
+  bf16_t* dwt = (bf16_t*)(base + ws.dwt);
+  const int BS = B*l.S;
+
+  HIP_OK(hipMemsetAsync(sums, 0, ws.stats_bytes, st));
+
+  GemmRowsParams g; WgradParams wg;
+  // decoder data gradient (framing of d_out) fused with the mask backward
+  memset(&g, 0, sizeof(g));
+  g.a = frames_of(d_out, L, l.hop, l.K);
+  g.W = prep + l.p_dec_b; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
+  g.e.out = dpre; g.e.ldo = l.Np; g.e.out2 = dw1; g.e.w_in = w; g.e.ld_w = l.Np;
+  g.e.m_in = m; g.e.S = l.S;
+  if (int r = launch_gemm_rows<A_FRAMES, E_MASK_BWD>(g, BS, st)) return r;
+  // decoder weight gradient: y^T * frames(d_out)
+  memset(&wg, 0, sizeof(wg));
+  wg.g = rows_bf16(y, l.Np, T); wg.h = frames_of(d_out, L, l.hop, l.K);
+  wg.B = BS; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
+  wg.out0 = grads + l.dec_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
+  if (int r = launch_wgrad<A_FRAMES>(wg, st)) return r;
+  // output conv data gradient, PReLU backward -> gradient wrt skip_sum
+  memset(&g, 0, sizeof(g));
+  g.a = rows_bf16(dpre, l.Np, T); g.a.nsrc = l.S;
+  g.W = prep + l.p_out_b; g.T = (int)T; g.Np = l.Scp; g.Kp = l.S*l.Np;
+  g.e.out = gskip; g.e.ldo = l.Scp; g.e.src_f32 = skip; g.e.ld_srcf = l.Scp;
+  g.e.src_slope = params + l.tcn_prelu; g.e.dslope = grads + l.tcn_prelu;
+  if (int r = launch_gemm_rows<A_BF16, E_PRELU_BWD>(g, B, st)) return r;
+  // output conv weight / bias gradients, one source at a time
+  for (int s = 0; s < l.S; ++s) {
+    memset(&wg, 0, sizeof(wg));
+    wg.g = rows_bf16(dpre + (long long)s*T*l.Np, l.Np, T); wg.g.bs0 = (long long)l.S*T*l.Np;
+    wg.h = rows_bf16(skip, l.Scp, T); wg.h.slope = params + l.tcn_prelu;
+    wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Scp;
+    wg.out0 = grads + l.out_w + (long long)s*l.N*l.Sc; wg.G0p = l.Np; wg.N0 = l.N;
+    wg.Kout = l.Sc; wg.ldo = l.Sc; wg.gbias0 = grads + l.out_b + (long long)s*l.N;
+    if (int r = launch_wgrad<A_F32>(wg, st)) return r;
+  }
+
+  for (int i = l.nb - 1; i >= 0; --i) {
+    const BlockOff& b = l.blk[i];
+    const bool has_res = i < l.nb - 1;
+    const int dil = 1 << (i % cfg->layers);
+    const int rs0 = has_res ? l.Bnp : 0;
+    // [res | skip] data gradient + gLN_2 backward partials
+    memset(&g, 0, sizeof(g));
+    g.a = rows_bf16(gout, l.Bnp, T); g.a.K0 = rs0;
+    g.a.p1 = gskip; g.a.ld1 = l.Scp; g.a.bs1 = T*l.Scp;
+    g.W = prep + b.p_rs_b; g.T = (int)T; g.Np = l.Hp; g.Kp = rs0 + l.Scp;
+    g.e.out = eA; g.e.ldo = l.Hp; g.e.N = l.H;
+    g.e.src = z2buf(i); g.e.ld_src = l.Hp; g.e.src_slope = params + b.prelu2;
+    g.e.src_stats = stat(2 + 2*i); g.e.inv_n = 1.0/((double)T*l.H); g.e.eps = 1e-8f;
+    g.e.gamma = params + b.n2_g; g.e.dgamma = grads + b.n2_g; g.e.dbeta = grads + b.n2_b;
+    g.e.sums_out = sum(2 + 2*i);
+    if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st)) return r;
+    // [res | skip] weight / bias gradients against gLN_2(prelu_2(z2))
+    memset(&wg, 0, sizeof(wg));
+    wg.g = rows_bf16(gout, l.Bnp, T); wg.g.K0 = rs0;
+    wg.g.p1 = gskip; wg.g.ld1 = l.Scp; wg.g.bs1 = T*l.Scp;
+    wg.h = rows_bf16(z2buf(i), l.Hp, T); wg.h.slope = params + b.prelu2;
+    set_affine(wg.h, stat(2 + 2*i), params + b.n2_g, params + b.n2_b, l.H, T);
+    wg.B = B; wg.T = (int)T; wg.Gp = rs0 + l.Scp; wg.Hp = l.Hp;
+    wg.out0 = has_res ? grads + b.res_w : nullptr; wg.out1 = grads + b.skip_w;
+    wg.G0p = rs0; wg.N0 = has_res ? l.Bn : 0; wg.N1 = l.Sc; wg.Kout = l.H; wg.ldo = l.H;
+    wg.gbias0 = has_res ? grads + b.res_b : nullptr; wg.gbias1 = grads + b.skip_b;
+    if (int r = launch_wgrad<A_BF16>(wg, st)) return r;
+    // gLN_2 + prelu_2 backward -> dz2 (in place)
+    DzParams dz; memset(&dz, 0, sizeof(dz));
+    dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
+    dz.slope = params + b.prelu2; dz.stats = stat(2 + 2*i); dz.sums = sum(2 + 2*i);
+    dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = grads + b.prelu2;
+    if (int r = launch_dz(dz, st)) return r;
+    // depthwise conv backward (data, taps, bias) + gLN_1 partials
+    DwParams d; memset(&d, 0, sizeof(d));
+    d.z1 = z1buf(i); d.dz2 = eA; d.e1 = eB; d.B = B; d.T = (int)T; d.Cp = l.Hp; d.C = l.H;
+    d.slope1 = params + b.prelu1; d.stats1 = stat(1 + 2*i);
+    d.gamma1 = params + b.n1_g; d.beta1 = params + b.n1_b;
+    d.inv_n = 1.0/((double)T*l.H); d.eps = 1e-8f;
+    d.taps = params + b.dconv_w; d.dil = dil; d.left = ((l.P - 1)*dil)/2;
+    d.dgamma1 = grads + b.n1_g; d.dbeta1 = grads + b.n1_b;
+    d.dtaps = grads + b.dconv_w; d.dbias = grads + b.dconv_b; d.sums1 = sum(1 + 2*i);
+    if (int r = dispatch_p<DwBwd>(l.P, d, st)) return r;
+    // gLN_1 + prelu_1 backward -> dz1 (in place)
+    memset(&dz, 0, sizeof(dz));
+    dz.e = eB; dz.z = z1buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
+    dz.slope = params + b.prelu1; dz.stats = stat(1 + 2*i); dz.sums = sum(1 + 2*i);
+    dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = grads + b.prelu1;
+    if (int r = launch_dz(dz, st)) return r;
+    // first 1x1 conv: weight / bias gradients
+    memset(&wg, 0, sizeof(wg));
+    wg.g = rows_bf16(eB, l.Hp, T); wg.h = rows_bf16(xbuf(i), l.Bnp, T);
+    wg.B = B; wg.T = (int)T; wg.Gp = l.Hp; wg.Hp = l.Bnp;
+    wg.out0 = grads + b.conv_w; wg.G0p = l.Hp; wg.N0 = l.H; wg.Kout = l.Bn; wg.ldo = l.Bn;
+    wg.gbias0 = grads + b.conv_b;
+    if (int r = launch_wgrad<A_BF16>(wg, st)) return r;
+    // first 1x1 conv: data gradient + residual path -> gradient wrt block input
+    memset(&g, 0, sizeof(g));
+    g.a = rows_bf16(eB, l.Hp, T);
+    g.W = prep + b.p_c1_b; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Hp;
+    g.e.out = gout; g.e.ldo = l.Bnp; g.e.add_in = has_res ? gout : nullptr; g.e.ld_add = l.Bnp;
+    if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st)) return r;
+  }
+  // bottleneck conv: data gradient + first gLN backward partials
+  memset(&g, 0, sizeof(g));
+  g.a = rows_bf16(gout, l.Bnp, T);
+  g.W = prep + l.p_bott_b; g.T = (int)T; g.Np = l.Np; g.Kp = l.Bnp;
+  g.e.out = e0; g.e.ldo = l.Np; g.e.N = l.N;
+  g.e.src = w; g.e.ld_src = l.Np; g.e.src_stats = stat(0);
+  g.e.inv_n = 1.0/((double)T*l.N); g.e.eps = 1e-8f;
+  g.e.gamma = params + l.ln_g; g.e.dgamma = grads + l.ln_g; g.e.dbeta = grads + l.ln_b;
+  g.e.sums_out = sum(0);
+  if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st)) return r;
+  // bottleneck conv: weight / bias gradients against gLN(w)
+  memset(&wg, 0, sizeof(wg));
+  wg.g = rows_bf16(gout, l.Bnp, T); wg.h = rows_bf16(w, l.Np, T);
+  set_affine(wg.h, stat(0), params + l.ln_g, params + l.ln_b, l.N, T);
+  wg.B = B; wg.T = (int)T; wg.Gp = l.Bnp; wg.Hp = l.Np;
+  wg.out0 = grads + l.bott_w; wg.G0p = l.Bnp; wg.N0 = l.Bn; wg.Kout = l.N; wg.ldo = l.N;
+  wg.gbias0 = grads + l.bott_b;
+  if (int r = launch_wgrad<A_BF16>(wg, st)) return r;
+  // total gradient wrt the encoder output
+  CombineParams cb; memset(&cb, 0, sizeof(cb));
+  cb.e0 = e0; cb.w = w; cb.dw1 = dw1; cb.dw = dwt; cb.B = B; cb.T = (int)T;
+  cb.Cp = l.Np; cb.C = l.N; cb.S = l.S; cb.stats = stat(0); cb.sums = sum(0);
+  cb.inv_n = 1.0/((double)T*l.N); cb.eps = 1e-8f;
+  {
+    const long long per_item = T*(l.Np/8);
+    int gx = (int)((per_item + 1023)/1024);
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gln0_bwd_combine_kernel, dim3(gx, B), dim3(256), 0, st, cb);
+    HIP_OK(hipGetLastError());
+  }
+  // encoder weight gradient: dw^T * frames(wave)
+  memset(&wg, 0, sizeof(wg));
+  wg.g = rows_bf16(dwt, l.Np, T); wg.h = frames_of(wave, L, l.hop, l.K);
+  wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
+  wg.out0 = grads + l.enc_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
+  if (int r = launch_wgrad<A_FRAMES>(wg, st)) return r;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,218 @@
+// Losses, optimizer and weight-preparation kernels (all HBM-bound).
+//
+//  masked_moments / snr_* / sisnr_* / mse_* : length-masked criteria of
+//      brever/criterion.py:21-132 (apply_mask :229-234 folded in; the lengths stay
+//      on the device, no host synchronisation)
+//  sumsq / clip_adam : torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step on one
+//      flat fp32 buffer (brever/models/base.py:296-301)
+//  prep_weights : fp32 master weights -> padded bf16 GEMM operands (both layouts)
+#pragma once
+#include "common.cuh"
+
+namespace brv {
+
+// ---------------------------------------------------------------------------
+// Raw masked moments of rows x[r][:len], y[r][:len] for r = item*S + s.
+// mom[r] = {sum x, sum y, sum x^2, sum y^2, sum x*y, sum (x-y)^2}
+struct MomentsParams {
+  const float* x; const float* y; long long stride; int L;
+  const long long* lengths; int S;          // rows per batch item
+  double* mom;                              // [rows][6]
+};
+
+__global__ __launch_bounds__(256) void masked_moments_kernel(const MomentsParams p) {
+  __shared__ double dscr[8];
+  const int r = blockIdx.y;
+  long long len = p.lengths[r / p.S];
+  if (len > p.L) len = p.L;
+  const float* x = p.x + (long long)r*p.stride;
+  const float* y = p.y + (long long)r*p.stride;
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < len;
+       i += (long long)gridDim.x*256) {
+    const double xv = x[i], yv = y[i], d = xv - yv;
+    a[0] += xv; a[1] += yv; a[2] += xv*xv; a[3] += yv*yv; a[4] += xv*yv; a[5] += d*d;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double s = block_sum(a[k], dscr);
+    if (threadIdx.x == 0 && s != 0.0) atomic_add_f64(p.mom + 6*r + k, s);
+  }
+}
+
+// Cross moments for PIT SI-SNR: cross[item][i][j] = sum x_j * y_i (est j, ref i)
+struct CrossParams {
+  const float* x; const float* y; long long stride; int L;
+  const long long* lengths; int S; double* cross;
+};
+__global__ __launch_bounds__(256) void masked_cross_kernel(const CrossParams p) {
+  __shared__ double dscr[8];
+  const int item = blockIdx.y;
+  const int i = blockIdx.z / p.S, j = blockIdx.z % p.S;
+  long long len = p.lengths[item];
+  if (len > p.L) len = p.L;
+  const float* y = p.y + ((long long)item*p.S + i)*p.stride;
+  const float* x = p.x + ((long long)item*p.S + j)*p.stride;
+  double a = 0;
+  for (long long n = (long long)blockIdx.x*256 + threadIdx.x; n < len;
+       n += (long long)gridDim.x*256) a += (double)x[n]*y[n];
+  const double s = block_sum(a, dscr);
+  if (threadIdx.x == 0 && s != 0.0)
+    atomic_add_f64(p.cross + ((long long)item*p.S + i)*p.S + j, s);
+}
+
+constexpr double kEps32 = 1.1920928955078125e-07;   // torch.finfo(float32).eps
+
+// loss[b] = -(1/S) sum_s 10 log10( sum y^2 / (sum (y-x)^2 + eps) + eps )
+// coef[r] = d loss[b] / d D_r * 2   (so that d loss / d x = coef * (x - y))
+__global__ void snr_finalize_kernel(const double* mom, int B, int S, float* loss,
+                                    float* coef) {
+  const int b = blockIdx.x*blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double acc = 0;
+  for (int s = 0; s < S; ++s) {
+    const double* m = mom + 6*((long long)b*S + s);
+    // the reference evaluates this in fp32: keep the same rounding of the ratio
+    const float num = (float)m[3];
+    const float den = (float)m[5] + (float)kEps32;
+    const float ratio = num/den;
+    const float val = 10.f*log10f(ratio + (float)kEps32);
+    acc += val;
+    if (coef) {
+      const double R = (double)ratio;
+      coef[(long long)b*S + s] =
+          (float)((10.0/log(10.0))/S*R/((R + kEps32)*((double)den))*2.0);
+    }
+  }
+  loss[b] = (float)(-acc/S);
+}
+
+struct SnrBwdParams {
+  const float* x; const float* y; float* dx; long long stride; int L;
+  const long long* lengths; int S; const float* coef; const float* gscale;  // [B]
+};
+__global__ __launch_bounds__(256) void snr_bwd_kernel(const SnrBwdParams p) {
+  const int r = blockIdx.y;
+  const int b = r / p.S;
+  long long len = p.lengths[b];
+  if (len > p.L) len = p.L;
+  const float c = p.coef[r]*p.gscale[b];
+  const float* x = p.x + (long long)r*p.stride;
+  const float* y = p.y + (long long)r*p.stride;
+  float* dx = p.dx + (long long)r*p.stride;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < p.L;
+       i += (long long)gridDim.x*256)
+    dx[i] = i < len ? c*(x[i] - y[i]) : 0.f;
+}
+
+// mse: loss[b] = mean_s ( sum (x-y)^2 / len ) * weight[b]
+__global__ void mse_finalize_kernel(const double* mom, int B, int S,
+                                    const long long* lengths, const float* weight,
+                                    float* loss) {
+  const int b = blockIdx.x*blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double acc = 0;
+  for (int s = 0; s < S; ++s) {
+    float v = (float)mom[6*((long long)b*S + s) + 5];
+    v = v/(float)lengths[b];
+    if (weight) v *= weight[b];
+    acc += v;
+  }
+  loss[b] = (float)(acc/S);
+}
+
+// PIT SI-SNR from raw moments (closed form in fp64), S <= 4.
+__global__ void sisnr_finalize_kernel(const double* mom, const double* cross, int B,
+                                      int S, const long long* lengths, float* loss) {
+  const int b = blockIdx.x*blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double n = (double)lengths[b];
+  double val[4][4];
+  for (int i = 0; i < S; ++i) {            // reference source i
+    const double* mi = mom + 6*((long long)b*S + i);
+    const double my = mi[1]/n;
+    const double syy = mi[3] - n*my*my;
+    for (int j = 0; j < S; ++j) {          // estimate j
+      const double* mj = mom + 6*((long long)b*S + j);
+      const double mx = mj[0]/n;
+      const double sxx = mj[2] - n*mx*mx;
+      const double sxy = cross[((long long)b*S + i)*S + j] - n*mx*my;
+      const double tgt = sxy*sxy/syy;                 // ||s_target||^2
+      double noise = sxx - tgt;                       // ||e_noise||^2
+      if (noise < 0) noise = 0;
+      const float ratio = (float)tgt/((float)noise + (float)kEps32);
+      val[i][j] = 10.f*log10f(ratio + (float)kEps32);
+    }
+  }
+  // enumerate permutations (est perm[i] assigned to ref i)
+  int perm[4] = {0, 1, 2, 3};
+  double best = -1e300;
+  // Heap-free enumeration of up to 4! permutations
+  int c[4] = {0, 0, 0, 0};
+  auto score = [&]() { double s = 0; for (int i = 0; i < S; ++i) s += val[i][perm[i]]; return s; };
+  best = score();
+  int i = 0;
+  while (i < S) {
+    if (c[i] < i) {
+      const int k = (i & 1) ? c[i] : 0;
+      const int tmp = perm[k]; perm[k] = perm[i]; perm[i] = tmp;
+      const double s = score();
+      if (s > best) best = s;
+      ++c[i]; i = 0;
+    } else { c[i] = 0; ++i; }
+  }
+  loss[b] = (float)(-best/S);
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long long n,
+                                                    double* acc) {
+  __shared__ double dscr[8];
+  double a = 0;
+  const long long n4 = n/4;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n4;
+       i += (long long)gridDim.x*256) {
+    const float4 v = g4[i];
+    a += (double)v.x*v.x + (double)v.y*v.y + (double)v.z*v.z + (double)v.w*v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - n4*4) {
+    const float v = g[n4*4 + threadIdx.x];
+    a += (double)v*v;
+  }
+  const double s = block_sum(a, dscr);
+  if (threadIdx.x == 0) atomic_add_f64(acc, s);
+}
+
+struct AdamParams {
+  float* p; float* g; float* m; float* v; long long n;
+  const double* sumsq;     // squared global gradient norm (after grad_scale)
+  float grad_scale;        // multiplies g before everything (1/world for DDP mean)
+  float max_norm;          // <= 0: no clipping
+  float lr, beta1, beta2, eps;
+  float bc1, bc2;          // 1 - beta^step
+  float* norm_out;         // nullable: total norm
+};
+__global__ __launch_bounds__(256) void clip_adam_kernel(const AdamParams a) {
+  const double total = sqrt(*a.sumsq)*(double)a.grad_scale;
+  float clip = 1.f;
+  if (a.max_norm > 0.f) {
+    const float c = a.max_norm/((float)total + 1e-6f);   // clip_grad_norm_
+    clip = c < 1.f ? c : 1.f;
+  }
+  if (a.norm_out && blockIdx.x == 0 && threadIdx.x == 0) *a.norm_out = (float)total;
+  const float gs = a.grad_scale*clip;
+  const float step_size = a.lr/a.bc1;
+  const float rbc2 = 1.f/sqrtf(a.bc2);
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < a.n;
+       i += (long long)gridDim.x*256) {
+    const float g = a.g[i]*gs;
+    const float m = a.beta1*a.m[i] + (1.f - a.beta1)*g;
+    const float v = a.beta2*a.v[i] + (1.f - a.beta2)*g*g;
+    const float denom = sqrtf(v)*rbc2 + a.eps;
+    a.p[i] -= step_size*(m/denom);
+    a.m[i] = m; a.v[i] = v; a.g[i] = g;
+  }
+}
+
+}  // namespace brv

@@ -1,0 +1,147 @@
+// C ABI of the standalone criteria and optimizer kernels (include/brever_hip.h).
+// Reference: brever/criterion.py:21-132,229-234; brever/models/base.py:296-301.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string>
+
+#include "../../include/brever_hip.h"
+#include "misc_kernels.cuh"
+
+using namespace brv;
+
+namespace {
+int ops_fail(int code, const char* what, hipError_t e) {
+  (void)what; (void)e;
+  return code;
+}
+#define OPS_OK(expr)                                                   \
+  do {                                                                 \
+    hipError_t e_ = (expr);                                            \
+    if (e_ != hipSuccess) return ops_fail((int)e_, #expr, e_);         \
+  } while (0)
+
+// scratch layout: mom [rows][6] f64 | cross [B][S][S] f64 | coef [rows] f32
+struct LossScratch {
+  double* mom; double* cross; float* coef; size_t zero_bytes;
+  LossScratch(void* p, int64_t B, int64_t S) {
+    mom = (double*)p;
+    cross = mom + B*S*6;
+    coef = (float*)(cross + B*S*S);
+    zero_bytes = (size_t)(B*S*6 + B*S*S)*sizeof(double);
+  }
+};
+
+int moments(const float* x, const float* y, const int64_t* lengths, int64_t B, int64_t S,
+            int64_t L, int64_t stride, const LossScratch& sc, hipStream_t st) {
+  OPS_OK(hipMemsetAsync(sc.mom, 0, sc.zero_bytes, st));
+  MomentsParams p;
+  p.x = x; p.y = y; p.stride = stride; p.L = (int)L;
+  p.lengths = (const long long*)lengths; p.S = (int)S; p.mom = sc.mom;
+  int gx = (int)((L + 256*16 - 1)/(256*16));
+  if (gx < 1) gx = 1;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(masked_moments_kernel, dim3(gx, (unsigned)(B*S)), dim3(256), 0, st, p);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t brv_loss_scratch_bytes(int64_t B, int64_t S) {
+  return (B*S*6 + B*S*S)*8 + B*S*4 + 64;
+}
+
+int brv_snr_forward(const float* x, const float* y, const int64_t* lengths, int64_t B,
+                    int64_t S, int64_t L, int64_t stride, void* scratch, float* loss,
+                    brv_stream_t stream) {
+  if (B < 1 || S < 1 || L < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  LossScratch sc(scratch, B, S);
+  if (int r = moments(x, y, lengths, B, S, L, stride, sc, st)) return r;
+  hipLaunchKernelGGL(snr_finalize_kernel, dim3((unsigned)((B + 63)/64)), dim3(64), 0, st,
+                     sc.mom, (int)B, (int)S, loss, sc.coef);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_snr_backward(const float* x, const float* y, const int64_t* lengths, int64_t B,
+                     int64_t S, int64_t L, int64_t stride, const void* scratch,
+                     const float* gscale, float* dx, brv_stream_t stream) {
+  if (B < 1 || S < 1 || L < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  LossScratch sc(const_cast<void*>(scratch), B, S);
+  SnrBwdParams p;
+  p.x = x; p.y = y; p.dx = dx; p.stride = stride; p.L = (int)L;
+  p.lengths = (const long long*)lengths; p.S = (int)S; p.coef = sc.coef; p.gscale = gscale;
+  int gx = (int)((L + 256*8 - 1)/(256*8));
+  if (gx < 1) gx = 1;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(snr_bwd_kernel, dim3(gx, (unsigned)(B*S)), dim3(256), 0, st, p);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_sisnr_forward(const float* x, const float* y, const int64_t* lengths, int64_t B,
+                      int64_t S, int64_t L, int64_t stride, void* scratch, float* loss,
+                      brv_stream_t stream) {
+  if (B < 1 || S < 1 || S > 4 || L < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  LossScratch sc(scratch, B, S);
+  if (int r = moments(x, y, lengths, B, S, L, stride, sc, st)) return r;
+  CrossParams c;
+  c.x = x; c.y = y; c.stride = stride; c.L = (int)L;
+  c.lengths = (const long long*)lengths; c.S = (int)S; c.cross = sc.cross;
+  int gx = (int)((L + 256*16 - 1)/(256*16));
+  if (gx < 1) gx = 1;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(masked_cross_kernel, dim3(gx, (unsigned)B, (unsigned)(S*S)), dim3(256),
+                     0, st, c);
+  OPS_OK(hipGetLastError());
+  hipLaunchKernelGGL(sisnr_finalize_kernel, dim3((unsigned)((B + 63)/64)), dim3(64), 0, st,
+                     sc.mom, sc.cross, (int)B, (int)S, (const long long*)lengths, loss);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_mse_forward(const float* x, const float* y, const int64_t* lengths,
+                    const float* weight, int64_t B, int64_t S, int64_t L, int64_t stride,
+                    void* scratch, float* loss, brv_stream_t stream) {
+  if (B < 1 || S < 1 || L < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  LossScratch sc(scratch, B, S);
+  if (int r = moments(x, y, lengths, B, S, L, stride, sc, st)) return r;
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3((unsigned)((B + 63)/64)), dim3(64), 0, st,
+                     sc.mom, (int)B, (int)S, (const long long*)lengths, weight, loss);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                       int64_t n, float grad_scale, float max_norm, float lr, float beta1,
+                       float beta2, float eps, int64_t step, void* scratch,
+                       float* norm_out, brv_stream_t stream) {
+  if (n < 1 || step < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  double* acc = (double*)scratch;
+  OPS_OK(hipMemsetAsync(acc, 0, sizeof(double), st));
+  int gx = (int)((n/4 + 255)/256);
+  if (gx < 1) gx = 1;
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(gx), dim3(256), 0, st, grads, (long long)n, acc);
+  OPS_OK(hipGetLastError());
+  AdamParams a;
+  a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+  a.sumsq = acc; a.grad_scale = grad_scale; a.max_norm = max_norm;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  a.norm_out = norm_out;
+  int ga = (int)((n + 255)/256);
+  if (ga > 2048) ga = 2048;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(ga), dim3(256), 0, st, a);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+"""ctypes binding of ``libbrever_hip.so`` (C ABI: ``include/brever_hip.h``).
+
+The HIP library is the product; there is no CPU or PyTorch fallback. Every
+helper here raises ``RuntimeError`` when the shared library is missing or when
+it is handed a tensor that is not on a ROCm device.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libbrever_hip.so')
+
+_c_i64 = ctypes.c_int64
+_c_f32 = ctypes.c_float
+_c_ptr = ctypes.c_void_p
+
+
+class CtnConfig(ctypes.Structure):
+    """``brv_ctn_config`` -- ConvTasNet.__init__ hyper-parameters."""
+    _fields_ = [(name, ctypes.c_int32) for name in (
+        'filters', 'filter_length', 'bottleneck_channels', 'hidden_channels',
+        'skip_channels', 'kernel_size', 'layers', 'repeats', 'output_sources',
+        'causal')]
+
+
+# name -> (restype, argtypes); the export test checks every name resolves.
+SIGNATURES = {
+    'brv_version': (ctypes.c_int, []),
+    'brv_last_error': (ctypes.c_char_p, []),
+    'brv_ctn_param_count': (_c_i64, [_c_ptr]),
+    'brv_ctn_param_tensors': (_c_i64, [_c_ptr]),
+    'brv_ctn_param_offset': (_c_i64, [_c_ptr, _c_i64]),
+    'brv_ctn_frames': (_c_i64, [_c_ptr, _c_i64]),
+    'brv_ctn_prepared_bytes': (_c_i64, [_c_ptr]),
+    'brv_ctn_workspace_bytes': (_c_i64, [_c_ptr, _c_i64, _c_i64]),
+    'brv_ctn_workspace_offset': (_c_i64, [_c_ptr, _c_i64, _c_i64,
+                                          ctypes.c_char_p, _c_i64]),
+    'brv_ctn_prepare': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    'brv_ctn_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                       _c_ptr, _c_i64, _c_i64, _c_ptr]),
+    'brv_ctn_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                        _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                        _c_ptr]),
+    'brv_loss_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
+    'brv_snr_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                       _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),
+    'brv_snr_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                        _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr,
+                                        _c_ptr]),
+    'brv_sisnr_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                         _c_i64, _c_i64, _c_i64, _c_ptr,
+                                         _c_ptr, _c_ptr]),
+    'brv_mse_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                       _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr,
+                                       _c_ptr]),
+    'brv_clip_adam_step': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                          _c_i64, _c_f32, _c_f32, _c_f32,
+                                          _c_f32, _c_f32, _c_f32, _c_i64,
+                                          _c_ptr, _c_ptr, _c_ptr]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; fail loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"` or '
+                '`make -C brever_amd/csrc` (needs hipcc, targets gfx950). '
+                'brever_amd has no CPU/PyTorch fallback for its kernels.'
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().brv_last_error()
+        raise RuntimeError(f'{what} failed with status {status}: '
+                           f'{msg.decode() if msg else ""}')
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                'brever_amd kernels run on a ROCm device only; got a '
+                f'{t.device} tensor (there is no CPU fallback)'
+            )
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,405 @@
+"""Conv-TasNet on the MI355X HIP path.
+
+Plugin-compatible with the reference model (registry key ``convtasnet``, same
+constructor signature and defaults, same ``state_dict`` keys and shapes, same
+seeded initialisation order -- brever/models/convtasnet/convtasnet.py:19-97 and
+SURVEY.md App. A.3) but *none* of its layers is ever executed by PyTorch: the
+``nn.Conv1d`` / ``nn.GroupNorm`` / ``nn.PReLU`` objects below are parameter
+containers only. All parameters are views of one flat fp32 buffer that the C
+ABI (``brv_ctn_forward`` / ``brv_ctn_backward``, ``include/brever_hip.h``)
+consumes; activations live in a caller-allocated workspace in HBM.
+
+Two ways in:
+
+* ``forward(x)`` is differentiable (``torch.autograd.Function``), so the
+  reference's generic ``loss`` -> ``update`` sequence works unchanged;
+* ``train_step`` short-circuits autograd: forward -> SNR loss -> backward ->
+  [gradient all-reduce hook] -> fused clip + Adam, all on flat buffers.
+
+Compute dtype: bf16 storage / MFMA operands with fp32 accumulation, statistics
+and master weights, whatever ``use_amp`` says (the reference's GPU branch would
+use fp16 + GradScaler, convtasnet.py:81; the scaler is not needed for bf16).
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip
+from ..optim import FlatAdam
+from .base import BreverBaseModel, ModelRegistry
+
+
+class _ParamOnly(nn.Module):
+    """Container whose children hold parameters but are never called."""
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError('this module only stores parameters; the compute '
+                           'runs in libbrever_hip.so')
+
+
+def _norm(causal, channels):
+    if causal:
+        raise NotImplementedError(
+            'causal=True (cumulative layer norm) is not built yet on the HIP '
+            'path'
+        )
+    return nn.GroupNorm(1, channels, eps=1e-8)
+
+
+class _Encoder(_ParamOnly):
+    def __init__(self, filters, filter_length):
+        super().__init__()
+        self.filter_length = filter_length
+        self.stride = filter_length//2
+        self.conv = nn.Conv1d(1, filters, filter_length, stride=self.stride,
+                              bias=False)
+
+
+class _Decoder(_ParamOnly):
+    def __init__(self, filters, filter_length):
+        super().__init__()
+        self.filter_length = filter_length
+        self.stride = filter_length//2
+        self.trans_conv = nn.ConvTranspose1d(filters, 1, filter_length,
+                                             stride=self.stride, bias=False)
+
+
+class _Block(_ParamOnly):
+    def __init__(self, bn, hidden, skip, kernel_size, dilation, causal, last):
+        super().__init__()
+        self.conv = nn.Conv1d(bn, hidden, 1)
+        self.d_conv = nn.Conv1d(hidden, hidden, kernel_size, dilation=dilation,
+                                groups=hidden)
+        self.res_conv = None if last else nn.Conv1d(hidden, bn, 1)
+        self.skip_conv = nn.Conv1d(hidden, skip, 1)
+        self.norm_1 = _norm(causal, hidden)
+        self.norm_2 = _norm(causal, hidden)
+        self.prelu_1 = nn.PReLU()
+        self.prelu_2 = nn.PReLU()
+
+
+class _TCN(_ParamOnly):
+    def __init__(self, filters, bn, hidden, skip, kernel_size, layers, repeats,
+                 sources, causal):
+        super().__init__()
+        self.sources = sources
+        self.layer_norm = _norm(causal, filters)
+        self.bottleneck_conv = nn.Conv1d(filters, bn, 1)
+        self.conv_blocks = nn.ModuleList()
+        for r in range(repeats):
+            for i in range(layers):
+                last = r == repeats - 1 and i == layers - 1
+                self.conv_blocks.append(
+                    _Block(bn, hidden, skip, kernel_size, 2**i, causal, last))
+        self.prelu = nn.PReLU()
+        self.output_conv = nn.Conv1d(skip, filters*sources, 1)
+
+
+class _ConvTasNetFunction(torch.autograd.Function):
+    """wave (B, L) -> (B, S, L) with gradients for every parameter."""
+
+    @staticmethod
+    def forward(ctx, model, wave, *params):
+        out = model._hip_forward(wave)
+        ctx.model = model
+        ctx.wave = wave
+        ctx.version = model._ws_version
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        model = ctx.model
+        if ctx.version != model._ws_version:
+            raise RuntimeError(
+                'the activation workspace was overwritten by a later forward; '
+                'call backward before running the model again'
+            )
+        flat_grad = torch.zeros_like(model._flat)
+        model._hip_backward(ctx.wave, d_out, flat_grad)
+        grads = tuple(flat_grad[off:off + p.numel()].view(p.shape)
+                      for p, off in model._offsets)
+        return (None, None) + grads
+
+
+@ModelRegistry.register('convtasnet')
+class ConvTasNet(BreverBaseModel):
+    def __init__(
+        self,
+        filters: int = 512,
+        filter_length: int = 32,
+        bottleneck_channels: int = 128,
+        hidden_channels: int = 512,
+        skip_channels: int = 128,
+        kernel_size: int = 3,
+        layers: int = 8,
+        repeats: int = 3,
+        output_sources: int = 1,
+        causal: bool = False,
+        criterion: str = 'snr',
+        optimizer: str = 'Adam',
+        learning_rate: float = 0.001,
+        grad_clip: float = 5.0,
+    ):
+        super().__init__(criterion=criterion)
+        self._criterion_name = criterion if isinstance(criterion, str) else None
+        self.cfg = hip.CtnConfig(
+            filters, filter_length, bottleneck_channels, hidden_channels,
+            skip_channels, kernel_size, layers, repeats, output_sources,
+            int(bool(causal)))
+        self.output_sources = output_sources
+        # parameter containers, constructed in the reference's RNG order
+        self.encoder = _Encoder(filters, filter_length)
+        self.decoder = _Decoder(filters, filter_length)
+        self.tcn = _TCN(filters, bottleneck_channels, hidden_channels,
+                        skip_channels, kernel_size, layers, repeats,
+                        output_sources, causal)
+
+        self._flat = None
+        self._flat_grad = None
+        self._offsets = []
+        self._prepared = None
+        self._prepared_dirty = True
+        self._workspace = None
+        self._ws_key = None
+        self._ws_version = 0
+        self._grad_sync = None
+        self._flatten()
+
+        self.optimizer = self.init_optimizer(optimizer, lr=learning_rate)
+        self.grad_clip = grad_clip
+
+    # ---- flat parameter storage -------------------------------------------------
+    def _flatten(self):
+        """(Re)pack all parameters, in ``parameters()`` order, into one buffer and
+        turn every ``nn.Parameter`` into a view of it."""
+        params = list(self.parameters())
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
+        offsets, off = [], 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = None
+            offsets.append((p, off))
+            off += n
+        self._flat = flat
+        self._flat_grad = None
+        self._offsets = offsets
+        self._prepared = None
+        self._prepared_dirty = True
+        self._workspace = None
+        self._ws_key = None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)   # copies in place
+        self._prepared_dirty = True
+        return out
+
+    def flat_params(self):
+        return self._flat
+
+    def param_offsets(self):
+        return self._offsets
+
+    def flat_grads(self):
+        """Flat gradient buffer with every ``p.grad`` bound to a view of it."""
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            self._flat_grad = torch.zeros_like(self._flat)
+        g = self._flat_grad
+        for p, off in self._offsets:
+            view = g[off:off + p.numel()].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                p.grad = view
+        return g
+
+    def gather_grads(self):
+        """Flat gradient for the optimizer: zero-copy when the ``.grad`` tensors
+        already are views of one buffer (both entry paths of this model),
+        otherwise gathered."""
+        first = self._offsets[0][0].grad
+        if first is not None:
+            base = first.data_ptr()
+            contiguous = all(
+                p.grad is not None and p.grad.is_contiguous()
+                and p.grad.data_ptr() == base + 4*off
+                for p, off in self._offsets)
+            if contiguous:
+                storage = first.untyped_storage()
+                start = (base - storage.data_ptr())//4
+                flat = torch.empty(0, dtype=torch.float32, device=first.device)
+                flat.set_(storage, start, (self._flat.numel(),))
+                return flat
+        g = torch.zeros_like(self._flat)
+        for p, off in self._offsets:
+            if p.grad is not None:
+                g[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        return g
+
+    def mark_params_changed(self):
+        self._prepared_dirty = True
+
+    def set_grad_sync(self, fn):
+        """``fn(flat_grad) -> grad_scale`` is called between backward and the
+        optimizer step of ``train_step`` (data-parallel all-reduce)."""
+        self._grad_sync = fn
+
+    def init_optimizer(self, optimizer, net=None, **kwargs):
+        if optimizer == 'Adam' and net is None:
+            return FlatAdam(self.parameters(), owner=self, **kwargs)
+        return super().init_optimizer(optimizer, net=net, **kwargs)
+
+    # ---- HIP calls ------------------------------------------------------------------
+    def _cfg_ptr(self):
+        import ctypes
+        return ctypes.byref(self.cfg)
+
+    def frames(self, length):
+        return hip.lib().brv_ctn_frames(self._cfg_ptr(), int(length))
+
+    def activation_bytes_per_second(self, fs=16000):
+        """HBM kept resident per second of input audio (for the dynamic batcher)."""
+        return hip.lib().brv_ctn_workspace_bytes(self._cfg_ptr(), 1, fs)
+
+    def _check_layout(self):
+        lib = hip.lib()
+        n = lib.brv_ctn_param_count(self._cfg_ptr())
+        if n < 0:
+            hip.check(int(n), 'brv_ctn_param_count')
+        if n != self._flat.numel():
+            raise RuntimeError(f'parameter layout mismatch: library expects {n} '
+                               f'floats, module holds {self._flat.numel()}')
+
+    def _prepare(self):
+        lib = hip.lib()
+        hip.require_device(self._flat)
+        if self._prepared is None:
+            self._check_layout()
+            nbytes = lib.brv_ctn_prepared_bytes(self._cfg_ptr())
+            self._prepared = torch.empty(nbytes, dtype=torch.uint8,
+                                         device=self._flat.device)
+            self._prepared_dirty = True
+        if self._prepared_dirty:
+            hip.check(lib.brv_ctn_prepare(
+                self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
+                hip.stream()), 'brv_ctn_prepare')
+            self._prepared_dirty = False
+
+    def _get_workspace(self, B, L):
+        key = (B, L, self._flat.device)
+        if self._ws_key != key:
+            nbytes = hip.lib().brv_ctn_workspace_bytes(self._cfg_ptr(), B, L)
+            if nbytes < 0:
+                hip.check(int(nbytes), 'brv_ctn_workspace_bytes')
+            if self._workspace is None or self._workspace.numel() < nbytes \
+                    or self._workspace.device != self._flat.device:
+                self._workspace = torch.empty(nbytes, dtype=torch.uint8,
+                                              device=self._flat.device)
+            self._ws_key = key
+        return self._workspace
+
+    def _hip_forward(self, wave):
+        hip.require_device(wave, self._flat)
+        if wave.ndim != 2:
+            raise ValueError(f'input must be (batch, length), got {wave.shape}')
+        wave = wave.float().contiguous()
+        B, L = wave.shape
+        self._prepare()
+        ws = self._get_workspace(B, L)
+        out = torch.empty(B, self.output_sources, L, dtype=torch.float32,
+                          device=wave.device)
+        hip.check(hip.lib().brv_ctn_forward(
+            self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
+            hip.ptr(ws), hip.ptr(wave), hip.ptr(out), B, L, hip.stream()),
+            'brv_ctn_forward')
+        self._ws_version += 1
+        return out
+
+    def _hip_backward(self, wave, d_out, flat_grad):
+        wave = wave.float().contiguous()
+        d_out = d_out.float().contiguous()
+        B, L = wave.shape
+        ws = self._get_workspace(B, L)
+        hip.check(hip.lib().brv_ctn_backward(
+            self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
+            hip.ptr(ws), hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad),
+            B, L, hip.stream()), 'brv_ctn_backward')
+
+    def workspace_tensor(self, name, index, B, L, shape, dtype):
+        """View of a saved activation (tests / profiling)."""
+        off = hip.lib().brv_ctn_workspace_offset(
+            self._cfg_ptr(), B, L, name.encode(), index)
+        if off < 0:
+            hip.check(int(off), 'brv_ctn_workspace_offset')
+        n = 1
+        for s in shape:
+            n *= s
+        itemsize = torch.empty(0, dtype=dtype).element_size()
+        raw = self._workspace[off:off + n*itemsize]
+        return raw.view(dtype).view(*shape)
+
+    # ---- plugin surface ---------------------------------------------------------------
+    def forward(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p, _ in self._offsets):
+            return _ConvTasNetFunction.apply(self, x, *[p for p, _ in self._offsets])
+        return self._hip_forward(x)
+
+    def transform(self, sources):
+        return sources.mean(axis=-2)      # mono; runs wherever `sources` lives
+
+    def loss(self, batch, lengths, use_amp):
+        inputs, labels = batch[:, 0], batch[:, 1:]
+        outputs = self(inputs)
+        loss = self.criterion(outputs, labels, lengths)
+        return loss.mean()
+
+    def update(self, loss, scaler):
+        super().update(loss, scaler, grad_clip=self.grad_clip)
+
+    def _enhance(self, x, use_amp):
+        return self._hip_forward(x.mean(axis=-2))
+
+    def train_step(self, batch, lengths, use_amp, scaler):
+        """Fused step when the criterion is the HIP ``snr`` and the optimizer the
+        flat Adam; otherwise the reference's generic sequence
+        (brever/models/base.py:178-210)."""
+        fused = (self._criterion_name == 'snr'
+                 and isinstance(self.optimizer, FlatAdam))
+        if not fused:
+            return super().train_step(batch, lengths, use_amp, scaler)
+        # bf16 needs no loss scaling: the GradScaler is left untouched
+        lib = hip.lib()
+        inputs, labels = batch[:, 0], batch[:, 1:]
+        hip.require_device(inputs, lengths)
+        B, L = inputs.shape
+        S = self.output_sources
+        with torch.no_grad():
+            out = self._hip_forward(inputs)
+            labels = labels.float().contiguous()
+            lengths = lengths.to(torch.int64).contiguous()
+            n = lib.brv_loss_scratch_bytes(B, S)
+            scratch = torch.empty(n, dtype=torch.uint8, device=out.device)
+            loss_b = torch.empty(B, dtype=torch.float32, device=out.device)
+            hip.check(lib.brv_snr_forward(
+                hip.ptr(out), hip.ptr(labels), hip.ptr(lengths), B, S, L, L,
+                hip.ptr(scratch), hip.ptr(loss_b), hip.stream()),
+                'brv_snr_forward')
+            gscale = torch.full((B,), 1.0/B, dtype=torch.float32,
+                                device=out.device)
+            d_out = torch.empty_like(out)
+            hip.check(lib.brv_snr_backward(
+                hip.ptr(out), hip.ptr(labels), hip.ptr(lengths), B, S, L, L,
+                hip.ptr(scratch), hip.ptr(gscale), hip.ptr(d_out), hip.stream()),
+                'brv_snr_backward')
+            grads = self.flat_grads()
+            grads.zero_()
+            self._hip_backward(inputs, d_out, grads)
+            grad_scale = 1.0
+            if self._grad_sync is not None:
+                grad_scale = self._grad_sync(grads)
+            self.optimizer.step(max_norm=self.grad_clip, grad_scale=grad_scale)
+            return loss_b.mean()

@@ -1,0 +1,125 @@
+/* brever_hip.h -- C ABI of the MI355X (gfx950) hot path of brever_amd.
+ *
+ * The reference (philgzl/brever) is pure Python/PyTorch and has no FFI; its
+ * boundary for this path is the Python plugin API (brever/models/base.py:12-358,
+ * brever/criterion.py, brever/models/convtasnet/convtasnet.py). This header is
+ * the C boundary the MI355X build puts *underneath* that API: each entry point
+ * names the reference code it replaces. Conventions:
+ *
+ *   - every pointer is a device pointer borrowed from the caller (PyTorch's
+ *     allocator); the library allocates nothing and keeps no global state;
+ *   - every call takes the HIP stream to launch on and never synchronises;
+ *   - return value: 0 ok, < 0 invalid argument / unsupported configuration,
+ *     > 0 a hipError_t; brv_last_error() gives a thread-local message.
+ *
+ * Activations inside the library are channels-last bf16 ([item][frame][channel],
+ * channels padded to a multiple of 64); this never leaks through the ABI: inputs
+ * and outputs are the reference's fp32 (batch, [sources,] samples) tensors and
+ * the parameters are one flat fp32 buffer in the reference's parameter order.
+ */
+#ifndef BREVER_HIP_H
+#define BREVER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* brv_stream_t;          /* hipStream_t */
+
+int brv_version(void);
+const char* brv_last_error(void);
+
+/* ---- Conv-TasNet ---------------------------------------------------------
+ * Hyper-parameters of brever.models.convtasnet.ConvTasNet.__init__
+ * (convtasnet.py:30-46). causal != 0 is not supported yet (returns -2). */
+typedef struct brv_ctn_config {
+  int32_t filters, filter_length, bottleneck_channels, hidden_channels,
+          skip_channels, kernel_size, layers, repeats, output_sources, causal;
+} brv_ctn_config;
+
+/* Number of fp32 parameters, in the order of ConvTasNet.parameters()
+ * (SURVEY.md App. A.3 "init-order contract"); 4 935 217 at the defaults. */
+int64_t brv_ctn_param_count(const brv_ctn_config* cfg);
+/* Offset (in floats) of the i-th parameter tensor and their number (343). */
+int64_t brv_ctn_param_tensors(const brv_ctn_config* cfg);
+int64_t brv_ctn_param_offset(const brv_ctn_config* cfg, int64_t index);
+
+/* Frames produced by Encoder.pad + Conv1d (convtasnet.py:115-126). */
+int64_t brv_ctn_frames(const brv_ctn_config* cfg, int64_t length);
+
+/* Bytes of the prepared-weight buffer (bf16 GEMM operands, both layouts). */
+int64_t brv_ctn_prepared_bytes(const brv_ctn_config* cfg);
+/* Bytes of the activation workspace for a (batch, length) input. The saved
+ * activations live here between forward and backward. */
+int64_t brv_ctn_workspace_bytes(const brv_ctn_config* cfg, int64_t batch,
+                                int64_t length);
+/* Byte offset of a named workspace tensor ("w", "x", "z1", "z2", "skip", "m",
+ * "y", "stats"; index selects the block) -- for tests and profiling only. */
+int64_t brv_ctn_workspace_offset(const brv_ctn_config* cfg, int64_t batch,
+                                 int64_t length, const char* name, int64_t index);
+
+/* fp32 parameters -> prepared bf16 operands. Call after every parameter update. */
+int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params,
+                    void* prepared, brv_stream_t stream);
+
+/* ConvTasNet.forward (convtasnet.py:66-72): wave (batch, length) fp32 ->
+ * out (batch, sources, length) fp32. Leaves the activations needed by
+ * brv_ctn_backward in `workspace`. */
+int brv_ctn_forward(const brv_ctn_config* cfg, const float* params,
+                    const void* prepared, void* workspace, const float* wave,
+                    float* out, int64_t batch, int64_t length,
+                    brv_stream_t stream);
+
+/* Autograd of ConvTasNet.forward: d_out (batch, sources, length) fp32 ->
+ * gradients ACCUMULATED into `grads` (flat fp32, same layout as params;
+ * the caller zeroes it, as optimizer.zero_grad() does). */
+int brv_ctn_backward(const brv_ctn_config* cfg, const float* params,
+                     const void* prepared, void* workspace, const float* wave,
+                     const float* d_out, float* grads, int64_t batch,
+                     int64_t length, brv_stream_t stream);
+
+/* ---- criteria (brever/criterion.py) ---------------------------------------
+ * x, y: (batch, sources, length) fp32 contiguous rows with `stride` floats
+ * between rows; lengths: (batch,) int64 on the device; scratch: at least
+ * brv_loss_scratch_bytes(batch, sources) bytes; loss: (batch,) fp32. */
+int64_t brv_loss_scratch_bytes(int64_t batch, int64_t sources);
+
+/* snr (criterion.py:75-101). coef (batch*sources) is kept in scratch for bwd. */
+int brv_snr_forward(const float* x, const float* y, const int64_t* lengths,
+                    int64_t batch, int64_t sources, int64_t length,
+                    int64_t stride, void* scratch, float* loss,
+                    brv_stream_t stream);
+/* d loss[b] * gscale[b] / d x -> dx (same layout as x). */
+int brv_snr_backward(const float* x, const float* y, const int64_t* lengths,
+                     int64_t batch, int64_t sources, int64_t length,
+                     int64_t stride, const void* scratch, const float* gscale,
+                     float* dx, brv_stream_t stream);
+/* sisnr with PIT (criterion.py:21-72), sources <= 4; forward only (metric). */
+int brv_sisnr_forward(const float* x, const float* y, const int64_t* lengths,
+                      int64_t batch, int64_t sources, int64_t length,
+                      int64_t stride, void* scratch, float* loss,
+                      brv_stream_t stream);
+/* mse (criterion.py:104-132) on real tensors; weight may be NULL. */
+int brv_mse_forward(const float* x, const float* y, const int64_t* lengths,
+                    const float* weight, int64_t batch, int64_t sources,
+                    int64_t length, int64_t stride, void* scratch, float* loss,
+                    brv_stream_t stream);
+
+/* ---- optimizer --------------------------------------------------------------
+ * clip_grad_norm_(max_norm) + Adam.step (base.py:296-301, torch.optim.Adam with
+ * amsgrad=False, weight_decay=0) on flat buffers of n floats. grads are first
+ * multiplied by grad_scale (1/world_size after a summing all-reduce). The
+ * clipped gradient is written back to g. scratch: >= 16 bytes, norm_out may be
+ * NULL. step is the 1-based step count. */
+int brv_clip_adam_step(float* params, float* grads, float* exp_avg,
+                       float* exp_avg_sq, int64_t n, float grad_scale,
+                       float max_norm, float lr, float beta1, float beta2,
+                       float eps, int64_t step, void* scratch, float* norm_out,
+                       brv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BREVER_HIP_H */

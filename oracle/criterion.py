@@ -1,0 +1,73 @@
+"""ORACLE (test infrastructure, not product code).
+
+CPU restatement in plain PyTorch of the length-masked losses of the reference,
+brever/criterion.py:21-132,229-234. Only ``tests/``, ``__graft_entry__.smoke``
+and the ``cpu_baseline`` leg of ``bench.py`` may import this module; the
+product path (``brever_amd``) never does.
+
+Pinning: checked against ``tests/golden/losses.npz`` produced from the imported
+reference (``tests/golden/make_golden.py``) and against the reference's own
+"batched == per-item" property (tests/test_losses.py:13-57).
+"""
+from itertools import permutations
+
+import torch
+
+EPS = torch.finfo(torch.float32).eps   # brever/criterion.py:9
+
+
+def length_mask(x, lengths):
+    """0/1 mask over the last dim, 1 where index < lengths[b]
+    (brever/criterion.py:229-234, without the per-item Python loop)."""
+    idx = torch.arange(x.shape[-1], device=x.device)
+    mask = idx.view(*[1]*(x.ndim - 1), -1) < lengths.view(-1, *[1]*(x.ndim - 1))
+    return mask.to(torch.float32)
+
+
+def snr(x, y, lengths):
+    """-mean_src 10 log10(sum y^2 / (sum (y-x)^2 + eps) + eps) -> (B,)
+    (brever/criterion.py:75-101)."""
+    assert x.shape == y.shape and x.ndim >= 2
+    m = length_mask(x, lengths)
+    x, y = x*m, y*m
+    ratio = y.pow(2).sum(-1)/((y - x).pow(2).sum(-1) + EPS)
+    val = 10*torch.log10(ratio + EPS)
+    return -val.mean(tuple(range(1, x.ndim - 1)))
+
+
+def sisnr(x, y, lengths):
+    """PIT SI-SNR, (B, S, L) x2 -> (B,) (brever/criterion.py:21-72)."""
+    assert x.shape == y.shape and x.ndim == 3
+    m = length_mask(x, lengths)
+    n = lengths.view(-1, 1, 1)
+    x, y = x*m, y*m
+    x = (x - x.sum(2, keepdim=True)/n)*m
+    y = (y - y.sum(2, keepdim=True)/n)*m
+    est = x.unsqueeze(1)                       # (B, 1, S, L)
+    ref = y.unsqueeze(2)                       # (B, S, 1, L)
+    proj = (est*ref).sum(3, keepdim=True)*ref/ref.pow(2).sum(3, keepdim=True)
+    noise = est - proj
+    val = proj.pow(2).sum(3)/(noise.pow(2).sum(3) + EPS)
+    val = 10*torch.log10(val + EPS)            # (B, S_ref, S_est)
+    S = x.shape[1]
+    best = None
+    for perm in permutations(range(S)):
+        # reference pairs ref i with est perm[i] through a one-hot einsum
+        total = sum(val[:, i, perm[i]] for i in range(S))
+        best = total if best is None else torch.maximum(best, total)
+    return -(best/S)
+
+
+def mse(x, y, lengths, weight=None):
+    """masked sum |x-y|^2 / length, mean over middle dims
+    (brever/criterion.py:104-132)."""
+    assert x.shape == y.shape and x.ndim >= 2
+    m = length_mask(x, lengths)
+    err = ((x - y)*m).abs().pow(2).sum(-1)
+    err = err/lengths.view(-1, *[1]*(x.ndim - 2))
+    if weight is not None:
+        err = err*weight.view(-1, *[1]*(x.ndim - 2))
+    return err.mean(tuple(range(1, x.ndim - 1)))
+
+
+CRITERIA = {'snr': snr, 'sisnr': sisnr, 'mse': mse}

@@ -1,0 +1,282 @@
+"""Generate the golden fixtures under tests/golden/ from the *imported reference*.
+
+Runs ONLY in the build container, where the reference checkout is mounted
+read-only at /root/reference; nothing of the reference (source or bytecode) is
+copied -- the fixtures are inputs-by-seed and outputs. Third-party wheels the
+reference imports but that are absent here (torchaudio, soundfile, h5py, wandb,
+dotenv, torch_ema, pesq, pystoi, batch_pystoi, sofa) are replaced by empty
+stand-in modules *before* import; none of them takes part in
+the arithmetic recorded here.
+
+    python tests/golden/make_golden.py            # writes *.npz / *.json next to it
+"""
+import json
+import os
+import random
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    def missing(*a, **k):
+        raise NotImplementedError('stubbed third-party function')
+
+    ta = mod('torchaudio', info=missing, load=missing, save=missing)
+    ta.functional = mod('torchaudio.functional', lfilter=missing)
+    mod('soundfile', read=missing, write=missing)
+    mod('wandb', log=missing, init=missing, login=missing)
+    mod('dotenv', load_dotenv=missing)
+    mod('h5py')
+    mod('sofa')
+    mod('pystoi', stoi=missing)
+    mod('batch_pystoi', stoi=missing)
+    pesq = mod('pesq', pesq=missing)
+    pesq._pesq = mod('pesq._pesq', USAGE_BATCH='', _check_fs_mode=missing,
+                     _pesq_inner=missing, _processor_mapping=missing)
+
+    class PesqError:
+        RAISE_EXCEPTION = 0
+        RETURN_VALUES = 1
+    pesq.cypesq = mod('pesq.cypesq', PesqError=PesqError)
+
+    class ExponentialMovingAverage:      # functional stand-in; unused here
+        def __init__(self, parameters, decay):
+            self.params = list(parameters)
+        def update(self): pass
+        def store(self): pass
+        def copy_to(self): pass
+        def restore(self): pass
+        def state_dict(self): return {}
+        def load_state_dict(self, s): pass
+    mod('torch_ema', ExponentialMovingAverage=ExponentialMovingAverage)
+
+
+def lengths_fixture(n=100, lo=1600, hi=160000, seed=42):
+    rng = random.Random(seed)
+    return [rng.randint(lo, hi) for _ in range(n)]
+
+
+class LengthOnlyDataset:
+    """Implements just what the reference samplers touch."""
+
+    def __init__(self, lengths):
+        self._lengths = lengths
+        self.rmm_dset = None
+
+    def __len__(self):
+        return len(self._lengths)
+
+    def get_segment_length(self, i):
+        return self._lengths[i]
+
+
+def golden_batching(out):
+    from brever.batching import (BatchSamplerRegistry,
+                                 DistributedBatchSamplerWrapper)
+    lengths = lengths_fixture()
+    dset = LengthOnlyDataset(lengths)
+    cases = []
+    for name in ['random', 'sorted', 'bucket']:
+        for dynamic, batch_size in [(False, 8), (True, 40.0)]:
+            for kwargs in [dict(), dict(drop_last=True), dict(shuffle=False),
+                           dict(seed=3)]:
+                if name == 'sorted':
+                    variants = [dict(kwargs), dict(kwargs, reverse=True)]
+                else:
+                    variants = [kwargs]
+                for kw in variants:
+                    sampler = BatchSamplerRegistry.get(name)(
+                        dset, batch_size, dynamic=dynamic, **kw)
+                    epochs = {}
+                    for epoch in range(4):
+                        sampler.set_epoch(epoch)
+                        if kw.get('shuffle', True) or epoch == 0:
+                            epochs[str(epoch)] = list(sampler)
+                    cases.append(dict(name=name, dynamic=dynamic,
+                                      batch_size=batch_size, kwargs=kw,
+                                      epochs=epochs))
+    # DDP wrapper, world sizes 2 and 4, fixed-length items (BASELINE config 3)
+    fixed = LengthOnlyDataset([64000]*64)
+    ddp = []
+    for world in [2, 4]:
+        for rank in range(world):
+            sampler = BatchSamplerRegistry.get('bucket')(fixed, 64.0, dynamic=True)
+            wrapper = DistributedBatchSamplerWrapper(sampler, num_replicas=world,
+                                                     rank=rank)
+            per_epoch = {}
+            for epoch in range(3):
+                wrapper.set_epoch(epoch)
+                per_epoch[str(epoch)] = list(wrapper)
+            ddp.append(dict(world=world, rank=rank, epochs=per_epoch))
+    sampler = BatchSamplerRegistry.get('bucket')(fixed, 64.0, dynamic=True)
+    single = {}
+    for epoch in range(2):
+        sampler.set_epoch(epoch)
+        single[str(epoch)] = list(sampler)
+    with open(os.path.join(out, 'batching.json'), 'w') as f:
+        json.dump(dict(lengths=lengths, cases=cases, ddp=ddp, fixed_single=single,
+                       seed0=sampler._seed), f)
+
+
+def golden_collate(out):
+    from brever.data import BreverDataLoader
+    g = torch.Generator().manual_seed(7)
+    items = [torch.randn(2, n, generator=g) for n in (5, 3, 4)]
+    batch, lengths = BreverDataLoader._collate_fn(items)
+    pairs = [(torch.randn(2, n, generator=g), torch.randn(1, generator=g))
+             for n in (5, 3, 4)]
+    pbatch, plengths = BreverDataLoader._collate_fn(pairs)
+    np.savez(os.path.join(out, 'collate.npz'),
+             **{f'item{i}': x.numpy() for i, x in enumerate(items)},
+             batch=batch.numpy(), lengths=lengths.numpy(),
+             **{f'pair{i}_0': a.numpy() for i, (a, b) in enumerate(pairs)},
+             **{f'pair{i}_1': b.numpy() for i, (a, b) in enumerate(pairs)},
+             pbatch0=pbatch[0].numpy(), pbatch1=pbatch[1].numpy(),
+             plengths=plengths.numpy())
+
+
+def golden_losses(out):
+    from brever.criterion import CriterionRegistry
+    torch.manual_seed(0)
+    B, S, lo, hi = 6, 3, 500, 1200
+    lengths = torch.randint(lo, hi, (B,))
+    x = torch.randn(B, S, hi)
+    y = torch.randn(B, S, hi) + 0.5*x
+    res = dict(x=x.numpy(), y=y.numpy(), lengths=lengths.numpy())
+    for name in ['snr', 'sisnr', 'mse']:
+        res[name] = CriterionRegistry.get(name)(x, y, lengths).numpy()
+    w = torch.rand(B)
+    res['weight'] = w.numpy()
+    res['mse_weighted'] = CriterionRegistry.get('mse')(x, y, lengths, weight=w).numpy()
+    xg = x.clone().requires_grad_(True)
+    CriterionRegistry.get('snr')(xg, y, lengths).mean().backward()
+    res['snr_grad'] = xg.grad.numpy()
+    np.savez_compressed(os.path.join(out, 'losses.npz'), **res)
+
+
+SMALL = dict(filters=48, filter_length=16, bottleneck_channels=24,
+             hidden_channels=40, skip_channels=16, kernel_size=3, layers=3,
+             repeats=2, output_sources=1)
+SMALL2 = dict(SMALL, output_sources=2, kernel_size=2)
+
+
+def flat_state(model):
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+
+
+def golden_convtasnet(out):
+    from brever.models import ModelRegistry
+    for tag, kw, B, L in [('small', SMALL, 3, 1000), ('small2', SMALL2, 2, 777)]:
+        torch.manual_seed(0)
+        model = ModelRegistry.get('convtasnet')(**kw)
+        # de-trivialise the affine / PReLU parameters (they initialise to 1/0/.25)
+        g = torch.Generator().manual_seed(1)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if 'norm' in name or 'prelu' in name:
+                    p.add_(0.1*torch.randn(p.shape, generator=g))
+        S = kw['output_sources']
+        batch = 0.3*torch.randn(B, 1 + S, L, generator=g)
+        lengths = torch.tensor([L, L - 137, L - 400][:B])
+        for b in range(B):
+            batch[b, :, lengths[b]:] = 0
+        out_t = model(batch[:, 0])
+        loss = model.loss(batch, lengths, use_amp=False)
+        loss.backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+        np.savez_compressed(
+            os.path.join(out, f'convtasnet_{tag}.npz'),
+            params=flat_state(model).numpy(), batch=batch.numpy(),
+            lengths=lengths.numpy(), output=out_t.detach().numpy(),
+            loss=loss.detach().numpy(), grads=grads.numpy(),
+            config=json.dumps(kw))
+    # default architecture: seeded init (reproducible by construction order),
+    # short input; outputs + per-tensor gradient norms only
+    torch.manual_seed(0)
+    model = ModelRegistry.get('convtasnet')()
+    g = torch.Generator().manual_seed(2)
+    batch = 0.3*torch.randn(1, 2, 4000, generator=g)
+    lengths = torch.tensor([4000])
+    out_t = model(batch[:, 0])
+    loss = model.loss(batch, lengths, use_amp=False)
+    loss.backward()
+    gnorm = torch.stack([p.grad.norm() for p in model.parameters()])
+    flat = flat_state(model)
+    np.savez_compressed(
+        os.path.join(out, 'convtasnet_default.npz'),
+        batch=batch.numpy(), lengths=lengths.numpy(), output=out_t.detach().numpy(),
+        loss=loss.detach().numpy(), grad_norms=gnorm.numpy(),
+        param_sum=flat.double().sum().numpy(),
+        param_abs_sum=flat.double().abs().sum().numpy(),
+        first_params=flat[:64].numpy())
+
+
+def golden_training(out):
+    """The 2-epoch flow of the reference's tests/test_training.py for the dummy
+    and convtasnet models (val_metrics reduced to {'snr'}: PESQ/ESTOI wheels are
+    absent). Records the first 10 parameters after training."""
+    sys.path.insert(0, os.path.join(REF, 'tests'))
+    from utils import DummyDataset, DummyModel
+    from brever.models import ModelRegistry
+    from brever.training import BreverTrainer
+    FS = 16000
+    res = {}
+    for tag, ctor, sources in [
+        ('dummy', lambda: DummyModel(channels=2, output_sources=2), 3),
+        ('convtasnet', lambda: ModelRegistry.get('convtasnet')(
+            filters=4, filter_length=2, bottleneck_channels=1, hidden_channels=1,
+            skip_channels=1, kernel_size=1, layers=1, repeats=1,
+            output_sources=2), 3),
+    ]:
+        torch.manual_seed(0)
+        random.seed(0)
+        np.random.seed(0)
+        model = ctor()
+        train = DummyDataset(16, sources, 2, int(FS*0.5), FS*4,
+                             transform=model.transform)
+        val = DummyDataset(4, sources, 2, int(FS*0.5), FS*4)
+        with tempfile.TemporaryDirectory() as tmp:
+            trainer = BreverTrainer(
+                model=model, train_dataset=train, val_dataset=val,
+                model_dirpath=tmp, epochs=2, val_period=1, val_metrics={'snr'},
+                batch_sampler='bucket', batch_size=8.0, dynamic_batch_size=True,
+                ema=True, device='cpu', preload=True)
+            trainer.run()
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        res[tag] = flat[:10].numpy()
+        res[tag + '_train_loss'] = np.array(
+            [float(d['loss']) for d in trainer.loss_logger.train_loss])
+        res[tag + '_val_loss'] = np.array(
+            [float(d['loss']) for d in trainer.loss_logger.val_loss])
+    np.savez(os.path.join(out, 'training.npz'), **res)
+
+
+def main():
+    install_stubs()
+    sys.path.insert(0, REF)
+    os.chdir(REF)       # the reference opens config/... relatively
+    torch.set_num_threads(4)
+    golden_batching(HERE)
+    golden_collate(HERE)
+    golden_losses(HERE)
+    golden_convtasnet(HERE)
+    golden_training(HERE)
+    print('golden fixtures written to', HERE)
+
+
+if __name__ == '__main__':
+    main()

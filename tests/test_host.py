@@ -1,0 +1,189 @@
+"""Host-side logic against the golden fixtures captured from the reference
+(tests/golden/make_golden.py) + the reference's own sampler invariants
+(tests/test_batching.py:20-211). CPU only."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from brever_amd import hip
+from brever_amd.batching import (BatchSamplerRegistry, BreverBatchSampler,
+                                 DistributedBatchSamplerWrapper)
+from brever_amd.data import BreverDataLoader, SyntheticMixtureDataset
+from brever_amd.registry import Registry
+
+
+class LengthOnlyDataset:
+    def __init__(self, lengths):
+        self._lengths = lengths
+        self.rmm_dset = None
+
+    def __len__(self):
+        return len(self._lengths)
+
+    def get_segment_length(self, i):
+        return self._lengths[i]
+
+
+@pytest.fixture(scope='module')
+def batching_golden(golden_dir):
+    with open(os.path.join(golden_dir, 'batching.json')) as f:
+        return json.load(f)
+
+
+def test_registry_contract():
+    reg = Registry('thing')
+    reg.register('a')(int)
+    assert reg.get('a') is int
+    with pytest.raises(ValueError):
+        reg.register('a')(float)
+    with pytest.raises(KeyError):
+        reg.get('b')
+    assert list(reg.keys()) == ['a']
+
+
+def test_sampler_keys():
+    assert set(BatchSamplerRegistry.keys()) == {'random', 'sorted', 'bucket'}
+
+
+def test_batch_composition_bit_exact(batching_golden):
+    dset = LengthOnlyDataset(batching_golden['lengths'])
+    assert len(batching_golden['cases']) >= 30
+    for case in batching_golden['cases']:
+        sampler = BatchSamplerRegistry.get(case['name'])(
+            dset, case['batch_size'], dynamic=case['dynamic'], **case['kwargs'])
+        for epoch, expected in case['epochs'].items():
+            sampler.set_epoch(int(epoch))
+            assert list(sampler) == expected, (case['name'], case['kwargs'], epoch)
+
+
+def test_ddp_wrapper_bit_exact(batching_golden):
+    fixed = LengthOnlyDataset([64000]*64)
+    for entry in batching_golden['ddp']:
+        sampler = BatchSamplerRegistry.get('bucket')(fixed, 64.0, dynamic=True)
+        wrapper = DistributedBatchSamplerWrapper(
+            sampler, num_replicas=entry['world'], rank=entry['rank'])
+        for epoch, expected in entry['epochs'].items():
+            wrapper.set_epoch(int(epoch))
+            assert list(wrapper) == expected
+    sampler = BatchSamplerRegistry.get('bucket')(fixed, 64.0, dynamic=True)
+    assert sampler._seed == batching_golden['seed0'] == 3626764237
+    for epoch, expected in batching_golden['fixed_single'].items():
+        sampler.set_epoch(int(epoch))
+        got = list(sampler)
+        assert got == expected
+        assert all(len(b) == 16 for b in got)
+
+
+@pytest.mark.parametrize('name', ['random', 'sorted', 'bucket'])
+@pytest.mark.parametrize('dynamic', [False, True])
+def test_sampler_invariants(name, dynamic):
+    dset = SyntheticMixtureDataset(60, 32000, min_length=1600)
+    batch_size = 4.0 if dynamic else 4
+    sampler = BatchSamplerRegistry.get(name)(dset, batch_size, dynamic=dynamic)
+    loader = BreverDataLoader(dset, batch_sampler=sampler)
+    with pytest.raises(ValueError):       # set_epoch is mandatory when shuffling
+        loader.set_epoch(0)
+        list(sampler)
+        list(sampler)
+    seen = []
+    orders = []
+    for epoch in range(1, 3):
+        loader.set_epoch(epoch)
+        order = []
+        for batch, lengths in loader:
+            assert batch.shape[0] == len(lengths)
+            assert batch.shape[-1] == int(lengths.max())
+            if dynamic:
+                assert batch.shape[0]*batch.shape[-1] <= sampler.batch_size
+            else:
+                assert batch.shape[0] <= batch_size
+            for item, n in zip(batch, lengths):
+                assert torch.all(item[..., n:] == 0)
+            order.append(lengths.tolist())
+        orders.append(order)
+        seen.append(sorted(i for b in sampler._batches for i, _ in b))
+    assert seen[0] == list(range(60))
+    assert orders[0] != orders[1]                 # reshuffled per epoch
+    if name == 'sorted':
+        sampler2 = BatchSamplerRegistry.get(name)(dset, batch_size,
+                                                  dynamic=dynamic, shuffle=False)
+        flat = [n for b in (sampler2.generate_batches() or sampler2._batches)
+                for _, n in b]
+        assert flat == sorted(flat)
+
+
+def test_base_sampler_is_abstract():
+    sampler = BreverBatchSampler(LengthOnlyDataset([3, 4]), 2)
+    sampler.set_epoch(1)
+    with pytest.raises(NotImplementedError):
+        list(sampler)
+
+
+def test_collate_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'collate.npz'))
+    items = [torch.from_numpy(g[f'item{i}']) for i in range(3)]
+    batch, lengths = BreverDataLoader._collate_fn(items)
+    assert torch.equal(batch, torch.from_numpy(g['batch']))
+    assert torch.equal(lengths, torch.from_numpy(g['lengths']))
+    pairs = [(torch.from_numpy(g[f'pair{i}_0']), torch.from_numpy(g[f'pair{i}_1']))
+             for i in range(3)]
+    pb, pl = BreverDataLoader._collate_fn(pairs)
+    assert torch.equal(pb[0], torch.from_numpy(g['pbatch0']))
+    assert torch.equal(pb[1], torch.from_numpy(g['pbatch1']))
+    assert torch.equal(pl, torch.from_numpy(g['plengths']))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports each symbol of include/brever_hip.h
+    (no compute without a GPU)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'brever_hip.h')).read()
+    declared = set(re.findall(r'\b(brv_[a-z0-9_]+)\s*\(', header))
+    declared -= {'brv_ctn_config'}
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    lib = hip.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.brv_version() >= 100
+
+
+def test_layout_queries_match_reference_constants():
+    from brever_amd.models import ConvTasNet, count_params
+    net = ConvTasNet()
+    assert count_params(net) == 4_935_217          # reference tests/test_models.py:103
+    assert len(net.state_dict()) == 343
+    lib = hip.lib()
+    cfg = ctypes.byref(net.cfg)
+    assert lib.brv_ctn_param_count(cfg) == 4_935_217
+    assert lib.brv_ctn_param_tensors(cfg) == 343
+    # offsets follow parameters() order
+    off = 0
+    for i, p in enumerate(net.parameters()):
+        assert lib.brv_ctn_param_offset(cfg, i) == off
+        off += p.numel()
+    # Encoder.pad arithmetic (convtasnet.py:115-120), bit-exact
+    for L in [1, 15, 16, 31, 32, 33, 47, 48, 63999, 64000, 64001]:
+        pad = (32 - L) % 16
+        expect = (L + pad - 32)//16 + 1 if L + pad >= 32 else 0
+        assert lib.brv_ctn_frames(cfg, L) == expect, L
+    assert lib.brv_ctn_frames(cfg, 64000) == 3999
+
+
+def test_product_rejects_cpu_tensors():
+    """No CPU fallback: the HIP-backed ops refuse host tensors loudly."""
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    x = torch.zeros(1, 1, 64)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        snr(x, x, torch.tensor([64]))
+    net = ConvTasNet(filters=8, bottleneck_channels=8, hidden_channels=8,
+                     skip_channels=8, layers=1, repeats=1)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net(torch.zeros(1, 256))
+    with pytest.raises(NotImplementedError):
+        ConvTasNet(causal=True)
