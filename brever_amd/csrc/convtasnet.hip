@@ -4,6 +4,7 @@
 // :100-260 (Encoder / Decoder / TCN / Conv1DBlock) and their autograd. The kernel
 // sequence and the saved-activation plan are described in DESIGN.md.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -29,6 +30,25 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 inline long long align_up(long long x, long long a) { return (x + a - 1)/a*a; }
+
+// ---- optional per-launch event timing (bench / profiling only) ---------------
+// Off by default. When enabled through brv_prof_enable(1) every kernel launch of
+// this file is bracketed by two events on the launch stream; brv_prof_collect()
+// aggregates them per label together with the algorithmic FLOPs / bytes.
+struct ProfEntry { const char* label; hipEvent_t a, b; double flops, bytes; };
+bool g_prof_on = false;
+std::vector<ProfEntry> g_prof;
+struct ProfScope {
+  hipStream_t st; bool on;
+  ProfScope(const char* label, double flops, double bytes, hipStream_t s) : st(s), on(g_prof_on) {
+    if (!on) return;
+    ProfEntry e; e.label = label; e.flops = flops; e.bytes = bytes;
+    hipEventCreate(&e.a); hipEventCreate(&e.b);
+    hipEventRecord(e.a, st);
+    g_prof.push_back(e);
+  }
+  ~ProfScope() { if (on) hipEventRecord(g_prof.back().b, st); }
+};
 
 struct BlockOff {
   long long conv_w, conv_b, dconv_w, dconv_b, res_w, res_b, skip_w, skip_b,
@@ -150,8 +170,10 @@ int launch_gemm_rows_t(const GemmRowsParams& p, int batch, hipStream_t st) {
 }
 
 template <int AK, int EM>
-int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st) {
+int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st,
+                     const char* label = "gemm_rows", double bytes = 0) {
   if (p.T <= 0 || batch <= 0) return 0;
+  ProfScope prof(label, 2.0*batch*p.T*(double)p.Np*p.Kp, bytes, st);
   if (p.Kp % GR_BK != 0 || p.Np % 64 != 0) return fail(-1, "gemm_rows: unpadded dims");
   if (p.Np % 128 == 0) return launch_gemm_rows_t<128, AK, EM>(p, batch, st);
   return launch_gemm_rows_t<64, AK, EM>(p, batch, st);
@@ -171,8 +193,10 @@ int launch_wgrad_t(WgradParams& p, hipStream_t st) {
   return 0;
 }
 template <int HK>
-int launch_wgrad(WgradParams& p, hipStream_t st) {
+int launch_wgrad(WgradParams& p, hipStream_t st, const char* label = "wgrad",
+                 double bytes = 0) {
   if (p.T <= 0 || p.B <= 0) return 0;
+  ProfScope prof(label, 2.0*p.B*p.T*(double)p.Gp*p.Hp, bytes, st);
   if (p.Hp % 64 != 0) return fail(-1, "wgrad: unpadded dims");
   if (p.Hp % 128 == 0) return launch_wgrad_t<128, HK>(p, st);
   return launch_wgrad_t<64, HK>(p, st);
@@ -191,6 +215,7 @@ int dispatch_p(int P, Args&&... args) {
 }
 template <int P> struct DwFwd {
   static int run(const DwParams& p, hipStream_t st) {
+    ProfScope prof("dwconv_fwd", 2.0*P*p.B*p.T*(double)p.Cp, 4.0*p.B*p.T*(double)p.Cp, st);
     dim3 grid(ceil_div(p.T, DW_TT), p.Cp/64, p.B);
     hipLaunchKernelGGL((dwconv_fwd_kernel<P>), grid, dim3(256), 0, st, p);
     HIP_OK(hipGetLastError());
@@ -199,6 +224,7 @@ template <int P> struct DwFwd {
 };
 template <int P> struct DwBwd {
   static int run(const DwParams& p, hipStream_t st) {
+    ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 6.0*p.B*p.T*(double)p.Cp, st);
     dim3 grid(ceil_div(p.T, DW_TT), p.Cp/64, p.B);
     hipLaunchKernelGGL((dwconv_bwd_kernel<P>), grid, dim3(256), 0, st, p);
     HIP_OK(hipGetLastError());
@@ -207,6 +233,7 @@ template <int P> struct DwBwd {
 };
 
 int launch_dz(const DzParams& p, hipStream_t st) {
+  ProfScope prof("gln_prelu_bwd", 0, 6.0*p.B*p.T*(double)p.Cp, st);
   const long long per_item = (long long)p.T*(p.Cp/8);
   int gx = (int)((per_item + 256*4 - 1)/(256*4));
   if (gx > 2048) gx = 2048;
@@ -246,6 +273,38 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* params,
 extern "C" {
 
 int brv_version(void) { return 100; }
+
+int brv_prof_enable(int on) {
+  for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return 0;
+}
+
+// Writes one line per label: "label calls total_ms flops bytes\n". Returns the
+// number of bytes needed (call again with a larger buffer if > buflen).
+int64_t brv_prof_collect(char* buf, int64_t buflen) {
+  struct Agg { std::string label; long long calls; double ms, flops, bytes; };
+  std::vector<Agg> agg;
+  for (auto& e : g_prof) {
+    hipEventSynchronize(e.b);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e.a, e.b);
+    Agg* a = nullptr;
+    for (auto& x : agg) if (x.label == e.label) { a = &x; break; }
+    if (!a) { agg.push_back({e.label, 0, 0, 0, 0}); a = &agg.back(); }
+    a->calls += 1; a->ms += ms; a->flops += e.flops; a->bytes += e.bytes;
+  }
+  std::string out;
+  char line[256];
+  for (auto& a : agg) {
+    snprintf(line, sizeof(line), "%s %lld %.6f %.6e %.6e\n", a.label.c_str(), a.calls, a.ms,
+             a.flops, a.bytes);
+    out += line;
+  }
+  if ((int64_t)out.size() + 1 <= buflen && buf) memcpy(buf, out.c_str(), out.size() + 1);
+  return (int64_t)out.size() + 1;
+}
 const char* brv_last_error(void) { return g_err.c_str(); }
 
 int64_t brv_ctn_param_count(const brv_ctn_config* cfg) {
@@ -346,6 +405,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   const long long T = l.frames(L);
   if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
   Workspace ws; ws.init(l, B, T);
+  const double BT = (double)B*(double)T;
   char* base = (char*)workspace;
   const bf16_t* prep = (const bf16_t*)prepared;
   double* stats = (double*)(base + ws.stats);
@@ -367,14 +427,14 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   g.a = frames_of(wave, L, l.hop, l.K);
   g.W = prep + l.p_enc; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
   g.e.out = w; g.e.ldo = l.Np; g.e.N = l.N; g.e.stats_out = stat(0);
-  if (int r = launch_gemm_rows<A_FRAMES, E_STORE>(g, B, st)) return r;
+  if (int r = launch_gemm_rows<A_FRAMES, E_STORE>(g, B, st, "enc_fwd", 4.0*B*L + 2.0*BT*l.Np)) return r;
   // bottleneck 1x1 conv on gLN(w)
   memset(&g, 0, sizeof(g));
   g.a = rows_bf16(w, l.Np, T);
   set_affine(g.a, stat(0), params + l.ln_g, params + l.ln_b, l.N, T);
   g.W = prep + l.p_bott_f; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Np;
   g.e.out = xbuf(0); g.e.ldo = l.Bnp; g.e.bias = params + l.bott_b; g.e.N = l.Bn;
-  if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st)) return r;
+  if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st, "bottleneck_fwd", 2.0*BT*(l.Np + l.Bnp))) return r;
 
   for (int i = 0; i < l.nb; ++i) {
     const BlockOff& b = l.blk[i];
@@ -386,7 +446,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
     g.W = prep + b.p_c1_f; g.T = (int)T; g.Np = l.Hp; g.Kp = l.Bnp;
     g.e.out = z1buf(i); g.e.ldo = l.Hp; g.e.bias = params + b.conv_b; g.e.N = l.H;
     g.e.stats_out = stat(1 + 2*i); g.e.stats_slope = params + b.prelu1;
-    if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st)) return r;
+    if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st, "pw1_fwd", 2.0*BT*(l.Bnp + l.Hp))) return r;
     // prelu_1 -> gLN -> depthwise dilated conv (+ statistics of prelu_2 output)
     DwParams d; memset(&d, 0, sizeof(d));
     d.z1 = z1buf(i); d.z2 = z2buf(i); d.B = B; d.T = (int)T; d.Cp = l.Hp; d.C = l.H;
@@ -409,7 +469,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
     g.e.Nsplit = rs0; g.e.bias2 = params + b.skip_b; g.e.N2 = l.Sc;
     g.e.res_in = xbuf(i); g.e.ld_res = l.Bnp;
     g.e.skip = skip; g.e.ld_skip = l.Scp; g.e.skip_init = (i == 0);
-    if (int r = launch_gemm_rows<A_BF16, E_RES_SKIP>(g, B, st)) return r;
+    if (int r = launch_gemm_rows<A_BF16, E_RES_SKIP>(g, B, st, "pw2_fwd", 2.0*BT*(l.Hp + l.Bnp + rs0) + 4.0*BT*l.Scp*(i == 0 ? 1 : 2))) return r;
   }
   // prelu -> output 1x1 conv -> sigmoid -> mask * encoder output
   memset(&g, 0, sizeof(g));
@@ -418,14 +478,14 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   g.W = prep + l.p_out_f; g.T = (int)T; g.Np = l.S*l.Np; g.Kp = l.Scp;
   g.e.out = y; g.e.ldo = l.Np; g.e.bias = params + l.out_b; g.e.N = l.N;
   g.e.w_in = w; g.e.ld_w = l.Np; g.e.m_out = m; g.e.S = l.S; g.e.Np_src = l.Np;
-  if (int r = launch_gemm_rows<A_F32, E_MASK>(g, B, st)) return r;
+  if (int r = launch_gemm_rows<A_F32, E_MASK>(g, B, st, "mask_fwd", 4.0*BT*l.Scp + 2.0*BT*l.Np*(1 + 2*l.S))) return r;
   // decoder: synthesis filterbank + overlap-add, cropped to the input length
   memset(&g, 0, sizeof(g));
   g.a = rows_bf16(y, l.Np, T);
   g.W = prep + l.p_dec_f; g.T = (int)T; g.Np = l.Kfp; g.Kp = l.Np;
   g.e.wave_out = out; g.e.hop = l.hop; g.e.Kf = l.K; g.e.wave_stride = L;
   g.e.wave_len = (int)L;
-  if (int r = launch_gemm_rows<A_BF16, E_OLA>(g, B*l.S, st)) return r;
+  if (int r = launch_gemm_rows<A_BF16, E_OLA>(g, B*l.S, st, "dec_fwd", 2.0*BT*l.S*l.Np + 4.0*B*l.S*L)) return r;
   return 0;
 }
 
@@ -438,6 +498,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   const long long T = l.frames(L);
   if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
   Workspace ws; ws.init(l, B, T);
+  const double BT = (double)B*(double)T;
   char* base = (char*)workspace;
   const bf16_t* prep = (const bf16_t*)prepared;
   double* stats = (double*)(base + ws.stats);
@@ -470,20 +531,20 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   g.W = prep + l.p_dec_b; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
   g.e.out = dpre; g.e.ldo = l.Np; g.e.out2 = dw1; g.e.w_in = w; g.e.ld_w = l.Np;
   g.e.m_in = m; g.e.S = l.S;
-  if (int r = launch_gemm_rows<A_FRAMES, E_MASK_BWD>(g, BS, st)) return r;
+  if (int r = launch_gemm_rows<A_FRAMES, E_MASK_BWD>(g, BS, st, "dec_bwd", 4.0*BS*L + 2.0*BT*l.Np*(1 + 3*l.S))) return r;
   // decoder weight gradient: y^T * frames(d_out)
   memset(&wg, 0, sizeof(wg));
   wg.g = rows_bf16(y, l.Np, T); wg.h = frames_of(d_out, L, l.hop, l.K);
   wg.B = BS; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
   wg.out0 = grads + l.dec_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
-  if (int r = launch_wgrad<A_FRAMES>(wg, st)) return r;
+  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_dec", 2.0*BT*l.S*l.Np + 4.0*BS*L)) return r;
   // output conv data gradient, PReLU backward -> gradient wrt skip_sum
   memset(&g, 0, sizeof(g));
   g.a = rows_bf16(dpre, l.Np, T); g.a.nsrc = l.S;
   g.W = prep + l.p_out_b; g.T = (int)T; g.Np = l.Scp; g.Kp = l.S*l.Np;
   g.e.out = gskip; g.e.ldo = l.Scp; g.e.src_f32 = skip; g.e.ld_srcf = l.Scp;
   g.e.src_slope = params + l.tcn_prelu; g.e.dslope = grads + l.tcn_prelu;
-  if (int r = launch_gemm_rows<A_BF16, E_PRELU_BWD>(g, B, st)) return r;
+  if (int r = launch_gemm_rows<A_BF16, E_PRELU_BWD>(g, B, st, "mask_bwd", 2.0*BT*l.S*l.Np + 6.0*BT*l.Scp)) return r;
   // output conv weight / bias gradients, one source at a time
   for (int s = 0; s < l.S; ++s) {
     memset(&wg, 0, sizeof(wg));
@@ -492,7 +553,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Scp;
     wg.out0 = grads + l.out_w + (long long)s*l.N*l.Sc; wg.G0p = l.Np; wg.N0 = l.N;
     wg.Kout = l.Sc; wg.ldo = l.Sc; wg.gbias0 = grads + l.out_b + (long long)s*l.N;
-    if (int r = launch_wgrad<A_F32>(wg, st)) return r;
+    if (int r = launch_wgrad<A_F32>(wg, st, "wgrad_out", 2.0*BT*l.Np + 4.0*BT*l.Scp)) return r;
   }
 
   for (int i = l.nb - 1; i >= 0; --i) {
@@ -510,7 +571,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     g.e.src_stats = stat(2 + 2*i); g.e.inv_n = 1.0/((double)T*l.H); g.e.eps = 1e-8f;
     g.e.gamma = params + b.n2_g; g.e.dgamma = grads + b.n2_g; g.e.dbeta = grads + b.n2_b;
     g.e.sums_out = sum(2 + 2*i);
-    if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st)) return r;
+    if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + 2*l.Hp))) return r;
     // [res | skip] weight / bias gradients against gLN_2(prelu_2(z2))
     memset(&wg, 0, sizeof(wg));
     wg.g = rows_bf16(gout, l.Bnp, T); wg.g.K0 = rs0;
@@ -521,7 +582,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     wg.out0 = has_res ? grads + b.res_w : nullptr; wg.out1 = grads + b.skip_w;
     wg.G0p = rs0; wg.N0 = has_res ? l.Bn : 0; wg.N1 = l.Sc; wg.Kout = l.H; wg.ldo = l.H;
     wg.gbias0 = has_res ? grads + b.res_b : nullptr; wg.gbias1 = grads + b.skip_b;
-    if (int r = launch_wgrad<A_BF16>(wg, st)) return r;
+    if (int r = launch_wgrad<A_BF16>(wg, st, "pw2_wgrad", 2.0*BT*(rs0 + l.Scp + l.Hp))) return r;
     // gLN_2 + prelu_2 backward -> dz2 (in place)
     DzParams dz; memset(&dz, 0, sizeof(dz));
     dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
@@ -550,13 +611,13 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     wg.B = B; wg.T = (int)T; wg.Gp = l.Hp; wg.Hp = l.Bnp;
     wg.out0 = grads + b.conv_w; wg.G0p = l.Hp; wg.N0 = l.H; wg.Kout = l.Bn; wg.ldo = l.Bn;
     wg.gbias0 = grads + b.conv_b;
-    if (int r = launch_wgrad<A_BF16>(wg, st)) return r;
+    if (int r = launch_wgrad<A_BF16>(wg, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp))) return r;
     // first 1x1 conv: data gradient + residual path -> gradient wrt block input
     memset(&g, 0, sizeof(g));
     g.a = rows_bf16(eB, l.Hp, T);
     g.W = prep + b.p_c1_b; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Hp;
     g.e.out = gout; g.e.ldo = l.Bnp; g.e.add_in = has_res ? gout : nullptr; g.e.ld_add = l.Bnp;
-    if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st)) return r;
+    if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
   }
   // bottleneck conv: data gradient + first gLN backward partials
   memset(&g, 0, sizeof(g));
@@ -567,7 +628,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   g.e.inv_n = 1.0/((double)T*l.N); g.e.eps = 1e-8f;
   g.e.gamma = params + l.ln_g; g.e.dgamma = grads + l.ln_g; g.e.dbeta = grads + l.ln_b;
   g.e.sums_out = sum(0);
-  if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st)) return r;
+  if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "bottleneck_dgrad", 2.0*BT*(l.Bnp + 2*l.Np))) return r;
   // bottleneck conv: weight / bias gradients against gLN(w)
   memset(&wg, 0, sizeof(wg));
   wg.g = rows_bf16(gout, l.Bnp, T); wg.h = rows_bf16(w, l.Np, T);
@@ -575,7 +636,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   wg.B = B; wg.T = (int)T; wg.Gp = l.Bnp; wg.Hp = l.Np;
   wg.out0 = grads + l.bott_w; wg.G0p = l.Bnp; wg.N0 = l.Bn; wg.Kout = l.N; wg.ldo = l.N;
   wg.gbias0 = grads + l.bott_b;
-  if (int r = launch_wgrad<A_BF16>(wg, st)) return r;
+  if (int r = launch_wgrad<A_BF16>(wg, st, "bottleneck_wgrad", 2.0*BT*(l.Bnp + l.Np))) return r;
   // total gradient wrt the encoder output
   CombineParams cb; memset(&cb, 0, sizeof(cb));
   cb.e0 = e0; cb.w = w; cb.dw1 = dw1; cb.dw = dwt; cb.B = B; cb.T = (int)T;
@@ -586,6 +647,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     int gx = (int)((per_item + 1023)/1024);
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
+    ProfScope prof("gln0_bwd", 0, 2.0*BT*l.Np*(3 + l.S), st);
     hipLaunchKernelGGL(gln0_bwd_combine_kernel, dim3(gx, B), dim3(256), 0, st, cb);
     HIP_OK(hipGetLastError());
   }
@@ -594,7 +656,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   wg.g = rows_bf16(dwt, l.Np, T); wg.h = frames_of(wave, L, l.hop, l.K);
   wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
   wg.out0 = grads + l.enc_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
-  if (int r = launch_wgrad<A_FRAMES>(wg, st)) return r;
+  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_enc", 2.0*BT*l.Np + 4.0*B*L)) return r;
   return 0;
 }
 

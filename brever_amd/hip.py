@@ -29,6 +29,8 @@ class CtnConfig(ctypes.Structure):
 SIGNATURES = {
     'brv_version': (ctypes.c_int, []),
     'brv_last_error': (ctypes.c_char_p, []),
+    'brv_prof_enable': (ctypes.c_int, [ctypes.c_int]),
+    'brv_prof_collect': (_c_i64, [ctypes.c_char_p, _c_i64]),
     'brv_ctn_param_count': (_c_i64, [_c_ptr]),
     'brv_ctn_param_tensors': (_c_i64, [_c_ptr]),
     'brv_ctn_param_offset': (_c_i64, [_c_ptr, _c_i64]),
@@ -106,3 +108,17 @@ def ptr(t):
 
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_collect():
+    """Per-label aggregate of the event-timed launches since ``brv_prof_enable(1)``:
+    ``{label: dict(calls, ms, flops, bytes)}``."""
+    n = lib().brv_prof_collect(None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 16)
+    lib().brv_prof_collect(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        label, calls, ms, flops, nbytes = line.split()
+        out[label] = dict(calls=int(calls), ms=float(ms), flops=float(flops),
+                          bytes=float(nbytes))
+    return out

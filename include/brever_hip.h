@@ -31,6 +31,13 @@ typedef void* brv_stream_t;          /* hipStream_t */
 int brv_version(void);
 const char* brv_last_error(void);
 
+/* Optional per-launch timing with HIP events on the launch stream (bench.py's
+ * roofline measurement; off by default, process-global, not thread-safe).
+ * brv_prof_collect writes "label calls total_ms flops bytes" lines (algorithmic
+ * FLOPs / HBM bytes as stated in DESIGN.md) and returns the buffer size needed. */
+int brv_prof_enable(int on);
+int64_t brv_prof_collect(char* buf, int64_t buflen);
+
 /* ---- Conv-TasNet ---------------------------------------------------------
  * Hyper-parameters of brever.models.convtasnet.ConvTasNet.__init__
  * (convtasnet.py:30-46). causal != 0 is not supported yet (returns -2). */

@@ -151,6 +151,11 @@ class OracleConvTasNet(BreverBaseModel):
         self.optimizer = self.init_optimizer(optimizer, lr=learning_rate)
         self.grad_clip = grad_clip
         self.emulate_bf16 = emulate_bf16
+        self.trace = None          # set to a dict to capture intermediates
+
+    def _tap(self, name, value):
+        if self.trace is not None:
+            self.trace[name] = value.detach()
 
     # ---- forward -----------------------------------------------------------
     def encode(self, x):
@@ -159,17 +164,21 @@ class OracleConvTasNet(BreverBaseModel):
         e = self.emulate_bf16
         w = F.conv1d(_rb(x, e).unsqueeze(1), _rb(self.encoder.conv.weight, e),
                      stride=hop)
-        return _rb(w, e)
+        w = _rb(w, e)
+        self._tap('w', w)
+        return w
 
-    def _block(self, blk, x):
+    def _block(self, blk, x, index=0):
         e = self.emulate_bf16
         z1 = _rb(F.conv1d(x, _rb(blk.conv.weight, e), blk.conv.bias), e)
+        self._tap(f'z1.{index}', z1)
         h = blk.norm_1(blk.prelu_1(z1))
         pad = (blk.kernel_size - 1)*blk.dilation
         left = pad if blk.causal else pad//2                # convtasnet.py:244-251
         h = F.pad(h, (left, pad - left))
         z2 = _rb(F.conv1d(h, blk.d_conv.weight, blk.d_conv.bias,
                           dilation=blk.dilation, groups=h.shape[1]), e)
+        self._tap(f'z2.{index}', z2)
         h = _rb(blk.norm_2(blk.prelu_2(z2)), e)
         out = None
         if blk.res_conv is not None:
@@ -184,13 +193,18 @@ class OracleConvTasNet(BreverBaseModel):
         x = _rb(tcn.layer_norm(w), e)
         x = _rb(F.conv1d(x, _rb(tcn.bottleneck_conv.weight, e),
                          tcn.bottleneck_conv.bias), e)
+        self._tap('x.0', x)
         skip_sum = 0
-        for blk in tcn.conv_blocks:
-            x, skip = self._block(blk, x)
+        for i, blk in enumerate(tcn.conv_blocks):
+            x, skip = self._block(blk, x, i)
+            if x is not None:
+                self._tap(f'x.{i + 1}', x)
             skip_sum = skip_sum + skip
+        self._tap('skip', skip_sum)
         h = _rb(tcn.prelu(skip_sum), e)
         m = torch.sigmoid(F.conv1d(h, _rb(tcn.output_conv.weight, e),
                                    tcn.output_conv.bias))
+        self._tap('m', m)
         return m.view(w.shape[0], tcn.sources, w.shape[1], w.shape[2])
 
     def decode(self, w, masks):
