@@ -183,7 +183,7 @@ template <int BH, int HK>
 int launch_wgrad_t(WgradParams& p, hipStream_t st) {
   const int tiles = ceil_div(p.Gp, WG_BG)*(p.Hp/BH);
   const int total = p.B*ceil_div(p.T, WG_BT);
-  int ns = ceil_div(768, tiles);
+  int ns = ceil_div(320, tiles);
   if (ns > total) ns = total;
   if (ns < 1) ns = 1;
   p.nsplit = ns;
@@ -216,7 +216,7 @@ int dispatch_p(int P, Args&&... args) {
 template <int P> struct DwFwd {
   static int run(const DwParams& p, hipStream_t st) {
     ProfScope prof("dwconv_fwd", 2.0*P*p.B*p.T*(double)p.Cp, 4.0*p.B*p.T*(double)p.Cp, st);
-    dim3 grid(ceil_div(p.T, DW_TT), p.Cp/64, p.B);
+    dim3 grid(ceil_div(p.T, DW_TT), p.B);
     hipLaunchKernelGGL((dwconv_fwd_kernel<P>), grid, dim3(256), 0, st, p);
     HIP_OK(hipGetLastError());
     return 0;
@@ -225,7 +225,7 @@ template <int P> struct DwFwd {
 template <int P> struct DwBwd {
   static int run(const DwParams& p, hipStream_t st) {
     ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 6.0*p.B*p.T*(double)p.Cp, st);
-    dim3 grid(ceil_div(p.T, DW_TT), p.Cp/64, p.B);
+    dim3 grid(ceil_div(p.T, DW_TT), p.B);
     hipLaunchKernelGGL((dwconv_bwd_kernel<P>), grid, dim3(256), 0, st, p);
     HIP_OK(hipGetLastError());
     return 0;
@@ -235,8 +235,11 @@ template <int P> struct DwBwd {
 int launch_dz(const DzParams& p, hipStream_t st) {
   ProfScope prof("gln_prelu_bwd", 0, 6.0*p.B*p.T*(double)p.Cp, st);
   const long long per_item = (long long)p.T*(p.Cp/8);
-  int gx = (int)((per_item + 256*4 - 1)/(256*4));
-  if (gx > 2048) gx = 2048;
+  // every workgroup ends with one atomic on the single PReLU-slope gradient word
+  // (~12 ns each, serialised): keep the grid near 1024 workgroups
+  int gx = (int)((per_item + 256*8 - 1)/(256*8));
+  const int cap = 1024/p.B > 1 ? 1024/p.B : 1;
+  if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(dz_kernel, dim3(gx, p.B), dim3(256), 0, st, p);
   HIP_OK(hipGetLastError());

@@ -1,0 +1,294 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed
+golden vectors. Every test here needs a real MI355X.
+
+Tolerances (bf16 storage / MFMA operands, fp32 accumulation):
+* forward vs the bf16-emulating oracle (same rounding points): rel L2 <= 5e-3
+* forward vs the fp32 reference golden: rel L2 <= 2e-2; loss |d| <= 1e-3 dB
+* gradients vs the fp32 reference golden: global rel L2 <= 8e-2 and not worse
+  than 2.5x the error the bf16-emulating oracle itself makes
+* fp32 kernels (criteria, clip+Adam): rtol 1e-5 / 1e-6
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import DummyDataset  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a ROCm device')
+    return torch.device('cuda:0')
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm()/(b.norm() + 1e-30))
+
+
+def load_pair(golden_dir, tag, emulate=True):
+    from brever_amd.models import ConvTasNet
+    from oracle.convtasnet import OracleConvTasNet
+    g = np.load(os.path.join(golden_dir, f'convtasnet_{tag}.npz'))
+    cfg = json.loads(str(g['config']))
+    oracle = OracleConvTasNet(**cfg, emulate_bf16=emulate)
+    off = 0
+    with torch.no_grad():
+        for p in oracle.parameters():
+            n = p.numel()
+            p.copy_(torch.from_numpy(g['params'][off:off + n]).view(p.shape))
+            off += n
+    net = ConvTasNet(**cfg)
+    net.load_state_dict(oracle.state_dict())
+    return g, cfg, oracle, net.to(_cuda())
+
+
+@pytest.mark.parametrize('tag', ['small', 'small2'])
+def test_forward_matches_oracle_and_reference(golden_dir, tag):
+    g, cfg, oracle, net = load_pair(golden_dir, tag)
+    batch = torch.from_numpy(g['batch'])
+    oracle.trace = {}
+    want_emu = oracle(batch[:, 0])
+    with torch.no_grad():
+        got = net(batch[:, 0].cuda())
+    assert got.shape == want_emu.shape
+    assert rel(got, want_emu) <= 5e-3
+    assert rel(got, torch.from_numpy(g['output'])) <= 2e-2
+    # encoder output is produced by one bf16 GEMM with K = filter_length: exact
+    B, _, L = batch.shape
+    T = net.frames(L)
+    Np = (cfg['filters'] + 63)//64*64
+    w = net.workspace_tensor('w', 0, B, L, (B, T, Np), torch.bfloat16).float()
+    assert torch.equal(w[..., cfg['filters']:], torch.zeros_like(w[..., cfg['filters']:]))
+    assert rel(w[..., :cfg['filters']], oracle.trace['w'].transpose(1, 2)) <= 1e-3
+
+
+@pytest.mark.parametrize('tag', ['small', 'small2'])
+def test_backward_matches_reference(golden_dir, tag):
+    from brever_amd.criterion import snr
+    g, cfg, oracle, net = load_pair(golden_dir, tag)
+    batch = torch.from_numpy(g['batch'])
+    lengths = torch.from_numpy(g['lengths'])
+    oracle.loss(batch, lengths, False).backward()
+    emu = torch.cat([p.grad.reshape(-1) for p in oracle.parameters()])
+    out = net(batch[:, 0].cuda())
+    loss = snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean()
+    assert abs(float(loss) - float(g['loss'])) <= 1e-3
+    loss.backward()
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+    gold = torch.from_numpy(g['grads'])
+    err_hip, err_emu = rel(got, gold), rel(emu, gold)
+    assert err_hip <= 8e-2, (err_hip, err_emu)
+    assert err_hip <= 2.5*err_emu + 1e-3, (err_hip, err_emu)
+    # tensor by tensor (the large ones), same criterion
+    off = 0
+    for name, p in net.named_parameters():
+        n = p.numel()
+        ref = gold[off:off + n]
+        if n >= 256 and float(ref.norm()) > 1e-3:
+            e_h = rel(got[off:off + n], ref)
+            e_e = rel(emu[off:off + n], ref)
+            assert e_h <= 3.0*e_e + 2e-2, (name, e_h, e_e)
+        off += n
+
+
+@pytest.mark.parametrize('B,L', [(1, 33), (1, 130), (2, 257), (3, 2049), (2, 4000)])
+def test_forward_odd_lengths(golden_dir, B, L):
+    """Frame-count arithmetic and tile tails: T not a multiple of the 128-frame tile,
+    inputs shorter than a tile, padding of (K - L) % hop samples."""
+    _, cfg, oracle, net = load_pair(golden_dir, 'small')
+    g = torch.Generator().manual_seed(L)
+    x = 0.3*torch.randn(B, L, generator=g)
+    want = oracle(x)
+    with torch.no_grad():
+        got = net(x.cuda())
+    assert got.shape == (B, 1, L)
+    assert rel(got, want) <= 1e-2
+
+
+def test_default_architecture_forward_and_loss(golden_dir):
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    g = np.load(os.path.join(golden_dir, 'convtasnet_default.npz'))
+    torch.manual_seed(0)
+    net = ConvTasNet().to(_cuda())          # same seeded init as the reference
+    batch = torch.from_numpy(g['batch'])
+    out = net(batch[:, 0].cuda())
+    assert rel(out, torch.from_numpy(g['output'])) <= 2e-2
+    loss = snr(out, batch[:, 1:].cuda(), torch.from_numpy(g['lengths']).cuda()).mean()
+    assert abs(float(loss) - float(g['loss'])) <= 2e-3
+    loss.backward()
+    gn = torch.stack([p.grad.norm() for p in net.parameters()]).cpu()
+    ref = torch.from_numpy(g['grad_norms'])
+    big = ref > 1e-3*ref.max()
+    assert float(((gn - ref).abs()/ref)[big].max()) <= 0.15
+
+
+def test_criteria_match_reference(golden_dir):
+    from brever_amd.criterion import mse, sisnr, snr
+    g = np.load(os.path.join(golden_dir, 'losses.npz'))
+    dev = _cuda()
+    x, y = torch.from_numpy(g['x']).to(dev), torch.from_numpy(g['y']).to(dev)
+    lengths = torch.from_numpy(g['lengths']).to(dev)
+    with torch.no_grad():
+        assert torch.allclose(snr(x, y, lengths).cpu(), torch.from_numpy(g['snr']),
+                              rtol=1e-5, atol=1e-5)
+        assert torch.allclose(sisnr(x, y, lengths).cpu(), torch.from_numpy(g['sisnr']),
+                              rtol=1e-4, atol=1e-4)
+        assert torch.allclose(mse(x, y, lengths).cpu(), torch.from_numpy(g['mse']),
+                              rtol=1e-5, atol=1e-7)
+        w = torch.from_numpy(g['weight']).to(dev)
+        assert torch.allclose(mse(x, y, lengths, weight=w).cpu(),
+                              torch.from_numpy(g['mse_weighted']), rtol=1e-5, atol=1e-7)
+    xg = x.clone().requires_grad_(True)
+    snr(xg, y, lengths).mean().backward()
+    assert torch.allclose(xg.grad.cpu(), torch.from_numpy(g['snr_grad']),
+                          rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize('name', ['snr', 'sisnr', 'mse'])
+def test_criteria_batched_equals_per_item(name):
+    """The reference's property test (tests/test_losses.py) on the HIP kernels, at its
+    sizes: 16 items x 4 sources, lengths 16-32 k; plus length-1 and full-length edges."""
+    from brever_amd.criterion import CriterionRegistry
+    dev = _cuda()
+    fn = CriterionRegistry.get(name)
+    torch.manual_seed(0)
+    B, S, lo, hi = 16, 4, 16000, 32000
+    lengths = torch.randint(lo, hi, (B,))
+    lengths[0], lengths[1] = hi, 2
+    x = torch.randn(B, S, hi)
+    y = torch.randn(B, S, hi)
+    with torch.no_grad():
+        batched = fn(x.to(dev), y.to(dev), lengths.to(dev)).cpu()
+        single = torch.stack([
+            fn(x[b:b+1, :, :lengths[b]].to(dev), y[b:b+1, :, :lengths[b]].to(dev),
+               lengths[b:b+1].to(dev))[0].cpu() for b in range(B)])
+    assert torch.allclose(batched, single, rtol=1e-5, atol=1e-5)
+
+
+def test_clip_adam_matches_torch():
+    from brever_amd import hip
+    dev = _cuda()
+    n = 100_003
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.clone().to(dev)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    scratch = torch.zeros(64, dtype=torch.uint8, device=dev)
+    norm = torch.zeros(1, device=dev)
+    for step in range(1, 5):
+        grad = torch.randn(n, generator=g)*(10.0 if step % 2 else 0.001)
+        ref.grad = grad.clone()
+        total = torch.nn.utils.clip_grad_norm_([ref], 5.0)
+        opt.step()
+        gd = grad.clone().to(dev)
+        hip.check(hip.lib().brv_clip_adam_step(
+            hip.ptr(p), hip.ptr(gd), hip.ptr(m), hip.ptr(v), n, 1.0, 5.0, 1e-3, 0.9,
+            0.999, 1e-8, step, hip.ptr(scratch), hip.ptr(norm), hip.stream()), 'adam')
+        assert abs(float(norm) - float(total)) <= 1e-4*float(total)
+        assert torch.allclose(gd.cpu(), ref.grad, rtol=1e-5, atol=1e-8)
+        assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_train_step_follows_oracle_trajectory(golden_dir):
+    """Protocol of SURVEY.md 8(d): same init, same batches, HIP fused step vs the fp32
+    CPU oracle (reference train_step: clip 5.0 + Adam)."""
+    g, cfg, _, net = load_pair(golden_dir, 'small')
+    from oracle.convtasnet import OracleConvTasNet
+    oracle = OracleConvTasNet(**cfg)
+    oracle.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    gen = torch.Generator().manual_seed(11)
+    worst = 0.0
+    for step in range(6):
+        batch = 0.3*torch.randn(4, 2, 3000, generator=gen)
+        lengths = torch.tensor([3000, 2500, 2000, 1600])
+        for b in range(4):
+            batch[b, :, lengths[b]:] = 0
+        want = float(oracle.train_step(batch, lengths, False, scaler))
+        got = float(net.train_step(batch.cuda(), lengths.cuda(), True, scaler))
+        worst = max(worst, abs(got - want))
+        if step == 0:
+            assert abs(got - want) <= 1e-3, (got, want)
+    assert worst <= 3e-2, worst
+    assert rel(net.flat_params(), torch.cat(
+        [p.detach().reshape(-1) for p in oracle.parameters()])) <= 2e-2
+
+
+def test_autograd_path_equals_fused_path(golden_dir):
+    from brever_amd.criterion import snr
+    g, cfg, _, net = load_pair(golden_dir, 'small2')
+    batch = torch.from_numpy(g['batch']).cuda()
+    lengths = torch.from_numpy(g['lengths']).cuda()
+    out = net(batch[:, 0])
+    snr(out, batch[:, 1:], lengths).mean().backward()
+    a = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+    net.optimizer.param_groups[0]['lr'] = 0.0     # keep the weights
+    net.train_step(batch, lengths, True, None)
+    b = net.flat_grads().clone()                  # clipped copy written back
+    norm = float(net.optimizer.last_grad_norm)
+    clip = min(1.0, 5.0/(norm + 1e-6))
+    assert rel(b, a*clip) <= 1e-3
+
+
+def test_module_plumbing(golden_dir):
+    """state_dict round trip, .to() re-flattening, enhance() shapes and errors."""
+    from brever_amd.models import ConvTasNet
+    g, cfg, oracle, net = load_pair(golden_dir, 'small')
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    other = ConvTasNet(**cfg).to(_cuda())
+    other.load_state_dict(sd)
+    x = torch.from_numpy(g['batch'])[:, :1].repeat(1, 2, 1).cuda()   # (B, 2, L)
+    with torch.no_grad():
+        a, b = net.enhance(x), other.enhance(x)
+        assert torch.equal(a, b)
+        assert a.shape == (x.shape[0], 1, x.shape[-1])
+        assert net.enhance(x[0]).shape == (1, x.shape[-1])
+        with pytest.raises(ValueError):
+            net.enhance(x[0, 0])
+    flat_before = net.flat_params().clone()
+    net.cpu()
+    net.cuda()
+    assert torch.equal(net.flat_params(), flat_before)
+    for p, off in net.param_offsets():
+        assert p.data_ptr() == net.flat_params().data_ptr() + 4*off
+
+
+def test_full_size_step_properties():
+    """BASELINE size (16 x 4 s): one fused training step runs, is finite, changes the
+    weights, and the forward is reproducible to fp32 rounding."""
+    from brever_amd.models import ConvTasNet
+    dev = _cuda()
+    torch.manual_seed(0)
+    net = ConvTasNet().to(dev)
+    g = torch.Generator().manual_seed(5)
+    batch = 0.1*torch.randn(16, 2, 64000, generator=g)
+    lengths = torch.randint(32000, 64001, (16,), generator=g)
+    lengths[0] = 64000
+    for b in range(16):
+        batch[b, :, lengths[b]:] = 0
+    batch, lengths = batch.to(dev), lengths.to(dev)
+    with torch.no_grad():
+        a = net(batch[:, 0])
+        b = net(batch[:, 0])
+    assert a.shape == (16, 1, 64000)
+    assert torch.isfinite(a).all()
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+    before = net.flat_params().clone()
+    l0 = float(net.train_step(batch, lengths, True, None))
+    l1 = float(net.train_step(batch, lengths, True, None))
+    l2 = float(net.train_step(batch, lengths, True, None))
+    assert np.isfinite([l0, l1, l2]).all()
+    assert l2 < l0                                   # Adam on a fixed batch descends
+    assert torch.isfinite(net.flat_params()).all()
+    assert not torch.equal(before, net.flat_params())
+    assert float(net.optimizer.last_grad_norm) > 0
