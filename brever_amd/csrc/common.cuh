@@ -98,6 +98,26 @@ __device__ __forceinline__ NormStat norm_stat(const double* stats, int b,
   return r;
 }
 
+// v[j] = p[c0 + j] for c0 + j < C, else 0 (p may be null -> zeros). The common case
+// (whole chunk inside the tensor) issues 8 unconditional loads the compiler can batch
+// and merge; the guarded form compiles to serialised load/wait pairs.
+__device__ __forceinline__ void load8_masked(const float* p, int c0, int C, float (&v)[8]) {
+  if (p != nullptr && c0 + 8 <= C) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[c0 + j];
+  } else if (p != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      const float x = p[c < C ? c : (C > 0 ? C - 1 : 0)];
+      v[j] = c < C ? x : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  }
+}
+
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1)/m*m; }
 __host__ __device__ inline int ceil_div(int x, int m) { return (x + m - 1)/m; }
 

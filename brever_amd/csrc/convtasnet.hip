@@ -129,7 +129,8 @@ struct Layout {
 
 struct Workspace {
   long long w, x, z1, z2, skip, m, y, stats, sums, dpre, dw1, gskip, gout, eA, eB,
-      e0, dwt, total;
+      e0, dwt, vg, total;
+  long long vg_stride, vg_bytes;      // replicated vector-gradient block (floats / bytes)
   long long x_stride, z_stride;       // bytes between consecutive blocks' buffers
   long long stats_bytes;
   void init(const Layout& l, long long B, long long T) {
@@ -156,14 +157,19 @@ struct Workspace {
     eB = take(BT*l.Hp*2);
     e0 = take(BT*l.Np*2);
     dwt = take(BT*l.Np*2);
+    vg_stride = align_up(2LL*l.N + (long long)l.nb*l.H*(5 + l.P), 64);
+    vg_bytes = vg_stride*kReplicas*4;
+    vg = take(vg_bytes);
     total = o;
   }
 };
 
 // ---------------------------------------------------------------------------
 template <int BN, int AK, int EM>
-int launch_gemm_rows_t(const GemmRowsParams& p, int batch, hipStream_t st) {
-  dim3 grid(ceil_div(p.T, GR_BM), ceil_div(p.Np, BN), batch);
+int launch_gemm_rows_t(const GemmRowsParams& p0, int batch, hipStream_t st) {
+  GemmRowsParams p = p0;
+  p.n_ttiles = ceil_div(p.T, GR_BM); p.n_ntiles = ceil_div(p.Np, BN); p.batch = batch;
+  dim3 grid(p.n_ttiles*p.n_ntiles*batch);
   hipLaunchKernelGGL((gemm_rows_kernel<BN, AK, EM>), grid, dim3(256), 0, st, p);
   HIP_OK(hipGetLastError());
   return 0;
@@ -216,7 +222,7 @@ int dispatch_p(int P, Args&&... args) {
 template <int P> struct DwFwd {
   static int run(const DwParams& p, hipStream_t st) {
     ProfScope prof("dwconv_fwd", 2.0*P*p.B*p.T*(double)p.Cp, 4.0*p.B*p.T*(double)p.Cp, st);
-    dim3 grid(ceil_div(p.T, DW_TT), p.B);
+    dim3 grid(ceil_div(p.T, DW_TT_F)*p.B);
     hipLaunchKernelGGL((dwconv_fwd_kernel<P>), grid, dim3(256), 0, st, p);
     HIP_OK(hipGetLastError());
     return 0;
@@ -225,7 +231,7 @@ template <int P> struct DwFwd {
 template <int P> struct DwBwd {
   static int run(const DwParams& p, hipStream_t st) {
     ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 6.0*p.B*p.T*(double)p.Cp, st);
-    dim3 grid(ceil_div(p.T, DW_TT), p.B);
+    dim3 grid(ceil_div(p.T, DW_TT_B)*p.B);
     hipLaunchKernelGGL((dwconv_bwd_kernel<P>), grid, dim3(256), 0, st, p);
     HIP_OK(hipGetLastError());
     return 0;
@@ -524,8 +530,12 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   bf16_t* e0 = (bf16_t*)(base + ws.e0);
   bf16_t* dwt = (bf16_t*)(base + ws.dwt);
   const int BS = B*l.S;
+  float* vg = (float*)(base + ws.vg);
+  const long long vper = (long long)l.H*(5 + l.P);
+  auto vslot = [&](int i) { return vg + 2LL*l.N + vper*i; };   // block i's vector grads
 
   HIP_OK(hipMemsetAsync(sums, 0, ws.stats_bytes, st));
+  HIP_OK(hipMemsetAsync(vg, 0, ws.vg_bytes, st));
 
   GemmRowsParams g; WgradParams wg;
   // decoder data gradient (framing of d_out) fused with the mask backward
@@ -572,7 +582,9 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     g.e.out = eA; g.e.ldo = l.Hp; g.e.N = l.H;
     g.e.src = z2buf(i); g.e.ld_src = l.Hp; g.e.src_slope = params + b.prelu2;
     g.e.src_stats = stat(2 + 2*i); g.e.inv_n = 1.0/((double)T*l.H); g.e.eps = 1e-8f;
-    g.e.gamma = params + b.n2_g; g.e.dgamma = grads + b.n2_g; g.e.dbeta = grads + b.n2_b;
+    g.e.gamma = params + b.n2_g;
+    g.e.dgamma = vslot(i) + 2*l.H; g.e.dbeta = vslot(i) + 3*l.H;
+    g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
     g.e.sums_out = sum(2 + 2*i);
     if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + 2*l.Hp))) return r;
     // [res | skip] weight / bias gradients against gLN_2(prelu_2(z2))
@@ -599,8 +611,9 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     d.gamma1 = params + b.n1_g; d.beta1 = params + b.n1_b;
     d.inv_n = 1.0/((double)T*l.H); d.eps = 1e-8f;
     d.taps = params + b.dconv_w; d.dil = dil; d.left = ((l.P - 1)*dil)/2;
-    d.dgamma1 = grads + b.n1_g; d.dbeta1 = grads + b.n1_b;
-    d.dtaps = grads + b.dconv_w; d.dbias = grads + b.dconv_b; d.sums1 = sum(1 + 2*i);
+    d.dgamma1 = vslot(i); d.dbeta1 = vslot(i) + l.H;
+    d.dtaps = vslot(i) + 4*l.H; d.dbias = vslot(i) + 4*l.H + (long long)l.H*l.P;
+    d.rep_stride = ws.vg_stride; d.sums1 = sum(1 + 2*i);
     if (int r = dispatch_p<DwBwd>(l.P, d, st)) return r;
     // gLN_1 + prelu_1 backward -> dz1 (in place)
     memset(&dz, 0, sizeof(dz));
@@ -629,7 +642,8 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   g.e.out = e0; g.e.ldo = l.Np; g.e.N = l.N;
   g.e.src = w; g.e.ld_src = l.Np; g.e.src_stats = stat(0);
   g.e.inv_n = 1.0/((double)T*l.N); g.e.eps = 1e-8f;
-  g.e.gamma = params + l.ln_g; g.e.dgamma = grads + l.ln_g; g.e.dbeta = grads + l.ln_b;
+  g.e.gamma = params + l.ln_g; g.e.dgamma = vg; g.e.dbeta = vg + l.N;
+  g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
   g.e.sums_out = sum(0);
   if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "bottleneck_dgrad", 2.0*BT*(l.Bnp + 2*l.Np))) return r;
   // bottleneck conv: weight / bias gradients against gLN(w)
@@ -660,6 +674,24 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
   wg.out0 = grads + l.enc_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
   if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_enc", 2.0*BT*l.Np + 4.0*B*L)) return r;
+  // fold the replicated per-channel gradients into the flat gradient
+  {
+    VgradParams vp; memset(&vp, 0, sizeof(vp));
+    vp.vg = vg; vp.grads = grads; vp.rep_stride = ws.vg_stride;
+    vp.N = l.N; vp.H = l.H; vp.P = l.P; vp.nb = l.nb;
+    vp.ln_g_off = l.ln_g; vp.blk0_off = l.blk[0].conv_w;
+    vp.blk_full = l.nb > 1 ? l.blk[1].conv_w - l.blk[0].conv_w : 0;
+    const BlockOff& b0 = l.blk[0];
+    const BlockOff& bl = l.blk[l.nb - 1];
+    vp.o_dconv_w = b0.dconv_w - b0.conv_w; vp.o_dconv_b = b0.dconv_b - b0.conv_w;
+    vp.o_n1_g_full = b0.n1_g - b0.conv_w; vp.o_n1_g_last = bl.n1_g - bl.conv_w;
+    const long long total = 2LL*l.N + vper*l.nb;
+    int gx = (int)((total + 255)/256);
+    if (gx > 1024) gx = 1024;
+    ProfScope prof("vgrad_reduce", 0, 4.0*total*(kReplicas + 2), st);
+    hipLaunchKernelGGL(vgrad_reduce_kernel, dim3(gx), dim3(256), 0, st, vp);
+    HIP_OK(hipGetLastError());
+  }
   return 0;
 }
 

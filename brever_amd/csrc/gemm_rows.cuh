@@ -58,6 +58,7 @@ struct EpiSpec {
   const bf16_t* src; int ld_src; const float* src_slope; const double* src_stats;
   double inv_n; float eps;
   const float* gamma; float* dgamma; float* dbeta; double* sums_out;
+  long long rep_stride; int n_rep;      // dgamma/dbeta replicas (see tcn_kernels.cuh)
   const bf16_t* add_in; int ld_add;
   const bf16_t* m_in; bf16_t* out2;
   const float* src_f32; int ld_srcf; float* dslope;
@@ -67,8 +68,20 @@ struct GemmRowsParams {
   ASpec a;
   const bf16_t* W;         // [Np][Kp]
   int T, Np, Kp;
+  int n_ttiles, n_ntiles, batch;   // filled by the launcher (1-D XCD-aware grid)
   EpiSpec e;
 };
+
+// 1-D grid -> (frame tile, channel tile, item). Workgroups are dealt round-robin over
+// the 8 XCDs (id % 8 share an XCD and its private L2), so the work list is cut into 8
+// contiguous chunks, one per XCD, with the channel tile fastest: the channel tiles
+// that re-read one A tile then run back to back on the same L2. Speed only -- any
+// placement computes the same result.
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int xcd = id & 7, slot = id >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd*(q + 1) : r*(q + 1) + (xcd - r)*q) + slot;
+}
 
 constexpr int GR_BM = 128;
 constexpr int GR_BK = 64;
@@ -94,9 +107,12 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.x*GR_BM;
-  const int n0 = blockIdx.y*BN;
+  const int vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int n_tile = vid % p.n_ntiles;
+  const int rest = vid / p.n_ntiles;
+  const int b = rest / p.n_ttiles;
+  const int t0 = (rest % p.n_ttiles)*GR_BM;
+  const int n0 = n_tile*BN;
   const int T = p.T;
 
   // ---- per-thread staging geometry --------------------------------------
@@ -164,13 +180,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
       }
     }
     if (affine) {
+      float g8[8], b8[8];
+      load8_masked(a.gamma, kbase, a.C, g8);
+      load8_masked(a.beta, kbase, a.C, b8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int k = kbase + j;
-        const float g = k < a.C ? a.gamma[k] : 0.f;
-        const float be = k < a.C ? a.beta[k] : 0.f;
-        asc[j] = ns.rstd*g;
-        ash[j] = be - ns.mean*ns.rstd*g;
+        asc[j] = ns.rstd*g8[j];
+        ash[j] = b8[j] - ns.mean*ns.rstd*g8[j];
       }
     }
 #pragma unroll
@@ -277,30 +293,20 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
 #pragma unroll
   for (int j = 0; j < 8; ++j) biasv[j] = 0.f;
   if (EM == E_STORE || EM == E_RES_SKIP) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int n = ncol + j;
-      if (EM == E_RES_SKIP && n >= e.Nsplit) {
-        const int n2 = n - e.Nsplit;
-        biasv[j] = (e.bias2 && n2 < e.N2) ? e.bias2[n2] : 0.f;
-      } else {
-        biasv[j] = (e.bias && n < e.N) ? e.bias[n] : 0.f;
-      }
-    }
+    // Nsplit is a multiple of 64, so an 8-column chunk never straddles it
+    if (EM == E_RES_SKIP && ncol >= e.Nsplit) load8_masked(e.bias2, ncol - e.Nsplit, e.N2, biasv);
+    else load8_masked(e.bias, ncol, e.N, biasv);
   }
   int msrc = 0, mf = 0;                     // E_MASK: source index / filter index
   if (EM == E_MASK) {
     msrc = ncol / e.Np_src; mf = ncol % e.Np_src;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      biasv[j] = (e.bias && mf + j < e.N) ? e.bias[msrc*e.N + mf + j] : 0.f;
+    load8_masked(e.bias ? e.bias + msrc*e.N : nullptr, mf, e.N, biasv);
   }
   NormStat es = {0.f, 1.f};
   float gam[8];
   if (EM == E_GLN_BWD) {
     es = norm_stat(e.src_stats, b, e.inv_n, e.eps);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) gam[j] = (ncol + j < e.N) ? e.gamma[ncol + j] : 0.f;
+    load8_masked(e.gamma, ncol, e.N, gam);
   }
   const float eslope = (EM == E_GLN_BWD && e.src_slope) ? *e.src_slope
                      : (EM == E_PRELU_BWD ? *e.src_slope
@@ -449,7 +455,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
       float a0 = 0.f, b0 = 0.f;
       for (int r = 0; r < RG; ++r) { a0 += sc[r*BN + tid]; b0 += sc[RG*BN + r*BN + tid]; }
       const int n = n0 + tid;
-      if (n < e.N) { atomic_add_f32(e.dgamma + n, a0); atomic_add_f32(e.dbeta + n, b0); }
+      const long long ro = e.n_rep > 1 ? (long long)(blockIdx.x % e.n_rep)*e.rep_stride : 0;
+      if (n < e.N) {
+        atomic_add_f32(e.dgamma + ro + n, a0);
+        atomic_add_f32(e.dbeta + ro + n, b0);
+      }
     }
   }
 }

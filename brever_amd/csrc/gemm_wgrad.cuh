@@ -103,11 +103,8 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradParams p) {
   const bool h_prelu = H.slope != nullptr;
   const float hslope = h_prelu ? *H.slope : 1.f;
   float hg[8], hb[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    hg[j] = (h_aff && hch + j < H.C) ? H.gamma[hch + j] : 0.f;
-    hb[j] = (h_aff && hch + j < H.C) ? H.beta[hch + j] : 0.f;
-  }
+  load8_masked(h_aff ? H.gamma : nullptr, hch, H.C, hg);
+  load8_masked(h_aff ? H.beta : nullptr, hch, H.C, hb);
 
   uint4 graw[4];
   uint4 hraw_b[HCH];

@@ -30,68 +30,108 @@ struct DwParams {
   int dil, left;
   double* stats2; const float* slope2;                   // fwd
   float* dgamma1; float* dbeta1; float* dtaps; float* dbias; double* sums1;   // bwd
+  long long rep_stride;    // bwd: per-channel gradients go to replica (wg % kReplicas)
 };
 
-constexpr int DW_TT = 128;     // frames per workgroup (4 waves x 32 consecutive frames)
-constexpr int DW_RPW = DW_TT/4;
+// Per-channel gradients (norm gains/biases, depthwise taps/biases) are summed over
+// every frame of the batch. Adding them from thousands of workgroups into a few KB
+// is the "all adders on one row" case of the float-atomic unit (an order of magnitude
+// below its rate), so workgroups add into one of kReplicas copies of the vector-
+// gradient block and vgrad_reduce_kernel folds the copies into the real gradient.
+constexpr int kReplicas = 64;
+
+constexpr int DW_TT_F = 32;    // forward: frames per workgroup (4 waves x 8 frames)
+constexpr int DW_TT_B = 64;    // backward: 4 waves x 16 frames (fewer per-channel atomics)
+
+// Workgroup id -> (item, frame tile): the work list is cut into 8 contiguous chunks,
+// one per XCD (ids congruent mod 8 share an XCD), so the tiles whose dilated taps
+// overlap are neighbours in time on one L2 instead of being fetched by 3 XCDs.
+__device__ __forceinline__ int dw_xcd_remap(int id, int nwg) {
+  const int xcd = id & 7, slot = id >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd*(q + 1) : r*(q + 1) + (xcd - r)*q) + slot;
+}
 
 // One wavefront handles whole frames: 64 lanes x 8 channels = 512 channels = 1 KiB
 // contiguous per access (channel chunks beyond 512 are looped over).
 template <int P>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p) {
   __shared__ double dscr[16];
+  constexpr int DW_RPW = DW_TT_F/4;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int b = blockIdx.y;
   const int T = p.T;
-  const int tw0 = blockIdx.x*DW_TT + wid*DW_RPW;
+  const int n_tt = ceil_div(T, DW_TT_F);
+  const int vid = dw_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = vid / n_tt;
+  const int tw0 = (vid % n_tt)*DW_TT_F + wid*DW_RPW;
   const NormStat ns = norm_stat(p.stats1, b, p.inv_n, p.eps);
   const float a1 = *p.slope1, a2 = *p.slope2;
   double s_sum = 0.0, s_sq = 0.0;
 
   for (int c0 = lane*8; c0 < p.Cp; c0 += 512) {
     float sc[8], sh[8], bs[8], w[P][8];
+    {
+      float g8[8], b8[8], tp[P][8];
+      load8_masked(p.gamma1, c0, p.C, g8);
+      load8_masked(p.beta1, c0, p.C, b8);
+      load8_masked(p.bias, c0, p.C, bs);
+      // taps are [C][P]: P chunks of 8 consecutive floats cover this lane's 8 channels
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = c0 + j;
-      const bool ok = c < p.C;
-      const float g = ok ? p.gamma1[c] : 0.f;
-      sc[j] = ns.rstd*g;
-      sh[j] = (ok ? p.beta1[c] : 0.f) - ns.mean*ns.rstd*g;
-      bs[j] = ok ? p.bias[c] : 0.f;
+      for (int k = 0; k < P; ++k) load8_masked(p.taps, c0*P + 8*k, p.C*P, tp[k]);
 #pragma unroll
-      for (int k = 0; k < P; ++k) w[k][j] = ok ? p.taps[c*P + k] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        sc[j] = ns.rstd*g8[j];
+        sh[j] = b8[j] - ns.mean*ns.rstd*g8[j];
+#pragma unroll
+        for (int k = 0; k < P; ++k) w[k][j] = tp[(j*P + k)/8][(j*P + k)%8];
+      }
     }
     const bf16_t* zin = p.z1 + (long long)b*T*p.Cp + c0;
     bf16_t* zout = p.z2 + (long long)b*T*p.Cp + c0;
-#pragma unroll 4
-    for (int i = 0; i < DW_RPW; ++i) {
-      const int t = tw0 + i;
-      if (t >= T) break;
-      float acc[8];
+    for (int i0 = 0; i0 < DW_RPW; i0 += 4) {
+      uint4 raw[4][P];
+      bool ok[4][P];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = bs[j];
+      for (int u = 0; u < 4; ++u) {
+        const int t = tw0 + i0 + u;
 #pragma unroll
-      for (int k = 0; k < P; ++k) {
-        const int ti = t + k*p.dil - p.left;
-        if (ti < 0 || ti >= T) continue;          // zero padding of the normalised input
-        float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(zin + (long long)ti*p.Cp), f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          acc[j] += w[k][j]*(prelu(f[j], a1)*sc[j] + sh[j]);
-      }
-      const uint4 q = pack8(acc);
-      *reinterpret_cast<uint4*>(zout + (long long)t*p.Cp) = q;
-      float r[8]; unpack8(q, r);
-      float ls = 0.f, lq = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (c0 + j < p.C) {
-          const float pv = prelu(r[j], a2);
-          ls += pv; lq += pv*pv;
+        for (int k = 0; k < P; ++k) {
+          const int ti = t + k*p.dil - p.left;
+          ok[u][k] = t < T && ti >= 0 && ti < T;   // outside: zero padding of gLN output
+          const int tc = ti < 0 ? 0 : (ti >= T ? T - 1 : ti);
+          raw[u][k] = *reinterpret_cast<const uint4*>(zin + (long long)tc*p.Cp);
         }
       }
-      s_sum += ls; s_sq += lq;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = tw0 + i0 + u;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bs[j];
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          float f[8];
+          unpack8(raw[u][k], f);
+          const float on = ok[u][k] ? 1.f : 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            acc[j] += on*w[k][j]*(prelu(f[j], a1)*sc[j] + sh[j]);
+        }
+        if (t < T) {
+          const uint4 q = pack8(acc);
+          *reinterpret_cast<uint4*>(zout + (long long)t*p.Cp) = q;
+          float r[8]; unpack8(q, r);
+          float ls = 0.f, lq = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (c0 + j < p.C) {
+              const float pv = prelu(r[j], a2);
+              ls += pv; lq += pv*pv;
+            }
+          }
+          s_sum += ls; s_sq += lq;
+        }
+      }
     }
   }
   const double r0 = block_sum(s_sum, dscr);
@@ -152,10 +192,13 @@ template <int P>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
   __shared__ float red[4*512];
   __shared__ double dscr[16];
+  constexpr int DW_RPW = DW_TT_B/4;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int b = blockIdx.y;
   const int T = p.T;
-  const int tw0 = blockIdx.x*DW_TT + wid*DW_RPW;
+  const int n_tt = ceil_div(T, DW_TT_B);
+  const int vid = dw_xcd_remap(blockIdx.x, gridDim.x);
+  const int b = vid / n_tt;
+  const int tw0 = (vid % n_tt)*DW_TT_B + wid*DW_RPW;
   const NormStat ns = norm_stat(p.stats1, b, p.inv_n, p.eps);
   const float a1 = *p.slope1;
   double s1 = 0.0, s2 = 0.0;
@@ -164,15 +207,19 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
     const int c0 = cb + lane*8;
     const bool lane_ok = c0 < p.Cp;
     float sc[8], sh[8], gm[8], w[P][8];
+    {
+      float b8[8], tp[P][8];
+      load8_masked(p.gamma1, c0, p.C, gm);
+      load8_masked(p.beta1, c0, p.C, b8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = c0 + j;
-      const bool ok = c < p.C;
-      gm[j] = ok ? p.gamma1[c] : 0.f;
-      sc[j] = ns.rstd*gm[j];
-      sh[j] = (ok ? p.beta1[c] : 0.f) - ns.mean*ns.rstd*gm[j];
+      for (int k = 0; k < P; ++k) load8_masked(p.taps, c0*P + 8*k, p.C*P, tp[k]);
 #pragma unroll
-      for (int k = 0; k < P; ++k) w[k][j] = ok ? p.taps[c*P + k] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        sc[j] = ns.rstd*gm[j];
+        sh[j] = b8[j] - ns.mean*ns.rstd*gm[j];
+#pragma unroll
+        for (int k = 0; k < P; ++k) w[k][j] = tp[(j*P + k)/8][(j*P + k)%8];
+      }
     }
     float dgam[8], dbet[8], dbia[8], dtap[P][8];
 #pragma unroll
@@ -183,57 +230,70 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
     }
     const long long base = (long long)b*T*p.Cp + c0;
     if (lane_ok) {
-#pragma unroll 2
-      for (int i = 0; i < DW_RPW; ++i) {
-        const int t = tw0 + i;
-        if (t >= T) break;
-        float zc[8], dzc[8], dh[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.z1 + base + (long long)t*p.Cp), zc);
-        unpack8(*reinterpret_cast<const uint4*>(p.dz2 + base + (long long)t*p.Cp), dzc);
+      for (int i0 = 0; i0 < DW_RPW; i0 += 2) {
+        // raw[u][0][k]: dz2 at the output frame fed through tap k; raw[u][1][k]: z1 at
+        // the input frame read through tap k (k*dil == left is the frame itself)
+        uint4 raw[2][2][P];
+        bool okd[2][P], okz[2][P];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { dh[j] = 0.f; dbia[j] += dzc[j]; }
+        for (int u = 0; u < 2; ++u) {
+          const int t = tw0 + i0 + u;
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-          // forward: z2[t'] += w[k] * h1n[t' + k*dil - left]
-          const int shift = k*p.dil - p.left;
-          const int to = t - shift;               // output frame fed by h1n[t] through tap k
-          if (to >= 0 && to < T) {
-            float g[8];
-            if (shift == 0) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) g[j] = dzc[j];
-            } else {
-              unpack8(*reinterpret_cast<const uint4*>(p.dz2 + base + (long long)to*p.Cp), g);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dh[j] += w[k][j]*g[j];
-          }
-          const int ti = t + shift;               // input frame read by output t through tap k
-          if (ti >= 0 && ti < T) {
-            float f[8];
-            if (shift == 0) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) f[j] = zc[j];
-            } else {
-              unpack8(*reinterpret_cast<const uint4*>(p.z1 + base + (long long)ti*p.Cp), f);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              dtap[k][j] += dzc[j]*(prelu(f[j], a1)*sc[j] + sh[j]);
+          for (int k = 0; k < P; ++k) {
+            const int shift = k*p.dil - p.left;    // fwd: z2[t'] += w[k]*h1n[t' + shift]
+            const int to = t - shift, ti = t + shift;
+            okd[u][k] = t < T && to >= 0 && to < T;
+            okz[u][k] = t < T && ti >= 0 && ti < T;
+            const int toc = to < 0 ? 0 : (to >= T ? T - 1 : to);
+            const int tic = ti < 0 ? 0 : (ti >= T ? T - 1 : ti);
+            raw[u][0][k] = *reinterpret_cast<const uint4*>(p.dz2 + base + (long long)toc*p.Cp);
+            raw[u][1][k] = *reinterpret_cast<const uint4*>(p.z1 + base + (long long)tic*p.Cp);
           }
         }
-        float o[8];
-        float l1 = 0.f, l2 = 0.f;
+        uint4 rawc[2][2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xh = (prelu(zc[j], a1) - ns.mean)*ns.rstd;
-          const float ev = gm[j]*dh[j];
-          o[j] = ev;
-          l1 += ev; l2 += ev*xh;
-          dgam[j] += dh[j]*xh; dbet[j] += dh[j];
+        for (int u = 0; u < 2; ++u) {
+          const int t = tw0 + i0 + u;
+          const int tcl = t < T ? t : T - 1;
+          rawc[u][0] = *reinterpret_cast<const uint4*>(p.dz2 + base + (long long)tcl*p.Cp);
+          rawc[u][1] = *reinterpret_cast<const uint4*>(p.z1 + base + (long long)tcl*p.Cp);
         }
-        s1 += l1; s2 += l2;
-        *reinterpret_cast<uint4*>(p.e1 + base + (long long)t*p.Cp) = pack8(o);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = tw0 + i0 + u;
+          const float live = t < T ? 1.f : 0.f;
+          float zc[8], dzc[8], dh[8];
+          unpack8(rawc[u][1], zc);
+          unpack8(rawc[u][0], dzc);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { dzc[j] *= live; dh[j] = 0.f; dbia[j] += dzc[j]; }
+#pragma unroll
+          for (int k = 0; k < P; ++k) {
+            float g[8], f[8];
+            unpack8(raw[u][0][k], g);
+            unpack8(raw[u][1][k], f);
+            const float ond = okd[u][k] ? 1.f : 0.f, onz = okz[u][k] ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              dh[j] += ond*w[k][j]*g[j];
+              dtap[k][j] += onz*dzc[j]*(prelu(f[j], a1)*sc[j] + sh[j]);
+            }
+          }
+          if (t < T) {
+            float o[8];
+            float l1 = 0.f, l2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float xh = (prelu(zc[j], a1) - ns.mean)*ns.rstd;
+              const float ev = gm[j]*dh[j];
+              o[j] = ev;
+              l1 += ev; l2 += ev*xh;
+              dgam[j] += dh[j]*xh; dbet[j] += dh[j];
+            }
+            s1 += l1; s2 += l2;
+            *reinterpret_cast<uint4*>(p.e1 + base + (long long)t*p.Cp) = pack8(o);
+          }
+        }
       }
     }
     // per-channel reductions over the 4 waves, then one atomic per channel and quantity
@@ -242,10 +302,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) red[wid*512 + lane*8 + j] = v[j];
       __syncthreads();
+      float* rdst = dst + (long long)(blockIdx.x % kReplicas)*p.rep_stride;
       for (int cc = tid; cc < 512; cc += 256) {
         const float sum = red[cc] + red[512 + cc] + red[1024 + cc] + red[1536 + cc];
         const int c = cb + cc;
-        if (c < p.C) atomic_add_f32(dst + (long long)c*stride + offset, sum);
+        if (c < p.C) atomic_add_f32(rdst + (long long)c*stride + offset, sum);
       }
     };
     reduce_cols(dgam, p.dgamma1, 1, 0);
@@ -259,6 +320,42 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
   if (tid == 0) {
     atomic_add_f64(p.sums1 + 2*b, r0);
     atomic_add_f64(p.sums1 + 2*b + 1, r1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Vector-gradient block layout (floats): [ln_g N][ln_b N] then per TCN block
+// [n1_g H][n1_b H][n2_g H][n2_b H][dconv_w H*P][dconv_b H].
+struct VgradParams {
+  const float* vg; float* grads; long long rep_stride;
+  int N, H, P, nb;
+  long long ln_g_off;        // flat offset of tcn.layer_norm.weight
+  long long blk0_off;        // flat offset of block 0's conv.weight
+  long long blk_full;        // floats per (non-last) block
+  long long o_dconv_w, o_dconv_b, o_n1_g_full, o_n1_g_last;   // offsets inside a block
+};
+__global__ __launch_bounds__(256) void vgrad_reduce_kernel(const VgradParams p) {
+  const long long per_blk = (long long)p.H*(5 + p.P);
+  const long long total = 2LL*p.N + per_blk*p.nb;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < total;
+       i += (long long)gridDim.x*256) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < kReplicas; ++r) s += p.vg[(long long)r*p.rep_stride + i];
+    long long dst;
+    if (i < 2LL*p.N) {
+      dst = p.ln_g_off + i;                        // ln_g then ln_b are adjacent
+    } else {
+      const long long j = i - 2LL*p.N;
+      const int blk = (int)(j / per_blk);
+      const long long k = j % per_blk;
+      const long long base = p.blk0_off + blk*p.blk_full;
+      const long long n1 = blk == p.nb - 1 ? p.o_n1_g_last : p.o_n1_g_full;
+      if (k < 4LL*p.H) dst = base + n1 + k;         // n1_g n1_b n2_g n2_b adjacent
+      else if (k < 4LL*p.H + (long long)p.H*p.P) dst = base + p.o_dconv_w + (k - 4LL*p.H);
+      else dst = base + p.o_dconv_b + (k - 4LL*p.H - (long long)p.H*p.P);
+    }
+    p.grads[dst] += s;
   }
 }
 
