@@ -1,0 +1,71 @@
+"""Training entry point: ``python scripts/train_model.py models/<id>/ [--overrides]``
+(reference: scripts/train_model.py:21-181). Under ``torchrun`` (one process per GPU)
+pass ``--ddp true``: gradients are all-reduced over RCCL every step."""
+import argparse
+import logging
+import os
+import pprint
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from _common import ROOT, add_override_flags, make_dataset  # noqa: F401
+
+from brever_amd.config import get_config, signature_defaults
+from brever_amd.logger import set_logger
+from brever_amd.models import ModelRegistry
+from brever_amd.training import BreverTrainer
+
+
+def main(args, arg_map):
+    loss_path = os.path.join(args.input, 'losses.npz')
+    if os.path.exists(loss_path) and not args.force:
+        raise FileExistsError(f'training already done: {loss_path}')
+    cfg = get_config(os.path.join(args.input, 'config.yaml'))
+    cfg.update_from_args(args, {d: ('trainer', k) for d, k in arg_map.items()})
+
+    trainer_kwargs = cfg.trainer.to_dict()
+    rank = trainer_kwargs.pop('rank')
+    device = trainer_kwargs.pop('device')
+    if cfg.trainer.ddp:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        dist.init_process_group(backend)        # nccl == RCCL on ROCm
+        rank = dist.get_rank()
+        if torch.cuda.is_available():
+            device = rank % torch.cuda.device_count()
+            torch.cuda.set_device(device)
+
+    set_logger(os.path.join(args.input, 'log_train.log'), cfg.trainer.ddp, rank)
+    if rank == 0:
+        logging.info(f'Training {args.input}')
+        logging.info(f'Configuration: \n {pprint.pformat(cfg.to_dict())}')
+
+    random.seed(cfg.seed)
+    np.random.seed(cfg.seed)
+    torch.manual_seed(cfg.seed)
+
+    model = ModelRegistry.get(cfg.arch)(**cfg.model.to_dict())
+    fs = cfg.dataset.fs
+    train_dataset = make_dataset(cfg.train_path, fs, transform=model.transform, seed=0)
+    val_dataset = make_dataset(cfg.val_path, fs, transform=None, seed=10_000)
+
+    ignore_checkpoint = trainer_kwargs.pop('ignore_checkpoint')
+    trainer = BreverTrainer(
+        model=model, train_dataset=train_dataset, val_dataset=val_dataset,
+        model_dirpath=args.input, device=device, rank=rank,
+        ignore_checkpoint=ignore_checkpoint or args.force, **trainer_kwargs)
+    trainer.run()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser(description='train a model')
+    parser.add_argument('input', help='model directory')
+    parser.add_argument('-f', '--force', action='store_true')
+    defaults = signature_defaults(BreverTrainer.__init__)
+    arg_map = add_override_flags(parser, defaults)
+    main(parser.parse_args(), arg_map)

@@ -1,0 +1,162 @@
+"""Data-parallel path on CPU: 2 processes, gloo backend (RCCL's stand-in), 127.0.0.1.
+
+The reference's DDP never synchronises gradients, so
+parity is defined against a single process on the union batch."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import DummyDataset, DummyModel
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+
+def _make_batch():
+    g = torch.Generator().manual_seed(3)
+    batch = torch.randn(4, 3, 2, 500, generator=g)      # (B, sources, channels, L)
+    lengths = torch.tensor([500, 500, 500, 500])
+    return batch, lengths
+
+
+def _worker_generic(rank, world, port, out_dir):
+    from brever_amd.parallel import GradSynchronizer, broadcast_parameters
+    _init(rank, world, port)
+    torch.manual_seed(100 + rank)                        # different init per rank ...
+    model = DummyModel(channels=2, output_sources=2)
+    broadcast_parameters(model)                          # ... until the broadcast
+    sync = GradSynchronizer(model)
+    assert not sync.flat_model
+    batch, lengths = _make_batch()
+    lo, hi = rank*2, rank*2 + 2
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    for _ in range(3):
+        sync.train_step(model, batch[lo:hi], lengths[lo:hi], False, scaler)
+    torch.save([p.detach().clone() for p in model.parameters()],
+               os.path.join(out_dir, f'params{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_equals_union_batch():
+    world, port = 2, _free_port()
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_generic, args=(world, port, tmp), nprocs=world, join=True)
+        p0 = torch.load(os.path.join(tmp, 'params0.pt'))
+        p1 = torch.load(os.path.join(tmp, 'params1.pt'))
+    # single process, union batch, same initial weights as rank 0
+    torch.manual_seed(100)
+    model = DummyModel(channels=2, output_sources=2)
+    batch, lengths = _make_batch()
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    for _ in range(3):
+        model.train_step(batch, lengths, False, scaler)
+    for a, b, ref in zip(p0, p1, model.parameters()):
+        assert torch.equal(a, b)                         # ranks stay in lock-step
+        assert torch.allclose(a, ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+class _FlatStub(torch.nn.Module):
+    """Mimics the flat-gradient protocol of the HIP Conv-TasNet on CPU."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(7))
+        self._sync = None
+        self.flat = torch.zeros(7)
+
+    def set_grad_sync(self, fn):
+        self._sync = fn
+
+    def flat_params(self):
+        return self.w.data
+
+    def mark_params_changed(self):
+        pass
+
+    def train_step(self, batch, lengths, use_amp, scaler):
+        self.flat.copy_(batch)
+        scale = self._sync(self.flat)
+        return self.flat*scale
+
+
+def _worker_flat(rank, world, port, out_dir):
+    from brever_amd.parallel import GradSynchronizer, broadcast_parameters
+    _init(rank, world, port)
+    model = _FlatStub()
+    with torch.no_grad():
+        model.w.fill_(float(rank + 1))
+    broadcast_parameters(model)
+    assert torch.all(model.w == 1.0)
+    sync = GradSynchronizer(model)
+    assert sync.flat_model
+    mean = sync.train_step(model, torch.full((7,), float(rank)), None, False, None)
+    assert torch.allclose(mean, torch.full((7,), 0.5))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_hook_sums_and_scales():
+    world, port = 2, _free_port()
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_flat, args=(world, port, tmp), nprocs=world, join=True)
+
+
+def _worker_trainer(rank, world, port, out_dir):
+    from brever_amd.training import BreverTrainer
+    _init(rank, world, port)
+    torch.manual_seed(rank)
+    model = DummyModel(channels=2, output_sources=2)
+    FS = 16000
+    train = DummyDataset(16, 3, 2, FS//2, FS*2, transform=model.transform)
+    val = DummyDataset(4, 3, 2, FS//2, FS*2)
+    trainer = BreverTrainer(
+        model=model, train_dataset=train, val_dataset=val,
+        model_dirpath=os.path.join(out_dir, 'model'), epochs=2, val_period=1,
+        val_metrics=set(), batch_sampler='bucket', batch_size=4.0,
+        dynamic_batch_size=True, device='cpu', preload=True, ddp=True, rank=rank)
+    trainer.run()
+    torch.save([p.detach().clone() for p in model.parameters()],
+               os.path.join(out_dir, f'params{rank}.pt'))
+    if rank == 0:
+        assert len(trainer.loss_logger.train_loss) == 2
+        assert os.path.exists(os.path.join(out_dir, 'model', 'checkpoints', 'last.ckpt'))
+    dist.destroy_process_group()
+
+
+def test_trainer_two_ranks():
+    world, port = 2, _free_port()
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_trainer, args=(world, port, tmp), nprocs=world, join=True)
+        p0 = torch.load(os.path.join(tmp, 'params0.pt'))
+        p1 = torch.load(os.path.join(tmp, 'params1.pt'))
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)          # broadcast + synchronised gradients
+
+
+def test_distributed_sampler_partitions_batches():
+    from brever_amd.batching import BucketBatchSampler, DistributedBatchSamplerWrapper
+    dset = DummyDataset(40, 1, 1, 1000, 8000)
+    seen = []
+    for rank in range(2):
+        sampler = BucketBatchSampler(dset, 1.0, dynamic=True)
+        wrapper = DistributedBatchSamplerWrapper(sampler, num_replicas=2, rank=rank)
+        wrapper.set_epoch(1)
+        got = list(wrapper)
+        assert len(got) == len(wrapper)
+        seen.append(got)
+    union = sorted(i for part in seen for b in part for i in b)
+    assert set(union) == set(range(40))
+    assert len(seen[0]) == len(seen[1])   # equal step counts (padding by repetition)

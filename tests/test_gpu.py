@@ -297,3 +297,33 @@ def test_full_size_step_properties():
     assert torch.isfinite(net.flat_params()).all()
     assert not torch.equal(before, net.flat_params())
     assert float(net.optimizer.last_grad_norm) > 0
+
+
+def test_entry_points_train_and_test(tmp_path):
+    """scripts/init_model.py -> train_model.py -> test_model.py on synthetic data."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
+                                    text=True, cwd=root)
+    out = run('scripts/init_model.py', 'convtasnet', '--models-dir', str(tmp_path),
+              '--filters', '64', '--bottleneck_channels', '32', '--hidden_channels', '64',
+              '--skip_channels', '32', '--layers', '2', '--repeats', '2',
+              '--trainer_epochs', '2', '--trainer_val_period', '1',
+              '--trainer_batch_size', '8', '--trainer_preload', 'true',
+              '--trainer_workers', '0',
+              '--train-path', 'synthetic:16:1.0:0.5', '--val-path', 'synthetic:4:1.0')
+    assert out.returncode == 0, out.stderr
+    model_dir = os.path.join(str(tmp_path), os.listdir(tmp_path)[0])
+    out = run('scripts/train_model.py', model_dir)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert os.path.exists(os.path.join(model_dir, 'losses.npz'))
+    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    assert losses['train_loss'].shape == (2, 2) and np.isfinite(losses['train_loss']).all()
+    assert 'metrics_snr' in losses
+    out = run('scripts/train_model.py', model_dir)
+    assert out.returncode != 0 and 'training already done' in out.stderr
+    out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:6:1.0')
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    scores = np.load(os.path.join(model_dir, 'scores.npz'))
+    assert scores['scores'].shape == (6, 2, 2) and np.isfinite(scores['scores']).all()
