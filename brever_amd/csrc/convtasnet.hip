@@ -5,6 +5,7 @@
 // sequence and the saved-activation plan are described in DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -12,6 +13,7 @@
 #include "../../include/brever_hip.h"
 #include "gemm_rows.cuh"
 #include "gemm_wgrad.cuh"
+#include "gemm_ws.cuh"
 #include "prep.cuh"
 #include "tcn_kernels.cuh"
 
@@ -151,8 +153,10 @@ struct Workspace {
     sums = take(stats_bytes);
     dpre = take(BT*l.S*l.Np*2);
     dw1 = take(BT*l.S*l.Np*2);
-    gskip = take(BT*l.Scp*2);
-    gout = take(BT*l.Bnp*2);
+    // [g_out | g_skip] side by side (row stride Bnp + Scp): the concatenated operand of
+    // the [res | skip] data/weight gradients is then ONE plain tensor
+    gout = take(BT*(l.Bnp + l.Scp)*2);
+    gskip = gout + (long long)l.Bnp*2;
     eA = take(BT*l.Hp*2);
     eB = take(BT*l.Hp*2);
     e0 = take(BT*l.Np*2);
@@ -175,11 +179,54 @@ int launch_gemm_rows_t(const GemmRowsParams& p0, int batch, hipStream_t st) {
   return 0;
 }
 
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n <= 0)
+      n = 256;
+  }
+  return n;
+}
+
+// Persistent weight-stationary fast path (gemm_ws.cuh) for the hot TCN shapes.
+template <int KP, int NSL, int WM, int EM, int AT, bool CAT, int NW = 8>
+int launch_gemm_ws(const GemmRowsParams& p0, int batch, hipStream_t st) {
+  using C = GemmWsCfg<KP, NSL, WM, NW>;
+  GemmRowsParams p = p0;
+  p.batch = batch;
+  if (!CAT && p.a.K0 <= 0) {          // everything comes from the second source
+    p.a.p0 = p.a.p1; p.a.ld0 = p.a.ld1; p.a.bs0 = p.a.bs1; p.a.K0 = 1 << 30;
+  }
+  const int total = ceil_div(p.T, C::BMW)*batch;
+  const int groups = p.Np / C::NP;             // column groups (blockIdx.y)
+  int grid = num_cus()/groups;
+  if (grid > total) grid = total;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((gemm_ws_kernel<KP, NSL, WM, EM, AT, CAT, NW>), dim3(grid, groups),
+                     dim3(64*NW), 0, st, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 template <int AK, int EM>
 int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st,
                      const char* label = "gemm_rows", double bytes = 0) {
   if (p.T <= 0 || batch <= 0) return 0;
   ProfScope prof(label, 2.0*batch*p.T*(double)p.Np*p.Kp, bytes, st);
+  if (AK == A_BF16 && p.a.nsrc <= 1 && !getenv("BRV_NO_WS")) {
+    const bool plain = p.a.slope == nullptr && p.a.stats == nullptr;
+    const bool full = p.a.slope != nullptr && p.a.stats != nullptr;
+    const bool one_src = p.a.K0 >= p.Kp || p.a.K0 <= 0;
+    if ((EM == E_STORE || EM == E_GLN_BWD) && p.Kp == 128 && p.Np == 512 && plain && one_src)
+      return launch_gemm_ws<128, 64, 1, (EM == E_STORE ? E_STORE : E_GLN_BWD), 0, false>(p, batch, st);
+    if (EM == E_RES_SKIP && p.Kp == 512 && p.Np == 256 && full && one_src)
+      return launch_gemm_ws<512, 32, 1, E_RES_SKIP, 1, false>(p, batch, st);
+    if (EM == E_GLN_BWD && p.Kp == 256 && p.Np == 512 && plain && one_src)
+      return launch_gemm_ws<256, 32, 1, E_GLN_BWD, 0, false>(p, batch, st);
+  }
   if (p.Kp % GR_BK != 0 || p.Np % 64 != 0) return fail(-1, "gemm_rows: unpadded dims");
   if (p.Np % 128 == 0) return launch_gemm_rows_t<128, AK, EM>(p, batch, st);
   return launch_gemm_rows_t<64, AK, EM>(p, batch, st);
@@ -525,6 +572,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   bf16_t* dw1 = (bf16_t*)(base + ws.dw1);
   bf16_t* gskip = (bf16_t*)(base + ws.gskip);
   bf16_t* gout = (bf16_t*)(base + ws.gout);
+  const int ldg = l.Bnp + l.Scp;           // row stride of [g_out | g_skip]
   bf16_t* eA = (bf16_t*)(base + ws.eA);
   bf16_t* eB = (bf16_t*)(base + ws.eB);
   bf16_t* e0 = (bf16_t*)(base + ws.e0);
@@ -555,7 +603,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   memset(&g, 0, sizeof(g));
   g.a = rows_bf16(dpre, l.Np, T); g.a.nsrc = l.S;
   g.W = prep + l.p_out_b; g.T = (int)T; g.Np = l.Scp; g.Kp = l.S*l.Np;
-  g.e.out = gskip; g.e.ldo = l.Scp; g.e.src_f32 = skip; g.e.ld_srcf = l.Scp;
+  g.e.out = gskip; g.e.ldo = ldg; g.e.src_f32 = skip; g.e.ld_srcf = l.Scp;
   g.e.src_slope = params + l.tcn_prelu; g.e.dslope = grads + l.tcn_prelu;
   if (int r = launch_gemm_rows<A_BF16, E_PRELU_BWD>(g, B, st, "mask_bwd", 2.0*BT*l.S*l.Np + 6.0*BT*l.Scp)) return r;
   // output conv weight / bias gradients, one source at a time
@@ -576,8 +624,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     const int rs0 = has_res ? l.Bnp : 0;
     // [res | skip] data gradient + gLN_2 backward partials
     memset(&g, 0, sizeof(g));
-    g.a = rows_bf16(gout, l.Bnp, T); g.a.K0 = rs0;
-    g.a.p1 = gskip; g.a.ld1 = l.Scp; g.a.bs1 = T*l.Scp;
+    g.a = rows_bf16(has_res ? gout : gskip, ldg, T);
     g.W = prep + b.p_rs_b; g.T = (int)T; g.Np = l.Hp; g.Kp = rs0 + l.Scp;
     g.e.out = eA; g.e.ldo = l.Hp; g.e.N = l.H;
     g.e.src = z2buf(i); g.e.ld_src = l.Hp; g.e.src_slope = params + b.prelu2;
@@ -589,8 +636,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + 2*l.Hp))) return r;
     // [res | skip] weight / bias gradients against gLN_2(prelu_2(z2))
     memset(&wg, 0, sizeof(wg));
-    wg.g = rows_bf16(gout, l.Bnp, T); wg.g.K0 = rs0;
-    wg.g.p1 = gskip; wg.g.ld1 = l.Scp; wg.g.bs1 = T*l.Scp;
+    wg.g = rows_bf16(has_res ? gout : gskip, ldg, T);
     wg.h = rows_bf16(z2buf(i), l.Hp, T); wg.h.slope = params + b.prelu2;
     set_affine(wg.h, stat(2 + 2*i), params + b.n2_g, params + b.n2_b, l.H, T);
     wg.B = B; wg.T = (int)T; wg.Gp = rs0 + l.Scp; wg.Hp = l.Hp;
@@ -632,12 +678,12 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     memset(&g, 0, sizeof(g));
     g.a = rows_bf16(eB, l.Hp, T);
     g.W = prep + b.p_c1_b; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Hp;
-    g.e.out = gout; g.e.ldo = l.Bnp; g.e.add_in = has_res ? gout : nullptr; g.e.ld_add = l.Bnp;
+    g.e.out = gout; g.e.ldo = ldg; g.e.add_in = has_res ? gout : nullptr; g.e.ld_add = ldg;
     if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
   }
   // bottleneck conv: data gradient + first gLN backward partials
   memset(&g, 0, sizeof(g));
-  g.a = rows_bf16(gout, l.Bnp, T);
+  g.a = rows_bf16(gout, ldg, T);
   g.W = prep + l.p_bott_b; g.T = (int)T; g.Np = l.Np; g.Kp = l.Bnp;
   g.e.out = e0; g.e.ldo = l.Np; g.e.N = l.N;
   g.e.src = w; g.e.ld_src = l.Np; g.e.src_stats = stat(0);
@@ -648,7 +694,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "bottleneck_dgrad", 2.0*BT*(l.Bnp + 2*l.Np))) return r;
   // bottleneck conv: weight / bias gradients against gLN(w)
   memset(&wg, 0, sizeof(wg));
-  wg.g = rows_bf16(gout, l.Bnp, T); wg.h = rows_bf16(w, l.Np, T);
+  wg.g = rows_bf16(gout, ldg, T); wg.h = rows_bf16(w, l.Np, T);
   set_affine(wg.h, stat(0), params + l.ln_g, params + l.ln_b, l.N, T);
   wg.B = B; wg.T = (int)T; wg.Gp = l.Bnp; wg.Hp = l.Np;
   wg.out0 = grads + l.bott_w; wg.G0p = l.Bnp; wg.N0 = l.Bn; wg.Kout = l.N; wg.ldo = l.N;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void dz_kernel(const DzParams p) {
   const float m2 = (float)(p.sums[2*b + 1]*p.inv_n);
   const float a = *p.slope;
   float da = 0.f;
-#pragma unroll 4
+#pragma unroll 1
   for (long long i = (long long)blockIdx.x*256 + tid; i < per_item;
        i += (long long)gridDim.x*256) {
     const int c0 = (int)(i % cpr)*8;
