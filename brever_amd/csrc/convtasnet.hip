@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -131,7 +132,8 @@ struct Layout {
 
 struct Workspace {
   long long w, x, z1, z2, skip, m, y, stats, sums, dpre, dw1, gskip, gout, eA, eB,
-      e0, dwt, vg, total;
+      e0, dwt, vg, gcopy, total;
+  long long gcopy_stride, eB_stride;
   long long vg_stride, vg_bytes;      // replicated vector-gradient block (floats / bytes)
   long long x_stride, z_stride;       // bytes between consecutive blocks' buffers
   long long stats_bytes;
@@ -158,7 +160,11 @@ struct Workspace {
     gout = take(BT*(l.Bnp + l.Scp)*2);
     gskip = gout + (long long)l.Bnp*2;
     eA = take(BT*l.Hp*2);
-    eB = take(BT*l.Hp*2);
+    // kept per block until the grouped weight-gradient launches at the end of backward
+    eB_stride = align_up(BT*l.Hp*2, 256);
+    eB = take(eB_stride*l.nb);
+    gcopy_stride = align_up(BT*l.Bnp*2, 256);
+    gcopy = take(gcopy_stride*l.nb);
     e0 = take(BT*l.Np*2);
     dwt = take(BT*l.Np*2);
     vg_stride = align_up(2LL*l.N + (long long)l.nb*l.H*(5 + l.P), 64);
@@ -202,7 +208,9 @@ int launch_gemm_ws(const GemmRowsParams& p0, int batch, hipStream_t st) {
   }
   const int total = ceil_div(p.T, C::BMW)*batch;
   const int groups = p.Np / C::NP;             // column groups (blockIdx.y)
-  int grid = num_cus()/groups;
+  // 8-wave workgroups fill a CU alone; 4-wave ones are sized so that 2-3 of them share
+  // a CU and progress independently between their own barriers
+  int grid = (NW == 8 ? num_cus() : 2*num_cus())/groups;
   if (grid > total) grid = total;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((gemm_ws_kernel<KP, NSL, WM, EM, AT, CAT, NW>), dim3(grid, groups),
@@ -221,11 +229,11 @@ int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st,
     const bool full = p.a.slope != nullptr && p.a.stats != nullptr;
     const bool one_src = p.a.K0 >= p.Kp || p.a.K0 <= 0;
     if ((EM == E_STORE || EM == E_GLN_BWD) && p.Kp == 128 && p.Np == 512 && plain && one_src)
-      return launch_gemm_ws<128, 64, 1, (EM == E_STORE ? E_STORE : E_GLN_BWD), 0, false>(p, batch, st);
+      return launch_gemm_ws<128, 64, 1, (EM == E_STORE ? E_STORE : E_GLN_BWD), 0, false, 4>(p, batch, st);
     if (EM == E_RES_SKIP && p.Kp == 512 && p.Np == 256 && full && one_src)
       return launch_gemm_ws<512, 32, 1, E_RES_SKIP, 1, false>(p, batch, st);
     if (EM == E_GLN_BWD && p.Kp == 256 && p.Np == 512 && plain && one_src)
-      return launch_gemm_ws<256, 32, 1, E_GLN_BWD, 0, false>(p, batch, st);
+      return launch_gemm_ws<256, 32, 1, E_GLN_BWD, 0, false, 4>(p, batch, st);
   }
   if (p.Kp % GR_BK != 0 || p.Np % 64 != 0) return fail(-1, "gemm_rows: unpadded dims");
   if (p.Np % 128 == 0) return launch_gemm_rows_t<128, AK, EM>(p, batch, st);
@@ -233,26 +241,39 @@ int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st,
 }
 
 template <int BH, int HK>
-int launch_wgrad_t(WgradParams& p, hipStream_t st) {
+int launch_wgrad_t(WgradGroupParams& gp, hipStream_t st) {
+  WgradParams& p = gp.base;
+  const int nprob = gp.nprob > 0 ? gp.nprob : 1;
   const int tiles = ceil_div(p.Gp, WG_BG)*(p.Hp/BH);
   const int total = p.B*ceil_div(p.T, WG_BT);
-  int ns = ceil_div(320, tiles);
+  int ns = ceil_div(384, tiles*nprob);
   if (ns > total) ns = total;
   if (ns < 1) ns = 1;
   p.nsplit = ns;
-  dim3 grid(tiles, ns);
-  hipLaunchKernelGGL((gemm_wgrad_kernel<BH, HK>), grid, dim3(256), 0, st, p);
+  dim3 grid(tiles, ns, nprob);
+  hipLaunchKernelGGL((gemm_wgrad_kernel<BH, HK>), grid, dim3(256), 0, st, gp);
   HIP_OK(hipGetLastError());
   return 0;
+}
+// `gp.base` carries the shared dimensions / strides; `gp.prob[0..nprob)` the tensors
+// (nprob == 0: a single problem described entirely by `gp.base`).
+template <int HK>
+int launch_wgrad_group(WgradGroupParams& gp, hipStream_t st, const char* label,
+                       double bytes) {
+  const WgradParams& p = gp.base;
+  if (p.T <= 0 || p.B <= 0) return 0;
+  const int nprob = gp.nprob > 0 ? gp.nprob : 1;
+  ProfScope prof(label, 2.0*nprob*p.B*p.T*(double)p.Gp*p.Hp, bytes*nprob, st);
+  if (p.Hp % 64 != 0) return fail(-1, "wgrad: unpadded dims");
+  if (p.Hp % 128 == 0) return launch_wgrad_t<128, HK>(gp, st);
+  return launch_wgrad_t<64, HK>(gp, st);
 }
 template <int HK>
 int launch_wgrad(WgradParams& p, hipStream_t st, const char* label = "wgrad",
                  double bytes = 0) {
-  if (p.T <= 0 || p.B <= 0) return 0;
-  ProfScope prof(label, 2.0*p.B*p.T*(double)p.Gp*p.Hp, bytes, st);
-  if (p.Hp % 64 != 0) return fail(-1, "wgrad: unpadded dims");
-  if (p.Hp % 128 == 0) return launch_wgrad_t<128, HK>(p, st);
-  return launch_wgrad_t<64, HK>(p, st);
+  WgradGroupParams gp;
+  gp.base = p; gp.nprob = 0;
+  return launch_wgrad_group<HK>(gp, st, label, bytes);
 }
 
 template <template <int> class F, typename... Args>
@@ -574,7 +595,8 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   bf16_t* gout = (bf16_t*)(base + ws.gout);
   const int ldg = l.Bnp + l.Scp;           // row stride of [g_out | g_skip]
   bf16_t* eA = (bf16_t*)(base + ws.eA);
-  bf16_t* eB = (bf16_t*)(base + ws.eB);
+  auto eBbuf = [&](int i) { return (bf16_t*)(base + ws.eB + ws.eB_stride*i); };
+  auto gcopy = [&](int i) { return (bf16_t*)(base + ws.gcopy + ws.gcopy_stride*i); };
   bf16_t* e0 = (bf16_t*)(base + ws.e0);
   bf16_t* dwt = (bf16_t*)(base + ws.dwt);
   const int BS = B*l.S;
@@ -634,16 +656,6 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
     g.e.sums_out = sum(2 + 2*i);
     if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + 2*l.Hp))) return r;
-    // [res | skip] weight / bias gradients against gLN_2(prelu_2(z2))
-    memset(&wg, 0, sizeof(wg));
-    wg.g = rows_bf16(has_res ? gout : gskip, ldg, T);
-    wg.h = rows_bf16(z2buf(i), l.Hp, T); wg.h.slope = params + b.prelu2;
-    set_affine(wg.h, stat(2 + 2*i), params + b.n2_g, params + b.n2_b, l.H, T);
-    wg.B = B; wg.T = (int)T; wg.Gp = rs0 + l.Scp; wg.Hp = l.Hp;
-    wg.out0 = has_res ? grads + b.res_w : nullptr; wg.out1 = grads + b.skip_w;
-    wg.G0p = rs0; wg.N0 = has_res ? l.Bn : 0; wg.N1 = l.Sc; wg.Kout = l.H; wg.ldo = l.H;
-    wg.gbias0 = has_res ? grads + b.res_b : nullptr; wg.gbias1 = grads + b.skip_b;
-    if (int r = launch_wgrad<A_BF16>(wg, st, "pw2_wgrad", 2.0*BT*(rs0 + l.Scp + l.Hp))) return r;
     // gLN_2 + prelu_2 backward -> dz2 (in place)
     DzParams dz; memset(&dz, 0, sizeof(dz));
     dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
@@ -652,6 +664,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     if (int r = launch_dz(dz, st)) return r;
     // depthwise conv backward (data, taps, bias) + gLN_1 partials
     DwParams d; memset(&d, 0, sizeof(d));
+    bf16_t* eB = eBbuf(i);
     d.z1 = z1buf(i); d.dz2 = eA; d.e1 = eB; d.B = B; d.T = (int)T; d.Cp = l.Hp; d.C = l.H;
     d.slope1 = params + b.prelu1; d.stats1 = stat(1 + 2*i);
     d.gamma1 = params + b.n1_g; d.beta1 = params + b.n1_b;
@@ -667,19 +680,70 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     dz.slope = params + b.prelu1; dz.stats = stat(1 + 2*i); dz.sums = sum(1 + 2*i);
     dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = grads + b.prelu1;
     if (int r = launch_dz(dz, st)) return r;
-    // first 1x1 conv: weight / bias gradients
-    memset(&wg, 0, sizeof(wg));
-    wg.g = rows_bf16(eB, l.Hp, T); wg.h = rows_bf16(xbuf(i), l.Bnp, T);
-    wg.B = B; wg.T = (int)T; wg.Gp = l.Hp; wg.Hp = l.Bnp;
-    wg.out0 = grads + b.conv_w; wg.G0p = l.Hp; wg.N0 = l.H; wg.Kout = l.Bn; wg.ldo = l.Bn;
-    wg.gbias0 = grads + b.conv_b;
-    if (int r = launch_wgrad<A_BF16>(wg, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp))) return r;
     // first 1x1 conv: data gradient + residual path -> gradient wrt block input
     memset(&g, 0, sizeof(g));
     g.a = rows_bf16(eB, l.Hp, T);
     g.W = prep + b.p_c1_b; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Hp;
     g.e.out = gout; g.e.ldo = ldg; g.e.add_in = has_res ? gout : nullptr; g.e.ld_add = ldg;
+    // block i-1's deferred [res | skip] weight gradient needs this g_out after gout is
+    // overwritten again: keep a copy (16 MB per block at the BASELINE size)
+    g.e.out2 = i > 0 ? gcopy(i - 1) : nullptr; g.e.ld_srcf = l.Bnp;
     if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
+  }
+  // deferred weight gradients of all blocks: two grouped launches
+  for (int i0 = 0; i0 < l.nb; i0 += kWgMaxProb) {
+    const int n = std::min(kWgMaxProb, l.nb - i0);
+    // [res | skip]: G = [g_out_i | g_skip], H = gLN_2(prelu_2(z2_i)); the last block has
+    // no residual conv, so it goes in a launch of its own (different G width)
+    WgradGroupParams gp; memset(&gp, 0, sizeof(gp));
+    WgradParams& q = gp.base;
+    q.g = rows_bf16(nullptr, l.Bnp, T); q.g.K0 = l.Bnp;
+    q.g.ld1 = ldg; q.g.bs1 = T*ldg;
+    q.h = rows_bf16(nullptr, l.Hp, T);
+    set_affine(q.h, nullptr, nullptr, nullptr, l.H, T);
+    q.B = B; q.T = (int)T; q.Gp = l.Bnp + l.Scp; q.Hp = l.Hp;
+    q.G0p = l.Bnp; q.N0 = l.Bn; q.N1 = l.Sc; q.Kout = l.H; q.ldo = l.H;
+    int np = 0;
+    for (int i = i0; i < i0 + n; ++i) {
+      if (i == l.nb - 1) continue;
+      const BlockOff& b = l.blk[i];
+      WgradProb& pr = gp.prob[np++];
+      pr.g0 = gcopy(i); pr.g1 = gskip; pr.h = z2buf(i);
+      pr.out0 = grads + b.res_w; pr.out1 = grads + b.skip_w;
+      pr.gbias0 = grads + b.res_b; pr.gbias1 = grads + b.skip_b;
+      pr.slope = params + b.prelu2; pr.stats = stat(2 + 2*i);
+      pr.gamma = params + b.n2_g; pr.beta = params + b.n2_b;
+    }
+    gp.nprob = np;
+    if (np > 0)
+      if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw2_wgrad",
+                                             2.0*BT*(l.Bnp + l.Scp + l.Hp))) return r;
+    if (i0 + n == l.nb) {             // last block: skip conv only
+      const BlockOff& b = l.blk[l.nb - 1];
+      memset(&wg, 0, sizeof(wg));
+      wg.g = rows_bf16(gskip, ldg, T);
+      wg.h = rows_bf16(z2buf(l.nb - 1), l.Hp, T); wg.h.slope = params + b.prelu2;
+      set_affine(wg.h, stat(2 + 2*(l.nb - 1)), params + b.n2_g, params + b.n2_b, l.H, T);
+      wg.B = B; wg.T = (int)T; wg.Gp = l.Scp; wg.Hp = l.Hp;
+      wg.out1 = grads + b.skip_w; wg.G0p = 0; wg.N0 = 0; wg.N1 = l.Sc;
+      wg.Kout = l.H; wg.ldo = l.H; wg.gbias1 = grads + b.skip_b;
+      if (int r = launch_wgrad<A_BF16>(wg, st, "pw2_wgrad", 2.0*BT*(l.Scp + l.Hp))) return r;
+    }
+    // first 1x1 conv: G = dz1_i, H = x_i
+    memset(&gp, 0, sizeof(gp));
+    WgradParams& q1 = gp.base;
+    q1.g = rows_bf16(nullptr, l.Hp, T); q1.h = rows_bf16(nullptr, l.Bnp, T);
+    q1.B = B; q1.T = (int)T; q1.Gp = l.Hp; q1.Hp = l.Bnp;
+    q1.G0p = l.Hp; q1.N0 = l.H; q1.Kout = l.Bn; q1.ldo = l.Bn;
+    for (int i = i0; i < i0 + n; ++i) {
+      const BlockOff& b = l.blk[i];
+      WgradProb& pr = gp.prob[i - i0];
+      pr.g0 = eBbuf(i); pr.h = xbuf(i);
+      pr.out0 = grads + b.conv_w; pr.gbias0 = grads + b.conv_b;
+    }
+    gp.nprob = n;
+    if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp)))
+      return r;
   }
   // bottleneck conv: data gradient + first gLN backward partials
   memset(&g, 0, sizeof(g));

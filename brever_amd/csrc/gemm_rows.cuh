@@ -397,7 +397,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
       }
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.out) + rowi*e.ldo + ncol) = pack8(v);
+      const uint4 qa = pack8(v);
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.out) + rowi*e.ldo + ncol) = qa;
+      if (e.out2) *reinterpret_cast<uint4*>(e.out2 + rowi*e.ld_srcf + ncol) = qa;   // copy
     } else if (EM == E_MASK_BWD) {
       // batch index of this GEMM is bs = b_item*S + s
       const long long wrow = (long long)(b / e.S)*T + t;

@@ -231,23 +231,22 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
     const long long base = (long long)b*T*p.Cp + c0;
     if (lane_ok) {
       for (int i0 = 0; i0 < DW_RPW; i0 += 2) {
-        // raw[u][0][k]: dz2 at the output frame fed through tap k; raw[u][1][k]: z1 at
-        // the input frame read through tap k (k*dil == left is the frame itself)
-        uint4 raw[2][2][P];
-        bool okd[2][P], okz[2][P];
+        // raw[u][k]: dz2 at the output frame that reads frame t through tap k
+        // (forward: z2[t'] += w[k]*h1n[t' + k*dil - left], so t' = t - k*dil + left).
+        // The same values serve the data gradient (sum_k w[k]*dz2[t']) and, paired with
+        // h1n at frame t itself, the tap gradient: sum_t' dz2[t']*h1n[t'+shift] re-indexed
+        // over t = t'+shift. No shifted read of z1 is needed.
+        uint4 raw[2][P];
+        bool okd[2][P];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int t = tw0 + i0 + u;
 #pragma unroll
           for (int k = 0; k < P; ++k) {
-            const int shift = k*p.dil - p.left;    // fwd: z2[t'] += w[k]*h1n[t' + shift]
-            const int to = t - shift, ti = t + shift;
+            const int to = t - (k*p.dil - p.left);
             okd[u][k] = t < T && to >= 0 && to < T;
-            okz[u][k] = t < T && ti >= 0 && ti < T;
             const int toc = to < 0 ? 0 : (to >= T ? T - 1 : to);
-            const int tic = ti < 0 ? 0 : (ti >= T ? T - 1 : ti);
-            raw[u][0][k] = *reinterpret_cast<const uint4*>(p.dz2 + base + (long long)toc*p.Cp);
-            raw[u][1][k] = *reinterpret_cast<const uint4*>(p.z1 + base + (long long)tic*p.Cp);
+            raw[u][k] = *reinterpret_cast<const uint4*>(p.dz2 + base + (long long)toc*p.Cp);
           }
         }
         uint4 rawc[2][2];
@@ -262,21 +261,26 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
         for (int u = 0; u < 2; ++u) {
           const int t = tw0 + i0 + u;
           const float live = t < T ? 1.f : 0.f;
-          float zc[8], dzc[8], dh[8];
+          float zc[8], dzc[8], dh[8], hp[8], hn[8];
           unpack8(rawc[u][1], zc);
           unpack8(rawc[u][0], dzc);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { dzc[j] *= live; dh[j] = 0.f; dbia[j] += dzc[j]; }
+          for (int j = 0; j < 8; ++j) {
+            dbia[j] += live*dzc[j];
+            dh[j] = 0.f;
+            hp[j] = prelu(zc[j], a1);              // prelu_1 output at frame t
+            hn[j] = live*(hp[j]*sc[j] + sh[j]);    // gLN_1 output at frame t
+          }
 #pragma unroll
           for (int k = 0; k < P; ++k) {
-            float g[8], f[8];
-            unpack8(raw[u][0][k], g);
-            unpack8(raw[u][1][k], f);
-            const float ond = okd[u][k] ? 1.f : 0.f, onz = okz[u][k] ? 1.f : 0.f;
+            float g[8];
+            unpack8(raw[u][k], g);
+            const float ond = okd[u][k] ? 1.f : 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              dh[j] += ond*w[k][j]*g[j];
-              dtap[k][j] += onz*dzc[j]*(prelu(f[j], a1)*sc[j] + sh[j]);
+              const float gk = ond*g[j];
+              dh[j] += w[k][j]*gk;
+              dtap[k][j] += gk*hn[j];
             }
           }
           if (t < T) {
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
             float l1 = 0.f, l2 = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float xh = (prelu(zc[j], a1) - ns.mean)*ns.rstd;
+              const float xh = (hp[j] - ns.mean)*ns.rstd;
               const float ev = gm[j]*dh[j];
               o[j] = ev;
               l1 += ev; l2 += ev*xh;
