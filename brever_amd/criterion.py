@@ -72,26 +72,73 @@ class _SnrFunction(torch.autograd.Function):
         return dx.view(ctx.shape).to(ctx.in_dtype), None, None
 
 
+class _SisnrFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, lengths):
+        x2, y2, lengths, B, S, L = _rows(x, y, lengths)
+        if S > 4:
+            raise ValueError('sisnr supports at most 4 sources on the HIP path')
+        scratch = _scratch(B, S, x.device)
+        loss = torch.empty(B, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_sisnr_forward(
+            hip.ptr(x2), hip.ptr(y2), hip.ptr(lengths), B, S, L, L,
+            hip.ptr(scratch), hip.ptr(loss), hip.stream()), 'brv_sisnr_forward')
+        ctx.save_for_backward(x2, y2, lengths, scratch)
+        ctx.shape = x.shape
+        ctx.in_dtype = x.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        x2, y2, lengths, scratch = ctx.saved_tensors
+        B, S, L = x2.shape
+        dx = torch.empty_like(x2)
+        g = grad.float().contiguous()
+        hip.check(hip.lib().brv_sisnr_backward(
+            hip.ptr(x2), hip.ptr(y2), hip.ptr(lengths), B, S, L, L,
+            hip.ptr(scratch), hip.ptr(g), hip.ptr(dx), hip.stream()),
+            'brv_sisnr_backward')
+        return dx.view(ctx.shape).to(ctx.in_dtype), None, None
+
+
+class _MseFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, lengths, weight):
+        x2, y2, lengths, B, S, L = _rows(x, y, lengths)
+        scratch = _scratch(B, S, x.device)
+        loss = torch.empty(B, dtype=torch.float32, device=x.device)
+        w = None
+        if weight is not None:
+            hip.require_device(weight)
+            w = weight.float().contiguous()
+        hip.check(hip.lib().brv_mse_forward(
+            hip.ptr(x2), hip.ptr(y2), hip.ptr(lengths), hip.ptr(w), B, S, L, L,
+            hip.ptr(scratch), hip.ptr(loss), hip.stream()), 'brv_mse_forward')
+        ctx.save_for_backward(x2, y2, lengths)
+        ctx.weight = w
+        ctx.shape = x.shape
+        ctx.in_dtype = x.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        x2, y2, lengths = ctx.saved_tensors
+        B, S, L = x2.shape
+        dx = torch.empty_like(x2)
+        g = grad.float().contiguous()
+        hip.check(hip.lib().brv_mse_backward(
+            hip.ptr(x2), hip.ptr(y2), hip.ptr(lengths), hip.ptr(ctx.weight), B, S,
+            L, L, hip.ptr(g), hip.ptr(dx), hip.stream()), 'brv_mse_backward')
+        return dx.view(ctx.shape).to(ctx.in_dtype), None, None, None
+
+
 @CriterionRegistry.register('sisnr')
 def sisnr(x, y, lengths):
     """PIT scale-invariant SNR, ``(B, S, L)`` -> ``(B,)``
-    (brever/criterion.py:21-72). Forward only for now (it is the evaluation
-    metric of the path); training with it raises."""
+    (brever/criterion.py:21-72); at most 4 sources on the HIP path."""
     assert x.shape == y.shape
     assert x.ndim == 3
-    if torch.is_grad_enabled() and x.requires_grad:
-        raise NotImplementedError(
-            'sisnr backward is not built yet on the HIP path'
-        )
-    x2, y2, lengths, B, S, L = _rows(x, y, lengths)
-    if S > 4:
-        raise ValueError('sisnr supports at most 4 sources on the HIP path')
-    scratch = _scratch(B, S, x.device)
-    loss = torch.empty(B, dtype=torch.float32, device=x.device)
-    hip.check(hip.lib().brv_sisnr_forward(
-        hip.ptr(x2), hip.ptr(y2), hip.ptr(lengths), B, S, L, L,
-        hip.ptr(scratch), hip.ptr(loss), hip.stream()), 'brv_sisnr_forward')
-    return loss
+    return _SisnrFunction.apply(x, y, lengths)
 
 
 @CriterionRegistry.register('snr')
@@ -105,21 +152,9 @@ def snr(x, y, lengths):
 @CriterionRegistry.register('mse')
 def mse(x, y, lengths, weight=None):
     """Masked mean squared error, ``(B, ..., L)`` -> ``(B,)``
-    (brever/criterion.py:104-132); real inputs, forward only for now."""
+    (brever/criterion.py:104-132); real inputs (complex spectrograms: not built)."""
     assert x.shape == y.shape
     assert x.ndim >= 2
     if x.is_complex() or y.is_complex():
         raise NotImplementedError('complex mse is not built yet on the HIP path')
-    if torch.is_grad_enabled() and x.requires_grad:
-        raise NotImplementedError('mse backward is not built yet on the HIP path')
-    x2, y2, lengths, B, S, L = _rows(x, y, lengths)
-    scratch = _scratch(B, S, x.device)
-    loss = torch.empty(B, dtype=torch.float32, device=x.device)
-    w = None
-    if weight is not None:
-        hip.require_device(weight)
-        w = weight.float().contiguous()
-    hip.check(hip.lib().brv_mse_forward(
-        hip.ptr(x2), hip.ptr(y2), hip.ptr(lengths), hip.ptr(w), B, S, L, L,
-        hip.ptr(scratch), hip.ptr(loss), hip.stream()), 'brv_mse_forward')
-    return loss
+    return _MseFunction.apply(x, y, lengths, weight)

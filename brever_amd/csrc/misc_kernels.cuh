@@ -122,12 +122,18 @@ __global__ void mse_finalize_kernel(const double* mom, int B, int S,
 }
 
 // PIT SI-SNR from raw moments (closed form in fp64), S <= 4.
+// coef (nullable): for estimate j of item b, 8 floats
+//   {c1, c2, mean_x, mean_y(ref), ref index, 0, 0, 0}
+// such that  d loss[b] / d x[b][j][n] = c1*(y[b][ref][n] - mean_y) + c2*(x[b][j][n] - mean_x)
+// for n < length (the mean removal of criterion.py:48-49 is transparent to the
+// gradient because both centred signals have zero mean over the valid samples).
 __global__ void sisnr_finalize_kernel(const double* mom, const double* cross, int B,
-                                      int S, const long long* lengths, float* loss) {
+                                      int S, const long long* lengths, float* loss,
+                                      float* coef) {
   const int b = blockIdx.x*blockDim.x + threadIdx.x;
   if (b >= B) return;
   const double n = (double)lengths[b];
-  double val[4][4];
+  double val[4][4], c1[4][4], c2[4][4];
   for (int i = 0; i < S; ++i) {            // reference source i
     const double* mi = mom + 6*((long long)b*S + i);
     const double my = mi[1]/n;
@@ -140,28 +146,81 @@ __global__ void sisnr_finalize_kernel(const double* mom, const double* cross, in
       const double tgt = sxy*sxy/syy;                 // ||s_target||^2
       double noise = sxx - tgt;                       // ||e_noise||^2
       if (noise < 0) noise = 0;
+      const double den = noise + kEps32;
       const float ratio = (float)tgt/((float)noise + (float)kEps32);
       val[i][j] = 10.f*log10f(ratio + (float)kEps32);
+      const double R = tgt/den;
+      const double dv = (10.0/log(10.0))/(R + kEps32);        // d val / d R
+      c1[i][j] = dv*(2.0*sxy/syy)*(1.0/den + tgt/(den*den));  // via <x, s>
+      c2[i][j] = dv*(-tgt/(den*den))*2.0;                     // via ||x||^2
     }
   }
-  // enumerate permutations (est perm[i] assigned to ref i)
-  int perm[4] = {0, 1, 2, 3};
-  double best = -1e300;
-  // Heap-free enumeration of up to 4! permutations
+  // enumerate permutations (estimate perm[i] is assigned to reference i)
+  int perm[4] = {0, 1, 2, 3}, best_perm[4] = {0, 1, 2, 3};
   int c[4] = {0, 0, 0, 0};
   auto score = [&]() { double s = 0; for (int i = 0; i < S; ++i) s += val[i][perm[i]]; return s; };
-  best = score();
+  double best = score();
   int i = 0;
   while (i < S) {
     if (c[i] < i) {
       const int k = (i & 1) ? c[i] : 0;
       const int tmp = perm[k]; perm[k] = perm[i]; perm[i] = tmp;
       const double s = score();
-      if (s > best) best = s;
+      if (s > best) { best = s; for (int q = 0; q < S; ++q) best_perm[q] = perm[q]; }
       ++c[i]; i = 0;
     } else { c[i] = 0; ++i; }
   }
   loss[b] = (float)(-best/S);
+  if (coef) {
+    for (int r = 0; r < S; ++r) {
+      const int j = best_perm[r];
+      float* o = coef + 8*((long long)b*S + j);
+      o[0] = (float)(-c1[r][j]/S); o[1] = (float)(-c2[r][j]/S);
+      o[2] = (float)(mom[6*((long long)b*S + j)]/n);
+      o[3] = (float)(mom[6*((long long)b*S + r) + 1]/n);
+      o[4] = (float)r; o[5] = 0.f; o[6] = 0.f; o[7] = 0.f;
+    }
+  }
+}
+
+struct SisnrBwdParams {
+  const float* x; const float* y; float* dx; long long stride; int L;
+  const long long* lengths; int S; const float* coef; const float* gscale;
+};
+__global__ __launch_bounds__(256) void sisnr_bwd_kernel(const SisnrBwdParams p) {
+  const int r = blockIdx.y;                       // row of the estimate: item*S + j
+  const int b = r / p.S;
+  long long len = p.lengths[b];
+  if (len > p.L) len = p.L;
+  const float* cf = p.coef + 8*(long long)r;
+  const float g = p.gscale[b];
+  const float c1 = cf[0]*g, c2 = cf[1]*g, mx = cf[2], my = cf[3];
+  const int ref = (int)cf[4];
+  const float* x = p.x + (long long)r*p.stride;
+  const float* y = p.y + ((long long)b*p.S + ref)*p.stride;
+  float* dx = p.dx + (long long)r*p.stride;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < p.L;
+       i += (long long)gridDim.x*256)
+    dx[i] = i < len ? c1*(y[i] - my) + c2*(x[i] - mx) : 0.f;
+}
+
+// d mse[b] / d x = weight[b] * 2/(S*len) * (x - y) on the valid samples
+struct MseBwdParams {
+  const float* x; const float* y; float* dx; long long stride; int L;
+  const long long* lengths; int S; const float* weight; const float* gscale;
+};
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const MseBwdParams p) {
+  const int r = blockIdx.y;
+  const int b = r / p.S;
+  long long len = p.lengths[b];
+  if (len > p.L) len = p.L;
+  const float c = p.gscale[b]*(p.weight ? p.weight[b] : 1.f)*2.f/((float)p.S*(float)p.lengths[b]);
+  const float* x = p.x + (long long)r*p.stride;
+  const float* y = p.y + (long long)r*p.stride;
+  float* dx = p.dx + (long long)r*p.stride;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < p.L;
+       i += (long long)gridDim.x*256)
+    dx[i] = i < len ? c*(x[i] - y[i]) : 0.f;
 }
 
 // ---------------------------------------------------------------------------

@@ -20,7 +20,7 @@ int ops_fail(int code, const char* what, hipError_t e) {
     if (e_ != hipSuccess) return ops_fail((int)e_, #expr, e_);         \
   } while (0)
 
-// scratch layout: mom [rows][6] f64 | cross [B][S][S] f64 | coef [rows] f32
+// scratch layout: mom [rows][6] f64 | cross [B][S][S] f64 | coef [rows][8] f32
 struct LossScratch {
   double* mom; double* cross; float* coef; size_t zero_bytes;
   LossScratch(void* p, int64_t B, int64_t S) {
@@ -49,7 +49,7 @@ int moments(const float* x, const float* y, const int64_t* lengths, int64_t B, i
 extern "C" {
 
 int64_t brv_loss_scratch_bytes(int64_t B, int64_t S) {
-  return (B*S*6 + B*S*S)*8 + B*S*4 + 64;
+  return (B*S*6 + B*S*S)*8 + B*S*8*4 + 64;
 }
 
 int brv_snr_forward(const float* x, const float* y, const int64_t* lengths, int64_t B,
@@ -99,7 +99,40 @@ int brv_sisnr_forward(const float* x, const float* y, const int64_t* lengths, in
                      0, st, c);
   OPS_OK(hipGetLastError());
   hipLaunchKernelGGL(sisnr_finalize_kernel, dim3((unsigned)((B + 63)/64)), dim3(64), 0, st,
-                     sc.mom, sc.cross, (int)B, (int)S, (const long long*)lengths, loss);
+                     sc.mom, sc.cross, (int)B, (int)S, (const long long*)lengths, loss, sc.coef);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_sisnr_backward(const float* x, const float* y, const int64_t* lengths, int64_t B,
+                       int64_t S, int64_t L, int64_t stride, const void* scratch,
+                       const float* gscale, float* dx, brv_stream_t stream) {
+  if (B < 1 || S < 1 || S > 4 || L < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  LossScratch sc(const_cast<void*>(scratch), B, S);
+  SisnrBwdParams p;
+  p.x = x; p.y = y; p.dx = dx; p.stride = stride; p.L = (int)L;
+  p.lengths = (const long long*)lengths; p.S = (int)S; p.coef = sc.coef; p.gscale = gscale;
+  int gx = (int)((L + 256*8 - 1)/(256*8));
+  if (gx < 1) gx = 1;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(sisnr_bwd_kernel, dim3(gx, (unsigned)(B*S)), dim3(256), 0, st, p);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_mse_backward(const float* x, const float* y, const int64_t* lengths,
+                     const float* weight, int64_t B, int64_t S, int64_t L, int64_t stride,
+                     const float* gscale, float* dx, brv_stream_t stream) {
+  if (B < 1 || S < 1 || L < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  MseBwdParams p;
+  p.x = x; p.y = y; p.dx = dx; p.stride = stride; p.L = (int)L;
+  p.lengths = (const long long*)lengths; p.S = (int)S; p.weight = weight; p.gscale = gscale;
+  int gx = (int)((L + 256*8 - 1)/(256*8));
+  if (gx < 1) gx = 1;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(gx, (unsigned)(B*S)), dim3(256), 0, st, p);
   OPS_OK(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,232 @@
+// STFT / inverse STFT / mel filterbank as small fp32 GEMMs on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain, so the transform keeps fp32
+// accuracy; the dense DFT costs 0.5 MFLOP per 512-sample frame, 4 GFLOP for a whole
+// 16 x 4 s batch -- far below the HBM time of writing the spectrogram).
+//
+// Reference: brever/modules/stft.py:59-149 (STFT.forward / backward / pad /
+// frame_count around torch.stft / torch.istft, center=True, pad_mode='constant') and
+// :152-198 (MelFilterbank). The window-weighted DFT bases are built on the host in
+// float64 (brever_amd/modules/stft.py) and passed in as fp32 matrices.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "../../include/brever_hip.h"
+#include "common.cuh"
+
+using namespace brv;
+
+namespace {
+
+enum AMode { GA_PLAIN = 0, GA_SPEC_T = 1 };
+enum BMode { GB_PLAIN = 0, GB_FRAMES = 1, GB_WT = 2 };
+enum SMode { GS_PLAIN = 0, GS_SPEC = 1 };
+
+struct G32 {
+  int M, N, K;                 // D[M][N] = A[M][K] * B[K][N], per batch item
+  const float* A; long long a_bs; int lda;
+  const float* B; long long b_bs; int ldb;
+  float* D; long long d_bs; int ldd;
+  // GB_FRAMES: B[k][j] = x[j*hop + k - pad_left], zero outside [0, len)
+  int hop, pad_left, len;
+  // GA_SPEC_T: A[i][c] = spectrum bin c/2, part c%2, frame i, of X[bins][frames] complex
+  //            (frames = M), after undoing scale / compression
+  int frames; float inv_scale, inv_comp;
+  // GS_SPEC: D rows are (bin, part) pairs; store complex [bins][N] after compression
+  float comp, scale; int bins;
+};
+
+constexpr int TM = 64, TN = 64, TK = 32;
+
+template <int AM, int BM, int SM>
+__global__ __launch_bounds__(256) void gemm32_kernel(const G32 p) {
+  __shared__ float As[TM][TK + 1];
+  __shared__ float Bs[TK][TN + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y*TM, n0 = blockIdx.x*TN, b = blockIdx.z;
+  const float* A = p.A + (long long)b*p.a_bs;
+  const float* B = p.B + (long long)b*p.b_bs;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < p.K; k0 += TK) {
+    // ---- stage A [TM][TK] ----
+#pragma unroll
+    for (int e = tid; e < TM*TK; e += 256) {
+      const int i = e / TK, k = e % TK;
+      const int m = m0 + i, kk = k0 + k;
+      float v = 0.f;
+      if (m < p.M && kk < p.K) {
+        if (AM == GA_PLAIN) {
+          v = A[(long long)m*p.lda + kk];
+        } else {
+          // spectrum element (bin, part) of frame m; undo scale and magnitude compression
+          const int bin = kk >> 1, part = kk & 1;
+          const float2 z = *reinterpret_cast<const float2*>(A + ((long long)bin*p.frames + m)*2);
+          float re = z.x*p.inv_scale, im = z.y*p.inv_scale;
+          if (p.inv_comp != 1.f) {
+            const float mag = sqrtf(re*re + im*im);
+            const float f = mag > 0.f ? powf(mag, p.inv_comp - 1.f) : 0.f;
+            re *= f; im *= f;
+          }
+          v = part ? im : re;
+        }
+      }
+      As[i][k] = v;
+    }
+    // ---- stage B [TK][TN] ----
+#pragma unroll
+    for (int e = tid; e < TK*TN; e += 256) {
+      const int k = e / TN, j = e % TN;
+      const int kk = k0 + k, n = n0 + j;
+      float v = 0.f;
+      if (kk < p.K && n < p.N) {
+        if (BM == GB_PLAIN) v = B[(long long)kk*p.ldb + n];
+        else if (BM == GB_WT) v = B[(long long)n*p.ldb + kk];
+        else {
+          const long long idx = (long long)n*p.hop + kk - p.pad_left;
+          if (idx >= 0 && idx < p.len) v = B[idx];
+        }
+      }
+      Bs[k][j] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TK/2; ++s) {
+      const float a = As[32*wm + (lane & 31)][2*s + (lane >> 5)];
+      const float bv = Bs[2*s + (lane >> 5)][32*wn + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D element (row, col): col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*(lane >> 5)
+  float* D = p.D + (long long)b*p.d_bs;
+  const int col = n0 + 32*wn + (lane & 31);
+  if (col >= p.N) return;
+  if (SM == GS_PLAIN) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = m0 + 32*wm + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
+      if (row < p.M) D[(long long)row*p.ldd + col] = acc[i];
+    }
+  } else {
+    // rows come in (re, im) pairs: registers (2q, 2q+1) of one lane
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = 2*q;
+      const int row = m0 + 32*wm + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
+      const int bin = row >> 1;
+      if (bin >= p.bins) continue;
+      float re = acc[i], im = acc[i + 1];
+      if (p.comp != 1.f) {
+        const float mag = sqrtf(re*re + im*im);
+        const float f = mag > 0.f ? powf(mag, p.comp - 1.f) : 0.f;
+        re *= f; im *= f;
+      }
+      *reinterpret_cast<float2*>(D + ((long long)bin*p.N + col)*2) =
+          make_float2(re*p.scale, im*p.scale);
+    }
+  }
+}
+
+// Windowed overlap-add with window-envelope normalisation (torch.istft, center=True):
+//   y[q] = sum_t frames[t][q + n/2 - t*hop] / sum_t w^2[q + n/2 - t*hop],  q < hop*(F-1)
+struct OlaParams {
+  const float* frames; float* y; const float* win; int F, n, hop, out_len;
+  long long f_bs, y_bs;
+};
+__global__ __launch_bounds__(256) void istft_ola_kernel(const OlaParams p) {
+  const int b = blockIdx.y;
+  const float* fr = p.frames + (long long)b*p.f_bs;
+  float* y = p.y + (long long)b*p.y_bs;
+  for (int q = blockIdx.x*256 + threadIdx.x; q < p.out_len; q += gridDim.x*256) {
+    const int pos = q + p.n/2;
+    int t_hi = pos/p.hop; if (t_hi > p.F - 1) t_hi = p.F - 1;
+    int t_lo = (pos - p.n + p.hop)/p.hop; if (pos - p.n + 1 <= 0) t_lo = 0;
+    if (t_lo < 0) t_lo = 0;
+    float s = 0.f, env = 0.f;
+    for (int t = t_lo; t <= t_hi; ++t) {          // fixed order: deterministic
+      const int m = pos - t*p.hop;
+      if (m < 0 || m >= p.n) continue;
+      const float w = p.win[m];
+      s += fr[(long long)t*p.n + m];
+      env += w*w;
+    }
+    y[q] = s/env;
+  }
+}
+
+template <int AM, int BM, int SM>
+int launch_g32(const G32& p, int batch, hipStream_t st) {
+  if (p.M <= 0 || p.N <= 0 || batch <= 0) return 0;
+  dim3 grid((p.N + TN - 1)/TN, (p.M + TM - 1)/TM, batch);
+  hipLaunchKernelGGL((gemm32_kernel<AM, BM, SM>), grid, dim3(256), 0, st, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t brv_stft_frames(int64_t length, int64_t frame_length, int64_t hop_length) {
+  // STFT.frame_count + the n/2 centre padding on both sides (stft.py:140-149, :72)
+  if (length < 0 || frame_length < 2 || hop_length < 1) return -1;
+  const int64_t d = length > frame_length ? length - frame_length : 0;
+  const int64_t nc = (d + hop_length - 1)/hop_length + 1;
+  const int64_t padded = (nc - 1)*hop_length + frame_length;     // after STFT.pad
+  return 1 + padded/hop_length;        // 1 + (padded + n - n)/hop with centre padding
+}
+
+int brv_stft_forward(const float* x, const float* basis, float* spec, int64_t rows,
+                     int64_t length, int64_t frame_length, int64_t hop_length,
+                     float compression, float scale, brv_stream_t stream) {
+  const int64_t F = brv_stft_frames(length, frame_length, hop_length);
+  if (rows < 1 || F < 1) return -1;
+  const int bins = (int)(frame_length/2 + 1);
+  G32 p; memset(&p, 0, sizeof(p));
+  p.M = 2*bins; p.N = (int)F; p.K = (int)frame_length;
+  p.A = basis; p.a_bs = 0; p.lda = (int)frame_length;
+  p.B = x; p.b_bs = length; p.hop = (int)hop_length; p.pad_left = (int)(frame_length/2);
+  p.len = (int)length;
+  p.D = spec; p.d_bs = (long long)bins*F*2; p.bins = bins;
+  p.comp = compression; p.scale = scale;
+  return launch_g32<GA_PLAIN, GB_FRAMES, GS_SPEC>(p, (int)rows, (hipStream_t)stream);
+}
+
+int brv_istft_backward(const float* spec, const float* inv_basis, const float* window,
+                       float* frames_scratch, float* y, int64_t rows, int64_t frames,
+                       int64_t frame_length, int64_t hop_length, float compression,
+                       float scale, brv_stream_t stream) {
+  if (rows < 1 || frames < 1 || frame_length < 2 || hop_length < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int bins = (int)(frame_length/2 + 1);
+  G32 p; memset(&p, 0, sizeof(p));
+  p.M = (int)frames; p.N = (int)frame_length; p.K = 2*bins;
+  p.A = spec; p.a_bs = (long long)bins*frames*2; p.frames = (int)frames;
+  p.inv_scale = 1.f/scale; p.inv_comp = 1.f/compression;
+  p.B = inv_basis; p.b_bs = 0; p.ldb = 2*bins;           // inv_basis[m][c] read transposed
+  p.D = frames_scratch; p.d_bs = (long long)frames*frame_length; p.ldd = (int)frame_length;
+  if (int r = launch_g32<GA_SPEC_T, GB_WT, GS_PLAIN>(p, (int)rows, st)) return r;
+  OlaParams o;
+  o.frames = frames_scratch; o.y = y; o.win = window; o.F = (int)frames;
+  o.n = (int)frame_length; o.hop = (int)hop_length;
+  o.out_len = (int)(hop_length*(frames - 1));
+  o.f_bs = (long long)frames*frame_length; o.y_bs = o.out_len;
+  int gx = (o.out_len + 255)/256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(istft_ola_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, o);
+  return (int)hipGetLastError();
+}
+
+int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,
+                   int64_t N, int64_t K, int64_t a_batch_stride, brv_stream_t stream) {
+  if (batch < 1 || M < 1 || N < 1 || K < 1) return -1;
+  G32 p; memset(&p, 0, sizeof(p));
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.A = a; p.a_bs = a_batch_stride; p.lda = (int)K;
+  p.B = b; p.b_bs = K*N; p.ldb = (int)N;
+  p.D = d; p.d_bs = M*N; p.ldd = (int)N;
+  return launch_g32<GA_PLAIN, GB_PLAIN, GS_PLAIN>(p, (int)batch, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -54,9 +54,23 @@ SIGNATURES = {
     'brv_sisnr_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64,
                                          _c_i64, _c_i64, _c_i64, _c_ptr,
                                          _c_ptr, _c_ptr]),
+    'brv_sisnr_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                          _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr,
+                                          _c_ptr]),
+    'brv_mse_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+                                        _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr,
+                                        _c_ptr]),
     'brv_mse_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                        _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr,
                                        _c_ptr]),
+    'brv_stft_frames': (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    'brv_stft_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                        _c_i64, _c_i64, _c_f32, _c_f32, _c_ptr]),
+    'brv_istft_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                          _c_i64, _c_i64, _c_i64, _c_i64, _c_f32,
+                                          _c_f32, _c_ptr]),
+    'brv_matmul_f32': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                      _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_clip_adam_step': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                           _c_i64, _c_f32, _c_f32, _c_f32,
                                           _c_f32, _c_f32, _c_f32, _c_i64,

@@ -1,0 +1,2 @@
+"""DSP modules of the HIP path (reference: brever/modules/)."""
+from .stft import STFT, MelFilterbank  # noqa: F401

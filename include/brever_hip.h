@@ -103,16 +103,46 @@ int brv_snr_backward(const float* x, const float* y, const int64_t* lengths,
                      int64_t batch, int64_t sources, int64_t length,
                      int64_t stride, const void* scratch, const float* gscale,
                      float* dx, brv_stream_t stream);
-/* sisnr with PIT (criterion.py:21-72), sources <= 4; forward only (metric). */
+/* sisnr with PIT (criterion.py:21-72), sources <= 4. The forward leaves the winning
+ * permutation and the gradient coefficients in scratch for the backward. */
 int brv_sisnr_forward(const float* x, const float* y, const int64_t* lengths,
                       int64_t batch, int64_t sources, int64_t length,
                       int64_t stride, void* scratch, float* loss,
                       brv_stream_t stream);
+int brv_sisnr_backward(const float* x, const float* y, const int64_t* lengths,
+                       int64_t batch, int64_t sources, int64_t length,
+                       int64_t stride, const void* scratch, const float* gscale,
+                       float* dx, brv_stream_t stream);
 /* mse (criterion.py:104-132) on real tensors; weight may be NULL. */
 int brv_mse_forward(const float* x, const float* y, const int64_t* lengths,
                     const float* weight, int64_t batch, int64_t sources,
                     int64_t length, int64_t stride, void* scratch, float* loss,
                     brv_stream_t stream);
+int brv_mse_backward(const float* x, const float* y, const int64_t* lengths,
+                     const float* weight, int64_t batch, int64_t sources,
+                     int64_t length, int64_t stride, const float* gscale,
+                     float* dx, brv_stream_t stream);
+
+/* ---- STFT / iSTFT / filterbank (brever/modules/stft.py) ------------------------
+ * One-sided transforms, hop dividing the frame length, center=True with constant
+ * (zero) padding exactly as STFT.forward / STFT.backward of the reference
+ * (stft.py:59-149). The DFT bases are fp32 matrices built by the caller:
+ *   basis     [2*(n/2+1)][n]  row 2k = w[m] cos(2 pi k m/n)*norm, row 2k+1 = -w[m] sin(...)*norm
+ *   inv_basis [n][2*(n/2+1)]  windowed inverse real DFT (norm undone)
+ * spec is complex64 laid out (rows, n/2+1, frames) like torch.stft's output. */
+int64_t brv_stft_frames(int64_t length, int64_t frame_length, int64_t hop_length);
+int brv_stft_forward(const float* x, const float* basis, float* spec, int64_t rows,
+                     int64_t length, int64_t frame_length, int64_t hop_length,
+                     float compression, float scale, brv_stream_t stream);
+/* frames_scratch: rows*frames*frame_length floats; y: (rows, hop*(frames-1)). */
+int brv_istft_backward(const float* spec, const float* inv_basis, const float* window,
+                       float* frames_scratch, float* y, int64_t rows, int64_t frames,
+                       int64_t frame_length, int64_t hop_length, float compression,
+                       float scale, brv_stream_t stream);
+/* d[b] = a[b or shared] (M x K) @ b[b] (K x N), fp32 (MelFilterbank.forward/backward,
+ * stft.py:189-198). a_batch_stride = 0 shares one matrix across the batch. */
+int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,
+                   int64_t N, int64_t K, int64_t a_batch_stride, brv_stream_t stream);
 
 /* ---- optimizer --------------------------------------------------------------
  * clip_grad_norm_(max_norm) + Adam.step (base.py:296-301, torch.optim.Adam with

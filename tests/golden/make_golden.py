@@ -165,6 +165,17 @@ def golden_losses(out):
     xg = x.clone().requires_grad_(True)
     CriterionRegistry.get('snr')(xg, y, lengths).mean().backward()
     res['snr_grad'] = xg.grad.numpy()
+    gw = torch.rand(B)                      # non-uniform upstream gradient per item
+    res['gweight'] = gw.numpy()
+    # (the reference's sisnr divides the amax output in place, criterion.py:70, which
+    # autograd of this torch version rejects: its gradient is checked against the
+    # oracle's autograd instead, tests/test_gpu.py)
+    xg = x.clone().requires_grad_(True)
+    (CriterionRegistry.get('mse')(xg, y, lengths)*gw).sum().backward()
+    res['mse_grad'] = xg.grad.numpy()
+    xg = x.clone().requires_grad_(True)
+    (CriterionRegistry.get('mse')(xg, y, lengths, weight=w)*gw).sum().backward()
+    res['mse_weighted_grad'] = xg.grad.numpy()
     np.savez_compressed(os.path.join(out, 'losses.npz'), **res)
 
 
@@ -265,6 +276,44 @@ def golden_training(out):
     np.savez(os.path.join(out, 'training.npz'), **res)
 
 
+def golden_stft(out):
+    """STFT.forward / backward of the reference on the seeded signal of its own
+    round-trip test (tests/test_modules.py:319-326), frame counts for edge lengths,
+    and the default MelFilterbank."""
+    from brever.modules import STFT, MelFilterbank
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(1, 4096, generator=g)
+    res = dict(x=x.numpy())
+    combos = [(256, 1.0, 1.0, True), (128, 0.5, 0.15, False), (128, 1.0, 1.0, True),
+              (256, 0.5, 0.15, True)]
+    res['combos'] = np.array(combos, dtype=np.float64)
+    for i, (hop, comp, scale, norm) in enumerate(combos):
+        stft = STFT(frame_length=512, hop_length=hop, compression_factor=comp,
+                    scale_factor=scale, normalized=norm)
+        X = stft(x)
+        res[f'spec{i}'] = X.numpy()
+        res[f'back{i}'] = stft.backward(X.clone()).numpy()
+    odd = STFT(frame_length=512, hop_length=128)
+    y = torch.randn(3000, generator=g)
+    res['x_odd'] = y.numpy()
+    res['spec_odd'] = odd(y).numpy()
+    res['back_odd'] = odd.backward(odd(y)).numpy()
+    lens = [1, 511, 512, 513, 3000, 63999, 64000, 64001]
+    res['lens'] = np.array(lens)
+    for hop in (128, 256):
+        s = STFT(frame_length=512, hop_length=hop)
+        res[f'frames{hop}'] = np.array([s(torch.zeros(n)).shape[-1] for n in lens])
+    mel = MelFilterbank()
+    res['mel_filters'] = mel.filters.numpy()
+    res['mel_fc'] = mel.fc.numpy()
+    res['mel_scaling'] = mel.scaling.numpy()
+    spec = torch.randn(2, 257, 12, generator=g).abs()
+    res['mel_in'] = spec.numpy()
+    res['mel_fwd'] = mel(spec).numpy()
+    res['mel_bwd'] = mel.backward(mel(spec)).numpy()
+    np.savez_compressed(os.path.join(out, 'stft.npz'), **res)
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
@@ -275,6 +324,7 @@ def main():
     golden_losses(HERE)
     golden_convtasnet(HERE)
     golden_training(HERE)
+    golden_stft(HERE)
     print('golden fixtures written to', HERE)
 
 

@@ -155,3 +155,45 @@ def test_training_flow_reproduces_reference_golden(golden_dir, tag, ema):
         assert trainer.epochs_ran == 3
         again = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
         assert not torch.allclose(flat[:10], again[:10])
+
+
+def test_stft_oracle_matches_reference(golden_dir):
+    """oracle/stft.py (framed rFFT restatement) vs the reference STFT wrapper."""
+    import scipy.signal
+    from oracle import stft as ost
+    g = np.load(os.path.join(golden_dir, 'stft.npz'))
+    w = scipy.signal.get_window('hann', 512)
+    x = g['x']
+    for i, (hop, comp, scale, norm) in enumerate(g['combos']):
+        X = ost.stft(x, w, int(hop), bool(norm), comp, scale)
+        assert X.shape == g[f'spec{i}'].shape
+        assert np.abs(X - g[f'spec{i}']).max() <= 2e-5*np.abs(g[f'spec{i}']).max()
+        y = ost.istft(g[f'spec{i}'], w, int(hop), bool(norm), comp, scale)
+        assert y.shape == g[f'back{i}'].shape
+        assert np.abs(y - g[f'back{i}']).max() <= 1e-5
+        assert np.abs(y[..., :4096] - x).max() <= 1e-5          # round trip
+    X = ost.stft(g['x_odd'], w, 128)
+    assert np.abs(X - g['spec_odd']).max() <= 2e-5*np.abs(g['spec_odd']).max()
+    assert ost.istft(g['spec_odd'], w, 128).shape == g['back_odd'].shape == (3072,)
+    for hop in (128, 256):
+        got = [ost.stft_frames(int(n), 512, hop) for n in g['lens']]
+        assert got == list(g[f'frames{hop}'])                 # integer, bit-exact
+    assert ost.stft_frames(64000, 512, 128) == 501
+
+
+def test_mel_filterbank_and_frame_count_bit_exact(golden_dir):
+    """Host-side constants of the product modules: mel matrix and frame arithmetic."""
+    from brever_amd import hip
+    from brever_amd.modules import STFT, MelFilterbank
+    g = np.load(os.path.join(golden_dir, 'stft.npz'))
+    mel = MelFilterbank()
+    assert np.array_equal(mel.filters.numpy(), g['mel_filters'])
+    assert np.array_equal(mel.fc.numpy(), g['mel_fc'])
+    assert np.array_equal(mel.scaling.numpy(), g['mel_scaling'])
+    for hop in (128, 256):
+        got = [hip.lib().brv_stft_frames(int(n), 512, hop) for n in g['lens']]
+        assert got == list(g[f'frames{hop}'])
+        s = STFT(512, hop)
+        assert [s.frame_count(int(n)) + 512//hop for n in g['lens']] == got
+    with pytest.raises(NotImplementedError):
+        STFT(512, 128, onesided=False)
