@@ -85,10 +85,19 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
 
 // ---- global layer norm statistics ----------------------------------------
 // stats[b] = {sum, sum of squares} over the (frames x true channels) of item b.
+// Layout of the per-item statistics: item b owns kStatStride doubles, the sum at +0 and the
+// sum of squares at +kStatStride/2, i.e. two PRIVATE 128-byte lines per item. Atomics
+// that land in the same 128-byte line serialise at ~12 ns each on MI355X whatever the
+// address inside the line (tools/atomicbench.hip): with the packed [B][2] layout the
+// 4000 wave-level adds of one 1x1 convolution cost 21 us after the last wave had
+// finished; spread over 2B lines they cost < 2 us.
+constexpr int kStatStride = 32;
+__host__ __device__ __forceinline__ constexpr long long stat_sum(long long b) { return b*kStatStride; }
+__host__ __device__ __forceinline__ constexpr long long stat_sq(long long b) { return b*kStatStride + kStatStride/2; }
 struct NormStat { float mean, rstd; };
 __device__ __forceinline__ NormStat norm_stat(const double* stats, int b,
                                               double inv_n, float eps) {
-  const double s = stats[2*b], ss = stats[2*b + 1];
+  const double s = stats[stat_sum(b)], ss = stats[stat_sq(b)];
   const double mean = s*inv_n;
   double var = ss*inv_n - mean*mean;      // biased variance, as nn.GroupNorm
   if (var < 0.0) var = 0.0;

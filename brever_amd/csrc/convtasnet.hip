@@ -150,7 +150,7 @@ struct Workspace {
     skip = take(BT*l.Scp*4);
     m = take(BT*l.S*l.Np*2);
     y = take(BT*l.S*l.Np*2);
-    stats_bytes = (long long)(1 + 2*l.nb)*B*2*8;
+    stats_bytes = (long long)(1 + 2*l.nb)*B*kStatStride*8;
     stats = take(stats_bytes);
     sums = take(stats_bytes);
     dpre = take(BT*l.S*l.Np*2);
@@ -167,7 +167,7 @@ struct Workspace {
     gcopy = take(gcopy_stride*l.nb);
     e0 = take(BT*l.Np*2);
     dwt = take(BT*l.Np*2);
-    vg_stride = align_up(2LL*l.N + (long long)l.nb*l.H*(5 + l.P), 64);
+    vg_stride = align_up(2LL*l.N + (long long)l.nb*l.H*(5 + l.P) + 1 + 2*l.nb, 64);
     vg_bytes = vg_stride*kReplicas*4;
     vg = take(vg_bytes);
     total = o;
@@ -184,6 +184,28 @@ int launch_gemm_rows_t(const GemmRowsParams& p0, int batch, hipStream_t st) {
   HIP_OK(hipGetLastError());
   return 0;
 }
+
+#ifdef BRV_DIAG
+// records the 100 MHz real-time counter: slot 0 = end of the kernel before, slot 1 = start
+// of the kernel after a stamped launch (slots 2 / 3 = first entry / last exit inside it)
+__global__ void diag_stamp_kernel(long long* out, int slot) {
+  long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  if (threadIdx.x == 0) {
+    out[slot] = t;
+    if (slot == 0) { out[2] = 0x7fffffffffffffffLL; out[3] = 0; }
+  }
+}
+// diagnostic builds only: a leaked 1 MiB device buffer for cycle stamps
+long long* debug_buffer() {
+  static long long* buf = nullptr;
+  if (!buf) {
+    if (hipMalloc(&buf, 1 << 20) != hipSuccess) return nullptr;
+    (void)hipMemset(buf, 0, 1 << 20);
+  }
+  return buf;
+}
+#endif
 
 int num_cus() {
   static int n = 0;
@@ -203,6 +225,10 @@ int launch_gemm_ws(const GemmRowsParams& p0, int batch, hipStream_t st) {
   using C = GemmWsCfg<KP, NSL, WM, NW>;
   GemmRowsParams p = p0;
   p.batch = batch;
+#ifdef BRV_DIAG
+  if (const char* d = getenv("BRV_DBG")) p.dbg = atoi(d);
+  if (p.dbg & (64 | 512)) p.dbg_out = debug_buffer();
+#endif
   if (!CAT && p.a.K0 <= 0) {          // everything comes from the second source
     p.a.p0 = p.a.p1; p.a.ld0 = p.a.ld1; p.a.bs0 = p.a.bs1; p.a.K0 = 1 << 30;
   }
@@ -213,8 +239,14 @@ int launch_gemm_ws(const GemmRowsParams& p0, int batch, hipStream_t st) {
   int grid = (NW == 8 ? num_cus() : 2*num_cus())/groups;
   if (grid > total) grid = total;
   if (grid < 1) grid = 1;
+#ifdef BRV_DIAG
+  if (p.dbg & 512) hipLaunchKernelGGL(diag_stamp_kernel, dim3(1), dim3(64), 0, st, debug_buffer() + 131000, 0);
+#endif
   hipLaunchKernelGGL((gemm_ws_kernel<KP, NSL, WM, EM, AT, CAT, NW>), dim3(grid, groups),
                      dim3(64*NW), 0, st, p);
+#ifdef BRV_DIAG
+  if (p.dbg & 512) hipLaunchKernelGGL(diag_stamp_kernel, dim3(1), dim3(64), 0, st, debug_buffer() + 131000, 1);
+#endif
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -229,7 +261,7 @@ int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st,
     const bool full = p.a.slope != nullptr && p.a.stats != nullptr;
     const bool one_src = p.a.K0 >= p.Kp || p.a.K0 <= 0;
     if ((EM == E_STORE || EM == E_GLN_BWD) && p.Kp == 128 && p.Np == 512 && plain && one_src)
-      return launch_gemm_ws<128, 64, 1, (EM == E_STORE ? E_STORE : E_GLN_BWD), 0, false, 4>(p, batch, st);
+      return launch_gemm_ws<128, 64, 1, (EM == E_STORE ? E_STORE : E_GLN_BWD), 0, false, 8>(p, batch, st);
     if (EM == E_RES_SKIP && p.Kp == 512 && p.Np == 256 && full && one_src)
       return launch_gemm_ws<512, 32, 1, E_RES_SKIP, 1, false>(p, batch, st);
     if (EM == E_GLN_BWD && p.Kp == 256 && p.Np == 512 && plain && one_src)
@@ -351,6 +383,16 @@ extern "C" {
 
 int brv_version(void) { return 100; }
 
+#ifdef BRV_DIAG
+// Copies the cycle stamps of a BRV_DBG=64 run (tools/ablate.py) to the host.
+int brv_debug_read(long long* out, int64_t n) {
+  (void)hipDeviceSynchronize();
+  const int r = (int)hipMemcpy(out, debug_buffer(), (size_t)n*8, hipMemcpyDeviceToHost);
+  (void)hipMemset(debug_buffer(), 0, 1 << 20);           // next run starts clean
+  return r;
+}
+#endif
+
 int brv_prof_enable(int on) {
   for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   g_prof.clear();
@@ -418,8 +460,8 @@ int64_t brv_ctn_workspace_offset(const brv_ctn_config* cfg, int64_t batch, int64
   if (n == "skip") return ws.skip;
   if (n == "m") return ws.m;
   if (n == "y") return ws.y;
-  if (n == "stats") return ws.stats + index*batch*16;
-  if (n == "sums") return ws.sums + index*batch*16;
+  if (n == "stats") return ws.stats + index*batch*kStatStride*8;
+  if (n == "sums") return ws.sums + index*batch*kStatStride*8;
   if (n == "dpre") return ws.dpre;
   if (n == "gskip") return ws.gskip;
   if (n == "gout") return ws.gout;
@@ -486,7 +528,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   char* base = (char*)workspace;
   const bf16_t* prep = (const bf16_t*)prepared;
   double* stats = (double*)(base + ws.stats);
-  auto stat = [&](int i) { return stats + (long long)i*B*2; };
+  auto stat = [&](int i) { return stats + (long long)i*B*kStatStride; };
   bf16_t* w = (bf16_t*)(base + ws.w);
   auto xbuf = [&](int i) { return (bf16_t*)(base + ws.x + ws.x_stride*i); };
   auto z1buf = [&](int i) { return (bf16_t*)(base + ws.z1 + ws.z_stride*i); };
@@ -580,8 +622,8 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   const bf16_t* prep = (const bf16_t*)prepared;
   double* stats = (double*)(base + ws.stats);
   double* sums = (double*)(base + ws.sums);
-  auto stat = [&](int i) { return stats + (long long)i*B*2; };
-  auto sum = [&](int i) { return sums + (long long)i*B*2; };
+  auto stat = [&](int i) { return stats + (long long)i*B*kStatStride; };
+  auto sum = [&](int i) { return sums + (long long)i*B*kStatStride; };
   bf16_t* w = (bf16_t*)(base + ws.w);
   auto xbuf = [&](int i) { return (bf16_t*)(base + ws.x + ws.x_stride*i); };
   auto z1buf = [&](int i) { return (bf16_t*)(base + ws.z1 + ws.z_stride*i); };
@@ -603,6 +645,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   float* vg = (float*)(base + ws.vg);
   const long long vper = (long long)l.H*(5 + l.P);
   auto vslot = [&](int i) { return vg + 2LL*l.N + vper*i; };   // block i's vector grads
+  float* vslope = vg + 2LL*l.N + vper*l.nb;    // PReLU slope grads: tcn, then (prelu1, prelu2) per block
 
   HIP_OK(hipMemsetAsync(sums, 0, ws.stats_bytes, st));
   HIP_OK(hipMemsetAsync(vg, 0, ws.vg_bytes, st));
@@ -626,7 +669,8 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   g.a = rows_bf16(dpre, l.Np, T); g.a.nsrc = l.S;
   g.W = prep + l.p_out_b; g.T = (int)T; g.Np = l.Scp; g.Kp = l.S*l.Np;
   g.e.out = gskip; g.e.ldo = ldg; g.e.src_f32 = skip; g.e.ld_srcf = l.Scp;
-  g.e.src_slope = params + l.tcn_prelu; g.e.dslope = grads + l.tcn_prelu;
+  g.e.src_slope = params + l.tcn_prelu; g.e.dslope = vslope;
+  g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
   if (int r = launch_gemm_rows<A_BF16, E_PRELU_BWD>(g, B, st, "mask_bwd", 2.0*BT*l.S*l.Np + 6.0*BT*l.Scp)) return r;
   // output conv weight / bias gradients, one source at a time
   for (int s = 0; s < l.S; ++s) {
@@ -660,7 +704,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     DzParams dz; memset(&dz, 0, sizeof(dz));
     dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
     dz.slope = params + b.prelu2; dz.stats = stat(2 + 2*i); dz.sums = sum(2 + 2*i);
-    dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = grads + b.prelu2;
+    dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 2 + 2*i; dz.rep_stride = ws.vg_stride;
     if (int r = launch_dz(dz, st)) return r;
     // depthwise conv backward (data, taps, bias) + gLN_1 partials
     DwParams d; memset(&d, 0, sizeof(d));
@@ -678,7 +722,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     memset(&dz, 0, sizeof(dz));
     dz.e = eB; dz.z = z1buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
     dz.slope = params + b.prelu1; dz.stats = stat(1 + 2*i); dz.sums = sum(1 + 2*i);
-    dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = grads + b.prelu1;
+    dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 1 + 2*i; dz.rep_stride = ws.vg_stride;
     if (int r = launch_dz(dz, st)) return r;
     // first 1x1 conv: data gradient + residual path -> gradient wrt block input
     memset(&g, 0, sizeof(g));
@@ -795,7 +839,10 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     const BlockOff& bl = l.blk[l.nb - 1];
     vp.o_dconv_w = b0.dconv_w - b0.conv_w; vp.o_dconv_b = b0.dconv_b - b0.conv_w;
     vp.o_n1_g_full = b0.n1_g - b0.conv_w; vp.o_n1_g_last = bl.n1_g - bl.conv_w;
-    const long long total = 2LL*l.N + vper*l.nb;
+    vp.tcn_prelu_off = l.tcn_prelu;
+    if (b0.prelu1 != b0.n1_g + 4LL*l.H || b0.prelu2 != b0.prelu1 + 1)
+      return fail(-1, "vgrad_reduce: unexpected PReLU offsets");
+    const long long total = 2LL*l.N + vper*l.nb + 1 + 2*l.nb;
     int gx = (int)((total + 255)/256);
     if (gx > 1024) gx = 1024;
     ProfScope prof("vgrad_reduce", 0, 4.0*total*(kReplicas + 2), st);

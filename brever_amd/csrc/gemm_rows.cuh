@@ -69,6 +69,10 @@ struct GemmRowsParams {
   const bf16_t* W;         // [Np][Kp]
   int T, Np, Kp;
   int n_ttiles, n_ntiles, batch;   // filled by the launcher (1-D XCD-aware grid)
+#ifdef BRV_DIAG                    // make DIAG=1: ablation flags + cycle stamps (tools/ablate.py)
+  int dbg;
+  long long* dbg_out;
+#endif
   EpiSpec e;
 };
 
@@ -436,13 +440,16 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
     const double s0 = block_sum(st_sum, dscr);
     const double s1 = block_sum(st_sq, dscr + 8);
     double* dst = (EM == E_STORE) ? e.stats_out : e.sums_out;
-    if (tid == 0) { atomic_add_f64(dst + 2*b, s0); atomic_add_f64(dst + 2*b + 1, s1); }
+    if (tid == 0) { atomic_add_f64(dst + stat_sum(b), s0); atomic_add_f64(dst + stat_sq(b), s1); }
   }
   if (EM == E_PRELU_BWD) {
     __syncthreads();
     float* fscr = reinterpret_cast<float*>(smem);
     const float s0 = block_sum(red_f, fscr);
-    if (tid == 0) atomic_add_f32(e.dslope, s0);
+    if (tid == 0) {
+      const long long ro = e.n_rep > 1 ? (long long)(blockIdx.x % e.n_rep)*e.rep_stride : 0;
+      atomic_add_f32(e.dslope + ro, s0);
+    }
   }
   if (EM == E_GLN_BWD) {
     __syncthreads();

@@ -26,6 +26,14 @@
 namespace brv {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;     // v_pk_{add,mul,fma}_f32 operands
+
+__device__ __forceinline__ uint4 pack8v(const f32x2 (&v)[4]) {
+  uint4 q;
+  q.x = pack2(v[0].x, v[0].y); q.y = pack2(v[1].x, v[1].y);
+  q.z = pack2(v[2].x, v[2].y); q.w = pack2(v[3].x, v[3].y);
+  return q;
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long long bytes) {
   const unsigned int n = bytes < 0 ? 0u : (bytes > 0xffffffffLL ? 0xffffffffu : (unsigned int)bytes);
@@ -37,7 +45,10 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned i
 }
 __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned int off, const uint4& q) {
   u32x4 v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, 0);
+#ifndef BRV_STORE_AUX
+#define BRV_STORE_AUX 0
+#endif
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, BRV_STORE_AUX);
 }
 constexpr unsigned int kOob = 0xfffffff0u;     // offset that is out of range for any descriptor
 
@@ -55,6 +66,15 @@ struct GemmWsCfg {
   static constexpr int kA = 2*BMW*LDA*2;
   static constexpr int kC = NW*32*LDW*4;
   static constexpr int kSmem = kA + kC + 2*KP*4;
+  // The dispatcher does not balance workgroups over CUs by itself: with room for more,
+  // it stacks several of these persistent workgroups on one CU and leaves others idle
+  // (measured: median workgroup 23 us, slowest 36 us). Claiming more than 1/2 (8 waves)
+  // or 1/3 (4 waves) of the 160 KB LDS caps residency at exactly the 1 or 2 workgroups
+  // per CU the grid is sized for, which forces an even spread.
+  static constexpr int kWgPerCu = NW == 8 ? 1 : 2;
+  static constexpr int kSmemMin = NW == 8 ? 84*1024 : 56*1024;
+  static constexpr int kSmemAlloc = kSmem > kSmemMin ? kSmem : kSmemMin;
+  static_assert(kSmemAlloc*kWgPerCu <= 160*1024, "LDS budget");
 };
 
 // AT: 0 = A used as stored, 1 = PReLU + gLN affine applied while staging.
@@ -63,12 +83,18 @@ template <int KP, int NSL, int WM, int EM, int AT, bool CAT, int NW = 8>
 __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) {
   using C = GemmWsCfg<KP, NSL, WM, NW>;
   static_assert(C::ACH >= 1, "tile too small for the workgroup");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[C::kSmem];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::kSmemAlloc];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem);
   float* Cw_all = reinterpret_cast<float*>(smem + C::kA);
   float* scs = reinterpret_cast<float*>(smem + C::kA + C::kC);      // [KP] scale
   float* shs = scs + KP;                                             // [KP] shift
 
+#ifdef BRV_DIAG
+  long long t_entry;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");
+  long long r_entry;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_entry) :: "memory");
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / C::WN, wn = wid % C::WN;
   const int fr = lane & 31, fh = lane >> 5;
@@ -95,8 +121,16 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
   const int tpi = ceil_div(T, C::BMW);                 // tiles per item
   const int total = tpi*p.batch;
   const int per = ceil_div(total, (int)gridDim.x);
+#ifdef BRV_DIAG
+  if ((p.dbg & 256) && gridDim.y > 1 && blockIdx.y == 0) return;   // only the second column group runs
+  if ((p.dbg & 32) && blockIdx.x < gridDim.x/2) return;       // only the later-dispatched half runs
+  if ((p.dbg & 128) && blockIdx.x >= gridDim.x/2) return;     // only the first half runs
+  const int t_begin = ((p.dbg & 16) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x)*per;
+#else
   const int t_begin = blockIdx.x*per;
+#endif
   const int t_end = min(total, t_begin + per);
+  const int t_items = tpi*C::BMW;                      // frame count rounded up to tiles
 
   // ---- A staging geometry (fixed k chunk per thread) -------------------------------
   constexpr int CPR = KP/8;                            // chunks per frame
@@ -108,8 +142,14 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
   const bool first = !CAT || kbase < a.K0;
   const unsigned int akoff = (unsigned int)((first ? kbase : kbase - a.K0)*2);
 
-  auto load_tile = [&](int tile, bool valid, uint4 (&araw)[C::ACH]) {
-    const int b = tile / tpi, t0 = (tile % tpi)*C::BMW;
+#ifdef BRV_DIAG
+  const int dbg = p.dbg;                               // ablation flags (tools/ablate.py)
+#else
+  constexpr int dbg = 0;
+#endif
+  // (b, t0) = item and first frame of the tile; `valid` false -> every lane reads zeros
+  auto load_tile = [&](int b, int t0, bool valid, uint4 (&araw)[C::ACH]) {
+    if (dbg & 8) valid = false;
     const __amdgpu_buffer_rsrc_t r0 = make_rsrc(
         reinterpret_cast<const bf16_t*>(a.p0) + (long long)b*a.bs0,
         valid ? (long long)T*a.ld0*2 : 0);
@@ -128,8 +168,7 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
       }
     }
   };
-  auto store_tile = [&](int tile, int buf, const uint4 (&araw)[C::ACH]) {
-    const int t0 = (tile % tpi)*C::BMW;
+  auto store_tile = [&](int t0, int buf, const uint4 (&araw)[C::ACH]) {
     bf16_t* dst = As + buf*C::BMW*C::LDA;
     float sc[8], sh[8];
     if (AT == 1) {
@@ -176,53 +215,84 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
   };
 
   // ---- epilogue state (wave-private) -------------------------------------------------
+  // The MFMA runs as D^T = W * A^T: a lane holds ONE frame (lane & 31) and, per 32-channel
+  // chunk, four runs of 4 consecutive channels -> the accumulators go to the staging
+  // tile as 16-byte LDS writes and come back as rows of 8 channels per lane.
   constexpr int CH = NSL/8;                            // 8-column chunks per staged row
   constexpr int RPP = 64/CH;                           // rows per pass
   constexpr int NPASS = 32/RPP;
   const int ech = lane % CH, erow0 = lane / CH;
   const int ncol = blockIdx.y*C::NP + wn*NSL + ech*8;  // global output column of the chunk
-  float biasv[8], gam[8];
+  // bias: folded into the accumulator initialisation (register i of chunk f is channel
+  // 32f + (i & 3) + 8(i >> 2) + 4(lane >> 5) of this wave's slice)
+  constexpr bool kBias = EM == E_STORE || EM == E_RES_SKIP;
+  float bias_r[kBias ? C::NF : 1][16];
+  if (kBias) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { biasv[j] = 0.f; gam[j] = 0.f; }
-  if (EM == E_STORE) load8_masked(e.bias, ncol, e.N, biasv);
-  const bool is_res = EM == E_RES_SKIP && ncol < e.Nsplit;
-  if (EM == E_RES_SKIP) {
-    if (is_res) load8_masked(e.bias, ncol, e.N, biasv);
-    else load8_masked(e.bias2, ncol - e.Nsplit, e.N2, biasv);
+    for (int f = 0; f < C::NF; ++f)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = blockIdx.y*C::NP + wn*NSL + 32*f + (i & 3) + 8*(i >> 2) + 4*fh;
+        const bool second = EM == E_RES_SKIP && n >= e.Nsplit;
+        const float* bp = second ? e.bias2 : e.bias;
+        const int idx = second ? n - e.Nsplit : n;
+        int lim = second ? e.N2 : e.N;
+        // unconditional (clamped) load + select: the 16*NF loads stay in flight together;
+        // a missing bias reads the weights instead and is masked to zero
+        if (bp == nullptr) { bp = reinterpret_cast<const float*>(p.W); lim = 0; }
+        const float x = bp[idx < lim ? idx : (lim > 0 ? lim - 1 : 0)];
+        bias_r[f][i] = idx < lim ? x : 0.f;
+      }
   }
+  float gam[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) gam[j] = 0.f;
+  const bool is_res = EM == E_RES_SKIP && ncol < e.Nsplit;
   if (EM == E_GLN_BWD) load8_masked(e.gamma, ncol, e.N, gam);
-  // slope 1 makes prelu() the identity: no "has a slope" branch inside the loop
   const float eslope = (EM == E_GLN_BWD && e.src_slope) ? *e.src_slope
                      : (EM == E_STORE && e.stats_slope ? *e.stats_slope : 1.f);
+  // prelu(r) = c1*r + c2*|r|: two VALU ops (|r| is a source modifier), no compare/select
+  const float c1 = 0.5f*(1.f + eslope), c2 = 0.5f*(1.f - eslope);
   const bool want_stats = EM == E_STORE && e.stats_out != nullptr;
-  float cmask[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) cmask[j] = (want_stats && ncol + j < e.N) ? 1.f : 0.f;
   const float skip_keep = (EM == E_RES_SKIP && !e.skip_init) ? 1.f : 0.f;
   double st_sum = 0.0, st_sq = 0.0;
   int st_item = -1;
-  float colA[8], colB[8];
+  f32x2 colA[4], colB[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { colA[j] = 0.f; colB[j] = 0.f; }
+  for (int j = 0; j < 4; ++j) { colA[j] = f32x2{0.f, 0.f}; colB[j] = f32x2{0.f, 0.f}; }
 
   auto flush_stats = [&]() {
     if (st_item < 0) return;
     if (want_stats || EM == E_GLN_BWD) {
       const double s0 = wave_sum(st_sum), s1 = wave_sum(st_sq);
       double* dst = (EM == E_STORE) ? e.stats_out : e.sums_out;
-      if (lane == 0) {
-        atomic_add_f64(dst + 2*st_item, s0);
-        atomic_add_f64(dst + 2*st_item + 1, s1);
+      if (lane == 0 && !(dbg & 1024)) {
+        atomic_add_f64(dst + stat_sum(st_item), s0);
+        atomic_add_f64(dst + stat_sq(st_item), s1);
       }
     }
     st_sum = 0.0; st_sq = 0.0;
   };
 
-  // compute + epilogue of one tile whose A operand sits in LDS buffer `buf`
-  auto process_tile = [&](int tile, bool valid, int buf) {
-    const int b = valid ? tile / tpi : (t_end - 1) / tpi;
-    const int t0 = (tile % tpi)*C::BMW + 32*wm;
-    const long long recs = valid ? 1 : 0;
+#ifdef BRV_DIAG
+  long long cyc_mfma = 0, cyc_epi = 0, cyc_stage = 0, cyc_total0 = 0;
+  auto stamp = [&]() -> long long {
+    long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+  };
+#define BRV_STAMP(expr) do { if (dbg & 64) { expr; } } while (0)
+#else
+#define BRV_STAMP(expr) do { } while (0)
+#endif
+  // compute + epilogue of one tile (item b, first frame t0w for this wave) whose A
+  // operand sits in LDS buffer `buf`
+  auto process_tile = [&](int b, int t0, int buf) {
+#ifdef BRV_DIAG
+    long long ts0 = 0, ts1 = 0;
+#endif
+    BRV_STAMP(ts0 = stamp());
+    const long long recs = (dbg & 1) ? 0 : 1;
     // per-item descriptors: frames >= T fall outside and are dropped / read as zero
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(
         reinterpret_cast<const bf16_t*>(e.out) + (long long)b*T*e.ldo, recs*T*e.ldo*2);
@@ -259,128 +329,164 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
 #pragma unroll
     for (int f = 0; f < C::NF; ++f)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[f][i] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[f][i] = kBias ? bias_r[kBias ? f : 0][i] : 0.f;
     const bf16_t* abuf = As + buf*C::BMW*C::LDA + (32*wm + fr)*C::LDA + 8*fh;
+    if (!(dbg & 4))
 #pragma unroll
     for (int s = 0; s < C::KS; ++s) {
       const bf16x8 af = *reinterpret_cast<const bf16x8*>(abuf + 16*s);
 #pragma unroll
       for (int f = 0; f < C::NF; ++f)
-        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[f][s], acc[f], 0, 0, 0);
+        acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[f][s], af, acc[f], 0, 0, 0);
+    }
+    if (dbg & 2) {
+      if (acc[0][0] == 123.456f) Cw[0] = acc[0][1];     // keep the MFMAs alive
+      return;
     }
     // accumulators -> this wave's private fp32 staging tile [32 frames][NSL]
 #pragma unroll
     for (int f = 0; f < C::NF; ++f)
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        Cw[((i & 3) + 8*(i >> 2) + 4*fh)*C::LDW + 32*f + fr] = acc[f][i];
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(Cw + fr*C::LDW + 32*f + 8*g + 4*fh) =
+            make_float4(acc[f][4*g], acc[f][4*g + 1], acc[f][4*g + 2], acc[f][4*g + 3]);
 
-    if (valid && b != st_item) { flush_stats(); st_item = b; }
-    NormStat es = {0.f, 1.f};
-    if (EM == E_GLN_BWD) es = norm_stat(e.src_stats, b, e.inv_n, e.eps);
+    BRV_STAMP(ts1 = stamp(); cyc_mfma += ts1 - ts0);
+    if (b != st_item) { flush_stats(); st_item = b; }
+    float mrs = 0.f;                                    // -mean*rstd
+    float rstd = 1.f;
+    if (EM == E_GLN_BWD) {
+      const NormStat es = norm_stat(e.src_stats, b, e.inv_n, e.eps);
+      rstd = es.rstd; mrs = -es.mean*es.rstd;
+    }
 
+    float tile_s = 0.f, tile_q = 0.f;
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       const int row = erow0 + RPP*pass;
       const unsigned int t = (unsigned int)(t0 + row);
-      float v[8];
-      {
-        const float4 lo = *reinterpret_cast<const float4*>(Cw + row*C::LDW + ech*8);
-        const float4 hi = *reinterpret_cast<const float4*>(Cw + row*C::LDW + ech*8 + 4);
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
-        v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-      }
+      const float4 lo = *reinterpret_cast<const float4*>(Cw + row*C::LDW + ech*8);
+      const float4 hi = *reinterpret_cast<const float4*>(Cw + row*C::LDW + ech*8 + 4);
+      f32x2 v[4] = {f32x2{lo.x, lo.y}, f32x2{lo.z, lo.w}, f32x2{hi.x, hi.y}, f32x2{hi.z, hi.w}};
       const unsigned int ooff = (t*(unsigned int)e.ldo + (unsigned int)ncol)*2u;
       if (EM == E_STORE) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += biasv[j];
-        const uint4 q = pack8(v);
+        const uint4 q = pack8v(v);
         buf_store16(rout, ooff, q);
-        float r[8]; unpack8(q, r);
-        const float rm = (valid && (int)t < T) ? 1.f : 0.f;
-        float ls = 0.f, lq = 0.f;
+        if (want_stats) {                               // wave-uniform, VALU only inside
+          float r[8]; unpack8(q, r);
+          f32x2 ls = {0.f, 0.f}, lq = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pv = rm*cmask[j]*prelu(r[j], eslope);
-          ls += pv; lq += pv*pv;
+          for (int j = 0; j < 4; ++j) {
+            f32x2 pv;
+            pv.x = __builtin_fmaf(c2, __builtin_fabsf(r[2*j]), c1*r[2*j]);
+            pv.y = __builtin_fmaf(c2, __builtin_fabsf(r[2*j + 1]), c1*r[2*j + 1]);
+            ls += pv; lq += pv*pv;
+          }
+          // frames past the end of the item hold the bias, not zero: mask the row
+          const float rm = (int)t < T ? 1.f : 0.f;
+          tile_s = __builtin_fmaf(rm, ls.x + ls.y, tile_s);
+          tile_q = __builtin_fmaf(rm, lq.x + lq.y, tile_q);
         }
-        st_sum += ls; st_sq += lq;
       } else if (EM == E_RES_SKIP) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += biasv[j];
         if (is_res) {                               // wave-uniform
           float r[8];
           unpack8(comp0[pass], r);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += r[j];
-          buf_store16(rout, ooff, pack8(v));
+          for (int j = 0; j < 4; ++j) v[j] += f32x2{r[2*j], r[2*j + 1]};
+          buf_store16(rout, ooff, pack8v(v));
         } else {
           const uint4 c0 = comp0[pass];
-          const uint4 c1 = comp1[(EM == E_RES_SKIP) ? pass : 0];
-          v[0] += skip_keep*__uint_as_float(c0.x); v[1] += skip_keep*__uint_as_float(c0.y);
-          v[2] += skip_keep*__uint_as_float(c0.z); v[3] += skip_keep*__uint_as_float(c0.w);
-          v[4] += skip_keep*__uint_as_float(c1.x); v[5] += skip_keep*__uint_as_float(c1.y);
-          v[6] += skip_keep*__uint_as_float(c1.z); v[7] += skip_keep*__uint_as_float(c1.w);
+          const uint4 c1q = comp1[(EM == E_RES_SKIP) ? pass : 0];
+          const f32x2 keep = {skip_keep, skip_keep};
+          v[0] += keep*f32x2{__uint_as_float(c0.x), __uint_as_float(c0.y)};
+          v[1] += keep*f32x2{__uint_as_float(c0.z), __uint_as_float(c0.w)};
+          v[2] += keep*f32x2{__uint_as_float(c1q.x), __uint_as_float(c1q.y)};
+          v[3] += keep*f32x2{__uint_as_float(c1q.z), __uint_as_float(c1q.w)};
           const unsigned int so = (t*(unsigned int)e.ld_skip + (unsigned int)(ncol - e.Nsplit))*4u;
-          buf_store16(rc1, so, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]),
-                                          __float_as_uint(v[2]), __float_as_uint(v[3])));
-          buf_store16(rc1, so + 16u, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]),
-                                                __float_as_uint(v[6]), __float_as_uint(v[7])));
+          buf_store16(rc1, so, make_uint4(__float_as_uint(v[0].x), __float_as_uint(v[0].y),
+                                          __float_as_uint(v[1].x), __float_as_uint(v[1].y)));
+          buf_store16(rc1, so + 16u, make_uint4(__float_as_uint(v[2].x), __float_as_uint(v[2].y),
+                                                __float_as_uint(v[3].x), __float_as_uint(v[3].y)));
         }
       } else if (EM == E_GLN_BWD) {
-        float s[8], o[8];
+        float s[8];
         unpack8(comp0[pass], s);
         // A rows past the end are zero, so v == 0 there: no row mask needed
-        float l1 = 0.f, l2 = 0.f;
+        f32x2 l1 = {0.f, 0.f}, l2 = {0.f, 0.f}, o[4];
+        const f32x2 rs2 = {rstd, rstd}, mrs2 = {mrs, mrs};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pv = prelu(s[j], eslope);
-          const float xh = (pv - es.mean)*es.rstd;
-          const float ev = gam[j]*v[j];
+        for (int j = 0; j < 4; ++j) {
+          f32x2 pv;
+          pv.x = __builtin_fmaf(c2, __builtin_fabsf(s[2*j]), c1*s[2*j]);
+          pv.y = __builtin_fmaf(c2, __builtin_fabsf(s[2*j + 1]), c1*s[2*j + 1]);
+          const f32x2 xh = pv*rs2 + mrs2;
+          const f32x2 ev = f32x2{gam[2*j], gam[2*j + 1]}*v[j];
           o[j] = ev;
           l1 += ev; l2 += ev*xh;
           colA[j] += v[j]*xh; colB[j] += v[j];
         }
-        st_sum += l1; st_sq += l2;
-        buf_store16(rout, ooff, pack8(o));
+        tile_s += l1.x + l1.y; tile_q += l2.x + l2.y;
+        buf_store16(rout, ooff, pack8v(o));
       } else if (EM == E_ADD) {
         float r[8];
         unpack8(comp0[pass], r);                    // zeros when add_in is null
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += r[j];
-        buf_store16(rout, ooff, pack8(v));
+        for (int j = 0; j < 4; ++j) v[j] += f32x2{r[2*j], r[2*j + 1]};
+        buf_store16(rout, ooff, pack8v(v));
       }
     }
+    st_sum += (double)tile_s; st_sq += (double)tile_q;
+    BRV_STAMP(cyc_epi += stamp() - ts1);
   };
 
-  // ---- main loop: ONE copy of the tile body (code size is a first-order cost: these
-  // kernels run ~40 us and a cold instruction fetch costs ~1 us per KiB), A prefetched
-  // one tile ahead behind counted waits ------------------------------------------------
+  // ---- main loop: A prefetched one tile ahead behind counted waits; (b, t0) of the
+  // current and the next tile advance incrementally (no integer division per tile) ------
   uint4 araw[C::ACH];
   if (t_begin < t_end) {
-    load_tile(t_begin, true, araw);
+    int b_cur = t_begin / tpi, t_cur = (t_begin % tpi)*C::BMW;
+    load_tile(b_cur, t_cur, true, araw);
+    if (EM == E_STORE) {
+      // vmcnt bookkeeping: the compiler merges the wait state of the loop entry with the
+      // back edge; the same number of younger VMEM ops on both paths keeps the wait on
+      // the A prefetch counted (vmcnt(NPASS)) instead of a full drain of the stores
+      const __amdgpu_buffer_rsrc_t rnull = make_rsrc(e.out, 0);
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) buf_store16(rnull, kOob - 32u*pass, make_uint4(pass, 0, 0, 0));
+    }
     int buf = 0;
+    BRV_STAMP(cyc_total0 = stamp());
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile, buf ^= 1) {
-      update_affine(tile / tpi);
-      store_tile(tile, buf, araw);
+#ifdef BRV_DIAG
+      long long tq = 0;
+#endif
+      BRV_STAMP(tq = stamp());
+      update_affine(b_cur);
+      store_tile(t_cur, buf, araw);
       __syncthreads();
-      load_tile(tile + 1, tile + 1 < t_end, araw);
-      process_tile(tile, true, buf);
+      int b_nxt = b_cur, t_nxt = t_cur + C::BMW;
+      if (t_nxt >= t_items) { t_nxt = 0; ++b_nxt; }
+      const bool more = tile + 1 < t_end;
+      load_tile(more ? b_nxt : b_cur, t_nxt, more, araw);
+      BRV_STAMP(cyc_stage += stamp() - tq);
+      process_tile(b_cur, t_cur + 32*wm, buf);
+      b_cur = b_nxt; t_cur = t_nxt;
     }
   }
   flush_stats();
   if (EM == E_GLN_BWD) {
     // column sums: reduce over the lanes that share a chunk (same lane % CH)
+    float ca[8], cb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float x = colA[j], y = colB[j];
+      float x = (j & 1) ? colA[j >> 1].y : colA[j >> 1].x;
+      float y = (j & 1) ? colB[j >> 1].y : colB[j >> 1].x;
 #pragma unroll
       for (int off = 32; off >= CH; off >>= 1) {
         x += __shfl_xor(x, off, 64);
         y += __shfl_xor(y, off, 64);
       }
-      colA[j] = x; colB[j] = y;
+      ca[j] = x; cb[j] = y;
     }
     if (lane < CH) {
       const long long ro = e.n_rep > 1 ? (long long)(blockIdx.x % e.n_rep)*e.rep_stride : 0;
@@ -388,12 +494,24 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
       for (int j = 0; j < 8; ++j) {
         const int n = ncol + j;
         if (n < e.N) {
-          atomic_add_f32(e.dgamma + ro + n, colA[j]);
-          atomic_add_f32(e.dbeta + ro + n, colB[j]);
+          atomic_add_f32(e.dgamma + ro + n, ca[j]);
+          atomic_add_f32(e.dbeta + ro + n, cb[j]);
         }
       }
     }
   }
+#ifdef BRV_DIAG
+  if ((dbg & 64) && p.dbg_out && lane == 0) {
+    long long* o = p.dbg_out + ((long long)(blockIdx.y*gridDim.x + blockIdx.x)*NW + wid)*4;
+    if (wid == 1) {
+      long long r_exit;
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_exit) :: "memory");
+      o[0] = stamp() - t_entry; o[1] = r_exit - r_entry; o[2] = r_entry; o[3] = r_exit;
+    }
+    else if (wid == 2) { o[0] = KP; o[1] = gridDim.x; o[2] = EM; o[3] = t_end - t_begin; }
+    else { o[0] = cyc_stage; o[1] = cyc_mfma; o[2] = cyc_epi; o[3] = stamp() - cyc_total0; }
+  }
+#endif
 }
 
 }  // namespace brv

@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p) {
   const double r0 = block_sum(s_sum, dscr);
   const double r1 = block_sum(s_sq, dscr + 8);
   if (tid == 0) {
-    atomic_add_f64(p.stats2 + 2*b, r0);
-    atomic_add_f64(p.stats2 + 2*b + 1, r1);
+    atomic_add_f64(p.stats2 + stat_sum(b), r0);
+    atomic_add_f64(p.stats2 + stat_sq(b), r1);
   }
 }
 
@@ -149,7 +149,8 @@ struct DzParams {
   int B, T, Cp, C;
   const float* slope; const double* stats; const double* sums;
   double inv_n; float eps;
-  float* dslope;
+  float* dslope;           // replicated (kReplicas copies rep_stride floats apart)
+  long long rep_stride;
 };
 
 __global__ __launch_bounds__(256) void dz_kernel(const DzParams p) {
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(256) void dz_kernel(const DzParams p) {
   const long long per_item = (long long)p.T*cpr;
   const int b = blockIdx.y;
   const NormStat ns = norm_stat(p.stats, b, p.inv_n, p.eps);
-  const float m1 = (float)(p.sums[2*b]*p.inv_n);
-  const float m2 = (float)(p.sums[2*b + 1]*p.inv_n);
+  const float m1 = (float)(p.sums[stat_sum(b)]*p.inv_n);
+  const float m2 = (float)(p.sums[stat_sq(b)]*p.inv_n);
   const float a = *p.slope;
   float da = 0.f;
 #pragma unroll 1
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(256) void dz_kernel(const DzParams p) {
     *reinterpret_cast<uint4*>(p.e + off) = pack8(o);
   }
   const float s = block_sum(da, fscr);
-  if (tid == 0) atomic_add_f32(p.dslope, s);
+  // one copy per 128-byte line: same-line atomics serialise (~12 ns each)
+  if (tid == 0) atomic_add_f32(p.dslope + (long long)(blockIdx.x % kReplicas)*p.rep_stride, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -322,8 +324,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
   const double r0 = block_sum(s1, dscr);
   const double r1 = block_sum(s2, dscr + 8);
   if (tid == 0) {
-    atomic_add_f64(p.sums1 + 2*b, r0);
-    atomic_add_f64(p.sums1 + 2*b + 1, r1);
+    atomic_add_f64(p.sums1 + stat_sum(b), r0);
+    atomic_add_f64(p.sums1 + stat_sq(b), r1);
   }
 }
 
@@ -337,17 +339,27 @@ struct VgradParams {
   long long blk0_off;        // flat offset of block 0's conv.weight
   long long blk_full;        // floats per (non-last) block
   long long o_dconv_w, o_dconv_b, o_n1_g_full, o_n1_g_last;   // offsets inside a block
+  long long tcn_prelu_off;   // PReLU slopes: slot 0 = tcn, 1+2i / 2+2i = block i (right after n2_b)
 };
 __global__ __launch_bounds__(256) void vgrad_reduce_kernel(const VgradParams p) {
   const long long per_blk = (long long)p.H*(5 + p.P);
-  const long long total = 2LL*p.N + per_blk*p.nb;
+  const long long n_vec = 2LL*p.N + per_blk*p.nb;
+  const long long total = n_vec + 1 + 2*p.nb;
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < total;
        i += (long long)gridDim.x*256) {
     float s = 0.f;
 #pragma unroll 8
     for (int r = 0; r < kReplicas; ++r) s += p.vg[(long long)r*p.rep_stride + i];
     long long dst;
-    if (i < 2LL*p.N) {
+    if (i >= n_vec) {                              // PReLU slopes
+      const int k = (int)(i - n_vec);
+      if (k == 0) dst = p.tcn_prelu_off;
+      else {                                       // the two slopes follow n2_b
+        const int blk = (k - 1) >> 1;
+        const long long n1 = blk == p.nb - 1 ? p.o_n1_g_last : p.o_n1_g_full;
+        dst = p.blk0_off + blk*p.blk_full + n1 + 4LL*p.H + ((k - 1) & 1);
+      }
+    } else if (i < 2LL*p.N) {
       dst = p.ln_g_off + i;                        // ln_g then ln_b are adjacent
     } else {
       const long long j = i - 2LL*p.N;
@@ -379,8 +391,8 @@ __global__ __launch_bounds__(256) void gln0_bwd_combine_kernel(const CombinePara
   const long long per_item = (long long)p.T*cpr;
   const int b = blockIdx.y;
   const NormStat ns = norm_stat(p.stats, b, p.inv_n, p.eps);
-  const float m1 = (float)(p.sums[2*b]*p.inv_n);
-  const float m2 = (float)(p.sums[2*b + 1]*p.inv_n);
+  const float m1 = (float)(p.sums[stat_sum(b)]*p.inv_n);
+  const float m2 = (float)(p.sums[stat_sq(b)]*p.inv_n);
   for (long long i = (long long)blockIdx.x*256 + tid; i < per_item;
        i += (long long)gridDim.x*256) {
     const int c0 = (int)(i % cpr)*8;
