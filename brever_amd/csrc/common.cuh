@@ -76,10 +76,17 @@ __device__ __forceinline__ T block_sum(T v, T* scratch) {
   return r;
 }
 
+// BRV_NO_ATOMICS (timing experiments only, results are wrong): bit 0 drops the f64 adds,
+// bit 1 the f32 adds -- the time that disappears is what the atomics cost.
+#ifndef BRV_NO_ATOMICS
+#define BRV_NO_ATOMICS 0
+#endif
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+  if (BRV_NO_ATOMICS & 1) return;
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  if (BRV_NO_ATOMICS & 2) return;
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

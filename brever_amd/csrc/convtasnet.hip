@@ -15,6 +15,7 @@
 #include "gemm_rows.cuh"
 #include "gemm_wgrad.cuh"
 #include "gemm_ws.cuh"
+#include "gemm_wgrad_full.cuh"
 #include "prep.cuh"
 #include "tcn_kernels.cuh"
 
@@ -735,6 +736,33 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
   }
   // deferred weight gradients of all blocks: two grouped launches
+  // residual / skip convs of every block in ONE launch when the padded widths are the
+  // default 128 | 128 (gemm_wgrad_full.cuh); other architectures use the generic path
+  const bool full_rs = l.Bnp == 128 && l.Scp == 128 && l.Hp % W2_BH == 0 && l.nb <= kWgMaxProb &&
+                       !getenv("BRV_NO_WGRAD_FULL");
+  if (full_rs) {
+    WgradFullParams fp; memset(&fp, 0, sizeof(fp));
+    fp.B = B; fp.T = (int)T; fp.nprob = l.nb; fp.n_htiles = l.Hp/W2_BH;
+    fp.ldg0 = l.Bnp; fp.bsg0 = T*l.Bnp; fp.ldg1 = ldg; fp.bsg1 = T*ldg;
+    fp.ldh = l.Hp; fp.bsh = T*l.Hp;
+    fp.N0 = l.Bn; fp.N1 = l.Sc; fp.Kout = l.H; fp.ldo = l.H;
+    fp.inv_n = 1.0/((double)T*l.H); fp.eps = 1e-8f;
+    for (int i = 0; i < l.nb; ++i) {
+      const BlockOff& b = l.blk[i];
+      WgradProb& pr = fp.prob[i];
+      const bool has_res = i < l.nb - 1;
+      pr.g0 = has_res ? gcopy(i) : nullptr; pr.g1 = gskip; pr.h = z2buf(i);
+      pr.out0 = has_res ? grads + b.res_w : nullptr; pr.out1 = grads + b.skip_w;
+      pr.gbias0 = has_res ? grads + b.res_b : nullptr; pr.gbias1 = grads + b.skip_b;
+      pr.slope = params + b.prelu2; pr.stats = stat(2 + 2*i);
+      pr.gamma = params + b.n2_g; pr.beta = params + b.n2_b;
+    }
+    ProfScope prof("pw2_wgrad", 2.0*l.nb*BT*(double)(l.Bnp + l.Scp)*l.Hp,
+                   2.0*BT*(l.Bnp + l.Scp + l.Hp)*l.nb, st);
+    const int grid = 8*ceil_div(l.nb, 8)*fp.n_htiles;
+    hipLaunchKernelGGL(wgrad_full_kernel, dim3(grid), dim3(256), 0, st, fp);
+    HIP_OK(hipGetLastError());
+  }
   for (int i0 = 0; i0 < l.nb; i0 += kWgMaxProb) {
     const int n = std::min(kWgMaxProb, l.nb - i0);
     // [res | skip]: G = [g_out_i | g_skip], H = gLN_2(prelu_2(z2_i)); the last block has
@@ -759,10 +787,10 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
       pr.gamma = params + b.n2_g; pr.beta = params + b.n2_b;
     }
     gp.nprob = np;
-    if (np > 0)
+    if (np > 0 && !full_rs)
       if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw2_wgrad",
                                              2.0*BT*(l.Bnp + l.Scp + l.Hp))) return r;
-    if (i0 + n == l.nb) {             // last block: skip conv only
+    if (i0 + n == l.nb && !full_rs) {             // last block: skip conv only
       const BlockOff& b = l.blk[l.nb - 1];
       memset(&wg, 0, sizeof(wg));
       wg.g = rows_bf16(gskip, ldg, T);
