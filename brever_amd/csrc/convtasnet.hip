@@ -266,7 +266,7 @@ int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st,
     if (EM == E_RES_SKIP && p.Kp == 512 && p.Np == 256 && full && one_src)
       return launch_gemm_ws<512, 32, 1, E_RES_SKIP, 1, false>(p, batch, st);
     if (EM == E_GLN_BWD && p.Kp == 256 && p.Np == 512 && plain && one_src)
-      return launch_gemm_ws<256, 32, 1, E_GLN_BWD, 0, false, 4>(p, batch, st);
+      return launch_gemm_ws<256, 32, 1, E_GLN_BWD, 0, false, 8>(p, batch, st);
   }
   if (p.Kp % GR_BK != 0 || p.Np % 64 != 0) return fail(-1, "gemm_rows: unpadded dims");
   if (p.Np % 128 == 0) return launch_gemm_rows_t<128, AK, EM>(p, batch, st);

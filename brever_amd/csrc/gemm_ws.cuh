@@ -25,32 +25,6 @@
 
 namespace brv {
 
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((ext_vector_type(2))) float f32x2;     // v_pk_{add,mul,fma}_f32 operands
-
-__device__ __forceinline__ uint4 pack8v(const f32x2 (&v)[4]) {
-  uint4 q;
-  q.x = pack2(v[0].x, v[0].y); q.y = pack2(v[1].x, v[1].y);
-  q.z = pack2(v[2].x, v[2].y); q.w = pack2(v[3].x, v[3].y);
-  return q;
-}
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long long bytes) {
-  const unsigned int n = bytes < 0 ? 0u : (bytes > 0xffffffffLL ? 0xffffffffu : (unsigned int)bytes);
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
-}
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned int off) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned int off, const uint4& q) {
-  u32x4 v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
-#ifndef BRV_STORE_AUX
-#define BRV_STORE_AUX 0
-#endif
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, 0, BRV_STORE_AUX);
-}
-constexpr unsigned int kOob = 0xfffffff0u;     // offset that is out of range for any descriptor
 
 template <int KP, int NSL, int WM, int NW = 8>
 struct GemmWsCfg {

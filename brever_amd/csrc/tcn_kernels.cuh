@@ -57,6 +57,7 @@ __device__ __forceinline__ int dw_xcd_remap(int id, int nwg) {
 template <int P>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p) {
   __shared__ double dscr[16];
+  __shared__ float wcs[P + 1][512];        // per-tap constant terms (+ bias) of 512 channels
   constexpr int DW_RPW = DW_TT_F/4;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = p.T;
@@ -68,9 +69,20 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p) {
   const float a1 = *p.slope1, a2 = *p.slope2;
   double s_sum = 0.0, s_sq = 0.0;
 
+  // PReLU_1 + gLN_1 + tap weight folded per channel:
+  //   w_k*(gamma*rstd*prelu(z) + beta - mean*rstd*gamma) = wa_k*z + wb_k*|z| + wc_k
+  // (prelu(z) = c1*z + c2*|z|): two FMAs per tap and element, |z| is a source modifier.
+  // Taps outside [0, T) read zeros through the item's buffer descriptor, which removes
+  // the z terms; the constant terms of the valid taps are summed per frame (uniform).
+  const float c1 = 0.5f*(1.f + a1), c2 = 0.5f*(1.f - a1);
+  const float d1 = 0.5f*(1.f + a2), d2 = 0.5f*(1.f - a2);     // statistics of PReLU_2
   for (int c0 = lane*8; c0 < p.Cp; c0 += 512) {
-    float sc[8], sh[8], bs[8], w[P][8];
+    // constant terms: `call` = bias + all taps (interior frames, in registers); the
+    // per-tap values are needed only at the item's edges and wait in LDS
+    float call[8], wa[P][8], wb[P][8];
+    __syncthreads();                                       // previous chunk's readers done
     {
+      float bs[8];
       float g8[8], b8[8], tp[P][8];
       load8_masked(p.gamma1, c0, p.C, g8);
       load8_masked(p.beta1, c0, p.C, b8);
@@ -80,58 +92,80 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p) {
       for (int k = 0; k < P; ++k) load8_masked(p.taps, c0*P + 8*k, p.C*P, tp[k]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        sc[j] = ns.rstd*g8[j];
-        sh[j] = b8[j] - ns.mean*ns.rstd*g8[j];
+        const float sc = ns.rstd*g8[j];
+        const float sh = b8[j] - ns.mean*ns.rstd*g8[j];
+        call[j] = bs[j];
 #pragma unroll
-        for (int k = 0; k < P; ++k) w[k][j] = tp[(j*P + k)/8][(j*P + k)%8];
+        for (int k = 0; k < P; ++k) {
+          const float w = tp[(j*P + k)/8][(j*P + k)%8];
+          wa[k][j] = w*c1*sc; wb[k][j] = w*c2*sc;
+          call[j] += w*sh;
+          if (wid == 0) wcs[k][lane*8 + j] = w*sh;
+        }
+        if (wid == 0) wcs[P][lane*8 + j] = bs[j];
       }
     }
-    const bf16_t* zin = p.z1 + (long long)b*T*p.Cp + c0;
-    bf16_t* zout = p.z2 + (long long)b*T*p.Cp + c0;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.z1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.z2 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+    const unsigned int coff = (unsigned int)(c0*2);
+    const unsigned int row = (unsigned int)(p.Cp*2);
+#pragma unroll 1
     for (int i0 = 0; i0 < DW_RPW; i0 += 4) {
       uint4 raw[4][P];
-      bool ok[4][P];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int t = tw0 + i0 + u;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-          const int ti = t + k*p.dil - p.left;
-          ok[u][k] = t < T && ti >= 0 && ti < T;   // outside: zero padding of gLN output
-          const int tc = ti < 0 ? 0 : (ti >= T ? T - 1 : ti);
-          raw[u][k] = *reinterpret_cast<const uint4*>(zin + (long long)tc*p.Cp);
+          const int ti = t + k*p.dil - p.left;            // < 0 wraps to a huge offset: zeros
+          raw[u][k] = buf_load16(rin, (unsigned int)ti*row + coff);
         }
       }
+      float ls = 0.f, lq = 0.f;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int t = tw0 + i0 + u;
         float acc[8];
+        if (t - p.left >= 0 && t + (P - 1)*p.dil - p.left < T) {     // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bs[j];
+          for (int j = 0; j < 8; ++j) acc[j] = call[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = wcs[P][lane*8 + j];
+#pragma unroll
+          for (int k = 0; k < P; ++k) {
+            const int ti = t + k*p.dil - p.left;
+            if (ti >= 0 && ti < T) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[j] += wcs[k][lane*8 + j];
+            }
+          }
+        }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
           float f[8];
           unpack8(raw[u][k], f);
-          const float on = ok[u][k] ? 1.f : 0.f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            acc[j] += on*w[k][j]*(prelu(f[j], a1)*sc[j] + sh[j]);
-        }
-        if (t < T) {
-          const uint4 q = pack8(acc);
-          *reinterpret_cast<uint4*>(zout + (long long)t*p.Cp) = q;
-          float r[8]; unpack8(q, r);
-          float ls = 0.f, lq = 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            if (c0 + j < p.C) {
-              const float pv = prelu(r[j], a2);
-              ls += pv; lq += pv*pv;
-            }
+            acc[j] = __builtin_fmaf(wa[k][j], f[j], acc[j]);
+            acc[j] = __builtin_fmaf(wb[k][j], __builtin_fabsf(f[j]), acc[j]);
           }
-          s_sum += ls; s_sq += lq;
         }
+        const uint4 q = pack8(acc);
+        buf_store16(rout, (unsigned int)t*row + coff, q);      // t >= T: dropped
+        float r[8]; unpack8(q, r);
+        const float live = t < T ? 1.f : 0.f;
+        float fs = 0.f, fq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // padded channels have zero taps, bias and affine: r == 0 there, no mask needed
+          const float pv = __builtin_fmaf(d2, __builtin_fabsf(r[j]), d1*r[j]);
+          fs += pv; fq = __builtin_fmaf(pv, pv, fq);
+        }
+        ls = __builtin_fmaf(live, fs, ls); lq = __builtin_fmaf(live, fq, lq);
       }
+      s_sum += ls; s_sq += lq;
     }
   }
   const double r0 = block_sum(s_sum, dscr);
