@@ -239,108 +239,118 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
   const float a1 = *p.slope1;
   double s1 = 0.0, s2 = 0.0;
 
+  // gLN_1 input statistics as scalars: xh = (prelu(z) - mean)*rstd = xa*z + xb*|z| + xc
+  const float xa = 0.5f*(1.f + a1)*ns.rstd, xb = 0.5f*(1.f - a1)*ns.rstd, xc = -ns.mean*ns.rstd;
+  // tap whose output frame is the input frame itself (the centre tap of a "same" padding):
+  // its dz2 doubles as the centre value of the bias gradient
+  int kc = -1;
+#pragma unroll
+  for (int k = 0; k < P; ++k) if (k*p.dil == p.left) kc = k;
+
   for (int cb = 0; cb < p.Cp; cb += 512) {
     const int c0 = cb + lane*8;
     const bool lane_ok = c0 < p.Cp;
-    float sc[8], sh[8], gm[8], w[P][8];
+    f32x2 gm[4], be[4], w[P][4];
     {
-      float b8[8], tp[P][8];
-      load8_masked(p.gamma1, c0, p.C, gm);
+      float g8[8], b8[8], tp[P][8];
+      load8_masked(p.gamma1, c0, p.C, g8);
       load8_masked(p.beta1, c0, p.C, b8);
 #pragma unroll
       for (int k = 0; k < P; ++k) load8_masked(p.taps, c0*P + 8*k, p.C*P, tp[k]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        sc[j] = ns.rstd*gm[j];
-        sh[j] = b8[j] - ns.mean*ns.rstd*gm[j];
+      for (int j = 0; j < 4; ++j) {
+        gm[j] = f32x2{g8[2*j], g8[2*j + 1]};
+        be[j] = f32x2{b8[2*j], b8[2*j + 1]};
 #pragma unroll
-        for (int k = 0; k < P; ++k) w[k][j] = tp[(j*P + k)/8][(j*P + k)%8];
+        for (int k = 0; k < P; ++k)
+          w[k][j] = f32x2{tp[(2*j*P + k)/8][(2*j*P + k)%8], tp[((2*j + 1)*P + k)/8][((2*j + 1)*P + k)%8]};
       }
     }
-    float dgam[8], dbet[8], dbia[8], dtap[P][8];
+    f32x2 dgam[4], dbet[4], dbia[4], dtap[P][4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      dgam[j] = 0.f; dbet[j] = 0.f; dbia[j] = 0.f;
+    for (int j = 0; j < 4; ++j) {
+      dgam[j] = f32x2{0.f, 0.f}; dbet[j] = f32x2{0.f, 0.f}; dbia[j] = f32x2{0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < P; ++k) dtap[k][j] = 0.f;
+      for (int k = 0; k < P; ++k) dtap[k][j] = f32x2{0.f, 0.f};
     }
-    const long long base = (long long)b*T*p.Cp + c0;
-    if (lane_ok) {
-      for (int i0 = 0; i0 < DW_RPW; i0 += 2) {
-        // raw[u][k]: dz2 at the output frame that reads frame t through tap k
-        // (forward: z2[t'] += w[k]*h1n[t' + k*dil - left], so t' = t - k*dil + left).
-        // The same values serve the data gradient (sum_k w[k]*dz2[t']) and, paired with
-        // h1n at frame t itself, the tap gradient: sum_t' dz2[t']*h1n[t'+shift] re-indexed
-        // over t = t'+shift. No shifted read of z1 is needed.
-        uint4 raw[2][P];
-        bool okd[2][P];
+    // frames outside [0, T) read zeros through the item's descriptors; a frame t >= T gets
+    // out-of-range offsets for ALL its loads, so every contribution of that frame vanishes
+    const __amdgpu_buffer_rsrc_t rdz = make_rsrc(p.dz2 + (long long)b*T*p.Cp, lane_ok ? (long long)T*p.Cp*2 : 0);
+    const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(p.z1 + (long long)b*T*p.Cp, lane_ok ? (long long)T*p.Cp*2 : 0);
+    const __amdgpu_buffer_rsrc_t re1 = make_rsrc(p.e1 + (long long)b*T*p.Cp, lane_ok ? (long long)T*p.Cp*2 : 0);
+    const unsigned int coff = (unsigned int)(c0*2), row = (unsigned int)(p.Cp*2);
+    float l1 = 0.f, l2 = 0.f;
+#pragma unroll 1
+    for (int i0 = 0; i0 < DW_RPW; i0 += 2) {
+      // raw[u][k]: dz2 at the output frame that reads frame t through tap k
+      // (forward: z2[t'] += w[k]*h1n[t' + k*dil - left], so t' = t - k*dil + left).
+      // The same values serve the data gradient (sum_k w[k]*dz2[t']) and, paired with
+      // h1n at frame t itself, the tap gradient: sum_t' dz2[t']*h1n[t'+shift] re-indexed
+      // over t = t'+shift. No shifted read of z1 is needed.
+      uint4 raw[2][P], rawz[2], rawc[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = tw0 + i0 + u;
+      for (int u = 0; u < 2; ++u) {
+        const int t = tw0 + i0 + u;
+        const bool live = t < T;
 #pragma unroll
-          for (int k = 0; k < P; ++k) {
-            const int to = t - (k*p.dil - p.left);
-            okd[u][k] = t < T && to >= 0 && to < T;
-            const int toc = to < 0 ? 0 : (to >= T ? T - 1 : to);
-            raw[u][k] = *reinterpret_cast<const uint4*>(p.dz2 + base + (long long)toc*p.Cp);
+        for (int k = 0; k < P; ++k) {
+          const int to = t - (k*p.dil - p.left);
+          raw[u][k] = buf_load16(rdz, live ? (unsigned int)to*row + coff : kOob);
+        }
+        rawz[u] = buf_load16(rz1, (unsigned int)t*row + coff);
+        rawc[u] = buf_load16(rdz, kc < 0 ? (unsigned int)t*row + coff : kOob);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = tw0 + i0 + u;
+        float zc[8];
+        unpack8(rawz[u], zc);
+        f32x2 xh[4], hn[4], dh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[j].x = __builtin_fmaf(xb, __builtin_fabsf(zc[2*j]), __builtin_fmaf(xa, zc[2*j], xc));
+          xh[j].y = __builtin_fmaf(xb, __builtin_fabsf(zc[2*j + 1]), __builtin_fmaf(xa, zc[2*j + 1], xc));
+          hn[j] = gm[j]*xh[j] + be[j];                  // gLN_1 output at frame t
+          dh[j] = f32x2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+          float g[8];
+          unpack8(raw[u][k], g);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x2 gk = {g[2*j], g[2*j + 1]};
+            dh[j] += w[k][j]*gk;
+            dtap[k][j] += gk*hn[j];
+            if (k == kc) dbia[j] += gk;                 // wave-uniform
           }
         }
-        uint4 rawc[2][2];
+        if (kc < 0) {
+          float g[8];
+          unpack8(rawc[u], g);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = tw0 + i0 + u;
-          const int tcl = t < T ? t : T - 1;
-          rawc[u][0] = *reinterpret_cast<const uint4*>(p.dz2 + base + (long long)tcl*p.Cp);
-          rawc[u][1] = *reinterpret_cast<const uint4*>(p.z1 + base + (long long)tcl*p.Cp);
+          for (int j = 0; j < 4; ++j) dbia[j] += f32x2{g[2*j], g[2*j + 1]};
         }
+        f32x2 o[4], a1s = {0.f, 0.f}, a2s = {0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = tw0 + i0 + u;
-          const float live = t < T ? 1.f : 0.f;
-          float zc[8], dzc[8], dh[8], hp[8], hn[8];
-          unpack8(rawc[u][1], zc);
-          unpack8(rawc[u][0], dzc);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            dbia[j] += live*dzc[j];
-            dh[j] = 0.f;
-            hp[j] = prelu(zc[j], a1);              // prelu_1 output at frame t
-            hn[j] = live*(hp[j]*sc[j] + sh[j]);    // gLN_1 output at frame t
-          }
-#pragma unroll
-          for (int k = 0; k < P; ++k) {
-            float g[8];
-            unpack8(raw[u][k], g);
-            const float ond = okd[u][k] ? 1.f : 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float gk = ond*g[j];
-              dh[j] += w[k][j]*gk;
-              dtap[k][j] += gk*hn[j];
-            }
-          }
-          if (t < T) {
-            float o[8];
-            float l1 = 0.f, l2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float xh = (hp[j] - ns.mean)*ns.rstd;
-              const float ev = gm[j]*dh[j];
-              o[j] = ev;
-              l1 += ev; l2 += ev*xh;
-              dgam[j] += dh[j]*xh; dbet[j] += dh[j];
-            }
-            s1 += l1; s2 += l2;
-            *reinterpret_cast<uint4*>(p.e1 + base + (long long)t*p.Cp) = pack8(o);
-          }
+        for (int j = 0; j < 4; ++j) {
+          const f32x2 ev = gm[j]*dh[j];
+          o[j] = ev;
+          a1s += ev; a2s += ev*xh[j];
+          dgam[j] += dh[j]*xh[j]; dbet[j] += dh[j];
         }
+        l1 += a1s.x + a1s.y; l2 += a2s.x + a2s.y;
+        buf_store16(re1, (unsigned int)t*row + coff, pack8v(o));     // t >= T: dropped
       }
     }
+    s1 += l1; s2 += l2;
     // per-channel reductions over the 4 waves, then one atomic per channel and quantity
-    auto reduce_cols = [&](const float (&v)[8], float* dst, int stride, int offset) {
+    auto reduce_cols = [&](const f32x2 (&v)[4], float* dst, int stride, int offset) {
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 8; ++j) red[wid*512 + lane*8 + j] = v[j];
+      for (int j = 0; j < 4; ++j) {
+        red[wid*512 + lane*8 + 2*j] = v[j].x; red[wid*512 + lane*8 + 2*j + 1] = v[j].y;
+      }
       __syncthreads();
       float* rdst = dst + (long long)(blockIdx.x % kReplicas)*p.rep_stride;
       for (int cc = tid; cc < 512; cc += 256) {
