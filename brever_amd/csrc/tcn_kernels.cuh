@@ -40,8 +40,8 @@ struct DwParams {
 // gradient block and vgrad_reduce_kernel folds the copies into the real gradient.
 constexpr int kReplicas = 64;
 
-constexpr int DW_TT_F = 32;    // forward: frames per workgroup (4 waves x 8 frames)
-constexpr int DW_TT_B = 64;    // backward: 4 waves x 16 frames (fewer per-channel atomics)
+constexpr int DW_TT_F = 32;    // forward: frames per workgroup (4 waves x 8 frames; 64 measured slower)
+constexpr int DW_TT_B = 128;   // backward: 4 waves x 32 frames (64: more per-channel atomics; 256: too few workgroups)
 
 // Workgroup id -> (item, frame tile): the work list is cut into 8 contiguous chunks,
 // one per XCD (ids congruent mod 8 share an XCD), so the tiles whose dilated taps
