@@ -75,6 +75,33 @@ def cpu_baseline():
     }
 
 
+# bench label -> substring of the HIP kernel name in the rocprofv3 output
+KERNEL_OF_LABEL = {
+    'gln_prelu_bwd': 'dz_kernel', 'dwconv_bwd': 'dwconv_bwd_kernel',
+    'dwconv_fwd': 'dwconv_fwd_kernel', 'pw2_wgrad': 'wgrad_full_kernel',
+    'pw1_fwd': 'gemm_ws_kernel<128, 64, 1, 0,', 'pw2_fwd': 'gemm_ws_kernel<512,',
+    'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': 'gemm_rows_kernel<128, 0, 5>',
+}
+
+
+def pmc_traffic(label):
+    """HBM bytes per launch of the kernel behind `label`, from the committed rocprofv3
+    PMC passes (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    separate passes, same bench command). bench.py cannot run the profiler on itself;
+    None when the file or the kernel is missing."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                        'r01_pmc_hbm_traffic.json')
+    key = KERNEL_OF_LABEL.get(label)
+    if key is None or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        kernels = json.load(f)['kernels']
+    for name, v in kernels.items():
+        if key in name:
+            return v['hbm_traffic_MB']*1e6
+    return None
+
+
 def kernel_roofline(model, batches, scaler, steps=3):
     """Event-timed steps (HIP events around every launch, on the launch stream):
     roofline of the kernel with the largest total time."""
@@ -104,7 +131,8 @@ def kernel_roofline(model, batches, scaler, steps=3):
         'peak': PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
         'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
         'frac': (gbs/PEAK_HBM_GBS) if hbm_bound else (tfs/PEAK_MFMA_TFLOPS),
-        'traffic': None,
+        'traffic': pmc_traffic(label),
+        'traffic_source': 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, bytes per launch)',
         'avg_launch_us': avg_s*1e6,
         'launches_per_step': top['calls']/steps,
         'algorithmic_bytes_per_launch': nbytes,
