@@ -331,9 +331,11 @@ template <int P> struct DwFwd {
 };
 template <int P> struct DwBwd {
   static int run(const DwParams& p, hipStream_t st) {
-    ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 6.0*p.B*p.T*(double)p.Cp, st);
+    const bool fuse = p.z2in != nullptr;
+    ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, (fuse ? 8.0 : 6.0)*p.B*p.T*(double)p.Cp, st);
     dim3 grid(ceil_div(p.T, DW_TT_B)*p.B);
-    hipLaunchKernelGGL((dwconv_bwd_kernel<P>), grid, dim3(256), 0, st, p);
+    if (fuse) hipLaunchKernelGGL((dwconv_bwd_kernel<P, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dwconv_bwd_kernel<P, false>), grid, dim3(256), 0, st, p);
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -701,12 +703,17 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
     g.e.sums_out = sum(2 + 2*i);
     if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + 2*l.Hp))) return r;
-    // gLN_2 + prelu_2 backward -> dz2 (in place)
+    // gLN_2 + prelu_2 backward: fused into the depthwise backward below (dz2 is rebuilt at
+    // each tap from e2 and z2 and never written). Opt-in (BRV_DZ_FUSE=1): rebuilding dz2 three
+    // times makes the stencil VALU-bound, 84 us vs 51 + 37 us for the two passes -- a wash
+    static const bool fuse_dz2 = getenv("BRV_DZ_FUSE") != nullptr;
     DzParams dz; memset(&dz, 0, sizeof(dz));
-    dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
-    dz.slope = params + b.prelu2; dz.stats = stat(2 + 2*i); dz.sums = sum(2 + 2*i);
-    dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 2 + 2*i; dz.rep_stride = ws.vg_stride;
-    if (int r = launch_dz(dz, st)) return r;
+    if (!fuse_dz2) {
+      dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
+      dz.slope = params + b.prelu2; dz.stats = stat(2 + 2*i); dz.sums = sum(2 + 2*i);
+      dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 2 + 2*i; dz.rep_stride = ws.vg_stride;
+      if (int r = launch_dz(dz, st)) return r;
+    }
     // depthwise conv backward (data, taps, bias) + gLN_1 partials
     DwParams d; memset(&d, 0, sizeof(d));
     bf16_t* eB = eBbuf(i);
@@ -718,13 +725,23 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     d.dgamma1 = vslot(i); d.dbeta1 = vslot(i) + l.H;
     d.dtaps = vslot(i) + 4*l.H; d.dbias = vslot(i) + 4*l.H + (long long)l.H*l.P;
     d.rep_stride = ws.vg_stride; d.sums1 = sum(1 + 2*i);
+    if (fuse_dz2) {
+      d.z2in = z2buf(i); d.stats2 = stat(2 + 2*i); d.sums2 = sum(2 + 2*i);
+      d.slope2 = params + b.prelu2; d.dslope2 = vslope + 2 + 2*i;
+    }
     if (int r = dispatch_p<DwBwd>(l.P, d, st)) return r;
-    // gLN_1 + prelu_1 backward -> dz1 (in place)
-    memset(&dz, 0, sizeof(dz));
-    dz.e = eB; dz.z = z1buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
-    dz.slope = params + b.prelu1; dz.stats = stat(1 + 2*i); dz.sums = sum(1 + 2*i);
-    dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 1 + 2*i; dz.rep_stride = ws.vg_stride;
-    if (int r = launch_dz(dz, st)) return r;
+    // gLN_1 + prelu_1 backward -> dz1: fused into the A staging of the data-gradient GEMM
+    // below (A_DZ: dz1 is computed from e1 and z1 on load and written back over e1 for the
+    // deferred weight gradient); BRV_NO_DZ1_FUSE keeps the separate pass
+    // (needs one n-tile: the workgroup that stages an A element must be its only reader)
+    const bool fuse_dz1 = !getenv("BRV_NO_DZ1_FUSE") && (l.Bnp == 128 || l.Bnp == 64);
+    if (!fuse_dz1) {
+      memset(&dz, 0, sizeof(dz));
+      dz.e = eB; dz.z = z1buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
+      dz.slope = params + b.prelu1; dz.stats = stat(1 + 2*i); dz.sums = sum(1 + 2*i);
+      dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 1 + 2*i; dz.rep_stride = ws.vg_stride;
+      if (int r = launch_dz(dz, st)) return r;
+    }
     // first 1x1 conv: data gradient + residual path -> gradient wrt block input
     memset(&g, 0, sizeof(g));
     g.a = rows_bf16(eB, l.Hp, T);
@@ -733,6 +750,14 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     // block i-1's deferred [res | skip] weight gradient needs this g_out after gout is
     // overwritten again: keep a copy (16 MB per block at the BASELINE size)
     g.e.out2 = i > 0 ? gcopy(i - 1) : nullptr; g.e.ld_srcf = l.Bnp;
+    if (fuse_dz1) {
+      g.a.p1 = z1buf(i); g.a.ld1 = l.Hp; g.a.bs1 = T*l.Hp;
+      g.a.slope = params + b.prelu1; g.a.stats = stat(1 + 2*i); g.a.sums = sum(1 + 2*i);
+      g.a.inv_n = 1.0/((double)T*l.H); g.a.eps = 1e-8f; g.a.C = l.H;
+      g.e.dslope = vslope + 1 + 2*i; g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
+      if (int r = launch_gemm_rows<A_DZ, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(3*l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
+      continue;
+    }
     if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
   }
   // deferred weight gradients of all blocks: two grouped launches

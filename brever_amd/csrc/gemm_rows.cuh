@@ -20,7 +20,9 @@
 
 namespace brv {
 
-enum AKind { A_BF16 = 0, A_F32 = 1, A_FRAMES = 2 };
+// A_DZ: A = gLN/PReLU backward of (e = p0, z = p1), computed while staging and written back
+// over e (the separate gln_prelu_bwd pass of the first 1x1 conv's data gradient, fused)
+enum AKind { A_BF16 = 0, A_F32 = 1, A_FRAMES = 2, A_DZ = 3 };
 enum EMode {
   E_STORE = 0,     // + bias, store bf16, optional gLN statistics of [prelu](out)
   E_RES_SKIP = 1,  // res: out = res_in + v ; skip: skip (+)= v
@@ -46,6 +48,7 @@ struct ASpec {
   const double* stats;     // [B][2] or null (no affine)
   const float* gamma; const float* beta; int C;   // true channel count
   double inv_n; float eps;
+  const double* sums;      // A_DZ: per-item {sum e, sum e*xh} of the gLN backward
 };
 
 struct EpiSpec {
@@ -125,10 +128,17 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
   const ASpec& a = p.a;
 
   NormStat ns = {0.f, 1.f};
-  const bool affine = a.stats != nullptr;
-  if (affine) ns = norm_stat(a.stats, b, a.inv_n, a.eps);
+  const bool affine = AK != A_DZ && a.stats != nullptr;
+  if (a.stats != nullptr) ns = norm_stat(a.stats, b, a.inv_n, a.eps);
   const float slope = a.slope ? *a.slope : 1.f;
-  const bool has_prelu = a.slope != nullptr;
+  const bool has_prelu = AK != A_DZ && a.slope != nullptr;
+  // A_DZ: dz = prelu'(z)*rstd*(e - m1 - xh*m2), xh = (prelu(z) - mean)*rstd
+  float dz_m1 = 0.f, dz_m2 = 0.f, dz_da = 0.f;
+  if (AK == A_DZ) {
+    dz_m1 = (float)(a.sums[stat_sum(b)]*a.inv_n);
+    dz_m2 = (float)(a.sums[stat_sq(b)]*a.inv_n);
+  }
+  uint4 araw_z[(AK == A_DZ) ? 4 : 1];
 
   uint4 araw_b[4];
   float araw_f[(AK == A_BF16) ? 1 : 4][8];
@@ -166,7 +176,15 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
       for (int ci = 0; ci < 4; ++ci) {
         const int t = t0 + arow + 32*ci;
         const long long off = boff + (long long)t*ld + kk;
-        if (AK == A_BF16) {
+        if (AK == A_DZ) {
+          const long long o0 = (long long)b*a.bs0 + (long long)t*a.ld0 + kbase;
+          const long long o1 = (long long)b*a.bs1 + (long long)t*a.ld1 + kbase;
+          araw_b[ci] = (t < T) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.p0) + o0)
+                               : make_uint4(0, 0, 0, 0);
+          araw_z[(AK == A_DZ) ? ci : 0] =
+              (t < T) ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.p1) + o1)
+                      : make_uint4(0, 0, 0, 0);
+        } else if (AK == A_BF16) {
           const bf16_t* src = reinterpret_cast<const bf16_t*>(first ? a.p0 : a.p1);
           araw_b[ci] = (t < T) ? *reinterpret_cast<const uint4*>(src + off)
                                : make_uint4(0, 0, 0, 0);
@@ -204,12 +222,32 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
     }
   };
 
-  auto store_tile = [&]() {
+  auto store_tile = [&](int kt) {
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
       const int row = arow + 32*ci;
       uint4 q;
-      if (AK == A_BF16 && !affine && !has_prelu) {
+      if (AK == A_DZ) {
+        float ev[8], zv[8], o[8];
+        unpack8(araw_b[ci], ev);
+        unpack8(araw_z[(AK == A_DZ) ? ci : 0], zv);
+        const int kbase = kt*GR_BK + kc*8;
+        const bool live = t0 + row < T;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool pos = zv[j] > 0.f;
+          const float pv = pos ? zv[j] : slope*zv[j];
+          const float xh = (pv - ns.mean)*ns.rstd;
+          const float dh = ns.rstd*(ev[j] - dz_m1 - xh*dz_m2);
+          const bool ok = live && kbase + j < a.C;
+          o[j] = ok ? (pos ? dh : slope*dh) : 0.f;
+          if (ok && !pos) dz_da += dh*zv[j];
+        }
+        q = pack8(o);
+        if (live)       // in place: this workgroup is the only reader of these elements
+          *reinterpret_cast<uint4*>(const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(a.p0))
+              + (long long)b*a.bs0 + (long long)(t0 + row)*a.ld0 + kbase) = q;
+      } else if (AK == A_BF16 && !affine && !has_prelu) {
         q = araw_b[ci];
       } else {
         float f[8];
@@ -252,7 +290,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
   load_tile(0);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
-    store_tile();
+    store_tile(kt);
     __syncthreads();
     if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
@@ -441,6 +479,15 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
     const double s1 = block_sum(st_sq, dscr + 8);
     double* dst = (EM == E_STORE) ? e.stats_out : e.sums_out;
     if (tid == 0) { atomic_add_f64(dst + stat_sum(b), s0); atomic_add_f64(dst + stat_sq(b), s1); }
+  }
+  if (AK == A_DZ) {                          // slope gradient of the fused gLN/PReLU backward
+    __syncthreads();
+    float* fscr = reinterpret_cast<float*>(smem);
+    const float s0 = block_sum(dz_da, fscr);
+    if (tid == 0 && e.dslope) {
+      const long long ro = e.n_rep > 1 ? (long long)(blockIdx.x % e.n_rep)*e.rep_stride : 0;
+      atomic_add_f32(e.dslope + ro, s0);
+    }
   }
   if (EM == E_PRELU_BWD) {
     __syncthreads();

@@ -31,6 +31,9 @@ struct DwParams {
   double* stats2; const float* slope2;                   // fwd
   float* dgamma1; float* dbeta1; float* dtaps; float* dbias; double* sums1;   // bwd
   long long rep_stride;    // bwd: per-channel gradients go to replica (wg % kReplicas)
+  // bwd, fused gLN_2 / PReLU_2 backward: dz2 is rebuilt at every tap from e2 = gamma2*dy
+  // (passed in `dz2`) and z2, so the dz2 tensor never exists in HBM
+  const bf16_t* z2in; const double* sums2; float* dslope2;
 };
 
 // Per-channel gradients (norm gains/biases, depthwise taps/biases) are summed over
@@ -224,11 +227,12 @@ __global__ __launch_bounds__(256) void dz_kernel(const DzParams p) {
 }
 
 // ---------------------------------------------------------------------------
-template <int P>
+template <int P, bool FUSE>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
   __shared__ float red[4*512];
   __shared__ double dscr[16];
   constexpr int DW_RPW = DW_TT_B/4;
+  constexpr int UB = FUSE ? 1 : 2;         // frames in flight per wave (register budget)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = p.T;
   const int n_tt = ceil_div(T, DW_TT_B);
@@ -241,6 +245,17 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
 
   // gLN_1 input statistics as scalars: xh = (prelu(z) - mean)*rstd = xa*z + xb*|z| + xc
   const float xa = 0.5f*(1.f + a1)*ns.rstd, xb = 0.5f*(1.f - a1)*ns.rstd, xc = -ns.mean*ns.rstd;
+  // fused gLN_2 backward (FUSE): dz2 = prelu2'(z2)*rstd2*(e2 - m1 - xh2*m2) with
+  // xh2 = ya*z2 + yb*|z2| + yc; as u = e2*R + K0 - xh2*M2R
+  float ya = 0.f, yb = 0.f, yc = 0.f, R2 = 0.f, K0 = 0.f, M2R = 0.f, a2 = 1.f, da2 = 0.f;
+  if (FUSE) {
+    const NormStat n2 = norm_stat(p.stats2, b, p.inv_n, p.eps);
+    a2 = *p.slope2;
+    const float m1 = (float)(p.sums2[stat_sum(b)]*p.inv_n);
+    const float m2 = (float)(p.sums2[stat_sq(b)]*p.inv_n);
+    ya = 0.5f*(1.f + a2)*n2.rstd; yb = 0.5f*(1.f - a2)*n2.rstd; yc = -n2.mean*n2.rstd;
+    R2 = n2.rstd; K0 = -m1*n2.rstd; M2R = m2*n2.rstd;
+  }
   // tap whose output frame is the input frame itself (the centre tap of a "same" padding):
   // its dz2 doubles as the centre value of the bias gradient
   int kc = -1;
@@ -278,30 +293,35 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
     const __amdgpu_buffer_rsrc_t rdz = make_rsrc(p.dz2 + (long long)b*T*p.Cp, lane_ok ? (long long)T*p.Cp*2 : 0);
     const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(p.z1 + (long long)b*T*p.Cp, lane_ok ? (long long)T*p.Cp*2 : 0);
     const __amdgpu_buffer_rsrc_t re1 = make_rsrc(p.e1 + (long long)b*T*p.Cp, lane_ok ? (long long)T*p.Cp*2 : 0);
+    const __amdgpu_buffer_rsrc_t rz2 = make_rsrc(p.z2in + (long long)b*T*p.Cp,
+                                                 (FUSE && lane_ok) ? (long long)T*p.Cp*2 : 0);
     const unsigned int coff = (unsigned int)(c0*2), row = (unsigned int)(p.Cp*2);
     float l1 = 0.f, l2 = 0.f;
 #pragma unroll 1
-    for (int i0 = 0; i0 < DW_RPW; i0 += 2) {
+    for (int i0 = 0; i0 < DW_RPW; i0 += UB) {
       // raw[u][k]: dz2 at the output frame that reads frame t through tap k
       // (forward: z2[t'] += w[k]*h1n[t' + k*dil - left], so t' = t - k*dil + left).
       // The same values serve the data gradient (sum_k w[k]*dz2[t']) and, paired with
       // h1n at frame t itself, the tap gradient: sum_t' dz2[t']*h1n[t'+shift] re-indexed
       // over t = t'+shift. No shifted read of z1 is needed.
-      uint4 raw[2][P], rawz[2], rawc[2];
+      uint4 raw[UB][P], rawz[UB], rawc[UB], raw2[UB][FUSE ? P : 1], rawc2[UB];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < UB; ++u) {
         const int t = tw0 + i0 + u;
         const bool live = t < T;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
           const int to = t - (k*p.dil - p.left);
-          raw[u][k] = buf_load16(rdz, live ? (unsigned int)to*row + coff : kOob);
+          const unsigned int off = live ? (unsigned int)to*row + coff : kOob;
+          raw[u][k] = buf_load16(rdz, off);
+          if (FUSE) raw2[u][k] = buf_load16(rz2, off);
         }
         rawz[u] = buf_load16(rz1, (unsigned int)t*row + coff);
         rawc[u] = buf_load16(rdz, kc < 0 ? (unsigned int)t*row + coff : kOob);
+        if (FUSE) rawc2[u] = buf_load16(rz2, kc < 0 ? (unsigned int)t*row + coff : kOob);
       }
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < UB; ++u) {
         const int t = tw0 + i0 + u;
         float zc[8];
         unpack8(rawz[u], zc);
@@ -313,10 +333,29 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
           hn[j] = gm[j]*xh[j] + be[j];                  // gLN_1 output at frame t
           dh[j] = f32x2{0.f, 0.f};
         }
+        // dz2 of one loaded frame; `on` (wave-uniform) zeroes frames outside the item
+        // (their e2 / z2 read as zeros, which alone would leave the constant terms)
+        auto dz2_of = [&](const uint4& qe, const uint4& qz, float on, bool centre, float (&g)[8]) {
+          unpack8(qe, g);
+          if (!FUSE) return;
+          float z[8];
+          unpack8(qz, z);
+          const float r = on*R2, k0 = on*K0, m = -on*M2R;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xh2 = __builtin_fmaf(yb, __builtin_fabsf(z[j]), __builtin_fmaf(ya, z[j], yc));
+            const float uu = __builtin_fmaf(m, xh2, __builtin_fmaf(g[j], r, k0));
+            const bool pos = z[j] > 0.f;
+            g[j] = pos ? uu : a2*uu;
+            if (centre) da2 += pos ? 0.f : uu*z[j];      // slope gradient: each element once
+          }
+        };
 #pragma unroll
         for (int k = 0; k < P; ++k) {
+          const int to = t - (k*p.dil - p.left);
+          const float on = (t < T && to >= 0 && to < T) ? 1.f : 0.f;
           float g[8];
-          unpack8(raw[u][k], g);
+          dz2_of(raw[u][k], raw2[u][FUSE ? k : 0], on, k == kc, g);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const f32x2 gk = {g[2*j], g[2*j + 1]};
@@ -327,7 +366,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
         }
         if (kc < 0) {
           float g[8];
-          unpack8(rawc[u], g);
+          dz2_of(rawc[u], rawc2[u], t < T ? 1.f : 0.f, true, g);
 #pragma unroll
           for (int j = 0; j < 4; ++j) dbia[j] += f32x2{g[2*j], g[2*j + 1]};
         }
@@ -370,6 +409,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
   if (tid == 0) {
     atomic_add_f64(p.sums1 + stat_sum(b), r0);
     atomic_add_f64(p.sums1 + stat_sq(b), r1);
+  }
+  if (FUSE) {
+    __syncthreads();
+    const float sa = block_sum(da2, red);
+    if (tid == 0) atomic_add_f32(p.dslope2 + (long long)(blockIdx.x % kReplicas)*p.rep_stride, sa);
   }
 }
 
