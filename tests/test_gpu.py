@@ -458,3 +458,40 @@ def test_mel_filterbank_matches_reference(golden_dir):
     assert torch.allclose(fwd.cpu(), torch.from_numpy(g['mel_fwd']), rtol=1e-5, atol=1e-6)
     assert torch.allclose(mel.backward(fwd).cpu(), torch.from_numpy(g['mel_bwd']),
                           rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_rccl_gradient_sync_path_single_rank():
+    """The N > 1 bench path (init_process_group('nccl'), parameter broadcast, flat-gradient
+    all-reduce hook) executed with one rank -- all a 1-GPU box allows. With world 1 the
+    all-reduce is the identity, so the trajectory must equal the un-hooked one."""
+    import socket
+    import torch.distributed as dist
+    from brever_amd.models import ConvTasNet
+    from brever_amd.parallel import GradSynchronizer, broadcast_parameters
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    device = _cuda()
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+    try:
+        cfg = dict(filters=48, filter_length=16, bottleneck_channels=24, hidden_channels=40,
+                   skip_channels=16, kernel_size=3, layers=2, repeats=2)
+        g = torch.Generator().manual_seed(5)
+        batch = 0.1*torch.randn(3, 2, 1500, generator=g).to(device)
+        lengths = torch.tensor([1500, 1400, 900], device=device)
+        scaler = torch.amp.GradScaler('cuda', enabled=False)
+        losses = []
+        for hooked in (False, True):
+            torch.manual_seed(0)
+            net = ConvTasNet(**cfg).to(device)
+            if hooked:
+                broadcast_parameters(net)
+                sync = GradSynchronizer(net)
+                assert sync.flat_model
+            losses.append([float(net.train_step(batch, lengths, True, scaler)) for _ in range(3)])
+        assert losses[0] == losses[1], losses
+    finally:
+        dist.destroy_process_group()
