@@ -132,6 +132,101 @@ class _MseFunction(torch.autograd.Function):
         return dx.view(ctx.shape).to(ctx.in_dtype), None, None, None
 
 
+class _MultiResYuFunction(torch.autograd.Function):
+    """Masked time-domain L1 + multi-resolution STFT-magnitude L1, per (item, source)
+    row divided by the item length (brever/criterion.py:193-226, scale_invariant=False)."""
+
+    @staticmethod
+    def forward(ctx, x, y, lengths, stfts, time_w, spec_w):
+        from .modules.stft import _StftFunction
+        lib = hip.lib()
+        x2, y2, lengths, B, S, L = _rows(x, y, lengths)
+        rows = B*S
+        xm, ym = torch.empty_like(x2), torch.empty_like(y2)
+        for src, dst in ((x2, xm), (y2, ym)):
+            hip.check(lib.brv_apply_mask(hip.ptr(src), hip.ptr(lengths), hip.ptr(dst), B, S, L,
+                                         hip.stream()), 'brv_apply_mask')
+        sums = torch.empty(rows, dtype=torch.float64, device=x.device)
+        hip.check(lib.brv_l1_forward(hip.ptr(xm), hip.ptr(ym), hip.ptr(sums), rows, L,
+                                     hip.stream()), 'brv_l1_forward')
+        total = time_w*sums
+        specs = []
+        for stft in stfts:
+            basis, _, _ = stft._get_tables(x.device)
+            args = (basis, stft.frame_length, stft.hop_length, 1.0, stft.scale_factor)
+            with torch.no_grad():
+                X = _StftFunction.apply(xm.view(rows, L), *args)
+                Y = _StftFunction.apply(ym.view(rows, L), *args)
+            n = X.shape[-2]*X.shape[-1]
+            ssum = torch.empty(rows, dtype=torch.float64, device=x.device)
+            hip.check(lib.brv_mag_l1_forward(
+                hip.ptr(torch.view_as_real(X)), hip.ptr(torch.view_as_real(Y)), hip.ptr(ssum),
+                rows, n, hip.stream()), 'brv_mag_l1_forward')
+            total = total + (spec_w/len(stfts))*ssum
+            specs.append((X, Y))
+        total = total.view(B, S)/lengths.view(B, 1).double()
+        ctx.save_for_backward(xm, ym, lengths, *[t for pair in specs for t in pair])
+        ctx.meta = (stfts, time_w, spec_w, x.shape, x.dtype)
+        return total.mean(1).float()
+
+    @staticmethod
+    def backward(ctx, grad):
+        from .modules.stft import stft_adjoint
+        lib = hip.lib()
+        xm, ym, lengths, *flat = ctx.saved_tensors
+        stfts, time_w, spec_w, shape, in_dtype = ctx.meta
+        B, S, L = xm.shape
+        rows = B*S
+        # d loss[b] / d row (b, s) total = 1/(S*len_b)
+        grow = (grad.float()/(S*lengths.float())).repeat_interleave(S).contiguous()
+        dx = torch.empty_like(xm)
+        g_t = (time_w*grow).contiguous()
+        hip.check(lib.brv_l1_backward(hip.ptr(xm), hip.ptr(ym), hip.ptr(g_t), hip.ptr(dx), rows,
+                                      L, 0, hip.stream()), 'brv_l1_backward')
+        for k, stft in enumerate(stfts):
+            X, Y = flat[2*k], flat[2*k + 1]
+            n = X.shape[-2]*X.shape[-1]
+            g_s = (spec_w/len(stfts)*grow).contiguous()
+            dX = torch.empty(*X.shape, 2, dtype=torch.float32, device=X.device)
+            hip.check(lib.brv_mag_l1_backward(
+                hip.ptr(torch.view_as_real(X)), hip.ptr(torch.view_as_real(Y)), hip.ptr(g_s),
+                hip.ptr(dX), rows, n, hip.stream()), 'brv_mag_l1_backward')
+            basis, _, _ = stft._get_tables(X.device)
+            dx += stft_adjoint(dX, basis, rows, L, stft.frame_length, stft.hop_length,
+                               X.shape[-1], stft.scale_factor).view(B, S, L)
+        out = torch.empty_like(dx)
+        hip.check(lib.brv_apply_mask(hip.ptr(dx), hip.ptr(lengths), hip.ptr(out), B, S, L,
+                                     hip.stream()), 'brv_apply_mask')
+        return out.view(shape).to(in_dtype), None, None, None, None, None
+
+
+@CriterionRegistry.register('multiresyu')
+class MultiResYuLoss:
+    """Multi-resolution STFT magnitude + L1 time-domain loss
+    (brever/criterion.py:135-226): boxcar, un-normalised STFTs of ``frame_lengths`` /
+    ``hop_lengths`` (default: half the frame), ``(B, ..., L)`` -> ``(B,)``.
+    ``scale_invariant=True`` is not built yet on the HIP path."""
+
+    def __init__(self, frame_lengths=[512], hop_lengths=None, time_domain_weight=0.5,
+                 spectral_weight=0.5, scale_invariant=False):
+        from .modules.stft import STFT
+        if hop_lengths is None:
+            hop_lengths = [x // 2 for x in frame_lengths]
+        if scale_invariant:
+            raise NotImplementedError('scale_invariant=True is not built yet on the HIP path')
+        self.stfts = [STFT(frame_length=n, hop_length=h, window=None, normalized=False)
+                      for n, h in zip(frame_lengths, hop_lengths)]
+        self.time_domain_weight = time_domain_weight
+        self.spectral_weight = spectral_weight
+        self.scale_invariant = scale_invariant
+
+    def __call__(self, x, y, lengths):
+        assert x.shape == y.shape
+        return _MultiResYuFunction.apply(x, y, lengths, self.stfts,
+                                         float(self.time_domain_weight),
+                                         float(self.spectral_weight))
+
+
 @CriterionRegistry.register('sisnr')
 def sisnr(x, y, lengths):
     """PIT scale-invariant SNR, ``(B, S, L)`` -> ``(B,)``

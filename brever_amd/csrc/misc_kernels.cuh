@@ -274,4 +274,63 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const AdamParams a) {
   }
 }
 
+// ---- pieces of MultiResYuLoss (brever/criterion.py:135-226) ------------------
+// out[r][i] = i < lengths[r / S] ? x[r][i] : 0           (apply_mask, criterion.py:229-234)
+__global__ __launch_bounds__(256) void mask_rows_kernel(const float* x, const long long* lengths,
+                                                        float* out, int S, long long L) {
+  const int r = blockIdx.y;
+  long long len = lengths[r / S];
+  if (len > L) len = L;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < L; i += (long long)gridDim.x*256)
+    out[(long long)r*L + i] = i < len ? x[(long long)r*L + i] : 0.f;
+}
+// sums[r] += sum_i |x[r][i] - y[r][i]|  (fp64 accumulation, one atomic per workgroup)
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const float* x, const float* y, double* sums,
+                                                     long long n) {
+  __shared__ double scr[8];
+  const int r = blockIdx.y;
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256)
+    s += (double)fabsf(x[(long long)r*n + i] - y[(long long)r*n + i]);
+  s = block_sum(s, scr);
+  if (threadIdx.x == 0 && s != 0.0) atomic_add_f64(sums + r, s);
+}
+// dx[r][i] (+)= g[r]*sign(x - y)   (sign(0) = 0, as torch's abs backward)
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* x, const float* y, const float* g,
+                                                     float* dx, long long n, int accumulate) {
+  const int r = blockIdx.y;
+  const float gr = g[r];
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const float d = x[(long long)r*n + i] - y[(long long)r*n + i];
+    const float v = d > 0.f ? gr : (d < 0.f ? -gr : 0.f);
+    if (accumulate) dx[(long long)r*n + i] += v; else dx[(long long)r*n + i] = v;
+  }
+}
+// sums[r] += sum_i | |X[r][i]| - |Y[r][i]| |   over n complex values per row
+__global__ __launch_bounds__(256) void mag_l1_fwd_kernel(const float2* X, const float2* Y,
+                                                         double* sums, long long n) {
+  __shared__ double scr[8];
+  const int r = blockIdx.y;
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const float2 a = X[(long long)r*n + i], b = Y[(long long)r*n + i];
+    s += (double)fabsf(sqrtf(a.x*a.x + a.y*a.y) - sqrtf(b.x*b.x + b.y*b.y));
+  }
+  s = block_sum(s, scr);
+  if (threadIdx.x == 0 && s != 0.0) atomic_add_f64(sums + r, s);
+}
+// dX[r][i] = g[r]*sign(|X| - |Y|)*X/|X|   (0 where |X| = 0: the subgradient torch uses)
+__global__ __launch_bounds__(256) void mag_l1_bwd_kernel(const float2* X, const float2* Y,
+                                                         const float* g, float2* dX, long long n) {
+  const int r = blockIdx.y;
+  const float gr = g[r];
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const float2 a = X[(long long)r*n + i], b = Y[(long long)r*n + i];
+    const float ma = sqrtf(a.x*a.x + a.y*a.y), mb = sqrtf(b.x*b.x + b.y*b.y);
+    const float sg = ma > mb ? gr : (ma < mb ? -gr : 0.f);
+    const float inv = ma > 0.f ? sg/ma : 0.f;
+    dX[(long long)r*n + i] = make_float2(a.x*inv, a.y*inv);
+  }
+}
+
 }  // namespace brv

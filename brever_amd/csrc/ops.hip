@@ -150,6 +150,63 @@ int brv_mse_forward(const float* x, const float* y, const int64_t* lengths,
   return 0;
 }
 
+namespace {
+dim3 row_grid(int64_t rows, int64_t n, int per_thread) {
+  long long gx = (n + 256LL*per_thread - 1)/(256LL*per_thread);
+  if (gx < 1) gx = 1;
+  if (gx > 512) gx = 512;
+  return dim3((unsigned)gx, (unsigned)rows);
+}
+}  // namespace
+
+int brv_apply_mask(const float* x, const int64_t* lengths, float* out, int64_t B, int64_t S,
+                   int64_t L, brv_stream_t stream) {
+  if (B < 1 || S < 1 || L < 1) return -1;
+  hipLaunchKernelGGL(mask_rows_kernel, row_grid(B*S, L, 8), dim3(256), 0, (hipStream_t)stream,
+                     x, (const long long*)lengths, out, (int)S, (long long)L);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_l1_forward(const float* x, const float* y, double* sums, int64_t rows, int64_t n,
+                   brv_stream_t stream) {
+  if (rows < 1 || n < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  OPS_OK(hipMemsetAsync(sums, 0, (size_t)rows*sizeof(double), st));
+  hipLaunchKernelGGL(l1_fwd_kernel, row_grid(rows, n, 16), dim3(256), 0, st, x, y, sums, (long long)n);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_l1_backward(const float* x, const float* y, const float* grow, float* dx, int64_t rows,
+                    int64_t n, int accumulate, brv_stream_t stream) {
+  if (rows < 1 || n < 1) return -1;
+  hipLaunchKernelGGL(l1_bwd_kernel, row_grid(rows, n, 8), dim3(256), 0, (hipStream_t)stream,
+                     x, y, grow, dx, (long long)n, accumulate);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_mag_l1_forward(const float* xspec, const float* yspec, double* sums, int64_t rows,
+                       int64_t n, brv_stream_t stream) {
+  if (rows < 1 || n < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  OPS_OK(hipMemsetAsync(sums, 0, (size_t)rows*sizeof(double), st));
+  hipLaunchKernelGGL(mag_l1_fwd_kernel, row_grid(rows, n, 8), dim3(256), 0, st,
+                     (const float2*)xspec, (const float2*)yspec, sums, (long long)n);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_mag_l1_backward(const float* xspec, const float* yspec, const float* grow,
+                        float* dxspec, int64_t rows, int64_t n, brv_stream_t stream) {
+  if (rows < 1 || n < 1) return -1;
+  hipLaunchKernelGGL(mag_l1_bwd_kernel, row_grid(rows, n, 4), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)xspec, (const float2*)yspec, grow, (float2*)dxspec, (long long)n);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
 int brv_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                        int64_t n, float grad_scale, float max_norm, float lr, float beta1,
                        float beta2, float eps, int64_t step, void* scratch,

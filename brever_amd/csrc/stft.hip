@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const G32 p) {
 struct OlaParams {
   const float* frames; float* y; const float* win; int F, n, hop, out_len;
   long long f_bs, y_bs;
+  int normalize;             // 1: divide by the window-square envelope (torch.istft)
 };
 __global__ __launch_bounds__(256) void istft_ola_kernel(const OlaParams p) {
   const int b = blockIdx.y;
@@ -149,11 +150,10 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const OlaParams p) {
     for (int t = t_lo; t <= t_hi; ++t) {          // fixed order: deterministic
       const int m = pos - t*p.hop;
       if (m < 0 || m >= p.n) continue;
-      const float w = p.win[m];
       s += fr[(long long)t*p.n + m];
-      env += w*w;
+      if (p.normalize) { const float w = p.win[m]; env += w*w; }
     }
-    y[q] = s/env;
+    y[q] = p.normalize ? s/env : s;
   }
 }
 
@@ -212,7 +212,35 @@ int brv_istft_backward(const float* spec, const float* inv_basis, const float* w
   o.frames = frames_scratch; o.y = y; o.win = window; o.F = (int)frames;
   o.n = (int)frame_length; o.hop = (int)hop_length;
   o.out_len = (int)(hop_length*(frames - 1));
-  o.f_bs = (long long)frames*frame_length; o.y_bs = o.out_len;
+  o.f_bs = (long long)frames*frame_length; o.y_bs = o.out_len; o.normalize = 1;
+  int gx = (o.out_len + 255)/256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(istft_ola_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, o);
+  return (int)hipGetLastError();
+}
+
+// Adjoint of brv_stft_forward with respect to x (compression 1): the gradient of a loss
+// through the framed, zero-padded, windowed DFT,
+//   dx[r][q] = scale * sum_t sum_c dspec[r][c][t] * basis[c][q + n/2 - t*hop],  q < length,
+// as a GEMM (dspec^T x basis -> per-frame gradients) + plain overlap-add.
+int brv_stft_adjoint(const float* dspec, const float* basis, float* frames_scratch, float* dx,
+                     int64_t rows, int64_t length, int64_t frame_length, int64_t hop_length,
+                     float scale, brv_stream_t stream) {
+  const int64_t F = brv_stft_frames(length, frame_length, hop_length);
+  if (rows < 1 || F < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int bins = (int)(frame_length/2 + 1);
+  G32 p; memset(&p, 0, sizeof(p));
+  p.M = (int)F; p.N = (int)frame_length; p.K = 2*bins;
+  p.A = dspec; p.a_bs = (long long)bins*F*2; p.frames = (int)F;
+  p.inv_scale = scale; p.inv_comp = 1.f;                  // GA_SPEC_T multiplies by inv_scale
+  p.B = basis; p.b_bs = 0; p.ldb = (int)frame_length;     // basis[c][m], plain
+  p.D = frames_scratch; p.d_bs = (long long)F*frame_length; p.ldd = (int)frame_length;
+  if (int r = launch_g32<GA_SPEC_T, GB_PLAIN, GS_PLAIN>(p, (int)rows, st)) return r;
+  OlaParams o;
+  o.frames = frames_scratch; o.y = dx; o.win = nullptr; o.F = (int)F;
+  o.n = (int)frame_length; o.hop = (int)hop_length;
+  o.out_len = (int)length; o.normalize = 0;
+  o.f_bs = (long long)F*frame_length; o.y_bs = length;
   int gx = (o.out_len + 255)/256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
   hipLaunchKernelGGL(istft_ola_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, o);
   return (int)hipGetLastError();

@@ -71,6 +71,15 @@ SIGNATURES = {
                                           _c_f32, _c_ptr]),
     'brv_matmul_f32': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
                                       _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_stft_adjoint': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                        _c_i64, _c_i64, _c_f32, _c_ptr]),
+    'brv_apply_mask': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_l1_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
+    'brv_l1_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                       ctypes.c_int, _c_ptr]),
+    'brv_mag_l1_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
+    'brv_mag_l1_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                           _c_ptr]),
     'brv_clip_adam_step': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                           _c_i64, _c_f32, _c_f32, _c_f32,
                                           _c_f32, _c_f32, _c_f32, _c_i64,

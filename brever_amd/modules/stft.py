@@ -15,7 +15,9 @@ The transforms run in ``libbrever_hip.so`` as fp32 DFT-GEMMs on the exact-fp32 M
 (``brv_stft_forward`` / ``brv_istft_backward``); the window-weighted DFT bases are
 built here once per instance in float64 and cached per device. Limits of the HIP
 path for now: one-sided spectra, ``center=True``, constant padding, hop dividing the
-frame length, ``n_fft == frame_length``; forward values only (no autograd).
+frame length, ``n_fft == frame_length``. ``STFT.forward`` is differentiable when
+``compression_factor == 1`` (``brv_stft_adjoint``: the transposed DFT-GEMM followed by
+a plain overlap-add); ``STFT.backward`` and the filterbank give values only.
 """
 import functools
 import math
@@ -35,6 +37,46 @@ def fft_freqs(fs=16e3, n_fft=512, onesided=True):
         return freqs[~mask]
     freqs[mask] = freqs[mask] - fs
     return freqs
+
+
+class _StftFunction(torch.autograd.Function):
+    """x (rows, L) fp32 -> spec (rows, bins, F) complex64; gradient through
+    ``brv_stft_adjoint`` (compression 1 only)."""
+
+    @staticmethod
+    def forward(ctx, x2, basis, frame_length, hop_length, compression, scale):
+        lib = hip.lib()
+        rows, L = x2.shape
+        F = lib.brv_stft_frames(L, frame_length, hop_length)
+        bins = frame_length//2 + 1
+        spec = torch.empty(rows, bins, F, 2, dtype=torch.float32, device=x2.device)
+        hip.check(lib.brv_stft_forward(
+            hip.ptr(x2), hip.ptr(basis), hip.ptr(spec), rows, L, frame_length,
+            hop_length, float(compression), float(scale), hip.stream()), 'brv_stft_forward')
+        ctx.save_for_backward(basis)
+        ctx.geom = (rows, L, frame_length, hop_length, F, float(compression), float(scale))
+        return torch.view_as_complex(spec)
+
+    @staticmethod
+    def backward(ctx, grad):
+        basis, = ctx.saved_tensors
+        rows, L, n, hop, F, compression, scale = ctx.geom
+        if compression != 1:
+            raise NotImplementedError('gradient of the magnitude compression is not built yet '
+                                      'on the HIP path')
+        dspec = torch.view_as_real(grad.to(torch.complex64).contiguous())
+        dx = stft_adjoint(dspec, basis, rows, L, n, hop, F, scale)
+        return dx, None, None, None, None, None
+
+
+def stft_adjoint(dspec, basis, rows, L, frame_length, hop_length, frames, scale):
+    """dx (rows, L) = adjoint of the framed DFT applied to dspec (rows, bins, F, 2)."""
+    scratch = torch.empty(rows, frames, frame_length, dtype=torch.float32, device=dspec.device)
+    dx = torch.empty(rows, L, dtype=torch.float32, device=dspec.device)
+    hip.check(hip.lib().brv_stft_adjoint(
+        hip.ptr(dspec), hip.ptr(basis), hip.ptr(scratch), hip.ptr(dx), rows, L,
+        frame_length, hop_length, float(scale), hip.stream()), 'brv_stft_adjoint')
+    return dx
 
 
 class STFT:
@@ -125,12 +167,9 @@ class STFT:
         x2 = x.reshape(rows, L).float().contiguous()
         F = lib.brv_stft_frames(L, self.frame_length, self.hop_length)
         bins = self.frame_length//2 + 1
-        spec = torch.empty(rows, bins, F, 2, dtype=torch.float32, device=x.device)
-        hip.check(lib.brv_stft_forward(
-            hip.ptr(x2), hip.ptr(basis), hip.ptr(spec), rows, L, self.frame_length,
-            self.hop_length, float(self.compression_factor), float(self.scale_factor),
-            hip.stream()), 'brv_stft_forward')
-        out = torch.view_as_complex(spec).view(*lead, bins, F)
+        out = _StftFunction.apply(x2, basis, self.frame_length, self.hop_length,
+                                  self.compression_factor, self.scale_factor)
+        out = out.view(*lead, bins, F)
         if return_type == 'complex':
             return out
         if return_type == 'real_imag':

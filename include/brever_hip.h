@@ -139,10 +139,32 @@ int brv_istft_backward(const float* spec, const float* inv_basis, const float* w
                        float* frames_scratch, float* y, int64_t rows, int64_t frames,
                        int64_t frame_length, int64_t hop_length, float compression,
                        float scale, brv_stream_t stream);
+/* Adjoint of brv_stft_forward wrt x for compression == 1 (autograd of STFT.forward,
+ * stft.py:59-99): dx (rows, length) from dspec (rows, n/2+1, frames) complex64;
+ * frames_scratch: rows*frames*frame_length floats. */
+int brv_stft_adjoint(const float* dspec, const float* basis, float* frames_scratch, float* dx,
+                     int64_t rows, int64_t length, int64_t frame_length, int64_t hop_length,
+                     float scale, brv_stream_t stream);
 /* d[b] = a[b or shared] (M x K) @ b[b] (K x N), fp32 (MelFilterbank.forward/backward,
  * stft.py:189-198). a_batch_stride = 0 shares one matrix across the batch. */
 int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,
                    int64_t N, int64_t K, int64_t a_batch_stride, brv_stream_t stream);
+
+/* ---- pieces of MultiResYuLoss (criterion.py:135-226) ----------------------------
+ * brv_apply_mask: out = x with samples >= lengths[b] zeroed (apply_mask, :229-234),
+ *   x/out (B, S, L). brv_l1_*: sums[r] = sum |x - y| over n samples of row r (fp64) and
+ *   dx (+)= grow[r]*sign(x - y). brv_mag_l1_*: the same on the magnitudes of complex64
+ *   rows of n values: sums[r] = sum ||X| - |Y||, dX = grow[r]*sign(|X|-|Y|)*X/|X|. */
+int brv_apply_mask(const float* x, const int64_t* lengths, float* out, int64_t B, int64_t S,
+                   int64_t L, brv_stream_t stream);
+int brv_l1_forward(const float* x, const float* y, double* sums, int64_t rows, int64_t n,
+                   brv_stream_t stream);
+int brv_l1_backward(const float* x, const float* y, const float* grow, float* dx, int64_t rows,
+                    int64_t n, int accumulate, brv_stream_t stream);
+int brv_mag_l1_forward(const float* xspec, const float* yspec, double* sums, int64_t rows,
+                       int64_t n, brv_stream_t stream);
+int brv_mag_l1_backward(const float* xspec, const float* yspec, const float* grow,
+                        float* dxspec, int64_t rows, int64_t n, brv_stream_t stream);
 
 /* ---- optimizer --------------------------------------------------------------
  * clip_grad_norm_(max_norm) + Adam.step (base.py:296-301, torch.optim.Adam with

@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure, not product code).
 
 CPU restatement in plain PyTorch of the length-masked losses of the reference,
-brever/criterion.py:21-132,229-234. Only ``tests/``, ``__graft_entry__.smoke``
+brever/criterion.py:21-234. Only ``tests/``, ``__graft_entry__.smoke``
 and the ``cpu_baseline`` leg of ``bench.py`` may import this module; the
 product path (``brever_amd``) never does.
 
@@ -70,4 +70,35 @@ def mse(x, y, lengths, weight=None):
     return err.mean(tuple(range(1, x.ndim - 1)))
 
 
-CRITERIA = {'snr': snr, 'sisnr': sisnr, 'mse': mse}
+def _boxcar_stft(x, frame_length, hop_length):
+    """STFT(window=None, normalized=False) of the reference (brever/modules/stft.py:59-99,
+    140-149): right-pad to whole frames, then torch.stft(center=True, constant padding)."""
+    L = x.shape[-1]
+    frames = -(-max(L - frame_length, 0)//hop_length) + 1
+    pad = (frames - 1)*hop_length + frame_length - L
+    x = torch.nn.functional.pad(x, (0, pad))
+    lead = x.shape[:-1]
+    out = torch.stft(x.reshape(-1, x.shape[-1]), n_fft=frame_length, hop_length=hop_length,
+                     window=torch.ones(frame_length, dtype=x.dtype), center=True,
+                     pad_mode='constant', normalized=False, onesided=True, return_complex=True)
+    return out.view(*lead, *out.shape[-2:])
+
+
+def multiresyu(x, y, lengths, frame_lengths=(512,), hop_lengths=None, time_domain_weight=0.5,
+               spectral_weight=0.5):
+    """Time-domain L1 + multi-resolution STFT-magnitude L1, divided by the item length
+    (brever/criterion.py:193-226, scale_invariant=False)."""
+    assert x.shape == y.shape
+    if hop_lengths is None:
+        hop_lengths = [n//2 for n in frame_lengths]
+    m = length_mask(x, lengths)
+    x, y = x*m, y*m
+    out = time_domain_weight*(x - y).abs().sum(-1)
+    for n, h in zip(frame_lengths, hop_lengths):
+        xm, ym = _boxcar_stft(x, n, h).abs(), _boxcar_stft(y, n, h).abs()
+        out = out + spectral_weight*(xm - ym).abs().sum((-2, -1))/len(frame_lengths)
+    out = out/lengths.view(-1, *[1]*(x.ndim - 2))
+    return out.mean(tuple(range(1, x.ndim - 1)))
+
+
+CRITERIA = {'snr': snr, 'sisnr': sisnr, 'mse': mse, 'multiresyu': multiresyu}

@@ -176,6 +176,16 @@ def golden_losses(out):
     xg = x.clone().requires_grad_(True)
     (CriterionRegistry.get('mse')(xg, y, lengths, weight=w)*gw).sum().backward()
     res['mse_weighted_grad'] = xg.grad.numpy()
+    # MultiResYuLoss (criterion.py:135-226): default single resolution and three resolutions
+    from brever.criterion import MultiResYuLoss
+    for tag, kw in (('multiresyu', {}),
+                    ('multiresyu3', dict(frame_lengths=[512, 256, 128], time_domain_weight=0.3,
+                                         spectral_weight=0.7))):
+        crit = MultiResYuLoss(**kw)
+        res[tag] = crit(x, y, lengths).numpy()
+        xg = x.clone().requires_grad_(True)
+        (crit(xg, y, lengths)*gw).sum().backward()
+        res[tag + '_grad'] = xg.grad.numpy()
     np.savez_compressed(os.path.join(out, 'losses.npz'), **res)
 
 

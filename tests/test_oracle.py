@@ -41,6 +41,23 @@ def test_losses_match_reference(golden_dir):
     assert torch.allclose(xg.grad, torch.from_numpy(g['snr_grad']), rtol=1e-4, atol=1e-8)
 
 
+def test_multiresyu_matches_reference(golden_dir):
+    """MultiResYuLoss values and gradients (default and 3 resolutions) vs the reference."""
+    g = np.load(os.path.join(golden_dir, 'losses.npz'))
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    lengths = torch.from_numpy(g['lengths'])
+    gw = torch.from_numpy(g['gweight'])
+    for tag, kw in (('multiresyu', {}),
+                    ('multiresyu3', dict(frame_lengths=[512, 256, 128], time_domain_weight=0.3,
+                                         spectral_weight=0.7))):
+        xg = x.clone().requires_grad_(True)
+        got = oc.multiresyu(xg, y, lengths, **kw)
+        assert torch.allclose(got, torch.from_numpy(g[tag]), rtol=1e-5, atol=1e-6), tag
+        (got*gw).sum().backward()
+        assert torch.allclose(xg.grad, torch.from_numpy(g[tag + '_grad']), rtol=1e-4,
+                              atol=1e-7), tag
+
+
 @pytest.mark.parametrize('name', ['snr', 'sisnr', 'mse'])
 def test_losses_batched_equals_per_item(name):
     """The reference's own property test (tests/test_losses.py:13-57)."""
