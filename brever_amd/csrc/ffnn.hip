@@ -1,0 +1,235 @@
+// Elementwise / small-reduction kernels of the FFNN mask model and its log-mel features.
+// Reference: brever/models/ffnn/ffnn.py:72-203 (transform, irm, stack, _FFNN,
+// StaticNormalizer, CumulativeNormalizer) and brever/modules/features.py:142-205 (fbe).
+// The dense parts (mel filterbank, Linear layers and their gradients) are brv_gemm_f32 /
+// brv_matmul_f32 in stft.hip. All tensors fp32, layouts as in the reference:
+// features/labels (B, rows, frames), spectra complex64 (B, channels, bins, frames).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/brever_hip.h"
+#include "common.cuh"
+
+using namespace brv;
+
+namespace {
+
+#define FF_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+dim3 flat_grid(long long n) {
+  long long g = (n + 255)/256;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  return dim3((unsigned)g);
+}
+#define GRID_STRIDE(i, n) \
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < (n); i += (long long)gridDim.x*256)
+
+// out[b][i] = mean_c |spec[b][c][i]|^2                      (features.py:186-188)
+__global__ __launch_bounds__(256) void fbe_power_kernel(const float2* spec, float* out, int C,
+                                                        long long n, long long total) {
+  GRID_STRIDE(idx, total) {
+    const long long b = idx / n, i = idx % n;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float2 v = spec[((long long)b*C + c)*n + i];
+      s += v.x*v.x + v.y*v.y;
+    }
+    out[idx] = s/(float)C;
+  }
+}
+// mode 1: log(x + eps); mode 2: x^(1/3)                      (features.py:194-198)
+__global__ __launch_bounds__(256) void compress_kernel(const float* x, float* out, long long n,
+                                                       int mode, float eps) {
+  GRID_STRIDE(i, n) out[i] = mode == 1 ? logf(x[i] + eps) : (mode == 2 ? cbrtf(x[i]) : x[i]);
+}
+// (1 + bg/(fg + eps))^(-1/2)                                 (ffnn.py:121-128)
+__global__ __launch_bounds__(256) void irm_kernel(const float* fg, const float* bg, float* out,
+                                                  long long n, float eps) {
+  GRID_STRIDE(i, n) out[i] = 1.f/sqrtf(1.f + bg[i]/(fg[i] + eps));
+}
+// out[b][k*nf + f][t] = x[b][f][max(t - k, 0)], k = 0..stacks        (ffnn.py:130-140)
+__global__ __launch_bounds__(256) void stack_kernel(const float* x, float* out, int nf, int T,
+                                                    int stacks, long long total) {
+  GRID_STRIDE(idx, total) {
+    const int t = (int)(idx % T);
+    const long long r = idx / T;
+    const int row = (int)(r % ((long long)(stacks + 1)*nf));
+    const long long b = r / ((long long)(stacks + 1)*nf);
+    const int k = row / nf, f = row % nf;
+    const int ts = t - k < 0 ? 0 : t - k;
+    out[idx] = x[((long long)b*nf + f)*T + ts];
+  }
+}
+// (x - mean[row])/std[row]                                    (ffnn.py:186-187)
+__global__ __launch_bounds__(256) void static_norm_kernel(const float* x, const float* mean,
+                                                          const float* stdv, float* out, int rows,
+                                                          int T, long long total) {
+  GRID_STRIDE(idx, total) {
+    const int row = (int)((idx / T) % rows);
+    out[idx] = (x[idx] - mean[row])/stdv[row];
+  }
+}
+// running mean / variance along time, one thread per (b, row)   (ffnn.py:195-203)
+__global__ __launch_bounds__(256) void cumulative_norm_kernel(const float* x, float* out, int T,
+                                                              long long nrows, float eps) {
+  GRID_STRIDE(r, nrows) {
+    const float* xi = x + r*T;
+    float* oi = out + r*T;
+    float s = 0.f, q = 0.f;
+    for (int t = 0; t < T; ++t) {
+      s += xi[t]; q += xi[t]*xi[t];
+      const float n = (float)(t + 1);
+      const float mean = s/n;
+      const float var = q/n - mean*mean;
+      oi[t] = (xi[t] - mean)/sqrtf(var + eps);
+    }
+  }
+}
+// y = relu(x)*mask*scale (mask: the dropout keep mask, or null)         (ffnn.py:160-162)
+__global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(const float* x, const float* mask,
+                                                               float* out, long long n, float scale) {
+  GRID_STRIDE(i, n) {
+    const float v = x[i] > 0.f ? x[i] : 0.f;
+    out[i] = mask ? v*mask[i]*scale : v;
+  }
+}
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* x, const float* mask,
+                                                               const float* dy, float* dx,
+                                                               long long n, float scale) {
+  GRID_STRIDE(i, n) {
+    const float g = x[i] > 0.f ? dy[i] : 0.f;
+    dx[i] = mask ? g*mask[i]*scale : g;
+  }
+}
+__global__ __launch_bounds__(256) void sigmoid_fwd_kernel(const float* x, float* out, long long n) {
+  GRID_STRIDE(i, n) out[i] = 1.f/(1.f + expf(-x[i]));
+}
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* y, const float* dy,
+                                                          float* dx, long long n) {
+  GRID_STRIDE(i, n) dx[i] = dy[i]*y[i]*(1.f - y[i]);
+}
+// out[m] = sum_{b,t} x[b][m][t]  (bias gradient): one workgroup per row, fixed order
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* x, float* out, int B, int M, int T) {
+  __shared__ double scr[8];
+  const int m = blockIdx.x;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b)
+    for (int t = threadIdx.x; t < T; t += 256) s += (double)x[((long long)b*M + m)*T + t];
+  s = block_sum(s, scr);
+  if (threadIdx.x == 0) out[m] = (float)s;
+}
+// out[b][i] = mask[b][i] * mean_c spec[b][c][i]   (complex)           (ffnn.py:113-115)
+__global__ __launch_bounds__(256) void masked_mean_spec_kernel(const float2* spec, const float* mask,
+                                                               float2* out, int C, long long n,
+                                                               long long total) {
+  GRID_STRIDE(idx, total) {
+    const long long b = idx / n, i = idx % n;
+    float re = 0.f, im = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float2 v = spec[((long long)b*C + c)*n + i];
+      re += v.x; im += v.y;
+    }
+    const float m = mask[idx]/(float)C;
+    out[idx] = make_float2(re*m, im*m);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int brv_fbe_power(const float* spec, float* out, int64_t B, int64_t C, int64_t n, brv_stream_t stream) {
+  if (B < 1 || C < 1 || n < 1) return -1;
+  hipLaunchKernelGGL(fbe_power_kernel, flat_grid(B*n), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)spec, out, (int)C, (long long)n, (long long)(B*n));
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_compress(const float* x, float* out, int64_t n, int mode, float eps, brv_stream_t stream) {
+  if (n < 1 || mode < 0 || mode > 2) return -1;
+  hipLaunchKernelGGL(compress_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (long long)n, mode, eps);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_irm(const float* fg, const float* bg, float* out, int64_t n, float eps, brv_stream_t stream) {
+  if (n < 1) return -1;
+  hipLaunchKernelGGL(irm_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, fg, bg, out,
+                     (long long)n, eps);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_stack_frames(const float* x, float* out, int64_t B, int64_t nf, int64_t T, int64_t stacks,
+                     brv_stream_t stream) {
+  if (B < 1 || nf < 1 || T < 1 || stacks < 0) return -1;
+  const long long total = B*(stacks + 1)*nf*T;
+  hipLaunchKernelGGL(stack_kernel, flat_grid(total), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (int)nf, (int)T, (int)stacks, total);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_static_norm(const float* x, const float* mean, const float* stdv, float* out, int64_t B,
+                    int64_t rows, int64_t T, brv_stream_t stream) {
+  if (B < 1 || rows < 1 || T < 1) return -1;
+  const long long total = B*rows*T;
+  hipLaunchKernelGGL(static_norm_kernel, flat_grid(total), dim3(256), 0, (hipStream_t)stream, x,
+                     mean, stdv, out, (int)rows, (int)T, total);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_cumulative_norm(const float* x, float* out, int64_t nrows, int64_t T, float eps,
+                        brv_stream_t stream) {
+  if (nrows < 1 || T < 1) return -1;
+  hipLaunchKernelGGL(cumulative_norm_kernel, flat_grid(nrows), dim3(256), 0, (hipStream_t)stream,
+                     x, out, (int)T, (long long)nrows, eps);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_relu_dropout_forward(const float* x, const float* mask, float* out, int64_t n, float scale,
+                             brv_stream_t stream) {
+  if (n < 1) return -1;
+  hipLaunchKernelGGL(relu_dropout_fwd_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, x,
+                     mask, out, (long long)n, scale);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_relu_dropout_backward(const float* x, const float* mask, const float* dy, float* dx,
+                              int64_t n, float scale, brv_stream_t stream) {
+  if (n < 1) return -1;
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, x,
+                     mask, dy, dx, (long long)n, scale);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_sigmoid_forward(const float* x, float* out, int64_t n, brv_stream_t stream) {
+  if (n < 1) return -1;
+  hipLaunchKernelGGL(sigmoid_fwd_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (long long)n);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_sigmoid_backward(const float* y, const float* dy, float* dx, int64_t n, brv_stream_t stream) {
+  if (n < 1) return -1;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, y, dy,
+                     dx, (long long)n);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_row_sum(const float* x, float* out, int64_t B, int64_t M, int64_t T, brv_stream_t stream) {
+  if (B < 1 || M < 1 || T < 1) return -1;
+  hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (int)B, (int)M, (int)T);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_masked_mean_spec(const float* spec, const float* mask, float* out, int64_t B, int64_t C,
+                         int64_t n, brv_stream_t stream) {
+  if (B < 1 || C < 1 || n < 1) return -1;
+  hipLaunchKernelGGL(masked_mean_spec_kernel, flat_grid(B*n), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)spec, mask, (float2*)out, (int)C, (long long)n, (long long)(B*n));
+  FF_OK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -18,7 +18,7 @@ using namespace brv;
 
 namespace {
 
-enum AMode { GA_PLAIN = 0, GA_SPEC_T = 1 };
+enum AMode { GA_PLAIN = 0, GA_SPEC_T = 1, GA_T = 2 };     // GA_T: A[i][k] = a[k*lda + i]
 enum BMode { GB_PLAIN = 0, GB_FRAMES = 1, GB_WT = 2 };
 enum SMode { GS_PLAIN = 0, GS_SPEC = 1 };
 
@@ -34,6 +34,10 @@ struct G32 {
   int frames; float inv_scale, inv_comp;
   // GS_SPEC: D rows are (bin, part) pairs; store complex [bins][N] after compression
   float comp, scale; int bins;
+  // general GEMM extras (brv_gemm_f32): the reduction also runs over kbatch operand pairs
+  // (a + kb*a_kbs, b + kb*b_kbs); D = acc + row_bias[m] (+ D if accumulate)
+  int kbatch; long long a_kbs, b_kbs;
+  const float* row_bias; int accumulate;
 };
 
 constexpr int TM = 64, TN = 64, TK = 32;
@@ -45,11 +49,13 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const G32 p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int m0 = blockIdx.y*TM, n0 = blockIdx.x*TN, b = blockIdx.z;
-  const float* A = p.A + (long long)b*p.a_bs;
-  const float* B = p.B + (long long)b*p.b_bs;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int nkb = p.kbatch > 1 ? p.kbatch : 1;
+  for (int kb = 0; kb < nkb; ++kb) {
+  const float* A = p.A + (long long)b*p.a_bs + (long long)kb*p.a_kbs;
+  const float* B = p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs;
   for (int k0 = 0; k0 < p.K; k0 += TK) {
     // ---- stage A [TM][TK] ----
 #pragma unroll
@@ -60,6 +66,8 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const G32 p) {
       if (m < p.M && kk < p.K) {
         if (AM == GA_PLAIN) {
           v = A[(long long)m*p.lda + kk];
+        } else if (AM == GA_T) {
+          v = A[(long long)kk*p.lda + m];
         } else {
           // spectrum element (bin, part) of frame m; undo scale and magnitude compression
           const int bin = kk >> 1, part = kk & 1;
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const G32 p) {
     }
     __syncthreads();
   }
+  }
   // D element (row, col): col = lane & 31, row = (i & 3) + 8*(i >> 2) + 4*(lane >> 5)
   float* D = p.D + (long long)b*p.d_bs;
   const int col = n0 + 32*wn + (lane & 31);
@@ -108,7 +117,12 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const G32 p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = m0 + 32*wm + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
-      if (row < p.M) D[(long long)row*p.ldd + col] = acc[i];
+      if (row < p.M) {
+        float v = acc[i];
+        if (p.row_bias) v += p.row_bias[row];
+        if (p.accumulate) v += D[(long long)row*p.ldd + col];
+        D[(long long)row*p.ldd + col] = v;
+      }
     }
   } else {
     // rows come in (re, im) pairs: registers (2q, 2q+1) of one lane
@@ -244,6 +258,30 @@ int brv_stft_adjoint(const float* dspec, const float* basis, float* frames_scrat
   int gx = (o.out_len + 255)/256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
   hipLaunchKernelGGL(istft_ola_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, o);
   return (int)hipGetLastError();
+}
+
+// General fp32 GEMM on the exact-fp32 MFMA (the Linear layers of the FFNN model and their
+// gradients, brever/models/ffnn/ffnn.py:151-171):
+//   d[z] (M x N) (+)= sum_kb op_a(a[z, kb]) (M x K) @ op_b(b[z, kb]) (K x N) + row_bias[m]
+// op_a = transpose iff trans_a (a stored K x M), op_b likewise (b stored N x K).
+int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
+                 int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
+                 int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                 int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
+                 const float* row_bias, int accumulate, brv_stream_t stream) {
+  if (batch < 1 || M < 1 || N < 1 || K < 1) return -1;
+  G32 p; memset(&p, 0, sizeof(p));
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.A = a; p.a_bs = a_batch_stride; p.lda = (int)lda;
+  p.B = b; p.b_bs = b_batch_stride; p.ldb = (int)ldb;
+  p.D = d; p.d_bs = d_batch_stride; p.ldd = (int)ldd;
+  p.kbatch = (int)kbatch; p.a_kbs = a_kbatch_stride; p.b_kbs = b_kbatch_stride;
+  p.row_bias = row_bias; p.accumulate = accumulate;
+  hipStream_t st = (hipStream_t)stream;
+  if (trans_a && trans_b) return launch_g32<GA_T, GB_WT, GS_PLAIN>(p, (int)batch, st);
+  if (trans_a) return launch_g32<GA_T, GB_PLAIN, GS_PLAIN>(p, (int)batch, st);
+  if (trans_b) return launch_g32<GA_PLAIN, GB_WT, GS_PLAIN>(p, (int)batch, st);
+  return launch_g32<GA_PLAIN, GB_PLAIN, GS_PLAIN>(p, (int)batch, st);
 }
 
 int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,

@@ -80,6 +80,24 @@ SIGNATURES = {
     'brv_mag_l1_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_mag_l1_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
                                            _c_ptr]),
+    'brv_gemm_f32': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*10
+                     + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_ptr,
+                        ctypes.c_int, _c_ptr]),
+    'brv_fbe_power': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_compress': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.c_int, _c_f32, _c_ptr]),
+    'brv_irm': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr]),
+    'brv_stack_frames': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_static_norm': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64,
+                                       _c_ptr]),
+    'brv_cumulative_norm': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_ptr]),
+    'brv_relu_dropout_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr]),
+    'brv_relu_dropout_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32,
+                                                 _c_ptr]),
+    'brv_sigmoid_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr]),
+    'brv_sigmoid_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
+    'brv_row_sum': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_masked_mean_spec': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64,
+                                            _c_ptr]),
     'brv_clip_adam_step': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                           _c_i64, _c_f32, _c_f32, _c_f32,
                                           _c_f32, _c_f32, _c_f32, _c_i64,

@@ -1,2 +1,3 @@
 """DSP modules of the HIP path (reference: brever/modules/)."""
 from .stft import STFT, MelFilterbank  # noqa: F401
+from .features import FeatureExtractor  # noqa: F401

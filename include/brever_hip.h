@@ -150,6 +150,44 @@ int brv_stft_adjoint(const float* dspec, const float* basis, float* frames_scrat
 int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,
                    int64_t N, int64_t K, int64_t a_batch_stride, brv_stream_t stream);
 
+/* General fp32 GEMM on the exact-fp32 MFMA (nn.Linear of the FFNN model and its gradients,
+ * models/ffnn/ffnn.py:151-171): d[z] (M x N) (+)= sum_kb op_a(a[z,kb]) @ op_b(b[z,kb]) +
+ * row_bias[m]; trans_a: a stored (K x M); trans_b: b stored (N x K); kbatch extends the
+ * reduction over kbatch operand pairs a/b_kbatch_stride apart (weight gradients summed over
+ * the batch). */
+int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
+                 int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
+                 int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                 int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
+                 const float* row_bias, int accumulate, brv_stream_t stream);
+
+/* ---- FFNN mask model and log-mel features (models/ffnn/ffnn.py:72-203,
+ * modules/features.py:142-205); fp32, (B, rows, frames) / complex64 (B, channels, bins*frames)
+ * brv_fbe_power: mean over channels of |spec|^2; brv_compress: mode 1 log(x+eps), 2 cube root;
+ * brv_irm: (1 + bg/(fg+eps))^-1/2; brv_stack_frames: delayed copies with first-frame fill;
+ * brv_static_norm / brv_cumulative_norm: StaticNormalizer / CumulativeNormalizer;
+ * brv_relu_dropout_*: ReLU followed by dropout with a caller-supplied keep mask (null: none)
+ * scaled by `scale`; brv_sigmoid_*; brv_row_sum: bias gradient sum over batch and frames;
+ * brv_masked_mean_spec: mask * mean over channels of a complex spectrum (FFNN._enhance). */
+int brv_fbe_power(const float* spec, float* out, int64_t B, int64_t C, int64_t n, brv_stream_t stream);
+int brv_compress(const float* x, float* out, int64_t n, int mode, float eps, brv_stream_t stream);
+int brv_irm(const float* fg, const float* bg, float* out, int64_t n, float eps, brv_stream_t stream);
+int brv_stack_frames(const float* x, float* out, int64_t B, int64_t nf, int64_t T, int64_t stacks,
+                     brv_stream_t stream);
+int brv_static_norm(const float* x, const float* mean, const float* stdv, float* out, int64_t B,
+                    int64_t rows, int64_t T, brv_stream_t stream);
+int brv_cumulative_norm(const float* x, float* out, int64_t nrows, int64_t T, float eps,
+                        brv_stream_t stream);
+int brv_relu_dropout_forward(const float* x, const float* mask, float* out, int64_t n, float scale,
+                             brv_stream_t stream);
+int brv_relu_dropout_backward(const float* x, const float* mask, const float* dy, float* dx,
+                              int64_t n, float scale, brv_stream_t stream);
+int brv_sigmoid_forward(const float* x, float* out, int64_t n, brv_stream_t stream);
+int brv_sigmoid_backward(const float* y, const float* dy, float* dx, int64_t n, brv_stream_t stream);
+int brv_row_sum(const float* x, float* out, int64_t B, int64_t M, int64_t T, brv_stream_t stream);
+int brv_masked_mean_spec(const float* spec, const float* mask, float* out, int64_t B, int64_t C,
+                         int64_t n, brv_stream_t stream);
+
 /* ---- pieces of MultiResYuLoss (criterion.py:135-226) ----------------------------
  * brv_apply_mask: out = x with samples >= lengths[b] zeroed (apply_mask, :229-234),
  *   x/out (B, S, L). brv_l1_*: sums[r] = sum |x - y| over n samples of row r (fp64) and

@@ -324,6 +324,50 @@ def golden_stft(out):
     np.savez_compressed(os.path.join(out, 'stft.npz'), **res)
 
 
+def golden_ffnn(out):
+    """FFNN (brever/models/ffnn/ffnn.py): seeded parameters, transform of a seeded item,
+    forward / loss / gradients at fixed weights (dropout 0, so no RNG enters), enhance in
+    eval mode, default parameter count."""
+    from brever.models import FFNN, count_params
+    torch.manual_seed(0)
+    res = dict(n_params_default=np.array(count_params(FFNN())))
+    net = FFNN(hidden_layers=[96, 80], dropout=0.0)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        net.normalization.set_statistics(torch.randn(384, 1, generator=g),
+                                         torch.rand(384, 1, generator=g) + 0.5)
+    res['params'] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    res['mean'] = net.normalization.mean.numpy().copy()
+    res['std'] = net.normalization.std.numpy().copy()
+    clean = 0.1*torch.randn(2, 9000, generator=g)
+    noise = 0.05*torch.randn(2, 9000, generator=g)
+    sources = torch.stack([clean + noise, clean])              # (mixture, foreground) x channels
+    res['sources'] = sources.numpy()
+    item = net.transform(sources)
+    res['item'] = item.numpy()
+    items = [net.transform(torch.stack([clean[:, :L] + noise[:, :L], clean[:, :L]]))
+             for L in (9000, 7000, 4000)]
+    T = max(i.shape[-1] for i in items)
+    batch = torch.stack([torch.nn.functional.pad(i, (0, T - i.shape[-1])) for i in items])
+    lengths = torch.tensor([i.shape[-1] for i in items])
+    res['batch'] = batch.numpy(); res['lengths'] = lengths.numpy()
+    net.train()
+    res['output'] = net(batch[:, :384]).detach().numpy()
+    loss = net.loss(batch, lengths, False)
+    res['loss'] = loss.detach().numpy()
+    loss.backward()
+    res['grads'] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    net.eval()
+    mix = torch.stack([(clean + noise)[:, :8000], (clean + noise)[:, :8000]*0.5])   # (B, 2, L)
+    with torch.no_grad():
+        res['enhance_in'] = mix.numpy()
+        res['enhance_out'] = net.enhance(mix).numpy()
+    cum = FFNN(hidden_layers=[32], normalization='cumulative', dropout=0.0)
+    with torch.no_grad():
+        res['cumnorm_out'] = cum.normalization(batch[:, :384]).numpy()
+    np.savez_compressed(os.path.join(out, 'ffnn.npz'), **res)
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
@@ -335,6 +379,7 @@ def main():
     golden_convtasnet(HERE)
     golden_training(HERE)
     golden_stft(HERE)
+    golden_ffnn(HERE)
     print('golden fixtures written to', HERE)
 
 

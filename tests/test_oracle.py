@@ -214,3 +214,41 @@ def test_mel_filterbank_and_frame_count_bit_exact(golden_dir):
         assert [s.frame_count(int(n)) + 512//hop for n in g['lens']] == got
     with pytest.raises(NotImplementedError):
         STFT(512, 128, onesided=False)
+
+
+def _load_oracle_ffnn(g):
+    from oracle.ffnn import OracleFFNN
+    net = OracleFFNN(hidden_layers=(96, 80), dropout=0.0)
+    flat = torch.from_numpy(g['params'])
+    o = 0
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        net.mean.copy_(torch.from_numpy(g['mean']))
+        net.std.copy_(torch.from_numpy(g['std']))
+    return net
+
+
+def test_ffnn_oracle_matches_reference(golden_dir):
+    """transform / forward / loss / gradients / enhance of the reference FFNN at fixed
+    weights (fixture from the imported reference, dropout 0)."""
+    from oracle.ffnn import OracleFFNN
+    g = np.load(os.path.join(golden_dir, 'ffnn.npz'))
+    assert sum(p.numel() for p in OracleFFNN().parameters()) == int(g['n_params_default'])
+    net = _load_oracle_ffnn(g)
+    item = net.transform(torch.from_numpy(g['sources']))
+    assert torch.allclose(item, torch.from_numpy(g['item']), rtol=1e-4, atol=1e-5)
+    batch, lengths = torch.from_numpy(g['batch']), torch.from_numpy(g['lengths'])
+    net.train()
+    out = net(batch[:, :384])
+    assert torch.allclose(out, torch.from_numpy(g['output']), rtol=1e-5, atol=1e-6)
+    loss = net.loss(batch, lengths)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-6
+    loss.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.allclose(grads, torch.from_numpy(g['grads']), rtol=1e-4, atol=1e-8)
+    net.eval()
+    with torch.no_grad():
+        y = net.enhance(torch.from_numpy(g['enhance_in']))
+    assert torch.allclose(y, torch.from_numpy(g['enhance_out']), rtol=1e-4, atol=1e-6)
