@@ -784,8 +784,11 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     }
     ProfScope prof("pw2_wgrad", 2.0*l.nb*BT*(double)(l.Bnp + l.Scp)*l.Hp,
                    2.0*BT*(l.Bnp + l.Scp + l.Hp)*l.nb, st);
+#ifdef BRV_DIAG
+    if (const char* d = getenv("BRV_DBG_WG")) fp.dbg = atoi(d);
+#endif
     const int grid = 8*ceil_div(l.nb, 8)*fp.n_htiles;
-    hipLaunchKernelGGL(wgrad_full_kernel, dim3(grid), dim3(256), 0, st, fp);
+    hipLaunchKernelGGL(wgrad_full_kernel, dim3(grid), dim3(64*W2_NW), 0, st, fp);
     HIP_OK(hipGetLastError());
   }
   for (int i0 = 0; i0 < l.nb; i0 += kWgMaxProb) {

@@ -34,7 +34,9 @@ constexpr int W2_HT_BYTES = W2_BT*W2_LDH*2;
 constexpr int W2_OFF_H = W2_STAGES*W2_GBYTES;
 constexpr int W2_OFF_HT = W2_OFF_H + W2_STAGES*W2_HBYTES;
 constexpr int W2_SMEM = W2_OFF_HT + 2*W2_HT_BYTES;     // 144 KiB
-constexpr int W2_DMA = 10;                 // LDS-DMA instructions per wave and chunk (8 G + 2 H)
+constexpr int W2_NW = 8;                   // waves per workgroup: two per SIMD, so that one wave's
+                                           // DMA issue / LDS latency hides behind the other's MFMAs
+constexpr int W2_DMA = 5;                  // LDS-DMA instructions per wave and chunk (4 G + 1 H)
 
 struct WgradFullParams {
   int B, T, nprob, n_htiles;
@@ -44,6 +46,9 @@ struct WgradFullParams {
   int Kout, ldo;                 // true H channels / leading dimension of D
   double inv_n; float eps;
   WgradProb prob[kWgMaxProb];    // g0 may be null (block without residual conv)
+#ifdef BRV_DIAG
+  int dbg;                       // 1: no DMA, 2: no fragment reads / MFMA, 4: no transform
+#endif
 };
 
 typedef __attribute__((address_space(3))) void* lds_void_p;
@@ -108,6 +113,10 @@ __device__ __forceinline__ TrAddr tr_addr_h(unsigned int img, int row0, int col0
   return t;
 }
 struct Frag { s16x4 lo, hi; };
+template <int N>
+__device__ __forceinline__ void lds_wait16_n(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
 __device__ __forceinline__ Frag frag_issue(const TrAddr& t) {
   Frag f; f.lo = lds_read_tr(t.a0); f.hi = lds_read_tr(t.a1); return f;
 }
@@ -117,6 +126,12 @@ __device__ __forceinline__ bf16x8 frag_value(const Frag& f) {
 }
 // s_waitcnt lgkmcnt(N) that the four fragments of one k-step depend on
 template <int N>
+__device__ __forceinline__ void frag_wait3(Frag& a, Frag& b, Frag& c) {
+  asm volatile("s_waitcnt lgkmcnt(%6)"
+               : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi)
+               : "n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void frag_wait(Frag& a, Frag& b, Frag& c, Frag& d) {
   asm volatile("s_waitcnt lgkmcnt(%8)"
                : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi),
@@ -124,7 +139,7 @@ __device__ __forceinline__ void frag_wait(Frag& a, Frag& b, Frag& c, Frag& d) {
                : "n"(N) : "memory");
 }
 
-__global__ __launch_bounds__(256) void wgrad_full_kernel(const WgradFullParams p) {
+__global__ __launch_bounds__(64*W2_NW) void wgrad_full_kernel(const WgradFullParams p) {
   // ONE shared array (a second object makes hipcc drain vmcnt before every ds_read):
   // [3 x G image | 3 x raw H | 2 x transformed H]
   __shared__ __attribute__((aligned(1024))) unsigned char smem[W2_SMEM];
@@ -141,28 +156,28 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WgradFullParams p
 
   // LDS starts out as zeros: rows never written (no residual part, frames past the end) must
   // hold finite values
-  for (int o = tid*16; o < W2_SMEM; o += 256*16)
+  for (int o = tid*16; o < W2_SMEM; o += 64*W2_NW*16)
     *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
   // ---- LDS-DMA geometry -----------------------------------------------------------------
-  // G: wave w issues the 1 KiB units u = w + 4j (j < 8): unit u = half image u >> 4, rows
+  // G: wave w issues the 1 KiB units u = w + 8j (j < 4): unit u = half image u >> 4, rows
   // 4(u & 15) .. +3, lane -> (row = 4(u & 15) + (lane >> 4), slot = lane & 15), and the
   // slot holds channel chunk slot ^ ((row & 7) << 1) (swizzle applied on the SOURCE side).
-  const int grow = lane >> 4;                               // + 4*((wid + 4j) & 15)
+  const int grow = lane >> 4;                               // + 4*((wid + 8j) & 15)
   const int gsw = ((4*(wid & 1) + grow) & 7) << 1;          // (row & 7) << 1, same for all j
   const int gch = (lane & 15) ^ gsw;                        // channel chunk inside the half
   const bf16_t* g0 = reinterpret_cast<const bf16_t*>(q.g0);
   const bf16_t* g1 = reinterpret_cast<const bf16_t*>(q.g1);
-  unsigned int gvoff[8];
+  unsigned int gvoff[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int u = wid + 4*j, row = 4*(u & 15) + grow;
-    const int ld = j < 4 ? p.ldg0 : p.ldg1;
+  for (int j = 0; j < 4; ++j) {
+    const int u = wid + 8*j, row = 4*(u & 15) + grow;
+    const int ld = j < 2 ? p.ldg0 : p.ldg1;
     gvoff[j] = (unsigned int)(row*ld*2 + gch*16);
   }
-  // H: units u = w + 4j (j < 2): 8 rows x 8 slots, lane -> (row = 8u + (lane >> 3), slot = lane & 7)
-  const int hcc = lane & 7, hrow = 8*wid + (lane >> 3);     // rows hrow + 32j
+  // H: unit u = w: 8 rows x 8 slots, lane -> (row = 8w + (lane >> 3), slot = lane & 7)
+  const int hcc = lane & 7, hrow = 8*wid + (lane >> 3);
   const int hch = k0 + hcc*8;
   const bf16_t* hsrc = reinterpret_cast<const bf16_t*>(q.h);
 
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WgradFullParams p
     }
   };
 
-  // issue the 10 DMAs of chunk (b, t0) into stage st; `live` false -> zeros (keeps the
+  // issue the 5 DMAs of chunk (b, t0) into stage st; `live` false -> zeros (keeps the
   // in-flight count uniform at the end of the frame range)
   auto issue_chunk = [&](int b, int t0, int st, bool live) {
     const long long recs = live ? 1 : 0;
@@ -193,15 +208,12 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WgradFullParams p
     const __amdgpu_buffer_rsrc_t rh = make_rsrc(hsrc + (long long)b*p.bsh, recs*T*p.ldh*2);
     unsigned char* gimg = smem + st*W2_GBYTES;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ld = j < 4 ? p.ldg0 : p.ldg1;
-      dma16(j < 4 ? r0 : r1, gimg + (wid + 4*j)*1024, gvoff[j] + (unsigned int)(t0*ld*2));
+    for (int j = 0; j < 4; ++j) {
+      const int ld = j < 2 ? p.ldg0 : p.ldg1;
+      dma16(j < 2 ? r0 : r1, gimg + (wid + 8*j)*1024, gvoff[j] + (unsigned int)(t0*ld*2));
     }
     unsigned char* himg = smem + W2_OFF_H + st*W2_HBYTES;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      dma16(rh, himg + (wid + 4*j)*1024,
-            (unsigned int)((t0 + hrow + 32*j)*p.ldh*2 + hch*2));
+    dma16(rh, himg + wid*1024, (unsigned int)((t0 + hrow)*p.ldh*2 + hch*2));
   };
 
   // bias gradient = column sums of G: the workgroups of a block take the chunks in turn;
@@ -217,52 +229,57 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WgradFullParams p
   // `nvalid` = frames of the chunk inside the item (0 for the dead chunks past the end):
   // rows beyond it are written as ZEROS -- an out-of-range LDS-DMA leaves the previous
   // (finite) contents of its G rows in place, and 0 * finite adds nothing.
-  auto transform_chunk = [&](int st, int par, bool bias_turn, int nvalid) {
-    const unsigned int himg = smem_a + W2_OFF_H + st*W2_HBYTES + wid*1024 + lane*16;
-    const unsigned int hd = smem_a + W2_OFF_HT + par*W2_HT_BYTES + (hrow*W2_LDH + hcc*8)*2;
-    u32x4 raw[2];
-    raw[0] = lds_read16(himg);
-    raw[1] = lds_read16(himg + 4*1024);
-    lds_wait16(raw[0], raw[1]);
+  // The transform of chunk c+1 is split so that its VALU work sits between the MFMAs of
+  // chunk c: raw reads (own DMA'd slots) are issued first, the math floats, the writes
+  // and the optional bias pass come after the last MFMA.
+  auto h_read = [&](int st, u32x4& raw) {
+    raw = lds_read16(smem_a + W2_OFF_H + st*W2_HBYTES + wid*1024 + lane*16);
+  };
+  auto h_math = [&](const u32x4& raw, int nvalid, uint4& packed) {
+    float f[8]; unpack8(as_uint4(raw), f);
+    f32x2 o[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float f[8]; unpack8(as_uint4(raw[j]), f);
-      f32x2 o[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const f32x2 zz = {f[2*k], f[2*k + 1]};
-        const f32x2 az = {__builtin_fabsf(f[2*k]), __builtin_fabsf(f[2*k + 1])};
-        o[k] = ca[k]*zz + (cb[k]*az + cc[k]);
-      }
-      uint4 packed = pack8v(o);
-      if (hrow + 32*j >= nvalid) packed = make_uint4(0, 0, 0, 0);
-      lds_write16(hd + j*32*W2_LDH*2, packed);
+    for (int k = 0; k < 4; ++k) {
+      const f32x2 zz = {f[2*k], f[2*k + 1]};
+      const f32x2 az = {__builtin_fabsf(f[2*k]), __builtin_fabsf(f[2*k + 1])};
+      o[k] = ca[k]*zz + (cb[k]*az + cc[k]);
     }
-    if (bias_turn) {                                      // workgroup-uniform
-      const unsigned int gimg = smem_a + st*W2_GBYTES + wid*1024 + lane*16;
+    packed = pack8v(o);
+    if (hrow >= nvalid) packed = make_uint4(0, 0, 0, 0);
+  };
+  auto h_write = [&](int par, const uint4& packed) {
+    lds_write16(smem_a + W2_OFF_HT + par*W2_HT_BYTES + (hrow*W2_LDH + hcc*8)*2, packed);
+  };
+  auto bias_pass = [&](int st, int nvalid) {
+    const unsigned int gimg = smem_a + st*W2_GBYTES + wid*1024 + lane*16;
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        u32x4 ga = lds_read16(gimg + 4*j*1024), gb = lds_read16(gimg + 4*(j + 1)*1024);
-        lds_wait16(ga, gb);
+    for (int j = 0; j < 4; j += 2) {
+      u32x4 ga = lds_read16(gimg + 8*j*1024), gb = lds_read16(gimg + 8*(j + 1)*1024);
+      lds_wait16(ga, gb);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float f[8]; unpack8(as_uint4(h ? gb : ga), f);
-          const float live = 4*((wid + 4*(j + h)) & 15) + grow < nvalid ? 1.f : 0.f;
+      for (int h = 0; h < 2; ++h) {
+        float f[8]; unpack8(as_uint4(h ? gb : ga), f);
+        const float live = 4*((wid + 8*(j + h)) & 15) + grow < nvalid ? 1.f : 0.f;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { if (j < 4) bias0[k] += live*f[k]; else bias1[k] += live*f[k]; }
-        }
+        for (int k = 0; k < 8; ++k) { if (j < 2) bias0[k] += live*f[k]; else bias1[k] += live*f[k]; }
       }
     }
   };
+  auto transform_chunk = [&](int st, int par, bool bias_turn, int nvalid) {
+    u32x4 raw, dummy = {0u, 0u, 0u, 0u}; uint4 packed;
+    h_read(st, raw);
+    lds_wait16(raw, dummy);
+    h_math(raw, nvalid, packed);
+    h_write(par, packed);
+    if (bias_turn) bias_pass(st, nvalid);
+  };
 
-  // wave `wid` owns G channels [64 wid, 64 wid + 64) x the 64 H channels
-  f32x16 acc[2][2];
+  // wave `wid` owns G channels [32 wid, 32 wid + 32) x the 64 H channels
+  f32x16 acc[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
   // chunk bookkeeping: (b1, t1) = chunk c+1, (b2, t2) = chunk c+2
   auto advance = [&](int& b, int& t) { t += W2_BT; if (t >= T) { t = 0; ++b; } };
@@ -283,40 +300,54 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WgradFullParams p
   // vmcnt(0) before the first ds_read of every chunk. The loop is unrolled 6x (3 stages x
   // 2 transformed-H buffers); the chunk count is rounded up with dead chunks (zeros).
   const int total6 = ceil_div(total, 6)*6;
+#ifdef BRV_DIAG
+  const int dbg = p.dbg;
+#else
+  constexpr int dbg = 0;
+#endif
   auto body = [&](auto tag, int c) {
     constexpr int S = decltype(tag)::value;
     constexpr int ST = S % 3, NX = (S + 1) % 3, FAR = (S + 2) % 3, PAR = S & 1;
     // stage FAR was last read by the MFMAs of chunk c-1: free after the barrier before
-    issue_chunk(b2, t2, FAR, c + 2 < total);
+    if (!(dbg & 1)) issue_chunk(b2, t2, FAR, c + 2 < total);
     const unsigned int gt = smem_a + ST*W2_GBYTES;
     const unsigned int ht = smem_a + W2_OFF_HT + PAR*W2_HT_BYTES;
-    // fragment reads run two k-steps ahead of the MFMAs (8 reads per k-step)
-    Frag fa[4], fb[4], fc[4], fd[4];
+    // fragment reads run two k-steps ahead of the MFMAs (6 reads per k-step: 1 G + 2 H)
+    Frag fa[4], fc[4], fd[4];
     auto issue = [&](int s) {
-      fa[s] = frag_issue(tr_addr_g(gt, 16*s, 64*wid, lane));
-      fb[s] = frag_issue(tr_addr_g(gt, 16*s, 64*wid + 32, lane));
+      fa[s] = frag_issue(tr_addr_g(gt, 16*s, 32*wid, lane));
       fc[s] = frag_issue(tr_addr_h(ht, 16*s, 0, lane));
       fd[s] = frag_issue(tr_addr_h(ht, 16*s, 32, lane));
     };
     auto mfma = [&](int s) {
-      const bf16x8 ga = frag_value(fa[s]), gb = frag_value(fb[s]);
+      const bf16x8 ga = frag_value(fa[s]);
       const bf16x8 h0 = frag_value(fc[s]), h1 = frag_value(fd[s]);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, h0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, h1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb, h0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gb, h1, acc[1][1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, h0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, h1, acc[1], 0, 0, 0);
     };
-    issue(0); issue(1);
-    frag_wait<8>(fa[0], fb[0], fc[0], fd[0]); mfma(0);
-    issue(2);
-    frag_wait<8>(fa[1], fb[1], fc[1], fd[1]); mfma(1);
-    issue(3);
-    frag_wait<8>(fa[2], fb[2], fc[2], fd[2]); mfma(2);
-    frag_wait<0>(fa[3], fb[3], fc[3], fd[3]); mfma(3);
-    // chunk c+1: this wave's DMAs have landed once only the 10 of chunk c+2 are pending
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W2_DMA) : "memory");
+    // chunk c+1 (issued one iteration ago): landed once only chunk c+2's DMAs are pending
+    if (dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W2_DMA) : "memory");
     if (t1 == 0 && b1 < p.B) item_coefs(b1);
-    transform_chunk(NX, PAR ^ 1, want_bias && (c + 1) % p.n_htiles == htile, b1 < p.B ? T - t1 : 0);
+    const int nvalid = b1 < p.B ? T - t1 : 0;
+    u32x4 raw, rdummy = {0u, 0u, 0u, 0u}; uint4 packed = make_uint4(0, 0, 0, 0);
+    h_read(NX, raw);                                  // oldest in the LDS queue
+    if (!(dbg & 2)) {
+    issue(0); issue(1);
+    lds_wait16_n<6>(raw, rdummy);                     // <= 6 pending: raw + k-step 0 are back
+    frag_wait3<6>(fa[0], fc[0], fd[0]); mfma(0);
+    if (!(dbg & 4)) h_math(raw, nvalid, packed);      // VALU between the MFMAs
+    issue(2);
+    frag_wait3<6>(fa[1], fc[1], fd[1]); mfma(1);
+    issue(3);
+    frag_wait3<6>(fa[2], fc[2], fd[2]); mfma(2);
+    frag_wait3<0>(fa[3], fc[3], fd[3]); mfma(3);
+    } else {
+      lds_wait16_n<0>(raw, rdummy);
+      if (!(dbg & 4)) h_math(raw, nvalid, packed);
+    }
+    if (!(dbg & 4)) h_write(PAR ^ 1, packed);
+    if (want_bias && (c + 1) % p.n_htiles == htile) bias_pass(NX, nvalid);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     b1 = b2; t1 = t2;
@@ -336,26 +367,24 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WgradFullParams p
   // ---- epilogue: this workgroup is the only writer of its tile ---------------------------
   const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int c = 0; c < 2; ++c) {
+    const int k = k0 + 32*c + fr;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int k = k0 + 32*c + fr;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = 64*wid + 32*a + (i & 3) + 8*(i >> 2) + 4*fh;
-        if (k < p.Kout) {
-          if (n < 128) {
-            if (q.out0 && n < p.N0) q.out0[(long long)n*p.ldo + k] += acc[a][c][i];
-          } else if (q.out1 && n - 128 < p.N1) {
-            q.out1[(long long)(n - 128)*p.ldo + k] += acc[a][c][i];
-          }
+    for (int i = 0; i < 16; ++i) {
+      const int n = 32*wid + (i & 3) + 8*(i >> 2) + 4*fh;
+      if (k < p.Kout) {
+        if (n < 128) {
+          if (q.out0 && n < p.N0) q.out0[(long long)n*p.ldo + k] += acc[c][i];
+        } else if (q.out1 && n - 128 < p.N1) {
+          q.out1[(long long)(n - 128)*p.ldo + k] += acc[c][i];
         }
       }
     }
+  }
   if (want_bias) {
-    // 16 lanes hold partial sums of the same channel chunk: (wid >> 1, row & 7) names them
+    // 32 lanes hold partial sums of the same channel chunk: (wid >> 1, row & 7) names them
     __syncthreads();
-    float* sc = reinterpret_cast<float*>(smem);           // [16][256]
+    float* sc = reinterpret_cast<float*>(smem);           // [32][256]
     const int part = (wid >> 1)*8 + (gsw >> 1);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -363,12 +392,14 @@ __global__ __launch_bounds__(256) void wgrad_full_kernel(const WgradFullParams p
       sc[part*W2_G + 128 + gch*8 + k] = bias1[k];
     }
     __syncthreads();
-    float s = 0.f;
+    if (tid < W2_G) {
+      float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += sc[r*W2_G + tid];
-    // one partial per workgroup of the block: 8-way atomics only
-    if (tid < 128) { if (q.gbias0 && tid < p.N0) atomic_add_f32(q.gbias0 + tid, s); }
-    else if (q.gbias1 && tid - 128 < p.N1) atomic_add_f32(q.gbias1 + (tid - 128), s);
+      for (int r = 0; r < 4*W2_NW; ++r) s += sc[r*W2_G + tid];
+      // one partial per workgroup of the block: 8-way atomics only
+      if (tid < 128) { if (q.gbias0 && tid < p.N0) atomic_add_f32(q.gbias0 + tid, s); }
+      else if (q.gbias1 && tid - 128 < p.N1) atomic_add_f32(q.gbias1 + (tid - 128), s);
+    }
   }
 }
 

@@ -211,9 +211,13 @@ class ConvTasNet(BreverBaseModel):
         if self._flat_grad is None or self._flat_grad.device != self._flat.device:
             self._flat_grad = torch.zeros_like(self._flat)
         g = self._flat_grad
-        for p, off in self._offsets:
-            view = g[off:off + p.numel()].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+        views = getattr(self, '_grad_views', None)
+        if views is None or views[0] is not g:
+            views = (g, [g[off:off + p.numel()].view(p.shape) for p, off in self._offsets])
+            self._grad_views = views
+        # re-bind only what something else replaced (zero_grad(set_to_none=True), autograd)
+        for (p, _), view in zip(self._offsets, views[1]):
+            if p.grad is not view:
                 p.grad = view
         return g
 
