@@ -18,6 +18,7 @@
 #include "gemm_wgrad_full.cuh"
 #include "prep.cuh"
 #include "tcn_kernels.cuh"
+#include "cln_kernels.cuh"
 
 using namespace brv;
 
@@ -61,7 +62,7 @@ struct BlockOff {
 };
 
 struct Layout {
-  int N, K, Bn, H, Sc, P, nb, S, hop;
+  int N, K, Bn, H, Sc, P, nb, S, hop, causal;
   int Np, Kfp, Bnp, Hp, Scp;
   long long enc_w, dec_w, ln_g, ln_b, bott_w, bott_b, tcn_prelu, out_w, out_b, n_params;
   long long p_enc, p_dec_f, p_dec_b, p_bott_f, p_bott_b, p_out_f, p_out_b, n_prepared;
@@ -70,7 +71,6 @@ struct Layout {
 
   int init(const brv_ctn_config* c) {
     if (!c) return fail(-1, "null config");
-    if (c->causal) return fail(-2, "causal=True (cLN) is not built yet in the HIP path");
     if (c->filters < 1 || c->filter_length < 2 || c->bottleneck_channels < 1 ||
         c->hidden_channels < 1 || c->skip_channels < 1 || c->layers < 1 ||
         c->repeats < 1 || c->output_sources < 1)
@@ -79,7 +79,7 @@ struct Layout {
       return fail(-2, "kernel_size must be in [1, 5] in the HIP path");
     N = c->filters; K = c->filter_length; Bn = c->bottleneck_channels;
     H = c->hidden_channels; Sc = c->skip_channels; P = c->kernel_size;
-    nb = c->layers*c->repeats; S = c->output_sources; hop = K/2;
+    nb = c->layers*c->repeats; S = c->output_sources; hop = K/2; causal = c->causal != 0;
     Np = round_up(N, 64); Kfp = round_up(K, 64); Bnp = round_up(Bn, 64);
     Hp = round_up(H, 64); Scp = round_up(Sc, 64);
     long long o = 0;
@@ -135,6 +135,9 @@ struct Workspace {
   long long w, x, z1, z2, skip, m, y, stats, sums, dpre, dw1, gskip, gout, eA, eB,
       e0, dwt, vg, gcopy, total;
   long long gcopy_stride, eB_stride;
+  // causal (cLN) model only: materialised normalised tensors, per-frame statistics tables,
+  // identity operands that let the non-causal kernels run as plain convolutions
+  long long h1, h2, wn, ctab, ctab_stride, cfs, cbt, ident, fake_stats, scratch_stats;
   long long vg_stride, vg_bytes;      // replicated vector-gradient block (floats / bytes)
   long long x_stride, z_stride;       // bytes between consecutive blocks' buffers
   long long stats_bytes;
@@ -168,9 +171,24 @@ struct Workspace {
     gcopy = take(gcopy_stride*l.nb);
     e0 = take(BT*l.Np*2);
     dwt = take(BT*l.Np*2);
-    vg_stride = align_up(2LL*l.N + (long long)l.nb*l.H*(5 + l.P) + 1 + 2*l.nb, 64);
+    // (+ 2H floats of scratch per replica for the outputs the causal path discards)
+    vg_stride = align_up(2LL*l.N + (long long)l.nb*l.H*(5 + l.P) + 1 + 2*l.nb + 2LL*l.Hp, 64);
     vg_bytes = vg_stride*kReplicas*4;
     vg = take(vg_bytes);
+    h1 = h2 = wn = ctab = cfs = cbt = ident = fake_stats = scratch_stats = 0; ctab_stride = 0;
+    if (l.causal) {
+      h1 = take(z_stride*l.nb);
+      h2 = take(z_stride*l.nb);
+      wn = take(BT*l.Np*2);
+      ctab_stride = align_up(BT*2*4, 256);
+      ctab = take(ctab_stride*(1 + 2*l.nb));
+      cfs = take(BT*2*4);
+      cbt = take(BT*2*4);
+      const long long cmax = l.Hp > l.Np ? l.Hp : l.Np;
+      ident = take((2*cmax + 64)*4);              // ones | zeros | 1.0f
+      fake_stats = take(B*kStatStride*8);
+      scratch_stats = take(B*kStatStride*8);
+    }
     total = o;
   }
 };
@@ -382,6 +400,330 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* params,
 }  // namespace
 
 // ===========================================================================
+// fold the replicated per-channel gradients into the flat gradient
+int reduce_vector_grads(const Layout& l, const Workspace& ws, const float* vg, float* grads,
+                        hipStream_t st) {
+  const long long vper = (long long)l.H*(5 + l.P);
+  {
+    VgradParams vp; memset(&vp, 0, sizeof(vp));
+    vp.vg = vg; vp.grads = grads; vp.rep_stride = ws.vg_stride;
+    vp.N = l.N; vp.H = l.H; vp.P = l.P; vp.nb = l.nb;
+    vp.ln_g_off = l.ln_g; vp.blk0_off = l.blk[0].conv_w;
+    vp.blk_full = l.nb > 1 ? l.blk[1].conv_w - l.blk[0].conv_w : 0;
+    const BlockOff& b0 = l.blk[0];
+    const BlockOff& bl = l.blk[l.nb - 1];
+    vp.o_dconv_w = b0.dconv_w - b0.conv_w; vp.o_dconv_b = b0.dconv_b - b0.conv_w;
+    vp.o_n1_g_full = b0.n1_g - b0.conv_w; vp.o_n1_g_last = bl.n1_g - bl.conv_w;
+    vp.tcn_prelu_off = l.tcn_prelu;
+    if (b0.prelu1 != b0.n1_g + 4LL*l.H || b0.prelu2 != b0.prelu1 + 1)
+      return fail(-1, "vgrad_reduce: unexpected PReLU offsets");
+    const long long total = 2LL*l.N + vper*l.nb + 1 + 2*l.nb;
+    int gx = (int)((total + 255)/256);
+    if (gx > 1024) gx = 1024;
+    ProfScope prof("vgrad_reduce", 0, 4.0*total*(kReplicas + 2), st);
+    hipLaunchKernelGGL(vgrad_reduce_kernel, dim3(gx), dim3(256), 0, st, vp);
+    HIP_OK(hipGetLastError());
+  }
+  return 0;
+}
+
+// ===========================================================================================
+// Causal Conv-TasNet (cumulative layer norm, all-left depthwise padding).
+// Reference: convtasnet.py:240-268 with causal=True, CausalLayerNorm (normalization.py:5-62).
+// Correctness-first variant: every cLN output is materialised (cln_kernels.cuh) and the
+// convolution kernels of the non-causal path run as plain convolutions on it -- their
+// "apply PReLU + gLN on load" hooks get identity operands (slope 1, mean 0, rstd 1, gain 1,
+// bias 0) and the statistics / norm-gradient outputs they still produce go to scratch.
+// ===========================================================================================
+__global__ void fill_identity_kernel(float* ones, float* zeros, float* one, int n,
+                                     double* fake_stats, int B, double sumsq) {
+  const int i = blockIdx.x*256 + threadIdx.x;
+  if (i < n) { ones[i] = 1.f; zeros[i] = 0.f; }
+  if (i == 0) *one = 1.f;
+  if (i < B) { fake_stats[stat_sum(i)] = 0.0; fake_stats[stat_sq(i)] = sumsq; }
+}
+
+struct CausalCtx {
+  float* ones; float* zeros; float* one; double* fake; double* scratch_stats;
+  float* cfs; float* cbt; char* ctab; long long ctab_stride;
+  float* tab(int i) const { return (float*)(ctab + ctab_stride*i); }
+};
+
+int causal_ctx(const Layout& l, const Workspace& ws, char* base, int B, long long T,
+               hipStream_t st, CausalCtx& c) {
+  const long long cmax = l.Hp > l.Np ? l.Hp : l.Np;
+  c.ones = (float*)(base + ws.ident); c.zeros = c.ones + cmax; c.one = c.zeros + cmax;
+  c.fake = (double*)(base + ws.fake_stats); c.scratch_stats = (double*)(base + ws.scratch_stats);
+  c.cfs = (float*)(base + ws.cfs); c.cbt = (float*)(base + ws.cbt);
+  c.ctab = base + ws.ctab; c.ctab_stride = ws.ctab_stride;
+  // fake statistics with mean 0 and rstd 1 for n = T*H elements (var + eps = 1)
+  const double sumsq = (1.0 - (double)1e-8f)*(double)T*(double)l.H;
+  const int n = (int)cmax > B ? (int)cmax : B;
+  hipLaunchKernelGGL(fill_identity_kernel, dim3((n + 255)/256), dim3(256), 0, st, c.ones, c.zeros,
+                     c.one, (int)cmax, c.fake, B, sumsq);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemsetAsync(c.scratch_stats, 0, (size_t)B*kStatStride*8, st));
+  return 0;
+}
+
+int cln_forward(const CausalCtx& cx, const bf16_t* z, const float* slope, const float* gain,
+                const float* bias, bf16_t* y, float* table, int B, long long T, int Cp, int C,
+                hipStream_t st) {
+  ClnParams p; memset(&p, 0, sizeof(p));
+  p.z = z; p.slope = slope; p.y = y; p.fsum = cx.cfs; p.table = table; p.gain = gain;
+  p.bias = bias; p.B = B; p.T = (int)T; p.Cp = Cp; p.C = C; p.eps = 1e-8f;
+  ProfScope prof("cln_fwd", 0, 6.0*B*T*(double)Cp, st);
+  hipLaunchKernelGGL(cln_frame_sums_kernel, dim3(ceil_div((int)T, CLN_FPB)*B), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(cln_scan_kernel, dim3(B), dim3(256), 0, st, p);
+  int gx = (int)(((long long)B*T*(Cp/8) + 255)/256);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(cln_apply_kernel, dim3(gx), dim3(256), 0, st, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// dz = d(loss)/dz of y = cLN(PReLU(z)); norm-parameter gradients to the replicated block
+int cln_backward(const CausalCtx& cx, const bf16_t* g, const bf16_t* z, const float* slope,
+                 const float* gain, const float* fwd_table, bf16_t* dz, const bf16_t* add_in,
+                 int n_add, float* dgain, float* dbias, float* dslope, long long rep_stride,
+                 int B, long long T, int Cp, int C, hipStream_t st) {
+  ClnParams p; memset(&p, 0, sizeof(p));
+  p.z = z; p.slope = slope; p.g = g; p.fsum = cx.cfs; p.table = cx.cbt; p.fwd_table = fwd_table;
+  p.gain = gain; p.B = B; p.T = (int)T; p.Cp = Cp; p.C = C; p.eps = 1e-8f;
+  p.dz = dz; p.add_in = add_in; p.n_add = n_add;
+  p.dgain = dgain; p.dbias = dbias; p.dslope = dslope; p.rep_stride = rep_stride;
+  ProfScope prof("cln_bwd", 0, 10.0*B*T*(double)Cp, st);
+  hipLaunchKernelGGL(cln_bwd_sums_kernel, dim3(ceil_div((int)T, CLN_FPB)*B), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(cln_bwd_scan_kernel, dim3(B), dim3(256), 0, st, p);
+  int gx = (int)(((long long)B*T*(Cp/8) + 255)/256);
+  if (gx > 2048) gx = 2048;
+  hipLaunchKernelGGL(cln_bwd_apply_kernel, dim3(gx), dim3(256), 0, st, p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int forward_causal(const Layout& l, const brv_ctn_config* cfg, const float* params,
+                   const void* prepared, void* workspace, const float* wave, float* out, int B,
+                   long long L, long long T, hipStream_t st) {
+  Workspace ws; ws.init(l, B, T);
+  const double BT = (double)B*(double)T;
+  char* base = (char*)workspace;
+  const bf16_t* prep = (const bf16_t*)prepared;
+  bf16_t* w = (bf16_t*)(base + ws.w);
+  bf16_t* wn = (bf16_t*)(base + ws.wn);
+  auto xbuf = [&](int i) { return (bf16_t*)(base + ws.x + ws.x_stride*i); };
+  auto z1buf = [&](int i) { return (bf16_t*)(base + ws.z1 + ws.z_stride*i); };
+  auto z2buf = [&](int i) { return (bf16_t*)(base + ws.z2 + ws.z_stride*i); };
+  auto h1buf = [&](int i) { return (bf16_t*)(base + ws.h1 + ws.z_stride*i); };
+  auto h2buf = [&](int i) { return (bf16_t*)(base + ws.h2 + ws.z_stride*i); };
+  float* skip = (float*)(base + ws.skip);
+  bf16_t* m = (bf16_t*)(base + ws.m);
+  bf16_t* y = (bf16_t*)(base + ws.y);
+  CausalCtx cx; if (int r = causal_ctx(l, ws, base, B, T, st, cx)) return r;
+  HIP_OK(hipMemsetAsync(out, 0, (size_t)B*l.S*L*sizeof(float), st));
+
+  GemmRowsParams g;
+  memset(&g, 0, sizeof(g));                                // encoder
+  g.a = frames_of(wave, L, l.hop, l.K);
+  g.W = prep + l.p_enc; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
+  g.e.out = w; g.e.ldo = l.Np; g.e.N = l.N;
+  if (int r = launch_gemm_rows<A_FRAMES, E_STORE>(g, B, st, "enc_fwd", 4.0*B*L + 2.0*BT*l.Np)) return r;
+  // cLN of the encoder output, bottleneck conv
+  if (int r = cln_forward(cx, w, nullptr, params + l.ln_g, params + l.ln_b, wn, cx.tab(0), B, T,
+                          l.Np, l.N, st)) return r;
+  memset(&g, 0, sizeof(g));
+  g.a = rows_bf16(wn, l.Np, T);
+  g.W = prep + l.p_bott_f; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Np;
+  g.e.out = xbuf(0); g.e.ldo = l.Bnp; g.e.bias = params + l.bott_b; g.e.N = l.Bn;
+  if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st, "bottleneck_fwd", 2.0*BT*(l.Np + l.Bnp))) return r;
+
+  for (int i = 0; i < l.nb; ++i) {
+    const BlockOff& b = l.blk[i];
+    const bool has_res = i < l.nb - 1;
+    const int dil = 1 << (i % cfg->layers);
+    memset(&g, 0, sizeof(g));                              // 1x1 conv Bn -> H
+    g.a = rows_bf16(xbuf(i), l.Bnp, T);
+    g.W = prep + b.p_c1_f; g.T = (int)T; g.Np = l.Hp; g.Kp = l.Bnp;
+    g.e.out = z1buf(i); g.e.ldo = l.Hp; g.e.bias = params + b.conv_b; g.e.N = l.H;
+    if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st, "pw1_fwd", 2.0*BT*(l.Bnp + l.Hp))) return r;
+    if (int r = cln_forward(cx, z1buf(i), params + b.prelu1, params + b.n1_g, params + b.n1_b,
+                            h1buf(i), cx.tab(1 + 2*i), B, T, l.Hp, l.H, st)) return r;
+    // depthwise dilated conv on h1, all padding on the left (convtasnet.py:244-247)
+    DwParams d; memset(&d, 0, sizeof(d));
+    d.z1 = h1buf(i); d.z2 = z2buf(i); d.B = B; d.T = (int)T; d.Cp = l.Hp; d.C = l.H;
+    d.slope1 = cx.one; d.stats1 = cx.fake; d.gamma1 = cx.ones; d.beta1 = cx.zeros;
+    d.inv_n = 1.0/((double)T*l.H); d.eps = 1e-8f;
+    d.taps = params + b.dconv_w; d.bias = params + b.dconv_b;
+    d.dil = dil; d.left = (l.P - 1)*dil;
+    d.stats2 = cx.scratch_stats; d.slope2 = cx.one;
+    if (int r = dispatch_p<DwFwd>(l.P, d, st)) return r;
+    if (int r = cln_forward(cx, z2buf(i), params + b.prelu2, params + b.n2_g, params + b.n2_b,
+                            h2buf(i), cx.tab(2 + 2*i), B, T, l.Hp, l.H, st)) return r;
+    memset(&g, 0, sizeof(g));                              // [res | skip] 1x1 convs
+    g.a = rows_bf16(h2buf(i), l.Hp, T);
+    const int rs0 = has_res ? l.Bnp : 0;
+    g.W = prep + b.p_rs_f; g.T = (int)T; g.Np = rs0 + l.Scp; g.Kp = l.Hp;
+    g.e.out = has_res ? xbuf(i + 1) : nullptr; g.e.ldo = l.Bnp;
+    g.e.bias = has_res ? params + b.res_b : nullptr; g.e.N = has_res ? l.Bn : 0;
+    g.e.Nsplit = rs0; g.e.bias2 = params + b.skip_b; g.e.N2 = l.Sc;
+    g.e.res_in = xbuf(i); g.e.ld_res = l.Bnp;
+    g.e.skip = skip; g.e.ld_skip = l.Scp; g.e.skip_init = (i == 0);
+    if (int r = launch_gemm_rows<A_BF16, E_RES_SKIP>(g, B, st, "pw2_fwd", 2.0*BT*(l.Hp + l.Bnp + rs0) + 4.0*BT*l.Scp*(i == 0 ? 1 : 2))) return r;
+  }
+  memset(&g, 0, sizeof(g));                                // prelu -> output conv -> mask
+  g.a = rows_bf16(skip, l.Scp, T);
+  g.a.slope = params + l.tcn_prelu;
+  g.W = prep + l.p_out_f; g.T = (int)T; g.Np = l.S*l.Np; g.Kp = l.Scp;
+  g.e.out = y; g.e.ldo = l.Np; g.e.bias = params + l.out_b; g.e.N = l.N;
+  g.e.w_in = w; g.e.ld_w = l.Np; g.e.m_out = m; g.e.S = l.S; g.e.Np_src = l.Np;
+  if (int r = launch_gemm_rows<A_F32, E_MASK>(g, B, st, "mask_fwd", 4.0*BT*l.Scp + 2.0*BT*l.Np*(1 + 2*l.S))) return r;
+  memset(&g, 0, sizeof(g));                                // decoder
+  g.a = rows_bf16(y, l.Np, T);
+  g.W = prep + l.p_dec_f; g.T = (int)T; g.Np = l.Kfp; g.Kp = l.Np;
+  g.e.wave_out = out; g.e.hop = l.hop; g.e.Kf = l.K; g.e.wave_stride = L;
+  g.e.wave_len = (int)L;
+  if (int r = launch_gemm_rows<A_BF16, E_OLA>(g, B*l.S, st, "dec_fwd", 2.0*BT*l.S*l.Np + 4.0*B*l.S*L)) return r;
+  return 0;
+}
+
+int backward_causal(const Layout& l, const brv_ctn_config* cfg, const float* params,
+                    const void* prepared, void* workspace, const float* wave, const float* d_out,
+                    float* grads, int B, long long L, long long T, hipStream_t st) {
+  Workspace ws; ws.init(l, B, T);
+  const double BT = (double)B*(double)T;
+  char* base = (char*)workspace;
+  const bf16_t* prep = (const bf16_t*)prepared;
+  bf16_t* w = (bf16_t*)(base + ws.w);
+  bf16_t* wn = (bf16_t*)(base + ws.wn);
+  auto xbuf = [&](int i) { return (bf16_t*)(base + ws.x + ws.x_stride*i); };
+  auto z1buf = [&](int i) { return (bf16_t*)(base + ws.z1 + ws.z_stride*i); };
+  auto z2buf = [&](int i) { return (bf16_t*)(base + ws.z2 + ws.z_stride*i); };
+  auto h1buf = [&](int i) { return (bf16_t*)(base + ws.h1 + ws.z_stride*i); };
+  auto h2buf = [&](int i) { return (bf16_t*)(base + ws.h2 + ws.z_stride*i); };
+  float* skip = (float*)(base + ws.skip);
+  bf16_t* m = (bf16_t*)(base + ws.m);
+  bf16_t* y = (bf16_t*)(base + ws.y);
+  bf16_t* dpre = (bf16_t*)(base + ws.dpre);
+  bf16_t* dw1 = (bf16_t*)(base + ws.dw1);
+  bf16_t* gskip = (bf16_t*)(base + ws.gskip);
+  bf16_t* gout = (bf16_t*)(base + ws.gout);
+  const int ldg = l.Bnp + l.Scp;
+  bf16_t* eA = (bf16_t*)(base + ws.eA);
+  bf16_t* eB = (bf16_t*)(base + ws.eB);
+  bf16_t* e0 = (bf16_t*)(base + ws.e0);
+  bf16_t* dwt = (bf16_t*)(base + ws.dwt);
+  const int BS = B*l.S;
+  float* vg = (float*)(base + ws.vg);
+  const long long vper = (long long)l.H*(5 + l.P);
+  auto vslot = [&](int i) { return vg + 2LL*l.N + vper*i; };
+  float* vslope = vg + 2LL*l.N + vper*l.nb;
+  float* vscratch = vslope + 1 + 2*l.nb;                   // 2*Hp floats per replica, discarded
+  CausalCtx cx; if (int r = causal_ctx(l, ws, base, B, T, st, cx)) return r;
+  HIP_OK(hipMemsetAsync(vg, 0, ws.vg_bytes, st));
+
+  GemmRowsParams g; WgradParams wg;
+  memset(&g, 0, sizeof(g));                                // decoder data gradient + mask backward
+  g.a = frames_of(d_out, L, l.hop, l.K);
+  g.W = prep + l.p_dec_b; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
+  g.e.out = dpre; g.e.ldo = l.Np; g.e.out2 = dw1; g.e.w_in = w; g.e.ld_w = l.Np;
+  g.e.m_in = m; g.e.S = l.S;
+  if (int r = launch_gemm_rows<A_FRAMES, E_MASK_BWD>(g, BS, st, "dec_bwd", 4.0*BS*L + 2.0*BT*l.Np*(1 + 3*l.S))) return r;
+  memset(&wg, 0, sizeof(wg));                              // decoder weight gradient
+  wg.g = rows_bf16(y, l.Np, T); wg.h = frames_of(d_out, L, l.hop, l.K);
+  wg.B = BS; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
+  wg.out0 = grads + l.dec_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
+  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_dec", 2.0*BT*l.S*l.Np + 4.0*BS*L)) return r;
+  memset(&g, 0, sizeof(g));                                // output conv dgrad + PReLU backward
+  g.a = rows_bf16(dpre, l.Np, T); g.a.nsrc = l.S;
+  g.W = prep + l.p_out_b; g.T = (int)T; g.Np = l.Scp; g.Kp = l.S*l.Np;
+  g.e.out = gskip; g.e.ldo = ldg; g.e.src_f32 = skip; g.e.ld_srcf = l.Scp;
+  g.e.src_slope = params + l.tcn_prelu; g.e.dslope = vslope;
+  g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
+  if (int r = launch_gemm_rows<A_BF16, E_PRELU_BWD>(g, B, st, "mask_bwd", 2.0*BT*l.S*l.Np + 6.0*BT*l.Scp)) return r;
+  for (int s = 0; s < l.S; ++s) {                          // output conv weight / bias gradients
+    memset(&wg, 0, sizeof(wg));
+    wg.g = rows_bf16(dpre + (long long)s*T*l.Np, l.Np, T); wg.g.bs0 = (long long)l.S*T*l.Np;
+    wg.h = rows_bf16(skip, l.Scp, T); wg.h.slope = params + l.tcn_prelu;
+    wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Scp;
+    wg.out0 = grads + l.out_w + (long long)s*l.N*l.Sc; wg.G0p = l.Np; wg.N0 = l.N;
+    wg.Kout = l.Sc; wg.ldo = l.Sc; wg.gbias0 = grads + l.out_b + (long long)s*l.N;
+    if (int r = launch_wgrad<A_F32>(wg, st, "wgrad_out", 2.0*BT*l.Np + 4.0*BT*l.Scp)) return r;
+  }
+
+  for (int i = l.nb - 1; i >= 0; --i) {
+    const BlockOff& b = l.blk[i];
+    const bool has_res = i < l.nb - 1;
+    const int dil = 1 << (i % cfg->layers);
+    const int rs0 = has_res ? l.Bnp : 0;
+    // [res | skip] weight / bias gradients: G = [g_out | g_skip], H = h2 (materialised)
+    memset(&wg, 0, sizeof(wg));
+    wg.g = rows_bf16(has_res ? gout : gskip, ldg, T);
+    wg.h = rows_bf16(h2buf(i), l.Hp, T);
+    wg.B = B; wg.T = (int)T; wg.Gp = rs0 + l.Scp; wg.Hp = l.Hp;
+    wg.out0 = has_res ? grads + b.res_w : nullptr; wg.out1 = grads + b.skip_w;
+    wg.G0p = rs0; wg.N0 = has_res ? l.Bn : 0; wg.N1 = l.Sc; wg.Kout = l.H; wg.ldo = l.H;
+    wg.gbias0 = has_res ? grads + b.res_b : nullptr; wg.gbias1 = grads + b.skip_b;
+    if (int r = launch_wgrad<A_BF16>(wg, st, "pw2_wgrad", 2.0*BT*(rs0 + l.Scp + l.Hp))) return r;
+    // [res | skip] data gradient -> gradient wrt h2
+    memset(&g, 0, sizeof(g));
+    g.a = rows_bf16(has_res ? gout : gskip, ldg, T);
+    g.W = prep + b.p_rs_b; g.T = (int)T; g.Np = l.Hp; g.Kp = rs0 + l.Scp;
+    g.e.out = eA; g.e.ldo = l.Hp; g.e.N = l.H;
+    if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + l.Hp))) return r;
+    // cLN_2 + PReLU_2 backward -> dz2 (in place over eA is not possible: g is read twice)
+    if (int r = cln_backward(cx, eA, z2buf(i), params + b.prelu2, params + b.n2_g,
+                             cx.tab(2 + 2*i), eB, nullptr, 0, vslot(i) + 2*l.H, vslot(i) + 3*l.H,
+                             vslope + 2 + 2*i, ws.vg_stride, B, T, l.Hp, l.H, st)) return r;
+    // depthwise conv backward on h1 (identity operands: plain transposed convolution)
+    DwParams d; memset(&d, 0, sizeof(d));
+    d.z1 = h1buf(i); d.dz2 = eB; d.e1 = eA; d.B = B; d.T = (int)T; d.Cp = l.Hp; d.C = l.H;
+    d.slope1 = cx.one; d.stats1 = cx.fake; d.gamma1 = cx.ones; d.beta1 = cx.zeros;
+    d.inv_n = 1.0/((double)T*l.H); d.eps = 1e-8f;
+    d.taps = params + b.dconv_w; d.dil = dil; d.left = (l.P - 1)*dil;
+    d.dgamma1 = vscratch; d.dbeta1 = vscratch + l.Hp;
+    d.dtaps = vslot(i) + 4*l.H; d.dbias = vslot(i) + 4*l.H + (long long)l.H*l.P;
+    d.rep_stride = ws.vg_stride; d.sums1 = cx.scratch_stats;
+    if (int r = dispatch_p<DwBwd>(l.P, d, st)) return r;
+    // cLN_1 + PReLU_1 backward -> dz1
+    if (int r = cln_backward(cx, eA, z1buf(i), params + b.prelu1, params + b.n1_g,
+                             cx.tab(1 + 2*i), eB, nullptr, 0, vslot(i), vslot(i) + l.H,
+                             vslope + 1 + 2*i, ws.vg_stride, B, T, l.Hp, l.H, st)) return r;
+    // first 1x1 conv: weight / bias gradients, then data gradient + residual path
+    memset(&wg, 0, sizeof(wg));
+    wg.g = rows_bf16(eB, l.Hp, T); wg.h = rows_bf16(xbuf(i), l.Bnp, T);
+    wg.B = B; wg.T = (int)T; wg.Gp = l.Hp; wg.Hp = l.Bnp;
+    wg.out0 = grads + b.conv_w; wg.G0p = l.Hp; wg.N0 = l.H; wg.Kout = l.Bn; wg.ldo = l.Bn;
+    wg.gbias0 = grads + b.conv_b;
+    if (int r = launch_wgrad<A_BF16>(wg, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp))) return r;
+    memset(&g, 0, sizeof(g));
+    g.a = rows_bf16(eB, l.Hp, T);
+    g.W = prep + b.p_c1_b; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Hp;
+    g.e.out = gout; g.e.ldo = ldg; g.e.add_in = has_res ? gout : nullptr; g.e.ld_add = ldg;
+    if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
+  }
+  // bottleneck conv: weight gradient (H = cLN(w), materialised), data gradient, cLN backward
+  memset(&wg, 0, sizeof(wg));
+  wg.g = rows_bf16(gout, ldg, T); wg.h = rows_bf16(wn, l.Np, T);
+  wg.B = B; wg.T = (int)T; wg.Gp = l.Bnp; wg.Hp = l.Np;
+  wg.out0 = grads + l.bott_w; wg.G0p = l.Bnp; wg.N0 = l.Bn; wg.Kout = l.N; wg.ldo = l.N;
+  wg.gbias0 = grads + l.bott_b;
+  if (int r = launch_wgrad<A_BF16>(wg, st, "bottleneck_wgrad", 2.0*BT*(l.Bnp + l.Np))) return r;
+  memset(&g, 0, sizeof(g));
+  g.a = rows_bf16(gout, ldg, T);
+  g.W = prep + l.p_bott_b; g.T = (int)T; g.Np = l.Np; g.Kp = l.Bnp;
+  g.e.out = e0; g.e.ldo = l.Np; g.e.N = l.N;
+  if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st, "bottleneck_dgrad", 2.0*BT*(l.Bnp + l.Np))) return r;
+  // total gradient wrt the encoder output: cLN backward + the S mask-path terms
+  if (int r = cln_backward(cx, e0, w, nullptr, params + l.ln_g, cx.tab(0), dwt, dw1, l.S, vg,
+                           vg + l.N, nullptr, ws.vg_stride, B, T, l.Np, l.N, st)) return r;
+  memset(&wg, 0, sizeof(wg));                              // encoder weight gradient
+  wg.g = rows_bf16(dwt, l.Np, T); wg.h = frames_of(wave, L, l.hop, l.K);
+  wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
+  wg.out0 = grads + l.enc_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
+  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_enc", 2.0*BT*l.Np + 4.0*B*L)) return r;
+  return reduce_vector_grads(l, ws, vg, grads, st);
+}
+
 extern "C" {
 
 int brv_version(void) { return 100; }
@@ -469,6 +811,8 @@ int64_t brv_ctn_workspace_offset(const brv_ctn_config* cfg, int64_t batch, int64
   if (n == "gskip") return ws.gskip;
   if (n == "gout") return ws.gout;
   if (n == "dwt") return ws.dwt;
+  if (n == "h1" && l.causal) return ws.h1 + ws.z_stride*index;
+  if (n == "h2" && l.causal) return ws.h2 + ws.z_stride*index;
   fail(-1, "unknown workspace tensor " + n);
   return -1;
 }
@@ -526,6 +870,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   const int B = (int)batch; const long long L = length;
   const long long T = l.frames(L);
   if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
+  if (l.causal) return forward_causal(l, cfg, params, prepared, workspace, wave, out, B, L, T, st);
   Workspace ws; ws.init(l, B, T);
   const double BT = (double)B*(double)T;
   char* base = (char*)workspace;
@@ -619,6 +964,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   const int B = (int)batch; const long long L = length;
   const long long T = l.frames(L);
   if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
+  if (l.causal) return backward_causal(l, cfg, params, prepared, workspace, wave, d_out, grads, B, L, T, st);
   Workspace ws; ws.init(l, B, T);
   const double BT = (double)B*(double)T;
   char* base = (char*)workspace;
@@ -884,28 +1230,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
   wg.out0 = grads + l.enc_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
   if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_enc", 2.0*BT*l.Np + 4.0*B*L)) return r;
-  // fold the replicated per-channel gradients into the flat gradient
-  {
-    VgradParams vp; memset(&vp, 0, sizeof(vp));
-    vp.vg = vg; vp.grads = grads; vp.rep_stride = ws.vg_stride;
-    vp.N = l.N; vp.H = l.H; vp.P = l.P; vp.nb = l.nb;
-    vp.ln_g_off = l.ln_g; vp.blk0_off = l.blk[0].conv_w;
-    vp.blk_full = l.nb > 1 ? l.blk[1].conv_w - l.blk[0].conv_w : 0;
-    const BlockOff& b0 = l.blk[0];
-    const BlockOff& bl = l.blk[l.nb - 1];
-    vp.o_dconv_w = b0.dconv_w - b0.conv_w; vp.o_dconv_b = b0.dconv_b - b0.conv_w;
-    vp.o_n1_g_full = b0.n1_g - b0.conv_w; vp.o_n1_g_last = bl.n1_g - bl.conv_w;
-    vp.tcn_prelu_off = l.tcn_prelu;
-    if (b0.prelu1 != b0.n1_g + 4LL*l.H || b0.prelu2 != b0.prelu1 + 1)
-      return fail(-1, "vgrad_reduce: unexpected PReLU offsets");
-    const long long total = 2LL*l.N + vper*l.nb + 1 + 2*l.nb;
-    int gx = (int)((total + 255)/256);
-    if (gx > 1024) gx = 1024;
-    ProfScope prof("vgrad_reduce", 0, 4.0*total*(kReplicas + 2), st);
-    hipLaunchKernelGGL(vgrad_reduce_kernel, dim3(gx), dim3(256), 0, st, vp);
-    HIP_OK(hipGetLastError());
-  }
-  return 0;
+  return reduce_vector_grads(l, ws, vg, grads, st);
 }
 
 }  // extern "C"

@@ -36,12 +36,19 @@ class _ParamOnly(nn.Module):
                            'runs in libbrever_hip.so')
 
 
+class _CausalLayerNorm(_ParamOnly):
+    """Parameter container of the cumulative layer norm: ``gain`` / ``bias`` as in the
+    reference (brever/modules/normalization.py:17-18), so causal state dicts load."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.gain = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+
+
 def _norm(causal, channels):
     if causal:
-        raise NotImplementedError(
-            'causal=True (cumulative layer norm) is not built yet on the HIP '
-            'path'
-        )
+        return _CausalLayerNorm(channels)
     return nn.GroupNorm(1, channels, eps=1e-8)
 
 

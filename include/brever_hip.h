@@ -40,7 +40,8 @@ int64_t brv_prof_collect(char* buf, int64_t buflen);
 
 /* ---- Conv-TasNet ---------------------------------------------------------
  * Hyper-parameters of brever.models.convtasnet.ConvTasNet.__init__
- * (convtasnet.py:30-46). causal != 0 is not supported yet (returns -2). */
+ * (convtasnet.py:30-46). causal != 0 selects the cumulative layer norm and all-left depthwise padding
+ * (convtasnet.py:244-247, modules/normalization.py:5-62). */
 typedef struct brv_ctn_config {
   int32_t filters, filter_length, bottleneck_channels, hidden_channels,
           skip_channels, kernel_size, layers, repeats, output_sources, causal;

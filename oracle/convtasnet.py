@@ -172,7 +172,9 @@ class OracleConvTasNet(BreverBaseModel):
         e = self.emulate_bf16
         z1 = _rb(F.conv1d(x, _rb(blk.conv.weight, e), blk.conv.bias), e)
         self._tap(f'z1.{index}', z1)
-        h = blk.norm_1(blk.prelu_1(z1))
+        # the causal HIP path keeps the cLN output in HBM as bf16; the non-causal one applies
+        # the norm in fp32 while loading z1
+        h = _rb(blk.norm_1(blk.prelu_1(z1)), e and blk.causal)
         pad = (blk.kernel_size - 1)*blk.dilation
         left = pad if blk.causal else pad//2                # convtasnet.py:244-251
         h = F.pad(h, (left, pad - left))

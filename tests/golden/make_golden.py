@@ -201,7 +201,9 @@ def flat_state(model):
 
 def golden_convtasnet(out):
     from brever.models import ModelRegistry
-    for tag, kw, B, L in [('small', SMALL, 3, 1000), ('small2', SMALL2, 2, 777)]:
+    for tag, kw, B, L in [('small', SMALL, 3, 1000), ('small2', SMALL2, 2, 777),
+                          ('causal', dict(SMALL, causal=True), 3, 1000),
+                          ('causal2', dict(SMALL2, causal=True), 2, 777)]:
         torch.manual_seed(0)
         model = ModelRegistry.get('convtasnet')(**kw)
         # de-trivialise the affine / PReLU parameters (they initialise to 1/0/.25)

@@ -48,7 +48,7 @@ def load_pair(golden_dir, tag, emulate=True):
     return g, cfg, oracle, net.to(_cuda())
 
 
-@pytest.mark.parametrize('tag', ['small', 'small2'])
+@pytest.mark.parametrize('tag', ['small', 'small2', 'causal', 'causal2'])
 def test_forward_matches_oracle_and_reference(golden_dir, tag):
     g, cfg, oracle, net = load_pair(golden_dir, tag)
     batch = torch.from_numpy(g['batch'])
@@ -68,7 +68,7 @@ def test_forward_matches_oracle_and_reference(golden_dir, tag):
     assert rel(w[..., :cfg['filters']], oracle.trace['w'].transpose(1, 2)) <= 1e-3
 
 
-@pytest.mark.parametrize('tag', ['small', 'small2'])
+@pytest.mark.parametrize('tag', ['small', 'small2', 'causal', 'causal2'])
 def test_backward_matches_reference(golden_dir, tag):
     from brever_amd.criterion import snr
     g, cfg, oracle, net = load_pair(golden_dir, tag)
@@ -329,13 +329,15 @@ def test_entry_points_train_and_test(tmp_path):
     assert scores['scores'].shape == (6, 2, 2) and np.isfinite(scores['scores']).all()
 
 
-def test_default_width_network_matches_oracle():
+@pytest.mark.parametrize('causal', [False, True])
+def test_default_width_network_matches_oracle(causal):
     """Default channel widths (512/128/512/128) with 4 blocks: exercises the persistent
-    weight-stationary GEMMs (the small golden configs take the generic tile kernel)."""
+    weight-stationary GEMMs (the small golden configs take the generic tile kernel), for
+    the global and the cumulative layer norm."""
     from brever_amd.criterion import snr
     from brever_amd.models import ConvTasNet
     from oracle.convtasnet import OracleConvTasNet
-    cfg = dict(layers=2, repeats=2)
+    cfg = dict(layers=2, repeats=2, causal=causal)
     torch.manual_seed(3)
     oracle = OracleConvTasNet(**cfg, emulate_bf16=True)
     gen = torch.Generator().manual_seed(4)
@@ -658,3 +660,33 @@ def test_fused_backward_paths_match_generic_kernels(B, L):
         got = grads(env)
         assert torch.isfinite(got).all(), env
         assert rel(got, base) <= 2e-3, (env, rel(got, base))
+
+
+@pytest.mark.gpu
+def test_causal_model_is_causal(golden_dir):
+    """The reference's latency test (tests/test_models.py:57-80): with causal=True a change
+    of the input after sample n cannot alter the output before n - filter_length; the
+    non-causal model of the same size does change there."""
+    g, cfg, _, net = load_pair(golden_dir, 'causal')
+    gen = torch.Generator().manual_seed(21)
+    x = (0.3*torch.randn(2, 3000, generator=gen)).cuda()
+    x2 = x.clone()
+    cut = 1500
+    x2[:, cut:] += 0.5*torch.randn(2, 3000 - cut, generator=gen).cuda()
+    with torch.no_grad():
+        y, y2 = net(x), net(x2)
+    K = cfg['filter_length']
+    assert torch.equal(y[..., :cut - K], y2[..., :cut - K])
+    assert not torch.equal(y[..., cut:], y2[..., cut:])
+    _, _, _, plain = load_pair(golden_dir, 'small')
+    with torch.no_grad():
+        z, z2 = plain(x), plain(x2)
+    assert not torch.equal(z[..., :cut - K], z2[..., :cut - K])
+    # one fused training step runs through the causal kernels as well
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    batch = torch.from_numpy(g['batch']).cuda()
+    lengths = torch.from_numpy(g['lengths']).cuda()
+    l0 = float(net.train_step(batch, lengths, True, scaler))
+    for _ in range(5):
+        l1 = float(net.train_step(batch, lengths, True, scaler))
+    assert l1 < l0

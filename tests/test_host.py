@@ -185,5 +185,8 @@ def test_product_rejects_cpu_tensors():
                      skip_channels=8, layers=1, repeats=1)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         net(torch.zeros(1, 256))
-    with pytest.raises(NotImplementedError):
-        ConvTasNet(causal=True)
+    causal = ConvTasNet(filters=8, bottleneck_channels=8, hidden_channels=8, skip_channels=8,
+                        layers=1, repeats=1, causal=True)
+    assert 'tcn.layer_norm.gain' in causal.state_dict()       # reference's cLN parameter names
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        causal(torch.zeros(1, 256))

@@ -75,7 +75,7 @@ def test_losses_batched_equals_per_item(name):
     assert torch.allclose(batched, single, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('tag', ['small', 'small2'])
+@pytest.mark.parametrize('tag', ['small', 'small2', 'causal', 'causal2'])
 def test_convtasnet_forward_backward_match_reference(golden_dir, tag):
     g = np.load(os.path.join(golden_dir, f'convtasnet_{tag}.npz'))
     model = OracleConvTasNet(**json.loads(str(g['config'])))
