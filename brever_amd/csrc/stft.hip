@@ -150,13 +150,14 @@ struct OlaParams {
   const float* frames; float* y; const float* win; int F, n, hop, out_len;
   long long f_bs, y_bs;
   int normalize;             // 1: divide by the window-square envelope (torch.istft)
+  int pad_left;              // frame t starts at sample t*hop - pad_left of the output
 };
 __global__ __launch_bounds__(256) void istft_ola_kernel(const OlaParams p) {
   const int b = blockIdx.y;
   const float* fr = p.frames + (long long)b*p.f_bs;
   float* y = p.y + (long long)b*p.y_bs;
   for (int q = blockIdx.x*256 + threadIdx.x; q < p.out_len; q += gridDim.x*256) {
-    const int pos = q + p.n/2;
+    const int pos = q + p.pad_left;
     int t_hi = pos/p.hop; if (t_hi > p.F - 1) t_hi = p.F - 1;
     int t_lo = (pos - p.n + p.hop)/p.hop; if (pos - p.n + 1 <= 0) t_lo = 0;
     if (t_lo < 0) t_lo = 0;
@@ -227,6 +228,7 @@ int brv_istft_backward(const float* spec, const float* inv_basis, const float* w
   o.n = (int)frame_length; o.hop = (int)hop_length;
   o.out_len = (int)(hop_length*(frames - 1));
   o.f_bs = (long long)frames*frame_length; o.y_bs = o.out_len; o.normalize = 1;
+  o.pad_left = (int)(frame_length/2);
   int gx = (o.out_len + 255)/256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
   hipLaunchKernelGGL(istft_ola_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, o);
   return (int)hipGetLastError();
@@ -253,8 +255,54 @@ int brv_stft_adjoint(const float* dspec, const float* basis, float* frames_scrat
   OlaParams o;
   o.frames = frames_scratch; o.y = dx; o.win = nullptr; o.F = (int)F;
   o.n = (int)frame_length; o.hop = (int)hop_length;
-  o.out_len = (int)length; o.normalize = 0;
+  o.out_len = (int)length; o.normalize = 0; o.pad_left = (int)(frame_length/2);
   o.f_bs = (long long)F*frame_length; o.y_bs = length;
+  int gx = (o.out_len + 255)/256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(istft_ola_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, o);
+  return (int)hipGetLastError();
+}
+
+// Framed DFT with explicit geometry (ConvSTFT, brever/modules/stft.py:201-319: the STFT as a
+// strided convolution with sqrt-window DFT rows): frame t covers samples
+// [t*hop - pad_left, t*hop - pad_left + n) of x (zeros outside [0, length)), `frames` frames.
+int brv_framed_dft_forward(const float* x, const float* basis, float* spec, int64_t rows,
+                           int64_t length, int64_t frame_length, int64_t hop_length,
+                           int64_t pad_left, int64_t frames, float compression, float scale,
+                           brv_stream_t stream) {
+  if (rows < 1 || frames < 1 || frame_length < 2 || hop_length < 1) return -1;
+  const int bins = (int)(frame_length/2 + 1);
+  G32 p; memset(&p, 0, sizeof(p));
+  p.M = 2*bins; p.N = (int)frames; p.K = (int)frame_length;
+  p.A = basis; p.a_bs = 0; p.lda = (int)frame_length;
+  p.B = x; p.b_bs = length; p.hop = (int)hop_length; p.pad_left = (int)pad_left;
+  p.len = (int)length;
+  p.D = spec; p.d_bs = (long long)bins*frames*2; p.bins = bins;
+  p.comp = compression; p.scale = scale;
+  return launch_g32<GA_PLAIN, GB_FRAMES, GS_SPEC>(p, (int)rows, (hipStream_t)stream);
+}
+
+// Transposed framed DFT (ConvSTFT.backward = conv_transpose1d with the same filters, and the
+// adjoint of brv_framed_dft_forward): y[r][q] = post * sum_t sum_c (spec/scale)[c][t] *
+// basis[c][q + pad_left - t*hop], q < out_len, after undoing the magnitude compression.
+int brv_framed_dft_transpose(const float* spec, const float* basis, float* frames_scratch,
+                             float* y, int64_t rows, int64_t frames, int64_t frame_length,
+                             int64_t hop_length, int64_t pad_left, int64_t out_len,
+                             float compression, float scale, brv_stream_t stream) {
+  if (rows < 1 || frames < 1 || out_len < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int bins = (int)(frame_length/2 + 1);
+  G32 p; memset(&p, 0, sizeof(p));
+  p.M = (int)frames; p.N = (int)frame_length; p.K = 2*bins;
+  p.A = spec; p.a_bs = (long long)bins*frames*2; p.frames = (int)frames;
+  p.inv_scale = 1.f/scale; p.inv_comp = 1.f/compression;
+  p.B = basis; p.b_bs = 0; p.ldb = (int)frame_length;
+  p.D = frames_scratch; p.d_bs = (long long)frames*frame_length; p.ldd = (int)frame_length;
+  if (int r = launch_g32<GA_SPEC_T, GB_PLAIN, GS_PLAIN>(p, (int)rows, st)) return r;
+  OlaParams o;
+  o.frames = frames_scratch; o.y = y; o.win = nullptr; o.F = (int)frames;
+  o.n = (int)frame_length; o.hop = (int)hop_length;
+  o.out_len = (int)out_len; o.normalize = 0; o.pad_left = (int)pad_left;
+  o.f_bs = (long long)frames*frame_length; o.y_bs = out_len;
   int gx = (o.out_len + 255)/256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
   hipLaunchKernelGGL(istft_ola_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, o);
   return (int)hipGetLastError();

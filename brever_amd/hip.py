@@ -80,6 +80,10 @@ SIGNATURES = {
     'brv_mag_l1_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_mag_l1_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
                                            _c_ptr]),
+    'brv_framed_dft_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*6
+                               + [_c_f32, _c_f32, _c_ptr]),
+    'brv_framed_dft_transpose': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_i64]*6
+                                 + [_c_f32, _c_f32, _c_ptr]),
     'brv_gemm_f32': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*10
                      + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_ptr,
                         ctypes.c_int, _c_ptr]),

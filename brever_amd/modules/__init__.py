@@ -1,3 +1,3 @@
 """DSP modules of the HIP path (reference: brever/modules/)."""
-from .stft import STFT, MelFilterbank  # noqa: F401
+from .stft import STFT, ConvSTFT, MelFilterbank  # noqa: F401
 from .features import FeatureExtractor  # noqa: F401

@@ -209,6 +209,114 @@ class STFT:
         return y.view(*lead, out_len)
 
 
+class ConvSTFT:
+    """STFT as a strided convolution with sqrt-window DFT rows and its transposed-convolution
+    inverse (brever/modules/stft.py:201-319), same arguments and return types. Forward and
+    backward are the framed DFT-GEMMs ``brv_framed_dft_forward / _transpose``."""
+
+    def __init__(self, frame_length=512, hop_length=256, window='hann',
+                 compression_factor=1, scale_factor=1, normalized=True):
+        self.frame_length = frame_length
+        self.hop_length = hop_length
+        self.compression_factor = compression_factor
+        self.scale_factor = scale_factor
+        self.normalized = normalized
+        if isinstance(window, str):
+            window = scipy.signal.get_window(window, frame_length)**0.5
+        if isinstance(window, np.ndarray):
+            window = torch.from_numpy(window)
+        self.window = window
+        self._normalization_factor = 0.5*frame_length/hop_length**0.5
+        n = frame_length
+        k = np.arange(n//2 + 1)[:, None]
+        m = np.arange(n)[None, :]
+        ang = 2.0*np.pi*k*m/n
+        re, im = np.cos(ang), -np.sin(ang)                 # rows of fft(eye(n))
+        re[0] /= 2**0.5
+        im[0] /= 2**0.5
+        if normalized:
+            re, im = re/self._normalization_factor, im/self._normalization_factor
+        w = self.window.double().numpy()[None, :]
+        basis = np.empty((2*(n//2 + 1), n))
+        basis[0::2] = re*w
+        basis[1::2] = im*w
+        self._basis_host = torch.from_numpy(basis).float()
+        # the reference's (2*bins, 1, n) convolution filters: real rows then imaginary rows
+        self.filters = torch.cat([torch.from_numpy(re*w), torch.from_numpy(im*w)]) \
+            .unsqueeze(1).float()
+        self._basis = {}
+
+    def _get_basis(self, device):
+        key = str(device)
+        if key not in self._basis:
+            self._basis[key] = self._basis_host.to(device).contiguous()
+        return self._basis[key]
+
+    def __call__(self, x, return_type='complex'):
+        return self.forward(x, return_type=return_type)
+
+    def frame_count(self, samples):
+        return math.ceil(max(samples - self.frame_length, 0)/self.hop_length) + 1
+
+    def pad(self, x):
+        frames = self.frame_count(x.shape[-1])
+        padding = (frames - 1)*self.hop_length + self.frame_length - x.shape[-1]
+        x = torch.nn.functional.pad(x, (0, padding))
+        padding = self.frame_length - self.hop_length
+        return torch.nn.functional.pad(x, (padding, padding))
+
+    def forward(self, x, return_type='complex'):
+        hip.require_device(x)
+        lead, L = x.shape[:-1], x.shape[-1]
+        rows = int(np.prod(lead)) if lead else 1
+        n, hop = self.frame_length, self.hop_length
+        side = n - hop
+        padded = (self.frame_count(L) - 1)*hop + n + 2*side     # length after ConvSTFT.pad
+        F = (padded - n)//hop + 1
+        bins = n//2 + 1
+        x2 = x.reshape(rows, L).float().contiguous()
+        spec = torch.empty(rows, bins, F, 2, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_framed_dft_forward(
+            hip.ptr(x2), hip.ptr(self._get_basis(x.device)), hip.ptr(spec), rows, L, n, hop,
+            side, F, float(self.compression_factor), float(self.scale_factor), hip.stream()),
+            'brv_framed_dft_forward')
+        out = torch.view_as_complex(spec).view(*lead, bins, F)
+        if return_type == 'complex':
+            return out
+        if return_type == 'real_imag':
+            return out.real, out.imag
+        if return_type == 'mag_phase':
+            return out.abs(), out.angle()
+        raise ValueError('return_type must be complex, real_imag or '
+                         f'mag_phase, got {return_type}')
+
+    def backward(self, x, input_type='complex'):
+        if input_type == 'real_imag':
+            x = torch.complex(*x)
+        elif input_type == 'mag_phase':
+            mag, phase = x
+            x = mag*torch.exp(1j*phase)
+        elif input_type != 'complex':
+            raise ValueError('input_type must be complex, real_imag or '
+                             f'mag_phase, got {input_type}')
+        hip.require_device(x)
+        lead, (bins, F) = x.shape[:-2], x.shape[-2:]
+        rows = int(np.prod(lead)) if lead else 1
+        n, hop = self.frame_length, self.hop_length
+        side = n - hop
+        out_len = (F - 1)*hop + n - 2*side                     # conv_transpose1d, trimmed
+        spec = torch.view_as_real(x.reshape(rows, bins, F).to(torch.complex64).contiguous())
+        scratch = torch.empty(rows, F, n, dtype=torch.float32, device=x.device)
+        y = torch.empty(rows, out_len, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_framed_dft_transpose(
+            hip.ptr(spec), hip.ptr(self._get_basis(x.device)), hip.ptr(scratch), hip.ptr(y), rows,
+            F, n, hop, side, out_len, float(self.compression_factor), float(self.scale_factor),
+            hip.stream()), 'brv_framed_dft_transpose')
+        if not self.normalized:
+            y = y/self._normalization_factor**2
+        return y.view(*lead, out_len)
+
+
 class MelFilterbank:
     """Triangular HTK-mel filterbank, rows normalised to sum 1
     (brever/modules/stft.py:152-198); ``forward`` / ``backward`` are fp32 GEMMs."""

@@ -146,6 +146,18 @@ int brv_istft_backward(const float* spec, const float* inv_basis, const float* w
 int brv_stft_adjoint(const float* dspec, const float* basis, float* frames_scratch, float* dx,
                      int64_t rows, int64_t length, int64_t frame_length, int64_t hop_length,
                      float scale, brv_stream_t stream);
+/* Framed DFT with explicit geometry and its transpose (ConvSTFT.forward / backward,
+ * stft.py:201-319: STFT as a strided convolution / transposed convolution with the same
+ * filters): frame t covers samples [t*hop - pad_left, ... + n); basis rows interleave
+ * (real_k, imag_k) like brv_stft_forward's. */
+int brv_framed_dft_forward(const float* x, const float* basis, float* spec, int64_t rows,
+                           int64_t length, int64_t frame_length, int64_t hop_length,
+                           int64_t pad_left, int64_t frames, float compression, float scale,
+                           brv_stream_t stream);
+int brv_framed_dft_transpose(const float* spec, const float* basis, float* frames_scratch,
+                             float* y, int64_t rows, int64_t frames, int64_t frame_length,
+                             int64_t hop_length, int64_t pad_left, int64_t out_len,
+                             float compression, float scale, brv_stream_t stream);
 /* d[b] = a[b or shared] (M x K) @ b[b] (K x N), fp32 (MelFilterbank.forward/backward,
  * stft.py:189-198). a_batch_stride = 0 shares one matrix across the batch. */
 int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,

@@ -315,6 +315,17 @@ def golden_stft(out):
     for hop in (128, 256):
         s = STFT(frame_length=512, hop_length=hop)
         res[f'frames{hop}'] = np.array([s(torch.zeros(n)).shape[-1] for n in lens])
+    # ConvSTFT (stft.py:201-319): forward / backward for three parameter combos
+    from brever.modules import ConvSTFT
+    ccombos = [(512, 256, 1.0, 1.0, True), (256, 64, 0.5, 0.3, True), (128, 64, 1.0, 1.0, False)]
+    res['conv_combos'] = np.array(ccombos, dtype=np.float64)
+    for i, (n, hop, comp, scale, norm) in enumerate(ccombos):
+        cs = ConvSTFT(frame_length=n, hop_length=hop, compression_factor=comp,
+                      scale_factor=scale, normalized=norm)
+        X = cs(y.unsqueeze(0))
+        res[f'conv_spec{i}'] = X.numpy()
+        re, im = X.real.clone(), X.imag.clone()
+        res[f'conv_back{i}'] = cs.backward((re, im), input_type='real_imag').numpy()
     mel = MelFilterbank()
     res['mel_filters'] = mel.filters.numpy()
     res['mel_fc'] = mel.fc.numpy()

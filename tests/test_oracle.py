@@ -198,6 +198,23 @@ def test_stft_oracle_matches_reference(golden_dir):
     assert ost.stft_frames(64000, 512, 128) == 501
 
 
+def test_conv_stft_oracle_matches_reference(golden_dir):
+    """oracle/stft.py conv_stft / conv_istft vs the reference ConvSTFT (3 combos)."""
+    import scipy.signal
+    from oracle import stft as ost
+    g = np.load(os.path.join(golden_dir, 'stft.npz'))
+    x = g['x_odd'][None]
+    for i, (n, hop, comp, scale, norm) in enumerate(g['conv_combos']):
+        w = scipy.signal.get_window('hann', int(n))**0.5
+        X = ost.conv_stft(x, w, int(hop), bool(norm), comp, scale)
+        ref = g[f'conv_spec{i}']
+        assert X.shape == ref.shape
+        assert np.abs(X - ref).max() <= 2e-5*np.abs(ref).max()
+        y = ost.conv_istft(ref, w, int(hop), bool(norm), comp, scale)
+        assert y.shape == g[f'conv_back{i}'].shape
+        assert np.abs(y - g[f'conv_back{i}']).max() <= 2e-5*np.abs(g[f'conv_back{i}']).max()
+
+
 def test_mel_filterbank_and_frame_count_bit_exact(golden_dir):
     """Host-side constants of the product modules: mel matrix and frame arithmetic."""
     from brever_amd import hip
