@@ -59,6 +59,7 @@ struct BlockOff {
   long long conv_w, conv_b, dconv_w, dconv_b, res_w, res_b, skip_w, skip_b,
       n1_g, n1_b, n2_g, n2_b, prelu1, prelu2;
   long long p_c1_f, p_c1_b, p_rs_f, p_rs_b;     // prepared (bf16 elements)
+  long long p_c1_fp, p_rs_fp, p_rs_bp;          // fragment-order copies (persistent GEMMs)
 };
 
 struct Layout {
@@ -116,6 +117,9 @@ struct Layout {
       blk[i].p_c1_b = ptake((long long)Bnp*Hp);
       blk[i].p_rs_f = ptake((long long)rs*Hp);
       blk[i].p_rs_b = ptake((long long)Hp*rs);
+      blk[i].p_c1_fp = ptake((long long)Hp*Bnp);
+      blk[i].p_rs_fp = ptake((long long)rs*Hp);
+      blk[i].p_rs_bp = ptake((long long)Hp*rs);
     }
     p_out_f = ptake((long long)S*Np*Scp);
     p_out_b = ptake((long long)Scp*S*Np);
@@ -391,6 +395,23 @@ ASpec frames_of(const float* wav, long long L, int hop, int K) {
 }
 
 struct PrepBatch { PrepJob jobs[64]; int n; };
+
+// plain [N][K] bf16 -> fragment order of the persistent GEMMs: slices of nsl rows, then
+// (f = 32-row chunk, s = 16-column step, lane = row % 32 + 32*((col % 16)/8), 8 values)
+struct PackJob { long long src_off, dst_off; int N, K, nsl; };
+struct PackBatch { PackJob jobs[96]; int n; };
+__global__ __launch_bounds__(256) void pack_frag_kernel(bf16_t* prepared, const PackBatch pb) {
+  const PackJob j = pb.jobs[blockIdx.y];
+  const long long total = (long long)j.N*j.K/8;
+  const int KS = j.K/16;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < total; i += (long long)gridDim.x*256) {
+    const int n = (int)(i / (j.K/8)), k = (int)(i % (j.K/8))*8;
+    const int slice = n / j.nsl, f = (n % j.nsl)/32, fr = n % 32, s = k/16, fh = (k % 16)/8;
+    const long long dst = (long long)slice*j.nsl*j.K + ((long long)(f*KS + s)*64 + fr + 32*fh)*8;
+    *reinterpret_cast<uint4*>(prepared + j.dst_off + dst) =
+        *reinterpret_cast<const uint4*>(prepared + j.src_off + (long long)n*j.K + k);
+  }
+}
 __global__ __launch_bounds__(256) void prep_weights_kernel(const float* params,
                                                            bf16_t* prepped,
                                                            const PrepBatch pb) {
@@ -859,6 +880,26 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
                        (bf16_t*)prepared, pb);
     HIP_OK(hipGetLastError());
   }
+  // fragment-order copies for the persistent GEMMs (default widths only)
+  std::vector<PackJob> packs;
+  auto pack = [&](long long src, long long dst, int N, int K, int nsl) {
+    if (N % nsl || K % 16) return;
+    PackJob j; j.src_off = src; j.dst_off = dst; j.N = N; j.K = K; j.nsl = nsl; packs.push_back(j);
+  };
+  for (int i = 0; i < l.nb; ++i) {
+    const BlockOff& b = l.blk[i];
+    const int rs = (i < l.nb - 1 ? l.Bnp : 0) + l.Scp;
+    pack(b.p_c1_f, b.p_c1_fp, l.Hp, l.Bnp, 64);
+    pack(b.p_rs_f, b.p_rs_fp, rs, l.Hp, 32);
+    pack(b.p_rs_b, b.p_rs_bp, l.Hp, rs, 32);
+  }
+  for (size_t i = 0; i < packs.size(); i += 96) {
+    PackBatch pb;
+    pb.n = (int)std::min<size_t>(96, packs.size() - i);
+    for (int k = 0; k < pb.n; ++k) pb.jobs[k] = packs[i + k];
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(16, pb.n), dim3(256), 0, st, (bf16_t*)prepared, pb);
+    HIP_OK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -911,6 +952,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
     memset(&g, 0, sizeof(g));
     g.a = rows_bf16(xbuf(i), l.Bnp, T);
     g.W = prep + b.p_c1_f; g.T = (int)T; g.Np = l.Hp; g.Kp = l.Bnp;
+    g.Wp = prep + b.p_c1_fp; g.wp_nsl = 64;
     g.e.out = z1buf(i); g.e.ldo = l.Hp; g.e.bias = params + b.conv_b; g.e.N = l.H;
     g.e.stats_out = stat(1 + 2*i); g.e.stats_slope = params + b.prelu1;
     if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st, "pw1_fwd", 2.0*BT*(l.Bnp + l.Hp))) return r;
@@ -931,6 +973,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
     set_affine(g.a, stat(2 + 2*i), params + b.n2_g, params + b.n2_b, l.H, T);
     const int rs0 = has_res ? l.Bnp : 0;
     g.W = prep + b.p_rs_f; g.T = (int)T; g.Np = rs0 + l.Scp; g.Kp = l.Hp;
+    g.Wp = prep + b.p_rs_fp; g.wp_nsl = 32;
     g.e.out = has_res ? xbuf(i + 1) : nullptr; g.e.ldo = l.Bnp;
     g.e.bias = has_res ? params + b.res_b : nullptr; g.e.N = has_res ? l.Bn : 0;
     g.e.Nsplit = rs0; g.e.bias2 = params + b.skip_b; g.e.N2 = l.Sc;
@@ -1041,6 +1084,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     memset(&g, 0, sizeof(g));
     g.a = rows_bf16(has_res ? gout : gskip, ldg, T);
     g.W = prep + b.p_rs_b; g.T = (int)T; g.Np = l.Hp; g.Kp = rs0 + l.Scp;
+    g.Wp = prep + b.p_rs_bp; g.wp_nsl = 32;
     g.e.out = eA; g.e.ldo = l.Hp; g.e.N = l.H;
     g.e.src = z2buf(i); g.e.ld_src = l.Hp; g.e.src_slope = params + b.prelu2;
     g.e.src_stats = stat(2 + 2*i); g.e.inv_n = 1.0/((double)T*l.H); g.e.eps = 1e-8f;

@@ -70,6 +70,8 @@ struct EpiSpec {
 struct GemmRowsParams {
   ASpec a;
   const bf16_t* W;         // [Np][Kp]
+  const bf16_t* Wp;        // optional: W in MFMA-fragment order for slices of wp_nsl rows
+  int wp_nsl;              // (persistent kernels, gemm_ws.cuh)
   int T, Np, Kp;
   int n_ttiles, n_ntiles, batch;   // filled by the launcher (1-D XCD-aware grid)
 #ifdef BRV_DIAG                    // make DIAG=1: ablation flags + cycle stamps (tools/ablate.py)

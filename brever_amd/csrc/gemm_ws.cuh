@@ -82,13 +82,19 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
   {
     // blockIdx.y selects a group of NP output channels when the layer is wider than
     // what one workgroup keeps in registers
-    const bf16_t* wbase = p.W + (long long)(blockIdx.y*C::NP + wn*NSL)*KP;
+    // Wp: the same weights re-packed by brv_ctn_prepare in fragment order (slice, f, s,
+    // lane, 8 values), so that every load instruction reads 1 KiB contiguous; the plain
+    // [N][K] layout makes each instruction touch 32 rows x 32 B (4x the L2 requests in the
+    // prologue every workgroup runs at the same time: pw2_fwd -7 %)
+    const bool packed = p.Wp != nullptr && p.wp_nsl == NSL;
+    const bf16_t* wbase = (packed ? p.Wp : p.W) + (long long)(blockIdx.y*C::NP + wn*NSL)*KP;
 #pragma unroll
     for (int f = 0; f < C::NF; ++f)
 #pragma unroll
       for (int s = 0; s < C::KS; ++s)
-        wf[f][s] = *reinterpret_cast<const bf16x8*>(wbase + (long long)(32*f + fr)*KP
-                                                    + 16*s + 8*fh);
+        wf[f][s] = *reinterpret_cast<const bf16x8*>(
+            packed ? wbase + ((long long)(f*C::KS + s)*64 + lane)*8
+                   : wbase + (long long)(32*f + fr)*KP + 16*s + 8*fh);
   }
 
   // ---- tile schedule: contiguous range per workgroup ------------------------------
