@@ -353,11 +353,17 @@ template <int P> struct DwFwd {
 };
 template <int P> struct DwBwd {
   static int run(const DwParams& p, hipStream_t st) {
-    const bool fuse = p.z2in != nullptr;
-    ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, (fuse ? 8.0 : 6.0)*p.B*p.T*(double)p.Cp, st);
+    if (p.z2in != nullptr) {      // gLN_2 backward fused: dz2 built once per element in LDS
+      ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 8.0*p.B*p.T*(double)p.Cp, st);
+      dim3 grid(ceil_div(p.T, HL_TT)*p.B*(p.Cp/HL_CG));
+      const size_t lds = (size_t)(HL_TT + (P - 1)*p.dil)*HL_CG*2;
+      hipLaunchKernelGGL((dwconv_bwd_halo_kernel<P>), grid, dim3(256), lds, st, p);
+      HIP_OK(hipGetLastError());
+      return 0;
+    }
+    ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 6.0*p.B*p.T*(double)p.Cp, st);
     dim3 grid(ceil_div(p.T, DW_TT_B)*p.B);
-    if (fuse) hipLaunchKernelGGL((dwconv_bwd_kernel<P, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((dwconv_bwd_kernel<P, false>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((dwconv_bwd_kernel<P>), grid, dim3(256), 0, st, p);
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -1093,10 +1099,11 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
     g.e.sums_out = sum(2 + 2*i);
     if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + 2*l.Hp))) return r;
-    // gLN_2 + prelu_2 backward: fused into the depthwise backward below (dz2 is rebuilt at
-    // each tap from e2 and z2 and never written). Opt-in (BRV_DZ_FUSE=1): rebuilding dz2 three
-    // times makes the stencil VALU-bound, 84 us vs 51 + 37 us for the two passes -- a wash
-    static const bool fuse_dz2 = getenv("BRV_DZ_FUSE") != nullptr;
+    // gLN_2 + prelu_2 backward: fused into the depthwise backward below when its LDS window
+    // (tile + halo rows) fits -- dz2 is then built once per element in LDS and never written
+    // (dwconv_bwd_halo_kernel). BRV_NO_DZ_FUSE keeps the separate pass.
+    const bool fuse_dz2 = !getenv("BRV_NO_DZ_FUSE") && l.Hp % HL_CG == 0 &&
+                          HL_TT + (l.P - 1)*dil <= HL_MAXROWS;
     DzParams dz; memset(&dz, 0, sizeof(dz));
     if (!fuse_dz2) {
       dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;

@@ -31,8 +31,8 @@ struct DwParams {
   double* stats2; const float* slope2;                   // fwd
   float* dgamma1; float* dbeta1; float* dtaps; float* dbias; double* sums1;   // bwd
   long long rep_stride;    // bwd: per-channel gradients go to replica (wg % kReplicas)
-  // bwd, fused gLN_2 / PReLU_2 backward: dz2 is rebuilt at every tap from e2 = gamma2*dy
-  // (passed in `dz2`) and z2, so the dz2 tensor never exists in HBM
+  // bwd, fused gLN_2 / PReLU_2 backward (dwconv_bwd_halo_kernel): `dz2` then carries
+  // e2 = gamma2*dy and dz2 is built from it and z2 in LDS; it never exists in HBM
   const bf16_t* z2in; const double* sums2; float* dslope2;
 };
 
@@ -227,12 +227,12 @@ __global__ __launch_bounds__(256) void dz_kernel(const DzParams p) {
 }
 
 // ---------------------------------------------------------------------------
-template <int P, bool FUSE>
+template <int P>
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
   __shared__ float red[4*512];
   __shared__ double dscr[16];
   constexpr int DW_RPW = DW_TT_B/4;
-  constexpr int UB = FUSE ? 1 : 2;         // frames in flight per wave (register budget)
+  constexpr int UB = 2;                    // frames in flight per wave
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = p.T;
   const int n_tt = ceil_div(T, DW_TT_B);
@@ -245,17 +245,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
 
   // gLN_1 input statistics as scalars: xh = (prelu(z) - mean)*rstd = xa*z + xb*|z| + xc
   const float xa = 0.5f*(1.f + a1)*ns.rstd, xb = 0.5f*(1.f - a1)*ns.rstd, xc = -ns.mean*ns.rstd;
-  // fused gLN_2 backward (FUSE): dz2 = prelu2'(z2)*rstd2*(e2 - m1 - xh2*m2) with
-  // xh2 = ya*z2 + yb*|z2| + yc; as u = e2*R + K0 - xh2*M2R
-  float ya = 0.f, yb = 0.f, yc = 0.f, R2 = 0.f, K0 = 0.f, M2R = 0.f, a2 = 1.f, da2 = 0.f;
-  if (FUSE) {
-    const NormStat n2 = norm_stat(p.stats2, b, p.inv_n, p.eps);
-    a2 = *p.slope2;
-    const float m1 = (float)(p.sums2[stat_sum(b)]*p.inv_n);
-    const float m2 = (float)(p.sums2[stat_sq(b)]*p.inv_n);
-    ya = 0.5f*(1.f + a2)*n2.rstd; yb = 0.5f*(1.f - a2)*n2.rstd; yc = -n2.mean*n2.rstd;
-    R2 = n2.rstd; K0 = -m1*n2.rstd; M2R = m2*n2.rstd;
-  }
   // tap whose output frame is the input frame itself (the centre tap of a "same" padding):
   // its dz2 doubles as the centre value of the bias gradient
   int kc = -1;
@@ -293,8 +282,6 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
     const __amdgpu_buffer_rsrc_t rdz = make_rsrc(p.dz2 + (long long)b*T*p.Cp, lane_ok ? (long long)T*p.Cp*2 : 0);
     const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(p.z1 + (long long)b*T*p.Cp, lane_ok ? (long long)T*p.Cp*2 : 0);
     const __amdgpu_buffer_rsrc_t re1 = make_rsrc(p.e1 + (long long)b*T*p.Cp, lane_ok ? (long long)T*p.Cp*2 : 0);
-    const __amdgpu_buffer_rsrc_t rz2 = make_rsrc(p.z2in + (long long)b*T*p.Cp,
-                                                 (FUSE && lane_ok) ? (long long)T*p.Cp*2 : 0);
     const unsigned int coff = (unsigned int)(c0*2), row = (unsigned int)(p.Cp*2);
     float l1 = 0.f, l2 = 0.f;
 #pragma unroll 1
@@ -304,7 +291,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
       // The same values serve the data gradient (sum_k w[k]*dz2[t']) and, paired with
       // h1n at frame t itself, the tap gradient: sum_t' dz2[t']*h1n[t'+shift] re-indexed
       // over t = t'+shift. No shifted read of z1 is needed.
-      uint4 raw[UB][P], rawz[UB], rawc[UB], raw2[UB][FUSE ? P : 1], rawc2[UB];
+      uint4 raw[UB][P], rawz[UB], rawc[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int t = tw0 + i0 + u;
@@ -314,11 +301,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
           const int to = t - (k*p.dil - p.left);
           const unsigned int off = live ? (unsigned int)to*row + coff : kOob;
           raw[u][k] = buf_load16(rdz, off);
-          if (FUSE) raw2[u][k] = buf_load16(rz2, off);
         }
         rawz[u] = buf_load16(rz1, (unsigned int)t*row + coff);
         rawc[u] = buf_load16(rdz, kc < 0 ? (unsigned int)t*row + coff : kOob);
-        if (FUSE) rawc2[u] = buf_load16(rz2, kc < 0 ? (unsigned int)t*row + coff : kOob);
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -333,29 +318,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
           hn[j] = gm[j]*xh[j] + be[j];                  // gLN_1 output at frame t
           dh[j] = f32x2{0.f, 0.f};
         }
-        // dz2 of one loaded frame; `on` (wave-uniform) zeroes frames outside the item
-        // (their e2 / z2 read as zeros, which alone would leave the constant terms)
-        auto dz2_of = [&](const uint4& qe, const uint4& qz, float on, bool centre, float (&g)[8]) {
-          unpack8(qe, g);
-          if (!FUSE) return;
-          float z[8];
-          unpack8(qz, z);
-          const float r = on*R2, k0 = on*K0, m = -on*M2R;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float xh2 = __builtin_fmaf(yb, __builtin_fabsf(z[j]), __builtin_fmaf(ya, z[j], yc));
-            const float uu = __builtin_fmaf(m, xh2, __builtin_fmaf(g[j], r, k0));
-            const bool pos = z[j] > 0.f;
-            g[j] = pos ? uu : a2*uu;
-            if (centre) da2 += pos ? 0.f : uu*z[j];      // slope gradient: each element once
-          }
-        };
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-          const int to = t - (k*p.dil - p.left);
-          const float on = (t < T && to >= 0 && to < T) ? 1.f : 0.f;
           float g[8];
-          dz2_of(raw[u][k], raw2[u][FUSE ? k : 0], on, k == kc, g);
+          unpack8(raw[u][k], g);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const f32x2 gk = {g[2*j], g[2*j + 1]};
@@ -366,7 +332,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
         }
         if (kc < 0) {
           float g[8];
-          dz2_of(rawc[u], rawc2[u], t < T ? 1.f : 0.f, true, g);
+          unpack8(rawc[u], g);
 #pragma unroll
           for (int j = 0; j < 4; ++j) dbia[j] += f32x2{g[2*j], g[2*j + 1]};
         }
@@ -410,11 +376,205 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
     atomic_add_f64(p.sums1 + stat_sum(b), r0);
     atomic_add_f64(p.sums1 + stat_sq(b), r1);
   }
-  if (FUSE) {
-    __syncthreads();
-    const float sa = block_sum(da2, red);
-    if (tid == 0) atomic_add_f32(p.dslope2 + (long long)(blockIdx.x % kReplicas)*p.rep_stride, sa);
+}
+
+// ---------------------------------------------------------------------------
+// Depthwise-conv backward with the gLN_2 / PReLU_2 backward folded in, each dz2 element
+// computed ONCE: a workgroup owns (item, HL_TT frames, HL_CG channels), first builds
+// dz2 = prelu2'(z2)*rstd2*(e2 - m1 - xh2*m2) for its frames plus the (P-1)*dil halo the taps
+// reach into LDS (bf16), then runs the transposed stencil out of LDS. The dz2 tensor never
+// exists in HBM: the separate gln_prelu_bwd pass (read e2, z2; write dz2) and this kernel's
+// re-read of dz2 become one read of e2 and z2 with a halo overhead of (P-1)*dil/HL_TT
+// (25 % averaged over the dilations 1..128). Replaces dz_kernel + dwconv_bwd_kernel for
+// gLN_2; outputs and parameter gradients are the same.
+constexpr int HL_TT = 256;                 // frames per workgroup
+constexpr int HL_CG = 64;                  // channels per workgroup (128-byte rows)
+constexpr int HL_MAXROWS = 512;            // LDS window: HL_TT + (P-1)*dil rows of 128 B
+
+template <int P>
+__global__ __launch_bounds__(256) void dwconv_bwd_halo_kernel(const DwParams p) {
+  // window of (HL_TT + halo) rows x 128 B, sized at launch: small dilations leave room for
+  // a third workgroup per CU
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  bf16_t* win = reinterpret_cast<bf16_t*>(dyn_lds);
+  __shared__ float red[32*HL_CG];
+  __shared__ double dscr[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int T = p.T;
+  const int n_tt = ceil_div(T, HL_TT), n_cg = p.Cp/HL_CG;
+  int id = blockIdx.x;
+  const int cg = id % n_cg; id /= n_cg;
+  const int b = id / n_tt;
+  const int t0 = (id % n_tt)*HL_TT;
+  const int cl = (tid & 7)*8;                          // channel offset inside the group
+  const int c0 = cg*HL_CG + cl;
+  const int rslot = tid >> 3;                          // 32 row slots per pass
+  const int halo = (P - 1)*p.dil;
+  const int W = HL_TT + halo;                          // rows of the window
+  const int ws = t0 - halo + p.left;                   // frame of window row 0
+
+  // ---- phase 1: dz2 of the window -> LDS ------------------------------------------------
+  const NormStat n2 = norm_stat(p.stats2, b, p.inv_n, p.eps);
+  const float a2 = *p.slope2;
+  const float m1 = (float)(p.sums2[stat_sum(b)]*p.inv_n);
+  const float m2 = (float)(p.sums2[stat_sq(b)]*p.inv_n);
+  const float ya = 0.5f*(1.f + a2)*n2.rstd, yb = 0.5f*(1.f - a2)*n2.rstd, yc = -n2.mean*n2.rstd;
+  const float R2 = n2.rstd, K0 = -m1*n2.rstd, M2R = -m2*n2.rstd;
+  const __amdgpu_buffer_rsrc_t re2 = make_rsrc(p.dz2 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+  const __amdgpu_buffer_rsrc_t rz2 = make_rsrc(p.z2in + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+  const unsigned int row = (unsigned int)(p.Cp*2), coff = (unsigned int)(c0*2);
+  float da2 = 0.f;
+  f32x2 dbia[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dbia[j] = f32x2{0.f, 0.f};
+  // four rows per thread in flight (8 loads) before any of them is consumed
+  for (int r0 = rslot; r0 < W; r0 += 128) {
+    uint4 qe[4], qz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 32*u, tf = ws + r;
+      const bool in = r < W && tf >= 0 && tf < T;
+      const unsigned int off = in ? (unsigned int)tf*row + coff : kOob;
+      qe[u] = buf_load16(re2, off); qz[u] = buf_load16(rz2, off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 32*u, tf = ws + r;
+      if (r >= W) break;
+      const bool in = tf >= 0 && tf < T;
+      float e[8], z[8], g[8];
+      unpack8(qe[u], e); unpack8(qz[u], z);
+      const float on = in ? 1.f : 0.f;
+      const float rr = on*R2, k0 = on*K0, mm = on*M2R;
+      const bool centre = tf >= t0 && tf < t0 + HL_TT;   // each element is "owned" by one tile
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh2 = __builtin_fmaf(yb, __builtin_fabsf(z[j]), __builtin_fmaf(ya, z[j], yc));
+        const float uu = __builtin_fmaf(mm, xh2, __builtin_fmaf(e[j], rr, k0));
+        const bool pos = z[j] > 0.f;
+        g[j] = c0 + j < p.C ? (pos ? uu : a2*uu) : 0.f;
+        if (centre && !pos) da2 += uu*z[j];
+      }
+      const uint4 q = pack8(g);
+      *reinterpret_cast<uint4*>(win + r*HL_CG + cl) = q;
+      if (centre) {                                      // bias gradient = sum of (rounded) dz2
+        float gr[8]; unpack8(q, gr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dbia[j] += f32x2{gr[2*j], gr[2*j + 1]};
+      }
+    }
   }
+  __syncthreads();
+
+  // ---- phase 2: transposed stencil out of LDS -------------------------------------------------
+  const NormStat ns = norm_stat(p.stats1, b, p.inv_n, p.eps);
+  const float a1 = *p.slope1;
+  const float xa = 0.5f*(1.f + a1)*ns.rstd, xb = 0.5f*(1.f - a1)*ns.rstd, xc = -ns.mean*ns.rstd;
+  f32x2 gm[4], be[4], w[P][4];
+  {
+    float g8[8], b8[8], tp[P][8];
+    load8_masked(p.gamma1, c0, p.C, g8);
+    load8_masked(p.beta1, c0, p.C, b8);
+#pragma unroll
+    for (int k = 0; k < P; ++k) load8_masked(p.taps, c0*P + 8*k, p.C*P, tp[k]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gm[j] = f32x2{g8[2*j], g8[2*j + 1]};
+      be[j] = f32x2{b8[2*j], b8[2*j + 1]};
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        w[k][j] = f32x2{tp[(2*j*P + k)/8][(2*j*P + k)%8], tp[((2*j + 1)*P + k)/8][((2*j + 1)*P + k)%8]};
+    }
+  }
+  f32x2 dgam[4], dbet[4], dtap[P][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dgam[j] = f32x2{0.f, 0.f}; dbet[j] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < P; ++k) dtap[k][j] = f32x2{0.f, 0.f};
+  }
+  const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(p.z1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+  const __amdgpu_buffer_rsrc_t re1 = make_rsrc(p.e1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+  float l1 = 0.f, l2 = 0.f;
+  for (int i0 = rslot; i0 < HL_TT; i0 += 128) {
+   uint4 qz4[4];
+#pragma unroll
+   for (int u = 0; u < 4; ++u)
+     qz4[u] = buf_load16(rz1, (unsigned int)(t0 + i0 + 32*u)*row + coff);   // t >= T: zeros
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+    const int i = i0 + 32*u;
+    const int t = t0 + i;
+    const uint4 qz = qz4[u];
+    const float live = t < T ? 1.f : 0.f;
+    float zc[8];
+    unpack8(qz, zc);
+    f32x2 xh[4], hn[4], dh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j].x = __builtin_fmaf(xb, __builtin_fabsf(zc[2*j]), __builtin_fmaf(xa, zc[2*j], xc));
+      xh[j].y = __builtin_fmaf(xb, __builtin_fabsf(zc[2*j + 1]), __builtin_fmaf(xa, zc[2*j + 1], xc));
+      hn[j] = f32x2{live, live}*(gm[j]*xh[j] + be[j]);   // gLN_1 output at frame t (0 past the end)
+      dh[j] = f32x2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      // output frame that reads frame t through tap k: t - (k*dil - left) = window row
+      const int r = i + halo - k*p.dil;
+      float g[8];
+      unpack8(*reinterpret_cast<const uint4*>(win + r*HL_CG + cl), g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 gk = {g[2*j], g[2*j + 1]};
+        dh[j] += w[k][j]*gk;
+        dtap[k][j] += gk*hn[j];
+      }
+    }
+    f32x2 o[4], a1s = {0.f, 0.f}, a2s = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 dl = f32x2{live, live}*dh[j];          // frames past the end contribute nothing
+      const f32x2 ev = gm[j]*dl;
+      o[j] = ev;
+      a1s += ev; a2s += ev*xh[j];
+      dgam[j] += dl*xh[j]; dbet[j] += dl;
+    }
+    l1 += a1s.x + a1s.y; l2 += a2s.x + a2s.y;
+    buf_store16(re1, (unsigned int)t*row + coff, pack8v(o));            // t >= T: dropped
+   }
+  }
+
+  // ---- reductions: 32 row slots share each channel chunk ----------------------------------------
+  auto reduce_cols = [&](const f32x2 (&v)[4], float* dst, int stride, int offset) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[rslot*HL_CG + cl + 2*j] = v[j].x; red[rslot*HL_CG + cl + 2*j + 1] = v[j].y;
+    }
+    __syncthreads();
+    if (tid < HL_CG) {
+      float sum = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) sum += red[r*HL_CG + tid];
+      const int c = cg*HL_CG + tid;
+      float* rdst = dst + (long long)(blockIdx.x % kReplicas)*p.rep_stride;
+      if (c < p.C) atomic_add_f32(rdst + (long long)c*stride + offset, sum);
+    }
+  };
+  reduce_cols(dgam, p.dgamma1, 1, 0);
+  reduce_cols(dbet, p.dbeta1, 1, 0);
+  reduce_cols(dbia, p.dbias, 1, 0);
+#pragma unroll
+  for (int k = 0; k < P; ++k) reduce_cols(dtap[k], p.dtaps, P, k);
+  const double r0 = block_sum((double)l1, dscr);
+  const double r1 = block_sum((double)l2, dscr + 8);
+  if (tid == 0) {
+    atomic_add_f64(p.sums1 + stat_sum(b), r0);
+    atomic_add_f64(p.sums1 + stat_sq(b), r1);
+  }
+  __syncthreads();
+  const float sa = block_sum(da2, red);
+  if (tid == 0) atomic_add_f32(p.dslope2 + (long long)(blockIdx.x % kReplicas)*p.rep_stride, sa);
 }
 
 // ---------------------------------------------------------------------------

@@ -650,8 +650,8 @@ def test_entry_points_ffnn(tmp_path):
 @pytest.mark.parametrize('B,L', [(1, 200), (2, 1100), (5, 16*70 + 5)])
 def test_fused_backward_paths_match_generic_kernels(B, L):
     """The specialised backward kernels of the default widths (atomics-free res/skip weight
-    gradient, gLN/PReLU backward fused into the first conv's data gradient, opt-in fused
-    depthwise stencil) against the generic kernels they replace, on edge sizes: one frame
+    gradient, gLN/PReLU backward fused into the first conv's data gradient and into the depthwise
+    stencil) against the generic kernels they replace, on edge sizes: one frame
     chunk, a ragged last chunk, more items than chunks. Same inputs, same weights; the
     paths differ only in summation order (fp32) and bf16 rounding of one intermediate."""
     from brever_amd.criterion import snr
@@ -664,7 +664,7 @@ def test_fused_backward_paths_match_generic_kernels(B, L):
     lengths = torch.tensor([L - 13*i for i in range(B)], device=dev)
 
     def grads(env):
-        for k in ('BRV_NO_WGRAD_FULL', 'BRV_NO_DZ1_FUSE', 'BRV_DZ_FUSE'):
+        for k in ('BRV_NO_WGRAD_FULL', 'BRV_NO_DZ1_FUSE', 'BRV_NO_DZ_FUSE'):
             os.environ.pop(k, None)
         os.environ.update(env)
         try:
@@ -676,9 +676,9 @@ def test_fused_backward_paths_match_generic_kernels(B, L):
             for k in env:
                 os.environ.pop(k, None)
 
-    base = grads({'BRV_NO_WGRAD_FULL': '1', 'BRV_NO_DZ1_FUSE': '1'})
+    base = grads({'BRV_NO_WGRAD_FULL': '1', 'BRV_NO_DZ1_FUSE': '1', 'BRV_NO_DZ_FUSE': '1'})
     assert torch.isfinite(base).all()
-    for env in ({}, {'BRV_NO_DZ1_FUSE': '1'}, {'BRV_NO_WGRAD_FULL': '1'}, {'BRV_DZ_FUSE': '1'}):
+    for env in ({}, {'BRV_NO_DZ1_FUSE': '1'}, {'BRV_NO_WGRAD_FULL': '1'}, {'BRV_NO_DZ_FUSE': '1'}):
         got = grads(env)
         assert torch.isfinite(got).all(), env
         assert rel(got, base) <= 2e-3, (env, rel(got, base))
