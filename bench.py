@@ -77,10 +77,10 @@ def cpu_baseline():
 
 # bench label -> substring of the HIP kernel name in the rocprofv3 output
 KERNEL_OF_LABEL = {
-    'gln_prelu_bwd': 'dz_kernel', 'dwconv_bwd': 'dwconv_bwd_kernel',
+    'gln_prelu_bwd': 'dz_kernel', 'dwconv_bwd': 'dwconv_bwd_halo_kernel',
     'dwconv_fwd': 'dwconv_fwd_kernel', 'pw2_wgrad': 'wgrad_full_kernel',
     'pw1_fwd': 'gemm_ws_kernel<128, 64, 1, 0,', 'pw2_fwd': 'gemm_ws_kernel<512,',
-    'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': 'gemm_rows_kernel<128, 0, 5>',
+    'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': 'gemm_rows_kernel<128, 3, 5>',
 }
 
 
