@@ -1,0 +1,541 @@
+// DCCRN building blocks, forward values (inference / validation path), fp32.
+// Reference: brever/models/dccrn/dccrn.py:28-358 (DCCRN, DCCRNMaskNet, ComplexWrapper,
+// EncoderBlock, DecoderBlock, LSTMBlock, ComplexLSTM, SingleLayerComplexLSTM) on top of
+// torch's Conv2d / ConvTranspose2d / BatchNorm2d / PReLU / LSTM / Linear.
+// Correctness-first direct kernels (one thread per output element); the dense pieces that
+// matter for speed (STFT / iSTFT, Linear) are the DFT / fp32 GEMM kernels of stft.hip.
+// Layout: NCHW as in the reference, (batch, channels, freqs, frames).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/brever_hip.h"
+#include "common.cuh"
+
+using namespace brv;
+
+namespace {
+
+#define DC_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+dim3 flat_grid(long long n) {
+  long long g = (n + 255)/256;
+  if (g < 1) g = 1;
+  if (g > 8192) g = 8192;
+  return dim3((unsigned)g);
+}
+#define GRID_STRIDE(i, n) \
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < (n); i += (long long)gridDim.x*256)
+
+struct ConvGeom {
+  int B, Cin, H, W, Cout, Ho, Wo, kh, kw, sh, sw, ph, pw;
+  long long x_bs, y_bs;      // batch strides in elements (views of wider tensors)
+};
+
+// y[b][co][ho][wo] (+)= sign*(bias[co] + sum x[b][ci][ho*sh - ph + i][wo*sw - pw + j] w[co][ci][i][j])
+__global__ __launch_bounds__(256) void conv2d_fwd_kernel(const float* x, const float* w,
+                                                         const float* bias, float* y, ConvGeom g,
+                                                         int accumulate, float sign) {
+  const long long total = (long long)g.B*g.Cout*g.Ho*g.Wo;
+  GRID_STRIDE(idx, total) {
+    const int wo = (int)(idx % g.Wo);
+    long long r = idx / g.Wo;
+    const int ho = (int)(r % g.Ho); r /= g.Ho;
+    const int co = (int)(r % g.Cout);
+    const int b = (int)(r / g.Cout);
+    float acc = bias ? bias[co] : 0.f;
+    const float* xb = x + (long long)b*g.x_bs;
+    for (int ci = 0; ci < g.Cin; ++ci) {
+      const float* xc = xb + (long long)ci*g.H*g.W;
+      const float* wc = w + ((long long)co*g.Cin + ci)*g.kh*g.kw;
+      for (int i = 0; i < g.kh; ++i) {
+        const int hi = ho*g.sh - g.ph + i;
+        if (hi < 0 || hi >= g.H) continue;
+        for (int j = 0; j < g.kw; ++j) {
+          const int wi = wo*g.sw - g.pw + j;
+          if (wi < 0 || wi >= g.W) continue;
+          acc += xc[(long long)hi*g.W + wi]*wc[i*g.kw + j];
+        }
+      }
+    }
+    float* dst = y + (long long)b*g.y_bs + ((long long)co*g.Ho + ho)*g.Wo + wo;
+    *dst = accumulate ? *dst + sign*acc : sign*acc;
+  }
+}
+
+// ConvTranspose2d (weight [Cin][Cout][kh][kw]): gather form
+// y[b][co][ho][wo] (+)= sign*(bias[co] + sum_{ci,i,j : ho = hi*sh - ph + i, wo = wi*sw - pw + j} x[b][ci][hi][wi] w[ci][co][i][j])
+__global__ __launch_bounds__(256) void conv_transpose2d_fwd_kernel(const float* x, const float* w,
+                                                                   const float* bias, float* y,
+                                                                   ConvGeom g, int accumulate,
+                                                                   float sign) {
+  const long long total = (long long)g.B*g.Cout*g.Ho*g.Wo;
+  GRID_STRIDE(idx, total) {
+    const int wo = (int)(idx % g.Wo);
+    long long r = idx / g.Wo;
+    const int ho = (int)(r % g.Ho); r /= g.Ho;
+    const int co = (int)(r % g.Cout);
+    const int b = (int)(r / g.Cout);
+    float acc = bias ? bias[co] : 0.f;
+    const float* xb = x + (long long)b*g.x_bs;
+    for (int i = 0; i < g.kh; ++i) {
+      const int hn = ho + g.ph - i;
+      if (hn < 0 || hn % g.sh) continue;
+      const int hi = hn/g.sh;
+      if (hi >= g.H) continue;
+      for (int j = 0; j < g.kw; ++j) {
+        const int wn = wo + g.pw - j;
+        if (wn < 0 || wn % g.sw) continue;
+        const int wi = wn/g.sw;
+        if (wi >= g.W) continue;
+        for (int ci = 0; ci < g.Cin; ++ci)
+          acc += xb[((long long)ci*g.H + hi)*g.W + wi]
+                 *w[(((long long)ci*g.Cout + co)*g.kh + i)*g.kw + j];
+      }
+    }
+    float* dst = y + (long long)b*g.y_bs + ((long long)co*g.Ho + ho)*g.Wo + wo;
+    *dst = accumulate ? *dst + sign*acc : sign*acc;
+  }
+}
+
+// BatchNorm2d statistics: one workgroup per channel (biased variance for the normalisation,
+// unbiased for the running estimate, as torch)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, int B, int C, long long HW,
+                                                       float* mean_out, float* invstd_out,
+                                                       float* running_mean, float* running_var,
+                                                       float eps, float momentum) {
+  __shared__ double scr[8];
+  const int c = blockIdx.x;
+  const long long n = (long long)B*HW;
+  double s = 0.0, q = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) {
+    const float v = x[((long long)(i / HW)*C + c)*HW + i % HW];
+    s += v; q += (double)v*v;
+  }
+  s = block_sum(s, scr);
+  __syncthreads();
+  q = block_sum(q, scr);
+  if (threadIdx.x == 0) {
+    const double mean = s/n;
+    double var = q/n - mean*mean;
+    if (var < 0) var = 0;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = (float)(1.0/sqrt(var + eps));
+    if (running_mean) {
+      const double unbiased = n > 1 ? var*n/(n - 1) : var;
+      running_mean[c] = (1.f - momentum)*running_mean[c] + momentum*(float)mean;
+      running_var[c] = (1.f - momentum)*running_var[c] + momentum*(float)unbiased;
+    }
+  }
+}
+// y = (x - mean[c])*invstd[c]*gamma[c] + beta[c], then optional PReLU (scalar slope)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* mean,
+                                                       const float* invstd, const float* gamma,
+                                                       const float* beta, const float* slope,
+                                                       float* y, int C, long long HW, long long total) {
+  const float a = slope ? *slope : 1.f;
+  GRID_STRIDE(i, total) {
+    const int c = (int)((i / HW) % C);
+    float v = (x[i] - mean[c])*invstd[c]*gamma[c] + beta[c];
+    if (slope) v = v > 0.f ? v : a*v;
+    y[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void invstd_from_var_kernel(const float* var, float* invstd,
+                                                              int C, float eps) {
+  const int c = blockIdx.x*256 + threadIdx.x;
+  if (c < C) invstd[c] = 1.f/sqrtf(var[c] + eps);
+}
+
+// LSTM recurrence for one layer (torch gate order i, f, g, o): gates_in = W_ih x precomputed
+// for all steps, bias = b_ih + b_hh; one workgroup per batch item, h and c in LDS.
+__global__ __launch_bounds__(256) void lstm_recurrent_kernel(const float* gates_in, const float* w_hh,
+                                                             const float* bias, float* y, float* act,
+                                                             float* cs, int T, int H) {
+  extern __shared__ float sm[];                   // h[H] | c[H] | gates[4H]
+  float* h = sm; float* c = sm + H; float* gt = sm + 2*H;
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < H; i += 256) { h[i] = 0.f; c[i] = 0.f; }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const float* gi = gates_in + ((long long)b*T + t)*4*H;
+    for (int r = threadIdx.x; r < 4*H; r += 256) {
+      float acc = gi[r] + (bias ? bias[r] : 0.f);
+      const float* wr = w_hh + (long long)r*H;
+      for (int k = 0; k < H; ++k) acc += wr[k]*h[k];
+      gt[r] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += 256) {
+      const float ig = 1.f/(1.f + expf(-gt[i]));
+      const float fg = 1.f/(1.f + expf(-gt[H + i]));
+      const float gg = tanhf(gt[2*H + i]);
+      const float og = 1.f/(1.f + expf(-gt[3*H + i]));
+      const float cn = fg*c[i] + ig*gg;
+      c[i] = cn;
+      const float hn = og*tanhf(cn);
+      h[i] = hn;
+      y[((long long)b*T + t)*H + i] = hn;
+      if (act) {                                  // saved for the backward pass
+        float* a = act + ((long long)b*T + t)*4*H;
+        a[i] = ig; a[H + i] = fg; a[2*H + i] = gg; a[3*H + i] = og;
+        cs[((long long)b*T + t)*H + i] = cn;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out = a - b  /  a + b  (the real / imaginary recombination of ComplexWrapper)
+__global__ __launch_bounds__(256) void combine_kernel(const float* a, const float* b, float* out,
+                                                      long long n, float sign) {
+  GRID_STRIDE(i, n) out[i] = a[i] + sign*b[i];
+}
+
+// DCCRN.apply_mask (dccrn.py:96-109): polar product with a tanh-bounded mask magnitude
+__global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* xr, const float* xi,
+                                                         const float* mr, const float* mi,
+                                                         float2* out, long long n) {
+  GRID_STRIDE(i, n) {
+    const float a = xr[i], b = xi[i];
+    const float in_mag = sqrtf(a*a + b*b), in_phase = atan2f(b, a);
+    float pr = mr[i];
+    const float pi = mi[i];
+    const float mag = tanhf(sqrtf(pr*pr + pi*pi + 1e-7f));
+    if (pr == 0.f) pr = 1e-7f;
+    const float ph = in_phase + atan2f(pi, pr);
+    const float om = in_mag*mag;
+    out[i] = make_float2(om*cosf(ph), om*sinf(ph));
+  }
+}
+
+
+// Conv2d weight gradient: dw[co][ci][i][j] (+)= sign * sum_{b,ho,wo} dy[b][co][ho][wo] *
+// x[b][ci][ho*sh - ph + i][wo*sw - pw + j]; one workgroup per weight element.
+// (ConvTranspose2d: call with x := the layer's output gradient, dy := the layer's input.)
+__global__ __launch_bounds__(256) void conv2d_wgrad_kernel(const float* x, const float* dy,
+                                                           float* dw, ConvGeom g, int accumulate,
+                                                           float sign) {
+  __shared__ double scr[8];
+  long long id = blockIdx.x;
+  const int j = (int)(id % g.kw); id /= g.kw;
+  const int i = (int)(id % g.kh); id /= g.kh;
+  const int ci = (int)(id % g.Cin);
+  const int co = (int)(id / g.Cin);
+  const long long n = (long long)g.B*g.Ho*g.Wo;
+  double acc = 0.0;
+  for (long long e = threadIdx.x; e < n; e += 256) {
+    const int wo = (int)(e % g.Wo);
+    const int ho = (int)((e / g.Wo) % g.Ho);
+    const int b = (int)(e / ((long long)g.Wo*g.Ho));
+    const int hi = ho*g.sh - g.ph + i, wi = wo*g.sw - g.pw + j;
+    if (hi < 0 || hi >= g.H || wi < 0 || wi >= g.W) continue;
+    acc += (double)dy[(long long)b*g.y_bs + ((long long)co*g.Ho + ho)*g.Wo + wo]
+           *x[(long long)b*g.x_bs + ((long long)ci*g.H + hi)*g.W + wi];
+  }
+  acc = block_sum(acc, scr);
+  if (threadIdx.x == 0) {
+    float* d = dw + blockIdx.x;
+    *d = accumulate ? *d + sign*(float)acc : sign*(float)acc;
+  }
+}
+// db[c] (+)= sign * sum_{b,hw} dy[b][c][hw]
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* dy, float* db, int B,
+                                                          long long HW, long long bs,
+                                                          int accumulate, float sign) {
+  __shared__ double scr[8];
+  const int c = blockIdx.x;
+  double acc = 0.0;
+  for (long long e = threadIdx.x; e < (long long)B*HW; e += 256)
+    acc += dy[(e / HW)*bs + (long long)c*HW + e % HW];
+  acc = block_sum(acc, scr);
+  if (threadIdx.x == 0) db[c] = accumulate ? db[c] + sign*(float)acc : sign*(float)acc;
+}
+
+// BatchNorm2d (+ optional scalar PReLU after it) backward, training mode.
+// pass 1 per channel: dpre = dy*prelu'(u), u = xh*gamma + beta; sums of dpre and dpre*xh;
+//                     slope gradient sum of dy*u over u < 0
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const float* dy,
+                                                           const float* mean, const float* invstd,
+                                                           const float* gamma, const float* beta,
+                                                           const float* slope, int B, int C,
+                                                           long long HW, float* dgamma,
+                                                           float* dbeta, float* dslope_part) {
+  __shared__ double scr[8];
+  const int c = blockIdx.x;
+  const float a = slope ? *slope : 1.f;
+  double s1 = 0.0, s2 = 0.0, sa = 0.0;
+  for (long long e = threadIdx.x; e < (long long)B*HW; e += 256) {
+    const long long idx = ((e / HW)*C + c)*HW + e % HW;
+    const float xh = (x[idx] - mean[c])*invstd[c];
+    const float u = xh*gamma[c] + beta[c];
+    float d = dy[idx];
+    if (slope && u <= 0.f) { sa += (double)d*u; d *= a; }
+    s1 += d; s2 += (double)d*xh;
+  }
+  s1 = block_sum(s1, scr); __syncthreads();
+  s2 = block_sum(s2, scr); __syncthreads();
+  sa = block_sum(sa, scr);
+  if (threadIdx.x == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; dslope_part[c] = (float)sa; }
+}
+// pass 2: dx = gamma*invstd*(dpre - dbeta/n - xh*dgamma/n)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const float* dy,
+                                                           const float* mean, const float* invstd,
+                                                           const float* gamma, const float* beta,
+                                                           const float* slope, const float* dgamma,
+                                                           const float* dbeta, float* dx, int C,
+                                                           long long HW, long long total,
+                                                           float inv_n) {
+  const float a = slope ? *slope : 1.f;
+  GRID_STRIDE(i, total) {
+    const int c = (int)((i / HW) % C);
+    const float xh = (x[i] - mean[c])*invstd[c];
+    const float u = xh*gamma[c] + beta[c];
+    float d = dy[i];
+    if (slope && u <= 0.f) d *= a;
+    dx[i] = gamma[c]*invstd[c]*(d - dbeta[c]*inv_n - xh*dgamma[c]*inv_n);
+  }
+}
+
+// LSTM backward through time for one layer and one batch item per workgroup.
+// Saved by the forward: act (B, T, 4H) gate activations (i, f, g, o), cs (B, T, H) cell states,
+// y (B, T, H) hidden states. In: dy (B, T, H). Out: dgates (B, T, 4H) = gradient wrt the gate
+// pre-activations (the weight / input gradients are GEMMs over it).
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* act, const float* cs,
+                                                       const float* w_hh, const float* dy,
+                                                       float* dgates, int T, int H) {
+  extern __shared__ float sm[];                   // dh[H] | dc[H] | dg[4H]
+  float* dh = sm; float* dc = sm + H; float* dg = sm + 2*H;
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < H; i += 256) { dh[i] = 0.f; dc[i] = 0.f; }
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    const float* a = act + ((long long)b*T + t)*4*H;
+    for (int i = threadIdx.x; i < H; i += 256) {
+      const float ig = a[i], fg = a[H + i], gg = a[2*H + i], og = a[3*H + i];
+      const float c = cs[((long long)b*T + t)*H + i];
+      const float cprev = t > 0 ? cs[((long long)b*T + t - 1)*H + i] : 0.f;
+      const float tc = tanhf(c);
+      const float dht = dh[i] + dy[((long long)b*T + t)*H + i];
+      const float dct = dc[i] + dht*og*(1.f - tc*tc);
+      dg[i] = dct*gg*ig*(1.f - ig);
+      dg[H + i] = dct*cprev*fg*(1.f - fg);
+      dg[2*H + i] = dct*ig*(1.f - gg*gg);
+      dg[3*H + i] = dht*tc*og*(1.f - og);
+      dc[i] = dct*fg;
+    }
+    __syncthreads();
+    float* out = dgates + ((long long)b*T + t)*4*H;
+    for (int r = threadIdx.x; r < 4*H; r += 256) out[r] = dg[r];
+    // dh_{t-1} = W_hh^T dg
+    for (int k = threadIdx.x; k < H; k += 256) {
+      float acc = 0.f;
+      for (int r = 0; r < 4*H; ++r) acc += w_hh[(long long)r*H + k]*dg[r];
+      dh[k] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// gradient of DCCRN.apply_mask with respect to the mask (the input spectrum needs none)
+__global__ __launch_bounds__(256) void dccrn_mask_bwd_kernel(const float* xr, const float* xi,
+                                                             const float* mr, const float* mi,
+                                                             const float2* gout, float* dmr,
+                                                             float* dmi, long long n) {
+  GRID_STRIDE(i, n) {
+    const float a = xr[i], b = xi[i];
+    const float in_mag = sqrtf(a*a + b*b), in_phase = atan2f(b, a);
+    const float pr0 = mr[i], pi = mi[i];
+    const float r1 = sqrtf(pr0*pr0 + pi*pi + 1e-7f);
+    const float M = tanhf(r1);
+    const float pr = pr0 == 0.f ? 1e-7f : pr0;
+    const float ph = in_phase + atan2f(pi, pr);
+    const float cs = cosf(ph), sn = sinf(ph);
+    const float2 g = gout[i];
+    const float dM = in_mag*(g.x*cs + g.y*sn);
+    const float dP = in_mag*M*(-g.x*sn + g.y*cs);
+    const float dMr = (1.f - M*M)/r1;
+    const float r2 = pr*pr + pi*pi;
+    dmr[i] = dM*dMr*pr0 + dP*(-pi/r2);
+    dmi[i] = dM*dMr*pi + dP*(pr/r2);
+  }
+}
+
+// dy[q] /= window-square envelope of torch.istft at sample q (centre padding n/2)
+__global__ __launch_bounds__(256) void env_divide_kernel(const float* dy, const float* win,
+                                                         float* out, int rows, int len, int n,
+                                                         int hop, int F) {
+  const long long total = (long long)rows*len;
+  GRID_STRIDE(idx, total) {
+    const int q = (int)(idx % len);
+    const int pos = q + n/2;
+    int t_hi = pos/hop; if (t_hi > F - 1) t_hi = F - 1;
+    int t_lo = (pos - n + hop)/hop; if (pos - n + 1 <= 0) t_lo = 0;
+    if (t_lo < 0) t_lo = 0;
+    float env = 0.f;
+    for (int t = t_lo; t <= t_hi; ++t) {
+      const int m = pos - t*hop;
+      if (m >= 0 && m < n) env += win[m]*win[m];
+    }
+    out[idx] = dy[idx]/env;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int brv_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int64_t B,
+                       int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t kh, int64_t kw,
+                       int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t x_batch_stride,
+                       int64_t y_batch_stride, int accumulate, float sign, brv_stream_t stream) {
+  ConvGeom g;
+  g.B = (int)B; g.Cin = (int)Cin; g.H = (int)H; g.W = (int)W; g.Cout = (int)Cout;
+  g.kh = (int)kh; g.kw = (int)kw; g.sh = (int)sh; g.sw = (int)sw; g.ph = (int)ph; g.pw = (int)pw;
+  g.Ho = (int)((H + 2*ph - kh)/sh + 1); g.Wo = (int)((W + 2*pw - kw)/sw + 1);
+  g.x_bs = x_batch_stride; g.y_bs = y_batch_stride;
+  if (B < 1 || g.Ho < 1 || g.Wo < 1) return -1;
+  hipLaunchKernelGGL(conv2d_fwd_kernel, flat_grid((long long)B*Cout*g.Ho*g.Wo), dim3(256), 0,
+                     (hipStream_t)stream, x, w, bias, y, g, accumulate, sign);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_conv_transpose2d_forward(const float* x, const float* w, const float* bias, float* y,
+                                 int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                 int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph,
+                                 int64_t pw, int64_t oph, int64_t opw, int64_t x_batch_stride,
+                                 int64_t y_batch_stride, int accumulate, float sign,
+                                 brv_stream_t stream) {
+  ConvGeom g;
+  g.B = (int)B; g.Cin = (int)Cin; g.H = (int)H; g.W = (int)W; g.Cout = (int)Cout;
+  g.kh = (int)kh; g.kw = (int)kw; g.sh = (int)sh; g.sw = (int)sw; g.ph = (int)ph; g.pw = (int)pw;
+  g.Ho = (int)((H - 1)*sh - 2*ph + kh + oph); g.Wo = (int)((W - 1)*sw - 2*pw + kw + opw);
+  g.x_bs = x_batch_stride; g.y_bs = y_batch_stride;
+  if (B < 1 || g.Ho < 1 || g.Wo < 1) return -1;
+  hipLaunchKernelGGL(conv_transpose2d_fwd_kernel, flat_grid((long long)B*Cout*g.Ho*g.Wo),
+                     dim3(256), 0, (hipStream_t)stream, x, w, bias, y, g, accumulate, sign);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_batchnorm2d_forward(const float* x, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, const float* prelu_slope,
+                            float* y, float* save_mean, float* save_invstd, int64_t B, int64_t C,
+                            int64_t HW, float eps, float momentum, int training,
+                            brv_stream_t stream) {
+  if (B < 1 || C < 1 || HW < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (training) {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)C), dim3(256), 0, st, x, (int)B, (int)C,
+                       (long long)HW, save_mean, save_invstd, running_mean, running_var, eps,
+                       momentum);
+  } else {
+    DC_OK(hipMemcpyAsync(save_mean, running_mean, (size_t)C*4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(invstd_from_var_kernel, dim3((unsigned)((C + 255)/256)), dim3(256), 0, st,
+                       running_var, save_invstd, (int)C, eps);
+  }
+  const long long total = B*C*HW;
+  hipLaunchKernelGGL(bn_apply_kernel, flat_grid(total), dim3(256), 0, st, x, save_mean,
+                     save_invstd, gamma, beta, prelu_slope, y, (int)C, (long long)HW, total);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_lstm_recurrent_forward(const float* gates_in, const float* w_hh, const float* bias,
+                               float* y, float* act, float* cs, int64_t B, int64_t T, int64_t H,
+                               brv_stream_t stream) {
+  if (B < 1 || T < 1 || H < 1) return -1;
+  hipLaunchKernelGGL(lstm_recurrent_kernel, dim3((unsigned)B), dim3(256), (size_t)6*H*4,
+                     (hipStream_t)stream, gates_in, w_hh, bias, y, act, cs, (int)T, (int)H);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_combine(const float* a, const float* b, float* out, int64_t n, float sign,
+                brv_stream_t stream) {
+  if (n < 1) return -1;
+  hipLaunchKernelGGL(combine_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                     (long long)n, sign);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_dccrn_apply_mask(const float* xr, const float* xi, const float* mr, const float* mi,
+                         float* out, int64_t n, brv_stream_t stream) {
+  if (n < 1) return -1;
+  hipLaunchKernelGGL(dccrn_mask_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, xr, xi,
+                     mr, mi, (float2*)out, (long long)n);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int64_t B,
+                     int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t Ho, int64_t Wo,
+                     int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                     int64_t x_batch_stride, int64_t dy_batch_stride, int accumulate, float sign,
+                     brv_stream_t stream) {
+  ConvGeom g;
+  g.B = (int)B; g.Cin = (int)Cin; g.H = (int)H; g.W = (int)W; g.Cout = (int)Cout;
+  g.kh = (int)kh; g.kw = (int)kw; g.sh = (int)sh; g.sw = (int)sw; g.ph = (int)ph; g.pw = (int)pw;
+  g.Ho = (int)Ho; g.Wo = (int)Wo; g.x_bs = x_batch_stride; g.y_bs = dy_batch_stride;
+  if (B < 1 || Ho < 1 || Wo < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv2d_wgrad_kernel, dim3((unsigned)(Cout*Cin*kh*kw)), dim3(256), 0, st, x,
+                     dy, dw, g, accumulate, sign);
+  if (dbias)
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)Cout), dim3(256), 0, st, dy, dbias,
+                       (int)B, (long long)Ho*Wo, (long long)dy_batch_stride, accumulate, sign);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_mean,
+                             const float* save_invstd, const float* gamma, const float* beta,
+                             const float* prelu_slope, float* dx, float* dgamma, float* dbeta,
+                             float* dslope_partial, int64_t B, int64_t C, int64_t HW,
+                             brv_stream_t stream) {
+  if (B < 1 || C < 1 || HW < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)C), dim3(256), 0, st, x, dy, save_mean,
+                     save_invstd, gamma, beta, prelu_slope, (int)B, (int)C, (long long)HW, dgamma,
+                     dbeta, dslope_partial);
+  const long long total = B*C*HW;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, flat_grid(total), dim3(256), 0, st, x, dy, save_mean,
+                     save_invstd, gamma, beta, prelu_slope, dgamma, dbeta, dx, (int)C,
+                     (long long)HW, total, 1.f/(float)(B*HW));
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* w_hh,
+                                const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
+                                brv_stream_t stream) {
+  if (B < 1 || T < 1 || H < 1) return -1;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)6*H*4,
+                     (hipStream_t)stream, act, cs, w_hh, dy, dgates, (int)T, (int)H);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_dccrn_apply_mask_backward(const float* xr, const float* xi, const float* mr,
+                                  const float* mi, const float* gout, float* dmr, float* dmi,
+                                  int64_t n, brv_stream_t stream) {
+  if (n < 1) return -1;
+  hipLaunchKernelGGL(dccrn_mask_bwd_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, xr,
+                     xi, mr, mi, (const float2*)gout, dmr, dmi, (long long)n);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_istft_env_divide(const float* dy, const float* window, float* out, int64_t rows,
+                         int64_t length, int64_t frame_length, int64_t hop_length, int64_t frames,
+                         brv_stream_t stream) {
+  if (rows < 1 || length < 1) return -1;
+  hipLaunchKernelGGL(env_divide_kernel, flat_grid(rows*length), dim3(256), 0, (hipStream_t)stream,
+                     dy, window, out, (int)rows, (int)length, (int)frame_length, (int)hop_length,
+                     (int)frames);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

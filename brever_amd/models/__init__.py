@@ -4,6 +4,7 @@ import torch
 
 from .base import BreverBaseModel, ModelRegistry  # noqa: F401
 from .convtasnet import ConvTasNet  # noqa: F401
+from .dccrn import DCCRN  # noqa: F401
 from .ffnn import FFNN  # noqa: F401
 
 

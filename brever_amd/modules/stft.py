@@ -69,6 +69,46 @@ class _StftFunction(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class _IstftFunction(torch.autograd.Function):
+    """spec (rows, bins, F) complex64 -> y (rows, hop*(F-1)): ``brv_istft_backward``; the
+    gradient (compression 1 only) is the window-envelope division followed by a framed DFT
+    with the transposed inverse basis."""
+
+    @staticmethod
+    def forward(ctx, spec, inv, win, inv_t, frame_length, hop_length, compression, scale):
+        rows, bins, F = spec.shape
+        spec_r = torch.view_as_real(spec.contiguous())
+        scratch = torch.empty(rows, F, frame_length, dtype=torch.float32, device=spec.device)
+        out_len = hop_length*(F - 1)
+        y = torch.empty(rows, out_len, dtype=torch.float32, device=spec.device)
+        hip.check(hip.lib().brv_istft_backward(
+            hip.ptr(spec_r), hip.ptr(inv), hip.ptr(win), hip.ptr(scratch), hip.ptr(y), rows, F,
+            frame_length, hop_length, float(compression), float(scale), hip.stream()),
+            'brv_istft_backward')
+        ctx.save_for_backward(win, inv_t)
+        ctx.geom = (rows, bins, F, frame_length, hop_length, float(compression), float(scale))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        win, inv_t = ctx.saved_tensors
+        rows, bins, F, n, hop, compression, scale = ctx.geom
+        if compression != 1:
+            raise NotImplementedError('gradient of the magnitude compression is not built yet '
+                                      'on the HIP path')
+        lib = hip.lib()
+        dy = dy.float().contiguous()
+        out_len = dy.shape[-1]
+        u = torch.empty_like(dy)
+        hip.check(lib.brv_istft_env_divide(hip.ptr(dy), hip.ptr(win), hip.ptr(u), rows, out_len,
+                                           n, hop, F, hip.stream()), 'brv_istft_env_divide')
+        dspec = torch.empty(rows, bins, F, 2, dtype=torch.float32, device=dy.device)
+        hip.check(lib.brv_framed_dft_forward(
+            hip.ptr(u), hip.ptr(inv_t), hip.ptr(dspec), rows, out_len, n, hop, n//2, F, 1.0,
+            1.0/scale, hip.stream()), 'brv_framed_dft_forward')
+        return torch.view_as_complex(dspec), None, None, None, None, None, None, None
+
+
 def stft_adjoint(dspec, basis, rows, L, frame_length, hop_length, frames, scale):
     """dx (rows, L) = adjoint of the framed DFT applied to dspec (rows, bins, F, 2)."""
     scratch = torch.empty(rows, frames, frame_length, dtype=torch.float32, device=dspec.device)
@@ -144,6 +184,9 @@ class STFT:
                 torch.from_numpy(inv).float().to(device).contiguous(),
                 self.window.float().to(device).contiguous(),
             )
+            # transposed inverse basis: the adjoint of the inverse transform is a framed DFT
+            self._inv_t = getattr(self, '_inv_t', {})
+            self._inv_t[key] = torch.from_numpy(np.ascontiguousarray(inv.T)).float().to(device)
         return self._tables[key]
 
     def __call__(self, x, return_type='complex'):
@@ -195,17 +238,11 @@ class STFT:
         if bins != self.frame_length//2 + 1:
             raise ValueError(f'expected {self.frame_length//2 + 1} bins, got {bins}')
         rows = int(np.prod(lead)) if lead else 1
-        spec = torch.view_as_real(x.reshape(rows, bins, F).to(torch.complex64)
-                                  .contiguous())
-        scratch = torch.empty(rows, F, self.frame_length, dtype=torch.float32,
-                              device=x.device)
+        spec = x.reshape(rows, bins, F).to(torch.complex64)
         out_len = self.hop_length*(F - 1)
-        y = torch.empty(rows, out_len, dtype=torch.float32, device=x.device)
-        hip.check(lib.brv_istft_backward(
-            hip.ptr(spec), hip.ptr(inv), hip.ptr(win), hip.ptr(scratch), hip.ptr(y),
-            rows, F, self.frame_length, self.hop_length,
-            float(self.compression_factor), float(self.scale_factor), hip.stream()),
-            'brv_istft_backward')
+        y = _IstftFunction.apply(spec, inv, win,
+                                 self._inv_t[str(x.device)], self.frame_length, self.hop_length,
+                                 self.compression_factor, self.scale_factor)
         return y.view(*lead, out_len)
 
 

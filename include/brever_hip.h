@@ -201,6 +201,66 @@ int brv_row_sum(const float* x, float* out, int64_t B, int64_t M, int64_t T, brv
 int brv_masked_mean_spec(const float* spec, const float* mask, float* out, int64_t B, int64_t C,
                          int64_t n, brv_stream_t stream);
 
+/* ---- DCCRN building blocks, forward values (models/dccrn/dccrn.py:28-358) --------------
+ * NCHW fp32 as in the reference; batch strides let real / imaginary halves of a wider
+ * tensor be addressed in place. conv / conv_transpose: y (+)= sign*(op(x, w) + bias)
+ * (accumulate != 0 adds to y): the four real convolutions of a ComplexWrapper are two
+ * such calls per output half. batchnorm2d: training != 0 uses batch statistics and updates
+ * the running estimates (momentum), else the running ones; an optional scalar PReLU
+ * follows. lstm_recurrent: gates_in (B, T, 4H) = W_ih x for all steps, bias (4H) =
+ * b_ih + b_hh, y (B, T, H), zero initial state, torch gate order; act / cs (nullable) receive the gate
+ * activations and cell states for the backward pass. dccrn_apply_mask: DCCRN.apply_mask. */
+int brv_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int64_t B,
+                       int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t kh, int64_t kw,
+                       int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t x_batch_stride,
+                       int64_t y_batch_stride, int accumulate, float sign, brv_stream_t stream);
+int brv_conv_transpose2d_forward(const float* x, const float* w, const float* bias, float* y,
+                                 int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                                 int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph,
+                                 int64_t pw, int64_t oph, int64_t opw, int64_t x_batch_stride,
+                                 int64_t y_batch_stride, int accumulate, float sign,
+                                 brv_stream_t stream);
+int brv_batchnorm2d_forward(const float* x, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, const float* prelu_slope,
+                            float* y, float* save_mean, float* save_invstd, int64_t B, int64_t C,
+                            int64_t HW, float eps, float momentum, int training,
+                            brv_stream_t stream);
+int brv_lstm_recurrent_forward(const float* gates_in, const float* w_hh, const float* bias,
+                               float* y, float* act, float* cs, int64_t B, int64_t T, int64_t H,
+                               brv_stream_t stream);
+/* Backward pieces (autograd of the above). conv2d_wgrad: dw (Cout, Cin, kh, kw) and dbias
+ * from x and dy (ConvTranspose2d: pass its output gradient as x and its input as dy; data
+ * gradients are the forward kernels of the opposite operation with the same weights).
+ * batchnorm2d_backward: training-mode batch norm followed by the optional PReLU;
+ * dslope_partial (C) holds per-channel partial sums of the slope gradient.
+ * lstm_recurrent_backward: act (B, T, 4H) gate activations and cs (B, T, H) cell states
+ * saved by the forward (act / cs non-null there), dy (B, T, H) -> dgates (B, T, 4H).
+ * dccrn_apply_mask_backward: gradient wrt the mask. istft_env_divide: dy / window-square
+ * envelope of torch.istft (first step of the adjoint of brv_istft_backward). */
+int brv_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, int64_t B,
+                     int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t Ho, int64_t Wo,
+                     int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                     int64_t x_batch_stride, int64_t dy_batch_stride, int accumulate, float sign,
+                     brv_stream_t stream);
+int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_mean,
+                             const float* save_invstd, const float* gamma, const float* beta,
+                             const float* prelu_slope, float* dx, float* dgamma, float* dbeta,
+                             float* dslope_partial, int64_t B, int64_t C, int64_t HW,
+                             brv_stream_t stream);
+int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* w_hh,
+                                const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
+                                brv_stream_t stream);
+int brv_dccrn_apply_mask_backward(const float* xr, const float* xi, const float* mr,
+                                  const float* mi, const float* gout, float* dmr, float* dmi,
+                                  int64_t n, brv_stream_t stream);
+int brv_istft_env_divide(const float* dy, const float* window, float* out, int64_t rows,
+                         int64_t length, int64_t frame_length, int64_t hop_length, int64_t frames,
+                         brv_stream_t stream);
+int brv_combine(const float* a, const float* b, float* out, int64_t n, float sign,
+                brv_stream_t stream);
+int brv_dccrn_apply_mask(const float* xr, const float* xi, const float* mr, const float* mi,
+                         float* out, int64_t n, brv_stream_t stream);
+
 /* ---- pieces of MultiResYuLoss (criterion.py:135-226) ----------------------------
  * brv_apply_mask: out = x with samples >= lengths[b] zeroed (apply_mask, :229-234),
  *   x/out (B, S, L). brv_l1_*: sums[r] = sum |x - y| over n samples of row r (fp64) and

@@ -1,0 +1,156 @@
+"""ORACLE (test infrastructure, not product code).
+
+CPU restatement in plain PyTorch of the reference DCCRN, brever/models/dccrn/dccrn.py:28-358
+(forward / apply_mask / mask network / complex wrappers / LSTM block), with STFT.forward /
+backward of brever/modules/stft.py:59-138 (hann, normalized). Only ``tests/`` import it.
+
+Pinning: tests/golden/dccrn.npz from the imported reference (tests/golden/make_golden.py):
+parameter count, forward output in train mode (batch statistics, running estimates after
+the step) and in eval mode on a seeded input.
+"""
+import math
+
+import scipy.signal
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _stft(x, n, hop):
+    w = torch.from_numpy(scipy.signal.get_window('hann', n)).to(x.dtype)
+    L = x.shape[-1]
+    frames = math.ceil(max(L - n, 0)/hop) + 1
+    x = F.pad(x, (0, (frames - 1)*hop + n - L))
+    X = torch.stft(x, n_fft=n, hop_length=hop, window=w, center=True, pad_mode='constant',
+                   normalized=False, onesided=True, return_complex=True)
+    return X/w.pow(2).sum().sqrt()
+
+
+def _istft(X, n, hop):
+    w = torch.from_numpy(scipy.signal.get_window('hann', n)).to(X.real.dtype)
+    return torch.istft(X*w.pow(2).sum().sqrt(), n_fft=n, hop_length=hop, window=w, center=True,
+                       normalized=False, onesided=True)
+
+
+class ComplexWrapper(nn.Module):                                   # dccrn.py:221-231
+    def __init__(self, module_cls, *args, **kwargs):
+        super().__init__()
+        self.module_real = module_cls(*args, **kwargs)
+        self.module_imag = module_cls(*args, **kwargs)
+
+    def forward(self, x):
+        in_real, in_imag = torch.chunk(x, 2, dim=1)
+        out_real = self.module_real(in_real) - self.module_imag(in_imag)
+        out_imag = self.module_real(in_imag) + self.module_imag(in_real)
+        return torch.cat([out_real, out_imag], dim=1)
+
+
+class _Block(nn.Module):                                           # dccrn.py:234-290
+    def __init__(self, cls, cin, cout, norm=True, activation=True, **kw):
+        super().__init__()
+        self.conv = ComplexWrapper(cls, in_channels=cin, out_channels=cout, **kw)
+        self.norm = nn.BatchNorm2d(2*cout) if norm else None
+        self.activation = nn.PReLU() if activation else None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+class _ComplexLSTMLayer(ComplexWrapper):                           # dccrn.py:330-358
+    def forward(self, real, imag):
+        rr, _ = self.module_real(real)
+        ii, _ = self.module_imag(imag)
+        ri, _ = self.module_real(imag)
+        ir, _ = self.module_imag(real)
+        return rr - ii, ri + ir
+
+
+class _ComplexLSTM(nn.Module):
+    def __init__(self, input_size, hidden_size, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList(
+            _ComplexLSTMLayer(nn.LSTM, input_size=input_size if i == 0 else hidden_size,
+                              hidden_size=hidden_size, batch_first=True, bidirectional=False)
+            for i in range(num_layers))
+
+
+class _LSTMBlock(nn.Module):                                       # dccrn.py:293-311
+    def __init__(self, input_size, hidden_size, num_layers):
+        super().__init__()
+        self.lstm = _ComplexLSTM(input_size, hidden_size, num_layers)
+        self.linear_r = nn.Linear(hidden_size, input_size)
+        self.linear_i = nn.Linear(hidden_size, input_size)
+
+    def forward(self, x):
+        real, imag = torch.chunk(x, 2, dim=-1)
+        for layer in self.lstm.layers:
+            real, imag = layer(real, imag)
+        return torch.cat([self.linear_r(real), self.linear_i(imag)], dim=-1)
+
+
+class _MaskNet(nn.Module):                                         # dccrn.py:145-218
+    def __init__(self, input_dim, channels, kernel_size, stride, padding, output_padding,
+                 lstm_channels, lstm_layers):
+        super().__init__()
+        kw = dict(kernel_size=kernel_size, stride=stride, padding=padding)
+        self.encoder = nn.ModuleList(
+            _Block(nn.Conv2d, 1 if i == 0 else channels[i - 1], channels[i], **kw)
+            for i in range(len(channels)))
+        self.decoder = nn.ModuleList(
+            _Block(nn.ConvTranspose2d, channels[i]*2, 1 if i == 0 else channels[i - 1],
+                   norm=i != 0, activation=i != 0, output_padding=output_padding, **kw)
+            for i in range(len(channels) - 1, -1, -1))
+        dim = input_dim
+        for _ in channels:
+            dim = (dim + 2*padding[0] - kernel_size[0])//stride[0] + 1
+        self.lstm = _LSTMBlock(channels[-1]*dim, lstm_channels, lstm_layers)
+
+    def forward(self, x):
+        outs = []
+        for blk in self.encoder:
+            x = blk(x)
+            outs.append(x)
+        x = x.permute(0, x.ndim - 1, *range(1, x.ndim - 1))
+        x = self.lstm(x.reshape(*x.shape[:2], -1)).reshape(*x.shape)
+        x = x.permute(0, *range(2, x.ndim), 1)
+        for blk, enc in zip(self.decoder, reversed(outs)):
+            real, imag = x.chunk(2, dim=1)
+            sr, si = enc.chunk(2, dim=1)
+            x = blk(torch.cat([real, sr, imag, si], dim=1))
+        return x
+
+
+class OracleDCCRN(nn.Module):
+    def __init__(self, n=512, hop=128, channels=(16, 32, 64, 128, 128, 128), kernel_size=(5, 2),
+                 stride=(2, 1), padding=(2, 0), output_padding=(1, 0), lstm_channels=128,
+                 lstm_layers=2):
+        super().__init__()
+        self.n, self.hop = n, hop
+        self.mask_net = _MaskNet(n//2, list(channels), kernel_size, stride, padding,
+                                 output_padding, lstm_channels, lstm_layers)
+
+    @staticmethod
+    def apply_mask(x, mask):                                       # dccrn.py:96-109
+        in_real, in_imag = torch.chunk(x, 2, dim=1)
+        in_mag = (in_real**2 + in_imag**2).sqrt()
+        in_phase = torch.atan2(in_imag, in_real)
+        mask_real, mask_imag = torch.chunk(mask, 2, dim=1)
+        mask_mag = (mask_real**2 + mask_imag**2 + 1e-7).sqrt().tanh()
+        mask_real = mask_real + (mask_real == 0)*1e-7
+        mask_phase = torch.atan2(mask_imag, mask_real)
+        out_mag = in_mag*mask_mag
+        out_phase = in_phase + mask_phase
+        return torch.complex(out_mag*out_phase.cos(), out_mag*out_phase.sin())
+
+    def forward(self, x):                                          # dccrn.py:83-94
+        length = x.shape[-1]
+        x = _stft(x, self.n, self.hop)[..., 1:, :]
+        x = torch.stack([x.real, x.imag], dim=1)
+        x = self.apply_mask(x, self.mask_net(x)).squeeze(1)
+        x = F.pad(x, (0, 0, 1, 0))
+        return _istft(x, self.n, self.hop)[..., :length]

@@ -381,6 +381,45 @@ def golden_ffnn(out):
     np.savez_compressed(os.path.join(out, 'ffnn.npz'), **res)
 
 
+def golden_dccrn(out):
+    """DCCRN (brever/models/dccrn/dccrn.py): a narrow configuration at seeded weights,
+    forward in train mode (batch statistics; running estimates after the call) and in eval
+    mode; default parameter count."""
+    from brever.models import DCCRN, count_params
+    torch.manual_seed(0)
+    res = dict(n_params_default=np.array(count_params(DCCRN())))
+    cfg = dict(channels=[4, 8, 8, 16, 16, 16], lstm_channels=24, lstm_layers=2)
+    res['config'] = json.dumps(cfg)
+    net = DCCRN(**cfg)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if 'norm' in name or 'activation' in name:
+                p.add_(0.1*torch.randn(p.shape, generator=g))
+    res['params'] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    x = 0.3*torch.randn(2, 3000, generator=g)
+    res['x'] = x.numpy()
+    net.train()
+    with torch.no_grad():
+        res['out_train'] = net(x).numpy()
+    res['running'] = torch.cat([b.detach().reshape(-1).float() for n, b in net.named_buffers()
+                                if 'running' in n]).numpy()
+    # loss and all gradients in train mode (snr criterion, ragged lengths)
+    batch = torch.stack([x, 0.7*x + 0.1*torch.randn(2, 3000, generator=g)], dim=1)
+    lengths = torch.tensor([3000, 2500])
+    res['batch'] = batch.numpy(); res['lengths'] = lengths.numpy()
+    net.zero_grad()
+    loss = net.loss(batch, lengths, use_amp=False)
+    loss.backward()
+    res['loss'] = loss.detach().numpy()
+    res['grads'] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    net.eval()
+    with torch.no_grad():
+        res['out_eval'] = net(x).numpy()
+        res['enhance'] = net.enhance(torch.stack([x, 0.5*x], dim=1)).numpy()
+    np.savez_compressed(os.path.join(out, 'dccrn.npz'), **res)
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
@@ -393,6 +432,7 @@ def main():
     golden_training(HERE)
     golden_stft(HERE)
     golden_ffnn(HERE)
+    golden_dccrn(HERE)
     print('golden fixtures written to', HERE)
 
 

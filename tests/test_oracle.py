@@ -269,3 +269,41 @@ def test_ffnn_oracle_matches_reference(golden_dir):
     with torch.no_grad():
         y = net.enhance(torch.from_numpy(g['enhance_in']))
     assert torch.allclose(y, torch.from_numpy(g['enhance_out']), rtol=1e-4, atol=1e-6)
+
+
+def _load_flat(model, flat):
+    o = 0
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.from_numpy(flat[o:o + p.numel()]).view(p.shape))
+            o += p.numel()
+    assert o == len(flat)
+
+
+def test_dccrn_oracle_matches_reference(golden_dir):
+    """oracle/dccrn.py vs the imported reference: parameter count, forward in train mode
+    (batch statistics and the running estimates it leaves behind) and in eval mode."""
+    from oracle.dccrn import OracleDCCRN
+    g = np.load(os.path.join(golden_dir, 'dccrn.npz'))
+    assert sum(p.numel() for p in OracleDCCRN().parameters()) == int(g['n_params_default'])
+    net = OracleDCCRN(**json.loads(str(g['config'])))
+    _load_flat(net, g['params'])
+    x = torch.from_numpy(g['x'])
+    net.train()
+    with torch.no_grad():
+        y = net(x)
+    assert torch.allclose(y, torch.from_numpy(g['out_train']), rtol=1e-4, atol=1e-6)
+    running = torch.cat([b.reshape(-1).float() for n, b in net.named_buffers() if 'running' in n])
+    assert torch.allclose(running, torch.from_numpy(g['running']), rtol=1e-5, atol=1e-7)
+    # loss (snr) and gradients, second train-mode call
+    from oracle.criterion import snr
+    batch, lengths = torch.from_numpy(g['batch']), torch.from_numpy(g['lengths'])
+    loss = snr(net(batch[:, 0]), batch[:, 1], lengths).mean()
+    assert abs(float(loss) - float(g['loss'])) <= 1e-5
+    loss.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.allclose(grads, torch.from_numpy(g['grads']), rtol=2e-3, atol=1e-5)
+    net.eval()
+    with torch.no_grad():
+        y = net(x)
+    assert torch.allclose(y, torch.from_numpy(g['out_eval']), rtol=1e-4, atol=1e-6)
