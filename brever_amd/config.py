@@ -93,6 +93,17 @@ def signature_defaults(func, skip=('self', 'model', 'train_dataset', 'val_datase
     return out
 
 
+def model_defaults(model_cls):
+    """Constructor defaults of a model class; sub-models (``_is_submodel``) inherit their
+    parent's and override some (brever/inspect.py:123-126)."""
+    out = {}
+    if model_cls.__dict__.get('_is_submodel', False):
+        out = model_defaults(model_cls.__bases__[0])
+    out.update(signature_defaults(model_cls.__init__))
+    out.update(model_cls.__dict__.get('_defaults', {}))
+    return out
+
+
 def get_model_default_config(arch):
     """Default ``config.yaml`` content for ``arch`` (model + trainer + dataset)."""
     from .models import ModelRegistry
@@ -106,5 +117,5 @@ def get_model_default_config(arch):
         'dataset': {'fs': 16000, 'sources': ['mixture', 'foreground'],
                     'segment_length': 0.0, 'max_segment_length': 0.0},
         'trainer': trainer,
-        'model': signature_defaults(model_cls.__init__),
+        'model': model_defaults(model_cls),
     })

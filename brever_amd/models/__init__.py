@@ -6,6 +6,7 @@ from .base import BreverBaseModel, ModelRegistry  # noqa: F401
 from .convtasnet import ConvTasNet  # noqa: F401
 from .dccrn import DCCRN  # noqa: F401
 from .ffnn import FFNN  # noqa: F401
+from .sgmse import IDMSE, SGMSEp, SGMSEpM  # noqa: F401
 
 
 def count_params(model):

@@ -1,0 +1,887 @@
+"""SGMSE+ (score-based generative speech enhancement) on the HIP path -- inference.
+
+Same constructor signature, registry keys (``sgmsep``, ``sgmsepm``), module tree / state-dict
+names and seeded initialisation as the reference (brever/models/sgmse/sgmse.py:23-213,
+net.py:12-477, preconditioning.py:5-58, sdes.py:11-81, solvers.py:8-77). ``enhance`` runs the
+reverse SDE (predictor-corrector or EDM/Heun sampler) with every network evaluation -- 3x3 /
+1x1 convolutions, group norms, SiLU, FIR resampling, self-attention, noise embedding -- and
+every state update in ``libbrever_hip.so``; torch draws the Gaussian noise, concatenates skip
+tensors and holds the parameters.
+
+Built: every SDE, both solvers (``pc``, ``edm``), all three preconditionings and every
+encoder / decoder / block type of ``DiffusionUNet``. Not built yet: training (``loss`` needs
+the backward pass of the U-Net and raises ``NotImplementedError``). fp32 kernels: ``use_amp``
+is ignored.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import hip
+from ..modules.stft import STFT
+from ..registry import Registry
+from .base import BreverBaseModel, ModelRegistry
+
+SDERegistry = Registry('sde')
+SolverRegistry = Registry('solver')
+
+
+# ------------------------------------------------------------------------------------------
+# HIP primitives (inference: plain functions on contiguous fp32 tensors)
+# ------------------------------------------------------------------------------------------
+def _conv(x, mod):
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    Cout = mod.out_channels
+    (kh, kw), (sh, sw), (ph, pw) = mod.kernel_size, mod.stride, mod.padding
+    Ho, Wo = (H + 2*ph - kh)//sh + 1, (W + 2*pw - kw)//sw + 1
+    y = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().brv_conv2d_forward(
+        hip.ptr(x), hip.ptr(mod.weight), hip.ptr(mod.bias), hip.ptr(y), B, Cin, H, W, Cout, kh, kw,
+        sh, sw, ph, pw, Cin*H*W, Cout*Ho*Wo, 0, 1.0, hip.stream()), 'brv_conv2d_forward')
+    return y
+
+
+def _group_norm(x, mod, add=None, silu=False):
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    hip.check(hip.lib().brv_groupnorm_forward(
+        hip.ptr(x), hip.ptr(add.contiguous()) if add is not None else None, hip.ptr(mod.weight),
+        hip.ptr(mod.bias), hip.ptr(y), B, C, H*W, mod.num_groups, float(mod.eps), int(silu),
+        hip.stream()), 'brv_groupnorm_forward')
+    return y
+
+
+def _silu(x):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    hip.check(hip.lib().brv_silu(hip.ptr(x), hip.ptr(y), x.numel(), hip.stream()), 'brv_silu')
+    return y
+
+
+def _linear(x, mod):
+    """(N, in) -> (N, out): W (out, in) @ x^T (+ bias per row), returned transposed back."""
+    x = x.contiguous()
+    N, K = x.shape
+    O = mod.out_features
+    d = torch.empty(O, N, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().brv_gemm_f32(
+        hip.ptr(mod.weight), hip.ptr(x), hip.ptr(d), 1, O, N, K, K, K, N, 0, 0, 0, 0, 1, 1, 0, 0,
+        hip.ptr(mod.bias), 0, hip.stream()), 'brv_gemm_f32')
+    return d.t().contiguous()
+
+
+def _axpby(a, alpha, b=None, beta=0.0):
+    a = a.contiguous()
+    out = torch.empty_like(a)
+    ar = torch.view_as_real(a) if a.is_complex() else a
+    orr = torch.view_as_real(out) if a.is_complex() else out
+    br = None
+    if b is not None:
+        b = b.contiguous()
+        if a.is_complex() and not b.is_complex():
+            b = torch.complex(b, torch.zeros_like(b))        # real noise added to a complex state
+        br = torch.view_as_real(b) if b.is_complex() else b
+    hip.check(hip.lib().brv_axpby(hip.ptr(ar), float(alpha), hip.ptr(br), float(beta),
+                                  hip.ptr(orr), ar.numel(), hip.stream()), 'brv_axpby')
+    return out
+
+
+class Resample(nn.Module):
+    """FIR up / down sampling by 2 (brever/modules/resampling.py:8-61); the paddings of the
+    down-sampling calls are stacked and reused by the matching up-sampling calls."""
+
+    def __init__(self, fir_kernel, buffer_padding=False):
+        super().__init__()
+        kernel = torch.as_tensor(fir_kernel, dtype=torch.float32)
+        kernel = kernel.outer(kernel).unsqueeze(0).unsqueeze(1)
+        kernel /= kernel.sum()
+        self.register_buffer('kernel', kernel)
+        self._paddings = [] if buffer_padding else None
+
+    def forward(self, x, up_or_down):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        K = self.kernel.shape[-1]
+        if up_or_down == 'down':
+            padding = tuple(math.ceil(K/2) - 1 if dim % 2 == 0 else math.ceil((K + 1)/2) - 1
+                            for dim in (H, W))
+            if self._paddings is not None:
+                out_pad = tuple(0 if (dim + 2*pad - K) % 2 == 0 else 1
+                                for dim, pad in zip((H, W), padding))
+                self._paddings.append((padding, out_pad))
+            Ho, Wo = (H + 2*padding[0] - K)//2 + 1, (W + 2*padding[1] - K)//2 + 1
+            up, gain = 0, 1.0
+        elif up_or_down == 'up':
+            if self._paddings is not None:
+                padding, out_pad = self._paddings.pop()
+            else:
+                padding, out_pad = ((K - 1)//2,)*2, (0, 0)
+            Ho = (H - 1)*2 - 2*padding[0] + K + out_pad[0]
+            Wo = (W - 1)*2 - 2*padding[1] + K + out_pad[1]
+            up, gain = 1, 4.0
+        else:
+            raise ValueError(f'up_or_down must be up or down, got {up_or_down}')
+        y = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_fir_resample2d(
+            hip.ptr(x), hip.ptr(self.kernel.float().contiguous()), hip.ptr(y), B*C, H, W, Ho, Wo, K,
+            padding[0], padding[1], up, gain, hip.stream()), 'brv_fir_resample2d')
+        return y
+
+
+# ------------------------------------------------------------------------------------------
+# U-Net (parameter containers in the reference's construction order + HIP forward)
+# ------------------------------------------------------------------------------------------
+class GroupNorm(nn.GroupNorm):
+    def __init__(self, num_channels, num_groups=32, min_channels_per_group=4, eps=1e-6):
+        super().__init__(num_groups=min(num_groups, num_channels//min_channels_per_group),
+                         num_channels=num_channels, eps=eps)
+
+
+class GaussianFourierProjection(nn.Module):
+    def __init__(self, embedding_size, scale=16.0):
+        super().__init__()
+        self.register_buffer('b', torch.randn(embedding_size//2)*scale)
+
+    def forward(self, x):
+        x = x.float().contiguous()
+        out = torch.empty(x.numel(), 2*self.b.numel(), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_fourier_features(hip.ptr(x), hip.ptr(self.b), hip.ptr(out),
+                                                 x.numel(), self.b.numel(), hip.stream()),
+                  'brv_fourier_features')
+        return out
+
+
+class NoiseEmbedding(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.fourier_proj = GaussianFourierProjection(in_channels)
+        self.linear_1 = nn.Linear(in_channels, out_channels)
+        self.linear_2 = nn.Linear(out_channels, out_channels)
+
+    def forward(self, x):
+        x = self.fourier_proj(x.reshape(-1))
+        x = _silu(_linear(x, self.linear_1))
+        return _silu(_linear(x, self.linear_2))
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, num_channels):
+        super().__init__()
+        self.norm = GroupNorm(num_channels)
+        self.conv_query = nn.Conv2d(num_channels, num_channels, 1)
+        self.conv_key = nn.Conv2d(num_channels, num_channels, 1)
+        self.conv_value = nn.Conv2d(num_channels, num_channels, 1)
+        self.conv_out = nn.Conv2d(num_channels, num_channels, 1)
+
+    def forward(self, x):
+        lib = hip.lib()
+        N, C, H, W = x.shape
+        L = H*W
+        xn = _group_norm(x, self.norm)
+        q, k, v = _conv(xn, self.conv_query), _conv(xn, self.conv_key), _conv(xn, self.conv_value)
+        # weights (L, L) = q^T (L, C) @ k (C, L) / sqrt(C), softmax over the last dim
+        w = torch.empty(N, L, L, dtype=torch.float32, device=x.device)
+        hip.check(lib.brv_gemm_f32(hip.ptr(q), hip.ptr(k), hip.ptr(w), N, L, L, C, L, L, L, C*L,
+                                   C*L, L*L, 1, 0, 1, 0, 0, None, 0, hip.stream()), 'brv_gemm_f32')
+        w = _axpby(w, 1.0/C**0.5)
+        p = torch.empty_like(w)
+        hip.check(lib.brv_softmax_rows(hip.ptr(w), hip.ptr(p), N*L, L, hip.stream()),
+                  'brv_softmax_rows')
+        # attention^T (C, L) = v (C, L) @ weights^T (L, L)
+        a = torch.empty(N, C, L, dtype=torch.float32, device=x.device)
+        hip.check(lib.brv_gemm_f32(hip.ptr(v), hip.ptr(p), hip.ptr(a), N, C, L, L, L, L, L, C*L,
+                                   L*L, C*L, 0, 1, 1, 0, 0, None, 0, hip.stream()), 'brv_gemm_f32')
+        return _axpby(x, 1.0, _conv(a.view(N, C, H, W), self.conv_out), 1.0)
+
+
+class UNetBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, emb_channels, block_type, skip_scale, dropout,
+                 attention=False, resampler=None, up_or_down='none'):
+        super().__init__()
+        self.skip_scale = skip_scale
+        self.norm_1 = GroupNorm(in_channels)
+        self.conv_1 = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.linear = nn.Linear(emb_channels, out_channels*(2 if block_type == 'adm' else 1))
+        self.norm_2 = GroupNorm(out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.conv_2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1)
+        if in_channels != out_channels or (block_type == 'ncsn' and resampler is not None):
+            self.skip_conv = nn.Conv2d(in_channels, out_channels, 1)
+        else:
+            self.skip_conv = None
+        self.resampler = resampler
+        self.up_or_down = up_or_down
+        self.attn = AttentionBlock(out_channels) if attention else None
+        self.block_type = block_type
+
+    def forward(self, x, emb):
+        h = _group_norm(x, self.norm_1, silu=True)
+        if self.resampler is not None:
+            h = self.resampler(h, self.up_or_down)
+            x = self.resampler(x, self.up_or_down)
+        h = _conv(h, self.conv_1)
+        e = _linear(emb, self.linear)                         # (N, out or 2*out)
+        if e.shape[0] != h.shape[0]:
+            e = e.expand(h.shape[0], -1)
+        if self.block_type == 'adm':
+            scale, shift = e.chunk(2, dim=1)
+            hn = _group_norm(h, self.norm_2)
+            # (scale + 1)*norm + shift, then SiLU
+            h = _silu(hn*(scale.contiguous()[:, :, None, None] + 1) + shift[:, :, None, None])
+        else:
+            h = _group_norm(h, self.norm_2, add=e, silu=True)
+        h = _conv(h, self.conv_2)                             # dropout: identity at inference
+        if self.skip_conv is not None:
+            x = _conv(x, self.skip_conv)
+        x = _axpby(x, self.skip_scale, h, self.skip_scale)
+        if self.attn is not None:
+            x = _axpby(self.attn(x), self.skip_scale)
+        return x
+
+
+class EncoderBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, emb_channels, block_type, num_blocks,
+                 skip_scale, dropout, attention, resampler):
+        super().__init__()
+        self.unet_blocks = nn.ModuleList([
+            UNetBlock(in_channels if i == 0 else out_channels, out_channels, emb_channels,
+                      block_type, skip_scale, dropout,
+                      attention=False if i == num_blocks else attention,
+                      resampler=resampler if i == num_blocks else None, up_or_down='down')
+            for i in range(num_blocks if resampler is None else num_blocks + 1)])
+
+    def forward(self, x, emb, skips):
+        for i, blk in enumerate(self.unet_blocks):
+            x = blk(x, emb)
+            if i != len(self.unet_blocks) - 1:
+                skips.append(x)
+        return x, skips
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, emb_channels, block_type, num_blocks,
+                 skip_scale, dropout, attention, resampler, skip_channels):
+        super().__init__()
+        self.unet_blocks = nn.ModuleList([
+            UNetBlock(in_channels if i == -1 else skip_channels.pop()
+                      + (in_channels if i == 0 else out_channels),
+                      in_channels if i == -1 else out_channels, emb_channels, block_type,
+                      skip_scale, dropout,
+                      attention=attention and (block_type == 'adm' or i == num_blocks - 1),
+                      resampler=resampler if i == -1 else None, up_or_down='up')
+            for i in range(0 if resampler is None else -1, num_blocks)])
+
+    def forward(self, x, emb, skips):
+        for blk in self.unet_blocks:
+            if blk.resampler is None:
+                x = torch.cat([x, skips.pop()], dim=1)
+            x = blk(x, emb)
+        return x
+
+
+class AuxiliaryDown(nn.Module):
+    def __init__(self, in_channels, out_channels, resampler, type_, skip_scale):
+        super().__init__()
+        self.resampler = resampler
+        self.type_ = type_
+        self.conv = nn.Conv2d(in_channels, out_channels, 1) if type_ == 'skip' \
+            else nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        self.skip_scale = skip_scale
+
+    def forward(self, x, aux):
+        aux = self.resampler(aux, 'down')
+        x = _axpby(x, 1.0, _conv(aux, self.conv), 1.0)
+        if self.type_ == 'residual':
+            aux = x = _axpby(x, self.skip_scale)
+        return x, aux
+
+
+class AuxiliaryUp(nn.Module):
+    def __init__(self, in_channels, out_channels, resampler, type_):
+        super().__init__()
+        self.resampler = resampler
+        self.type_ = type_
+        self.conv = nn.Conv2d(in_channels, out_channels, 3, 1, 1)
+        if type_ == 'skip' or resampler is None:
+            self.norm = GroupNorm(in_channels)
+
+    def forward(self, x, aux):
+        if self.resampler is not None:
+            aux = self.resampler(aux, 'up')
+        if self.type_ == 'skip' or self.resampler is None:
+            h = _conv(_group_norm(x, self.norm, silu=True), self.conv)
+            aux = h if aux is None else _axpby(aux, 1.0, h, 1.0)
+        else:
+            x = aux = _axpby(x, 1.0, _conv(aux, self.conv), 1.0)
+        return x, aux
+
+
+class _OutputConv(nn.Sequential):
+    def forward(self, x):
+        return _conv(_group_norm(x, self[0]), self[1])
+
+
+class DiffusionUNet(nn.Module):
+    def __init__(self, num_freqs, base_channels, channel_mult, num_blocks_per_res,
+                 noise_channel_mult, emb_channel_mult, fir_kernel, attn_resolutions,
+                 attn_bottleneck, encoder_type, decoder_type, block_type, skip_scale, dropout,
+                 aux_out_channels, in_channels=4, out_channels=2):
+        super().__init__()
+        assert encoder_type in ['standard', 'residual', 'skip']
+        assert decoder_type in ['standard', 'residual', 'skip']
+        assert block_type in ['ncsn', 'adm']
+        self.resampler = Resample(fir_kernel, buffer_padding=True)
+        emb_channels = base_channels*emb_channel_mult
+        self.emb = NoiseEmbedding(base_channels*noise_channel_mult, emb_channels)
+        self.input_conv = nn.Conv2d(in_channels, base_channels, 3, 1, 1)
+        num_res = len(channel_mult)
+        channels = [base_channels*m for m in channel_mult]
+        common = dict(emb_channels=emb_channels, block_type=block_type, skip_scale=skip_scale,
+                      dropout=dropout)
+        self.encoder = nn.ModuleList(
+            EncoderBlock(base_channels if i == 0 else channels[i - 1], channels[i],
+                         num_blocks=num_blocks_per_res, attention=num_freqs >> i in attn_resolutions,
+                         resampler=None if i == num_res - 1 else self.resampler, **common)
+            for i in range(num_res))
+        if encoder_type != 'standard':
+            self.aux_downs = nn.ModuleList(
+                None if i == num_res - 1 else AuxiliaryDown(
+                    in_channels if encoder_type == 'skip' or i == 0 else channels[i - 1],
+                    channels[i], self.resampler, encoder_type, skip_scale)
+                for i in range(num_res))
+        else:
+            self.aux_downs = [None]*num_res
+        skip_channels = [base_channels] + [channels[i] for i in range(num_res)
+                                           for _ in self.encoder[i].unet_blocks]
+        self.bottleneck_block_1 = UNetBlock(channels[-1], channels[-1], attention=attn_bottleneck,
+                                            **common)
+        self.bottleneck_block_2 = UNetBlock(channels[-1], channels[-1], **common)
+        self.decoder = nn.ModuleList(
+            DecoderBlock(channels[i] if i == num_res - 1 else channels[i + 1], channels[i],
+                         num_blocks=num_blocks_per_res + 1,
+                         attention=num_freqs >> i in attn_resolutions,
+                         resampler=None if i == num_res - 1 else self.resampler,
+                         skip_channels=skip_channels, **common)
+            for i in reversed(range(num_res)))
+        if decoder_type != 'standard':
+            self.aux_ups = nn.ModuleList(
+                AuxiliaryUp(channels[i] if decoder_type == 'skip' or i == num_res - 1
+                            else channels[i + 1],
+                            aux_out_channels if decoder_type == 'skip' else channels[i],
+                            None if i == num_res - 1 else self.resampler, decoder_type)
+                for i in reversed(range(num_res)))
+        else:
+            self.aux_ups = [None]*num_res
+        if decoder_type != 'skip':
+            self.output_conv = _OutputConv(GroupNorm(channels[0]),
+                                           nn.Conv2d(channels[0], out_channels, 3, 1, 1))
+        else:
+            self.output_conv = nn.Conv2d(aux_out_channels, out_channels, 1)
+
+    def forward(self, x, sigma):
+        emb = self.emb(torch.as_tensor(sigma, dtype=torch.float32).to(x.device))
+        aux = x
+        x = _conv(x, self.input_conv)
+        skips = [x]
+        for enc, aux_block in zip(self.encoder, self.aux_downs):
+            x, skips = enc(x, emb, skips)
+            if aux_block is not None:
+                x, aux = aux_block(x, aux)
+            skips.append(x)
+        x = self.bottleneck_block_1(x, emb)
+        x = self.bottleneck_block_2(x, emb)
+        aux = None
+        for dec, aux_block in zip(self.decoder, self.aux_ups):
+            x = dec(x, emb, skips)
+            if aux_block is not None:
+                x, aux = aux_block(x, aux)
+        if aux is None:
+            aux = x
+        if isinstance(self.output_conv, nn.Conv2d):
+            return _conv(aux, self.output_conv)
+        return self.output_conv(aux)
+
+
+# ------------------------------------------------------------------------------------------
+# SDEs, preconditioning, solvers (scalars on the host, tensors through brv_axpby)
+# ------------------------------------------------------------------------------------------
+class _SDE:
+    """Scalar schedules on the host (0-d / 1-d CPU tensors); the drift is
+    ``drift_coef(t)*(y - x)`` for every SDE of the reference (sdes.py:11-251)."""
+
+    def f(self, x, y, t):
+        c = float(self.drift_coef(t))
+        return _axpby(y, c, x, -c)
+
+
+class _OUVE(_SDE):
+    def __init__(self, stiffness, sigma_min, sigma_max, **kwargs):
+        self.stiffness = stiffness
+        self.sigma_min = sigma_min
+        self.sigma_max = sigma_max
+        self._sigma_p = sigma_max/sigma_min
+        self._log_sigma_p = math.log(sigma_max/sigma_min)
+
+    def s(self, t):
+        return (-self.stiffness*t).exp()
+
+    def drift_coef(self, t):
+        return self.stiffness
+
+
+@SDERegistry.register('richter-ouve')
+class RichterOUVESDE(_OUVE):
+    def sigma(self, t):
+        return self.sigma_min*(((self._sigma_p**t/self.s(t))**2 - 1)
+                               / (1 + self.stiffness/self._log_sigma_p))**0.5
+
+    def g(self, t):
+        return self.sigma_min*self._sigma_p**t*(2*self._log_sigma_p)**0.5
+
+    def sigma_inv(self, sigma):
+        return 0.5*(1 + (1 + self.stiffness/self._log_sigma_p)*(sigma/self.sigma_min)**2).log() \
+            / (self.stiffness + self._log_sigma_p)
+
+
+@SDERegistry.register('brever-ouve')
+class BreverOUVESDE(_OUVE):
+    def sigma(self, t):
+        return self.sigma_min*(self._sigma_p**(2*t) - 1)**0.5
+
+    def g(self, t):
+        return self.s(t)*self.sigma_min*self._sigma_p**t*(2*self._log_sigma_p)**0.5
+
+    def sigma_inv(self, sigma):
+        return 0.5*((sigma/self.sigma_min)**2 + 1).log()/self._log_sigma_p
+
+
+class _VP(_SDE):
+    def s(self, t):
+        return (-self.stiffness*t).exp()/(1 + self.sigma(t)**2)**0.5
+
+    def drift_coef(self, t):
+        return self.stiffness + 0.5*self.beta(t)
+
+    def g(self, t):
+        return (-self.stiffness*t).exp()*self.beta(t)**0.5
+
+
+@SDERegistry.register('brever-ouvp')
+class BreverOUVPSDE(_VP):
+    def __init__(self, stiffness, beta_min, beta_max, **kwargs):
+        self.stiffness = stiffness
+        self.beta_min = beta_min
+        self._beta_d = beta_max - beta_min
+
+    def beta(self, t):
+        return self.beta_min + self._beta_d*t
+
+    def sigma(self, t):
+        return ((0.5*self._beta_d*t**2 + self.beta_min*t).exp() - 1)**0.5
+
+    def sigma_inv(self, sigma):
+        return ((self.beta_min**2 + 2*self._beta_d*(sigma**2 + 1).log())**0.5
+                - self.beta_min)/self._beta_d
+
+
+@SDERegistry.register('brever-oucosine')
+class BreverOUCosineSDE(_VP):
+    def __init__(self, stiffness, lambda_min, lambda_max, shift, beta_clamp, **kwargs):
+        self.stiffness = stiffness
+        self.shift = shift
+        self.t_min = self._lambda_inv(lambda_min + shift)
+        self.t_max = self._lambda_inv(lambda_max + shift)
+        self.t_d = self.t_min - self.t_max
+        self.beta_clamp = beta_clamp
+
+    def _lambda_inv(self, lam):
+        if isinstance(lam, torch.Tensor):
+            return 2/math.pi*((self.shift - lam)/2).exp().atan()
+        return 2/math.pi*math.atan(math.exp((self.shift - lam)/2))
+
+    def _angle(self, t):
+        return math.pi*(self.t_max + self.t_d*t)/2
+
+    def beta(self, t):
+        a = self._angle(t)
+        return (math.pi*self.t_d/a.cos()**2*a.tan()
+                / (math.exp(self.shift) + a.tan()**2)).clamp(max=self.beta_clamp)
+
+    def sigma(self, t):
+        lam = -2*self._angle(t).tan().log() + self.shift
+        return (-lam/2).exp()
+
+    def sigma_inv(self, sigma):
+        return (self._lambda_inv(-2*sigma.log()) - self.t_max)/self.t_d
+
+
+class _BridgeSDE(_SDE):
+    t_max = 0.999
+
+    def __init__(self, scaling=0.1, **kwargs):
+        self.scaling = scaling
+
+    def s(self, t):
+        return 1 - t*self.t_max
+
+    def drift_coef(self, t):
+        return 1/(1 - t*self.t_max)
+
+
+@SDERegistry.register('bbed')
+class BBEDSDE(_BridgeSDE):
+    def __init__(self, scaling=0.1, k=10.0, **kwargs):
+        super().__init__(scaling)
+        self.k = k
+
+    def g(self, t):
+        return self.scaling*self.k**(t*self.t_max)
+
+    def sigma(self, t):
+        from scipy.special import expi
+        t = t*self.t_max
+        k2, logk2 = self.k**2, 2*math.log(self.k)
+        ei = torch.as_tensor(expi(((t - 1)*logk2).numpy()))
+        return self.scaling*(k2*logk2*(ei - float(expi(-logk2))) - k2**t/(t - 1) - 1)**0.5
+
+
+@SDERegistry.register('bbcd')
+class BBCD(_BridgeSDE):
+    def g(self, t):
+        return self.scaling
+
+    def sigma(self, t):
+        t = t*self.t_max
+        return self.scaling*(t/(1 - t))**0.5
+
+    def sigma_inv(self, sigma):
+        return sigma**2/(self.scaling**2 + sigma**2)/self.t_max
+
+
+@SDERegistry.register('bbls')
+class BBLS(_BridgeSDE):
+    def g(self, t):
+        t = t*self.t_max
+        return self.scaling*(1 - t)*(2*t)**0.5
+
+    def sigma(self, t):
+        return self.scaling*t*self.t_max
+
+    def sigma_inv(self, sigma):
+        return sigma/(self.scaling*self.t_max)
+
+
+def _randn(model, shape, device, complex_):
+    """Gaussian noise of the solvers (tests replace ``model._noise_source`` to replay)."""
+    if model._noise_source is not None:
+        return model._noise_source(shape, complex_).to(device)
+    dtype = torch.complex64 if complex_ else torch.float32
+    return torch.randn(shape, dtype=dtype, device=device)
+
+
+class Preconditioning(nn.Module):
+    def __init__(self, raw_net, sde, cskip, cout, cin, cshift, cnoise, weight, sigma_data):
+        super().__init__()
+        self.net = raw_net
+        self.sde = sde
+        table = {
+            'richter': dict(
+                cskip=lambda sigma: 1,
+                cout=lambda sigma, scaling, t: -scaling*sigma**2/t,
+                cin=lambda sigma, scaling: scaling,
+                cshift=lambda cin, scaling: 1.0,                    # multiplies y
+                cnoise=lambda sigma, t: t.log(),
+                weight=lambda sigma: 1/sigma**2),
+            'edm': dict(
+                cskip=lambda sigma: sigma_data**2/(sigma**2 + sigma_data**2),
+                cout=lambda sigma, scaling, t: sigma*sigma_data/(sigma**2 + sigma_data**2)**0.5,
+                cin=lambda sigma, scaling: 1/(sigma**2 + sigma_data**2)**0.5,
+                cshift=lambda cin, scaling: 0.0,
+                cnoise=lambda sigma, t: sigma.log()/4,
+                weight=lambda sigma: (sigma**2 + sigma_data**2)/(sigma*sigma_data)**2),
+            'edm-scaled-shift': dict(cshift=lambda cin, scaling: cin/scaling),
+        }
+        for arg, val in (('cskip', cskip), ('cout', cout), ('cin', cin), ('cshift', cshift),
+                         ('cnoise', cnoise), ('weight', weight)):
+            if val not in table or arg not in table[val]:
+                raise ValueError(f'Invalid preconditioning {arg}: {val}')
+            setattr(self, arg, table[val][arg])
+
+    def forward(self, x, y, sigma, t):
+        """x, y complex (B, 1, F, T); sigma, t 0-d tensors (one noise level per call)."""
+        scaling = self.sde.s(t)
+        cskip, cout = self.cskip(sigma), self.cout(sigma, scaling, t)
+        cin = self.cin(sigma, scaling)
+        x_in = _axpby(x, float(cin), y, float(self.cshift(cin, scaling)))
+        net_in = torch.cat([x_in.real, x_in.imag, y.real, y.imag], dim=1).contiguous()
+        net_out = self.net(net_in, self.cnoise(sigma, t))
+        net_out = torch.complex(net_out[:, 0], net_out[:, 1]).unsqueeze(1)
+        return _axpby(x, float(cskip), net_out, float(cout))
+
+    def score(self, x, y, sigma, t):
+        d = self(x, y, sigma, t)
+        c = 1.0/float(self.sde.s(t)*sigma**2)
+        return _axpby(d, c, x, -c)
+
+
+@SolverRegistry.register('pc')
+class PCSolver:
+    def __init__(self, num_steps, corrector_steps, corrector_snr, **kwargs):
+        self.num_steps = num_steps
+        self.corrector_steps = corrector_steps
+        self.corrector_snr = corrector_snr
+
+    def __call__(self, sde, y, model, owner):
+        dt = -1/self.num_steps
+        t = torch.arange(1, 0, dt)                             # host scalars, fp32 as the reference
+        sigma = sde.sigma(t)
+        one = torch.tensor(1)
+        x = _axpby(y, 1.0, _randn(owner, y.shape, y.device, True), float(sde.s(one)*sde.sigma(one)))
+        eps = 2*(self.corrector_snr*sde.s(t)*sigma)**2
+
+        def score_at(i):
+            x_tilde = _axpby(x, 1.0/float(sde.s(t[i])), y, -1.0/float(sde.s(t[i])))
+            return model.score(x_tilde, y, sigma[i], t[i])
+        for i in range(self.num_steps):
+            for _ in range(self.corrector_steps):
+                x = _axpby(x, 1.0, score_at(i), float(eps[i]))
+                x = _axpby(x, 1.0, _randn(owner, x.shape, x.device, True), float((2*eps[i])**0.5))
+            score = score_at(i)
+            g = float(sde.g(t[i]))
+            drift = sde.f(x, y, t[i])
+            if i < self.num_steps - 1:                         # reverse_step (sdes.py:17-19)
+                step = _axpby(drift, dt, score, -g*g*dt)
+                x = _axpby(x, 1.0, step, 1.0)
+                x = _axpby(x, 1.0, _randn(owner, x.shape, x.device, False), g*(-dt)**0.5)
+            else:                                              # probability flow, no noise
+                step = _axpby(drift, dt, score, -0.5*g*g*dt)
+                x = _axpby(x, 1.0, step, 1.0)
+        return x, self.num_steps*(self.corrector_steps + 1)
+
+
+@SolverRegistry.register('edm')
+class EDMSolver:
+    def __init__(self, num_steps, schurn, smin, smax, snoise, **kwargs):
+        self.num_steps = num_steps
+        self.schurn = schurn
+        self.smin = smin
+        self.smax = smax
+        self.snoise = snoise
+        self._gamma = min(schurn/num_steps, 2**0.5 - 1)
+
+    def __call__(self, sde, y, model, owner):
+        t = torch.linspace(1, 0, self.num_steps + 1)
+        sigma = sde.sigma(t)
+        one = torch.tensor(1)
+        x = _axpby(y, 1.0, _randn(owner, y.shape, y.device, True), float(sde.s(one)*sde.sigma(one)))
+
+        def flow(xc, tc, sc):
+            x_tilde = _axpby(xc, 1.0/float(sde.s(tc)), y, -1.0/float(sde.s(tc)))
+            score = model.score(x_tilde, y, sc, tc)
+            return _axpby(sde.f(xc, y, tc), 1.0, score, -0.5*float(sde.g(tc))**2)
+        for i in range(self.num_steps):
+            eps = _randn(owner, x.shape, x.device, True)
+            gamma = self._gamma if self.smin <= sigma[i] <= self.smax else 0
+            sigma_hat = sigma[i]*(1 + gamma)
+            t_hat = sde.sigma_inv(sigma_hat)
+            r = float(sde.s(t_hat)/sde.s(t[i]))
+            x_hat = _axpby(x, r, y, 1.0 - r)
+            x_hat = _axpby(x_hat, 1.0, eps, self.snoise*float(
+                sde.s(t_hat)*(sigma_hat**2 - sigma[i]**2)**0.5))
+            d_hat = flow(x_hat, t_hat, sigma_hat)
+            h = float(t[i + 1] - t_hat)
+            x = _axpby(x_hat, 1.0, d_hat, h)
+            if i < self.num_steps - 1:
+                d_next = flow(x, t[i + 1], sigma[i + 1])
+                x = _axpby(x_hat, 1.0, _axpby(d_hat, 1.0, d_next, 1.0), 0.5*h)
+        return x, 2*self.num_steps
+
+
+# ------------------------------------------------------------------------------------------
+@ModelRegistry.register('sgmsep')
+class SGMSEp(BreverBaseModel):
+    def __init__(
+        self,
+        stft_frame_length: int = 512,
+        stft_hop_length: int = 128,
+        stft_window: str = 'hann',
+        stft_compression_factor: float = 0.5,
+        stft_scale_factor: float = 0.15,
+        stft_discard_nyquist: bool = True,
+        sde_name: str = 'richter-ouve',
+        sde_stiffness: float = 1.5,
+        sde_ve_sigma_min: float = 0.05,
+        sde_ve_sigma_max: float = 0.5,
+        sde_vp_beta_min: float = 0.01,
+        sde_vp_beta_max: float = 1.0,
+        sde_cosine_lambda_min: float = -12.0,
+        sde_cosine_lambda_max: float = float('inf'),
+        sde_cosine_shift: float = 3.0,
+        sde_cosine_beta_clamp: float = 10.0,
+        sde_bb_scaling: float = 0.1,
+        sde_bb_k: float = 10.0,
+        solver_name: str = 'pc',
+        solver_num_steps: int = 16,
+        solver_edm_schurn: float = float('inf'),
+        solver_edm_smin: float = 0.0,
+        solver_edm_smax: float = float('inf'),
+        solver_edm_snoise: float = 1.0,
+        solver_pc_corrector_steps: int = 1,
+        solver_pc_corrector_snr: float = 0.5,
+        net_base_channels: int = 128,
+        net_channel_mult: list[int] = [1, 1, 2, 2, 2, 2, 2],
+        net_num_blocks_per_res: int = 2,
+        net_noise_channel_mult: int = 2,
+        net_emb_channel_mult: int = 4,
+        net_fir_kernel: list[int] = [1, 3, 3, 1],
+        net_attn_resolutions: list[int] = [16],
+        net_attn_bottleneck: bool = True,
+        net_encoder_type: str = 'skip',
+        net_decoder_type: str = 'skip',
+        net_block_type: str = 'ncsn',
+        net_skip_scale: float = 0.5 ** 0.5,
+        net_dropout: float = 0.0,
+        net_aux_out_channels: int = 4,
+        preconditioning_cskip: str = 'richter',
+        preconditioning_cout: str = 'richter',
+        preconditioning_cin: str = 'richter',
+        preconditioning_cnoise: str = 'richter',
+        preconditioning_cshift: str = 'richter',
+        preconditioning_weight: str = 'richter',
+        preconditioning_sigma_data: float = 0.1,
+        t_eps: float = 0.01,
+        criterion: str = 'mse',
+        optimizer: str = 'Adam',
+        learning_rate: float = 0.0001,
+    ):
+        super().__init__(criterion=criterion)
+        self.stft = STFT(frame_length=stft_frame_length, hop_length=stft_hop_length,
+                         window=stft_window, compression_factor=stft_compression_factor,
+                         scale_factor=stft_scale_factor, normalized=False)
+        self.stft_discard_nyquist = stft_discard_nyquist
+        self.sde = SDERegistry.get(sde_name)(
+            stiffness=sde_stiffness, sigma_min=sde_ve_sigma_min, sigma_max=sde_ve_sigma_max,
+            beta_min=sde_vp_beta_min, beta_max=sde_vp_beta_max, lambda_min=sde_cosine_lambda_min,
+            lambda_max=sde_cosine_lambda_max, shift=sde_cosine_shift,
+            beta_clamp=sde_cosine_beta_clamp, scaling=sde_bb_scaling, k=sde_bb_k)
+        self.solver = SolverRegistry.get(solver_name)(
+            num_steps=solver_num_steps, schurn=solver_edm_schurn, smin=solver_edm_smin,
+            smax=solver_edm_smax, snoise=solver_edm_snoise,
+            corrector_steps=solver_pc_corrector_steps, corrector_snr=solver_pc_corrector_snr)
+        raw_net = DiffusionUNet(
+            num_freqs=stft_frame_length//2, base_channels=net_base_channels,
+            channel_mult=net_channel_mult, num_blocks_per_res=net_num_blocks_per_res,
+            noise_channel_mult=net_noise_channel_mult, emb_channel_mult=net_emb_channel_mult,
+            fir_kernel=net_fir_kernel, attn_resolutions=net_attn_resolutions,
+            attn_bottleneck=net_attn_bottleneck, encoder_type=net_encoder_type,
+            decoder_type=net_decoder_type, block_type=net_block_type, skip_scale=net_skip_scale,
+            dropout=net_dropout, aux_out_channels=net_aux_out_channels)
+        self.model = Preconditioning(
+            raw_net=raw_net, sde=self.sde, cskip=preconditioning_cskip, cout=preconditioning_cout,
+            cin=preconditioning_cin, cnoise=preconditioning_cnoise, cshift=preconditioning_cshift,
+            weight=preconditioning_weight, sigma_data=preconditioning_sigma_data)
+        self.t_eps = t_eps
+        self._noise_source = None
+        self.optimizer = self.init_optimizer(optimizer, lr=learning_rate)
+
+    def transform(self, sources):
+        assert sources.shape[0] == 2  # mixture, foreground
+        home = sources.device
+        dev = home if home.type == 'cuda' else next(self.parameters()).device
+        if dev.type != 'cuda':
+            if not torch.cuda.is_available():
+                raise RuntimeError('the HIP path needs a ROCm device (no CPU fallback)')
+            dev = torch.device('cuda', torch.cuda.current_device())
+        sources = sources.to(dev).mean(axis=-2)
+        sources = sources/sources[0].abs().max()
+        sources = self.stft(sources)
+        if self.stft_discard_nyquist:
+            sources = sources[..., :-1, :]
+        return sources.to(home)
+
+    @torch.no_grad()
+    def forward(self, x, y, sigma, t):
+        """Denoiser D(x; y, sigma, t) for one noise level (0-d ``sigma``, ``t``)."""
+        hip.require_device(x, y)
+        return self.model(x.to(torch.complex64), y.to(torch.complex64),
+                          torch.as_tensor(sigma).float().cpu(), torch.as_tensor(t).float().cpu())
+
+    def loss(self, batch, lengths, use_amp):
+        raise NotImplementedError('SGMSE+ training (backward pass of the score network) is not '
+                                  'built yet on the HIP path')
+
+    @torch.no_grad()
+    def _enhance(self, x, use_amp):
+        hip.require_device(x)
+        length = x.shape[-1]
+        x = x.mean(axis=-2, keepdims=True)                     # (B, 1, L)
+        norm = x.abs().amax(axis=-1, keepdims=True)
+        x = x/norm
+        x = self.stft(x)
+        if self.stft_discard_nyquist:
+            x = x[..., :-1, :]
+        x, nfe = self.solver(self.sde, x.contiguous(), self.model, self)
+        x = torch.nn.functional.pad(x, (0, 0, 0, 1))           # pad the Nyquist bin
+        x = self.stft.backward(x)
+        x = x*norm
+        return x[..., :length].squeeze(1)
+
+
+@ModelRegistry.register('sgmsepm')
+class SGMSEpM(SGMSEp):
+    _is_submodel = True
+
+    def __init__(self, net_channel_mult: list[int] = [1, 2, 2, 2], net_num_blocks_per_res: int = 1,
+                 net_attn_resolutions: list[int] = [], **kwargs):
+        super().__init__(net_channel_mult=net_channel_mult,
+                         net_num_blocks_per_res=net_num_blocks_per_res,
+                         net_attn_resolutions=net_attn_resolutions, **kwargs)
+
+
+def _edm_kwargs(defaults, kwargs):
+    """Merged constructor arguments of the EDM sub-models. The reference declares
+    ``sde_stiffness = 0.0`` on them but never forwards it to ``SGMSEp.__init__``
+    (sgmse.py:243-264, 268-289, 293-338), so the effective stiffness is the parent's 1.5
+    whatever the caller passes; reproduced here so that results are identical."""
+    merged = {**defaults, **kwargs}
+    merged.pop('sde_stiffness', None)
+    return merged
+
+
+_EDM_COSINE = dict(sde_name='brever-oucosine', sde_stiffness=0.0, solver_name='edm',
+                   preconditioning_cskip='edm', preconditioning_cout='edm',
+                   preconditioning_cin='edm', preconditioning_cnoise='edm',
+                   preconditioning_cshift='edm', preconditioning_weight='edm')
+
+
+@ModelRegistry.register('sgmsepheun')
+class sgmsepheun(SGMSEp):
+    _is_submodel = True
+    _defaults = _EDM_COSINE          # read by config.model_defaults like a signature
+
+    def __init__(self, **kwargs):
+        super().__init__(**_edm_kwargs(sgmsepheun._defaults, kwargs))
+
+
+@ModelRegistry.register('sgmsepmheun')
+class sgmsepmheun(SGMSEpM):
+    _is_submodel = True
+    _defaults = _EDM_COSINE
+
+    def __init__(self, **kwargs):
+        super().__init__(**_edm_kwargs(sgmsepmheun._defaults, kwargs))
+
+
+@ModelRegistry.register('idmse')
+class IDMSE(SGMSEp):
+    _is_submodel = True
+    _defaults = dict(_EDM_COSINE, net_base_channels=64, net_channel_mult=[1, 2, 3, 4],
+                     net_num_blocks_per_res=1, net_noise_channel_mult=1, net_emb_channel_mult=4,
+                     net_fir_kernel=[1, 1], net_attn_resolutions=[], net_encoder_type='standard',
+                     net_decoder_type='standard', net_block_type='adm')
+
+    def __init__(self, **kwargs):
+        super().__init__(**_edm_kwargs(IDMSE._defaults, kwargs))

@@ -261,6 +261,24 @@ int brv_combine(const float* a, const float* b, float* out, int64_t n, float sig
 int brv_dccrn_apply_mask(const float* xr, const float* xi, const float* mr, const float* mi,
                          float* out, int64_t n, brv_stream_t stream);
 
+/* ---- SGMSE+ score network building blocks, forward values (models/sgmse/net.py:12-477,
+ * modules/resampling.py:8-61). groupnorm: nn.GroupNorm on x + add_bc[b][c] (nullable; the
+ * noise-embedding term of UNetBlock) with optional SiLU; softmax_rows: attention weights;
+ * fir_resample2d: Resample.forward on `planes` = B*C images (up: transposed, kernel*gain);
+ * axpby: alpha*a + beta*b; fourier_features: GaussianFourierProjection. */
+int brv_groupnorm_forward(const float* x, const float* add_bc, const float* gamma,
+                          const float* beta, float* y, int64_t B, int64_t C, int64_t HW,
+                          int64_t groups, float eps, int act_silu, brv_stream_t stream);
+int brv_silu(const float* x, float* y, int64_t n, brv_stream_t stream);
+int brv_softmax_rows(const float* x, float* y, int64_t rows, int64_t cols, brv_stream_t stream);
+int brv_fir_resample2d(const float* x, const float* kernel, float* y, int64_t planes, int64_t H,
+                       int64_t W, int64_t Ho, int64_t Wo, int64_t K, int64_t pad_h, int64_t pad_w,
+                       int up, float gain, brv_stream_t stream);
+int brv_axpby(const float* a, float alpha, const float* b, float beta, float* out, int64_t n,
+              brv_stream_t stream);
+int brv_fourier_features(const float* x, const float* b, float* out, int64_t n, int64_t m,
+                         brv_stream_t stream);
+
 /* ---- pieces of MultiResYuLoss (criterion.py:135-226) ----------------------------
  * brv_apply_mask: out = x with samples >= lengths[b] zeroed (apply_mask, :229-234),
  *   x/out (B, S, L). brv_l1_*: sums[r] = sum |x - y| over n samples of row r (fp64) and

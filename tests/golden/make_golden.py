@@ -8,7 +8,7 @@ dotenv, torch_ema, pesq, pystoi, batch_pystoi, sofa) are replaced by empty
 stand-in modules *before* import; none of them takes part in
 the arithmetic recorded here.
 
-    python tests/golden/make_golden.py            # writes *.npz / *.json next to it
+    python tests/golden/make_golden.py [name ...]  # writes *.npz / *.json next to it
 """
 import json
 import os
@@ -420,19 +420,95 @@ def golden_dccrn(out):
     np.savez_compressed(os.path.join(out, 'dccrn.npz'), **res)
 
 
+SGMSE_CASES = {
+    # NCSN++ style: skip encoder / skip decoder, attention at one resolution and in the
+    # bottleneck, odd frame count (padding stack), predictor-corrector sampler
+    'pc': ('sgmsep', dict(stft_frame_length=64, stft_hop_length=16, net_base_channels=8,
+                          net_channel_mult=[1, 2, 2], net_num_blocks_per_res=1,
+                          net_attn_resolutions=[16], solver_num_steps=3), 600),
+    # ADM blocks, standard encoder / decoder, box FIR, cosine SDE + Heun sampler
+    'edm': ('idmse', dict(stft_frame_length=64, stft_hop_length=16, net_base_channels=8,
+                          net_channel_mult=[1, 2, 2], solver_num_steps=3,
+                          solver_edm_schurn=1.0), 560),
+    # residual encoder / residual decoder (denoiser only)
+    'res': ('sgmsep', dict(stft_frame_length=64, stft_hop_length=16, net_base_channels=8,
+                           net_channel_mult=[1, 2], net_num_blocks_per_res=1,
+                           net_attn_resolutions=[], net_attn_bottleneck=False,
+                           net_encoder_type='residual', net_decoder_type='residual',
+                           solver_num_steps=2), 500),
+}
+
+
+def golden_sgmse(out):
+    """SGMSE+ (brever/models/sgmse): seeded narrow models; the preconditioned denoiser at one
+    noise level and a full ``enhance`` whose Gaussian draws are recorded (in call order) so
+    that another implementation can replay them."""
+    import brever.models.sgmse.sdes as sdes
+    import brever.models.sgmse.solvers as solvers
+    from brever.models import ModelRegistry
+    res = {}
+    for tag, (arch, cfg, length) in SGMSE_CASES.items():
+        torch.manual_seed(3)
+        net = ModelRegistry.get(arch)(**cfg)
+        g = torch.Generator().manual_seed(11)
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if 'norm' in name:
+                    p.add_(0.1*torch.randn(p.shape, generator=g))
+        net.eval()
+        res[f'{tag}_arch'] = np.array(arch)
+        res[f'{tag}_config'] = np.array(json.dumps(cfg))
+        res[f'{tag}_params'] = torch.cat([p.detach().reshape(-1)
+                                          for p in net.parameters()]).numpy()
+        wav = 0.3*torch.randn(1, 2, length, generator=g)
+        res[f'{tag}_wav'] = wav.numpy()
+        with torch.no_grad():
+            y = net.stft(wav.mean(axis=-2, keepdims=True)/wav.mean(axis=-2).abs().max())
+            y = y[..., :-1, :]
+            x = y + 0.2*torch.randn(y.shape, generator=g).to(y.dtype)
+            t = torch.tensor(0.6)
+            sigma = net.sde.sigma(t)
+            res[f'{tag}_den_x'] = x.numpy(); res[f'{tag}_den_y'] = y.numpy()
+            res[f'{tag}_den_t'] = t.numpy()
+            res[f'{tag}_den_out'] = net(x, y, sigma, t).numpy()
+            draws = []
+            real_randn, real_randn_like = torch.randn, torch.randn_like
+
+            def randn(*a, **k):
+                k.pop('device', None)
+                d = real_randn(*a, generator=g, **k)
+                draws.append(d)
+                return d
+
+            def randn_like(ref, **k):
+                d = real_randn(ref.shape, generator=g, dtype=ref.dtype)
+                draws.append(d)
+                return d
+            patched = types.SimpleNamespace(**{n: getattr(torch, n) for n in dir(torch)})
+            patched.randn, patched.randn_like = randn, randn_like
+            sdes.torch, solvers.torch = patched, patched
+            try:
+                if tag != 'res':
+                    res[f'{tag}_enhance'] = net.enhance(wav.clone()).numpy()
+            finally:
+                sdes.torch, solvers.torch = torch, torch
+            for i, d in enumerate(draws):
+                res[f'{tag}_noise_{i}'] = d.numpy()
+            res[f'{tag}_n_noise'] = np.array(len(draws))
+    np.savez_compressed(os.path.join(out, 'sgmse.npz'), **res)
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
     os.chdir(REF)       # the reference opens config/... relatively
     torch.set_num_threads(4)
-    golden_batching(HERE)
-    golden_collate(HERE)
-    golden_losses(HERE)
-    golden_convtasnet(HERE)
-    golden_training(HERE)
-    golden_stft(HERE)
-    golden_ffnn(HERE)
-    golden_dccrn(HERE)
+    todo = [golden_batching, golden_collate, golden_losses, golden_convtasnet, golden_training,
+            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse]
+    only = sys.argv[1:]                  # e.g. `make_golden.py sgmse` regenerates one file
+    for fn in todo:
+        if not only or fn.__name__[len('golden_'):] in only:
+            fn(HERE)
     print('golden fixtures written to', HERE)
 
 

@@ -76,3 +76,46 @@ class DummyModel(BreverBaseModel):
 
     def _enhance(self, x, use_amp):
         return x.mean(-2)
+
+
+def sgmse_case(golden, tag):
+    """Oracle network, SDE, sampler and replayed noise for one case of tests/golden/sgmse.npz;
+    the weights come from the seeded construction the golden script used."""
+    import functools
+    import json
+
+    import scipy.signal
+
+    from brever_amd.models import ModelRegistry
+    from oracle import sgmse as osg
+    cfg = json.loads(str(golden[f'{tag}_config']))
+    torch.manual_seed(3)
+    model = ModelRegistry.get(str(golden[f'{tag}_arch']))(**cfg)
+    gen = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if 'norm' in name:
+                p.add_(0.1*torch.randn(p.shape, generator=gen))
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert torch.equal(flat, torch.from_numpy(golden[f'{tag}_params']))
+    edm = tag == 'edm'
+    net = osg.Net(model.state_dict(), 'model.net.', skip_scale=0.5**0.5,
+                  block_type='adm' if edm else 'ncsn')
+    sde = osg.OUCosine() if edm else osg.RichterOUVE()
+    kw = dict(precond='edm' if edm else 'richter')
+    draws = [torch.from_numpy(golden[f'{tag}_noise_{i}'])
+             for i in range(int(golden[f'{tag}_n_noise']))]
+
+    def noise(shape, complex_, it=iter(draws)):
+        d = next(it)
+        assert tuple(d.shape) == tuple(shape) and d.is_complex() == complex_
+        return d
+    if edm:
+        sampler = functools.partial(osg.edm_sample, noise=noise, num_steps=3, schurn=1.0,
+                                    smin=0.0, smax=float('inf'), snoise=1.0, **kw)
+    else:
+        sampler = functools.partial(osg.pc_sample, noise=noise,
+                                    num_steps=cfg['solver_num_steps'], corrector_steps=1,
+                                    corrector_snr=0.5, **kw)
+    window = scipy.signal.get_window('hann', cfg['stft_frame_length'])
+    return model, net, sde, kw, sampler, window, draws

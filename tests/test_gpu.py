@@ -792,3 +792,112 @@ def test_entry_points_dccrn(tmp_path):
     out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:3:0.5')
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert np.isfinite(np.load(os.path.join(model_dir, 'scores.npz'))['scores']).all()
+
+
+@pytest.mark.gpu
+def test_sgmse_building_blocks_match_torch():
+    """The SGMSE+ kernels one by one against torch on the CPU at odd sizes: group norm (+ the
+    per-(item, channel) embedding term + SiLU), FIR down / up sampling with the reference's
+    padding stack, row softmax, Fourier features, complex axpby (fp32: rel-L2 1e-5)."""
+    import torch.nn.functional as F
+
+    from brever_amd.models import sgmse as M
+    dev = _cuda()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 24, 13, 7, generator=g)
+    e = torch.randn(2, 24, generator=g)
+    gn = M.GroupNorm(24)
+    with torch.no_grad():
+        gn.weight.add_(0.2*torch.randn(24, generator=g)); gn.bias.add_(0.2*torch.randn(24, generator=g))
+    ref = F.silu(gn(x + e[:, :, None, None]))
+    got = M._group_norm(x.to(dev), gn.to(dev), add=e.to(dev), silu=True)
+    assert rel(got, ref.detach()) <= 1e-5
+    assert rel(M._group_norm(x.to(dev), gn), gn.cpu()(x).detach()) <= 1e-5
+    gn.cpu()
+    for fir in ([1, 3, 3, 1], [1, 1], [1, 2, 1]):
+        rs = M.Resample(fir, buffer_padding=True)
+        kern = rs.kernel.clone()
+        rs = rs.to(dev)
+        for H, W in ((13, 7), (8, 10), (5, 6)):
+            xx = torch.randn(2, 3, H, W, generator=g)
+            K = kern.shape[-1]
+            pad = tuple(-(-K//2) - 1 if d % 2 == 0 else -(-(K + 1)//2) - 1 for d in (H, W))
+            opad = tuple((d + 2*p - K) % 2 for d, p in zip((H, W), pad))
+            down_ref = F.conv2d(xx, kern.tile([3, 1, 1, 1]), padding=pad, groups=3, stride=2)
+            down = rs(xx.to(dev), 'down')
+            assert down.shape == down_ref.shape and rel(down, down_ref) <= 1e-5
+            up_ref = F.conv_transpose2d(down_ref, 4*kern.tile([3, 1, 1, 1]), padding=pad,
+                                        output_padding=opad, groups=3, stride=2)
+            up = rs(down, 'up')
+            assert up.shape == up_ref.shape == xx.shape and rel(up, up_ref) <= 1e-5
+    w = torch.randn(37, 91, generator=g)*3
+    p = torch.empty_like(w, device=dev)
+    from brever_amd import hip
+    hip.check(hip.lib().brv_softmax_rows(hip.ptr(w.to(dev)), hip.ptr(p), 37, 91, hip.stream()), 'sm')
+    assert rel(p, w.softmax(-1)) <= 1e-6
+    fp = M.GaussianFourierProjection(16)
+    tt = torch.tensor([-0.51, 0.3])
+    ang = 2*np.pi*tt.outer(fp.b)
+    assert torch.allclose(fp.to(dev)(tt.to(dev)).cpu(), torch.cat([ang.sin(), ang.cos()], -1),
+                          atol=2e-5)
+    a = torch.randn(5, 3, dtype=torch.complex64, generator=g)
+    b = torch.randn(5, 3, generator=g)
+    assert rel(torch.view_as_real(M._axpby(a.to(dev), 0.3, b.to(dev), -1.7)),
+               torch.view_as_real(0.3*a - 1.7*b)) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['pc', 'edm', 'res'])
+def test_sgmse_matches_reference(golden_dir, tag):
+    """HIP SGMSE+ vs the oracle and the reference golden at seeded weights: the preconditioned
+    denoiser at one noise level, then ``enhance`` (reverse SDE with the recorded Gaussian draws
+    replayed through ``_noise_source``). fp32 kernels: rel-L2 1e-4 / 5e-4."""
+    from helpers import sgmse_case
+    from oracle import sgmse as osg
+    g = np.load(os.path.join(golden_dir, 'sgmse.npz'))
+    dev = _cuda()
+    model, net, sde, kw, sampler, window, draws = sgmse_case(g, tag)
+    model = model.to(dev).eval()
+    x, y = torch.from_numpy(g[f'{tag}_den_x']), torch.from_numpy(g[f'{tag}_den_y'])
+    t = torch.from_numpy(g[f'{tag}_den_t'])
+    with torch.no_grad():
+        want = osg.denoise(net, sde, x, y, sde.sigma(t), t, **kw)
+    got = model(x.to(dev), y.to(dev), model.sde.sigma(t), t)
+    gold = torch.from_numpy(g[f'{tag}_den_out'])
+    assert rel(torch.view_as_real(got), torch.view_as_real(want)) <= 1e-4
+    assert rel(torch.view_as_real(got), torch.view_as_real(gold)) <= 1e-4
+    if tag == 'res':
+        return
+    it = iter(draws)
+    model._noise_source = lambda shape, complex_: next(it)
+    out = model.enhance(torch.from_numpy(g[f'{tag}_wav']).to(dev))
+    assert next(it, None) is None                       # every recorded draw was consumed
+    gold = torch.from_numpy(g[f'{tag}_enhance'])
+    assert out.shape == gold.shape
+    assert rel(out, gold) <= 5e-4, rel(out, gold)
+    with pytest.raises(NotImplementedError):
+        model.loss(torch.zeros(1, 2, 32, 8, dtype=torch.complex64, device=dev), None, False)
+
+
+@pytest.mark.gpu
+def test_sgmse_default_architecture_denoiser():
+    """The default SGMSE+ score network (65.6 M parameters, 7 resolutions, attention at 16
+    bins and in the bottleneck) on a 256 x 40 spectrogram vs the CPU oracle; the sampler only
+    repeats this call."""
+    from brever_amd.models import SGMSEp, count_params
+    from oracle import sgmse as osg
+    dev = _cuda()
+    torch.manual_seed(1)
+    model = SGMSEp()
+    assert count_params(model) == 65590694
+    net = osg.Net(model.state_dict(), 'model.net.', skip_scale=0.5**0.5)
+    sde = osg.RichterOUVE()
+    g = torch.Generator().manual_seed(2)
+    y = 0.3*torch.randn(1, 1, 256, 40, dtype=torch.complex64, generator=g)
+    x = y + 0.2*torch.randn(1, 1, 256, 40, dtype=torch.complex64, generator=g)
+    t = torch.tensor(0.5)
+    with torch.no_grad():
+        want = osg.denoise(net, sde, x, y, sde.sigma(t), t)
+    model = model.to(dev).eval()
+    got = model(x.to(dev), y.to(dev), model.sde.sigma(t), t)
+    assert rel(torch.view_as_real(got), torch.view_as_real(want)) <= 2e-4

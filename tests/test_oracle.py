@@ -307,3 +307,25 @@ def test_dccrn_oracle_matches_reference(golden_dir):
     with torch.no_grad():
         y = net(x)
     assert torch.allclose(y, torch.from_numpy(g['out_eval']), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag', ['pc', 'edm', 'res'])
+def test_sgmse_oracle_matches_reference(golden_dir, tag):
+    """oracle/sgmse.py vs the imported reference: the preconditioned denoiser at one noise
+    level and a full ``enhance`` with the recorded Gaussian draws replayed."""
+    from helpers import sgmse_case
+    from oracle import sgmse as osg
+    g = np.load(os.path.join(golden_dir, 'sgmse.npz'))
+    model, net, sde, kw, sampler, window, _ = sgmse_case(g, tag)
+    x, y = torch.from_numpy(g[f'{tag}_den_x']), torch.from_numpy(g[f'{tag}_den_y'])
+    t = torch.from_numpy(g[f'{tag}_den_t'])
+    with torch.no_grad():
+        d = osg.denoise(net, sde, x, y, sde.sigma(t), t, **kw)
+    ref = torch.from_numpy(g[f'{tag}_den_out'])
+    assert (d - ref).abs().max() <= 1e-5*ref.abs().max()
+    if tag == 'res':
+        return
+    with torch.no_grad():
+        out = osg.enhance(net, sde, torch.from_numpy(g[f'{tag}_wav']), window, 16, sampler)
+    ref = torch.from_numpy(g[f'{tag}_enhance'])
+    assert (out - ref).abs().max() <= 1e-4*ref.abs().max()
