@@ -26,39 +26,85 @@ dim3 flat_grid(long long n) {
 
 __device__ __forceinline__ float silu(float v) { return v/(1.f + expf(-v)); }
 
-// GroupNorm over (channels of the group, H, W) per item, input x + add[b][c] (nullable), then
-// optional SiLU. One workgroup per (item, group).
-__global__ __launch_bounds__(256) void groupnorm_kernel(const float* x, const float* add,
-                                                        const float* gamma, const float* beta,
-                                                        float* y, int C, long long HW, int groups,
-                                                        float eps, int act) {
+// GroupNorm in three small steps so that the normalisation itself can be folded into the
+// consumer: (1) partial sums of x + add[b][c] over slices of each (item, group), fp64, one
+// atomic pair per workgroup on the group's private 128-byte line; (2) fold into a per-(item,
+// channel) affine: scale = rstd*gamma*(1 + adm_scale), shift = (beta + (add - mean)*rstd*gamma)
+// *(1 + adm_scale) + adm_shift; (3) y = act(scale*x + shift) -- here (affine_act_kernel) or on
+// the load path of brv_conv2d_mfma_forward.
+constexpr int kGnLine = 16;      // doubles per (item, group) slot
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, const float* add,
+                                                       double* sums, int C, long long HW,
+                                                       int groups, long long slice) {
   __shared__ double scr[8];
-  __shared__ float stat[2];
-  const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int bg = blockIdx.x, b = bg / groups, g = bg % groups;
   const int cpg = C/groups;
   const long long n = (long long)cpg*HW;
   const float* xg = x + ((long long)b*C + (long long)g*cpg)*HW;
-  float* yg = y + ((long long)b*C + (long long)g*cpg)*HW;
   const float* ag = add ? add + (long long)b*C + (long long)g*cpg : nullptr;
+  const long long lo = (long long)blockIdx.y*slice;
+  long long hi = lo + slice;
+  if (hi > n) hi = n;
   double s = 0.0, q = 0.0;
-  for (long long i = threadIdx.x; i < n; i += 256) {
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const float v = xg[i] + (ag ? ag[i / HW] : 0.f);
     s += v; q += (double)v*v;
   }
   s = block_sum(s, scr); __syncthreads();
   q = block_sum(q, scr);
-  if (threadIdx.x == 0) {
-    const double mean = s/n;
-    double var = q/n - mean*mean;
-    if (var < 0) var = 0;
-    stat[0] = (float)mean; stat[1] = (float)(1.0/sqrt(var + eps));
+  if (threadIdx.x == 0 && lo < hi) {
+    atomicAdd(&sums[(long long)bg*kGnLine], s);
+    atomicAdd(&sums[(long long)bg*kGnLine + 1], q);
   }
+}
+
+// one workgroup per (item, group); the group's sums are cleared again once read, so the
+// scratch is all zeros whenever a stats kernel starts (it is zeroed once, when allocated)
+__global__ __launch_bounds__(64) void gn_fold_kernel(double* sums, const float* add,
+                                                     const float* gamma, const float* beta,
+                                                     const float* adm_scale, const float* adm_shift,
+                                                     float* scale, float* shift, int C,
+                                                     long long HW, int groups, float eps) {
+  const int bg = blockIdx.x, b = bg / groups, g = bg % groups;
+  const int cpg = C/groups;
+  const double n = (double)cpg*(double)HW;
+  const double s1 = sums[(long long)bg*kGnLine], s2 = sums[(long long)bg*kGnLine + 1];
   __syncthreads();
-  const float mean = stat[0], rstd = stat[1];
-  for (long long i = threadIdx.x; i < n; i += 256) {
-    const int c = g*cpg + (int)(i / HW);
-    float v = (xg[i] + (ag ? ag[i / HW] : 0.f) - mean)*rstd*gamma[c] + beta[c];
-    yg[i] = act ? silu(v) : v;
+  if (threadIdx.x == 0) { sums[(long long)bg*kGnLine] = 0.0; sums[(long long)bg*kGnLine + 1] = 0.0; }
+  const double mean = s1/n;
+  double var = s2/n - mean*mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0/sqrt(var + (double)eps));
+  for (int j = threadIdx.x; j < cpg; j += 64) {
+    const int c = g*cpg + j, idx = b*C + c;
+    float sc = rstd*gamma[c];
+    float sh = beta[c] + ((add ? add[idx] : 0.f) - (float)mean)*sc;
+    if (adm_scale) { const float m = 1.f + adm_scale[idx]; sc *= m; sh = sh*m + adm_shift[idx]; }
+    scale[idx] = sc; shift[idx] = sh;
+  }
+}
+
+// y[b][c][:] = act(scale[b][c]*x + shift[b][c])
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* x, const float* scale,
+                                                         const float* shift, float* y,
+                                                         long long HW, long long total, int act) {
+  GRID_STRIDE(i4, total/4) {
+    const long long i = i4*4;
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long bc = (i + j)/HW;
+      const float t = scale[bc]*r[j] + shift[bc];
+      r[j] = act ? silu(t) : t;
+    }
+    *reinterpret_cast<float4*>(y + i) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {
+    const long long i = (total & ~3LL) + threadIdx.x;
+    const float t = scale[i/HW]*x[i] + shift[i/HW];
+    y[i] = act ? silu(t) : t;
   }
 }
 
@@ -159,13 +205,33 @@ __global__ __launch_bounds__(256) void fourier_kernel(const float* x, const floa
 
 extern "C" {
 
-int brv_groupnorm_forward(const float* x, const float* add_bc, const float* gamma,
-                          const float* beta, float* y, int64_t B, int64_t C, int64_t HW,
-                          int64_t groups, float eps, int act_silu, brv_stream_t stream) {
+int64_t brv_groupnorm_scratch_bytes(int64_t B, int64_t groups) {
+  return B*groups*kGnLine*(int64_t)sizeof(double);
+}
+int brv_groupnorm_fold(const float* x, const float* add_bc, const float* gamma, const float* beta,
+                       const float* adm_scale, const float* adm_shift, void* scratch, float* scale,
+                       float* shift, int64_t B, int64_t C, int64_t HW, int64_t groups, float eps,
+                       brv_stream_t stream) {
   if (B < 1 || C < 1 || HW < 1 || groups < 1 || C % groups) return -1;
-  hipLaunchKernelGGL(groupnorm_kernel, dim3((unsigned)(B*groups)), dim3(256), 0,
-                     (hipStream_t)stream, x, add_bc, gamma, beta, y, (int)C, (long long)HW,
-                     (int)groups, eps, act_silu);
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (C/groups)*HW;
+  long long nsplit = (n + 16383)/16384;
+  if (nsplit > 64) nsplit = 64;
+  const long long slice = ((n + nsplit - 1)/nsplit + 3) & ~3LL;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(B*groups), (unsigned)nsplit), dim3(256), 0,
+                     st, x, add_bc, (double*)scratch, (int)C, (long long)HW, (int)groups, slice);
+  hipLaunchKernelGGL(gn_fold_kernel, dim3((unsigned)(B*groups)), dim3(64), 0, st,
+                     (double*)scratch, add_bc, gamma, beta, adm_scale, adm_shift, scale, shift,
+                     (int)C, (long long)HW, (int)groups, eps);
+  SG_OK(hipGetLastError());
+  return 0;
+}
+int brv_affine_act(const float* x, const float* scale_bc, const float* shift_bc, float* y,
+                   int64_t B, int64_t C, int64_t HW, int act_silu, brv_stream_t stream) {
+  if (B < 1 || C < 1 || HW < 1) return -1;
+  const long long total = B*C*HW;
+  hipLaunchKernelGGL(affine_act_kernel, flat_grid(total/4 + 1), dim3(256), 0, (hipStream_t)stream,
+                     x, scale_bc, shift_bc, y, (long long)HW, total, act_silu);
   SG_OK(hipGetLastError());
   return 0;
 }

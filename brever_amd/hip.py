@@ -118,13 +118,19 @@ SIGNATURES = {
     'brv_combine': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr]),
     'brv_dccrn_apply_mask': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                             _c_ptr]),
-    'brv_groupnorm_forward': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*4 + [_c_f32, ctypes.c_int, _c_ptr]),
+    'brv_groupnorm_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
+    'brv_groupnorm_fold': (ctypes.c_int, [_c_ptr]*9 + [_c_i64]*4 + [_c_f32, _c_ptr]),
+    'brv_affine_act': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*3 + [ctypes.c_int, _c_ptr]),
     'brv_silu': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr]),
     'brv_softmax_rows': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_fir_resample2d': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*8
                            + [ctypes.c_int, _c_f32, _c_ptr]),
     'brv_axpby': (ctypes.c_int, [_c_ptr, _c_f32, _c_ptr, _c_f32, _c_ptr, _c_i64, _c_ptr]),
     'brv_fourier_features': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
+    'brv_conv2d_packed_size': (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    'brv_conv2d_pack_f16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_conv2d_mfma_forward': (ctypes.c_int, [_c_ptr]*6 + [ctypes.c_int, _c_ptr] + [_c_i64]*8
+                                + [_c_f32, _c_ptr]),
     'brv_clip_adam_step': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                           _c_i64, _c_f32, _c_f32, _c_f32,
                                           _c_f32, _c_f32, _c_f32, _c_i64,

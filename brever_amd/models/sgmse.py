@@ -5,13 +5,13 @@ names and seeded initialisation as the reference (brever/models/sgmse/sgmse.py:2
 net.py:12-477, preconditioning.py:5-58, sdes.py:11-81, solvers.py:8-77). ``enhance`` runs the
 reverse SDE (predictor-corrector or EDM/Heun sampler) with every network evaluation -- 3x3 /
 1x1 convolutions, group norms, SiLU, FIR resampling, self-attention, noise embedding -- and
-every state update in ``libbrever_hip.so``; torch draws the Gaussian noise, concatenates skip
+every state update in ``libbrever_hip.so`` (``enhance(x, use_amp=True)`` puts the convolutions
+on the fp16 MFMA with folded group norms, ``hip_autocast``); torch draws the Gaussian noise, concatenates skip
 tensors and holds the parameters.
 
 Built: every SDE, both solvers (``pc``, ``edm``), all three preconditionings and every
 encoder / decoder / block type of ``DiffusionUNet``. Not built yet: training (``loss`` needs
-the backward pass of the U-Net and raises ``NotImplementedError``). fp32 kernels: ``use_amp``
-is ignored.
+the backward pass of the U-Net and raises ``NotImplementedError``).
 """
 import math
 
@@ -30,28 +30,103 @@ SolverRegistry = Registry('solver')
 # ------------------------------------------------------------------------------------------
 # HIP primitives (inference: plain functions on contiguous fp32 tensors)
 # ------------------------------------------------------------------------------------------
-def _conv(x, mod):
+_STATE = {'amp': False}
+_GN_SCRATCH = {}
+
+
+class hip_autocast:
+    """``use_amp`` of the HIP path: inside the block the 1x1 / 3x3 convolutions run on the fp16
+    MFMA with fp32 accumulation and fp32 activations (``brv_conv2d_mfma_forward``; the
+    reference autocasts to fp16, sgmse.py:190-193) and the group norms feeding them are folded
+    into their load path; outside, every kernel is fp32."""
+
+    def __init__(self, enabled):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _STATE['amp']
+        _STATE['amp'] = self.enabled
+
+    def __exit__(self, *exc):
+        _STATE['amp'] = self.prev
+
+
+def _packed_weight(mod):
+    w = mod.weight
+    key = (w.data_ptr(), w._version)
+    if getattr(mod, '_brv_wp_key', None) != key:
+        Cout, Cin, k, _ = w.shape
+        n = hip.lib().brv_conv2d_packed_size(Cout, Cin, k)
+        wp = torch.empty(n, dtype=torch.float16, device=w.device)
+        hip.check(hip.lib().brv_conv2d_pack_f16(hip.ptr(w.detach().contiguous()), hip.ptr(wp), Cout,
+                                                Cin, k, hip.stream()), 'brv_conv2d_pack_f16')
+        mod._brv_wp, mod._brv_wp_key = wp, key
+    return mod._brv_wp
+
+
+def _conv(x, mod, fold=None, silu=False, res=None, out_scale=1.0):
+    """out_scale*(conv(act(fold(x))) + bias + res); ``fold`` = (scale, shift) per (item, channel)
+    from ``_gn_fold`` (a GroupNorm reduced to an affine map), applied on the load path of the
+    MFMA kernel under ``hip_autocast`` and by ``brv_affine_act`` otherwise."""
     x = x.contiguous()
     B, Cin, H, W = x.shape
     Cout = mod.out_channels
     (kh, kw), (sh, sw), (ph, pw) = mod.kernel_size, mod.stride, mod.padding
+    if _STATE['amp'] and kh == kw and kh in (1, 3) and (sh, sw) == (1, 1) and ph == pw == kh//2:
+        y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+        sc, sf = fold if fold is not None else (None, None)
+        hip.check(hip.lib().brv_conv2d_mfma_forward(
+            hip.ptr(x), hip.ptr(_packed_weight(mod)), hip.ptr(mod.bias),
+            hip.ptr(res.contiguous()) if res is not None else None, hip.ptr(sc), hip.ptr(sf),
+            int(silu), hip.ptr(y), B, Cin, H, W, Cout, kh, Cin*H*W, Cout*H*W, float(out_scale),
+            hip.stream()), 'brv_conv2d_mfma_forward')
+        return y
+    if fold is not None:
+        x = _affine_act(x, fold, silu)
     Ho, Wo = (H + 2*ph - kh)//sh + 1, (W + 2*pw - kw)//sw + 1
     y = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
     hip.check(hip.lib().brv_conv2d_forward(
         hip.ptr(x), hip.ptr(mod.weight), hip.ptr(mod.bias), hip.ptr(y), B, Cin, H, W, Cout, kh, kw,
         sh, sw, ph, pw, Cin*H*W, Cout*Ho*Wo, 0, 1.0, hip.stream()), 'brv_conv2d_forward')
+    if res is not None or out_scale != 1.0:
+        y = _axpby(y, out_scale, res, out_scale)
+    return y
+
+
+def _gn_fold(x, mod, add=None, adm=None):
+    """GroupNorm(x + add[:, :, None, None]) [then (1 + adm[0])*. + adm[1]] as a per-(item,
+    channel) affine map of x: returns (scale, shift), each (B, C)."""
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    lib = hip.lib()
+    need = lib.brv_groupnorm_scratch_bytes(B, mod.num_groups)
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    scratch = _GN_SCRATCH.get(key)
+    if scratch is None or scratch.numel() < need:        # zero once; the kernels leave it zero
+        scratch = _GN_SCRATCH[key] = torch.zeros(max(need, 1 << 16), dtype=torch.uint8,
+                                                 device=x.device)
+    scale = torch.empty(B, C, dtype=torch.float32, device=x.device)
+    shift = torch.empty_like(scale)
+    a0, a1 = (adm[0].contiguous(), adm[1].contiguous()) if adm is not None else (None, None)
+    hip.check(lib.brv_groupnorm_fold(
+        hip.ptr(x), hip.ptr(add.contiguous()) if add is not None else None, hip.ptr(mod.weight),
+        hip.ptr(mod.bias), hip.ptr(a0), hip.ptr(a1), hip.ptr(scratch), hip.ptr(scale),
+        hip.ptr(shift), B, C, H*W, mod.num_groups, float(mod.eps), hip.stream()),
+        'brv_groupnorm_fold')
+    return scale, shift
+
+
+def _affine_act(x, fold, silu=False):
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    hip.check(hip.lib().brv_affine_act(hip.ptr(x), hip.ptr(fold[0]), hip.ptr(fold[1]), hip.ptr(y),
+                                       B, C, H*W, int(silu), hip.stream()), 'brv_affine_act')
     return y
 
 
 def _group_norm(x, mod, add=None, silu=False):
-    x = x.contiguous()
-    B, C, H, W = x.shape
-    y = torch.empty_like(x)
-    hip.check(hip.lib().brv_groupnorm_forward(
-        hip.ptr(x), hip.ptr(add.contiguous()) if add is not None else None, hip.ptr(mod.weight),
-        hip.ptr(mod.bias), hip.ptr(y), B, C, H*W, mod.num_groups, float(mod.eps), int(silu),
-        hip.stream()), 'brv_groupnorm_forward')
-    return y
+    return _affine_act(x, _gn_fold(x, mod, add), silu)
 
 
 def _silu(x):
@@ -176,12 +251,12 @@ class AttentionBlock(nn.Module):
         self.conv_value = nn.Conv2d(num_channels, num_channels, 1)
         self.conv_out = nn.Conv2d(num_channels, num_channels, 1)
 
-    def forward(self, x):
+    def forward(self, x, out_scale=1.0):
         lib = hip.lib()
         N, C, H, W = x.shape
         L = H*W
-        xn = _group_norm(x, self.norm)
-        q, k, v = _conv(xn, self.conv_query), _conv(xn, self.conv_key), _conv(xn, self.conv_value)
+        fold = _gn_fold(x, self.norm)
+        q, k, v = (_conv(x, m, fold=fold) for m in (self.conv_query, self.conv_key, self.conv_value))
         # weights (L, L) = q^T (L, C) @ k (C, L) / sqrt(C), softmax over the last dim
         w = torch.empty(N, L, L, dtype=torch.float32, device=x.device)
         hip.check(lib.brv_gemm_f32(hip.ptr(q), hip.ptr(k), hip.ptr(w), N, L, L, C, L, L, L, C*L,
@@ -194,7 +269,7 @@ class AttentionBlock(nn.Module):
         a = torch.empty(N, C, L, dtype=torch.float32, device=x.device)
         hip.check(lib.brv_gemm_f32(hip.ptr(v), hip.ptr(p), hip.ptr(a), N, C, L, L, L, L, L, C*L,
                                    L*L, C*L, 0, 1, 1, 0, 0, None, 0, hip.stream()), 'brv_gemm_f32')
-        return _axpby(x, 1.0, _conv(a.view(N, C, H, W), self.conv_out), 1.0)
+        return _conv(a.view(N, C, H, W), self.conv_out, res=x, out_scale=out_scale)
 
 
 class UNetBlock(nn.Module):
@@ -216,29 +291,28 @@ class UNetBlock(nn.Module):
         self.up_or_down = up_or_down
         self.attn = AttentionBlock(out_channels) if attention else None
         self.block_type = block_type
+        self._e = None            # this block's slice of DiffusionUNet._block_embeddings
 
     def forward(self, x, emb):
-        h = _group_norm(x, self.norm_1, silu=True)
         if self.resampler is not None:
-            h = self.resampler(h, self.up_or_down)
+            h = self.resampler(_group_norm(x, self.norm_1, silu=True), self.up_or_down)
             x = self.resampler(x, self.up_or_down)
-        h = _conv(h, self.conv_1)
-        e = _linear(emb, self.linear)                         # (N, out or 2*out)
-        if e.shape[0] != h.shape[0]:
-            e = e.expand(h.shape[0], -1)
-        if self.block_type == 'adm':
-            scale, shift = e.chunk(2, dim=1)
-            hn = _group_norm(h, self.norm_2)
-            # (scale + 1)*norm + shift, then SiLU
-            h = _silu(hn*(scale.contiguous()[:, :, None, None] + 1) + shift[:, :, None, None])
+            h = _conv(h, self.conv_1)
         else:
-            h = _group_norm(h, self.norm_2, add=e, silu=True)
-        h = _conv(h, self.conv_2)                             # dropout: identity at inference
+            h = _conv(x, self.conv_1, fold=_gn_fold(x, self.norm_1), silu=True)
+        e = self._e if self._e is not None else _linear(emb, self.linear)   # (N, out or 2*out)
+        if e.shape[0] != h.shape[0]:
+            e = e.expand(h.shape[0], -1).contiguous()
+        if self.block_type == 'adm':                          # silu((scale + 1)*norm(h) + shift)
+            fold = _gn_fold(h, self.norm_2, adm=e.chunk(2, dim=1))
+        else:                                                 # silu(norm(h + emb))
+            fold = _gn_fold(h, self.norm_2, add=e)
         if self.skip_conv is not None:
             x = _conv(x, self.skip_conv)
-        x = _axpby(x, self.skip_scale, h, self.skip_scale)
+        # dropout: identity at inference; x = skip_scale*(x + conv_2(...))
+        x = _conv(h, self.conv_2, fold=fold, silu=True, res=x, out_scale=self.skip_scale)
         if self.attn is not None:
-            x = _axpby(self.attn(x), self.skip_scale)
+            x = self.attn(x, out_scale=self.skip_scale)
         return x
 
 
@@ -312,7 +386,7 @@ class AuxiliaryUp(nn.Module):
         if self.resampler is not None:
             aux = self.resampler(aux, 'up')
         if self.type_ == 'skip' or self.resampler is None:
-            h = _conv(_group_norm(x, self.norm, silu=True), self.conv)
+            h = _conv(x, self.conv, fold=_gn_fold(x, self.norm), silu=True)
             aux = h if aux is None else _axpby(aux, 1.0, h, 1.0)
         else:
             x = aux = _axpby(x, 1.0, _conv(aux, self.conv), 1.0)
@@ -321,7 +395,7 @@ class AuxiliaryUp(nn.Module):
 
 class _OutputConv(nn.Sequential):
     def forward(self, x):
-        return _conv(_group_norm(x, self[0]), self[1])
+        return _conv(x, self[1], fold=_gn_fold(x, self[0]))
 
 
 class DiffusionUNet(nn.Module):
@@ -333,6 +407,7 @@ class DiffusionUNet(nn.Module):
         assert encoder_type in ['standard', 'residual', 'skip']
         assert decoder_type in ['standard', 'residual', 'skip']
         assert block_type in ['ncsn', 'adm']
+        self._blocks, self._emb_key = None, None
         self.resampler = Resample(fir_kernel, buffer_padding=True)
         emb_channels = base_channels*emb_channel_mult
         self.emb = NoiseEmbedding(base_channels*noise_channel_mult, emb_channels)
@@ -381,8 +456,32 @@ class DiffusionUNet(nn.Module):
         else:
             self.output_conv = nn.Conv2d(aux_out_channels, out_channels, 1)
 
+    def _block_embeddings(self, emb):
+        """``linear(emb)`` of every U-Net block in ONE matrix product per network evaluation
+        (they depend on the noise level only); each block reads its slice."""
+        if self._blocks is None:
+            self._blocks = [m for m in self.modules() if isinstance(m, UNetBlock)]
+        key = tuple((b.linear.weight.data_ptr(), b.linear.weight._version, b.linear.bias._version)
+                    for b in self._blocks)
+        if self._emb_key != key:
+            self._emb_w = torch.cat([b.linear.weight.detach() for b in self._blocks]).contiguous()
+            self._emb_b = torch.cat([b.linear.bias.detach() for b in self._blocks]).contiguous()
+            self._emb_key = key
+        N, K = emb.shape
+        O = self._emb_w.shape[0]
+        d = torch.empty(O, N, dtype=torch.float32, device=emb.device)
+        hip.check(hip.lib().brv_gemm_f32(
+            hip.ptr(self._emb_w), hip.ptr(emb.contiguous()), hip.ptr(d), 1, O, N, K, K, K, N, 0, 0,
+            0, 0, 1, 1, 0, 0, hip.ptr(self._emb_b), 0, hip.stream()), 'brv_gemm_f32')
+        o = 0
+        for b in self._blocks:
+            n = b.linear.out_features
+            b._e = d[o:o + n].t().contiguous()
+            o += n
+
     def forward(self, x, sigma):
         emb = self.emb(torch.as_tensor(sigma, dtype=torch.float32).to(x.device))
+        self._block_embeddings(emb)
         aux = x
         x = _conv(x, self.input_conv)
         skips = [x]
@@ -823,7 +922,8 @@ class SGMSEp(BreverBaseModel):
         x = self.stft(x)
         if self.stft_discard_nyquist:
             x = x[..., :-1, :]
-        x, nfe = self.solver(self.sde, x.contiguous(), self.model, self)
+        with hip_autocast(use_amp):
+            x, nfe = self.solver(self.sde, x.contiguous(), self.model, self)
         x = torch.nn.functional.pad(x, (0, 0, 0, 1))           # pad the Nyquist bin
         x = self.stft.backward(x)
         x = x*norm

@@ -262,13 +262,23 @@ int brv_dccrn_apply_mask(const float* xr, const float* xi, const float* mr, cons
                          float* out, int64_t n, brv_stream_t stream);
 
 /* ---- SGMSE+ score network building blocks, forward values (models/sgmse/net.py:12-477,
- * modules/resampling.py:8-61). groupnorm: nn.GroupNorm on x + add_bc[b][c] (nullable; the
- * noise-embedding term of UNetBlock) with optional SiLU; softmax_rows: attention weights;
+ * modules/resampling.py:8-61). groupnorm_fold: nn.GroupNorm on x + add_bc[b][c] (nullable; the
+ * noise-embedding term of UNetBlock) reduced to a per-(item, channel) affine scale / shift
+ * (B, C), optionally followed by the ADM modulation (1 + adm_scale)*norm + adm_shift
+ * (net.py:405-407); scratch: brv_groupnorm_scratch_bytes(), ZERO on entry and left zero on
+ * exit (clear it once after allocation, then reuse it call after call on one stream).
+ * affine_act applies it
+ * (y = act(scale*x + shift)); brv_conv2d_mfma_forward can apply it on load instead.
+ * softmax_rows: attention weights;
  * fir_resample2d: Resample.forward on `planes` = B*C images (up: transposed, kernel*gain);
  * axpby: alpha*a + beta*b; fourier_features: GaussianFourierProjection. */
-int brv_groupnorm_forward(const float* x, const float* add_bc, const float* gamma,
-                          const float* beta, float* y, int64_t B, int64_t C, int64_t HW,
-                          int64_t groups, float eps, int act_silu, brv_stream_t stream);
+int64_t brv_groupnorm_scratch_bytes(int64_t B, int64_t groups);
+int brv_groupnorm_fold(const float* x, const float* add_bc, const float* gamma, const float* beta,
+                       const float* adm_scale, const float* adm_shift, void* scratch, float* scale,
+                       float* shift, int64_t B, int64_t C, int64_t HW, int64_t groups, float eps,
+                       brv_stream_t stream);
+int brv_affine_act(const float* x, const float* scale_bc, const float* shift_bc, float* y,
+                   int64_t B, int64_t C, int64_t HW, int act_silu, brv_stream_t stream);
 int brv_silu(const float* x, float* y, int64_t n, brv_stream_t stream);
 int brv_softmax_rows(const float* x, float* y, int64_t rows, int64_t cols, brv_stream_t stream);
 int brv_fir_resample2d(const float* x, const float* kernel, float* y, int64_t planes, int64_t H,
@@ -278,6 +288,22 @@ int brv_axpby(const float* a, float alpha, const float* b, float beta, float* ou
               brv_stream_t stream);
 int brv_fourier_features(const float* x, const float* b, float* out, int64_t n, int64_t m,
                          brv_stream_t stream);
+
+/* Stride-1 "same" convolution (ksize 1 or 3) on the fp16 MFMA with fp32 accumulation -- the
+ * precision class of the reference's fp16 autocast inference (models/sgmse/sgmse.py:190-193)
+ * -- for the convolutions of UNetBlock / AttentionBlock (net.py:352-452). x / y fp32 NCHW
+ * with batch strides; wp: weights (Cout, Cin, k, k) packed once by brv_conv2d_pack_f16 into
+ * brv_conv2d_packed_size() halves. Fused on the way in (nullable): in_scale[b][ci]*x +
+ * in_shift[b][ci] then SiLU if in_silu = a folded GroupNorm, padding stays zero; on the way out:
+ * y = out_scale*(conv + bias + res), res (nullable) laid out like y. */
+int64_t brv_conv2d_packed_size(int64_t Cout, int64_t Cin, int64_t ksize);
+int brv_conv2d_pack_f16(const float* w, void* wp, int64_t Cout, int64_t Cin, int64_t ksize,
+                        brv_stream_t stream);
+int brv_conv2d_mfma_forward(const float* x, const void* wp, const float* bias, const float* res,
+                            const float* in_scale, const float* in_shift, int in_silu, float* y,
+                            int64_t B, int64_t Cin, int64_t H, int64_t W, int64_t Cout,
+                            int64_t ksize, int64_t x_batch_stride, int64_t y_batch_stride,
+                            float out_scale, brv_stream_t stream);
 
 /* ---- pieces of MultiResYuLoss (criterion.py:135-226) ----------------------------
  * brv_apply_mask: out = x with samples >= lengths[b] zeroed (apply_mask, :229-234),

@@ -840,6 +840,22 @@ def test_sgmse_building_blocks_match_torch():
     ang = 2*np.pi*tt.outer(fp.b)
     assert torch.allclose(fp.to(dev)(tt.to(dev)).cpu(), torch.cat([ang.sin(), ang.cos()], -1),
                           atol=2e-5)
+    # MFMA convolution (fp16 operands, fp32 accumulation) with every fusion, ragged sizes
+    from brever_amd.models.sgmse import hip_autocast
+    for (ci, co, k, H, W) in ((40, 72, 3, 13, 37), (64, 130, 1, 9, 33), (4, 2, 3, 5, 6),
+                              (96, 64, 3, 16, 64)):
+        conv = torch.nn.Conv2d(ci, co, k, 1, k//2)
+        gn2 = M.GroupNorm(ci)
+        xx = torch.randn(2, ci, H, W, generator=g)
+        ee = torch.randn(2, ci, generator=g)
+        rr = torch.randn(2, co, H, W, generator=g)
+        ref = 0.7*(conv(F.silu(gn2(xx + ee[:, :, None, None]))) + rr).detach()
+        conv, gn2 = conv.to(dev), gn2.to(dev)
+        for amp in (False, True):
+            with hip_autocast(amp):
+                got = M._conv(xx.to(dev), conv, fold=M._gn_fold(xx.to(dev), gn2, add=ee.to(dev)),
+                              silu=True, res=rr.to(dev), out_scale=0.7)
+            assert rel(got, ref) <= (2e-3 if amp else 1e-5), (ci, co, k, amp, rel(got, ref))
     a = torch.randn(5, 3, dtype=torch.complex64, generator=g)
     b = torch.randn(5, 3, generator=g)
     assert rel(torch.view_as_real(M._axpby(a.to(dev), 0.3, b.to(dev), -1.7)),
@@ -877,6 +893,10 @@ def test_sgmse_matches_reference(golden_dir, tag):
     assert rel(out, gold) <= 5e-4, rel(out, gold)
     with pytest.raises(NotImplementedError):
         model.loss(torch.zeros(1, 2, 32, 8, dtype=torch.complex64, device=dev), None, False)
+    # the same sampling run with use_amp (fp16 MFMA convolutions): 60 chained evaluations
+    it = iter(draws)
+    out16 = model.enhance(torch.from_numpy(g[f'{tag}_wav']).to(dev), use_amp=True)
+    assert rel(out16, gold) <= 2e-2, rel(out16, gold)
 
 
 @pytest.mark.gpu
@@ -901,3 +921,10 @@ def test_sgmse_default_architecture_denoiser():
     model = model.to(dev).eval()
     got = model(x.to(dev), y.to(dev), model.sde.sigma(t), t)
     assert rel(torch.view_as_real(got), torch.view_as_real(want)) <= 2e-4
+    # use_amp: convolutions on the fp16 MFMA (fp32 accumulation and activations), group norms
+    # folded into their load path -- the precision class of the reference's fp16 autocast
+    from brever_amd.models.sgmse import hip_autocast
+    with hip_autocast(True):
+        got16 = model(x.to(dev), y.to(dev), model.sde.sigma(t), t)
+    err = rel(torch.view_as_real(got16), torch.view_as_real(want))
+    assert err <= 5e-3, err
