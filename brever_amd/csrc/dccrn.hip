@@ -251,6 +251,80 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* dy, float
   if (threadIdx.x == 0) db[c] = accumulate ? db[c] + sign*(float)acc : sign*(float)acc;
 }
 
+// ---- convolution as GEMM: column matrices --------------------------------------------------
+// col[b][(c*kh + i)*kw + j][ho*Wo + wo] = x[b][c][ho*sh - ph + i][wo*sw - pw + j] (0 outside)
+__global__ __launch_bounds__(256) void im2col_kernel(const float* x, float* col, ConvGeom g,
+                                                     long long total) {
+  const long long HoWo = (long long)g.Ho*g.Wo;
+  GRID_STRIDE(idx, total) {
+    const long long pix = idx % HoWo;
+    long long r = idx / HoWo;
+    const int j = (int)(r % g.kw); r /= g.kw;
+    const int i = (int)(r % g.kh); r /= g.kh;
+    const int c = (int)(r % g.Cin);
+    const int b = (int)(r / g.Cin);
+    const int wo = (int)(pix % g.Wo), ho = (int)(pix / g.Wo);
+    const int hi = ho*g.sh - g.ph + i, wi = wo*g.sw - g.pw + j;
+    float v = 0.f;
+    if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
+      v = x[(long long)b*g.x_bs + ((long long)c*g.H + hi)*g.W + wi];
+    col[idx] = v;
+  }
+}
+// the adjoint: y[b][c][h][w] = bias[c] + sum over the column entries that im2col filled from it
+// (g.H x g.W is the image, g.Ho x g.Wo the column grid)
+__global__ __launch_bounds__(256) void col2im_kernel(const float* col, const float* bias, float* y,
+                                                     ConvGeom g, long long total) {
+  const long long HoWo = (long long)g.Ho*g.Wo;
+  GRID_STRIDE(idx, total) {
+    const int w = (int)(idx % g.W);
+    long long r = idx / g.W;
+    const int h = (int)(r % g.H); r /= g.H;
+    const int c = (int)(r % g.Cin);
+    const int b = (int)(r / g.Cin);
+    float acc = bias ? bias[c] : 0.f;
+    const float* cb = col + ((long long)b*g.Cin + c)*g.kh*g.kw*HoWo;
+    for (int i = 0; i < g.kh; ++i) {
+      const int hn = h + g.ph - i;
+      if (hn < 0 || hn % g.sh) continue;
+      const int ho = hn/g.sh;
+      if (ho >= g.Ho) continue;
+      for (int j = 0; j < g.kw; ++j) {
+        const int wn = w + g.pw - j;
+        if (wn < 0 || wn % g.sw) continue;
+        const int wo = wn/g.sw;
+        if (wo >= g.Wo) continue;
+        acc += cb[(long long)(i*g.kw + j)*HoWo + (long long)ho*g.Wo + wo];
+      }
+    }
+    y[(long long)b*g.y_bs + ((long long)c*g.H + h)*g.W + w] = acc;
+  }
+}
+// complex weight as one real matrix: wc (2R x 2C) = [[wr, -s*wi], [s*wi, wr]], and its adjoint
+__global__ __launch_bounds__(256) void cweight_pack_kernel(const float* wr, const float* wi, float* wc,
+                                                           int R, int C, float s) {
+  GRID_STRIDE(idx, (long long)4*R*C) {
+    const int col = (int)(idx % (2*C)), row = (int)(idx / (2*C));
+    const int r = row % R, c = col % C;
+    const bool lower = row >= R, right = col >= C;
+    float v;
+    if (lower == right) v = wr[(long long)r*C + c];
+    else v = (right ? -s : s)*wi[(long long)r*C + c];
+    wc[idx] = v;
+  }
+}
+__global__ __launch_bounds__(256) void cweight_unpack_kernel(const float* dwc, float* dwr, float* dwi,
+                                                             int R, int C, float s) {
+  GRID_STRIDE(idx, (long long)R*C) {
+    const int c = (int)(idx % C), r = (int)(idx / C);
+    const long long ld = 2*C;
+    const float d00 = dwc[(long long)r*ld + c], d01 = dwc[(long long)r*ld + C + c];
+    const float d10 = dwc[(long long)(R + r)*ld + c], d11 = dwc[(long long)(R + r)*ld + C + c];
+    dwr[idx] = d00 + d11;
+    dwi[idx] = s*(d10 - d01);
+  }
+}
+
 // BatchNorm2d (+ optional scalar PReLU after it) backward, training mode.
 // pass 1 per channel: dpre = dy*prelu'(u), u = xh*gamma + beta; sums of dpre and dpre*xh;
 //                     slope gradient sum of dy*u over u < 0
@@ -534,6 +608,51 @@ int brv_istft_env_divide(const float* dy, const float* window, float* out, int64
   hipLaunchKernelGGL(env_divide_kernel, flat_grid(rows*length), dim3(256), 0, (hipStream_t)stream,
                      dy, window, out, (int)rows, (int)length, (int)frame_length, (int)hop_length,
                      (int)frames);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_im2col(const float* x, float* col, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
+               int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t Ho, int64_t Wo,
+               brv_stream_t stream) {
+  if (B < 1 || C < 1 || Ho < 1 || Wo < 1) return -1;
+  ConvGeom g;
+  g.B = (int)B; g.Cin = (int)C; g.H = (int)H; g.W = (int)W; g.Cout = 0;
+  g.kh = (int)kh; g.kw = (int)kw; g.sh = (int)sh; g.sw = (int)sw; g.ph = (int)ph; g.pw = (int)pw;
+  g.Ho = (int)Ho; g.Wo = (int)Wo; g.x_bs = C*H*W; g.y_bs = 0;
+  const long long total = B*C*kh*kw*Ho*Wo;
+  hipLaunchKernelGGL(im2col_kernel, flat_grid(total), dim3(256), 0, (hipStream_t)stream, x, col, g,
+                     total);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+int brv_col2im(const float* col, const float* bias, float* y, int64_t B, int64_t C, int64_t H,
+               int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+               int64_t Ho, int64_t Wo, brv_stream_t stream) {
+  if (B < 1 || C < 1 || H < 1 || W < 1) return -1;
+  ConvGeom g;
+  g.B = (int)B; g.Cin = (int)C; g.H = (int)H; g.W = (int)W; g.Cout = 0;
+  g.kh = (int)kh; g.kw = (int)kw; g.sh = (int)sh; g.sw = (int)sw; g.ph = (int)ph; g.pw = (int)pw;
+  g.Ho = (int)Ho; g.Wo = (int)Wo; g.x_bs = 0; g.y_bs = C*H*W;
+  const long long total = B*C*H*W;
+  hipLaunchKernelGGL(col2im_kernel, flat_grid(total), dim3(256), 0, (hipStream_t)stream, col, bias,
+                     y, g, total);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+int brv_complex_weight_pack(const float* wr, const float* wi, float* wc, int64_t R, int64_t C,
+                            float sign, brv_stream_t stream) {
+  if (R < 1 || C < 1) return -1;
+  hipLaunchKernelGGL(cweight_pack_kernel, flat_grid(4*R*C), dim3(256), 0, (hipStream_t)stream, wr,
+                     wi, wc, (int)R, (int)C, sign);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+int brv_complex_weight_unpack(const float* dwc, float* dwr, float* dwi, int64_t R, int64_t C,
+                              float sign, brv_stream_t stream) {
+  if (R < 1 || C < 1) return -1;
+  hipLaunchKernelGGL(cweight_unpack_kernel, flat_grid(R*C), dim3(256), 0, (hipStream_t)stream, dwc,
+                     dwr, dwi, (int)R, (int)C, sign);
   DC_OK(hipGetLastError());
   return 0;
 }

@@ -8,11 +8,11 @@ arithmetic (STFT, the four real convolutions of every complex layer, batch norm 
 complex LSTM, the mask application, iSTFT) runs in ``libbrever_hip.so``.
 
 Forward and backward are ``torch.autograd.Function`` pieces whose two sides call the HIP
-kernels (``brv_conv2d_* / brv_conv_transpose2d_forward / brv_conv2d_wgrad``,
+kernels (``brv_im2col / brv_col2im / brv_complex_weight_pack`` around ``brv_gemm_f32``,
 ``brv_batchnorm2d_*``, ``brv_lstm_recurrent_*``, ``brv_gemm_f32``, ``brv_dccrn_apply_mask*``,
 ``brv_stft_forward`` / ``brv_istft_backward`` and its adjoint); torch only concatenates, slices
-and transposes between them. fp32 throughout: correctness-first direct convolutions, not yet
-tuned (the reference's autocast has no counterpart here, ``use_amp`` is ignored).
+and transposes between them. fp32 throughout (exact-fp32 MFMA matrix products; the reference's autocast has no counterpart
+here, ``use_amp`` is ignored).
 """
 import torch
 import torch.nn as nn
@@ -116,97 +116,115 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, t
         trans_a, trans_b, 1, 0, 0, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_f32')
 
 
-def _conv(x, w, bias, y, geom, transpose, acc, sign, out_pad=(0, 0)):
-    """One real (transposed) convolution: y (+)= sign*(op(x, w) + bias); x, y contiguous."""
-    lib = hip.lib()
+def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, trans_b=0,
+          kbatch=1, a_kbs=0, b_kbs=0, bias=None):
+    hip.check(hip.lib().brv_gemm_f32(
+        hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
+        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_f32')
+
+
+def _im2col(x, geom, grid):
     (kh, kw), (sh, sw), (ph, pw) = geom
-    B, Cin, H, W = x.shape
-    Cout = y.shape[1]
-    args = [hip.ptr(x), hip.ptr(w), hip.ptr(bias), hip.ptr(y), B, Cin, H, W, Cout, kh, kw, sh, sw,
-            ph, pw]
-    if transpose:
-        hip.check(lib.brv_conv_transpose2d_forward(*args, out_pad[0], out_pad[1], Cin*H*W,
-                                                   y[0].numel(), acc, sign, hip.stream()),
-                  'brv_conv_transpose2d_forward')
-    else:
-        hip.check(lib.brv_conv2d_forward(*args, Cin*H*W, y[0].numel(), acc, sign, hip.stream()),
-                  'brv_conv2d_forward')
+    B, C, H, W = x.shape
+    col = torch.empty(B, C*kh*kw, grid[0]*grid[1], dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().brv_im2col(hip.ptr(x), hip.ptr(col), B, C, H, W, kh, kw, sh, sw, ph, pw,
+                                   grid[0], grid[1], hip.stream()), 'brv_im2col')
+    return col
+
+
+def _col2im(col, bias, C, image, geom, grid):
+    (kh, kw), (sh, sw), (ph, pw) = geom
+    B = col.shape[0]
+    y = torch.empty(B, C, image[0], image[1], dtype=torch.float32, device=col.device)
+    hip.check(hip.lib().brv_col2im(hip.ptr(col), hip.ptr(bias), hip.ptr(y), B, C, image[0], image[1],
+                                   kh, kw, sh, sw, ph, pw, grid[0], grid[1], hip.stream()),
+              'brv_col2im')
+    return y
+
+
+def _combine(a, b, sign):
+    out = torch.empty_like(a)
+    hip.check(hip.lib().brv_combine(hip.ptr(a), hip.ptr(b), hip.ptr(out), a.numel(), float(sign),
+                                    hip.stream()), 'brv_combine')
+    return out
 
 
 class _ComplexConvFunction(torch.autograd.Function):
     """ComplexWrapper(nn.Conv2d | nn.ConvTranspose2d) (dccrn.py:221-231) on (B, 2*Cin, H, W)
-    with the real half first: real = M_r(x_r) - M_i(x_i), imag = M_r(x_i) + M_i(x_r)."""
+    with the real half first: real = M_r(x_r) - M_i(x_i), imag = M_r(x_i) + M_i(x_r).
+
+    The four real convolutions are one matrix product per batch item on the exact-fp32 MFMA:
+    the complex weight becomes the real matrix [[Wr, -Wi], [Wi, Wr]] (``brv_complex_weight_pack``)
+    applied to the column matrix of the whole (real | imaginary) input (``brv_im2col``); the
+    transposed convolution applies the transposed matrix and scatters back (``brv_col2im``).
+    The backward pass is the same three pieces with the roles swapped; the column matrix is
+    rebuilt there instead of being kept."""
 
     @staticmethod
     def forward(ctx, x, wr, br, wi, bi, geom4, transpose):
         (kh, kw), (sh, sw), (ph, pw), (oph, opw) = geom4
         geom = geom4[:3]
+        lib = hip.lib()
+        x = x.contiguous()
         B, C2, H, W = x.shape
-        xr, xi = (t.contiguous() for t in x.chunk(2, dim=1))
+        Cin = C2//2
+        R = wr.shape[0]
+        Cw = wr[0].numel()
+        wc = torch.empty(2*R, 2*Cw, dtype=torch.float32, device=x.device)
+        hip.check(lib.brv_complex_weight_pack(hip.ptr(wr.contiguous()), hip.ptr(wi.contiguous()),
+                                              hip.ptr(wc), R, Cw, -1.0 if transpose else 1.0,
+                                              hip.stream()), 'brv_complex_weight_pack')
+        bias = torch.cat([_combine(br, bi, -1.0), _combine(br, bi, 1.0)])
         if transpose:
             Cout = wr.shape[1]
             Ho, Wo = (H - 1)*sh - 2*ph + kh + oph, (W - 1)*sw - 2*pw + kw + opw
+            col = torch.empty(B, 2*Cw, H*W, dtype=torch.float32, device=x.device)
+            _gemm(wc, x, col, B, 2*Cw, H*W, 2*Cin, 2*Cw, H*W, H*W, 0, 2*Cin*H*W, 2*Cw*H*W,
+                  trans_a=1)
+            y = _col2im(col, bias, 2*Cout, (Ho, Wo), geom, (H, W))
         else:
-            Cout = wr.shape[0]
+            Cout = R
             Ho, Wo = (H + 2*ph - kh)//sh + 1, (W + 2*pw - kw)//sw + 1
-        yr = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
-        yi = torch.empty_like(yr)
-        op = (oph, opw)
-        _conv(xr, wr, br, yr, geom, transpose, 0, 1.0, op)
-        _conv(xi, wi, bi, yr, geom, transpose, 1, -1.0, op)
-        _conv(xi, wr, br, yi, geom, transpose, 0, 1.0, op)
-        _conv(xr, wi, bi, yi, geom, transpose, 1, 1.0, op)
-        ctx.save_for_backward(xr, xi, wr, wi)
-        ctx.cfg = (geom, transpose, (H, W), (Ho, Wo))
-        return torch.cat([yr, yi], dim=1)
+            col = _im2col(x, geom, (Ho, Wo))
+            y = torch.empty(B, 2*Cout, Ho, Wo, dtype=torch.float32, device=x.device)
+            _gemm(wc, col, y, B, 2*Cout, Ho*Wo, 2*Cw, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cw*Ho*Wo,
+                  2*Cout*Ho*Wo, bias=bias)
+        ctx.save_for_backward(x, wc)
+        ctx.cfg = (geom, transpose, (H, W), (Ho, Wo), Cin, Cout, R, Cw, wr.shape)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = hip.lib()
-        xr, xi, wr, wi = ctx.saved_tensors
-        geom, transpose, (H, W), (Ho, Wo) = ctx.cfg
-        (kh, kw), (sh, sw), (ph, pw) = geom
-        dr, di = (t.contiguous() for t in dy.chunk(2, dim=1))
-        B, Cin = xr.shape[:2]
-        Cout = dr.shape[1]
-        # data gradients: the opposite operation with the same weights, no bias
-        dxr, dxi = torch.empty_like(xr), torch.empty_like(xi)
+        x, wc = ctx.saved_tensors
+        geom, transpose, (H, W), (Ho, Wo), Cin, Cout, R, Cw, wshape = ctx.cfg
+        dy = dy.contiguous()
+        B = x.shape[0]
+        dwc = torch.empty_like(wc)
         if transpose:
-            back = dict(transpose=False)
+            dcol = _im2col(dy, geom, (H, W))                       # (B, 2*Cw, H*W)
+            dx = torch.empty_like(x)
+            _gemm(wc, dcol, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, H*W, 0, 2*Cw*H*W, 2*Cin*H*W)
+            _gemm(x, dcol, dwc, 1, 2*Cin, 2*Cw, H*W, H*W, H*W, 2*Cw, 0, 0, 0, trans_b=1,
+                  kbatch=B, a_kbs=2*Cin*H*W, b_kbs=2*Cw*H*W)
         else:
-            back = dict(transpose=True,
-                        out_pad=(H - ((Ho - 1)*sh - 2*ph + kh), W - ((Wo - 1)*sw - 2*pw + kw)))
-        _conv(dr, wr, None, dxr, geom, acc=0, sign=1.0, **back)       # dx_r = Mr^T dr + Mi^T di
-        _conv(di, wi, None, dxr, geom, acc=1, sign=1.0, **back)
-        _conv(di, wr, None, dxi, geom, acc=0, sign=1.0, **back)       # dx_i = Mr^T di - Mi^T dr
-        _conv(dr, wi, None, dxi, geom, acc=1, sign=-1.0, **back)
-        dwr, dwi = torch.empty_like(wr), torch.empty_like(wi)
-        dbr = torch.empty(Cout, dtype=torch.float32, device=dy.device)
-        dbi = torch.empty_like(dbr)
-
-        def wgrad(inp, grad, dw, db, acc, sign):
-            if transpose:      # weight (Cin, Cout, kh, kw): roles of input and gradient swap
-                hip.check(lib.brv_conv2d_wgrad(
-                    hip.ptr(grad), hip.ptr(inp), hip.ptr(dw), None, B, Cout, Ho, Wo, Cin, H, W,
-                    kh, kw, sh, sw, ph, pw, Cout*Ho*Wo, Cin*H*W, acc, sign, hip.stream()),
-                    'brv_conv2d_wgrad')
-            else:
-                hip.check(lib.brv_conv2d_wgrad(
-                    hip.ptr(inp), hip.ptr(grad), hip.ptr(dw), None, B, Cin, H, W, Cout, Ho, Wo,
-                    kh, kw, sh, sw, ph, pw, Cin*H*W, Cout*Ho*Wo, acc, sign, hip.stream()),
-                    'brv_conv2d_wgrad')
-        wgrad(xr, dr, dwr, dbr, 0, 1.0)            # dWr = x_r*dr + x_i*di
-        wgrad(xi, di, dwr, dbr, 1, 1.0)
-        wgrad(xr, di, dwi, dbi, 0, 1.0)            # dWi = x_r*di - x_i*dr
-        wgrad(xi, dr, dwi, dbi, 1, -1.0)
-        # bias gradients: channel sums of the output gradient
-        sr, si = torch.empty_like(dbr), torch.empty_like(dbr)
-        for src, dst in ((dr, sr), (di, si)):
-            hip.check(lib.brv_row_sum(hip.ptr(src), hip.ptr(dst), B, Cout, Ho*Wo, hip.stream()),
-                      'brv_row_sum')
-        dbr = _CombineFunction.apply(sr, si, 1.0)
-        dbi = _CombineFunction.apply(si, sr, -1.0)
-        return torch.cat([dxr, dxi], dim=1), dwr, dbr, dwi, dbi, None, None
+            col = _im2col(x, geom, (Ho, Wo))                       # (B, 2*Cw, Ho*Wo)
+            _gemm(dy, col, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, trans_b=1,
+                  kbatch=B, a_kbs=2*Cout*Ho*Wo, b_kbs=2*Cw*Ho*Wo)
+            _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,
+                  2*Cw*Ho*Wo, trans_a=1)                           # the buffer now holds dcol
+            dx = _col2im(col, None, 2*Cin, (H, W), geom, (Ho, Wo))
+        dwr = torch.empty(wshape, dtype=torch.float32, device=dy.device)
+        dwi = torch.empty_like(dwr)
+        hip.check(lib.brv_complex_weight_unpack(hip.ptr(dwc), hip.ptr(dwr), hip.ptr(dwi), R, Cw,
+                                                -1.0 if transpose else 1.0, hip.stream()),
+                  'brv_complex_weight_unpack')
+        # bias gradients: channel sums of the output gradient, bias = [br - bi | br + bi]
+        sums = torch.empty(2*Cout, dtype=torch.float32, device=dy.device)
+        hip.check(lib.brv_row_sum(hip.ptr(dy), hip.ptr(sums), B, 2*Cout, Ho*Wo, hip.stream()),
+                  'brv_row_sum')
+        sr, si = sums[:Cout].contiguous(), sums[Cout:].contiguous()
+        return dx, dwr, _combine(sr, si, 1.0), dwi, _combine(si, sr, -1.0), None, None
 
 
 class _CombineFunction(torch.autograd.Function):

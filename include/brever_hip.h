@@ -261,6 +261,23 @@ int brv_combine(const float* a, const float* b, float* out, int64_t n, float sig
 int brv_dccrn_apply_mask(const float* xr, const float* xi, const float* mr, const float* mi,
                          float* out, int64_t n, brv_stream_t stream);
 
+/* Convolution as matrix products (ComplexWrapper(nn.Conv2d / nn.ConvTranspose2d),
+ * models/dccrn/dccrn.py:221-231): im2col writes col (B, C*kh*kw, Ho*Wo) from x (B, C, H, W);
+ * col2im is its adjoint (+ per-channel bias) onto y (B, C, H, W) from a column grid Ho x Wo;
+ * the four real convolutions of a complex one are ONE brv_gemm_f32 with the weight
+ * wc (2R x 2C) = [[wr, -sign*wi], [sign*wi, wr]] built by complex_weight_pack from wr, wi
+ * (R x C each); complex_weight_unpack is the adjoint (dwr, dwi from dwc). */
+int brv_im2col(const float* x, float* col, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
+               int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t Ho, int64_t Wo,
+               brv_stream_t stream);
+int brv_col2im(const float* col, const float* bias, float* y, int64_t B, int64_t C, int64_t H,
+               int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+               int64_t Ho, int64_t Wo, brv_stream_t stream);
+int brv_complex_weight_pack(const float* wr, const float* wi, float* wc, int64_t R, int64_t C,
+                            float sign, brv_stream_t stream);
+int brv_complex_weight_unpack(const float* dwc, float* dwr, float* dwi, int64_t R, int64_t C,
+                              float sign, brv_stream_t stream);
+
 /* ---- SGMSE+ score network building blocks, forward values (models/sgmse/net.py:12-477,
  * modules/resampling.py:8-61). groupnorm_fold: nn.GroupNorm on x + add_bc[b][c] (nullable; the
  * noise-embedding term of UNetBlock) reduced to a per-(item, channel) affine scale / shift

@@ -1,0 +1,77 @@
+"""Throughput of the widened SURVEY.md section-8 rows on one GPU (BASELINE.json configs[0],
+[3], [4]); bench.py stays the Conv-TasNet headline. One JSON line per row.
+
+    python tools/bench_rows.py [--rows ffnn,dccrn,sgmse]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def timed(fn, warmup, steps):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0)/steps
+
+
+def train_row(arch, batch, seconds, steps, use_amp):
+    from brever_amd.models import ModelRegistry
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    model = ModelRegistry.get(arch)().to(dev)
+    model.train()
+    L = int(seconds*16000)
+    wav = 0.1*torch.randn(batch, 2, 2, L, device=dev)         # (B, sources, channels, L)
+    items = [model.transform(w) for w in wav]
+    x = torch.stack(items) if not isinstance(items[0], (tuple, list)) else None
+    if x is None:
+        x = tuple(torch.stack([it[i] for it in items]) for i in range(len(items[0])))
+    lengths = torch.full((batch,), (x[0] if isinstance(x, tuple) else x).shape[-1], device=dev)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    dt = timed(lambda: model.train_step(x, lengths, use_amp, scaler), 3, steps)
+    return {'row': f'{arch} train', 'utt_per_s': batch/dt, 'ms_per_step': dt*1e3, 'batch': batch,
+            'seconds': seconds}
+
+
+def sgmse_row(seconds, steps):
+    from brever_amd.models import ModelRegistry
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    model = ModelRegistry.get('sgmsep')(solver_num_steps=steps).to(dev).eval()
+    wav = 0.1*torch.randn(1, 2, int(seconds*16000), device=dev)
+    out = {}
+    for amp in (True, False):
+        model.enhance(wav[..., :16000], use_amp=amp)
+        dt = timed(lambda: model.enhance(wav, use_amp=amp), 0, 1)
+        out['fp16_mfma' if amp else 'fp32'] = {'s_per_utt': dt, 'ms_per_nfe': dt/(2*steps)*1e3,
+                                               'rtf': dt/seconds}
+    return {'row': f'sgmsep enhance, {steps}-step PC sampler ({2*steps} network evaluations)',
+            'seconds': seconds, **out}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rows', default='ffnn,dccrn,sgmse')
+    args = ap.parse_args()
+    rows = args.rows.split(',')
+    if 'ffnn' in rows:
+        print(json.dumps(train_row('ffnn', 32, 2.0, 20, False)), flush=True)
+    if 'dccrn' in rows:
+        print(json.dumps(train_row('dccrn', 16, 4.0, 5, False)), flush=True)
+    if 'sgmse' in rows:
+        print(json.dumps(sgmse_row(4.0, 30)), flush=True)
+
+
+if __name__ == '__main__':
+    main()
