@@ -144,6 +144,106 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const G32 p) {
   }
 }
 
+// ---- general fp32 GEMM (brv_gemm_f32): 128 x 128 tile, 4 waves of 2 x 2 MFMA accumulators ----
+// D[z] (M x N) (+)= sum over (kb, k) of op(A)[m][k] * op(B)[k][n] (+ row_bias[m]). The k-tiles of
+// all kbatch operand pairs form one reduction stream; with ksplit > 1 it is divided over
+// workgroups that add their partial tiles into a zeroed D with fp32 atomics (weight-gradient
+// shapes: small M x N, very long reduction). Operands are staged k-major in LDS whatever
+// their storage order, through registers so that the next tile's loads fly during the MFMAs.
+constexpr int BM2 = 128, BN2 = 128, BK2 = 16, LD2 = BM2 + 4;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const G32 p, int ksplit) {
+  __shared__ float As[BK2][LD2];
+  __shared__ float Bs[BK2][LD2];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y*BM2, n0 = blockIdx.x*BN2;
+  const int b = blockIdx.z / ksplit, split = blockIdx.z % ksplit;
+  const int nkb = p.kbatch > 1 ? p.kbatch : 1;
+  const int ktiles = (p.K + BK2 - 1)/BK2;
+  const long long total = (long long)nkb*ktiles;
+  const long long per = (total + ksplit - 1)/ksplit;
+  const long long t_lo = split*per, t_hi = t_lo + per < total ? t_lo + per : total;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging maps: 128 x 16 elements per operand, 8 per thread; the fast thread index runs along
+  // the operand's contiguous storage direction
+  float ra[8], rb[8];
+  auto fetch = [&](long long t) {
+    const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BK2;
+    const float* A = p.A + (long long)b*p.a_bs + (long long)kb*p.a_kbs;
+    const float* B = p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int e = tid + r*256;
+      int i, k;
+      if (TA) { i = e % BM2; k = e / BM2; } else { k = e % BK2; i = e / BK2; }
+      const int m = m0 + i, kk = k0 + k;
+      ra[r] = (m < p.M && kk < p.K) ? (TA ? A[(long long)kk*p.lda + m] : A[(long long)m*p.lda + kk]) : 0.f;
+      int j, k2;
+      if (TB) { k2 = e % BK2; j = e / BK2; } else { j = e % BN2; k2 = e / BN2; }
+      const int n = n0 + j, kk2 = k0 + k2;
+      rb[r] = (n < p.N && kk2 < p.K) ? (TB ? B[(long long)n*p.ldb + kk2] : B[(long long)kk2*p.ldb + n]) : 0.f;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int e = tid + r*256;
+      if (TA) As[e / BM2][e % BM2] = ra[r]; else As[e % BK2][e / BK2] = ra[r];
+      if (TB) Bs[e % BK2][e / BK2] = rb[r]; else Bs[e / BN2][e % BN2] = rb[r];
+    }
+  };
+  if (t_lo < t_hi) fetch(t_lo);
+  for (long long t = t_lo; t < t_hi; ++t) {
+    __syncthreads();
+    stash();
+    __syncthreads();
+    if (t + 1 < t_hi) fetch(t + 1);
+#pragma unroll
+    for (int s = 0; s < BK2/2; ++s) {
+      const int kk = 2*s + (lane >> 5), c = lane & 31;
+      const float a0 = As[kk][64*wm + c], a1 = As[kk][64*wm + 32 + c];
+      const float b0 = Bs[kk][64*wn + c], b1 = Bs[kk][64*wn + 32 + c];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  float* D = p.D + (long long)b*p.d_bs;
+#pragma unroll
+  for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj) {
+      const int col = n0 + 64*wn + 32*fj + (lane & 31);
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + 64*wm + 32*fi + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
+        if (row >= p.M) continue;
+        float v = acc[fi][fj][i];
+        float* d = D + (long long)row*p.ldd + col;
+        if (ksplit > 1) {
+          if (split == 0 && p.row_bias) v += p.row_bias[row];
+          atomicAdd(d, v);
+        } else {
+          if (p.row_bias) v += p.row_bias[row];
+          if (p.accumulate) v += *d;
+          *d = v;
+        }
+      }
+    }
+}
+
 // Windowed overlap-add with window-envelope normalisation (torch.istft, center=True):
 //   y[q] = sum_t frames[t][q + n/2 - t*hop] / sum_t w^2[q + n/2 - t*hop],  q < hop*(F-1)
 struct OlaParams {
@@ -326,10 +426,36 @@ int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_
   p.kbatch = (int)kbatch; p.a_kbs = a_kbatch_stride; p.b_kbs = b_kbatch_stride;
   p.row_bias = row_bias; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
-  if (trans_a && trans_b) return launch_g32<GA_T, GB_WT, GS_PLAIN>(p, (int)batch, st);
-  if (trans_a) return launch_g32<GA_T, GB_PLAIN, GS_PLAIN>(p, (int)batch, st);
-  if (trans_b) return launch_g32<GA_PLAIN, GB_WT, GS_PLAIN>(p, (int)batch, st);
-  return launch_g32<GA_PLAIN, GB_PLAIN, GS_PLAIN>(p, (int)batch, st);
+  // reduction split: fill the chip when the output has few tiles and the reduction is long
+  const long long tiles = ((M + BM2 - 1)/BM2)*((N + BN2 - 1)/BN2)*batch;
+  const long long red = (kbatch > 1 ? kbatch : 1)*((K + BK2 - 1)/BK2);
+  long long ksplit = 1;
+  if (tiles < 128 && red >= 16) {
+    ksplit = 512/tiles;
+    if (ksplit > red/4) ksplit = red/4;
+    if (ksplit < 1) ksplit = 1;
+  }
+  if (ksplit > 1 && !accumulate) {
+    if (ldd == N) {
+      for (int64_t z = 0; z < batch; ++z)
+        if (hipMemsetAsync(d + z*d_batch_stride, 0, (size_t)M*N*4, st) != hipSuccess) return -2;
+    } else {
+      for (int64_t z = 0; z < batch; ++z)
+        if (hipMemset2DAsync(d + z*d_batch_stride, (size_t)ldd*4, 0, (size_t)N*4, (size_t)M, st)
+            != hipSuccess) return -2;
+    }
+  }
+  const dim3 grid((unsigned)((N + BN2 - 1)/BN2), (unsigned)((M + BM2 - 1)/BM2),
+                  (unsigned)(batch*ksplit));
+  if (trans_a && trans_b)
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p, (int)ksplit);
+  else if (trans_a)
+    hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, p, (int)ksplit);
+  else if (trans_b)
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p, (int)ksplit);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p, (int)ksplit);
+  return (int)hipGetLastError();
 }
 
 int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,
