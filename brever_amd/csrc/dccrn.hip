@@ -185,6 +185,105 @@ __global__ __launch_bounds__(256) void lstm_recurrent_kernel(const float* gates_
   }
 }
 
+// The same recurrence with the recurrent weights resident in REGISTERS (H <= 128, H % 16 == 0):
+// 4H threads, thread r keeps row r of W_hh (H floats) for all T steps, h lives in LDS and is
+// read as broadcast float4; the cell state stays in the register of the thread that owns the
+// unit. One step = one H-long dot product per thread + the gate math: the chain of T dependent
+// steps, not bandwidth, is what this kernel is bound by.
+constexpr int kLstmRegH = 128;
+__global__ __launch_bounds__(512) void lstm_fwd_reg_kernel(const float* gates_in, const float* w_hh,
+                                                           const float* bias, float* y, float* act,
+                                                           float* cs, int T, int H) {
+  __shared__ __attribute__((aligned(16))) float h[kLstmRegH];
+  __shared__ float gt[4*kLstmRegH];
+  const int b = blockIdx.x, r = threadIdx.x;           // blockDim.x == 4H
+  float w[kLstmRegH];
+#pragma unroll
+  for (int k = 0; k < kLstmRegH; ++k) w[k] = k < H ? w_hh[(long long)r*H + k] : 0.f;
+  const float br = bias ? bias[r] : 0.f;
+  if (r < kLstmRegH) h[r] = 0.f;
+  float c = 0.f;
+  const float* gi = gates_in + (long long)b*T*4*H + r;
+  float g_next = gi[0];
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    float acc = g_next + br;
+    if (t + 1 < T) g_next = gi[(long long)(t + 1)*4*H];
+#pragma unroll
+    for (int k = 0; k < kLstmRegH; k += 4) {
+      if (k < H) {
+        const float4 hv = *reinterpret_cast<const float4*>(h + k);
+        acc += w[k]*hv.x + w[k + 1]*hv.y + w[k + 2]*hv.z + w[k + 3]*hv.w;
+      }
+    }
+    gt[r] = acc;
+    __syncthreads();
+    if (r < H) {
+      const float ig = 1.f/(1.f + expf(-gt[r]));
+      const float fg = 1.f/(1.f + expf(-gt[H + r]));
+      const float gg = tanhf(gt[2*H + r]);
+      const float og = 1.f/(1.f + expf(-gt[3*H + r]));
+      c = fg*c + ig*gg;
+      const float hn = og*tanhf(c);
+      h[r] = hn;
+      y[((long long)b*T + t)*H + r] = hn;
+      if (act) {
+        float* a = act + ((long long)b*T + t)*4*H;
+        a[r] = ig; a[H + r] = fg; a[2*H + r] = gg; a[3*H + r] = og;
+        cs[((long long)b*T + t)*H + r] = c;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Backward through time with W_hh^T resident in registers: thread j owns hidden unit k = j % H
+// and the quarter q = j / H of the gate rows, i.e. W_hh[qH + i][k] for i < H; the four partial
+// sums of dh_{t-1}[k] meet in LDS.
+__global__ __launch_bounds__(512) void lstm_bwd_reg_kernel(const float* act, const float* cs,
+                                                           const float* w_hh, const float* dy,
+                                                           float* dgates, int T, int H) {
+  __shared__ __attribute__((aligned(16))) float dg[4*kLstmRegH];
+  __shared__ float part[4][kLstmRegH];
+  const int b = blockIdx.x, j = threadIdx.x;
+  const int k = j % H, q = j / H;
+  float w[kLstmRegH];
+#pragma unroll
+  for (int i = 0; i < kLstmRegH; ++i) w[i] = i < H ? w_hh[(long long)(q*H + i)*H + k] : 0.f;
+  part[q][k] = 0.f;
+  float dc = 0.f;
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    if (j < H) {
+      const float* a = act + ((long long)b*T + t)*4*H;
+      const float ig = a[j], fg = a[H + j], gg = a[2*H + j], og = a[3*H + j];
+      const float c = cs[((long long)b*T + t)*H + j];
+      const float cprev = t > 0 ? cs[((long long)b*T + t - 1)*H + j] : 0.f;
+      const float tc = tanhf(c);
+      const float dht = part[0][j] + part[1][j] + part[2][j] + part[3][j]
+                        + dy[((long long)b*T + t)*H + j];
+      const float dct = dc + dht*og*(1.f - tc*tc);
+      const float d0 = dct*gg*ig*(1.f - ig), d1 = dct*cprev*fg*(1.f - fg);
+      const float d2 = dct*ig*(1.f - gg*gg), d3 = dht*tc*og*(1.f - og);
+      dg[j] = d0; dg[H + j] = d1; dg[2*H + j] = d2; dg[3*H + j] = d3;
+      float* out = dgates + ((long long)b*T + t)*4*H;
+      out[j] = d0; out[H + j] = d1; out[2*H + j] = d2; out[3*H + j] = d3;
+      dc = dct*fg;
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLstmRegH; i += 4) {
+      if (i < H) {
+        const float4 v = *reinterpret_cast<const float4*>(dg + q*H + i);
+        acc += w[i]*v.x + w[i + 1]*v.y + w[i + 2]*v.z + w[i + 3]*v.w;
+      }
+    }
+    part[q][k] = acc;
+    __syncthreads();
+  }
+}
+
 // out = a - b  /  a + b  (the real / imaginary recombination of ComplexWrapper)
 __global__ __launch_bounds__(256) void combine_kernel(const float* a, const float* b, float* out,
                                                       long long n, float sign) {
@@ -519,6 +618,10 @@ int brv_lstm_recurrent_forward(const float* gates_in, const float* w_hh, const f
                                float* y, float* act, float* cs, int64_t B, int64_t T, int64_t H,
                                brv_stream_t stream) {
   if (B < 1 || T < 1 || H < 1) return -1;
+  if (H <= kLstmRegH && H % 16 == 0)
+    hipLaunchKernelGGL(lstm_fwd_reg_kernel, dim3((unsigned)B), dim3((unsigned)(4*H)), 0,
+                       (hipStream_t)stream, gates_in, w_hh, bias, y, act, cs, (int)T, (int)H);
+  else
   hipLaunchKernelGGL(lstm_recurrent_kernel, dim3((unsigned)B), dim3(256), (size_t)6*H*4,
                      (hipStream_t)stream, gates_in, w_hh, bias, y, act, cs, (int)T, (int)H);
   DC_OK(hipGetLastError());
@@ -585,6 +688,10 @@ int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* 
                                 const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
                                 brv_stream_t stream) {
   if (B < 1 || T < 1 || H < 1) return -1;
+  if (H <= kLstmRegH && H % 16 == 0)
+    hipLaunchKernelGGL(lstm_bwd_reg_kernel, dim3((unsigned)B), dim3((unsigned)(4*H)), 0,
+                       (hipStream_t)stream, act, cs, w_hh, dy, dgates, (int)T, (int)H);
+  else
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)6*H*4,
                      (hipStream_t)stream, act, cs, w_hh, dy, dgates, (int)T, (int)H);
   DC_OK(hipGetLastError());

@@ -110,13 +110,6 @@ class DCCRNMaskNet(_ParamOnly):
 
 
 def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, trans_b=0,
-          bias=None):
-    hip.check(hip.lib().brv_gemm_f32(
-        hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
-        trans_a, trans_b, 1, 0, 0, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_f32')
-
-
-def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, trans_b=0,
           kbatch=1, a_kbs=0, b_kbs=0, bias=None):
     hip.check(hip.lib().brv_gemm_f32(
         hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,

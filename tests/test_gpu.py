@@ -928,3 +928,29 @@ def test_sgmse_default_architecture_denoiser():
         got16 = model(x.to(dev), y.to(dev), model.sde.sigma(t), t)
     err = rel(torch.view_as_real(got16), torch.view_as_real(want))
     assert err <= 5e-3, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H', [32, 128, 24])
+def test_lstm_kernels_match_torch(H):
+    """The LSTM recurrence (register-resident weights for H <= 128 with H % 16 == 0, the generic
+    kernel otherwise) and its backward pass vs ``torch.nn.LSTM`` on the CPU: hidden states and
+    every gradient, fp32 (rel-L2 1e-5 / 1e-4)."""
+    from brever_amd.models.dccrn import _LSTMFunction
+    dev = _cuda()
+    torch.manual_seed(H)
+    B, T, I = 3, 37, 20
+    ref = torch.nn.LSTM(I, H, batch_first=True)
+    x = torch.randn(B, T, I, requires_grad=True)
+    gy = torch.randn(B, T, H)
+    y, _ = ref(x)
+    y.backward(gy)
+    params = [ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0]
+    xd = x.detach().to(dev).requires_grad_(True)
+    pd = [p.detach().to(dev).requires_grad_(True) for p in params]
+    yd = _LSTMFunction.apply(xd, *pd)
+    yd.backward(gy.to(dev))
+    assert rel(yd, y.detach()) <= 1e-5
+    assert rel(xd.grad, x.grad) <= 1e-4
+    for got, want in zip(pd, params):
+        assert rel(got.grad, want.grad) <= 1e-4, rel(got.grad, want.grad)
