@@ -99,15 +99,23 @@ __global__ __launch_bounds__(256) void conv_transpose2d_fwd_kernel(const float* 
 
 // BatchNorm2d statistics: one workgroup per channel (biased variance for the normalisation,
 // unbiased for the running estimate, as torch)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, int B, int C, long long HW,
-                                                       float* mean_out, float* invstd_out,
-                                                       float* running_mean, float* running_var,
-                                                       float eps, float momentum) {
+// Per-channel reductions over (B, HW) run as gridDim.y slices per channel whose fp64 partial
+// sums land in a scratch (C, slices, K) and are combined in a fixed order by a finishing
+// kernel: deterministic, and C = 16..512 channels alone would leave most of the chip idle.
+constexpr int kRedSlices = 64;
+__device__ __forceinline__ void slice_range(long long n, long long& lo, long long& hi) {
+  const long long per = (n + gridDim.y - 1)/gridDim.y;
+  lo = (long long)blockIdx.y*per;
+  hi = lo + per < n ? lo + per : n;
+}
+__global__ __launch_bounds__(256) void bn_stats_part_kernel(const float* x, int B, int C,
+                                                            long long HW, double* part) {
   __shared__ double scr[8];
   const int c = blockIdx.x;
-  const long long n = (long long)B*HW;
+  long long lo, hi;
+  slice_range((long long)B*HW, lo, hi);
   double s = 0.0, q = 0.0;
-  for (long long i = threadIdx.x; i < n; i += 256) {
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const float v = x[((long long)(i / HW)*C + c)*HW + i % HW];
     s += v; q += (double)v*v;
   }
@@ -115,6 +123,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, int B, in
   __syncthreads();
   q = block_sum(q, scr);
   if (threadIdx.x == 0) {
+    part[((long long)c*gridDim.y + blockIdx.y)*2] = s;
+    part[((long long)c*gridDim.y + blockIdx.y)*2 + 1] = q;
+  }
+}
+__global__ __launch_bounds__(256) void bn_stats_kernel(const double* part, int slices, int B, int C,
+                                                       long long HW, float* mean_out,
+                                                       float* invstd_out, float* running_mean,
+                                                       float* running_var, float eps,
+                                                       float momentum) {
+  const int c = blockIdx.x*256 + threadIdx.x;
+  if (c >= C) return;
+  const long long n = (long long)B*HW;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < slices; ++i) { s += part[((long long)c*slices + i)*2]; q += part[((long long)c*slices + i)*2 + 1]; }
+  {
     const double mean = s/n;
     double var = q/n - mean*mean;
     if (var < 0) var = 0;
@@ -431,13 +454,14 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
                                                            const float* mean, const float* invstd,
                                                            const float* gamma, const float* beta,
                                                            const float* slope, int B, int C,
-                                                           long long HW, float* dgamma,
-                                                           float* dbeta, float* dslope_part) {
+                                                           long long HW, double* part) {
   __shared__ double scr[8];
   const int c = blockIdx.x;
   const float a = slope ? *slope : 1.f;
   double s1 = 0.0, s2 = 0.0, sa = 0.0;
-  for (long long e = threadIdx.x; e < (long long)B*HW; e += 256) {
+  long long lo, hi;
+  slice_range((long long)B*HW, lo, hi);
+  for (long long e = lo + threadIdx.x; e < hi; e += 256) {
     const long long idx = ((e / HW)*C + c)*HW + e % HW;
     const float xh = (x[idx] - mean[c])*invstd[c];
     const float u = xh*gamma[c] + beta[c];
@@ -448,7 +472,22 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
   s1 = block_sum(s1, scr); __syncthreads();
   s2 = block_sum(s2, scr); __syncthreads();
   sa = block_sum(sa, scr);
-  if (threadIdx.x == 0) { dbeta[c] = (float)s1; dgamma[c] = (float)s2; dslope_part[c] = (float)sa; }
+  if (threadIdx.x == 0) {
+    double* o = part + ((long long)c*gridDim.y + blockIdx.y)*3;
+    o[0] = s1; o[1] = s2; o[2] = sa;
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* part, int slices, int C,
+                                                           float* dgamma, float* dbeta,
+                                                           float* dslope_part) {
+  const int c = blockIdx.x*256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0, sa = 0.0;
+  for (int i = 0; i < slices; ++i) {
+    const double* o = part + ((long long)c*slices + i)*3;
+    s1 += o[0]; s2 += o[1]; sa += o[2];
+  }
+  dbeta[c] = (float)s1; dgamma[c] = (float)s2; dslope_part[c] = (float)sa;
 }
 // pass 2: dx = gamma*invstd*(dpre - dbeta/n - xh*dgamma/n)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const float* dy,
@@ -553,6 +592,11 @@ __global__ __launch_bounds__(256) void env_divide_kernel(const float* dy, const 
   }
 }
 
+int red_slices(long long n) {
+  long long s = (n + 16383)/16384;
+  return (int)(s < 1 ? 1 : (s > kRedSlices ? kRedSlices : s));
+}
+
 }  // namespace
 
 extern "C" {
@@ -599,9 +643,15 @@ int brv_batchnorm2d_forward(const float* x, const float* gamma, const float* bet
   if (B < 1 || C < 1 || HW < 1) return -1;
   hipStream_t st = (hipStream_t)stream;
   if (training) {
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)C), dim3(256), 0, st, x, (int)B, (int)C,
-                       (long long)HW, save_mean, save_invstd, running_mean, running_var, eps,
-                       momentum);
+    const int slices = red_slices(B*HW);
+    double* part = nullptr;
+    DC_OK(hipMallocAsync((void**)&part, (size_t)C*slices*2*sizeof(double), st));
+    hipLaunchKernelGGL(bn_stats_part_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st,
+                       x, (int)B, (int)C, (long long)HW, part);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((C + 255)/256)), dim3(256), 0, st, part,
+                       slices, (int)B, (int)C, (long long)HW, save_mean, save_invstd, running_mean,
+                       running_var, eps, momentum);
+    DC_OK(hipFreeAsync(part, st));
   } else {
     DC_OK(hipMemcpyAsync(save_mean, running_mean, (size_t)C*4, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(invstd_from_var_kernel, dim3((unsigned)((C + 255)/256)), dim3(256), 0, st,
@@ -673,9 +723,15 @@ int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_
                              brv_stream_t stream) {
   if (B < 1 || C < 1 || HW < 1) return -1;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)C), dim3(256), 0, st, x, dy, save_mean,
-                     save_invstd, gamma, beta, prelu_slope, (int)B, (int)C, (long long)HW, dgamma,
-                     dbeta, dslope_partial);
+  const int slices = red_slices(B*HW);
+  double* part = nullptr;
+  DC_OK(hipMallocAsync((void**)&part, (size_t)C*slices*3*sizeof(double), st));
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st, x,
+                     dy, save_mean, save_invstd, gamma, beta, prelu_slope, (int)B, (int)C,
+                     (long long)HW, part);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)((C + 255)/256)), dim3(256), 0, st, part,
+                     slices, (int)C, dgamma, dbeta, dslope_partial);
+  DC_OK(hipFreeAsync(part, st));
   const long long total = B*C*HW;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, flat_grid(total), dim3(256), 0, st, x, dy, save_mean,
                      save_invstd, gamma, beta, prelu_slope, dgamma, dbeta, dx, (int)C,

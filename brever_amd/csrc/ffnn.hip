@@ -110,14 +110,29 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* y, const 
   GRID_STRIDE(i, n) dx[i] = dy[i]*y[i]*(1.f - y[i]);
 }
 // out[m] = sum_{b,t} x[b][m][t]  (bias gradient): one workgroup per row, fixed order
-__global__ __launch_bounds__(256) void row_sum_kernel(const float* x, float* out, int B, int M, int T) {
+// (long rows: gridDim.y slices per row write fp64 partials that a second kernel adds in order)
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* x, float* out, double* part, int B,
+                                                      int M, int T) {
   __shared__ double scr[8];
   const int m = blockIdx.x;
+  const long long n = (long long)B*T;
+  const long long per = (n + gridDim.y - 1)/gridDim.y;
+  const long long lo = (long long)blockIdx.y*per, hi = lo + per < n ? lo + per : n;
   double s = 0.0;
-  for (int b = 0; b < B; ++b)
-    for (int t = threadIdx.x; t < T; t += 256) s += (double)x[((long long)b*M + m)*T + t];
+  for (long long e = lo + threadIdx.x; e < hi; e += 256)
+    s += (double)x[((e / T)*M + m)*T + e % T];
   s = block_sum(s, scr);
-  if (threadIdx.x == 0) out[m] = (float)s;
+  if (threadIdx.x == 0) {
+    if (part) part[(long long)m*gridDim.y + blockIdx.y] = s; else out[m] = (float)s;
+  }
+}
+__global__ __launch_bounds__(256) void row_sum_final_kernel(const double* part, float* out, int M,
+                                                            int slices) {
+  const int m = blockIdx.x*256 + threadIdx.x;
+  if (m >= M) return;
+  double s = 0.0;
+  for (int i = 0; i < slices; ++i) s += part[(long long)m*slices + i];
+  out[m] = (float)s;
 }
 // out[b][i] = mask[b][i] * mean_c spec[b][c][i]   (complex)           (ffnn.py:113-115)
 __global__ __launch_bounds__(256) void masked_mean_spec_kernel(const float2* spec, const float* mask,
@@ -218,8 +233,21 @@ int brv_sigmoid_backward(const float* y, const float* dy, float* dx, int64_t n, 
 }
 int brv_row_sum(const float* x, float* out, int64_t B, int64_t M, int64_t T, brv_stream_t stream) {
   if (B < 1 || M < 1 || T < 1) return -1;
-  hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, x, out,
-                     (int)B, (int)M, (int)T);
+  hipStream_t st = (hipStream_t)stream;
+  long long slices = (B*T + 16383)/16384;
+  if (slices > 64) slices = 64;
+  if (slices <= 1) {
+    hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)M, 1), dim3(256), 0, st, x, out,
+                       (double*)nullptr, (int)B, (int)M, (int)T);
+  } else {
+    double* part = nullptr;
+    FF_OK(hipMallocAsync((void**)&part, (size_t)M*slices*sizeof(double), st));
+    hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)M, (unsigned)slices), dim3(256), 0, st, x, out,
+                       part, (int)B, (int)M, (int)T);
+    hipLaunchKernelGGL(row_sum_final_kernel, dim3((unsigned)((M + 255)/256)), dim3(256), 0, st, part,
+                       out, (int)M, (int)slices);
+    FF_OK(hipFreeAsync(part, st));
+  }
   FF_OK(hipGetLastError());
   return 0;
 }
