@@ -43,7 +43,7 @@ constexpr int CM_MAX_FOLD = 1024; // padded input channels whose folded norm fit
                    // reloads, 4 no MFMA, 8 no LDS commit, 16 no stores, 32 no B reads
 #endif
 #ifndef CM_RING
-#define CM_RING 6
+#define CM_RING 3
 #endif
 
 struct ConvMfmaParams {
@@ -58,8 +58,14 @@ struct ConvMfmaParams {
 
 __device__ __forceinline__ float silu_f(float v) { return v/(1.f + __expf(-v)); }
 
+#ifndef CM_OCC
+#define CM_OCC 2     // resident workgroups per CU the register budget is sized for
+#endif
+#ifndef CM_BPRE
+#define CM_BPRE 1    // read the B fragments one step ahead
+#endif
 template <int KS>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMfmaParams p) {
+__global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p) {
   constexpr int PAD = KS/2, TAPS = KS*KS;
   constexpr int PR = CM_ROWS + KS - 1, PC = CM_COLS + KS - 1;
   constexpr int NITEMS = PR*4*PC;                 // (row, channel group, column) 16-byte slots
@@ -107,22 +113,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMfmaParams p) {
   }
   const unsigned int ch_stride = (unsigned int)(HW*4);
 
-  float stage[ROUNDS][8];
-  auto issue = [&](int chunk) {
+  // the patch is fetched in two halves (rounds [0, RH) and [RH, ROUNDS)) through ONE set of
+  // RH x 8 staging registers: the first half is committed to LDS in the middle of the chunk
+  constexpr int RH = (ROUNDS + 1)/2;
+  float stage[RH][8];
+  auto issue = [&](int chunk, int r0) {
     if (CM_ABL & 1) return;
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
+    for (int q = 0; q < RH; ++q) {
+      const int r = r0 + q;
+      if (r >= ROUNDS) continue;
       const unsigned int base = pix_off[r] + (unsigned int)(chunk*CM_CK + kg_of[r]*8)*ch_stride;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        stage[r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+        stage[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
             xr, (int)(base + (unsigned int)j*ch_stride), 0, 0));
     }
   };
-  auto commit = [&](int chunk, int buf) {
+  auto commit = [&](int chunk, int buf, int r0) {
     if (CM_ABL & 8) return;
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
+    for (int q = 0; q < RH; ++q) {
+      const int r = r0 + q;
+      if (r >= ROUNDS) continue;
       const int item = tid + r*256;
       if (item >= NITEMS) continue;
       h8 v;
@@ -130,14 +143,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMfmaParams p) {
         const int c0 = chunk*CM_CK + kg_of[r]*8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float t = fold_tab[0][c0 + j]*stage[r][j] + fold_tab[1][c0 + j];
+          float t = fold_tab[0][c0 + j]*stage[q][j] + fold_tab[1][c0 + j];
           const float ts = silu_f(t);
           t = p.in_silu ? ts : t;
           v[j] = (_Float16)(pix_ok[r] ? t : 0.f);
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (_Float16)(pix_ok[r] ? stage[r][j] : 0.f);
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)(pix_ok[r] ? stage[q][j] : 0.f);
       }
       patch[buf][item] = v;
     }
@@ -166,9 +179,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMfmaParams p) {
     ring[d][0] = wa[(f*2 + 0)*64];
     ring[d][1] = wa[(f*2 + 1)*64];
   }
-  issue(chunk_lo);
+  issue(chunk_lo, 0);
   __syncthreads();                 // fold_tab
-  commit(chunk_lo, 0);
+  commit(chunk_lo, 0, 0);
+  issue(chunk_lo, RH);
+  commit(chunk_lo, 0, RH);
   __syncthreads();
   const int n32 = lane & 31, khalf = lane >> 5;
   for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
@@ -176,7 +191,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMfmaParams p) {
     const bool more = chunk + 1 < chunk_hi;
     // issued even after the last chunk (a discarded reload) so that the wait counts of the
     // ring loads do not depend on a branch
-    issue(more ? chunk + 1 : chunk);
+    const int nxt = more ? chunk + 1 : chunk;
+    issue(nxt, 0);
     // B fragments are read from LDS one step ahead of the MFMAs that consume them
     h8 bf[2][4];
     auto load_b = [&](h8 (&dst)[4], int st) {
@@ -189,7 +205,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMfmaParams p) {
     load_b(bf[0], 0);
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
-      if (st + 1 < STEPS) load_b(bf[(st + 1) & 1], st + 1);
+      if (CM_BPRE) { if (st + 1 < STEPS) load_b(bf[(st + 1) & 1], st + 1); }
+      else if (st > 0) load_b(bf[st & 1], st);
       const h8 a0 = ring[st % RD][0], a1 = ring[st % RD][1];
       if (CM_ABL & 4) {
 #pragma unroll
@@ -206,9 +223,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvMfmaParams p) {
       ring[st % RD][0] = wa[(f*2 + 0)*64];
       ring[st % RD][1] = wa[(f*2 + 1)*64];
       }
+      if (st == STEPS/2 - 1) {               // first half lands in the other buffer, second half goes out
+        if (more) commit(nxt, buf ^ 1, 0);
+        issue(nxt, RH);
+      }
       __builtin_amdgcn_sched_barrier(0);     // keep the ring RD steps deep
     }
-    if (more) commit(chunk + 1, buf ^ 1);
+    if (more) commit(nxt, buf ^ 1, RH);
     __syncthreads();
   }
 

@@ -14,6 +14,7 @@ encoder / decoder / block type of ``DiffusionUNet``. Not built yet: training (``
 the backward pass of the U-Net and raises ``NotImplementedError``).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -30,7 +31,7 @@ SolverRegistry = Registry('solver')
 # ------------------------------------------------------------------------------------------
 # HIP primitives (inference: plain functions on contiguous fp32 tensors)
 # ------------------------------------------------------------------------------------------
-_STATE = {'amp': False}
+_STATE = {'amp': False, 'graph': False, 'pver': None}
 _GN_SCRATCH = {}
 
 
@@ -408,6 +409,7 @@ class DiffusionUNet(nn.Module):
         assert decoder_type in ['standard', 'residual', 'skip']
         assert block_type in ['ncsn', 'adm']
         self._blocks, self._emb_key = None, None
+        self._graphs = {}
         self.resampler = Resample(fir_kernel, buffer_padding=True)
         emb_channels = base_channels*emb_channel_mult
         self.emb = NoiseEmbedding(base_channels*noise_channel_mult, emb_channels)
@@ -480,7 +482,34 @@ class DiffusionUNet(nn.Module):
             o += n
 
     def forward(self, x, sigma):
-        emb = self.emb(torch.as_tensor(sigma, dtype=torch.float32).to(x.device))
+        """One network evaluation. Inside ``SGMSEp.enhance`` the ~800 kernel launches of an
+        evaluation are captured once per input shape into a HIP graph and replayed (the
+        Python-side launch cost, not the GPU, bounds an eager evaluation)."""
+        sigma = torch.as_tensor(sigma, dtype=torch.float32).to(x.device).reshape(-1)
+        if not _STATE['graph']:
+            return self._forward_impl(x, sigma)
+        key = (tuple(x.shape), tuple(sigma.shape), _STATE['amp'], _STATE['pver'])
+        entry = self._graphs.get(key)
+        if entry is None:
+            sx, ss = x.clone(), sigma.clone()
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):                 # warm-up: packs weights, fills caches
+                self._forward_impl(sx, ss)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward_impl(sx, ss)
+            self._graphs.clear()                          # one shape at a time: bound the memory
+            entry = self._graphs[key] = (graph, sx, ss, out)
+        graph, sx, ss, out = entry
+        sx.copy_(x)
+        ss.copy_(sigma)
+        graph.replay()
+        return out
+
+    def _forward_impl(self, x, sigma):
+        emb = self.emb(sigma)
         self._block_embeddings(emb)
         aux = x
         x = _conv(x, self.input_conv)
@@ -922,8 +951,15 @@ class SGMSEp(BreverBaseModel):
         x = self.stft(x)
         if self.stft_discard_nyquist:
             x = x[..., :-1, :]
-        with hip_autocast(use_amp):
-            x, nfe = self.solver(self.sde, x.contiguous(), self.model, self)
+        net = self.model.net
+        first = next(net.parameters())
+        _STATE['pver'] = (first.data_ptr(), sum(p._version for p in net.parameters()))
+        _STATE['graph'] = os.environ.get('BRV_NO_GRAPH', '0') != '1'
+        try:
+            with hip_autocast(use_amp):
+                x, nfe = self.solver(self.sde, x.contiguous(), self.model, self)
+        finally:
+            _STATE['graph'] = False
         x = torch.nn.functional.pad(x, (0, 0, 0, 1))           # pad the Nyquist bin
         x = self.stft.backward(x)
         x = x*norm
