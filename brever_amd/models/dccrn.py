@@ -425,10 +425,9 @@ class DCCRN(BreverBaseModel):
         rows = x.reshape(B, C2*Fq, T).transpose(1, 2)        # (B, T, features): real then imag
         real, imag = rows.chunk(2, dim=-1)
         for layer in blk.lstm.layers:
-            rr = self._lstm(layer.module_real, real)
-            ii = self._lstm(layer.module_imag, imag)
-            ri = self._lstm(layer.module_real, imag)
-            ir = self._lstm(layer.module_imag, real)
+            # each module sees both halves: one recurrence launch of 2B items per module
+            rr, ri = self._lstm(layer.module_real, torch.cat([real, imag], dim=0)).chunk(2, dim=0)
+            ii, ir = self._lstm(layer.module_imag, torch.cat([imag, real], dim=0)).chunk(2, dim=0)
             real, imag = _CombineFunction.apply(rr, ii, -1.0), _CombineFunction.apply(ri, ir, 1.0)
         # Linear applied on the feature axis of (B, features, T): the output is already in the
         # (channels*freqs, frames) layout of the decoder input
