@@ -4,12 +4,22 @@ protocol the samplers / trainer rely on.
 Reference: brever/data.py:389-491 (``BreverDataLoader``) and the attribute /
 method set of ``BreverDataset`` that ``BreverTrainer`` and the samplers touch
 (brever/data.py:225-326; the minimal spec is the reference's own
-tests/utils.py:9-42 ``DummyDataset``). FLAC-in-tar reading and segmentation are
-out of scope for this round: the benchmark and tests run
-on synthetic mixtures generated in memory by ``SyntheticMixtureDataset``.
+tests/utils.py:9-42 ``DummyDataset``). ``BreverDataset`` reads the
+reference's dataset layout -- ``audio/NNNNN_<source>.flac`` in a directory or in
+``audio.tar`` -- with the reference's segmentation strategies (brever/data.py:112-210,
+integer arithmetic, bit-exact against fixtures); WAV files are decoded here, FLAC needs the
+``soundfile`` wheel (absent in this image: a clear ``ImportError``). The benchmark and most
+tests run on synthetic mixtures generated in memory by ``SyntheticMixtureDataset``.
 """
+import io
+import logging
+import os
 import random
+import re
+import struct
+import tarfile
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -127,3 +137,262 @@ class SyntheticMixtureDataset(torch.utils.data.Dataset):
 
     def set_epoch(self, epoch):
         pass
+
+
+# ---------------------------------------------------------------------------------------------
+# audio files
+# ---------------------------------------------------------------------------------------------
+def _wav_header(f):
+    """(sample rate, channels, frames, format tag, bits, data offset) of a RIFF/WAVE stream."""
+    head = f.read(12)
+    if len(head) < 12 or head[:4] != b'RIFF' or head[8:12] != b'WAVE':
+        raise ValueError('not a RIFF/WAVE file')
+    fmt = None
+    while True:
+        chunk = f.read(8)
+        if len(chunk) < 8:
+            raise ValueError('WAVE file without a data chunk')
+        tag, size = chunk[:4], struct.unpack('<I', chunk[4:])[0]
+        if tag == b'fmt ':
+            body = f.read(size + (size & 1))
+            code, channels, rate, _, _, bits = struct.unpack('<HHIIHH', body[:16])
+            if code == 0xFFFE and size >= 26:                   # WAVE_FORMAT_EXTENSIBLE
+                code = struct.unpack('<H', body[24:26])[0]
+            fmt = (rate, channels, code, bits)
+        elif tag == b'data':
+            if fmt is None:
+                raise ValueError('WAVE data chunk before fmt chunk')
+            rate, channels, code, bits = fmt
+            return rate, channels, size//(channels*bits//8), code, bits, f.tell()
+        else:
+            f.seek(size + (size & 1), io.SEEK_CUR)
+
+
+def audio_info(f, name):
+    """(frames, sample rate) of an open audio file (``torchaudio.info`` in data.py:143)."""
+    if name.lower().endswith('.wav'):
+        rate, _, frames, _, _, _ = _wav_header(f)
+        return frames, rate
+    try:
+        import soundfile as sf
+    except ImportError as e:
+        raise ImportError(f'reading {name} needs the soundfile wheel (FLAC); WAV files are '
+                          'decoded without it') from e
+    info = sf.info(f)
+    return info.frames, info.samplerate
+
+
+def audio_read(f, name):
+    """float32 array (frames,) or (frames, channels) and the sample rate (``sf.read`` in
+    data.py:265)."""
+    if not name.lower().endswith('.wav'):
+        try:
+            import soundfile as sf
+        except ImportError as e:
+            raise ImportError(f'reading {name} needs the soundfile wheel (FLAC); WAV files '
+                              'are decoded without it') from e
+        return sf.read(f, dtype='float32')
+    rate, channels, frames, code, bits, _ = _wav_header(f)
+    raw = f.read(frames*channels*bits//8)
+    if code == 3 and bits == 32:
+        x = np.frombuffer(raw, dtype='<f4').astype(np.float32)
+    elif code == 1 and bits == 16:
+        x = np.frombuffer(raw, dtype='<i2').astype(np.float32)/32768.0
+    elif code == 1 and bits == 32:
+        x = (np.frombuffer(raw, dtype='<i4').astype(np.float64)/2147483648.0).astype(np.float32)
+    elif code == 1 and bits == 24:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        x = (np.where(v >= 1 << 23, v - (1 << 24), v)/8388608.0).astype(np.float32)
+    else:
+        raise ValueError(f'unsupported WAVE encoding (format {code}, {bits} bits)')
+    return (x.reshape(frames, channels) if channels > 1 else x), rate
+
+
+class TarArchive:
+    """Member lookup in ``audio.tar`` with one file handle per DataLoader worker
+    (``tarfile`` objects cannot be shared across processes; brever/data.py:374-386)."""
+
+    def __init__(self, archive):
+        self.archive = archive
+        self._handles = {}
+        self.members = {m.name: m for m in self._handle().getmembers()}
+
+    def _handle(self):
+        info = torch.utils.data.get_worker_info()
+        key = info.id if info is not None else None
+        if key not in self._handles:
+            self._handles[key] = tarfile.open(self.archive)
+        return self._handles[key]
+
+    def get_file(self, name):
+        return self._handle().extractfile(self.members[name])
+
+
+class BreverDataset(torch.utils.data.Dataset):
+    """Reads a dataset made by the reference's ``scripts/create_dataset.py``: same constructor,
+    segmentation and item contract as brever/data.py:23-326 (items are
+    ``(n_sources, 2, n_samples)`` float32 tensors, or whatever ``transform`` makes of them).
+    ``dynamic_mixing`` (on-the-fly mixture synthesis) is not built."""
+
+    def __init__(self, path, segment_length=0.0, overlap_length=0.0, fs=16000,
+                 sources=('mixture', 'foreground'), segment_strategy='pass',
+                 max_segment_length=0.0, tar=True, transform=None, dynamic_mixing=False,
+                 dynamic_mixtures_per_epoch=1000):
+        if dynamic_mixing:
+            raise NotImplementedError('dynamic mixing is not built yet on this path')
+        self.path = path
+        self.segment_length = round(segment_length*fs)
+        self.overlap_length = round(overlap_length*fs)
+        self.fs = fs
+        self.sources = list(sources)
+        self.segment_strategy = segment_strategy
+        self.max_segment_length = round(max_segment_length*fs)
+        self.archive = TarArchive(os.path.join(path, 'audio.tar')) if tar else None
+        self.rmm_dset = None
+        self.transform = transform
+        self.preloaded_data = None
+        self._ext = None
+        self.get_segment_info()
+
+    # -- files ---------------------------------------------------------------------------------
+    def _names(self):
+        if self.archive is None:
+            return [f'audio/{f}' for f in os.listdir(os.path.join(self.path, 'audio'))]
+        return list(self.archive.members)
+
+    def count_files(self):
+        found = [re.match(r'audio/(\d+)_.+\.(flac|wav)$', n) for n in self._names()]
+        found = [m for m in found if m]
+        if not found:
+            raise FileNotFoundError(f'no audio/NNNNN_<source>.flac|wav files under {self.path}')
+        self._ext = found[0].group(2)
+        return max(int(m.group(1)) for m in found) + 1
+
+    def build_paths(self, file_idx):
+        return [os.path.join('audio', f'{file_idx:05d}_{source}.{self._ext}')
+                for source in self.sources]
+
+    def get_file(self, name):
+        if self.archive is None:
+            return open(os.path.join(self.path, name), 'rb')
+        return self.archive.get_file(name.replace('\\', '/'))
+
+    def get_file_lengths(self):
+        lengths = []
+        for file_idx in range(self.count_files()):
+            per_source = []
+            for p in self.build_paths(file_idx):
+                with self.get_file(p) as f:
+                    per_source.append(audio_info(f, p)[0])
+            if any(n != per_source[0] for n in per_source):
+                raise ValueError(f'sources {file_idx} do not all have the same length')
+            lengths.append(per_source[0])
+        self._duration = sum(lengths)/self.fs
+        return lengths
+
+    # -- segmentation (integer arithmetic) -----------------------------------------------------
+    def get_segment_info(self):
+        self._segment_info = segment_table(
+            self.get_file_lengths(), self.segment_length, self.overlap_length,
+            self.segment_strategy, self.max_segment_length, owner=self)
+        self._effective_duration = sum(e - s for _, (s, e) in self._segment_info)/self.fs
+
+    def __len__(self):
+        return len(self._segment_info)
+
+    def get_segment_length(self, i):
+        if self.segment_strategy == 'random':
+            return self.segment_length
+        _, (start, end) = self._segment_info[i]
+        return end - start
+
+    def get_max_segment_length(self):
+        if self.segment_strategy == 'random':
+            return self.segment_length
+        return max(end - start for _, (start, end) in self._segment_info)
+
+    # -- items -------------------------------------------------------------------------------
+    def load_file(self, path):
+        with self.get_file(path) as f:
+            x, fs = audio_read(f, path)
+        if fs != self.fs:
+            raise ValueError('file sampling rate does not match dataset fs attribute, got '
+                             f'{fs} and {self.fs}')
+        return x
+
+    def load_segment(self, index):
+        file_idx, (start, end) = self._segment_info[index]
+        if self.segment_strategy == 'random' and self.segment_length != 0.0:
+            start = random.randint(start, end - self.segment_length)
+            end = start + self.segment_length
+        sources = torch.from_numpy(np.stack([self.load_file(p)
+                                             for p in self.build_paths(file_idx)]))
+        sources = sources.unsqueeze(1) if sources.ndim == 2 else sources.transpose(1, 2)
+        if end > sources.shape[-1]:
+            if self.segment_strategy not in ('pad', 'random'):
+                raise ValueError("attempting to load a segment outside of file range but segment "
+                                 f"strategy is not in ['pad', 'random'], got "
+                                 f'{self.segment_strategy}')
+            sources = F.pad(sources, (0, end - sources.shape[-1]))
+        return sources[..., start:end]
+
+    def __getitem__(self, index):
+        if self.preloaded_data is not None:
+            return self.preloaded_data[index]
+        sources = self.load_segment(index)
+        if self.transform is not None:
+            sources = self.transform(sources)
+        return sources
+
+    def preload(self, device, tqdm_desc=None):
+        if self.segment_strategy == 'random':
+            raise ValueError("can't preload when segment_strategy is 'random'")
+        data = []
+        for i in range(len(self)):
+            item = self[i]
+            data.append(item.to(device) if isinstance(item, torch.Tensor)
+                        else [t.to(device) for t in item])
+        self.preloaded_data = data      # only now: __getitem__ must not see a partial list
+
+    def set_epoch(self, epoch):
+        pass
+
+
+def segment_table(file_lengths, segment_length, overlap_length, strategy, max_segment_length=0,
+                  owner=None):
+    """``[(file index, (start, end)), ...]`` in samples for the five trailing-segment
+    strategies (brever/data.py:112-210). With ``segment_length == 0`` files are taken whole
+    unless one exceeds ``max_segment_length``, which then becomes the segment length (and is
+    written back to ``owner.segment_length`` as the reference does)."""
+    if segment_length == 0 and max_segment_length != 0 and max(file_lengths) > max_segment_length:
+        logging.warning('Found a file longer than max_segment_length. Setting segment_length '
+                        f'to max_segment_length ({max_segment_length}).')
+        segment_length = max_segment_length
+        if owner is not None:
+            owner.segment_length = segment_length
+    if segment_length == 0:
+        return [(i, (0, n)) for i, n in enumerate(file_lengths)]
+    if strategy not in ('drop', 'pass', 'pad', 'overlap', 'random'):
+        raise ValueError(f'unrecognized segment strategy, got {strategy}')
+    table = []
+    hop = segment_length - overlap_length
+    for i, n in enumerate(file_lengths):
+        if strategy == 'random':
+            table.append((i, (0, max(n, segment_length))))
+            continue
+        whole = (n - segment_length)//hop + 1
+        table.extend((i, (k*hop, k*hop + segment_length)) for k in range(whole))
+        covered = (whole - 1)*hop + segment_length if whole > 0 else 0
+        if covered == n or strategy == 'drop':
+            continue
+        # files shorter than a segment with overlap give whole < 0 and a negative start, exactly
+        # as the reference computes it (data.py:186-203); kept for identical segment tables
+        tail_start = whole*hop
+        if strategy == 'pass':
+            table.append((i, (tail_start, n)))
+        elif strategy == 'pad':
+            table.append((i, (tail_start, tail_start + segment_length)))
+        else:                                                     # overlap
+            table.append((i, (n - segment_length, n)))
+    return table

@@ -39,15 +39,18 @@ def add_override_flags(parser, defaults, prefix=''):
     return arg_map
 
 
-def make_dataset(spec, fs, transform=None, seed=0):
-    """``synthetic:<items>:<seconds>[:<min_seconds>]`` -> in-memory synthetic mixtures.
-    Reading the reference's FLAC-in-tar datasets is not built yet."""
-    from brever_amd.data import SyntheticMixtureDataset
+def make_dataset(spec, fs, transform=None, seed=0, **dataset_kwargs):
+    """``synthetic:<items>:<seconds>[:<min_seconds>]`` -> in-memory synthetic mixtures; any
+    other value is the path of a dataset directory in the reference's layout
+    (``audio/NNNNN_<source>.flac|wav`` or ``audio.tar``), read by ``BreverDataset`` with the
+    ``dataset`` section of the model config (``tar=False`` is tried when there is no
+    ``audio.tar``)."""
+    import os
+
+    from brever_amd.data import BreverDataset, SyntheticMixtureDataset
     if not str(spec).startswith('synthetic:'):
-        raise NotImplementedError(
-            f'dataset {spec!r}: only synthetic:<items>:<seconds>[:<min_seconds>] '
-            'datasets are supported for now (FLAC/tar reading is the next row of '
-            'the scope table, SURVEY.md 8f)')
+        dataset_kwargs.setdefault('tar', os.path.exists(os.path.join(spec, 'audio.tar')))
+        return BreverDataset(spec, fs=fs, transform=transform, **dataset_kwargs)
     parts = spec.split(':')[1:]
     n, seconds = int(parts[0]), float(parts[1])
     min_len = int(float(parts[2])*fs) if len(parts) > 2 else None

@@ -49,8 +49,12 @@ def main(args, arg_map):
 
     model = ModelRegistry.get(cfg.arch)(**cfg.model.to_dict())
     fs = cfg.dataset.fs
-    train_dataset = make_dataset(cfg.train_path, fs, transform=model.transform, seed=0)
-    val_dataset = make_dataset(cfg.val_path, fs, transform=None, seed=10_000)
+    dset_kw = {k: v for k, v in cfg.dataset.to_dict().items() if k != 'fs'}
+    real = lambda spec: {} if str(spec).startswith('synthetic:') else dset_kw  # noqa: E731
+    train_dataset = make_dataset(cfg.train_path, fs, transform=model.transform, seed=0,
+                                 **real(cfg.train_path))
+    val_dataset = make_dataset(cfg.val_path, fs, transform=None, seed=10_000,
+                               **real(cfg.val_path))
 
     ignore_checkpoint = trainer_kwargs.pop('ignore_checkpoint')
     trainer = BreverTrainer(

@@ -498,13 +498,43 @@ def golden_sgmse(out):
     np.savez_compressed(os.path.join(out, 'sgmse.npz'), **res)
 
 
+def golden_segments(out):
+    """Segment tables of BreverDataset.get_segment_info (brever/data.py:112-210) for seeded
+    file lengths x strategies x (segment, overlap, max segment) settings; the file-length
+    query (torchaudio.info on FLAC members) is replaced by the given list."""
+    from brever.data import BreverDataset
+    rng = random.Random(7)
+    cases = []
+    for _ in range(120):
+        lens = [rng.randint(1, 50000) for _ in range(rng.randint(1, 5))]
+        seg = rng.choice([0, 100, 1600, 16000, 20000])
+        ov = rng.choice([0, 0, 10, 800]) if seg else 0
+        if seg and ov >= seg:
+            ov = 0
+        strat = rng.choice(['drop', 'pass', 'pad', 'overlap', 'random'])
+        mx = rng.choice([0, 0, 8000, 30000])
+        ref = object.__new__(BreverDataset)
+        ref.segment_length, ref.overlap_length, ref.segment_strategy = seg, ov, strat
+        ref.max_segment_length, ref.fs, ref.rmm_dset = mx, 16000, None
+        ref.get_file_lengths = lambda l=lens: l
+        logging_off = __import__('logging')
+        logging_off.disable(logging_off.WARNING)
+        ref.get_segment_info()
+        logging_off.disable(logging_off.NOTSET)
+        cases.append(dict(lengths=lens, segment=seg, overlap=ov, strategy=strat, max_segment=mx,
+                          segment_after=ref.segment_length,
+                          table=[[i, s, e] for i, (s, e) in ref._segment_info]))
+    with open(os.path.join(out, 'segments.json'), 'w') as f:
+        json.dump(cases, f)
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
     os.chdir(REF)       # the reference opens config/... relatively
     torch.set_num_threads(4)
     todo = [golden_batching, golden_collate, golden_losses, golden_convtasnet, golden_training,
-            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse]
+            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments]
     only = sys.argv[1:]                  # e.g. `make_golden.py sgmse` regenerates one file
     for fn in todo:
         if not only or fn.__name__[len('golden_'):] in only:

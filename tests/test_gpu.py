@@ -954,3 +954,44 @@ def test_lstm_kernels_match_torch(H):
     assert rel(xd.grad, x.grad) <= 1e-4
     for got, want in zip(pd, params):
         assert rel(got.grad, want.grad) <= 1e-4, rel(got.grad, want.grad)
+
+
+@pytest.mark.gpu
+def test_entry_points_on_a_dataset_directory(tmp_path):
+    """init -> train -> test on a dataset directory in the reference's layout
+    (audio/NNNNN_<source>.wav, no tar) read by ``BreverDataset`` with segmentation from the
+    config's dataset section."""
+    import subprocess
+    import sys
+    import wave
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(1)
+    for split, n in (('train', 6), ('val', 3)):
+        os.makedirs(tmp_path/split/'audio')
+        for i in range(n):
+            L = 16000 + 800*i
+            fg = 0.1*rng.standard_normal((L, 2))
+            mix = fg + 0.05*rng.standard_normal((L, 2))
+            for src, x in (('mixture', mix), ('foreground', fg)):
+                with wave.open(str(tmp_path/split/'audio'/f'{i:05d}_{src}.wav'), 'wb') as w:
+                    w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000)
+                    w.writeframes((np.clip(x, -1, 1)*32767).astype('<i2').tobytes())
+    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
+                                    text=True, cwd=root)
+    models = tmp_path/'models'
+    os.makedirs(models)
+    out = run('scripts/init_model.py', 'convtasnet', '--models-dir', str(models),
+              '--filters', '64', '--bottleneck_channels', '32', '--hidden_channels', '64',
+              '--skip_channels', '32', '--layers', '2', '--repeats', '2',
+              '--trainer_epochs', '1', '--trainer_val_period', '1', '--trainer_batch_size', '4',
+              '--trainer_preload', 'true', '--trainer_workers', '0',
+              '--train-path', str(tmp_path/'train'), '--val-path', str(tmp_path/'val'))
+    assert out.returncode == 0, out.stderr
+    model_dir = os.path.join(str(models), os.listdir(models)[0])
+    out = run('scripts/train_model.py', model_dir)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert np.isfinite(np.load(os.path.join(model_dir, 'losses.npz'))['train_loss']).all()
+    out = run('scripts/test_model.py', '-i', model_dir, '-t', str(tmp_path/'val'))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    scores = np.load(os.path.join(model_dir, 'scores.npz'))['scores']
+    assert scores.shape[0] == 3 and np.isfinite(scores).all()

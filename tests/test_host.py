@@ -190,3 +190,88 @@ def test_product_rejects_cpu_tensors():
     assert 'tcn.layer_norm.gain' in causal.state_dict()       # reference's cLN parameter names
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         causal(torch.zeros(1, 256))
+
+
+def test_segment_tables_match_reference(golden_dir):
+    """BreverDataset segmentation (drop / pass / pad / overlap / random, overlap, the
+    max_segment_length rule) vs tables produced by the imported reference: bit-exact."""
+    from brever_amd.data import segment_table
+    with open(os.path.join(golden_dir, 'segments.json')) as f:
+        cases = json.load(f)
+    assert len(cases) == 120
+
+    class Owner:
+        segment_length = None
+    for c in cases:
+        owner = Owner()
+        got = segment_table(c['lengths'], c['segment'], c['overlap'], c['strategy'],
+                            c['max_segment'], owner=owner)
+        assert [[i, s, e] for i, (s, e) in got] == c['table'], c
+        if owner.segment_length is not None:
+            assert owner.segment_length == c['segment_after']
+
+
+def _write_wav(path_or_file, x, fs=16000):
+    import wave
+    with wave.open(path_or_file, 'wb') as w:
+        w.setnchannels(x.shape[1]); w.setsampwidth(2); w.setframerate(fs)
+        w.writeframes((x*32767).round().astype('<i2').tobytes())
+
+
+@pytest.mark.parametrize('tar', [False, True])
+def test_brever_dataset_reads_wav_datasets(tmp_path, tar):
+    """A dataset directory in the reference's layout (audio/NNNNN_<source>.wav, optionally inside
+    audio.tar): lengths per strategy as in the reference's tests/test_datasets.py:87-160, item
+    shapes, sample values, padding, preload, transform, the collate path."""
+    import io
+    import tarfile
+
+    from brever_amd.batching import BatchSamplerRegistry
+    from brever_amd.data import BreverDataLoader, BreverDataset
+    rng = np.random.default_rng(0)
+    lengths = [16000 + 37*i for i in range(6)]
+    audio = {}
+    for i, n in enumerate(lengths):
+        for src in ('mixture', 'foreground'):
+            audio[f'audio/{i:05d}_{src}.wav'] = (rng.uniform(-0.5, 0.5, (n, 2))*32767).round()/32767
+    root = str(tmp_path)
+    if tar:
+        with tarfile.open(os.path.join(root, 'audio.tar'), 'w') as t:
+            for name, x in audio.items():
+                buf = io.BytesIO(); _write_wav(buf, x); data = buf.getvalue()
+                info = tarfile.TarInfo(name); info.size = len(data)
+                t.addfile(info, io.BytesIO(data))
+    else:
+        os.makedirs(os.path.join(root, 'audio'))
+        for name, x in audio.items():
+            _write_wav(os.path.join(root, name), x)
+    whole = BreverDataset(root, tar=tar)
+    assert len(whole) == 6 and whole.get_max_segment_length() == max(lengths)
+    item = whole[3]
+    assert item.shape == (2, 2, lengths[3]) and item.dtype == torch.float32
+    # 16-bit PCM decodes as integer/32768 (the libsndfile convention of the reference's sf.read)
+    want = torch.from_numpy((audio['audio/00003_foreground.wav'].T*32767/32768).astype(np.float32))
+    assert torch.allclose(item[1], want, atol=1e-7)
+    for strat, n in (('drop', 12), ('pass', 17), ('pad', 17), ('overlap', 17)):
+        d = BreverDataset(root, tar=tar, segment_strategy=strat, segment_length=0.5)
+        assert len(d) == n
+        last = d[len(d) - 1]
+        assert last.shape[-1] == (d.get_segment_length(len(d) - 1))
+        if strat == 'pad':
+            assert last.shape[-1] == 8000 and float(last[..., 37*5:].abs().max()) == 0.0
+        if strat == 'overlap':
+            assert torch.equal(last, whole[5][..., -8000:])
+    r = BreverDataset(root, tar=tar, segment_strategy='random', segment_length=0.25)
+    assert len(r) == 6 and r[0].shape == (2, 2, 4000)
+    with pytest.raises(ValueError):
+        r.preload('cpu')
+    t = BreverDataset(root, tar=tar, transform=lambda s: s.mean(axis=-2), segment_length=1.0,
+                      segment_strategy='pass')
+    t.preload('cpu')
+    sampler = BatchSamplerRegistry.get('bucket')(t, 2.5, dynamic=True, fs=16000)
+    batch, lens = next(iter(BreverDataLoader(t, batch_sampler=sampler)))
+    assert batch.shape[1] == 2 and batch.shape[0] == len(lens)
+    with pytest.raises(ValueError):
+        BreverDataset(root, tar=tar, segment_strategy='nope', segment_length=1.0)
+    with pytest.raises(NotImplementedError):
+        BreverDataset(root, tar=tar, dynamic_mixing=True)
