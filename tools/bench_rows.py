@@ -49,13 +49,14 @@ def sgmse_row(seconds, steps):
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
     model = ModelRegistry.get('sgmsep')(solver_num_steps=steps).to(dev).eval()
-    wav = 0.1*torch.randn(1, 2, int(seconds*16000), device=dev)
     out = {}
-    for amp in (True, False):
-        model.enhance(wav[..., :16000], use_amp=amp)
+    for amp, batch in ((True, 1), (True, 8), (False, 1)):
+        wav = 0.1*torch.randn(batch, 2, int(seconds*16000), device=dev)
+        model.enhance(wav, use_amp=amp)                  # captures the HIP graph of this shape
         dt = timed(lambda: model.enhance(wav, use_amp=amp), 0, 1)
-        out['fp16_mfma' if amp else 'fp32'] = {'s_per_utt': dt, 'ms_per_nfe': dt/(2*steps)*1e3,
-                                               'rtf': dt/seconds}
+        out[f"{'fp16_mfma' if amp else 'fp32'}_b{batch}"] = {
+            's_per_utt': dt/batch, 'utt_per_s': batch/dt, 'ms_per_nfe': dt/(2*steps)*1e3,
+            'rtf': dt/batch/seconds}
     return {'row': f'sgmsep enhance, {steps}-step PC sampler ({2*steps} network evaluations)',
             'seconds': seconds, **out}
 

@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--nfe-only', type=int, default=0)
     ap.add_argument('--arch', default='sgmsep')
     ap.add_argument('--amp', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=1)
     args = ap.parse_args()
     from brever_amd.models import ModelRegistry
     from brever_amd.models.sgmse import hip_autocast
@@ -31,7 +32,7 @@ def main():
     wav = 0.1*torch.randn(1, 2, L, device=dev)
     if args.nfe_only:
         T = L//128 + 1
-        y = 0.3*torch.randn(1, 1, 256, T, dtype=torch.complex64, device=dev)
+        y = 0.3*torch.randn(args.batch, 1, 256, T, dtype=torch.complex64, device=dev)
         t = torch.tensor(0.5)
         sigma = model.sde.sigma(t)
         with hip_autocast(args.amp):
