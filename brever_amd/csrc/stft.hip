@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const G32 p) {
 // workgroups that add their partial tiles into a zeroed D with fp32 atomics (weight-gradient
 // shapes: small M x N, very long reduction). Operands are staged k-major in LDS whatever
 // their storage order, through registers so that the next tile's loads fly during the MFMAs.
-constexpr int BM2 = 128, BN2 = 128, BK2 = 16, LD2 = BM2 + 4;
+constexpr int BM2 = 128, BN2 = 128, BK2 = 32, LD2 = BM2 + 4;
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const G32 p, int ksplit) {
@@ -174,15 +174,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const G32 p, int ksplit) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging maps: 128 x 16 elements per operand, 8 per thread; the fast thread index runs along
+  // staging maps: 128 x BK2 elements per operand, NR per thread; the fast thread index runs along
   // the operand's contiguous storage direction
-  float ra[8], rb[8];
+  constexpr int NR = BM2*BK2/256;
+  float ra[NR], rb[NR];
   auto fetch = [&](long long t) {
     const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BK2;
     const float* A = p.A + (long long)b*p.a_bs + (long long)kb*p.a_kbs;
     const float* B = p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < NR; ++r) {
       const int e = tid + r*256;
       int i, k;
       if (TA) { i = e % BM2; k = e / BM2; } else { k = e % BK2; i = e / BK2; }
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const G32 p, int ksplit) 
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < NR; ++r) {
       const int e = tid + r*256;
       if (TA) As[e / BM2][e % BM2] = ra[r]; else As[e % BK2][e / BK2] = ra[r];
       if (TB) Bs[e % BK2][e / BK2] = rb[r]; else Bs[e / BN2][e % BN2] = rb[r];
