@@ -34,7 +34,13 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CM_ROWS = 8;       // output rows per workgroup
+#ifndef CM_PF
+#define CM_PF 4       // 32x32 pixel fragments (= output rows) per wave
+#endif
+#ifndef CM_HALF
+#define CM_HALF 1     // 1: fetch the patch in two halves through one small register set
+#endif
+constexpr int CM_ROWS = 2*CM_PF; // output rows per workgroup
 constexpr int CM_COLS = 32;      // output columns per workgroup (= MFMA N)
 constexpr int CM_CK = 32;        // reduction channels per chunk (2 MFMA k-steps)
 constexpr int CM_MAX_FOLD = 1024; // padded input channels whose folded norm fits the LDS table
@@ -49,7 +55,7 @@ constexpr int CM_MAX_FOLD = 1024; // padded input channels whose folded norm fit
 struct ConvMfmaParams {
   const float* x; const h8* wp; const float* bias; const float* res; float* y;
   const float* in_scale; const float* in_shift;      // (B, Cin) each, nullable: silu(a*x + b)
-  int B, Cin, Cout, H, W, n_wt, n_chunks;
+  int B, Cin, Cout, H, W, n_wt, n_tiles, n_chunks;
   int n_split, split_chunks;     // split-K over workgroups (small images): atomics into y
   long long x_bs, y_bs;
   float out_scale;
@@ -74,7 +80,13 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wco = wave >> 1, wpx = wave & 1;
-  const int wt = blockIdx.x % p.n_wt, ht = blockIdx.x / p.n_wt;
+  // XCD-aware order: workgroups go round-robin over the 8 XCDs (each with its own L2), so
+  // XCD k takes the k-th contiguous eighth of the tiles -- neighbours share halo rows and the
+  // cache lines that straddle tile edges in ONE L2 instead of fetching them 2-3 times from HBM
+  const int per_xcd = gridDim.x >> 3;
+  const int tile = (blockIdx.x & 7)*per_xcd + (blockIdx.x >> 3);
+  if (tile >= p.n_tiles) return;
+  const int wt = tile % p.n_wt, ht = tile / p.n_wt;
   const int w0 = wt*CM_COLS, h0 = ht*CM_ROWS;
   const int b = blockIdx.z / p.n_split, split = blockIdx.z % p.n_split;
   const int chunk_lo = split*p.split_chunks;
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
 
   // the patch is fetched in two halves (rounds [0, RH) and [RH, ROUNDS)) through ONE set of
   // RH x 8 staging registers: the first half is committed to LDS in the middle of the chunk
-  constexpr int RH = (ROUNDS + 1)/2;
+  constexpr int RH = CM_HALF ? (ROUNDS + 1)/2 : ROUNDS;
   float stage[RH][8];
   auto issue = [&](int chunk, int r0) {
     if (CM_ABL & 1) return;
@@ -156,11 +168,11 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
     }
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][CM_PF];
 #pragma unroll
   for (int cf = 0; cf < 2; ++cf)
 #pragma unroll
-    for (int pf = 0; pf < 4; ++pf)
+    for (int pf = 0; pf < CM_PF; ++pf)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[cf][pf][i] = 0.f;
 
@@ -182,8 +194,7 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
   issue(chunk_lo, 0);
   __syncthreads();                 // fold_tab
   commit(chunk_lo, 0, 0);
-  issue(chunk_lo, RH);
-  commit(chunk_lo, 0, RH);
+  if (CM_HALF) { issue(chunk_lo, RH); commit(chunk_lo, 0, RH); }
   __syncthreads();
   const int n32 = lane & 31, khalf = lane >> 5;
   for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
@@ -194,13 +205,13 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
     const int nxt = more ? chunk + 1 : chunk;
     issue(nxt, 0);
     // B fragments are read from LDS one step ahead of the MFMAs that consume them
-    h8 bf[2][4];
-    auto load_b = [&](h8 (&dst)[4], int st) {
+    h8 bf[2][CM_PF];
+    auto load_b = [&](h8 (&dst)[CM_PF], int st) {
       const int tap = st >> 1, ks = st & 1;
       const int kh = tap/KS, kw = tap % KS;
 #pragma unroll
-      for (int pf = 0; pf < 4; ++pf)
-        dst[pf] = patch[(CM_ABL & 32) ? 0 : buf][(CM_ABL & 32) ? lane : ((wpx*4 + pf + kh)*4 + ks*2 + khalf)*PC + n32 + kw];
+      for (int pf = 0; pf < CM_PF; ++pf)
+        dst[pf] = patch[(CM_ABL & 32) ? 0 : buf][(CM_ABL & 32) ? lane : ((wpx*CM_PF + pf + kh)*4 + ks*2 + khalf)*PC + n32 + kw];
     };
     load_b(bf[0], 0);
 #pragma unroll
@@ -210,10 +221,10 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
       const h8 a0 = ring[st % RD][0], a1 = ring[st % RD][1];
       if (CM_ABL & 4) {
 #pragma unroll
-        for (int pf = 0; pf < 4; ++pf) asm volatile("" :: "v"(bf[st & 1][pf]), "v"(a0), "v"(a1));
+        for (int pf = 0; pf < CM_PF; ++pf) asm volatile("" :: "v"(bf[st & 1][pf]), "v"(a0), "v"(a1));
       } else
 #pragma unroll
-      for (int pf = 0; pf < 4; ++pf) {
+      for (int pf = 0; pf < CM_PF; ++pf) {
         acc[0][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bf[st & 1][pf], acc[0][pf], 0, 0, 0);
         acc[1][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bf[st & 1][pf], acc[1][pf], 0, 0, 0);
       }
@@ -223,13 +234,13 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
       ring[st % RD][0] = wa[(f*2 + 0)*64];
       ring[st % RD][1] = wa[(f*2 + 1)*64];
       }
-      if (st == STEPS/2 - 1) {               // first half lands in the other buffer, second half goes out
+      if (CM_HALF && st == STEPS/2 - 1) {    // first half lands in the other buffer, second half goes out
         if (more) commit(nxt, buf ^ 1, 0);
         issue(nxt, RH);
       }
       __builtin_amdgcn_sched_barrier(0);     // keep the ring RD steps deep
     }
-    if (more) commit(nxt, buf ^ 1, RH);
+    if (more) commit(nxt, buf ^ 1, CM_HALF ? RH : 0);
     __syncthreads();
   }
 
@@ -244,8 +255,8 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
       for (int i = 0; i < 16; ++i) {
         const int co = co_blk*64 + cf*32 + (i >> 2)*8 + khalf*4 + (i & 3);
 #pragma unroll
-        for (int pf = 0; pf < 4; ++pf) {
-          const int h = h0 + wpx*4 + pf;
+        for (int pf = 0; pf < CM_PF; ++pf) {
+          const int h = h0 + wpx*CM_PF + pf;
           if (co < p.Cout && h < p.H && w < p.W)
             atomicAdd(yb + ((long long)co*p.H + h)*p.W + w, acc[cf][pf][i]*p.out_scale);
         }
@@ -260,8 +271,8 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
       if (co >= p.Cout) continue;
       const float bias = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
-      for (int pf = 0; pf < 4; ++pf) {
-        const int h = h0 + wpx*4 + pf;
+      for (int pf = 0; pf < CM_PF; ++pf) {
+        const int h = h0 + wpx*CM_PF + pf;
         if (h >= p.H || w >= p.W) continue;
         if ((CM_ABL & 16) && acc[cf][pf][i] != 12345.f) continue;
         const long long o = ((long long)co*p.H + h)*p.W + w;
@@ -343,6 +354,7 @@ int brv_conv2d_mfma_forward(const float* x, const void* wp, const float* bias, c
   p.in_scale = in_scale; p.in_shift = in_shift; p.in_silu = in_silu;
   p.B = (int)B; p.Cin = (int)Cin; p.Cout = (int)Cout; p.H = (int)H; p.W = (int)W;
   p.n_wt = (int)((W + CM_COLS - 1)/CM_COLS); p.n_chunks = (int)n_chunks;
+  p.n_tiles = (int)(p.n_wt*((H + CM_ROWS - 1)/CM_ROWS));
   p.x_bs = x_batch_stride; p.y_bs = y_batch_stride; p.out_scale = out_scale;
 
   // small images leave most CUs idle and run the whole reduction as one latency chain: split it
@@ -361,7 +373,7 @@ int brv_conv2d_mfma_forward(const float* x, const void* wp, const float* bias, c
                        (hipStream_t)stream, bias, res, y, (int)Cout, (long long)(H*W),
                        (long long)y_batch_stride, out_scale);
   }
-  const dim3 grid((unsigned)(p.n_wt*((H + CM_ROWS - 1)/CM_ROWS)), (unsigned)((Cout + 127)/128),
+  const dim3 grid((unsigned)((p.n_tiles + 7)/8*8), (unsigned)((Cout + 127)/128),
                   (unsigned)(B*p.n_split));
   if (ksize == 3)
     hipLaunchKernelGGL(conv_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, p);

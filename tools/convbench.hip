@@ -7,7 +7,7 @@
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 1;
   struct S { int ci, co, k, H, W; };
-  const S shapes[] = {{128, 128, 3, 256, 501}, {256, 128, 3, 256, 501}, {256, 256, 3, 64, 126}, {256, 256, 3, 4, 8}};
+  const S shapes[] = {{128, 128, 3, 256, 501}, {128, 128, 3, 256, 512}, {128, 128, 3, 256, 480}, {256, 128, 3, 256, 501}, {256, 256, 3, 64, 126}, {256, 256, 3, 4, 8}};
   for (const S& s : shapes) {
     float *x, *y, *w, *bias; void* wp;
     const size_t nx1 = (size_t)s.ci*s.H*s.W, ny1 = (size_t)s.co*s.H*s.W, nx = nx1*B, ny = ny1*B, nw = (size_t)s.co*s.ci*s.k*s.k;
