@@ -245,6 +245,124 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const G32 p, int ksplit) 
     }
 }
 
+// ---- the same product with bf16 operands (brv_gemm_bf16): fp32 matrices in HBM are rounded to
+// bf16 on their way into LDS ([row][k] images, 32 k per tile, rows padded to 80 bytes so that
+// the 16-byte fragment reads are conflict-free), v_mfma_f32_32x32x16_bf16 accumulates in fp32.
+// 16x the matrix rate of the fp32 MFMA: these products then run at the speed of their loads.
+constexpr int BKL = 32, LDL = BKL + 8;            // k per tile, bf16 elements per LDS row
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit) {
+  __shared__ __attribute__((aligned(16))) bf16_t As[BM2][LDL];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[BN2][LDL];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y*BM2, n0 = blockIdx.x*BN2;
+  const int b = blockIdx.z / ksplit, split = blockIdx.z % ksplit;
+  const int nkb = p.kbatch > 1 ? p.kbatch : 1;
+  const int ktiles = (p.K + BKL - 1)/BKL;
+  const long long total = (long long)nkb*ktiles;
+  const long long per = (total + ksplit - 1)/ksplit;
+  const long long t_lo = split*per, t_hi = t_lo + per < total ? t_lo + per : total;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // each thread stages 8 (row, k-pair) items per operand: 128 rows x 16 pairs; the fast thread
+  // index follows the operand's contiguous axis (rows when transposed, k pairs otherwise)
+  constexpr int NP = BM2*(BKL/2)/256;
+  float2 ra[NP], rb[NP];
+  auto item = [&](int e, bool trans, int& row, int& kp) {
+    if (trans) { row = e % BM2; kp = e / BM2; } else { kp = e % (BKL/2); row = e / (BKL/2); }
+  };
+  auto fetch = [&](long long t) {
+    const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BKL;
+    const float* A = p.A + (long long)b*p.a_bs + (long long)kb*p.a_kbs;
+    const float* B = p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs;
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+      int row, kp;
+      item(tid + r*256, TA, row, kp);
+      const int m = m0 + row, k = k0 + 2*kp;
+      float2 v = make_float2(0.f, 0.f);
+      if (m < p.M) {
+        if (k < p.K) v.x = TA ? A[(long long)k*p.lda + m] : A[(long long)m*p.lda + k];
+        if (k + 1 < p.K) v.y = TA ? A[(long long)(k + 1)*p.lda + m] : A[(long long)m*p.lda + k + 1];
+      }
+      ra[r] = v;
+      item(tid + r*256, !TB, row, kp);
+      const int n = n0 + row;
+      v = make_float2(0.f, 0.f);
+      if (n < p.N) {
+        if (k0 + 2*kp < p.K)
+          v.x = TB ? B[(long long)n*p.ldb + k0 + 2*kp] : B[(long long)(k0 + 2*kp)*p.ldb + n];
+        if (k0 + 2*kp + 1 < p.K)
+          v.y = TB ? B[(long long)n*p.ldb + k0 + 2*kp + 1] : B[(long long)(k0 + 2*kp + 1)*p.ldb + n];
+      }
+      rb[r] = v;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int r = 0; r < NP; ++r) {
+      int row, kp;
+      item(tid + r*256, TA, row, kp);
+      *reinterpret_cast<unsigned int*>(&As[row][2*kp]) =
+          (unsigned int)f2bf(ra[r].x) | ((unsigned int)f2bf(ra[r].y) << 16);
+      item(tid + r*256, !TB, row, kp);
+      *reinterpret_cast<unsigned int*>(&Bs[row][2*kp]) =
+          (unsigned int)f2bf(rb[r].x) | ((unsigned int)f2bf(rb[r].y) << 16);
+    }
+  };
+  if (t_lo < t_hi) fetch(t_lo);
+  for (long long t = t_lo; t < t_hi; ++t) {
+    __syncthreads();
+    stash();
+    __syncthreads();
+    if (t + 1 < t_hi) fetch(t + 1);
+    const int c = lane & 31, kh = (lane >> 5)*8;
+#pragma unroll
+    for (int s = 0; s < BKL/16; ++s) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[64*wm + c][16*s + kh]);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[64*wm + 32 + c][16*s + kh]);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[64*wn + c][16*s + kh]);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[64*wn + 32 + c][16*s + kh]);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  float* D = p.D + (long long)b*p.d_bs;
+#pragma unroll
+  for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj) {
+      const int col = n0 + 64*wn + 32*fj + (lane & 31);
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + 64*wm + 32*fi + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
+        if (row >= p.M) continue;
+        float v = acc[fi][fj][i];
+        float* d = D + (long long)row*p.ldd + col;
+        if (ksplit > 1) {
+          if (split == 0 && p.row_bias) v += p.row_bias[row];
+          atomicAdd(d, v);
+        } else {
+          if (p.row_bias) v += p.row_bias[row];
+          if (p.accumulate) v += *d;
+          *d = v;
+        }
+      }
+    }
+}
+
 // Windowed overlap-add with window-envelope normalisation (torch.istft, center=True):
 //   y[q] = sum_t frames[t][q + n/2 - t*hop] / sum_t w^2[q + n/2 - t*hop],  q < hop*(F-1)
 struct OlaParams {
@@ -413,11 +531,12 @@ int brv_framed_dft_transpose(const float* spec, const float* basis, float* frame
 // gradients, brever/models/ffnn/ffnn.py:151-171):
 //   d[z] (M x N) (+)= sum_kb op_a(a[z, kb]) (M x K) @ op_b(b[z, kb]) (K x N) + row_bias[m]
 // op_a = transpose iff trans_a (a stored K x M), op_b likewise (b stored N x K).
-int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
-                 int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
-                 int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
-                 int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
-                 const float* row_bias, int accumulate, brv_stream_t stream) {
+static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t batch, int64_t M,
+                    int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd,
+                    int64_t a_batch_stride, int64_t b_batch_stride, int64_t d_batch_stride,
+                    int trans_a, int trans_b, int64_t kbatch, int64_t a_kbatch_stride,
+                    int64_t b_kbatch_stride, const float* row_bias, int accumulate,
+                    brv_stream_t stream) {
   if (batch < 1 || M < 1 || N < 1 || K < 1) return -1;
   G32 p; memset(&p, 0, sizeof(p));
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
@@ -448,6 +567,17 @@ int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_
   }
   const dim3 grid((unsigned)((N + BN2 - 1)/BN2), (unsigned)((M + BM2 - 1)/BM2),
                   (unsigned)(batch*ksplit));
+  if (lowp) {
+    if (trans_a && trans_b)
+      hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, p, (int)ksplit);
+    else if (trans_a)
+      hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, p, (int)ksplit);
+    else if (trans_b)
+      hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, st, p, (int)ksplit);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, p, (int)ksplit);
+    return (int)hipGetLastError();
+  }
   if (trans_a && trans_b)
     hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p, (int)ksplit);
   else if (trans_a)
@@ -457,6 +587,25 @@ int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_
   else
     hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p, (int)ksplit);
   return (int)hipGetLastError();
+}
+
+int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
+                 int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
+                 int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                 int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
+                 const float* row_bias, int accumulate, brv_stream_t stream) {
+  return gemm_any(0, a, b, d, batch, M, N, K, lda, ldb, ldd, a_batch_stride, b_batch_stride,
+                  d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride, b_kbatch_stride,
+                  row_bias, accumulate, stream);
+}
+int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
+                  int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
+                  int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                  int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
+                  const float* row_bias, int accumulate, brv_stream_t stream) {
+  return gemm_any(1, a, b, d, batch, M, N, K, lda, ldb, ldd, a_batch_stride, b_batch_stride,
+                  d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride, b_kbatch_stride,
+                  row_bias, accumulate, stream);
 }
 
 int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,

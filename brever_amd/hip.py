@@ -87,6 +87,9 @@ SIGNATURES = {
     'brv_gemm_f32': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*10
                      + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_ptr,
                         ctypes.c_int, _c_ptr]),
+    'brv_gemm_bf16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*10
+                      + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_ptr,
+                         ctypes.c_int, _c_ptr]),
     'brv_fbe_power': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_compress': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.c_int, _c_f32, _c_ptr]),
     'brv_irm': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr]),

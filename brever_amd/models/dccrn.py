@@ -11,8 +11,8 @@ Forward and backward are ``torch.autograd.Function`` pieces whose two sides call
 kernels (``brv_im2col / brv_col2im / brv_complex_weight_pack`` around ``brv_gemm_f32``,
 ``brv_batchnorm2d_*``, ``brv_lstm_recurrent_*``, ``brv_gemm_f32``, ``brv_dccrn_apply_mask*``,
 ``brv_stft_forward`` / ``brv_istft_backward`` and its adjoint); torch only concatenates, slices
-and transposes between them. fp32 throughout (exact-fp32 MFMA matrix products; the reference's autocast has no counterpart
-here, ``use_amp`` is ignored).
+and transposes between them. fp32 activations throughout; ``use_amp`` runs the matrix products (convolutions, LSTM input
+projections) with bf16 operands and fp32 accumulation, otherwise on the exact-fp32 MFMA.
 """
 import torch
 import torch.nn as nn
@@ -109,11 +109,18 @@ class DCCRNMaskNet(_ParamOnly):
                               num_layers=lstm_layers)
 
 
+_AMP = {'on': False}      # set by DCCRN.loss / _enhance around the forward pass (use_amp)
+
+
 def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, trans_b=0,
-          kbatch=1, a_kbs=0, b_kbs=0, bias=None):
-    hip.check(hip.lib().brv_gemm_f32(
+          kbatch=1, a_kbs=0, b_kbs=0, bias=None, lowp=False):
+    """fp32 matrices in HBM; ``lowp``: operands rounded to bf16 inside the kernel, fp32
+    accumulation (``use_amp``), else the exact-fp32 MFMA."""
+    fn = hip.lib().brv_gemm_bf16 if lowp else hip.lib().brv_gemm_f32
+    hip.check(fn(
         hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
-        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_f32')
+        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()),
+        'brv_gemm_bf16' if lowp else 'brv_gemm_f32')
 
 
 def _im2col(x, geom, grid):
@@ -158,6 +165,7 @@ class _ComplexConvFunction(torch.autograd.Function):
         (kh, kw), (sh, sw), (ph, pw), (oph, opw) = geom4
         geom = geom4[:3]
         lib = hip.lib()
+        lowp = ctx.lowp = _AMP['on']
         x = x.contiguous()
         B, C2, H, W = x.shape
         Cin = C2//2
@@ -173,7 +181,7 @@ class _ComplexConvFunction(torch.autograd.Function):
             Ho, Wo = (H - 1)*sh - 2*ph + kh + oph, (W - 1)*sw - 2*pw + kw + opw
             col = torch.empty(B, 2*Cw, H*W, dtype=torch.float32, device=x.device)
             _gemm(wc, x, col, B, 2*Cw, H*W, 2*Cin, 2*Cw, H*W, H*W, 0, 2*Cin*H*W, 2*Cw*H*W,
-                  trans_a=1)
+                  trans_a=1, lowp=lowp)
             y = _col2im(col, bias, 2*Cout, (Ho, Wo), geom, (H, W))
         else:
             Cout = R
@@ -181,7 +189,7 @@ class _ComplexConvFunction(torch.autograd.Function):
             col = _im2col(x, geom, (Ho, Wo))
             y = torch.empty(B, 2*Cout, Ho, Wo, dtype=torch.float32, device=x.device)
             _gemm(wc, col, y, B, 2*Cout, Ho*Wo, 2*Cw, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cw*Ho*Wo,
-                  2*Cout*Ho*Wo, bias=bias)
+                  2*Cout*Ho*Wo, bias=bias, lowp=lowp)
         ctx.save_for_backward(x, wc)
         ctx.cfg = (geom, transpose, (H, W), (Ho, Wo), Cin, Cout, R, Cw, wr.shape)
         return y
@@ -193,19 +201,21 @@ class _ComplexConvFunction(torch.autograd.Function):
         geom, transpose, (H, W), (Ho, Wo), Cin, Cout, R, Cw, wshape = ctx.cfg
         dy = dy.contiguous()
         B = x.shape[0]
+        lowp = ctx.lowp
         dwc = torch.empty_like(wc)
         if transpose:
             dcol = _im2col(dy, geom, (H, W))                       # (B, 2*Cw, H*W)
             dx = torch.empty_like(x)
-            _gemm(wc, dcol, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, H*W, 0, 2*Cw*H*W, 2*Cin*H*W)
+            _gemm(wc, dcol, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, H*W, 0, 2*Cw*H*W, 2*Cin*H*W,
+                  lowp=lowp)
             _gemm(x, dcol, dwc, 1, 2*Cin, 2*Cw, H*W, H*W, H*W, 2*Cw, 0, 0, 0, trans_b=1,
-                  kbatch=B, a_kbs=2*Cin*H*W, b_kbs=2*Cw*H*W)
+                  kbatch=B, a_kbs=2*Cin*H*W, b_kbs=2*Cw*H*W, lowp=lowp)
         else:
             col = _im2col(x, geom, (Ho, Wo))                       # (B, 2*Cw, Ho*Wo)
             _gemm(dy, col, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, trans_b=1,
-                  kbatch=B, a_kbs=2*Cout*Ho*Wo, b_kbs=2*Cw*Ho*Wo)
+                  kbatch=B, a_kbs=2*Cout*Ho*Wo, b_kbs=2*Cw*Ho*Wo, lowp=lowp)
             _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,
-                  2*Cw*Ho*Wo, trans_a=1)                           # the buffer now holds dcol
+                  2*Cw*Ho*Wo, trans_a=1, lowp=lowp)                           # the buffer now holds dcol
             dx = _col2im(col, None, 2*Cin, (H, W), geom, (Ho, Wo))
         dwr = torch.empty(wshape, dtype=torch.float32, device=dy.device)
         dwi = torch.empty_like(dwr)
@@ -294,8 +304,9 @@ class _LSTMFunction(torch.autograd.Function):
         x = x.contiguous()
         B, T, I = x.shape
         H = w_hh.shape[1]
+        lowp = ctx.lowp = _AMP['on']
         gates = torch.empty(B, T, 4*H, dtype=torch.float32, device=x.device)
-        _gemm(x, w_ih, gates, 1, B*T, 4*H, I, I, I, 4*H, 0, 0, 0, trans_b=1)
+        _gemm(x, w_ih, gates, 1, B*T, 4*H, I, I, I, 4*H, 0, 0, 0, trans_b=1, lowp=lowp)
         bias = _CombineFunction.apply(b_ih.detach(), b_hh.detach(), 1.0)
         y = torch.empty(B, T, H, dtype=torch.float32, device=x.device)
         act = torch.empty(B, T, 4*H, dtype=torch.float32, device=x.device)
@@ -318,13 +329,14 @@ class _LSTMFunction(torch.autograd.Function):
                                                   hip.ptr(dy), hip.ptr(dg), B, T, H, hip.stream()),
                   'brv_lstm_recurrent_backward')
         dx = torch.empty_like(x)                                   # dg (BT, 4H) @ W_ih (4H, I)
-        _gemm(dg, w_ih, dx, 1, B*T, I, 4*H, 4*H, I, I, 0, 0, 0)
+        lowp = ctx.lowp
+        _gemm(dg, w_ih, dx, 1, B*T, I, 4*H, 4*H, I, I, 0, 0, 0, lowp=lowp)
         dw_ih = torch.empty_like(w_ih)                             # dg^T (4H, BT) @ x (BT, I)
-        _gemm(dg, x, dw_ih, 1, 4*H, I, B*T, 4*H, I, I, 0, 0, 0, trans_a=1)
+        _gemm(dg, x, dw_ih, 1, 4*H, I, B*T, 4*H, I, I, 0, 0, 0, trans_a=1, lowp=lowp)
         h_prev = torch.zeros_like(y)                               # hidden state entering step t
         h_prev[:, 1:] = y[:, :-1]
         dw_hh = torch.empty_like(w_hh)
-        _gemm(dg, h_prev, dw_hh, 1, 4*H, H, B*T, 4*H, H, H, 0, 0, 0, trans_a=1)
+        _gemm(dg, h_prev, dw_hh, 1, 4*H, H, B*T, 4*H, H, H, 0, 0, 0, trans_a=1, lowp=lowp)
         db = torch.empty(4*H, dtype=torch.float32, device=x.device)
         # column sums of dg (BT, 4H): row_sum over the transposed view (1, 4H, BT) needs a
         # contiguous (4H, BT) copy
@@ -471,12 +483,20 @@ class DCCRN(BreverBaseModel):
 
     def loss(self, batch, lengths, use_amp):
         inputs, labels = batch[:, 0], batch[:, 1]
-        outputs = self(inputs)                        # fp32 kernels; use_amp has no effect yet
+        _AMP['on'] = bool(use_amp)      # bf16-operand matrix products (the reference autocasts)
+        try:
+            outputs = self(inputs)
+        finally:
+            _AMP['on'] = False
         return self.criterion(outputs, labels, lengths).mean()
 
     def update(self, loss, scaler):
         super().update(loss, scaler, grad_clip=5.0)
 
     def _enhance(self, x, use_amp):
-        with torch.no_grad():
-            return self.forward(x.mean(axis=-2))
+        _AMP['on'] = bool(use_amp)
+        try:
+            with torch.no_grad():
+                return self.forward(x.mean(axis=-2))
+        finally:
+            _AMP['on'] = False

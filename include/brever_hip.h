@@ -173,6 +173,14 @@ int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_
                  int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
                  int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
                  const float* row_bias, int accumulate, brv_stream_t stream);
+/* The same product with the operands rounded to bf16 on their way into LDS and fp32
+ * accumulation (v_mfma_f32_32x32x16_bf16): the use_amp path of DCCRN's convolutions, LSTM
+ * projections and Linear layers (the reference autocasts them, models/dccrn/dccrn.py:113-121). */
+int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
+                  int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
+                  int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                  int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
+                  const float* row_bias, int accumulate, brv_stream_t stream);
 
 /* ---- FFNN mask model and log-mel features (models/ffnn/ffnn.py:72-203,
  * modules/features.py:142-205); fp32, (B, rows, frames) / complex64 (B, channels, bins*frames)

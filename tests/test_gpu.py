@@ -761,6 +761,19 @@ def test_dccrn_matches_reference(golden_dir):
         assert rel(y, torch.from_numpy(g['out_eval'])) <= 2e-4
         e = net.enhance(torch.stack([x, 0.5*x], dim=1))
     assert rel(e, torch.from_numpy(g['enhance'])) <= 2e-4
+    # use_amp: the matrix products take bf16 operands (fp32 accumulation and activations)
+    with torch.no_grad():
+        e16 = net.enhance(torch.stack([x, 0.5*x], dim=1), use_amp=True)
+    err = rel(e16, torch.from_numpy(g['enhance']))
+    assert 0 < err <= 5e-3, err
+    net.train()
+    net.zero_grad()
+    loss16 = net.loss(batch, lengths, True)
+    loss16.backward()
+    got16 = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+    assert torch.isfinite(got16).all() and torch.isfinite(loss16)
+    assert abs(float(loss16) - float(g['loss'])) <= 2e-3          # measured 3e-4
+    assert rel(got16, gold) <= 5e-2, rel(got16, gold)             # measured 1.7e-2
     # the base-class training step (clip 5.0 + Adam) runs and descends
     net.train()
     scaler = torch.amp.GradScaler('cuda', enabled=False)

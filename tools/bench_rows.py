@@ -70,6 +70,9 @@ def main():
         print(json.dumps(train_row('ffnn', 32, 2.0, 20, False)), flush=True)
     if 'dccrn' in rows:
         print(json.dumps(train_row('dccrn', 16, 4.0, 5, False)), flush=True)
+        row = train_row('dccrn', 16, 4.0, 5, True)
+        row['row'] += ' (use_amp: bf16 matrix products)'
+        print(json.dumps(row), flush=True)
     if 'sgmse' in rows:
         print(json.dumps(sgmse_row(4.0, 30)), flush=True)
 
