@@ -375,52 +375,49 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* dy, float
 
 // ---- convolution as GEMM: column matrices --------------------------------------------------
 // col[b][(c*kh + i)*kw + j][ho*Wo + wo] = x[b][c][ho*sh - ph + i][wo*sw - pw + j] (0 outside)
-__global__ __launch_bounds__(256) void im2col_kernel(const float* x, float* col, ConvGeom g,
-                                                     long long total) {
-  const long long HoWo = (long long)g.Ho*g.Wo;
-  GRID_STRIDE(idx, total) {
-    const long long pix = idx % HoWo;
-    long long r = idx / HoWo;
-    const int j = (int)(r % g.kw); r /= g.kw;
-    const int i = (int)(r % g.kh); r /= g.kh;
-    const int c = (int)(r % g.Cin);
-    const int b = (int)(r / g.Cin);
-    const int wo = (int)(pix % g.Wo), ho = (int)(pix / g.Wo);
+// grid (pixel blocks, C*kh*kw, B): one column-matrix row per blockIdx.y, 32-bit index math,
+// 4 pixels per thread
+__global__ __launch_bounds__(256) void im2col_kernel(const float* x, float* col, ConvGeom g) {
+  const int HoWo = g.Ho*g.Wo;
+  const int r = blockIdx.y, b = blockIdx.z;
+  const int j = r % g.kw, i = (r / g.kw) % g.kh, c = r / (g.kw*g.kh);
+  const float* xc = x + (long long)b*g.x_bs + (long long)c*g.H*g.W;
+  float* out = col + ((long long)b*gridDim.y + r)*HoWo;
+  const int p0 = (blockIdx.x*256 + threadIdx.x)*4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int pix = p0 + q;
+    if (pix >= HoWo) break;
+    const int ho = pix / g.Wo, wo = pix - ho*g.Wo;
     const int hi = ho*g.sh - g.ph + i, wi = wo*g.sw - g.pw + j;
-    float v = 0.f;
-    if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
-      v = x[(long long)b*g.x_bs + ((long long)c*g.H + hi)*g.W + wi];
-    col[idx] = v;
+    out[pix] = (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? xc[hi*g.W + wi] : 0.f;
   }
 }
 // the adjoint: y[b][c][h][w] = bias[c] + sum over the column entries that im2col filled from it
-// (g.H x g.W is the image, g.Ho x g.Wo the column grid)
+// (g.H x g.W is the image, g.Ho x g.Wo the column grid); grid (pixel blocks, C, B)
 __global__ __launch_bounds__(256) void col2im_kernel(const float* col, const float* bias, float* y,
-                                                     ConvGeom g, long long total) {
-  const long long HoWo = (long long)g.Ho*g.Wo;
-  GRID_STRIDE(idx, total) {
-    const int w = (int)(idx % g.W);
-    long long r = idx / g.W;
-    const int h = (int)(r % g.H); r /= g.H;
-    const int c = (int)(r % g.Cin);
-    const int b = (int)(r / g.Cin);
-    float acc = bias ? bias[c] : 0.f;
-    const float* cb = col + ((long long)b*g.Cin + c)*g.kh*g.kw*HoWo;
-    for (int i = 0; i < g.kh; ++i) {
-      const int hn = h + g.ph - i;
-      if (hn < 0 || hn % g.sh) continue;
-      const int ho = hn/g.sh;
-      if (ho >= g.Ho) continue;
-      for (int j = 0; j < g.kw; ++j) {
-        const int wn = w + g.pw - j;
-        if (wn < 0 || wn % g.sw) continue;
-        const int wo = wn/g.sw;
-        if (wo >= g.Wo) continue;
-        acc += cb[(long long)(i*g.kw + j)*HoWo + (long long)ho*g.Wo + wo];
-      }
+                                                     ConvGeom g) {
+  const int HoWo = g.Ho*g.Wo, HW = g.H*g.W;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int pix = blockIdx.x*256 + threadIdx.x;
+  if (pix >= HW) return;
+  const int h = pix / g.W, w = pix - h*g.W;
+  float acc = bias ? bias[c] : 0.f;
+  const float* cb = col + ((long long)b*gridDim.y + c)*g.kh*g.kw*HoWo;
+  for (int i = 0; i < g.kh; ++i) {
+    const int hn = h + g.ph - i;
+    if (hn < 0 || hn % g.sh) continue;
+    const int ho = hn/g.sh;
+    if (ho >= g.Ho) continue;
+    for (int j = 0; j < g.kw; ++j) {
+      const int wn = w + g.pw - j;
+      if (wn < 0 || wn % g.sw) continue;
+      const int wo = wn/g.sw;
+      if (wo >= g.Wo) continue;
+      acc += cb[(long long)(i*g.kw + j)*HoWo + ho*g.Wo + wo];
     }
-    y[(long long)b*g.y_bs + ((long long)c*g.H + h)*g.W + w] = acc;
   }
+  y[(long long)b*g.y_bs + (long long)c*HW + pix] = acc;
 }
 // complex weight as one real matrix: wc (2R x 2C) = [[wr, -s*wi], [s*wi, wr]], and its adjoint
 __global__ __launch_bounds__(256) void cweight_pack_kernel(const float* wr, const float* wi, float* wc,
@@ -783,9 +780,9 @@ int brv_im2col(const float* x, float* col, int64_t B, int64_t C, int64_t H, int6
   g.B = (int)B; g.Cin = (int)C; g.H = (int)H; g.W = (int)W; g.Cout = 0;
   g.kh = (int)kh; g.kw = (int)kw; g.sh = (int)sh; g.sw = (int)sw; g.ph = (int)ph; g.pw = (int)pw;
   g.Ho = (int)Ho; g.Wo = (int)Wo; g.x_bs = C*H*W; g.y_bs = 0;
-  const long long total = B*C*kh*kw*Ho*Wo;
-  hipLaunchKernelGGL(im2col_kernel, flat_grid(total), dim3(256), 0, (hipStream_t)stream, x, col, g,
-                     total);
+  if (C*kh*kw > 65535 || B > 65535 || H*W >= (1LL << 31) || Ho*Wo >= (1LL << 31)) return -2;
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((Ho*Wo + 1023)/1024), (unsigned)(C*kh*kw),
+                                         (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, col, g);
   DC_OK(hipGetLastError());
   return 0;
 }
@@ -797,9 +794,9 @@ int brv_col2im(const float* col, const float* bias, float* y, int64_t B, int64_t
   g.B = (int)B; g.Cin = (int)C; g.H = (int)H; g.W = (int)W; g.Cout = 0;
   g.kh = (int)kh; g.kw = (int)kw; g.sh = (int)sh; g.sw = (int)sw; g.ph = (int)ph; g.pw = (int)pw;
   g.Ho = (int)Ho; g.Wo = (int)Wo; g.x_bs = 0; g.y_bs = C*H*W;
-  const long long total = B*C*H*W;
-  hipLaunchKernelGGL(col2im_kernel, flat_grid(total), dim3(256), 0, (hipStream_t)stream, col, bias,
-                     y, g, total);
+  if (C > 65535 || B > 65535 || H*W >= (1LL << 31) || Ho*Wo >= (1LL << 31)) return -2;
+  hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((H*W + 255)/256), (unsigned)C, (unsigned)B),
+                     dim3(256), 0, (hipStream_t)stream, col, bias, y, g);
   DC_OK(hipGetLastError());
   return 0;
 }
