@@ -86,9 +86,24 @@ def _conv(x, mod, fold=None, silu=False, res=None, out_scale=1.0):
         x = _affine_act(x, fold, silu)
     Ho, Wo = (H + 2*ph - kh)//sh + 1, (W + 2*pw - kw)//sw + 1
     y = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
-    hip.check(hip.lib().brv_conv2d_forward(
-        hip.ptr(x), hip.ptr(mod.weight), hip.ptr(mod.bias), hip.ptr(y), B, Cin, H, W, Cout, kh, kw,
-        sh, sw, ph, pw, Cin*H*W, Cout*Ho*Wo, 0, 1.0, hip.stream()), 'brv_conv2d_forward')
+    lib = hip.lib()
+    K = Cin*kh*kw
+    if Cout >= 16 and K >= 16:
+        # fp32 path: column matrix + one exact-fp32 MFMA product per item (a 1x1 convolution
+        # is the product on the image itself)
+        if (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0):
+            col = x
+        else:
+            col = torch.empty(B, K, Ho*Wo, dtype=torch.float32, device=x.device)
+            hip.check(lib.brv_im2col(hip.ptr(x), hip.ptr(col), B, Cin, H, W, kh, kw, sh, sw, ph, pw,
+                                     Ho, Wo, hip.stream()), 'brv_im2col')
+        hip.check(lib.brv_gemm_f32(
+            hip.ptr(mod.weight), hip.ptr(col), hip.ptr(y), B, Cout, Ho*Wo, K, K, Ho*Wo, Ho*Wo, 0,
+            K*Ho*Wo, Cout*Ho*Wo, 0, 0, 1, 0, 0, hip.ptr(mod.bias), 0, hip.stream()), 'brv_gemm_f32')
+    else:
+        hip.check(lib.brv_conv2d_forward(
+            hip.ptr(x), hip.ptr(mod.weight), hip.ptr(mod.bias), hip.ptr(y), B, Cin, H, W, Cout, kh,
+            kw, sh, sw, ph, pw, Cin*H*W, Cout*Ho*Wo, 0, 1.0, hip.stream()), 'brv_conv2d_forward')
     if res is not None or out_scale != 1.0:
         y = _axpby(y, out_scale, res, out_scale)
     return y
