@@ -247,9 +247,14 @@ def snr(x, y, lengths):
 @CriterionRegistry.register('mse')
 def mse(x, y, lengths, weight=None):
     """Masked mean squared error, ``(B, ..., L)`` -> ``(B,)``
-    (brever/criterion.py:104-132); real inputs (complex spectrograms: not built)."""
+    (brever/criterion.py:104-132); real or complex inputs."""
     assert x.shape == y.shape
     assert x.ndim >= 2
     if x.is_complex() or y.is_complex():
-        raise NotImplementedError('complex mse is not built yet on the HIP path')
-    return _MseFunction.apply(x, y, lengths, weight)
+        # |x - y|^2 = re^2 + im^2: the real / imaginary parts become an extra middle axis of
+        # size 2 (whose mean halves the sum) in front of the masked time axis
+        xr = torch.view_as_real(x.to(torch.complex64)).movedim(-1, -2).contiguous()
+        yr = torch.view_as_real(y.to(torch.complex64)).movedim(-1, -2).contiguous()
+        w = weight.reshape(-1) if weight is not None else None
+        return 2.0*_MseFunction.apply(xr, yr, lengths, w)
+    return _MseFunction.apply(x, y, lengths, weight.reshape(-1) if weight is not None else None)

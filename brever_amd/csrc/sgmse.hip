@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, const flo
 __global__ __launch_bounds__(64) void gn_fold_kernel(double* sums, const float* add,
                                                      const float* gamma, const float* beta,
                                                      const float* adm_scale, const float* adm_shift,
-                                                     float* scale, float* shift, int C,
-                                                     long long HW, int groups, float eps) {
+                                                     float* scale, float* shift, float* mu_out,
+                                                     float* rstd_out, int C, long long HW,
+                                                     int groups, float eps) {
   const int bg = blockIdx.x, b = bg / groups, g = bg % groups;
   const int cpg = C/groups;
   const double n = (double)cpg*(double)HW;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(64) void gn_fold_kernel(double* sums, const float* 
     float sh = beta[c] + ((add ? add[idx] : 0.f) - (float)mean)*sc;
     if (adm_scale) { const float m = 1.f + adm_scale[idx]; sc *= m; sh = sh*m + adm_shift[idx]; }
     scale[idx] = sc; shift[idx] = sh;
+    if (mu_out) { mu_out[idx] = (float)mean - (add ? add[idx] : 0.f); rstd_out[idx] = rstd; }
   }
 }
 
@@ -106,6 +108,106 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* x, const f
     const float t = scale[i/HW]*x[i] + shift[i/HW];
     y[i] = act ? silu(t) : t;
   }
+}
+
+// ---- backward of y = act(GroupNorm(x + add)) in the folded form ------------------------------
+// pre = scale*x + shift, u = dy*act'(pre), xhat = (x - mu)*rstd (mu = group mean - add).
+// (1) per (item, channel): s1 = sum u, s2 = sum u*xhat, s3 = sum xhat over the pixels (fp64
+// partials per slice); (2) per (item, group): A = sum_c gamma s1, Bg = sum_c gamma s2 and the
+// coefficients of dx = k1*u + k2*xhat + k3 with k1 = rstd*gamma, k2 = -rstd*Bg/n, k3 =
+// -rstd*A/n, plus d add = k1*s1 + k2*s3 + k3*HW; (3) the elementwise pass.
+__device__ __forceinline__ float dsilu(float p) {
+  const float sg = 1.f/(1.f + expf(-p));
+  return sg*(1.f + p*(1.f - sg));
+}
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float* x, const float* dy,
+                                                          const float* scale, const float* shift,
+                                                          const float* mu, const float* rstd,
+                                                          double* part, long long HW, int act) {
+  __shared__ double scr[8];
+  const long long bc = blockIdx.x;
+  const long long per = (HW + gridDim.y - 1)/gridDim.y;
+  const long long lo = blockIdx.y*per, hi = lo + per < HW ? lo + per : HW;
+  const float sc = scale[bc], sh = shift[bc], m = mu[bc], r = rstd[bc];
+  const float* xp = x + bc*HW; const float* dp = dy + bc*HW;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float xv = xp[i];
+    const float u = act ? dp[i]*dsilu(sc*xv + sh) : dp[i];
+    const float xh = (xv - m)*r;
+    s1 += u; s2 += (double)u*xh; s3 += xh;
+  }
+  s1 = block_sum(s1, scr); __syncthreads();
+  s2 = block_sum(s2, scr); __syncthreads();
+  s3 = block_sum(s3, scr);
+  if (threadIdx.x == 0) {
+    double* o = part + (bc*gridDim.y + blockIdx.y)*3;
+    o[0] = s1; o[1] = s2; o[2] = s3;
+  }
+}
+__global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const double* part, int slices,
+                                                         const float* gamma, const float* rstd,
+                                                         float* k1, float* k2, float* k3,
+                                                         float* s1_out, float* s2_out, float* dadd,
+                                                         int C, long long HW, int groups) {
+  __shared__ double gs1[64], gs2[64];              // gamma-weighted sums of the group's channels
+  const int bg = blockIdx.x, b = bg / groups, g = bg % groups;
+  const int cpg = C/groups, j = threadIdx.x;       // cpg <= 64 (checked by the caller)
+  const long long bc = (long long)b*C + g*cpg + j;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  float gm = 0.f;
+  if (j < cpg) {
+    for (int i = 0; i < slices; ++i) {
+      const double* o = part + (bc*slices + i)*3;
+      s1 += o[0]; s2 += o[1]; s3 += o[2];
+    }
+    gm = gamma[g*cpg + j];
+    s1_out[bc] = (float)s1; s2_out[bc] = (float)s2;
+  }
+  gs1[j] = gm*s1; gs2[j] = gm*s2;
+  __syncthreads();
+  double A = 0.0, Bg = 0.0;
+  for (int t = 0; t < cpg; ++t) { A += gs1[t]; Bg += gs2[t]; }
+  if (j < cpg) {
+    const double n = (double)cpg*(double)HW;
+    const float r = rstd[bc];
+    const float c1 = r*gm, c2 = (float)(-r*Bg/n), c3 = (float)(-r*A/n);
+    k1[bc] = c1; k2[bc] = c2; k3[bc] = c3;
+    if (dadd) dadd[bc] = (float)(c1*s1 + c2*s3 + c3*(double)HW);
+  }
+}
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* x, const float* dy,
+                                                           const float* scale, const float* shift,
+                                                           const float* mu, const float* rstd,
+                                                           const float* k1, const float* k2,
+                                                           const float* k3, float* dx, long long HW,
+                                                           long long total, int act) {
+  GRID_STRIDE(i, total) {
+    const long long bc = i/HW;
+    const float xv = x[i];
+    const float u = act ? dy[i]*dsilu(scale[bc]*xv + shift[bc]) : dy[i];
+    dx[i] = k1[bc]*u + k2[bc]*(xv - mu[bc])*rstd[bc] + k3[bc];
+  }
+}
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* x, const float* dy, float* dx,
+                                                       long long n) {
+  GRID_STRIDE(i, n) dx[i] = dy[i]*dsilu(x[i]);
+}
+// dx = p*(dy - sum_j dy_j p_j) per row
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* p, const float* dy, float* dx,
+                                                          int cols) {
+  __shared__ float red[8];
+  __shared__ float bc;
+  const float* pr = p + (long long)blockIdx.x*cols;
+  const float* dr = dy + (long long)blockIdx.x*cols;
+  float* xr = dx + (long long)blockIdx.x*cols;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) s += pr[i]*dr[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) bc = s;
+  __syncthreads();
+  const float dot = bc;
+  for (int i = threadIdx.x; i < cols; i += 256) xr[i] = pr[i]*(dr[i] - dot);
 }
 
 __global__ __launch_bounds__(256) void silu_kernel(const float* x, float* y, long long n) {
@@ -210,8 +312,8 @@ int64_t brv_groupnorm_scratch_bytes(int64_t B, int64_t groups) {
 }
 int brv_groupnorm_fold(const float* x, const float* add_bc, const float* gamma, const float* beta,
                        const float* adm_scale, const float* adm_shift, void* scratch, float* scale,
-                       float* shift, int64_t B, int64_t C, int64_t HW, int64_t groups, float eps,
-                       brv_stream_t stream) {
+                       float* shift, float* mu_bc, float* rstd_bc, int64_t B, int64_t C, int64_t HW,
+                       int64_t groups, float eps, brv_stream_t stream) {
   if (B < 1 || C < 1 || HW < 1 || groups < 1 || C % groups) return -1;
   hipStream_t st = (hipStream_t)stream;
   const long long n = (C/groups)*HW;
@@ -222,7 +324,7 @@ int brv_groupnorm_fold(const float* x, const float* add_bc, const float* gamma, 
                      st, x, add_bc, (double*)scratch, (int)C, (long long)HW, (int)groups, slice);
   hipLaunchKernelGGL(gn_fold_kernel, dim3((unsigned)(B*groups)), dim3(64), 0, st,
                      (double*)scratch, add_bc, gamma, beta, adm_scale, adm_shift, scale, shift,
-                     (int)C, (long long)HW, (int)groups, eps);
+                     mu_bc, rstd_bc, (int)C, (long long)HW, (int)groups, eps);
   SG_OK(hipGetLastError());
   return 0;
 }
@@ -232,6 +334,45 @@ int brv_affine_act(const float* x, const float* scale_bc, const float* shift_bc,
   const long long total = B*C*HW;
   hipLaunchKernelGGL(affine_act_kernel, flat_grid(total/4 + 1), dim3(256), 0, (hipStream_t)stream,
                      x, scale_bc, shift_bc, y, (long long)HW, total, act_silu);
+  SG_OK(hipGetLastError());
+  return 0;
+}
+int brv_groupnorm_backward(const float* x, const float* dy, const float* scale_bc,
+                           const float* shift_bc, const float* mu_bc, const float* rstd_bc,
+                           const float* gamma, float* dx, float* s1_bc, float* s2_bc, float* dadd_bc,
+                           float* coef_scratch, int64_t B, int64_t C, int64_t HW, int64_t groups,
+                           int act_silu, brv_stream_t stream) {
+  if (B < 1 || C < 1 || HW < 1 || groups < 1 || C % groups || C/groups > 64) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  long long slices = (HW + 16383)/16384;
+  if (slices > 32) slices = 32;
+  double* part = nullptr;
+  SG_OK(hipMallocAsync((void**)&part, (size_t)B*C*slices*3*sizeof(double), st));
+  hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3((unsigned)(B*C), (unsigned)slices), dim3(256), 0, st, x,
+                     dy, scale_bc, shift_bc, mu_bc, rstd_bc, part, (long long)HW, act_silu);
+  float* k1 = coef_scratch; float* k2 = k1 + B*C; float* k3 = k2 + B*C;
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((unsigned)(B*groups)), dim3(64), 0, st, part,
+                     (int)slices, gamma, rstd_bc, k1, k2, k3, s1_bc, s2_bc, dadd_bc, (int)C,
+                     (long long)HW, (int)groups);
+  SG_OK(hipFreeAsync(part, st));
+  const long long total = B*C*HW;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, flat_grid(total), dim3(256), 0, st, x, dy, scale_bc,
+                     shift_bc, mu_bc, rstd_bc, k1, k2, k3, dx, (long long)HW, total, act_silu);
+  SG_OK(hipGetLastError());
+  return 0;
+}
+int brv_silu_backward(const float* x, const float* dy, float* dx, int64_t n, brv_stream_t stream) {
+  if (n < 1) return -1;
+  hipLaunchKernelGGL(silu_bwd_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, x, dy, dx,
+                     (long long)n);
+  SG_OK(hipGetLastError());
+  return 0;
+}
+int brv_softmax_rows_backward(const float* p, const float* dy, float* dx, int64_t rows, int64_t cols,
+                              brv_stream_t stream) {
+  if (rows < 1 || cols < 1) return -1;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p,
+                     dy, dx, (int)cols);
   SG_OK(hipGetLastError());
   return 0;
 }

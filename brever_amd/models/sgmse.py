@@ -10,8 +10,8 @@ on the fp16 MFMA with folded group norms, ``hip_autocast``); torch draws the Gau
 tensors and holds the parameters.
 
 Built: every SDE, both solvers (``pc``, ``edm``), all three preconditionings and every
-encoder / decoder / block type of ``DiffusionUNet``. Not built yet: training (``loss`` needs
-the backward pass of the U-Net and raises ``NotImplementedError``).
+encoder / decoder / block type of ``DiffusionUNet``; training (``loss``) runs the differentiable
+fp32 network of ``sgmse_train.py`` (``block_type='adm'`` not built for training).
 """
 import math
 import os
@@ -127,7 +127,7 @@ def _gn_fold(x, mod, add=None, adm=None):
     hip.check(lib.brv_groupnorm_fold(
         hip.ptr(x), hip.ptr(add.contiguous()) if add is not None else None, hip.ptr(mod.weight),
         hip.ptr(mod.bias), hip.ptr(a0), hip.ptr(a1), hip.ptr(scratch), hip.ptr(scale),
-        hip.ptr(shift), B, C, H*W, mod.num_groups, float(mod.eps), hip.stream()),
+        hip.ptr(shift), None, None, B, C, H*W, mod.num_groups, float(mod.eps), hip.stream()),
         'brv_groupnorm_fold')
     return scale, shift
 
@@ -192,9 +192,10 @@ class Resample(nn.Module):
         self.register_buffer('kernel', kernel)
         self._paddings = [] if buffer_padding else None
 
-    def forward(self, x, up_or_down):
-        x = x.contiguous()
-        B, C, H, W = x.shape
+    def plan(self, shape, up_or_down):
+        """(padding, output (H, W), is_up) of one call; 'down' calls push their padding on the
+        stack that the matching 'up' calls pop (resampling.py:30-55)."""
+        H, W = shape[-2:]
         K = self.kernel.shape[-1]
         if up_or_down == 'down':
             padding = tuple(math.ceil(K/2) - 1 if dim % 2 == 0 else math.ceil((K + 1)/2) - 1
@@ -203,22 +204,26 @@ class Resample(nn.Module):
                 out_pad = tuple(0 if (dim + 2*pad - K) % 2 == 0 else 1
                                 for dim, pad in zip((H, W), padding))
                 self._paddings.append((padding, out_pad))
-            Ho, Wo = (H + 2*padding[0] - K)//2 + 1, (W + 2*padding[1] - K)//2 + 1
-            up, gain = 0, 1.0
-        elif up_or_down == 'up':
+            return padding, ((H + 2*padding[0] - K)//2 + 1, (W + 2*padding[1] - K)//2 + 1), False
+        if up_or_down == 'up':
             if self._paddings is not None:
                 padding, out_pad = self._paddings.pop()
             else:
                 padding, out_pad = ((K - 1)//2,)*2, (0, 0)
-            Ho = (H - 1)*2 - 2*padding[0] + K + out_pad[0]
-            Wo = (W - 1)*2 - 2*padding[1] + K + out_pad[1]
-            up, gain = 1, 4.0
-        else:
-            raise ValueError(f'up_or_down must be up or down, got {up_or_down}')
+            return padding, ((H - 1)*2 - 2*padding[0] + K + out_pad[0],
+                             (W - 1)*2 - 2*padding[1] + K + out_pad[1]), True
+        raise ValueError(f'up_or_down must be up or down, got {up_or_down}')
+
+    def forward(self, x, up_or_down):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        K = self.kernel.shape[-1]
+        padding, (Ho, Wo), up = self.plan(x.shape, up_or_down)
         y = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=x.device)
         hip.check(hip.lib().brv_fir_resample2d(
             hip.ptr(x), hip.ptr(self.kernel.float().contiguous()), hip.ptr(y), B*C, H, W, Ho, Wo, K,
-            padding[0], padding[1], up, gain, hip.stream()), 'brv_fir_resample2d')
+            padding[0], padding[1], int(up), 4.0 if up else 1.0, hip.stream()),
+            'brv_fir_resample2d')
         return y
 
 
@@ -764,6 +769,21 @@ class Preconditioning(nn.Module):
         net_out = torch.complex(net_out[:, 0], net_out[:, 1]).unsqueeze(1)
         return _axpby(x, float(cskip), net_out, float(cout))
 
+    def forward_train(self, x, y, sigma, t):
+        """The same denoiser with per-item noise levels (``sigma``, ``t`` of shape (B, 1, 1, 1) on
+        the device) and gradients with respect to the network parameters (the training
+        objective, sgmse.py:163-176); the pre / post scaling are a few elementwise torch ops on
+        (B, 1, F, T), the network is ``sgmse_train.unet``."""
+        from . import sgmse_train
+        scaling = self.sde.s(t)
+        cskip, cout = self.cskip(sigma), self.cout(sigma, scaling, t)
+        cin = self.cin(sigma, scaling)
+        x_in = cin*x + self.cshift(cin, scaling)*y
+        net_in = torch.cat([x_in.real, x_in.imag, y.real, y.imag], dim=1).float().contiguous()
+        net_out = sgmse_train.unet(self.net, net_in, self.cnoise(sigma, t).float())
+        net_out = torch.complex(net_out[:, 0], net_out[:, 1]).unsqueeze(1)
+        return cskip*x + cout*net_out
+
     def score(self, x, y, sigma, t):
         d = self(x, y, sigma, t)
         c = 1.0/float(self.sde.s(t)*sigma**2)
@@ -952,9 +972,23 @@ class SGMSEp(BreverBaseModel):
         return self.model(x.to(torch.complex64), y.to(torch.complex64),
                           torch.as_tensor(sigma).float().cpu(), torch.as_tensor(t).float().cpu())
 
+    def _draw_t(self, n, device):
+        return torch.rand(n, 1, 1, 1, device=device)*(1 - self.t_eps) + self.t_eps
+
+    def _draw_noise(self, x_0):
+        return torch.randn_like(x_0)
+
     def loss(self, batch, lengths, use_amp):
-        raise NotImplementedError('SGMSE+ training (backward pass of the score network) is not '
-                                  'built yet on the HIP path')
+        """Denoising score matching objective (sgmse.py:163-176): fp32 kernels, ``use_amp`` is
+        not used for training yet."""
+        hip.require_device(batch)
+        y, x_0 = batch[:, 0].unsqueeze(1), batch[:, 1].unsqueeze(1)     # noisy, clean
+        t = self._draw_t(x_0.shape[0], y.device)
+        sigma = self.sde.sigma(t)
+        n = sigma*self._draw_noise(x_0)
+        weight = self.model.weight(sigma)
+        d = self.model.forward_train(x_0 - y + n, y, sigma, t)
+        return self.criterion(d, x_0 - y, lengths, weight=weight).mean()
 
     @torch.no_grad()
     def _enhance(self, x, use_amp):

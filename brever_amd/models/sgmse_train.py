@@ -1,0 +1,352 @@
+"""Differentiable forward of the SGMSE+ score network for training (``SGMSEp.loss``).
+
+The inference path of ``sgmse.py`` launches bare kernels; here the same operators are
+``torch.autograd.Function`` pairs whose two sides call ``libbrever_hip.so`` (fp32: column
+matrix + exact-fp32 MFMA products for the convolutions and their weight / data gradients,
+``brv_groupnorm_fold / brv_affine_act / brv_groupnorm_backward``, ``brv_silu*``,
+``brv_fir_resample2d`` in both directions, ``brv_softmax_rows*``). The block structure follows
+brever/models/sgmse/net.py:232-452 exactly as the inference path does; torch only
+concatenates, slices and carries the autograd graph. ``block_type='adm'`` is not built for
+training.
+"""
+import torch
+
+from .. import hip
+
+
+def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, trans_b=0,
+          kbatch=1, a_kbs=0, b_kbs=0, bias=None):
+    hip.check(hip.lib().brv_gemm_f32(
+        hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
+        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_f32')
+
+
+def _empty(*shape, like):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+class ConvFn(torch.autograd.Function):
+    """nn.Conv2d (stride 1, 'same' padding k//2): y_b = W (Cout x Cin*k*k) @ col_b + bias."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        Cout, _, k, _ = w.shape
+        K, HW = Cin*k*k, H*W
+        col = ConvFn._col(x, k)
+        y = _empty(B, Cout, H, W, like=x)
+        _gemm(w, col, y, B, Cout, HW, K, K, HW, HW, 0, K*HW, Cout*HW, bias=bias)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def _col(x, k):
+        if k == 1:
+            return x
+        B, Cin, H, W = x.shape
+        col = _empty(B, Cin*k*k, H*W, like=x)
+        hip.check(hip.lib().brv_im2col(hip.ptr(x), hip.ptr(col), B, Cin, H, W, k, k, 1, 1, k//2,
+                                       k//2, H, W, hip.stream()), 'brv_im2col')
+        return col
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Cin, H, W = x.shape
+        Cout, _, k, _ = w.shape
+        K, HW = Cin*k*k, H*W
+        col = ConvFn._col(x, k)
+        dw = torch.empty_like(w)
+        _gemm(dy, col, dw, 1, Cout, K, HW, HW, HW, K, 0, 0, 0, trans_b=1, kbatch=B,
+              a_kbs=Cout*HW, b_kbs=K*HW)
+        db = _empty(Cout, like=x)
+        hip.check(hip.lib().brv_row_sum(hip.ptr(dy), hip.ptr(db), B, Cout, HW, hip.stream()),
+                  'brv_row_sum')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dcol = col if k != 1 else _empty(B, K, HW, like=x)
+            _gemm(w, dy, dcol, B, K, HW, Cout, K, HW, HW, 0, Cout*HW, K*HW, trans_a=1)
+            if k == 1:
+                dx = dcol.view(B, Cin, H, W)
+            else:
+                dx = torch.empty_like(x)
+                hip.check(hip.lib().brv_col2im(hip.ptr(dcol), None, hip.ptr(dx), B, Cin, H, W, k, k,
+                                               1, 1, k//2, k//2, H, W, hip.stream()), 'brv_col2im')
+        return dx, dw, db
+
+
+class GroupNormFn(torch.autograd.Function):
+    """act(GroupNorm(x + add[:, :, None, None])), act = SiLU or identity."""
+
+    @staticmethod
+    def forward(ctx, x, add, gamma, beta, groups, eps, silu):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        lib = hip.lib()
+        scratch = torch.zeros(lib.brv_groupnorm_scratch_bytes(B, groups), dtype=torch.uint8,
+                              device=x.device)
+        scale, shift, mu, rstd = (_empty(B, C, like=x) for _ in range(4))
+        addc = add.contiguous() if add is not None else None
+        hip.check(lib.brv_groupnorm_fold(
+            hip.ptr(x), hip.ptr(addc), hip.ptr(gamma), hip.ptr(beta), None, None, hip.ptr(scratch),
+            hip.ptr(scale), hip.ptr(shift), hip.ptr(mu), hip.ptr(rstd), B, C, H*W, groups,
+            float(eps), hip.stream()), 'brv_groupnorm_fold')
+        y = torch.empty_like(x)
+        hip.check(lib.brv_affine_act(hip.ptr(x), hip.ptr(scale), hip.ptr(shift), hip.ptr(y), B, C,
+                                     H*W, int(silu), hip.stream()), 'brv_affine_act')
+        ctx.save_for_backward(x, gamma, scale, shift, mu, rstd)
+        ctx.cfg = (groups, bool(silu), add is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, scale, shift, mu, rstd = ctx.saved_tensors
+        groups, silu, has_add = ctx.cfg
+        dy = dy.contiguous()
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        s1, s2, dadd = (_empty(B, C, like=x) for _ in range(3))
+        coef = _empty(3*B*C, like=x)
+        hip.check(hip.lib().brv_groupnorm_backward(
+            hip.ptr(x), hip.ptr(dy), hip.ptr(scale), hip.ptr(shift), hip.ptr(mu), hip.ptr(rstd),
+            hip.ptr(gamma), hip.ptr(dx), hip.ptr(s1), hip.ptr(s2), hip.ptr(dadd), hip.ptr(coef), B,
+            C, H*W, groups, int(silu), hip.stream()), 'brv_groupnorm_backward')
+        # d gamma / d beta: (B, C) -> (C,), a handful of values
+        return dx, (dadd if has_add else None), s2.sum(0), s1.sum(0), None, None, None
+
+
+class SiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        hip.check(hip.lib().brv_silu(hip.ptr(x), hip.ptr(y), x.numel(), hip.stream()), 'brv_silu')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        hip.check(hip.lib().brv_silu_backward(hip.ptr(x), hip.ptr(dy), hip.ptr(dx), x.numel(),
+                                              hip.stream()), 'brv_silu_backward')
+        return dx
+
+
+def _axpby_raw(a, alpha, b, beta):
+    out = torch.empty_like(a)
+    hip.check(hip.lib().brv_axpby(hip.ptr(a), float(alpha), hip.ptr(b), float(beta), hip.ptr(out),
+                                  a.numel(), hip.stream()), 'brv_axpby')
+    return out
+
+
+class AxpbyFn(torch.autograd.Function):
+    """alpha*a + beta*b (b may be None)."""
+
+    @staticmethod
+    def forward(ctx, a, alpha, b, beta):
+        ctx.coef = (float(alpha), float(beta), b is not None)
+        return _axpby_raw(a.contiguous(), alpha, b.contiguous() if b is not None else None, beta)
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, beta, has_b = ctx.coef
+        g = g.contiguous()
+        return (_axpby_raw(g, alpha, None, 0.0), None,
+                _axpby_raw(g, beta, None, 0.0) if has_b else None, None)
+
+
+class ResampleFn(torch.autograd.Function):
+    """Resample.forward with an explicit plan (padding, output size); the backward pass is the
+    adjoint FIR operator (down <-> up) with the same padding."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, up, pad, out_hw):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        K = kernel.shape[-1]
+        y = _empty(B, C, out_hw[0], out_hw[1], like=x)
+        hip.check(hip.lib().brv_fir_resample2d(
+            hip.ptr(x), hip.ptr(kernel), hip.ptr(y), B*C, H, W, out_hw[0], out_hw[1], K, pad[0],
+            pad[1], int(up), 4.0 if up else 1.0, hip.stream()), 'brv_fir_resample2d')
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (bool(up), pad, (H, W))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        kernel, = ctx.saved_tensors
+        up, pad, (H, W) = ctx.cfg
+        dy = dy.contiguous()
+        B, C, Ho, Wo = dy.shape
+        K = kernel.shape[-1]
+        dx = _empty(B, C, H, W, like=dy)
+        if up:       # adjoint of the transposed convolution with 4*kernel: strided FIR with 4*kernel
+            k4 = (4.0*kernel).contiguous()
+            hip.check(hip.lib().brv_fir_resample2d(
+                hip.ptr(dy), hip.ptr(k4), hip.ptr(dx), B*C, Ho, Wo, H, W, K, pad[0], pad[1], 0, 1.0,
+                hip.stream()), 'brv_fir_resample2d')
+        else:        # adjoint of the strided FIR: transposed convolution onto the input grid
+            hip.check(hip.lib().brv_fir_resample2d(
+                hip.ptr(dy), hip.ptr(kernel), hip.ptr(dx), B*C, Ho, Wo, H, W, K, pad[0], pad[1], 1,
+                1.0, hip.stream()), 'brv_fir_resample2d')
+        return dx, None, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """(N, I) -> (N, O) = x @ W^T + b."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x = x.contiguous()
+        N, I = x.shape
+        O = w.shape[0]
+        yt = _empty(O, N, like=x)
+        _gemm(w, x, yt, 1, O, N, I, I, I, N, 0, 0, 0, trans_b=1, bias=bias)
+        ctx.save_for_backward(x, w)
+        return yt.t().contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, I = x.shape
+        O = w.shape[0]
+        dx = _empty(N, I, like=x)
+        _gemm(dy, w, dx, 1, N, I, O, O, I, I, 0, 0, 0)
+        dw = torch.empty_like(w)
+        _gemm(dy, x, dw, 1, O, I, N, O, I, I, 0, 0, 0, trans_a=1)
+        return dx, dw, dy.sum(0)
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """softmax(q^T k / sqrt(C)) applied to v, on (N, C, L) maps (net.py:432-443)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        N, C, L = q.shape
+        lib = hip.lib()
+        w = _empty(N, L, L, like=q)
+        _gemm(q, k, w, N, L, L, C, L, L, L, C*L, C*L, L*L, trans_a=1)
+        w = _axpby_raw(w, 1.0/C**0.5, None, 0.0)
+        p = torch.empty_like(w)
+        hip.check(lib.brv_softmax_rows(hip.ptr(w), hip.ptr(p), N*L, L, hip.stream()),
+                  'brv_softmax_rows')
+        a = _empty(N, C, L, like=q)
+        _gemm(v, p, a, N, C, L, L, L, L, L, C*L, L*L, C*L, trans_b=1)
+        ctx.save_for_backward(q, k, v, p)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        q, k, v, p = ctx.saved_tensors
+        da = da.contiguous()
+        N, C, L = q.shape
+        dv = torch.empty_like(v)                      # da (C x L) @ P (L x L)
+        _gemm(da, p, dv, N, C, L, L, L, L, L, C*L, L*L, C*L)
+        dp = torch.empty_like(p)                      # da^T (L x C) @ v (C x L)
+        _gemm(da, v, dp, N, L, L, C, L, L, L, C*L, C*L, L*L, trans_a=1)
+        dw = torch.empty_like(p)
+        hip.check(hip.lib().brv_softmax_rows_backward(hip.ptr(p), hip.ptr(dp), hip.ptr(dw), N*L, L,
+                                                      hip.stream()), 'brv_softmax_rows_backward')
+        dw = _axpby_raw(dw, 1.0/C**0.5, None, 0.0)
+        dq = torch.empty_like(q)                      # k (C x L) @ dW^T
+        _gemm(k, dw, dq, N, C, L, L, L, L, L, C*L, L*L, C*L, trans_b=1)
+        dk = torch.empty_like(k)                      # q (C x L) @ dW
+        _gemm(q, dw, dk, N, C, L, L, L, L, L, C*L, L*L, C*L)
+        return dq, dk, dv
+
+
+# ---------------------------------------------------------------------------------------------
+# the network, block by block (same order of operations as sgmse.py / net.py)
+# ---------------------------------------------------------------------------------------------
+def conv(x, mod):
+    return ConvFn.apply(x, mod.weight, mod.bias)
+
+
+def group_norm(x, mod, add=None, silu=False):
+    return GroupNormFn.apply(x, add, mod.weight, mod.bias, mod.num_groups, mod.eps, silu)
+
+
+def resample(resampler, x, direction):
+    padding, out_hw, up = resampler.plan(x.shape, direction)
+    return ResampleFn.apply(x, resampler.kernel.float().contiguous(), up, padding, out_hw)
+
+
+def attention(blk, x, out_scale):
+    N, C, H, W = x.shape
+    xn = group_norm(x, blk.norm)
+    q, k, v = (conv(xn, m).view(N, C, H*W) for m in (blk.conv_query, blk.conv_key, blk.conv_value))
+    a = AttentionCoreFn.apply(q, k, v).view(N, C, H, W)
+    return AxpbyFn.apply(x, out_scale, conv(a, blk.conv_out), out_scale)
+
+
+def unet_block(blk, x, emb):
+    if blk.block_type == 'adm':
+        raise NotImplementedError("training with block_type='adm' is not built yet")
+    h = group_norm(x, blk.norm_1, silu=True)
+    if blk.resampler is not None:
+        h = resample(blk.resampler, h, blk.up_or_down)
+        x = resample(blk.resampler, x, blk.up_or_down)
+    h = conv(h, blk.conv_1)
+    e = LinearFn.apply(emb, blk.linear.weight, blk.linear.bias)
+    if e.shape[0] != h.shape[0]:
+        e = e.expand(h.shape[0], -1)
+    h = group_norm(h, blk.norm_2, add=e, silu=True)
+    if blk.dropout.p > 0:
+        h = torch.nn.functional.dropout(h, blk.dropout.p, training=blk.training)
+    h = conv(h, blk.conv_2)
+    if blk.skip_conv is not None:
+        x = conv(x, blk.skip_conv)
+    x = AxpbyFn.apply(x, blk.skip_scale, h, blk.skip_scale)
+    if blk.attn is not None:
+        x = attention(blk.attn, x, blk.skip_scale)
+    return x
+
+
+def unet(net, x, sigma):
+    """DiffusionUNet.forward (net.py:232-262) with gradients."""
+    from .sgmse import AuxiliaryDown, AuxiliaryUp  # noqa: F401
+    emb = net.emb.fourier_proj(sigma.reshape(-1))
+    emb = SiluFn.apply(LinearFn.apply(emb, net.emb.linear_1.weight, net.emb.linear_1.bias))
+    emb = SiluFn.apply(LinearFn.apply(emb, net.emb.linear_2.weight, net.emb.linear_2.bias))
+    aux = x
+    x = conv(x, net.input_conv)
+    skips = [x]
+    for enc, aux_block in zip(net.encoder, net.aux_downs):
+        n = len(enc.unet_blocks)
+        for i, blk in enumerate(enc.unet_blocks):
+            x = unet_block(blk, x, emb)
+            if i != n - 1:
+                skips.append(x)
+        if aux_block is not None:
+            aux = resample(aux_block.resampler, aux, 'down')
+            x = AxpbyFn.apply(x, 1.0, conv(aux, aux_block.conv), 1.0)
+            if aux_block.type_ == 'residual':
+                aux = x = AxpbyFn.apply(x, aux_block.skip_scale, None, 0.0)
+        skips.append(x)
+    x = unet_block(net.bottleneck_block_1, x, emb)
+    x = unet_block(net.bottleneck_block_2, x, emb)
+    aux = None
+    for dec, aux_block in zip(net.decoder, net.aux_ups):
+        for blk in dec.unet_blocks:
+            if blk.resampler is None:
+                x = torch.cat([x, skips.pop()], dim=1)
+            x = unet_block(blk, x, emb)
+        if aux_block is not None:
+            if aux_block.resampler is not None:
+                aux = resample(aux_block.resampler, aux, 'up')
+            if aux_block.type_ == 'skip' or aux_block.resampler is None:
+                h = conv(group_norm(x, aux_block.norm, silu=True), aux_block.conv)
+                aux = h if aux is None else AxpbyFn.apply(aux, 1.0, h, 1.0)
+            else:
+                x = aux = AxpbyFn.apply(x, 1.0, conv(aux, aux_block.conv), 1.0)
+    if aux is None:
+        aux = x
+    if isinstance(net.output_conv, torch.nn.Conv2d):
+        return conv(aux, net.output_conv)
+    return conv(group_norm(aux, net.output_conv[0]), net.output_conv[1])

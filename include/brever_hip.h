@@ -300,8 +300,22 @@ int brv_complex_weight_unpack(const float* dwc, float* dwr, float* dwi, int64_t 
 int64_t brv_groupnorm_scratch_bytes(int64_t B, int64_t groups);
 int brv_groupnorm_fold(const float* x, const float* add_bc, const float* gamma, const float* beta,
                        const float* adm_scale, const float* adm_shift, void* scratch, float* scale,
-                       float* shift, int64_t B, int64_t C, int64_t HW, int64_t groups, float eps,
-                       brv_stream_t stream);
+                       float* shift, float* mu_bc, float* rstd_bc, int64_t B, int64_t C, int64_t HW,
+                       int64_t groups, float eps, brv_stream_t stream);
+/* Backward of y = act(GroupNorm(x + add)) (autograd of net.py:395-412 for SGMSE+ training):
+ * mu_bc / rstd_bc (nullable in the forward call) are the per-(item, channel) centre (group
+ * mean - add) and inverse deviation saved by brv_groupnorm_fold. Writes dx, the per-(item,
+ * channel) sums s1 = sum dpre and s2 = sum dpre*xhat (d beta and d gamma are their sums over
+ * the batch), d add (nullable); coef_scratch: 3*B*C floats. silu / softmax_rows backward:
+ * autograd of F.silu and of the attention softmax. */
+int brv_groupnorm_backward(const float* x, const float* dy, const float* scale_bc,
+                           const float* shift_bc, const float* mu_bc, const float* rstd_bc,
+                           const float* gamma, float* dx, float* s1_bc, float* s2_bc, float* dadd_bc,
+                           float* coef_scratch, int64_t B, int64_t C, int64_t HW, int64_t groups,
+                           int act_silu, brv_stream_t stream);
+int brv_silu_backward(const float* x, const float* dy, float* dx, int64_t n, brv_stream_t stream);
+int brv_softmax_rows_backward(const float* p, const float* dy, float* dx, int64_t rows, int64_t cols,
+                              brv_stream_t stream);
 int brv_affine_act(const float* x, const float* scale_bc, const float* shift_bc, float* y,
                    int64_t B, int64_t C, int64_t HW, int act_silu, brv_stream_t stream);
 int brv_silu(const float* x, float* y, int64_t n, brv_stream_t stream);

@@ -16,9 +16,13 @@ import torch.nn.functional as F
 
 
 class Net:
-    def __init__(self, state, prefix, skip_scale, block_type='ncsn'):
-        self.sd = {k[len(prefix):]: v.detach().float().cpu() for k, v in state.items()
+    def __init__(self, state, prefix, skip_scale, block_type='ncsn', requires_grad=False):
+        self.sd = {k[len(prefix):]: v.detach().float().cpu().clone() for k, v in state.items()
                    if k.startswith(prefix)}
+        if requires_grad:                  # training oracle: leaves of the autograd graph
+            for v in self.sd.values():
+                if v.is_floating_point():
+                    v.requires_grad_(True)
         self.skip_scale = skip_scale
         self.block_type = block_type
         self.paddings = []
@@ -281,3 +285,19 @@ def enhance(net, sde, wav, window, hop_length, sampler, compression=0.5, scale=0
     wave = ostft.istft(out, window, hop_length, normalized=False, compression=compression,
                        scale=scale)
     return (torch.from_numpy(wave).float()*norm)[..., :length].squeeze(1)
+
+
+def train_loss(net, sde, batch, lengths, t, noise, precond='richter'):
+    """SGMSEp.loss (sgmse.py:163-176) with the draws of t and of the noise given: weighted,
+    length-masked complex MSE (criterion.py:104-132) between the denoiser output and the
+    clean-minus-noisy target."""
+    y, x0 = batch[:, 0].unsqueeze(1), batch[:, 1].unsqueeze(1)
+    sigma = sde.sigma(t)
+    weight = 1/sigma**2 if precond == 'richter' else None
+    d = denoise(net, sde, x0 - y + sigma*noise, y, sigma, t, precond=precond)
+    frames = torch.arange(d.shape[-1])
+    mask = (frames[None, :] < lengths[:, None])[:, None, None, :]
+    err = ((d - (x0 - y))*mask).abs().pow(2).sum(-1)/lengths.view(-1, 1, 1)
+    if weight is not None:
+        err = err*weight.view(-1, 1, 1)
+    return err.mean((1, 2)).mean()

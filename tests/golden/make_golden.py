@@ -495,6 +495,37 @@ def golden_sgmse(out):
             for i, d in enumerate(draws):
                 res[f'{tag}_noise_{i}'] = d.numpy()
             res[f'{tag}_n_noise'] = np.array(len(draws))
+        if tag == 'edm':
+            continue
+        # training objective (sgmse.py:163-176) on a ragged batch of two items with the draws of
+        # t and of the Gaussian noise fixed: loss value and all parameter gradients
+        import brever.models.sgmse.sgmse as sg
+        items = [net.transform(0.3*torch.randn(2, 2, n, generator=g)) for n in (length, length - 90)]
+        lengths = torch.tensor([it.shape[-1] for it in items])
+        batch = torch.stack([torch.nn.functional.pad(it, (0, int(lengths.max()) - it.shape[-1]))
+                             for it in items])
+        t_draw = torch.rand(2, 1, 1, 1, generator=g)
+        n_draw = torch.randn(batch[:, 1].unsqueeze(1).shape, generator=g, dtype=batch.dtype)
+        patched = types.SimpleNamespace(**{n: getattr(torch, n) for n in dir(torch)})
+        patched.rand = lambda *a, **k: t_draw.clone()
+        patched.randn_like = lambda ref, **k: n_draw.clone()
+        sg.torch = patched
+        try:
+            net.train()
+            net.zero_grad()
+            loss = net.loss(batch, lengths, use_amp=False)
+            loss.backward()
+        finally:
+            sg.torch = torch
+            net.eval()
+        res[f'{tag}_train_batch'] = batch.numpy(); res[f'{tag}_train_lengths'] = lengths.numpy()
+        # the reference maps the uniform draw to [t_eps, 1]: the effective t is what is stored
+        res[f'{tag}_train_t'] = (t_draw*(1 - net.t_eps) + net.t_eps).numpy()
+        res[f'{tag}_train_noise'] = n_draw.numpy()
+        res[f'{tag}_train_loss'] = loss.detach().numpy()
+        res[f'{tag}_train_grads'] = torch.cat([p.grad.reshape(-1) if p.grad is not None
+                                               else torch.zeros(p.numel())
+                                               for p in net.parameters()]).numpy()
     np.savez_compressed(os.path.join(out, 'sgmse.npz'), **res)
 
 

@@ -329,3 +329,25 @@ def test_sgmse_oracle_matches_reference(golden_dir, tag):
         out = osg.enhance(net, sde, torch.from_numpy(g[f'{tag}_wav']), window, 16, sampler)
     ref = torch.from_numpy(g[f'{tag}_enhance'])
     assert (out - ref).abs().max() <= 1e-4*ref.abs().max()
+
+
+@pytest.mark.parametrize('tag', ['pc', 'res'])
+def test_sgmse_training_oracle_matches_reference(golden_dir, tag):
+    """The training objective and ALL parameter gradients of the oracle network vs the imported
+    reference with the draws of t and of the noise fixed."""
+    from helpers import sgmse_case
+    from oracle import sgmse as osg
+    g = np.load(os.path.join(golden_dir, 'sgmse.npz'))
+    model, _, sde, kw, _, _, _ = sgmse_case(g, tag)
+    net = osg.Net(model.state_dict(), 'model.net.', skip_scale=0.5**0.5, requires_grad=True)
+    loss = osg.train_loss(net, sde, torch.from_numpy(g[f'{tag}_train_batch']),
+                          torch.from_numpy(g[f'{tag}_train_lengths']),
+                          torch.from_numpy(g[f'{tag}_train_t']),
+                          torch.from_numpy(g[f'{tag}_train_noise']))
+    assert abs(float(loss) - float(g[f'{tag}_train_loss'])) <= 1e-5
+    loss.backward()
+    names = [n[len('model.net.'):] for n, _ in model.named_parameters()]
+    got = torch.cat([net.sd[n].grad.reshape(-1) if net.sd[n].grad is not None
+                     else torch.zeros(net.sd[n].numel()) for n in names])
+    gold = torch.from_numpy(g[f'{tag}_train_grads'])
+    assert (got - gold).norm() <= 1e-4*gold.norm()
