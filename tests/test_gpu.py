@@ -1042,3 +1042,30 @@ def test_sgmse_training_matches_reference(golden_dir, tag):
     for _ in range(5):
         last = float(model.train_step(batch, lengths, False, scaler))
     assert last < first
+
+
+@pytest.mark.gpu
+def test_entry_points_sgmse(tmp_path):
+    """SGMSE+ (BASELINE config 4, narrow network, 4 sampler steps) through init -> train ->
+    test: training on the HIP score network, validation / test through the reverse sampler."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
+                                    text=True, cwd=root)
+    out = run('scripts/init_model.py', 'sgmsep', '--models-dir', str(tmp_path),
+              '--stft_frame_length', '64', '--stft_hop_length', '16', '--net_base_channels', '8',
+              '--net_channel_mult', '1,2,2', '--net_num_blocks_per_res', '1',
+              '--net_attn_resolutions', '16', '--solver_num_steps', '4',
+              '--trainer_epochs', '1', '--trainer_val_period', '1',
+              '--trainer_batch_size', '4', '--trainer_preload', 'true', '--trainer_workers', '0',
+              '--train-path', 'synthetic:8:0.25', '--val-path', 'synthetic:2:0.25')
+    assert out.returncode == 0, out.stderr
+    model_dir = os.path.join(str(tmp_path), os.listdir(tmp_path)[0])
+    out = run('scripts/train_model.py', model_dir)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    assert np.isfinite(losses['train_loss']).all()
+    out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:2:0.25')
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert np.isfinite(np.load(os.path.join(model_dir, 'scores.npz'))['scores']).all()

@@ -61,9 +61,23 @@ def sgmse_row(seconds, steps):
             'seconds': seconds, **out}
 
 
+def sgmse_train_row(batch, frames, steps):
+    from brever_amd.models import ModelRegistry
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    model = ModelRegistry.get('sgmsep')().to(dev).train()
+    x = 0.3*torch.randn(batch, 2, 256, frames, dtype=torch.complex64, device=dev)
+    lengths = torch.full((batch,), frames, device=dev)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    dt = timed(lambda: model.train_step(x, lengths, False, scaler), 1, steps)
+    return {'row': 'sgmsep train (fp32, default 65.6 M-param network)', 'batch': batch,
+            'frames': frames, 'seconds_per_item': (frames - 1)*128/16000, 'ms_per_step': dt*1e3,
+            'items_per_s': batch/dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--rows', default='ffnn,dccrn,sgmse')
+    ap.add_argument('--rows', default='ffnn,dccrn,sgmse,sgmse_train')
     args = ap.parse_args()
     rows = args.rows.split(',')
     if 'ffnn' in rows:
@@ -73,6 +87,8 @@ def main():
         row = train_row('dccrn', 16, 4.0, 5, True)
         row['row'] += ' (use_amp: bf16 matrix products)'
         print(json.dumps(row), flush=True)
+    if 'sgmse_train' in rows:
+        print(json.dumps(sgmse_train_row(4, 128, 3)), flush=True)
     if 'sgmse' in rows:
         print(json.dumps(sgmse_row(4.0, 30)), flush=True)
 
