@@ -979,15 +979,21 @@ class SGMSEp(BreverBaseModel):
         return torch.randn_like(x_0)
 
     def loss(self, batch, lengths, use_amp):
-        """Denoising score matching objective (sgmse.py:163-176): fp32 kernels, ``use_amp`` is
-        not used for training yet."""
+        """Denoising score matching objective (sgmse.py:163-176); ``use_amp`` runs the
+        convolutions (forward, data and weight gradients) with bf16 operands and fp32
+        accumulation, everything else stays fp32."""
         hip.require_device(batch)
         y, x_0 = batch[:, 0].unsqueeze(1), batch[:, 1].unsqueeze(1)     # noisy, clean
         t = self._draw_t(x_0.shape[0], y.device)
         sigma = self.sde.sigma(t)
         n = sigma*self._draw_noise(x_0)
         weight = self.model.weight(sigma)
-        d = self.model.forward_train(x_0 - y + n, y, sigma, t)
+        from . import sgmse_train
+        sgmse_train.AMP['on'] = bool(use_amp)
+        try:
+            d = self.model.forward_train(x_0 - y + n, y, sigma, t)
+        finally:
+            sgmse_train.AMP['on'] = False
         return self.criterion(d, x_0 - y, lengths, weight=weight).mean()
 
     @torch.no_grad()

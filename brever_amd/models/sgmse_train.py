@@ -14,11 +14,17 @@ import torch
 from .. import hip
 
 
+AMP = {'on': False}       # set by SGMSEp.loss around the forward pass (use_amp)
+
+
 def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, trans_b=0,
-          kbatch=1, a_kbs=0, b_kbs=0, bias=None):
-    hip.check(hip.lib().brv_gemm_f32(
+          kbatch=1, a_kbs=0, b_kbs=0, bias=None, lowp=False):
+    """``lowp``: bf16 operands with fp32 accumulation (the convolutions under ``use_amp``)."""
+    fn = hip.lib().brv_gemm_bf16 if lowp else hip.lib().brv_gemm_f32
+    hip.check(fn(
         hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
-        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_f32')
+        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()),
+        'brv_gemm_bf16' if lowp else 'brv_gemm_f32')
 
 
 def _empty(*shape, like):
@@ -36,7 +42,8 @@ class ConvFn(torch.autograd.Function):
         K, HW = Cin*k*k, H*W
         col = ConvFn._col(x, k)
         y = _empty(B, Cout, H, W, like=x)
-        _gemm(w, col, y, B, Cout, HW, K, K, HW, HW, 0, K*HW, Cout*HW, bias=bias)
+        ctx.lowp = AMP['on']
+        _gemm(w, col, y, B, Cout, HW, K, K, HW, HW, 0, K*HW, Cout*HW, bias=bias, lowp=ctx.lowp)
         ctx.save_for_backward(x, w)
         return y
 
@@ -60,14 +67,15 @@ class ConvFn(torch.autograd.Function):
         col = ConvFn._col(x, k)
         dw = torch.empty_like(w)
         _gemm(dy, col, dw, 1, Cout, K, HW, HW, HW, K, 0, 0, 0, trans_b=1, kbatch=B,
-              a_kbs=Cout*HW, b_kbs=K*HW)
+              a_kbs=Cout*HW, b_kbs=K*HW, lowp=ctx.lowp)
         db = _empty(Cout, like=x)
         hip.check(hip.lib().brv_row_sum(hip.ptr(dy), hip.ptr(db), B, Cout, HW, hip.stream()),
                   'brv_row_sum')
         dx = None
         if ctx.needs_input_grad[0]:
             dcol = col if k != 1 else _empty(B, K, HW, like=x)
-            _gemm(w, dy, dcol, B, K, HW, Cout, K, HW, HW, 0, Cout*HW, K*HW, trans_a=1)
+            _gemm(w, dy, dcol, B, K, HW, Cout, K, HW, HW, 0, Cout*HW, K*HW, trans_a=1,
+                  lowp=ctx.lowp)
             if k == 1:
                 dx = dcol.view(B, Cin, H, W)
             else:

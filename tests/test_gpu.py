@@ -1037,6 +1037,14 @@ def test_sgmse_training_matches_reference(golden_dir, tag):
         if float(ref.norm()) > 1e-5:
             assert rel(got[o:o + k], ref) <= 2e-2, (name, rel(got[o:o + k], ref))
         o += k
+    # use_amp: bf16-operand convolutions (fp32 accumulation): same loss / gradients to bf16 accuracy
+    model.zero_grad()
+    loss16 = model.loss(batch, lengths, True)
+    loss16.backward()
+    got16 = torch.cat([p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device=dev)
+                       for p in model.parameters()]).cpu()
+    assert abs(float(loss16) - float(g[f'{tag}_train_loss'])) <= 5e-3, float(loss16)
+    assert rel(got16, gold) <= 5e-2, rel(got16, gold)
     scaler = torch.amp.GradScaler('cuda', enabled=False)
     first = float(loss)
     for _ in range(5):

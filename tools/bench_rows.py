@@ -61,7 +61,7 @@ def sgmse_row(seconds, steps):
             'seconds': seconds, **out}
 
 
-def sgmse_train_row(batch, frames, steps):
+def sgmse_train_row(batch, frames, steps, use_amp=False):
     from brever_amd.models import ModelRegistry
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
@@ -69,8 +69,8 @@ def sgmse_train_row(batch, frames, steps):
     x = 0.3*torch.randn(batch, 2, 256, frames, dtype=torch.complex64, device=dev)
     lengths = torch.full((batch,), frames, device=dev)
     scaler = torch.amp.GradScaler('cuda', enabled=False)
-    dt = timed(lambda: model.train_step(x, lengths, False, scaler), 1, steps)
-    return {'row': 'sgmsep train (fp32, default 65.6 M-param network)', 'batch': batch,
+    dt = timed(lambda: model.train_step(x, lengths, use_amp, scaler), 1, steps)
+    return {'row': f"sgmsep train ({'bf16 convolutions' if use_amp else 'fp32'}, default 65.6 M-param network)", 'batch': batch,
             'frames': frames, 'seconds_per_item': (frames - 1)*128/16000, 'ms_per_step': dt*1e3,
             'items_per_s': batch/dt}
 
@@ -89,6 +89,7 @@ def main():
         print(json.dumps(row), flush=True)
     if 'sgmse_train' in rows:
         print(json.dumps(sgmse_train_row(4, 128, 3)), flush=True)
+        print(json.dumps(sgmse_train_row(4, 128, 3, True)), flush=True)
     if 'sgmse' in rows:
         print(json.dumps(sgmse_row(4.0, 30)), flush=True)
 
