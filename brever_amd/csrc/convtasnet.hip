@@ -16,6 +16,8 @@
 #include "gemm_wgrad.cuh"
 #include "gemm_ws.cuh"
 #include "gemm_wgrad_full.cuh"
+
+constexpr int kWgSplit = 4;          // item splits of the [res | skip] weight-gradient launch
 #include "prep.cuh"
 #include "tcn_kernels.cuh"
 #include "cln_kernels.cuh"
@@ -139,6 +141,7 @@ struct Workspace {
   long long w, x, z1, z2, skip, m, y, stats, sums, dpre, dw1, gskip, gout, eA, eB,
       e0, dwt, vg, gcopy, total;
   long long gcopy_stride, eB_stride;
+  long long wgpart;                   // partial tiles of the split [res | skip] weight gradient
   // causal (cLN) model only: materialised normalised tensors, per-frame statistics tables,
   // identity operands that let the non-causal kernels run as plain convolutions
   long long h1, h2, wn, ctab, ctab_stride, cfs, cbt, ident, fake_stats, scratch_stats;
@@ -179,6 +182,7 @@ struct Workspace {
     vg_stride = align_up(2LL*l.N + (long long)l.nb*l.H*(5 + l.P) + 1 + 2*l.nb + 2LL*l.Hp, 64);
     vg_bytes = vg_stride*kReplicas*4;
     vg = take(vg_bytes);
+    wgpart = take((long long)kWgSplit*l.nb*W2_G*l.H*4);
     h1 = h2 = wn = ctab = cfs = cbt = ident = fake_stats = scratch_stats = 0; ctab_stride = 0;
     if (l.causal) {
       h1 = take(z_stride*l.nb);
@@ -1184,8 +1188,14 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
 #ifdef BRV_DIAG
     if (const char* d = getenv("BRV_DBG_WG")) fp.dbg = atoi(d);
 #endif
-    const int grid = 8*ceil_div(l.nb, 8)*fp.n_htiles;
+    // 24 blocks x 8 H slices = 192 owners would leave a quarter of the CUs idle: the items are
+    // divided over kWgSplit workgroups each (768 = 3 full rounds) when the batch allows
+    fp.n_split = (B >= kWgSplit && !getenv("BRV_NO_WGRAD_SPLIT")) ? kWgSplit : 1;
+    fp.part = reinterpret_cast<float*>(base + ws.wgpart);
+    const int grid = 8*ceil_div(l.nb, 8)*fp.n_htiles*fp.n_split;
     hipLaunchKernelGGL(wgrad_full_kernel, dim3(grid), dim3(64*W2_NW), 0, st, fp);
+    if (fp.n_split > 1)
+      hipLaunchKernelGGL(wgrad_full_reduce_kernel, dim3(128, (unsigned)l.nb), dim3(256), 0, st, fp);
     HIP_OK(hipGetLastError());
   }
   for (int i0 = 0; i0 < l.nb; i0 += kWgMaxProb) {

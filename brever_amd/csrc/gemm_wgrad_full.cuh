@@ -46,6 +46,11 @@ struct WgradFullParams {
   int Kout, ldo;                 // true H channels / leading dimension of D
   double inv_n; float eps;
   WgradProb prob[kWgMaxProb];    // g0 may be null (block without residual conv)
+  // the items are divided over n_split workgroups per (block, H slice) so that the launch
+  // fills whole rounds of the 256 CUs (24 x 8 = 192 owners alone leave a quarter of the chip
+  // idle); each writes its tile of partial sums to `part` [split][block][256][ldo], which
+  // wgrad_full_reduce_kernel adds into the gradients in a fixed order (no atomics)
+  int n_split; float* part;
 #ifdef BRV_DIAG
   int dbg;                       // 1: no DMA, 2: no fragment reads / MFMA, 4: no transform
 #endif
@@ -146,12 +151,15 @@ __global__ __launch_bounds__(64*W2_NW) void wgrad_full_kernel(const WgradFullPar
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int z = (slot / p.n_htiles)*8 + xcd, htile = slot % p.n_htiles;
+  const int per_z = p.n_htiles*p.n_split;
+  const int z = (slot / per_z)*8 + xcd, htile = (slot % per_z) / p.n_split;
+  const int split = slot % p.n_split;
   if (z >= p.nprob) return;
   const WgradProb& q = p.prob[z];
   const int T = p.T;
   const int cpi = ceil_div(T, W2_BT);
-  const int total = p.B*cpi;
+  const int b_lo = split*p.B/p.n_split, b_hi = (split + 1)*p.B/p.n_split;   // this split's items
+  const int total = (b_hi - b_lo)*cpi;
   const int k0 = htile*W2_BH;
 
   // LDS starts out as zeros: rows never written (no residual part, frames past the end) must
@@ -283,9 +291,9 @@ __global__ __launch_bounds__(64*W2_NW) void wgrad_full_kernel(const WgradFullPar
 
   // chunk bookkeeping: (b1, t1) = chunk c+1, (b2, t2) = chunk c+2
   auto advance = [&](int& b, int& t) { t += W2_BT; if (t >= T) { t = 0; ++b; } };
-  int b1 = 0, t1 = 0;
-  item_coefs(0);
-  issue_chunk(0, 0, 0, true);
+  int b1 = b_lo, t1 = 0;
+  item_coefs(b_lo);
+  issue_chunk(b_lo, 0, 0, total > 0);
   advance(b1, t1);
   int b2 = b1, t2 = t1;
   issue_chunk(b1, t1, 1, total > 1);
@@ -328,8 +336,8 @@ __global__ __launch_bounds__(64*W2_NW) void wgrad_full_kernel(const WgradFullPar
     // chunk c+1 (issued one iteration ago): landed once only chunk c+2's DMAs are pending
     if (dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W2_DMA) : "memory");
-    if (t1 == 0 && b1 < p.B) item_coefs(b1);
-    const int nvalid = b1 < p.B ? T - t1 : 0;
+    if (t1 == 0 && b1 < b_hi) item_coefs(b1);
+    const int nvalid = b1 < b_hi ? T - t1 : 0;
     u32x4 raw, rdummy = {0u, 0u, 0u, 0u}; uint4 packed = make_uint4(0, 0, 0, 0);
     h_read(NX, raw);                                  // oldest in the LDS queue
     if (!(dbg & 2)) {
@@ -372,6 +380,10 @@ __global__ __launch_bounds__(64*W2_NW) void wgrad_full_kernel(const WgradFullPar
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int n = 32*wid + (i & 3) + 8*(i >> 2) + 4*fh;
+      if (p.n_split > 1) {
+        if (k < p.Kout) p.part[(((long long)split*p.nprob + z)*W2_G + n)*p.ldo + k] = acc[c][i];
+        continue;
+      }
       if (k < p.Kout) {
         if (n < 128) {
           if (q.out0 && n < p.N0) q.out0[(long long)n*p.ldo + k] += acc[c][i];
@@ -400,6 +412,24 @@ __global__ __launch_bounds__(64*W2_NW) void wgrad_full_kernel(const WgradFullPar
       if (tid < 128) { if (q.gbias0 && tid < p.N0) atomic_add_f32(q.gbias0 + tid, s); }
       else if (q.gbias1 && tid - 128 < p.N1) atomic_add_f32(q.gbias1 + (tid - 128), s);
     }
+  }
+}
+
+// out += sum over the splits of the partial tiles, in split order (deterministic)
+__global__ __launch_bounds__(256) void wgrad_full_reduce_kernel(const WgradFullParams p) {
+  const int z = blockIdx.y;
+  const WgradProb& q = p.prob[z];
+  const long long per = (long long)W2_G*p.ldo;
+  for (long long e = (long long)blockIdx.x*256 + threadIdx.x; e < per; e += (long long)gridDim.x*256) {
+    const int n = (int)(e / p.ldo), k = (int)(e % p.ldo);
+    if (k >= p.Kout) continue;
+    float* dst = nullptr;
+    if (n < 128) { if (q.out0 && n < p.N0) dst = q.out0 + (long long)n*p.ldo + k; }
+    else if (q.out1 && n - 128 < p.N1) dst = q.out1 + (long long)(n - 128)*p.ldo + k;
+    if (!dst) continue;
+    float s = 0.f;
+    for (int sp = 0; sp < p.n_split; ++sp) s += p.part[((long long)sp*p.nprob + z)*per + e];
+    *dst += s;
   }
 }
 
