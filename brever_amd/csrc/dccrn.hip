@@ -173,10 +173,12 @@ __global__ __launch_bounds__(256) void invstd_from_var_kernel(const float* var, 
 // for all steps, bias = b_ih + b_hh; one workgroup per batch item, h and c in LDS.
 __global__ __launch_bounds__(256) void lstm_recurrent_kernel(const float* gates_in, const float* w_hh,
                                                              const float* bias, float* y, float* act,
-                                                             float* cs, int T, int H) {
+                                                             float* cs, int T, int H, int per_group) {
   extern __shared__ float sm[];                   // h[H] | c[H] | gates[4H]
   float* h = sm; float* c = sm + H; float* gt = sm + 2*H;
   const int b = blockIdx.x;
+  w_hh += (long long)(b / per_group)*4*H*H;        // the item's parameter group
+  if (bias) bias += (long long)(b / per_group)*4*H;
   for (int i = threadIdx.x; i < H; i += 256) { h[i] = 0.f; c[i] = 0.f; }
   __syncthreads();
   for (int t = 0; t < T; ++t) {
@@ -216,10 +218,12 @@ __global__ __launch_bounds__(256) void lstm_recurrent_kernel(const float* gates_
 constexpr int kLstmRegH = 128;
 __global__ __launch_bounds__(512) void lstm_fwd_reg_kernel(const float* gates_in, const float* w_hh,
                                                            const float* bias, float* y, float* act,
-                                                           float* cs, int T, int H) {
+                                                           float* cs, int T, int H, int per_group) {
   __shared__ __attribute__((aligned(16))) float h[kLstmRegH];
   __shared__ float gt[4*kLstmRegH];
   const int b = blockIdx.x, r = threadIdx.x;           // blockDim.x == 4H
+  w_hh += (long long)(b / per_group)*4*H*H;            // the item's parameter group
+  if (bias) bias += (long long)(b / per_group)*4*H;
   float w[kLstmRegH];
 #pragma unroll
   for (int k = 0; k < kLstmRegH; ++k) w[k] = k < H ? w_hh[(long long)r*H + k] : 0.f;
@@ -265,10 +269,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_reg_kernel(const float* gates_in
 // sums of dh_{t-1}[k] meet in LDS.
 __global__ __launch_bounds__(512) void lstm_bwd_reg_kernel(const float* act, const float* cs,
                                                            const float* w_hh, const float* dy,
-                                                           float* dgates, int T, int H) {
+                                                           float* dgates, int T, int H,
+                                                           int per_group) {
   __shared__ __attribute__((aligned(16))) float dg[4*kLstmRegH];
   __shared__ float part[4][kLstmRegH];
   const int b = blockIdx.x, j = threadIdx.x;
+  w_hh += (long long)(b / per_group)*4*H*H;
   const int k = j % H, q = j / H;
   float w[kLstmRegH];
 #pragma unroll
@@ -511,10 +517,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
 // pre-activations (the weight / input gradients are GEMMs over it).
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* act, const float* cs,
                                                        const float* w_hh, const float* dy,
-                                                       float* dgates, int T, int H) {
+                                                       float* dgates, int T, int H, int per_group) {
   extern __shared__ float sm[];                   // dh[H] | dc[H] | dg[4H]
   float* dh = sm; float* dc = sm + H; float* dg = sm + 2*H;
   const int b = blockIdx.x;
+  w_hh += (long long)(b / per_group)*4*H*H;
   for (int i = threadIdx.x; i < H; i += 256) { dh[i] = 0.f; dc[i] = 0.f; }
   __syncthreads();
   for (int t = T - 1; t >= 0; --t) {
@@ -663,14 +670,17 @@ int brv_batchnorm2d_forward(const float* x, const float* gamma, const float* bet
 
 int brv_lstm_recurrent_forward(const float* gates_in, const float* w_hh, const float* bias,
                                float* y, float* act, float* cs, int64_t B, int64_t T, int64_t H,
-                               brv_stream_t stream) {
-  if (B < 1 || T < 1 || H < 1) return -1;
+                               int64_t groups, brv_stream_t stream) {
+  if (B < 1 || T < 1 || H < 1 || groups < 1 || B % groups) return -1;
+  const int per_group = (int)(B/groups);
   if (H <= kLstmRegH && H % 16 == 0)
     hipLaunchKernelGGL(lstm_fwd_reg_kernel, dim3((unsigned)B), dim3((unsigned)(4*H)), 0,
-                       (hipStream_t)stream, gates_in, w_hh, bias, y, act, cs, (int)T, (int)H);
+                       (hipStream_t)stream, gates_in, w_hh, bias, y, act, cs, (int)T, (int)H,
+                       per_group);
   else
   hipLaunchKernelGGL(lstm_recurrent_kernel, dim3((unsigned)B), dim3(256), (size_t)6*H*4,
-                     (hipStream_t)stream, gates_in, w_hh, bias, y, act, cs, (int)T, (int)H);
+                     (hipStream_t)stream, gates_in, w_hh, bias, y, act, cs, (int)T, (int)H,
+                     per_group);
   DC_OK(hipGetLastError());
   return 0;
 }
@@ -739,14 +749,15 @@ int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_
 
 int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* w_hh,
                                 const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
-                                brv_stream_t stream) {
-  if (B < 1 || T < 1 || H < 1) return -1;
+                                int64_t groups, brv_stream_t stream) {
+  if (B < 1 || T < 1 || H < 1 || groups < 1 || B % groups) return -1;
+  const int per_group = (int)(B/groups);
   if (H <= kLstmRegH && H % 16 == 0)
     hipLaunchKernelGGL(lstm_bwd_reg_kernel, dim3((unsigned)B), dim3((unsigned)(4*H)), 0,
-                       (hipStream_t)stream, act, cs, w_hh, dy, dgates, (int)T, (int)H);
+                       (hipStream_t)stream, act, cs, w_hh, dy, dgates, (int)T, (int)H, per_group);
   else
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)6*H*4,
-                     (hipStream_t)stream, act, cs, w_hh, dy, dgates, (int)T, (int)H);
+                     (hipStream_t)stream, act, cs, w_hh, dy, dgates, (int)T, (int)H, per_group);
   DC_OK(hipGetLastError());
   return 0;
 }

@@ -295,24 +295,28 @@ class _BatchNormActFunction(torch.autograd.Function):
 
 
 class _LSTMFunction(torch.autograd.Function):
-    """Single-layer unidirectional nn.LSTM, batch_first, zero initial state: x (B, T, I) ->
-    hidden states (B, T, H)."""
+    """G independent single-layer unidirectional nn.LSTMs (batch_first, zero initial state) in
+    one set of launches: x (G, B, T, I) -> hidden states (G, B, T, H), parameters stacked on a
+    leading group axis (w_ih (G, 4H, I), w_hh (G, 4H, H), b_ih / b_hh (G, 4H)). The input
+    projections and their gradients are batched matrix products over G; the recurrence runs
+    all G*B chains concurrently, one workgroup each."""
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
         lib = hip.lib()
-        x = x.contiguous()
-        B, T, I = x.shape
-        H = w_hh.shape[1]
+        x, w_ih, w_hh = x.contiguous(), w_ih.contiguous(), w_hh.contiguous()
+        G, B, T, I = x.shape
+        H = w_hh.shape[-1]
         lowp = ctx.lowp = _AMP['on']
-        gates = torch.empty(B, T, 4*H, dtype=torch.float32, device=x.device)
-        _gemm(x, w_ih, gates, 1, B*T, 4*H, I, I, I, 4*H, 0, 0, 0, trans_b=1, lowp=lowp)
-        bias = _CombineFunction.apply(b_ih.detach(), b_hh.detach(), 1.0)
-        y = torch.empty(B, T, H, dtype=torch.float32, device=x.device)
-        act = torch.empty(B, T, 4*H, dtype=torch.float32, device=x.device)
-        cs = torch.empty(B, T, H, dtype=torch.float32, device=x.device)
+        gates = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
+        _gemm(x, w_ih, gates, G, B*T, 4*H, I, I, I, 4*H, B*T*I, 4*H*I, B*T*4*H, trans_b=1,
+              lowp=lowp)
+        bias = _combine(b_ih.detach().contiguous(), b_hh.detach().contiguous(), 1.0)
+        y = torch.empty(G, B, T, H, dtype=torch.float32, device=x.device)
+        act = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
+        cs = torch.empty(G, B, T, H, dtype=torch.float32, device=x.device)
         hip.check(lib.brv_lstm_recurrent_forward(hip.ptr(gates), hip.ptr(w_hh), hip.ptr(bias),
-                                                 hip.ptr(y), hip.ptr(act), hip.ptr(cs), B, T, H,
+                                                 hip.ptr(y), hip.ptr(act), hip.ptr(cs), G*B, T, H, G,
                                                  hip.stream()), 'brv_lstm_recurrent_forward')
         ctx.save_for_backward(x, w_ih, w_hh, y, act, cs)
         return y
@@ -321,28 +325,30 @@ class _LSTMFunction(torch.autograd.Function):
     def backward(ctx, dy):
         lib = hip.lib()
         x, w_ih, w_hh, y, act, cs = ctx.saved_tensors
-        B, T, I = x.shape
-        H = w_hh.shape[1]
-        dy = dy.contiguous()
-        dg = torch.empty(B, T, 4*H, dtype=torch.float32, device=x.device)
-        hip.check(lib.brv_lstm_recurrent_backward(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh),
-                                                  hip.ptr(dy), hip.ptr(dg), B, T, H, hip.stream()),
-                  'brv_lstm_recurrent_backward')
-        dx = torch.empty_like(x)                                   # dg (BT, 4H) @ W_ih (4H, I)
+        G, B, T, I = x.shape
+        H = w_hh.shape[-1]
         lowp = ctx.lowp
-        _gemm(dg, w_ih, dx, 1, B*T, I, 4*H, 4*H, I, I, 0, 0, 0, lowp=lowp)
+        dy = dy.contiguous()
+        dg = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
+        hip.check(lib.brv_lstm_recurrent_backward(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh),
+                                                  hip.ptr(dy), hip.ptr(dg), G*B, T, H, G,
+                                                  hip.stream()), 'brv_lstm_recurrent_backward')
+        BT = B*T
+        dx = torch.empty_like(x)                                   # dg (BT, 4H) @ W_ih (4H, I)
+        _gemm(dg, w_ih, dx, G, BT, I, 4*H, 4*H, I, I, BT*4*H, 4*H*I, BT*I, lowp=lowp)
         dw_ih = torch.empty_like(w_ih)                             # dg^T (4H, BT) @ x (BT, I)
-        _gemm(dg, x, dw_ih, 1, 4*H, I, B*T, 4*H, I, I, 0, 0, 0, trans_a=1, lowp=lowp)
+        _gemm(dg, x, dw_ih, G, 4*H, I, BT, 4*H, I, I, BT*4*H, BT*I, 4*H*I, trans_a=1, lowp=lowp)
         h_prev = torch.zeros_like(y)                               # hidden state entering step t
-        h_prev[:, 1:] = y[:, :-1]
+        h_prev[:, :, 1:] = y[:, :, :-1]
         dw_hh = torch.empty_like(w_hh)
-        _gemm(dg, h_prev, dw_hh, 1, 4*H, H, B*T, 4*H, H, H, 0, 0, 0, trans_a=1, lowp=lowp)
-        db = torch.empty(4*H, dtype=torch.float32, device=x.device)
-        # column sums of dg (BT, 4H): row_sum over the transposed view (1, 4H, BT) needs a
-        # contiguous (4H, BT) copy
-        dgt = dg.view(B*T, 4*H).t().contiguous()
-        hip.check(lib.brv_row_sum(hip.ptr(dgt), hip.ptr(db), 1, 4*H, B*T, hip.stream()),
-                  'brv_row_sum')
+        _gemm(dg, h_prev, dw_hh, G, 4*H, H, BT, 4*H, H, H, BT*4*H, BT*H, 4*H*H, trans_a=1,
+              lowp=lowp)
+        # bias gradients: column sums of dg (BT, 4H) per group = row sums of its transpose
+        db = torch.empty(G, 4*H, dtype=torch.float32, device=x.device)
+        dgt = dg.view(G, BT, 4*H).transpose(1, 2).contiguous()
+        for g in range(G):
+            hip.check(lib.brv_row_sum(hip.ptr(dgt[g]), hip.ptr(db[g]), 1, 4*H, BT, hip.stream()),
+                      'brv_row_sum')
         return dx, dw_ih, dw_hh, db, db.clone()
 
 
@@ -425,9 +431,11 @@ class DCCRN(BreverBaseModel):
                                            act.weight if act is not None else None, norm, training)
 
     @staticmethod
-    def _lstm(lstm, x):
-        return _LSTMFunction.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0,
-                                   lstm.bias_hh_l0)
+    def _lstm(lstms, xs):
+        """The single-layer LSTMs ``lstms`` on their inputs ``xs`` (same shapes), concurrently."""
+        stack = lambda name: torch.stack([getattr(m, name) for m in lstms])  # noqa: E731
+        return _LSTMFunction.apply(torch.stack(xs), stack('weight_ih_l0'), stack('weight_hh_l0'),
+                                   stack('bias_ih_l0'), stack('bias_hh_l0'))
 
     def _lstm_block(self, x):
         """LSTMBlock (dccrn.py:293-311) on the encoder output (B, 2C, Fq, T) -> same shape."""
@@ -437,9 +445,10 @@ class DCCRN(BreverBaseModel):
         rows = x.reshape(B, C2*Fq, T).transpose(1, 2)        # (B, T, features): real then imag
         real, imag = rows.chunk(2, dim=-1)
         for layer in blk.lstm.layers:
-            # each module sees both halves: one recurrence launch of 2B items per module
-            rr, ri = self._lstm(layer.module_real, torch.cat([real, imag], dim=0)).chunk(2, dim=0)
-            ii, ir = self._lstm(layer.module_imag, torch.cat([imag, real], dim=0)).chunk(2, dim=0)
+            # each module sees both halves; both modules run in one set of launches (4B chains)
+            out = self._lstm((layer.module_real, layer.module_imag),
+                             (torch.cat([real, imag], dim=0), torch.cat([imag, real], dim=0)))
+            (rr, ri), (ii, ir) = out[0].chunk(2, dim=0), out[1].chunk(2, dim=0)
             real, imag = _CombineFunction.apply(rr, ii, -1.0), _CombineFunction.apply(ri, ir, 1.0)
         # Linear applied on the feature axis of (B, features, T): the output is already in the
         # (channels*freqs, frames) layout of the decoder input

@@ -216,7 +216,9 @@ int brv_masked_mean_spec(const float* spec, const float* mask, float* out, int64
  * such calls per output half. batchnorm2d: training != 0 uses batch statistics and updates
  * the running estimates (momentum), else the running ones; an optional scalar PReLU
  * follows. lstm_recurrent: gates_in (B, T, 4H) = W_ih x for all steps, bias (4H) =
- * b_ih + b_hh, y (B, T, H), zero initial state, torch gate order; act / cs (nullable) receive the gate
+ * b_ih + b_hh, y (B, T, H), zero initial state, torch gate order; `groups` independent LSTMs
+ * in one launch: the B items are `groups` consecutive sets of B/groups items, w_hh
+ * (groups, 4H, H) and bias (groups, 4H) hold one parameter set per group; act / cs (nullable) receive the gate
  * activations and cell states for the backward pass. dccrn_apply_mask: DCCRN.apply_mask. */
 int brv_conv2d_forward(const float* x, const float* w, const float* bias, float* y, int64_t B,
                        int64_t Cin, int64_t H, int64_t W, int64_t Cout, int64_t kh, int64_t kw,
@@ -235,7 +237,7 @@ int brv_batchnorm2d_forward(const float* x, const float* gamma, const float* bet
                             brv_stream_t stream);
 int brv_lstm_recurrent_forward(const float* gates_in, const float* w_hh, const float* bias,
                                float* y, float* act, float* cs, int64_t B, int64_t T, int64_t H,
-                               brv_stream_t stream);
+                               int64_t groups, brv_stream_t stream);
 /* Backward pieces (autograd of the above). conv2d_wgrad: dw (Cout, Cin, kh, kw) and dbias
  * from x and dy (ConvTranspose2d: pass its output gradient as x and its input as dy; data
  * gradients are the forward kernels of the opposite operation with the same weights).
@@ -257,7 +259,7 @@ int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_
                              brv_stream_t stream);
 int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* w_hh,
                                 const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
-                                brv_stream_t stream);
+                                int64_t groups, brv_stream_t stream);
 int brv_dccrn_apply_mask_backward(const float* xr, const float* xi, const float* mr,
                                   const float* mi, const float* gout, float* dmr, float* dmi,
                                   int64_t n, brv_stream_t stream);

@@ -957,14 +957,22 @@ def test_lstm_kernels_match_torch(H):
     y, _ = ref(x)
     y.backward(gy)
     params = [ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0]
-    xd = x.detach().to(dev).requires_grad_(True)
-    pd = [p.detach().to(dev).requires_grad_(True) for p in params]
+    # two parameter groups in one launch: the torch module and a second, differently seeded one
+    ref2 = torch.nn.LSTM(I, H, batch_first=True)
+    x2 = torch.randn(B, T, I, requires_grad=True)
+    y2, _ = ref2(x2)
+    y2.backward(0.5*gy)
+    params2 = [ref2.weight_ih_l0, ref2.weight_hh_l0, ref2.bias_ih_l0, ref2.bias_hh_l0]
+    xd = torch.stack([x.detach(), x2.detach()]).to(dev).requires_grad_(True)
+    pd = [torch.stack([p.detach(), q.detach()]).to(dev).requires_grad_(True)
+          for p, q in zip(params, params2)]
     yd = _LSTMFunction.apply(xd, *pd)
-    yd.backward(gy.to(dev))
-    assert rel(yd, y.detach()) <= 1e-5
-    assert rel(xd.grad, x.grad) <= 1e-4
-    for got, want in zip(pd, params):
-        assert rel(got.grad, want.grad) <= 1e-4, rel(got.grad, want.grad)
+    yd.backward(torch.stack([gy, 0.5*gy]).to(dev))
+    for g, (yy, xx, pp) in enumerate(((y, x, params), (y2, x2, params2))):
+        assert rel(yd[g], yy.detach()) <= 1e-5
+        assert rel(xd.grad[g], xx.grad) <= 1e-4
+        for got, want in zip(pd, pp):
+            assert rel(got.grad[g], want.grad) <= 1e-4, rel(got.grad[g], want.grad)
 
 
 @pytest.mark.gpu
