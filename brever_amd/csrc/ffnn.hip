@@ -43,6 +43,45 @@ __global__ __launch_bounds__(256) void compress_kernel(const float* x, float* ou
                                                        int mode, float eps) {
   GRID_STRIDE(i, n) out[i] = mode == 1 ? logf(x[i] + eps) : (mode == 2 ? cbrtf(x[i]) : x[i]);
 }
+// binaural cues per time-frequency unit of a 2-channel spectrum (features.py:222-262):
+// mode 0: ILD = 20 log10((|X_R| + eps)/(|X_L| + eps)); mode 1: IPD = angle(X_R) - angle(X_L)
+__global__ __launch_bounds__(256) void binaural_kernel(const float2* spec, float* out, long long n,
+                                                       long long total, int mode, float eps) {
+  GRID_STRIDE(idx, total) {
+    const long long b = idx / n, i = idx % n;
+    const float2 l = spec[(b*2)*n + i], r = spec[(b*2 + 1)*n + i];
+    if (mode == 0)
+      out[idx] = 20.f*log10f((sqrtf(r.x*r.x + r.y*r.y) + eps)/(sqrtf(l.x*l.x + l.y*l.y) + eps));
+    else
+      out[idx] = atan2f(r.y, r.x) - atan2f(l.y, l.x);
+  }
+}
+// x[b][m][t] /= sum_m x[b][m][t] + eps                      (features.py:190-191, 'pdf')
+__global__ __launch_bounds__(256) void col_normalize_kernel(float* x, int M, int T, long long total,
+                                                            float eps) {
+  GRID_STRIDE(idx, total) {                       // idx over (b, t)
+    const long long b = idx / T; const int t = (int)(idx % T);
+    float* col = x + b*M*T + t;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += col[(long long)m*T];
+    const float inv = 1.f/(s + eps);
+    for (int m = 0; m < M; ++m) col[(long long)m*T] *= inv;
+  }
+}
+// out (B, 3M, T) = [x | first difference | second difference] along the frames, zero-padded
+// on the left                                               (features.py:207-218)
+__global__ __launch_bounds__(256) void deltas_kernel(const float* x, float* out, int M, int T,
+                                                     long long total) {
+  GRID_STRIDE(idx, total) {
+    const int t = (int)(idx % T);
+    const long long bm = idx / T, b = bm / M, m = bm % M;
+    const float v0 = x[idx], v1 = t >= 1 ? x[idx - 1] : 0.f, v2 = t >= 2 ? x[idx - 2] : 0.f;
+    float* o = out + (b*3*M + m)*T + t;
+    o[0] = v0;
+    o[(long long)M*T] = t >= 1 ? v0 - v1 : 0.f;
+    o[(long long)2*M*T] = t >= 2 ? v0 - 2.f*v1 + v2 : 0.f;
+  }
+}
 // (1 + bg/(fg + eps))^(-1/2)                                 (ffnn.py:121-128)
 __global__ __launch_bounds__(256) void irm_kernel(const float* fg, const float* bg, float* out,
                                                   long long n, float eps) {
@@ -165,6 +204,28 @@ int brv_compress(const float* x, float* out, int64_t n, int mode, float eps, brv
   if (n < 1 || mode < 0 || mode > 2) return -1;
   hipLaunchKernelGGL(compress_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, x, out,
                      (long long)n, mode, eps);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_binaural(const float* spec, float* out, int64_t B, int64_t n, int mode, float eps,
+                 brv_stream_t stream) {
+  if (B < 1 || n < 1 || mode < 0 || mode > 1) return -1;
+  hipLaunchKernelGGL(binaural_kernel, flat_grid(B*n), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)spec, out, (long long)n, (long long)(B*n), mode, eps);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_col_normalize(float* x, int64_t B, int64_t M, int64_t T, float eps, brv_stream_t stream) {
+  if (B < 1 || M < 1 || T < 1) return -1;
+  hipLaunchKernelGGL(col_normalize_kernel, flat_grid(B*T), dim3(256), 0, (hipStream_t)stream, x,
+                     (int)M, (int)T, (long long)(B*T), eps);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_deltas(const float* x, float* out, int64_t B, int64_t M, int64_t T, brv_stream_t stream) {
+  if (B < 1 || M < 1 || T < 1) return -1;
+  hipLaunchKernelGGL(deltas_kernel, flat_grid(B*M*T), dim3(256), 0, (hipStream_t)stream, x, out,
+                     (int)M, (int)T, (long long)(B*M*T));
   FF_OK(hipGetLastError());
   return 0;
 }

@@ -92,6 +92,9 @@ SIGNATURES = {
                          ctypes.c_int, _c_ptr]),
     'brv_fbe_power': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_compress': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.c_int, _c_f32, _c_ptr]),
+    'brv_binaural': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, ctypes.c_int, _c_f32, _c_ptr]),
+    'brv_col_normalize': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_f32, _c_ptr]),
+    'brv_deltas': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_irm': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr]),
     'brv_stack_frames': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_static_norm': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64,

@@ -1,14 +1,18 @@
-"""Log-mel filterbank features on the HIP path.
+"""Filterbank features on the HIP path.
 
-Reference: ``FeatureExtractor`` (brever/modules/features.py:13-140) and its ``fbe``
-family (:142-205): squared magnitude averaged over the two channels, mel filterbank,
-optional normalisation / compression. Built here: ``fbe``, ``logfbe``, ``cubicfbe``
-(what the FFNN model uses by default is ``logfbe``). The binaural features (``ild``,
-``ipd``, ``ic``) and the DCT-based ones (``mfcc`` ...) need ``torchaudio.lfilter`` /
-``scipy.fft`` host code in the reference and are not built: asking for them raises
-``NotImplementedError`` (same names, so configurations fail loudly instead of silently
-computing something else).
+Reference: ``FeatureExtractor`` (brever/modules/features.py:13-140), its ``fbe`` family
+(:142-220: squared magnitude averaged over the two channels, mel filterbank, optional
+normalisation over the filters ('pdf'), log / cubic compression, DCT-II + delta /
+double-delta rows ('mfcc' ...)) and the binaural level / phase differences ``ild`` / ``ipd``
+(:222-262). Every step is a kernel of ``libbrever_hip.so`` (``brv_fbe_power``,
+``brv_binaural``, the mel and DCT products ``brv_matmul_f32``, ``brv_col_normalize``,
+``brv_compress``, ``brv_deltas``). Not built: ``ic`` (interaural coherence), whose recursive
+smoothing is ``torchaudio.functional.lfilter`` in the reference (absent wheel, parity
+unpinned): asking for it raises ``NotImplementedError``.
 """
+import math
+
+import numpy as np
 import torch
 
 from .. import hip
@@ -17,9 +21,14 @@ eps = torch.finfo().eps          # features.py:10
 
 
 class FeatureExtractor:
-    _built = {'fbe': 0, 'logfbe': 1, 'cubicfbe': 2}
-    _known = {'ild', 'ipd', 'ic', 'fbe', 'logfbe', 'cubicfbe', 'pdf', 'logpdf', 'cubicpdf',
-              'mfcc', 'cubicmfcc', 'pdfcc'}
+    # name -> (normalize, compression mode, dct); compression 0 none, 1 log, 2 cubic
+    _fbe_family = {'fbe': (False, 0, False), 'logfbe': (False, 1, False),
+                   'cubicfbe': (False, 2, False), 'pdf': (True, 0, False),
+                   'logpdf': (True, 1, False), 'cubicpdf': (True, 2, False),
+                   'mfcc': (False, 1, True), 'cubicmfcc': (False, 2, True),
+                   'pdfcc': (True, 1, True)}
+    _known = set(_fbe_family) | {'ild', 'ipd', 'ic'}
+    _n_dct = 14                   # DCT coefficients kept, the DC term is dropped (features.py:143)
 
     def __init__(self, features, mel_fb, hop_length=256, fs=16e3):
         self.features = sorted(features)
@@ -27,15 +36,21 @@ class FeatureExtractor:
         self.hop_length = hop_length
         self.fs = fs
         self.indices = None
+        self._dct = None
         for f in self.features:
             if f not in self._known:
                 raise ValueError(f'unrecognized feature, got {f}')
-            if f not in self._built:
-                raise NotImplementedError(f'feature {f} is not built yet on the HIP path')
+            if f == 'ic':
+                raise NotImplementedError('feature ic is not built on the HIP path')
+
+    def _n(self, feature):
+        # the reference's table lists 13 for the DCT features although they come with their
+        # delta and double-delta rows (39 rows); kept for an identical n_features
+        return 13 if self._fbe_family.get(feature, (0, 0, False))[2] else self.mel_fb.n_filters
 
     @property
     def n_features(self):
-        return self.mel_fb.n_filters*len(self.features)
+        return sum(self._n(f) for f in self.features)
 
     def __call__(self, x):
         output = []
@@ -55,11 +70,41 @@ class FeatureExtractor:
             x = x.unsqueeze(0)
         elif x.ndim != 4:
             raise ValueError(f'input must be 3 or 4 dimensional, got {x.ndim}')
-        out = self.fbe(x, mode=self._built[feature])
+        if feature in ('ild', 'ipd'):
+            out = self.binaural(x, 0 if feature == 'ild' else 1)
+        elif feature in self._fbe_family:
+            out = self.fbe(x, *self._fbe_family[feature])
+        elif feature == 'ic':
+            raise NotImplementedError('feature ic is not built on the HIP path')
+        else:
+            raise ValueError(f'unrecognized feature, got {feature}')
         return out.squeeze(0) if unbatched else out
 
-    def fbe(self, x, mode=0):
-        """(B, channels, bins, frames) complex -> (B, n_filters, frames)."""
+    def binaural(self, x, mode):
+        """ILD / IPD of (B, 2, bins, frames) complex -> (B, n_filters, frames)."""
+        hip.require_device(x)
+        B, C, bins, F = x.shape
+        if C != 2:
+            raise ValueError(f'binaural features need 2 channels, got {C}')
+        spec = torch.view_as_real(x.to(torch.complex64).contiguous())
+        cue = torch.empty(B, bins, F, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_binaural(hip.ptr(spec), hip.ptr(cue), B, bins*F, mode, float(eps),
+                                         hip.stream()), 'brv_binaural')
+        return self.mel_fb(cue)
+
+    def _dct_matrix(self, M, device):
+        """Rows 1..n_dct-1 of the orthonormal DCT-II of length M (scipy.fft.dct(type=2,
+        norm='ortho'), features.py:200-205), built in float64."""
+        if self._dct is None or self._dct.shape[1] != M or self._dct.device != device:
+            k = np.arange(1, self._n_dct)[:, None]
+            n = np.arange(M)[None, :]
+            D = math.sqrt(2.0/M)*np.cos(math.pi*(2*n + 1)*k/(2*M))
+            self._dct = torch.from_numpy(D).float().to(device).contiguous()
+        return self._dct
+
+    def fbe(self, x, normalize=False, compression=0, dct=False):
+        """(B, channels, bins, frames) complex -> (B, n_filters, frames), or (B, 39, frames) with
+        the DCT (13 cepstral rows + their first and second differences)."""
         hip.require_device(x)
         lib = hip.lib()
         B, C, bins, F = x.shape
@@ -67,8 +112,21 @@ class FeatureExtractor:
         power = torch.empty(B, bins, F, dtype=torch.float32, device=x.device)
         hip.check(lib.brv_fbe_power(hip.ptr(spec), hip.ptr(power), B, C, bins*F, hip.stream()),
                   'brv_fbe_power')
-        out = self.mel_fb(power)
-        if mode:
-            hip.check(lib.brv_compress(hip.ptr(out), hip.ptr(out), out.numel(), mode,
+        out = self.mel_fb(power).contiguous()
+        M = out.shape[1]
+        if normalize:
+            hip.check(lib.brv_col_normalize(hip.ptr(out), B, M, F, float(eps), hip.stream()),
+                      'brv_col_normalize')
+        if compression:
+            hip.check(lib.brv_compress(hip.ptr(out), hip.ptr(out), out.numel(), compression,
                                        float(eps), hip.stream()), 'brv_compress')
+        if dct:
+            D = self._dct_matrix(M, x.device)
+            K = D.shape[0]
+            cep = torch.empty(B, K, F, dtype=torch.float32, device=x.device)
+            hip.check(lib.brv_matmul_f32(hip.ptr(D), hip.ptr(out), hip.ptr(cep), B, K, F, M, 0,
+                                         hip.stream()), 'brv_matmul_f32')
+            out = torch.empty(B, 3*K, F, dtype=torch.float32, device=x.device)
+            hip.check(lib.brv_deltas(hip.ptr(cep), hip.ptr(out), B, K, F, hip.stream()),
+                      'brv_deltas')
         return out

@@ -192,6 +192,15 @@ int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64
  * brv_masked_mean_spec: mask * mean over channels of a complex spectrum (FFNN._enhance). */
 int brv_fbe_power(const float* spec, float* out, int64_t B, int64_t C, int64_t n, brv_stream_t stream);
 int brv_compress(const float* x, float* out, int64_t n, int mode, float eps, brv_stream_t stream);
+/* The other members of the FeatureExtractor family (modules/features.py:142-262): binaural:
+ * ILD (mode 0) / IPD (mode 1) of a (B, 2, n) complex64 spectrum -> (B, n); col_normalize: the
+ * 'pdf' normalisation over the filter axis of (B, M, T), in place; deltas: (B, M, T) ->
+ * (B, 3M, T) = [x | first | second difference along the frames, zero left padding] (the
+ * delta / double-delta rows of the mfcc features; the DCT itself is a brv_matmul_f32). */
+int brv_binaural(const float* spec, float* out, int64_t B, int64_t n, int mode, float eps,
+                 brv_stream_t stream);
+int brv_col_normalize(float* x, int64_t B, int64_t M, int64_t T, float eps, brv_stream_t stream);
+int brv_deltas(const float* x, float* out, int64_t B, int64_t M, int64_t T, brv_stream_t stream);
 int brv_irm(const float* fg, const float* bg, float* out, int64_t n, float eps, brv_stream_t stream);
 int brv_stack_frames(const float* x, float* out, int64_t B, int64_t nf, int64_t T, int64_t stacks,
                      brv_stream_t stream);

@@ -529,6 +529,24 @@ def golden_sgmse(out):
     np.savez_compressed(os.path.join(out, 'sgmse.npz'), **res)
 
 
+def golden_features(out):
+    """FeatureExtractor (brever/modules/features.py) on a seeded 2-channel spectrum: every
+    feature except 'ic' (needs torchaudio.lfilter), one by one and concatenated."""
+    from brever.modules import FeatureExtractor, MelFilterbank
+    g = torch.Generator().manual_seed(21)
+    spec = torch.randn(2, 2, 257, 23, generator=g, dtype=torch.complex64)
+    names = ['cubicfbe', 'cubicmfcc', 'cubicpdf', 'fbe', 'ild', 'ipd', 'logfbe', 'logpdf', 'mfcc',
+             'pdf', 'pdfcc']
+    res = dict(spec=spec.numpy(), names=np.array(names))
+    mel = MelFilterbank()
+    for name in names:                       # batched, one feature at a time
+        res[name] = FeatureExtractor({name}, mel).calc_feature(spec, name).numpy()
+    fx = FeatureExtractor(set(names), mel)
+    res['all'] = fx(spec[0]).numpy()         # the reference's __call__ takes unbatched input
+    res['n_features'] = np.array(fx.n_features)
+    np.savez_compressed(os.path.join(out, 'features.npz'), **res)
+
+
 def golden_segments(out):
     """Segment tables of BreverDataset.get_segment_info (brever/data.py:112-210) for seeded
     file lengths x strategies x (segment, overlap, max segment) settings; the file-length
@@ -565,7 +583,7 @@ def main():
     os.chdir(REF)       # the reference opens config/... relatively
     torch.set_num_threads(4)
     todo = [golden_batching, golden_collate, golden_losses, golden_convtasnet, golden_training,
-            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments]
+            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features]
     only = sys.argv[1:]                  # e.g. `make_golden.py sgmse` regenerates one file
     for fn in todo:
         if not only or fn.__name__[len('golden_'):] in only:

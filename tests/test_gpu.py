@@ -615,7 +615,7 @@ def test_ffnn_matches_reference(golden_dir):
         l1 = float(net.train_step(batch, lengths, False, scaler))
     assert l1 < l0
     with pytest.raises(NotImplementedError):
-        FFNN(features={'ild'})
+        FFNN(features={'ic'})
 
 
 @pytest.mark.gpu
@@ -1085,3 +1085,34 @@ def test_entry_points_sgmse(tmp_path):
     out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:2:0.25')
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert np.isfinite(np.load(os.path.join(model_dir, 'scores.npz'))['scores']).all()
+
+
+@pytest.mark.gpu
+def test_feature_extractor_matches_reference(golden_dir):
+    """Every FeatureExtractor feature except 'ic' (filterbank energies, 'pdf' normalisation,
+    log / cubic compression, DCT cepstra with delta rows, ILD, IPD) vs the reference goldens,
+    batched one by one and concatenated on an unbatched item (fp32: 2e-4 of the feature's
+    range; the cepstral rows amplify the log's rounding: 1e-3)."""
+    from brever_amd.modules import FeatureExtractor, MelFilterbank
+    g = np.load(os.path.join(golden_dir, 'features.npz'))
+    dev = _cuda()
+    spec = torch.from_numpy(g['spec']).to(dev)
+    mel = MelFilterbank()
+    names = [str(n) for n in g['names']]
+    for name in names:
+        got = FeatureExtractor({name}, mel).calc_feature(spec, name).cpu()
+        want = torch.from_numpy(g[name])
+        assert got.shape == want.shape, name
+        tol = 1e-3 if 'cc' in name else 2e-4
+        assert float((got - want).abs().max()) <= tol*float(want.abs().max()), \
+            (name, float((got - want).abs().max()), float(want.abs().max()))
+    fx = FeatureExtractor(set(names), mel)
+    allf = fx(spec[0]).cpu()
+    want = torch.from_numpy(g['all'])
+    assert allf.shape == want.shape and fx.n_features == int(g['n_features'])
+    assert float((allf - want).abs().max()) <= 1e-3*float(want.abs().max())
+    assert fx.indices['ild'] == (64*3 + 39*1, 64*4 + 39*1)       # sorted names, reference layout
+    with pytest.raises(NotImplementedError):
+        FeatureExtractor({'ic'}, mel)
+    with pytest.raises(ValueError):
+        FeatureExtractor({'nope'}, mel)

@@ -351,3 +351,18 @@ def test_sgmse_training_oracle_matches_reference(golden_dir, tag):
                      else torch.zeros(net.sd[n].numel()) for n in names])
     gold = torch.from_numpy(g[f'{tag}_train_grads'])
     assert (got - gold).norm() <= 1e-4*gold.norm()
+
+
+def test_features_oracle_matches_reference(golden_dir):
+    """oracle/features.py vs the imported reference for every feature except 'ic'."""
+    from oracle import features as of
+    from oracle.ffnn import mel_filters
+    g = np.load(os.path.join(golden_dir, 'features.npz'))
+    filters = mel_filters()[0] if isinstance(mel_filters(), tuple) else mel_filters()
+    filters = np.asarray(filters, dtype=np.float64)
+    spec = g['spec'].astype(np.complex128)
+    for name in g['names']:
+        want = g[str(name)]
+        got = of.FEATURES[str(name)](spec, filters)
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 2e-4*scale, (name, np.abs(got - want).max(), scale)
