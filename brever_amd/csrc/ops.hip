@@ -234,4 +234,27 @@ int brv_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
   return 0;
 }
 
+
+// ema += (1 - beta)*(param - ema), each operation rounded on its own (the reference's
+// `ema_param += (1 - beta) * (param - ema_param)`, brever/modules/ema.py:36-39: no FMA
+// contraction, so the averages are bit-identical to the reference's)
+__global__ __launch_bounds__(256) void ema_update_kernel(float* ema, const float* param,
+                                                         float one_minus_beta, long long n) {
+#pragma clang fp contract(off)
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const float d = param[i] - ema[i];
+    const float s = one_minus_beta*d;
+    ema[i] = ema[i] + s;
+  }
+}
+int brv_ema_update(float* ema, const float* param, float one_minus_beta, int64_t n,
+                   brv_stream_t stream) {
+  if (n < 1) return -1;
+  long long g = (n + 255)/256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ema,
+                     param, one_minus_beta, (long long)n);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
 }  // extern "C"

@@ -1,3 +1,4 @@
 """DSP modules of the HIP path (reference: brever/modules/)."""
 from .stft import STFT, ConvSTFT, MelFilterbank  # noqa: F401
 from .features import FeatureExtractor  # noqa: F401
+from .ema import EMA, EMAKarras  # noqa: F401

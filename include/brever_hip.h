@@ -383,6 +383,11 @@ int brv_clip_adam_step(float* params, float* grads, float* exp_avg,
                        float eps, int64_t step, void* scratch, float* norm_out,
                        brv_stream_t stream);
 
+/* Exponential moving average of the parameters (EMA / EMAKarras.update,
+ * brever/modules/ema.py:36-39): ema += (1 - beta)*(param - ema), rounded as the reference. */
+int brv_ema_update(float* ema, const float* param, float one_minus_beta, int64_t n,
+                   brv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -547,6 +547,45 @@ def golden_features(out):
     np.savez_compressed(os.path.join(out, 'features.npz'), **res)
 
 
+def golden_ema(out):
+    """EMA / EMAKarras (brever/modules/ema.py) on a tiny Linear model through 12 seeded parameter
+    updates: running averages, Karras exponents, post-hoc weights and the post-hoc average
+    reconstructed from per-step checkpoints."""
+    import brever.modules.ema as ema_mod
+    from brever.modules import EMA, EMAKarras
+    # torch >= 2.6 loads with weights_only=True by default, which rejects the numpy scalars of
+    # the reference's own checkpoints (SURVEY 8c): load them the way the pinned torch did
+    patched = types.SimpleNamespace(**{n: getattr(torch, n) for n in dir(torch)})
+    patched.load = lambda f, **k: torch.load(f, weights_only=False)
+    ema_mod.torch = patched
+    g = torch.Generator().manual_seed(5)
+    model = torch.nn.Linear(6, 5)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.randn(p.shape, generator=g))
+    res = dict(init=torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy())
+    ema = EMA(model, beta=0.97)
+    kar = EMAKarras(model, sigma_rels=[0.05, 0.1])
+    steps = []
+    with tempfile.TemporaryDirectory() as d:
+        for i in range(12):
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(0.1*torch.randn(p.shape, generator=g))
+            steps.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy())
+            ema.update(); kar.update()
+            torch.save(kar.state_dict(), f'{d}/{i:02d}.ckpt')
+        post = kar.post_hoc_ema(d, 0.2, apply=False)
+        post2 = kar.post_hoc_ema(d, [0.15, 0.3], t_r=[8, 12], apply=False)
+    flat = lambda ps: torch.cat([p.reshape(-1) for p in ps]).numpy()   # noqa: E731
+    res.update(params=np.stack(steps), ema=flat(ema.ema_params),
+               kar_005=flat(kar.ema_params[0.05]), kar_010=flat(kar.ema_params[0.1]),
+               gammas=np.array([kar._gammas[0.05], kar._gammas[0.1]]),
+               post=flat(post), post2=np.stack([flat(p) for p in post2]),
+               weights=EMAKarras.solve_weights([3, 7, 12], [5.0, 9.0, 5.0], [12, 10], [6.5, 7.0]))
+    np.savez_compressed(os.path.join(out, 'ema.npz'), **res)
+
+
 def golden_segments(out):
     """Segment tables of BreverDataset.get_segment_info (brever/data.py:112-210) for seeded
     file lengths x strategies x (segment, overlap, max segment) settings; the file-length
@@ -583,7 +622,7 @@ def main():
     os.chdir(REF)       # the reference opens config/... relatively
     torch.set_num_threads(4)
     todo = [golden_batching, golden_collate, golden_losses, golden_convtasnet, golden_training,
-            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features]
+            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features, golden_ema]
     only = sys.argv[1:]                  # e.g. `make_golden.py sgmse` regenerates one file
     for fn in todo:
         if not only or fn.__name__[len('golden_'):] in only:

@@ -1116,3 +1116,17 @@ def test_feature_extractor_matches_reference(golden_dir):
         FeatureExtractor({'ic'}, mel)
     with pytest.raises(ValueError):
         FeatureExtractor({'nope'}, mel)
+
+
+@pytest.mark.gpu
+def test_ema_on_device_matches_reference(golden_dir):
+    """The same EMA / EMAKarras sequence with the parameters on the GPU (``brv_ema_update``):
+    bit-identical running averages, post-hoc reconstruction within fp32 rounding."""
+    from test_host import _ema_run
+    g = np.load(os.path.join(golden_dir, 'ema.npz'))
+    ema, kar, flat, post, post2, applied, _ = _ema_run(g, _cuda())
+    assert np.array_equal(flat(ema.ema_params), g['ema'])
+    assert np.array_equal(flat(kar.ema_params[0.05]), g['kar_005'])
+    assert np.array_equal(flat(kar.ema_params[0.1]), g['kar_010'])
+    assert np.allclose(flat(post), g['post'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(applied.numpy(), g['post'], rtol=1e-5, atol=1e-6)

@@ -275,3 +275,56 @@ def test_brever_dataset_reads_wav_datasets(tmp_path, tar):
         BreverDataset(root, tar=tar, segment_strategy='nope', segment_length=1.0)
     with pytest.raises(NotImplementedError):
         BreverDataset(root, tar=tar, dynamic_mixing=True)
+
+
+def _ema_run(g, device):
+    """The golden's update sequence on ``device`` with brever_amd's EMA classes."""
+    import tempfile
+
+    from brever_amd.modules import EMA, EMAKarras
+    model = torch.nn.Linear(6, 5).to(device)
+
+    def assign(flat):
+        o = 0
+        with torch.no_grad():
+            for p in model.parameters():
+                p.copy_(torch.from_numpy(flat[o:o + p.numel()]).view_as(p))
+                o += p.numel()
+    assign(g['init'])
+    ema, kar = EMA(model, beta=0.97), EMAKarras(model, sigma_rels=[0.05, 0.1])
+    with tempfile.TemporaryDirectory() as d:
+        for i, flat in enumerate(g['params']):
+            assign(flat)
+            ema.update(); kar.update()
+            torch.save(kar.state_dict(), f'{d}/{i:02d}.ckpt')
+        post = kar.post_hoc_ema(d, 0.2, apply=False)
+        post2 = kar.post_hoc_ema(d, [0.15, 0.3], t_r=[8, 12], apply=False)
+        kar.store()
+        kar.post_hoc_ema(d, 0.2)                               # apply=True writes the model
+        applied = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+        kar.restore()
+    flat = lambda ps: torch.cat([p.detach().reshape(-1) for p in ps]).cpu().numpy()   # noqa: E731
+    return ema, kar, flat, post, post2, applied, model
+
+
+def test_ema_matches_reference_on_cpu(golden_dir):
+    """EMA / EMAKarras vs the imported reference on CPU parameters: running averages bit-exact,
+    Karras exponents, post-hoc weights and reconstructions; store / restore / state_dict."""
+    from brever_amd.modules import EMA, EMAKarras
+    g = np.load(os.path.join(golden_dir, 'ema.npz'))
+    ema, kar, flat, post, post2, applied, model = _ema_run(g, 'cpu')
+    assert np.array_equal(flat(ema.ema_params), g['ema'])
+    assert np.array_equal(flat(kar.ema_params[0.05]), g['kar_005'])
+    assert np.array_equal(flat(kar.ema_params[0.1]), g['kar_010'])
+    assert np.allclose([kar._gammas[0.05], kar._gammas[0.1]], g['gammas'], rtol=1e-12)
+    assert np.allclose(EMAKarras.solve_weights([3, 7, 12], [5.0, 9.0, 5.0], [12, 10], [6.5, 7.0]),
+                       g['weights'], rtol=1e-9)
+    assert np.allclose(flat(post), g['post'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(np.stack([flat(p) for p in post2]), g['post2'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(applied.numpy(), g['post'], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(flat(list(model.parameters())), g['params'][-1])     # restored
+    other = EMA(torch.nn.Linear(6, 5), beta=0.97)
+    other.load_state_dict(ema.state_dict())
+    assert np.array_equal(flat(other.ema_params), g['ema'])
+    with pytest.raises(RuntimeError):
+        ema.restore()
