@@ -176,6 +176,14 @@ __global__ __launch_bounds__(64) void gn_bwd_coef_kernel(const double* part, int
     if (dadd) dadd[bc] = (float)(c1*s1 + c2*s3 + c3*(double)HW);
   }
 }
+__global__ __launch_bounds__(256) void affine_bwd_final_kernel(const double* part, int slices,
+                                                               float* s1_out, float* s2_out, int n) {
+  const int bc = blockIdx.x*256 + threadIdx.x;
+  if (bc >= n) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < slices; ++i) { s1 += part[((long long)bc*slices + i)*3]; s2 += part[((long long)bc*slices + i)*3 + 1]; }
+  s1_out[bc] = (float)s1; s2_out[bc] = (float)s2;
+}
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* x, const float* dy,
                                                            const float* scale, const float* shift,
                                                            const float* mu, const float* rstd,
@@ -358,6 +366,31 @@ int brv_groupnorm_backward(const float* x, const float* dy, const float* scale_b
   const long long total = B*C*HW;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, flat_grid(total), dim3(256), 0, st, x, dy, scale_bc,
                      shift_bc, mu_bc, rstd_bc, k1, k2, k3, dx, (long long)HW, total, act_silu);
+  SG_OK(hipGetLastError());
+  return 0;
+}
+// backward of y = act(scale[b][c]*x + shift[b][c]) (brv_affine_act): dx = scale*u, d scale =
+// sum_hw u*x, d shift = sum_hw u with u = dy*act'(pre): the group-norm sums kernel with a
+// unit "normalisation" (mu = 0, rstd = 1) and its apply kernel with k1 = scale, k2 = k3 = 0
+int brv_affine_act_backward(const float* x, const float* dy, const float* scale_bc,
+                            const float* shift_bc, const float* zeros_bc, const float* ones_bc,
+                            float* dx, float* dscale_bc, float* dshift_bc, int64_t B, int64_t C,
+                            int64_t HW, int act_silu, brv_stream_t stream) {
+  if (B < 1 || C < 1 || HW < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  long long slices = (HW + 16383)/16384;
+  if (slices > 32) slices = 32;
+  double* part = nullptr;
+  SG_OK(hipMallocAsync((void**)&part, (size_t)B*C*slices*3*sizeof(double), st));
+  hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3((unsigned)(B*C), (unsigned)slices), dim3(256), 0, st, x,
+                     dy, scale_bc, shift_bc, zeros_bc, ones_bc, part, (long long)HW, act_silu);
+  hipLaunchKernelGGL(affine_bwd_final_kernel, dim3((unsigned)((B*C + 255)/256)), dim3(256), 0, st,
+                     part, (int)slices, dshift_bc, dscale_bc, (int)(B*C));
+  SG_OK(hipFreeAsync(part, st));
+  const long long total = B*C*HW;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, flat_grid(total), dim3(256), 0, st, x, dy, scale_bc,
+                     shift_bc, zeros_bc, ones_bc, scale_bc, zeros_bc, zeros_bc, dx, (long long)HW,
+                     total, act_silu);
   SG_OK(hipGetLastError());
   return 0;
 }

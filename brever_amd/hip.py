@@ -131,6 +131,7 @@ SIGNATURES = {
     'brv_groupnorm_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_groupnorm_fold': (ctypes.c_int, [_c_ptr]*11 + [_c_i64]*4 + [_c_f32, _c_ptr]),
     'brv_groupnorm_backward': (ctypes.c_int, [_c_ptr]*12 + [_c_i64]*4 + [ctypes.c_int, _c_ptr]),
+    'brv_affine_act_backward': (ctypes.c_int, [_c_ptr]*9 + [_c_i64]*3 + [ctypes.c_int, _c_ptr]),
     'brv_silu_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
     'brv_softmax_rows_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_affine_act': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*3 + [ctypes.c_int, _c_ptr]),

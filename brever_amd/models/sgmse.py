@@ -11,7 +11,7 @@ tensors and holds the parameters.
 
 Built: every SDE, both solvers (``pc``, ``edm``), all three preconditionings and every
 encoder / decoder / block type of ``DiffusionUNet``; training (``loss``) runs the differentiable
-fp32 network of ``sgmse_train.py`` (``block_type='adm'`` not built for training).
+network of ``sgmse_train.py``.
 """
 import math
 import os

@@ -6,8 +6,7 @@ matrix + exact-fp32 MFMA products for the convolutions and their weight / data g
 ``brv_groupnorm_fold / brv_affine_act / brv_groupnorm_backward``, ``brv_silu*``,
 ``brv_fir_resample2d`` in both directions, ``brv_softmax_rows*``). The block structure follows
 brever/models/sgmse/net.py:232-452 exactly as the inference path does; torch only
-concatenates, slices and carries the autograd graph. ``block_type='adm'`` is not built for
-training.
+concatenates, slices and carries the autograd graph.
 """
 import torch
 
@@ -123,6 +122,36 @@ class GroupNormFn(torch.autograd.Function):
             C, H*W, groups, int(silu), hip.stream()), 'brv_groupnorm_backward')
         # d gamma / d beta: (B, C) -> (C,), a handful of values
         return dx, (dadd if has_add else None), s2.sum(0), s1.sum(0), None, None, None
+
+
+class AffineActFn(torch.autograd.Function):
+    """act(scale[:, :, None, None]*x + shift[:, :, None, None]) with per-(item, channel) scale and
+    shift that carry gradients (the ADM modulation (1 + m)*norm + s followed by SiLU)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, silu):
+        x, scale, shift = x.contiguous(), scale.contiguous(), shift.contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        hip.check(hip.lib().brv_affine_act(hip.ptr(x), hip.ptr(scale), hip.ptr(shift), hip.ptr(y), B,
+                                           C, H*W, int(silu), hip.stream()), 'brv_affine_act')
+        ctx.save_for_backward(x, scale, shift)
+        ctx.silu = bool(silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dscale, dshift = torch.empty_like(scale), torch.empty_like(shift)
+        zeros, ones = torch.zeros_like(scale), torch.ones_like(scale)
+        hip.check(hip.lib().brv_affine_act_backward(
+            hip.ptr(x), hip.ptr(dy), hip.ptr(scale), hip.ptr(shift), hip.ptr(zeros), hip.ptr(ones),
+            hip.ptr(dx), hip.ptr(dscale), hip.ptr(dshift), B, C, H*W, int(ctx.silu), hip.stream()),
+            'brv_affine_act_backward')
+        return dx, dscale, dshift, None
 
 
 class SiluFn(torch.autograd.Function):
@@ -294,8 +323,6 @@ def attention(blk, x, out_scale):
 
 
 def unet_block(blk, x, emb):
-    if blk.block_type == 'adm':
-        raise NotImplementedError("training with block_type='adm' is not built yet")
     h = group_norm(x, blk.norm_1, silu=True)
     if blk.resampler is not None:
         h = resample(blk.resampler, h, blk.up_or_down)
@@ -304,7 +331,12 @@ def unet_block(blk, x, emb):
     e = LinearFn.apply(emb, blk.linear.weight, blk.linear.bias)
     if e.shape[0] != h.shape[0]:
         e = e.expand(h.shape[0], -1)
-    h = group_norm(h, blk.norm_2, add=e, silu=True)
+    if blk.block_type == 'adm':       # silu((scale + 1)*norm(h) + shift), net.py:405-407
+        m, sh = e.chunk(2, dim=1)
+        h = AffineActFn.apply(group_norm(h, blk.norm_2), AxpbyFn.apply(m, 1.0, torch.ones_like(m), 1.0),
+                              sh, True)
+    else:
+        h = group_norm(h, blk.norm_2, add=e, silu=True)
     if blk.dropout.p > 0:
         h = torch.nn.functional.dropout(h, blk.dropout.p, training=blk.training)
     h = conv(h, blk.conv_2)

@@ -324,6 +324,12 @@ int brv_groupnorm_backward(const float* x, const float* dy, const float* scale_b
                            const float* gamma, float* dx, float* s1_bc, float* s2_bc, float* dadd_bc,
                            float* coef_scratch, int64_t B, int64_t C, int64_t HW, int64_t groups,
                            int act_silu, brv_stream_t stream);
+/* Backward of brv_affine_act (the ADM modulation of UNetBlock, net.py:405-407): dx and the
+ * per-(item, channel) gradients of scale and shift; zeros_bc / ones_bc: (B, C) constants. */
+int brv_affine_act_backward(const float* x, const float* dy, const float* scale_bc,
+                            const float* shift_bc, const float* zeros_bc, const float* ones_bc,
+                            float* dx, float* dscale_bc, float* dshift_bc, int64_t B, int64_t C,
+                            int64_t HW, int act_silu, brv_stream_t stream);
 int brv_silu_backward(const float* x, const float* dy, float* dx, int64_t n, brv_stream_t stream);
 int brv_softmax_rows_backward(const float* p, const float* dy, float* dx, int64_t rows, int64_t cols,
                               brv_stream_t stream);

@@ -287,13 +287,14 @@ def enhance(net, sde, wav, window, hop_length, sampler, compression=0.5, scale=0
     return (torch.from_numpy(wave).float()*norm)[..., :length].squeeze(1)
 
 
-def train_loss(net, sde, batch, lengths, t, noise, precond='richter'):
+def train_loss(net, sde, batch, lengths, t, noise, precond='richter', sigma_data=0.1):
     """SGMSEp.loss (sgmse.py:163-176) with the draws of t and of the noise given: weighted,
     length-masked complex MSE (criterion.py:104-132) between the denoiser output and the
     clean-minus-noisy target."""
     y, x0 = batch[:, 0].unsqueeze(1), batch[:, 1].unsqueeze(1)
     sigma = sde.sigma(t)
-    weight = 1/sigma**2 if precond == 'richter' else None
+    weight = 1/sigma**2 if precond == 'richter' \
+        else (sigma**2 + sigma_data**2)/(sigma*sigma_data)**2
     d = denoise(net, sde, x0 - y + sigma*noise, y, sigma, t, precond=precond)
     frames = torch.arange(d.shape[-1])
     mask = (frames[None, :] < lengths[:, None])[:, None, None, :]

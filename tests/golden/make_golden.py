@@ -495,8 +495,6 @@ def golden_sgmse(out):
             for i, d in enumerate(draws):
                 res[f'{tag}_noise_{i}'] = d.numpy()
             res[f'{tag}_n_noise'] = np.array(len(draws))
-        if tag == 'edm':
-            continue
         # training objective (sgmse.py:163-176) on a ragged batch of two items with the draws of
         # t and of the Gaussian noise fixed: loss value and all parameter gradients
         import brever.models.sgmse.sgmse as sg

@@ -1017,7 +1017,7 @@ def test_entry_points_on_a_dataset_directory(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['pc', 'res'])
+@pytest.mark.parametrize('tag', ['pc', 'res', 'edm'])
 def test_sgmse_training_matches_reference(golden_dir, tag):
     """SGMSE+ training on the HIP path: the denoising score matching loss and ALL parameter
     gradients vs the reference golden (t and noise draws replayed), fp32 kernels: loss 1e-4,

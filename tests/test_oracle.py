@@ -331,7 +331,7 @@ def test_sgmse_oracle_matches_reference(golden_dir, tag):
     assert (out - ref).abs().max() <= 1e-4*ref.abs().max()
 
 
-@pytest.mark.parametrize('tag', ['pc', 'res'])
+@pytest.mark.parametrize('tag', ['pc', 'res', 'edm'])
 def test_sgmse_training_oracle_matches_reference(golden_dir, tag):
     """The training objective and ALL parameter gradients of the oracle network vs the imported
     reference with the draws of t and of the noise fixed."""
@@ -339,11 +339,12 @@ def test_sgmse_training_oracle_matches_reference(golden_dir, tag):
     from oracle import sgmse as osg
     g = np.load(os.path.join(golden_dir, 'sgmse.npz'))
     model, _, sde, kw, _, _, _ = sgmse_case(g, tag)
-    net = osg.Net(model.state_dict(), 'model.net.', skip_scale=0.5**0.5, requires_grad=True)
+    net = osg.Net(model.state_dict(), 'model.net.', skip_scale=0.5**0.5,
+                  block_type='adm' if tag == 'edm' else 'ncsn', requires_grad=True)
     loss = osg.train_loss(net, sde, torch.from_numpy(g[f'{tag}_train_batch']),
                           torch.from_numpy(g[f'{tag}_train_lengths']),
                           torch.from_numpy(g[f'{tag}_train_t']),
-                          torch.from_numpy(g[f'{tag}_train_noise']))
+                          torch.from_numpy(g[f'{tag}_train_noise']), **kw)
     assert abs(float(loss) - float(g[f'{tag}_train_loss'])) <= 1e-5
     loss.backward()
     names = [n[len('model.net.'):] for n, _ in model.named_parameters()]
