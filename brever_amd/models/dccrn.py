@@ -502,6 +502,15 @@ class DCCRN(BreverBaseModel):
     def update(self, loss, scaler):
         super().update(loss, scaler, grad_clip=5.0)
 
+    @property
+    def latency(self):
+        """Algorithmic latency in samples (dccrn.py:136-142): one STFT frame plus the look-ahead of
+        the encoder / decoder convolutions along the frame axis."""
+        _, kernel_size = self.kernel_size
+        _, stride = self.stride
+        enc_dec = (kernel_size - 1)*sum(stride**i for i in range(len(self.channels)))
+        return self.stft.frame_length + enc_dec*self.stft.hop_length
+
     def _enhance(self, x, use_amp):
         _AMP['on'] = bool(use_amp)
         try:

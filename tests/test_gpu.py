@@ -1130,3 +1130,30 @@ def test_ema_on_device_matches_reference(golden_dir):
     assert np.array_equal(flat(kar.ema_params[0.1]), g['kar_010'])
     assert np.allclose(flat(post), g['post'], rtol=1e-5, atol=1e-6)
     assert np.allclose(applied.numpy(), g['post'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_dccrn_latency_bound():
+    """The reference's latency test (tests/test_models.py:57-80) on the HIP DCCRN: samples from
+    ``nan_start`` on are NaN; the first NaN of the enhanced signal may not come earlier than
+    ``nan_start - latency + 1`` (time-causality of the convolutions, the LSTM, the STFT pair)."""
+    import random
+
+    from brever_amd.models import DCCRN
+    dev = _cuda()
+    torch.manual_seed(0)
+    net = DCCRN(channels=[4, 8, 8, 16, 16, 16], lstm_channels=16).to(dev).eval()
+    latency = net.latency
+    assert latency == 512 + (2 - 1)*6*128                  # default STFT 512 / 128, six layers
+    random.seed(0)
+    lo = max(1600, latency + 1)
+    for i in range(12):
+        length = random.randint(lo, 3200)
+        x = torch.randn(2, length)
+        nan_start = latency if i == 0 else random.randint(latency, length - 1)
+        x[..., nan_start:] = float('nan')
+        y = net.enhance(x.to(dev)).cpu()
+        assert y.shape[-1] == length
+        bad = torch.isnan(y).nonzero()
+        first = int(bad.min()) if bad.numel() else length
+        assert first >= nan_start - latency + 1, (i, first, nan_start, latency)
