@@ -967,10 +967,15 @@ class SGMSEp(BreverBaseModel):
 
     @torch.no_grad()
     def forward(self, x, y, sigma, t):
-        """Denoiser D(x; y, sigma, t) for one noise level (0-d ``sigma``, ``t``)."""
+        """Denoiser D(x; y, sigma, t): one noise level for the whole batch (0-d ``sigma``, ``t``:
+        the samplers' fast path), or one level per item (``sigma``, ``t`` of shape (B, 1, 1, 1), as
+        the training objective and the reference's known-answer test use it)."""
         hip.require_device(x, y)
-        return self.model(x.to(torch.complex64), y.to(torch.complex64),
-                          torch.as_tensor(sigma).float().cpu(), torch.as_tensor(t).float().cpu())
+        sigma, t = torch.as_tensor(sigma).float(), torch.as_tensor(t).float()
+        if sigma.numel() > 1 or t.numel() > 1:
+            return self.model.forward_train(x.to(torch.complex64), y.to(torch.complex64),
+                                            sigma.to(x.device), t.to(x.device))
+        return self.model(x.to(torch.complex64), y.to(torch.complex64), sigma.cpu(), t.cpu())
 
     def _draw_t(self, n, device):
         return torch.rand(n, 1, 1, 1, device=device)*(1 - self.t_eps) + self.t_eps

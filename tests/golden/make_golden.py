@@ -264,6 +264,13 @@ def golden_training(out):
             filters=4, filter_length=2, bottleneck_channels=1, hidden_channels=1,
             skip_channels=1, kernel_size=1, layers=1, repeats=1,
             output_sources=2), 3),
+        # reference tests/test_training.py:125-150 ('sgmse'): its random draws (training t and
+        # noise, the sampler's noise during validation) all come from the global CPU generator
+        ('sgmse', lambda: ModelRegistry.get('sgmsep')(
+            stft_frame_length=512, stft_hop_length=256, net_base_channels=4,
+            net_channel_mult=[1, 1, 1, 1], net_num_blocks_per_res=1, net_noise_channel_mult=1,
+            net_emb_channel_mult=1, net_fir_kernel=[1, 1], net_attn_resolutions=[0],
+            net_attn_bottleneck=False, solver_num_steps=1), 2),
     ]:
         torch.manual_seed(0)
         random.seed(0)

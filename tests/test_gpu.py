@@ -1157,3 +1157,72 @@ def test_dccrn_latency_bound():
         bad = torch.isnan(y).nonzero()
         first = int(bad.min()) if bad.numel() else length
         assert first >= nan_start - latency + 1, (i, first, nan_start, latency)
+
+
+@pytest.mark.gpu
+def test_sgmse_reproduces_the_reference_known_answer():
+    """The reference's own golden vector for the default SGMSE+ network
+    (tests/test_models.py:126-146) on the HIP path: same literals, torch.allclose defaults."""
+    from brever_amd.models import SGMSEp, set_all_weights
+    from test_oracle import SGMSE_KAT, sgmse_kat_inputs
+    dev = _cuda()
+    model = SGMSEp()
+    with torch.no_grad():
+        set_all_weights(model)
+    x, y, sigma, t, idx, randn = sgmse_kat_inputs()
+    model.model.net.emb.fourier_proj.b = randn(model.model.net.emb.fourier_proj.b.shape)
+    model = model.to(dev).eval()
+    out = model(x.to(dev), y.to(dev), sigma.to(dev), t.to(dev)).cpu()
+    assert torch.allclose(out.flatten()[idx], SGMSE_KAT), (out.flatten()[idx], SGMSE_KAT)
+
+
+@pytest.mark.gpu
+def test_sgmse_training_flow_reproduces_reference_literals(golden_dir):
+    """The reference's own 2-epoch training test for SGMSE+ (tests/test_training.py:125-150,
+    231-300) on the HIP path: seeded init, DummyDataset, bucket batching, Adam, validation
+    through the reverse sampler. The reference draws every random number (training t and noise,
+    the sampler's noise) from the global CPU generator; the three hooks of the model are
+    pointed at it here, so the run consumes the same stream. The first 10 parameters must
+    equal the literals of the reference's test file, the epoch losses its fixture."""
+    import random
+    import tempfile
+
+    from helpers import DummyDataset
+    from brever_amd.models import ModelRegistry
+    from brever_amd.training import BreverTrainer
+    literals = torch.tensor([-0.1922940910, 0.1330814660, -0.0099604866, 0.3955351412,
+                             -0.0439126305, 0.1317846030, -0.1510771811, -0.0984570533,
+                             -0.4786233008, -0.3303738832])
+    g = np.load(os.path.join(golden_dir, 'training.npz'))
+    assert np.allclose(g['sgmse'], literals.numpy(), atol=1e-7)
+    dev = _cuda()
+    FS = 16000
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    model = ModelRegistry.get('sgmsep')(
+        stft_frame_length=512, stft_hop_length=256, net_base_channels=4,
+        net_channel_mult=[1, 1, 1, 1], net_num_blocks_per_res=1, net_noise_channel_mult=1,
+        net_emb_channel_mult=1, net_fir_kernel=[1, 1], net_attn_resolutions=[0],
+        net_attn_bottleneck=False, solver_num_steps=1)
+    model._draw_t = lambda n, device: (torch.rand(n, 1, 1, 1)*(1 - model.t_eps) + model.t_eps).to(device)
+    model._draw_noise = lambda x0: torch.randn(x0.shape, dtype=torch.complex64).to(x0.device)
+    def sampler_noise(shape, complex_):
+        # the reference draws with randn_like on spectra that keep torch.stft's memory layout
+        # (frequency innermost: a transposed, non-contiguous tensor), for which torch's CPU
+        # generator takes its element-wise path: other values and another stream consumption
+        # than for a contiguous tensor of the same shape. Mimicked to stay on its stream.
+        B, C, F, T = shape
+        return torch.randn_like(torch.empty(B, C, T, F, dtype=torch.complex64).transpose(-1, -2))
+    model._noise_source = sampler_noise
+    train = DummyDataset(16, 2, 2, int(FS*0.5), FS*4, transform=model.transform)
+    val = DummyDataset(4, 2, 2, int(FS*0.5), FS*4)
+    with tempfile.TemporaryDirectory() as tmp:
+        trainer = BreverTrainer(
+            model=model, train_dataset=train, val_dataset=val, model_dirpath=tmp, epochs=2,
+            val_period=1, val_metrics={'snr'}, batch_sampler='bucket', batch_size=8.0,
+            dynamic_batch_size=True, ema=True, device=dev, preload=True)
+        trainer.run()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])[:10].cpu()
+    tl = np.array([float(d['loss']) for d in trainer.loss_logger.train_loss])
+    vl = np.array([float(d['loss']) for d in trainer.loss_logger.val_loss])
+    assert np.allclose(tl, g['sgmse_train_loss'], rtol=1e-3), (tl, g['sgmse_train_loss'])
+    assert torch.allclose(flat, literals, rtol=1e-3, atol=1e-4), (flat, literals)

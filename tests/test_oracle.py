@@ -367,3 +367,39 @@ def test_features_oracle_matches_reference(golden_dir):
         got = of.FEATURES[str(name)](spec, filters)
         scale = np.abs(want).max()
         assert np.abs(got - want).max() <= 2e-4*scale, (name, np.abs(got - want).max(), scale)
+
+
+# the literals of the reference's own known-answer test for the default SGMSE+ network
+# (tests/test_models.py:126-146: every parameter 1e-3, seeded Fourier frequencies and inputs)
+SGMSE_KAT = torch.tensor([
+    -0.8220521808+0.0136900125j, 0.6403278708-0.1466773599j, 0.0641574562-0.8893111944j,
+    1.0807795525-0.0940670595j, -0.6070679426-0.2562257946j, 0.2370606065+0.0774136111j,
+    0.6943444610-1.1398884058j, 0.3865116835-0.1694955975j, -0.3641569018-0.5190436840j,
+    0.0308193229+0.7649886608j])
+
+
+def sgmse_kat_inputs():
+    def randn(*shape, dtype=torch.float32):
+        return torch.randn(*shape, generator=torch.Generator().manual_seed(0), dtype=dtype)
+
+    def rand(*shape):
+        return torch.rand(*shape, generator=torch.Generator().manual_seed(0))
+    x = randn(4, 1, 256, 32, dtype=torch.cfloat)
+    idx = torch.randint(x.numel(), (10,), generator=torch.Generator().manual_seed(0))
+    return x, randn(4, 1, 256, 32, dtype=torch.cfloat), rand(4, 1, 1, 1), rand(4, 1, 1, 1), idx, randn
+
+
+def test_sgmse_oracle_reproduces_the_reference_known_answer():
+    """oracle/sgmse.py on the reference's own golden vector (default 65.6 M-parameter network,
+    all weights 1e-3, batch of four noise levels)."""
+    from brever_amd.models import SGMSEp, set_all_weights
+    from oracle import sgmse as osg
+    model = SGMSEp()
+    with torch.no_grad():
+        set_all_weights(model)
+    x, y, sigma, t, idx, randn = sgmse_kat_inputs()
+    model.model.net.emb.fourier_proj.b = randn(model.model.net.emb.fourier_proj.b.shape)
+    net = osg.Net(model.state_dict(), 'model.net.', skip_scale=0.5**0.5)
+    with torch.no_grad():
+        out = osg.denoise(net, osg.RichterOUVE(), x, y, sigma, t)
+    assert torch.allclose(out.flatten()[idx], SGMSE_KAT)
