@@ -200,20 +200,47 @@ class _MultiResYuFunction(torch.autograd.Function):
         return out.view(shape).to(in_dtype), None, None, None, None, None
 
 
+class _ScaleInvariantFunction(torch.autograd.Function):
+    """x -> alpha*x with alpha = <x, y>/(<x, x> + eps) per (item, source) row over the samples
+    below the item length (brever/criterion.py:207-212); zero beyond the length."""
+
+    @staticmethod
+    def forward(ctx, x, y, lengths):
+        x2, y2, lengths, B, S, L = _rows(x, y, lengths)
+        out = torch.empty_like(x2)
+        stats = torch.empty(B*S, 2, dtype=torch.float64, device=x2.device)
+        hip.check(hip.lib().brv_si_scale_forward(
+            hip.ptr(x2), hip.ptr(y2), hip.ptr(lengths), hip.ptr(out), hip.ptr(stats), B, S, L,
+            float(eps), hip.stream()), 'brv_si_scale_forward')
+        ctx.save_for_backward(x2, y2, lengths, stats)
+        ctx.shape = x.shape
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, y2, lengths, stats = ctx.saved_tensors
+        B, S, L = x2.shape
+        g2 = g.reshape(B, S, L).float().contiguous()
+        dx = torch.empty_like(x2)
+        hip.check(hip.lib().brv_si_scale_backward(
+            hip.ptr(g2), hip.ptr(x2), hip.ptr(y2), hip.ptr(lengths), hip.ptr(stats), hip.ptr(dx), B,
+            S, L, hip.stream()), 'brv_si_scale_backward')
+        return dx.view(ctx.shape), None, None
+
+
 @CriterionRegistry.register('multiresyu')
 class MultiResYuLoss:
     """Multi-resolution STFT magnitude + L1 time-domain loss
     (brever/criterion.py:135-226): boxcar, un-normalised STFTs of ``frame_lengths`` /
     ``hop_lengths`` (default: half the frame), ``(B, ..., L)`` -> ``(B,)``.
-    ``scale_invariant=True`` is not built yet on the HIP path."""
+    ``scale_invariant=True`` first rescales each estimate by its least-squares gain towards the
+    target (``_ScaleInvariantFunction``)."""
 
     def __init__(self, frame_lengths=[512], hop_lengths=None, time_domain_weight=0.5,
                  spectral_weight=0.5, scale_invariant=False):
         from .modules.stft import STFT
         if hop_lengths is None:
             hop_lengths = [x // 2 for x in frame_lengths]
-        if scale_invariant:
-            raise NotImplementedError('scale_invariant=True is not built yet on the HIP path')
         self.stfts = [STFT(frame_length=n, hop_length=h, window=None, normalized=False)
                       for n, h in zip(frame_lengths, hop_lengths)]
         self.time_domain_weight = time_domain_weight
@@ -222,6 +249,8 @@ class MultiResYuLoss:
 
     def __call__(self, x, y, lengths):
         assert x.shape == y.shape
+        if self.scale_invariant:
+            x = _ScaleInvariantFunction.apply(x, y, lengths)
         return _MultiResYuFunction.apply(x, y, lengths, self.stfts,
                                          float(self.time_domain_weight),
                                          float(self.spectral_weight))

@@ -257,4 +257,69 @@ int brv_ema_update(float* ema, const float* param, float one_minus_beta, int64_t
   OPS_OK(hipGetLastError());
   return 0;
 }
+
+// Scale-invariant pre-scaling of MultiResYuLoss (criterion.py:207-212): per row (item, source)
+// alpha = <x, y>/(<x, x> + eps) over the samples below the item length; out = alpha*x there,
+// zero beyond. One workgroup per row: reduce, then scale. stats[row] = (alpha, <x, x> + eps).
+__global__ __launch_bounds__(256) void si_scale_fwd_kernel(const float* x, const float* y,
+                                                           const long long* lengths, float* out,
+                                                           double* stats, int S, long long L,
+                                                           float eps) {
+  __shared__ double scr[8];
+  __shared__ double bc[2];
+  const long long row = blockIdx.x;
+  const long long n = lengths[row / S] < L ? lengths[row / S] : L;
+  const float* xr = x + row*L; const float* yr = y + row*L; float* orow = out + row*L;
+  double sxy = 0.0, sxx = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) { sxy += (double)xr[i]*yr[i]; sxx += (double)xr[i]*xr[i]; }
+  sxy = block_sum(sxy, scr); __syncthreads();
+  sxx = block_sum(sxx, scr);
+  if (threadIdx.x == 0) {
+    // fp32 arithmetic of the reference: sums, then the quotient, all in float
+    const float d = (float)sxx + eps;
+    bc[0] = (double)((float)sxy/d); bc[1] = (double)d;
+    stats[2*row] = bc[0]; stats[2*row + 1] = bc[1];
+  }
+  __syncthreads();
+  const float a = (float)bc[0];
+  for (long long i = threadIdx.x; i < L; i += 256) orow[i] = i < n ? a*xr[i] : 0.f;
+}
+// dx = alpha*g + <g, x>*(y - 2 alpha x)/D below the length, 0 beyond
+__global__ __launch_bounds__(256) void si_scale_bwd_kernel(const float* g, const float* x,
+                                                           const float* y, const long long* lengths,
+                                                           const double* stats, float* dx, int S,
+                                                           long long L) {
+  __shared__ double scr[8];
+  __shared__ double bc;
+  const long long row = blockIdx.x;
+  const long long n = lengths[row / S] < L ? lengths[row / S] : L;
+  const float* gr = g + row*L; const float* xr = x + row*L; const float* yr = y + row*L;
+  double sgx = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 256) sgx += (double)gr[i]*xr[i];
+  sgx = block_sum(sgx, scr);
+  if (threadIdx.x == 0) bc = sgx;
+  __syncthreads();
+  const float a = (float)stats[2*row], c = (float)(bc/stats[2*row + 1]);
+  float* drow = dx + row*L;
+  for (long long i = threadIdx.x; i < L; i += 256)
+    drow[i] = i < n ? a*gr[i] + c*(yr[i] - 2.f*a*xr[i]) : 0.f;
+}
+int brv_si_scale_forward(const float* x, const float* y, const int64_t* lengths, float* out,
+                         double* stats, int64_t B, int64_t S, int64_t L, float eps,
+                         brv_stream_t stream) {
+  if (B < 1 || S < 1 || L < 1) return -1;
+  hipLaunchKernelGGL(si_scale_fwd_kernel, dim3((unsigned)(B*S)), dim3(256), 0, (hipStream_t)stream,
+                     x, y, (const long long*)lengths, out, stats, (int)S, (long long)L, eps);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+int brv_si_scale_backward(const float* g, const float* x, const float* y, const int64_t* lengths,
+                          const double* stats, float* dx, int64_t B, int64_t S, int64_t L,
+                          brv_stream_t stream) {
+  if (B < 1 || S < 1 || L < 1) return -1;
+  hipLaunchKernelGGL(si_scale_bwd_kernel, dim3((unsigned)(B*S)), dim3(256), 0, (hipStream_t)stream,
+                     g, x, y, (const long long*)lengths, stats, dx, (int)S, (long long)L);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
 }  // extern "C"

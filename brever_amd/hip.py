@@ -145,6 +145,8 @@ SIGNATURES = {
     'brv_conv2d_pack_f16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_conv2d_mfma_forward': (ctypes.c_int, [_c_ptr]*6 + [ctypes.c_int, _c_ptr] + [_c_i64]*8
                                 + [_c_f32, _c_ptr]),
+    'brv_si_scale_forward': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*3 + [_c_f32, _c_ptr]),
+    'brv_si_scale_backward': (ctypes.c_int, [_c_ptr]*6 + [_c_i64]*3 + [_c_ptr]),
     'brv_ema_update': (ctypes.c_int, [_c_ptr, _c_ptr, _c_f32, _c_i64, _c_ptr]),
     'brv_clip_adam_step': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                           _c_i64, _c_f32, _c_f32, _c_f32,

@@ -377,6 +377,17 @@ int brv_mag_l1_forward(const float* xspec, const float* yspec, double* sums, int
 int brv_mag_l1_backward(const float* xspec, const float* yspec, const float* grow,
                         float* dxspec, int64_t rows, int64_t n, brv_stream_t stream);
 
+/* Scale-invariant variant of MultiResYuLoss (criterion.py:207-212): x is first multiplied per
+ * (item, source) row by alpha = <x, y>/(<x, x> + eps) over the samples below the item length.
+ * forward: out = alpha*x (zero beyond the length), stats (rows, 2) doubles = (alpha, <x,x>+eps);
+ * backward: dx from the gradient g with respect to alpha*x. */
+int brv_si_scale_forward(const float* x, const float* y, const int64_t* lengths, float* out,
+                         double* stats, int64_t B, int64_t S, int64_t L, float eps,
+                         brv_stream_t stream);
+int brv_si_scale_backward(const float* g, const float* x, const float* y, const int64_t* lengths,
+                          const double* stats, float* dx, int64_t B, int64_t S, int64_t L,
+                          brv_stream_t stream);
+
 /* ---- optimizer --------------------------------------------------------------
  * clip_grad_norm_(max_norm) + Adam.step (base.py:296-301, torch.optim.Adam with
  * amsgrad=False, weight_decay=0) on flat buffers of n floats. grads are first

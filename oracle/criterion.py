@@ -85,14 +85,17 @@ def _boxcar_stft(x, frame_length, hop_length):
 
 
 def multiresyu(x, y, lengths, frame_lengths=(512,), hop_lengths=None, time_domain_weight=0.5,
-               spectral_weight=0.5):
+               spectral_weight=0.5, scale_invariant=False):
     """Time-domain L1 + multi-resolution STFT-magnitude L1, divided by the item length
-    (brever/criterion.py:193-226, scale_invariant=False)."""
+    (brever/criterion.py:193-226); scale_invariant: the estimate is first multiplied by
+    <x, y>/(<x, x> + eps) per row (:207-212)."""
     assert x.shape == y.shape
     if hop_lengths is None:
         hop_lengths = [n//2 for n in frame_lengths]
     m = length_mask(x, lengths)
     x, y = x*m, y*m
+    if scale_invariant:
+        x = x*((x*y).sum(-1, keepdim=True)/(x.pow(2).sum(-1, keepdim=True) + EPS))
     out = time_domain_weight*(x - y).abs().sum(-1)
     for n, h in zip(frame_lengths, hop_lengths):
         xm, ym = _boxcar_stft(x, n, h).abs(), _boxcar_stft(y, n, h).abs()

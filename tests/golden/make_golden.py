@@ -180,7 +180,8 @@ def golden_losses(out):
     from brever.criterion import MultiResYuLoss
     for tag, kw in (('multiresyu', {}),
                     ('multiresyu3', dict(frame_lengths=[512, 256, 128], time_domain_weight=0.3,
-                                         spectral_weight=0.7))):
+                                         spectral_weight=0.7)),
+                    ('multiresyu_si', dict(frame_lengths=[256, 128], scale_invariant=True))):
         crit = MultiResYuLoss(**kw)
         res[tag] = crit(x, y, lengths).numpy()
         xg = x.clone().requires_grad_(True)

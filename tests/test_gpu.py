@@ -421,7 +421,8 @@ def test_multiresyu_matches_reference(golden_dir):
     assert 'multiresyu' in CriterionRegistry
     for tag, kw in (('multiresyu', {}),
                     ('multiresyu3', dict(frame_lengths=[512, 256, 128], time_domain_weight=0.3,
-                                         spectral_weight=0.7))):
+                                         spectral_weight=0.7)),
+                    ('multiresyu_si', dict(frame_lengths=[256, 128], scale_invariant=True))):
         crit = init_criterion('multiresyu', **kw)
         xg = x.clone().requires_grad_(True)
         got = crit(xg, y, lengths)

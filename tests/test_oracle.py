@@ -49,7 +49,8 @@ def test_multiresyu_matches_reference(golden_dir):
     gw = torch.from_numpy(g['gweight'])
     for tag, kw in (('multiresyu', {}),
                     ('multiresyu3', dict(frame_lengths=[512, 256, 128], time_domain_weight=0.3,
-                                         spectral_weight=0.7))):
+                                         spectral_weight=0.7)),
+                    ('multiresyu_si', dict(frame_lengths=[256, 128], scale_invariant=True))):
         xg = x.clone().requires_grad_(True)
         got = oc.multiresyu(xg, y, lengths, **kw)
         assert torch.allclose(got, torch.from_numpy(g[tag]), rtol=1e-5, atol=1e-6), tag
