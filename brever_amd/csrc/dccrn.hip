@@ -169,6 +169,120 @@ __global__ __launch_bounds__(256) void invstd_from_var_kernel(const float* var, 
   if (c < C) invstd[c] = 1.f/sqrtf(var[c] + eps);
 }
 
+// ---- complex batch norm (models/dccrn/complex_batchnorm.py) as three pieces ------------------
+// x (B, 2C, HW), real half first. (1) per complex channel the five means E[xr], E[xi], E[xr^2],
+// E[xi^2], E[xr xi] over (B, HW) (sliced fp64 partial sums); the 2x2 whitening and the affine
+// map are a handful of per-channel scalars computed by the caller; (2) y = A x + o per channel
+// with A (4, C) = [a_rr, a_ri, a_ir, a_ii] and o (2, C), then the optional scalar PReLU;
+// (3) the adjoints of both.
+__global__ __launch_bounds__(256) void cplx_moments_part_kernel(const float* x, int B, int C,
+                                                                long long HW, double* part) {
+  __shared__ double scr[8];
+  const int c = blockIdx.x;
+  long long lo, hi;
+  slice_range((long long)B*HW, lo, hi);
+  double s[5] = {0, 0, 0, 0, 0};
+  for (long long e = lo + threadIdx.x; e < hi; e += 256) {
+    const long long b = e / HW, i = e % HW;
+    const float xr = x[((b*2*C) + c)*HW + i], xi = x[((b*2*C) + C + c)*HW + i];
+    s[0] += xr; s[1] += xi; s[2] += (double)xr*xr; s[3] += (double)xi*xi; s[4] += (double)xr*xi;
+  }
+  for (int k = 0; k < 5; ++k) {
+    const double v = block_sum(s[k], scr);
+    __syncthreads();
+    if (threadIdx.x == 0) part[((long long)c*gridDim.y + blockIdx.y)*5 + k] = v;
+  }
+}
+__global__ __launch_bounds__(256) void slice_final_kernel(const double* part, int slices, int K,
+                                                          int C, double inv_n, float* out) {
+  const int idx = blockIdx.x*256 + threadIdx.x;          // (k, c) -> out[k][c]
+  if (idx >= K*C) return;
+  const int k = idx / C, c = idx % C;
+  double s = 0.0;
+  for (int i = 0; i < slices; ++i) s += part[((long long)c*slices + i)*K + k];
+  out[idx] = (float)(s*inv_n);
+}
+__global__ __launch_bounds__(256) void cplx_affine_fwd_kernel(const float* x, const float* A,
+                                                              const float* o, const float* slope,
+                                                              float* y, int C, long long HW,
+                                                              long long total) {
+  const float a = slope ? *slope : 1.f;
+  GRID_STRIDE(idx, total) {                       // idx over (b, c, i) of the REAL half
+    const long long i = idx % HW, bc = idx / HW;
+    const int c = (int)(bc % C); const long long b = bc / C;
+    const long long pr = ((b*2*C) + c)*HW + i, pi = pr + (long long)C*HW;
+    const float xr = x[pr], xi = x[pi];
+    float yr = A[c]*xr + A[C + c]*xi + o[c];
+    float yi = A[2*C + c]*xr + A[3*C + c]*xi + o[C + c];
+    if (slope) { yr = yr > 0.f ? yr : a*yr; yi = yi > 0.f ? yi : a*yi; }
+    y[pr] = yr; y[pi] = yi;
+  }
+}
+// partial sums per channel: [u_r xr, u_r xi, u_i xr, u_i xi, u_r, u_i, slope grad], u = dy*prelu'
+__global__ __launch_bounds__(256) void cplx_affine_bwd_part_kernel(const float* x, const float* dy,
+                                                                   const float* A, const float* o,
+                                                                   const float* slope, int B, int C,
+                                                                   long long HW, double* part) {
+  __shared__ double scr[8];
+  const int c = blockIdx.x;
+  const float a = slope ? *slope : 1.f;
+  long long lo, hi;
+  slice_range((long long)B*HW, lo, hi);
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (long long e = lo + threadIdx.x; e < hi; e += 256) {
+    const long long b = e / HW, i = e % HW;
+    const long long pr = ((b*2*C) + c)*HW + i, pi = pr + (long long)C*HW;
+    const float xr = x[pr], xi = x[pi];
+    float ur = dy[pr], ui = dy[pi];
+    if (slope) {
+      const float yr = A[c]*xr + A[C + c]*xi + o[c];
+      const float yi = A[2*C + c]*xr + A[3*C + c]*xi + o[C + c];
+      if (yr <= 0.f) { s[6] += (double)ur*yr; ur *= a; }
+      if (yi <= 0.f) { s[6] += (double)ui*yi; ui *= a; }
+    }
+    s[0] += (double)ur*xr; s[1] += (double)ur*xi; s[2] += (double)ui*xr; s[3] += (double)ui*xi;
+    s[4] += ur; s[5] += ui;
+  }
+  for (int k = 0; k < 7; ++k) {
+    const double v = block_sum(s[k], scr);
+    __syncthreads();
+    if (threadIdx.x == 0) part[((long long)c*gridDim.y + blockIdx.y)*7 + k] = v;
+  }
+}
+// dx = A^T u (+ the gradient that flows through the five means, gm (5, C), already divided by
+// the number of elements per channel)
+__global__ __launch_bounds__(256) void cplx_affine_bwd_apply_kernel(const float* x, const float* dy,
+                                                                    const float* A, const float* o,
+                                                                    const float* slope,
+                                                                    const float* gm, float* dx,
+                                                                    int C, long long HW,
+                                                                    long long total) {
+  const float a = slope ? *slope : 1.f;
+  GRID_STRIDE(idx, total) {
+    const long long i = idx % HW, bc = idx / HW;
+    const int c = (int)(bc % C); const long long b = bc / C;
+    const long long pr = ((b*2*C) + c)*HW + i, pi = pr + (long long)C*HW;
+    const float xr = x[pr], xi = x[pi];
+    float dr = 0.f, di = 0.f;
+    if (dy) {
+      float ur = dy[pr], ui = dy[pi];
+      if (slope) {
+        const float yr = A[c]*xr + A[C + c]*xi + o[c];
+        const float yi = A[2*C + c]*xr + A[3*C + c]*xi + o[C + c];
+        if (yr <= 0.f) ur *= a;
+        if (yi <= 0.f) ui *= a;
+      }
+      dr = A[c]*ur + A[2*C + c]*ui;
+      di = A[C + c]*ur + A[3*C + c]*ui;
+    }
+    if (gm) {
+      dr += gm[c] + 2.f*xr*gm[2*C + c] + xi*gm[4*C + c];
+      di += gm[C + c] + 2.f*xi*gm[3*C + c] + xr*gm[4*C + c];
+    }
+    dx[pr] = dr; dx[pi] = di;
+  }
+}
+
 // LSTM recurrence for one layer (torch gate order i, f, g, o): gates_in = W_ih x precomputed
 // for all steps, bias = b_ih + b_hh; one workgroup per batch item, h and c in LDS.
 __global__ __launch_bounds__(256) void lstm_recurrent_kernel(const float* gates_in, const float* w_hh,
@@ -824,6 +938,69 @@ int brv_complex_weight_unpack(const float* dwc, float* dwr, float* dwi, int64_t 
   if (R < 1 || C < 1) return -1;
   hipLaunchKernelGGL(cweight_unpack_kernel, flat_grid(R*C), dim3(256), 0, (hipStream_t)stream, dwc,
                      dwr, dwi, (int)R, (int)C, sign);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_cplx_moments(const float* x, float* moments, int64_t B, int64_t C, int64_t HW,
+                     brv_stream_t stream) {
+  if (B < 1 || C < 1 || HW < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int slices = red_slices(B*HW);
+  double* part = nullptr;
+  DC_OK(hipMallocAsync((void**)&part, (size_t)C*slices*5*sizeof(double), st));
+  hipLaunchKernelGGL(cplx_moments_part_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st,
+                     x, (int)B, (int)C, (long long)HW, part);
+  hipLaunchKernelGGL(slice_final_kernel, dim3((unsigned)((5*C + 255)/256)), dim3(256), 0, st, part,
+                     slices, 5, (int)C, 1.0/((double)B*(double)HW), moments);
+  DC_OK(hipFreeAsync(part, st));
+  DC_OK(hipGetLastError());
+  return 0;
+}
+int brv_cplx_affine_forward(const float* x, const float* A, const float* o, const float* prelu_slope,
+                            float* y, int64_t B, int64_t C, int64_t HW, brv_stream_t stream) {
+  if (B < 1 || C < 1 || HW < 1) return -1;
+  const long long total = B*C*HW;
+  hipLaunchKernelGGL(cplx_affine_fwd_kernel, flat_grid(total), dim3(256), 0, (hipStream_t)stream, x,
+                     A, o, prelu_slope, y, (int)C, (long long)HW, total);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+int brv_cplx_affine_backward(const float* x, const float* dy, const float* A, const float* o,
+                             const float* prelu_slope, float* dx, float* dA, float* d_o,
+                             float* dslope_partial, int64_t B, int64_t C, int64_t HW,
+                             brv_stream_t stream) {
+  if (B < 1 || C < 1 || HW < 1) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const int slices = red_slices(B*HW);
+  double* part = nullptr;
+  float* sums = nullptr;
+  DC_OK(hipMallocAsync((void**)&part, (size_t)C*slices*7*sizeof(double), st));
+  DC_OK(hipMallocAsync((void**)&sums, (size_t)7*C*sizeof(float), st));
+  hipLaunchKernelGGL(cplx_affine_bwd_part_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0,
+                     st, x, dy, A, o, prelu_slope, (int)B, (int)C, (long long)HW, part);
+  hipLaunchKernelGGL(slice_final_kernel, dim3((unsigned)((7*C + 255)/256)), dim3(256), 0, st, part,
+                     slices, 7, (int)C, 1.0, sums);
+  DC_OK(hipMemcpyAsync(dA, sums, (size_t)4*C*4, hipMemcpyDeviceToDevice, st));
+  DC_OK(hipMemcpyAsync(d_o, sums + 4*C, (size_t)2*C*4, hipMemcpyDeviceToDevice, st));
+  if (dslope_partial)
+    DC_OK(hipMemcpyAsync(dslope_partial, sums + 6*C, (size_t)C*4, hipMemcpyDeviceToDevice, st));
+  DC_OK(hipFreeAsync(part, st));
+  DC_OK(hipFreeAsync(sums, st));
+  const long long total = B*C*HW;
+  hipLaunchKernelGGL(cplx_affine_bwd_apply_kernel, flat_grid(total), dim3(256), 0, st, x, dy, A, o,
+                     prelu_slope, (const float*)nullptr, dx, (int)C, (long long)HW, total);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+int brv_cplx_moments_backward(const float* x, const float* gm, float* dx, int64_t B, int64_t C,
+                              int64_t HW, brv_stream_t stream) {
+  if (B < 1 || C < 1 || HW < 1) return -1;
+  const long long total = B*C*HW;
+  hipLaunchKernelGGL(cplx_affine_bwd_apply_kernel, flat_grid(total), dim3(256), 0,
+                     (hipStream_t)stream, x, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, gm, dx, (int)C, (long long)HW,
+                     total);
   DC_OK(hipGetLastError());
   return 0;
 }

@@ -124,6 +124,10 @@ SIGNATURES = {
     'brv_combine': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr]),
     'brv_dccrn_apply_mask': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                             _c_ptr]),
+    'brv_cplx_moments': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_cplx_affine_forward': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*3 + [_c_ptr]),
+    'brv_cplx_affine_backward': (ctypes.c_int, [_c_ptr]*9 + [_c_i64]*3 + [_c_ptr]),
+    'brv_cplx_moments_backward': (ctypes.c_int, [_c_ptr]*3 + [_c_i64]*3 + [_c_ptr]),
     'brv_im2col': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*12 + [_c_ptr]),
     'brv_col2im': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*12 + [_c_ptr]),
     'brv_complex_weight_pack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_ptr]),

@@ -35,15 +35,33 @@ class ComplexWrapper(_ParamOnly):
         self.module_imag = module_cls(*args, **kwargs)
 
 
+class ComplexBatchNorm2d(_ParamOnly):
+    """Parameter / buffer container of the reference's ComplexBatchNorm2d
+    (complex_batchnorm.py:29-74): weight (3, C) = W_rr, W_ri, W_ii, bias (2, C), running mean
+    (2, C) and running 2x2 covariance (2, 2, C)."""
+
+    def __init__(self, num_features, eps=1e-05, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.track_running_stats = True
+        self.weight = nn.Parameter(torch.empty(3, num_features))
+        self.bias = nn.Parameter(torch.empty(2, num_features))
+        self.register_buffer('running_mean', torch.zeros(2, num_features))
+        self.register_buffer('running_var', torch.eye(2, 2).unsqueeze(-1).repeat(1, 1, num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        with torch.no_grad():
+            self.weight.copy_(torch.tensor([[1.0], [0.0], [1.0]]))
+            self.bias.zero_()
+
+
 class EncoderBlock(_ParamOnly):
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding,
                  use_complex_batchnorm):
         super().__init__()
         self.conv = ComplexWrapper(nn.Conv2d, in_channels=in_channels, out_channels=out_channels,
                                    kernel_size=kernel_size, stride=stride, padding=padding)
-        if use_complex_batchnorm:
-            raise NotImplementedError('use_complex_batchnorm=True is not built yet on the HIP path')
-        self.norm = nn.BatchNorm2d(2*out_channels)
+        self.norm = ComplexBatchNorm2d(out_channels) if use_complex_batchnorm \
+            else nn.BatchNorm2d(2*out_channels)
         self.activation = nn.PReLU()
 
 
@@ -56,10 +74,8 @@ class DecoderBlock(_ParamOnly):
                                    stride=stride, padding=padding, output_padding=output_padding)
         self.norm, self.activation = None, None
         if norm:
-            if use_complex_batchnorm:
-                raise NotImplementedError('use_complex_batchnorm=True is not built yet on the '
-                                          'HIP path')
-            self.norm = nn.BatchNorm2d(2*out_channels)
+            self.norm = ComplexBatchNorm2d(out_channels) if use_complex_batchnorm \
+                else nn.BatchNorm2d(2*out_channels)
         if activation:
             self.activation = nn.PReLU()
 
@@ -294,6 +310,98 @@ class _BatchNormActFunction(torch.autograd.Function):
         return dx, dgamma, dbeta, dslope, None, None
 
 
+class _CplxMomentsFunction(torch.autograd.Function):
+    """x (B, 2C, H, W) -> (5, C): per-channel means of xr, xi, xr^2, xi^2, xr*xi."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C2, H, W = x.shape
+        m = torch.empty(5, C2//2, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_cplx_moments(hip.ptr(x), hip.ptr(m), B, C2//2, H*W, hip.stream()),
+                  'brv_cplx_moments')
+        ctx.save_for_backward(x)
+        return m
+
+    @staticmethod
+    def backward(ctx, gm):
+        x, = ctx.saved_tensors
+        B, C2, H, W = x.shape
+        gm = (gm.float()/(B*H*W)).contiguous()
+        dx = torch.empty_like(x)
+        hip.check(hip.lib().brv_cplx_moments_backward(hip.ptr(x), hip.ptr(gm), hip.ptr(dx), B, C2//2,
+                                                      H*W, hip.stream()), 'brv_cplx_moments_backward')
+        return dx
+
+
+class _CplxAffineFunction(torch.autograd.Function):
+    """y = A x + o per complex channel (A (4, C), o (2, C)) then the optional scalar PReLU."""
+
+    @staticmethod
+    def forward(ctx, x, A, o, slope):
+        x, A, o = x.contiguous(), A.contiguous(), o.contiguous()
+        B, C2, H, W = x.shape
+        y = torch.empty_like(x)
+        hip.check(hip.lib().brv_cplx_affine_forward(hip.ptr(x), hip.ptr(A), hip.ptr(o), hip.ptr(slope),
+                                                    hip.ptr(y), B, C2//2, H*W, hip.stream()),
+                  'brv_cplx_affine_forward')
+        ctx.save_for_backward(x, A, o, slope if slope is not None else A.new_zeros(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, A, o, slope = ctx.saved_tensors
+        has_slope = slope.numel() > 0
+        dy = dy.contiguous()
+        B, C2, H, W = x.shape
+        C = C2//2
+        dx = torch.empty_like(x)
+        dA, do = torch.empty_like(A), torch.empty_like(o)
+        dsl = torch.empty(C, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_cplx_affine_backward(
+            hip.ptr(x), hip.ptr(dy), hip.ptr(A), hip.ptr(o), hip.ptr(slope) if has_slope else None,
+            hip.ptr(dx), hip.ptr(dA), hip.ptr(do), hip.ptr(dsl), B, C, H*W, hip.stream()),
+            'brv_cplx_affine_backward')
+        dslope = None
+        if has_slope:
+            dslope = torch.empty(1, dtype=torch.float32, device=x.device)
+            hip.check(hip.lib().brv_row_sum(hip.ptr(dsl), hip.ptr(dslope), 1, 1, C, hip.stream()),
+                      'brv_row_sum')
+        return dx, dA, do, dslope
+
+
+def _complex_batch_norm(x, norm, slope):
+    """ComplexBatchNorm2d.forward (complex_batchnorm.py:76-215) + the block's PReLU. The reductions
+    over the tensor and the normalisation itself are HIP kernels; the 2x2 inverse square root of
+    the covariance and its composition with the affine weights are per-channel scalars (a few
+    element-wise torch operations on (C,) vectors that also carry their gradients)."""
+    training = norm.training
+    if training:
+        m = _CplxMomentsFunction.apply(x)
+        mean = m[:2]
+        vrr, vii = m[2] - m[0]*m[0] + norm.eps, m[3] - m[1]*m[1] + norm.eps
+        vri = m[4] - m[0]*m[1]
+        with torch.no_grad():
+            norm.num_batches_tracked += 1
+            norm.running_mean += norm.momentum*(mean - norm.running_mean)
+            cov = torch.stack([vrr, vri, vri, vii]).reshape(2, 2, -1)
+            norm.running_var += norm.momentum*(cov - norm.running_var)
+    else:
+        mean = norm.running_mean
+        vrr, vri, _, vii = norm.running_var.reshape(4, -1)
+    s = torch.sqrt(vrr*vii - vri*vri)
+    t = torch.sqrt(vrr + vii + 2*s)
+    denom = t*s
+    p, q, r, s2 = (vii + s)/denom, -vri/denom, -vri/denom, (vrr + s)/denom
+    w0, w1, w2 = norm.weight
+    a_rr, a_ri = p*w0 + q*w1, r*w0 + s2*w1
+    a_ir, a_ii = p*w1 + q*w2, r*w1 + s2*w2
+    A = torch.stack([a_rr, a_ri, a_ir, a_ii])
+    o = torch.stack([norm.bias[0] - (a_rr*mean[0] + a_ri*mean[1]),
+                     norm.bias[1] - (a_ir*mean[0] + a_ii*mean[1])])
+    return _CplxAffineFunction.apply(x, A, o, slope)
+
+
 class _LSTMFunction(torch.autograd.Function):
     """G independent single-layer unidirectional nn.LSTMs (batch_first, zero initial state) in
     one set of launches: x (G, B, T, I) -> hidden states (G, B, T, H), parameters stacked on a
@@ -426,6 +534,8 @@ class DCCRN(BreverBaseModel):
     def _norm_act(self, x, norm, act):
         if norm is None:
             return x
+        if isinstance(norm, ComplexBatchNorm2d):
+            return _complex_batch_norm(x, norm, act.weight if act is not None else None)
         training = norm.training and norm.track_running_stats
         return _BatchNormActFunction.apply(x, norm.weight, norm.bias,
                                            act.weight if act is not None else None, norm, training)

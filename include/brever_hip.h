@@ -297,6 +297,24 @@ int brv_complex_weight_pack(const float* wr, const float* wi, float* wc, int64_t
 int brv_complex_weight_unpack(const float* dwc, float* dwr, float* dwi, int64_t R, int64_t C,
                               float sign, brv_stream_t stream);
 
+/* ComplexBatchNorm2d (models/dccrn/complex_batchnorm.py:29-215) on x (B, 2C, HW), real half
+ * first: cplx_moments writes the five per-channel means (5, C) = E[xr], E[xi], E[xr^2],
+ * E[xi^2], E[xr xi]; the 2x2 whitening / affine scalars derived from them are applied by
+ * cplx_affine_forward: y_r = A[0]xr + A[1]xi + o[0], y_i = A[2]xr + A[3]xi + o[1] (A (4, C),
+ * o (2, C)) followed by the optional scalar PReLU; cplx_affine_backward returns dx, dA, d_o and
+ * per-channel partial sums of the slope gradient; cplx_moments_backward turns the gradient with
+ * respect to the five means (already divided by B*HW) into dx. */
+int brv_cplx_moments(const float* x, float* moments, int64_t B, int64_t C, int64_t HW,
+                     brv_stream_t stream);
+int brv_cplx_affine_forward(const float* x, const float* A, const float* o, const float* prelu_slope,
+                            float* y, int64_t B, int64_t C, int64_t HW, brv_stream_t stream);
+int brv_cplx_affine_backward(const float* x, const float* dy, const float* A, const float* o,
+                             const float* prelu_slope, float* dx, float* dA, float* d_o,
+                             float* dslope_partial, int64_t B, int64_t C, int64_t HW,
+                             brv_stream_t stream);
+int brv_cplx_moments_backward(const float* x, const float* gm, float* dx, int64_t B, int64_t C,
+                              int64_t HW, brv_stream_t stream);
+
 /* ---- SGMSE+ score network building blocks, forward values (models/sgmse/net.py:12-477,
  * modules/resampling.py:8-61). groupnorm_fold: nn.GroupNorm on x + add_bc[b][c] (nullable; the
  * noise-embedding term of UNetBlock) reduced to a per-(item, channel) affine scale / shift

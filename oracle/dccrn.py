@@ -45,11 +45,55 @@ class ComplexWrapper(nn.Module):                                   # dccrn.py:22
         return torch.cat([out_real, out_imag], dim=1)
 
 
+class ComplexBatchNorm2d(nn.Module):
+    """complex_batchnorm.py:29-215: centre, whiten with the inverse square root of the 2x2
+    covariance of (real, imaginary) per channel, then a 2x2 affine map."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.tensor([[1.0], [0.0], [1.0]]).repeat(1, num_features))
+        self.bias = nn.Parameter(torch.zeros(2, num_features))
+        self.register_buffer('running_mean', torch.zeros(2, num_features))
+        self.register_buffer('running_var', torch.eye(2).unsqueeze(-1).repeat(1, 1, num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x):
+        xr, xi = torch.chunk(x, 2, dim=1)
+        t = torch.stack([xr, xi])                                  # (2, B, C, H, W)
+        ax = (1, 3, 4)
+        if self.training:
+            self.num_batches_tracked += 1
+            mean = t.mean(dim=ax)
+            self.running_mean += self.momentum*(mean.detach() - self.running_mean)
+        else:
+            mean = self.running_mean
+        t = t - mean[:, None, :, None, None]
+        if self.training:
+            var = (t*t).mean(dim=ax) + self.eps
+            vrr, vii = var[0], var[1]
+            vri = (t[0]*t[1]).mean(dim=(0, 2, 3))
+            cov = torch.stack([vrr, vri, vri, vii]).detach().reshape(2, 2, -1)
+            self.running_var += self.momentum*(cov - self.running_var)
+        else:
+            vrr, vri, _, vii = self.running_var.reshape(4, -1)
+        s = torch.sqrt(vrr*vii - vri*vri)
+        den = torch.sqrt(vrr + vii + 2*s)*s
+        p, q, r, s2 = (vii + s)/den, -vri/den, -vri/den, (vrr + s)/den
+        sh = (1, -1, 1, 1)
+        z0 = t[0]*p.view(sh) + t[1]*r.view(sh)
+        z1 = t[0]*q.view(sh) + t[1]*s2.view(sh)
+        w, b = self.weight, self.bias
+        return torch.cat([z0*w[0].view(sh) + z1*w[1].view(sh) + b[0].view(sh),
+                          z0*w[1].view(sh) + z1*w[2].view(sh) + b[1].view(sh)], dim=1)
+
+
 class _Block(nn.Module):                                           # dccrn.py:234-290
-    def __init__(self, cls, cin, cout, norm=True, activation=True, **kw):
+    def __init__(self, cls, cin, cout, norm=True, activation=True, complex_bn=False, **kw):
         super().__init__()
         self.conv = ComplexWrapper(cls, in_channels=cin, out_channels=cout, **kw)
-        self.norm = nn.BatchNorm2d(2*cout) if norm else None
+        self.norm = (ComplexBatchNorm2d(cout) if complex_bn else nn.BatchNorm2d(2*cout)) \
+            if norm else None
         self.activation = nn.PReLU() if activation else None
 
     def forward(self, x):
@@ -95,15 +139,17 @@ class _LSTMBlock(nn.Module):                                       # dccrn.py:29
 
 class _MaskNet(nn.Module):                                         # dccrn.py:145-218
     def __init__(self, input_dim, channels, kernel_size, stride, padding, output_padding,
-                 lstm_channels, lstm_layers):
+                 lstm_channels, lstm_layers, complex_bn=False):
         super().__init__()
         kw = dict(kernel_size=kernel_size, stride=stride, padding=padding)
         self.encoder = nn.ModuleList(
-            _Block(nn.Conv2d, 1 if i == 0 else channels[i - 1], channels[i], **kw)
+            _Block(nn.Conv2d, 1 if i == 0 else channels[i - 1], channels[i], complex_bn=complex_bn,
+                   **kw)
             for i in range(len(channels)))
         self.decoder = nn.ModuleList(
             _Block(nn.ConvTranspose2d, channels[i]*2, 1 if i == 0 else channels[i - 1],
-                   norm=i != 0, activation=i != 0, output_padding=output_padding, **kw)
+                   norm=i != 0, activation=i != 0, output_padding=output_padding,
+                   complex_bn=complex_bn, **kw)
             for i in range(len(channels) - 1, -1, -1))
         dim = input_dim
         for _ in channels:
@@ -128,11 +174,12 @@ class _MaskNet(nn.Module):                                         # dccrn.py:14
 class OracleDCCRN(nn.Module):
     def __init__(self, n=512, hop=128, channels=(16, 32, 64, 128, 128, 128), kernel_size=(5, 2),
                  stride=(2, 1), padding=(2, 0), output_padding=(1, 0), lstm_channels=128,
-                 lstm_layers=2):
+                 lstm_layers=2, use_complex_batchnorm=False):
         super().__init__()
         self.n, self.hop = n, hop
         self.mask_net = _MaskNet(n//2, list(channels), kernel_size, stride, padding,
-                                 output_padding, lstm_channels, lstm_layers)
+                                 output_padding, lstm_channels, lstm_layers,
+                                 complex_bn=use_complex_batchnorm)
 
     @staticmethod
     def apply_mask(x, mask):                                       # dccrn.py:96-109

@@ -425,6 +425,30 @@ def golden_dccrn(out):
     with torch.no_grad():
         res['out_eval'] = net(x).numpy()
         res['enhance'] = net.enhance(torch.stack([x, 0.5*x], dim=1)).numpy()
+    # the complex batch norm variant (complex_batchnorm.py): same recipe, prefixed 'cbn_'
+    torch.manual_seed(0)
+    cfg2 = dict(cfg, use_complex_batchnorm=True)
+    net = DCCRN(**cfg2)
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if 'norm' in name or 'activation' in name:
+                p.add_(0.1*torch.randn(p.shape, generator=g))
+    res['cbn_config'] = json.dumps(cfg2)
+    res['cbn_params'] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+    net.train()
+    with torch.no_grad():
+        res['cbn_out_train'] = net(x).numpy()
+    res['cbn_running'] = torch.cat([b.detach().reshape(-1).float() for n, b in net.named_buffers()
+                                    if 'running' in n]).numpy()
+    net.zero_grad()
+    loss = net.loss(batch, lengths, use_amp=False)
+    loss.backward()
+    res['cbn_loss'] = loss.detach().numpy()
+    res['cbn_grads'] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    net.eval()
+    with torch.no_grad():
+        res['cbn_out_eval'] = net(x).numpy()
     np.savez_compressed(os.path.join(out, 'dccrn.npz'), **res)
 
 

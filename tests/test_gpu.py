@@ -1227,3 +1227,47 @@ def test_sgmse_training_flow_reproduces_reference_literals(golden_dir):
     vl = np.array([float(d['loss']) for d in trainer.loss_logger.val_loss])
     assert np.allclose(tl, g['sgmse_train_loss'], rtol=1e-3), (tl, g['sgmse_train_loss'])
     assert torch.allclose(flat, literals, rtol=1e-3, atol=1e-4), (flat, literals)
+
+
+@pytest.mark.gpu
+def test_dccrn_complex_batchnorm_matches_reference(golden_dir):
+    """DCCRN(use_complex_batchnorm=True) on the HIP path (moments, 2x2 whitening + affine map,
+    their adjoints) vs the reference golden: train / eval outputs, running statistics, loss and
+    every parameter gradient (same tolerances as the real batch-norm variant)."""
+    from brever_amd.models import DCCRN
+    g = np.load(os.path.join(golden_dir, 'dccrn.npz'))
+    dev = _cuda()
+    net = DCCRN(**json.loads(str(g['cbn_config']))).to(dev)
+    flat = torch.from_numpy(g['cbn_params']).to(dev)
+    o = 0
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+    assert o == flat.numel()
+    x = torch.from_numpy(g['x']).to(dev)
+    net.train()
+    with torch.no_grad():
+        y = net(x)
+    assert rel(y, torch.from_numpy(g['cbn_out_train'])) <= 2e-4
+    running = torch.cat([b.reshape(-1).float() for n, b in net.named_buffers()
+                         if 'running' in n]).cpu()
+    assert torch.allclose(running, torch.from_numpy(g['cbn_running']), rtol=1e-4, atol=1e-6)
+    batch = torch.from_numpy(g['batch']).to(dev)
+    lengths = torch.from_numpy(g['lengths']).to(dev)
+    loss = net.loss(batch, lengths, False)
+    assert abs(float(loss) - float(g['cbn_loss'])) <= 1e-4
+    loss.backward()
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+    gold = torch.from_numpy(g['cbn_grads'])
+    assert rel(got, gold) <= 2e-3, rel(got, gold)
+    o = 0
+    for n_, p in net.named_parameters():
+        k = p.numel()
+        ref = gold[o:o + k]
+        if float(ref.norm()) > 1e-4:
+            assert rel(got[o:o + k], ref) <= 1e-2, (n_, rel(got[o:o + k], ref))
+        o += k
+    net.eval()
+    with torch.no_grad():
+        assert rel(net(x), torch.from_numpy(g['cbn_out_eval'])) <= 2e-4

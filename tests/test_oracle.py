@@ -404,3 +404,29 @@ def test_sgmse_oracle_reproduces_the_reference_known_answer():
     with torch.no_grad():
         out = osg.denoise(net, osg.RichterOUVE(), x, y, sigma, t)
     assert torch.allclose(out.flatten()[idx], SGMSE_KAT)
+
+
+def test_dccrn_complex_batchnorm_oracle_matches_reference(golden_dir):
+    """oracle ComplexBatchNorm2d variant of DCCRN vs the imported reference: train / eval
+    outputs, running mean and covariance, loss and all gradients."""
+    from oracle.criterion import snr
+    from oracle.dccrn import OracleDCCRN
+    g = np.load(os.path.join(golden_dir, 'dccrn.npz'))
+    net = OracleDCCRN(**json.loads(str(g['cbn_config'])))
+    _load_flat(net, g['cbn_params'])
+    x = torch.from_numpy(g['x'])
+    net.train()
+    with torch.no_grad():
+        y = net(x)
+    assert torch.allclose(y, torch.from_numpy(g['cbn_out_train']), rtol=1e-4, atol=1e-6)
+    running = torch.cat([b.reshape(-1).float() for n, b in net.named_buffers() if 'running' in n])
+    assert torch.allclose(running, torch.from_numpy(g['cbn_running']), rtol=1e-5, atol=1e-7)
+    batch, lengths = torch.from_numpy(g['batch']), torch.from_numpy(g['lengths'])
+    loss = snr(net(batch[:, 0]), batch[:, 1], lengths).mean()
+    assert abs(float(loss) - float(g['cbn_loss'])) <= 1e-5
+    loss.backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.allclose(grads, torch.from_numpy(g['cbn_grads']), rtol=2e-3, atol=1e-5)
+    net.eval()
+    with torch.no_grad():
+        assert torch.allclose(net(x), torch.from_numpy(g['cbn_out_eval']), rtol=1e-4, atol=1e-6)
