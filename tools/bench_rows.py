@@ -40,8 +40,12 @@ def train_row(arch, batch, seconds, steps, use_amp):
     lengths = torch.full((batch,), (x[0] if isinstance(x, tuple) else x).shape[-1], device=dev)
     scaler = torch.amp.GradScaler('cuda', enabled=False)
     dt = timed(lambda: model.train_step(x, lengths, use_amp, scaler), 3, steps)
-    return {'row': f'{arch} train', 'utt_per_s': batch/dt, 'ms_per_step': dt*1e3, 'batch': batch,
-            'seconds': seconds}
+    row = {'row': f'{arch} train', 'utt_per_s': batch/dt, 'ms_per_step': dt*1e3, 'batch': batch,
+           'seconds': seconds}
+    if arch == 'dccrn' and seconds == 4.0:
+        # 51.2 GFLOP per 4 s utterance forward, x3 for a training step
+        row['tflops'] = batch/dt*3*51.2e9/1e12
+    return row
 
 
 def sgmse_row(seconds, steps):
@@ -56,7 +60,9 @@ def sgmse_row(seconds, steps):
         dt = timed(lambda: model.enhance(wav, use_amp=amp), 0, 1)
         out[f"{'fp16_mfma' if amp else 'fp32'}_b{batch}"] = {
             's_per_utt': dt/batch, 'utt_per_s': batch/dt, 'ms_per_nfe': dt/(2*steps)*1e3,
-            'rtf': dt/batch/seconds}
+            'rtf': dt/batch/seconds,
+            # 1.04 TFLOP per network evaluation and 4 s utterance
+            'tflops': batch*2*steps*1.04*(seconds/4.0)/dt}
     return {'row': f'sgmsep enhance, {steps}-step PC sampler ({2*steps} network evaluations)',
             'seconds': seconds, **out}
 
