@@ -73,7 +73,11 @@ def _conv(x, mod, fold=None, silu=False, res=None, out_scale=1.0):
     B, Cin, H, W = x.shape
     Cout = mod.out_channels
     (kh, kw), (sh, sw), (ph, pw) = mod.kernel_size, mod.stride, mod.padding
-    if _STATE['amp'] and kh == kw and kh in (1, 3) and (sh, sw) == (1, 1) and ph == pw == kh//2:
+    # (the MFMA kernel addresses its input with 32-bit byte offsets: very long spectrograms take
+    # the fp32 matrix-product path below instead)
+    fits = (-(-Cin//32)*32 + 1)*H*W*4 < (1 << 32)
+    if _STATE['amp'] and fits and kh == kw and kh in (1, 3) and (sh, sw) == (1, 1) \
+            and ph == pw == kh//2:
         y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
         sc, sf = fold if fold is not None else (None, None)
         hip.check(hip.lib().brv_conv2d_mfma_forward(
