@@ -315,6 +315,20 @@ int brv_cplx_affine_backward(const float* x, const float* dy, const float* A, co
 int brv_cplx_moments_backward(const float* x, const float* gm, float* dx, int64_t B, int64_t C,
                               int64_t HW, brv_stream_t stream);
 
+/* Causal (cumulative) group normalisation, fp32 (modules/normalization.py:5-62: CausalGroupNorm,
+ * CausalLayerNorm = 1 group, CausalInstanceNorm = one group per channel): x (B, C, inner, T)
+ * with the frames last, every frame normalised with the statistics of its group over all frames
+ * up to it. stats (B*groups, T, 2) receives (mean, rstd) for the backward pass; scratch:
+ * brv_causal_groupnorm_scratch_bytes(); uv_scratch: B*groups*T*2 floats. */
+int64_t brv_causal_groupnorm_scratch_bytes(int64_t B, int64_t groups, int64_t T);
+int brv_causal_groupnorm_forward(const float* x, const float* gain, const float* bias, float* y,
+                                 float* stats, void* scratch, int64_t B, int64_t C, int64_t inner,
+                                 int64_t T, int64_t groups, float eps, brv_stream_t stream);
+int brv_causal_groupnorm_backward(const float* x, const float* dy, const float* gain,
+                                  const float* stats, float* dx, float* dgain, float* dbias,
+                                  void* scratch, float* uv_scratch, int64_t B, int64_t C,
+                                  int64_t inner, int64_t T, int64_t groups, brv_stream_t stream);
+
 /* ---- SGMSE+ score network building blocks, forward values (models/sgmse/net.py:12-477,
  * modules/resampling.py:8-61). groupnorm_fold: nn.GroupNorm on x + add_bc[b][c] (nullable; the
  * noise-embedding term of UNetBlock) reduced to a per-(item, channel) affine scale / shift

@@ -616,6 +616,33 @@ def golden_ema(out):
     np.savez_compressed(os.path.join(out, 'ema.npz'), **res)
 
 
+def golden_norms(out):
+    """CausalGroupNorm / LayerNorm / InstanceNorm (brever/modules/normalization.py) on a seeded
+    (B, C, F, T) tensor with non-trivial gain / bias: outputs and the gradients wrt the input,
+    gain and bias for a random upstream gradient; also with the frames on axis 2."""
+    from brever.modules import CausalGroupNorm, CausalInstanceNorm, CausalLayerNorm
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 6, 5, 37, generator=g)
+    gy = torch.randn(3, 6, 5, 37, generator=g)
+    gain = 1 + 0.3*torch.randn(6, generator=g)
+    bias = 0.2*torch.randn(6, generator=g)
+    res = dict(x=x.numpy(), gy=gy.numpy(), gain=gain.numpy(), bias=bias.numpy())
+    for tag, ctor in (('layer', lambda: CausalLayerNorm(6)), ('group', lambda: CausalGroupNorm(6, 2)),
+                      ('instance', lambda: CausalInstanceNorm(6)),
+                      ('group_t2', lambda: CausalGroupNorm(6, 3, time_dim=2))):
+        norm = ctor()
+        with torch.no_grad():
+            norm.gain.copy_(gain); norm.bias.copy_(bias)
+        xg = x.clone().requires_grad_(True)
+        y = norm(xg)
+        (y*gy).sum().backward()
+        res[tag] = y.detach().numpy()
+        res[tag + '_dx'] = xg.grad.numpy()
+        res[tag + '_dgain'] = norm.gain.grad.numpy()
+        res[tag + '_dbias'] = norm.bias.grad.numpy()
+    np.savez_compressed(os.path.join(out, 'norms.npz'), **res)
+
+
 def golden_segments(out):
     """Segment tables of BreverDataset.get_segment_info (brever/data.py:112-210) for seeded
     file lengths x strategies x (segment, overlap, max segment) settings; the file-length
@@ -652,7 +679,7 @@ def main():
     os.chdir(REF)       # the reference opens config/... relatively
     torch.set_num_threads(4)
     todo = [golden_batching, golden_collate, golden_losses, golden_convtasnet, golden_training,
-            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features, golden_ema]
+            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features, golden_ema, golden_norms]
     only = sys.argv[1:]                  # e.g. `make_golden.py sgmse` regenerates one file
     for fn in todo:
         if not only or fn.__name__[len('golden_'):] in only:

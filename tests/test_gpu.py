@@ -1271,3 +1271,41 @@ def test_dccrn_complex_batchnorm_matches_reference(golden_dir):
     net.eval()
     with torch.no_grad():
         assert rel(net(x), torch.from_numpy(g['cbn_out_eval'])) <= 2e-4
+
+
+@pytest.mark.gpu
+def test_causal_norm_modules_match_reference(golden_dir):
+    """CausalLayerNorm / CausalGroupNorm / CausalInstanceNorm (frames last and on axis 2) on
+    the HIP path vs the reference golden: outputs 1e-5, gradients wrt input, gain and bias 1e-4
+    (rel-L2); causality as the reference's own test checks it (NaN from frame i on leaves the
+    earlier frames finite); the Upsample / Downsample shorthands."""
+    from brever_amd.modules import (CausalGroupNorm, CausalInstanceNorm, CausalLayerNorm,
+                                    Downsample, Upsample)
+    g = np.load(os.path.join(golden_dir, 'norms.npz'))
+    dev = _cuda()
+    x, gy = torch.from_numpy(g['x']).to(dev), torch.from_numpy(g['gy']).to(dev)
+    for tag, ctor in (('layer', lambda: CausalLayerNorm(6)), ('group', lambda: CausalGroupNorm(6, 2)),
+                      ('instance', lambda: CausalInstanceNorm(6)),
+                      ('group_t2', lambda: CausalGroupNorm(6, 3, time_dim=2))):
+        norm = ctor().to(dev)
+        with torch.no_grad():
+            norm.gain.copy_(torch.from_numpy(g['gain'])); norm.bias.copy_(torch.from_numpy(g['bias']))
+        xg = x.clone().requires_grad_(True)
+        y = norm(xg)
+        (y*gy).sum().backward()
+        assert rel(y.detach(), torch.from_numpy(g[tag])) <= 1e-5, tag
+        assert rel(xg.grad, torch.from_numpy(g[tag + '_dx'])) <= 1e-4, (tag, rel(xg.grad, torch.from_numpy(g[tag + '_dx'])))
+        assert rel(norm.gain.grad, torch.from_numpy(g[tag + '_dgain'])) <= 1e-4, tag
+        assert rel(norm.bias.grad, torch.from_numpy(g[tag + '_dbias'])) <= 1e-4, tag
+    norm = CausalInstanceNorm(3).to(dev)
+    for i in (1, 17, 36):
+        xn = torch.randn(2, 3, 4, 37, device=dev)
+        xn[..., i] = float('nan')
+        assert not torch.isnan(norm(xn)[..., :i]).any()
+    with pytest.raises(ValueError):
+        CausalGroupNorm(6, 4)
+    with pytest.raises(ValueError):
+        CausalLayerNorm(6, time_dim=1)
+    up, down = Upsample([1, 3, 3, 1]).to(dev), Downsample([1, 3, 3, 1]).to(dev)
+    z = torch.randn(2, 3, 8, 10, device=dev)
+    assert down(z).shape == (2, 3, 4, 5) and up(down(z)).shape == z.shape

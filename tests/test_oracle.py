@@ -430,3 +430,22 @@ def test_dccrn_complex_batchnorm_oracle_matches_reference(golden_dir):
     net.eval()
     with torch.no_grad():
         assert torch.allclose(net(x), torch.from_numpy(g['cbn_out_eval']), rtol=1e-4, atol=1e-6)
+
+
+def test_causal_norm_oracle_matches_reference(golden_dir):
+    """oracle.norm.causal_group_norm vs the reference's CausalLayerNorm / CausalGroupNorm /
+    CausalInstanceNorm (frames last and on axis 2): outputs and the gradients wrt input, gain and
+    bias, fp32, 1e-5 rel-L2."""
+    from oracle.norm import causal_group_norm
+    g = np.load(os.path.join(golden_dir, 'norms.npz'))
+    x, gy = torch.from_numpy(g['x']), torch.from_numpy(g['gy'])
+    for tag, groups, tdim in (('layer', 1, -1), ('group', 2, -1), ('instance', 6, -1), ('group_t2', 3, 2)):
+        xg = x.clone().requires_grad_(True)
+        gain = torch.from_numpy(g['gain']).requires_grad_(True)
+        bias = torch.from_numpy(g['bias']).requires_grad_(True)
+        y = causal_group_norm(xg, gain, bias, groups, tdim)
+        (y*gy).sum().backward()
+        for got, key in ((y.detach(), tag), (xg.grad, tag + '_dx'), (gain.grad, tag + '_dgain'),
+                         (bias.grad, tag + '_dbias')):
+            ref = torch.from_numpy(g[key])
+            assert ((got - ref).norm()/ref.norm()).item() <= 1e-5, (tag, key)
