@@ -1,0 +1,236 @@
+// Row-wise operators of TF-GridNet, fp32 (brever/models/tfgridnet/tfgridnet.py):
+//   * brv_rownorm_*: layer normalisation of contiguous rows with an optional PReLU in front and a
+//     per-(group, column) gain / bias. One operator covers nn.LayerNorm(emb_dim) on the
+//     channels-last grid (tfgridnet.py:199,213: rows = (item, frame, band), one group),
+//     LayerNormalization4DCF (tfgridnet.py:356-380: rows = (item, frame) holding channel x band,
+//     one group) and AllHeadPReLULayerNormalization4DCF (tfgridnet.py:383-415: rows = (item,
+//     head, frame) holding E x band, one group and one PReLU slope per head). The group of row r
+//     is (r / inner) % groups.
+//   * brv_row_std / brv_row_scale: the RMS normalisation of the mixture by its unbiased standard
+//     deviation and its reversal on the output (tfgridnet.py:108-109,128).
+// All of them are HBM-bound streaming kernels: a wavefront owns a row (rows are 32 ... 4 128
+// floats: 128 B ... 16 KB contiguous), reads it twice (second pass from L2) and writes it once.
+// The parameter gradients are column sums over the rows of a group: fixed slices of rows are
+// reduced by one workgroup each into a partial table that a second kernel folds in a fixed
+// order (deterministic, no atomics).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/brever_hip.h"
+#include "common.cuh"
+
+using namespace brv;
+
+namespace {
+
+#define TG_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+constexpr int kSlices = 64;       // row slices of the parameter-gradient reduction
+
+__device__ __forceinline__ float prelu(float v, float a) { return v > 0.f ? v : a*v; }
+
+// y = (prelu(x) - mean) * rstd * gain[g][j] + bias[g][j]; stats[r] = (mean, rstd)
+__global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ slope,
+                                                          const float* __restrict__ gain,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ y, float2* stats,
+                                                          long long rows, int n, int inner, int G,
+                                                          float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x*4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int g = (int)((r / inner) % G);
+  const float a = slope ? slope[g] : 1.f;
+  const float* xr = x + r*n;
+  float s = 0.f;
+  for (int j = lane; j < n; j += 64) s += prelu(xr[j], a);
+  const float mean = wave_sum(s)/n;
+  float q = 0.f;
+  for (int j = lane; j < n; j += 64) { const float d = prelu(xr[j], a) - mean; q += d*d; }
+  const float rstd = 1.f/sqrtf(wave_sum(q)/n + eps);
+  const float* gg = gain + (long long)g*n;
+  const float* bb = bias + (long long)g*n;
+  float* yr = y + r*n;
+  for (int j = lane; j < n; j += 64) yr[j] = (prelu(xr[j], a) - mean)*rstd*gg[j] + bb[j];
+  if (lane == 0) stats[r] = make_float2(mean, rstd);
+}
+
+// dx = prelu'(x) * rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gain;
+// dslope_rows[r] = sum over the row of (gradient wrt prelu(x)) * x where x <= 0
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ dy,
+                                                          const float* __restrict__ slope,
+                                                          const float* __restrict__ gain,
+                                                          const float2* __restrict__ stats,
+                                                          float* __restrict__ dx,
+                                                          float* __restrict__ dslope_rows,
+                                                          long long rows, int n, int inner, int G) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x*4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int g = (int)((r / inner) % G);
+  const float a = slope ? slope[g] : 1.f;
+  const float2 st = stats[r];
+  const float* xr = x + r*n;
+  const float* dr = dy + r*n;
+  const float* gg = gain + (long long)g*n;
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const float d = dr[j]*gg[j];
+    s1 += d; s2 += d*((prelu(xr[j], a) - st.x)*st.y);
+  }
+  const float m1 = wave_sum(s1)/n, m2 = wave_sum(s2)/n;
+  float* out = dx + r*n;
+  float da = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const float v = xr[j];
+    const float xh = (prelu(v, a) - st.x)*st.y;
+    const float dp = st.y*(dr[j]*gg[j] - m1 - xh*m2);
+    out[j] = v > 0.f ? dp : a*dp;
+    if (!(v > 0.f)) da += dp*v;
+  }
+  if (dslope_rows) {
+    da = wave_sum(da);
+    if (lane == 0) dslope_rows[r] = da;
+  }
+}
+
+// part[slice][g][j] = sum over the slice's rows of group g of (dy * xhat, dy)
+__global__ __launch_bounds__(256) void rownorm_pgrad_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dy,
+                                                            const float* __restrict__ slope,
+                                                            const float2* __restrict__ stats,
+                                                            float2* __restrict__ part,
+                                                            long long rows, int n, int inner, int G) {
+  __shared__ float2 red[4][64];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x*64 + col;
+  const int g = blockIdx.y, slice = blockIdx.z;
+  const float a = slope ? slope[g] : 1.f;
+  const long long per_group = rows/G;                       // rows of one group
+  const long long chunk = (per_group + kSlices - 1)/kSlices;
+  const long long k0 = slice*chunk, k1 = min(per_group, k0 + chunk);
+  float sg = 0.f, sb = 0.f;
+  if (j < n) {
+    for (long long k = k0 + rl; k < k1; k += 4) {
+      const long long r = (k / inner)*((long long)inner*G) + (long long)g*inner + k % inner;
+      const float2 st = stats[r];
+      const float d = dy[r*n + j];
+      sg += d*((prelu(x[r*n + j], a) - st.x)*st.y);
+      sb += d;
+    }
+  }
+  red[rl][col] = make_float2(sg, sb);
+  __syncthreads();
+  if (rl == 0 && j < n) {
+    float2 t = red[0][col];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { t.x += red[k][col].x; t.y += red[k][col].y; }
+    part[((long long)slice*G + g)*n + j] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void rownorm_pgrad_fold_kernel(const float2* __restrict__ part,
+                                                                 float* __restrict__ dgain,
+                                                                 float* __restrict__ dbias,
+                                                                 long long total) {
+  const long long i = (long long)blockIdx.x*256 + threadIdx.x;
+  if (i >= total) return;
+  float sg = 0.f, sb = 0.f;
+  for (int s = 0; s < kSlices; ++s) { const float2 t = part[s*total + i]; sg += t.x; sb += t.y; }
+  dgain[i] = sg; dbias[i] = sb;
+}
+
+// unbiased standard deviation of each row (two passes, fp64 accumulators)
+__global__ __launch_bounds__(256) void row_std_kernel(const float* __restrict__ x,
+                                                      float* __restrict__ out, long long n) {
+  __shared__ double scr[8];
+  __shared__ double mean_s;
+  const float* xr = x + (long long)blockIdx.x*n;
+  double s = 0.0;
+  for (long long j = threadIdx.x; j < n; j += 256) s += xr[j];
+  const double tot = block_sum(s, scr);
+  if (threadIdx.x == 0) mean_s = tot/(double)n;
+  __syncthreads();
+  const double mean = mean_s;
+  double q = 0.0;
+  for (long long j = threadIdx.x; j < n; j += 256) { const double d = xr[j] - mean; q += d*d; }
+  const double var = block_sum(q, scr);
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)sqrt(var/(double)(n - 1));
+}
+
+template <bool DIV>
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ s,
+                                                        float* __restrict__ y, long long n) {
+  const long long r = blockIdx.y;
+  const float f = s[r];
+  for (long long j = (long long)blockIdx.x*256 + threadIdx.x; j < n; j += (long long)gridDim.x*256)
+    y[r*n + j] = DIV ? x[r*n + j]/f : x[r*n + j]*f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int brv_rownorm_forward(const float* x, const float* slope, const float* gain, const float* bias,
+                        float* y, float* stats, int64_t rows, int64_t n, int64_t inner,
+                        int64_t groups, float eps, brv_stream_t stream) {
+  if (rows < 1 || n < 1 || inner < 1 || groups < 1 || rows % (inner*groups)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((unsigned)((rows + 3)/4)), dim3(256), 0, st, x, slope,
+                     gain, bias, y, reinterpret_cast<float2*>(stats), (long long)rows, (int)n,
+                     (int)inner, (int)groups, eps);
+  TG_OK(hipGetLastError());
+  return 0;
+}
+
+int64_t brv_rownorm_scratch_bytes(int64_t n, int64_t groups) {
+  return (int64_t)kSlices*groups*n*(int64_t)sizeof(float2);
+}
+
+int brv_rownorm_backward(const float* x, const float* dy, const float* slope, const float* gain,
+                         const float* stats, float* dx, float* dgain, float* dbias,
+                         float* dslope_rows, void* scratch, int64_t rows, int64_t n, int64_t inner,
+                         int64_t groups, brv_stream_t stream) {
+  if (rows < 1 || n < 1 || inner < 1 || groups < 1 || rows % (inner*groups)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const float2* stp = reinterpret_cast<const float2*>(stats);
+  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)((rows + 3)/4)), dim3(256), 0, st, x, dy,
+                     slope, gain, stp, dx, slope ? dslope_rows : nullptr, (long long)rows, (int)n,
+                     (int)inner, (int)groups);
+  float2* part = reinterpret_cast<float2*>(scratch);
+  hipLaunchKernelGGL(rownorm_pgrad_kernel, dim3((unsigned)((n + 63)/64), (unsigned)groups, kSlices),
+                     dim3(256), 0, st, x, dy, slope, stp, part, (long long)rows, (int)n, (int)inner,
+                     (int)groups);
+  const long long total = (long long)groups*n;
+  hipLaunchKernelGGL(rownorm_pgrad_fold_kernel, dim3((unsigned)((total + 255)/256)), dim3(256), 0,
+                     st, part, dgain, dbias, total);
+  TG_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_row_std(const float* x, float* out, int64_t rows, int64_t n, brv_stream_t stream) {
+  if (rows < 1 || n < 2) return -1;
+  hipLaunchKernelGGL(row_std_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x,
+                     out, (long long)n);
+  TG_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_row_scale(const float* x, const float* s, float* y, int64_t rows, int64_t n, int divide,
+                  brv_stream_t stream) {
+  if (rows < 1 || n < 1 || rows > 65535) return -1;
+  const unsigned gx = (unsigned)min((long long)1024, (long long)((n + 255)/256));
+  if (divide)
+    hipLaunchKernelGGL(row_scale_kernel<true>, dim3(gx, (unsigned)rows), dim3(256), 0,
+                       (hipStream_t)stream, x, s, y, (long long)n);
+  else
+    hipLaunchKernelGGL(row_scale_kernel<false>, dim3(gx, (unsigned)rows), dim3(256), 0,
+                       (hipStream_t)stream, x, s, y, (long long)n);
+  TG_OK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -127,6 +127,11 @@ SIGNATURES = {
     'brv_causal_groupnorm_scratch_bytes': (_c_i64, [_c_i64, _c_i64, _c_i64]),
     'brv_causal_groupnorm_forward': (ctypes.c_int, [_c_ptr]*6 + [_c_i64]*5 + [_c_f32, _c_ptr]),
     'brv_causal_groupnorm_backward': (ctypes.c_int, [_c_ptr]*9 + [_c_i64]*5 + [_c_ptr]),
+    'brv_rownorm_forward': (ctypes.c_int, [_c_ptr]*6 + [_c_i64]*4 + [_c_f32, _c_ptr]),
+    'brv_rownorm_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
+    'brv_rownorm_backward': (ctypes.c_int, [_c_ptr]*10 + [_c_i64]*4 + [_c_ptr]),
+    'brv_row_std': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
+    'brv_row_scale': (ctypes.c_int, [_c_ptr]*3 + [_c_i64, _c_i64, ctypes.c_int, _c_ptr]),
     'brv_cplx_moments': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_cplx_affine_forward': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*3 + [_c_ptr]),
     'brv_cplx_affine_backward': (ctypes.c_int, [_c_ptr]*9 + [_c_i64]*3 + [_c_ptr]),

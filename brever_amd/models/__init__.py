@@ -7,6 +7,7 @@ from .convtasnet import ConvTasNet  # noqa: F401
 from .dccrn import DCCRN  # noqa: F401
 from .ffnn import FFNN  # noqa: F401
 from .sgmse import IDMSE, SGMSEp, SGMSEpM  # noqa: F401
+from .tfgridnet import TFGridNet  # noqa: F401
 
 
 def count_params(model):

@@ -1,0 +1,383 @@
+"""TF-GridNet on the HIP path (reference: brever/models/tfgridnet/tfgridnet.py:28-415).
+
+The ``nn`` modules below only hold parameters (same names, shapes, construction order and
+therefore the same default initialisation and ``state_dict`` as the reference); every arithmetic
+operation runs in ``libbrever_hip.so`` through ``torch.autograd.Function`` pairs:
+
+* RMS normalisation by the unbiased standard deviation and its reversal: ``brv_row_std`` /
+  ``brv_row_scale`` (tfgridnet.py:108-109,128);
+* STFT / inverse STFT: the differentiable DFT-GEMM kernels of ``modules/stft.py``;
+* the 3x3 input convolution and the output transposed convolution (= a convolution with the
+  flipped, transposed kernel): column matrix + MFMA product (``sgmse_train.ConvFn``);
+  ``nn.GroupNorm(1, C)``: ``brv_groupnorm_*``;
+* the grid blocks work channels-last, (B, T, Q, C): ``nn.LayerNorm(C)``,
+  ``LayerNormalization4DCF`` and ``AllHeadPReLULayerNormalization4DCF`` are one row-norm operator
+  (``brv_rownorm_*``) on rows laid out so that the normalised axes are contiguous; the
+  bidirectional LSTMs run both directions of all sequences concurrently in the register-resident
+  recurrence kernels (``dccrn._LSTMFunction``, two groups: the sequence and its reversal); the
+  linear layers and 1x1 convolutions are MFMA products over the channel axis; the attention is
+  two batched products around ``brv_softmax_rows``.
+
+torch only pads, slices, permutes, concatenates and carries the autograd graph.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip
+from ..modules.stft import STFT
+from . import sgmse_train as T
+from .base import BreverBaseModel, ModelRegistry
+from .dccrn import _AMP, _LSTMFunction, _ParamOnly
+
+
+class LayerNormalization4DCF(_ParamOnly):
+    """Parameters of tfgridnet.py:356-380: gamma / beta (1, C, 1, F)."""
+
+    def __init__(self, input_dimension, eps=1e-5):
+        super().__init__()
+        assert len(input_dimension) == 2
+        size = [1, input_dimension[0], 1, input_dimension[1]]
+        self.gamma = nn.Parameter(torch.ones(*size))
+        self.beta = nn.Parameter(torch.zeros(*size))
+        self.eps = eps
+
+
+class AllHeadPReLULayerNormalization4DCF(_ParamOnly):
+    """Parameters of tfgridnet.py:383-415: gamma / beta (1, H, E, 1, F), one PReLU slope per
+    head."""
+
+    def __init__(self, input_dimension, eps=1e-5):
+        super().__init__()
+        assert len(input_dimension) == 3
+        H, E, n_freqs = input_dimension
+        self.gamma = nn.Parameter(torch.ones(1, H, E, 1, n_freqs))
+        self.beta = nn.Parameter(torch.zeros(1, H, E, 1, n_freqs))
+        self.act = nn.PReLU(num_parameters=H, init=0.25)
+        self.eps, self.H, self.E, self.n_freqs = eps, H, E, n_freqs
+
+
+class GridNetV2Block(_ParamOnly):
+    """Parameters of one grid block (tfgridnet.py:176-253)."""
+
+    def __init__(self, emb_dim, emb_ks, emb_hs, n_freqs, hidden_channels, n_head=4,
+                 approx_qk_dim=512, activation='PReLU', eps=1e-5):
+        super().__init__()
+        if emb_ks != emb_hs:
+            raise NotImplementedError('overlapping sub-band / sub-frame windows (emb_ks != emb_hs) '
+                                      'are not built on the HIP path yet')
+        in_channels = emb_dim*emb_ks
+        self.intra_norm = nn.LayerNorm(emb_dim, eps=eps)
+        self.intra_rnn = nn.LSTM(in_channels, hidden_channels, 1, batch_first=True,
+                                 bidirectional=True)
+        self.intra_linear = nn.Linear(hidden_channels*2, in_channels)
+        self.inter_norm = nn.LayerNorm(emb_dim, eps=eps)
+        self.inter_rnn = nn.LSTM(in_channels, hidden_channels, 1, batch_first=True,
+                                 bidirectional=True)
+        self.inter_linear = nn.Linear(hidden_channels*2, in_channels)
+        E = math.ceil(approx_qk_dim*1.0/n_freqs)
+        assert emb_dim % n_head == 0
+        self.attn_conv_Q = nn.Conv2d(emb_dim, n_head*E, 1)
+        self.attn_norm_Q = AllHeadPReLULayerNormalization4DCF((n_head, E, n_freqs), eps=eps)
+        self.attn_conv_K = nn.Conv2d(emb_dim, n_head*E, 1)
+        self.attn_norm_K = AllHeadPReLULayerNormalization4DCF((n_head, E, n_freqs), eps=eps)
+        self.attn_conv_V = nn.Conv2d(emb_dim, n_head*emb_dim//n_head, 1)
+        self.attn_norm_V = AllHeadPReLULayerNormalization4DCF((n_head, emb_dim//n_head, n_freqs),
+                                                              eps=eps)
+        self.attn_concat_proj = nn.Sequential(
+            nn.Conv2d(emb_dim, emb_dim, 1),
+            getattr(nn, activation)(),
+            LayerNormalization4DCF((emb_dim, n_freqs), eps=eps),
+        )
+        self.emb_dim, self.emb_ks, self.emb_hs, self.n_head = emb_dim, emb_ks, emb_hs, n_head
+
+
+# ---------------------------------------------------------------------------------------------
+class _RowNormFn(torch.autograd.Function):
+    """y = (prelu(x) - mean_row) * rstd_row * gain[g] + bias[g] on rows (R, n); the group of row r
+    is (r // inner) % G; ``slope`` (G,) or None."""
+
+    @staticmethod
+    def forward(ctx, x, slope, gain, bias, inner, eps):
+        x, gain, bias = x.contiguous(), gain.contiguous(), bias.contiguous()
+        R, n = x.shape
+        G = gain.shape[0]
+        y = torch.empty_like(x)
+        stats = torch.empty(R, 2, dtype=torch.float32, device=x.device)
+        sl = slope.contiguous() if slope is not None else None
+        hip.check(hip.lib().brv_rownorm_forward(hip.ptr(x), hip.ptr(sl), hip.ptr(gain), hip.ptr(bias),
+                                                hip.ptr(y), hip.ptr(stats), R, n, inner, G,
+                                                float(eps), hip.stream()), 'brv_rownorm_forward')
+        ctx.save_for_backward(x, sl, gain, stats)
+        ctx.cfg = (inner, G, slope is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sl, gain, stats = ctx.saved_tensors
+        inner, G, has_slope = ctx.cfg
+        lib = hip.lib()
+        R, n = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgain, dbias = torch.empty_like(gain), torch.empty_like(gain)
+        rows = torch.empty(R, dtype=torch.float32, device=x.device) if has_slope else None
+        scratch = torch.empty(lib.brv_rownorm_scratch_bytes(n, G), dtype=torch.uint8,
+                              device=x.device)
+        hip.check(lib.brv_rownorm_backward(
+            hip.ptr(x), hip.ptr(dy), hip.ptr(sl), hip.ptr(gain), hip.ptr(stats), hip.ptr(dx),
+            hip.ptr(dgain), hip.ptr(dbias), hip.ptr(rows), hip.ptr(scratch), R, n, inner, G,
+            hip.stream()), 'brv_rownorm_backward')
+        dslope = None
+        if has_slope:                                   # rows are (outer, G, inner)
+            dslope = torch.empty(G, dtype=torch.float32, device=x.device)
+            hip.check(lib.brv_row_sum(hip.ptr(rows), hip.ptr(dslope), R//(G*inner), G, inner,
+                                      hip.stream()), 'brv_row_sum')
+        return dx, dslope, dgain, dbias, None, None
+
+
+class _RowScaleFn(torch.autograd.Function):
+    """y[r] = x[r] * s[r] (``divide`` False) or x[r] / s[r] on (R, n); gradient wrt x only."""
+
+    @staticmethod
+    def forward(ctx, x, s, divide):
+        x, s = x.contiguous(), s.contiguous()
+        y = torch.empty_like(x)
+        hip.check(hip.lib().brv_row_scale(hip.ptr(x), hip.ptr(s), hip.ptr(y), x.shape[0], x.shape[1],
+                                          int(divide), hip.stream()), 'brv_row_scale')
+        ctx.save_for_backward(s)
+        ctx.divide = divide
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, = ctx.saved_tensors
+        return _RowScaleFn.apply(dy, s, ctx.divide), None, None
+
+
+class _AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(D)) v on q, k (N, L, D), v (N, L, Dv) (tfgridnet.py:325-327)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        N, L, D = q.shape
+        Dv = v.shape[-1]
+        lowp = ctx.lowp = _AMP['on']
+        w = T._empty(N, L, L, like=q)
+        T._gemm(q, k, w, N, L, L, D, D, D, L, L*D, L*D, L*L, trans_b=1, lowp=lowp)
+        w = T._axpby_raw(w, 1.0/D**0.5, None, 0.0)
+        p = torch.empty_like(w)
+        hip.check(hip.lib().brv_softmax_rows(hip.ptr(w), hip.ptr(p), N*L, L, hip.stream()),
+                  'brv_softmax_rows')
+        a = T._empty(N, L, Dv, like=q)
+        T._gemm(p, v, a, N, L, Dv, L, L, Dv, Dv, L*L, L*Dv, L*Dv, lowp=lowp)
+        ctx.save_for_backward(q, k, v, p)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        q, k, v, p = ctx.saved_tensors
+        da = da.contiguous()
+        N, L, D = q.shape
+        Dv = v.shape[-1]
+        lowp = ctx.lowp
+        dv = torch.empty_like(v)                       # P^T (L x L) @ da (L x Dv)
+        T._gemm(p, da, dv, N, L, Dv, L, L, Dv, Dv, L*L, L*Dv, L*Dv, trans_a=1, lowp=lowp)
+        dp = torch.empty_like(p)                       # da (L x Dv) @ v^T
+        T._gemm(da, v, dp, N, L, L, Dv, Dv, Dv, L, L*Dv, L*Dv, L*L, trans_b=1, lowp=lowp)
+        dw = torch.empty_like(p)
+        hip.check(hip.lib().brv_softmax_rows_backward(hip.ptr(p), hip.ptr(dp), hip.ptr(dw), N*L, L,
+                                                      hip.stream()), 'brv_softmax_rows_backward')
+        dw = T._axpby_raw(dw, 1.0/D**0.5, None, 0.0)
+        dq = torch.empty_like(q)                       # dW (L x L) @ k (L x D)
+        T._gemm(dw, k, dq, N, L, D, L, L, D, D, L*L, L*D, L*D, lowp=lowp)
+        dk = torch.empty_like(k)                       # dW^T @ q
+        T._gemm(dw, q, dk, N, L, D, L, L, D, D, L*L, L*D, L*D, trans_a=1, lowp=lowp)
+        return dq, dk, dv
+
+
+def _linear(x, mod):
+    """nn.Linear / 1x1 convolution over the last axis of a channels-last tensor."""
+    w = mod.weight.reshape(mod.weight.shape[0], -1)
+    return T.LinearFn.apply(x.reshape(-1, x.shape[-1]), w, mod.bias).view(*x.shape[:-1], w.shape[0])
+
+
+def _add(a, b):
+    return T.AxpbyFn.apply(a, 1.0, b, 1.0)
+
+
+def _bilstm(x, rnn):
+    """Bidirectional single-layer nn.LSTM (batch_first) on (N, S, I) -> (N, S, 2H): the sequence
+    and its reversal are two groups of one launch set."""
+    stack = lambda name: torch.stack([getattr(rnn, name + '_l0'),  # noqa: E731
+                                      getattr(rnn, name + '_l0_reverse')])
+    y = _LSTMFunction.apply(torch.stack([x, x.flip(1)]), stack('weight_ih'), stack('weight_hh'),
+                            stack('bias_ih'), stack('bias_hh'))
+    return torch.cat([y[0], y[1].flip(1)], dim=-1)
+
+
+@ModelRegistry.register('tfgridnet')
+class TFGridNet(BreverBaseModel):
+    def __init__(
+        self,
+        n_srcs: int = 1,
+        n_fft: int = 256,
+        stride: int = 128,
+        window: str = 'hann',
+        n_layers: int = 6,
+        lstm_hidden_units: int = 128,
+        attn_n_head: int = 4,
+        attn_approx_qk_dim: int = 512,
+        emb_dim: int = 32,
+        emb_ks: int = 4,
+        emb_hs: int = 4,
+        activation: str = 'PReLU',
+        eps: float = 1e-5,
+        criterion: str = 'multiresyu',
+        optimizer: str = 'Adam',
+        learning_rate: float = 0.001,
+        grad_clip: float = 1.0,
+    ):
+        super().__init__(criterion=criterion)
+        self.n_srcs = n_srcs
+        self.n_layers = n_layers
+        n_freqs = n_fft//2 + 1
+        self.stft = STFT(frame_length=n_fft, hop_length=stride, window=window, normalized=False)
+        n_imics = 2
+        ks, padding = (3, 3), (1, 1)
+        self.conv = nn.Sequential(
+            nn.Conv2d(2*n_imics, emb_dim, ks, padding=padding),
+            nn.GroupNorm(1, emb_dim, eps=eps),
+        )
+        self.blocks = nn.ModuleList([
+            GridNetV2Block(emb_dim, emb_ks, emb_hs, n_freqs, lstm_hidden_units, n_head=attn_n_head,
+                           approx_qk_dim=attn_approx_qk_dim, activation=activation, eps=eps)
+            for _ in range(n_layers)])
+        self.deconv = nn.ConvTranspose2d(emb_dim, n_srcs*2, ks, padding=padding)
+        self.optimizer = self.init_optimizer(optimizer, lr=learning_rate)
+        self.grad_clip = grad_clip
+        self.scheduler = self.init_lr_scheduler()
+
+    # ---- the grid block, channels-last -------------------------------------------------------
+    @staticmethod
+    def _layer_norm(x, norm):
+        C = x.shape[-1]
+        y = _RowNormFn.apply(x.reshape(-1, C), None, norm.weight.view(1, C), norm.bias.view(1, C), 1,
+                             norm.eps)
+        return y.view(x.shape)
+
+    @staticmethod
+    def _head_norm(x, norm):
+        """AllHeadPReLULayerNormalization4DCF on channels-last x (B, T, F, H*E) -> (B*H, T, E*F),
+        which is the (items, frames, features) layout the attention products read."""
+        B, Tn, Fq, _ = x.shape
+        H, E = norm.H, norm.E
+        rows = x.view(B, Tn, Fq, H, E).permute(0, 3, 1, 4, 2).reshape(B*H*Tn, E*Fq)
+        y = _RowNormFn.apply(rows, norm.act.weight, norm.gamma.view(H, E*Fq), norm.beta.view(H, E*Fq),
+                             Tn, norm.eps)
+        return y.view(B*H, Tn, E*Fq)
+
+    def _block(self, blk, x):
+        """x (B, T, Q, C) channels-last -> same shape (tfgridnet.py:255-353)."""
+        B, old_T, old_Q, C = x.shape
+        ks, hs = blk.emb_ks, blk.emb_hs
+        olp = ks - hs
+        Tp = math.ceil((old_T + 2*olp - ks)/hs)*hs + ks
+        Qp = math.ceil((old_Q + 2*olp - ks)/hs)*hs + ks
+        x = F.pad(x, (0, 0, olp, Qp - old_Q - olp, olp, Tp - old_T - olp))
+        # intra-frame (full-band) recurrence along the bands
+        h = self._layer_norm(x, blk.intra_norm).view(B*Tp, Qp//ks, ks*C)
+        h = _linear(_bilstm(h, blk.intra_rnn), blk.intra_linear).view(B, Tp, Qp, C)
+        x = _add(h, x)
+        # sub-band recurrence along the frames
+        x = x.transpose(1, 2).contiguous()                                   # (B, Q, T, C)
+        h = self._layer_norm(x, blk.inter_norm).view(B*Qp, Tp//ks, ks*C)
+        h = _linear(_bilstm(h, blk.inter_rnn), blk.inter_linear).view(B, Qp, Tp, C)
+        x = _add(h, x)
+        x = x.transpose(1, 2)[:, olp:olp + old_T, olp:olp + old_Q].contiguous()   # (B, T, Q, C)
+        # full-band self-attention across the frames
+        q = self._head_norm(_linear(x, blk.attn_conv_Q), blk.attn_norm_Q)
+        k = self._head_norm(_linear(x, blk.attn_conv_K), blk.attn_norm_K)
+        v = self._head_norm(_linear(x, blk.attn_conv_V), blk.attn_norm_V)
+        a = _AttentionFn.apply(q, k, v)                                      # (B*H, T, Ev*Q)
+        H, Ev = blk.n_head, blk.attn_norm_V.E
+        a = a.view(B, H, old_T, Ev, old_Q).permute(0, 2, 4, 1, 3).reshape(B, old_T, old_Q, H*Ev)
+        conv, act, norm = blk.attn_concat_proj
+        a = _linear(a, conv)                                                 # (B, T, Q, C)
+        rows = a.transpose(2, 3).reshape(B*old_T, C*old_Q)                   # (channel, band) rows
+        slope = act.weight if isinstance(act, nn.PReLU) else None
+        if slope is None and not isinstance(act, nn.Identity):
+            raise NotImplementedError(f'activation {type(act).__name__} is not built on the HIP '
+                                      'path (PReLU and Identity are)')
+        rows = _RowNormFn.apply(rows, slope, norm.gamma.view(1, C*old_Q), norm.beta.view(1, C*old_Q),
+                                1, norm.eps)
+        a = rows.view(B, old_T, C, old_Q).transpose(2, 3)
+        return _add(a, x)
+
+    def forward(self, x):
+        hip.require_device(x)
+        B, M, L = x.shape
+        with torch.no_grad():                          # the mixture carries no gradient
+            x = x.float().contiguous()
+            std = torch.empty(B, dtype=torch.float32, device=x.device)
+            hip.check(hip.lib().brv_row_std(hip.ptr(x), hip.ptr(std), B, M*L, hip.stream()),
+                      'brv_row_std')
+            xn = _RowScaleFn.apply(x.view(B, M*L), std, True).view(B, M, L)
+            spec = self.stft(xn).transpose(2, 3)                              # (B, M, T, F)
+            batch = torch.cat((spec.real, spec.imag), dim=1).contiguous()     # (B, 2M, T, F)
+        n_frames, n_freqs = batch.shape[2:]
+        conv, norm = self.conv
+        batch = T.GroupNormFn.apply(T.ConvFn.apply(batch, conv.weight, conv.bias), None, norm.weight,
+                                    norm.bias, 1, norm.eps, False)
+        batch = batch.permute(0, 2, 3, 1).contiguous()                        # (B, T, F, C)
+        for blk in self.blocks:
+            batch = self._block(blk, batch)
+        batch = batch.permute(0, 3, 1, 2)                                      # (B, C, T, F)
+        # transposed convolution, stride 1 = convolution with the flipped, transposed kernel
+        w = self.deconv.weight.transpose(0, 1).flip(2, 3)
+        batch = T.ConvFn.apply(batch, w.contiguous(), self.deconv.bias)       # (B, 2S, T, F)
+        batch = batch.view(B, self.n_srcs, 2, n_frames, n_freqs)
+        spec = torch.complex(batch[:, :, 0], batch[:, :, 1]).transpose(2, 3)  # (B, S, F, T)
+        y = self.stft.backward(spec)[..., :L]
+        S, Ly = y.shape[1:]
+        return _RowScaleFn.apply(y.reshape(B, S*Ly), std, False).view(B, S, Ly)
+
+    def loss(self, batch, lengths, use_amp):
+        inputs, labels = batch[:, 0], batch[:, 1:]
+        # reference signal: the average of the left and right direct-path signals
+        # (tfgridnet.py:135-139)
+        labels = T._axpby_raw(labels[:, :, 0].contiguous(), 0.5, labels[:, :, 1].contiguous(), 0.5)
+        _AMP['on'] = T.AMP['on'] = bool(use_amp)
+        try:
+            outputs = self(inputs)
+        finally:
+            _AMP['on'] = T.AMP['on'] = False
+        return self.criterion(outputs, labels, lengths).mean()
+
+    def _enhance(self, x, use_amp):
+        _AMP['on'] = T.AMP['on'] = bool(use_amp)
+        try:
+            with torch.no_grad():
+                return self.forward(x)
+        finally:
+            _AMP['on'] = T.AMP['on'] = False
+
+    def update(self, loss, scaler):
+        super().update(loss, scaler, grad_clip=self.grad_clip)
+
+    def on_validate(self, val_loss):
+        self.scheduler.step(val_loss)
+
+    def state_dict(self):
+        return {'net': super().state_dict(), 'scheduler': self.scheduler.state_dict()}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict['net'])
+        self.scheduler.load_state_dict(state_dict['scheduler'])
+
+    def init_lr_scheduler(self):
+        return torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='min', factor=0.5,
+                                                          patience=3)

@@ -329,6 +329,27 @@ int brv_causal_groupnorm_backward(const float* x, const float* dy, const float* 
                                   void* scratch, float* uv_scratch, int64_t B, int64_t C,
                                   int64_t inner, int64_t T, int64_t groups, brv_stream_t stream);
 
+/* ---- TF-GridNet row operators (models/tfgridnet/tfgridnet.py). rownorm: layer normalisation of
+ * `rows` contiguous rows of n floats, optionally behind a PReLU, with gain / bias (groups, n); the
+ * group (and PReLU slope, nullable = no PReLU) of row r is (r / inner) % groups. Replaces
+ * nn.LayerNorm(emb_dim) (tfgridnet.py:199,213), LayerNormalization4DCF (tfgridnet.py:356-380) and
+ * AllHeadPReLULayerNormalization4DCF (tfgridnet.py:383-415) on rows laid out so that the
+ * normalised axes are contiguous. stats (rows, 2) = (mean, rstd). backward: dx, dgain / dbias
+ * (groups, n), dslope_rows (rows) = per-row PReLU slope gradient (written only with a slope);
+ * scratch: brv_rownorm_scratch_bytes(). row_std: unbiased standard deviation of each row
+ * (torch.std, tfgridnet.py:108); row_scale: y = x * s[row] or x / s[row] (tfgridnet.py:109,128). */
+int brv_rownorm_forward(const float* x, const float* slope, const float* gain, const float* bias,
+                        float* y, float* stats, int64_t rows, int64_t n, int64_t inner,
+                        int64_t groups, float eps, brv_stream_t stream);
+int64_t brv_rownorm_scratch_bytes(int64_t n, int64_t groups);
+int brv_rownorm_backward(const float* x, const float* dy, const float* slope, const float* gain,
+                         const float* stats, float* dx, float* dgain, float* dbias,
+                         float* dslope_rows, void* scratch, int64_t rows, int64_t n, int64_t inner,
+                         int64_t groups, brv_stream_t stream);
+int brv_row_std(const float* x, float* out, int64_t rows, int64_t n, brv_stream_t stream);
+int brv_row_scale(const float* x, const float* s, float* y, int64_t rows, int64_t n, int divide,
+                  brv_stream_t stream);
+
 /* ---- SGMSE+ score network building blocks, forward values (models/sgmse/net.py:12-477,
  * modules/resampling.py:8-61). groupnorm_fold: nn.GroupNorm on x + add_bc[b][c] (nullable; the
  * noise-embedding term of UNetBlock) reduced to a per-(item, channel) affine scale / shift

@@ -272,6 +272,10 @@ def golden_training(out):
             net_channel_mult=[1, 1, 1, 1], net_num_blocks_per_res=1, net_noise_channel_mult=1,
             net_emb_channel_mult=1, net_fir_kernel=[1, 1], net_attn_resolutions=[0],
             net_attn_bottleneck=False, solver_num_steps=1), 2),
+        # reference tests/test_training.py:196-217 ('tfgridnet')
+        ('tfgridnet', lambda: ModelRegistry.get('tfgridnet')(
+            n_srcs=2, n_layers=1, lstm_hidden_units=1, attn_n_head=1, attn_approx_qk_dim=1,
+            emb_dim=1), 3),
     ]:
         torch.manual_seed(0)
         random.seed(0)
@@ -616,6 +620,51 @@ def golden_ema(out):
     np.savez_compressed(os.path.join(out, 'ema.npz'), **res)
 
 
+def golden_tfgridnet(out):
+    """TF-GridNet (brever/models/tfgridnet/tfgridnet.py): a narrow configuration at seeded
+    weights (norm gains / biases and PReLU slopes perturbed): forward output, multiresyu loss and
+    all gradients on a ragged two-item batch, `enhance`, default parameter count; the same for a
+    two-source network with odd frame / band counts that need the grid padding."""
+    from brever.models import count_params
+    from brever.models.tfgridnet import TFGridNet
+    torch.manual_seed(0)
+    res = dict(n_params_default=np.array(count_params(TFGridNet())))
+    cases = {
+        'a': (dict(n_fft=32, stride=16, n_layers=2, lstm_hidden_units=16, attn_n_head=2,
+                   attn_approx_qk_dim=34, emb_dim=8), 400, 11),
+        'b': (dict(n_srcs=2, n_fft=24, stride=8, n_layers=1, lstm_hidden_units=32, attn_n_head=4,
+                   attn_approx_qk_dim=20, emb_dim=8, emb_ks=2, emb_hs=2), 333, 12),
+    }
+    for tag, (cfg, L, seed) in cases.items():
+        torch.manual_seed(seed)
+        net = TFGridNet(**cfg)
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if 'norm' in name or 'act' in name or name.startswith('conv.1') \
+                        or 'attn_concat_proj.1' in name or 'attn_concat_proj.2' in name:
+                    p.add_(0.1*torch.randn(p.shape, generator=g))
+        res[tag + '_config'] = json.dumps(cfg)
+        res[tag + '_names'] = json.dumps([n for n, _ in net.named_parameters()])
+        res[tag + '_params'] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy()
+        S = cfg.get('n_srcs', 1)
+        mix = 0.3*torch.randn(2, 2, L, generator=g)
+        tgt = 0.3*torch.randn(2, S, 2, L, generator=g)
+        batch = torch.cat([mix[:, None], tgt], dim=1)            # (B, 1 + S, 2, L)
+        lengths = torch.tensor([L, L - 57])
+        res[tag + '_batch'] = batch.numpy(); res[tag + '_lengths'] = lengths.numpy()
+        with torch.no_grad():
+            res[tag + '_out'] = net(mix).numpy()
+        net.zero_grad()
+        loss = net.loss(batch, lengths, use_amp=False)
+        loss.backward()
+        res[tag + '_loss'] = loss.detach().numpy()
+        res[tag + '_grads'] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+        with torch.no_grad():
+            res[tag + '_enhance'] = net.enhance(mix).numpy()
+    np.savez_compressed(os.path.join(out, 'tfgridnet.npz'), **res)
+
+
 def golden_norms(out):
     """CausalGroupNorm / LayerNorm / InstanceNorm (brever/modules/normalization.py) on a seeded
     (B, C, F, T) tensor with non-trivial gain / bias: outputs and the gradients wrt the input,
@@ -679,7 +728,7 @@ def main():
     os.chdir(REF)       # the reference opens config/... relatively
     torch.set_num_threads(4)
     todo = [golden_batching, golden_collate, golden_losses, golden_convtasnet, golden_training,
-            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features, golden_ema, golden_norms]
+            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features, golden_ema, golden_norms, golden_tfgridnet]
     only = sys.argv[1:]                  # e.g. `make_golden.py sgmse` regenerates one file
     for fn in todo:
         if not only or fn.__name__[len('golden_'):] in only:

@@ -449,3 +449,34 @@ def test_causal_norm_oracle_matches_reference(golden_dir):
                          (bias.grad, tag + '_dbias')):
             ref = torch.from_numpy(g[key])
             assert ((got - ref).norm()/ref.norm()).item() <= 1e-5, (tag, key)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_tfgridnet_oracle_matches_reference(golden_dir, tag):
+    """oracle.tfgridnet vs the reference TF-GridNet at seeded weights (two narrow configurations:
+    one source / two sources with grid padding): output 1e-5, multiresyu loss 1e-5 relative, every
+    parameter gradient 1e-4 (rel-L2 over the concatenation), fp32."""
+    import json
+    from oracle import tfgridnet as ot
+    g = np.load(os.path.join(golden_dir, 'tfgridnet.npz'))
+    cfg = json.loads(str(g[tag + '_config']))
+    names = json.loads(str(g[tag + '_names']))
+    flat = torch.from_numpy(g[tag + '_params'])
+    shapes = ot.parameter_shapes(cfg)
+    P, o = {}, 0
+    for n in names:
+        k = int(np.prod(shapes[n]))
+        P[n] = flat[o:o + k].view(shapes[n]).clone().requires_grad_(True)
+        o += k
+    assert o == flat.numel()
+    batch, lengths = torch.from_numpy(g[tag + '_batch']), torch.from_numpy(g[tag + '_lengths'])
+    with torch.no_grad():
+        out = ot.forward(P, cfg, batch[:, 0])
+    ref = torch.from_numpy(g[tag + '_out'])
+    assert ((out - ref).norm()/ref.norm()).item() <= 1e-5
+    loss = ot.loss(P, cfg, batch, lengths)
+    loss.backward()
+    assert abs(loss.item() - float(g[tag + '_loss'])) <= 1e-5*abs(float(g[tag + '_loss']))
+    grads = torch.cat([P[n].grad.reshape(-1) for n in names])
+    gref = torch.from_numpy(g[tag + '_grads'])
+    assert ((grads - gref).norm()/gref.norm()).item() <= 1e-4
