@@ -1,0 +1,234 @@
+// LSTM recurrence for MANY short chains (TF-GridNet: thousands of sequences of 33 ... 126
+// steps, hidden size 128; brever/models/tfgridnet/tfgridnet.py:200-216,268-313 -> nn.LSTM).
+//
+// dccrn.hip's recurrence gives every chain a workgroup of its own, which is right for DCCRN's
+// few long chains and wrong here: a step is then one 128-long dot product per thread between two
+// barriers. This kernel steps a TILE of 16 chains per workgroup, so that a step is a small
+// matrix product on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, bitwise an fmaf chain):
+//
+//   forward   G^T (4H x 16) = W_hh (4H x H) . h^T (H x 16)   + input projection
+//   backward  dh^T (H x 16) = W_hh^T (H x 4H) . dG^T (4H x 16)
+//
+// Eight wavefronts; wave w keeps its 64 rows of W_hh (forward: the four gates of hidden units
+// 16w .. 16w+15) or its 16 rows of W_hh^T (backward: the same units) as MFMA A fragments in 128
+// VGPRs for all T steps. The B operand (h^T or dG^T) is re-read from LDS every step, stored so
+// that four consecutive k-slices come back with one ds_read_b128. Rows are assigned to fragment
+// slots such that a lane's accumulators are the four gates of four CONSECUTIVE units of one
+// chain: all gate arithmetic is lane-local and every global access is 16 or 64 contiguous bytes.
+// One barrier per step (double-buffered B operand).
+//
+// Gate layout: the input projection, the saved activations and the gate gradients use the
+// INTERLEAVED order (column = 4*unit + gate, gates i, f, g, o) instead of torch's gate-major
+// order; the host permutes the rows of W_ih once per call (models/dccrn.py _LSTMFunction).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/brever_hip.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LH = 128;       // hidden size
+constexpr int LC = 16;        // chains per workgroup
+
+__device__ __forceinline__ float sigm(float x) { return 1.f/(1.f + expf(-x)); }
+
+// B-operand storage: element (k, n) of a (K x 16) matrix, k = 4*kk + j: the four kk of a group
+// q = kk/4 are adjacent, so lane (j, n) fetches its operands for kk = 4q .. 4q+3 with one b128
+__device__ __forceinline__ int bslot(int k, int n) {
+  const int kk = k >> 2, j = k & 3;
+  return ((((kk >> 2) << 2) + j)*LC + n)*4 + (kk & 3);
+}
+
+__global__ __launch_bounds__(512) void lstm_tile_fwd_kernel(const float* __restrict__ gates_in,
+                                                            const float* __restrict__ w_hh,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ y,
+                                                            float* __restrict__ act,
+                                                            float* __restrict__ cs, int per_group,
+                                                            int T) {
+  __shared__ __attribute__((aligned(16))) float hbuf[2][LH*LC];
+  const int tiles = (per_group + LC - 1)/LC;
+  const int grp = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, j = lane >> 4;
+  const int cl = tile*LC + n;
+  const bool live = cl < per_group;
+  const long long chain = (long long)grp*per_group + (live ? cl : per_group - 1);
+  w_hh += (long long)grp*4*LH*LH;
+  // A fragments: block b, slice kk: A[m = lane & 15][k = 4 kk + (lane >> 4)]; row m = 4 jm + g
+  // of block b is gate g of unit 16 w + 4 jm + b
+  float wf[4][LH/4];
+  {
+    const int jm = (lane & 15) >> 2, g = lane & 3;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float* row = w_hh + (long long)(g*LH + 16*w + 4*jm + b)*LH + (lane >> 4);
+#pragma unroll
+      for (int kk = 0; kk < LH/4; ++kk) wf[b][kk] = row[4*kk];
+    }
+  }
+  const int u0 = 16*w + 4*j;                      // this lane's cells: units u0 .. u0+3 of chain n
+  f32x4 bs[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bs[b][g] = bias ? bias[(long long)grp*4*LH + g*LH + u0 + b] : 0.f;
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < LH*LC; i += 512) hbuf[0][i] = 0.f;
+  const float* gin = gates_in + chain*T*4*LH + 4*u0;
+  f32x4 gnext[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) gnext[b] = *reinterpret_cast<const f32x4*>(gin + 4*b);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = gnext[b] + bs[b];
+    if (t + 1 < T) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        gnext[b] = *reinterpret_cast<const f32x4*>(gin + (long long)(t + 1)*4*LH + 4*b);
+    }
+    const float* hb = hbuf[t & 1];
+#pragma unroll
+    for (int q = 0; q < LH/16; ++q) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hb + ((q*4 + j)*LC + n)*4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[b][4*q + s], hv[s], acc[b], 0, 0, 0);
+    }
+    f32x4 hn, cn;
+    f32x4 a[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float ig = sigm(acc[b][0]), fg = sigm(acc[b][1]);
+      const float gg = tanhf(acc[b][2]), og = sigm(acc[b][3]);
+      c[b] = fg*c[b] + ig*gg;
+      cn[b] = c[b];
+      hn[b] = og*tanhf(c[b]);
+      a[b] = f32x4{ig, fg, gg, og};
+    }
+    float* hw = hbuf[(t + 1) & 1];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) hw[bslot(u0 + b, n)] = hn[b];
+    if (live) {
+      const long long step = chain*T + t;
+      *reinterpret_cast<f32x4*>(y + step*LH + u0) = hn;
+      if (act) {
+        *reinterpret_cast<f32x4*>(cs + step*LH + u0) = cn;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          *reinterpret_cast<f32x4*>(act + step*4*LH + 4*(u0 + b)) = a[b];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(512) void lstm_tile_bwd_kernel(const float* __restrict__ act,
+                                                            const float* __restrict__ cs,
+                                                            const float* __restrict__ w_hh,
+                                                            const float* __restrict__ dy,
+                                                            float* __restrict__ dgates,
+                                                            int per_group, int T) {
+  __shared__ __attribute__((aligned(16))) float gbuf[2][4*LH*LC];      // dG^T, 2 x 32 KB
+  const int tiles = (per_group + LC - 1)/LC;
+  const int grp = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, j = lane >> 4;
+  const int cl = tile*LC + n;
+  const bool live = cl < per_group;
+  const long long chain = (long long)grp*per_group + (live ? cl : per_group - 1);
+  w_hh += (long long)grp*4*LH*LH;
+  // A = W_hh^T rows 16 w .. 16 w + 15: A[m][k] = W_hh[row(k)][16 w + m], k in interleaved order
+  // (k = 4 unit' + gate <-> torch row gate*H + unit'); slice kk covers k = 4 kk .. 4 kk + 3 =
+  // the four gates of unit' = kk, the lane supplying gate (lane >> 4)
+  float wf[LH];
+#pragma unroll
+  for (int kk = 0; kk < LH; ++kk)
+    wf[kk] = w_hh[(long long)((lane >> 4)*LH + kk)*LH + 16*w + (lane & 15)];
+  const int u0 = 16*w + 4*j;
+  f32x4 dh = {0.f, 0.f, 0.f, 0.f};       // gradient reaching h_t through the recurrence
+  f32x4 dc = {0.f, 0.f, 0.f, 0.f};
+  for (int t = T - 1; t >= 0; --t) {
+    const long long step = chain*T + t;
+    f32x4 a[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) a[b] = *reinterpret_cast<const f32x4*>(act + step*4*LH + 4*(u0 + b));
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(cs + step*LH + u0);
+    f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+    if (t > 0) cp = *reinterpret_cast<const f32x4*>(cs + (step - 1)*LH + u0);
+    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + step*LH + u0);
+    float* gw = gbuf[t & 1];
+    f32x4 d[4];                                   // d[gate][b]
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float ig = a[b][0], fg = a[b][1], gg = a[b][2], og = a[b][3];
+      const float tc = tanhf(cv[b]);
+      const float dht = dh[b] + dyv[b];
+      const float dct = dc[b] + dht*og*(1.f - tc*tc);
+      d[0][b] = dct*gg*ig*(1.f - ig);
+      d[1][b] = dct*cp[b]*fg*(1.f - fg);
+      d[2][b] = dct*ig*(1.f - gg*gg);
+      d[3][b] = dht*tc*og*(1.f - og);
+      dc[b] = dct*fg;
+    }
+    // element (k = 4 (u0 + b) + g, n): kk = u0 + b -> group (u0 >> 2) = 4 w + j, kk & 3 = b
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(gw + (((4*w + j)*4 + g)*LC + n)*4) = d[g];
+    if (live) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        *reinterpret_cast<f32x4*>(dgates + step*4*LH + 4*(u0 + b)) =
+            f32x4{d[0][b], d[1][b], d[2][b], d[3][b]};
+    }
+    __syncthreads();
+    if (t == 0) break;
+    f32x4 p[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) p[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < LH/4; ++q) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gw + ((q*4 + j)*LC + n)*4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        p[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4*q + s], gv[s], p[s], 0, 0, 0);
+    }
+    dh = (p[0] + p[1]) + (p[2] + p[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int brv_lstm_tile_supported(int64_t H) { return H == LH ? 1 : 0; }
+
+int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float* bias, float* y,
+                          float* act, float* cs, int64_t B, int64_t T, int64_t H, int64_t groups,
+                          brv_stream_t stream) {
+  if (H != LH || B < 1 || T < 1 || groups < 1 || B % groups) return -1;
+  const int per_group = (int)(B/groups);
+  const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
+  hipLaunchKernelGGL(lstm_tile_fwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, gates_in,
+                     w_hh, bias, y, act, cs, per_group, (int)T);
+  return (int)hipGetLastError();
+}
+
+int brv_lstm_tile_backward(const float* act, const float* cs, const float* w_hh, const float* dy,
+                           float* dgates, int64_t B, int64_t T, int64_t H, int64_t groups,
+                           brv_stream_t stream) {
+  if (H != LH || B < 1 || T < 1 || groups < 1 || B % groups) return -1;
+  const int per_group = (int)(B/groups);
+  const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
+  hipLaunchKernelGGL(lstm_tile_bwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, act, cs,
+                     w_hh, dy, dgates, per_group, (int)T);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

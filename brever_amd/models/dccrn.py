@@ -409,6 +409,19 @@ class _LSTMFunction(torch.autograd.Function):
     projections and their gradients are batched matrix products over G; the recurrence runs
     all G*B chains concurrently, one workgroup each."""
 
+    TILE_MIN_CHAINS = 256       # below this the one-chain-per-workgroup kernels have more parallelism
+
+    @staticmethod
+    def _interleave(w, H):
+        """Rows gate*H + unit -> 4*unit + gate (the gate layout of brv_lstm_tile_*)."""
+        G = w.shape[0]
+        return w.view(G, 4, H, *w.shape[2:]).transpose(1, 2).reshape(w.shape).contiguous()
+
+    @staticmethod
+    def _deinterleave(w, H):
+        G = w.shape[0]
+        return w.view(G, H, 4, *w.shape[2:]).transpose(1, 2).reshape(w.shape).contiguous()
+
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
         lib = hip.lib()
@@ -416,6 +429,12 @@ class _LSTMFunction(torch.autograd.Function):
         G, B, T, I = x.shape
         H = w_hh.shape[-1]
         lowp = ctx.lowp = _AMP['on']
+        # many short chains (TF-GridNet): 16 chains per workgroup on the exact-fp32 MFMA, gates
+        # interleaved; few long chains (DCCRN): one workgroup per chain
+        tiled = ctx.tiled = bool(lib.brv_lstm_tile_supported(H)) and \
+            G*B >= _LSTMFunction.TILE_MIN_CHAINS
+        if tiled:
+            w_ih = _LSTMFunction._interleave(w_ih, H)
         gates = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
         _gemm(x, w_ih, gates, G, B*T, 4*H, I, I, I, 4*H, B*T*I, 4*H*I, B*T*4*H, trans_b=1,
               lowp=lowp)
@@ -423,24 +442,26 @@ class _LSTMFunction(torch.autograd.Function):
         y = torch.empty(G, B, T, H, dtype=torch.float32, device=x.device)
         act = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
         cs = torch.empty(G, B, T, H, dtype=torch.float32, device=x.device)
-        hip.check(lib.brv_lstm_recurrent_forward(hip.ptr(gates), hip.ptr(w_hh), hip.ptr(bias),
-                                                 hip.ptr(y), hip.ptr(act), hip.ptr(cs), G*B, T, H, G,
-                                                 hip.stream()), 'brv_lstm_recurrent_forward')
+        fn, name = (lib.brv_lstm_tile_forward, 'brv_lstm_tile_forward') if tiled else \
+            (lib.brv_lstm_recurrent_forward, 'brv_lstm_recurrent_forward')
+        hip.check(fn(hip.ptr(gates), hip.ptr(w_hh), hip.ptr(bias), hip.ptr(y), hip.ptr(act),
+                     hip.ptr(cs), G*B, T, H, G, hip.stream()), name)
         ctx.save_for_backward(x, w_ih, w_hh, y, act, cs)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = hip.lib()
-        x, w_ih, w_hh, y, act, cs = ctx.saved_tensors
+        x, w_ih, w_hh, y, act, cs = ctx.saved_tensors          # w_ih interleaved when tiled
         G, B, T, I = x.shape
         H = w_hh.shape[-1]
         lowp = ctx.lowp
         dy = dy.contiguous()
         dg = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
-        hip.check(lib.brv_lstm_recurrent_backward(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh),
-                                                  hip.ptr(dy), hip.ptr(dg), G*B, T, H, G,
-                                                  hip.stream()), 'brv_lstm_recurrent_backward')
+        fn, name = (lib.brv_lstm_tile_backward, 'brv_lstm_tile_backward') if ctx.tiled else \
+            (lib.brv_lstm_recurrent_backward, 'brv_lstm_recurrent_backward')
+        hip.check(fn(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh), hip.ptr(dy), hip.ptr(dg), G*B, T, H,
+                     G, hip.stream()), name)
         BT = B*T
         dx = torch.empty_like(x)                                   # dg (BT, 4H) @ W_ih (4H, I)
         _gemm(dg, w_ih, dx, G, BT, I, 4*H, 4*H, I, I, BT*4*H, 4*H*I, BT*I, lowp=lowp)
@@ -457,6 +478,8 @@ class _LSTMFunction(torch.autograd.Function):
         for g in range(G):
             hip.check(lib.brv_row_sum(hip.ptr(dgt[g]), hip.ptr(db[g]), 1, 4*H, BT, hip.stream()),
                       'brv_row_sum')
+        if ctx.tiled:
+            dw_ih, dw_hh, db = (_LSTMFunction._deinterleave(t, H) for t in (dw_ih, dw_hh, db))
         return dx, dw_ih, dw_hh, db, db.clone()
 
 

@@ -329,6 +329,19 @@ int brv_causal_groupnorm_backward(const float* x, const float* dy, const float* 
                                   void* scratch, float* uv_scratch, int64_t B, int64_t C,
                                   int64_t inner, int64_t T, int64_t groups, brv_stream_t stream);
 
+/* ---- LSTM recurrence for many short chains (nn.LSTM as used by tfgridnet.py:200-216): 16
+ * chains per workgroup, one exact-fp32 MFMA product per step, hidden size 128 only
+ * (brv_lstm_tile_supported). Same arguments as brv_lstm_recurrent_forward / _backward EXCEPT the
+ * gate layout of gates_in, act and dgates, which is interleaved (column = 4*unit + gate) instead
+ * of torch's gate-major order; w_hh and bias stay in torch's layout. */
+int brv_lstm_tile_supported(int64_t H);
+int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float* bias, float* y,
+                          float* act, float* cs, int64_t B, int64_t T, int64_t H, int64_t groups,
+                          brv_stream_t stream);
+int brv_lstm_tile_backward(const float* act, const float* cs, const float* w_hh, const float* dy,
+                           float* dgates, int64_t B, int64_t T, int64_t H, int64_t groups,
+                           brv_stream_t stream);
+
 /* ---- TF-GridNet row operators (models/tfgridnet/tfgridnet.py). rownorm: layer normalisation of
  * `rows` contiguous rows of n floats, optionally behind a PReLU, with gain / bias (groups, n); the
  * group (and PReLU slope, nullable = no PReLU) of row r is (r / inner) % groups. Replaces

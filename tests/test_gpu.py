@@ -1447,3 +1447,34 @@ def test_tfgridnet_training_flow_reproduces_reference_literals(golden_dir):
     # torch_ema wheel (raw weights), so they only bound the EMA-weight losses loosely
     assert np.allclose(vl, g['tfgridnet_val_loss'], rtol=1e-2), (vl, g['tfgridnet_val_loss'])
     assert torch.allclose(flat, literals, rtol=1e-3, atol=1e-5), (flat, literals)
+
+
+@pytest.mark.gpu
+def test_lstm_tiled_kernels_match_torch():
+    """The 16-chains-per-workgroup MFMA recurrence (H = 128, interleaved gate layout; chain count
+    not a multiple of the tile) and its backward pass vs ``torch.nn.LSTM`` on the CPU, two
+    parameter groups in one launch: hidden states 1e-5, every gradient 1e-4 (rel-L2, fp32)."""
+    from brever_amd.models.dccrn import _LSTMFunction
+    dev = _cuda()
+    torch.manual_seed(7)
+    H, B, T, I = 128, 150, 9, 24
+    assert 2*B >= _LSTMFunction.TILE_MIN_CHAINS and B % 16
+    refs = [torch.nn.LSTM(I, H, batch_first=True) for _ in range(2)]
+    xs = [torch.randn(B, T, I, requires_grad=True) for _ in range(2)]
+    gy = torch.randn(2, B, T, H)
+    ys = []
+    for m, x, g in zip(refs, xs, gy):
+        y, _ = m(x)
+        y.backward(g)
+        ys.append(y.detach())
+    names = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')
+    xd = torch.stack([x.detach() for x in xs]).to(dev).requires_grad_(True)
+    pd = [torch.stack([getattr(m, n).detach() for m in refs]).to(dev).requires_grad_(True)
+          for n in names]
+    yd = _LSTMFunction.apply(xd, *pd)
+    yd.backward(gy.to(dev))
+    for g in range(2):
+        assert rel(yd[g], ys[g]) <= 1e-5, rel(yd[g], ys[g])
+        assert rel(xd.grad[g], xs[g].grad) <= 1e-4
+        for got, n in zip(pd, names):
+            assert rel(got.grad[g], getattr(refs[g], n).grad) <= 1e-4, (n, rel(got.grad[g], getattr(refs[g], n).grad))

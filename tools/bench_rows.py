@@ -83,7 +83,7 @@ def sgmse_train_row(batch, frames, steps, use_amp=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--rows', default='ffnn,dccrn,sgmse,sgmse_train')
+    ap.add_argument('--rows', default='ffnn,dccrn,tfgridnet,sgmse,sgmse_train')
     args = ap.parse_args()
     rows = args.rows.split(',')
     if 'ffnn' in rows:
@@ -91,6 +91,11 @@ def main():
     if 'dccrn' in rows:
         print(json.dumps(train_row('dccrn', 16, 4.0, 5, False)), flush=True)
         row = train_row('dccrn', 16, 4.0, 5, True)
+        row['row'] += ' (use_amp: bf16 matrix products)'
+        print(json.dumps(row), flush=True)
+    if 'tfgridnet' in rows:
+        print(json.dumps(train_row('tfgridnet', 4, 4.0, 3, False)), flush=True)
+        row = train_row('tfgridnet', 4, 4.0, 3, True)
         row['row'] += ' (use_amp: bf16 matrix products)'
         print(json.dumps(row), flush=True)
     if 'sgmse_train' in rows:
