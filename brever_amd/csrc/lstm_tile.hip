@@ -47,7 +47,8 @@ __global__ __launch_bounds__(512) void lstm_tile_fwd_kernel(const float* __restr
                                                             float* __restrict__ y,
                                                             float* __restrict__ act,
                                                             float* __restrict__ cs, int per_group,
-                                                            int T) {
+                                                            int T, int reverse_mask, long long y_ld,
+                                                            long long y_goff) {
   __shared__ __attribute__((aligned(16))) float hbuf[2][LH*LC];
   const int tiles = (per_group + LC - 1)/LC;
   const int grp = blockIdx.x / tiles, tile = blockIdx.x % tiles;
@@ -77,19 +78,26 @@ __global__ __launch_bounds__(512) void lstm_tile_fwd_kernel(const float* __restr
     for (int g = 0; g < 4; ++g) bs[b][g] = bias ? bias[(long long)grp*4*LH + g*LH + u0 + b] : 0.f;
   float c[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i = tid; i < LH*LC; i += 512) hbuf[0][i] = 0.f;
+  // a reversed group walks the frames backwards: step t of the recurrence is frame T-1-t of
+  // gates_in and y (the saved act / cs stay indexed by the recurrence step)
+  const bool rev = (reverse_mask >> grp) & 1;
+  const int t_first = rev ? T - 1 : 0, t_inc = rev ? -1 : 1;
   const float* gin = gates_in + chain*T*4*LH + 4*u0;
+  float* yrow = y + (long long)(live ? cl : per_group - 1)*T*y_ld + grp*y_goff + u0;
   f32x4 gnext[4];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) gnext[b] = *reinterpret_cast<const f32x4*>(gin + 4*b);
+  for (int b = 0; b < 4; ++b)
+    gnext[b] = *reinterpret_cast<const f32x4*>(gin + (long long)t_first*4*LH + 4*b);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
+    const int tt = t_first + t*t_inc;
     f32x4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = gnext[b] + bs[b];
     if (t + 1 < T) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
-        gnext[b] = *reinterpret_cast<const f32x4*>(gin + (long long)(t + 1)*4*LH + 4*b);
+        gnext[b] = *reinterpret_cast<const f32x4*>(gin + (long long)(tt + t_inc)*4*LH + 4*b);
     }
     const float* hb = hbuf[t & 1];
 #pragma unroll
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(512) void lstm_tile_fwd_kernel(const float* __restr
     for (int b = 0; b < 4; ++b) hw[bslot(u0 + b, n)] = hn[b];
     if (live) {
       const long long step = chain*T + t;
-      *reinterpret_cast<f32x4*>(y + step*LH + u0) = hn;
+      *reinterpret_cast<f32x4*>(yrow + tt*y_ld) = hn;
       if (act) {
         *reinterpret_cast<f32x4*>(cs + step*LH + u0) = cn;
 #pragma unroll
@@ -134,7 +142,8 @@ __global__ __launch_bounds__(512) void lstm_tile_bwd_kernel(const float* __restr
                                                             const float* __restrict__ w_hh,
                                                             const float* __restrict__ dy,
                                                             float* __restrict__ dgates,
-                                                            int per_group, int T) {
+                                                            int per_group, int T, int reverse_mask,
+                                                            long long dy_ld, long long dy_goff) {
   __shared__ __attribute__((aligned(16))) float gbuf[2][4*LH*LC];      // dG^T, 2 x 32 KB
   const int tiles = (per_group + LC - 1)/LC;
   const int grp = blockIdx.x / tiles, tile = blockIdx.x % tiles;
@@ -154,15 +163,18 @@ __global__ __launch_bounds__(512) void lstm_tile_bwd_kernel(const float* __restr
   const int u0 = 16*w + 4*j;
   f32x4 dh = {0.f, 0.f, 0.f, 0.f};       // gradient reaching h_t through the recurrence
   f32x4 dc = {0.f, 0.f, 0.f, 0.f};
+  const bool rev = (reverse_mask >> grp) & 1;
+  const float* dyrow = dy + (long long)(live ? cl : per_group - 1)*T*dy_ld + grp*dy_goff + u0;
   for (int t = T - 1; t >= 0; --t) {
     const long long step = chain*T + t;
+    const int tt = rev ? T - 1 - t : t;             // frame of recurrence step t
     f32x4 a[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) a[b] = *reinterpret_cast<const f32x4*>(act + step*4*LH + 4*(u0 + b));
     const f32x4 cv = *reinterpret_cast<const f32x4*>(cs + step*LH + u0);
     f32x4 cp = {0.f, 0.f, 0.f, 0.f};
     if (t > 0) cp = *reinterpret_cast<const f32x4*>(cs + (step - 1)*LH + u0);
-    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + step*LH + u0);
+    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dyrow + tt*dy_ld);
     float* gw = gbuf[t & 1];
     f32x4 d[4];                                   // d[gate][b]
 #pragma unroll
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(512) void lstm_tile_bwd_kernel(const float* __restr
     if (live) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
-        *reinterpret_cast<f32x4*>(dgates + step*4*LH + 4*(u0 + b)) =
+        *reinterpret_cast<f32x4*>(dgates + (chain*T + tt)*4*LH + 4*(u0 + b)) =
             f32x4{d[0][b], d[1][b], d[2][b], d[3][b]};
     }
     __syncthreads();
@@ -211,23 +223,27 @@ int brv_lstm_tile_supported(int64_t H) { return H == LH ? 1 : 0; }
 
 int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float* bias, float* y,
                           float* act, float* cs, int64_t B, int64_t T, int64_t H, int64_t groups,
+                          int64_t reverse_mask, int64_t y_ld, int64_t y_group_offset,
                           brv_stream_t stream) {
-  if (H != LH || B < 1 || T < 1 || groups < 1 || B % groups) return -1;
+  if (H != LH || B < 1 || T < 1 || groups < 1 || groups > 30 || B % groups) return -1;
   const int per_group = (int)(B/groups);
   const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
   hipLaunchKernelGGL(lstm_tile_fwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, gates_in,
-                     w_hh, bias, y, act, cs, per_group, (int)T);
+                     w_hh, bias, y, act, cs, per_group, (int)T, (int)reverse_mask, (long long)y_ld,
+                     (long long)y_group_offset);
   return (int)hipGetLastError();
 }
 
 int brv_lstm_tile_backward(const float* act, const float* cs, const float* w_hh, const float* dy,
                            float* dgates, int64_t B, int64_t T, int64_t H, int64_t groups,
+                           int64_t reverse_mask, int64_t dy_ld, int64_t dy_group_offset,
                            brv_stream_t stream) {
-  if (H != LH || B < 1 || T < 1 || groups < 1 || B % groups) return -1;
+  if (H != LH || B < 1 || T < 1 || groups < 1 || groups > 30 || B % groups) return -1;
   const int per_group = (int)(B/groups);
   const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
   hipLaunchKernelGGL(lstm_tile_bwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, act, cs,
-                     w_hh, dy, dgates, per_group, (int)T);
+                     w_hh, dy, dgates, per_group, (int)T, (int)reverse_mask, (long long)dy_ld,
+                     (long long)dy_group_offset);
   return (int)hipGetLastError();
 }
 

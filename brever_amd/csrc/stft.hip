@@ -38,6 +38,7 @@ struct G32 {
   // (a + kb*a_kbs, b + kb*b_kbs); D = acc + row_bias[m] (+ D if accumulate)
   int kbatch; long long a_kbs, b_kbs;
   const float* row_bias; int accumulate;
+  int col_bias;            // the bias is per output COLUMN (accumulate == 2 at the C ABI)
 };
 
 constexpr int TM = 64, TN = 64, TK = 32;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const G32 p) {
       const int row = m0 + 32*wm + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
       if (row < p.M) {
         float v = acc[i];
-        if (p.row_bias) v += p.row_bias[row];
+        if (p.row_bias) v += p.row_bias[p.col_bias ? col : row];
         if (p.accumulate) v += D[(long long)row*p.ldd + col];
         D[(long long)row*p.ldd + col] = v;
       }
@@ -234,10 +235,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const G32 p, int ksplit) 
         float v = acc[fi][fj][i];
         float* d = D + (long long)row*p.ldd + col;
         if (ksplit > 1) {
-          if (split == 0 && p.row_bias) v += p.row_bias[row];
+          if (split == 0 && p.row_bias) v += p.row_bias[p.col_bias ? col : row];
           atomicAdd(d, v);
         } else {
-          if (p.row_bias) v += p.row_bias[row];
+          if (p.row_bias) v += p.row_bias[p.col_bias ? col : row];
           if (p.accumulate) v += *d;
           *d = v;
         }
@@ -352,10 +353,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
         float v = acc[fi][fj][i];
         float* d = D + (long long)row*p.ldd + col;
         if (ksplit > 1) {
-          if (split == 0 && p.row_bias) v += p.row_bias[row];
+          if (split == 0 && p.row_bias) v += p.row_bias[p.col_bias ? col : row];
           atomicAdd(d, v);
         } else {
-          if (p.row_bias) v += p.row_bias[row];
+          if (p.row_bias) v += p.row_bias[p.col_bias ? col : row];
           if (p.accumulate) v += *d;
           *d = v;
         }
@@ -544,6 +545,8 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   p.B = b; p.b_bs = b_batch_stride; p.ldb = (int)ldb;
   p.D = d; p.d_bs = d_batch_stride; p.ldd = (int)ldd;
   p.kbatch = (int)kbatch; p.a_kbs = a_kbatch_stride; p.b_kbs = b_kbatch_stride;
+  p.col_bias = accumulate == 2;
+  if (accumulate == 2) accumulate = 0;
   p.row_bias = row_bias; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
   // reduction split: fill the chip when the output has few tiles and the reduction is long

@@ -25,7 +25,13 @@ namespace {
 
 #define TG_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
-constexpr int kSlices = 64;       // row slices of the parameter-gradient reduction
+// row slices of the parameter-gradient reduction: enough workgroups to fill the chip whatever the
+// row length (32 ... 4 128), at most 1 024 partial tables
+__host__ __device__ inline int pgrad_slices(long long n, long long groups) {
+  const long long wgs = ((n + 63)/64)*groups;
+  long long s = (2048 + wgs - 1)/wgs;
+  return (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
+}
 
 __device__ __forceinline__ float prelu(float v, float a) { return v > 0.f ? v : a*v; }
 
@@ -104,6 +110,7 @@ __global__ __launch_bounds__(256) void rownorm_pgrad_kernel(const float* __restr
                                                             float2* __restrict__ part,
                                                             long long rows, int n, int inner, int G) {
   __shared__ float2 red[4][64];
+  const int kSlices = gridDim.z;
   const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int j = blockIdx.x*64 + col;
   const int g = blockIdx.y, slice = blockIdx.z;
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256) void rownorm_pgrad_kernel(const float* __restr
 __global__ __launch_bounds__(256) void rownorm_pgrad_fold_kernel(const float2* __restrict__ part,
                                                                  float* __restrict__ dgain,
                                                                  float* __restrict__ dbias,
-                                                                 long long total) {
+                                                                 long long total, int kSlices) {
   const long long i = (long long)blockIdx.x*256 + threadIdx.x;
   if (i >= total) return;
   float sg = 0.f, sb = 0.f;
@@ -187,7 +194,7 @@ int brv_rownorm_forward(const float* x, const float* slope, const float* gain, c
 }
 
 int64_t brv_rownorm_scratch_bytes(int64_t n, int64_t groups) {
-  return (int64_t)kSlices*groups*n*(int64_t)sizeof(float2);
+  return (int64_t)pgrad_slices(n, groups)*groups*n*(int64_t)sizeof(float2);
 }
 
 int brv_rownorm_backward(const float* x, const float* dy, const float* slope, const float* gain,
@@ -201,12 +208,13 @@ int brv_rownorm_backward(const float* x, const float* dy, const float* slope, co
                      slope, gain, stp, dx, slope ? dslope_rows : nullptr, (long long)rows, (int)n,
                      (int)inner, (int)groups);
   float2* part = reinterpret_cast<float2*>(scratch);
+  const int kSlices = pgrad_slices(n, groups);
   hipLaunchKernelGGL(rownorm_pgrad_kernel, dim3((unsigned)((n + 63)/64), (unsigned)groups, kSlices),
                      dim3(256), 0, st, x, dy, slope, stp, part, (long long)rows, (int)n, (int)inner,
                      (int)groups);
   const long long total = (long long)groups*n;
   hipLaunchKernelGGL(rownorm_pgrad_fold_kernel, dim3((unsigned)((total + 255)/256)), dim3(256), 0,
-                     st, part, dgain, dbias, total);
+                     st, part, dgain, dbias, total, kSlices);
   TG_OK(hipGetLastError());
   return 0;
 }

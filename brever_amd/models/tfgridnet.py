@@ -199,10 +199,112 @@ class _AttentionFn(torch.autograd.Function):
         return dq, dk, dv
 
 
+def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_a=0, trans_b=0,
+          kbatch=1, a_kbs=0, b_kbs=0, bias=None, mode=0, lowp=False):
+    """brv_gemm_f32 / brv_gemm_bf16 (bf16 operands, fp32 accumulation: ``use_amp``); ``mode`` 1
+    adds to d, 2 reads ``bias`` per output column."""
+    fn = hip.lib().brv_gemm_bf16 if lowp else hip.lib().brv_gemm_f32
+    hip.check(fn(hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
+                 trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), mode, hip.stream()),
+              'brv_gemm_bf16' if lowp else 'brv_gemm_f32')
+
+
+def _column_sums(x, rows, cols, batch=1):
+    """(batch, rows, cols) -> (batch, cols): a ones-vector product (one pass over x)."""
+    ones = torch.ones(rows, dtype=torch.float32, device=x.device)
+    out = torch.empty(batch, cols, dtype=torch.float32, device=x.device)
+    _gemm(ones, x, out, batch, 1, cols, rows, rows, cols, cols, 0, rows*cols, cols)
+    return out
+
+
+class _LinearFn(torch.autograd.Function):
+    """(N, I) -> (N, O) = x @ W^T + b, row-major in and out (no transposed copies)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, w = x.contiguous(), w.contiguous()
+        N, I = x.shape
+        O = w.shape[0]
+        lowp = ctx.lowp = _AMP['on']
+        y = T._empty(N, O, like=x)
+        _gemm(x, w, y, 1, N, O, I, I, I, O, trans_b=1, bias=bias.contiguous(), mode=2, lowp=lowp)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, I = x.shape
+        O = w.shape[0]
+        dx = T._empty(N, I, like=x)
+        _gemm(dy, w, dx, 1, N, I, O, O, I, I, lowp=ctx.lowp)
+        dw = torch.empty_like(w)
+        _gemm(dy, x, dw, 1, O, I, N, O, I, I, trans_a=1, lowp=ctx.lowp)
+        return dx, dw, _column_sums(dy, N, O)[0]
+
+
 def _linear(x, mod):
     """nn.Linear / 1x1 convolution over the last axis of a channels-last tensor."""
     w = mod.weight.reshape(mod.weight.shape[0], -1)
-    return T.LinearFn.apply(x.reshape(-1, x.shape[-1]), w, mod.bias).view(*x.shape[:-1], w.shape[0])
+    return _LinearFn.apply(x.reshape(-1, x.shape[-1]), w, mod.bias).view(*x.shape[:-1], w.shape[0])
+
+
+class _BiLSTMFn(torch.autograd.Function):
+    """Bidirectional single-layer nn.LSTM (batch_first, zero initial state) on x (N, S, I) ->
+    (N, S, 2H) with the tiled recurrence kernels: both directions are groups of ONE launch, the
+    second walking the frames backwards in place (no flipped copies), both writing their half of
+    the output rows. Input projections, their gradients and the bias gradients are batched
+    products; the recurrent weight gradient pairs every gate gradient with the previous hidden
+    state of its own direction through shifted views (no shifted copy)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        lib = hip.lib()
+        x, w_hh = x.contiguous(), w_hh.contiguous()
+        N, S, I = x.shape
+        H = w_hh.shape[-1]
+        lowp = ctx.lowp = _AMP['on']
+        w_ih = _LSTMFunction._interleave(w_ih.contiguous(), H)
+        gates = T._empty(2, N, S, 4*H, like=x)
+        _gemm(x, w_ih, gates, 2, N*S, 4*H, I, I, I, 4*H, 0, 4*H*I, N*S*4*H, trans_b=1, lowp=lowp)
+        bias = T._axpby_raw(b_ih.detach().contiguous(), 1.0, b_hh.detach().contiguous(), 1.0)
+        y = T._empty(N, S, 2*H, like=x)
+        act, cs = T._empty(2, N, S, 4*H, like=x), T._empty(2, N, S, H, like=x)
+        hip.check(lib.brv_lstm_tile_forward(hip.ptr(gates), hip.ptr(w_hh), hip.ptr(bias), hip.ptr(y),
+                                            hip.ptr(act), hip.ptr(cs), 2*N, S, H, 2, 2, 2*H, H,
+                                            hip.stream()), 'brv_lstm_tile_forward')
+        ctx.save_for_backward(x, w_ih, w_hh, y, act, cs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = hip.lib()
+        x, w_ih, w_hh, y, act, cs = ctx.saved_tensors            # w_ih interleaved
+        N, S, I = x.shape
+        H = w_hh.shape[-1]
+        lowp, NS = ctx.lowp, N*S
+        dy = dy.contiguous()
+        dg = T._empty(2, N, S, 4*H, like=x)
+        hip.check(lib.brv_lstm_tile_backward(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh), hip.ptr(dy),
+                                             hip.ptr(dg), 2*N, S, H, 2, 2, 2*H, H, hip.stream()),
+                  'brv_lstm_tile_backward')
+        dx = torch.empty_like(x)                      # sum over both directions: dg_g @ W_ih_g
+        _gemm(dg, w_ih, dx, 1, NS, I, 4*H, 4*H, I, I, kbatch=2, a_kbs=NS*4*H, b_kbs=4*H*I,
+              lowp=lowp)
+        dw_ih = torch.empty_like(w_ih)                # dg_g^T @ x
+        _gemm(dg, x, dw_ih, 2, 4*H, I, NS, 4*H, I, I, NS*4*H, 0, 4*H*I, trans_a=1, lowp=lowp)
+        dw_hh = torch.zeros_like(w_hh)
+        if S > 1:
+            flat_dg, flat_y = dg.view(2, -1), y.view(-1)
+            # forward direction: gate gradients of frames 1.. against hidden states of frames 0..;
+            # backward direction: frames ..S-2 against hidden states of frames 1..
+            for g, (dg_off, y_off) in enumerate(((4*H, 0), (0, 2*H + H))):
+                _gemm(flat_dg[g, dg_off:], flat_y[y_off:], dw_hh[g], 1, 4*H, H, S - 1, 4*H, 2*H, H,
+                      trans_a=1, kbatch=N, a_kbs=S*4*H, b_kbs=S*2*H, lowp=lowp)
+        db = _column_sums(dg, NS, 4*H, batch=2)
+        dw_ih, dw_hh, db = (_LSTMFunction._deinterleave(t, H) for t in (dw_ih, dw_hh, db))
+        return dx, dw_ih, dw_hh, db, db.clone()
 
 
 def _add(a, b):
@@ -214,6 +316,9 @@ def _bilstm(x, rnn):
     and its reversal are two groups of one launch set."""
     stack = lambda name: torch.stack([getattr(rnn, name + '_l0'),  # noqa: E731
                                       getattr(rnn, name + '_l0_reverse')])
+    if hip.lib().brv_lstm_tile_supported(rnn.hidden_size):
+        return _BiLSTMFn.apply(x, stack('weight_ih'), stack('weight_hh'), stack('bias_ih'),
+                               stack('bias_hh'))
     y = _LSTMFunction.apply(torch.stack([x, x.flip(1)]), stack('weight_ih'), stack('weight_hh'),
                             stack('bias_ih'), stack('bias_hh'))
     return torch.cat([y[0], y[1].flip(1)], dim=-1)

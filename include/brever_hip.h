@@ -167,7 +167,8 @@ int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int6
  * models/ffnn/ffnn.py:151-171): d[z] (M x N) (+)= sum_kb op_a(a[z,kb]) @ op_b(b[z,kb]) +
  * row_bias[m]; trans_a: a stored (K x M); trans_b: b stored (N x K); kbatch extends the
  * reduction over kbatch operand pairs a/b_kbatch_stride apart (weight gradients summed over
- * the batch). */
+ * the batch). accumulate: 0 overwrite, 1 add to d, 2 overwrite with row_bias read per output
+ * COLUMN (bias[n]: nn.Linear on row-major activations without a transposed copy). */
 int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
                  int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
                  int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
@@ -333,13 +334,20 @@ int brv_causal_groupnorm_backward(const float* x, const float* dy, const float* 
  * chains per workgroup, one exact-fp32 MFMA product per step, hidden size 128 only
  * (brv_lstm_tile_supported). Same arguments as brv_lstm_recurrent_forward / _backward EXCEPT the
  * gate layout of gates_in, act and dgates, which is interleaved (column = 4*unit + gate) instead
- * of torch's gate-major order; w_hh and bias stay in torch's layout. */
+ * of torch's gate-major order; w_hh and bias stay in torch's layout. Bit g of reverse_mask makes
+ * group g run over the frames backwards (the second direction of a bidirectional nn.LSTM, no
+ * flipped copies). y / dy element (group g, chain c of the group, frame t, unit u) lives at
+ * g*group_offset + (c*T + t)*ld + u: ld = H, group_offset = chains_per_group*T*H is the plain
+ * (groups, chains, T, H) layout; ld = 2H, group_offset = H writes both directions straight into
+ * nn.LSTM's (chains, T, 2H) output. */
 int brv_lstm_tile_supported(int64_t H);
 int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float* bias, float* y,
                           float* act, float* cs, int64_t B, int64_t T, int64_t H, int64_t groups,
+                          int64_t reverse_mask, int64_t y_ld, int64_t y_group_offset,
                           brv_stream_t stream);
 int brv_lstm_tile_backward(const float* act, const float* cs, const float* w_hh, const float* dy,
                            float* dgates, int64_t B, int64_t T, int64_t H, int64_t groups,
+                           int64_t reverse_mask, int64_t dy_ld, int64_t dy_group_offset,
                            brv_stream_t stream);
 
 /* ---- TF-GridNet row operators (models/tfgridnet/tfgridnet.py). rownorm: layer normalisation of

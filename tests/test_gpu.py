@@ -1478,3 +1478,20 @@ def test_lstm_tiled_kernels_match_torch():
         assert rel(xd.grad[g], xs[g].grad) <= 1e-4
         for got, n in zip(pd, names):
             assert rel(got.grad[g], getattr(refs[g], n).grad) <= 1e-4, (n, rel(got.grad[g], getattr(refs[g], n).grad))
+    # the bidirectional form: both directions in one launch, the second walking backwards in place
+    from brever_amd.models.tfgridnet import _bilstm
+    ref = torch.nn.LSTM(I, H, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, I, requires_grad=True)
+    gy2 = torch.randn(B, T, 2*H)
+    y, _ = ref(x)
+    y.backward(gy2)
+    import copy
+    dut = copy.deepcopy(ref).to(dev)
+    dut.zero_grad()
+    xd = x.detach().to(dev).requires_grad_(True)
+    yd = _bilstm(xd, dut)
+    yd.backward(gy2.to(dev))
+    assert rel(yd, y.detach()) <= 1e-5, rel(yd, y.detach())
+    assert rel(xd.grad, x.grad) <= 1e-4
+    for (n, p), q in zip(ref.named_parameters(), dut.parameters()):
+        assert rel(q.grad, p.grad) <= 1e-4, (n, rel(q.grad, p.grad))
