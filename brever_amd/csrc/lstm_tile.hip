@@ -32,7 +32,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LH = 128;       // hidden size
 constexpr int LC = 16;        // chains per workgroup
 
-__device__ __forceinline__ float sigm(float x) { return 1.f/(1.f + expf(-x)); }
+// gate non-linearities on the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each; the gate
+// math is as long as the MFMA phase of a step when done with the libm forms)
+__device__ __forceinline__ float sigm(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __expf(-x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {      // 2 sigm(2x) - 1, saturates cleanly
+  return 2.f*__builtin_amdgcn_rcpf(1.f + __expf(-2.f*x)) - 1.f;
+}
 
 // B-operand storage: element (k, n) of a (K x 16) matrix, k = 4*kk + j: the four kk of a group
 // q = kk/4 are adjacent, so lane (j, n) fetches its operands for kk = 4q .. 4q+3 with one b128
@@ -114,10 +121,10 @@ __global__ __launch_bounds__(512) void lstm_tile_fwd_kernel(const float* __restr
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const float ig = sigm(acc[b][0]), fg = sigm(acc[b][1]);
-      const float gg = tanhf(acc[b][2]), og = sigm(acc[b][3]);
+      const float gg = tanh_fast(acc[b][2]), og = sigm(acc[b][3]);
       c[b] = fg*c[b] + ig*gg;
       cn[b] = c[b];
-      hn[b] = og*tanhf(c[b]);
+      hn[b] = og*tanh_fast(c[b]);
       a[b] = f32x4{ig, fg, gg, og};
     }
     float* hw = hbuf[(t + 1) & 1];
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(512) void lstm_tile_bwd_kernel(const float* __restr
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const float ig = a[b][0], fg = a[b][1], gg = a[b][2], og = a[b][3];
-      const float tc = tanhf(cv[b]);
+      const float tc = tanh_fast(cv[b]);
       const float dht = dh[b] + dyv[b];
       const float dct = dc[b] + dht*og*(1.f - tc*tc);
       d[0][b] = dct*gg*ig*(1.f - ig);

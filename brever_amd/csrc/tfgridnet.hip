@@ -142,11 +142,19 @@ __global__ __launch_bounds__(256) void rownorm_pgrad_fold_kernel(const float2* _
                                                                  float* __restrict__ dgain,
                                                                  float* __restrict__ dbias,
                                                                  long long total, int kSlices) {
-  const long long i = (long long)blockIdx.x*256 + threadIdx.x;
-  if (i >= total) return;
+  // 64 columns per workgroup, the slices dealt to 4 row lanes, fixed summation order
+  __shared__ float2 red[4][64];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x*64 + col;
   float sg = 0.f, sb = 0.f;
-  for (int s = 0; s < kSlices; ++s) { const float2 t = part[s*total + i]; sg += t.x; sb += t.y; }
-  dgain[i] = sg; dbias[i] = sb;
+  if (i < total)
+    for (int s = rl; s < kSlices; s += 4) { const float2 t = part[s*total + i]; sg += t.x; sb += t.y; }
+  red[rl][col] = make_float2(sg, sb);
+  __syncthreads();
+  if (rl == 0 && i < total) {
+    dgain[i] = (red[0][col].x + red[1][col].x) + (red[2][col].x + red[3][col].x);
+    dbias[i] = (red[0][col].y + red[1][col].y) + (red[2][col].y + red[3][col].y);
+  }
 }
 
 // unbiased standard deviation of each row (two passes, fp64 accumulators)
@@ -213,7 +221,7 @@ int brv_rownorm_backward(const float* x, const float* dy, const float* slope, co
                      dim3(256), 0, st, x, dy, slope, stp, part, (long long)rows, (int)n, (int)inner,
                      (int)groups);
   const long long total = (long long)groups*n;
-  hipLaunchKernelGGL(rownorm_pgrad_fold_kernel, dim3((unsigned)((total + 255)/256)), dim3(256), 0,
+  hipLaunchKernelGGL(rownorm_pgrad_fold_kernel, dim3((unsigned)((total + 63)/64)), dim3(256), 0,
                      st, part, dgain, dbias, total, kSlices);
   TG_OK(hipGetLastError());
   return 0;
