@@ -24,6 +24,7 @@
 #include <math.h>
 
 #include "../../include/brever_hip.h"
+#include "common.cuh"
 
 namespace {
 
@@ -222,6 +223,197 @@ __global__ __launch_bounds__(512) void lstm_tile_bwd_kernel(const float* __restr
   }
 }
 
+// ---- bf16-operand variants (use_amp): W_hh and the B operand (h^T or dG^T) are rounded to bf16
+// and multiplied on v_mfma_f32_16x16x32_bf16 (K = 32 per instruction: 16 instead of 128 MFMAs per
+// wave and step); accumulators, cell state, gate math and every tensor in HBM stay fp32. The B
+// operand sits in LDS chain-major ([chain][k], rows padded by 16 B so that the 16-byte fragment
+// reads of 16 chains fall on distinct banks); same row -> fragment assignment as above.
+using brv::bf16x8;
+using brv::pack2;
+constexpr int HROW = LH + 8;          // bf16 elements per chain row of h^T
+constexpr int GROW = 4*LH + 8;        // ... of dG^T
+
+__device__ __forceinline__ bf16x8 load_frag(const float* p, long long stride) {
+  uint4 q;
+  q.x = pack2(p[0], p[stride]); q.y = pack2(p[2*stride], p[3*stride]);
+  q.z = pack2(p[4*stride], p[5*stride]); q.w = pack2(p[6*stride], p[7*stride]);
+  return __builtin_bit_cast(bf16x8, q);
+}
+
+__global__ __launch_bounds__(512) void lstm_tile_fwd_bf16_kernel(const float* __restrict__ gates_in,
+                                                                 const float* __restrict__ w_hh,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ y,
+                                                                 float* __restrict__ act,
+                                                                 float* __restrict__ cs,
+                                                                 int per_group, int T,
+                                                                 int reverse_mask, long long y_ld,
+                                                                 long long y_goff) {
+  __shared__ __attribute__((aligned(16))) uint16_t hbuf[2][LC*HROW];
+  const int tiles = (per_group + LC - 1)/LC;
+  const int grp = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, j = lane >> 4;
+  const int cl = tile*LC + n;
+  const bool live = cl < per_group;
+  const long long chain = (long long)grp*per_group + (live ? cl : per_group - 1);
+  w_hh += (long long)grp*4*LH*LH;
+  // A[m = lane & 15][k = 32 kq + 8 (lane >> 4) + i]; row m = 4 jm + g of block b = gate g of unit
+  // 16 w + 4 jm + b
+  bf16x8 wf[4][LH/32];
+  {
+    const int jm = (lane & 15) >> 2, g = lane & 3;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float* row = w_hh + (long long)(g*LH + 16*w + 4*jm + b)*LH + 8*(lane >> 4);
+#pragma unroll
+      for (int kq = 0; kq < LH/32; ++kq) wf[b][kq] = load_frag(row + 32*kq, 1);
+    }
+  }
+  const int u0 = 16*w + 4*j;
+  f32x4 bs[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bs[b][g] = bias ? bias[(long long)grp*4*LH + g*LH + u0 + b] : 0.f;
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < LC*HROW; i += 512) hbuf[0][i] = 0;
+  const bool rev = (reverse_mask >> grp) & 1;
+  const int t_first = rev ? T - 1 : 0, t_inc = rev ? -1 : 1;
+  const float* gin = gates_in + chain*T*4*LH + 4*u0;
+  float* yrow = y + (long long)(live ? cl : per_group - 1)*T*y_ld + grp*y_goff + u0;
+  f32x4 gnext[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    gnext[b] = *reinterpret_cast<const f32x4*>(gin + (long long)t_first*4*LH + 4*b);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int tt = t_first + t*t_inc;
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = gnext[b] + bs[b];
+    if (t + 1 < T) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        gnext[b] = *reinterpret_cast<const f32x4*>(gin + (long long)(tt + t_inc)*4*LH + 4*b);
+    }
+    const uint16_t* hb = hbuf[t & 1] + n*HROW + 8*j;
+#pragma unroll
+    for (int kq = 0; kq < LH/32; ++kq) {
+      const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hb + 32*kq);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[b][kq], hv, acc[b], 0, 0, 0);
+    }
+    f32x4 hn, cn;
+    f32x4 a[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float ig = sigm(acc[b][0]), fg = sigm(acc[b][1]);
+      const float gg = tanh_fast(acc[b][2]), og = sigm(acc[b][3]);
+      c[b] = fg*c[b] + ig*gg;
+      cn[b] = c[b];
+      hn[b] = og*tanh_fast(c[b]);
+      a[b] = f32x4{ig, fg, gg, og};
+    }
+    *reinterpret_cast<uint2*>(hbuf[(t + 1) & 1] + n*HROW + u0) =
+        make_uint2(pack2(hn[0], hn[1]), pack2(hn[2], hn[3]));
+    if (live) {
+      const long long step = chain*T + t;
+      *reinterpret_cast<f32x4*>(yrow + tt*y_ld) = hn;
+      if (act) {
+        *reinterpret_cast<f32x4*>(cs + step*LH + u0) = cn;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          *reinterpret_cast<f32x4*>(act + step*4*LH + 4*(u0 + b)) = a[b];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(512) void lstm_tile_bwd_bf16_kernel(const float* __restrict__ act,
+                                                                 const float* __restrict__ cs,
+                                                                 const float* __restrict__ w_hh,
+                                                                 const float* __restrict__ dy,
+                                                                 float* __restrict__ dgates,
+                                                                 int per_group, int T,
+                                                                 int reverse_mask, long long dy_ld,
+                                                                 long long dy_goff) {
+  __shared__ __attribute__((aligned(16))) uint16_t gbuf[2][LC*GROW];
+  const int tiles = (per_group + LC - 1)/LC;
+  const int grp = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, j = lane >> 4;
+  const int cl = tile*LC + n;
+  const bool live = cl < per_group;
+  const long long chain = (long long)grp*per_group + (live ? cl : per_group - 1);
+  w_hh += (long long)grp*4*LH*LH;
+  // A[m][k] = W_hh[torch row of k][16 w + m], k = 4 unit' + gate = 32 kq + 8 (lane >> 4) + i:
+  // unit' = 8 kq + 2 (lane >> 4) + (i >> 2), gate = i & 3
+  bf16x8 wf[4*LH/32];
+#pragma unroll
+  for (int kq = 0; kq < 4*LH/32; ++kq) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int unit = 8*kq + 2*(lane >> 4) + (i >> 2), gate = i & 3;
+      v[i] = w_hh[(long long)(gate*LH + unit)*LH + 16*w + (lane & 15)];
+    }
+    uint4 q;
+    q.x = pack2(v[0], v[1]); q.y = pack2(v[2], v[3]); q.z = pack2(v[4], v[5]); q.w = pack2(v[6], v[7]);
+    wf[kq] = __builtin_bit_cast(bf16x8, q);
+  }
+  const int u0 = 16*w + 4*j;
+  f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dc = {0.f, 0.f, 0.f, 0.f};
+  const bool rev = (reverse_mask >> grp) & 1;
+  const float* dyrow = dy + (long long)(live ? cl : per_group - 1)*T*dy_ld + grp*dy_goff + u0;
+  for (int t = T - 1; t >= 0; --t) {
+    const long long step = chain*T + t;
+    const int tt = rev ? T - 1 - t : t;
+    f32x4 a[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) a[b] = *reinterpret_cast<const f32x4*>(act + step*4*LH + 4*(u0 + b));
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(cs + step*LH + u0);
+    f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+    if (t > 0) cp = *reinterpret_cast<const f32x4*>(cs + (step - 1)*LH + u0);
+    const f32x4 dyv = *reinterpret_cast<const f32x4*>(dyrow + tt*dy_ld);
+    f32x4 d[4];                                   // d[b] = the four gate gradients of unit u0 + b
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float ig = a[b][0], fg = a[b][1], gg = a[b][2], og = a[b][3];
+      const float tc = tanh_fast(cv[b]);
+      const float dht = dh[b] + dyv[b];
+      const float dct = dc[b] + dht*og*(1.f - tc*tc);
+      d[b] = f32x4{dct*gg*ig*(1.f - ig), dct*cp[b]*fg*(1.f - fg), dct*ig*(1.f - gg*gg),
+                   dht*tc*og*(1.f - og)};
+      dc[b] = dct*fg;
+    }
+    // k = 4 (u0 + b) + g: 16 consecutive bf16 of this chain's row
+    uint16_t* gw = gbuf[t & 1] + n*GROW + 4*u0;
+    *reinterpret_cast<uint4*>(gw) = make_uint4(pack2(d[0][0], d[0][1]), pack2(d[0][2], d[0][3]),
+                                               pack2(d[1][0], d[1][1]), pack2(d[1][2], d[1][3]));
+    *reinterpret_cast<uint4*>(gw + 8) = make_uint4(pack2(d[2][0], d[2][1]), pack2(d[2][2], d[2][3]),
+                                                   pack2(d[3][0], d[3][1]), pack2(d[3][2], d[3][3]));
+    if (live) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        *reinterpret_cast<f32x4*>(dgates + (chain*T + tt)*4*LH + 4*(u0 + b)) = d[b];
+    }
+    __syncthreads();
+    if (t == 0) break;
+    f32x4 p[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const uint16_t* gr = gbuf[t & 1] + n*GROW + 8*j;
+#pragma unroll
+    for (int kq = 0; kq < 4*LH/32; ++kq) {
+      const bf16x8 gv = *reinterpret_cast<const bf16x8*>(gr + 32*kq);
+      p[kq & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kq], gv, p[kq & 1], 0, 0, 0);
+    }
+    dh = p[0] + p[1];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -230,11 +422,16 @@ int brv_lstm_tile_supported(int64_t H) { return H == LH ? 1 : 0; }
 
 int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float* bias, float* y,
                           float* act, float* cs, int64_t B, int64_t T, int64_t H, int64_t groups,
-                          int64_t reverse_mask, int64_t y_ld, int64_t y_group_offset,
+                          int64_t reverse_mask, int64_t y_ld, int64_t y_group_offset, int lowp,
                           brv_stream_t stream) {
   if (H != LH || B < 1 || T < 1 || groups < 1 || groups > 30 || B % groups) return -1;
   const int per_group = (int)(B/groups);
   const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
+  if (lowp)
+    hipLaunchKernelGGL(lstm_tile_fwd_bf16_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream,
+                       gates_in, w_hh, bias, y, act, cs, per_group, (int)T, (int)reverse_mask,
+                       (long long)y_ld, (long long)y_group_offset);
+  else
   hipLaunchKernelGGL(lstm_tile_fwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, gates_in,
                      w_hh, bias, y, act, cs, per_group, (int)T, (int)reverse_mask, (long long)y_ld,
                      (long long)y_group_offset);
@@ -243,11 +440,16 @@ int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float*
 
 int brv_lstm_tile_backward(const float* act, const float* cs, const float* w_hh, const float* dy,
                            float* dgates, int64_t B, int64_t T, int64_t H, int64_t groups,
-                           int64_t reverse_mask, int64_t dy_ld, int64_t dy_group_offset,
+                           int64_t reverse_mask, int64_t dy_ld, int64_t dy_group_offset, int lowp,
                            brv_stream_t stream) {
   if (H != LH || B < 1 || T < 1 || groups < 1 || groups > 30 || B % groups) return -1;
   const int per_group = (int)(B/groups);
   const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
+  if (lowp)
+    hipLaunchKernelGGL(lstm_tile_bwd_bf16_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, act,
+                       cs, w_hh, dy, dgates, per_group, (int)T, (int)reverse_mask, (long long)dy_ld,
+                       (long long)dy_group_offset);
+  else
   hipLaunchKernelGGL(lstm_tile_bwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, act, cs,
                      w_hh, dy, dgates, per_group, (int)T, (int)reverse_mask, (long long)dy_ld,
                      (long long)dy_group_offset);

@@ -444,7 +444,7 @@ class _LSTMFunction(torch.autograd.Function):
         cs = torch.empty(G, B, T, H, dtype=torch.float32, device=x.device)
         fn, name = (lib.brv_lstm_tile_forward, 'brv_lstm_tile_forward') if tiled else \
             (lib.brv_lstm_recurrent_forward, 'brv_lstm_recurrent_forward')
-        extra = (0, H, B*T*H) if tiled else ()        # no reversed group, plain (G, B, T, H) output
+        extra = (0, H, B*T*H, int(lowp)) if tiled else ()   # no reversed group, (G, B, T, H) output
         hip.check(fn(hip.ptr(gates), hip.ptr(w_hh), hip.ptr(bias), hip.ptr(y), hip.ptr(act),
                      hip.ptr(cs), G*B, T, H, G, *extra, hip.stream()), name)
         ctx.save_for_backward(x, w_ih, w_hh, y, act, cs)
@@ -461,7 +461,7 @@ class _LSTMFunction(torch.autograd.Function):
         dg = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
         fn, name = (lib.brv_lstm_tile_backward, 'brv_lstm_tile_backward') if ctx.tiled else \
             (lib.brv_lstm_recurrent_backward, 'brv_lstm_recurrent_backward')
-        extra = (0, H, B*T*H) if ctx.tiled else ()
+        extra = (0, H, B*T*H, int(lowp)) if ctx.tiled else ()
         hip.check(fn(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh), hip.ptr(dy), hip.ptr(dg), G*B, T, H,
                      G, *extra, hip.stream()), name)
         BT = B*T

@@ -273,7 +273,7 @@ class _BiLSTMFn(torch.autograd.Function):
         act, cs = T._empty(2, N, S, 4*H, like=x), T._empty(2, N, S, H, like=x)
         hip.check(lib.brv_lstm_tile_forward(hip.ptr(gates), hip.ptr(w_hh), hip.ptr(bias), hip.ptr(y),
                                             hip.ptr(act), hip.ptr(cs), 2*N, S, H, 2, 2, 2*H, H,
-                                            hip.stream()), 'brv_lstm_tile_forward')
+                                            int(lowp), hip.stream()), 'brv_lstm_tile_forward')
         ctx.save_for_backward(x, w_ih, w_hh, y, act, cs)
         return y
 
@@ -287,7 +287,8 @@ class _BiLSTMFn(torch.autograd.Function):
         dy = dy.contiguous()
         dg = T._empty(2, N, S, 4*H, like=x)
         hip.check(lib.brv_lstm_tile_backward(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh), hip.ptr(dy),
-                                             hip.ptr(dg), 2*N, S, H, 2, 2, 2*H, H, hip.stream()),
+                                             hip.ptr(dg), 2*N, S, H, 2, 2, 2*H, H, int(lowp),
+                                             hip.stream()),
                   'brv_lstm_tile_backward')
         dx = torch.empty_like(x)                      # sum over both directions: dg_g @ W_ih_g
         _gemm(dg, w_ih, dx, 1, NS, I, 4*H, 4*H, I, I, kbatch=2, a_kbs=NS*4*H, b_kbs=4*H*I,

@@ -339,15 +339,17 @@ int brv_causal_groupnorm_backward(const float* x, const float* dy, const float* 
  * flipped copies). y / dy element (group g, chain c of the group, frame t, unit u) lives at
  * g*group_offset + (c*T + t)*ld + u: ld = H, group_offset = chains_per_group*T*H is the plain
  * (groups, chains, T, H) layout; ld = 2H, group_offset = H writes both directions straight into
- * nn.LSTM's (chains, T, 2H) output. */
+ * nn.LSTM's (chains, T, 2H) output. lowp != 0 (use_amp): W_hh and the recurrent operand (h or the
+ * gate gradients) are rounded to bf16 for the MFMA; accumulation, cell state, gate arithmetic and
+ * every tensor in memory stay fp32. */
 int brv_lstm_tile_supported(int64_t H);
 int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float* bias, float* y,
                           float* act, float* cs, int64_t B, int64_t T, int64_t H, int64_t groups,
-                          int64_t reverse_mask, int64_t y_ld, int64_t y_group_offset,
+                          int64_t reverse_mask, int64_t y_ld, int64_t y_group_offset, int lowp,
                           brv_stream_t stream);
 int brv_lstm_tile_backward(const float* act, const float* cs, const float* w_hh, const float* dy,
                            float* dgates, int64_t B, int64_t T, int64_t H, int64_t groups,
-                           int64_t reverse_mask, int64_t dy_ld, int64_t dy_group_offset,
+                           int64_t reverse_mask, int64_t dy_ld, int64_t dy_group_offset, int lowp,
                            brv_stream_t stream);
 
 /* ---- TF-GridNet row operators (models/tfgridnet/tfgridnet.py). rownorm: layer normalisation of

@@ -1495,3 +1495,17 @@ def test_lstm_tiled_kernels_match_torch():
     assert rel(xd.grad, x.grad) <= 1e-4
     for (n, p), q in zip(ref.named_parameters(), dut.parameters()):
         assert rel(q.grad, p.grad) <= 1e-4, (n, rel(q.grad, p.grad))
+    # use_amp: bf16 operands on the MFMA (projections and recurrence), fp32 state and accumulation
+    from brever_amd.models.dccrn import _AMP
+    dut.zero_grad()
+    xa = x.detach().to(dev).requires_grad_(True)
+    _AMP['on'] = True
+    try:
+        ya = _bilstm(xa, dut)
+        ya.backward(gy2.to(dev))
+    finally:
+        _AMP['on'] = False
+    assert 0 < rel(ya, y.detach()) <= 2e-2, rel(ya, y.detach())
+    assert rel(xa.grad, x.grad) <= 3e-2, rel(xa.grad, x.grad)
+    for (n, p), q in zip(ref.named_parameters(), dut.parameters()):
+        assert rel(q.grad, p.grad) <= 3e-2, (n, rel(q.grad, p.grad))
