@@ -1509,3 +1509,27 @@ def test_lstm_tiled_kernels_match_torch():
     assert rel(xa.grad, x.grad) <= 3e-2, rel(xa.grad, x.grad)
     for (n, p), q in zip(ref.named_parameters(), dut.parameters()):
         assert rel(q.grad, p.grad) <= 3e-2, (n, rel(q.grad, p.grad))
+
+
+@pytest.mark.gpu
+def test_entry_points_tfgridnet(tmp_path):
+    """TF-GridNet (narrow configuration) through init -> train -> test on synthetic mixtures."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
+                                    text=True, cwd=root)
+    out = run('scripts/init_model.py', 'tfgridnet', '--models-dir', str(tmp_path),
+              '--n_layers', '1', '--lstm_hidden_units', '16', '--emb_dim', '8', '--attn_n_head', '2',
+              '--trainer_epochs', '1', '--trainer_val_period', '1',
+              '--trainer_batch_size', '4', '--trainer_preload', 'true', '--trainer_workers', '0',
+              '--train-path', 'synthetic:8:0.5', '--val-path', 'synthetic:4:0.5')
+    assert out.returncode == 0, out.stderr
+    model_dir = os.path.join(str(tmp_path), os.listdir(tmp_path)[0])
+    out = run('scripts/train_model.py', model_dir)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    assert np.isfinite(losses['train_loss']).all()
+    out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:3:0.5')
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert np.isfinite(np.load(os.path.join(model_dir, 'scores.npz'))['scores']).all()
