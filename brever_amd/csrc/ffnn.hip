@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void fbe_power_kernel(const float2* spec, floa
 // mode 1: log(x + eps); mode 2: x^(1/3)                      (features.py:194-198)
 __global__ __launch_bounds__(256) void compress_kernel(const float* x, float* out, long long n,
                                                        int mode, float eps) {
-  GRID_STRIDE(i, n) out[i] = mode == 1 ? logf(x[i] + eps) : (mode == 2 ? cbrtf(x[i]) : x[i]);
+  GRID_STRIDE(i, n)
+    out[i] = mode == 1 ? logf(x[i] + eps) : (mode == 2 ? cbrtf(x[i]) : (mode == 3 ? sqrtf(x[i]) : x[i]));
 }
 // binaural cues per time-frequency unit of a 2-channel spectrum (features.py:222-262):
 // mode 0: ILD = 20 log10((|X_R| + eps)/(|X_L| + eps)); mode 1: IPD = angle(X_R) - angle(X_L)
@@ -54,6 +55,35 @@ __global__ __launch_bounds__(256) void binaural_kernel(const float2* spec, float
       out[idx] = 20.f*log10f((sqrtf(r.x*r.x + r.y*r.y) + eps)/(sqrtf(l.x*l.x + l.y*l.y) + eps));
     else
       out[idx] = atan2f(r.y, r.x) - atan2f(l.y, l.x);
+  }
+}
+// Interaural coherence per time-frequency unit (features.py:263-293): exponentially weighted
+// auto- and cross-power spectra along the frames, phi[t] = (1 - alpha) x[t] + alpha phi[t-1]
+// (torchaudio.functional.lfilter with a = [1, -alpha], b = [1 - alpha, 0], whose default
+// clamp=True limits every OUTPUT sample to [-1, 1] while the recursion runs on the unclamped
+// state), then |phi_lr|^2 / (phi_ll phi_rr). One thread per (item, bin) walks the frames.
+__global__ __launch_bounds__(256) void ic_kernel(const float2* spec, float* out, int bins, int F,
+                                                 long long total, float alpha) {
+  GRID_STRIDE(idx, total) {                       // idx over (b, bin)
+    const long long b = idx / bins; const int k = (int)(idx % bins);
+    const float2* l = spec + ((b*2)*bins + k)*(long long)F;
+    const float2* r = spec + ((b*2 + 1)*bins + k)*(long long)F;
+    float* o = out + idx*F;
+    float pll = 0.f, prr = 0.f, pre = 0.f, pim = 0.f;
+    const float beta = 1.f - alpha;
+    for (int t = 0; t < F; ++t) {
+      const float2 a = l[t], c = r[t];
+      // x_lr = |L||R| exp(j(angle L - angle R)) = L conj(R)
+      pll = beta*(a.x*a.x + a.y*a.y) + alpha*pll;
+      prr = beta*(c.x*c.x + c.y*c.y) + alpha*prr;
+      pre = beta*(a.x*c.x + a.y*c.y) + alpha*pre;
+      pim = beta*(a.y*c.x - a.x*c.y) + alpha*pim;
+      const float cl = fminf(fmaxf(pll, -1.f), 1.f), cr = fminf(fmaxf(prr, -1.f), 1.f);
+      const float ce = fminf(fmaxf(pre, -1.f), 1.f), ci = fminf(fmaxf(pim, -1.f), 1.f);
+      // the reference takes sqrt(re^2 + im^2) and squares it again
+      const float mag = sqrtf(ce*ce + ci*ci);
+      o[t] = mag*mag/(cl*cr);
+    }
   }
 }
 // x[b][m][t] /= sum_m x[b][m][t] + eps                      (features.py:190-191, 'pdf')
@@ -201,7 +231,7 @@ int brv_fbe_power(const float* spec, float* out, int64_t B, int64_t C, int64_t n
   return 0;
 }
 int brv_compress(const float* x, float* out, int64_t n, int mode, float eps, brv_stream_t stream) {
-  if (n < 1 || mode < 0 || mode > 2) return -1;
+  if (n < 1 || mode < 0 || mode > 3) return -1;
   hipLaunchKernelGGL(compress_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, x, out,
                      (long long)n, mode, eps);
   FF_OK(hipGetLastError());
@@ -212,6 +242,14 @@ int brv_binaural(const float* spec, float* out, int64_t B, int64_t n, int mode, 
   if (B < 1 || n < 1 || mode < 0 || mode > 1) return -1;
   hipLaunchKernelGGL(binaural_kernel, flat_grid(B*n), dim3(256), 0, (hipStream_t)stream,
                      (const float2*)spec, out, (long long)n, (long long)(B*n), mode, eps);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_interaural_coherence(const float* spec, float* out, int64_t B, int64_t bins, int64_t F,
+                             float alpha, brv_stream_t stream) {
+  if (B < 1 || bins < 1 || F < 1) return -1;
+  hipLaunchKernelGGL(ic_kernel, flat_grid(B*bins), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)spec, out, (int)bins, (int)F, (long long)(B*bins), alpha);
   FF_OK(hipGetLastError());
   return 0;
 }

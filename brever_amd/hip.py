@@ -92,6 +92,7 @@ SIGNATURES = {
                          ctypes.c_int, _c_ptr]),
     'brv_fbe_power': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_compress': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.c_int, _c_f32, _c_ptr]),
+    'brv_interaural_coherence': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_f32, _c_ptr]),
     'brv_binaural': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, ctypes.c_int, _c_f32, _c_ptr]),
     'brv_col_normalize': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_i64, _c_f32, _c_ptr]),
     'brv_deltas': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),

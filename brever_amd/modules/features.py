@@ -40,8 +40,6 @@ class FeatureExtractor:
         for f in self.features:
             if f not in self._known:
                 raise ValueError(f'unrecognized feature, got {f}')
-            if f == 'ic':
-                raise NotImplementedError('feature ic is not built on the HIP path')
 
     def _n(self, feature):
         # the reference's table lists 13 for the DCT features although they come with their
@@ -75,7 +73,7 @@ class FeatureExtractor:
         elif feature in self._fbe_family:
             out = self.fbe(x, *self._fbe_family[feature])
         elif feature == 'ic':
-            raise NotImplementedError('feature ic is not built on the HIP path')
+            out = self.ic(x)
         else:
             raise ValueError(f'unrecognized feature, got {feature}')
         return out.squeeze(0) if unbatched else out
@@ -91,6 +89,24 @@ class FeatureExtractor:
         hip.check(hip.lib().brv_binaural(hip.ptr(spec), hip.ptr(cue), B, bins*F, mode, float(eps),
                                          hip.stream()), 'brv_binaural')
         return self.mel_fb(cue)
+
+    def ic(self, x, tau=10e-3):
+        """Interaural coherence (features.py:263-293) of (B, 2, bins, frames) complex ->
+        (B, n_filters, frames)."""
+        hip.require_device(x)
+        lib = hip.lib()
+        B, C, bins, F = x.shape
+        if C != 2:
+            raise ValueError(f'binaural features need 2 channels, got {C}')
+        alpha = math.exp(-self.hop_length/(tau*self.fs))
+        spec = torch.view_as_real(x.to(torch.complex64).contiguous())
+        coh = torch.empty(B, bins, F, dtype=torch.float32, device=x.device)
+        hip.check(lib.brv_interaural_coherence(hip.ptr(spec), hip.ptr(coh), B, bins, F, alpha,
+                                               hip.stream()), 'brv_interaural_coherence')
+        out = self.mel_fb(coh).contiguous()
+        hip.check(lib.brv_compress(hip.ptr(out), hip.ptr(out), out.numel(), 3, 0.0, hip.stream()),
+                  'brv_compress')
+        return out
 
     def _dct_matrix(self, M, device):
         """Rows 1..n_dct-1 of the orthonormal DCT-II of length M (scipy.fft.dct(type=2,

@@ -185,7 +185,7 @@ int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64
 
 /* ---- FFNN mask model and log-mel features (models/ffnn/ffnn.py:72-203,
  * modules/features.py:142-205); fp32, (B, rows, frames) / complex64 (B, channels, bins*frames)
- * brv_fbe_power: mean over channels of |spec|^2; brv_compress: mode 1 log(x+eps), 2 cube root;
+ * brv_fbe_power: mean over channels of |spec|^2; brv_compress: mode 1 log(x+eps), 2 cube root, 3 square root;
  * brv_irm: (1 + bg/(fg+eps))^-1/2; brv_stack_frames: delayed copies with first-frame fill;
  * brv_static_norm / brv_cumulative_norm: StaticNormalizer / CumulativeNormalizer;
  * brv_relu_dropout_*: ReLU followed by dropout with a caller-supplied keep mask (null: none)
@@ -198,6 +198,12 @@ int brv_compress(const float* x, float* out, int64_t n, int mode, float eps, brv
  * 'pdf' normalisation over the filter axis of (B, M, T), in place; deltas: (B, M, T) ->
  * (B, 3M, T) = [x | first | second difference along the frames, zero left padding] (the
  * delta / double-delta rows of the mfcc features; the DCT itself is a brv_matmul_f32). */
+/* Interaural coherence (FeatureExtractor.ic, features.py:263-293) of spec (B, 2, bins, F) complex
+ * -> (B, bins, F): first-order recursive smoothing of the auto- / cross-power spectra along the
+ * frames with coefficient alpha (torchaudio lfilter semantics incl. its output clamp to [-1, 1]),
+ * then |phi_lr|^2 / (phi_ll phi_rr); brv_compress mode 3 is the final square root. */
+int brv_interaural_coherence(const float* spec, float* out, int64_t B, int64_t bins, int64_t F,
+                             float alpha, brv_stream_t stream);
 int brv_binaural(const float* spec, float* out, int64_t B, int64_t n, int mode, float eps,
                  brv_stream_t stream);
 int brv_col_normalize(float* x, int64_t B, int64_t M, int64_t T, float eps, brv_stream_t stream);

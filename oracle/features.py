@@ -39,6 +39,21 @@ def ipd(spec, filters):
     return np.einsum('mk,bkt->bmt', filters, ph[:, 1] - ph[:, 0])
 
 
+def ic(spec, filters, hop_length=256, fs=16e3, tau=10e-3):
+    """Interaural coherence (features.py:263-293). PARITY UNPINNED: the reference calls
+    torchaudio.functional.lfilter (torchaudio 2.1.1, requirements.txt; absent from this image),
+    restated here from its documented behaviour: y[t] = b0 x[t] + b1 x[t-1] - a1 y[t-1] with
+    a = [1, -alpha], b = [1 - alpha, 0], the OUTPUT clamped to [-1, 1] (``clamp=True`` default)."""
+    import scipy.signal
+    alpha = np.exp(-hop_length/(tau*fs))
+    mag, ph = np.abs(spec), np.angle(spec)
+    x_lr = mag[:, 0]*mag[:, 1]*np.exp(1j*(ph[:, 0] - ph[:, 1]))
+    chans = np.stack([mag[:, 0]**2, mag[:, 1]**2, x_lr.real, x_lr.imag])
+    phi = np.clip(scipy.signal.lfilter([1 - alpha, 0.0], [1.0, -alpha], chans, axis=-1), -1.0, 1.0)
+    coh = (phi[2]**2 + phi[3]**2)/(phi[0]*phi[1])
+    return np.sqrt(np.einsum('mk,bkt->bmt', filters, coh))
+
+
 FEATURES = {
     'fbe': lambda s, f: fbe(s, f), 'logfbe': lambda s, f: fbe(s, f, compression='log'),
     'cubicfbe': lambda s, f: fbe(s, f, compression='cubic'),

@@ -615,8 +615,6 @@ def test_ffnn_matches_reference(golden_dir):
     for _ in range(20):
         l1 = float(net.train_step(batch, lengths, False, scaler))
     assert l1 < l0
-    with pytest.raises(NotImplementedError):
-        FFNN(features={'ic'})
 
 
 @pytest.mark.gpu
@@ -1090,7 +1088,7 @@ def test_entry_points_sgmse(tmp_path):
 
 @pytest.mark.gpu
 def test_feature_extractor_matches_reference(golden_dir):
-    """Every FeatureExtractor feature except 'ic' (filterbank energies, 'pdf' normalisation,
+    """Every FeatureExtractor feature (filterbank energies, 'pdf' normalisation,
     log / cubic compression, DCT cepstra with delta rows, ILD, IPD) vs the reference goldens,
     batched one by one and concatenated on an unbatched item (fp32: 2e-4 of the feature's
     range; the cepstral rows amplify the log's rounding: 1e-3)."""
@@ -1113,10 +1111,23 @@ def test_feature_extractor_matches_reference(golden_dir):
     assert allf.shape == want.shape and fx.n_features == int(g['n_features'])
     assert float((allf - want).abs().max()) <= 1e-3*float(want.abs().max())
     assert fx.indices['ild'] == (64*3 + 39*1, 64*4 + 39*1)       # sorted names, reference layout
-    with pytest.raises(NotImplementedError):
-        FeatureExtractor({'ic'}, mel)
     with pytest.raises(ValueError):
         FeatureExtractor({'nope'}, mel)
+    # interaural coherence: no reference golden (torchaudio is absent from the image: parity
+    # unpinned), checked against the oracle's restatement of lfilter incl. its output clamp, on
+    # the golden spectrum as it is (powers > 1: clamped) and scaled down (unclamped); identical
+    # channels are fully coherent
+    from oracle import features as of
+    filt = mel.filters.double().numpy()
+    for scale in (1.0, 0.02):
+        sp = spec*scale
+        got = FeatureExtractor({'ic'}, mel).calc_feature(sp, 'ic').cpu().numpy()
+        want = of.ic(sp.cpu().numpy().astype(np.complex128), filt)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-4*np.abs(want).max(), (scale, np.abs(got - want).max())
+    same = torch.stack([spec[:, 0], spec[:, 0]], dim=1)*0.02
+    one = FeatureExtractor({'ic'}, mel).calc_feature(same, 'ic').cpu()
+    assert torch.allclose(one, torch.ones_like(one), atol=1e-4)
 
 
 @pytest.mark.gpu
