@@ -65,18 +65,21 @@ class GridNetV2Block(_ParamOnly):
     def __init__(self, emb_dim, emb_ks, emb_hs, n_freqs, hidden_channels, n_head=4,
                  approx_qk_dim=512, activation='PReLU', eps=1e-5):
         super().__init__()
-        if emb_ks != emb_hs:
-            raise NotImplementedError('overlapping sub-band / sub-frame windows (emb_ks != emb_hs) '
-                                      'are not built on the HIP path yet')
         in_channels = emb_dim*emb_ks
         self.intra_norm = nn.LayerNorm(emb_dim, eps=eps)
         self.intra_rnn = nn.LSTM(in_channels, hidden_channels, 1, batch_first=True,
                                  bidirectional=True)
-        self.intra_linear = nn.Linear(hidden_channels*2, in_channels)
+        if emb_ks == emb_hs:
+            self.intra_linear = nn.Linear(hidden_channels*2, in_channels)
+        else:
+            self.intra_linear = nn.ConvTranspose1d(hidden_channels*2, emb_dim, emb_ks, stride=emb_hs)
         self.inter_norm = nn.LayerNorm(emb_dim, eps=eps)
         self.inter_rnn = nn.LSTM(in_channels, hidden_channels, 1, batch_first=True,
                                  bidirectional=True)
-        self.inter_linear = nn.Linear(hidden_channels*2, in_channels)
+        if emb_ks == emb_hs:
+            self.inter_linear = nn.Linear(hidden_channels*2, in_channels)
+        else:
+            self.inter_linear = nn.ConvTranspose1d(hidden_channels*2, emb_dim, emb_ks, stride=emb_hs)
         E = math.ceil(approx_qk_dim*1.0/n_freqs)
         assert emb_dim % n_head == 0
         self.attn_conv_Q = nn.Conv2d(emb_dim, n_head*E, 1)
@@ -308,6 +311,55 @@ class _BiLSTMFn(torch.autograd.Function):
         return dx, dw_ih, dw_hh, db, db.clone()
 
 
+class _WindowFn(torch.autograd.Function):
+    """F.unfold of (N, C, S) with windows of ``ks`` every ``hs`` along S -> (N, C*ks, n)
+    (``fold`` False: brv_im2col, gradient brv_col2im) or its adjoint, the overlap-add of
+    (N, C*ks, n) windows onto (N, C, S) plus a per-channel bias (``fold`` True: what a
+    ConvTranspose1d does after its channel product)."""
+
+    @staticmethod
+    def _geom(C, S, ks, hs):
+        return (C, S, 1, ks, 1, hs, 1, 0, 0, (S - ks)//hs + 1, 1)
+
+    @staticmethod
+    def _unfold(x, C, S, ks, hs):
+        N = x.shape[0]
+        n = (S - ks)//hs + 1
+        col = T._empty(N, C*ks, n, like=x)
+        hip.check(hip.lib().brv_im2col(hip.ptr(x), hip.ptr(col), N, *_WindowFn._geom(C, S, ks, hs),
+                                       hip.stream()), 'brv_im2col')
+        return col
+
+    @staticmethod
+    def _fold(col, bias, C, S, ks, hs):
+        N = col.shape[0]
+        out = T._empty(N, C, S, like=col)
+        hip.check(hip.lib().brv_col2im(hip.ptr(col), hip.ptr(bias), hip.ptr(out), N,
+                                       *_WindowFn._geom(C, S, ks, hs), hip.stream()), 'brv_col2im')
+        return out
+
+    @staticmethod
+    def forward(ctx, x, bias, C, S, ks, hs, fold):
+        ctx.cfg = (C, S, ks, hs, fold, bias is not None)
+        x = x.contiguous()
+        if fold:
+            return _WindowFn._fold(x, bias.contiguous() if bias is not None else None, C, S, ks, hs)
+        return _WindowFn._unfold(x, C, S, ks, hs)
+
+    @staticmethod
+    def backward(ctx, g):
+        C, S, ks, hs, fold, has_bias = ctx.cfg
+        g = g.contiguous()
+        if not fold:
+            return _WindowFn._fold(g, None, C, S, ks, hs), None, None, None, None, None, None
+        db = None
+        if has_bias:
+            db = T._empty(C, like=g)
+            hip.check(hip.lib().brv_row_sum(hip.ptr(g), hip.ptr(db), g.shape[0], C, S, hip.stream()),
+                      'brv_row_sum')
+        return _WindowFn._unfold(g, C, S, ks, hs), db, None, None, None, None, None
+
+
 def _add(a, b):
     return T.AxpbyFn.apply(a, 1.0, b, 1.0)
 
@@ -386,6 +438,25 @@ class TFGridNet(BreverBaseModel):
                              Tn, norm.eps)
         return y.view(B*H, Tn, E*Fq)
 
+    def _grid_rnn(self, x, norm, rnn, linear, ks, hs):
+        """x (B, A, S, C): layer norm over C, windows of ``ks`` every ``hs`` along S as LSTM
+        steps, bidirectional LSTM, back to (B, A, S, C) (tfgridnet.py:268-313)."""
+        B, A, S, C = x.shape
+        h = self._layer_norm(x, norm)
+        if ks == hs:                                   # disjoint windows: plain views
+            h = _bilstm(h.view(B*A, S//ks, ks*C), rnn)
+            return _linear(h, linear).view(B, A, S, C)
+        # overlapping windows: unfold (feature = channel*ks + offset), transposed convolution =
+        # channel product + overlap-add
+        hc = h.view(B*A, S, C).transpose(1, 2)                               # (BA, C, S)
+        col = _WindowFn.apply(hc, None, C, S, ks, hs, False)                 # (BA, C*ks, n)
+        h = _bilstm(col.transpose(1, 2).contiguous(), rnn)                   # (BA, n, 2H)
+        w = linear.weight.reshape(linear.weight.shape[0], C*ks).t()          # (C*ks, 2H)
+        col = _LinearFn.apply(h.reshape(-1, h.shape[-1]), w, torch.zeros(C*ks, device=x.device))
+        col = col.view(B*A, -1, C*ks).transpose(1, 2)                        # (BA, C*ks, n)
+        out = _WindowFn.apply(col, linear.bias, C, S, ks, hs, True)          # (BA, C, S)
+        return out.transpose(1, 2).reshape(B, A, S, C)
+
     def _block(self, blk, x):
         """x (B, T, Q, C) channels-last -> same shape (tfgridnet.py:255-353)."""
         B, old_T, old_Q, C = x.shape
@@ -395,14 +466,10 @@ class TFGridNet(BreverBaseModel):
         Qp = math.ceil((old_Q + 2*olp - ks)/hs)*hs + ks
         x = F.pad(x, (0, 0, olp, Qp - old_Q - olp, olp, Tp - old_T - olp))
         # intra-frame (full-band) recurrence along the bands
-        h = self._layer_norm(x, blk.intra_norm).view(B*Tp, Qp//ks, ks*C)
-        h = _linear(_bilstm(h, blk.intra_rnn), blk.intra_linear).view(B, Tp, Qp, C)
-        x = _add(h, x)
+        x = _add(self._grid_rnn(x, blk.intra_norm, blk.intra_rnn, blk.intra_linear, ks, hs), x)
         # sub-band recurrence along the frames
         x = x.transpose(1, 2).contiguous()                                   # (B, Q, T, C)
-        h = self._layer_norm(x, blk.inter_norm).view(B*Qp, Tp//ks, ks*C)
-        h = _linear(_bilstm(h, blk.inter_rnn), blk.inter_linear).view(B, Qp, Tp, C)
-        x = _add(h, x)
+        x = _add(self._grid_rnn(x, blk.inter_norm, blk.inter_rnn, blk.inter_linear, ks, hs), x)
         x = x.transpose(1, 2)[:, olp:olp + old_T, olp:olp + old_Q].contiguous()   # (B, T, Q, C)
         # full-band self-attention across the frames
         q = self._head_norm(_linear(x, blk.attn_conv_Q), blk.attn_norm_Q)

@@ -61,27 +61,41 @@ def _head_norm(x, P, prefix, H, eps):
     return x*gamma + beta
 
 
-def _grid_rnn(x, P, prefix, ks, eps):
+def _grid_rnn(x, P, prefix, ks, eps, hs=None):
+    hs = ks if hs is None else hs
     """Layer norm over channels, groups of ``ks`` neighbours along axis 2 as one LSTM step,
     bidirectional LSTM, linear back to ks*C, residual (tfgridnet.py:268-292 with ks == hs)."""
     B, A, S, C = x.shape
     h = F.layer_norm(x, (C,), P[prefix + 'norm.weight'], P[prefix + 'norm.bias'], eps)
-    h = _bilstm(h.reshape(B*A, S//ks, ks*C), P, prefix + 'rnn.')
-    h = h @ P[prefix + 'linear.weight'].t() + P[prefix + 'linear.bias']
-    return x + h.reshape(B, A, S, C)
+    if ks == hs:
+        h = _bilstm(h.reshape(B*A, S//ks, ks*C), P, prefix + 'rnn.')
+        h = h @ P[prefix + 'linear.weight'].t() + P[prefix + 'linear.bias']
+        return x + h.reshape(B, A, S, C)
+    # overlapping windows (tfgridnet.py:275-291): every window of ks neighbours (stride hs) is
+    # one LSTM step with features ordered channel-major; the ConvTranspose1d spreads each step's
+    # output back over its window and overlapping contributions add
+    win = h.unfold(2, ks, hs)                                   # (B, A, n, C, ks)
+    n = win.shape[2]
+    r = _bilstm(win.reshape(B*A, n, C*ks), P, prefix + 'rnn.')  # (BA, n, 2H)
+    w = P[prefix + 'linear.weight']                             # (2H, C, ks)
+    spread = torch.einsum('bnh,hci->bnci', r, w)
+    out = x.new_zeros(B*A, S, C) + P[prefix + 'linear.bias']
+    for i in range(ks):
+        idx = torch.arange(n)*hs + i
+        out = out.index_add(1, idx, spread[..., i])
+    return x + out.reshape(B, A, S, C)
 
 
 def _block(x, P, prefix, cfg):
     """One GridNetV2Block (tfgridnet.py:255-353) on (B, T, Q, C)."""
     ks, hs, H, eps = cfg['emb_ks'], cfg['emb_hs'], cfg['attn_n_head'], cfg['eps']
-    assert ks == hs
     B, T0, Q0, C = x.shape
     olp = ks - hs
     T = math.ceil((T0 + 2*olp - ks)/hs)*hs + ks
     Q = math.ceil((Q0 + 2*olp - ks)/hs)*hs + ks
     x = F.pad(x, (0, 0, olp, Q - Q0 - olp, olp, T - T0 - olp))
-    x = _grid_rnn(x, P, prefix + 'intra_', ks, eps)                                   # along bands
-    x = _grid_rnn(x.transpose(1, 2), P, prefix + 'inter_', ks, eps).transpose(1, 2)   # along frames
+    x = _grid_rnn(x, P, prefix + 'intra_', ks, eps, hs)                                 # along bands
+    x = _grid_rnn(x.transpose(1, 2), P, prefix + 'inter_', ks, eps, hs).transpose(1, 2)   # along frames
     x = x[:, olp:olp + T0, olp:olp + Q0]
 
     def proj(name):
@@ -156,7 +170,10 @@ def parameter_shapes(cfg):
                 sh[p + part + 'rnn.weight_hh_l0' + d] = (4*Hh, Hh)
                 sh[p + part + 'rnn.bias_ih_l0' + d] = (4*Hh,)
                 sh[p + part + 'rnn.bias_hh_l0' + d] = (4*Hh,)
-            sh[p + part + 'linear.weight'] = (ks*C, 2*Hh); sh[p + part + 'linear.bias'] = (ks*C,)
+            if ks == cfg['emb_hs']:
+                sh[p + part + 'linear.weight'] = (ks*C, 2*Hh); sh[p + part + 'linear.bias'] = (ks*C,)
+            else:
+                sh[p + part + 'linear.weight'] = (2*Hh, C, ks); sh[p + part + 'linear.bias'] = (C,)
         for name, e in (('Q', E), ('K', E), ('V', C//H)):
             sh[p + f'attn_conv_{name}.weight'] = (H*e, C, 1, 1); sh[p + f'attn_conv_{name}.bias'] = (H*e,)
             sh[p + f'attn_norm_{name}.gamma'] = (1, H, e, 1, Q); sh[p + f'attn_norm_{name}.beta'] = (1, H, e, 1, Q)

@@ -634,6 +634,9 @@ def golden_tfgridnet(out):
                    attn_approx_qk_dim=34, emb_dim=8), 400, 11),
         'b': (dict(n_srcs=2, n_fft=24, stride=8, n_layers=1, lstm_hidden_units=32, attn_n_head=4,
                    attn_approx_qk_dim=20, emb_dim=8, emb_ks=2, emb_hs=2), 333, 12),
+        # overlapping windows: unfold + transposed-convolution branch
+        'c': (dict(n_fft=24, stride=12, n_layers=1, lstm_hidden_units=16, attn_n_head=2,
+                   attn_approx_qk_dim=20, emb_dim=4, emb_ks=4, emb_hs=2), 300, 13),
     }
     for tag, (cfg, L, seed) in cases.items():
         torch.manual_seed(seed)

@@ -1367,7 +1367,7 @@ def test_rownorm_kernels_match_torch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('tag', ['a', 'b'])
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
 def test_tfgridnet_matches_reference(golden_dir, tag):
     """HIP TF-GridNet (RMS normalisation, STFT, conv + group norm, grid blocks: layer norms,
     bidirectional LSTMs in both directions, linear layers, all-head attention, transposed conv,

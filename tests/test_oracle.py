@@ -451,7 +451,7 @@ def test_causal_norm_oracle_matches_reference(golden_dir):
             assert ((got - ref).norm()/ref.norm()).item() <= 1e-5, (tag, key)
 
 
-@pytest.mark.parametrize('tag', ['a', 'b'])
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
 def test_tfgridnet_oracle_matches_reference(golden_dir, tag):
     """oracle.tfgridnet vs the reference TF-GridNet at seeded weights (two narrow configurations:
     one source / two sources with grid padding): output 1e-5, multiresyu loss 1e-5 relative, every
