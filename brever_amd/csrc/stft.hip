@@ -252,7 +252,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const G32 p, int ksplit) 
 // 16x the matrix rate of the fp32 MFMA: these products then run at the speed of their loads.
 constexpr int BKL = 32, LDL = BKL + 8;            // k per tile, bf16 elements per LDS row
 
-template <bool TA, bool TB>
+// VEC: every operand row / column the loader touches is a whole, 16-byte aligned float4 (checked
+// by the host): 4 x 16-byte loads per operand, thread and tile instead of 16 scalar ones -- the
+// instruction stream of the scalar loader, not the MFMA, is what bounds this kernel.
+template <bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit) {
   __shared__ __attribute__((aligned(16))) bf16_t As[BM2][LDL];
   __shared__ __attribute__((aligned(16))) bf16_t Bs[BN2][LDL];
@@ -320,12 +323,57 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
           (unsigned int)f2bf(rb[r].x) | ((unsigned int)f2bf(rb[r].y) << 16);
     }
   };
-  if (t_lo < t_hi) fetch(t_lo);
+  // vector loader: an operand whose k axis is contiguous is cut into (row, 4 k) items, one whose
+  // rows are contiguous into (4 rows, k pair) items -- 4 float4 loads per operand either way
+  float4 va[4], vb[4];
+  auto vfetch1 = [&](const float* X, long long ld, bool kcontig, int r0, int R, int k0, float4* v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = tid + (r >> (kcontig ? 0 : 1))*256;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kcontig) {
+        const int kq = e & 7, row = e >> 3;
+        if (r0 + row < R && k0 + 4*kq < p.K) q = *reinterpret_cast<const float4*>(X + (long long)(r0 + row)*ld + k0 + 4*kq);
+      } else {
+        const int rq = e & 31, kp = e >> 5, k = k0 + 2*kp + (r & 1);
+        if (r0 + 4*rq < R && k < p.K) q = *reinterpret_cast<const float4*>(X + (long long)k*ld + r0 + 4*rq);
+      }
+      v[r] = q;
+    }
+  };
+  auto vstash1 = [&](bf16_t (*S)[LDL], bool kcontig, const float4* v) {
+    if (kcontig) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = tid + r*256, kq = e & 7, row = e >> 3;
+        *reinterpret_cast<uint2*>(&S[row][4*kq]) =
+            make_uint2((unsigned int)f2bf(v[r].x) | ((unsigned int)f2bf(v[r].y) << 16),
+                       (unsigned int)f2bf(v[r].z) | ((unsigned int)f2bf(v[r].w) << 16));
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = tid + h*256, rq = e & 31, kp = e >> 5;
+        const float4 lo = v[2*h], hi = v[2*h + 1];          // k = 2 kp and 2 kp + 1
+        *reinterpret_cast<unsigned int*>(&S[4*rq][2*kp]) = (unsigned int)f2bf(lo.x) | ((unsigned int)f2bf(hi.x) << 16);
+        *reinterpret_cast<unsigned int*>(&S[4*rq + 1][2*kp]) = (unsigned int)f2bf(lo.y) | ((unsigned int)f2bf(hi.y) << 16);
+        *reinterpret_cast<unsigned int*>(&S[4*rq + 2][2*kp]) = (unsigned int)f2bf(lo.z) | ((unsigned int)f2bf(hi.z) << 16);
+        *reinterpret_cast<unsigned int*>(&S[4*rq + 3][2*kp]) = (unsigned int)f2bf(lo.w) | ((unsigned int)f2bf(hi.w) << 16);
+      }
+    }
+  };
+  auto vfetch = [&](long long t) {
+    const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BKL;
+    vfetch1(p.A + (long long)b*p.a_bs + (long long)kb*p.a_kbs, p.lda, !TA, m0, p.M, k0, va);
+    vfetch1(p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs, p.ldb, TB, n0, p.N, k0, vb);
+  };
+  auto vstash = [&]() { vstash1(As, !TA, va); vstash1(Bs, TB, vb); };
+  if (t_lo < t_hi) { if (VEC) vfetch(t_lo); else fetch(t_lo); }
   for (long long t = t_lo; t < t_hi; ++t) {
     __syncthreads();
-    stash();
+    if (VEC) vstash(); else stash();
     __syncthreads();
-    if (t + 1 < t_hi) fetch(t + 1);
+    if (t + 1 < t_hi) { if (VEC) vfetch(t + 1); else fetch(t + 1); }
     const int c = lane & 31, kh = (lane >> 5)*8;
 #pragma unroll
     for (int s = 0; s < BKL/16; ++s) {
@@ -571,14 +619,21 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   const dim3 grid((unsigned)((N + BN2 - 1)/BN2), (unsigned)((M + BM2 - 1)/BM2),
                   (unsigned)(batch*ksplit));
   if (lowp) {
-    if (trans_a && trans_b)
-      hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, p, (int)ksplit);
-    else if (trans_a)
-      hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, p, (int)ksplit);
-    else if (trans_b)
-      hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(256), 0, st, p, (int)ksplit);
-    else
-      hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, p, (int)ksplit);
+    // vector loader: strides, bases and the extent along each operand's contiguous axis are
+    // multiples of 4 floats
+    auto q4 = [](long long v) { return (v & 3) == 0; };
+    const bool vec = q4(lda) && q4(ldb) && q4(a_batch_stride) && q4(b_batch_stride) &&
+                     q4(a_kbatch_stride) && q4(b_kbatch_stride) &&
+                     ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 &&
+                     q4(trans_a ? M : K) && q4(trans_b ? K : N) && !getenv("BRV_GEMM_SCALAR");
+#define BRV_BF16_LAUNCH(TA_, TB_) \
+    do { if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, p, (int)ksplit); \
+         else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, false>), grid, dim3(256), 0, st, p, (int)ksplit); } while (0)
+    if (trans_a && trans_b) BRV_BF16_LAUNCH(true, true);
+    else if (trans_a) BRV_BF16_LAUNCH(true, false);
+    else if (trans_b) BRV_BF16_LAUNCH(false, true);
+    else BRV_BF16_LAUNCH(false, false);
+#undef BRV_BF16_LAUNCH
     return (int)hipGetLastError();
   }
   if (trans_a && trans_b)
