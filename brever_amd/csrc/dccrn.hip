@@ -497,25 +497,60 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* dy, float
 // col[b][(c*kh + i)*kw + j][ho*Wo + wo] = x[b][c][ho*sh - ph + i][wo*sw - pw + j] (0 outside)
 // grid (pixel blocks, C*kh*kw, B): one column-matrix row per blockIdx.y, 32-bit index math,
 // 4 pixels per thread
-__global__ __launch_bounds__(256) void im2col_kernel(const float* x, float* col, ConvGeom g) {
+// ColT = float, or bf16_t for the use_amp path (the column matrix is the largest tensor of a
+// convolution: half the bytes on its way to and from the MFMA product)
+template <typename ColT> __device__ __forceinline__ ColT to_col(float v);
+template <> __device__ __forceinline__ float to_col<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t to_col<bf16_t>(float v) { return f2bf(v); }
+__device__ __forceinline__ float from_col(float v) { return v; }
+__device__ __forceinline__ float from_col(bf16_t v) { return bf2f(v); }
+
+__device__ __forceinline__ void store_col4(float* out, const float4& v) {
+  *reinterpret_cast<float4*>(out) = v;
+}
+__device__ __forceinline__ void store_col4(bf16_t* out, const float4& v) {
+  *reinterpret_cast<uint2*>(out) = make_uint2((unsigned int)f2bf(v.x) | ((unsigned int)f2bf(v.y) << 16),
+                                              (unsigned int)f2bf(v.z) | ((unsigned int)f2bf(v.w) << 16));
+}
+
+template <typename ColT>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* x, ColT* col, ConvGeom g) {
   const int HoWo = g.Ho*g.Wo;
   const int r = blockIdx.y, b = blockIdx.z;
   const int j = r % g.kw, i = (r / g.kw) % g.kh, c = r / (g.kw*g.kh);
   const float* xc = x + (long long)b*g.x_bs + (long long)c*g.H*g.W;
-  float* out = col + ((long long)b*gridDim.y + r)*HoWo;
+  ColT* out = col + ((long long)b*gridDim.y + r)*HoWo;
   const int p0 = (blockIdx.x*256 + threadIdx.x)*4;
+  if (p0 >= HoWo) return;
+  // fast path: unit stride along W, the 4 pixels in one output row and their sources inside the
+  // image (or the whole source row outside it): one 16-byte load (4-byte aligned: legal on
+  // gfx950), one aligned vector store
+  if (g.sw == 1 && (HoWo & 3) == 0) {
+    const int ho = p0 / g.Wo, wo = p0 - ho*g.Wo;
+    const int hi = ho*g.sh - g.ph + i, wi = wo - g.pw + j;
+    if (wo + 3 < g.Wo) {
+      if (hi < 0 || hi >= g.H) { store_col4(out + p0, make_float4(0.f, 0.f, 0.f, 0.f)); return; }
+      if (wi >= 0 && wi + 3 < g.W) {
+        float4 v;
+        __builtin_memcpy(&v, xc + (long long)hi*g.W + wi, 16);
+        store_col4(out + p0, v);
+        return;
+      }
+    }
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int pix = p0 + q;
     if (pix >= HoWo) break;
     const int ho = pix / g.Wo, wo = pix - ho*g.Wo;
     const int hi = ho*g.sh - g.ph + i, wi = wo*g.sw - g.pw + j;
-    out[pix] = (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? xc[hi*g.W + wi] : 0.f;
+    out[pix] = to_col<ColT>((hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? xc[hi*g.W + wi] : 0.f);
   }
 }
 // the adjoint: y[b][c][h][w] = bias[c] + sum over the column entries that im2col filled from it
 // (g.H x g.W is the image, g.Ho x g.Wo the column grid); grid (pixel blocks, C, B)
-__global__ __launch_bounds__(256) void col2im_kernel(const float* col, const float* bias, float* y,
+template <typename ColT>
+__global__ __launch_bounds__(256) void col2im_kernel(const ColT* col, const float* bias, float* y,
                                                      ConvGeom g) {
   const int HoWo = g.Ho*g.Wo, HW = g.H*g.W;
   const int c = blockIdx.y, b = blockIdx.z;
@@ -523,7 +558,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* col, const flo
   if (pix >= HW) return;
   const int h = pix / g.W, w = pix - h*g.W;
   float acc = bias ? bias[c] : 0.f;
-  const float* cb = col + ((long long)b*gridDim.y + c)*g.kh*g.kw*HoWo;
+  const ColT* cb = col + ((long long)b*gridDim.y + c)*g.kh*g.kw*HoWo;
   for (int i = 0; i < g.kh; ++i) {
     const int hn = h + g.ph - i;
     if (hn < 0 || hn % g.sh) continue;
@@ -534,7 +569,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* col, const flo
       if (wn < 0 || wn % g.sw) continue;
       const int wo = wn/g.sw;
       if (wo >= g.Wo) continue;
-      acc += cb[(long long)(i*g.kw + j)*HoWo + ho*g.Wo + wo];
+      acc += from_col(cb[(long long)(i*g.kw + j)*HoWo + ho*g.Wo + wo]);
     }
   }
   y[(long long)b*g.y_bs + (long long)c*HW + pix] = acc;
@@ -897,33 +932,58 @@ int brv_istft_env_divide(const float* dy, const float* window, float* out, int64
   return 0;
 }
 
-int brv_im2col(const float* x, float* col, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
-               int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t Ho, int64_t Wo,
-               brv_stream_t stream) {
+extern "C++" {
+template <typename ColT>
+static int im2col_any(const float* x, ColT* col, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
+                      int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t Ho,
+                      int64_t Wo, brv_stream_t stream) {
   if (B < 1 || C < 1 || Ho < 1 || Wo < 1) return -1;
   ConvGeom g;
   g.B = (int)B; g.Cin = (int)C; g.H = (int)H; g.W = (int)W; g.Cout = 0;
   g.kh = (int)kh; g.kw = (int)kw; g.sh = (int)sh; g.sw = (int)sw; g.ph = (int)ph; g.pw = (int)pw;
   g.Ho = (int)Ho; g.Wo = (int)Wo; g.x_bs = C*H*W; g.y_bs = 0;
   if (C*kh*kw > 65535 || B > 65535 || H*W >= (1LL << 31) || Ho*Wo >= (1LL << 31)) return -2;
-  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((Ho*Wo + 1023)/1024), (unsigned)(C*kh*kw),
-                                         (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, col, g);
+  hipLaunchKernelGGL(im2col_kernel<ColT>, dim3((unsigned)((Ho*Wo + 1023)/1024), (unsigned)(C*kh*kw),
+                                               (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, col, g);
   DC_OK(hipGetLastError());
   return 0;
 }
-int brv_col2im(const float* col, const float* bias, float* y, int64_t B, int64_t C, int64_t H,
-               int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
-               int64_t Ho, int64_t Wo, brv_stream_t stream) {
+template <typename ColT>
+static int col2im_any(const ColT* col, const float* bias, float* y, int64_t B, int64_t C, int64_t H,
+                      int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                      int64_t Ho, int64_t Wo, brv_stream_t stream) {
   if (B < 1 || C < 1 || H < 1 || W < 1) return -1;
   ConvGeom g;
   g.B = (int)B; g.Cin = (int)C; g.H = (int)H; g.W = (int)W; g.Cout = 0;
   g.kh = (int)kh; g.kw = (int)kw; g.sh = (int)sh; g.sw = (int)sw; g.ph = (int)ph; g.pw = (int)pw;
   g.Ho = (int)Ho; g.Wo = (int)Wo; g.x_bs = 0; g.y_bs = C*H*W;
   if (C > 65535 || B > 65535 || H*W >= (1LL << 31) || Ho*Wo >= (1LL << 31)) return -2;
-  hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((H*W + 255)/256), (unsigned)C, (unsigned)B),
+  hipLaunchKernelGGL(col2im_kernel<ColT>, dim3((unsigned)((H*W + 255)/256), (unsigned)C, (unsigned)B),
                      dim3(256), 0, (hipStream_t)stream, col, bias, y, g);
   DC_OK(hipGetLastError());
   return 0;
+}
+}  // extern "C++"
+int brv_im2col(const float* x, float* col, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
+               int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t Ho, int64_t Wo,
+               brv_stream_t stream) {
+  return im2col_any<float>(x, col, B, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo, stream);
+}
+int brv_col2im(const float* col, const float* bias, float* y, int64_t B, int64_t C, int64_t H,
+               int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+               int64_t Ho, int64_t Wo, brv_stream_t stream) {
+  return col2im_any<float>(col, bias, y, B, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo, stream);
+}
+int brv_im2col_bf16(const float* x, void* col, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
+                    int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t Ho,
+                    int64_t Wo, brv_stream_t stream) {
+  return im2col_any<bf16_t>(x, (bf16_t*)col, B, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo, stream);
+}
+int brv_col2im_bf16(const void* col, const float* bias, float* y, int64_t B, int64_t C, int64_t H,
+                    int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                    int64_t Ho, int64_t Wo, brv_stream_t stream) {
+  return col2im_any<bf16_t>((const bf16_t*)col, bias, y, B, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo,
+                            stream);
 }
 int brv_complex_weight_pack(const float* wr, const float* wi, float* wc, int64_t R, int64_t C,
                             float sign, brv_stream_t stream) {

@@ -39,6 +39,7 @@ struct G32 {
   int kbatch; long long a_kbs, b_kbs;
   const float* row_bias; int accumulate;
   int col_bias;            // the bias is per output COLUMN (accumulate == 2 at the C ABI)
+  int b_bf16, d_bf16;      // gemm_bf16 only: operand B / result D are bf16 in memory (strides in elements)
 };
 
 constexpr int TM = 64, TN = 64, TK = 32;
@@ -287,7 +288,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
   auto fetch = [&](long long t) {
     const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BKL;
     const float* A = p.A + (long long)b*p.a_bs + (long long)kb*p.a_kbs;
-    const float* B = p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs;
+    const long long boff = (long long)b*p.b_bs + (long long)kb*p.b_kbs;
+    const float* B = p.B + boff;
+    const bf16_t* Bh = reinterpret_cast<const bf16_t*>(p.B) + boff;
+    auto ldb = [&](long long i) { return p.b_bf16 ? bf2f(Bh[i]) : B[i]; };
 #pragma unroll
     for (int r = 0; r < NP; ++r) {
       int row, kp;
@@ -304,9 +308,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
       v = make_float2(0.f, 0.f);
       if (n < p.N) {
         if (k0 + 2*kp < p.K)
-          v.x = TB ? B[(long long)n*p.ldb + k0 + 2*kp] : B[(long long)(k0 + 2*kp)*p.ldb + n];
+          v.x = ldb(TB ? (long long)n*p.ldb + k0 + 2*kp : (long long)(k0 + 2*kp)*p.ldb + n);
         if (k0 + 2*kp + 1 < p.K)
-          v.y = TB ? B[(long long)n*p.ldb + k0 + 2*kp + 1] : B[(long long)(k0 + 2*kp + 1)*p.ldb + n];
+          v.y = ldb(TB ? (long long)n*p.ldb + k0 + 2*kp + 1 : (long long)(k0 + 2*kp + 1)*p.ldb + n);
       }
       rb[r] = v;
     }
@@ -326,17 +330,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
   // vector loader: an operand whose k axis is contiguous is cut into (row, 4 k) items, one whose
   // rows are contiguous into (4 rows, k pair) items -- 4 float4 loads per operand either way
   float4 va[4], vb[4];
-  auto vfetch1 = [&](const float* X, long long ld, bool kcontig, int r0, int R, int k0, float4* v) {
+  auto ld4 = [&](const float* X, long long i, bool half) {
+    if (!half) return *reinterpret_cast<const float4*>(X + i);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(X) + i);
+    return make_float4(bf2f((bf16_t)(u.x & 0xffffu)), bf2f((bf16_t)(u.x >> 16)),
+                       bf2f((bf16_t)(u.y & 0xffffu)), bf2f((bf16_t)(u.y >> 16)));
+  };
+  auto vfetch1 = [&](const float* X, long long off, long long ld, bool kcontig, int r0, int R, int k0,
+                     float4* v, bool half) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e = tid + (r >> (kcontig ? 0 : 1))*256;
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
       if (kcontig) {
         const int kq = e & 7, row = e >> 3;
-        if (r0 + row < R && k0 + 4*kq < p.K) q = *reinterpret_cast<const float4*>(X + (long long)(r0 + row)*ld + k0 + 4*kq);
+        if (r0 + row < R && k0 + 4*kq < p.K) q = ld4(X, off + (long long)(r0 + row)*ld + k0 + 4*kq, half);
       } else {
         const int rq = e & 31, kp = e >> 5, k = k0 + 2*kp + (r & 1);
-        if (r0 + 4*rq < R && k < p.K) q = *reinterpret_cast<const float4*>(X + (long long)k*ld + r0 + 4*rq);
+        if (r0 + 4*rq < R && k < p.K) q = ld4(X, off + (long long)k*ld + r0 + 4*rq, half);
       }
       v[r] = q;
     }
@@ -364,8 +375,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
   };
   auto vfetch = [&](long long t) {
     const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BKL;
-    vfetch1(p.A + (long long)b*p.a_bs + (long long)kb*p.a_kbs, p.lda, !TA, m0, p.M, k0, va);
-    vfetch1(p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs, p.ldb, TB, n0, p.N, k0, vb);
+    vfetch1(p.A, (long long)b*p.a_bs + (long long)kb*p.a_kbs, p.lda, !TA, m0, p.M, k0, va, false);
+    vfetch1(p.B, (long long)b*p.b_bs + (long long)kb*p.b_kbs, p.ldb, TB, n0, p.N, k0, vb, p.b_bf16 != 0);
   };
   auto vstash = [&]() { vstash1(As, !TA, va); vstash1(Bs, TB, vb); };
   if (t_lo < t_hi) { if (VEC) vfetch(t_lo); else fetch(t_lo); }
@@ -399,6 +410,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
         const int row = m0 + 64*wm + 32*fi + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
         if (row >= p.M) continue;
         float v = acc[fi][fj][i];
+        if (p.d_bf16) {                      // bf16 result (host guarantees ksplit == 1, no accumulate)
+          if (p.row_bias) v += p.row_bias[p.col_bias ? col : row];
+          (reinterpret_cast<bf16_t*>(p.D) + (long long)b*p.d_bs)[(long long)row*p.ldd + col] = f2bf(v);
+          continue;
+        }
         float* d = D + (long long)row*p.ldd + col;
         if (ksplit > 1) {
           if (split == 0 && p.row_bias) v += p.row_bias[p.col_bias ? col : row];
@@ -585,8 +601,9 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
                     int64_t a_batch_stride, int64_t b_batch_stride, int64_t d_batch_stride,
                     int trans_a, int trans_b, int64_t kbatch, int64_t a_kbatch_stride,
                     int64_t b_kbatch_stride, const float* row_bias, int accumulate,
-                    brv_stream_t stream) {
+                    brv_stream_t stream, int flags = 0) {
   if (batch < 1 || M < 1 || N < 1 || K < 1) return -1;
+  if (flags && (!lowp || ((flags & 2) && accumulate == 1))) return -1;
   G32 p; memset(&p, 0, sizeof(p));
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.A = a; p.a_bs = a_batch_stride; p.lda = (int)lda;
@@ -594,6 +611,7 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   p.D = d; p.d_bs = d_batch_stride; p.ldd = (int)ldd;
   p.kbatch = (int)kbatch; p.a_kbs = a_kbatch_stride; p.b_kbs = b_kbatch_stride;
   p.col_bias = accumulate == 2;
+  p.b_bf16 = flags & 1; p.d_bf16 = (flags >> 1) & 1;
   if (accumulate == 2) accumulate = 0;
   p.row_bias = row_bias; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
@@ -601,7 +619,7 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   const long long tiles = ((M + BM2 - 1)/BM2)*((N + BN2 - 1)/BN2)*batch;
   const long long red = (kbatch > 1 ? kbatch : 1)*((K + BK2 - 1)/BK2);
   long long ksplit = 1;
-  if (tiles < 128 && red >= 16) {
+  if (tiles < 128 && red >= 16 && !(flags & 2)) {
     ksplit = 512/tiles;
     if (ksplit > red/4) ksplit = red/4;
     if (ksplit < 1) ksplit = 1;
@@ -624,7 +642,7 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
     auto q4 = [](long long v) { return (v & 3) == 0; };
     const bool vec = q4(lda) && q4(ldb) && q4(a_batch_stride) && q4(b_batch_stride) &&
                      q4(a_kbatch_stride) && q4(b_kbatch_stride) &&
-                     ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 &&
+                     ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & ((flags & 1) ? 7 : 15)) == 0 &&
                      q4(trans_a ? M : K) && q4(trans_b ? K : N) && !getenv("BRV_GEMM_SCALAR");
 #define BRV_BF16_LAUNCH(TA_, TB_) \
     do { if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, p, (int)ksplit); \
@@ -655,6 +673,15 @@ int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_
   return gemm_any(0, a, b, d, batch, M, N, K, lda, ldb, ldd, a_batch_stride, b_batch_stride,
                   d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride, b_kbatch_stride,
                   row_bias, accumulate, stream);
+}
+int brv_gemm_bf16_mixed(const float* a, const void* b, void* d, int64_t batch, int64_t M, int64_t N,
+                        int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
+                        int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                        int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
+                        const float* row_bias, int accumulate, int flags, brv_stream_t stream) {
+  return gemm_any(1, a, (const float*)b, (float*)d, batch, M, N, K, lda, ldb, ldd, a_batch_stride,
+                  b_batch_stride, d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride,
+                  b_kbatch_stride, row_bias, accumulate, stream, flags & 3);
 }
 int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
                   int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,

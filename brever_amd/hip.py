@@ -90,6 +90,9 @@ SIGNATURES = {
     'brv_gemm_bf16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*10
                       + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_ptr,
                          ctypes.c_int, _c_ptr]),
+    'brv_gemm_bf16_mixed': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*10
+                            + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_ptr,
+                               ctypes.c_int, ctypes.c_int, _c_ptr]),
     'brv_fbe_power': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_compress': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, ctypes.c_int, _c_f32, _c_ptr]),
     'brv_interaural_coherence': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_f32, _c_ptr]),
@@ -142,6 +145,8 @@ SIGNATURES = {
     'brv_cplx_moments_backward': (ctypes.c_int, [_c_ptr]*3 + [_c_i64]*3 + [_c_ptr]),
     'brv_im2col': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*12 + [_c_ptr]),
     'brv_col2im': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*12 + [_c_ptr]),
+    'brv_im2col_bf16': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*12 + [_c_ptr]),
+    'brv_col2im_bf16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*12 + [_c_ptr]),
     'brv_complex_weight_pack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_ptr]),
     'brv_complex_weight_unpack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_f32, _c_ptr]),
     'brv_groupnorm_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),

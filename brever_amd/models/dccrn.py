@@ -131,7 +131,16 @@ _AMP = {'on': False}      # set by DCCRN.loss / _enhance around the forward pass
 def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, trans_b=0,
           kbatch=1, a_kbs=0, b_kbs=0, bias=None, lowp=False):
     """fp32 matrices in HBM; ``lowp``: operands rounded to bf16 inside the kernel, fp32
-    accumulation (``use_amp``), else the exact-fp32 MFMA."""
+    accumulation (``use_amp``), else the exact-fp32 MFMA. A bf16 ``b`` or ``d`` tensor (the
+    column matrices of the use_amp convolutions) selects ``brv_gemm_bf16_mixed``."""
+    flags = int(b.dtype == torch.bfloat16) | int(d.dtype == torch.bfloat16) << 1
+    if flags:
+        assert lowp
+        hip.check(hip.lib().brv_gemm_bf16_mixed(
+            hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
+            trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, flags, hip.stream()),
+            'brv_gemm_bf16_mixed')
+        return
     fn = hip.lib().brv_gemm_bf16 if lowp else hip.lib().brv_gemm_f32
     hip.check(fn(
         hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
@@ -139,12 +148,16 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, t
         'brv_gemm_bf16' if lowp else 'brv_gemm_f32')
 
 
-def _im2col(x, geom, grid):
+def _im2col(x, geom, grid, lowp=False):
+    """``lowp``: the column matrix in bf16 (half the bytes of the largest tensor of the layer)."""
     (kh, kw), (sh, sw), (ph, pw) = geom
     B, C, H, W = x.shape
-    col = torch.empty(B, C*kh*kw, grid[0]*grid[1], dtype=torch.float32, device=x.device)
-    hip.check(hip.lib().brv_im2col(hip.ptr(x), hip.ptr(col), B, C, H, W, kh, kw, sh, sw, ph, pw,
-                                   grid[0], grid[1], hip.stream()), 'brv_im2col')
+    col = torch.empty(B, C*kh*kw, grid[0]*grid[1], dtype=torch.bfloat16 if lowp else torch.float32,
+                      device=x.device)
+    fn, name = (hip.lib().brv_im2col_bf16, 'brv_im2col_bf16') if lowp else \
+        (hip.lib().brv_im2col, 'brv_im2col')
+    hip.check(fn(hip.ptr(x), hip.ptr(col), B, C, H, W, kh, kw, sh, sw, ph, pw, grid[0], grid[1],
+                 hip.stream()), name)
     return col
 
 
@@ -152,9 +165,10 @@ def _col2im(col, bias, C, image, geom, grid):
     (kh, kw), (sh, sw), (ph, pw) = geom
     B = col.shape[0]
     y = torch.empty(B, C, image[0], image[1], dtype=torch.float32, device=col.device)
-    hip.check(hip.lib().brv_col2im(hip.ptr(col), hip.ptr(bias), hip.ptr(y), B, C, image[0], image[1],
-                                   kh, kw, sh, sw, ph, pw, grid[0], grid[1], hip.stream()),
-              'brv_col2im')
+    fn, name = (hip.lib().brv_col2im_bf16, 'brv_col2im_bf16') if col.dtype == torch.bfloat16 else \
+        (hip.lib().brv_col2im, 'brv_col2im')
+    hip.check(fn(hip.ptr(col), hip.ptr(bias), hip.ptr(y), B, C, image[0], image[1], kh, kw, sh, sw,
+                 ph, pw, grid[0], grid[1], hip.stream()), name)
     return y
 
 
@@ -195,14 +209,15 @@ class _ComplexConvFunction(torch.autograd.Function):
         if transpose:
             Cout = wr.shape[1]
             Ho, Wo = (H - 1)*sh - 2*ph + kh + oph, (W - 1)*sw - 2*pw + kw + opw
-            col = torch.empty(B, 2*Cw, H*W, dtype=torch.float32, device=x.device)
+            col = torch.empty(B, 2*Cw, H*W, dtype=torch.bfloat16 if lowp else torch.float32,
+                              device=x.device)
             _gemm(wc, x, col, B, 2*Cw, H*W, 2*Cin, 2*Cw, H*W, H*W, 0, 2*Cin*H*W, 2*Cw*H*W,
                   trans_a=1, lowp=lowp)
             y = _col2im(col, bias, 2*Cout, (Ho, Wo), geom, (H, W))
         else:
             Cout = R
             Ho, Wo = (H + 2*ph - kh)//sh + 1, (W + 2*pw - kw)//sw + 1
-            col = _im2col(x, geom, (Ho, Wo))
+            col = _im2col(x, geom, (Ho, Wo), lowp)
             y = torch.empty(B, 2*Cout, Ho, Wo, dtype=torch.float32, device=x.device)
             _gemm(wc, col, y, B, 2*Cout, Ho*Wo, 2*Cw, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cw*Ho*Wo,
                   2*Cout*Ho*Wo, bias=bias, lowp=lowp)
@@ -220,14 +235,14 @@ class _ComplexConvFunction(torch.autograd.Function):
         lowp = ctx.lowp
         dwc = torch.empty_like(wc)
         if transpose:
-            dcol = _im2col(dy, geom, (H, W))                       # (B, 2*Cw, H*W)
+            dcol = _im2col(dy, geom, (H, W), lowp)                 # (B, 2*Cw, H*W)
             dx = torch.empty_like(x)
             _gemm(wc, dcol, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, H*W, 0, 2*Cw*H*W, 2*Cin*H*W,
                   lowp=lowp)
             _gemm(x, dcol, dwc, 1, 2*Cin, 2*Cw, H*W, H*W, H*W, 2*Cw, 0, 0, 0, trans_b=1,
                   kbatch=B, a_kbs=2*Cin*H*W, b_kbs=2*Cw*H*W, lowp=lowp)
         else:
-            col = _im2col(x, geom, (Ho, Wo))                       # (B, 2*Cw, Ho*Wo)
+            col = _im2col(x, geom, (Ho, Wo), lowp)                 # (B, 2*Cw, Ho*Wo)
             _gemm(dy, col, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, trans_b=1,
                   kbatch=B, a_kbs=2*Cout*Ho*Wo, b_kbs=2*Cw*Ho*Wo, lowp=lowp)
             _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,

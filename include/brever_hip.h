@@ -182,6 +182,22 @@ int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64
                   int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
                   int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
                   const float* row_bias, int accumulate, brv_stream_t stream);
+/* brv_gemm_bf16 with bf16 tensors in memory: flags bit 0: b holds bf16 elements, bit 1: d is written
+ * as bf16 (no accumulate, no split reduction); strides count elements. Used with
+ * brv_im2col_bf16 / brv_col2im_bf16 (same arguments as brv_im2col / brv_col2im, the column matrix
+ * in bf16) by the use_amp path of DCCRN's convolutions: the column matrix is the largest tensor
+ * of a convolution-as-product. */
+int brv_gemm_bf16_mixed(const float* a, const void* b, void* d, int64_t batch, int64_t M, int64_t N,
+                        int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
+                        int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                        int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
+                        const float* row_bias, int accumulate, int flags, brv_stream_t stream);
+int brv_im2col_bf16(const float* x, void* col, int64_t B, int64_t C, int64_t H, int64_t W, int64_t kh,
+                    int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw, int64_t Ho,
+                    int64_t Wo, brv_stream_t stream);
+int brv_col2im_bf16(const void* col, const float* bias, float* y, int64_t B, int64_t C, int64_t H,
+                    int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph, int64_t pw,
+                    int64_t Ho, int64_t Wo, brv_stream_t stream);
 
 /* ---- FFNN mask model and log-mel features (models/ffnn/ffnn.py:72-203,
  * modules/features.py:142-205); fp32, (B, rows, frames) / complex64 (B, channels, bins*frames)
