@@ -330,6 +330,12 @@ __global__ __launch_bounds__(256) void lstm_recurrent_kernel(const float* gates_
 // unit. One step = one H-long dot product per thread + the gate math: the chain of T dependent
 // steps, not bandwidth, is what this kernel is bound by.
 constexpr int kLstmRegH = 128;
+// gate non-linearities on the hardware exp / rcp (v_exp_f32, v_rcp_f32, ~1 ulp each): the libm
+// forms are a large share of a recurrence step, which is latency- not throughput-bound
+__device__ __forceinline__ float fast_sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 2.f*__builtin_amdgcn_rcpf(1.f + __expf(-2.f*x)) - 1.f;
+}
 __global__ __launch_bounds__(512) void lstm_fwd_reg_kernel(const float* gates_in, const float* w_hh,
                                                            const float* bias, float* y, float* act,
                                                            float* cs, int T, int H, int per_group) {
@@ -360,12 +366,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_reg_kernel(const float* gates_in
     gt[r] = acc;
     __syncthreads();
     if (r < H) {
-      const float ig = 1.f/(1.f + expf(-gt[r]));
-      const float fg = 1.f/(1.f + expf(-gt[H + r]));
-      const float gg = tanhf(gt[2*H + r]);
-      const float og = 1.f/(1.f + expf(-gt[3*H + r]));
+      const float ig = fast_sigm(gt[r]);
+      const float fg = fast_sigm(gt[H + r]);
+      const float gg = fast_tanh(gt[2*H + r]);
+      const float og = fast_sigm(gt[3*H + r]);
       c = fg*c + ig*gg;
-      const float hn = og*tanhf(c);
+      const float hn = og*fast_tanh(c);
       h[r] = hn;
       y[((long long)b*T + t)*H + r] = hn;
       if (act) {
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_reg_kernel(const float* act, con
       const float ig = a[j], fg = a[H + j], gg = a[2*H + j], og = a[3*H + j];
       const float c = cs[((long long)b*T + t)*H + j];
       const float cprev = t > 0 ? cs[((long long)b*T + t - 1)*H + j] : 0.f;
-      const float tc = tanhf(c);
+      const float tc = fast_tanh(c);
       const float dht = part[0][j] + part[1][j] + part[2][j] + part[3][j]
                         + dy[((long long)b*T + t)*H + j];
       const float dct = dc + dht*og*(1.f - tc*tc);
