@@ -32,8 +32,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(bf16_t, h);
 }
+// two values -> one dword: the vector conversion is ONE v_cvt_pk_bf16_f32 (two scalar casts
+// compile to two of them plus a shift and an or)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void unpack8(const uint4& q, float (&f)[8]) {
   f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
