@@ -515,8 +515,8 @@ __device__ __forceinline__ void store_col4(float* out, const float4& v) {
   *reinterpret_cast<float4*>(out) = v;
 }
 __device__ __forceinline__ void store_col4(bf16_t* out, const float4& v) {
-  *reinterpret_cast<uint2*>(out) = make_uint2((unsigned int)f2bf(v.x) | ((unsigned int)f2bf(v.y) << 16),
-                                              (unsigned int)f2bf(v.z) | ((unsigned int)f2bf(v.w) << 16));
+  *reinterpret_cast<uint2*>(out) = make_uint2(pack2(v.x, v.y),
+                                              pack2(v.z, v.w));
 }
 
 template <typename ColT>

@@ -321,10 +321,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
       int row, kp;
       item(tid + r*256, TA, row, kp);
       *reinterpret_cast<unsigned int*>(&As[row][2*kp]) =
-          (unsigned int)f2bf(ra[r].x) | ((unsigned int)f2bf(ra[r].y) << 16);
+          pack2(ra[r].x, ra[r].y);
       item(tid + r*256, !TB, row, kp);
       *reinterpret_cast<unsigned int*>(&Bs[row][2*kp]) =
-          (unsigned int)f2bf(rb[r].x) | ((unsigned int)f2bf(rb[r].y) << 16);
+          pack2(rb[r].x, rb[r].y);
     }
   };
   // vector loader: an operand whose k axis is contiguous is cut into (row, 4 k) items, one whose
@@ -358,18 +358,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
       for (int r = 0; r < 4; ++r) {
         const int e = tid + r*256, kq = e & 7, row = e >> 3;
         *reinterpret_cast<uint2*>(&S[row][4*kq]) =
-            make_uint2((unsigned int)f2bf(v[r].x) | ((unsigned int)f2bf(v[r].y) << 16),
-                       (unsigned int)f2bf(v[r].z) | ((unsigned int)f2bf(v[r].w) << 16));
+            make_uint2(pack2(v[r].x, v[r].y),
+                       pack2(v[r].z, v[r].w));
       }
     } else {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int e = tid + h*256, rq = e & 31, kp = e >> 5;
         const float4 lo = v[2*h], hi = v[2*h + 1];          // k = 2 kp and 2 kp + 1
-        *reinterpret_cast<unsigned int*>(&S[4*rq][2*kp]) = (unsigned int)f2bf(lo.x) | ((unsigned int)f2bf(hi.x) << 16);
-        *reinterpret_cast<unsigned int*>(&S[4*rq + 1][2*kp]) = (unsigned int)f2bf(lo.y) | ((unsigned int)f2bf(hi.y) << 16);
-        *reinterpret_cast<unsigned int*>(&S[4*rq + 2][2*kp]) = (unsigned int)f2bf(lo.z) | ((unsigned int)f2bf(hi.z) << 16);
-        *reinterpret_cast<unsigned int*>(&S[4*rq + 3][2*kp]) = (unsigned int)f2bf(lo.w) | ((unsigned int)f2bf(hi.w) << 16);
+        *reinterpret_cast<unsigned int*>(&S[4*rq][2*kp]) = pack2(lo.x, hi.x);
+        *reinterpret_cast<unsigned int*>(&S[4*rq + 1][2*kp]) = pack2(lo.y, hi.y);
+        *reinterpret_cast<unsigned int*>(&S[4*rq + 2][2*kp]) = pack2(lo.z, hi.z);
+        *reinterpret_cast<unsigned int*>(&S[4*rq + 3][2*kp]) = pack2(lo.w, hi.w);
       }
     }
   };
