@@ -328,3 +328,32 @@ def test_ema_matches_reference_on_cpu(golden_dir):
     assert np.array_equal(flat(other.ema_params), g['ema'])
     with pytest.raises(RuntimeError):
         ema.restore()
+
+
+def test_tfgridnet_parameter_containers_match_reference(golden_dir):
+    """TFGridNet on the host: same parameter names / order / shapes as the reference (golden
+    ``*_names``, oracle.tfgridnet.parameter_shapes), default parameter count, nested state_dict with
+    the plateau scheduler, gate (de)interleaving of the tiled LSTM is a permutation; forward on a
+    CPU tensor fails loudly (no fallback)."""
+    import json
+    from brever_amd.models import TFGridNet, count_params
+    from brever_amd.models.dccrn import _LSTMFunction
+    from oracle.tfgridnet import parameter_shapes
+    g = np.load(os.path.join(golden_dir, 'tfgridnet.npz'))
+    assert count_params(TFGridNet()) == int(g['n_params_default']) == 3_735_344
+    for tag in ('a', 'b', 'c'):
+        cfg = json.loads(str(g[tag + '_config']))
+        net = TFGridNet(**cfg)
+        names = [n for n, _ in net.named_parameters()]
+        assert names == json.loads(str(g[tag + '_names']))
+        shapes = parameter_shapes(cfg)
+        assert {n: tuple(p.shape) for n, p in net.named_parameters()} == {n: tuple(shapes[n]) for n in names}
+        sd = net.state_dict()
+        assert set(sd) == {'net', 'scheduler'} and 'blocks.0.intra_rnn.weight_hh_l0_reverse' in sd['net']
+        net.load_state_dict(sd)
+    w = torch.arange(2*8*3, dtype=torch.float32).view(2, 8, 3)        # G = 2, 4H = 8 (H = 2)
+    wi = _LSTMFunction._interleave(w, 2)
+    assert torch.equal(wi[0, :, 0], w[0, [0, 2, 4, 6, 1, 3, 5, 7], 0])   # row 4*unit + gate
+    assert torch.equal(_LSTMFunction._deinterleave(wi, 2), w)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 2, 400))
