@@ -47,9 +47,35 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* x, const flo
   long long hi = lo + slice;
   if (hi > n) hi = n;
   double s = 0.0, q = 0.0;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    const float v = xg[i] + (ag ? ag[i / HW] : 0.f);
-    s += v; q += (double)v*v;
+  if ((HW & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+    // channel by channel (the embedding term is constant along a channel; one division per
+    // channel instead of one per element), 16-byte loads, fp32 partial sums over at most 16
+    // vectors before they are added to the fp64 accumulators
+    long long i = lo;                                     // lo, HW: multiples of 4
+    while (i < hi) {
+      const long long c = i / HW;
+      const long long seg_end = min(hi, (c + 1)*HW);
+      const float a = ag ? ag[c] : 0.f;
+      for (long long j0 = i + 4*threadIdx.x; j0 < seg_end; j0 += 16*1024) {
+        float fs = 0.f, fq = 0.f;
+#pragma unroll 4
+        for (int u = 0; u < 16; ++u) {
+          const long long j = j0 + (long long)u*1024;
+          if (j >= seg_end) break;
+          float4 v = *reinterpret_cast<const float4*>(xg + j);
+          v.x += a; v.y += a; v.z += a; v.w += a;
+          fs += (v.x + v.y) + (v.z + v.w);
+          fq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fq))));
+        }
+        s += fs; q += fq;
+      }
+      i = seg_end;
+    }
+  } else {
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+      const float v = xg[i] + (ag ? ag[i / HW] : 0.f);
+      s += v; q += (double)v*v;
+    }
   }
   s = block_sum(s, scr); __syncthreads();
   q = block_sum(q, scr);
