@@ -276,10 +276,12 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* x, float* y, 
 __global__ __launch_bounds__(256) void fir_down_kernel(const float* x, const float* k, float* y,
                                                        long long planes, int H, int W, int Ho,
                                                        int Wo, int K, int ph, int pw) {
-  const long long total = planes*Ho*Wo;
-  GRID_STRIDE(idx, total) {
-    const int wo = (int)(idx % Wo), ho = (int)((idx / Wo) % Ho);
-    const long long pl = idx / ((long long)Wo*Ho);
+  // grid (column blocks, output rows, planes): the index arithmetic is per workgroup
+  const int wo = blockIdx.x*256 + threadIdx.x, ho = blockIdx.y;
+  const long long pl = blockIdx.z;
+  if (wo >= Wo) return;
+  const long long idx = (pl*Ho + ho)*(long long)Wo + wo;
+  {
     const float* xp = x + pl*H*W;
     float acc = 0.f;
     for (int i = 0; i < K; ++i) {
@@ -297,10 +299,12 @@ __global__ __launch_bounds__(256) void fir_down_kernel(const float* x, const flo
 __global__ __launch_bounds__(256) void fir_up_kernel(const float* x, const float* k, float* y,
                                                      long long planes, int H, int W, int Ho, int Wo,
                                                      int K, int ph, int pw, float gain) {
-  const long long total = planes*Ho*Wo;
-  GRID_STRIDE(idx, total) {
-    const int wo = (int)(idx % Wo), ho = (int)((idx / Wo) % Ho);
-    const long long pl = idx / ((long long)Wo*Ho);
+  // grid (column blocks, output rows, planes): the index arithmetic is per workgroup
+  const int wo = blockIdx.x*256 + threadIdx.x, ho = blockIdx.y;
+  const long long pl = blockIdx.z;
+  if (wo >= Wo) return;
+  const long long idx = (pl*Ho + ho)*(long long)Wo + wo;
+  {
     const float* xp = x + pl*H*W;
     float acc = 0.f;
     for (int i = 0; i < K; ++i) {
@@ -451,13 +455,14 @@ int brv_softmax_rows(const float* x, float* y, int64_t rows, int64_t cols, brv_s
 int brv_fir_resample2d(const float* x, const float* kernel, float* y, int64_t planes, int64_t H,
                        int64_t W, int64_t Ho, int64_t Wo, int64_t K, int64_t pad_h, int64_t pad_w,
                        int up, float gain, brv_stream_t stream) {
-  if (planes < 1 || Ho < 1 || Wo < 1) return -1;
+  if (planes < 1 || Ho < 1 || Wo < 1 || Ho > 65535 || planes > 65535) return -1;
+  const dim3 grid((unsigned)((Wo + 255)/256), (unsigned)Ho, (unsigned)planes);
   if (up)
-    hipLaunchKernelGGL(fir_up_kernel, flat_grid(planes*Ho*Wo), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(fir_up_kernel, grid, dim3(256), 0, (hipStream_t)stream, x,
                        kernel, y, (long long)planes, (int)H, (int)W, (int)Ho, (int)Wo, (int)K,
                        (int)pad_h, (int)pad_w, gain);
   else
-    hipLaunchKernelGGL(fir_down_kernel, flat_grid(planes*Ho*Wo), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(fir_down_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                        x, kernel, y, (long long)planes, (int)H, (int)W, (int)Ho, (int)Wo, (int)K,
                        (int)pad_h, (int)pad_w);
   SG_OK(hipGetLastError());
