@@ -455,16 +455,22 @@ int brv_softmax_rows(const float* x, float* y, int64_t rows, int64_t cols, brv_s
 int brv_fir_resample2d(const float* x, const float* kernel, float* y, int64_t planes, int64_t H,
                        int64_t W, int64_t Ho, int64_t Wo, int64_t K, int64_t pad_h, int64_t pad_w,
                        int up, float gain, brv_stream_t stream) {
-  if (planes < 1 || Ho < 1 || Wo < 1 || Ho > 65535 || planes > 65535) return -1;
-  const dim3 grid((unsigned)((Wo + 255)/256), (unsigned)Ho, (unsigned)planes);
-  if (up)
-    hipLaunchKernelGGL(fir_up_kernel, grid, dim3(256), 0, (hipStream_t)stream, x,
-                       kernel, y, (long long)planes, (int)H, (int)W, (int)Ho, (int)Wo, (int)K,
-                       (int)pad_h, (int)pad_w, gain);
-  else
-    hipLaunchKernelGGL(fir_down_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                       x, kernel, y, (long long)planes, (int)H, (int)W, (int)Ho, (int)Wo, (int)K,
-                       (int)pad_h, (int)pad_w);
+  if (planes < 1 || Ho < 1 || Wo < 1 || Ho > 65535) return -1;
+  // grid.z carries the planes: at most 65 535 per launch
+  for (int64_t p0 = 0; p0 < planes; p0 += 65535) {
+    const int64_t np = planes - p0 < 65535 ? planes - p0 : 65535;
+    const dim3 grid((unsigned)((Wo + 255)/256), (unsigned)Ho, (unsigned)np);
+    const float* xs = x + p0*H*W;
+    float* ys = y + p0*Ho*Wo;
+    if (up)
+      hipLaunchKernelGGL(fir_up_kernel, grid, dim3(256), 0, (hipStream_t)stream, xs, kernel, ys,
+                         (long long)np, (int)H, (int)W, (int)Ho, (int)Wo, (int)K, (int)pad_h,
+                         (int)pad_w, gain);
+    else
+      hipLaunchKernelGGL(fir_down_kernel, grid, dim3(256), 0, (hipStream_t)stream, xs, kernel, ys,
+                         (long long)np, (int)H, (int)W, (int)Ho, (int)Wo, (int)K, (int)pad_h,
+                         (int)pad_w);
+  }
   SG_OK(hipGetLastError());
   return 0;
 }
