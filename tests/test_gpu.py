@@ -1544,3 +1544,51 @@ def test_entry_points_tfgridnet(tmp_path):
     out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:3:0.5')
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert np.isfinite(np.load(os.path.join(model_dir, 'scores.npz'))['scores']).all()
+
+
+@pytest.mark.gpu
+def test_bf16_column_matrix_kernels():
+    """brv_im2col_bf16 == bf16(F.unfold) bit for bit (DCCRN's (5, 2) / stride (2, 1) / padding (2, 0)
+    geometry, fast path and edges); brv_col2im_bf16 == F.fold of the same bf16 values (fp32 sums,
+    1e-6); brv_gemm_bf16_mixed with a bf16 B operand and a bf16 result vs the fp32 product of the
+    bf16-rounded operands (fp32 accumulation: 2e-3 of bf16 output rounding), vector and scalar
+    operand loaders alike."""
+    import torch.nn.functional as F
+    from brever_amd import hip
+    dev = _cuda()
+    lib = hip.lib()
+    gen = torch.Generator().manual_seed(11)
+    B, C, H, W = 2, 3, 16, 21
+    kh, kw, sh, sw, ph, pw = 5, 2, 2, 1, 2, 0
+    Ho, Wo = (H + 2*ph - kh)//sh + 1, (W + 2*pw - kw)//sw + 1
+    x = torch.randn(B, C, H, W, generator=gen)
+    xd = x.to(dev)
+    col = torch.empty(B, C*kh*kw, Ho*Wo, dtype=torch.bfloat16, device=dev)
+    hip.check(lib.brv_im2col_bf16(hip.ptr(xd), hip.ptr(col), B, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo,
+                                  hip.stream()), 'brv_im2col_bf16')
+    want = F.unfold(x, (kh, kw), padding=(ph, pw), stride=(sh, sw)).bfloat16()
+    assert torch.equal(col.cpu().view(torch.int16), want.view(torch.int16))
+    y = torch.empty(B, C, H, W, device=dev)
+    bias = torch.randn(C, generator=gen)
+    bias_d = bias.to(dev)
+    hip.check(lib.brv_col2im_bf16(hip.ptr(col), hip.ptr(bias_d), hip.ptr(y), B, C, H, W, kh, kw,
+                                  sh, sw, ph, pw, Ho, Wo, hip.stream()), 'brv_col2im_bf16')
+    fold = F.fold(want.float(), (H, W), (kh, kw), padding=(ph, pw), stride=(sh, sw)) + bias.view(1, C, 1, 1)
+    assert rel(y, fold) <= 1e-6
+    # mixed-dtype product: d (bf16) = a (fp32, M x K) @ b (bf16, K x N), batch of 2
+    M, K, N = 40, 72, 256
+    a = torch.randn(M, K, generator=gen)
+    b = torch.randn(2, K, N, generator=gen).bfloat16()
+    ref = (a.bfloat16().float() @ b.float())
+    ad, bd = a.to(dev), b.to(dev)
+    for scalar in (False, True):
+        if scalar:
+            os.environ['BRV_GEMM_SCALAR'] = '1'
+        try:
+            d = torch.empty(2, M, N, dtype=torch.bfloat16, device=dev)
+            hip.check(lib.brv_gemm_bf16_mixed(hip.ptr(ad), hip.ptr(bd), hip.ptr(d), 2, M, N,
+                                              K, K, N, N, 0, K*N, M*N, 0, 0, 1, 0, 0, None, 0, 3,
+                                              hip.stream()), 'brv_gemm_bf16_mixed')
+        finally:
+            os.environ.pop('BRV_GEMM_SCALAR', None)
+        assert rel(d.float(), ref) <= 4e-3, rel(d.float(), ref)
