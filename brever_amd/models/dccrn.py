@@ -202,7 +202,8 @@ class _ComplexConvFunction(torch.autograd.Function):
         R = wr.shape[0]
         Cw = wr[0].numel()
         wc = torch.empty(2*R, 2*Cw, dtype=torch.float32, device=x.device)
-        hip.check(lib.brv_complex_weight_pack(hip.ptr(wr.contiguous()), hip.ptr(wi.contiguous()),
+        wr_c, wi_c = wr.contiguous(), wi.contiguous()      # alive until the launch is queued
+        hip.check(lib.brv_complex_weight_pack(hip.ptr(wr_c), hip.ptr(wi_c),
                                               hip.ptr(wc), R, Cw, -1.0 if transpose else 1.0,
                                               hip.stream()), 'brv_complex_weight_pack')
         bias = torch.cat([_combine(br, bi, -1.0), _combine(br, bi, 1.0)])

@@ -162,10 +162,10 @@ class StaticNormalizer(nn.Module):
         x3 = (x.unsqueeze(0) if unbatched else x).float().contiguous()
         B, R, T = x3.shape
         out = torch.empty_like(x3)
-        hip.check(hip.lib().brv_static_norm(
-            hip.ptr(x3), hip.ptr(self.mean.float().contiguous()),
-            hip.ptr(self.std.float().contiguous()), hip.ptr(out), B, R, T, hip.stream()),
-            'brv_static_norm')
+        # locals keep both (possibly converted) tensors alive until the launch is queued
+        mean, std = self.mean.float().contiguous(), self.std.float().contiguous()
+        hip.check(hip.lib().brv_static_norm(hip.ptr(x3), hip.ptr(mean), hip.ptr(std), hip.ptr(out), B,
+                                            R, T, hip.stream()), 'brv_static_norm')
         return out.squeeze(0) if unbatched else out
 
 
