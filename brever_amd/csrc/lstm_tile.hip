@@ -240,6 +240,21 @@ __device__ __forceinline__ bf16x8 load_frag(const float* p, long long stride) {
   return __builtin_bit_cast(bf16x8, q);
 }
 
+// IO16: gates_in and the saved activations are bf16 in memory (lowp == 2): the two largest
+// streams of this HBM-bound kernel at half the bytes
+__device__ __forceinline__ f32x4 load4(const float* p, long long i, bool half) {
+  if (!half) return *reinterpret_cast<const f32x4*>(p + i);
+  const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + i);
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+               __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void store4(float* p, long long i, const f32x4& v, bool half) {
+  if (!half) { *reinterpret_cast<f32x4*>(p + i) = v; return; }
+  *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p) + i) =
+      make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+}
+
+template <bool IO16>
 __global__ __launch_bounds__(512) void lstm_tile_fwd_bf16_kernel(const float* __restrict__ gates_in,
                                                                  const float* __restrict__ w_hh,
                                                                  const float* __restrict__ bias,
@@ -280,12 +295,13 @@ __global__ __launch_bounds__(512) void lstm_tile_fwd_bf16_kernel(const float* __
   for (int i = tid; i < LC*HROW; i += 512) hbuf[0][i] = 0;
   const bool rev = (reverse_mask >> grp) & 1;
   const int t_first = rev ? T - 1 : 0, t_inc = rev ? -1 : 1;
-  const float* gin = gates_in + chain*T*4*LH + 4*u0;
+  const float* gin = gates_in;
+  const long long gbase = chain*T*4*LH + 4*u0;
   float* yrow = y + (long long)(live ? cl : per_group - 1)*T*y_ld + grp*y_goff + u0;
   f32x4 gnext[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b)
-    gnext[b] = *reinterpret_cast<const f32x4*>(gin + (long long)t_first*4*LH + 4*b);
+    gnext[b] = load4(gin, gbase + (long long)t_first*4*LH + 4*b, IO16);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     const int tt = t_first + t*t_inc;
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(512) void lstm_tile_fwd_bf16_kernel(const float* __
     if (t + 1 < T) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
-        gnext[b] = *reinterpret_cast<const f32x4*>(gin + (long long)(tt + t_inc)*4*LH + 4*b);
+        gnext[b] = load4(gin, gbase + (long long)(tt + t_inc)*4*LH + 4*b, IO16);
     }
     const uint16_t* hb = hbuf[t & 1] + n*HROW + 8*j;
 #pragma unroll
@@ -325,13 +341,14 @@ __global__ __launch_bounds__(512) void lstm_tile_fwd_bf16_kernel(const float* __
         *reinterpret_cast<f32x4*>(cs + step*LH + u0) = cn;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          *reinterpret_cast<f32x4*>(act + step*4*LH + 4*(u0 + b)) = a[b];
+          store4(act, step*4*LH + 4*(u0 + b), a[b], IO16);
       }
     }
     __syncthreads();
   }
 }
 
+template <bool IO16>
 __global__ __launch_bounds__(512) void lstm_tile_bwd_bf16_kernel(const float* __restrict__ act,
                                                                  const float* __restrict__ cs,
                                                                  const float* __restrict__ w_hh,
@@ -374,7 +391,7 @@ __global__ __launch_bounds__(512) void lstm_tile_bwd_bf16_kernel(const float* __
     const int tt = rev ? T - 1 - t : t;
     f32x4 a[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) a[b] = *reinterpret_cast<const f32x4*>(act + step*4*LH + 4*(u0 + b));
+    for (int b = 0; b < 4; ++b) a[b] = load4(act, step*4*LH + 4*(u0 + b), IO16);
     const f32x4 cv = *reinterpret_cast<const f32x4*>(cs + step*LH + u0);
     f32x4 cp = {0.f, 0.f, 0.f, 0.f};
     if (t > 0) cp = *reinterpret_cast<const f32x4*>(cs + (step - 1)*LH + u0);
@@ -427,8 +444,12 @@ int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float*
   if (H != LH || B < 1 || T < 1 || groups < 1 || groups > 30 || B % groups) return -1;
   const int per_group = (int)(B/groups);
   const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
-  if (lowp)
-    hipLaunchKernelGGL(lstm_tile_fwd_bf16_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream,
+  if (lowp == 2)
+    hipLaunchKernelGGL(lstm_tile_fwd_bf16_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream,
+                       gates_in, w_hh, bias, y, act, cs, per_group, (int)T, (int)reverse_mask,
+                       (long long)y_ld, (long long)y_group_offset);
+  else if (lowp)
+    hipLaunchKernelGGL(lstm_tile_fwd_bf16_kernel<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream,
                        gates_in, w_hh, bias, y, act, cs, per_group, (int)T, (int)reverse_mask,
                        (long long)y_ld, (long long)y_group_offset);
   else
@@ -445,10 +466,14 @@ int brv_lstm_tile_backward(const float* act, const float* cs, const float* w_hh,
   if (H != LH || B < 1 || T < 1 || groups < 1 || groups > 30 || B % groups) return -1;
   const int per_group = (int)(B/groups);
   const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
-  if (lowp)
-    hipLaunchKernelGGL(lstm_tile_bwd_bf16_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, act,
-                       cs, w_hh, dy, dgates, per_group, (int)T, (int)reverse_mask, (long long)dy_ld,
-                       (long long)dy_group_offset);
+  if (lowp == 2)
+    hipLaunchKernelGGL(lstm_tile_bwd_bf16_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream,
+                       act, cs, w_hh, dy, dgates, per_group, (int)T, (int)reverse_mask,
+                       (long long)dy_ld, (long long)dy_group_offset);
+  else if (lowp)
+    hipLaunchKernelGGL(lstm_tile_bwd_bf16_kernel<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream,
+                       act, cs, w_hh, dy, dgates, per_group, (int)T, (int)reverse_mask,
+                       (long long)dy_ld, (long long)dy_group_offset);
   else
   hipLaunchKernelGGL(lstm_tile_bwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, act, cs,
                      w_hh, dy, dgates, per_group, (int)T, (int)reverse_mask, (long long)dy_ld,

@@ -205,7 +205,13 @@ class _AttentionFn(torch.autograd.Function):
 def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_a=0, trans_b=0,
           kbatch=1, a_kbs=0, b_kbs=0, bias=None, mode=0, lowp=False):
     """brv_gemm_f32 / brv_gemm_bf16 (bf16 operands, fp32 accumulation: ``use_amp``); ``mode`` 1
-    adds to d, 2 reads ``bias`` per output column."""
+    adds to d, 2 reads ``bias`` per output column; a bf16 ``d`` tensor is written directly."""
+    if d.dtype == torch.bfloat16:
+        hip.check(hip.lib().brv_gemm_bf16_mixed(
+            hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
+            trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), mode, 2, hip.stream()),
+            'brv_gemm_bf16_mixed')
+        return
     fn = hip.lib().brv_gemm_bf16 if lowp else hip.lib().brv_gemm_f32
     hip.check(fn(hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
                  trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), mode, hip.stream()),
@@ -269,14 +275,17 @@ class _BiLSTMFn(torch.autograd.Function):
         H = w_hh.shape[-1]
         lowp = ctx.lowp = _AMP['on']
         w_ih = _LSTMFunction._interleave(w_ih.contiguous(), H)
-        gates = T._empty(2, N, S, 4*H, like=x)
+        # use_amp: the input projection and the saved gate activations are bf16 tensors (the
+        # recurrence kernel is HBM-bound on exactly these two streams)
+        io = torch.bfloat16 if lowp else torch.float32
+        gates = torch.empty(2, N, S, 4*H, dtype=io, device=x.device)
         _gemm(x, w_ih, gates, 2, N*S, 4*H, I, I, I, 4*H, 0, 4*H*I, N*S*4*H, trans_b=1, lowp=lowp)
         bias = T._axpby_raw(b_ih.detach().contiguous(), 1.0, b_hh.detach().contiguous(), 1.0)
         y = T._empty(N, S, 2*H, like=x)
-        act, cs = T._empty(2, N, S, 4*H, like=x), T._empty(2, N, S, H, like=x)
+        act, cs = torch.empty(2, N, S, 4*H, dtype=io, device=x.device), T._empty(2, N, S, H, like=x)
         hip.check(lib.brv_lstm_tile_forward(hip.ptr(gates), hip.ptr(w_hh), hip.ptr(bias), hip.ptr(y),
                                             hip.ptr(act), hip.ptr(cs), 2*N, S, H, 2, 2, 2*H, H,
-                                            int(lowp), hip.stream()), 'brv_lstm_tile_forward')
+                                            2*int(lowp), hip.stream()), 'brv_lstm_tile_forward')
         ctx.save_for_backward(x, w_ih, w_hh, y, act, cs)
         return y
 
@@ -290,7 +299,7 @@ class _BiLSTMFn(torch.autograd.Function):
         dy = dy.contiguous()
         dg = T._empty(2, N, S, 4*H, like=x)
         hip.check(lib.brv_lstm_tile_backward(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh), hip.ptr(dy),
-                                             hip.ptr(dg), 2*N, S, H, 2, 2, 2*H, H, int(lowp),
+                                             hip.ptr(dg), 2*N, S, H, 2, 2, 2*H, H, 2*int(lowp),
                                              hip.stream()),
                   'brv_lstm_tile_backward')
         dx = torch.empty_like(x)                      # sum over both directions: dg_g @ W_ih_g

@@ -363,7 +363,9 @@ int brv_causal_groupnorm_backward(const float* x, const float* dy, const float* 
  * (groups, chains, T, H) layout; ld = 2H, group_offset = H writes both directions straight into
  * nn.LSTM's (chains, T, 2H) output. lowp != 0 (use_amp): W_hh and the recurrent operand (h or the
  * gate gradients) are rounded to bf16 for the MFMA; accumulation, cell state, gate arithmetic and
- * every tensor in memory stay fp32. */
+ * every tensor in memory stay fp32; lowp == 2 additionally keeps gates_in and act as bf16 tensors
+ * (the two largest streams of the then HBM-bound kernel; the input projection writes bf16 through
+ * brv_gemm_bf16_mixed). */
 int brv_lstm_tile_supported(int64_t H);
 int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float* bias, float* y,
                           float* act, float* cs, int64_t B, int64_t T, int64_t H, int64_t groups,
