@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512) void lstm_tile_bwd_bf16_kernel(const float* __
     if (live) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
-        *reinterpret_cast<f32x4*>(dgates + (chain*T + tt)*4*LH + 4*(u0 + b)) = d[b];
+        store4(dgates, (chain*T + tt)*4*LH + 4*(u0 + b), d[b], IO16);
     }
     __syncthreads();
     if (t == 0) break;

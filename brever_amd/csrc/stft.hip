@@ -39,7 +39,7 @@ struct G32 {
   int kbatch; long long a_kbs, b_kbs;
   const float* row_bias; int accumulate;
   int col_bias;            // the bias is per output COLUMN (accumulate == 2 at the C ABI)
-  int b_bf16, d_bf16;      // gemm_bf16 only: operand B / result D are bf16 in memory (strides in elements)
+  int b_bf16, d_bf16, a_bf16;   // gemm_bf16 only: operands / result are bf16 in memory (strides in elements)
 };
 
 constexpr int TM = 64, TN = 64, TK = 32;
@@ -287,7 +287,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
   };
   auto fetch = [&](long long t) {
     const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BKL;
-    const float* A = p.A + (long long)b*p.a_bs + (long long)kb*p.a_kbs;
+    const long long aoff = (long long)b*p.a_bs + (long long)kb*p.a_kbs;
+    const float* A = p.A + aoff;
+    const bf16_t* Ah = reinterpret_cast<const bf16_t*>(p.A) + aoff;
+    auto lda_ = [&](long long i) { return p.a_bf16 ? bf2f(Ah[i]) : A[i]; };
     const long long boff = (long long)b*p.b_bs + (long long)kb*p.b_kbs;
     const float* B = p.B + boff;
     const bf16_t* Bh = reinterpret_cast<const bf16_t*>(p.B) + boff;
@@ -299,8 +302,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
       const int m = m0 + row, k = k0 + 2*kp;
       float2 v = make_float2(0.f, 0.f);
       if (m < p.M) {
-        if (k < p.K) v.x = TA ? A[(long long)k*p.lda + m] : A[(long long)m*p.lda + k];
-        if (k + 1 < p.K) v.y = TA ? A[(long long)(k + 1)*p.lda + m] : A[(long long)m*p.lda + k + 1];
+        if (k < p.K) v.x = lda_(TA ? (long long)k*p.lda + m : (long long)m*p.lda + k);
+        if (k + 1 < p.K) v.y = lda_(TA ? (long long)(k + 1)*p.lda + m : (long long)m*p.lda + k + 1);
       }
       ra[r] = v;
       item(tid + r*256, !TB, row, kp);
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
   };
   auto vfetch = [&](long long t) {
     const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BKL;
-    vfetch1(p.A, (long long)b*p.a_bs + (long long)kb*p.a_kbs, p.lda, !TA, m0, p.M, k0, va, false);
+    vfetch1(p.A, (long long)b*p.a_bs + (long long)kb*p.a_kbs, p.lda, !TA, m0, p.M, k0, va, p.a_bf16 != 0);
     vfetch1(p.B, (long long)b*p.b_bs + (long long)kb*p.b_kbs, p.ldb, TB, n0, p.N, k0, vb, p.b_bf16 != 0);
   };
   auto vstash = [&]() { vstash1(As, !TA, va); vstash1(Bs, TB, vb); };
@@ -611,7 +614,7 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   p.D = d; p.d_bs = d_batch_stride; p.ldd = (int)ldd;
   p.kbatch = (int)kbatch; p.a_kbs = a_kbatch_stride; p.b_kbs = b_kbatch_stride;
   p.col_bias = accumulate == 2;
-  p.b_bf16 = flags & 1; p.d_bf16 = (flags >> 1) & 1;
+  p.b_bf16 = flags & 1; p.d_bf16 = (flags >> 1) & 1; p.a_bf16 = (flags >> 2) & 1;
   if (accumulate == 2) accumulate = 0;
   p.row_bias = row_bias; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
@@ -642,7 +645,8 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
     auto q4 = [](long long v) { return (v & 3) == 0; };
     const bool vec = q4(lda) && q4(ldb) && q4(a_batch_stride) && q4(b_batch_stride) &&
                      q4(a_kbatch_stride) && q4(b_kbatch_stride) &&
-                     ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & ((flags & 1) ? 7 : 15)) == 0 &&
+                     ((uintptr_t)a & ((flags & 4) ? 7 : 15)) == 0 &&
+                     ((uintptr_t)b & ((flags & 1) ? 7 : 15)) == 0 &&
                      q4(trans_a ? M : K) && q4(trans_b ? K : N) && !getenv("BRV_GEMM_SCALAR");
 #define BRV_BF16_LAUNCH(TA_, TB_) \
     do { if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, p, (int)ksplit); \
@@ -674,14 +678,14 @@ int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_
                   d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride, b_kbatch_stride,
                   row_bias, accumulate, stream);
 }
-int brv_gemm_bf16_mixed(const float* a, const void* b, void* d, int64_t batch, int64_t M, int64_t N,
+int brv_gemm_bf16_mixed(const void* a, const void* b, void* d, int64_t batch, int64_t M, int64_t N,
                         int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
                         int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
                         int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
                         const float* row_bias, int accumulate, int flags, brv_stream_t stream) {
-  return gemm_any(1, a, (const float*)b, (float*)d, batch, M, N, K, lda, ldb, ldd, a_batch_stride,
+  return gemm_any(1, (const float*)a, (const float*)b, (float*)d, batch, M, N, K, lda, ldb, ldd, a_batch_stride,
                   b_batch_stride, d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride,
-                  b_kbatch_stride, row_bias, accumulate, stream, flags & 3);
+                  b_kbatch_stride, row_bias, accumulate, stream, flags & 7);
 }
 int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
                   int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,

@@ -206,10 +206,12 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_
           kbatch=1, a_kbs=0, b_kbs=0, bias=None, mode=0, lowp=False):
     """brv_gemm_f32 / brv_gemm_bf16 (bf16 operands, fp32 accumulation: ``use_amp``); ``mode`` 1
     adds to d, 2 reads ``bias`` per output column; a bf16 ``d`` tensor is written directly."""
-    if d.dtype == torch.bfloat16:
+    half = torch.bfloat16
+    flags = int(b.dtype == half) | int(d.dtype == half) << 1 | int(a.dtype == half) << 2
+    if flags:
         hip.check(hip.lib().brv_gemm_bf16_mixed(
             hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
-            trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), mode, 2, hip.stream()),
+            trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), mode, flags, hip.stream()),
             'brv_gemm_bf16_mixed')
         return
     fn = hip.lib().brv_gemm_bf16 if lowp else hip.lib().brv_gemm_f32
@@ -222,7 +224,8 @@ def _column_sums(x, rows, cols, batch=1):
     """(batch, rows, cols) -> (batch, cols): a ones-vector product (one pass over x)."""
     ones = torch.ones(rows, dtype=torch.float32, device=x.device)
     out = torch.empty(batch, cols, dtype=torch.float32, device=x.device)
-    _gemm(ones, x, out, batch, 1, cols, rows, rows, cols, cols, 0, rows*cols, cols)
+    _gemm(ones, x, out, batch, 1, cols, rows, rows, cols, cols, 0, rows*cols, cols,
+          lowp=x.dtype == torch.bfloat16)
     return out
 
 
@@ -297,7 +300,7 @@ class _BiLSTMFn(torch.autograd.Function):
         H = w_hh.shape[-1]
         lowp, NS = ctx.lowp, N*S
         dy = dy.contiguous()
-        dg = T._empty(2, N, S, 4*H, like=x)
+        dg = torch.empty(2, N, S, 4*H, dtype=act.dtype, device=x.device)     # bf16 under use_amp
         hip.check(lib.brv_lstm_tile_backward(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh), hip.ptr(dy),
                                              hip.ptr(dg), 2*N, S, H, 2, 2, 2*H, H, 2*int(lowp),
                                              hip.stream()),

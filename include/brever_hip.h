@@ -182,12 +182,12 @@ int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64
                   int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
                   int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
                   const float* row_bias, int accumulate, brv_stream_t stream);
-/* brv_gemm_bf16 with bf16 tensors in memory: flags bit 0: b holds bf16 elements, bit 1: d is written
- * as bf16 (no accumulate, no split reduction); strides count elements. Used with
+/* brv_gemm_bf16 with bf16 tensors in memory: flags bit 0: b holds bf16 elements, bit 2: a does, bit 1:
+ * d is written as bf16 (no accumulate, no split reduction); strides count elements. Used with
  * brv_im2col_bf16 / brv_col2im_bf16 (same arguments as brv_im2col / brv_col2im, the column matrix
  * in bf16) by the use_amp path of DCCRN's convolutions: the column matrix is the largest tensor
  * of a convolution-as-product. */
-int brv_gemm_bf16_mixed(const float* a, const void* b, void* d, int64_t batch, int64_t M, int64_t N,
+int brv_gemm_bf16_mixed(const void* a, const void* b, void* d, int64_t batch, int64_t M, int64_t N,
                         int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
                         int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
                         int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
@@ -363,7 +363,7 @@ int brv_causal_groupnorm_backward(const float* x, const float* dy, const float* 
  * (groups, chains, T, H) layout; ld = 2H, group_offset = H writes both directions straight into
  * nn.LSTM's (chains, T, 2H) output. lowp != 0 (use_amp): W_hh and the recurrent operand (h or the
  * gate gradients) are rounded to bf16 for the MFMA; accumulation, cell state, gate arithmetic and
- * every tensor in memory stay fp32; lowp == 2 additionally keeps gates_in and act as bf16 tensors
+ * every tensor in memory stay fp32; lowp == 2 additionally keeps gates_in, act and dgates as bf16 tensors
  * (the two largest streams of the then HBM-bound kernel; the input projection writes bf16 through
  * brv_gemm_bf16_mixed). */
 int brv_lstm_tile_supported(int64_t H);
