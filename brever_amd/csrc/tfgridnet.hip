@@ -102,6 +102,63 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restric
   }
 }
 
+// Short rows (n <= 64, the nn.LayerNorm(emb_dim) rows of the grid: 32 floats): a wavefront
+// carries 64/npad rows (npad = n rounded up to a power of two), one element per lane, read once;
+// the row reductions are xor-shuffles inside the lane group.
+__device__ __forceinline__ float group_sum(float v, int npad) {
+  for (int off = npad >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void rownorm_small_fwd_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ slope,
+                                                                const float* __restrict__ gain,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ y, float2* stats,
+                                                                long long rows, int n, int npad,
+                                                                int inner, int G, float eps) {
+  const int lane = threadIdx.x & 63, rpw = 64/npad;
+  const int sub = lane / npad, j = lane % npad;
+  const long long r = ((long long)blockIdx.x*4 + (threadIdx.x >> 6))*rpw + sub;
+  const bool live = r < rows && j < n;
+  const long long rr = r < rows ? r : rows - 1;
+  const int g = (int)((rr / inner) % G);
+  const float a = slope ? slope[g] : 1.f;
+  const float v = live ? prelu(x[rr*n + j], a) : 0.f;
+  const float mean = group_sum(v, npad)/n;
+  const float d = live ? v - mean : 0.f;
+  const float rstd = 1.f/sqrtf(group_sum(d*d, npad)/n + eps);
+  if (live) y[rr*n + j] = d*rstd*gain[(long long)g*n + j] + bias[(long long)g*n + j];
+  if (j == 0 && r < rows) stats[r] = make_float2(mean, rstd);
+}
+__global__ __launch_bounds__(256) void rownorm_small_bwd_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ dy,
+                                                                const float* __restrict__ slope,
+                                                                const float* __restrict__ gain,
+                                                                const float2* __restrict__ stats,
+                                                                float* __restrict__ dx,
+                                                                float* __restrict__ dslope_rows,
+                                                                long long rows, int n, int npad,
+                                                                int inner, int G) {
+  const int lane = threadIdx.x & 63, rpw = 64/npad;
+  const int sub = lane / npad, j = lane % npad;
+  const long long r = ((long long)blockIdx.x*4 + (threadIdx.x >> 6))*rpw + sub;
+  const bool live = r < rows && j < n;
+  const long long rr = r < rows ? r : rows - 1;
+  const int g = (int)((rr / inner) % G);
+  const float a = slope ? slope[g] : 1.f;
+  const float2 st = stats[rr];
+  const float v = live ? x[rr*n + j] : 0.f;
+  const float xh = live ? (prelu(v, a) - st.x)*st.y : 0.f;
+  const float dg = live ? dy[rr*n + j]*gain[(long long)g*n + j] : 0.f;
+  const float m1 = group_sum(dg, npad)/n, m2 = group_sum(dg*xh, npad)/n;
+  const float dp = st.y*(dg - m1 - xh*m2);
+  if (live) dx[rr*n + j] = v > 0.f ? dp : a*dp;
+  if (dslope_rows) {
+    const float da = group_sum(live && !(v > 0.f) ? dp*v : 0.f, npad);
+    if (j == 0 && r < rows) dslope_rows[r] = da;
+  }
+}
+
 // part[slice][g][j] = sum over the slice's rows of group g of (dy * xhat, dy)
 __global__ __launch_bounds__(256) void rownorm_pgrad_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ dy,
@@ -194,6 +251,14 @@ int brv_rownorm_forward(const float* x, const float* slope, const float* gain, c
                         int64_t groups, float eps, brv_stream_t stream) {
   if (rows < 1 || n < 1 || inner < 1 || groups < 1 || rows % (inner*groups)) return -1;
   hipStream_t st = (hipStream_t)stream;
+  if (n <= 64) {
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    const long long rows_per_wg = 4*(64/npad);
+    hipLaunchKernelGGL(rownorm_small_fwd_kernel, dim3((unsigned)((rows + rows_per_wg - 1)/rows_per_wg)),
+                       dim3(256), 0, st, x, slope, gain, bias, y, reinterpret_cast<float2*>(stats),
+                       (long long)rows, (int)n, npad, (int)inner, (int)groups, eps);
+  } else
   hipLaunchKernelGGL(rownorm_fwd_kernel, dim3((unsigned)((rows + 3)/4)), dim3(256), 0, st, x, slope,
                      gain, bias, y, reinterpret_cast<float2*>(stats), (long long)rows, (int)n,
                      (int)inner, (int)groups, eps);
@@ -212,6 +277,14 @@ int brv_rownorm_backward(const float* x, const float* dy, const float* slope, co
   if (rows < 1 || n < 1 || inner < 1 || groups < 1 || rows % (inner*groups)) return -1;
   hipStream_t st = (hipStream_t)stream;
   const float2* stp = reinterpret_cast<const float2*>(stats);
+  if (n <= 64) {
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    const long long rows_per_wg = 4*(64/npad);
+    hipLaunchKernelGGL(rownorm_small_bwd_kernel, dim3((unsigned)((rows + rows_per_wg - 1)/rows_per_wg)),
+                       dim3(256), 0, st, x, dy, slope, gain, stp, dx, slope ? dslope_rows : nullptr,
+                       (long long)rows, (int)n, npad, (int)inner, (int)groups);
+  } else
   hipLaunchKernelGGL(rownorm_bwd_kernel, dim3((unsigned)((rows + 3)/4)), dim3(256), 0, st, x, dy,
                      slope, gain, stp, dx, slope ? dslope_rows : nullptr, (long long)rows, (int)n,
                      (int)inner, (int)groups);

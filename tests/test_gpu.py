@@ -1331,7 +1331,8 @@ def test_rownorm_kernels_match_torch():
     from brever_amd.models.tfgridnet import _RowNormFn
     dev = _cuda()
     gen = torch.Generator().manual_seed(3)
-    for (outer, G, inner, n, use_slope) in ((5, 1, 1, 32, False), (2, 3, 7, 516, True), (3, 1, 4, 1000, True)):
+    for (outer, G, inner, n, use_slope) in ((5, 1, 1, 32, False), (2, 3, 7, 516, True), (3, 1, 4, 1000, True),
+                                            (7, 2, 3, 24, True), (9, 1, 1, 1, False), (4, 1, 2, 64, True)):
         R = outer*G*inner
         x = torch.randn(R, n, generator=gen)
         gain, bias = 1 + 0.2*torch.randn(G, n, generator=gen), 0.2*torch.randn(G, n, generator=gen)
