@@ -214,6 +214,37 @@ __global__ __launch_bounds__(256) void rownorm_pgrad_fold_kernel(const float2* _
   }
 }
 
+// column sums of a (rows x cols) matrix (bias gradients of the linear layers / LSTM gates):
+// 64 columns x a slice of rows per workgroup, then a fold over the slices in a fixed order
+constexpr int kColSlices = 128;
+__global__ __launch_bounds__(256) void col_sum_part_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ part, long long rows,
+                                                           int cols) {
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x*64 + col, slice = blockIdx.y;
+  const float* xb = x + (long long)blockIdx.z*rows*cols;
+  const long long chunk = (rows + kColSlices - 1)/kColSlices;
+  const long long r0 = slice*chunk, r1 = min(rows, r0 + chunk);
+  float acc = 0.f;
+  if (j < cols)
+    for (long long r = r0 + rl; r < r1; r += 4) acc += xb[r*cols + j];
+  red[rl][col] = acc;
+  __syncthreads();
+  if (rl == 0 && j < cols)
+    part[((long long)blockIdx.z*kColSlices + slice)*cols + j] =
+        (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+__global__ __launch_bounds__(256) void col_sum_fold_kernel(const float* __restrict__ part,
+                                                           float* __restrict__ out, int cols) {
+  const int j = blockIdx.x*256 + threadIdx.x;
+  if (j >= cols) return;
+  const float* p = part + (long long)blockIdx.y*kColSlices*cols;
+  float acc = 0.f;
+  for (int s = 0; s < kColSlices; ++s) acc += p[(long long)s*cols + j];
+  out[(long long)blockIdx.y*cols + j] = acc;
+}
+
 // unbiased standard deviation of each row (two passes, fp64 accumulators)
 __global__ __launch_bounds__(256) void row_std_kernel(const float* __restrict__ x,
                                                       float* __restrict__ out, long long n) {
@@ -300,6 +331,20 @@ int brv_rownorm_backward(const float* x, const float* dy, const float* slope, co
   return 0;
 }
 
+int64_t brv_col_sum_scratch_bytes(int64_t batch, int64_t cols) {
+  return batch*kColSlices*cols*(int64_t)sizeof(float);
+}
+int brv_col_sum(const float* x, float* out, void* scratch, int64_t batch, int64_t rows, int64_t cols,
+                brv_stream_t stream) {
+  if (batch < 1 || rows < 1 || cols < 1 || batch > 65535) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(col_sum_part_kernel, dim3((unsigned)((cols + 63)/64), kColSlices, (unsigned)batch),
+                     dim3(256), 0, st, x, (float*)scratch, (long long)rows, (int)cols);
+  hipLaunchKernelGGL(col_sum_fold_kernel, dim3((unsigned)((cols + 255)/256), (unsigned)batch), dim3(256),
+                     0, st, (const float*)scratch, out, (int)cols);
+  TG_OK(hipGetLastError());
+  return 0;
+}
 int brv_row_std(const float* x, float* out, int64_t rows, int64_t n, brv_stream_t stream) {
   if (rows < 1 || n < 2) return -1;
   hipLaunchKernelGGL(row_std_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x,

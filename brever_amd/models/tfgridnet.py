@@ -221,12 +221,18 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_
 
 
 def _column_sums(x, rows, cols, batch=1, lowp=False):
-    """(batch, rows, cols) -> (batch, cols): a ones-vector product (one pass over x; ``lowp``: on
-    the bf16 MFMA, the exact-fp32 one wastes 127 of its 128 tile rows at 1/16 of the rate)."""
-    ones = torch.ones(rows, dtype=torch.float32, device=x.device)
+    """(batch, rows, cols) -> (batch, cols). fp32: ``brv_col_sum`` (fixed order); bf16 tensors or
+    ``lowp``: a ones-vector product on the bf16 MFMA."""
     out = torch.empty(batch, cols, dtype=torch.float32, device=x.device)
-    _gemm(ones, x, out, batch, 1, cols, rows, rows, cols, cols, 0, rows*cols, cols,
-          lowp=lowp or x.dtype == torch.bfloat16)
+    if not lowp and x.dtype == torch.float32:
+        lib = hip.lib()
+        scratch = torch.empty(lib.brv_col_sum_scratch_bytes(batch, cols), dtype=torch.uint8,
+                              device=x.device)
+        hip.check(lib.brv_col_sum(hip.ptr(x), hip.ptr(out), hip.ptr(scratch), batch, rows, cols,
+                                  hip.stream()), 'brv_col_sum')
+        return out
+    ones = torch.ones(rows, dtype=torch.float32, device=x.device)
+    _gemm(ones, x, out, batch, 1, cols, rows, rows, cols, cols, 0, rows*cols, cols, lowp=True)
     return out
 
 

@@ -393,6 +393,11 @@ int brv_rownorm_backward(const float* x, const float* dy, const float* slope, co
                          const float* stats, float* dx, float* dgain, float* dbias,
                          float* dslope_rows, void* scratch, int64_t rows, int64_t n, int64_t inner,
                          int64_t groups, brv_stream_t stream);
+/* out (batch, cols) = column sums of x (batch, rows, cols), fp32, fixed summation order (the bias
+ * gradients of nn.Linear / nn.LSTM on row-major activations); scratch: brv_col_sum_scratch_bytes(). */
+int64_t brv_col_sum_scratch_bytes(int64_t batch, int64_t cols);
+int brv_col_sum(const float* x, float* out, void* scratch, int64_t batch, int64_t rows, int64_t cols,
+                brv_stream_t stream);
 int brv_row_std(const float* x, float* out, int64_t rows, int64_t n, brv_stream_t stream);
 int brv_row_scale(const float* x, const float* s, float* y, int64_t rows, int64_t n, int divide,
                   brv_stream_t stream);
