@@ -32,6 +32,7 @@ namespace {
 #define CM_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef CM_PF
@@ -150,7 +151,9 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
       if (r >= ROUNDS) continue;
       const int item = tid + r*256;
       if (item >= NITEMS) continue;
-      h8 v;
+      // the 8 values are converted as a vector: four v_cvt_pk_f16_f32 (element-wise casts compile
+      // to a conversion per element plus the packing ors)
+      f32x8 tv;
       if (folded) {
         const int c0 = chunk*CM_CK + kg_of[r]*8;
 #pragma unroll
@@ -158,13 +161,13 @@ __global__ __launch_bounds__(256, CM_OCC) void conv_mfma_kernel(ConvMfmaParams p
           float t = fold_tab[0][c0 + j]*stage[q][j] + fold_tab[1][c0 + j];
           const float ts = silu_f(t);
           t = p.in_silu ? ts : t;
-          v[j] = (_Float16)(pix_ok[r] ? t : 0.f);
+          tv[j] = pix_ok[r] ? t : 0.f;
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (_Float16)(pix_ok[r] ? stage[q][j] : 0.f);
+        for (int j = 0; j < 8; ++j) tv[j] = pix_ok[r] ? stage[q][j] : 0.f;
       }
-      patch[buf][item] = v;
+      patch[buf][item] = __builtin_convertvector(tv, h8);
     }
   };
 
