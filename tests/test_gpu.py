@@ -1365,6 +1365,14 @@ def test_rownorm_kernels_match_torch():
     zc = z.to(dev)
     hip.check(hip.lib().brv_row_std(hip.ptr(zc), hip.ptr(out), 3, 12345, hip.stream()), 'brv_row_std')
     assert torch.allclose(out.cpu(), z.std(dim=1), rtol=1e-6)
+    # column sums (bias gradients): fixed-order fp32 sums vs float64
+    m = torch.randn(2, 3001, 130, generator=gen)
+    md = m.to(dev)
+    cs = torch.empty(2, 130, device=dev)
+    scratch = torch.empty(hip.lib().brv_col_sum_scratch_bytes(2, 130), dtype=torch.uint8, device=dev)
+    hip.check(hip.lib().brv_col_sum(hip.ptr(md), hip.ptr(cs), hip.ptr(scratch), 2, 3001, 130,
+                                    hip.stream()), 'brv_col_sum')
+    assert torch.allclose(cs.cpu(), m.double().sum(1).float(), rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.gpu
