@@ -43,6 +43,10 @@ struct DwParams {
 // gradient block and vgrad_reduce_kernel folds the copies into the real gradient.
 constexpr int kReplicas = 64;
 
+#ifndef BRV_DW_NB
+#define BRV_DW_NB 4
+#endif
+constexpr int DW_NB = BRV_DW_NB;   // rows whose tap loads are in flight together (forward)
 constexpr int DW_TT_F = 32;    // forward: frames per workgroup (4 waves x 8 frames; 64 measured slower)
 constexpr int DW_TT_B = 128;   // backward: 4 waves x 32 frames (64: more per-channel atomics; 256: too few workgroups)
 
@@ -114,10 +118,10 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p) {
     const unsigned int coff = (unsigned int)(c0*2);
     const unsigned int row = (unsigned int)(p.Cp*2);
 #pragma unroll 1
-    for (int i0 = 0; i0 < DW_RPW; i0 += 4) {
-      uint4 raw[4][P];
+    for (int i0 = 0; i0 < DW_RPW; i0 += DW_NB) {
+      uint4 raw[DW_NB][P];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < DW_NB; ++u) {
         const int t = tw0 + i0 + u;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const DwParams p) {
       }
       float ls = 0.f, lq = 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < DW_NB; ++u) {
         const int t = tw0 + i0 + u;
         float acc[8];
         if (t - p.left >= 0 && t + (P - 1)*p.dil - p.left < T) {     // wave-uniform
