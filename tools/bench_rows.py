@@ -1,7 +1,8 @@
 """Throughput of the widened SURVEY.md section-8 rows on one GPU (BASELINE.json configs[0],
-[3], [4]); bench.py stays the Conv-TasNet headline. One JSON line per row.
+[3], [4] and the section-8f models TF-GridNet / SGMSE+ training); bench.py stays the Conv-TasNet
+headline. One JSON line per row.
 
-    python tools/bench_rows.py [--rows ffnn,dccrn,sgmse]
+    python tools/bench_rows.py [--rows ffnn,dccrn,tfgridnet,sgmse,sgmse_train]
 """
 import argparse
 import json
