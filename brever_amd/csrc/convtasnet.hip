@@ -801,6 +801,8 @@ int64_t brv_prof_collect(char* buf, int64_t buflen) {
   return (int64_t)out.size() + 1;
 }
 const char* brv_last_error(void) { return g_err.c_str(); }
+// other translation units of the library report through the same thread-local message
+void brv_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
 
 int64_t brv_ctn_param_count(const brv_ctn_config* cfg) {
   Layout l; if (l.init(cfg)) return -1; return l.n_params;

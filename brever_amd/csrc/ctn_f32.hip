@@ -1,0 +1,726 @@
+// Conv-TasNet with fp32 activations: the `use_amp=False` path (C ABI brv_ctn_f32_*).
+//
+// Reference being replaced: brever/models/convtasnet/convtasnet.py:66-97 run WITHOUT autocast
+// (`enhance(x, use_amp=False)` of scripts/test_model.py, `BreverTrainer(use_amp=False)`), i.e.
+// every tensor and every product in fp32. The bf16 path of convtasnet.hip is the throughput
+// path; this one is the precision path: channels-last fp32 tensors [item][frame][channel] with
+// no channel padding, every 1x1 convolution one product on the exact-fp32 MFMA (brv_gemm_f32,
+// v_mfma_f32_32x32x2_f32), everything between the products as plain HBM-bound fp32 kernels.
+// Global (non-causal) and cumulative (causal) layer norms share one formulation: a per-frame
+// table (mean_t, rstd_t) in the forward pass and (U_t, V_t) in the backward pass with
+//   d prelu_out[t][c] = e[t][c] gain[c] rstd_t + U_t + p[t][c] V_t,
+// where the tables are totals over the item's frames (gLN: nn.GroupNorm(1, C, eps=1e-8),
+// convtasnet.py:267) or prefix / suffix sums (cLN: modules/normalization.py:5-62). Frame sums
+// are fp32 over the channels of one frame, the scans over frames fp64.
+// Per-channel parameter gradients are reduced in two deterministic stages (row slices, then
+// a fold in slice order); the weight gradients are brv_gemm_f32 products accumulated into
+// the flat gradient.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/brever_hip.h"
+#include "common.cuh"
+
+using namespace brv;
+
+namespace {
+
+}  // namespace
+extern "C" void brv_internal_set_error(const char* msg);     // convtasnet.hip: feeds brv_last_error()
+namespace {
+int fail32(int code, const std::string& msg) { brv_internal_set_error(msg.c_str()); return code; }
+
+#define HIP_OK32(expr)                                                          \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess)                                                       \
+      return fail32((int)e_, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define OK32(expr) do { if (int r_ = (expr)) return r_; } while (0)
+
+inline long long up(long long x, long long a) { return (x + a - 1)/a*a; }
+
+struct Blk32 {
+  long long conv_w, conv_b, dconv_w, dconv_b, res_w, res_b, skip_w, skip_b,
+      n1_g, n1_b, n2_g, n2_b, prelu1, prelu2;
+};
+// parameter offsets in ConvTasNet.parameters() order (identical to the bf16 path)
+struct Lay32 {
+  int N, K, Bn, H, Sc, P, nb, S, hop, causal, layers;
+  long long enc_w, dec_w, ln_g, ln_b, bott_w, bott_b, tcn_prelu, out_w, out_b, n_params;
+  std::vector<Blk32> blk;
+  int init(const brv_ctn_config* c) {
+    if (!c) return fail32(-1, "null config");
+    if (c->filters < 1 || c->filter_length < 2 || c->bottleneck_channels < 1 ||
+        c->hidden_channels < 1 || c->skip_channels < 1 || c->layers < 1 || c->repeats < 1 ||
+        c->output_sources < 1 || c->kernel_size < 1)
+      return fail32(-1, "invalid Conv-TasNet hyper-parameters");
+    if (c->kernel_size > 7) return fail32(-2, "kernel_size must be <= 7 in the fp32 HIP path");
+    N = c->filters; K = c->filter_length; Bn = c->bottleneck_channels; H = c->hidden_channels;
+    Sc = c->skip_channels; P = c->kernel_size; layers = c->layers; nb = c->layers*c->repeats;
+    S = c->output_sources; hop = K/2; causal = c->causal != 0;
+    long long o = 0;
+    auto take = [&](long long n) { long long r = o; o += n; return r; };
+    enc_w = take((long long)N*K); dec_w = take((long long)N*K);
+    ln_g = take(N); ln_b = take(N);
+    bott_w = take((long long)Bn*N); bott_b = take(Bn);
+    blk.resize(nb);
+    for (int i = 0; i < nb; ++i) {
+      Blk32& b = blk[i];
+      b.conv_w = take((long long)H*Bn); b.conv_b = take(H);
+      b.dconv_w = take((long long)H*P); b.dconv_b = take(H);
+      if (i < nb - 1) { b.res_w = take((long long)Bn*H); b.res_b = take(Bn); }
+      else { b.res_w = -1; b.res_b = -1; }
+      b.skip_w = take((long long)Sc*H); b.skip_b = take(Sc);
+      b.n1_g = take(H); b.n1_b = take(H); b.n2_g = take(H); b.n2_b = take(H);
+      b.prelu1 = take(1); b.prelu2 = take(1);
+    }
+    tcn_prelu = take(1);
+    out_w = take((long long)S*N*Sc); out_b = take((long long)S*N);
+    n_params = o;
+    return 0;
+  }
+  long long frames(long long L) const {
+    const long long pad = ((K - L) % hop + hop) % hop;     // Python modulo (convtasnet.py:115-120)
+    const long long Lp = L + pad;
+    return Lp < K ? 0 : (Lp - K)/hop + 1;
+  }
+};
+
+constexpr int kSliceRows = 64;          // rows per workgroup of the per-channel reductions
+
+// workspace offsets in floats
+struct Ws32 {
+  long long Lp, wavep, w, wn, x, x_stride, z1, z2, z_stride, tab, tab_stride, skip, h, pre, dpre,
+      y, fr, dop, dy, dwm, act, G, e, dz, fsum, btab, part, part_floats, scalars, total;
+  void init(const Lay32& l, long long B, long long T, long long L) {
+    long long o = 0;
+    auto take = [&](long long n) { long long r = o; o += up(n, 64); return r; };
+    const long long BT = B*T;
+    Lp = (T - 1)*l.hop + l.K;
+    if (Lp < L) Lp = L;
+    const long long BS = B*l.S;
+    wavep = take(B*Lp);
+    w = take(BT*l.N); wn = take(BT*l.N);
+    x_stride = up(BT*l.Bn, 64); x = take(x_stride*l.nb);
+    z_stride = up(BT*l.H, 64); z1 = take(z_stride*l.nb); z2 = take(z_stride*l.nb);
+    tab_stride = up(BT*2, 64); tab = take(tab_stride*(1 + 2*l.nb));
+    skip = take(BT*l.Sc);
+    h = take(BT*l.H);
+    pre = take(BT*l.S*l.N);
+    y = take(BS*T*l.N);
+    fr = take(BS*T*l.K);
+    // backward
+    dop = take(BS*Lp);
+    dy = take(BS*T*l.N);
+    dpre = take(BT*l.S*l.N);
+    dwm = take(BT*l.N);
+    act = take(BT*l.Sc);
+    G = take(BT*(l.Bn + l.Sc));
+    const long long cmax = l.H > l.N ? l.H : l.N;
+    e = take(BT*cmax); dz = take(BT*cmax);
+    fsum = take(BT*2); btab = take(BT*2);
+    // partial sums of the per-channel reductions: slices x quantities (<= 2 + P + 1) x channels
+    const long long slices = (BT + kSliceRows - 1)/kSliceRows;
+    long long cq = (long long)(l.P + 1)*l.H;
+    if (2*cmax > cq) cq = 2*cmax;
+    if ((long long)l.S*l.N > cq) cq = (long long)l.S*l.N;
+    part_floats = slices*cq;
+    part = take(part_floats);
+    scalars = take(4096);
+    total = o;
+  }
+};
+
+// ---- small kernels ----------------------------------------------------------------------------
+__global__ void pad_rows_kernel(const float* src, float* dst, long long rows, long long L, long long Lp) {
+  const long long n = rows*Lp;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const long long r = i / Lp, l = i % Lp;
+    dst[i] = l < L ? src[r*L + l] : 0.f;
+  }
+}
+
+// per-frame sums of p = prelu(z) and p^2 over the C channels of a row; one wavefront per row
+__global__ __launch_bounds__(256) void f32_frame_sums_kernel(const float* z, const float* slope,
+                                                             float* fsum, long long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x*4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float a = slope ? *slope : 1.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = z[row*C + c];
+    const float p = (v > 0.f || !slope) ? v : a*v;
+    s1 += p; s2 = __builtin_fmaf(p, p, s2);
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { fsum[2*row] = s1; fsum[2*row + 1] = s2; }
+}
+
+__device__ __forceinline__ void scan2(double& a, double& b, double* scr, bool reverse) {
+  const int tid = threadIdx.x;
+  scr[tid] = a; scr[256 + tid] = b;
+  __syncthreads();
+  double sa = 0.0, sb = 0.0;
+  if (!reverse) { for (int i = 0; i < tid; ++i) { sa += scr[i]; sb += scr[256 + i]; } }
+  else { for (int i = tid + 1; i < 256; ++i) { sa += scr[i]; sb += scr[256 + i]; } }
+  __syncthreads();
+  a = sa; b = sb;
+}
+
+// forward table (mean_t, rstd_t): causal = statistics of frames <= t, else of the whole item
+__global__ __launch_bounds__(256) void f32_fwd_table_kernel(const float* fsum, float* table, int T,
+                                                            int C, float eps, int causal) {
+  __shared__ double scr[512];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int per = (T + 255)/256;
+  const int lo = min(T, tid*per), hi = min(T, lo + per);
+  const float* fs = fsum + (long long)b*T*2;
+  float* tb = table + (long long)b*T*2;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = lo; t < hi; ++t) { s1 += fs[2*t]; s2 += fs[2*t + 1]; }
+  if (causal) {
+    scan2(s1, s2, scr, false);
+    for (int t = lo; t < hi; ++t) {
+      s1 += fs[2*t]; s2 += fs[2*t + 1];
+      const double n = (double)C*(double)(t + 1);
+      const double mean = s1/n, var = s2/n - mean*mean;
+      tb[2*t] = (float)mean; tb[2*t + 1] = (float)(1.0/sqrt(var + (double)eps));
+    }
+  } else {
+    scr[tid] = s1; scr[256 + tid] = s2;
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < 256; ++i) { t1 += scr[i]; t2 += scr[256 + i]; }
+    const double n = (double)C*(double)T;
+    const double mean = t1/n;
+    double var = t2/n - mean*mean;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)mean, r = (float)(1.0/sqrt(var + (double)eps));
+    for (int t = lo; t < hi; ++t) { tb[2*t] = m; tb[2*t + 1] = r; }
+  }
+}
+
+// y = (prelu(z) - mean_t) rstd_t gain[c] + bias[c]
+__global__ void f32_norm_apply_kernel(const float* z, const float* slope, const float* table,
+                                      const float* gain, const float* bias, float* y,
+                                      long long rows, int C) {
+  const long long n = rows*C;
+  const float a = slope ? *slope : 1.f;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const long long row = i / C; const int c = (int)(i % C);
+    const float v = z[i];
+    const float p = (v > 0.f || !slope) ? v : a*v;
+    y[i] = (p - table[2*row])*table[2*row + 1]*gain[c] + bias[c];
+  }
+}
+
+// backward frame sums: A_t = sum_c e gain, B_t = sum_c e gain xhat
+__global__ __launch_bounds__(256) void f32_bwd_frame_sums_kernel(const float* e, const float* z,
+                                                                 const float* slope, const float* table,
+                                                                 const float* gain, float* fsum,
+                                                                 long long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x*4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float a = slope ? *slope : 1.f;
+  const float mean = table[2*row], rstd = table[2*row + 1];
+  float A = 0.f, Bq = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = z[row*C + c];
+    const float p = (v > 0.f || !slope) ? v : a*v;
+    const float xh = (p - mean)*rstd;
+    const float g = e[row*C + c]*gain[c];
+    A += g; Bq = __builtin_fmaf(g, xh, Bq);
+  }
+  A = wave_sum(A); Bq = wave_sum(Bq);
+  if (lane == 0) { fsum[2*row] = A; fsum[2*row + 1] = Bq; }
+}
+
+// backward table (U_t, V_t): dp = e gain rstd_t + U_t + p V_t, with per-frame terms
+//   u_t = (-rstd_t A_t + mean_t rstd_t^2 B_t)/n_t,  v_t = -rstd_t^2 B_t/n_t
+// summed over frames >= t (causal, n_t = C (t+1)) or over the whole item (n_t = C T).
+__global__ __launch_bounds__(256) void f32_bwd_table_kernel(const float* fsum, const float* ftab,
+                                                            float* btab, int T, int C, int causal) {
+  __shared__ double scr[512];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int per = (T + 255)/256;
+  const int lo = min(T, tid*per), hi = min(T, lo + per);
+  const float* fs = fsum + (long long)b*T*2;
+  const float* ft = ftab + (long long)b*T*2;
+  float* tb = btab + (long long)b*T*2;
+  auto terms = [&](int t, double& u, double& v) {
+    const double n = causal ? (double)C*(double)(t + 1) : (double)C*(double)T;
+    const double mean = ft[2*t], r = ft[2*t + 1];
+    const double A = fs[2*t], Bq = fs[2*t + 1];
+    u = (-r*A + mean*r*r*Bq)/n;
+    v = -r*r*Bq/n;
+  };
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = lo; t < hi; ++t) { double u, v; terms(t, u, v); s1 += u; s2 += v; }
+  if (causal) {
+    scan2(s1, s2, scr, true);
+    for (int t = hi - 1; t >= lo; --t) {
+      double u, v; terms(t, u, v);
+      s1 += u; s2 += v;
+      tb[2*t] = (float)s1; tb[2*t + 1] = (float)s2;
+    }
+  } else {
+    scr[tid] = s1; scr[256 + tid] = s2;
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+    for (int i = 0; i < 256; ++i) { t1 += scr[i]; t2 += scr[256 + i]; }
+    for (int t = lo; t < hi; ++t) { tb[2*t] = (float)t1; tb[2*t + 1] = (float)t2; }
+  }
+}
+
+// dz = prelu'(z) (e gain rstd_t + U_t + p V_t) (+ add); slope gradient partials per workgroup
+__global__ __launch_bounds__(256) void f32_norm_bwd_apply_kernel(
+    const float* e, const float* z, const float* slope, const float* ftab, const float* btab,
+    const float* gain, const float* add, float* dz, float* dslope_part, long long rows, int C) {
+  __shared__ float scr[8];
+  const long long n = rows*C;
+  const float a = slope ? *slope : 1.f;
+  float da = 0.f;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const long long row = i / C; const int c = (int)(i % C);
+    const float v = z[i];
+    const bool pos = v > 0.f || !slope;
+    const float p = pos ? v : a*v;
+    const float dp = e[i]*gain[c]*ftab[2*row + 1] + btab[2*row] + p*btab[2*row + 1];
+    float o = pos ? dp : a*dp;
+    if (!pos) da = __builtin_fmaf(dp, v, da);
+    if (add) o += add[i];
+    dz[i] = o;
+  }
+  if (dslope_part) {
+    const float s = block_sum(da, scr);
+    if (threadIdx.x == 0) dslope_part[blockIdx.x] = s;
+  }
+}
+
+// ---- per-channel reductions: thread = channel, workgroup = slice of kSliceRows rows ----------
+// mode 0: q0 = sum src                                   (bias gradients)
+// mode 1: q0 = sum e xhat, q1 = sum e                    (norm gain / bias gradients)
+// mode 2: q_k = sum_t dz2[t] h1[t + k dil - left] (k < P), q_P = sum dz2   (depthwise taps / bias)
+struct Red32 {
+  int mode; const float* a; const float* z; const float* slope; const float* table;
+  long long rows; int C, ld, T, P, dil, left; float* part;
+};
+__global__ __launch_bounds__(256) void f32_chan_reduce_kernel(const Red32 p) {
+  const long long r0 = (long long)blockIdx.x*kSliceRows;
+  const long long r1 = r0 + kSliceRows < p.rows ? r0 + kSliceRows : p.rows;
+  const int nq = p.mode == 0 ? 1 : (p.mode == 1 ? 2 : p.P + 1);
+  const float sl = p.slope ? *p.slope : 1.f;
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    float q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+      const float av = p.a[r*p.ld + c];
+      if (p.mode == 0) {
+        q[0] += av;
+      } else if (p.mode == 1) {
+        const float v = p.z[r*p.C + c];
+        const float pv = (v > 0.f || !p.slope) ? v : sl*v;
+        q[0] = __builtin_fmaf(av, (pv - p.table[2*r])*p.table[2*r + 1], q[0]);
+        q[1] += av;
+      } else {
+        const long long b = r / p.T; const int t = (int)(r % p.T);
+        for (int k = 0; k < p.P; ++k) {
+          const int ti = t + k*p.dil - p.left;
+          if (ti >= 0 && ti < p.T) q[k] = __builtin_fmaf(av, p.z[(b*p.T + ti)*p.C + c], q[k]);
+        }
+        q[p.P] += av;
+      }
+    }
+    for (int k = 0; k < nq; ++k) p.part[((long long)blockIdx.x*nq + k)*p.C + c] = q[k];
+  }
+}
+// dst[c*stride + off_k] += sum over slices, in slice order
+__global__ void f32_chan_fold_kernel(const float* part, int slices, int nq, int C, float* d0,
+                                     float* d1, int stride0, int P) {
+  // quantity k of channel c goes to: mode-agnostic mapping given by (d0, stride0) for k < P and d1 for k == P
+  const int i = blockIdx.x*256 + threadIdx.x;
+  if (i >= nq*C) return;
+  const int k = i / C, c = i % C;
+  float s = 0.f;
+  for (int sidx = 0; sidx < slices; ++sidx) s += part[((long long)sidx*nq + k)*C + c];
+  if (k < P) d0[(long long)c*stride0 + k] += s; else d1[c] += s;
+}
+__global__ void f32_fold_scalar_kernel(const float* part, int n, float* dst) {
+  __shared__ float scr[8];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  const float r = block_sum(s, scr);
+  if (threadIdx.x == 0) *dst += r;
+}
+
+// depthwise dilated convolution on the normalised tensor h: z2[t][c] = bias[c] + sum_k w[c][k] h[t + k dil - left][c]
+__global__ void f32_dw_fwd_kernel(const float* h, const float* taps, const float* bias, float* z2,
+                                  long long B, int T, int C, int P, int dil, int left) {
+  const long long n = B*T*C;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const int c = (int)(i % C); const long long row = i / C;
+    const int t = (int)(row % T); const long long b = row / T;
+    float acc = bias[c];
+    for (int k = 0; k < P; ++k) {
+      const int ti = t + k*dil - left;
+      if (ti >= 0 && ti < T) acc = __builtin_fmaf(taps[c*P + k], h[(b*T + ti)*C + c], acc);
+    }
+    z2[i] = acc;
+  }
+}
+// transposed stencil: e1[t][c] = sum_k w[c][k] dz2[t - k dil + left][c]
+__global__ void f32_dw_bwd_kernel(const float* dz2, const float* taps, float* e1, long long B, int T,
+                                  int C, int P, int dil, int left) {
+  const long long n = B*T*C;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const int c = (int)(i % C); const long long row = i / C;
+    const int t = (int)(row % T); const long long b = row / T;
+    float acc = 0.f;
+    for (int k = 0; k < P; ++k) {
+      const int to = t - k*dil + left;
+      if (to >= 0 && to < T) acc = __builtin_fmaf(taps[c*P + k], dz2[(b*T + to)*C + c], acc);
+    }
+    e1[i] = acc;
+  }
+}
+
+// dst[r][c] = (src ? src[r*lds + c] : (init ? 0 : dst)) + bias[c]
+__global__ void f32_bias_rows_kernel(float* dst, int ldd, const float* src, int lds, const float* bias,
+                                     long long rows, int C, int init) {
+  const long long n = rows*C;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const long long r = i / C; const int c = (int)(i % C);
+    const float base = src ? src[r*lds + c] : (init ? 0.f : dst[r*ldd + c]);
+    dst[r*ldd + c] = base + bias[c];
+  }
+}
+__global__ void f32_prelu_kernel(const float* x, const float* slope, float* y, long long n) {
+  const float a = *slope;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const float v = x[i];
+    y[i] = v > 0.f ? v : a*v;
+  }
+}
+// gskip = da * prelu'(skip) written with row stride ldg; slope-gradient partial per workgroup
+__global__ __launch_bounds__(256) void f32_prelu_bwd_kernel(const float* da, const float* x,
+                                                            const float* slope, float* g, int ldg,
+                                                            float* part, long long rows, int C) {
+  __shared__ float scr[8];
+  const float a = *slope;
+  const long long n = rows*C;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const long long r = i / C; const int c = (int)(i % C);
+    const float v = x[i], d = da[i];
+    const bool pos = v > 0.f;
+    g[r*ldg + c] = pos ? d : a*d;
+    if (!pos) acc = __builtin_fmaf(d, v, acc);
+  }
+  const float s = block_sum(acc, scr);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// m = sigmoid(pre) in place; y[(b S + s)][t][n] = m w[b][t][n]      (convtasnet.py:144-151,199)
+__global__ void f32_mask_kernel(float* pre, const float* w, float* y, long long B, int T, int S, int N) {
+  const long long n = B*T*S*N;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const int c = (int)(i % N); long long q = i / N;
+    const int s = (int)(q % S); q /= S;
+    const int t = (int)(q % T); const long long b = q / T;
+    const float m = 1.f/(1.f + __expf(-pre[i]));
+    pre[i] = m;
+    y[((b*S + s)*T + t)*N + c] = m*w[(b*T + t)*N + c];
+  }
+}
+// dpre = dy w m (1 - m) (over pre's layout), dwm[b][t][n] = sum_s dy m
+__global__ void f32_mask_bwd_kernel(const float* dy, const float* m, const float* w, float* dpre,
+                                    float* dwm, long long B, int T, int S, int N) {
+  const long long n = B*T*N;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const int c = (int)(i % N); const long long row = i / N;
+    const int t = (int)(row % T); const long long b = row / T;
+    const float wv = w[i];
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float d = dy[((b*S + s)*T + t)*N + c];
+      const long long j = (row*S + s)*N + c;
+      const float mv = m[j];
+      dpre[j] = d*wv*mv*(1.f - mv);
+      acc = __builtin_fmaf(d, mv, acc);
+    }
+    dwm[i] = acc;
+  }
+}
+// overlap-add of the decoder frames fr[(bs)][t][K] with hop K/2, cropped to L (convtasnet.py:71,144-151)
+__global__ void f32_ola_kernel(const float* fr, float* out, long long BS, int T, int K, int hop, long long L) {
+  const long long n = BS*L;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const long long bs = i / L, l = i % L;
+    float acc = 0.f;
+    long long t_hi = l / hop;
+    for (long long t = t_hi; t >= 0 && l - t*hop < K; --t)
+      if (t < T) acc += fr[(bs*T + t)*K + (l - t*hop)];
+    out[i] = acc;
+  }
+}
+__global__ void f32_add_kernel(float* dst, const float* a, long long n) {
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256)
+    dst[i] += a[i];
+}
+
+inline int grid_for(long long n) {
+  long long g = (n + 255)/256;
+  if (g > 65535*4) g = 65535*4;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+constexpr int kSlopeBlocks = 1024;
+
+struct Ctx32 {
+  const Lay32& l; const Ws32& ws; float* base; const float* params; float* grads;
+  long long B, T, L, BT; hipStream_t st;
+  float* f(long long off) const { return base + off; }
+  float* tab(int i) const { return base + ws.tab + ws.tab_stride*i; }
+  float* xb(int i) const { return base + ws.x + ws.x_stride*i; }
+  float* z1b(int i) const { return base + ws.z1 + ws.z_stride*i; }
+  float* z2b(int i) const { return base + ws.z2 + ws.z_stride*i; }
+};
+
+int gemm32(const Ctx32& c, const float* a, const float* b, float* d, long long batch, long long M,
+           long long N, long long K, long long lda, long long ldb, long long ldd, long long abs_,
+           long long bbs, long long dbs, int ta, int tb, long long kbatch, long long akbs,
+           long long bkbs, const float* bias, int acc) {
+  const int r = brv_gemm_f32(a, b, d, batch, M, N, K, lda, ldb, ldd, abs_, bbs, dbs, ta, tb, kbatch,
+                             akbs, bkbs, bias, acc, (brv_stream_t)c.st);
+  if (r) return fail32(r, "brv_gemm_f32 failed inside the fp32 Conv-TasNet path");
+  return 0;
+}
+// rows-major 1x1 convolution: d[rows][n] = a[rows][k] W[n][k]^T (+ col bias | accumulate)
+int conv1x1(const Ctx32& c, const float* a, int lda, const float* W, int N, int K, float* d, int ldd,
+            const float* bias, int acc) {
+  return gemm32(c, a, W, d, 1, c.BT, N, K, lda, K, ldd, 0, 0, 0, 0, 1, 1, 0, 0, bias, acc);
+}
+// data gradient: d[rows][k] (+)= g[rows][n] W[n][k]
+int conv1x1_dgrad(const Ctx32& c, const float* g, int ldg, const float* W, int N, int K, float* d,
+                  int ldd, int acc) {
+  return gemm32(c, g, W, d, 1, c.BT, K, N, ldg, K, ldd, 0, 0, 0, 0, 0, 1, 0, 0, nullptr, acc);
+}
+// weight gradient: dW[n][k] += sum_rows g[rows][n] a[rows][k]
+int conv1x1_wgrad(const Ctx32& c, const float* g, int ldg, const float* a, int lda, int N, int K,
+                  float* dW) {
+  return gemm32(c, g, a, dW, 1, N, K, c.BT, ldg, lda, K, 0, 0, 0, 1, 0, 1, 0, 0, nullptr, 1);
+}
+
+int norm_forward(const Ctx32& c, const float* z, const float* slope, float* table, int C) {
+  const long long rows = c.BT;
+  float* fsum = c.f(c.ws.fsum);
+  hipLaunchKernelGGL(f32_frame_sums_kernel, dim3((unsigned)((rows + 3)/4)), dim3(256), 0, c.st, z,
+                     slope, fsum, rows, C);
+  hipLaunchKernelGGL(f32_fwd_table_kernel, dim3((unsigned)c.B), dim3(256), 0, c.st, fsum, table,
+                     (int)c.T, C, 1e-8f, c.l.causal);
+  HIP_OK32(hipGetLastError());
+  return 0;
+}
+int norm_apply(const Ctx32& c, const float* z, const float* slope, const float* table,
+               const float* gain, const float* bias, float* y, int C) {
+  hipLaunchKernelGGL(f32_norm_apply_kernel, dim3(grid_for(c.BT*C)), dim3(256), 0, c.st, z, slope,
+                     table, gain, bias, y, c.BT, C);
+  HIP_OK32(hipGetLastError());
+  return 0;
+}
+int chan_reduce(const Ctx32& c, Red32 r, float* d0, int stride0, int nq_main, float* d1) {
+  const int slices = (int)((r.rows + kSliceRows - 1)/kSliceRows);
+  const int nq = r.mode == 0 ? 1 : (r.mode == 1 ? 2 : r.P + 1);
+  r.part = c.f(c.ws.part);
+  if ((long long)slices*nq*r.C > c.ws.part_floats) return fail32(-1, "fp32 path: reduction scratch too small");
+  hipLaunchKernelGGL(f32_chan_reduce_kernel, dim3(slices), dim3(256), 0, c.st, r);
+  hipLaunchKernelGGL(f32_chan_fold_kernel, dim3((nq*r.C + 255)/256), dim3(256), 0, c.st, r.part,
+                     slices, nq, r.C, d0, d1, stride0, nq_main);
+  HIP_OK32(hipGetLastError());
+  return 0;
+}
+int col_sum(const Ctx32& c, const float* src, int ld, int C, float* dst) {
+  Red32 r; memset(&r, 0, sizeof(r));
+  r.mode = 0; r.a = src; r.rows = c.BT; r.C = C; r.ld = ld;
+  return chan_reduce(c, r, dst, 1, 0, dst);       // k = 0 >= P = 0 -> d1
+}
+// gradient through y = norm(prelu(z)): e (wrt y) -> dz (wrt z), gain / bias / slope gradients
+int norm_backward(const Ctx32& c, const float* e, const float* z, const float* slope_p,
+                  const float* table, const float* gain, int C, const float* add, float* dz,
+                  float* dgain, float* dbias, float* dslope) {
+  const long long rows = c.BT;
+  Red32 r; memset(&r, 0, sizeof(r));
+  r.mode = 1; r.a = e; r.z = z; r.slope = slope_p; r.table = table; r.rows = rows; r.C = C; r.ld = C;
+  // quantity 0 -> dgain (stride 1, "P" = 1), quantity 1 -> dbias
+  OK32(chan_reduce(c, r, dgain, 1, 1, dbias));
+  float* fsum = c.f(c.ws.fsum); float* btab = c.f(c.ws.btab);
+  hipLaunchKernelGGL(f32_bwd_frame_sums_kernel, dim3((unsigned)((rows + 3)/4)), dim3(256), 0, c.st, e,
+                     z, slope_p, table, gain, fsum, rows, C);
+  hipLaunchKernelGGL(f32_bwd_table_kernel, dim3((unsigned)c.B), dim3(256), 0, c.st, fsum, table, btab,
+                     (int)c.T, C, c.l.causal);
+  int g = grid_for(rows*C);
+  if (g > kSlopeBlocks) g = kSlopeBlocks;
+  float* part = c.f(c.ws.scalars);
+  hipLaunchKernelGGL(f32_norm_bwd_apply_kernel, dim3(g), dim3(256), 0, c.st, e, z, slope_p, table, btab,
+                     gain, add, dz, dslope ? part : nullptr, rows, C);
+  if (dslope) hipLaunchKernelGGL(f32_fold_scalar_kernel, dim3(1), dim3(256), 0, c.st, part, g, dslope);
+  HIP_OK32(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t brv_ctn_f32_workspace_bytes(const brv_ctn_config* cfg, int64_t batch, int64_t length) {
+  Lay32 l; if (l.init(cfg)) return -1;
+  Ws32 ws; ws.init(l, batch, l.frames(length), length);
+  return ws.total*4;
+}
+
+int brv_ctn_f32_forward(const brv_ctn_config* cfg, const float* params, void* workspace,
+                        const float* wave, float* out, int64_t batch, int64_t length,
+                        brv_stream_t stream) {
+  Lay32 l; OK32(l.init(cfg));
+  const long long B = batch, L = length, T = l.frames(L);
+  if (B < 1 || T < 1) return fail32(-1, "empty batch or input shorter than one frame");
+  Ws32 ws; ws.init(l, B, T, L);
+  Ctx32 c{l, ws, (float*)workspace, params, nullptr, B, T, L, B*T, (hipStream_t)stream};
+  const long long BT = c.BT;
+  hipStream_t st = c.st;
+  float* w = c.f(ws.w); float* wn = c.f(ws.wn); float* h = c.f(ws.h); float* skip = c.f(ws.skip);
+  // encoder: right-padded frames (row stride hop) x filterbank
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(B*ws.Lp)), dim3(256), 0, st, wave, c.f(ws.wavep),
+                     B, L, ws.Lp);
+  OK32(gemm32(c, c.f(ws.wavep), params + l.enc_w, w, B, T, l.N, l.K, l.hop, l.K, l.N, ws.Lp, 0,
+              T*l.N, 0, 1, 1, 0, 0, nullptr, 0));
+  OK32(norm_forward(c, w, nullptr, c.tab(0), l.N));
+  OK32(norm_apply(c, w, nullptr, c.tab(0), params + l.ln_g, params + l.ln_b, wn, l.N));
+  OK32(conv1x1(c, wn, l.N, params + l.bott_w, l.Bn, l.N, c.xb(0), l.Bn, params + l.bott_b, 2));
+  for (int i = 0; i < l.nb; ++i) {
+    const Blk32& b = l.blk[i];
+    const bool has_res = i < l.nb - 1;
+    const int dil = 1 << (i % l.layers);
+    const int total = (l.P - 1)*dil;
+    const int left = l.causal ? total : total/2;
+    OK32(conv1x1(c, c.xb(i), l.Bn, params + b.conv_w, l.H, l.Bn, c.z1b(i), l.H, params + b.conv_b, 2));
+    OK32(norm_forward(c, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), l.H));
+    OK32(norm_apply(c, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), params + b.n1_g, params + b.n1_b, h, l.H));
+    hipLaunchKernelGGL(f32_dw_fwd_kernel, dim3(grid_for(BT*l.H)), dim3(256), 0, st, h,
+                       params + b.dconv_w, params + b.dconv_b, c.z2b(i), B, (int)T, l.H, l.P, dil, left);
+    OK32(norm_forward(c, c.z2b(i), params + b.prelu2, c.tab(2 + 2*i), l.H));
+    OK32(norm_apply(c, c.z2b(i), params + b.prelu2, c.tab(2 + 2*i), params + b.n2_g, params + b.n2_b, h, l.H));
+    if (has_res) {
+      hipLaunchKernelGGL(f32_bias_rows_kernel, dim3(grid_for(BT*l.Bn)), dim3(256), 0, st, c.xb(i + 1),
+                         l.Bn, c.xb(i), l.Bn, params + b.res_b, BT, l.Bn, 0);
+      OK32(conv1x1(c, h, l.H, params + b.res_w, l.Bn, l.H, c.xb(i + 1), l.Bn, nullptr, 1));
+    }
+    hipLaunchKernelGGL(f32_bias_rows_kernel, dim3(grid_for(BT*l.Sc)), dim3(256), 0, st, skip, l.Sc,
+                       (const float*)nullptr, 0, params + b.skip_b, BT, l.Sc, i == 0 ? 1 : 0);
+    OK32(conv1x1(c, h, l.H, params + b.skip_w, l.Sc, l.H, skip, l.Sc, nullptr, 1));
+  }
+  float* act = c.f(ws.act); float* pre = c.f(ws.pre); float* y = c.f(ws.y); float* fr = c.f(ws.fr);
+  hipLaunchKernelGGL(f32_prelu_kernel, dim3(grid_for(BT*l.Sc)), dim3(256), 0, st, skip,
+                     params + l.tcn_prelu, act, BT*l.Sc);
+  OK32(conv1x1(c, act, l.Sc, params + l.out_w, l.S*l.N, l.Sc, pre, l.S*l.N, params + l.out_b, 2));
+  hipLaunchKernelGGL(f32_mask_kernel, dim3(grid_for(BT*l.S*l.N)), dim3(256), 0, st, pre, w, y, B,
+                     (int)T, l.S, l.N);
+  // decoder: frames = y dec_w (N x K), overlap-add
+  OK32(gemm32(c, y, params + l.dec_w, fr, 1, B*l.S*T, l.K, l.N, l.N, l.K, l.K, 0, 0, 0, 0, 0, 1, 0, 0,
+              nullptr, 0));
+  hipLaunchKernelGGL(f32_ola_kernel, dim3(grid_for(B*l.S*L)), dim3(256), 0, st, fr, out, B*l.S,
+                     (int)T, l.K, l.hop, L);
+  HIP_OK32(hipGetLastError());
+  return 0;
+}
+
+int brv_ctn_f32_backward(const brv_ctn_config* cfg, const float* params, void* workspace,
+                         const float* wave, const float* d_out, float* grads, int64_t batch,
+                         int64_t length, brv_stream_t stream) {
+  Lay32 l; OK32(l.init(cfg));
+  const long long B = batch, L = length, T = l.frames(L);
+  if (B < 1 || T < 1) return fail32(-1, "empty batch or input shorter than one frame");
+  Ws32 ws; ws.init(l, B, T, L);
+  Ctx32 c{l, ws, (float*)workspace, params, grads, B, T, L, B*T, (hipStream_t)stream};
+  const long long BT = c.BT, BS = B*l.S;
+  hipStream_t st = c.st;
+  float* w = c.f(ws.w); float* wn = c.f(ws.wn); float* h = c.f(ws.h); float* skip = c.f(ws.skip);
+  float* act = c.f(ws.act); float* m = c.f(ws.pre); float* y = c.f(ws.y);
+  float* dop = c.f(ws.dop); float* dy = c.f(ws.dy); float* dwm = c.f(ws.dwm);
+  float* dpre = c.f(ws.dpre);
+  float* G = c.f(ws.G); float* e = c.f(ws.e); float* dz = c.f(ws.dz);
+  const int ldg = l.Bn + l.Sc;
+  float* part = c.f(ws.scalars);
+  // decoder: d frames = framing of the padded d_out; dy = d frames x dec_w^T; dec_w gradient
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(BS*ws.Lp)), dim3(256), 0, st, d_out, dop, BS, L, ws.Lp);
+  OK32(gemm32(c, dop, params + l.dec_w, dy, BS, T, l.N, l.K, l.hop, l.K, l.N, ws.Lp, 0, T*l.N, 0, 1,
+              1, 0, 0, nullptr, 0));
+  OK32(gemm32(c, y, dop, grads + l.dec_w, 1, l.N, l.K, T, l.N, l.hop, l.K, 0, 0, 0, 1, 0, BS, T*l.N,
+              ws.Lp, nullptr, 1));
+  // mask backward: gradient wrt the mask logits and the mask-path term of the gradient wrt w
+  hipLaunchKernelGGL(f32_mask_bwd_kernel, dim3(grid_for(BT*l.N)), dim3(256), 0, st, dy, m, w, dpre, dwm,
+                     B, (int)T, l.S, l.N);
+  // output conv: weight / bias gradients against prelu(skip), data gradient, PReLU backward
+  OK32(conv1x1_wgrad(c, dpre, l.S*l.N, act, l.Sc, l.S*l.N, l.Sc, grads + l.out_w));
+  OK32(col_sum(c, dpre, l.S*l.N, l.S*l.N, grads + l.out_b));
+  OK32(conv1x1_dgrad(c, dpre, l.S*l.N, params + l.out_w, l.S*l.N, l.Sc, e, l.Sc, 0));
+  {
+    int g = grid_for(BT*l.Sc); if (g > kSlopeBlocks) g = kSlopeBlocks;
+    hipLaunchKernelGGL(f32_prelu_bwd_kernel, dim3(g), dim3(256), 0, st, e, skip, params + l.tcn_prelu,
+                       G + l.Bn, ldg, part, BT, l.Sc);
+    hipLaunchKernelGGL(f32_fold_scalar_kernel, dim3(1), dim3(256), 0, st, part, g, grads + l.tcn_prelu);
+  }
+  for (int i = l.nb - 1; i >= 0; --i) {
+    const Blk32& b = l.blk[i];
+    const bool has_res = i < l.nb - 1;
+    const int dil = 1 << (i % l.layers);
+    const int total = (l.P - 1)*dil;
+    const int left = l.causal ? total : total/2;
+    // h2 again; [res | skip] weight / bias gradients; data gradient -> e (wrt h2)
+    OK32(norm_apply(c, c.z2b(i), params + b.prelu2, c.tab(2 + 2*i), params + b.n2_g, params + b.n2_b, h, l.H));
+    OK32(conv1x1_wgrad(c, G + l.Bn, ldg, h, l.H, l.Sc, l.H, grads + b.skip_w));
+    OK32(col_sum(c, G + l.Bn, ldg, l.Sc, grads + b.skip_b));
+    OK32(conv1x1_dgrad(c, G + l.Bn, ldg, params + b.skip_w, l.Sc, l.H, e, l.H, 0));
+    if (has_res) {
+      OK32(conv1x1_wgrad(c, G, ldg, h, l.H, l.Bn, l.H, grads + b.res_w));
+      OK32(col_sum(c, G, ldg, l.Bn, grads + b.res_b));
+      OK32(conv1x1_dgrad(c, G, ldg, params + b.res_w, l.Bn, l.H, e, l.H, 1));
+    }
+    OK32(norm_backward(c, e, c.z2b(i), params + b.prelu2, c.tab(2 + 2*i), params + b.n2_g, l.H, nullptr,
+                       dz, grads + b.n2_g, grads + b.n2_b, grads + b.prelu2));
+    // depthwise conv: taps / bias gradients against h1, transposed stencil -> e (wrt h1)
+    OK32(norm_apply(c, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), params + b.n1_g, params + b.n1_b, h, l.H));
+    {
+      Red32 r; memset(&r, 0, sizeof(r));
+      r.mode = 2; r.a = dz; r.z = h; r.rows = BT; r.C = l.H; r.ld = l.H; r.T = (int)T; r.P = l.P;
+      r.dil = dil; r.left = left;
+      OK32(chan_reduce(c, r, grads + b.dconv_w, l.P, l.P, grads + b.dconv_b));
+    }
+    hipLaunchKernelGGL(f32_dw_bwd_kernel, dim3(grid_for(BT*l.H)), dim3(256), 0, st, dz,
+                       params + b.dconv_w, e, B, (int)T, l.H, l.P, dil, left);
+    OK32(norm_backward(c, e, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), params + b.n1_g, l.H, nullptr,
+                       dz, grads + b.n1_g, grads + b.n1_b, grads + b.prelu1));
+    // first 1x1 conv: weight / bias gradients, data gradient (+ residual path) -> G[:, :Bn]
+    OK32(conv1x1_wgrad(c, dz, l.H, c.xb(i), l.Bn, l.H, l.Bn, grads + b.conv_w));
+    OK32(col_sum(c, dz, l.H, l.H, grads + b.conv_b));
+    OK32(conv1x1_dgrad(c, dz, l.H, params + b.conv_w, l.H, l.Bn, G, ldg, has_res ? 1 : 0));
+  }
+  // bottleneck conv, first layer norm, encoder
+  OK32(conv1x1_wgrad(c, G, ldg, wn, l.N, l.Bn, l.N, grads + l.bott_w));
+  OK32(col_sum(c, G, ldg, l.Bn, grads + l.bott_b));
+  OK32(conv1x1_dgrad(c, G, ldg, params + l.bott_w, l.Bn, l.N, e, l.N, 0));
+  OK32(norm_backward(c, e, w, nullptr, c.tab(0), params + l.ln_g, l.N, dwm, dz, grads + l.ln_g,
+                     grads + l.ln_b, nullptr));
+  OK32(gemm32(c, dz, c.f(ws.wavep), grads + l.enc_w, 1, l.N, l.K, T, l.N, l.hop, l.K, 0, 0, 0, 1, 0, B,
+              T*l.N, ws.Lp, nullptr, 1));
+  HIP_OK32(hipGetLastError());
+  (void)wave; (void)wn;
+  return 0;
+}
+
+}  // extern "C"

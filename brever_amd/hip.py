@@ -45,6 +45,11 @@ SIGNATURES = {
     'brv_ctn_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                         _c_ptr, _c_ptr, _c_i64, _c_i64,
                                         _c_ptr]),
+    'brv_ctn_f32_workspace_bytes': (_c_i64, [_c_ptr, _c_i64, _c_i64]),
+    'brv_ctn_f32_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                           _c_i64, _c_i64, _c_ptr]),
+    'brv_ctn_f32_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                            _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_loss_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_snr_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
                                        _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),

@@ -16,9 +16,14 @@ Two ways in:
 * ``train_step`` short-circuits autograd: forward -> SNR loss -> backward ->
   [gradient all-reduce hook] -> fused clip + Adam, all on flat buffers.
 
-Compute dtype: bf16 storage / MFMA operands with fp32 accumulation, statistics
-and master weights, whatever ``use_amp`` says (the reference's GPU branch would
-use fp16 + GradScaler, convtasnet.py:81; the scaler is not needed for bf16).
+Compute dtype follows ``use_amp`` like the reference's autocast switch
+(convtasnet.py:78-97): ``use_amp=True`` = bf16 storage / MFMA operands with fp32
+accumulation, statistics and master weights (``brv_ctn_*``; the reference's GPU
+branch would use fp16 + GradScaler, convtasnet.py:81 -- bf16 needs no scaler);
+``use_amp=False`` = fp32 activations and exact-fp32 MFMA products
+(``brv_ctn_f32_*``), the precision of ``enhance(x)`` in scripts/test_model.py
+and of ``BreverTrainer(use_amp=False)``. A bare ``model(x)`` is fp32 unless it
+runs under ``torch.autocast``.
 """
 import torch
 import torch.nn as nn
@@ -105,26 +110,27 @@ class _ConvTasNetFunction(torch.autograd.Function):
     """wave (B, L) -> (B, S, L) with gradients for every parameter."""
 
     @staticmethod
-    def forward(ctx, model, wave, *params):
-        out = model._hip_forward(wave)
+    def forward(ctx, model, wave, amp, *params):
+        out = model._hip_forward(wave, amp)
         ctx.model = model
         ctx.wave = wave
-        ctx.version = model._ws_version
+        ctx.amp = amp
+        ctx.version = model._ws_version[amp]
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         model = ctx.model
-        if ctx.version != model._ws_version:
+        if ctx.version != model._ws_version[ctx.amp]:
             raise RuntimeError(
                 'the activation workspace was overwritten by a later forward; '
                 'call backward before running the model again'
             )
-        flat_grad = torch.zeros_like(model._flat)
-        model._hip_backward(ctx.wave, d_out, flat_grad)
+        flat_grad = model._autograd_buffer()
+        model._hip_backward(ctx.wave, d_out, flat_grad, ctx.amp)
         grads = tuple(flat_grad[off:off + p.numel()].view(p.shape)
                       for p, off in model._offsets)
-        return (None, None) + grads
+        return (None, None, None) + grads
 
 
 @ModelRegistry.register('convtasnet')
@@ -165,10 +171,13 @@ class ConvTasNet(BreverBaseModel):
         self._offsets = []
         self._prepared = None
         self._prepared_dirty = True
-        self._workspace = None
-        self._ws_key = None
-        self._ws_version = 0
+        self._workspace = {}
+        self._ws_key = {}
+        self._ws_version = {True: 0, False: 0}
         self._grad_sync = None
+        self._amp = False
+        self._ag_grad = None
+        self._step_bufs = None
         self._flatten()
 
         self.optimizer = self.init_optimizer(optimizer, lr=learning_rate)
@@ -194,8 +203,10 @@ class ConvTasNet(BreverBaseModel):
         self._offsets = offsets
         self._prepared = None
         self._prepared_dirty = True
-        self._workspace = None
-        self._ws_key = None
+        self._workspace = {}
+        self._ws_key = {}
+        self._ag_grad = None
+        self._step_bufs = None
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -300,48 +311,83 @@ class ConvTasNet(BreverBaseModel):
                 hip.stream()), 'brv_ctn_prepare')
             self._prepared_dirty = False
 
-    def _get_workspace(self, B, L):
+    def _get_workspace(self, B, L, amp=True):
+        """Activation workspace of one precision (``amp``: bf16 path, else fp32)."""
+        amp = bool(amp)
         key = (B, L, self._flat.device)
-        if self._ws_key != key:
-            nbytes = hip.lib().brv_ctn_workspace_bytes(self._cfg_ptr(), B, L)
+        if self._ws_key.get(amp) != key:
+            fn = hip.lib().brv_ctn_workspace_bytes if amp \
+                else hip.lib().brv_ctn_f32_workspace_bytes
+            nbytes = fn(self._cfg_ptr(), B, L)
             if nbytes < 0:
                 hip.check(int(nbytes), 'brv_ctn_workspace_bytes')
-            if self._workspace is None or self._workspace.numel() < nbytes \
-                    or self._workspace.device != self._flat.device:
-                self._workspace = torch.empty(nbytes, dtype=torch.uint8,
-                                              device=self._flat.device)
-            self._ws_key = key
-        return self._workspace
+            ws = self._workspace.get(amp)
+            if ws is None or ws.numel() < nbytes \
+                    or ws.device != self._flat.device:
+                self._workspace[amp] = torch.empty(
+                    nbytes, dtype=torch.uint8, device=self._flat.device)
+            self._ws_key[amp] = key
+        return self._workspace[amp]
 
-    def _hip_forward(self, wave):
+    def _autograd_buffer(self):
+        """Zeroed flat buffer for the gradients autograd hands back. Reused across
+        steps while no ``p.grad`` still refers to it (``zero_grad(set_to_none=True)``,
+        the default, or the flat-gradient binding of ``train_step``)."""
+        buf = self._ag_grad
+        if buf is not None and buf.device == self._flat.device \
+                and buf.numel() == self._flat.numel():
+            lo = buf.data_ptr()
+            hi = lo + 4*buf.numel()
+            if all(p.grad is None or not lo <= p.grad.data_ptr() < hi
+                   for p, _ in self._offsets):
+                return buf.zero_()
+        self._ag_grad = torch.zeros_like(self._flat)
+        return self._ag_grad
+
+    def _hip_forward(self, wave, amp=True):
         hip.require_device(wave, self._flat)
         if wave.ndim != 2:
             raise ValueError(f'input must be (batch, length), got {wave.shape}')
+        amp = bool(amp)
         wave = wave.float().contiguous()
         B, L = wave.shape
-        self._prepare()
-        ws = self._get_workspace(B, L)
+        ws = self._get_workspace(B, L, amp)
         out = torch.empty(B, self.output_sources, L, dtype=torch.float32,
                           device=wave.device)
-        hip.check(hip.lib().brv_ctn_forward(
-            self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
-            hip.ptr(ws), hip.ptr(wave), hip.ptr(out), B, L, hip.stream()),
-            'brv_ctn_forward')
-        self._ws_version += 1
+        if amp:
+            self._prepare()
+            hip.check(hip.lib().brv_ctn_forward(
+                self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
+                hip.ptr(ws), hip.ptr(wave), hip.ptr(out), B, L, hip.stream()),
+                'brv_ctn_forward')
+        else:
+            self._check_layout()
+            hip.check(hip.lib().brv_ctn_f32_forward(
+                self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(ws),
+                hip.ptr(wave), hip.ptr(out), B, L, hip.stream()),
+                'brv_ctn_f32_forward')
+        self._ws_version[amp] += 1
         return out
 
-    def _hip_backward(self, wave, d_out, flat_grad):
+    def _hip_backward(self, wave, d_out, flat_grad, amp=True):
+        amp = bool(amp)
         wave = wave.float().contiguous()
         d_out = d_out.float().contiguous()
         B, L = wave.shape
-        ws = self._get_workspace(B, L)
-        hip.check(hip.lib().brv_ctn_backward(
-            self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
-            hip.ptr(ws), hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad),
-            B, L, hip.stream()), 'brv_ctn_backward')
+        ws = self._get_workspace(B, L, amp)
+        if amp:
+            hip.check(hip.lib().brv_ctn_backward(
+                self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
+                hip.ptr(ws), hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad),
+                B, L, hip.stream()), 'brv_ctn_backward')
+        else:
+            hip.check(hip.lib().brv_ctn_f32_backward(
+                self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(ws),
+                hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad), B, L,
+                hip.stream()), 'brv_ctn_f32_backward')
 
     def workspace_tensor(self, name, index, B, L, shape, dtype):
-        """View of a saved activation (tests / profiling)."""
+        """View of a saved activation of the bf16 path (tests / profiling)."""
         off = hip.lib().brv_ctn_workspace_offset(
             self._cfg_ptr(), B, L, name.encode(), index)
         if off < 0:
@@ -350,29 +396,64 @@ class ConvTasNet(BreverBaseModel):
         for s in shape:
             n *= s
         itemsize = torch.empty(0, dtype=dtype).element_size()
-        raw = self._workspace[off:off + n*itemsize]
+        raw = self._workspace[True][off:off + n*itemsize]
         return raw.view(dtype).view(*shape)
 
     # ---- plugin surface ---------------------------------------------------------------
+    def _use_amp(self):
+        return bool(self._amp) or torch.is_autocast_enabled()
+
     def forward(self, x):
+        amp = self._use_amp()
         if torch.is_grad_enabled() and any(p.requires_grad for p, _ in self._offsets):
-            return _ConvTasNetFunction.apply(self, x, *[p for p, _ in self._offsets])
-        return self._hip_forward(x)
+            return _ConvTasNetFunction.apply(self, x, amp,
+                                             *[p for p, _ in self._offsets])
+        return self._hip_forward(x, amp)
 
     def transform(self, sources):
         return sources.mean(axis=-2)      # mono; runs wherever `sources` lives
 
     def loss(self, batch, lengths, use_amp):
         inputs, labels = batch[:, 0], batch[:, 1:]
-        outputs = self(inputs)
+        prev, self._amp = self._amp, bool(use_amp)     # convtasnet.py:78-86 autocast switch
+        try:
+            outputs = self(inputs)
+        finally:
+            self._amp = prev
         loss = self.criterion(outputs, labels, lengths)
         return loss.mean()
 
     def update(self, loss, scaler):
-        super().update(loss, scaler, grad_clip=self.grad_clip)
+        """backward -> [gradient all-reduce hook] -> clip -> step (base.py:270-301).
+        The data-parallel hook runs here too, so every criterion / optimizer is
+        synchronised, not only the fused ``train_step``."""
+        scaler.scale(loss).backward()
+        scaler.unscale_(self.optimizer)
+        flat_opt = isinstance(self.optimizer, FlatAdam)
+        grad_scale = 1.0
+        if self._grad_sync is not None:
+            grads = self.gather_grads()
+            grad_scale = self._grad_sync(grads)
+            if not flat_opt or scaler.is_enabled():
+                grads.mul_(grad_scale)
+                grad_scale = 1.0
+            self._scatter_grads(grads)       # no-op when the .grad tensors are views of `grads`
+        if flat_opt and not scaler.is_enabled():
+            self.optimizer.step(max_norm=self.grad_clip, grad_scale=grad_scale)
+            return
+        if self.grad_clip != 0.0:
+            torch.nn.utils.clip_grad_norm_(self.parameters(), self.grad_clip)
+        scaler.step(self.optimizer)
+        scaler.update()
+
+    def _scatter_grads(self, flat):
+        """Write a gathered (copied) flat gradient back to the ``.grad`` tensors."""
+        for p, off in self._offsets:
+            if p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + 4*off:
+                p.grad.copy_(flat[off:off + p.numel()].view(p.shape))
 
     def _enhance(self, x, use_amp):
-        return self._hip_forward(x.mean(axis=-2))
+        return self._hip_forward(x.mean(axis=-2), use_amp)
 
     def train_step(self, batch, lengths, use_amp, scaler):
         """Fused step when the criterion is the HIP ``snr`` and the optimizer the
@@ -382,35 +463,44 @@ class ConvTasNet(BreverBaseModel):
                  and isinstance(self.optimizer, FlatAdam))
         if not fused:
             return super().train_step(batch, lengths, use_amp, scaler)
-        # bf16 needs no loss scaling: the GradScaler is left untouched
+        # neither bf16 nor fp32 needs loss scaling: the GradScaler is left untouched
         lib = hip.lib()
         inputs, labels = batch[:, 0], batch[:, 1:]
         hip.require_device(inputs, lengths)
         B, L = inputs.shape
         S = self.output_sources
+        amp = bool(use_amp)
         with torch.no_grad():
-            out = self._hip_forward(inputs)
+            out = self._hip_forward(inputs, amp)
             labels = labels.float().contiguous()
             lengths = lengths.to(torch.int64).contiguous()
-            n = lib.brv_loss_scratch_bytes(B, S)
-            scratch = torch.empty(n, dtype=torch.uint8, device=out.device)
-            loss_b = torch.empty(B, dtype=torch.float32, device=out.device)
+            scratch, loss_b, gscale, d_out = self._step_buffers(B, S, L, out.device)
             hip.check(lib.brv_snr_forward(
                 hip.ptr(out), hip.ptr(labels), hip.ptr(lengths), B, S, L, L,
                 hip.ptr(scratch), hip.ptr(loss_b), hip.stream()),
                 'brv_snr_forward')
-            gscale = torch.full((B,), 1.0/B, dtype=torch.float32,
-                                device=out.device)
-            d_out = torch.empty_like(out)
             hip.check(lib.brv_snr_backward(
                 hip.ptr(out), hip.ptr(labels), hip.ptr(lengths), B, S, L, L,
                 hip.ptr(scratch), hip.ptr(gscale), hip.ptr(d_out), hip.stream()),
                 'brv_snr_backward')
             grads = self.flat_grads()
             grads.zero_()
-            self._hip_backward(inputs, d_out, grads)
+            self._hip_backward(inputs, d_out, grads, amp)
             grad_scale = 1.0
             if self._grad_sync is not None:
                 grad_scale = self._grad_sync(grads)
             self.optimizer.step(max_norm=self.grad_clip, grad_scale=grad_scale)
             return loss_b.mean()
+
+    def _step_buffers(self, B, S, L, device):
+        """Loss scratch, per-item losses, gradient scales and d_out of the fused
+        step, allocated once per (B, S, L) instead of every step."""
+        key = (B, S, L, device)
+        if self._step_bufs is None or self._step_bufs[0] != key:
+            n = hip.lib().brv_loss_scratch_bytes(B, S)
+            self._step_bufs = (key, (
+                torch.empty(n, dtype=torch.uint8, device=device),
+                torch.empty(B, dtype=torch.float32, device=device),
+                torch.full((B,), 1.0/B, dtype=torch.float32, device=device),
+                torch.empty(B, S, L, dtype=torch.float32, device=device)))
+        return self._step_bufs[1]

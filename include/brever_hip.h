@@ -88,6 +88,21 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params,
                      const float* d_out, float* grads, int64_t batch,
                      int64_t length, brv_stream_t stream);
 
+/* The same model with fp32 activations and exact-fp32 products: ConvTasNet.forward WITHOUT
+ * autocast (convtasnet.py:78-97 with use_amp=False -- `enhance(x, use_amp=False)` of
+ * scripts/test_model.py:173-175, BreverTrainer(use_amp=False)). No prepared operands: the flat
+ * fp32 parameters are read directly. Own workspace layout (brv_ctn_f32_workspace_bytes);
+ * causal and non-causal; gradients are ACCUMULATED into `grads` like brv_ctn_backward. */
+int64_t brv_ctn_f32_workspace_bytes(const brv_ctn_config* cfg, int64_t batch,
+                                    int64_t length);
+int brv_ctn_f32_forward(const brv_ctn_config* cfg, const float* params,
+                        void* workspace, const float* wave, float* out,
+                        int64_t batch, int64_t length, brv_stream_t stream);
+int brv_ctn_f32_backward(const brv_ctn_config* cfg, const float* params,
+                         void* workspace, const float* wave, const float* d_out,
+                         float* grads, int64_t batch, int64_t length,
+                         brv_stream_t stream);
+
 /* ---- criteria (brever/criterion.py) ---------------------------------------
  * x, y: (batch, sources, length) fp32 contiguous rows with `stride` floats
  * between rows; lengths: (batch,) int64 on the device; scratch: at least

@@ -31,7 +31,9 @@ def rel(a, b):
     return float((a - b).norm()/(b.norm() + 1e-30))
 
 
-def load_pair(golden_dir, tag, emulate=True):
+def load_pair(golden_dir, tag, emulate=True, amp=True):
+    """Oracle + HIP model at the golden weights. ``amp`` selects the HIP precision of bare
+    ``net(x)`` calls (True: bf16 path = use_amp=True; False: the fp32 path)."""
     from brever_amd.models import ConvTasNet
     from oracle.convtasnet import OracleConvTasNet
     g = np.load(os.path.join(golden_dir, f'convtasnet_{tag}.npz'))
@@ -45,6 +47,7 @@ def load_pair(golden_dir, tag, emulate=True):
             off += n
     net = ConvTasNet(**cfg)
     net.load_state_dict(oracle.state_dict())
+    net._amp = amp
     return g, cfg, oracle, net.to(_cuda())
 
 
@@ -117,6 +120,7 @@ def test_default_architecture_forward_and_loss(golden_dir):
     g = np.load(os.path.join(golden_dir, 'convtasnet_default.npz'))
     torch.manual_seed(0)
     net = ConvTasNet().to(_cuda())          # same seeded init as the reference
+    net._amp = True
     batch = torch.from_numpy(g['batch'])
     out = net(batch[:, 0].cuda())
     assert rel(out, torch.from_numpy(g['output'])) <= 2e-2
@@ -257,6 +261,8 @@ def test_module_plumbing(golden_dir):
         a, b = net.enhance(x), other.enhance(x)
         assert torch.equal(a, b)
         assert a.shape == (x.shape[0], 1, x.shape[-1])
+        a16 = net.enhance(x, use_amp=True)           # bf16 path: close, not equal
+        assert 0 < rel(a16, a) <= 2e-2
         assert net.enhance(x[0]).shape == (1, x.shape[-1])
         with pytest.raises(ValueError):
             net.enhance(x[0, 0])
@@ -275,6 +281,7 @@ def test_full_size_step_properties():
     dev = _cuda()
     torch.manual_seed(0)
     net = ConvTasNet().to(dev)
+    net._amp = True
     g = torch.Generator().manual_seed(5)
     batch = 0.1*torch.randn(16, 2, 64000, generator=g)
     lengths = torch.randint(32000, 64001, (16,), generator=g)
@@ -348,6 +355,7 @@ def test_default_width_network_matches_oracle(causal):
     net = ConvTasNet(**cfg)
     net.load_state_dict(oracle.state_dict())
     net = net.to(_cuda())
+    net._amp = True
     B, L = 3, 2500
     batch = 0.3*torch.randn(B, 2, L, generator=gen)
     lengths = torch.tensor([L, L - 300, L - 1111])
@@ -376,6 +384,214 @@ def test_default_width_network_matches_oracle(causal):
         if p.numel() >= 512 and float(q.grad.norm()) > 1e-4:
             worst = max(worst, rel(p.grad, q.grad))
             assert rel(p.grad, q.grad) <= 0.15, (name, rel(p.grad, q.grad))
+
+
+
+# ---- fp32 path (use_amp=False): the parity protocol of SURVEY.md 8(d) at fp32 tolerances -------
+@pytest.mark.parametrize('tag', ['small', 'small2', 'causal', 'causal2'])
+def test_fp32_path_matches_reference(golden_dir, tag):
+    """Reference goldens (fp32 CPU): output rel-L2 <= 1e-5, loss |d| <= 1e-5, gradients global
+    rel-L2 <= 1e-4 and every tensor <= 1e-3 (convtasnet.py:78-97 without autocast)."""
+    from brever_amd.criterion import snr
+    g, cfg, oracle, net = load_pair(golden_dir, tag, emulate=False, amp=False)
+    batch = torch.from_numpy(g['batch'])
+    lengths = torch.from_numpy(g['lengths'])
+    out = net(batch[:, 0].cuda())
+    assert rel(out, torch.from_numpy(g['output'])) <= 1e-5
+    loss = snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean()
+    assert abs(float(loss) - float(g['loss'])) <= 1e-5
+    loss.backward()
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+    gold = torch.from_numpy(g['grads'])
+    assert rel(got, gold) <= 1e-4, rel(got, gold)
+    off = 0
+    for name, p in net.named_parameters():
+        n = p.numel()
+        ref = gold[off:off + n]
+        if float(ref.norm()) > 1e-6:
+            assert rel(got[off:off + n], ref) <= 1e-3, (name, rel(got[off:off + n], ref))
+        off += n
+    # enhance(x) defaults to use_amp=False = this path
+    with torch.no_grad():
+        e = net.enhance(batch[:, :1].repeat(1, 2, 1).cuda())
+    assert rel(e, torch.from_numpy(g['output'])) <= 1e-5
+
+
+@pytest.mark.parametrize('B,L', [(1, 33), (2, 257), (3, 2049)])
+def test_fp32_path_odd_lengths(golden_dir, B, L):
+    _, cfg, oracle, net = load_pair(golden_dir, 'small', emulate=False, amp=False)
+    g = torch.Generator().manual_seed(L)
+    x = 0.3*torch.randn(B, L, generator=g)
+    want = oracle(x)
+    with torch.no_grad():
+        got = net(x.cuda())
+    assert got.shape == (B, 1, L)
+    assert rel(got, want) <= 1e-5
+
+
+def test_fp32_trajectory_20_steps(golden_dir):
+    """20 fused HIP steps (fp32 path) vs the CPU fp32 oracle from identical
+    init and data order; default channel widths, 4 blocks, Adam lr 1e-3 + clip 5, synthetic
+    noisy / clean pairs of the 8(d) recipe (ragged lengths).
+
+    Bound: per-step |d loss| <= 1e-3 dB. Early Adam training amplifies rounding differences
+    (measured on MI355X, tools/traj_debug.py: the CPU fp32 oracle itself is 2e-4 dB from its
+    own fp64 run at step 9 and 7e-4 at step 19), so the bound is asserted in two ways: against
+    the fp32 oracle it must hold with margin over the first 10 steps and within 3x over all 20;
+    against the fp64 oracle (the trajectory both fp32 runs approximate) the HIP run may not be
+    further away than the CPU fp32 run's own worst distance times 3."""
+    from brever_amd.models import ConvTasNet
+    from oracle.convtasnet import OracleConvTasNet
+    cfg = dict(layers=2, repeats=2)
+    torch.manual_seed(7)
+    oracle = OracleConvTasNet(**cfg)
+    o64 = OracleConvTasNet(**cfg).double()
+    o64.load_state_dict({k: v.double() for k, v in oracle.state_dict().items()})
+    net = ConvTasNet(**cfg)
+    net.load_state_dict(oracle.state_dict())
+    net = net.to(_cuda())
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    gen = torch.Generator().manual_seed(11)
+    d32, d64, c64 = [], [], []
+    for step in range(20):
+        clean = 0.1*torch.randn(4, 3000, generator=gen)
+        noise = 0.1*torch.randn(4, 3000, generator=gen)
+        snr_db = -5 + 15*torch.rand(4, 1, generator=gen)
+        batch = torch.stack([clean + 10**(-snr_db/20)*noise, clean], dim=1)
+        lengths = torch.tensor([3000, 2500, 2000, 1600])
+        for b in range(4):
+            batch[b, :, lengths[b]:] = 0
+        want = float(oracle.train_step(batch, lengths, False, scaler).detach())
+        truth = float(o64.train_step(batch.double(), lengths, False, scaler).detach())
+        got = float(net.train_step(batch.cuda(), lengths.cuda(), False, scaler))
+        d32.append(abs(got - want)); d64.append(abs(got - truth)); c64.append(abs(want - truth))
+    print('fp32 trajectory |hip - cpu32|:', ['%.1e' % d for d in d32])
+    print('               |cpu32 - cpu64|:', ['%.1e' % d for d in c64])
+    assert max(d32[:10]) <= 1e-3, d32
+    assert max(d32) <= 3e-3, d32
+    assert max(d64) <= 3*max(c64) + 1e-4, (d64, c64)
+    ref = torch.cat([p.detach().reshape(-1) for p in oracle.parameters()])
+    assert rel(net.flat_params(), ref) <= 1e-2, rel(net.flat_params(), ref)
+
+
+def _mixtures(gen, B, L, lengths):
+    """Synthetic noisy / clean pairs: a harmonic "voice" (random f0 in 100-400 Hz, 4 harmonics)
+    in white noise at -5..10 dB, batch (B, 2, L) = [mixture, clean], zero beyond the lengths."""
+    import math
+    t = torch.arange(L)/16000.0
+    f0 = 100 + 300*torch.rand(B, 1, generator=gen)
+    clean = 0.05*sum(torch.sin(2*math.pi*f0*(h + 1)*t + 6.28*torch.rand(B, 1, generator=gen))/(h + 1)
+                     for h in range(4))
+    noise = 0.1*torch.randn(B, L, generator=gen)
+    snr_db = -5 + 15*torch.rand(B, 1, generator=gen)
+    gain = 10**(-snr_db/20)*clean.norm(dim=1, keepdim=True)/noise.norm(dim=1, keepdim=True)
+    batch = torch.stack([clean + gain*noise, clean], dim=1)
+    for b in range(B):
+        batch[b, :, lengths[b]:] = 0
+    return batch
+
+
+def test_sisnri_matches_oracle(golden_dir):
+    """BASELINE metric "SI-SNRi vs ref" (scripts/test_model.py:189-199):
+    metrics.sisnr(output, target) - metrics.sisnr(input, target) at fixed weights, both HIP
+    precisions vs the CPU fp32 oracle. The weights come from 60 fused HIP training steps on
+    noisy / clean pairs, so that the output is correlated with the target (at random weights
+    SI-SNR is a ratio of two near-zero correlations and means nothing). fp32 path:
+    |d| <= 1e-5*max(1, |value|) dB; bf16 path: |d| <= 1e-3 dB on the batch mean and 5e-3 dB per item."""
+    from brever_amd import metrics
+    from brever_amd.models import ConvTasNet
+    from oracle import criterion as oc
+    from oracle.convtasnet import OracleConvTasNet
+    g, cfg, _, _ = load_pair(golden_dir, 'small', emulate=False)
+    torch.manual_seed(1)
+    net = ConvTasNet(**cfg).to(_cuda())
+    gen = torch.Generator().manual_seed(21)
+    lengths = torch.tensor([4000, 3500, 3000, 2600])
+    for _ in range(60):
+        net.train_step(_mixtures(gen, 4, 4000, lengths).cuda(), lengths.cuda(), False, None)
+    oracle = OracleConvTasNet(**cfg)
+    oracle.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    batch = _mixtures(gen, 4, 4000, lengths)
+    mix, tgt = batch[:, 0], batch[:, 1]
+    stereo = batch[:, :1].repeat(1, 2, 1).cuda()
+    with torch.no_grad():
+        want_out = oracle(mix)[:, 0]
+        want = (-oc.sisnr(want_out[:, None], tgt[:, None], lengths)
+                + oc.sisnr(mix[:, None], tgt[:, None], lengths)).reshape(-1)
+        base = metrics.sisnr(mix.cuda(), tgt.cuda(), lengths=lengths.cuda())
+        got = {}
+        for amp in (False, True):
+            out = net.enhance(stereo, use_amp=amp)[:, 0]
+            got[amp] = (metrics.sisnr(out, tgt.cuda(), lengths=lengths.cuda()) - base).cpu().reshape(-1)
+    print('SI-SNRi oracle', want.tolist())
+    print('SI-SNRi |hip fp32 - oracle|', (got[False] - want).abs().tolist())
+    print('SI-SNRi |hip bf16 - oracle|', (got[True] - want).abs().tolist())
+    assert float(want.mean()) > 1.0                      # the network does enhance
+    assert torch.allclose(got[False], want, rtol=1e-5, atol=1e-5), got[False] - want
+    assert abs(float(got[True].mean() - want.mean())) <= 1e-3, got[True] - want
+    assert torch.allclose(got[True], want, rtol=0, atol=5e-3), got[True] - want
+
+
+@pytest.mark.parametrize('amp', [False, True])
+def test_full_size_forward_and_loss_vs_oracle(amp):
+    """BASELINE size, default architecture (24 blocks, 16 x 64 000 samples, ragged lengths):
+    forward + snr loss of both HIP precisions against the CPU fp32 oracle."""
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    from oracle.convtasnet import OracleConvTasNet
+    from oracle import criterion as oc
+    dev = _cuda()
+    torch.manual_seed(0)
+    oracle = OracleConvTasNet()
+    net = ConvTasNet()
+    net.load_state_dict(oracle.state_dict())
+    net = net.to(dev)
+    g = torch.Generator().manual_seed(5)
+    batch = 0.1*torch.randn(16, 2, 64000, generator=g)
+    lengths = torch.randint(32000, 64001, (16,), generator=g)
+    lengths[0] = 64000
+    for b in range(16):
+        batch[b, :, lengths[b]:] = 0
+    with torch.no_grad():
+        want = oracle(batch[:, 0])
+        want_loss = oc.snr(want, batch[:, 1:], lengths)
+        net._amp = amp
+        got = net(batch[:, 0].to(dev))
+        got_loss = snr(got, batch[:, 1:].to(dev), lengths.to(dev)).cpu()
+    if amp:
+        assert rel(got, want) <= 2e-2, rel(got, want)
+        assert float((got_loss - want_loss).abs().max()) <= 2e-2
+        assert abs(float(got_loss.mean() - want_loss.mean())) <= 1e-2
+    else:
+        assert rel(got, want) <= 1e-4, rel(got, want)
+        assert float((got_loss - want_loss).abs().max()) <= 1e-4
+
+
+def test_update_path_runs_grad_sync(golden_dir):
+    """the generic loss -> update sequence (criterion != snr) must call the
+    data-parallel gradient hook too, and the hook's scale must reach the optimizer."""
+    from brever_amd.models import ConvTasNet
+    g, cfg, _, _ = load_pair(golden_dir, 'small2')
+    cfg = dict(cfg, criterion='sisnr')
+    batch = torch.from_numpy(g['batch']).cuda()
+    lengths = torch.from_numpy(g['lengths']).cuda()
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    torch.manual_seed(0)
+    a = ConvTasNet(**cfg).cuda()
+    b = ConvTasNet(**cfg).cuda()
+    b.load_state_dict(a.state_dict())
+    calls = []
+
+    def sync(flat):                       # a summing all-reduce over 2 identical ranks
+        calls.append(flat.numel())
+        flat.mul_(2.0)
+        return 0.5
+    b.set_grad_sync(sync)
+    la = a.train_step(batch, lengths, True, scaler)
+    lb = b.train_step(batch, lengths, True, scaler)
+    assert calls == [a.flat_params().numel()]
+    assert float(la) == float(lb)
+    assert rel(b.flat_params(), a.flat_params()) <= 1e-6
 
 
 def test_criteria_gradients(golden_dir):
