@@ -38,6 +38,12 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 inline long long align_up(long long x, long long a) { return (x + a - 1)/a*a; }
 
+// opt-in fused forward (BRV_FWD_FUSE=1, see brv_ctn_forward)
+inline bool fwd_fuse_requested() {
+  const char* e = getenv("BRV_FWD_FUSE");
+  return e && e[0] == '1' && !getenv("BRV_NO_WS");
+}
+
 // ---- optional per-launch event timing (bench / profiling only) ---------------
 // Off by default. When enabled through brv_prof_enable(1) every kernel launch of
 // this file is bracketed by two events on the launch stream; brv_prof_collect()
@@ -62,6 +68,10 @@ struct BlockOff {
       n1_g, n1_b, n2_g, n2_b, prelu1, prelu2;
   long long p_c1_f, p_c1_b, p_rs_f, p_rs_b;     // prepared (bf16 elements)
   long long p_c1_fp, p_rs_fp, p_rs_bp;          // fragment-order copies (persistent GEMMs)
+  // lazy second norm (fused forward): [res | skip] weights times gamma_2, always Bnp + Scp rows
+  // (zero residual rows in the last block), plain and in fragment order; p_lazy: floats
+  // v0[n] = bias[n] + sum_k W[n][k] beta_2[k], v1[n] = sum_k bf16(W[n][k] gamma_2[k]), n < Bnp + Scp
+  long long p_rs_g, p_rs_gp, p_lazy;
 };
 
 struct Layout {
@@ -122,6 +132,9 @@ struct Layout {
       blk[i].p_c1_fp = ptake((long long)Hp*Bnp);
       blk[i].p_rs_fp = ptake((long long)rs*Hp);
       blk[i].p_rs_bp = ptake((long long)Hp*rs);
+      blk[i].p_rs_g = ptake((long long)(Bnp + Scp)*Hp);
+      blk[i].p_rs_gp = ptake((long long)(Bnp + Scp)*Hp);
+      blk[i].p_lazy = ptake(4LL*(Bnp + Scp));           // 2 x (Bnp + Scp) floats
     }
     p_out_f = ptake((long long)S*Np*Scp);
     p_out_b = ptake((long long)Scp*S*Np);
@@ -147,6 +160,7 @@ struct Workspace {
   long long h1, h2, wn, ctab, ctab_stride, cfs, cbt, ident, fake_stats, scratch_stats;
   long long vg_stride, vg_bytes;      // replicated vector-gradient block (floats / bytes)
   long long x_stride, z_stride;       // bytes between consecutive blocks' buffers
+  long long u, u_stride;              // fused forward: unfinished [res | skip] products per block
   long long stats_bytes;
   void init(const Layout& l, long long B, long long T) {
     long long o = 0;
@@ -183,6 +197,8 @@ struct Workspace {
     vg_bytes = vg_stride*kReplicas*4;
     vg = take(vg_bytes);
     wgpart = take((long long)kWgSplit*l.nb*W2_G*l.H*4);
+    u_stride = align_up(BT*(l.Bnp + l.Scp)*2, 256);
+    u = fwd_fuse_requested() ? take(u_stride*l.nb) : 0;
     h1 = h2 = wn = ctab = cfs = cbt = ident = fake_stats = scratch_stats = 0; ctab_stride = 0;
     if (l.causal) {
       h1 = take(z_stride*l.nb);
@@ -426,6 +442,75 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* params,
                                                            bf16_t* prepped,
                                                            const PrepBatch pb) {
   prep_job_run(params, prepped, pb.jobs[blockIdx.y], blockIdx.x, gridDim.x);
+}
+
+// Constants of the lazily applied second norm (fused forward, gemm_ws.cuh AT == 3): with
+// u = (W gamma) p the finished convolution output is rstd u + v0 - mean rstd v1.
+struct LazyPrepBlk { long long res_w, res_b, skip_w, skip_b, beta, wg, out; };
+struct LazyPrepParams { int nb, H, Hp, Bn, Sc, Bnp, Scp; LazyPrepBlk blk[kWgMaxProb]; };
+__global__ __launch_bounds__(256) void lazy_prep_kernel(const float* params, bf16_t* prepped,
+                                                        const LazyPrepParams p) {
+  const LazyPrepBlk& b = p.blk[blockIdx.x];
+  float* out = reinterpret_cast<float*>(prepped + b.out);
+  const int NP = p.Bnp + p.Scp;
+  for (int n = threadIdx.x; n < NP; n += 256) {
+    const bool res = n < p.Bnp;
+    const int r = res ? n : n - p.Bnp;
+    const bool ok = res ? (r < p.Bn && b.res_w >= 0) : r < p.Sc;
+    float v0 = 0.f, v1 = 0.f;
+    if (ok) {
+      const float* W = params + (res ? b.res_w : b.skip_w) + (long long)r*p.H;
+      v0 = params[(res ? b.res_b : b.skip_b) + r];
+      for (int k = 0; k < p.H; ++k) v0 = __builtin_fmaf(W[k], params[b.beta + k], v0);
+      const bf16_t* wg = prepped + b.wg + (long long)n*p.Hp;
+      for (int k = 0; k < p.H; ++k) v1 += bf2f(wg[k]);
+    }
+    out[n] = v0; out[NP + n] = v1;
+  }
+}
+
+// skip_sum[b][t][n] = sum_i rstd_i[b] u_i[b][t][Bnp + n] + v0_i[n] - mean_i[b] rstd_i[b] v1_i[n]:
+// the skip connections of all blocks finished in one pass (fp32 out, as the backward expects)
+struct SkipCombineParams {
+  const bf16_t* u; long long u_stride;     // elements between blocks
+  const double* stats; long long stats_stride;   // stats of block i's second norm: stats + (2 + 2i)*stats_stride
+  const bf16_t* prepared; long long lazy_off[kWgMaxProb];
+  float* skip; int nb, B, T, Bnp, Scp; double inv_n; float eps;
+};
+__global__ __launch_bounds__(256) void skip_combine_kernel(const SkipCombineParams p) {
+  __shared__ float rs[kWgMaxProb];
+  __shared__ float cs[kWgMaxProb][128];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int NP = p.Bnp + p.Scp;
+  for (int i = tid; i < p.nb; i += 256)
+    rs[i] = norm_stat(p.stats + (2 + 2*i)*p.stats_stride, b, p.inv_n, p.eps).rstd;
+  __syncthreads();
+  for (int e = tid; e < p.nb*p.Scp; e += 256) {
+    const int i = e / p.Scp, n = e % p.Scp;
+    const NormStat ns = norm_stat(p.stats + (2 + 2*i)*p.stats_stride, b, p.inv_n, p.eps);
+    const float* lz = reinterpret_cast<const float*>(p.prepared + p.lazy_off[i]);
+    cs[i][n] = lz[p.Bnp + n] - ns.mean*ns.rstd*lz[NP + p.Bnp + n];
+  }
+  __syncthreads();
+  const int cpr = p.Scp/8;
+  const long long per_item = (long long)p.T*cpr;
+  for (long long e = (long long)blockIdx.x*256 + tid; e < per_item; e += (long long)gridDim.x*256) {
+    const int c0 = (int)(e % cpr)*8; const long long t = e / cpr;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < p.nb; ++i) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(p.u + i*p.u_stride + ((long long)b*p.T + t)*NP + p.Bnp + c0), f);
+      const float r = rs[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += __builtin_fmaf(r, f[j], cs[i][c0 + j]);
+    }
+    float* dst = p.skip + ((long long)b*p.T + t)*p.Scp + c0;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
 }
 
 }  // namespace
@@ -858,7 +943,7 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
   auto add = [&](long long src, long long dst, int R, int C, int rows, int cols, int ld,
                  int tr) {
     PrepJob j; j.src_off = src; j.dst_off = dst; j.R = R; j.C = C; j.rows = rows;
-    j.cols = cols; j.dst_ld = ld; j.tr = tr; jobs.push_back(j);
+    j.cols = cols; j.dst_ld = ld; j.tr = tr; j.scale_off = -1; jobs.push_back(j);
   };
   add(l.enc_w, l.p_enc, l.N, l.K, l.Np, l.Kfp, l.Kfp, 0);
   add(l.dec_w, l.p_dec_f, l.N, l.K, l.Kfp, l.Np, l.Np, 1);
@@ -877,6 +962,13 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
     }
     add(b.skip_w, b.p_rs_f + (long long)rs0*l.Hp, l.Sc, l.H, l.Scp, l.Hp, l.Hp, 0);
     add(b.skip_w, b.p_rs_b + rs0, l.Sc, l.H, l.Hp, l.Scp, rs, 1);
+    if (fwd_fuse_requested()) {
+      // gamma_2-folded [res | skip] weights of the fused forward (residual rows zero in the last block)
+      add(has_res ? b.res_w : 0, b.p_rs_g, has_res ? l.Bn : 0, l.H, l.Bnp, l.Hp, l.Hp, 0);
+      jobs.back().scale_off = b.n2_g;
+      add(b.skip_w, b.p_rs_g + (long long)l.Bnp*l.Hp, l.Sc, l.H, l.Scp, l.Hp, l.Hp, 0);
+      jobs.back().scale_off = b.n2_g;
+    }
   }
   for (int s = 0; s < l.S; ++s) {
     add(l.out_w + (long long)s*l.N*l.Sc, l.p_out_f + (long long)s*l.Np*l.Scp,
@@ -904,12 +996,25 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
     pack(b.p_c1_f, b.p_c1_fp, l.Hp, l.Bnp, 64);
     pack(b.p_rs_f, b.p_rs_fp, rs, l.Hp, 32);
     pack(b.p_rs_b, b.p_rs_bp, l.Hp, rs, 32);
+    if (fwd_fuse_requested()) pack(b.p_rs_g, b.p_rs_gp, l.Bnp + l.Scp, l.Hp, 32);
   }
   for (size_t i = 0; i < packs.size(); i += 96) {
     PackBatch pb;
     pb.n = (int)std::min<size_t>(96, packs.size() - i);
     for (int k = 0; k < pb.n; ++k) pb.jobs[k] = packs[i + k];
     hipLaunchKernelGGL(pack_frag_kernel, dim3(16, pb.n), dim3(256), 0, st, (bf16_t*)prepared, pb);
+    HIP_OK(hipGetLastError());
+  }
+  if (fwd_fuse_requested()) {
+    LazyPrepParams lp; memset(&lp, 0, sizeof(lp));
+    lp.nb = l.nb; lp.H = l.H; lp.Hp = l.Hp; lp.Bn = l.Bn; lp.Sc = l.Sc; lp.Bnp = l.Bnp; lp.Scp = l.Scp;
+    if (l.nb > kWgMaxProb) return 0;                       // (fused forward is off for such depths)
+    for (int i = 0; i < l.nb; ++i) {
+      const BlockOff& b = l.blk[i];
+      lp.blk[i].res_w = b.res_w; lp.blk[i].res_b = b.res_b; lp.blk[i].skip_w = b.skip_w;
+      lp.blk[i].skip_b = b.skip_b; lp.blk[i].beta = b.n2_b; lp.blk[i].wg = b.p_rs_g; lp.blk[i].out = b.p_lazy;
+    }
+    hipLaunchKernelGGL(lazy_prep_kernel, dim3(l.nb), dim3(256), 0, st, params, (bf16_t*)prepared, lp);
     HIP_OK(hipGetLastError());
   }
   return 0;
@@ -956,6 +1061,74 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   g.e.out = xbuf(0); g.e.ldo = l.Bnp; g.e.bias = params + l.bott_b; g.e.N = l.Bn;
   if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st, "bottleneck_fwd", 2.0*BT*(l.Np + l.Bnp))) return r;
 
+  // Fused forward (opt-in: BRV_FWD_FUSE=1; default widths, non-causal, kernel_size 3): two launches
+  // per block instead of three. MEASURED SLOWER than the three-launch sequence on MI355X (DESIGN.md
+  // section 5c: 79 + 28 us against 29 + 46 + 47 us per block, but + 0.25 ms of per-step table
+  // preparation and the final skip pass; inside one persistent 8-wave workgroup the stencil,
+  // the MFMAs and the loads of a tile run back to back instead of overlapping across many small
+  // workgroups, and the 128 weight registers leave no room for the stencil tables), so the default
+  // stays the three-launch sequence. pw1_fwd finishes the block input lazily (x_i = x_{i-1} + rstd u_{i-1} + c) while staging
+  // it; dwpw2_fwd runs the depthwise stage inside the A staging of the [res | skip] product and
+  // leaves the second norm to the consumers (gemm_ws.cuh AT == 2 / 3). z2 never comes back from
+  // HBM in the forward pass and the fp32 skip accumulation (read + write of 4 B x 128 channels
+  // per frame and block) becomes one bf16 write per block and one pass at the end.
+  const bool fused_fwd = fwd_fuse_requested() && l.P == 3 &&
+                         l.H == 512 && l.Bn == 128 && l.Sc == 128 && l.nb <= kWgMaxProb;
+  auto ubuf = [&](int i) { return (bf16_t*)(base + ws.u + ws.u_stride*i); };
+  const int NPu = l.Bnp + l.Scp;
+  if (fused_fwd) {
+    for (int i = 0; i < l.nb; ++i) {
+      const BlockOff& b = l.blk[i];
+      const int dil = 1 << (i % cfg->layers);
+      memset(&g, 0, sizeof(g));
+      g.W = prep + b.p_c1_f; g.T = (int)T; g.Np = l.Hp; g.Kp = l.Bnp;
+      g.Wp = prep + b.p_c1_fp; g.wp_nsl = 64;
+      g.e.out = z1buf(i); g.e.ldo = l.Hp; g.e.bias = params + b.conv_b; g.e.N = l.H;
+      g.e.stats_out = stat(1 + 2*i); g.e.stats_slope = params + b.prelu1;
+      if (i == 0) {
+        g.a = rows_bf16(xbuf(0), l.Bnp, T);
+        ProfScope prof("pw1_fwd", 2.0*BT*l.Hp*l.Bnp, 2.0*BT*(l.Bnp + l.Hp), st);
+        if (int r = launch_gemm_ws<128, 64, 1, E_STORE, 0, false, 8>(g, B, st)) return r;
+      } else {
+        const BlockOff& pb = l.blk[i - 1];
+        g.a = rows_bf16(xbuf(i - 1), l.Bnp, T);
+        g.a.p1 = ubuf(i - 1); g.a.ld1 = NPu; g.a.bs1 = T*NPu;
+        g.a.xout = xbuf(i);
+        g.a.stats = stat(2 + 2*(i - 1)); g.a.inv_n = 1.0/((double)T*l.H); g.a.eps = 1e-8f;
+        const float* lz = reinterpret_cast<const float*>(prep + pb.p_lazy);
+        g.a.lazy_v0 = lz; g.a.lazy_v1 = lz + NPu;
+        ProfScope prof("pw1_fwd", 2.0*BT*l.Hp*l.Bnp, 2.0*BT*(3*l.Bnp + l.Hp), st);
+        if (int r = launch_gemm_ws<128, 64, 1, E_STORE, 2, false, 8>(g, B, st)) return r;
+      }
+      memset(&g, 0, sizeof(g));
+      g.a = rows_bf16(z1buf(i), l.Hp, T);
+      g.a.slope = params + b.prelu1; g.a.stats = stat(1 + 2*i);
+      g.a.gamma = params + b.n1_g; g.a.beta = params + b.n1_b; g.a.C = l.H;
+      g.a.inv_n = 1.0/((double)T*l.H); g.a.eps = 1e-8f;
+      g.a.z2out = z2buf(i); g.a.taps = params + b.dconv_w; g.a.dbias = params + b.dconv_b;
+      g.a.slope2 = params + b.prelu2; g.a.stats2_out = stat(2 + 2*i);
+      g.a.dil = dil; g.a.left = ((l.P - 1)*dil)/2;
+      g.W = prep + b.p_rs_g; g.Wp = prep + b.p_rs_gp; g.wp_nsl = 32;
+      g.T = (int)T; g.Np = NPu; g.Kp = l.Hp;
+      g.e.out = ubuf(i); g.e.ldo = NPu; g.e.N = NPu;
+      {
+        ProfScope prof("dwpw2_fwd", 2.0*BT*l.Hp*(NPu + l.P), 2.0*BT*(2*l.Hp + NPu), st);
+        if (int r = launch_gemm_ws<512, 32, 1, E_STORE, 3, false, 8>(g, B, st)) return r;
+      }
+    }
+    SkipCombineParams sc; memset(&sc, 0, sizeof(sc));
+    sc.u = ubuf(0); sc.u_stride = ws.u_stride/2; sc.stats = stats; sc.stats_stride = (long long)B*kStatStride;
+    sc.prepared = prep; sc.skip = skip; sc.nb = l.nb; sc.B = B; sc.T = (int)T; sc.Bnp = l.Bnp; sc.Scp = l.Scp;
+    sc.inv_n = 1.0/((double)T*l.H); sc.eps = 1e-8f;
+    for (int i = 0; i < l.nb; ++i) sc.lazy_off[i] = l.blk[i].p_lazy;
+    {
+      ProfScope prof("skip_combine", 0, 2.0*BT*l.Scp*l.nb + 4.0*BT*l.Scp, st);
+      int gx = (int)((T*(l.Scp/8) + 255)/256);
+      if (gx > 128) gx = 128;
+      hipLaunchKernelGGL(skip_combine_kernel, dim3(gx, B), dim3(256), 0, st, sc);
+      HIP_OK(hipGetLastError());
+    }
+  } else
   for (int i = 0; i < l.nb; ++i) {
     const BlockOff& b = l.blk[i];
     const bool has_res = i < l.nb - 1;

@@ -49,6 +49,14 @@ struct ASpec {
   const float* gamma; const float* beta; int C;   // true channel count
   double inv_n; float eps;
   const double* sums;      // A_DZ: per-item {sum e, sum e*xh} of the gLN backward
+  // gemm_ws AT == 2 (lazy residual): A = p0 + rstd_b*p1 + (lazy_v0 - mean_b*rstd_b*lazy_v1), the
+  // finished rows are written to xout (row stride ld0); `stats` are those of the producing
+  // block's second norm
+  void* xout; const float* lazy_v0; const float* lazy_v1;
+  // gemm_ws AT == 3 (fused depthwise stage): A = PReLU_2(z2), z2 = dconv(gLN_1(PReLU_1(p0))) + bias
+  // built while staging; z2 goes to z2out (row stride ld0), the statistics of PReLU_2(z2) to stats2_out
+  void* z2out; const float* taps; const float* dbias; const float* slope2; double* stats2_out;
+  int dil, left;
 };
 
 struct EpiSpec {

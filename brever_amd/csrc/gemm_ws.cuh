@@ -51,7 +51,15 @@ struct GemmWsCfg {
   static_assert(kSmemAlloc*kWgPerCu <= 160*1024, "LDS budget");
 };
 
-// AT: 0 = A used as stored, 1 = PReLU + gLN affine applied while staging.
+// AT: 0 = A used as stored, 1 = PReLU + gLN affine applied while staging,
+//     2 = lazy residual: A = x + rstd*u + c built while staging and written back (the block input
+//         the previous block's fused [res | skip] product left unfinished, see AT == 3),
+//     3 = fused depthwise stage: A = PReLU_2(z2) with z2 = dconv(gLN_1(PReLU_1(z1))) + bias
+//         computed while staging from three dilated taps of z1; z2 is stored for the backward
+//         pass, the statistics of PReLU_2(z2) are accumulated, and the second norm is NOT
+//         applied: W.gLN(p) = rstd (W gamma) p + (W beta - mean rstd W gamma 1) is linear in p,
+//         so the product runs on p with gamma-folded weights and the per-item scale / offset
+//         are applied by the consumers (AT == 2 and skip_combine_kernel).
 // CAT: A is the concatenation [p0 | p1] along k (split at a.K0).
 template <int KP, int NSL, int WM, int EM, int AT, bool CAT, int NW = 8>
 __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) {
@@ -62,6 +70,11 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
   float* Cw_all = reinterpret_cast<float*>(smem + C::kA);
   float* scs = reinterpret_cast<float*>(smem + C::kA + C::kC);      // [KP] scale
   float* shs = scs + KP;                                             // [KP] shift
+  // AT == 3: per-channel stencil tables [10][KP]: tap k < 3: wa_k (z), 3 + k: wb_k (|z|),
+  // 6 + k: constant term of tap k, 9: bias
+  __shared__ __attribute__((aligned(16))) float tabs[AT == 3 ? 10*KP : 4];
+  static_assert(AT != 3 || C::kSmemAlloc + 10*KP*4 <= 160*1024, "LDS budget (fused stage)");
+  constexpr int NA = AT == 2 ? 2 : (AT == 3 ? 3 : 1);                // raw chunks per staged chunk
 
 #ifdef BRV_DIAG
   long long t_entry;
@@ -118,7 +131,8 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
   const int kc = tid % CPR;
   const int arow0 = tid / CPR;                         // + RSTEP*ci
   const int kbase = kc*8;
-  const float slope = (AT == 1 && a.slope) ? *a.slope : 1.f;
+  const float slope = ((AT == 1 || AT == 3) && a.slope) ? *a.slope : 1.f;
+  const float slope2 = (AT == 3 && a.slope2) ? *a.slope2 : 1.f;
   const bool first = !CAT || kbase < a.K0;
   const unsigned int akoff = (unsigned int)((first ? kbase : kbase - a.K0)*2);
 
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
   constexpr int dbg = 0;
 #endif
   // (b, t0) = item and first frame of the tile; `valid` false -> every lane reads zeros
-  auto load_tile = [&](int b, int t0, bool valid, uint4 (&araw)[C::ACH]) {
+  auto load_tile = [&](int b, int t0, bool valid, uint4 (&araw)[C::ACH*NA]) {
     if (dbg & 8) valid = false;
     const __amdgpu_buffer_rsrc_t r0 = make_rsrc(
         reinterpret_cast<const bf16_t*>(a.p0) + (long long)b*a.bs0,
@@ -136,7 +150,18 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
 #pragma unroll
     for (int ci = 0; ci < C::ACH; ++ci) {
       const unsigned int t = (unsigned int)(t0 + arow0 + RSTEP*ci);
-      if (!CAT) {
+      if (AT == 2) {
+        const __amdgpu_buffer_rsrc_t r1 = make_rsrc(
+            reinterpret_cast<const bf16_t*>(a.p1) + (long long)b*a.bs1,
+            valid ? (long long)T*a.ld1*2 : 0);
+        araw[2*ci] = buf_load16(r0, t*(unsigned int)(a.ld0*2) + akoff);
+        araw[2*ci + 1] = buf_load16(r1, t*(unsigned int)(a.ld1*2) + akoff);
+      } else if (AT == 3) {
+        // taps outside [0, T) wrap to offsets beyond the descriptor: zeros
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          araw[3*ci + k] = buf_load16(r0, (t + (unsigned int)(k*a.dil - a.left))*(unsigned int)(a.ld0*2) + akoff);
+      } else if (!CAT) {
         araw[ci] = buf_load16(r0, t*(unsigned int)(a.ld0*2) + akoff);
       } else {
         const __amdgpu_buffer_rsrc_t r1 = make_rsrc(
@@ -148,8 +173,112 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
       }
     }
   };
-  auto store_tile = [&](int t0, int buf, const uint4 (&araw)[C::ACH]) {
+  double a_sum = 0.0, a_sq = 0.0;          // AT == 3: statistics of PReLU_2(z2), current item
+  int a_item = -1;
+  auto flush_astats = [&]() {
+    if (AT != 3 || a_item < 0) return;
+    const double s0 = wave_sum(a_sum), s1 = wave_sum(a_sq);
+    if (lane == 0) {
+      atomic_add_f64(a.stats2_out + stat_sum(a_item), s0);
+      atomic_add_f64(a.stats2_out + stat_sq(a_item), s1);
+    }
+    a_sum = 0.0; a_sq = 0.0;
+  };
+  auto store_tile = [&](int b, int t0, int buf, const uint4 (&araw)[C::ACH*NA]) {
     bf16_t* dst = As + buf*C::BMW*C::LDA;
+    if (AT == 2) {
+      // x_next = x + rstd*u + c (c, rstd: per-item table built by update_affine)
+      const __amdgpu_buffer_rsrc_t rx = make_rsrc(
+          reinterpret_cast<bf16_t*>(a.xout) + (long long)b*a.bs0, (long long)T*a.ld0*2);
+      const float rl = shs[0];
+      float cl[8];
+      {
+        const float4 c0 = *reinterpret_cast<const float4*>(scs + kbase);
+        const float4 c1 = *reinterpret_cast<const float4*>(scs + kbase + 4);
+        cl[0] = c0.x; cl[1] = c0.y; cl[2] = c0.z; cl[3] = c0.w;
+        cl[4] = c1.x; cl[5] = c1.y; cl[6] = c1.z; cl[7] = c1.w;
+      }
+#pragma unroll
+      for (int ci = 0; ci < C::ACH; ++ci) {
+        const int row = arow0 + RSTEP*ci;
+        float f[8], u[8];
+        unpack8(araw[2*ci], f); unpack8(araw[2*ci + 1], u);
+        const float live = (t0 + row < T) ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = live*(f[j] + __builtin_fmaf(rl, u[j], cl[j]));
+        const uint4 q = pack8(f);
+        buf_store16(rx, (unsigned int)(t0 + row)*(unsigned int)(a.ld0*2) + akoff, q);   // t >= T: dropped
+        *reinterpret_cast<uint4*>(dst + row*C::LDA + kbase) = q;
+      }
+      return;
+    }
+    if (AT == 3) {
+      const __amdgpu_buffer_rsrc_t rz = make_rsrc(
+          reinterpret_cast<bf16_t*>(a.z2out) + (long long)b*a.bs0, (long long)T*a.ld0*2);
+      if (b != a_item) { flush_astats(); a_item = b; }
+      auto ld8 = [&](int which, float (&v)[8]) {
+        const float4 x0 = *reinterpret_cast<const float4*>(tabs + which*KP + kbase);
+        const float4 x1 = *reinterpret_cast<const float4*>(tabs + which*KP + kbase + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+        v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      };
+      const float d1 = 0.5f*(1.f + slope2), d2 = 0.5f*(1.f - slope2);
+      float ts = 0.f, tq = 0.f;
+      // rows in groups of RG; the per-channel tables are re-read from LDS per group. Measured:
+      // RG = 2 (fewer live registers) costs 28 us per launch in LDS reads, so all rows go at once
+      constexpr int RG = C::ACH;
+#pragma unroll
+      for (int c0i = 0; c0i < C::ACH; c0i += RG) {
+        float acc[RG][8];
+        // constant terms: bias + the taps that fall inside the item (wave-uniform per row)
+        {
+          float bs[8];
+          ld8(9, bs);
+#pragma unroll
+          for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[g][j] = bs[j];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float wa[8], wb[8], wc[8];
+          ld8(k, wa); ld8(3 + k, wb); ld8(6 + k, wc);
+#pragma unroll
+          for (int g = 0; g < RG; ++g) {
+            const int ci = c0i + g;
+            const int ti = t0 + arow0 + RSTEP*ci + k*a.dil - a.left;
+            const float in = (ti >= 0 && ti < T) ? 1.f : 0.f;
+            float f[8];
+            unpack8(araw[3*ci + k], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              acc[g][j] = __builtin_fmaf(in, wc[j], acc[g][j]);
+              acc[g][j] = __builtin_fmaf(wa[j], f[j], acc[g][j]);
+              acc[g][j] = __builtin_fmaf(wb[j], __builtin_fabsf(f[j]), acc[g][j]);
+            }
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+          const int row = arow0 + RSTEP*(c0i + g);
+          const uint4 q = pack8(acc[g]);
+          buf_store16(rz, (unsigned int)(t0 + row)*(unsigned int)(a.ld0*2) + akoff, q);   // t >= T: dropped
+          float r[8], pv[8];
+          unpack8(q, r);
+          const float live = (t0 + row < T) ? 1.f : 0.f;
+          float fs = 0.f, fq = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            pv[j] = live*__builtin_fmaf(d2, __builtin_fabsf(r[j]), d1*r[j]);
+            fs += pv[j]; fq = __builtin_fmaf(pv[j], pv[j], fq);
+          }
+          ts += fs; tq += fq;
+          *reinterpret_cast<uint4*>(dst + row*C::LDA + kbase) = pack8(pv);
+        }
+      }
+      a_sum += (double)ts; a_sq += (double)tq;
+      return;
+    }
     float sc[8], sh[8];
     if (AT == 1) {
       const float4 s0 = *reinterpret_cast<const float4*>(scs + kbase);
@@ -181,14 +310,34 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
   // per-item gLN scale/shift table in LDS (rebuilt when the item changes: rare)
   int cur_item = -1;
   auto update_affine = [&](int b) {
-    if (AT != 1 || b == cur_item) return;
+    if (AT == 0 || b == cur_item) return;
     __syncthreads();
-    if (tid < KP) {
+    if (AT == 1 && tid < KP) {
       const NormStat ns = norm_stat(a.stats, b, a.inv_n, a.eps);
       const float g = tid < a.C ? a.gamma[tid] : 0.f;
       const float be = tid < a.C ? a.beta[tid] : 0.f;
       scs[tid] = ns.rstd*g;
       shs[tid] = be - ns.mean*ns.rstd*g;
+    }
+    if (AT == 2 && tid < KP) {
+      const NormStat ns = norm_stat(a.stats, b, a.inv_n, a.eps);
+      scs[tid] = a.lazy_v0[tid] - ns.mean*ns.rstd*a.lazy_v1[tid];
+      if (tid == 0) shs[0] = ns.rstd;
+    }
+    if (AT == 3) {
+      const NormStat ns = norm_stat(a.stats, b, a.inv_n, a.eps);
+      const float c1 = 0.5f*(1.f + slope), c2 = 0.5f*(1.f - slope);
+      for (int c = tid; c < KP; c += C::NTHR) {
+        const bool ok = c < a.C;
+        const float g = ok ? a.gamma[c] : 0.f, be = ok ? a.beta[c] : 0.f;
+        const float scv = ns.rstd*g, shv = be - ns.mean*ns.rstd*g;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float w = ok ? a.taps[c*3 + k] : 0.f;
+          tabs[k*KP + c] = w*c1*scv; tabs[(3 + k)*KP + c] = w*c2*scv; tabs[(6 + k)*KP + c] = w*shv;
+        }
+        tabs[9*KP + c] = ok ? a.dbias[c] : 0.f;
+      }
     }
     __syncthreads();
     cur_item = b;
@@ -205,7 +354,7 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
   const int ncol = blockIdx.y*C::NP + wn*NSL + ech*8;  // global output column of the chunk
   // bias: folded into the accumulator initialisation (register i of chunk f is channel
   // 32f + (i & 3) + 8(i >> 2) + 4(lane >> 5) of this wave's slice)
-  constexpr bool kBias = EM == E_STORE || EM == E_RES_SKIP;
+  constexpr bool kBias = (EM == E_STORE || EM == E_RES_SKIP) && AT != 3;   // the fused stage has no bias
   float bias_r[kBias ? C::NF : 1][16];
   if (kBias) {
 #pragma unroll
@@ -421,7 +570,7 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
 
   // ---- main loop: A prefetched one tile ahead behind counted waits; (b, t0) of the
   // current and the next tile advance incrementally (no integer division per tile) ------
-  uint4 araw[C::ACH];
+  uint4 araw[C::ACH*NA];
   if (t_begin < t_end) {
     int b_cur = t_begin / tpi, t_cur = (t_begin % tpi)*C::BMW;
     load_tile(b_cur, t_cur, true, araw);
@@ -442,7 +591,7 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
 #endif
       BRV_STAMP(tq = stamp());
       update_affine(b_cur);
-      store_tile(t_cur, buf, araw);
+      store_tile(b_cur, t_cur, buf, araw);
       __syncthreads();
       int b_nxt = b_cur, t_nxt = t_cur + C::BMW;
       if (t_nxt >= t_items) { t_nxt = 0; ++b_nxt; }
@@ -454,6 +603,7 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
     }
   }
   flush_stats();
+  flush_astats();
   if (EM == E_GLN_BWD) {
     // column sums: reduce over the lanes that share a chunk (same lane % CH)
     float ca[8], cb[8];

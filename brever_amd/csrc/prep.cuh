@@ -10,6 +10,7 @@ namespace brv {
 struct PrepJob {
   long long src_off, dst_off;
   int R, C, rows, cols, dst_ld, tr;
+  long long scale_off;       // >= 0: source column c is multiplied by params[scale_off + c] first
 };
 __device__ __forceinline__ void prep_job_run(const float* params, bf16_t* prepped,
                                              const PrepJob& j, int part, int nparts) {
@@ -19,7 +20,10 @@ __device__ __forceinline__ void prep_job_run(const float* params, bf16_t* preppe
     const int r = (int)(i / j.cols), c = (int)(i % j.cols);
     const int sr = j.tr ? c : r, sc = j.tr ? r : c;
     float v = 0.f;
-    if (sr < j.R && sc < j.C) v = params[j.src_off + (long long)sr*j.C + sc];
+    if (sr < j.R && sc < j.C) {
+      v = params[j.src_off + (long long)sr*j.C + sc];
+      if (j.scale_off >= 0) v *= params[j.scale_off + sc];
+    }
     prepped[j.dst_off + (long long)r*j.dst_ld + c] = f2bf(v);
   }
 }

@@ -387,6 +387,49 @@ def test_default_width_network_matches_oracle(causal):
 
 
 
+
+def test_fused_forward_option_matches_oracle(monkeypatch):
+    """BRV_FWD_FUSE=1 (opt-in; measured slower): depthwise stage inside the [res | skip]
+    product's operand staging, second norm applied lazily by the consumers. Same function, other
+    rounding points: output and gradients vs the fp32 oracle at the bf16 tolerances, next to
+    the default three-launch path."""
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    from oracle.convtasnet import OracleConvTasNet
+    cfg = dict(layers=4, repeats=2)
+    torch.manual_seed(3)
+    oracle = OracleConvTasNet(**cfg)
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for name, p in oracle.named_parameters():
+            if 'norm' in name or 'prelu' in name:
+                p.add_(0.1*torch.randn(p.shape, generator=gen))
+    B, L = 3, 2500
+    batch = 0.3*torch.randn(B, 2, L, generator=gen)
+    lengths = torch.tensor([L, L - 300, L - 1111])
+    for b in range(B):
+        batch[b, :, lengths[b]:] = 0
+    want = oracle(batch[:, 0])
+    oracle.criterion(want, batch[:, 1:], lengths).mean().backward()
+    want = want.detach()
+    gold = torch.cat([p.grad.reshape(-1) for p in oracle.parameters()])
+    grads = {}
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('BRV_FWD_FUSE', fuse)
+        net = ConvTasNet(**cfg)
+        net.load_state_dict(oracle.state_dict())
+        net = net.to(_cuda())
+        net._amp = True
+        out = net(batch[:, 0].cuda())
+        assert rel(out, want) <= 2e-2, (fuse, rel(out, want))
+        loss = snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean()
+        loss.backward()
+        grads[fuse] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+    # both paths are bf16 approximations of the same fp32 function (8 blocks): the gradient
+    # tolerance of the bf16 path, and the fused path no further from the reference than 1.5x
+    e0, e1 = rel(grads['0'], gold), rel(grads['1'], gold)
+    assert e0 <= 8e-2 and e1 <= 8e-2 and e1 <= 1.5*e0 + 1e-2, (e0, e1)
+
 # ---- fp32 path (use_amp=False): the parity protocol of SURVEY.md 8(d) at fp32 tolerances -------
 @pytest.mark.parametrize('tag', ['small', 'small2', 'causal', 'causal2'])
 def test_fp32_path_matches_reference(golden_dir, tag):
