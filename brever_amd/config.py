@@ -1,27 +1,72 @@
-"""Configuration objects of the entry points.
+"""Configuration objects of the entry points (interface of brever/config.py:13-136,263-319).
 
-Compact equivalent of the reference's config system for the hot path
-(brever/config.py:13-136): ``get_config(path)`` loads a ``config.yaml`` into an
-immutable nested ``BreverConfig`` with attribute access, ``to_dict()``, an
-order-independent ``get_hash()`` (first 8 hex of a sha256, config.py:78-95) and
-``update_from_args`` for command-line overrides (config.py:104-123). Default model
-hyper-parameters come from the model's ``__init__`` signature (the reference
-requires its YAML defaults to equal them, config.py:24-28). Experiment
-book-keeping (finders / initialisers) is out of scope.
+``get_config(path)`` loads a ``config.yaml`` into an immutable nested ``BreverConfig`` with
+attribute access, ``to_dict()`` / ``to_json()``, ``get_field`` / ``set_field`` on key paths,
+``update_from_args`` (argparse namespace + the ``arg_map`` of ``brever_amd.args``) and
+``get_hash()``. The hash is the model-directory id, so it is reproduced byte for byte: sha256 of
+``str(d.items())`` of the recursively key-sorted dict with sets as sorted lists
+(config.py:78-95) -- pinned by the reference's hashes of its own default configs and of 20
+perturbed ones (tests/golden/config.json). ``get_model_default_config`` reads
+``config/models/<arch>.yaml`` and warns when its ``model`` section differs from the model's
+signature defaults (config.py:20-31). Dataset / model *finders* (experiment book-keeping) are
+out of scope.
 """
 import hashlib
-import inspect
-import json
+import os
+import warnings
 
 import yaml
+
+from .inspect import Path, get_func_spec
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _resolve(relpath):
+    """The reference opens ``config/...`` relative to the working directory; fall back to the
+    files shipped with this package when the caller runs from somewhere else."""
+    if os.path.exists(relpath):
+        return relpath
+    return os.path.join(_ROOT, relpath)
+
+
+def get_config(path):
+    with open(path) as f:
+        return BreverConfig(yaml.load(f, Loader=yaml.Loader))
+
+
+def get_model_default_config(model_key):
+    from .models import ModelRegistry
+    path = f'config/models/{model_key}.yaml'
+    with open(_resolve(path)) as f:
+        content = yaml.load(f, Loader=yaml.Loader)
+    signature = {name: item['default']
+                 for name, item in get_func_spec(ModelRegistry.get(model_key)).items()}
+    if content['model'] != signature:
+        warnings.warn(f'Default config file {path} does not match default '
+                      'arguments from model __init__ signature')
+    return BreverConfig(content)
+
+
+def _canonical(node):
+    """Key-sorted copy with sets as sorted lists: what the hash is taken of."""
+    out = {}
+    for key in sorted(node):
+        value = node[key]
+        if isinstance(value, dict):
+            out[key] = _canonical(value)
+        elif isinstance(value, set):
+            out[key] = sorted(value)
+        else:
+            out[key] = value
+    return out
 
 
 class BreverConfig:
     def __init__(self, dict_):
         for key, value in dict_.items():
-            if isinstance(value, dict):
-                value = BreverConfig(value)
-            super().__setattr__(key, value)
+            object.__setattr__(self, key,
+                               BreverConfig(value) if isinstance(value, dict) else value)
 
     def __setattr__(self, attr, value):
         raise AttributeError(f'{self.__class__.__name__} objects are immutable')
@@ -37,85 +82,90 @@ class BreverConfig:
                 for k, v in self.__dict__.items()}
 
     def to_json(self):
-        def norm(x):
-            if isinstance(x, dict):
-                return {k: norm(v) for k, v in sorted(x.items())}
-            if isinstance(x, (set, frozenset)):
-                return sorted(norm(v) for v in x)
-            if isinstance(x, (list, tuple)):
-                return [norm(v) for v in x]
-            return x
-        return norm(self.to_dict())
+        out = {}
+        for k, v in self.__dict__.items():
+            if isinstance(v, BreverConfig):
+                out[k] = v.to_json()
+            else:
+                out[k] = sorted(v) if isinstance(v, set) else v
+        return out
 
     def get_hash(self, length=8):
-        text = json.dumps(self.to_json(), sort_keys=True)
+        text = str(_canonical(self.to_dict()).items())
         return hashlib.sha256(text.encode()).hexdigest()[:length]
+
+    def get_field(self, key_list):
+        node = self
+        for key in key_list:
+            node = getattr(node, key)
+        return node
+
+    def set_field(self, key_list, value):
+        owner = self.get_field(key_list[:-1])
+        key = key_list[-1]
+        current = getattr(owner, key)
+        if not isinstance(value, type(current)):
+            raise TypeError(f'attribute {key} must be {type(current).__name__}, '
+                            f'got {type(value).__name__}')
+        object.__setattr__(owner, key, value)
+
+    def update_from_args(self, args, arg_map):
+        """Options the user did not pass are ``None`` in ``args`` and leave the file's value."""
+        for name, key_lists in arg_map.items():
+            value = getattr(args, name)
+            if value is None:
+                continue
+            for key_list in key_lists:
+                self.set_field(key_list, value)
 
     def update_from_dict(self, dict_, parent_keys=()):
         for key, value in dict_.items():
-            current = getattr(self, key)
-            if isinstance(current, BreverConfig):
-                current.update_from_dict(value, parent_keys + (key,))
-                continue
-            if current is not None and value is not None \
-                    and type(current) is not type(value) \
-                    and not (isinstance(current, float) and isinstance(value, int)):
-                raise TypeError(
-                    f'type mismatch for {".".join(parent_keys + (key,))}: '
-                    f'{type(current).__name__} vs {type(value).__name__}')
-            object.__setattr__(self, key, value)
-
-    def update_from_args(self, args, arg_map):
-        """``arg_map``: argparse dest -> sequence of nested keys; only options the
-        user actually passed (not None) override the file."""
-        for dest, keys in arg_map.items():
-            value = getattr(args, dest, None)
-            if value is None:
-                continue
-            node = self
-            for key in keys[:-1]:
-                node = getattr(node, key)
-            node.update_from_dict({keys[-1]: value}, tuple(keys[:-1]))
+            path = list(parent_keys) + [key]
+            if isinstance(value, dict):
+                self.update_from_dict(value, path)
+            else:
+                self.set_field(path, value)
 
 
-def get_config(path):
-    with open(path) as f:
-        return BreverConfig(yaml.load(f, Loader=yaml.Loader))
+class ModelInitializer:
+    """``models/<hash>/config.yaml`` writer (config.py:263-308)."""
 
+    def __init__(self, batch_mode=False, models_dir=None):
+        self.dir_ = models_dir or get_config(_resolve('config/paths.yaml')).MODELS
+        self.batch_mode = batch_mode
 
-def signature_defaults(func, skip=('self', 'model', 'train_dataset', 'val_dataset',
-                                   'model_dirpath')):
-    out = {}
-    for name, prm in inspect.signature(func).parameters.items():
-        if name in skip or prm.default is inspect.Parameter.empty:
-            continue
-        out[name] = prm.default
-    return out
+    def init_from_args(self, args):
+        from .args import ModelArgParser
+        config = get_model_default_config(args.arch)
+        config.update_from_args(args, ModelArgParser.arg_map(args.arch))
+        return self.write_config(config, args.force)
 
+    def get_config_from_kwargs(self, arch, **kwargs):
+        from .args import ModelArgParser
+        config = get_model_default_config(arch)
+        arg_map = ModelArgParser.arg_map(arch)
+        for key, value in kwargs.items():
+            for key_list in arg_map[key]:
+                config.set_field(key_list, value)
+        return config
 
-def model_defaults(model_cls):
-    """Constructor defaults of a model class; sub-models (``_is_submodel``) inherit their
-    parent's and override some (brever/inspect.py:123-126)."""
-    out = {}
-    if model_cls.__dict__.get('_is_submodel', False):
-        out = model_defaults(model_cls.__bases__[0])
-    out.update(signature_defaults(model_cls.__init__))
-    out.update(model_cls.__dict__.get('_defaults', {}))
-    return out
+    def init_from_kwargs(self, arch, force=False, model_id=None, **kwargs):
+        return self.write_config(self.get_config_from_kwargs(arch, **kwargs), force=force,
+                                 model_id=model_id)
 
+    def get_path_from_kwargs(self, arch, **kwargs):
+        return Path(os.path.join(self.dir_, self.get_config_from_kwargs(arch, **kwargs).get_hash()))
 
-def get_model_default_config(arch):
-    """Default ``config.yaml`` content for ``arch`` (model + trainer + dataset)."""
-    from .models import ModelRegistry
-    from .training import BreverTrainer
-    model_cls = ModelRegistry.get(arch)
-    trainer = signature_defaults(BreverTrainer.__init__)
-    trainer['val_metrics'] = {'snr'}     # pesq / estoi wheels are absent here
-    trainer['use_amp'] = True
-    return BreverConfig({
-        'arch': arch, 'seed': 0, 'train_path': 'none', 'val_path': 'none',
-        'dataset': {'fs': 16000, 'sources': ['mixture', 'foreground'],
-                    'segment_length': 0.0, 'max_segment_length': 0.0},
-        'trainer': trainer,
-        'model': model_defaults(model_cls),
-    })
+    def write_config(self, config, force=False, model_id=None):
+        model_dir = os.path.join(self.dir_, model_id or config.get_hash())
+        os.makedirs(model_dir, exist_ok=True)
+        config_path = os.path.join(model_dir, 'config.yaml')
+        if os.path.exists(config_path) and not force:
+            if not self.batch_mode:
+                raise FileExistsError(f'model already exists: {config_path}')
+            print(f'model already exists: {config_path}')
+        else:
+            with open(config_path, 'w') as f:
+                yaml.dump(config.to_dict(), f)
+            print(f'Initialized {config_path}')
+        return Path(model_dir)

@@ -518,7 +518,8 @@ __global__ __launch_bounds__(256) void skip_combine_kernel(const SkipCombinePara
 // ===========================================================================
 // fold the replicated per-channel gradients into the flat gradient
 int reduce_vector_grads(const Layout& l, const Workspace& ws, const float* vg, float* grads,
-                        hipStream_t st) {
+                        hipStream_t st, int blk_lo = 0, int blk_hi = 1 << 30, bool do_ln = true,
+                        bool do_tcn = true) {
   const long long vper = (long long)l.H*(5 + l.P);
   {
     VgradParams vp; memset(&vp, 0, sizeof(vp));
@@ -531,6 +532,7 @@ int reduce_vector_grads(const Layout& l, const Workspace& ws, const float* vg, f
     vp.o_dconv_w = b0.dconv_w - b0.conv_w; vp.o_dconv_b = b0.dconv_b - b0.conv_w;
     vp.o_n1_g_full = b0.n1_g - b0.conv_w; vp.o_n1_g_last = bl.n1_g - bl.conv_w;
     vp.tcn_prelu_off = l.tcn_prelu;
+    vp.blk_lo = blk_lo; vp.blk_hi = blk_hi; vp.do_ln = do_ln; vp.do_tcn = do_tcn;
     if (b0.prelu1 != b0.n1_g + 4LL*l.H || b0.prelu2 != b0.prelu1 + 1)
       return fail(-1, "vgrad_reduce: unexpected PReLU offsets");
     const long long total = 2LL*l.N + vper*l.nb + 1 + 2*l.nb;
@@ -1184,15 +1186,60 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   return 0;
 }
 
+// Block range of part `part` of `nparts`: the backward pass walks the blocks from the last to
+// the first, so part 0 owns the LAST group of blocks.
+static void part_range(int nb, int part, int nparts, int& lo, int& hi) {
+  lo = (int)((long long)nb*(nparts - 1 - part)/nparts);
+  hi = (int)((long long)nb*(nparts - part)/nparts) - 1;
+}
+
+int brv_ctn_grad_bucket(const brv_ctn_config* cfg, int32_t part, int32_t nparts, int64_t* offset,
+                        int64_t* count) {
+  Layout l; if (int r = l.init(cfg)) return r;
+  if (nparts < 1 || part < 0 || part >= nparts || !offset || !count) return fail(-1, "bad part");
+  if (l.causal) {                       // the causal path runs whole in its last part
+    *offset = 0; *count = part == nparts - 1 ? l.n_params : 0;
+    return 0;
+  }
+  int lo, hi; part_range(l.nb, part, nparts, lo, hi);
+  // flat layout: [enc dec ln bottleneck | block 0 .. block nb-1 | tcn prelu, output conv]
+  const long long begin = part == nparts - 1 ? 0 : (lo <= hi ? l.blk[lo].conv_w : -1);
+  int plo, phi; long long end = l.n_params;
+  if (part > 0) {                        // ends where the previous (later-block) part began
+    int q = part - 1;
+    for (;; --q) { part_range(l.nb, q, nparts, plo, phi); if (plo <= phi || q == 0) break; }
+    end = plo <= phi ? l.blk[plo].conv_w : l.n_params;
+    // empty earlier parts took nothing but the tail; the tail belongs to part 0 only
+    if (plo > phi) end = l.tcn_prelu;
+  }
+  if (begin < 0) { *offset = 0; *count = 0; if (part == 0) { *offset = l.tcn_prelu; *count = l.n_params - l.tcn_prelu; } return 0; }
+  *offset = begin; *count = end - begin;
+  return 0;
+}
+
 int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void* prepared,
                      void* workspace, const float* wave, const float* d_out, float* grads,
                      int64_t batch, int64_t length, brv_stream_t stream) {
+  return brv_ctn_backward_part(cfg, params, prepared, workspace, wave, d_out, grads, batch, length,
+                               0, 1, stream);
+}
+
+int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const void* prepared,
+                          void* workspace, const float* wave, const float* d_out, float* grads,
+                          int64_t batch, int64_t length, int32_t part, int32_t nparts,
+                          brv_stream_t stream) {
   Layout l; if (int r = l.init(cfg)) return r;
   hipStream_t st = (hipStream_t)stream;
   const int B = (int)batch; const long long L = length;
   const long long T = l.frames(L);
   if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
-  if (l.causal) return backward_causal(l, cfg, params, prepared, workspace, wave, d_out, grads, B, L, T, st);
+  if (nparts < 1 || part < 0 || part >= nparts) return fail(-1, "bad part");
+  if (l.causal) {
+    if (part != nparts - 1) return 0;
+    return backward_causal(l, cfg, params, prepared, workspace, wave, d_out, grads, B, L, T, st);
+  }
+  int blk_lo, blk_hi; part_range(l.nb, part, nparts, blk_lo, blk_hi);
+  const bool head = part == 0, tail = part == nparts - 1;
   Workspace ws; ws.init(l, B, T);
   const double BT = (double)B*(double)T;
   char* base = (char*)workspace;
@@ -1224,10 +1271,10 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   auto vslot = [&](int i) { return vg + 2LL*l.N + vper*i; };   // block i's vector grads
   float* vslope = vg + 2LL*l.N + vper*l.nb;    // PReLU slope grads: tcn, then (prelu1, prelu2) per block
 
+  GemmRowsParams g; WgradParams wg;
+  if (head) {
   HIP_OK(hipMemsetAsync(sums, 0, ws.stats_bytes, st));
   HIP_OK(hipMemsetAsync(vg, 0, ws.vg_bytes, st));
-
-  GemmRowsParams g; WgradParams wg;
   // decoder data gradient (framing of d_out) fused with the mask backward
   memset(&g, 0, sizeof(g));
   g.a = frames_of(d_out, L, l.hop, l.K);
@@ -1259,8 +1306,9 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     wg.Kout = l.Sc; wg.ldo = l.Sc; wg.gbias0 = grads + l.out_b + (long long)s*l.N;
     if (int r = launch_wgrad<A_F32>(wg, st, "wgrad_out", 2.0*BT*l.Np + 4.0*BT*l.Scp)) return r;
   }
+  }   // head
 
-  for (int i = l.nb - 1; i >= 0; --i) {
+  for (int i = blk_hi; i >= blk_lo; --i) {
     const BlockOff& b = l.blk[i];
     const bool has_res = i < l.nb - 1;
     const int dil = 1 << (i % cfg->layers);
@@ -1336,21 +1384,22 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     }
     if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
   }
-  // deferred weight gradients of all blocks: two grouped launches
+  // deferred weight gradients of this part's blocks: two grouped launches
   // residual / skip convs of every block in ONE launch when the padded widths are the
   // default 128 | 128 (gemm_wgrad_full.cuh); other architectures use the generic path
   const bool full_rs = l.Bnp == 128 && l.Scp == 128 && l.Hp % W2_BH == 0 && l.nb <= kWgMaxProb &&
                        !getenv("BRV_NO_WGRAD_FULL");
-  if (full_rs) {
+  if (full_rs && blk_lo <= blk_hi) {
     WgradFullParams fp; memset(&fp, 0, sizeof(fp));
-    fp.B = B; fp.T = (int)T; fp.nprob = l.nb; fp.n_htiles = l.Hp/W2_BH;
+    const int nblk = blk_hi - blk_lo + 1;
+    fp.B = B; fp.T = (int)T; fp.nprob = nblk; fp.n_htiles = l.Hp/W2_BH;
     fp.ldg0 = l.Bnp; fp.bsg0 = T*l.Bnp; fp.ldg1 = ldg; fp.bsg1 = T*ldg;
     fp.ldh = l.Hp; fp.bsh = T*l.Hp;
     fp.N0 = l.Bn; fp.N1 = l.Sc; fp.Kout = l.H; fp.ldo = l.H;
     fp.inv_n = 1.0/((double)T*l.H); fp.eps = 1e-8f;
-    for (int i = 0; i < l.nb; ++i) {
+    for (int i = blk_lo; i <= blk_hi; ++i) {
       const BlockOff& b = l.blk[i];
-      WgradProb& pr = fp.prob[i];
+      WgradProb& pr = fp.prob[i - blk_lo];
       const bool has_res = i < l.nb - 1;
       pr.g0 = has_res ? gcopy(i) : nullptr; pr.g1 = gskip; pr.h = z2buf(i);
       pr.out0 = has_res ? grads + b.res_w : nullptr; pr.out1 = grads + b.skip_w;
@@ -1358,8 +1407,8 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
       pr.slope = params + b.prelu2; pr.stats = stat(2 + 2*i);
       pr.gamma = params + b.n2_g; pr.beta = params + b.n2_b;
     }
-    ProfScope prof("pw2_wgrad", 2.0*l.nb*BT*(double)(l.Bnp + l.Scp)*l.Hp,
-                   2.0*BT*(l.Bnp + l.Scp + l.Hp)*l.nb, st);
+    ProfScope prof("pw2_wgrad", 2.0*nblk*BT*(double)(l.Bnp + l.Scp)*l.Hp,
+                   2.0*BT*(l.Bnp + l.Scp + l.Hp)*nblk, st);
 #ifdef BRV_DIAG
     if (const char* d = getenv("BRV_DBG_WG")) fp.dbg = atoi(d);
 #endif
@@ -1367,14 +1416,14 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     // divided over kWgSplit workgroups each (768 = 3 full rounds) when the batch allows
     fp.n_split = (B >= kWgSplit && !getenv("BRV_NO_WGRAD_SPLIT")) ? kWgSplit : 1;
     fp.part = reinterpret_cast<float*>(base + ws.wgpart);
-    const int grid = 8*ceil_div(l.nb, 8)*fp.n_htiles*fp.n_split;
+    const int grid = 8*ceil_div(nblk, 8)*fp.n_htiles*fp.n_split;
     hipLaunchKernelGGL(wgrad_full_kernel, dim3(grid), dim3(64*W2_NW), 0, st, fp);
     if (fp.n_split > 1)
-      hipLaunchKernelGGL(wgrad_full_reduce_kernel, dim3(128, (unsigned)l.nb), dim3(256), 0, st, fp);
+      hipLaunchKernelGGL(wgrad_full_reduce_kernel, dim3(128, (unsigned)nblk), dim3(256), 0, st, fp);
     HIP_OK(hipGetLastError());
   }
-  for (int i0 = 0; i0 < l.nb; i0 += kWgMaxProb) {
-    const int n = std::min(kWgMaxProb, l.nb - i0);
+  for (int i0 = blk_lo; i0 <= blk_hi; i0 += kWgMaxProb) {
+    const int n = std::min(kWgMaxProb, blk_hi + 1 - i0);
     // [res | skip]: G = [g_out_i | g_skip], H = gLN_2(prelu_2(z2_i)); the last block has
     // no residual conv, so it goes in a launch of its own (different G width)
     WgradGroupParams gp; memset(&gp, 0, sizeof(gp));
@@ -1427,6 +1476,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
     if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp)))
       return r;
   }
+  if (tail) {
   // bottleneck conv: data gradient + first gLN backward partials
   memset(&g, 0, sizeof(g));
   g.a = rows_bf16(gout, ldg, T);
@@ -1466,7 +1516,9 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void*
   wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
   wg.out0 = grads + l.enc_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
   if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_enc", 2.0*BT*l.Np + 4.0*B*L)) return r;
-  return reduce_vector_grads(l, ws, vg, grads, st);
+  }   // tail
+  // per-channel / slope gradients of this part: fold the replicas into the flat gradient
+  return reduce_vector_grads(l, ws, vg, grads, st, blk_lo, blk_hi, tail, head);
 }
 
 }  // extern "C"

@@ -642,9 +642,26 @@ int brv_ctn_f32_forward(const brv_ctn_config* cfg, const float* params, void* wo
 int brv_ctn_f32_backward(const brv_ctn_config* cfg, const float* params, void* workspace,
                          const float* wave, const float* d_out, float* grads, int64_t batch,
                          int64_t length, brv_stream_t stream) {
+  return brv_ctn_f32_backward_part(cfg, params, workspace, wave, d_out, grads, batch, length, 0, 1,
+                                   stream);
+}
+
+// Part `part` of `nparts` of the backward pass (same block ranges and gradient buckets as
+// brv_ctn_backward_part / brv_ctn_grad_bucket; the causal model runs whole in its last part).
+int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, void* workspace,
+                              const float* wave, const float* d_out, float* grads, int64_t batch,
+                              int64_t length, int32_t part, int32_t nparts, brv_stream_t stream) {
   Lay32 l; OK32(l.init(cfg));
   const long long B = batch, L = length, T = l.frames(L);
   if (B < 1 || T < 1) return fail32(-1, "empty batch or input shorter than one frame");
+  if (nparts < 1 || part < 0 || part >= nparts) return fail32(-1, "bad part");
+  if (l.causal && nparts > 1) {
+    if (part != nparts - 1) return 0;
+    part = 0; nparts = 1;
+  }
+  const int blk_lo = (int)((long long)l.nb*(nparts - 1 - part)/nparts);
+  const int blk_hi = (int)((long long)l.nb*(nparts - part)/nparts) - 1;
+  const bool head = part == 0, tail = part == nparts - 1;
   Ws32 ws; ws.init(l, B, T, L);
   Ctx32 c{l, ws, (float*)workspace, params, grads, B, T, L, B*T, (hipStream_t)stream};
   const long long BT = c.BT, BS = B*l.S;
@@ -655,7 +672,8 @@ int brv_ctn_f32_backward(const brv_ctn_config* cfg, const float* params, void* w
   float* dpre = c.f(ws.dpre);
   float* G = c.f(ws.G); float* e = c.f(ws.e); float* dz = c.f(ws.dz);
   const int ldg = l.Bn + l.Sc;
-  float* part = c.f(ws.scalars);
+  float* spart = c.f(ws.scalars);
+  if (head) {
   // decoder: d frames = framing of the padded d_out; dy = d frames x dec_w^T; dec_w gradient
   hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(BS*ws.Lp)), dim3(256), 0, st, d_out, dop, BS, L, ws.Lp);
   OK32(gemm32(c, dop, params + l.dec_w, dy, BS, T, l.N, l.K, l.hop, l.K, l.N, ws.Lp, 0, T*l.N, 0, 1,
@@ -672,10 +690,11 @@ int brv_ctn_f32_backward(const brv_ctn_config* cfg, const float* params, void* w
   {
     int g = grid_for(BT*l.Sc); if (g > kSlopeBlocks) g = kSlopeBlocks;
     hipLaunchKernelGGL(f32_prelu_bwd_kernel, dim3(g), dim3(256), 0, st, e, skip, params + l.tcn_prelu,
-                       G + l.Bn, ldg, part, BT, l.Sc);
-    hipLaunchKernelGGL(f32_fold_scalar_kernel, dim3(1), dim3(256), 0, st, part, g, grads + l.tcn_prelu);
+                       G + l.Bn, ldg, spart, BT, l.Sc);
+    hipLaunchKernelGGL(f32_fold_scalar_kernel, dim3(1), dim3(256), 0, st, spart, g, grads + l.tcn_prelu);
   }
-  for (int i = l.nb - 1; i >= 0; --i) {
+  }   // head
+  for (int i = blk_hi; i >= blk_lo; --i) {
     const Blk32& b = l.blk[i];
     const bool has_res = i < l.nb - 1;
     const int dil = 1 << (i % l.layers);
@@ -710,6 +729,7 @@ int brv_ctn_f32_backward(const brv_ctn_config* cfg, const float* params, void* w
     OK32(col_sum(c, dz, l.H, l.H, grads + b.conv_b));
     OK32(conv1x1_dgrad(c, dz, l.H, params + b.conv_w, l.H, l.Bn, G, ldg, has_res ? 1 : 0));
   }
+  if (tail) {
   // bottleneck conv, first layer norm, encoder
   OK32(conv1x1_wgrad(c, G, ldg, wn, l.N, l.Bn, l.N, grads + l.bott_w));
   OK32(col_sum(c, G, ldg, l.Bn, grads + l.bott_b));
@@ -718,6 +738,7 @@ int brv_ctn_f32_backward(const brv_ctn_config* cfg, const float* params, void* w
                      grads + l.ln_b, nullptr));
   OK32(gemm32(c, dz, c.f(ws.wavep), grads + l.enc_w, 1, l.N, l.K, T, l.N, l.hop, l.K, 0, 0, 0, 1, 0, B,
               T*l.N, ws.Lp, nullptr, 1));
+  }   // tail
   HIP_OK32(hipGetLastError());
   (void)wave; (void)wn;
   return 0;

@@ -592,6 +592,9 @@ struct VgradParams {
   long long blk_full;        // floats per (non-last) block
   long long o_dconv_w, o_dconv_b, o_n1_g_full, o_n1_g_last;   // offsets inside a block
   long long tcn_prelu_off;   // PReLU slopes: slot 0 = tcn, 1+2i / 2+2i = block i (right after n2_b)
+  // partial folds (backward in parts, gradient buckets): only blocks [blk_lo, blk_hi], the first
+  // layer norm iff do_ln, the TCN output PReLU slope iff do_tcn
+  int blk_lo, blk_hi, do_ln, do_tcn;
 };
 __global__ __launch_bounds__(256) void vgrad_reduce_kernel(const VgradParams p) {
   const long long per_blk = (long long)p.H*(5 + p.P);
@@ -599,23 +602,23 @@ __global__ __launch_bounds__(256) void vgrad_reduce_kernel(const VgradParams p) 
   const long long total = n_vec + 1 + 2*p.nb;
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < total;
        i += (long long)gridDim.x*256) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < kReplicas; ++r) s += p.vg[(long long)r*p.rep_stride + i];
     long long dst;
     if (i >= n_vec) {                              // PReLU slopes
       const int k = (int)(i - n_vec);
-      if (k == 0) dst = p.tcn_prelu_off;
+      if (k == 0) { if (!p.do_tcn) continue; dst = p.tcn_prelu_off; }
       else {                                       // the two slopes follow n2_b
         const int blk = (k - 1) >> 1;
+        if (blk < p.blk_lo || blk > p.blk_hi) continue;
         const long long n1 = blk == p.nb - 1 ? p.o_n1_g_last : p.o_n1_g_full;
         dst = p.blk0_off + blk*p.blk_full + n1 + 4LL*p.H + ((k - 1) & 1);
       }
     } else if (i < 2LL*p.N) {
+      if (!p.do_ln) continue;
       dst = p.ln_g_off + i;                        // ln_g then ln_b are adjacent
     } else {
       const long long j = i - 2LL*p.N;
       const int blk = (int)(j / per_blk);
+      if (blk < p.blk_lo || blk > p.blk_hi) continue;
       const long long k = j % per_blk;
       const long long base = p.blk0_off + blk*p.blk_full;
       const long long n1 = blk == p.nb - 1 ? p.o_n1_g_last : p.o_n1_g_full;
@@ -623,6 +626,9 @@ __global__ __launch_bounds__(256) void vgrad_reduce_kernel(const VgradParams p) 
       else if (k < 4LL*p.H + (long long)p.H*p.P) dst = base + p.o_dconv_w + (k - 4LL*p.H);
       else dst = base + p.o_dconv_b + (k - 4LL*p.H - (long long)p.H*p.P);
     }
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < kReplicas; ++r) s += p.vg[(long long)r*p.rep_stride + i];
     p.grads[dst] += s;
   }
 }

@@ -23,6 +23,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .inspect import NoParse
+
 
 class BreverDataLoader(torch.utils.data.DataLoader):
     """DataLoader that right-zero-pads ragged items to the batch maximum."""
@@ -64,6 +66,90 @@ class BreverDataLoader(torch.utils.data.DataLoader):
         if single:
             return batched[0], lengths.squeeze(-1)
         return batched, lengths
+
+
+class DevicePrefetcher:
+    """Pinned, double-buffered host -> HBM staging of the batches of a loader.
+
+    The reference moves every batch with a synchronous ``.to(device)`` inside the step
+    loop (brever/training.py:310-314) after an optional ``pin_memory`` DataLoader
+    (brever/data.py:494-530). Here batch ``i + 1`` is copied on a side HIP stream from
+    one of ``depth`` reusable pinned host buffers while batch ``i`` computes; the
+    consumer's stream waits on the copy's event only. A 16 x 2 x 64 000 fp32 batch is
+    8.2 MB (~0.15 ms over PCIe Gen5): fully hidden behind a multi-millisecond step.
+    Iterating yields the same ``(batch, lengths)`` pairs as the loader, on ``device``.
+    CPU devices pass through unchanged.
+    """
+
+    def __init__(self, loader, device, depth=2):
+        self.loader = loader
+        self.device = torch.device(device)
+        self.depth = max(1, int(depth))
+        self._pinned = {}
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _pin(self, slot, key, t):
+        """Copy ``t`` into this slot's pinned buffer (grown on demand)."""
+        buf = self._pinned.get((slot, key))
+        n = t.numel()
+        if buf is None or buf.dtype != t.dtype or buf.numel() < n:
+            buf = torch.empty(max(n, 1), dtype=t.dtype).pin_memory()
+            self._pinned[(slot, key)] = buf
+        view = buf[:n].view(t.shape)
+        view.copy_(t)
+        return view
+
+    def _stage(self, item, slot, stream, fence):
+        if fence is not None:
+            fence.synchronize()          # the copy that last used this slot's buffers is done
+        batch, lengths = item
+        with torch.cuda.stream(stream):
+            def up(key, t):
+                if t.is_cuda:
+                    return t
+                return self._pin(slot, key, t.contiguous()).to(self.device, non_blocking=True)
+            if isinstance(batch, (list, tuple)):
+                dev_batch = [up(('b', i), x) for i, x in enumerate(batch)]
+            else:
+                dev_batch = up('b', batch)
+            dev_lengths = up('l', lengths)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return dev_batch, dev_lengths, ev
+
+    def __iter__(self):
+        if self.device.type != 'cuda':
+            yield from self.loader
+            return
+        stream = torch.cuda.Stream(self.device)
+        it = iter(self.loader)
+        queue, fences, slot = [], [None]*self.depth, 0
+
+        def fill():
+            nonlocal slot
+            try:
+                item = next(it)
+            except StopIteration:
+                return False
+            staged = self._stage(item, slot, stream, fences[slot])
+            fences[slot] = staged[2]
+            queue.append(staged)
+            slot = (slot + 1) % self.depth
+            return True
+
+        for _ in range(self.depth):
+            if not fill():
+                break
+        while queue:
+            batch, lengths, ev = queue.pop(0)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in (batch if isinstance(batch, list) else [batch]) + [lengths]:
+                t.record_stream(cur)
+            fill()                       # next copy runs while this batch computes
+            yield batch, lengths
 
 
 class SyntheticMixtureDataset(torch.utils.data.Dataset):
@@ -235,10 +321,20 @@ class BreverDataset(torch.utils.data.Dataset):
     ``(n_sources, 2, n_samples)`` float32 tensors, or whatever ``transform`` makes of them).
     ``dynamic_mixing`` (on-the-fly mixture synthesis) is not built."""
 
-    def __init__(self, path, segment_length=0.0, overlap_length=0.0, fs=16000,
-                 sources=('mixture', 'foreground'), segment_strategy='pass',
-                 max_segment_length=0.0, tar=True, transform=None, dynamic_mixing=False,
-                 dynamic_mixtures_per_epoch=1000):
+    def __init__(
+        self,
+        path: NoParse[str],
+        segment_length: float = 0.0,
+        overlap_length: float = 0.0,
+        fs: int = 16000,
+        sources: list[str] = ['mixture', 'foreground'],
+        segment_strategy: str = 'pass',
+        max_segment_length: float = 0.0,
+        tar: bool = True,
+        transform: NoParse[object] = None,
+        dynamic_mixing: bool = False,
+        dynamic_mixtures_per_epoch: int = 1000,
+    ):
         if dynamic_mixing:
             raise NotImplementedError('dynamic mixing is not built yet on this path')
         self.path = path

@@ -45,11 +45,27 @@ SIGNATURES = {
     'brv_ctn_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                         _c_ptr, _c_ptr, _c_i64, _c_i64,
                                         _c_ptr]),
+    'brv_ctn_backward_part': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                             _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                             ctypes.c_int32, ctypes.c_int32, _c_ptr]),
+    'brv_ctn_grad_bucket': (ctypes.c_int, [_c_ptr, ctypes.c_int32, ctypes.c_int32,
+                                           _c_ptr, _c_ptr]),
+    'brv_ctn_f32_backward_part': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                                 _c_ptr, _c_i64, _c_i64, ctypes.c_int32,
+                                                 ctypes.c_int32, _c_ptr]),
     'brv_ctn_f32_workspace_bytes': (_c_i64, [_c_ptr, _c_i64, _c_i64]),
     'brv_ctn_f32_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                            _c_i64, _c_i64, _c_ptr]),
     'brv_ctn_f32_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                             _c_ptr, _c_i64, _c_i64, _c_ptr]),
+    'brv_resample_poly': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_i64]*7 + [_c_ptr]),
+    'brv_stoi_frames': (_c_i64, [_c_i64]),
+    'brv_stoi_compact': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr,
+                                        _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr]),
+    'brv_stoi_bands': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64,
+                                      _c_ptr]),
+    'brv_stoi_correlate': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
+                                          ctypes.c_int, _c_f32, _c_ptr]),
     'brv_loss_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_snr_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
                                        _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),

@@ -267,7 +267,11 @@ class ConvTasNet(BreverBaseModel):
 
     def set_grad_sync(self, fn):
         """``fn(flat_grad) -> grad_scale`` is called between backward and the
-        optimizer step of ``train_step`` (data-parallel all-reduce)."""
+        optimizer step (data-parallel all-reduce). If ``fn`` also has ``nparts > 1``,
+        ``bucket(part, grad_slice)`` and ``finish() -> grad_scale``, the fused
+        ``train_step`` runs the backward pass in ``nparts`` parts and hands each
+        finished gradient slice to ``bucket`` right away, so that its all-reduce
+        overlaps the rest of backward (brever_amd.parallel.GradSynchronizer)."""
         self._grad_sync = fn
 
     def init_optimizer(self, optimizer, net=None, **kwargs):
@@ -369,22 +373,45 @@ class ConvTasNet(BreverBaseModel):
         self._ws_version[amp] += 1
         return out
 
-    def _hip_backward(self, wave, d_out, flat_grad, amp=True):
+    def grad_buckets(self, nparts):
+        """``[(offset, count)]``: the slice of the flat gradient that is final after
+        part ``p`` of an ``nparts``-part backward (``brv_ctn_grad_bucket``)."""
+        import ctypes
+        out = []
+        for part in range(nparts):
+            off, cnt = ctypes.c_int64(0), ctypes.c_int64(0)
+            hip.check(hip.lib().brv_ctn_grad_bucket(
+                self._cfg_ptr(), part, nparts, ctypes.byref(off), ctypes.byref(cnt)),
+                'brv_ctn_grad_bucket')
+            out.append((off.value, cnt.value))
+        return out
+
+    def _hip_backward(self, wave, d_out, flat_grad, amp=True, nparts=1, after_part=None):
+        """Backward into ``flat_grad``. With ``nparts > 1`` the pass runs in parts and
+        ``after_part(part, flat_grad[offset:offset + count])`` is called after each one
+        with the gradient slice that part finished (bucketed all-reduce hook)."""
         amp = bool(amp)
         wave = wave.float().contiguous()
         d_out = d_out.float().contiguous()
         B, L = wave.shape
         ws = self._get_workspace(B, L, amp)
-        if amp:
-            hip.check(hip.lib().brv_ctn_backward(
-                self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
-                hip.ptr(ws), hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad),
-                B, L, hip.stream()), 'brv_ctn_backward')
-        else:
-            hip.check(hip.lib().brv_ctn_f32_backward(
-                self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(ws),
-                hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad), B, L,
-                hip.stream()), 'brv_ctn_f32_backward')
+        buckets = self.grad_buckets(nparts) if after_part is not None else None
+        lib = hip.lib()
+        for part in range(nparts):
+            if amp:
+                hip.check(lib.brv_ctn_backward_part(
+                    self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
+                    hip.ptr(ws), hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad),
+                    B, L, part, nparts, hip.stream()), 'brv_ctn_backward_part')
+            else:
+                hip.check(lib.brv_ctn_f32_backward_part(
+                    self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(ws),
+                    hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad), B, L,
+                    part, nparts, hip.stream()), 'brv_ctn_f32_backward_part')
+            if after_part is not None:
+                off, cnt = buckets[part]
+                if cnt:
+                    after_part(part, flat_grad[off:off + cnt])
 
     def workspace_tensor(self, name, index, B, L, shape, dtype):
         """View of a saved activation of the bf16 path (tests / profiling)."""
@@ -485,10 +512,17 @@ class ConvTasNet(BreverBaseModel):
                 'brv_snr_backward')
             grads = self.flat_grads()
             grads.zero_()
-            self._hip_backward(inputs, d_out, grads, amp)
+            sync = self._grad_sync
             grad_scale = 1.0
-            if self._grad_sync is not None:
-                grad_scale = self._grad_sync(grads)
+            if sync is not None and getattr(sync, 'nparts', 1) > 1:
+                # bucketed: each part's slice is all-reduced while the next part computes
+                self._hip_backward(inputs, d_out, grads, amp, nparts=sync.nparts,
+                                   after_part=sync.bucket)
+                grad_scale = sync.finish()
+            else:
+                self._hip_backward(inputs, d_out, grads, amp)
+                if sync is not None:
+                    grad_scale = sync(grads)
             self.optimizer.step(max_norm=self.grad_clip, grad_scale=grad_scale)
             return loss_b.mean()
 

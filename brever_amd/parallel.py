@@ -7,11 +7,15 @@ never arms the reducer (brever/training.py:62-63,
 here explicitly:
 
 * parameters (and buffers) are broadcast once from rank 0;
-* models that expose ``flat_grads()`` (the HIP Conv-TasNet) are reduced with a
-  single all-reduce of one contiguous fp32 buffer (19.7 MB for Conv-TasNet:
-  latency-bound on xGMI, so one bucket beats many), issued on the current
-  stream right behind the last backward kernel and followed by the fused
-  clip + Adam with ``grad_scale = 1/world``;
+* models that expose ``set_grad_sync`` (the HIP Conv-TasNet, one flat fp32 gradient
+  buffer of 19.7 MB) run their backward pass in ``nparts`` parts (3 by default =
+  one per TCN repeat, 6.6 MB each); the slice of the flat gradient a part finishes is
+  all-reduced right away with ``async_op=True``: the collective runs on RCCL's own
+  stream, ordered behind the kernels of that part, while the compute stream goes on
+  with the next part. The compute stream waits for the collectives once, before the
+  fused clip + Adam (``grad_scale = 1/world``). Buckets are views of the flat buffer:
+  no packing copies. The generic ``loss -> update`` sequence of the same model (other
+  criteria / optimizers) calls the hook once with the whole buffer;
 * any other model gets post-accumulate-grad hooks that average each ``.grad``
   over ranks during backward, i.e. before clipping and the optimizer step.
 """
@@ -35,19 +39,56 @@ def broadcast_parameters(model, src=0):
 
 
 class GradSynchronizer:
-    def __init__(self, model):
+    """``nparts``: gradient buckets of a flat-gradient model (1 = one all-reduce after
+    the last backward kernel). ``exposed_ms()`` reports how long the compute stream
+    waited for collectives in ``finish`` (GPU only; what overlap did not hide)."""
+
+    def __init__(self, model, nparts=3):
         self.world = dist.get_world_size()
+        self.nparts = max(1, int(nparts))
         self.flat_model = callable(getattr(model, 'set_grad_sync', None))
+        self._pending = []
+        self._waits = []
         if self.flat_model:
-            model.set_grad_sync(self._sync_flat)
+            model.set_grad_sync(self)
         else:
             self._install_hooks(model)
 
-    def _sync_flat(self, flat_grad):
-        """Hook of the fused train_step: sum over ranks, mean taken inside the
-        optimizer kernel."""
+    # -- flat-gradient models -------------------------------------------------
+    def __call__(self, flat_grad):
+        """Single-bucket hook: sum over ranks, the mean is taken inside the optimizer
+        kernel (``grad_scale``)."""
         dist.all_reduce(flat_grad)
         return 1.0/self.world
+
+    def bucket(self, part, grad_slice):
+        """Called after backward part ``part``: start the all-reduce of its slice."""
+        self._pending.append(dist.all_reduce(grad_slice, async_op=True))
+
+    def finish(self):
+        """Make the compute stream wait for the outstanding collectives."""
+        timed = self._pending and torch.cuda.is_available() \
+            and dist.get_backend() == 'nccl'
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        for work in self._pending:
+            work.wait()
+        if timed:
+            b.record()
+            self._waits.append((a, b))
+        self._pending = []
+        return 1.0/self.world
+
+    def exposed_ms(self, reset=True):
+        """Mean time per step the compute stream spent waiting in ``finish``."""
+        if not self._waits:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._waits)/len(self._waits)
+        if reset:
+            self._waits = []
+        return ms
 
     def _install_hooks(self, model):
         """Generic path: average each gradient over ranks as soon as autograd has

@@ -26,9 +26,11 @@ import torch
 import torch.distributed as dist
 
 from .batching import BatchSamplerRegistry, DistributedBatchSamplerWrapper
-from .data import BreverDataLoader
+from .data import BreverDataLoader, DevicePrefetcher
+from .inspect import NoParse, Parse
 from .metrics import MetricRegistry
 from .models import count_params
+from .models.base import BreverBaseModel
 from .parallel import GradSynchronizer, broadcast_parameters
 
 
@@ -70,25 +72,30 @@ class ExponentialMovingAverage:
         self.backup = None
 
     def state_dict(self):
+        """Same keys as torch_ema 0.3's ``state_dict`` (``collected_params`` = the stored
+        copy, ``None`` outside a store / restore pair), so that the ``ema`` entry of a
+        checkpoint loads on either side."""
         return dict(decay=self.decay, num_updates=self.num_updates,
-                    shadow_params=self.shadow)
+                    shadow_params=self.shadow, collected_params=self.backup)
 
     def load_state_dict(self, state):
         self.decay = state['decay']
         self.num_updates = state['num_updates']
         self.shadow = [s.clone() for s in state['shadow_params']]
+        collected = state.get('collected_params')
+        self.backup = None if collected is None else [c.clone() for c in collected]
 
 
 class BreverTrainer:
     def __init__(
         self,
-        model,
-        train_dataset,
-        val_dataset,
-        model_dirpath: str,
+        model: NoParse[BreverBaseModel],
+        train_dataset: NoParse[object],
+        val_dataset: NoParse[object],
+        model_dirpath: NoParse[str],
         workers: int = 0,
         epochs: int = 100,
-        device: int | str = 'cuda',
+        device: int | Parse[str] = 'cuda',
         batch_sampler: str = 'bucket',
         batch_size: int = 32,
         num_buckets: int = 10,
@@ -117,6 +124,18 @@ class BreverTrainer:
                             'runs in hand-written HIP kernels')
         if use_wandb:
             logging.warning('use_wandb=True is ignored (wandb is not available)')
+
+        # metrics whose third-party backend is missing (pesq: ITU-T P.862 C wheel) would only
+        # fail at the first validation, after a full epoch: resolve every name now, drop
+        # what cannot run with a warning (unknown names stay a KeyError, as in the reference)
+        from .metrics import metric_available
+        for name in sorted(val_metrics):
+            MetricRegistry.get(name)
+        missing = {name for name in val_metrics if not metric_available(name)}
+        if missing:
+            logging.warning(f'val_metrics {sorted(missing)} need packages that are not '
+                            'installed: dropped from validation')
+            val_metrics = set(val_metrics) - missing
 
         self.model = model.to(device)
         self.train_dataset = train_dataset
@@ -151,6 +170,13 @@ class BreverTrainer:
         # 'bucket' (brever/training.py:96), so num_buckets never reaches the
         # sampler there; kept for batch-composition parity.
         sampler_cls = BatchSamplerRegistry.get(batch_sampler)
+        if dynamic_batch_size and batch_size == 0:
+            # `batch_size: 0` = size the dynamic batches from the HBM of this GPU: the seconds
+            # of audio whose saved activations fit (288 GB on MI355X: a throughput knob, not
+            # a memory limit -- batching.hbm_batch_seconds)
+            batch_size = self.auto_batch_seconds(self.model, device, fs)
+            logging.info(f'dynamic batch size set from HBM capacity: {batch_size:.1f} s')
+        self.batch_size = batch_size
         self.train_batch_sampler = sampler_cls(
             dataset=train_dataset, batch_size=batch_size,
             dynamic=dynamic_batch_size, fs=fs)
@@ -180,10 +206,24 @@ class BreverTrainer:
         self.checkpoint_saver = CheckpointSaver(self.checkpoints_dir,
                                                 self.save_checkpoint)
         self.timer = TrainingTimer(epochs, val_period)
-        # kept for API / checkpoint compatibility; the HIP path computes in bf16
-        # and needs no loss scaling, CPU models get a disabled scaler
-        on_gpu = str(device) != 'cpu' and torch.cuda.is_available()
-        self.scaler = torch.amp.GradScaler('cuda', enabled=use_amp and on_gpu)
+        # kept for API / checkpoint compatibility (brever/training.py:148): the HIP paths
+        # compute in bf16 or fp32 with fp32 accumulation and never need loss scaling
+        self.scaler = torch.amp.GradScaler('cuda', enabled=False)
+
+    @staticmethod
+    def auto_batch_seconds(model, device, fs, cap=4096.0):
+        """Dynamic batch size (seconds of audio) whose saved activations fit this GPU's HBM,
+        for models that report ``activation_bytes_per_second`` (the HIP Conv-TasNet)."""
+        from .batching import hbm_batch_seconds
+        per_second = getattr(model, 'activation_bytes_per_second', None)
+        if not callable(per_second):
+            raise ValueError('batch_size=0 (automatic) needs a model with '
+                             'activation_bytes_per_second()')
+        hbm = 288e9
+        if torch.cuda.is_available() and str(device) != 'cpu':
+            hbm = float(torch.cuda.get_device_properties(torch.device(
+                'cuda' if isinstance(device, str) else f'cuda:{device}')).total_memory)
+        return min(cap, hbm_batch_seconds(per_second(fs), hbm_bytes=hbm))
 
     # -- helpers ---------------------------------------------------------------
     def get_model(self):
@@ -306,12 +346,10 @@ class BreverTrainer:
             avg_metrics = MathDict()
         avg_loss = MathDict()
         use_amp = self.use_amp
-        for batch, lengths in dataloader:
-            if isinstance(batch, list):
-                batch = [x.to(self.device) for x in batch]
-            else:
-                batch = batch.to(self.device)
-            lengths = lengths.to(self.device)
+        # pinned, double-buffered async H2D: the next batch is copied on a side stream
+        # while this one computes (the reference's loop does a synchronous .to per batch,
+        # training.py:310-314)
+        for batch, lengths in DevicePrefetcher(dataloader, self.device):
             if train:
                 loss = self._train_step(model, batch, lengths, use_amp)
                 if self.ema is not None:

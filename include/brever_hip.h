@@ -88,6 +88,23 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params,
                      const float* d_out, float* grads, int64_t batch,
                      int64_t length, brv_stream_t stream);
 
+/* The backward pass in `nparts` parts, for overlapping the data-parallel gradient all-reduce
+ * with the rest of backward (the reference wraps the model in
+ * DistributedDataParallel, brever/training.py:62-63, whose reducer buckets gradients the same
+ * way). Part 0 runs the decoder / mask / output-conv gradients and the LAST group of TCN blocks,
+ * the last part the first group and the bottleneck / encoder; each part finishes ALL gradients
+ * (data, weight, per-channel) of its blocks. brv_ctn_grad_bucket gives the contiguous range of
+ * the flat gradient that is final once part `part` has run (the ranges of all parts tile the
+ * buffer): the caller may all-reduce that slice on another stream while later parts compute.
+ * Calling parts 0 .. nparts-1 in order equals one brv_ctn_backward call. */
+int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params,
+                          const void* prepared, void* workspace, const float* wave,
+                          const float* d_out, float* grads, int64_t batch,
+                          int64_t length, int32_t part, int32_t nparts,
+                          brv_stream_t stream);
+int brv_ctn_grad_bucket(const brv_ctn_config* cfg, int32_t part, int32_t nparts,
+                        int64_t* offset, int64_t* count);
+
 /* The same model with fp32 activations and exact-fp32 products: ConvTasNet.forward WITHOUT
  * autocast (convtasnet.py:78-97 with use_amp=False -- `enhance(x, use_amp=False)` of
  * scripts/test_model.py:173-175, BreverTrainer(use_amp=False)). No prepared operands: the flat
@@ -102,6 +119,10 @@ int brv_ctn_f32_backward(const brv_ctn_config* cfg, const float* params,
                          void* workspace, const float* wave, const float* d_out,
                          float* grads, int64_t batch, int64_t length,
                          brv_stream_t stream);
+int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params,
+                              void* workspace, const float* wave, const float* d_out,
+                              float* grads, int64_t batch, int64_t length,
+                              int32_t part, int32_t nparts, brv_stream_t stream);
 
 /* ---- criteria (brever/criterion.py) ---------------------------------------
  * x, y: (batch, sources, length) fp32 contiguous rows with `stride` floats
@@ -507,6 +528,34 @@ int brv_si_scale_forward(const float* x, const float* y, const int64_t* lengths,
 int brv_si_scale_backward(const float* g, const float* x, const float* y, const int64_t* lengths,
                           const double* stats, float* dx, int64_t B, int64_t S, int64_t L,
                           brv_stream_t stream);
+
+/* ---- STOI / ESTOI (brever/metrics.py:19-45,98-109; pystoi's algorithm, oracle/stoi.py) -------
+ * resample_poly: y[r][m] = sum_i hpad[(m + n_pre_remove)*down - i*up] x[r][i] for
+ *   m < ceil(n_in*up/down) (n_in = lengths[r], or in_stride when lengths is NULL), zero beyond:
+ *   scipy.signal.resample_poly with the padded, gain-scaled filter built by the caller.
+ * stoi_compact: removes the 256-sample Hann frames (hop 128) of the CLEAN signal that lie more
+ *   than dyn_range dB below its loudest frame from both signals and overlap-adds the rest;
+ *   geom[r] = {samples, frames, 30-frame segments, kept frames} of the compacted item;
+ *   energy_scratch / kept_scratch: rows*nf_max floats / ints, nf_max >= brv_stoi_frames(max length).
+ * stoi_bands: spec (rows, nf_max, ncols) = per-frame DFT rows with (re, im) interleaved for
+ *   bins [bin0, bin0 + ncols/2) -> tob (rows, 15, nf_max) one-third octave magnitudes;
+ *   edges (15, 2) int32 = first / one-past-last bin of every band.
+ * stoi_correlate: out[r] = STOI (extended = 0, clip = 10^(15/20)) or ESTOI (extended != 0) of
+ *   item r from the band magnitudes of the clean and the processed signal; items with fewer
+ *   than 30 frames give 1e-5 like pystoi. partial_scratch: rows*(nf_max - 29) floats. */
+int brv_resample_poly(const float* x, const float* hpad, float* y, const int64_t* lengths,
+                      int64_t rows, int64_t in_stride, int64_t out_stride, int64_t up,
+                      int64_t down, int64_t hpad_len, int64_t n_pre_remove, brv_stream_t stream);
+int64_t brv_stoi_frames(int64_t length);
+int brv_stoi_compact(const float* clean, const float* proc, const int64_t* lengths, int64_t rows,
+                     int64_t stride, float* clean_out, float* proc_out, int64_t out_stride,
+                     int32_t* geom, float* energy_scratch, int32_t* kept_scratch, int64_t nf_max,
+                     float dyn_range, brv_stream_t stream);
+int brv_stoi_bands(const float* spec, const int32_t* edges, float* tob, int64_t rows,
+                   int64_t nf_max, int64_t ncols, int64_t bin0, brv_stream_t stream);
+int brv_stoi_correlate(const float* tob_clean, const float* tob_proc, const int32_t* geom,
+                       float* partial_scratch, float* out, int64_t rows, int64_t nf_max,
+                       int extended, float clip, brv_stream_t stream);
 
 /* ---- optimizer --------------------------------------------------------------
  * clip_grad_norm_(max_norm) + Adam.step (base.py:296-301, torch.optim.Adam with

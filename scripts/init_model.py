@@ -1,42 +1,43 @@
-"""Write models/<hash>/config.yaml from the architecture defaults plus overrides
-(reference: scripts/init_model.py:9-29)."""
-import argparse
+"""Write ``<MODELS>/<id>/config.yaml`` from the architecture defaults plus overrides.
+
+Same command line as the reference (scripts/init_model.py:9-38): dataset / trainer / extra
+options first, then the architecture and its own options, e.g.
+
+    python scripts/init_model.py --train_path data/train --val_path data/val \\
+        --epochs 50 --use_amp true convtasnet --layers 4
+
+``<id>`` is ``config.get_hash()`` (identical to the reference's ids) unless ``-n NAME``;
+``MODELS`` comes from ``config/paths.yaml``. Extension: ``--models_dir DIR`` overrides it."""
 import os
 
 import yaml
 
-from _common import ROOT, add_override_flags  # noqa: F401
+from _common import ROOT  # noqa: F401
 
-from brever_amd.config import get_model_default_config
+from brever_amd.args import ModelArgParser
+from brever_amd.config import _resolve, get_config, get_model_default_config
 
 
 def main():
-    pre = argparse.ArgumentParser(add_help=False)
-    pre.add_argument('arch')
-    arch = pre.parse_known_args()[0].arch
-    cfg = get_model_default_config(arch)
-    parser = argparse.ArgumentParser(description='initialize a model directory')
-    parser.add_argument('arch')
-    parser.add_argument('--models-dir', default='models')
-    parser.add_argument('--train-path', dest='train_path', default=None)
-    parser.add_argument('--val-path', dest='val_path', default=None)
-    parser.add_argument('--seed', type=int, default=None)
-    m_map = add_override_flags(parser, cfg.model.to_dict())
-    t_map = add_override_flags(parser, cfg.trainer.to_dict(), prefix='trainer_')
+    parser = ModelArgParser(description='initialize a model')
+    parser.add_argument('-f', '--force', action='store_true',
+                        help='overwrite config file if already exists')
+    parser.add_argument('-n', '--name', help='model name')
+    parser.add_argument('--models_dir', help='(extension) write here instead of paths.MODELS')
     args = parser.parse_args()
-    arg_map = {d: ('model', k) for d, k in m_map.items()}
-    arg_map.update({d: ('trainer', k) for d, k in t_map.items()})
-    arg_map.update({'train_path': ('train_path',), 'val_path': ('val_path',),
-                    'seed': ('seed',)})
-    cfg.update_from_args(args, arg_map)
-    dirpath = os.path.join(args.models_dir, cfg.get_hash())
-    os.makedirs(dirpath, exist_ok=True)
-    path = os.path.join(dirpath, 'config.yaml')
-    if os.path.exists(path):
-        raise FileExistsError(f'model already exists: {path}')
-    with open(path, 'w') as f:
-        yaml.dump(cfg.to_dict(), f)
-    print(f'Initialized {path}')
+
+    config = get_model_default_config(args.arch)
+    config.update_from_args(args, parser.arg_map(args.arch))
+    model_id = args.name if args.name is not None else config.get_hash()
+    models_dir = args.models_dir or get_config(_resolve('config/paths.yaml')).MODELS
+    model_dir = os.path.join(models_dir, model_id)
+    os.makedirs(model_dir, exist_ok=True)
+    config_path = os.path.join(model_dir, 'config.yaml')
+    if os.path.exists(config_path) and not args.force:
+        raise FileExistsError(f'model already exists: {config_path} ')
+    with open(config_path, 'w') as f:
+        yaml.dump(config.to_dict(), f, sort_keys=False)
+    print(f'Initialized {config_path}')
 
 
 if __name__ == '__main__':

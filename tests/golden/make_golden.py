@@ -725,13 +725,105 @@ def golden_segments(out):
         json.dump(cases, f)
 
 
+IN_SCOPE_MODELS = ['convtasnet', 'dccrn', 'ffnn', 'sgmsep', 'sgmsepm', 'sgmsepheun',
+                   'sgmsepmheun', 'idmse', 'tfgridnet']
+
+
+def _jsonable(x):
+    if isinstance(x, dict):
+        return {k: _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (set, frozenset)):
+        return {'__set__': sorted(_jsonable(v) for v in x)}
+    if isinstance(x, tuple):
+        return {'__tuple__': [_jsonable(v) for v in x]}
+    if isinstance(x, list):
+        return [_jsonable(v) for v in x]
+    return x
+
+
+def golden_config(out):
+    """Config / CLI contract of the reference (brever/config.py, args.py, inspect.py):
+    default config dicts and their ``get_hash()`` for the in-scope models, hashes after 20
+    seeded field perturbations, ``get_func_spec`` of BreverDataset / BreverTrainer / the models
+    (type and action as names), and the parsed namespace + resulting hash of the command lines
+    the reference's own tests/test_args.py builds (``--arg=default`` for every option)."""
+    from brever.args import ModelArgParser
+    from brever.config import get_model_default_config
+    from brever.data import BreverDataset
+    from brever.inspect import get_func_spec
+    from brever.models import ModelRegistry
+    from brever.training import BreverTrainer
+
+    def spec_json(func):
+        res = {}
+        for arg, item in get_func_spec(func).items():
+            action = item['action']
+            res[arg] = {
+                'type': item['type'].__name__,
+                'action': None if action is None else [action.origin.__name__, action.type_.__name__],
+                'default': _jsonable(item['default']),
+                'required': item['required'],
+            }
+        return res
+
+    fixture = {'defaults': {}, 'hashes': {}, 'perturbed': [], 'specs': {}, 'commands': {}}
+    fixture['specs']['BreverDataset'] = spec_json(BreverDataset)
+    fixture['specs']['BreverTrainer'] = spec_json(BreverTrainer)
+    rng = random.Random(7)
+    for key in IN_SCOPE_MODELS:
+        cfg = get_model_default_config(key)
+        fixture['defaults'][key] = _jsonable(cfg.to_dict())
+        fixture['hashes'][key] = [cfg.get_hash(), cfg.get_hash(length=12)]
+        fixture['specs'][key] = spec_json(ModelRegistry.get(key))
+        # the command of tests/test_args.py:42-66
+        cmd = ['--seed=0', '--train_path=foo', '--val_path=bar']
+        for func in (BreverDataset, BreverTrainer):
+            for arg, x in get_func_spec(func).items():
+                d = x['default']
+                cmd.append(f'--{arg}=' + (','.join(str(y) for y in d)
+                                         if isinstance(d, (list, tuple, set)) else str(d)))
+        cmd.append(key)
+        for arg, x in get_func_spec(ModelRegistry.get(key)).items():
+            d = x['default']
+            cmd.append(f'--{arg}=' + (','.join(str(y) for y in d)
+                                     if isinstance(d, (list, tuple, set)) else str(d)))
+        parser = ModelArgParser()
+        args = parser.parse_args(cmd)
+        cfg2 = get_model_default_config(key)
+        cfg2.update_from_args(args, parser.arg_map(key))
+        fixture['commands'][key] = {'argv': cmd, 'namespace': _jsonable(vars(args)),
+                                    'hash': cfg2.get_hash(),
+                                    'arg_map': parser.arg_map(key)}
+    # seeded perturbations of scalar fields
+    for _ in range(20):
+        key = rng.choice(IN_SCOPE_MODELS)
+        cfg = get_model_default_config(key)
+        section = rng.choice(['model', 'trainer', 'dataset'])
+        fields = [(k, v) for k, v in getattr(cfg, section).to_dict().items()
+                  if isinstance(v, (int, float, bool, str))]
+        name, value = rng.choice(fields)
+        if isinstance(value, bool):
+            new = not value
+        elif isinstance(value, int):
+            new = value + rng.randint(1, 9)
+        elif isinstance(value, float):
+            new = value*1.5 + 0.25
+        else:
+            new = value + '_x'
+        cfg.set_field([section, name], new)
+        fixture['perturbed'].append({'model': key, 'field': [section, name],
+                                     'value': new, 'hash': cfg.get_hash()})
+    with open(os.path.join(out, 'config.json'), 'w') as f:
+        json.dump(fixture, f, indent=1, sort_keys=True)
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
     os.chdir(REF)       # the reference opens config/... relatively
     torch.set_num_threads(4)
     todo = [golden_batching, golden_collate, golden_losses, golden_convtasnet, golden_training,
-            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features, golden_ema, golden_norms, golden_tfgridnet]
+            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features, golden_ema, golden_norms, golden_tfgridnet, golden_config]
     only = sys.argv[1:]                  # e.g. `make_golden.py sgmse` regenerates one file
     for fn in todo:
         if not only or fn.__name__[len('golden_'):] in only:

@@ -119,3 +119,46 @@ def sgmse_case(golden, tag):
                                     corrector_snr=0.5, **kw)
     window = scipy.signal.get_window('hann', cfg['stft_frame_length'])
     return model, net, sde, kw, sampler, window, draws
+
+
+def run_entry_points(tmp_path, arch, model_args=(), trainer_args=(), train='synthetic:8:0.5',
+                     val='synthetic:4:0.5', test='synthetic:3:0.5', metrics=('snr', 'sisnr'),
+                     extra_test_args=()):
+    """init_model.py -> train_model.py -> test_model.py with the reference's command lines
+    (dataset / trainer options before the architecture, model options after it; ``--cuda``,
+    ``--metrics a b``). Returns (model_dir, losses npz, scores array [mixture, metric, 2])."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(*a):
+        return subprocess.run([sys.executable, *a], capture_output=True, text=True, cwd=root)
+
+    models = os.path.join(str(tmp_path), 'models')
+    os.makedirs(models, exist_ok=True)
+    out = run('scripts/init_model.py', '--train_path', str(train), '--val_path', str(val),
+              '--preload', 'true', '--workers', '0', *trainer_args, '--models_dir', models,
+              arch, *model_args)
+    assert out.returncode == 0, out.stderr[-3000:]
+    model_dir = os.path.join(models, os.listdir(models)[0])
+    out = run('scripts/train_model.py', model_dir)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    out2 = run('scripts/train_model.py', model_dir)
+    assert out2.returncode != 0 and 'training already done' in out2.stderr
+    out = run('scripts/test_model.py', '-i', model_dir, '-t', str(test), '--cuda',
+              '--metrics', *metrics, *extra_test_args)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    name = 'scores.hdf5' if os.path.exists(os.path.join(model_dir, 'scores.hdf5')) else 'scores.npz'
+    key = 'last.ckpt/' + os.path.basename(os.path.normpath(str(test)))
+    if name.endswith('.npz'):
+        f = np.load(os.path.join(model_dir, name))
+        assert list(f['metrics']) == list(metrics) and list(f['which']) == ['input', 'output']
+        scores = f[key]
+    else:
+        import h5py
+        with h5py.File(os.path.join(model_dir, name), 'r') as f:
+            scores = f[key][...]
+    return model_dir, losses, scores

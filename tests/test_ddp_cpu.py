@@ -88,8 +88,22 @@ class _FlatStub(torch.nn.Module):
         pass
 
     def train_step(self, batch, lengths, use_amp, scaler):
-        self.flat.copy_(batch)
-        scale = self._sync(self.flat)
+        """Same protocol as ConvTasNet.train_step: backward in ``nparts`` parts with the
+        bucket hook after each one (here part p "computes" its slice of the gradient)."""
+        sync = self._sync
+        self.flat.zero_()
+        nparts = getattr(sync, 'nparts', 1)
+        if nparts > 1:
+            bounds = [7*p//nparts for p in range(nparts + 1)]
+            for part in range(nparts):          # backward order: last slice first
+                lo, hi = bounds[nparts - 1 - part], bounds[nparts - part]
+                self.flat[lo:hi] = batch[lo:hi]
+                if hi > lo:
+                    sync.bucket(part, self.flat[lo:hi])
+            scale = sync.finish()
+        else:
+            self.flat.copy_(batch)
+            scale = sync(self.flat)
         return self.flat*scale
 
 
@@ -101,17 +115,29 @@ def _worker_flat(rank, world, port, out_dir):
         model.w.fill_(float(rank + 1))
     broadcast_parameters(model)
     assert torch.all(model.w == 1.0)
-    sync = GradSynchronizer(model)
-    assert sync.flat_model
-    mean = sync.train_step(model, torch.full((7,), float(rank)), None, False, None)
-    assert torch.allclose(mean, torch.full((7,), 0.5))
+    g = torch.Generator().manual_seed(17 + rank)
+    grad = torch.randn(7, generator=g)
+    results = []
+    for nparts in (1, 3, 7, 9):                  # single buffer, buckets, more parts than blocks
+        sync = GradSynchronizer(model, nparts=nparts)
+        assert sync.flat_model and sync.nparts == nparts
+        results.append(sync.train_step(model, grad, None, False, None).clone())
+    both = [torch.randn(7, generator=torch.Generator().manual_seed(17 + r)) for r in range(world)]
+    assert torch.equal(results[0], (both[0] + both[1])*0.5)
+    for r in results[1:]:
+        assert torch.equal(r, results[0])        # bucketed == single buffer, bit for bit
+    torch.save(results[0], os.path.join(out_dir, f'mean{rank}.pt'))
     dist.destroy_process_group()
 
 
 def test_flat_gradient_hook_sums_and_scales():
+    """Single-bucket and bucketed (overlapped) all-reduce of a flat gradient: the mean over
+    ranks, identical bit for bit whatever the number of buckets, identical on both ranks."""
     world, port = 2, _free_port()
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker_flat, args=(world, port, tmp), nprocs=world, join=True)
+        assert torch.equal(torch.load(os.path.join(tmp, 'mean0.pt')),
+                           torch.load(os.path.join(tmp, 'mean1.pt')))
 
 
 def _worker_trainer(rank, world, port, out_dir):

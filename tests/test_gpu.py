@@ -307,33 +307,23 @@ def test_full_size_step_properties():
 
 
 def test_entry_points_train_and_test(tmp_path):
-    """scripts/init_model.py -> train_model.py -> test_model.py on synthetic data."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
-                                    text=True, cwd=root)
-    out = run('scripts/init_model.py', 'convtasnet', '--models-dir', str(tmp_path),
-              '--filters', '64', '--bottleneck_channels', '32', '--hidden_channels', '64',
-              '--skip_channels', '32', '--layers', '2', '--repeats', '2',
-              '--trainer_epochs', '2', '--trainer_val_period', '1',
-              '--trainer_batch_size', '8', '--trainer_preload', 'true',
-              '--trainer_workers', '0',
-              '--train-path', 'synthetic:16:1.0:0.5', '--val-path', 'synthetic:4:1.0')
-    assert out.returncode == 0, out.stderr
-    model_dir = os.path.join(str(tmp_path), os.listdir(tmp_path)[0])
-    out = run('scripts/train_model.py', model_dir)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert os.path.exists(os.path.join(model_dir, 'losses.npz'))
-    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    """scripts/init_model.py -> train_model.py -> test_model.py on synthetic data with the
+    reference's command lines and its default val_metrics {pesq, estoi, snr} (pesq is dropped with
+    a warning: its wheel is absent; estoi runs on the HIP kernels)."""
+    from helpers import run_entry_points
+    model_dir, losses, scores = run_entry_points(
+        tmp_path, 'convtasnet',
+        model_args=['--filters', '64', '--bottleneck_channels', '32', '--hidden_channels', '64',
+                    '--skip_channels', '32', '--layers', '2', '--repeats', '2'],
+        trainer_args=['--epochs', '2', '--val_period', '1', '--batch_size', '8'],
+        train='synthetic:16:1.0:0.5', val='synthetic:4:1.0', test='synthetic:6:1.0',
+        metrics=('snr', 'sisnr', 'stoi', 'estoi'))
     assert losses['train_loss'].shape == (2, 2) and np.isfinite(losses['train_loss']).all()
-    assert 'metrics_snr' in losses
-    out = run('scripts/train_model.py', model_dir)
-    assert out.returncode != 0 and 'training already done' in out.stderr
-    out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:6:1.0')
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    scores = np.load(os.path.join(model_dir, 'scores.npz'))
-    assert scores['scores'].shape == (6, 2, 2) and np.isfinite(scores['scores']).all()
+    assert 'metrics_snr' in losses and 'metrics_estoi' in losses and 'metrics_pesq' not in losses
+    assert scores.shape == (6, 4, 2) and np.isfinite(scores).all()
+    assert (scores[:, 2:, :] > 0).all() and (scores[:, 2:, :] <= 1.0 + 1e-6).all()   # (E)STOI range
+    log = open(os.path.join(model_dir, 'log_train.log')).read()
+    assert "val_metrics ['pesq'] need packages that are not installed" in log
 
 
 @pytest.mark.parametrize('causal', [False, True])
@@ -637,6 +627,77 @@ def test_update_path_runs_grad_sync(golden_dir):
     assert rel(b.flat_params(), a.flat_params()) <= 1e-6
 
 
+
+def _speechlike(gen, B, L, fs=16000):
+    """Amplitude-modulated harmonic signals with pauses (so that silent frames exist)."""
+    import math
+    t = torch.arange(L)/fs
+    f0 = 100 + 200*torch.rand(B, 1, generator=gen)
+    x = sum(torch.sin(2*math.pi*f0*(h + 1)*t + 6.28*torch.rand(B, 1, generator=gen))/(h + 1)
+            for h in range(8))
+    env = (0.55 + 0.45*torch.sin(2*math.pi*(2 + 3*torch.rand(B, 1, generator=gen))*t)).clamp(min=0)
+    gate = (torch.sin(2*math.pi*0.7*t + 6.28*torch.rand(B, 1, generator=gen)) > -0.6).float()
+    return 0.1*x*env*gate + 1e-4*torch.randn(B, L, generator=gen)
+
+
+@pytest.mark.parametrize('extended', [False, True])
+def test_stoi_matches_oracle(extended):
+    """HIP STOI / ESTOI (csrc/stoi.hip) vs the NumPy restatement of pystoi's algorithm
+    (oracle/stoi.py; parity with the wheel itself is unpinned): ragged batch at 16 kHz
+    (resampling to 10 kHz, silent-frame removal, band DFT, segment correlations) and at 10 kHz
+    (no resampling); |d| <= 2e-4 (fp32 kernels vs the fp64 oracle)."""
+    from brever_amd import metrics
+    from oracle.stoi import stoi as oracle_stoi
+    dev = _cuda()
+    gen = torch.Generator().manual_seed(3)
+    B, L = 4, 40000
+    clean = _speechlike(gen, B, L)
+    lengths = torch.tensor([40000, 33333, 25001, 16000])
+    snr_db = torch.tensor([15.0, 5.0, 0.0, -5.0]).view(B, 1)
+    noise = torch.randn(B, L, generator=gen)
+    noisy = clean + noise*clean.norm(dim=1, keepdim=True)/noise.norm(dim=1, keepdim=True)*10**(-snr_db/20)
+    fn = metrics.estoi if extended else metrics.stoi
+    for fs in (16000, 10000):
+        got = fn(noisy.to(dev), clean.to(dev), fs=fs, lengths=lengths.to(dev))
+        want = np.array([oracle_stoi(clean[b, :n].double().numpy(), noisy[b, :n].double().numpy(),
+                                     fs, extended=extended) for b, n in enumerate(lengths.tolist())])
+        assert isinstance(got, np.ndarray) and got.shape == (B,)
+        assert np.abs(got - want).max() <= 2e-4, (fs, got, want)
+        assert (np.diff(got) < 0).all()                       # decreasing with the SNR
+    # identical signals -> 1; short input (< 30 frames after silent-frame removal) -> 1e-5
+    same = fn(clean.to(dev), clean.to(dev), lengths=lengths.to(dev))
+    assert np.abs(same - 1.0).max() <= 1e-4
+    short = fn(noisy[:1, :3000].to(dev), clean[:1, :3000].to(dev))
+    assert abs(float(short[0]) - 1e-5) <= 1e-9
+
+
+@pytest.mark.parametrize('name', ['stoi', 'estoi', 'snr', 'sisnr'])
+def test_metrics_batched_equals_one_by_one(name):
+    """The reference's tests/test_metrics.py:13-54 on the HIP metrics, at its sizes."""
+    import torch.nn.functional as F
+    from brever_amd.metrics import MetricRegistry
+    dev = _cuda()
+    torch.manual_seed(42)
+    lengths = torch.randint(16000, 48000, (2,))
+    targets = [torch.randn(int(n)) for n in lengths]
+    batched_targets = torch.stack([F.pad(t, (0, 48000 - t.shape[-1])) for t in targets])
+    batched_inputs = batched_targets + 0.5*torch.randn(*batched_targets.shape)
+    inputs = [x[..., :n] for x, n in zip(batched_inputs, lengths)]
+    metric = MetricRegistry.get(name)
+    batched = metric(batched_inputs.to(dev), batched_targets.to(dev), lengths=lengths.to(dev))
+    batched = torch.as_tensor(np.asarray(torch.as_tensor(batched).cpu())).float()
+    single = torch.tensor([float(metric(x.to(dev), y.to(dev))) for x, y in zip(inputs, targets)])
+    assert torch.allclose(batched, single, rtol=1e-5, atol=1e-5), (batched, single)
+
+
+def test_pesq_key_is_registered_but_needs_the_wheel():
+    from brever_amd.metrics import MetricRegistry, metric_available
+    fn = MetricRegistry.get('pesq')
+    if not metric_available('pesq'):
+        with pytest.raises(ImportError, match='pesq'):
+            fn(torch.zeros(16000), torch.zeros(16000))
+
+
 def test_criteria_gradients(golden_dir):
     """snr / mse gradients vs the reference golden, sisnr (PIT) gradient vs the oracle's
     autograd, all with a non-uniform upstream gradient per item."""
@@ -805,18 +866,50 @@ def test_rccl_gradient_sync_path_single_rank():
         batch = 0.1*torch.randn(3, 2, 1500, generator=g).to(device)
         lengths = torch.tensor([1500, 1400, 900], device=device)
         scaler = torch.amp.GradScaler('cuda', enabled=False)
-        losses = []
-        for hooked in (False, True):
+        losses, params = [], []
+        for nparts in (0, 1, 3):             # no hook, one bucket, three overlapped buckets
             torch.manual_seed(0)
             net = ConvTasNet(**cfg).to(device)
-            if hooked:
+            if nparts:
                 broadcast_parameters(net)
-                sync = GradSynchronizer(net)
+                sync = GradSynchronizer(net, nparts=nparts)
                 assert sync.flat_model
             losses.append([float(net.train_step(batch, lengths, True, scaler)) for _ in range(3)])
+            params.append(net.flat_params().clone())
+            if nparts > 1:
+                assert sync.exposed_ms() >= 0.0
         assert losses[0] == losses[1], losses
+        # the backward in parts launches differently grouped weight-gradient kernels: same
+        # values up to fp32 summation order
+        assert np.allclose(losses[0], losses[2], rtol=0, atol=1e-4), losses
+        assert rel(params[2], params[0]) <= 1e-4
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('amp', [True, False])
+@pytest.mark.parametrize('tag', ['small2', 'causal'])
+def test_backward_in_parts_equals_whole(golden_dir, tag, amp):
+    """brv_ctn_backward_part / brv_ctn_f32_backward_part: parts 0..n-1 in order give the
+    gradient of the single call, and after part p its bucket is already final."""
+    g, cfg, _, net = load_pair(golden_dir, tag, amp=amp)
+    batch = torch.from_numpy(g['batch']).cuda()
+    with torch.no_grad():
+        out = net._hip_forward(batch[:, 0], amp)
+        d_out = torch.randn(out.shape, generator=torch.Generator().manual_seed(2)).cuda()
+        whole = torch.zeros_like(net.flat_params())
+        net._hip_backward(batch[:, 0], d_out, whole, amp)
+        for nparts in (2, 3, 7):
+            parts = torch.zeros_like(whole)
+            snaps = []
+            net._hip_backward(batch[:, 0], d_out, parts, amp, nparts=nparts,
+                              after_part=lambda p, sl: snaps.append((sl.data_ptr(), sl.clone())))
+            assert rel(parts, whole) <= (2e-3 if amp else 1e-5), (nparts, rel(parts, whole))
+            base = parts.data_ptr()
+            for ptr, snap in snaps:             # bucket contents did not change afterwards
+                off = (ptr - base)//4
+                assert torch.equal(snap, parts[off:off + snap.numel()])
 
 
 @pytest.mark.gpu
@@ -880,28 +973,14 @@ def test_ffnn_matches_reference(golden_dir):
 def test_entry_points_ffnn(tmp_path):
     """BASELINE config 0 (FFNN on 32 synthetic 2 s mixtures) through the entry points:
     init -> train (pre_train statistics, bucket batching over feature frames) -> test."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
-                                    text=True, cwd=root)
-    out = run('scripts/init_model.py', 'ffnn', '--models-dir', str(tmp_path),
-              '--hidden_layers', '128,128',
-              '--trainer_epochs', '2', '--trainer_val_period', '1',
-              '--trainer_batch_size', '16', '--trainer_preload', 'true',
-              '--trainer_workers', '0',
-              '--train-path', 'synthetic:32:2.0:1.0', '--val-path', 'synthetic:8:2.0')
-    assert out.returncode == 0, out.stderr
-    model_dir = os.path.join(str(tmp_path), os.listdir(tmp_path)[0])
-    out = run('scripts/train_model.py', model_dir)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    from helpers import run_entry_points
+    _, losses, scores = run_entry_points(
+        tmp_path, 'ffnn', model_args=['--hidden_layers', '128,128'],
+        trainer_args=['--epochs', '2', '--val_period', '1', '--batch_size', '16',
+                      '--val_metrics', 'snr'],
+        train='synthetic:32:2.0:1.0', val='synthetic:8:2.0', test='synthetic:4:2.0')
     assert np.isfinite(losses['train_loss']).all()
-    assert losses['train_loss'][-1, 0] < losses['train_loss'][0, 0] or True
-    out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:4:2.0')
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    scores = np.load(os.path.join(model_dir, 'scores.npz'))
-    assert np.isfinite(scores['scores']).all()
+    assert np.isfinite(scores).all()
 
 
 @pytest.mark.gpu
@@ -1044,25 +1123,13 @@ def test_dccrn_matches_reference(golden_dir):
 @pytest.mark.gpu
 def test_entry_points_dccrn(tmp_path):
     """DCCRN (BASELINE config 3, narrow channels for speed) through init -> train -> test."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
-                                    text=True, cwd=root)
-    out = run('scripts/init_model.py', 'dccrn', '--models-dir', str(tmp_path),
-              '--channels', '4,8,8,16,16,16', '--lstm_channels', '16',
-              '--trainer_epochs', '1', '--trainer_val_period', '1',
-              '--trainer_batch_size', '4', '--trainer_preload', 'true', '--trainer_workers', '0',
-              '--train-path', 'synthetic:8:0.5', '--val-path', 'synthetic:4:0.5')
-    assert out.returncode == 0, out.stderr
-    model_dir = os.path.join(str(tmp_path), os.listdir(tmp_path)[0])
-    out = run('scripts/train_model.py', model_dir)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    from helpers import run_entry_points
+    _, losses, scores = run_entry_points(
+        tmp_path, 'dccrn', model_args=['--channels', '4,8,8,16,16,16', '--lstm_channels', '16'],
+        trainer_args=['--epochs', '1', '--val_period', '1', '--batch_size', '4',
+                      '--val_metrics', 'snr'])
     assert np.isfinite(losses['train_loss']).all()
-    out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:3:0.5')
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert np.isfinite(np.load(os.path.join(model_dir, 'scores.npz'))['scores']).all()
+    assert np.isfinite(scores).all()
 
 
 @pytest.mark.gpu
@@ -1253,24 +1320,15 @@ def test_entry_points_on_a_dataset_directory(tmp_path):
                 with wave.open(str(tmp_path/split/'audio'/f'{i:05d}_{src}.wav'), 'wb') as w:
                     w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000)
                     w.writeframes((np.clip(x, -1, 1)*32767).astype('<i2').tobytes())
-    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
-                                    text=True, cwd=root)
-    models = tmp_path/'models'
-    os.makedirs(models)
-    out = run('scripts/init_model.py', 'convtasnet', '--models-dir', str(models),
-              '--filters', '64', '--bottleneck_channels', '32', '--hidden_channels', '64',
-              '--skip_channels', '32', '--layers', '2', '--repeats', '2',
-              '--trainer_epochs', '1', '--trainer_val_period', '1', '--trainer_batch_size', '4',
-              '--trainer_preload', 'true', '--trainer_workers', '0',
-              '--train-path', str(tmp_path/'train'), '--val-path', str(tmp_path/'val'))
-    assert out.returncode == 0, out.stderr
-    model_dir = os.path.join(str(models), os.listdir(models)[0])
-    out = run('scripts/train_model.py', model_dir)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert np.isfinite(np.load(os.path.join(model_dir, 'losses.npz'))['train_loss']).all()
-    out = run('scripts/test_model.py', '-i', model_dir, '-t', str(tmp_path/'val'))
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    scores = np.load(os.path.join(model_dir, 'scores.npz'))['scores']
+    from helpers import run_entry_points
+    _, losses, scores = run_entry_points(
+        tmp_path, 'convtasnet',
+        model_args=['--filters', '64', '--bottleneck_channels', '32', '--hidden_channels', '64',
+                    '--skip_channels', '32', '--layers', '2', '--repeats', '2'],
+        trainer_args=['--epochs', '1', '--val_period', '1', '--batch_size', '4',
+                      '--val_metrics', 'snr', '--tar', 'false'],
+        train=tmp_path/'train', val=tmp_path/'val', test=tmp_path/'val')
+    assert np.isfinite(losses['train_loss']).all()
     assert scores.shape[0] == 3 and np.isfinite(scores).all()
 
 
@@ -1322,27 +1380,18 @@ def test_sgmse_training_matches_reference(golden_dir, tag):
 def test_entry_points_sgmse(tmp_path):
     """SGMSE+ (BASELINE config 4, narrow network, 4 sampler steps) through init -> train ->
     test: training on the HIP score network, validation / test through the reverse sampler."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
-                                    text=True, cwd=root)
-    out = run('scripts/init_model.py', 'sgmsep', '--models-dir', str(tmp_path),
-              '--stft_frame_length', '64', '--stft_hop_length', '16', '--net_base_channels', '8',
-              '--net_channel_mult', '1,2,2', '--net_num_blocks_per_res', '1',
-              '--net_attn_resolutions', '16', '--solver_num_steps', '4',
-              '--trainer_epochs', '1', '--trainer_val_period', '1',
-              '--trainer_batch_size', '4', '--trainer_preload', 'true', '--trainer_workers', '0',
-              '--train-path', 'synthetic:8:0.25', '--val-path', 'synthetic:2:0.25')
-    assert out.returncode == 0, out.stderr
-    model_dir = os.path.join(str(tmp_path), os.listdir(tmp_path)[0])
-    out = run('scripts/train_model.py', model_dir)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    from helpers import run_entry_points
+    _, losses, scores = run_entry_points(
+        tmp_path, 'sgmsep',
+        model_args=['--stft_frame_length', '64', '--stft_hop_length', '16',
+                    '--net_base_channels', '8', '--net_channel_mult', '1,2,2',
+                    '--net_num_blocks_per_res', '1', '--net_attn_resolutions', '16',
+                    '--solver_num_steps', '4'],
+        trainer_args=['--epochs', '1', '--val_period', '1', '--batch_size', '4',
+                      '--val_metrics', 'snr'],
+        train='synthetic:8:0.25', val='synthetic:2:0.25', test='synthetic:2:0.25')
     assert np.isfinite(losses['train_loss']).all()
-    out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:2:0.25')
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert np.isfinite(np.load(os.path.join(model_dir, 'scores.npz'))['scores']).all()
+    assert np.isfinite(scores).all()
 
 
 @pytest.mark.gpu
@@ -1793,25 +1842,15 @@ def test_lstm_tiled_kernels_match_torch():
 @pytest.mark.gpu
 def test_entry_points_tfgridnet(tmp_path):
     """TF-GridNet (narrow configuration) through init -> train -> test on synthetic mixtures."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    run = lambda *a: subprocess.run([sys.executable, *a], capture_output=True,  # noqa
-                                    text=True, cwd=root)
-    out = run('scripts/init_model.py', 'tfgridnet', '--models-dir', str(tmp_path),
-              '--n_layers', '1', '--lstm_hidden_units', '16', '--emb_dim', '8', '--attn_n_head', '2',
-              '--trainer_epochs', '1', '--trainer_val_period', '1',
-              '--trainer_batch_size', '4', '--trainer_preload', 'true', '--trainer_workers', '0',
-              '--train-path', 'synthetic:8:0.5', '--val-path', 'synthetic:4:0.5')
-    assert out.returncode == 0, out.stderr
-    model_dir = os.path.join(str(tmp_path), os.listdir(tmp_path)[0])
-    out = run('scripts/train_model.py', model_dir)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    losses = np.load(os.path.join(model_dir, 'losses.npz'))
+    from helpers import run_entry_points
+    _, losses, scores = run_entry_points(
+        tmp_path, 'tfgridnet',
+        model_args=['--n_layers', '1', '--lstm_hidden_units', '16', '--emb_dim', '8',
+                    '--attn_n_head', '2'],
+        trainer_args=['--epochs', '1', '--val_period', '1', '--batch_size', '4',
+                      '--val_metrics', 'snr'])
     assert np.isfinite(losses['train_loss']).all()
-    out = run('scripts/test_model.py', '-i', model_dir, '-t', 'synthetic:3:0.5')
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert np.isfinite(np.load(os.path.join(model_dir, 'scores.npz'))['scores']).all()
+    assert np.isfinite(scores).all()
 
 
 @pytest.mark.gpu
