@@ -663,7 +663,11 @@ def test_stoi_matches_oracle(extended):
                                      fs, extended=extended) for b, n in enumerate(lengths.tolist())])
         assert isinstance(got, np.ndarray) and got.shape == (B,)
         assert np.abs(got - want).max() <= 2e-4, (fs, got, want)
-        assert (np.diff(got) < 0).all()                       # decreasing with the SNR
+    # the same item at decreasing SNR: decreasing score
+    one = clean[:1].repeat(4, 1)
+    n1 = noise[:1]*one.norm()/noise[:1].norm()*10**(-torch.tensor([20.0, 10.0, 0.0, -10.0]).view(4, 1)/20)
+    ladder = fn((one + n1).to(dev), one.to(dev))
+    assert (np.diff(ladder) < 0).all(), ladder
     # identical signals -> 1; short input (< 30 frames after silent-frame removal) -> 1e-5
     same = fn(clean.to(dev), clean.to(dev), lengths=lengths.to(dev))
     assert np.abs(same - 1.0).max() <= 1e-4
