@@ -7,9 +7,14 @@ mixtures (BASELINE.json configs[1]; weak scaling over N GPUs of one node).
 
 One "step" = one optimizer step of the reference's hot path on one batch of 16
 utterances per GPU, inputs already resident in HBM: ConvTasNet.train_step =
-forward -> SNR loss -> backward -> [gradient all-reduce over RCCL] -> clip(5.0) +
-Adam (brever/models/base.py:178-210, convtasnet.py:78-89). Rank 0 prints ONE JSON
-line. The CPU oracle (oracle/) is used only for the `cpu_baseline` field.
+forward -> SNR loss -> backward in parts -> [bucketed gradient all-reduce over RCCL,
+overlapped with backward] -> clip(5.0) + Adam (brever/models/base.py:178-210,
+convtasnet.py:78-89). Rank 0 prints ONE JSON line. Beside `value` (resident inputs) the
+line carries `through_trainer`: the same step fed by the trainer's own data path (bucket
+sampler -> BreverDataLoader collate -> pinned double-buffered async H2D), `roofline` for the
+kernel with the largest share plus `kernels` (every launch label >= 5 % of the step with its
+algorithmic and measured HBM bytes), `allreduce_exposed_ms` for N > 1, and `cpu_baseline`
+(N = 1 only): the CPU oracle (oracle/) on the same configuration, B = 16, fp32 and CPU-bf16.
 """
 import argparse
 import json
@@ -24,7 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from brever_amd import hip                                    # noqa: E402
-from brever_amd.data import BreverDataLoader, SyntheticMixtureDataset  # noqa: E402
+from brever_amd.batching import BucketBatchSampler                # noqa: E402
+from brever_amd.data import (BreverDataLoader, DevicePrefetcher,   # noqa: E402
+                             SyntheticMixtureDataset)
 from brever_amd.models import ConvTasNet                      # noqa: E402
 from brever_amd.parallel import GradSynchronizer, broadcast_parameters  # noqa: E402
 
@@ -50,28 +57,54 @@ def make_batches(n_batches, rank, device):
     return batches
 
 
+def physical_cores():
+    """Physical cores of the host (SMT siblings counted once); falls back to the logical count."""
+    try:
+        pairs = set()
+        phys = core = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('physical id'):
+                    phys = line.split(':')[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':')[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline():
-    """Oracle (pure-PyTorch CPU restatement of the reference path) timed on the host
-    cores on a bounded sample of the same workload."""
+    """Oracle (pure-PyTorch CPU restatement of the reference path) timed on the host cores on
+    the benchmark configuration itself: ONE train step of 16 x 4 s utterances in fp32 and one
+    under CPU bf16 autocast (the reference's CPU autocast dtype, convtasnet.py:81), after a
+    2-utterance warm-up step each; threads = physical cores. `value` is the fp32 figure."""
     from oracle.convtasnet import OracleConvTasNet
-    torch.manual_seed(0)
-    model = OracleConvTasNet()
-    bsz = 2
+    cores = physical_cores()
+    torch.set_num_threads(cores)
     model_transform = lambda s: s.mean(axis=-2)   # noqa: E731
-    dset = SyntheticMixtureDataset(bsz, int(SECONDS*FS), transform=model_transform)
-    batch, lengths = BreverDataLoader._collate_fn([dset[i] for i in range(bsz)])
+    dset = SyntheticMixtureDataset(BATCH, int(SECONDS*FS), transform=model_transform)
+    batch, lengths = BreverDataLoader._collate_fn([dset[i] for i in range(BATCH)])
     scaler = torch.amp.GradScaler('cuda', enabled=False)
-    model.train_step(batch, lengths, False, scaler)           # warm-up
-    steps = 2
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        model.train_step(batch, lengths, False, scaler)
-    dt = time.perf_counter() - t0
+    out = {}
+    for name, amp in (('fp32', False), ('bf16', True)):
+        torch.manual_seed(0)
+        model = OracleConvTasNet()
+        model.train_step(batch[:2], lengths[:2], amp, scaler)      # warm-up (threads, allocator)
+        t0 = time.perf_counter()
+        model.train_step(batch, lengths, amp, scaler)
+        out[name] = BATCH/(time.perf_counter() - t0)
     return {
-        'value': steps*bsz/dt, 'unit': 'utterances/s',
-        'cores': torch.get_num_threads(), 'kind': 'port',
-        'sample': f'{steps} fp32 train steps of {bsz} x 4 s utterances (1 warm-up), '
-                  f'Conv-TasNet defaults, torch CPU oracle',
+        'value': out['fp32'], 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
+        'value_cpu_bf16': out['bf16'],
+        'sample': f'1 train step of {BATCH} x 4 s utterances (after a 2-utterance warm-up step), '
+                  'Conv-TasNet defaults, torch CPU oracle, fp32 (value) and CPU bf16 autocast '
+                  f'(value_cpu_bf16), {cores} threads = physical cores',
     }
 
 
@@ -81,25 +114,27 @@ KERNEL_OF_LABEL = {
     'dwconv_fwd': 'dwconv_fwd_kernel', 'pw2_wgrad': 'wgrad_full_kernel',
     'pw1_fwd': 'gemm_ws_kernel<128, 64, 1, 0,', 'pw2_fwd': 'gemm_ws_kernel<512,',
     'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': 'gemm_rows_kernel<128, 3, 5>',
+    'pw1_wgrad': 'gemm_wgrad_kernel<128, 0>', 'clip_adam': 'clip_adam_kernel',
 }
+PMC_FILES = ('r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
 
 
 def pmc_traffic(label):
-    """HBM bytes per launch of the kernel behind `label`, from the committed rocprofv3
-    PMC passes (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-    separate passes, same bench command). bench.py cannot run the profiler on itself;
-    None when the file or the kernel is missing."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                        'r01_pmc_hbm_traffic.json')
+    """(HBM bytes per launch, source file) of the kernel behind `label`, from the committed
+    rocprofv3 PMC passes (profiles/rNN_pmc_hbm_traffic.json, tools/pmc_traffic.py: FETCH_SIZE
+    x2 on gfx950 + WRITE_SIZE, separate passes, same bench command). bench.py cannot run the
+    profiler on itself; (None, None) when the file or the kernel is missing."""
     key = KERNEL_OF_LABEL.get(label)
-    if key is None or not os.path.exists(path):
-        return None
-    with open(path) as f:
-        kernels = json.load(f)['kernels']
-    for name, v in kernels.items():
-        if key in name:
-            return v['hbm_traffic_MB']*1e6
-    return None
+    for fname in PMC_FILES:
+        path = os.path.join(ROOT, 'profiles', fname)
+        if key is None or not os.path.exists(path):
+            continue
+        with open(path) as f:
+            kernels = json.load(f)['kernels']
+        for name, v in kernels.items():
+            if key in name:
+                return v['hbm_traffic_MB']*1e6, f'profiles/{fname}'
+    return None, None
 
 
 def kernel_roofline(model, batches, scaler, steps=3):
@@ -124,6 +159,7 @@ def kernel_roofline(model, batches, scaler, steps=3):
     intensity = flops/max(nbytes, 1.0)
     ridge = PEAK_MFMA_TFLOPS*1e12/(PEAK_HBM_GBS*1e9)
     hbm_bound = intensity < ridge
+    traffic, traffic_src = pmc_traffic(label)
     roof = {
         'kernel': label,
         'bound': 'hbm' if hbm_bound else 'mfma',
@@ -131,8 +167,8 @@ def kernel_roofline(model, batches, scaler, steps=3):
         'peak': PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
         'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
         'frac': (gbs/PEAK_HBM_GBS) if hbm_bound else (tfs/PEAK_MFMA_TFLOPS),
-        'traffic': pmc_traffic(label),
-        'traffic_source': 'profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc, bytes per launch)',
+        'traffic': traffic,
+        'traffic_source': f'{traffic_src} (rocprofv3 --pmc, bytes per launch)' if traffic_src else None,
         'avg_launch_us': avg_s*1e6,
         'launches_per_step': top['calls']/steps,
         'algorithmic_bytes_per_launch': nbytes,
@@ -140,6 +176,19 @@ def kernel_roofline(model, batches, scaler, steps=3):
         'tflops': tfs, 'gbs': gbs,
         'share_of_kernel_time': top['ms']/sum(v['ms'] for v in prof.values()),
     }
+    total_ms = sum(v['ms'] for v in prof.values())
+    kernels = []
+    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms']):
+        if v['ms'] < 0.05*total_ms:
+            continue
+        per = v['ms']/v['calls']*1e-3
+        kb = v['bytes']/v['calls']
+        kernels.append({
+            'kernel': k, 'launches_per_step': v['calls']/steps, 'avg_launch_us': per*1e6,
+            'share_of_kernel_time': v['ms']/total_ms,
+            'algorithmic_bytes_per_launch': kb, 'achieved_GBs': kb/per/1e9,
+            'frac_of_hbm_peak': kb/per/1e9/PEAK_HBM_GBS, 'traffic': pmc_traffic(k)[0]})
+    roof['kernels_over_5pct'] = kernels
     table = {k: {'calls_per_step': v['calls']/steps,
                  'ms_per_step': v['ms']/steps,
                  'gbs': v['bytes']/max(v['ms'], 1e-9)/1e6,
@@ -148,12 +197,41 @@ def kernel_roofline(model, batches, scaler, steps=3):
     return roof, table
 
 
+def through_trainer(model, scaler, rank, device, steps, warmup):
+    """The same train step fed by the trainer's data path instead of resident batches: items of
+    a host-side SyntheticMixtureDataset (what BreverDataset.__getitem__ + model.transform
+    return) -> BucketBatchSampler (dynamic, 64 s = 16 utterances) -> BreverDataLoader collate
+    -> DevicePrefetcher (pinned double-buffered async H2D) -> train_step. ms per step."""
+    # as BreverTrainer does on a GPU: few host threads (collate is small copies; 128 spinning
+    # OpenMP workers cost 40+ ms per step on this host, tools/trainer_path_debug.py)
+    torch.set_num_threads(min(torch.get_num_threads(), int(os.environ.get('BREVER_HOST_THREADS', '4'))))
+    n_items = BATCH*(steps + warmup)
+    dset = SyntheticMixtureDataset(n_items, int(SECONDS*FS),
+                                   transform=lambda s: s.mean(axis=-2), seed=100 + rank)
+    dset.preload('cpu')               # synthesis is not part of the path being timed
+    sampler = BucketBatchSampler(dset, batch_size=BATCH*SECONDS, dynamic=True, fs=FS)
+    loader = BreverDataLoader(dataset=dset, batch_sampler=sampler, num_workers=0)
+    t0 = None
+    done = 0
+    for batch, lengths in DevicePrefetcher(loader, device):
+        if done == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        model.train_step(batch, lengths, True, scaler)
+        done += 1
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0)/max(done - warmup, 1)*1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-through-trainer', action='store_true')
+    ap.add_argument('--buckets', type=int, default=3,
+                    help='gradient buckets of the overlapped all-reduce (N > 1)')
     ap.add_argument('--kernel-table', action='store_true',
                     help='also print the per-kernel table (stderr)')
     args = ap.parse_args()
@@ -162,8 +240,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m '
+                         f'torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ...` '
+                         '(one rank per GPU) or pass --gpus 1')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device (no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -174,9 +253,10 @@ def main():
 
     torch.manual_seed(0)
     model = ConvTasNet().to(device)          # defaults = BASELINE config
+    sync = None
     if world > 1:
         broadcast_parameters(model)
-        GradSynchronizer(model)
+        sync = GradSynchronizer(model, nparts=args.buckets)
     scaler = torch.amp.GradScaler('cuda', enabled=False)   # bf16: no loss scaling
     batches = make_batches(4, rank, device)
 
@@ -201,6 +281,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     final_loss = float(loss)
+    exposed = sync.exposed_ms() if sync is not None else None
+    trainer_ms = None
+    if not args.no_through_trainer:
+        trainer_ms = through_trainer(model, scaler, rank, device, min(args.steps, 40), 6)
+        if world > 1:
+            t = torch.tensor([trainer_ms], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trainer_ms = float(t)
 
     roof, table = kernel_roofline(model, batches, scaler)
     if world > 1:
@@ -225,6 +313,15 @@ def main():
             'whole_step_mfma_frac': value/world*FLOP_PER_UTT_TRAIN/(PEAK_MFMA_TFLOPS*1e12),
             'roofline': roof,
         }
+        if trainer_ms is not None:
+            line['through_trainer'] = {
+                'value': world*BATCH/(trainer_ms*1e-3), 'unit': 'utterances/s',
+                'ms_per_step': trainer_ms,
+                'path': 'host items -> BucketBatchSampler -> BreverDataLoader collate -> pinned '
+                        'double-buffered async H2D (DevicePrefetcher) -> train_step'}
+        if exposed is not None:
+            line['allreduce_exposed_ms'] = exposed
+            line['allreduce_buckets'] = args.buckets
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         if args.kernel_table:

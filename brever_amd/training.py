@@ -137,6 +137,16 @@ class BreverTrainer:
                             'installed: dropped from validation')
             val_metrics = set(val_metrics) - missing
 
+        if str(device) != 'cpu' and torch.cuda.is_available():
+            # On a GPU the host only collates batches and queues kernels. PyTorch's default of
+            # one OpenMP thread per core makes those small copies SLOWER and the spinning
+            # workers delay the HIP runtime calls: measured on the 128-thread MI355X host,
+            # collate + pinned staging of a 16 x 4 s batch 58 ms at 128 threads, 2.3 ms at 1
+            # (tools/trainer_path_debug.py). BREVER_HOST_THREADS overrides.
+            host_threads = int(os.environ.get('BREVER_HOST_THREADS', '4'))
+            if torch.get_num_threads() > host_threads:
+                torch.set_num_threads(host_threads)
+
         self.model = model.to(device)
         self.train_dataset = train_dataset
         self.val_dataset = val_dataset
