@@ -138,7 +138,6 @@ class _MultiResYuFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, y, lengths, stfts, time_w, spec_w):
-        from .modules.stft import _StftFunction
         lib = hip.lib()
         x2, y2, lengths, B, S, L = _rows(x, y, lengths)
         rows = B*S
@@ -152,11 +151,10 @@ class _MultiResYuFunction(torch.autograd.Function):
         total = time_w*sums
         specs = []
         for stft in stfts:
-            basis, _, _ = stft._get_tables(x.device)
-            args = (basis, stft.frame_length, stft.hop_length, 1.0, stft.scale_factor)
+            basis = stft._tables(x.device)['basis']
             with torch.no_grad():
-                X = _StftFunction.apply(xm.view(rows, L), *args)
-                Y = _StftFunction.apply(ym.view(rows, L), *args)
+                X = stft._dft_forward(xm.view(rows, L), basis, 1.0, stft.scale_factor)
+                Y = stft._dft_forward(ym.view(rows, L), basis, 1.0, stft.scale_factor)
             n = X.shape[-2]*X.shape[-1]
             ssum = torch.empty(rows, dtype=torch.float64, device=x.device)
             hip.check(lib.brv_mag_l1_forward(
@@ -171,7 +169,6 @@ class _MultiResYuFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        from .modules.stft import stft_adjoint
         lib = hip.lib()
         xm, ym, lengths, *flat = ctx.saved_tensors
         stfts, time_w, spec_w, shape, in_dtype = ctx.meta
@@ -191,9 +188,8 @@ class _MultiResYuFunction(torch.autograd.Function):
             hip.check(lib.brv_mag_l1_backward(
                 hip.ptr(torch.view_as_real(X)), hip.ptr(torch.view_as_real(Y)), hip.ptr(g_s),
                 hip.ptr(dX), rows, n, hip.stream()), 'brv_mag_l1_backward')
-            basis, _, _ = stft._get_tables(X.device)
-            dx += stft_adjoint(dX, basis, rows, L, stft.frame_length, stft.hop_length,
-                               X.shape[-1], stft.scale_factor).view(B, S, L)
+            # adjoint of X = scale * DFT(x): scale * DFT^T
+            dx += stft._dft_adjoint(dX, L, stft.scale_factor).view(B, S, L)
         out = torch.empty_like(dx)
         hip.check(lib.brv_apply_mask(hip.ptr(dx), hip.ptr(lengths), hip.ptr(out), B, S, L,
                                      hip.stream()), 'brv_apply_mask')

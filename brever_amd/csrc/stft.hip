@@ -40,6 +40,9 @@ struct G32 {
   const float* row_bias; int accumulate;
   int col_bias;            // the bias is per output COLUMN (accumulate == 2 at the C ABI)
   int b_bf16, d_bf16, a_bf16;   // gemm_bf16 only: operands / result are bf16 in memory (strides in elements)
+  // gemm64_kernel only: the DFT basis in double precision (replaces A for GA_PLAIN / B for
+  // GB_PLAIN and GB_WT); the other operand is fp32 data converted on load
+  const double* A64; const double* B64;
 };
 
 constexpr int TM = 64, TN = 64, TK = 32;
@@ -467,6 +470,172 @@ int launch_g32(const G32& p, int batch, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// ---- the same framed products with fp64 accumulation (STFT.forward / STFT.backward) ------------
+// The reference's transforms are FFTs (torch.stft / torch.istft): log2(n) rounding stages, round
+// trip within 1e-6 (tests/test_modules.py:319-326). A DFT as a plain fp32 product accumulates n
+// terms in sequence and lands at ~2e-5. The DFT products of the STFT module therefore run on the
+// double-precision matrix pipe: v_mfma_f64_16x16x4_f64, basis in double, fp32 data converted on
+// load, result rounded to fp32 once. Lane maps (MI355X guide): A[row = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][col = lane & 15], D register r: row = (lane >> 4) + 4 r, col = lane & 15.
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+
+template <int AM, int BM, int SM>
+__global__ __launch_bounds__(256) void gemm64_kernel(const G32 p) {
+  __shared__ double As[TM][TK + 1];
+  __shared__ double Bs[TK][TN + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.y*TM, n0 = blockIdx.x*TN, b = blockIdx.z;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
+  const float* A = p.A + (long long)b*p.a_bs;
+  const float* B = p.B + (long long)b*p.b_bs;
+  for (int k0 = 0; k0 < p.K; k0 += TK) {
+    for (int e = tid; e < TM*TK; e += 256) {
+      const int i = e / TK, k = e % TK;
+      const int m = m0 + i, kk = k0 + k;
+      double v = 0.0;
+      if (m < p.M && kk < p.K) {
+        if (AM == GA_PLAIN) {
+          v = p.A64 ? p.A64[(long long)m*p.lda + kk] : (double)A[(long long)m*p.lda + kk];
+        } else {                                   // GA_SPEC_T
+          const int bin = kk >> 1, part = kk & 1;
+          const float2 z = *reinterpret_cast<const float2*>(A + ((long long)bin*p.frames + m)*2);
+          double re = (double)z.x*p.inv_scale, im = (double)z.y*p.inv_scale;
+          if (p.inv_comp != 1.f) {
+            const double mag = sqrt(re*re + im*im);
+            const double f = mag > 0.0 ? pow(mag, (double)p.inv_comp - 1.0) : 0.0;
+            re *= f; im *= f;
+          }
+          v = part ? im : re;
+        }
+      }
+      As[i][k] = v;
+    }
+    for (int e = tid; e < TK*TN; e += 256) {
+      const int k = e / TN, j = e % TN;
+      const int kk = k0 + k, n = n0 + j;
+      double v = 0.0;
+      if (kk < p.K && n < p.N) {
+        if (BM == GB_PLAIN) v = p.B64 ? p.B64[(long long)kk*p.ldb + n] : (double)B[(long long)kk*p.ldb + n];
+        else if (BM == GB_WT) v = p.B64 ? p.B64[(long long)n*p.ldb + kk] : (double)B[(long long)n*p.ldb + kk];
+        else {
+          const long long idx = (long long)n*p.hop + kk - p.pad_left;
+          if (idx >= 0 && idx < p.len) v = (double)B[idx];
+        }
+      }
+      Bs[k][j] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TK/4; ++s) {
+      const int kk = 4*s + (lane >> 4), c = lane & 15;
+      const double a0 = As[32*wm + c][kk], a1 = As[32*wm + 16 + c][kk];
+      const double b0 = Bs[kk][32*wn + c], b1 = Bs[kk][32*wn + 16 + c];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // accumulators -> LDS tile (rows of one (re, im) pair sit in different lanes), then row-wise out
+  double (*Cs)[TK + 1] = As;                        // 64 x 33 doubles: half a tile at a time
+  float* D = p.D + (long long)b*p.d_bs;
+  for (int half = 0; half < 2; ++half) {            // columns [32 half, 32 half + 32) of the tile
+    __syncthreads();
+    if (wn == half) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            Cs[32*wm + 16*i + (lane >> 4) + 4*r][16*j + (lane & 15)] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (SM == GS_PLAIN) {
+      for (int e = tid; e < TM*32; e += 256) {
+        const int i = e / 32, j = e % 32;
+        const int row = m0 + i, col = n0 + 32*half + j;
+        if (row < p.M && col < p.N) D[(long long)row*p.ldd + col] = (float)Cs[i][j];
+      }
+    } else {
+      for (int e = tid; e < (TM/2)*32; e += 256) {
+        const int q = e / 32, j = e % 32;
+        const int bin = (m0 >> 1) + q, col = n0 + 32*half + j;
+        if (bin >= p.bins || col >= p.N) continue;
+        double re = Cs[2*q][j], im = Cs[2*q + 1][j];
+        if (p.comp != 1.f) {
+          const double mag = sqrt(re*re + im*im);
+          const double f = mag > 0.0 ? pow(mag, (double)p.comp - 1.0) : 0.0;
+          re *= f; im *= f;
+        }
+        *reinterpret_cast<float2*>(D + ((long long)bin*p.N + col)*2) =
+            make_float2((float)(re*p.scale), (float)(im*p.scale));
+      }
+    }
+  }
+}
+
+// complex <-> (magnitude, phase): the 'mag_phase' return / input types of the STFT module
+__global__ void polar_kernel(const float* mag, const float* phase, float2* out, long long n) {
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    float sn, cs;
+    sincosf(phase[i], &sn, &cs);
+    out[i] = make_float2(mag[i]*cs, mag[i]*sn);
+  }
+}
+__global__ void mag_phase_kernel(const float2* x, float* mag, float* phase, long long n) {
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const float2 z = x[i];
+    mag[i] = sqrtf(z.x*z.x + z.y*z.y);
+    phase[i] = atan2f(z.y, z.x);
+  }
+}
+
+template <int AM, int BM, int SM>
+int launch_g64(const G32& p, int batch, hipStream_t st) {
+  if (p.M <= 0 || p.N <= 0 || batch <= 0) return 0;
+  dim3 grid((p.N + TN - 1)/TN, (p.M + TM - 1)/TM, batch);
+  hipLaunchKernelGGL((gemm64_kernel<AM, BM, SM>), grid, dim3(256), 0, st, p);
+  return (int)hipGetLastError();
+}
+
+// Y = scale |X|^(c-1) X (magnitude compression + scaling, stft.py:85-87) and its gradient:
+// gX = scale r^(c-1) u (c Re(gY conj u) + j Im(gY conj u)), u = X/|X|, r = |X| (0 at r = 0)
+__global__ void spec_compress_kernel(const float2* x, float2* y, long long n, float c, float scale) {
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const float2 z = x[i];
+    const float r = sqrtf(z.x*z.x + z.y*z.y);
+    const float f = (c == 1.f) ? scale : (r > 0.f ? scale*powf(r, c - 1.f) : 0.f);
+    y[i] = make_float2(z.x*f, z.y*f);
+  }
+}
+__global__ void spec_compress_bwd_kernel(const float2* x, const float2* gy, float2* gx, long long n,
+                                         float c, float scale) {
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const float2 z = x[i], g = gy[i];
+    const float r = sqrtf(z.x*z.x + z.y*z.y);
+    float2 o = make_float2(0.f, 0.f);
+    if (c == 1.f) {
+      o = make_float2(scale*g.x, scale*g.y);
+    } else if (r > 0.f) {
+      const float ux = z.x/r, uy = z.y/r;
+      const float a = g.x*ux + g.y*uy;            // Re(g conj u)
+      const float b = g.y*ux - g.x*uy;            // Im(g conj u)
+      const float f = scale*powf(r, c - 1.f);
+      o = make_float2(f*(c*a*ux - b*uy), f*(c*a*uy + b*ux));
+    }
+    gx[i] = o;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -695,6 +864,85 @@ int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64
   return gemm_any(1, a, b, d, batch, M, N, K, lda, ldb, ldd, a_batch_stride, b_batch_stride,
                   d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride, b_kbatch_stride,
                   row_bias, accumulate, stream);
+}
+
+// Framed DFT / its transposes with every size explicit and the basis in DOUBLE precision (fp64
+// MFMA accumulation): what STFT.forward / STFT.backward run on. `rows2` = basis rows = 2 x bins
+// (bins = n_fft/2 + 1 one-sided, n_fft two-sided); frame t covers samples [t*hop - pad_left, + n).
+int brv_dft64_forward(const float* x, const double* basis, float* spec, int64_t rows, int64_t length,
+                      int64_t n, int64_t hop, int64_t pad_left, int64_t frames, int64_t bins,
+                      float compression, float scale, brv_stream_t stream) {
+  if (rows < 1 || frames < 1 || n < 2 || hop < 1 || bins < 1) return -1;
+  G32 p; memset(&p, 0, sizeof(p));
+  p.M = (int)(2*bins); p.N = (int)frames; p.K = (int)n;
+  p.A64 = basis; p.A = nullptr; p.a_bs = 0; p.lda = (int)n;
+  p.B = x; p.b_bs = length; p.hop = (int)hop; p.pad_left = (int)pad_left; p.len = (int)length;
+  p.D = spec; p.d_bs = (long long)bins*frames*2; p.bins = (int)bins;
+  p.comp = compression; p.scale = scale;
+  return launch_g64<GA_PLAIN, GB_FRAMES, GS_SPEC>(p, (int)rows, (hipStream_t)stream);
+}
+
+// frames_out[r][t][m] = sum_c (spec/scale, decompressed)[c][t] * tbasis[c][m]  (tbasis: (2 bins, n)
+// doubles, row-major): the synthesis product of the inverse transform (tbasis = inverse basis
+// transposed) and of the forward transform's adjoint (tbasis = forward basis).
+int brv_dft64_synthesis(const float* spec, const double* tbasis, float* frames_out, int64_t rows,
+                        int64_t frames, int64_t n, int64_t bins, float compression, float scale,
+                        brv_stream_t stream) {
+  if (rows < 1 || frames < 1 || n < 2 || bins < 1) return -1;
+  G32 p; memset(&p, 0, sizeof(p));
+  p.M = (int)frames; p.N = (int)n; p.K = (int)(2*bins);
+  p.A = spec; p.a_bs = (long long)bins*frames*2; p.frames = (int)frames;
+  p.inv_scale = 1.f/scale; p.inv_comp = 1.f/compression;
+  p.B64 = tbasis; p.B = nullptr; p.b_bs = 0; p.ldb = (int)n;
+  p.D = frames_out; p.d_bs = (long long)frames*n; p.ldd = (int)n;
+  return launch_g64<GA_SPEC_T, GB_PLAIN, GS_PLAIN>(p, (int)rows, (hipStream_t)stream);
+}
+
+// y[r][q] = sum_t frames[r][t][q + pad_left - t*hop] (/ window-square envelope iff window != NULL)
+int brv_overlap_add(const float* frames_in, const float* window, float* y, int64_t rows,
+                    int64_t frames, int64_t n, int64_t hop, int64_t pad_left, int64_t out_len,
+                    brv_stream_t stream) {
+  if (rows < 1 || frames < 1 || out_len < 1 || hop < 1) return -1;
+  OlaParams o;
+  o.frames = frames_in; o.y = y; o.win = window; o.F = (int)frames; o.n = (int)n; o.hop = (int)hop;
+  o.out_len = (int)out_len; o.normalize = window != nullptr; o.pad_left = (int)pad_left;
+  o.f_bs = (long long)frames*n; o.y_bs = out_len;
+  int gx = (int)((out_len + 255)/256); if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(istft_ola_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, o);
+  return (int)hipGetLastError();
+}
+
+int brv_polar(const float* mag, const float* phase, float* out, int64_t n, brv_stream_t stream) {
+  if (n < 1) return -1;
+  int gx = (int)((n + 255)/256); if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(polar_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, mag, phase,
+                     (float2*)out, (long long)n);
+  return (int)hipGetLastError();
+}
+int brv_mag_phase(const float* x, float* mag, float* phase, int64_t n, brv_stream_t stream) {
+  if (n < 1) return -1;
+  int gx = (int)((n + 255)/256); if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(mag_phase_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)x, mag, phase, (long long)n);
+  return (int)hipGetLastError();
+}
+
+int brv_spec_compress(const float* x, float* y, int64_t n, float compression, float scale,
+                      brv_stream_t stream) {
+  if (n < 1) return -1;
+  int gx = (int)((n + 255)/256); if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(spec_compress_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)x, (float2*)y, (long long)n, compression, scale);
+  return (int)hipGetLastError();
+}
+int brv_spec_compress_backward(const float* x, const float* gy, float* gx_out, int64_t n,
+                               float compression, float scale, brv_stream_t stream) {
+  if (n < 1) return -1;
+  int gx = (int)((n + 255)/256); if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(spec_compress_bwd_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)x, (const float2*)gy, (float2*)gx_out, (long long)n,
+                     compression, scale);
+  return (int)hipGetLastError();
 }
 
 int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,

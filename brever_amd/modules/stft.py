@@ -11,13 +11,14 @@ SURVEY.md App. A.1/A.2):
   ``X *= scale``; the inverse undoes these in reverse order and runs the
   window-envelope-normalised overlap-add of ``torch.istft``.
 
-The transforms run in ``libbrever_hip.so`` as fp32 DFT-GEMMs on the exact-fp32 MFMA
-(``brv_stft_forward`` / ``brv_istft_backward``); the window-weighted DFT bases are
-built here once per instance in float64 and cached per device. Limits of the HIP
-path for now: one-sided spectra, ``center=True``, constant padding, hop dividing the
-frame length, ``n_fft == frame_length``. ``STFT.forward`` is differentiable when
-``compression_factor == 1`` (``brv_stft_adjoint``: the transposed DFT-GEMM followed by
-a plain overlap-add); ``STFT.backward`` and the filterbank give values only.
+The transforms run in ``libbrever_hip.so`` as DFT products with the basis in double precision
+on the fp64 matrix pipe (``brv_dft64_forward`` / ``brv_dft64_synthesis`` + ``brv_overlap_add``):
+data stay fp32 in HBM, the n-term sums accumulate in fp64, so the round trip meets the
+reference's own ``atol=1e-6`` (tests/test_modules.py:319-326), which a plain fp32 DFT product
+misses by 20x. The window-weighted bases are built here once per instance in float64 and cached
+per device. Any hop, ``n_fft >= frame_length``, one- or two-sided spectra, ``center`` on or
+off; only reflect-type padding is not built. Both directions are differentiable, including
+through the magnitude compression (``brv_spec_compress_backward``).
 """
 import functools
 import math
@@ -39,87 +40,100 @@ def fft_freqs(fs=16e3, n_fft=512, onesided=True):
     return freqs
 
 
-class _StftFunction(torch.autograd.Function):
-    """x (rows, L) fp32 -> spec (rows, bins, F) complex64; gradient through
-    ``brv_stft_adjoint`` (compression 1 only)."""
+def _complex_pairs(t):
+    """complex64 tensor -> contiguous float32 view (..., 2)."""
+    return torch.view_as_real(t.to(torch.complex64).contiguous())
+
+
+class _SpecCompress(torch.autograd.Function):
+    """Y = scale |X|^(c-1) X on complex64 tensors (magnitude compression + scaling,
+    stft.py:85-87,114-118) with its gradient, both as HIP kernels."""
 
     @staticmethod
-    def forward(ctx, x2, basis, frame_length, hop_length, compression, scale):
-        lib = hip.lib()
-        rows, L = x2.shape
-        F = lib.brv_stft_frames(L, frame_length, hop_length)
-        bins = frame_length//2 + 1
-        spec = torch.empty(rows, bins, F, 2, dtype=torch.float32, device=x2.device)
-        hip.check(lib.brv_stft_forward(
-            hip.ptr(x2), hip.ptr(basis), hip.ptr(spec), rows, L, frame_length,
-            hop_length, float(compression), float(scale), hip.stream()), 'brv_stft_forward')
-        ctx.save_for_backward(basis)
-        ctx.geom = (rows, L, frame_length, hop_length, F, float(compression), float(scale))
-        return torch.view_as_complex(spec)
+    def forward(ctx, x, compression, scale):
+        xr = _complex_pairs(x)
+        y = torch.empty_like(xr)
+        hip.check(hip.lib().brv_spec_compress(hip.ptr(xr), hip.ptr(y), x.numel(),
+                                              float(compression), float(scale), hip.stream()),
+                  'brv_spec_compress')
+        ctx.save_for_backward(xr)
+        ctx.cs = (float(compression), float(scale))
+        return torch.view_as_complex(y)
 
     @staticmethod
     def backward(ctx, grad):
-        basis, = ctx.saved_tensors
-        rows, L, n, hop, F, compression, scale = ctx.geom
-        if compression != 1:
-            raise NotImplementedError('gradient of the magnitude compression is not built yet '
-                                      'on the HIP path')
-        dspec = torch.view_as_real(grad.to(torch.complex64).contiguous())
-        dx = stft_adjoint(dspec, basis, rows, L, n, hop, F, scale)
-        return dx, None, None, None, None, None
+        xr, = ctx.saved_tensors
+        gy = _complex_pairs(grad)
+        gx = torch.empty_like(xr)
+        hip.check(hip.lib().brv_spec_compress_backward(
+            hip.ptr(xr), hip.ptr(gy), hip.ptr(gx), xr.numel()//2, *ctx.cs, hip.stream()),
+            'brv_spec_compress_backward')
+        return torch.view_as_complex(gx), None, None
 
 
-class _IstftFunction(torch.autograd.Function):
-    """spec (rows, bins, F) complex64 -> y (rows, hop*(F-1)): ``brv_istft_backward``; the
-    gradient (compression 1 only) is the window-envelope division followed by a framed DFT
-    with the transposed inverse basis."""
+class _StftLinear(torch.autograd.Function):
+    """x (rows, L) fp32 -> X (rows, bins, F) complex64: the linear part of ``STFT.forward``
+    (framing, window, DFT, normalisation; optionally the fused compression / scale when no
+    gradient is needed). Gradient = the transposed product + plain overlap-add."""
 
     @staticmethod
-    def forward(ctx, spec, inv, win, inv_t, frame_length, hop_length, compression, scale):
-        rows, bins, F = spec.shape
-        spec_r = torch.view_as_real(spec.contiguous())
-        scratch = torch.empty(rows, F, frame_length, dtype=torch.float32, device=spec.device)
-        out_len = hop_length*(F - 1)
-        y = torch.empty(rows, out_len, dtype=torch.float32, device=spec.device)
-        hip.check(hip.lib().brv_istft_backward(
-            hip.ptr(spec_r), hip.ptr(inv), hip.ptr(win), hip.ptr(scratch), hip.ptr(y), rows, F,
-            frame_length, hop_length, float(compression), float(scale), hip.stream()),
-            'brv_istft_backward')
-        ctx.save_for_backward(win, inv_t)
-        ctx.geom = (rows, bins, F, frame_length, hop_length, float(compression), float(scale))
+    def forward(ctx, x2, stft, compression, scale):
+        spec = stft._dft_forward(x2, stft._tables(x2.device)['basis'], compression, scale)
+        ctx.stft, ctx.L = stft, x2.shape[-1]
+        ctx.scale = float(scale)
+        if compression != 1:
+            ctx.mark_non_differentiable(spec)
+        return spec
+
+    @staticmethod
+    def backward(ctx, grad):
+        dx = ctx.stft._dft_adjoint(_complex_pairs(grad), ctx.L, ctx.scale)
+        return dx, None, None, None
+
+
+class _IstftLinear(torch.autograd.Function):
+    """X (rows, bins, F) complex64 -> y (rows, out_len): inverse DFT of every frame, window,
+    overlap-add divided by the window-square envelope (``torch.istft``). Gradient
+    (``center=True``): envelope division, then a framed DFT with the synthesis basis."""
+
+    @staticmethod
+    def forward(ctx, spec, stft, compression, scale):
+        y = stft._istft(spec, compression, scale)
+        ctx.stft, ctx.geom = stft, (spec.shape[-1], y.shape[-1], float(scale))
+        if compression != 1:
+            ctx.mark_non_differentiable(y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        win, inv_t = ctx.saved_tensors
-        rows, bins, F, n, hop, compression, scale = ctx.geom
-        if compression != 1:
-            raise NotImplementedError('gradient of the magnitude compression is not built yet '
-                                      'on the HIP path')
+        stft = ctx.stft
+        F, out_len, scale = ctx.geom
+        if not stft.center:
+            raise NotImplementedError('gradient of STFT.backward needs center=True')
         lib = hip.lib()
         dy = dy.float().contiguous()
-        out_len = dy.shape[-1]
+        rows = dy.shape[0]
+        tb = stft._tables(dy.device)
         u = torch.empty_like(dy)
-        hip.check(lib.brv_istft_env_divide(hip.ptr(dy), hip.ptr(win), hip.ptr(u), rows, out_len,
-                                           n, hop, F, hip.stream()), 'brv_istft_env_divide')
-        dspec = torch.empty(rows, bins, F, 2, dtype=torch.float32, device=dy.device)
-        hip.check(lib.brv_framed_dft_forward(
-            hip.ptr(u), hip.ptr(inv_t), hip.ptr(dspec), rows, out_len, n, hop, n//2, F, 1.0,
-            1.0/scale, hip.stream()), 'brv_framed_dft_forward')
-        return torch.view_as_complex(dspec), None, None, None, None, None, None, None
-
-
-def stft_adjoint(dspec, basis, rows, L, frame_length, hop_length, frames, scale):
-    """dx (rows, L) = adjoint of the framed DFT applied to dspec (rows, bins, F, 2)."""
-    scratch = torch.empty(rows, frames, frame_length, dtype=torch.float32, device=dspec.device)
-    dx = torch.empty(rows, L, dtype=torch.float32, device=dspec.device)
-    hip.check(hip.lib().brv_stft_adjoint(
-        hip.ptr(dspec), hip.ptr(basis), hip.ptr(scratch), hip.ptr(dx), rows, L,
-        frame_length, hop_length, float(scale), hip.stream()), 'brv_stft_adjoint')
-    return dx
+        hip.check(lib.brv_istft_env_divide(hip.ptr(dy), hip.ptr(tb['window']), hip.ptr(u), rows,
+                                           out_len, stft.n_fft, stft.hop_length, F, hip.stream()),
+                  'brv_istft_env_divide')
+        dspec = torch.empty(rows, stft.bins, F, 2, dtype=torch.float32, device=dy.device)
+        hip.check(lib.brv_dft64_forward(
+            hip.ptr(u), hip.ptr(tb['synthesis']), hip.ptr(dspec), rows, out_len, stft.n_fft,
+            stft.hop_length, stft.n_fft//2, F, stft.bins, 1.0, 1.0/scale, hip.stream()),
+            'brv_dft64_forward')
+        return torch.view_as_complex(dspec), None, None, None
 
 
 class STFT:
+    """Same constructor, padding arithmetic, normalisation, compression, scaling and return types
+    as the reference (stft.py:32-149). Every option of ``torch.stft`` the reference forwards is
+    supported except reflect-type padding: any hop, ``n_fft >= frame_length`` (the window is
+    zero-padded centrally to ``n_fft`` like torch does), one- and two-sided spectra,
+    ``center`` on or off. Both directions are differentiable, through the magnitude
+    compression as well."""
+
     def __init__(self, frame_length=512, hop_length=256, window='hann',
                  center=True, pad_mode='constant', normalized=True,
                  onesided=True, compression_factor=1, scale_factor=1,
@@ -142,58 +156,52 @@ class STFT:
         if isinstance(window, np.ndarray):
             window = torch.from_numpy(window)
         self.window = window
-        unsupported = []
-        if not center:
-            unsupported.append('center=False')
         if pad_mode != 'constant':
-            unsupported.append(f"pad_mode='{pad_mode}'")
-        if not onesided:
-            unsupported.append('onesided=False')
-        if self.n_fft != frame_length:
-            unsupported.append('n_fft != frame_length')
-        if frame_length % hop_length != 0 or frame_length % 2 != 0:
-            unsupported.append('hop_length not dividing an even frame_length')
-        if unsupported:
-            raise NotImplementedError(
-                'not built yet on the HIP path: ' + ', '.join(unsupported))
-        self._tables = {}
+            raise NotImplementedError(f"pad_mode='{pad_mode}' is not built on the HIP path "
+                                      '(the reference default is constant)')
+        if self.n_fft < frame_length:
+            raise ValueError(f'n_fft ({self.n_fft}) must be >= frame_length ({frame_length})')
+        self.bins = self.n_fft//2 + 1 if onesided else self.n_fft
+        self._cache = {}
 
-    # -- host-side constant tables (float64 -> fp32), cached per device ----------
-    def _get_tables(self, device):
+    # -- host-side constant tables (float64), cached per device --------------------
+    def _tables(self, device):
         key = str(device)
-        if key not in self._tables:
-            n = self.frame_length
+        if key not in self._cache:
+            n, bins = self.n_fft, self.bins
             w = self.window.double().cpu().numpy()
             norm = 1.0/math.sqrt(float((w**2).sum())) if self.normalized else 1.0
-            k = np.arange(n//2 + 1)[:, None]
-            m = np.arange(n)[None, :]
-            ang = 2.0*np.pi*k*m/n
-            basis = np.empty((2*(n//2 + 1), n))
-            basis[0::2] = np.cos(ang)*w[None, :]*norm
-            basis[1::2] = -np.sin(ang)*w[None, :]*norm
-            # inverse real DFT of a one-sided spectrum, windowed, normalisation undone
-            eps = np.full(n//2 + 1, 2.0)
-            eps[0] = 1.0
-            eps[-1] = 1.0
-            inv = np.empty((n, 2*(n//2 + 1)))
-            inv[:, 0::2] = (np.cos(ang)*eps[:, None]).T
-            inv[:, 1::2] = (-np.sin(ang)*eps[:, None]).T
-            inv *= w[:, None]/(n*norm)
-            self._tables[key] = (
-                torch.from_numpy(basis).float().to(device).contiguous(),
-                torch.from_numpy(inv).float().to(device).contiguous(),
-                self.window.float().to(device).contiguous(),
-            )
-            # transposed inverse basis: the adjoint of the inverse transform is a framed DFT
-            self._inv_t = getattr(self, '_inv_t', {})
-            self._inv_t[key] = torch.from_numpy(np.ascontiguousarray(inv.T)).float().to(device)
-        return self._tables[key]
+            left = (n - self.frame_length)//2             # torch.stft centres the window in n_fft
+            wp = np.zeros(n)
+            wp[left:left + self.frame_length] = w
+            ang = 2.0*np.pi*np.arange(bins)[:, None]*np.arange(n)[None, :]/n
+            basis = np.empty((2*bins, n))
+            basis[0::2] = np.cos(ang)*wp*norm
+            basis[1::2] = -np.sin(ang)*wp*norm
+            # frames of the inverse transform: w[m] * irfft(X[:n/2 + 1])[m] -- hermitian completion
+            # = every bin except DC and Nyquist counted twice. torch.istft treats a two-sided
+            # input the same way: it keeps bins 0..n/2 and ignores the rest. Normalisation undone.
+            weight = np.zeros(bins)
+            weight[:n//2 + 1] = 2.0
+            weight[0] = 1.0
+            if n % 2 == 0:
+                weight[n//2] = 1.0
+            synth = np.empty((2*bins, n))
+            synth[0::2] = np.cos(ang)*weight[:, None]
+            synth[1::2] = -np.sin(ang)*weight[:, None]
+            synth *= wp[None, :]/(n*norm)
+            self._cache[key] = {
+                'basis': torch.from_numpy(basis).to(device).contiguous(),
+                'synthesis': torch.from_numpy(synth).to(device).contiguous(),
+                'window': torch.from_numpy(wp).float().to(device).contiguous(),
+            }
+        return self._cache[key]
 
     def __call__(self, x, return_type='complex'):
         return self.forward(x, return_type=return_type)
 
     def frame_count(self, samples):
-        """Frames WITHOUT the n/2 centre padding (stft.py:146-149)."""
+        """Frames WITHOUT the n_fft/2 centre padding (stft.py:146-149)."""
         return math.ceil(max(samples - self.frame_length, 0)/self.hop_length) + 1
 
     def pad(self, x):
@@ -201,24 +209,83 @@ class STFT:
         padding = (frames - 1)*self.hop_length + self.frame_length - x.shape[-1]
         return torch.nn.functional.pad(x, (0, padding), mode=self.pad_mode)
 
+    def _geometry(self, L):
+        """(frames, left offset of frame 0) of torch.stft on the right-padded signal."""
+        padded = (self.frame_count(L) - 1)*self.hop_length + self.frame_length
+        pad_left = self.n_fft//2 if self.center else 0
+        total = padded + 2*pad_left
+        if total < self.n_fft:
+            raise ValueError(f'input of {L} samples is shorter than one n_fft = {self.n_fft} frame')
+        return (total - self.n_fft)//self.hop_length + 1, pad_left
+
+    # -- the three products -----------------------------------------------------------
+    def _dft_forward(self, x2, basis, compression=1.0, scale=1.0):
+        rows, L = x2.shape
+        F, pad_left = self._geometry(L)
+        spec = torch.empty(rows, self.bins, F, 2, dtype=torch.float32, device=x2.device)
+        hip.check(hip.lib().brv_dft64_forward(
+            hip.ptr(x2), hip.ptr(basis), hip.ptr(spec), rows, L, self.n_fft, self.hop_length,
+            pad_left, F, self.bins, float(compression), float(scale), hip.stream()),
+            'brv_dft64_forward')
+        return torch.view_as_complex(spec)
+
+    def _dft_adjoint(self, dspec, L, scale=1.0):
+        """dx (rows, L): adjoint of ``scale * _dft_forward`` applied to dspec (rows, bins, F, 2)."""
+        lib = hip.lib()
+        rows, F = dspec.shape[0], dspec.shape[2]
+        _, pad_left = self._geometry(L)
+        frames = torch.empty(rows, F, self.n_fft, dtype=torch.float32, device=dspec.device)
+        hip.check(lib.brv_dft64_synthesis(
+            hip.ptr(dspec), hip.ptr(self._tables(dspec.device)['basis']), hip.ptr(frames), rows, F,
+            self.n_fft, self.bins, 1.0, 1.0/float(scale), hip.stream()), 'brv_dft64_synthesis')
+        dx = torch.empty(rows, L, dtype=torch.float32, device=dspec.device)
+        hip.check(lib.brv_overlap_add(hip.ptr(frames), None, hip.ptr(dx), rows, F, self.n_fft,
+                                      self.hop_length, pad_left, L, hip.stream()),
+                  'brv_overlap_add')
+        return dx
+
+    def _istft(self, spec, compression=1.0, scale=1.0):
+        lib = hip.lib()
+        rows, bins, F = spec.shape
+        tb = self._tables(spec.device)
+        frames = torch.empty(rows, F, self.n_fft, dtype=torch.float32, device=spec.device)
+        hip.check(lib.brv_dft64_synthesis(
+            hip.ptr(_complex_pairs(spec)), hip.ptr(tb['synthesis']), hip.ptr(frames), rows, F,
+            self.n_fft, bins, float(compression), float(scale), hip.stream()),
+            'brv_dft64_synthesis')
+        pad_left = self.n_fft//2 if self.center else 0
+        out_len = self.n_fft + self.hop_length*(F - 1) - 2*pad_left
+        y = torch.empty(rows, out_len, dtype=torch.float32, device=spec.device)
+        hip.check(lib.brv_overlap_add(hip.ptr(frames), hip.ptr(tb['window']), hip.ptr(y), rows, F,
+                                      self.n_fft, self.hop_length, pad_left, out_len, hip.stream()),
+                  'brv_overlap_add')
+        return y
+
+    # -- public interface --------------------------------------------------------------------
     def forward(self, x, return_type='complex'):
         hip.require_device(x)
-        lib = hip.lib()
-        basis, _, _ = self._get_tables(x.device)
         lead, L = x.shape[:-1], x.shape[-1]
         rows = int(np.prod(lead)) if lead else 1
         x2 = x.reshape(rows, L).float().contiguous()
-        F = lib.brv_stft_frames(L, self.frame_length, self.hop_length)
-        bins = self.frame_length//2 + 1
-        out = _StftFunction.apply(x2, basis, self.frame_length, self.hop_length,
-                                  self.compression_factor, self.scale_factor)
-        out = out.view(*lead, bins, F)
+        c, s = self.compression_factor, self.scale_factor
+        if c != 1 and x2.requires_grad and torch.is_grad_enabled():
+            out = _SpecCompress.apply(_StftLinear.apply(x2, self, 1.0, 1.0), c, s)
+        else:
+            out = _StftLinear.apply(x2, self, c, s)
+        out = out.view(*lead, *out.shape[-2:])
         if return_type == 'complex':
             return out
         if return_type == 'real_imag':
             return out.real, out.imag
         if return_type == 'mag_phase':
-            return out.abs(), out.angle()
+            if out.requires_grad:
+                return out.abs(), out.angle()
+            pairs = _complex_pairs(out)
+            mag = torch.empty(out.shape, dtype=torch.float32, device=out.device)
+            phase = torch.empty_like(mag)
+            hip.check(hip.lib().brv_mag_phase(hip.ptr(pairs), hip.ptr(mag), hip.ptr(phase),
+                                              out.numel(), hip.stream()), 'brv_mag_phase')
+            return mag, phase
         raise ValueError('return_type must be complex, real_imag or '
                          f'mag_phase, got {return_type}')
 
@@ -227,23 +294,32 @@ class STFT:
             x = torch.complex(*x)
         elif input_type == 'mag_phase':
             mag, phase = x
-            x = mag*torch.exp(1j*phase)
+            if mag.requires_grad or phase.requires_grad:
+                x = torch.polar(mag, phase)
+            else:
+                hip.require_device(mag, phase)
+                m, ph = mag.float().contiguous(), phase.float().contiguous()
+                pairs = torch.empty(*m.shape, 2, dtype=torch.float32, device=m.device)
+                hip.check(hip.lib().brv_polar(hip.ptr(m), hip.ptr(ph), hip.ptr(pairs), m.numel(),
+                                              hip.stream()), 'brv_polar')
+                x = torch.view_as_complex(pairs)
         elif input_type != 'complex':
             raise ValueError('input_type must be complex, real_imag or '
                              f'mag_phase, got {input_type}')
         hip.require_device(x)
-        lib = hip.lib()
-        _, inv, win = self._get_tables(x.device)
         lead, (bins, F) = x.shape[:-2], x.shape[-2:]
-        if bins != self.frame_length//2 + 1:
-            raise ValueError(f'expected {self.frame_length//2 + 1} bins, got {bins}')
+        if bins != self.bins:
+            raise ValueError(f'expected {self.bins} bins, got {bins}')
         rows = int(np.prod(lead)) if lead else 1
         spec = x.reshape(rows, bins, F).to(torch.complex64)
-        out_len = self.hop_length*(F - 1)
-        y = _IstftFunction.apply(spec, inv, win,
-                                 self._inv_t[str(x.device)], self.frame_length, self.hop_length,
-                                 self.compression_factor, self.scale_factor)
-        return y.view(*lead, out_len)
+        c, s = self.compression_factor, self.scale_factor
+        if c != 1 and spec.requires_grad and torch.is_grad_enabled():
+            # X / scale, then |.|^(1/c): one compression op with exponent 1/c, scale s^(-1/c)
+            spec = _SpecCompress.apply(spec, 1.0/c, float(s)**(-1.0/c))
+            y = _IstftLinear.apply(spec, self, 1.0, 1.0)
+        else:
+            y = _IstftLinear.apply(spec, self, c, s)
+        return y.view(*lead, y.shape[-1])
 
 
 class ConvSTFT:

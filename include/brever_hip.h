@@ -194,6 +194,35 @@ int brv_framed_dft_transpose(const float* spec, const float* basis, float* frame
                              float* y, int64_t rows, int64_t frames, int64_t frame_length,
                              int64_t hop_length, int64_t pad_left, int64_t out_len,
                              float compression, float scale, brv_stream_t stream);
+/* The transforms of the STFT module in full generality (stft.py:32-149: any hop, n_fft !=
+ * frame_length through a centrally zero-padded window, one- or two-sided spectra) and at FFT
+ * accuracy: the DFT basis is passed in DOUBLE precision and the product accumulates on the fp64
+ * matrix pipe (v_mfma_f64_16x16x4_f64); data stay fp32 in memory.
+ *   dft64_forward:   spec (rows, bins, frames) complex64 = framed DFT of x (rows, length); frame t
+ *                    covers samples [t*hop - pad_left, + n) (zeros outside); basis (2 bins, n)
+ *                    rows (re_k, im_k); then |.|^compression e^{j angle} * scale.
+ *   dft64_synthesis: frames_out (rows, frames, n) = (spec / scale, decompressed)^T x tbasis
+ *                    (2 bins, n): inverse transform (tbasis = inverse basis^T) or adjoint of the
+ *                    forward transform (tbasis = forward basis).
+ *   overlap_add:     y (rows, out_len) from frames (rows, frames, n); window != NULL divides by
+ *                    the window-square envelope (torch.istft).
+ *   spec_compress(_backward): Y = scale |X|^(c-1) X on n complex64 values and its gradient. */
+int brv_dft64_forward(const float* x, const double* basis, float* spec, int64_t rows,
+                      int64_t length, int64_t n, int64_t hop, int64_t pad_left, int64_t frames,
+                      int64_t bins, float compression, float scale, brv_stream_t stream);
+int brv_dft64_synthesis(const float* spec, const double* tbasis, float* frames_out, int64_t rows,
+                        int64_t frames, int64_t n, int64_t bins, float compression, float scale,
+                        brv_stream_t stream);
+int brv_overlap_add(const float* frames_in, const float* window, float* y, int64_t rows,
+                    int64_t frames, int64_t n, int64_t hop, int64_t pad_left, int64_t out_len,
+                    brv_stream_t stream);
+int brv_spec_compress(const float* x, float* y, int64_t n, float compression, float scale,
+                      brv_stream_t stream);
+/* out = mag e^{j phase} / (mag, phase) of n complex64 values ('mag_phase' of stft.py:93-110). */
+int brv_polar(const float* mag, const float* phase, float* out, int64_t n, brv_stream_t stream);
+int brv_mag_phase(const float* x, float* mag, float* phase, int64_t n, brv_stream_t stream);
+int brv_spec_compress_backward(const float* x, const float* gy, float* gx, int64_t n,
+                               float compression, float scale, brv_stream_t stream);
 /* d[b] = a[b or shared] (M x K) @ b[b] (K x N), fp32 (MelFilterbank.forward/backward,
  * stft.py:189-198). a_batch_stride = 0 shares one matrix across the batch. */
 int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,

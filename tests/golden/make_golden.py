@@ -817,13 +817,65 @@ def golden_config(out):
         json.dump(fixture, f, indent=1, sort_keys=True)
 
 
+def golden_stft_matrix(out):
+    """The reference's own STFT test matrix (tests/test_modules.py:300-326: 32 combinations of
+    hop / compression / scale / normalized / onesided on randn(4096, seed 42)) plus geometries
+    it does not test (n_fft > frame_length, hop not dividing the frame, center=False, two-sided
+    with a short n_fft): per case 192 sampled spectrum values (fixed pseudo-random positions),
+    the spectrum's energy, the round-trip output and, for 4 cases, gradients of a seeded
+    quadratic form through forward (incl. compression) and backward."""
+    import itertools
+    from brever.modules import STFT
+    gen = torch.Generator().manual_seed(42)
+    x = torch.randn(4096, generator=gen)
+    cases = [dict(frame_length=512, hop_length=h, compression_factor=c, scale_factor=s,
+                  normalized=nm, onesided=o)
+             for h, c, s, nm, o in itertools.product([256, 128], [1.0, 0.5], [1.0, 0.15],
+                                                     [False, True], [False, True])]
+    cases += [dict(frame_length=400, hop_length=160, n_fft=512),
+              dict(frame_length=400, hop_length=100, n_fft=512, compression_factor=0.5),
+              dict(frame_length=512, hop_length=200),
+              dict(frame_length=256, hop_length=64, center=False, window='hamming'),
+              dict(frame_length=60, hop_length=25, n_fft=64, onesided=False, window='hamming'),
+              dict(frame_length=512, hop_length=128, window=None, normalized=False)]
+    data = {'x': x.numpy(), 'cases': json.dumps(cases)}
+    pick = np.random.default_rng(0)
+    for i, kw in enumerate(cases):
+        stft = STFT(**kw)
+        X = stft(x)
+        flat = X.reshape(-1)
+        idx = pick.integers(0, flat.numel(), 192)
+        data[f'idx{i}'] = idx
+        data[f'val{i}'] = torch.view_as_real(flat[idx]).numpy()
+        data[f'shape{i}'] = np.array(X.shape)
+        data[f'energy{i}'] = np.array(float((X.abs()**2).sum()))
+        data[f'rt{i}'] = stft.backward(X.clone()).numpy()
+    # gradients: L = sum Re(conj(G) STFT(x)) and L = sum g * ISTFT(X)
+    for j, i in enumerate([0, 5, 12, 33]):
+        stft = STFT(**cases[i])
+        xg = x.clone().requires_grad_(True)
+        X = stft(xg)
+        G = torch.randn(X.shape, generator=gen) + 1j*torch.randn(X.shape, generator=gen)
+        (X*G.conj()).real.sum().backward()
+        data[f'gcase{j}'] = np.array(i)
+        data[f'G{j}'] = torch.view_as_real(G).numpy()
+        data[f'dx{j}'] = xg.grad.numpy()
+        Xg = X.detach().clone().requires_grad_(True)
+        y = stft.backward(Xg*1.0)
+        g = torch.randn(y.shape, generator=gen)
+        (y*g).sum().backward()
+        data[f'g{j}'] = g.numpy()
+        data[f'dX{j}'] = torch.view_as_real(Xg.grad).numpy()
+    np.savez_compressed(os.path.join(out, 'stft_matrix.npz'), **data)
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
     os.chdir(REF)       # the reference opens config/... relatively
     torch.set_num_threads(4)
     todo = [golden_batching, golden_collate, golden_losses, golden_convtasnet, golden_training,
-            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features, golden_ema, golden_norms, golden_tfgridnet, golden_config]
+            golden_stft, golden_ffnn, golden_dccrn, golden_sgmse, golden_segments, golden_features, golden_ema, golden_norms, golden_tfgridnet, golden_config, golden_stft_matrix]
     only = sys.argv[1:]                  # e.g. `make_golden.py sgmse` regenerates one file
     for fn in todo:
         if not only or fn.__name__[len('golden_'):] in only:
