@@ -7,9 +7,10 @@ method set of ``BreverDataset`` that ``BreverTrainer`` and the samplers touch
 tests/utils.py:9-42 ``DummyDataset``). ``BreverDataset`` reads the
 reference's dataset layout -- ``audio/NNNNN_<source>.flac`` in a directory or in
 ``audio.tar`` -- with the reference's segmentation strategies (brever/data.py:112-210,
-integer arithmetic, bit-exact against fixtures); WAV files are decoded here, FLAC needs the
-``soundfile`` wheel (absent in this image: a clear ``ImportError``). The benchmark and most
-tests run on synthetic mixtures generated in memory by ``SyntheticMixtureDataset``.
+integer arithmetic, bit-exact against fixtures); WAV files are decoded here, FLAC by the
+native decoder of the library (``csrc/flac.hip``, RFC 9639; the ``soundfile`` wheel the reference
+uses is absent). The benchmark and most tests run on synthetic mixtures generated in memory by
+``SyntheticMixtureDataset``.
 """
 import io
 import logging
@@ -254,30 +255,47 @@ def _wav_header(f):
             f.seek(size + (size & 1), io.SEEK_CUR)
 
 
+def _flac_info(data, name):
+    import ctypes
+    from . import hip
+    frames, rate = ctypes.c_int64(0), ctypes.c_int32(0)
+    channels, bits = ctypes.c_int32(0), ctypes.c_int32(0)
+    status = hip.lib().brv_flac_info(data, len(data), ctypes.byref(frames), ctypes.byref(rate),
+                                     ctypes.byref(channels), ctypes.byref(bits))
+    if status != 0:
+        raise ValueError(f'{name}: not a FLAC stream this decoder reads (status {status})')
+    return frames.value, rate.value, channels.value, bits.value
+
+
 def audio_info(f, name):
-    """(frames, sample rate) of an open audio file (``torchaudio.info`` in data.py:143)."""
+    """(frames, sample rate) of an open audio file (``torchaudio.info`` in data.py:143). WAV
+    and FLAC headers are parsed here (FLAC: ``brv_flac_info`` of the native library)."""
     if name.lower().endswith('.wav'):
         rate, _, frames, _, _, _ = _wav_header(f)
         return frames, rate
-    try:
-        import soundfile as sf
-    except ImportError as e:
-        raise ImportError(f'reading {name} needs the soundfile wheel (FLAC); WAV files are '
-                          'decoded without it') from e
-    info = sf.info(f)
-    return info.frames, info.samplerate
+    head = f.read(1 << 16)                 # STREAMINFO is the first metadata block
+    frames, rate, _, _ = _flac_info(head, name)
+    if frames == 0:                        # unknown length in the header: decode to count
+        return len(audio_read(io.BytesIO(head + f.read()), name)[0]), rate
+    return frames, rate
 
 
 def audio_read(f, name):
     """float32 array (frames,) or (frames, channels) and the sample rate (``sf.read`` in
-    data.py:265)."""
+    data.py:265). FLAC goes through the native decoder ``brv_flac_decode`` (csrc/flac.hip)."""
     if not name.lower().endswith('.wav'):
-        try:
-            import soundfile as sf
-        except ImportError as e:
-            raise ImportError(f'reading {name} needs the soundfile wheel (FLAC); WAV files '
-                              'are decoded without it') from e
-        return sf.read(f, dtype='float32')
+        import ctypes
+        from . import hip
+        data = f.read()
+        frames, rate, channels, _ = _flac_info(data, name)
+        capacity = frames if frames > 0 else 8*len(data)
+        out = np.empty((capacity, channels), dtype=np.float32)
+        got = hip.lib().brv_flac_decode(data, len(data),
+                                        out.ctypes.data_as(ctypes.c_void_p), capacity)
+        if got < 0:
+            raise ValueError(f'{name}: FLAC decoding failed (status {got})')
+        out = out[:got]
+        return (out if channels > 1 else out[:, 0]), rate
     rate, channels, frames, code, bits, _ = _wav_header(f)
     raw = f.read(frames*channels*bits//8)
     if code == 3 and bits == 32:
@@ -315,11 +333,65 @@ class TarArchive:
         return self._handle().extractfile(self.members[name])
 
 
+_mixture_maker = None
+
+
+def set_mixture_maker(factory):
+    """Install the mixture maker behind ``BreverDataset(dynamic_mixing=True)``.
+
+    The reference hard-wires ``RandomMixtureMakerDataset`` (brever/data.py:494-532), which
+    synthesises mixtures on the fly from raw speech / noise corpora and BRIRs through
+    ``brever.mixture.RandomMixtureMaker`` -- the dataset-synthesis subsystem, out of scope of
+    this build. The dataset side of dynamic mixing IS built: any class with that object's
+    protocol plugs in here --
+
+        factory(path, sources=[...], size=N)   # N mixtures per epoch
+        .set_epoch(epoch)                      # redraw the epoch's mixtures
+        .file_lengths                          # list of N lengths in samples
+        [i] -> list of float32 arrays (frames, 2), one per source
+
+    ``SyntheticMixtureMaker`` below is such a class (the synthetic recipe of SURVEY.md 8d).
+    ``None`` uninstalls."""
+    global _mixture_maker
+    _mixture_maker = factory
+
+
+class SyntheticMixtureMaker:
+    """Mixture maker in the ``RandomMixtureMakerDataset`` protocol drawing the synthetic noisy /
+    clean pairs of ``SyntheticMixtureDataset`` with a new seed and new lengths every epoch."""
+
+    def __init__(self, path, sources, size, fs=16000, min_seconds=1.0, max_seconds=4.0):
+        self.sources, self.size, self.fs = list(sources), size, fs
+        self.bounds = (int(min_seconds*fs), int(max_seconds*fs))
+        self.set_epoch(0)
+
+    def set_epoch(self, epoch):
+        rng = random.Random(epoch)
+        self._lengths = [rng.randint(*self.bounds) for _ in range(self.size)]
+        self._seed = 7919*epoch
+
+    @property
+    def file_lengths(self):
+        return list(self._lengths)
+
+    def __getitem__(self, i):
+        L = self._lengths[i]
+        g = torch.Generator().manual_seed(self._seed + i)
+        clean = 0.1*torch.randn(L, generator=g)
+        noise = 0.1*torch.randn(L, generator=g)
+        snr = -5 + 15*float(torch.rand(1, generator=g))
+        mix = clean + noise*(clean.norm()/noise.norm())*10**(-snr/20)
+        named = {'mixture': mix, 'foreground': clean, 'background': mix - clean}
+        return [named[s].unsqueeze(1).repeat(1, 2).numpy().astype('float32')
+                for s in self.sources]
+
+
 class BreverDataset(torch.utils.data.Dataset):
     """Reads a dataset made by the reference's ``scripts/create_dataset.py``: same constructor,
     segmentation and item contract as brever/data.py:23-326 (items are
     ``(n_sources, 2, n_samples)`` float32 tensors, or whatever ``transform`` makes of them).
-    ``dynamic_mixing`` (on-the-fly mixture synthesis) is not built."""
+    ``dynamic_mixing=True`` draws every epoch's mixtures from the installed mixture maker
+    (``set_mixture_maker``) instead of the audio files."""
 
     def __init__(
         self,
@@ -335,8 +407,12 @@ class BreverDataset(torch.utils.data.Dataset):
         dynamic_mixing: bool = False,
         dynamic_mixtures_per_epoch: int = 1000,
     ):
-        if dynamic_mixing:
-            raise NotImplementedError('dynamic mixing is not built yet on this path')
+        if dynamic_mixing and _mixture_maker is None:
+            raise NotImplementedError(
+                'dynamic_mixing=True needs a mixture maker: the reference synthesises mixtures '
+                'from raw corpora with brever.mixture.RandomMixtureMaker, which is outside this '
+                'build; install a class with the same protocol through '
+                'brever_amd.data.set_mixture_maker (e.g. SyntheticMixtureMaker)')
         self.path = path
         self.segment_length = round(segment_length*fs)
         self.overlap_length = round(overlap_length*fs)
@@ -344,8 +420,11 @@ class BreverDataset(torch.utils.data.Dataset):
         self.sources = list(sources)
         self.segment_strategy = segment_strategy
         self.max_segment_length = round(max_segment_length*fs)
-        self.archive = TarArchive(os.path.join(path, 'audio.tar')) if tar else None
-        self.rmm_dset = None
+        self.archive = TarArchive(os.path.join(path, 'audio.tar')) \
+            if tar and not dynamic_mixing else None
+        self.rmm_dset = _mixture_maker(path, sources=self.sources,
+                                       size=dynamic_mixtures_per_epoch) \
+            if dynamic_mixing else None
         self.transform = transform
         self.preloaded_data = None
         self._ext = None
@@ -375,6 +454,9 @@ class BreverDataset(torch.utils.data.Dataset):
         return self.archive.get_file(name.replace('\\', '/'))
 
     def get_file_lengths(self):
+        if self.rmm_dset is not None:                  # data.py:155-158
+            self._duration = float('inf')
+            return list(self.rmm_dset.file_lengths)
         lengths = []
         for file_idx in range(self.count_files()):
             per_source = []
@@ -392,7 +474,8 @@ class BreverDataset(torch.utils.data.Dataset):
         self._segment_info = segment_table(
             self.get_file_lengths(), self.segment_length, self.overlap_length,
             self.segment_strategy, self.max_segment_length, owner=self)
-        self._effective_duration = sum(e - s for _, (s, e) in self._segment_info)/self.fs
+        self._effective_duration = float('inf') if self.rmm_dset is not None else \
+            sum(e - s for _, (s, e) in self._segment_info)/self.fs
 
     def __len__(self):
         return len(self._segment_info)
@@ -422,8 +505,11 @@ class BreverDataset(torch.utils.data.Dataset):
         if self.segment_strategy == 'random' and self.segment_length != 0.0:
             start = random.randint(start, end - self.segment_length)
             end = start + self.segment_length
-        sources = torch.from_numpy(np.stack([self.load_file(p)
-                                             for p in self.build_paths(file_idx)]))
+        if self.rmm_dset is None:
+            loaded = [self.load_file(p) for p in self.build_paths(file_idx)]
+        else:
+            loaded = self.rmm_dset[file_idx]
+        sources = torch.from_numpy(np.stack(loaded))
         sources = sources.unsqueeze(1) if sources.ndim == 2 else sources.transpose(1, 2)
         if end > sources.shape[-1]:
             if self.segment_strategy not in ('pad', 'random'):
@@ -444,6 +530,8 @@ class BreverDataset(torch.utils.data.Dataset):
     def preload(self, device, tqdm_desc=None):
         if self.segment_strategy == 'random':
             raise ValueError("can't preload when segment_strategy is 'random'")
+        if self.rmm_dset is not None:
+            raise ValueError("can't preload when using dynamic mixing")
         data = []
         for i in range(len(self)):
             item = self[i]
@@ -452,7 +540,9 @@ class BreverDataset(torch.utils.data.Dataset):
         self.preloaded_data = data      # only now: __getitem__ must not see a partial list
 
     def set_epoch(self, epoch):
-        pass
+        if self.rmm_dset is not None:                  # new mixtures, new lengths (data.py:323-326)
+            self.rmm_dset.set_epoch(epoch)
+            self.get_segment_info()
 
 
 def segment_table(file_lengths, segment_length, overlap_length, strategy, max_segment_length=0,

@@ -586,6 +586,16 @@ int brv_stoi_correlate(const float* tob_clean, const float* tob_proc, const int3
                        float* partial_scratch, float* out, int64_t rows, int64_t nf_max,
                        int extended, float clip, brv_stream_t stream);
 
+/* ---- FLAC decoding (HOST pointers: runs in the data loader, brever/data.py:143,259-268 read the
+ * dataset's audio/NNNNN_<source>.flac members through soundfile / torchaudio.info) ------------
+ * flac_info: frames per channel, sample rate, channels, bits per sample from STREAMINFO.
+ * flac_decode: interleaved float32 samples (frames, channels) scaled by 2^-(bps-1) into `out`
+ *   (capacity in frames); returns the number of frames decoded or < 0 (malformed stream, CRC
+ *   mismatch, unsupported feature). RFC 9639 subset: see csrc/flac.hip. */
+int brv_flac_info(const uint8_t* data, int64_t size, int64_t* frames, int32_t* sample_rate,
+                  int32_t* channels, int32_t* bits_per_sample);
+int64_t brv_flac_decode(const uint8_t* data, int64_t size, float* out, int64_t capacity_frames);
+
 /* ---- optimizer --------------------------------------------------------------
  * clip_grad_norm_(max_norm) + Adam.step (base.py:296-301, torch.optim.Adam with
  * amsgrad=False, weight_decay=0) on flat buffers of n floats. grads are first

@@ -162,3 +162,173 @@ def run_entry_points(tmp_path, arch, model_args=(), trainer_args=(), train='synt
         with h5py.File(os.path.join(model_dir, name), 'r') as f:
             scores = f[key][...]
     return model_dir, losses, scores
+
+
+# ---- a small FLAC ENCODER (test infrastructure only) ---------------------------------------------
+# Writes RFC 9639 streams that exercise the decoder of csrc/flac.hip: fixed predictors of every
+# order, LPC with quantised coefficients, verbatim and constant subframes, wasted bits,
+# left/side / side/right / mid/side stereo, partitioned Rice residuals with both parameter
+# widths and escape partitions, fixed- and variable-length last blocks.
+class _BitWriter:
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def write(self, value, bits):
+        if bits == 0:
+            return
+        self.acc = (self.acc << bits) | (value & ((1 << bits) - 1))
+        self.n += bits
+        while self.n >= 8:
+            self.n -= 8
+            self.out.append((self.acc >> self.n) & 0xff)
+        self.acc &= (1 << self.n) - 1
+
+    def unary(self, q):
+        while q >= 32:
+            self.write(0, 32)
+            q -= 32
+        self.write(1, q + 1)
+
+    def align(self):
+        if self.n:
+            self.write(0, 8 - self.n)
+
+
+def _crc(data, poly, width):
+    top, mask, c = 1 << (width - 1), (1 << width) - 1, 0
+    for b in data:
+        c ^= b << (width - 8)
+        for _ in range(8):
+            c = ((c << 1) ^ poly) & mask if c & top else (c << 1) & mask
+    return c
+
+
+def _flac_residual(bw, res, blocksize, order, porder, five_bit, escape):
+    bw.write(1 if five_bit else 0, 2)
+    bw.write(porder, 4)
+    pbits = 5 if five_bit else 4
+    pos = 0
+    for part in range(1 << porder):
+        count = blocksize - order if porder == 0 else (blocksize >> porder) - (order if part == 0 else 0)
+        chunk = res[pos:pos + count]
+        pos += count
+        if escape and part % 2 == 1:
+            nb = max([1] + [int(v).bit_length() + 1 for v in chunk])
+            bw.write((1 << pbits) - 1, pbits)
+            bw.write(nb, 5)
+            for v in chunk:
+                bw.write(int(v), nb)
+            continue
+        mean = sum(abs(int(v)) for v in chunk)/max(len(chunk), 1)
+        k = min(max(int(mean).bit_length(), 0), (1 << pbits) - 2)
+        bw.write(k, pbits)
+        for v in chunk:
+            v = int(v)
+            u = (v << 1) if v >= 0 else ((-v << 1) - 1)
+            bw.unary(u >> k)
+            bw.write(u & ((1 << k) - 1), k)
+
+
+def _flac_subframe(bw, x, bps, kind, order, porder, five_bit, escape):
+    x = [int(v) for v in x]
+    n = len(x)
+    wasted = 0
+    if kind != 'constant' and any(x):
+        while all(v % (1 << (wasted + 1)) == 0 for v in x) and wasted < bps - 1:
+            wasted += 1
+    if wasted:
+        x = [v >> wasted for v in x]
+        bps -= wasted
+    if kind == 'constant':
+        assert len(set(x)) == 1
+        bw.write(0, 8)
+        bw.write(x[0], bps)
+        return
+    type_bits = {'verbatim': 1, 'fixed': 8 + order, 'lpc': 31 + order}[kind]
+    bw.write(0, 1); bw.write(type_bits, 6); bw.write(1 if wasted else 0, 1)
+    if wasted:
+        bw.unary(wasted - 1)
+    if kind == 'verbatim':
+        for v in x:
+            bw.write(v, bps)
+        return
+    for v in x[:order]:
+        bw.write(v, bps)
+    if kind == 'fixed':
+        coef = [[], [1], [2, -1], [3, -3, 1], [4, -6, 4, -1]][order]
+        shift = 0
+    else:
+        import numpy as np
+        a = np.asarray(x, dtype=float)
+        # least-squares predictor, quantised to 12 bits
+        rows = np.stack([a[order - 1 - j:n - 1 - j] for j in range(order)], axis=1)
+        sol = np.linalg.lstsq(rows, a[order:], rcond=None)[0] if n > 2*order else np.zeros(order)
+        precision, shift = 12, 9
+        coef = [int(max(-2048, min(2047, round(c*(1 << shift))))) for c in sol]
+        bw.write(precision - 1, 4)
+        bw.write(shift, 5)
+        for c in coef:
+            bw.write(c, precision)
+    res = []
+    for i in range(order, n):
+        pred = sum(c*x[i - 1 - j] for j, c in enumerate(coef)) >> shift
+        res.append(x[i] - pred)
+    _flac_residual(bw, res, n, order, porder, five_bit, escape)
+
+
+def flac_encode(pcm, rate=16000, bps=16, blocksize=1024, kind='fixed', order=2, stereo='independent',
+                porder=2, five_bit=False, escape=False):
+    """``pcm``: int array (frames, channels). Returns the bytes of a FLAC stream."""
+    import numpy as np
+    pcm = np.asarray(pcm, dtype=np.int64)
+    if pcm.ndim == 1:
+        pcm = pcm[:, None]
+    frames, C = pcm.shape
+    out = bytearray(b'fLaC')
+    info = _BitWriter()
+    info.write(blocksize, 16); info.write(blocksize, 16); info.write(0, 24); info.write(0, 24)
+    info.write(rate, 20); info.write(C - 1, 3); info.write(bps - 1, 5); info.write(frames, 36)
+    info.write(0, 128)
+    out += bytes([0x80, 0, 0, 34]) + bytes(info.out)
+    ch_code = {'independent': C - 1, 'left_side': 8, 'side_right': 9, 'mid_side': 10}[stereo]
+    for fno, start in enumerate(range(0, frames, blocksize)):
+        block = pcm[start:start + blocksize]
+        n = len(block)
+        bw = _BitWriter()
+        bw.write(0xfff8 >> 2, 14); bw.write(0, 1); bw.write(0, 1)
+        bw.write(7, 4)                                   # 16-bit (blocksize - 1) follows
+        bw.write(0, 4)                                   # sample rate from STREAMINFO
+        bw.write(ch_code, 4)
+        bw.write({8: 1, 12: 2, 16: 4, 20: 5, 24: 6}[bps], 3); bw.write(0, 1)
+        assert fno < 0x800
+        if fno < 0x80:
+            bw.write(fno, 8)
+        else:
+            bw.write(0xc0 | (fno >> 6), 8); bw.write(0x80 | (fno & 0x3f), 8)
+        bw.write(n - 1, 16)
+        bw.write(_crc(bytes(bw.out), 0x07, 8), 8)
+        chans = [block[:, c] for c in range(C)]
+        widths = [bps]*C
+        if stereo != 'independent':
+            left, right = chans
+            side = left - right
+            if stereo == 'left_side':
+                chans, widths = [left, side], [bps, bps + 1]
+            elif stereo == 'side_right':
+                chans, widths = [side, right], [bps + 1, bps]
+            else:
+                chans, widths = [(left + right) >> 1, side], [bps, bps + 1]
+        po = porder
+        while po > 0 and (n % (1 << po) or (n >> po) <= order):
+            po -= 1
+        for x, w in zip(chans, widths):
+            k = kind
+            if k != 'verbatim' and len(set(int(v) for v in x)) == 1:
+                k = 'constant'
+            elif k in ('fixed', 'lpc') and n <= order:
+                k = 'verbatim'
+            _flac_subframe(bw, x, w, k, order, po, five_bit, escape)
+        bw.align()
+        bw.write(_crc(bytes(bw.out), 0x8005, 16), 16)
+        out += bytes(bw.out)
+    return bytes(out)

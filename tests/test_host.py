@@ -273,7 +273,7 @@ def test_brever_dataset_reads_wav_datasets(tmp_path, tar):
     assert batch.shape[1] == 2 and batch.shape[0] == len(lens)
     with pytest.raises(ValueError):
         BreverDataset(root, tar=tar, segment_strategy='nope', segment_length=1.0)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError, match='set_mixture_maker'):
         BreverDataset(root, tar=tar, dynamic_mixing=True)
 
 
@@ -380,3 +380,121 @@ def test_gradient_buckets_tile_the_flat_gradient(causal):
             if not causal and nparts > 1:
                 assert buckets[0][0] + buckets[0][1] == n     # part 0: the tail of the buffer
                 assert buckets[-1][0] == 0
+
+
+def _flac_decode(data):
+    import io
+    from brever_amd.data import audio_info, audio_read
+    frames, rate = audio_info(io.BytesIO(data), 'x.flac')
+    x, rate2 = audio_read(io.BytesIO(data), 'x.flac')
+    assert rate == rate2 and frames == len(x)
+    return x, rate
+
+
+def test_flac_decoder_known_stream():
+    """A 57-byte single-frame stream in the layout of RFC 9639's first appendix example (44.1 kHz
+    stereo, block size 1 through the 8-bit escape, verbatim subframes with 2 and 4 wasted bits):
+    header CRC-8 and frame CRC-16 verify and the two samples decode to 0x63f4 and 0x28b0."""
+    data = bytes.fromhex('664c614380000022100010000000' '0f00000f0ac442f000000001'
+                         '3e84b41807dc6903075' '86a3dad1a2e0f' 'fff869180000bf' '0358fd03128b' 'aa9a')
+    x, rate = _flac_decode(data)
+    assert rate == 44100 and x.shape == (1, 2)
+    assert (x*32768).tolist() == [[25588.0, 10416.0]]
+    bad = bytearray(data); bad[-3] ^= 1                       # payload bit flip -> CRC-16 mismatch
+    with pytest.raises(ValueError):
+        _flac_decode(bytes(bad))
+
+
+@pytest.mark.parametrize('kw', [
+    dict(kind='fixed', order=0), dict(kind='fixed', order=1, stereo='left_side'),
+    dict(kind='fixed', order=2, stereo='mid_side', porder=3),
+    dict(kind='fixed', order=3, stereo='side_right', five_bit=True),
+    dict(kind='fixed', order=4, escape=True), dict(kind='lpc', order=8, stereo='mid_side'),
+    dict(kind='lpc', order=12, blocksize=4096, porder=4), dict(kind='verbatim'),
+    dict(kind='fixed', order=2, bps=24, porder=0), dict(kind='lpc', order=4, bps=8),
+])
+def test_flac_decoder_round_trips(kw):
+    """Lossless: streams written by the test suite's encoder (tests/helpers.py) decode to the
+    original PCM bit for bit -- every subframe type, predictor order, stereo decorrelation, Rice
+    parameter width, escape partitions, wasted bits, a short last block, mono and stereo."""
+    from helpers import flac_encode
+    rng = np.random.default_rng(5)
+    bps = kw.get('bps', 16)
+    n = 5000
+    t = np.arange(n)
+    amp = 2**(bps - 3)
+    left = amp*np.sin(2*np.pi*220*t/16000)*(0.6 + 0.4*np.sin(2*np.pi*3*t/16000)) + rng.normal(0, amp/200, n)
+    right = 0.8*left + amp/8*np.sin(2*np.pi*950*t/16000) + rng.normal(0, amp/300, n)
+    for channels in (1, 2):
+        if channels == 1 and kw.get('stereo', 'independent') != 'independent':
+            continue
+        pcm = np.stack([left, right], axis=1)[:, :channels].round().astype(np.int64)
+        pcm[100:400] = 0                                     # a constant stretch
+        pcm[1024:2048] = (pcm[1024:2048] >> 3) << 3          # wasted bits in one block
+        data = flac_encode(pcm, **dict(kw, bps=bps))
+        x, rate = _flac_decode(data)
+        assert rate == 16000
+        got = np.asarray(x).reshape(n, channels)
+        assert np.array_equal(np.round(got.astype(np.float64)*2**(bps - 1)).astype(np.int64), pcm)
+    assert len(data) < pcm.size*bps//8 or kw['kind'] == 'verbatim'    # it does compress
+
+
+def test_dataset_reads_flac_members(tmp_path):
+    """BreverDataset on the reference layout with FLAC members in audio.tar (data.py:259-268)."""
+    import tarfile
+    from helpers import flac_encode
+    from brever_amd.data import BreverDataset
+    rng = np.random.default_rng(0)
+    root = tmp_path/'dset'
+    os.makedirs(root/'audio')
+    want = {}
+    for i, n in enumerate((3000, 4100)):
+        for src in ('mixture', 'foreground'):
+            pcm = rng.integers(-2000, 2000, (n, 2)).cumsum(axis=0).clip(-30000, 30000)
+            (root/'audio'/f'{i:05d}_{src}.flac').write_bytes(
+                flac_encode(pcm, stereo='mid_side', kind='fixed', order=2))
+            want[(i, src)] = pcm
+    with tarfile.open(root/'audio.tar', 'w') as tar:
+        tar.add(root/'audio', arcname='audio')
+    for tar_flag in (True, False):
+        dset = BreverDataset(str(root), tar=tar_flag)
+        assert len(dset) == 2 and dset.get_segment_length(1) == 4100
+        item = dset[1]
+        assert item.shape == (2, 2, 4100)
+        assert np.array_equal(np.round(item[0].numpy().T*32768).astype(np.int64), want[(1, 'mixture')])
+
+
+def test_dynamic_mixing_through_an_installed_mixture_maker(tmp_path):
+    """dynamic_mixing=True (brever/data.py:98-104,155-158,236-241,323-326) with a mixture maker in
+    the RandomMixtureMakerDataset protocol: lengths and items come from the maker, every epoch
+    redraws them, samplers regenerate their batches, segmentation still applies, preload refuses."""
+    from brever_amd import data
+    from brever_amd.batching import BatchSamplerRegistry
+    data.set_mixture_maker(data.SyntheticMixtureMaker)
+    try:
+        dset = data.BreverDataset(str(tmp_path), dynamic_mixing=True, dynamic_mixtures_per_epoch=12,
+                                  transform=lambda s: s.mean(axis=-2))
+        assert len(dset) == 12 and dset.archive is None
+        lengths0 = [dset.get_segment_length(i) for i in range(12)]
+        item = dset[3]
+        assert item.shape == (2, lengths0[3]) and item.dtype == torch.float32
+        assert torch.equal(dset[3], item)                       # deterministic within an epoch
+        sampler = BatchSamplerRegistry.get('bucket')(dset, 8.0, dynamic=True, fs=16000)
+        loader = data.BreverDataLoader(dset, batch_sampler=sampler)
+        loader.set_epoch(0)
+        first = [tuple(b) for b in sampler]
+        loader.set_epoch(1)
+        lengths1 = [dset.get_segment_length(i) for i in range(12)]
+        assert lengths1 != lengths0 and not torch.equal(dset[3][..., :100], item[..., :100])
+        assert [tuple(b) for b in sampler] != first
+        loader.set_epoch(2)
+        batch, lens = next(iter(loader))
+        assert batch.shape[-1] == int(lens.max()) and batch.shape[1] == 2
+        with pytest.raises(ValueError, match='dynamic mixing'):
+            dset.preload('cpu')
+        seg = data.BreverDataset(str(tmp_path), dynamic_mixing=True, dynamic_mixtures_per_epoch=4,
+                                 segment_length=0.5, segment_strategy='drop')
+        assert all(seg.get_segment_length(i) == 8000 for i in range(len(seg)))
+        assert seg[0].shape == (2, 2, 8000)
+    finally:
+        data.set_mixture_maker(None)
