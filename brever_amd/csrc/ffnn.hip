@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float* x, c
     dx[i] = mask ? g*mask[i]*scale : g;
   }
 }
+// y = x*mask*scale: nn.Dropout with a caller-drawn keep mask (forward, and backward on dy)
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* x, const float* mask,
+                                                            float* out, long long n, float scale) {
+  GRID_STRIDE(i, n) out[i] = x[i]*mask[i]*scale;
+}
 __global__ __launch_bounds__(256) void sigmoid_fwd_kernel(const float* x, float* out, long long n) {
   GRID_STRIDE(i, n) out[i] = 1.f/(1.f + expf(-x[i]));
 }
@@ -313,6 +318,14 @@ int brv_relu_dropout_backward(const float* x, const float* mask, const float* dy
   if (n < 1) return -1;
   hipLaunchKernelGGL(relu_dropout_bwd_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, x,
                      mask, dy, dx, (long long)n, scale);
+  FF_OK(hipGetLastError());
+  return 0;
+}
+int brv_dropout_apply(const float* x, const float* mask, float* out, int64_t n, float scale,
+                      brv_stream_t stream) {
+  if (n < 1 || !mask) return -1;
+  hipLaunchKernelGGL(dropout_apply_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, x, mask,
+                     out, (long long)n, scale);
   FF_OK(hipGetLastError());
   return 0;
 }

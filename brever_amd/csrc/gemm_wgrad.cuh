@@ -80,8 +80,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int ld, int row0,
 template <int BH, int HK>
 __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradGroupParams gp) {
   WgradParams p = gp.base;
+  // XCD-aware order: the tiles of one (frame split, problem) pair all stream the same H rows
+  // (and, for several H tiles, the same G rows). Dispatch ids congruent mod 8 share an XCD and
+  // its L2: with the tile index fastest in the plain grid order the 4 G tiles of the first 1x1
+  // convolution's weight gradient landed on 4 different XCDs and each fetched H from HBM
+  // (PMC: 1.6x the algorithmic bytes). Here the tiles of a pair take consecutive slots of ONE XCD.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int tiles = gridDim.x, pairs = gridDim.y*gridDim.z;
+    if ((pairs & 7) == 0) {
+      const int L = bx + tiles*(by + (int)gridDim.y*bz);
+      const int xcd = L & 7, slot = L >> 3;
+      const int pair = (slot / tiles)*8 + xcd;
+      bx = slot % tiles; by = pair % (int)gridDim.y; bz = pair / (int)gridDim.y;
+    }
+  }
   if (gp.nprob > 0) {
-    const WgradProb& q = gp.prob[blockIdx.z];
+    const WgradProb& q = gp.prob[bz];
     p.g.p0 = q.g0; p.g.p1 = q.g1; p.h.p0 = q.h;
     p.out0 = q.out0; p.out1 = q.out1; p.gbias0 = q.gbias0; p.gbias1 = q.gbias1;
     p.h.slope = q.slope; p.h.stats = q.stats; p.h.gamma = q.gamma; p.h.beta = q.beta;
@@ -96,13 +111,13 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradGroupParams 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n_htiles = p.Hp/BH;
-  const int gtile = blockIdx.x / n_htiles, htile = blockIdx.x % n_htiles;
+  const int gtile = bx / n_htiles, htile = bx % n_htiles;
   const int n0 = gtile*WG_BG, k0 = htile*BH;
   const int T = p.T;
   const int cpi = ceil_div(T, WG_BT);
   const int total = p.B*cpi;
   const int per = ceil_div(total, p.nsplit);
-  const int c_begin = blockIdx.y*per;
+  const int c_begin = by*per;
   const int c_end = min(total, c_begin + per);
 
   // staging geometry: fixed channel chunk per thread

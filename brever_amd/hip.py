@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libbrever_hip.so')
+# BRV_LIB_PATH: load another build of the same library (tools/: diagnostic builds)
+LIB_PATH = os.environ.get('BRV_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libbrever_hip.so')
 
 _c_i64 = ctypes.c_int64
 _c_f32 = ctypes.c_float
@@ -137,6 +138,7 @@ SIGNATURES = {
     'brv_relu_dropout_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr]),
     'brv_relu_dropout_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32,
                                                  _c_ptr]),
+    'brv_dropout_apply': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_f32, _c_ptr]),
     'brv_sigmoid_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr]),
     'brv_sigmoid_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
     'brv_row_sum': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),

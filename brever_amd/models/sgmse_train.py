@@ -322,6 +322,31 @@ def attention(blk, x, out_scale):
     return AxpbyFn.apply(x, out_scale, conv(a, blk.conv_out), out_scale)
 
 
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout (UNetBlock.dropout, net.py:409): the keep mask is drawn on the device
+    generator, mask and 1/keep are applied by ``brv_dropout_apply`` in both directions."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        keep = 1.0 - p
+        mask = torch.empty_like(x).bernoulli_(keep)
+        out = torch.empty_like(x)
+        hip.check(hip.lib().brv_dropout_apply(hip.ptr(x.contiguous()), hip.ptr(mask), hip.ptr(out),
+                                              x.numel(), 1.0/keep, hip.stream()), 'brv_dropout_apply')
+        ctx.save_for_backward(mask)
+        ctx.scale = 1.0/keep
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        mask, = ctx.saved_tensors
+        dx = torch.empty_like(mask)
+        hip.check(hip.lib().brv_dropout_apply(hip.ptr(dy.contiguous()), hip.ptr(mask), hip.ptr(dx),
+                                              mask.numel(), ctx.scale, hip.stream()),
+                  'brv_dropout_apply')
+        return dx, None
+
+
 def unet_block(blk, x, emb):
     h = group_norm(x, blk.norm_1, silu=True)
     if blk.resampler is not None:
@@ -337,8 +362,8 @@ def unet_block(blk, x, emb):
                               sh, True)
     else:
         h = group_norm(h, blk.norm_2, add=e, silu=True)
-    if blk.dropout.p > 0:
-        h = torch.nn.functional.dropout(h, blk.dropout.p, training=blk.training)
+    if blk.dropout.p > 0 and blk.training:
+        h = DropoutFn.apply(h, blk.dropout.p)
     h = conv(h, blk.conv_2)
     if blk.skip_conv is not None:
         x = conv(x, blk.skip_conv)

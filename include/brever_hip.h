@@ -300,6 +300,10 @@ int brv_relu_dropout_forward(const float* x, const float* mask, float* out, int6
                              brv_stream_t stream);
 int brv_relu_dropout_backward(const float* x, const float* mask, const float* dy, float* dx,
                               int64_t n, float scale, brv_stream_t stream);
+/* nn.Dropout with a caller-drawn keep mask (UNetBlock.dropout, sgmse/net.py:409; forward on x,
+ * backward on dy): out = x*mask*scale. */
+int brv_dropout_apply(const float* x, const float* mask, float* out, int64_t n, float scale,
+                      brv_stream_t stream);
 int brv_sigmoid_forward(const float* x, float* out, int64_t n, brv_stream_t stream);
 int brv_sigmoid_backward(const float* y, const float* dy, float* dx, int64_t n, brv_stream_t stream);
 int brv_row_sum(const float* x, float* out, int64_t B, int64_t M, int64_t T, brv_stream_t stream);

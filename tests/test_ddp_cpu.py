@@ -20,6 +20,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn(worker, world, tmp):
+    """mp.spawn with a fresh rendezvous port; one retry (a probed free port can be taken by
+    another process between the probe and the bind)."""
+    for attempt in range(2):
+        try:
+            mp.spawn(worker, args=(world, _free_port(), tmp), nprocs=world, join=True)
+            return
+        except Exception:
+            if attempt == 1:
+                raise
+
+
 def _init(rank, world, port):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -52,9 +64,9 @@ def _worker_generic(rank, world, port, out_dir):
 
 
 def test_gradient_allreduce_equals_union_batch():
-    world, port = 2, _free_port()
+    world = 2
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker_generic, args=(world, port, tmp), nprocs=world, join=True)
+        _spawn(_worker_generic, world, tmp)
         p0 = torch.load(os.path.join(tmp, 'params0.pt'))
         p1 = torch.load(os.path.join(tmp, 'params1.pt'))
     # single process, union batch, same initial weights as rank 0
@@ -133,9 +145,9 @@ def _worker_flat(rank, world, port, out_dir):
 def test_flat_gradient_hook_sums_and_scales():
     """Single-bucket and bucketed (overlapped) all-reduce of a flat gradient: the mean over
     ranks, identical bit for bit whatever the number of buckets, identical on both ranks."""
-    world, port = 2, _free_port()
+    world = 2
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker_flat, args=(world, port, tmp), nprocs=world, join=True)
+        _spawn(_worker_flat, world, tmp)
         assert torch.equal(torch.load(os.path.join(tmp, 'mean0.pt')),
                            torch.load(os.path.join(tmp, 'mean1.pt')))
 
@@ -163,9 +175,9 @@ def _worker_trainer(rank, world, port, out_dir):
 
 
 def test_trainer_two_ranks():
-    world, port = 2, _free_port()
+    world = 2
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker_trainer, args=(world, port, tmp), nprocs=world, join=True)
+        _spawn(_worker_trainer, world, tmp)
         p0 = torch.load(os.path.join(tmp, 'params0.pt'))
         p1 = torch.load(os.path.join(tmp, 'params1.pt'))
     for a, b in zip(p0, p1):

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round profile of the headline benchmark on the GPU box (run through gpurun from the repo root):
+#   kernel statistics (rocprofv3 --kernel-trace --stats), the bench JSON line of that run, the
+#   per-label HIP-event table, and HBM traffic per kernel from two PMC passes (FETCH_SIZE,
+#   WRITE_SIZE: separate runs, --pmc never combined with other trace domains).
+# usage: bash tools/profile_round.sh r02
+set -u
+TAG=${1:-r02}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-through-trainer"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o main -- python3 $REPO/bench.py $ARGS --kernel-table > $OUT/${TAG}_rocprofv3_bench_line.json 2> $OUT/${TAG}_kernel_table.txt
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv
+PMCARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-through-trainer"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
+python3 $REPO/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $OUT/${TAG}_pmc_hbm_traffic.json
+grep -v "^/opt" $OUT/${TAG}_kernel_table.txt | head -30
