@@ -375,8 +375,10 @@ template <int P> struct DwBwd {
   static int run(const DwParams& p, hipStream_t st) {
     if (p.z2in != nullptr) {      // gLN_2 backward fused: dz2 built once per element in LDS
       ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 8.0*p.B*p.T*(double)p.Cp, st);
-      dim3 grid(ceil_div(p.T, HL_TT)*p.B*(p.Cp/HL_CG));
-      const size_t lds = (size_t)(HL_TT + (P - 1)*p.dil)*HL_CG*2;
+      const int R = hl_rows_per_tooth(p.dil), K = HL_TT/R;
+      const int tiles = ceil_div(p.dil, R)*ceil_div((p.T - 1)/p.dil + 1, K);
+      dim3 grid(tiles*p.B*(p.Cp/HL_CG));
+      const size_t lds = (size_t)hl_window_rows(p.dil, P)*HL_CG*2;
       hipLaunchKernelGGL((dwconv_bwd_halo_kernel<P>), grid, dim3(256), lds, st, p);
       HIP_OK(hipGetLastError());
       return 0;
@@ -1330,7 +1332,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
     // (tile + halo rows) fits -- dz2 is then built once per element in LDS and never written
     // (dwconv_bwd_halo_kernel). BRV_NO_DZ_FUSE keeps the separate pass.
     const bool fuse_dz2 = !getenv("BRV_NO_DZ_FUSE") && l.Hp % HL_CG == 0 &&
-                          HL_TT + (l.P - 1)*dil <= HL_MAXROWS;
+                          (((l.P - 1)*dil)/2) % dil == 0 && hl_window_rows(dil, l.P) <= HL_MAXROWS;
     DzParams dz; memset(&dz, 0, sizeof(dz));
     if (!fuse_dz2) {
       dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;

@@ -385,37 +385,56 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const DwParams p) {
 // ---------------------------------------------------------------------------
 // Depthwise-conv backward with the gLN_2 / PReLU_2 backward folded in, each dz2 element
 // computed ONCE: a workgroup owns (item, HL_TT frames, HL_CG channels), first builds
-// dz2 = prelu2'(z2)*rstd2*(e2 - m1 - xh2*m2) for its frames plus the (P-1)*dil halo the taps
-// reach into LDS (bf16), then runs the transposed stencil out of LDS. The dz2 tensor never
-// exists in HBM: the separate gln_prelu_bwd pass (read e2, z2; write dz2) and this kernel's
-// re-read of dz2 become one read of e2 and z2 with a halo overhead of (P-1)*dil/HL_TT
-// (25 % averaged over the dilations 1..128). Replaces dz_kernel + dwconv_bwd_kernel for
-// gLN_2; outputs and parameter gradients are the same.
+// dz2 = prelu2'(z2)*rstd2*(e2 - m1 - xh2*m2) for its frames plus the halo the taps reach into
+// LDS (bf16), then runs the transposed stencil out of LDS. The dz2 tensor never exists in HBM:
+// the separate gln_prelu_bwd pass (read e2, z2; write dz2) and this kernel's re-read of dz2
+// become one read of e2 and z2 with a halo overhead of (P-1)*R/HL_TT <= 6 % (comb tiles, below).
+// Replaces dz_kernel + dwconv_bwd_kernel for gLN_2; outputs and parameter gradients are the same.
 constexpr int HL_TT = 256;                 // frames per workgroup
 constexpr int HL_CG = 64;                  // channels per workgroup (128-byte rows)
-constexpr int HL_MAXROWS = 512;            // LDS window: HL_TT + (P-1)*dil rows of 128 B
+constexpr int HL_RMAX = 8;                 // consecutive frames per comb tooth
+// Tile shape. The stencil only couples frames that are `dil` apart, so a tile is a COMB:
+// R consecutive frames (residues r0 .. r0+R-1 modulo dil) x K teeth dil apart, R*K = HL_TT; its
+// window adds P-1 teeth, i.e. (P-1)*R halo rows whatever the dilation. (A contiguous 256-frame
+// tile needs (P-1)*dil halo rows: 2x the tile at dilation 128, which doubled phase 1 and cut the
+// residency to 2 workgroups per CU for the widest layers.) Rows of 64 channels are separate
+// 128-byte segments in HBM anyway, so non-contiguous frames cost nothing. For dil <= HL_RMAX the
+// comb IS the contiguous tile. Needs left % dil == 0 (odd kernel sizes, or causal padding).
+__host__ __device__ inline int hl_rows_per_tooth(int dil) {
+  int r = 1;
+  while (2*r <= dil && 2*r <= HL_RMAX) r *= 2;
+  return r;
+}
+__host__ __device__ inline int hl_window_rows(int dil, int P) {
+  const int R = hl_rows_per_tooth(dil);
+  return (HL_TT/R + P - 1)*R;
+}
+constexpr int HL_MAXROWS = HL_TT + 4*HL_RMAX;   // window rows for kernel sizes up to 5
 
 template <int P>
 __global__ __launch_bounds__(256) void dwconv_bwd_halo_kernel(const DwParams p) {
-  // window of (HL_TT + halo) rows x 128 B, sized at launch: small dilations leave room for
-  // a third workgroup per CU
+  // window of (K + P - 1) teeth x R rows x 128 B
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   bf16_t* win = reinterpret_cast<bf16_t*>(dyn_lds);
   __shared__ float red[32*HL_CG];
   __shared__ double dscr[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int T = p.T;
-  const int n_tt = ceil_div(T, HL_TT), n_cg = p.Cp/HL_CG;
+  const int T = p.T, d = p.dil;
+  const int R = hl_rows_per_tooth(d), K = HL_TT/R;
+  const int n_rt = ceil_div(d, R);                       // residue groups
+  const int n_teeth = (T - 1)/d + 1;
+  const int n_qt = ceil_div(n_teeth, K);                 // tooth groups
+  const int n_tt = n_rt*n_qt, n_cg = p.Cp/HL_CG;
   int id = blockIdx.x;
   const int cg = id % n_cg; id /= n_cg;
   const int b = id / n_tt;
-  const int t0 = (id % n_tt)*HL_TT;
+  const int tile = id % n_tt;
+  const int r0 = (tile % n_rt)*R, q0 = (tile / n_rt)*K;
   const int cl = (tid & 7)*8;                          // channel offset inside the group
   const int c0 = cg*HL_CG + cl;
   const int rslot = tid >> 3;                          // 32 row slots per pass
-  const int halo = (P - 1)*p.dil;
-  const int W = HL_TT + halo;                          // rows of the window
-  const int ws = t0 - halo + p.left;                   // frame of window row 0
+  const int W = (K + P - 1)*R;                         // rows of the window
+  const int qbase = q0 - (P - 1) + p.left/d;           // tooth of window row 0
 
   // ---- phase 1: dz2 of the window -> LDS ------------------------------------------------
   const NormStat n2 = norm_stat(p.stats2, b, p.inv_n, p.eps);
@@ -431,26 +450,38 @@ __global__ __launch_bounds__(256) void dwconv_bwd_halo_kernel(const DwParams p) 
   f32x2 dbia[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) dbia[j] = f32x2{0.f, 0.f};
+  // window row r -> frame: tooth qbase + r / R, residue r0 + r % R
+  auto frame_of = [&](int r, bool& ok) {
+    const int qi = r / R, ri = r % R;
+    const int q = qbase + qi;
+    ok = r < W && q >= 0 && r0 + ri < d;
+    return q*d + r0 + ri;
+  };
   // four rows per thread in flight (8 loads) before any of them is consumed
-  for (int r0 = rslot; r0 < W; r0 += 128) {
+  for (int rw = rslot; rw < W; rw += 128) {
     uint4 qe[4], qz[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int r = r0 + 32*u, tf = ws + r;
-      const bool in = r < W && tf >= 0 && tf < T;
+      bool ok;
+      const int tf = frame_of(rw + 32*u, ok);
+      const bool in = ok && tf < T;
       const unsigned int off = in ? (unsigned int)tf*row + coff : kOob;
       qe[u] = buf_load16(re2, off); qz[u] = buf_load16(rz2, off);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int r = r0 + 32*u, tf = ws + r;
+      const int r = rw + 32*u;
       if (r >= W) break;
-      const bool in = tf >= 0 && tf < T;
+      bool ok;
+      const int tf = frame_of(r, ok);
+      const bool in = ok && tf < T;
       float e[8], z[8], g[8];
       unpack8(qe[u], e); unpack8(qz[u], z);
       const float on = in ? 1.f : 0.f;
       const float rr = on*R2, k0 = on*K0, mm = on*M2R;
-      const bool centre = tf >= t0 && tf < t0 + HL_TT;   // each element is "owned" by one tile
+      // each element is "owned" by the tile whose teeth [q0, q0 + K) contain it
+      const int q = qbase + r / R;
+      const bool centre = in && q >= q0 && q < q0 + K;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xh2 = __builtin_fmaf(yb, __builtin_fabsf(z[j]), __builtin_fmaf(ya, z[j], yc));
@@ -459,10 +490,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_halo_kernel(const DwParams p) 
         g[j] = c0 + j < p.C ? (pos ? uu : a2*uu) : 0.f;
         if (centre && !pos) da2 += uu*z[j];
       }
-      const uint4 q = pack8(g);
-      *reinterpret_cast<uint4*>(win + r*HL_CG + cl) = q;
+      const uint4 q4 = pack8(g);
+      *reinterpret_cast<uint4*>(win + r*HL_CG + cl) = q4;
       if (centre) {                                      // bias gradient = sum of (rounded) dz2
-        float gr[8]; unpack8(q, gr);
+        float gr[8]; unpack8(q4, gr);
 #pragma unroll
         for (int j = 0; j < 4; ++j) dbia[j] += f32x2{gr[2*j], gr[2*j + 1]};
       }
@@ -500,17 +531,27 @@ __global__ __launch_bounds__(256) void dwconv_bwd_halo_kernel(const DwParams p) 
   const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(p.z1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
   const __amdgpu_buffer_rsrc_t re1 = make_rsrc(p.e1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
   float l1 = 0.f, l2 = 0.f;
+  // output row i -> frame: tooth q0 + i / R, residue r0 + i % R
+  auto out_frame = [&](int i, bool& ok) {
+    const int ro = r0 + i % R;
+    ok = ro < d;
+    return (q0 + i / R)*d + ro;
+  };
   for (int i0 = rslot; i0 < HL_TT; i0 += 128) {
    uint4 qz4[4];
 #pragma unroll
-   for (int u = 0; u < 4; ++u)
-     qz4[u] = buf_load16(rz1, (unsigned int)(t0 + i0 + 32*u)*row + coff);   // t >= T: zeros
+   for (int u = 0; u < 4; ++u) {
+     bool ok;
+     const int t = out_frame(i0 + 32*u, ok);
+     qz4[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);   // outside: zeros
+   }
 #pragma unroll
    for (int u = 0; u < 4; ++u) {
     const int i = i0 + 32*u;
-    const int t = t0 + i;
+    bool ok;
+    const int t = out_frame(i, ok);
     const uint4 qz = qz4[u];
-    const float live = t < T ? 1.f : 0.f;
+    const float live = (ok && t < T) ? 1.f : 0.f;
     float zc[8];
     unpack8(qz, zc);
     f32x2 xh[4], hn[4], dh[4];
@@ -523,8 +564,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_halo_kernel(const DwParams p) 
     }
 #pragma unroll
     for (int k = 0; k < P; ++k) {
-      // output frame that reads frame t through tap k: t - (k*dil - left) = window row
-      const int r = i + halo - k*p.dil;
+      // output frame that reads frame t through tap k: tooth + left/dil - k = window tooth
+      // (i / R) + P - 1 - k, same residue
+      const int r = (i / R + P - 1 - k)*R + i % R;
       float g[8];
       unpack8(*reinterpret_cast<const uint4*>(win + r*HL_CG + cl), g);
 #pragma unroll
@@ -544,7 +586,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_halo_kernel(const DwParams p) 
       dgam[j] += dl*xh[j]; dbet[j] += dl;
     }
     l1 += a1s.x + a1s.y; l2 += a2s.x + a2s.y;
-    buf_store16(re1, (unsigned int)t*row + coff, pack8v(o));            // t >= T: dropped
+    buf_store16(re1, live != 0.f ? (unsigned int)t*row + coff : kOob, pack8v(o));   // outside: dropped
    }
   }
 
@@ -570,11 +612,11 @@ __global__ __launch_bounds__(256) void dwconv_bwd_halo_kernel(const DwParams p) 
   reduce_cols(dbia, p.dbias, 1, 0);
 #pragma unroll
   for (int k = 0; k < P; ++k) reduce_cols(dtap[k], p.dtaps, P, k);
-  const double r0 = block_sum((double)l1, dscr);
-  const double r1 = block_sum((double)l2, dscr + 8);
+  const double tot1 = block_sum((double)l1, dscr);
+  const double tot2 = block_sum((double)l2, dscr + 8);
   if (tid == 0) {
-    atomic_add_f64(p.sums1 + stat_sum(b), r0);
-    atomic_add_f64(p.sums1 + stat_sq(b), r1);
+    atomic_add_f64(p.sums1 + stat_sum(b), tot1);
+    atomic_add_f64(p.sums1 + stat_sq(b), tot2);
   }
   __syncthreads();
   const float sa = block_sum(da2, red);
