@@ -89,7 +89,7 @@ struct Lay32 {
   }
 };
 
-constexpr int kSliceRows = 64;          // rows per workgroup of the per-channel reductions
+constexpr int kSliceRows = 256;         // rows per workgroup of the per-channel reductions
 
 // workspace offsets in floats
 struct Ws32 {
@@ -218,6 +218,29 @@ __global__ void f32_norm_apply_kernel(const float* z, const float* slope, const 
   }
 }
 
+// the same, 4 channels per thread (C % 4 == 0): 16-byte loads and stores
+__device__ __forceinline__ float4 ld4(const float* p, int c4) {      // 4 floats, any alignment
+  return make_float4(p[4*c4], p[4*c4 + 1], p[4*c4 + 2], p[4*c4 + 3]);
+}
+__global__ void f32_norm_apply4_kernel(const float4* z, const float* slope, const float* table,
+                                       const float* gain, const float* bias, float4* y,
+                                       long long rows, int C4) {
+  const long long n = rows*C4;
+  const float a = slope ? *slope : 1.f;
+  const bool act = slope != nullptr;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const long long row = i / C4; const int c = (int)(i % C4);
+    const float m = table[2*row], r = table[2*row + 1];
+    const float4 v = z[i], g = ld4(gain, c), b = ld4(bias, c);
+    float4 o;
+    o.x = (((v.x > 0.f || !act) ? v.x : a*v.x) - m)*r*g.x + b.x;
+    o.y = (((v.y > 0.f || !act) ? v.y : a*v.y) - m)*r*g.y + b.y;
+    o.z = (((v.z > 0.f || !act) ? v.z : a*v.z) - m)*r*g.z + b.z;
+    o.w = (((v.w > 0.f || !act) ? v.w : a*v.w) - m)*r*g.w + b.w;
+    y[i] = o;
+  }
+}
+
 // backward frame sums: A_t = sum_c e gain, B_t = sum_c e gain xhat
 __global__ __launch_bounds__(256) void f32_bwd_frame_sums_kernel(const float* e, const float* z,
                                                                  const float* slope, const float* table,
@@ -302,6 +325,35 @@ __global__ __launch_bounds__(256) void f32_norm_bwd_apply_kernel(
   }
 }
 
+// 4 channels per thread (C % 4 == 0)
+__global__ __launch_bounds__(256) void f32_norm_bwd_apply4_kernel(
+    const float4* e, const float4* z, const float* slope, const float* ftab, const float* btab,
+    const float* gain, const float4* add, float4* dz, float* dslope_part, long long rows, int C4) {
+  __shared__ float scr[8];
+  const long long n = rows*C4;
+  const float a = slope ? *slope : 1.f;
+  const bool act = slope != nullptr;
+  float da = 0.f;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const long long row = i / C4; const int c = (int)(i % C4);
+    const float r = ftab[2*row + 1], U = btab[2*row], V = btab[2*row + 1];
+    const float4 v = z[i], ev = e[i], g = ld4(gain, c);
+    float4 o;
+#define BRV_ONE(f)                                                   \
+    { const bool pos = v.f > 0.f || !act; const float p = pos ? v.f : a*v.f;   \
+      const float dp = ev.f*g.f*r + U + p*V; o.f = pos ? dp : a*dp;  \
+      if (!pos) da = __builtin_fmaf(dp, v.f, da); }
+    BRV_ONE(x) BRV_ONE(y) BRV_ONE(z) BRV_ONE(w)
+#undef BRV_ONE
+    if (add) { const float4 ad = add[i]; o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w; }
+    dz[i] = o;
+  }
+  if (dslope_part) {
+    const float sres = block_sum(da, scr);
+    if (threadIdx.x == 0) dslope_part[blockIdx.x] = sres;
+  }
+}
+
 // ---- per-channel reductions: thread = channel, workgroup = slice of kSliceRows rows ----------
 // mode 0: q0 = sum src                                   (bias gradients)
 // mode 1: q0 = sum e xhat, q1 = sum e                    (norm gain / bias gradients)
@@ -311,15 +363,20 @@ struct Red32 {
   long long rows; int C, ld, T, P, dil, left; float* part;
 };
 __global__ __launch_bounds__(256) void f32_chan_reduce_kernel(const Red32 p) {
+  // workgroup = (row slice, 64 channels): 64 columns x 4 row lanes; a lane walks rows lane, lane + 4,
+  // ... of the slice, the 4 lane sums are added in lane order (deterministic)
+  __shared__ float red[4][8][65];
   const long long r0 = (long long)blockIdx.x*kSliceRows;
   const long long r1 = r0 + kSliceRows < p.rows ? r0 + kSliceRows : p.rows;
   const int nq = p.mode == 0 ? 1 : (p.mode == 1 ? 2 : p.P + 1);
   const float sl = p.slope ? *p.slope : 1.f;
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    float q[8];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y*64 + col;
+  float q[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) q[k] = 0.f;
-    for (long long r = r0; r < r1; ++r) {
+  for (int k = 0; k < 8; ++k) q[k] = 0.f;
+  if (c < p.C) {
+    for (long long r = r0 + rl; r < r1; r += 4) {
       const float av = p.a[r*p.ld + c];
       if (p.mode == 0) {
         q[0] += av;
@@ -337,19 +394,37 @@ __global__ __launch_bounds__(256) void f32_chan_reduce_kernel(const Red32 p) {
         q[p.P] += av;
       }
     }
-    for (int k = 0; k < nq; ++k) p.part[((long long)blockIdx.x*nq + k)*p.C + c] = q[k];
   }
+  for (int k = 0; k < nq; ++k) red[rl][k][col] = q[k];
+  __syncthreads();
+  if (rl == 0 && c < p.C)
+    for (int k = 0; k < nq; ++k)
+      p.part[((long long)blockIdx.x*nq + k)*p.C + c] =
+          ((red[0][k][col] + red[1][k][col]) + red[2][k][col]) + red[3][k][col];
 }
-// dst[c*stride + off_k] += sum over slices, in slice order
-__global__ void f32_chan_fold_kernel(const float* part, int slices, int nq, int C, float* d0,
-                                     float* d1, int stride0, int P) {
-  // quantity k of channel c goes to: mode-agnostic mapping given by (d0, stride0) for k < P and d1 for k == P
-  const int i = blockIdx.x*256 + threadIdx.x;
-  if (i >= nq*C) return;
-  const int k = i / C, c = i % C;
+// dst[c*stride + off_k] += sum over slices: 16 columns x 16 slice lanes per workgroup, each lane
+// adds its slices in order, the 16 lane sums are added in lane order (deterministic)
+__global__ __launch_bounds__(256) void f32_chan_fold_kernel(const float* part, int slices, int nq,
+                                                            int C, float* d0, float* d1, int stride0,
+                                                            int P) {
+  // quantity k of channel c goes to (d0, stride0) for k < P and to d1 for k == P
+  __shared__ float acc[16][17];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int i = blockIdx.x*16 + col;
   float s = 0.f;
-  for (int sidx = 0; sidx < slices; ++sidx) s += part[((long long)sidx*nq + k)*C + c];
-  if (k < P) d0[(long long)c*stride0 + k] += s; else d1[c] += s;
+  if (i < nq*C) {
+    const int k = i / C, c = i % C;
+    for (int sidx = sl; sidx < slices; sidx += 16) s += part[((long long)sidx*nq + k)*C + c];
+  }
+  acc[sl][col] = s;
+  __syncthreads();
+  if (sl == 0 && i < nq*C) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += acc[j][col];
+    const int k = i / C, c = i % C;
+    if (k < P) d0[(long long)c*stride0 + k] += t; else d1[c] += t;
+  }
 }
 __global__ void f32_fold_scalar_kernel(const float* part, int n, float* dst) {
   __shared__ float scr[8];
@@ -374,6 +449,27 @@ __global__ void f32_dw_fwd_kernel(const float* h, const float* taps, const float
     z2[i] = acc;
   }
 }
+// 4 channels per thread (C % 4 == 0): `sign` +1 reads h[t + k dil - left] (forward), -1 reads
+// dz2[t - k dil + left] (transposed stencil); bias may be null
+__global__ void f32_dw4_kernel(const float4* src, const float* taps, const float* bias, float4* dst,
+                               long long B, int T, int C4, int P, int dil, int left, int sign) {
+  const long long n = B*T*C4;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const int c = (int)(i % C4); const long long row = i / C4;
+    const int t = (int)(row % T); const long long b = row / T;
+    float4 acc = bias ? ld4(bias, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < P; ++k) {
+      const int ti = t + sign*(k*dil - left);
+      if (ti < 0 || ti >= T) continue;
+      const float4 v = src[(b*T + ti)*C4 + c];
+      const float* w = taps + (long long)4*c*P + k;
+      acc.x = __builtin_fmaf(w[0], v.x, acc.x); acc.y = __builtin_fmaf(w[P], v.y, acc.y);
+      acc.z = __builtin_fmaf(w[2*P], v.z, acc.z); acc.w = __builtin_fmaf(w[3*P], v.w, acc.w);
+    }
+    dst[i] = acc;
+  }
+}
+
 // transposed stencil: e1[t][c] = sum_k w[c][k] dz2[t - k dil + left][c]
 __global__ void f32_dw_bwd_kernel(const float* dz2, const float* taps, float* e1, long long B, int T,
                                   int C, int P, int dil, int left) {
@@ -473,6 +569,10 @@ __global__ void f32_add_kernel(float* dst, const float* a, long long n) {
     dst[i] += a[i];
 }
 
+inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr,
+                      const void* d = nullptr, const void* e = nullptr) {
+  return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d) | ((uintptr_t)e)) & 15) == 0;
+}
 inline int grid_for(long long n) {
   long long g = (n + 255)/256;
   if (g > 65535*4) g = 65535*4;
@@ -528,6 +628,10 @@ int norm_forward(const Ctx32& c, const float* z, const float* slope, float* tabl
 }
 int norm_apply(const Ctx32& c, const float* z, const float* slope, const float* table,
                const float* gain, const float* bias, float* y, int C) {
+  if (C % 4 == 0 && aligned16(z, y))
+    hipLaunchKernelGGL(f32_norm_apply4_kernel, dim3(grid_for(c.BT*C/4)), dim3(256), 0, c.st,
+                       (const float4*)z, slope, table, gain, bias, (float4*)y, c.BT, C/4);
+  else
   hipLaunchKernelGGL(f32_norm_apply_kernel, dim3(grid_for(c.BT*C)), dim3(256), 0, c.st, z, slope,
                      table, gain, bias, y, c.BT, C);
   HIP_OK32(hipGetLastError());
@@ -538,8 +642,8 @@ int chan_reduce(const Ctx32& c, Red32 r, float* d0, int stride0, int nq_main, fl
   const int nq = r.mode == 0 ? 1 : (r.mode == 1 ? 2 : r.P + 1);
   r.part = c.f(c.ws.part);
   if ((long long)slices*nq*r.C > c.ws.part_floats) return fail32(-1, "fp32 path: reduction scratch too small");
-  hipLaunchKernelGGL(f32_chan_reduce_kernel, dim3(slices), dim3(256), 0, c.st, r);
-  hipLaunchKernelGGL(f32_chan_fold_kernel, dim3((nq*r.C + 255)/256), dim3(256), 0, c.st, r.part,
+  hipLaunchKernelGGL(f32_chan_reduce_kernel, dim3(slices, (r.C + 63)/64), dim3(256), 0, c.st, r);
+  hipLaunchKernelGGL(f32_chan_fold_kernel, dim3((nq*r.C + 15)/16), dim3(256), 0, c.st, r.part,
                      slices, nq, r.C, d0, d1, stride0, nq_main);
   HIP_OK32(hipGetLastError());
   return 0;
@@ -566,6 +670,13 @@ int norm_backward(const Ctx32& c, const float* e, const float* z, const float* s
   int g = grid_for(rows*C);
   if (g > kSlopeBlocks) g = kSlopeBlocks;
   float* part = c.f(c.ws.scalars);
+  if (C % 4 == 0 && aligned16(e, z, add, dz)) {
+    int g4 = grid_for(rows*C/4);
+    if (g4 < g) g = g4;
+    hipLaunchKernelGGL(f32_norm_bwd_apply4_kernel, dim3(g), dim3(256), 0, c.st, (const float4*)e,
+                       (const float4*)z, slope_p, table, btab, gain,
+                       (const float4*)add, (float4*)dz, dslope ? part : nullptr, rows, C/4);
+  } else
   hipLaunchKernelGGL(f32_norm_bwd_apply_kernel, dim3(g), dim3(256), 0, c.st, e, z, slope_p, table, btab,
                      gain, add, dz, dslope ? part : nullptr, rows, C);
   if (dslope) hipLaunchKernelGGL(f32_fold_scalar_kernel, dim3(1), dim3(256), 0, c.st, part, g, dslope);
@@ -611,6 +722,11 @@ int brv_ctn_f32_forward(const brv_ctn_config* cfg, const float* params, void* wo
     OK32(conv1x1(c, c.xb(i), l.Bn, params + b.conv_w, l.H, l.Bn, c.z1b(i), l.H, params + b.conv_b, 2));
     OK32(norm_forward(c, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), l.H));
     OK32(norm_apply(c, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), params + b.n1_g, params + b.n1_b, h, l.H));
+    if (l.H % 4 == 0 && aligned16(h, c.z2b(i)))
+      hipLaunchKernelGGL(f32_dw4_kernel, dim3(grid_for(BT*l.H/4)), dim3(256), 0, st, (const float4*)h,
+                         params + b.dconv_w, params + b.dconv_b, (float4*)c.z2b(i), B,
+                         (int)T, l.H/4, l.P, dil, left, 1);
+    else
     hipLaunchKernelGGL(f32_dw_fwd_kernel, dim3(grid_for(BT*l.H)), dim3(256), 0, st, h,
                        params + b.dconv_w, params + b.dconv_b, c.z2b(i), B, (int)T, l.H, l.P, dil, left);
     OK32(norm_forward(c, c.z2b(i), params + b.prelu2, c.tab(2 + 2*i), l.H));
@@ -720,6 +836,11 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
       r.dil = dil; r.left = left;
       OK32(chan_reduce(c, r, grads + b.dconv_w, l.P, l.P, grads + b.dconv_b));
     }
+    if (l.H % 4 == 0 && aligned16(dz, e))
+      hipLaunchKernelGGL(f32_dw4_kernel, dim3(grid_for(BT*l.H/4)), dim3(256), 0, st, (const float4*)dz,
+                         params + b.dconv_w, (const float*)nullptr, (float4*)e, B, (int)T, l.H/4, l.P,
+                         dil, left, -1);
+    else
     hipLaunchKernelGGL(f32_dw_bwd_kernel, dim3(grid_for(BT*l.H)), dim3(256), 0, st, dz,
                        params + b.dconv_w, e, B, (int)T, l.H, l.P, dil, left);
     OK32(norm_backward(c, e, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), params + b.n1_g, l.H, nullptr,

@@ -82,18 +82,59 @@ def sgmse_train_row(batch, frames, steps, use_amp=False):
             'items_per_s': batch/dt}
 
 
+PEAK = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}     # dense MFMA TFLOP/s (MI355X guide)
+
+
+def driver_line(row, metric, value, unit, dtype, workload, tflops=None, higher=True):
+    """The fields of bench.py's JSON line for a widened row, with a whole-workload MFMA roofline
+    when the algorithmic FLOPs are known."""
+    row.update({'metric': metric, 'value': value, 'unit': unit, 'n_gpus': 1, 'dtype': dtype,
+                'higher_is_better': higher, 'data': 'synthetic', 'vs_baseline': None,
+                'config': {'workload': workload}})
+    if tflops is not None:
+        row['roofline'] = {'bound': 'mfma', 'achieved': tflops, 'peak': PEAK[dtype],
+                           'unit': 'TFLOP/s', 'frac': tflops/PEAK[dtype], 'traffic': None,
+                           'scope': 'whole workload: algorithmic FLOPs of SURVEY.md 8(d) over the '
+                                    'measured wall time (per-kernel tables: profiles/r02_rows_*.csv)'}
+    return row
+
+
+def convtasnet_fp32_row(steps=5):
+    """The Conv-TasNet benchmark step on the fp32 path (use_amp=False, brv_ctn_f32_*)."""
+    from brever_amd.models import ConvTasNet
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    model = ConvTasNet().to(dev)
+    batch = 0.1*torch.randn(16, 2, 64000, device=dev)
+    lengths = torch.full((16,), 64000, device=dev)
+    dt = timed(lambda: model.train_step(batch, lengths, False, None), 2, steps)
+    row = {'row': 'convtasnet train, fp32 path (use_amp=False)', 'ms_per_step': dt*1e3}
+    return driver_line(row, 'utterances/sec (4 s @16 kHz) Conv-TasNet train, fp32 activations',
+                       16/dt, 'utterances/s', 'fp32',
+                       'Conv-TasNet defaults, 16 x 4 s, fwd + SNR loss + bwd + clip + Adam, '
+                       'exact-fp32 MFMA products (brv_ctn_f32_*)', tflops=16/dt*116.46e9/1e12)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--rows', default='ffnn,dccrn,tfgridnet,sgmse,sgmse_train')
+    ap.add_argument('--rows', default='convtasnet_fp32,ffnn,dccrn,tfgridnet,sgmse,sgmse_train')
     args = ap.parse_args()
     rows = args.rows.split(',')
+    if 'convtasnet_fp32' in rows:
+        print(json.dumps(convtasnet_fp32_row()), flush=True)
     if 'ffnn' in rows:
         print(json.dumps(train_row('ffnn', 32, 2.0, 20, False)), flush=True)
     if 'dccrn' in rows:
-        print(json.dumps(train_row('dccrn', 16, 4.0, 5, False)), flush=True)
-        row = train_row('dccrn', 16, 4.0, 5, True)
-        row['row'] += ' (use_amp: bf16 matrix products)'
-        print(json.dumps(row), flush=True)
+        for amp in (False, True):
+            row = train_row('dccrn', 16, 4.0, 5, amp)
+            if amp:
+                row['row'] += ' (use_amp: bf16 matrix products)'
+            driver_line(row, 'utterances/sec (4 s @16 kHz) DCCRN train (BASELINE config 3)',
+                        row['utt_per_s'], 'utterances/s', 'bf16' if amp else 'fp32',
+                        'DCCRN defaults (3 671 053 params), 16 x 4 s, STFT 512/128 -> complex '
+                        'Conv2d + LSTM -> iSTFT, fwd + SNR loss + bwd + clip 5.0 + Adam',
+                        tflops=row['tflops'])
+            print(json.dumps(row), flush=True)
     if 'tfgridnet' in rows:
         print(json.dumps(train_row('tfgridnet', 4, 4.0, 3, False)), flush=True)
         row = train_row('tfgridnet', 4, 4.0, 3, True)
@@ -103,7 +144,15 @@ def main():
         print(json.dumps(sgmse_train_row(4, 128, 3)), flush=True)
         print(json.dumps(sgmse_train_row(4, 128, 3, True)), flush=True)
     if 'sgmse' in rows:
-        print(json.dumps(sgmse_row(4.0, 30)), flush=True)
+        row = sgmse_row(4.0, 30)
+        b8 = row['fp16_mfma_b8']
+        driver_line(row, 'utterances/sec SGMSE+ enhance (BASELINE config 4)', b8['utt_per_s'],
+                    'utterances/s', 'fp16',
+                    'SGMSE+ defaults (65.6 M params), 30-step reverse SDE (PC sampler, 60 network '
+                    'evaluations), 8 x 4 s utterances, fp16-MFMA convolutions, iSTFT overlap-add',
+                    tflops=b8['tflops'])
+        row['s_per_utt_batch1'] = row['fp16_mfma_b1']['s_per_utt']
+        print(json.dumps(row), flush=True)
 
 
 if __name__ == '__main__':
