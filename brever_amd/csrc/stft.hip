@@ -583,6 +583,26 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const G32 p) {
   }
 }
 
+// y[r][i] = x[r][reflect(i - left)], i < out_len: F.pad(mode='reflect' | 'replicate' | 'circular')
+// of the STFT module's pad_mode (stft.py:140-149 and torch.stft's centre padding)
+__global__ void pad_signal_kernel(const float* x, float* y, long long rows, long long L, long long left,
+                                  long long out_len, int mode) {
+  const long long n = rows*out_len;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const long long r = i / out_len;
+    long long j = i % out_len - left;
+    if (mode == 1) {                      // reflect (no edge repeat); valid for pads < L
+      if (j < 0) j = -j;
+      if (j >= L) j = 2*(L - 1) - j;
+    } else if (mode == 2) {               // replicate
+      j = j < 0 ? 0 : (j >= L ? L - 1 : j);
+    } else if (mode == 3) {               // circular
+      j %= L; if (j < 0) j += L;
+    }
+    y[i] = (j >= 0 && j < L) ? x[r*L + j] : 0.f;
+  }
+}
+
 // complex <-> (magnitude, phase): the 'mag_phase' return / input types of the STFT module
 __global__ void polar_kernel(const float* mag, const float* phase, float2* out, long long n) {
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
@@ -912,6 +932,15 @@ int brv_overlap_add(const float* frames_in, const float* window, float* y, int64
   return (int)hipGetLastError();
 }
 
+int brv_pad_signal(const float* x, float* y, int64_t rows, int64_t length, int64_t left,
+                   int64_t out_len, int mode, brv_stream_t stream) {
+  if (rows < 1 || length < 1 || out_len < 1 || mode < 0 || mode > 3) return -1;
+  if (mode == 1 && (left >= length || out_len - left - length >= length)) return -2;
+  int gx = (int)((rows*out_len + 255)/256); if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(pad_signal_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, x, y,
+                     (long long)rows, (long long)length, (long long)left, (long long)out_len, mode);
+  return (int)hipGetLastError();
+}
 int brv_polar(const float* mag, const float* phase, float* out, int64_t n, brv_stream_t stream) {
   if (n < 1) return -1;
   int gx = (int)((n + 255)/256); if (gx > 4096) gx = 4096;

@@ -96,6 +96,7 @@ SIGNATURES = {
     'brv_dft64_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*7 + [_c_f32, _c_f32, _c_ptr]),
     'brv_dft64_synthesis': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*4 + [_c_f32, _c_f32, _c_ptr]),
     'brv_overlap_add': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*6 + [_c_ptr]),
+    'brv_pad_signal': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_int, _c_ptr]),
     'brv_polar': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
     'brv_mag_phase': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
     'brv_spec_compress': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_f32, _c_f32, _c_ptr]),

@@ -17,8 +17,9 @@ data stay fp32 in HBM, the n-term sums accumulate in fp64, so the round trip mee
 reference's own ``atol=1e-6`` (tests/test_modules.py:319-326), which a plain fp32 DFT product
 misses by 20x. The window-weighted bases are built here once per instance in float64 and cached
 per device. Any hop, ``n_fft >= frame_length``, one- or two-sided spectra, ``center`` on or
-off; only reflect-type padding is not built. Both directions are differentiable, including
-through the magnitude compression (``brv_spec_compress_backward``).
+off, every ``pad_mode`` of ``F.pad``. Both directions are differentiable, including through the
+magnitude compression (``brv_spec_compress_backward``); the gradient through non-constant
+padding is not built (``_dft_adjoint`` raises).
 """
 import functools
 import math
@@ -129,10 +130,12 @@ class _IstftLinear(torch.autograd.Function):
 class STFT:
     """Same constructor, padding arithmetic, normalisation, compression, scaling and return types
     as the reference (stft.py:32-149). Every option of ``torch.stft`` the reference forwards is
-    supported except reflect-type padding: any hop, ``n_fft >= frame_length`` (the window is
+    supported: any ``pad_mode``, any hop, ``n_fft >= frame_length`` (the window is
     zero-padded centrally to ``n_fft`` like torch does), one- and two-sided spectra,
     ``center`` on or off. Both directions are differentiable, through the magnitude
     compression as well."""
+
+    _PAD_MODES = {'constant': 0, 'reflect': 1, 'replicate': 2, 'circular': 3}
 
     def __init__(self, frame_length=512, hop_length=256, window='hann',
                  center=True, pad_mode='constant', normalized=True,
@@ -156,9 +159,8 @@ class STFT:
         if isinstance(window, np.ndarray):
             window = torch.from_numpy(window)
         self.window = window
-        if pad_mode != 'constant':
-            raise NotImplementedError(f"pad_mode='{pad_mode}' is not built on the HIP path "
-                                      '(the reference default is constant)')
+        if pad_mode not in self._PAD_MODES:
+            raise ValueError(f"pad_mode must be one of {sorted(self._PAD_MODES)}, got '{pad_mode}'")
         if self.n_fft < frame_length:
             raise ValueError(f'n_fft ({self.n_fft}) must be >= frame_length ({frame_length})')
         self.bins = self.n_fft//2 + 1 if onesided else self.n_fft
@@ -219,9 +221,35 @@ class STFT:
         return (total - self.n_fft)//self.hop_length + 1, pad_left
 
     # -- the three products -----------------------------------------------------------
+    def _explicit_padding(self, x2):
+        """pad_mode != 'constant': the right padding of ``STFT.pad`` and torch.stft's centre
+        padding are applied one after the other, each in ``pad_mode`` (zeros need no copy: the
+        framed product reads them implicitly). Values only (no gradient through the padding)."""
+        lib = hip.lib()
+        mode = self._PAD_MODES[self.pad_mode]
+        rows, L = x2.shape
+        padded = (self.frame_count(L) - 1)*self.hop_length + self.frame_length
+        stages = [(0, padded)] if padded > L else []
+        if self.center:
+            half = self.n_fft//2
+            stages.append((half, padded + 2*half))
+        for left, out_len in stages:
+            y = torch.empty(rows, out_len, dtype=torch.float32, device=x2.device)
+            status = lib.brv_pad_signal(hip.ptr(x2), hip.ptr(y), rows, x2.shape[-1], left, out_len,
+                                        mode, hip.stream())
+            if status == -2:
+                raise ValueError(f"pad_mode='{self.pad_mode}' needs padding smaller than the "
+                                 f'input ({x2.shape[-1]} samples)')
+            hip.check(status, 'brv_pad_signal')
+            x2 = y
+        return x2
+
     def _dft_forward(self, x2, basis, compression=1.0, scale=1.0):
         rows, L = x2.shape
         F, pad_left = self._geometry(L)
+        if self.pad_mode != 'constant':
+            x2 = self._explicit_padding(x2)
+            L, pad_left = x2.shape[-1], 0
         spec = torch.empty(rows, self.bins, F, 2, dtype=torch.float32, device=x2.device)
         hip.check(hip.lib().brv_dft64_forward(
             hip.ptr(x2), hip.ptr(basis), hip.ptr(spec), rows, L, self.n_fft, self.hop_length,
@@ -231,6 +259,8 @@ class STFT:
 
     def _dft_adjoint(self, dspec, L, scale=1.0):
         """dx (rows, L): adjoint of ``scale * _dft_forward`` applied to dspec (rows, bins, F, 2)."""
+        if self.pad_mode != 'constant':
+            raise NotImplementedError("gradient through pad_mode != 'constant' is not built")
         lib = hip.lib()
         rows, F = dspec.shape[0], dspec.shape[2]
         _, pad_left = self._geometry(L)

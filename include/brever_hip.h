@@ -218,6 +218,11 @@ int brv_overlap_add(const float* frames_in, const float* window, float* y, int64
                     brv_stream_t stream);
 int brv_spec_compress(const float* x, float* y, int64_t n, float compression, float scale,
                       brv_stream_t stream);
+/* y (rows, out_len) = x (rows, length) shifted right by `left` and extended by mode 0 zeros,
+ * 1 reflect, 2 replicate, 3 circular: F.pad of STFT.pad and torch.stft's centre padding for
+ * pad_mode != 'constant' (stft.py:140-149,66-77). */
+int brv_pad_signal(const float* x, float* y, int64_t rows, int64_t length, int64_t left,
+                   int64_t out_len, int mode, brv_stream_t stream);
 /* out = mag e^{j phase} / (mag, phase) of n complex64 values ('mag_phase' of stft.py:93-110). */
 int brv_polar(const float* mag, const float* phase, float* out, int64_t n, brv_stream_t stream);
 int brv_mag_phase(const float* x, float* mag, float* phase, int64_t n, brv_stream_t stream);

@@ -837,12 +837,15 @@ def golden_stft_matrix(out):
               dict(frame_length=512, hop_length=200),
               dict(frame_length=256, hop_length=64, center=False, window='hamming'),
               dict(frame_length=60, hop_length=25, n_fft=64, onesided=False, window='hamming'),
-              dict(frame_length=512, hop_length=128, window=None, normalized=False)]
+              dict(frame_length=512, hop_length=128, window=None, normalized=False),
+              dict(frame_length=512, hop_length=128, pad_mode='reflect'),
+              dict(frame_length=400, hop_length=160, n_fft=512, pad_mode='replicate', onesided=False)]
     data = {'x': x.numpy(), 'cases': json.dumps(cases)}
     pick = np.random.default_rng(0)
     for i, kw in enumerate(cases):
         stft = STFT(**kw)
-        X = stft(x)
+        # (F.pad only reflects / replicates batched input: those cases take x as (1, 4096))
+        X = stft(x if kw.get('pad_mode', 'constant') == 'constant' else x.unsqueeze(0))
         flat = X.reshape(-1)
         idx = pick.integers(0, flat.numel(), 192)
         data[f'idx{i}'] = idx

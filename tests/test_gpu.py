@@ -838,7 +838,7 @@ def test_stft_istft_match_reference(golden_dir):
 def test_stft_matrix_matches_reference(golden_dir):
     """The reference's whole STFT test matrix (tests/test_modules.py:300-326: 32 combinations, two- and
     one-sided) + n_fft > frame_length, hops that do not divide the frame, center=False, a
-    boxcar window: sampled spectrum values, spectrum energy, STFT.backward(STFT(x)) against the
+    boxcar window, reflect / replicate padding: sampled spectrum values, spectrum energy, STFT.backward(STFT(x)) against the
     reference's own output AND its round-trip assertion (atol 1e-6, rtol 2e-3), gradients through
     both directions incl. the magnitude compression."""
     import json
@@ -846,11 +846,11 @@ def test_stft_matrix_matches_reference(golden_dir):
     g = np.load(os.path.join(golden_dir, 'stft_matrix.npz'))
     dev = _cuda()
     cases = json.loads(str(g['cases']))
-    assert len(cases) == 38
+    assert len(cases) == 40
     x = torch.from_numpy(g['x']).to(dev)
     for i, kw in enumerate(cases):
         stft = STFT(**kw)
-        X = stft(x)
+        X = stft(x if kw.get('pad_mode', 'constant') == 'constant' else x.unsqueeze(0))
         assert tuple(X.shape) == tuple(g[f'shape{i}']), (i, kw)
         ref = torch.view_as_complex(torch.from_numpy(g[f'val{i}']))
         got = X.reshape(-1)[torch.from_numpy(g[f'idx{i}']).to(dev)].cpu()
@@ -934,6 +934,61 @@ def test_rccl_gradient_sync_path_single_rank():
     finally:
         dist.destroy_process_group()
 
+
+
+def _two_rank_worker(rank, world, port, out_dir, criterion):
+    """One of two processes sharing cuda:0 (gloo moves the CUDA gradient through the host)."""
+    import torch.distributed as dist
+    from brever_amd.models import ConvTasNet
+    from brever_amd.parallel import GradSynchronizer, broadcast_parameters
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda', 0)
+    cfg = dict(filters=48, filter_length=16, bottleneck_channels=24, hidden_channels=40,
+               skip_channels=16, kernel_size=3, layers=2, repeats=2, criterion=criterion)
+    torch.manual_seed(100 + rank)                   # different init per rank until the broadcast
+    net = ConvTasNet(**cfg).to(dev)
+    broadcast_parameters(net)
+    GradSynchronizer(net, nparts=2)
+    g = torch.Generator().manual_seed(9)
+    batch = 0.1*torch.randn(4, 2, 1500, generator=g).to(dev)
+    lengths = torch.full((4,), 1500, device=dev)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    lo, hi = 2*rank, 2*rank + 2
+    for _ in range(3):
+        net.train_step(batch[lo:hi], lengths[lo:hi], False, scaler)
+    torch.save(net.flat_params().cpu(), os.path.join(out_dir, f'p{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('criterion', ['snr', 'sisnr'])
+def test_two_ranks_equal_single_process_on_union_batch(tmp_path, criterion):
+    """two ranks (gloo, both on this GPU), each on half of the batch, against a
+    single process on the union batch, for the fused step (snr: bucketed all-reduce) AND the
+    generic loss -> update sequence (sisnr: the hook in ConvTasNet.update); fp32 path."""
+    import socket
+    import torch.multiprocessing as mp
+    from brever_amd.models import ConvTasNet
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), criterion), nprocs=2, join=True)
+    p0, p1 = torch.load(tmp_path/'p0.pt'), torch.load(tmp_path/'p1.pt')
+    assert torch.equal(p0, p1)
+    dev = _cuda()
+    cfg = dict(filters=48, filter_length=16, bottleneck_channels=24, hidden_channels=40,
+               skip_channels=16, kernel_size=3, layers=2, repeats=2, criterion=criterion)
+    torch.manual_seed(100)
+    net = ConvTasNet(**cfg).to(dev)
+    g = torch.Generator().manual_seed(9)
+    batch = 0.1*torch.randn(4, 2, 1500, generator=g).to(dev)
+    lengths = torch.full((4,), 1500, device=dev)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    for _ in range(3):
+        net.train_step(batch, lengths, False, scaler)
+    assert rel(p0, net.flat_params()) <= 1e-5, rel(p0, net.flat_params())
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('amp', [True, False])

@@ -231,8 +231,8 @@ def test_mel_filterbank_and_frame_count_bit_exact(golden_dir):
         s = STFT(512, hop)
         assert [s.frame_count(int(n)) + 512//hop for n in g['lens']] == got
     assert STFT(512, 128, onesided=False).bins == 512 and STFT(400, 160, n_fft=512).bins == 257
-    with pytest.raises(NotImplementedError):
-        STFT(512, 128, pad_mode='reflect')          # the one torch.stft option not built
+    with pytest.raises(ValueError):
+        STFT(512, 128, pad_mode='mirror')
     with pytest.raises(ValueError):
         STFT(512, 128, n_fft=256)
 
