@@ -321,7 +321,8 @@ int launch_wgrad_t(WgradGroupParams& gp, hipStream_t st) {
   const int nprob = gp.nprob > 0 ? gp.nprob : 1;
   const int tiles = ceil_div(p.Gp, WG_BG)*(p.Hp/BH);
   const int total = p.B*ceil_div(p.T, WG_BT);
-  int ns = ceil_div(384, tiles*nprob);
+  static const int target = getenv("BRV_WG_TARGET") ? atoi(getenv("BRV_WG_TARGET")) : 384;
+  int ns = ceil_div(target, tiles*nprob);
   if (ns > total) ns = total;
   if (ns < 1) ns = 1;
   p.nsplit = ns;

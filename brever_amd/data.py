@@ -274,7 +274,11 @@ def audio_info(f, name):
         rate, _, frames, _, _, _ = _wav_header(f)
         return frames, rate
     head = f.read(1 << 16)                 # STREAMINFO is the first metadata block
-    frames, rate, _, _ = _flac_info(head, name)
+    try:
+        frames, rate, _, _ = _flac_info(head, name)
+    except ValueError:                     # metadata (pictures, tags) longer than the head
+        head += f.read()
+        frames, rate, _, _ = _flac_info(head, name)
     if frames == 0:                        # unknown length in the header: decode to count
         return len(audio_read(io.BytesIO(head + f.read()), name)[0]), rate
     return frames, rate
