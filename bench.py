@@ -114,7 +114,7 @@ KERNEL_OF_LABEL = {
     'dwconv_fwd': 'dwconv_fwd_kernel', 'pw2_wgrad': 'wgrad_full_kernel',
     'pw1_fwd': 'gemm_ws_kernel<128, 64, 1, 0,', 'pw2_fwd': 'gemm_ws_kernel<512,',
     'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': 'gemm_rows_kernel<128, 3, 5>',
-    'pw1_wgrad': 'gemm_wgrad_kernel<128, 0>', 'clip_adam': 'clip_adam_kernel',
+    'pw1_wgrad': ('gemm_wgrad_kernel<128, 0>', 'largest'), 'clip_adam': 'clip_adam_kernel',
 }
 PMC_FILES = ('r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
 
@@ -125,6 +125,9 @@ def pmc_traffic(label):
     x2 on gfx950 + WRITE_SIZE, separate passes, same bench command). bench.py cannot run the
     profiler on itself; (None, None) when the file or the kernel is missing."""
     key = KERNEL_OF_LABEL.get(label)
+    field = 'hbm_traffic_MB'
+    if isinstance(key, tuple):        # the template also serves smaller launches: take the largest
+        key, field = key[0], 'hbm_traffic_MB_largest_launch'
     for fname in PMC_FILES:
         path = os.path.join(ROOT, 'profiles', fname)
         if key is None or not os.path.exists(path):
@@ -132,8 +135,8 @@ def pmc_traffic(label):
         with open(path) as f:
             kernels = json.load(f)['kernels']
         for name, v in kernels.items():
-            if key in name:
-                return v['hbm_traffic_MB']*1e6, f'profiles/{fname}'
+            if key in name and field in v:
+                return v[field]*1e6, f'profiles/{fname}'
     return None, None
 
 

@@ -20,7 +20,7 @@ from collections import defaultdict
 
 
 def read_counter(directory, counter):
-    sums, counts = defaultdict(float), defaultdict(int)
+    sums, counts, peaks = defaultdict(float), defaultdict(int), defaultdict(float)
     files = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)
     if not files:
         raise SystemExit(f'no counter_collection.csv under {directory}')
@@ -30,9 +30,11 @@ def read_counter(directory, counter):
                 if row.get('Counter_Name') != counter:
                     continue
                 name = row['Kernel_Name']
-                sums[name] += float(row['Counter_Value'])
+                value = float(row['Counter_Value'])
+                sums[name] += value
                 counts[name] += 1
-    return {k: (sums[k]/counts[k], counts[k]) for k in sums}
+                peaks[name] = max(peaks[name], value)
+    return {k: (sums[k]/counts[k], counts[k], peaks[k]) for k in sums}
 
 
 def main():
@@ -41,13 +43,16 @@ def main():
     write = read_counter(write_dir, 'WRITE_SIZE')
     kernels = {}
     for name in sorted(set(fetch) | set(write)):
-        f_kb, n = fetch.get(name, (0.0, 0))
-        w_kb, n2 = write.get(name, (0.0, 0))
+        f_kb, n, f_max = fetch.get(name, (0.0, 0, 0.0))
+        w_kb, n2, w_max = write.get(name, (0.0, 0, 0.0))
         rd = 2.0*f_kb*1024/1e6
         wr = w_kb*1024/1e6
+        # one kernel template can serve launches of very different sizes (the grouped
+        # weight gradient of 24 blocks and a single layer's): the largest launch is kept too
         kernels[name] = {'launches_sampled': max(n, n2), 'FETCH_SIZE_KB_raw': f_kb,
                          'WRITE_SIZE_KB': w_kb, 'hbm_read_MB_corrected': rd,
-                         'hbm_write_MB': wr, 'hbm_traffic_MB': rd + wr}
+                         'hbm_write_MB': wr, 'hbm_traffic_MB': rd + wr,
+                         'hbm_traffic_MB_largest_launch': (2.0*f_max + w_max)*1024/1e6}
     note = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py '
             '--steps 3 --warmup 1; per-launch averages; FETCH_SIZE doubled (gfx950: 128-B requests '
             'tallied at 64 B, MI355X_MICROARCH.md HBM section); KB = 1024 B')

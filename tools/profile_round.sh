@@ -17,4 +17,7 @@ PMCARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-through-trainer"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
 python3 $REPO/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $OUT/${TAG}_pmc_hbm_traffic.json
-grep -v "^/opt" $OUT/${TAG}_kernel_table.txt | head -30
+# the complete default line without a profiler attached (what the driver runs)
+cd $REPO && python3 bench.py > $OUT/${TAG}_bench_line.json 2> /dev/null
+grep -v "^/opt" $OUT/${TAG}_kernel_table.txt | grep -E "^[a-z_0-9]+ +[0-9]" | head -12
+cut -c1-400 $OUT/${TAG}_bench_line.json
