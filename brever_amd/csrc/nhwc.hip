@@ -1,0 +1,579 @@
+// Channels-last fp16 companions of brv_conv_nhwc_forward: what the SGMSE+ score network does
+// between its 3x3 convolutions under use_amp (reference brever/models/sgmse/net.py:180-477 --
+// GroupNorm, FIR resampling, 1x1 convolutions, the progressive 4-channel side branch).
+// Activations are (B, H, W, Cs) fp16, Cs a multiple of 8, channels >= C hold zeros; the 4-channel
+// side branch and the network's input / output stay (B, C, H, W) fp32.
+// All of these stream their tensors once; none is MFMA work.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "../../include/brever_hip.h"
+#include "common.cuh"
+
+using namespace brv;
+
+namespace {
+
+#define NH_OK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float nh_silu(float v) {
+  return v*__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f*v));
+}
+
+// ---- layout conversion ------------------------------------------------------------------
+// (B, C, HW) fp32 -> (B, HW, Cs) fp16, zero channels beyond C. One thread per (pixel, octet):
+// reads are strided by HW per channel but consecutive threads take consecutive pixels.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, _Float16* y, int C,
+                                                           int Cs, long long HW) {
+  const int oct = Cs >> 3;
+  const long long b = blockIdx.z;
+  const int o = blockIdx.y;
+  if (o >= oct) return;
+  const long long px = (long long)blockIdx.x*256 + threadIdx.x;
+  if (px >= HW) return;
+  h8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = o*8 + j;
+    v[j] = c < C ? (_Float16)x[(b*C + c)*HW + px] : (_Float16)0.f;
+  }
+  *reinterpret_cast<h8*>(y + (b*HW + px)*Cs + o*8) = v;
+}
+// (B, HW, Cs) fp16 -> (B, C, HW) fp32
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const _Float16* x, float* y, int C, int Cs,
+                                                           long long HW) {
+  const long long b = blockIdx.z;
+  const int o = blockIdx.y;
+  const long long px = (long long)blockIdx.x*256 + threadIdx.x;
+  if (px >= HW) return;
+  const h8 v = *reinterpret_cast<const h8*>(x + (b*HW + px)*Cs + o*8);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = o*8 + j;
+    if (c < C) y[(b*C + c)*HW + px] = (float)v[j];
+  }
+}
+
+// ---- GroupNorm: per-channel sums, then the fold ---------------------------------------------
+// sums[b][c][0..1] += (sum, sum of squares) of channel c over the pixels of this slice. Thread =
+// (pixel lane, octet); fp32 partials over at most `per_thread` pixels, combined through LDS,
+// one fp64 atomic pair per (workgroup, channel). Per-CHANNEL sums make the statistics of a channel
+// concatenation the concatenation of the statistics, and a per-channel shift (the embedding
+// term) an algebraic correction in the fold.
+__global__ __launch_bounds__(256) void chan_stats_kernel(const _Float16* x, double* sums, int C,
+                                                         int Cs, long long HW, int c_off, int Ctot,
+                                                         long long slice) {
+  __shared__ float red[256][17];
+  const int oct = Cs >> 3;
+  const int lanes = 256/oct;                        // pixels in flight
+  const int o = threadIdx.x % oct, pl = threadIdx.x / oct;
+  const long long b = blockIdx.y;
+  const long long lo = (long long)blockIdx.x*slice;
+  long long hi = lo + slice;
+  if (hi > HW) hi = HW;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  if (pl < lanes) {
+    const _Float16* xb = x + b*HW*Cs + o*8;
+    for (long long px = lo + pl; px < hi; px += lanes) {
+      const f32x8 v = __builtin_convertvector(*reinterpret_cast<const h8*>(xb + px*Cs), f32x8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] = fmaf(v[j], v[j], q[j]); }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s[j]; red[threadIdx.x][8 + j] = q[j]; }
+  __syncthreads();
+  // thread t < 16*oct: (octet, value k of 16) summed over the pixel lanes
+  for (int t = threadIdx.x; t < oct*16; t += 256) {
+    const int oo = t >> 4, k = t & 15;
+    double a = 0.0;
+    for (int l = 0; l < lanes; ++l) a += (double)red[l*oct + oo][k];
+    const int c = oo*8 + (k & 7);
+    if (c < C) atomicAdd(&sums[((b*Ctot + c_off + c) << 1) + (k >> 3)], a);
+  }
+}
+
+// one workgroup (64 threads) per (item, group): statistics of x + add[b][c] from the channel
+// sums, then scale = rstd*gamma*(1 + adm_scale), shift = (beta + (add - mean)*rstd*gamma)*(1 +
+// adm_scale) + adm_shift (the arithmetic of gn_fold_kernel, sgmse.hip)
+__global__ __launch_bounds__(64) void chan_fold_kernel(const double* sums, const float* add,
+                                                       const float* gamma, const float* beta,
+                                                       const float* adm_scale, const float* adm_shift,
+                                                       float* scale, float* shift, int C, long long HW,
+                                                       int groups, float eps) {
+  __shared__ double red[2][64];
+  const int bg = blockIdx.x, b = bg / groups, g = bg % groups;
+  const int cpg = C/groups;
+  double s1 = 0.0, s2 = 0.0;
+  for (int j = threadIdx.x; j < cpg; j += 64) {
+    const long long idx = (long long)b*C + g*cpg + j;
+    const double e = add ? (double)add[idx] : 0.0;
+    const double cs = sums[idx << 1], cq = sums[(idx << 1) + 1];
+    s1 += cs + (double)HW*e;
+    s2 += cq + 2.0*e*cs + (double)HW*e*e;
+  }
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 64; ++i) { s1 += red[0][i]; s2 += red[1][i]; }
+    red[0][0] = s1; red[1][0] = s2;
+  }
+  __syncthreads();
+  const double n = (double)cpg*(double)HW;
+  const double mean = red[0][0]/n;
+  double var = red[1][0]/n - mean*mean;
+  if (var < 0) var = 0;
+  const float rstd = (float)(1.0/sqrt(var + (double)eps));
+  for (int j = threadIdx.x; j < cpg; j += 64) {
+    const int c = g*cpg + j;
+    const long long idx = (long long)b*C + c;
+    float sc = rstd*gamma[c];
+    float sh = beta[c] + ((add ? add[idx] : 0.f) - (float)mean)*sc;
+    if (adm_scale) { const float m = 1.f + adm_scale[idx]; sc *= m; sh = sh*m + adm_shift[idx]; }
+    scale[idx] = sc; shift[idx] = sh;
+  }
+}
+
+// y = act(scale[b][c]*x + shift[b][c]), channels-last fp16 both sides (zero beyond C)
+__global__ __launch_bounds__(256) void nhwc_affine_act_kernel(const _Float16* x, const float* scale,
+                                                              const float* shift, _Float16* y, int C,
+                                                              int Cs, long long HW, int act) {
+  const int oct = Cs >> 3;
+  const long long b = blockIdx.y;
+  const long long n = HW*oct;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const int o = (int)(i % oct);
+    const f32x8 v = __builtin_convertvector(*reinterpret_cast<const h8*>(x + b*HW*Cs + i*8), f32x8);
+    f32x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = o*8 + j;
+      float t = 0.f;
+      if (c < C) { t = scale[b*C + c]*v[j] + shift[b*C + c]; if (act) t = nh_silu(t); }
+      r[j] = t;
+    }
+    *reinterpret_cast<h8*>(y + b*HW*Cs + i*8) = __builtin_convertvector(r, h8);
+  }
+}
+
+// ---- depthwise FIR resampling by 2 (Resample.forward), channels-last fp16 ---------------------
+// down = conv2d(stride 2, padding (ph, pw)); up = conv_transpose2d(stride 2, padding, output
+// padding) with the kernel times `gain`. One thread per (output pixel, octet).
+template <bool UP>
+__global__ __launch_bounds__(256) void nhwc_fir_kernel(const _Float16* x, const float* k, _Float16* y,
+                                                       int Cs, int H, int W, int Ho, int Wo, int K,
+                                                       int ph, int pw, float gain) {
+  const int oct = Cs >> 3;
+  const long long b = blockIdx.y;
+  const long long n = (long long)Ho*Wo*oct;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const int o = (int)(i % oct);
+    const long long opx = i / oct;
+    const int wo = (int)(opx % Wo), ho = (int)(opx / Wo);
+    f32x8 acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int a = 0; a < K; ++a) {
+      int hi;
+      if (UP) { const int hn = ho + ph - a; if (hn < 0 || (hn & 1)) continue; hi = hn >> 1; }
+      else hi = ho*2 - ph + a;
+      if (hi < 0 || hi >= H) continue;
+      for (int c = 0; c < K; ++c) {
+        int wi;
+        if (UP) { const int wn = wo + pw - c; if (wn < 0 || (wn & 1)) continue; wi = wn >> 1; }
+        else wi = wo*2 - pw + c;
+        if (wi < 0 || wi >= W) continue;
+        const f32x8 v = __builtin_convertvector(
+            *reinterpret_cast<const h8*>(x + ((b*H + hi)*W + wi)*Cs + o*8), f32x8);
+        const float kv = k[a*K + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(v[j], kv, acc[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= gain;
+    *reinterpret_cast<h8*>(y + ((b*Ho + ho)*Wo + wo)*(long long)Cs + o*8) = __builtin_convertvector(acc, h8);
+  }
+}
+
+// out = alpha*a + beta*b on fp16 tensors (b nullable), fp32 arithmetic
+__global__ __launch_bounds__(256) void nhwc_axpby_kernel(const _Float16* a, float alpha,
+                                                         const _Float16* b, float beta, _Float16* out,
+                                                         long long n8) {
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n8; i += (long long)gridDim.x*256) {
+    const f32x8 va = __builtin_convertvector(*reinterpret_cast<const h8*>(a + i*8), f32x8);
+    f32x8 r;
+    if (b) {
+      const f32x8 vb = __builtin_convertvector(*reinterpret_cast<const h8*>(b + i*8), f32x8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = alpha*va[j] + beta*vb[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = alpha*va[j];
+    }
+    *reinterpret_cast<h8*>(out + i*8) = __builtin_convertvector(r, h8);
+  }
+}
+
+// ---- 1x1 convolution, channels-last fp16 (UNetBlock.skip_conv): a row-major GEMM
+//   Y[pixel][co] = out_scale*(bias[co] + sum_ci W[co][ci] X[pixel][ci]),  X = [x1 | x2]
+// on v_mfma_f32_32x32x16_f16 with NO LDS staging of the operands: channels-last rows ARE the B
+// fragment (lane (pixel n, k-half) reads its 16 contiguous bytes), the packed weights the A
+// fragment (the same 1-KB pieces for every workgroup: L1 / L2 hits). A workgroup = 4 waves x 32
+// pixels x up to 128 output channels; the result leaves through LDS as whole pixel rows.
+// Memory-bound by construction (arithmetic intensity Cout/2 FLOP per byte).
+struct Pw1Params {
+  const _Float16* x1; const _Float16* x2; const h8* wp; const float* bias; _Float16* y;
+  int C1, C1s, C2, C2s, Cout, Cys, n_ks1, n_ks;
+  long long npx; float out_scale;
+};
+__global__ __launch_bounds__(256) void nhwc_conv1x1_kernel(const Pw1Params p) {
+  constexpr int ESTRIDE = 272;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[128*ESTRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n32 = lane & 31, khalf = lane >> 5;
+  const long long px0 = (long long)blockIdx.x*128;
+  const int cob = blockIdx.y;
+  const long long px = px0 + wave*32 + n32;
+  const bool pok = px < p.npx;
+  f32x16 acc[4];
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[cf][i] = 0.f;
+  const h8* wa = p.wp + (long long)cob*p.n_ks*4*64 + lane;
+  const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int ks = 0; ks < p.n_ks; ++ks) {
+    const bool second = ks >= p.n_ks1;
+    const _Float16* xb = second ? p.x2 : p.x1;
+    const int cs = second ? p.C2s : p.C1s;
+    const int c0 = (second ? ks - p.n_ks1 : ks)*16 + khalf*8;
+    h8 bv = zero;
+    if (pok && c0 < cs) bv = *reinterpret_cast<const h8*>(xb + px*cs + c0);
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf)
+      acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[(ks*4 + cf)*64], bv, acc[cf], 0, 0, 0);
+  }
+  // D[co][pixel] -> LDS [pixel][co] -> 16-byte pieces of whole pixel rows
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      h4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (_Float16)acc[cf][g*4 + j];
+      *reinterpret_cast<h4*>(stage + (wave*32 + n32)*ESTRIDE + (cf*32 + g*8 + khalf*4)*2) = o;
+    }
+  __syncthreads();
+  const int c8 = tid & 15, co = cob*128 + c8*8;
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = p.bias && co + j < p.Cout ? p.bias[co + j] : 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = (it*256 + tid) >> 4;
+    const long long q = px0 + r;
+    if (q >= p.npx || co >= p.Cout) continue;
+    const f32x8 v = __builtin_convertvector(*reinterpret_cast<const h8*>(stage + r*ESTRIDE + c8*16), f32x8);
+    f32x8 w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = (v[j] + bv[j])*p.out_scale;
+    const h8 o = __builtin_convertvector(w, h8);
+    if (co + 8 <= p.Cout) *reinterpret_cast<h8*>(p.y + q*p.Cys + co) = o;
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (co + j < p.Cout) p.y[q*p.Cys + co + j] = o[j];
+    }
+  }
+}
+// wp[co block of 128][k-step][co fragment 4][lane][8] <- w[co][ci]; the k-steps of the second
+// source start at a multiple of 16 channels (C1 padded up)
+__global__ __launch_bounds__(256) void conv1x1_pack_kernel(const float* w, _Float16* wp, int Cout,
+                                                           int C1, int C2, int n_ks1, int n_ks,
+                                                           long long total) {
+  for (long long idx = (long long)blockIdx.x*256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x*256) {
+    long long r = idx;
+    const int j = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int cf = (int)(r % 4); r /= 4;
+    const int ks = (int)(r % n_ks); r /= n_ks;
+    const int co = (int)r*128 + cf*32 + (lane & 31);
+    const int kk = (lane >> 5)*8 + j;
+    int ci = -1;
+    if (ks < n_ks1) { const int c = ks*16 + kk; if (c < C1) ci = c; }
+    else { const int c = (ks - n_ks1)*16 + kk; if (c < C2) ci = C1 + c; }
+    float v = 0.f;
+    if (co < Cout && ci >= 0) v = w[(long long)co*(C1 + C2) + ci];
+    wp[idx] = (_Float16)v;
+  }
+}
+
+// ---- 3x3 convolution to a FEW output channels (<= 8): the 4-channel progressive output branch
+// (AuxiliaryUp.conv) and the final output convolution. x channels-last fp16 with an optional
+// folded GroupNorm (+SiLU); y (B, Cout, H, W) fp32, y = [y +] conv + bias. One thread per pixel
+// would re-read every input 9 times from L1; instead a workgroup stages the (8+2) x (32+2) pixel
+// patch of 64-channel slabs in LDS, already activated, and its 256 threads each own one pixel.
+struct SmallCoutParams {
+  const _Float16* x; const float* w; const float* bias; const float* scale; const float* shift;
+  const float* yin; float* y;
+  int C, Cs, Cout, H, W, silu;
+};
+__global__ __launch_bounds__(256) void nhwc_conv3x3_small_kernel(const SmallCoutParams p) {
+  constexpr int TR = 8, TC = 32, PR = TR + 2, PC = TC + 2, SLAB = 64;
+  __shared__ _Float16 patch[PR*PC][SLAB + 8];          // +8: rows 144 B apart (bank spread)
+  __shared__ float wl[8][9][SLAB];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, h0 = blockIdx.y*TR, w0 = blockIdx.x*TC;
+  const int r = tid / TC, c = tid % TC;
+  float acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+  const long long HW = (long long)p.H*p.W;
+  for (int cb = 0; cb < p.C; cb += SLAB) {
+    __syncthreads();
+    for (int i = tid; i < PR*PC*(SLAB/8); i += 256) {
+      const int px = i / (SLAB/8), o8 = i % (SLAB/8);
+      const int h = h0 + px / PC - 1, w = w0 + px % PC - 1;
+      const int ch = cb + o8*8;
+      f32x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      if (h >= 0 && h < p.H && w >= 0 && w < p.W && ch < p.Cs) {
+        v = __builtin_convertvector(*reinterpret_cast<const h8*>(p.x + (b*HW + (long long)h*p.W + w)*p.Cs + ch), f32x8);
+        if (p.scale) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float t = 0.f;
+            if (ch + j < p.C) {
+              t = p.scale[(long long)b*p.C + ch + j]*v[j] + p.shift[(long long)b*p.C + ch + j];
+              if (p.silu) t = nh_silu(t);
+            }
+            v[j] = t;
+          }
+        }
+      }
+      *reinterpret_cast<h8*>(&patch[px][o8*8]) = __builtin_convertvector(v, h8);
+    }
+    for (int i = tid; i < 8*9*SLAB; i += 256) {
+      const int o = i / (9*SLAB), t = (i / SLAB) % 9, k = i % SLAB;
+      wl[o][t][k] = o < p.Cout && cb + k < p.C ? p.w[((long long)o*p.C + cb + k)*9 + t] : 0.f;
+    }
+    __syncthreads();
+    for (int t = 0; t < 9; ++t) {
+      const _Float16* pp = patch[(r + t/3)*PC + c + t%3];
+      for (int k = 0; k < SLAB; k += 8) {
+        const f32x8 v = __builtin_convertvector(*reinterpret_cast<const h8*>(pp + k), f32x8);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          if (o >= p.Cout) break;
+          const float* wk = &wl[o][t][k];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[o] = fmaf(v[j], wk[j], acc[o]);
+        }
+      }
+    }
+  }
+  const int h = h0 + r, w = w0 + c;
+  if (h >= p.H || w >= p.W) return;
+  for (int o = 0; o < p.Cout; ++o) {
+    const long long idx = ((long long)b*p.Cout + o)*HW + (long long)h*p.W + w;
+    float v = acc[o] + (p.bias ? p.bias[o] : 0.f);
+    if (p.yin) v += p.yin[idx];
+    p.y[idx] = v;
+  }
+}
+
+// ---- x[b][px][c] = out_scale*(x + bias[c] + sum_k W[c][k]*aux[b][k][px]): the 1x1 convolution of
+// the 4-channel side branch added into the trunk (AuxiliaryDown, encoder type "skip")
+__global__ __launch_bounds__(256) void nhwc_add_pointwise_kernel(const _Float16* x, const float* aux,
+                                                                 const float* w, const float* bias,
+                                                                 _Float16* y, int C, int Cs, int K,
+                                                                 long long HW, float out_scale) {
+  const int oct = Cs >> 3;
+  const long long b = blockIdx.y;
+  const long long n = HW*oct;
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256) {
+    const int o = (int)(i % oct);
+    const long long px = i / oct;
+    const f32x8 v = __builtin_convertvector(*reinterpret_cast<const h8*>(x + b*HW*Cs + i*8), f32x8);
+    float a[8];
+    for (int k = 0; k < K && k < 8; ++k) a[k] = aux[(b*K + k)*HW + px];
+    f32x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = o*8 + j;
+      float t = 0.f;
+      if (c < C) {
+        t = v[j] + (bias ? bias[c] : 0.f);
+        for (int k = 0; k < K && k < 8; ++k) t = fmaf(w[c*K + k], a[k], t);
+        t *= out_scale;
+      }
+      r[j] = t;
+    }
+    *reinterpret_cast<h8*>(y + b*HW*Cs + i*8) = __builtin_convertvector(r, h8);
+  }
+}
+
+dim3 nh_grid(long long n, long long b) {
+  long long g = (n + 255)/256;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  return dim3((unsigned)g, (unsigned)b);
+}
+
+}  // namespace
+
+extern "C" {
+
+int brv_nchw_to_nhwc_f16(const float* x, void* y, int64_t B, int64_t C, int64_t Cs, int64_t HW,
+                         brv_stream_t stream) {
+  if (B < 1 || C < 1 || Cs < C || (Cs & 7) || HW < 1) return -1;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((HW + 255)/256), (unsigned)(Cs/8), (unsigned)B),
+                     dim3(256), 0, (hipStream_t)stream, x, (_Float16*)y, (int)C, (int)Cs, (long long)HW);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_f16_to_nchw(const void* x, float* y, int64_t B, int64_t C, int64_t Cs, int64_t HW,
+                         brv_stream_t stream) {
+  if (B < 1 || C < 1 || Cs < C || (Cs & 7) || HW < 1) return -1;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((HW + 255)/256), (unsigned)((C + 7)/8), (unsigned)B),
+                     dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, y, (int)C, (int)Cs, (long long)HW);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_chan_stats(const void* x, double* sums, int64_t B, int64_t C, int64_t Cs, int64_t HW,
+                        int64_t c_off, int64_t Ctot, brv_stream_t stream) {
+  if (B < 1 || C < 1 || Cs < C || (Cs & 7) || Cs > 2048 || HW < 1 || c_off < 0 || c_off + C > Ctot) return -1;
+  const int oct = (int)(Cs/8), lanes = 256/oct;
+  long long slice = (long long)lanes*64;            // <= 64 pixels per thread
+  const long long min_slice = (HW + 1023)/1024;     // <= 1024 workgroups per item
+  if (slice < min_slice) slice = min_slice;
+  const unsigned ns = (unsigned)((HW + slice - 1)/slice);
+  hipLaunchKernelGGL(chan_stats_kernel, dim3(ns, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)x, sums, (int)C, (int)Cs, (long long)HW, (int)c_off, (int)Ctot,
+                     slice);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_groupnorm_fold_chan(const double* sums, const float* add_bc, const float* gamma,
+                            const float* beta, const float* adm_scale, const float* adm_shift,
+                            float* scale_bc, float* shift_bc, int64_t B, int64_t C, int64_t HW,
+                            int64_t groups, float eps, brv_stream_t stream) {
+  if (B < 1 || C < 1 || groups < 1 || C % groups || HW < 1) return -1;
+  hipLaunchKernelGGL(chan_fold_kernel, dim3((unsigned)(B*groups)), dim3(64), 0, (hipStream_t)stream,
+                     sums, add_bc, gamma, beta, adm_scale, adm_shift, scale_bc, shift_bc, (int)C,
+                     (long long)HW, (int)groups, eps);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_affine_act(const void* x, const float* scale_bc, const float* shift_bc, void* y,
+                        int64_t B, int64_t C, int64_t Cs, int64_t HW, int act, brv_stream_t stream) {
+  if (B < 1 || C < 1 || Cs < C || (Cs & 7) || HW < 1) return -1;
+  hipLaunchKernelGGL(nhwc_affine_act_kernel, nh_grid(HW*(Cs/8), B), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)x, scale_bc, shift_bc, (_Float16*)y, (int)C, (int)Cs,
+                     (long long)HW, act);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_fir_resample2d(const void* x, const float* kernel, void* y, int64_t B, int64_t Cs,
+                            int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t K, int64_t pad_h,
+                            int64_t pad_w, int up, float gain, brv_stream_t stream) {
+  if (B < 1 || (Cs & 7) || Cs < 8 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || K < 1) return -1;
+  const dim3 grid = nh_grid(Ho*Wo*(Cs/8), B);
+  if (up)
+    hipLaunchKernelGGL(nhwc_fir_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)x, kernel, (_Float16*)y, (int)Cs, (int)H, (int)W, (int)Ho,
+                       (int)Wo, (int)K, (int)pad_h, (int)pad_w, gain);
+  else
+    hipLaunchKernelGGL(nhwc_fir_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)x, kernel, (_Float16*)y, (int)Cs, (int)H, (int)W, (int)Ho,
+                       (int)Wo, (int)K, (int)pad_h, (int)pad_w, gain);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_axpby(const void* a, float alpha, const void* b, float beta, void* out, int64_t n,
+                   brv_stream_t stream) {
+  if (n < 0 || (n & 7)) return -1;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(nhwc_axpby_kernel, nh_grid(n/8, 1), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)a, alpha, (const _Float16*)b, beta, (_Float16*)out,
+                     (long long)(n/8));
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int64_t brv_nhwc_conv1x1_packed_size(int64_t Cout, int64_t C1, int64_t C2) {
+  if (Cout < 1 || C1 < 1 || C2 < 0) return -1;
+  return ((Cout + 127)/128)*128*(((C1 + 15)/16) + ((C2 + 15)/16))*16;
+}
+
+int brv_nhwc_conv1x1_pack(const float* w, void* wp, int64_t Cout, int64_t C1, int64_t C2,
+                          brv_stream_t stream) {
+  const int64_t total = brv_nhwc_conv1x1_packed_size(Cout, C1, C2);
+  if (total < 0) return -1;
+  long long g = (total + 255)/256;
+  if (g > 4096) g = 4096;
+  const int n_ks1 = (int)((C1 + 15)/16), n_ks = n_ks1 + (int)((C2 + 15)/16);
+  hipLaunchKernelGGL(conv1x1_pack_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, w,
+                     (_Float16*)wp, (int)Cout, (int)C1, (int)C2, n_ks1, n_ks, (long long)total);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_conv1x1_forward(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                             int64_t C2s, const void* wp, const float* bias, void* y, int64_t Cys,
+                             int64_t npx, int64_t Cout, float out_scale, brv_stream_t stream) {
+  if (npx < 1 || C1 < 1 || Cout < 1 || (C1s & 7) || C1 > C1s || (Cys & 7) || Cout > Cys) return -1;
+  if (x2 && (C2 < 1 || (C2s & 7) || C2 > C2s)) return -1;
+  Pw1Params p;
+  p.x1 = (const _Float16*)x1; p.x2 = (const _Float16*)x2; p.wp = (const h8*)wp; p.bias = bias;
+  p.y = (_Float16*)y; p.C1 = (int)C1; p.C1s = (int)C1s; p.C2 = x2 ? (int)C2 : 0; p.C2s = (int)C2s;
+  p.Cout = (int)Cout; p.Cys = (int)Cys;
+  p.n_ks1 = (int)((C1 + 15)/16); p.n_ks = p.n_ks1 + (x2 ? (int)((C2 + 15)/16) : 0);
+  p.npx = npx; p.out_scale = out_scale;
+  hipLaunchKernelGGL(nhwc_conv1x1_kernel, dim3((unsigned)((npx + 127)/128), (unsigned)((Cout + 127)/128)),
+                     dim3(256), 0, (hipStream_t)stream, p);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_conv3x3_small(const void* x, const float* w, const float* bias, const float* scale_bc,
+                           const float* shift_bc, int silu, const float* y_in, float* y, int64_t B,
+                           int64_t C, int64_t Cs, int64_t H, int64_t W, int64_t Cout,
+                           brv_stream_t stream) {
+  if (B < 1 || C < 1 || Cs < C || (Cs & 7) || H < 1 || W < 1 || Cout < 1 || Cout > 8) return -1;
+  SmallCoutParams p;
+  p.x = (const _Float16*)x; p.w = w; p.bias = bias; p.scale = scale_bc; p.shift = shift_bc;
+  p.yin = y_in; p.y = y; p.C = (int)C; p.Cs = (int)Cs; p.Cout = (int)Cout; p.H = (int)H; p.W = (int)W;
+  p.silu = silu;
+  hipLaunchKernelGGL(nhwc_conv3x3_small_kernel, dim3((unsigned)((W + 31)/32), (unsigned)((H + 7)/8), (unsigned)B),
+                     dim3(256), 0, (hipStream_t)stream, p);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_add_pointwise(const void* x, const float* aux, const float* w, const float* bias,
+                           void* y, int64_t B, int64_t C, int64_t Cs, int64_t K, int64_t HW,
+                           float out_scale, brv_stream_t stream) {
+  if (B < 1 || C < 1 || Cs < C || (Cs & 7) || K < 1 || K > 8 || HW < 1) return -1;
+  hipLaunchKernelGGL(nhwc_add_pointwise_kernel, nh_grid(HW*(Cs/8), B), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)x, aux, w, bias, (_Float16*)y, (int)C, (int)Cs, (int)K,
+                     (long long)HW, out_scale);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

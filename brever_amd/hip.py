@@ -201,6 +201,25 @@ SIGNATURES = {
     'brv_conv2d_pack_f16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_conv2d_mfma_forward': (ctypes.c_int, [_c_ptr]*6 + [ctypes.c_int, _c_ptr] + [_c_i64]*8
                                 + [_c_f32, _c_ptr]),
+    'brv_conv_nhwc_packed_size': (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    'brv_conv_nhwc_pack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_conv_nhwc_forward': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr,
+                                             _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, ctypes.c_int,
+                                             _c_ptr] + [_c_i64]*6 + [_c_f32, _c_ptr]),
+    'brv_nchw_to_nhwc_f16': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*4 + [_c_ptr]),
+    'brv_nhwc_f16_to_nchw': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*4 + [_c_ptr]),
+    'brv_nhwc_chan_stats': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*6 + [_c_ptr]),
+    'brv_groupnorm_fold_chan': (ctypes.c_int, [_c_ptr]*8 + [_c_i64]*4 + [_c_f32, _c_ptr]),
+    'brv_nhwc_affine_act': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*4 + [ctypes.c_int, _c_ptr]),
+    'brv_nhwc_fir_resample2d': (ctypes.c_int, [_c_ptr]*3 + [_c_i64]*9 + [ctypes.c_int, _c_f32, _c_ptr]),
+    'brv_nhwc_axpby': (ctypes.c_int, [_c_ptr, _c_f32, _c_ptr, _c_f32, _c_ptr, _c_i64, _c_ptr]),
+    'brv_nhwc_conv1x1_packed_size': (_c_i64, [_c_i64, _c_i64, _c_i64]),
+    'brv_nhwc_conv1x1_pack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_nhwc_conv1x1_forward': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64,
+                                                _c_ptr, _c_ptr, _c_ptr] + [_c_i64]*3 + [_c_f32, _c_ptr]),
+    'brv_nhwc_conv3x3_small': (ctypes.c_int, [_c_ptr]*5 + [ctypes.c_int, _c_ptr, _c_ptr] + [_c_i64]*6
+                               + [_c_ptr]),
+    'brv_nhwc_add_pointwise': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*5 + [_c_f32, _c_ptr]),
     'brv_si_scale_forward': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*3 + [_c_f32, _c_ptr]),
     'brv_si_scale_backward': (ctypes.c_int, [_c_ptr]*6 + [_c_i64]*3 + [_c_ptr]),
     'brv_ema_update': (ctypes.c_int, [_c_ptr, _c_ptr, _c_f32, _c_i64, _c_ptr]),

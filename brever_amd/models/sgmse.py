@@ -186,6 +186,194 @@ def _axpby(a, alpha, b=None, beta=0.0):
 
 
 # ------------------------------------------------------------------------------------------
+# use_amp, second form: channels-last fp16 activations between the layers (the tensors the
+# reference's fp16 autocast holds there too). ``_Act`` = (B, H, W, Cs) fp16 with C valid channels
+# (Cs = C rounded up to 8, the rest zeros), optionally followed by a second one along the
+# channels (a U-Net skip connection: never copied together, the consumers read both).
+# ------------------------------------------------------------------------------------------
+class _Act:
+    __slots__ = ('t', 'C', 'second', 'sums')
+
+    def __init__(self, t, C, second=None):
+        self.t, self.C, self.second, self.sums = t, C, second, None
+
+    @property
+    def Cs(self):
+        return self.t.shape[3]
+
+    @property
+    def channels(self):
+        return self.C + (self.second.C if self.second is not None else 0)
+
+    @property
+    def hw(self):
+        return self.t.shape[1], self.t.shape[2]
+
+
+def _h_new(B, H, W, C, device):
+    return _Act(torch.empty(B, H, W, -(-C//8)*8, dtype=torch.float16, device=device), C)
+
+
+def _h_from_nchw(x):
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    a = _h_new(B, H, W, C, x.device)
+    hip.check(hip.lib().brv_nchw_to_nhwc_f16(hip.ptr(x), hip.ptr(a.t), B, C, a.Cs, H*W, hip.stream()),
+              'brv_nchw_to_nhwc_f16')
+    return a
+
+
+def _h_to_nchw(a):
+    if a.second is not None:
+        return torch.cat([_h_to_nchw(_Act(a.t, a.C)), _h_to_nchw(a.second)], dim=1)
+    B, H, W, Cs = a.t.shape
+    y = torch.empty(B, a.C, H, W, dtype=torch.float32, device=a.t.device)
+    hip.check(hip.lib().brv_nhwc_f16_to_nchw(hip.ptr(a.t), hip.ptr(y), B, a.C, Cs, H*W, hip.stream()),
+              'brv_nhwc_f16_to_nchw')
+    return y
+
+
+def _h_single(a):
+    """One tensor holding all the channels of ``a`` (a copy only if ``a`` is a concatenation)."""
+    if a.second is None:
+        return a
+    parts = [a.t[..., :a.C], a.second.t[..., :a.second.C]]
+    C = a.channels
+    pad = -(-C//8)*8 - C
+    if pad:
+        parts.append(torch.zeros(*a.t.shape[:3], pad, dtype=torch.float16, device=a.t.device))
+    return _Act(torch.cat(parts, dim=3).contiguous(), C)
+
+
+def _h_sums(a):
+    """Per-channel (sum, sum of squares) over the pixels, (B, C, 2) fp64; kept with the tensor: a
+    skip connection's are computed once, where the encoder normalises it."""
+    if a.sums is None:
+        B, H, W, Cs = a.t.shape
+        a.sums = torch.zeros(B, a.C, 2, dtype=torch.float64, device=a.t.device)
+        hip.check(hip.lib().brv_nhwc_chan_stats(hip.ptr(a.t), hip.ptr(a.sums), B, a.C, Cs, H*W, 0, a.C,
+                                                hip.stream()), 'brv_nhwc_chan_stats')
+    return a.sums
+
+
+def _h_gn_fold(a, mod, add=None, adm=None):
+    """GroupNorm(a + add[:, :, None, None]) [then (1 + adm[0])*. + adm[1]] as a per-(item,
+    channel) affine map: (scale, shift), each (B, C)."""
+    sums = _h_sums(a)
+    if a.second is not None:
+        sums = torch.cat([sums, _h_sums(a.second)], dim=1).contiguous()
+    B, (H, W), C = a.t.shape[0], a.hw, a.channels
+    scale = torch.empty(B, C, dtype=torch.float32, device=a.t.device)
+    shift = torch.empty_like(scale)
+    a0, a1 = (adm[0].contiguous(), adm[1].contiguous()) if adm is not None else (None, None)
+    hip.check(hip.lib().brv_groupnorm_fold_chan(
+        hip.ptr(sums), hip.ptr(add.contiguous()) if add is not None else None, hip.ptr(mod.weight),
+        hip.ptr(mod.bias), hip.ptr(a0), hip.ptr(a1), hip.ptr(scale), hip.ptr(shift), B, C, H*W,
+        mod.num_groups, float(mod.eps), hip.stream()), 'brv_groupnorm_fold_chan')
+    return scale, shift
+
+
+def _h_packed3(mod):
+    w = mod.weight
+    key = (w.data_ptr(), w._version)
+    if getattr(mod, '_brv_hp_key', None) != key:
+        Cout, Cin, k, _ = w.shape
+        n = hip.lib().brv_conv_nhwc_packed_size(Cout, Cin, k)
+        wp = torch.empty(n, dtype=torch.float16, device=w.device)
+        hip.check(hip.lib().brv_conv_nhwc_pack(hip.ptr(w.detach().contiguous()), hip.ptr(wp), Cout, Cin,
+                                               k, hip.stream()), 'brv_conv_nhwc_pack')
+        mod._brv_hp, mod._brv_hp_key = wp, key
+    return mod._brv_hp
+
+
+def _h_conv3(a, mod, fold=None, silu=False, res=None, out_scale=1.0):
+    """out_scale*(conv3x3(act(fold(a))) + bias + res) on the fp16 MFMA (brv_conv_nhwc_forward)."""
+    if a.second is not None and a.C % 32:
+        a = _h_single(a)
+    B, (H, W) = a.t.shape[0], a.hw
+    y = _h_new(B, H, W, mod.out_channels, a.t.device)
+    if res is not None:
+        res = _h_single(res)
+    sc, sf = fold if fold is not None else (None, None)
+    b = a.second
+    hip.check(hip.lib().brv_conv_nhwc_forward(
+        hip.ptr(a.t), a.C, a.Cs, hip.ptr(b.t) if b is not None else None, b.C if b is not None else 0,
+        b.Cs if b is not None else 0, hip.ptr(_h_packed3(mod)), hip.ptr(mod.bias),
+        hip.ptr(res.t) if res is not None else None, res.Cs if res is not None else 0, hip.ptr(sc),
+        hip.ptr(sf), int(silu), hip.ptr(y.t), y.Cs, B, H, W, mod.out_channels, 3, float(out_scale),
+        hip.stream()), 'brv_conv_nhwc_forward')
+    return y
+
+
+def _h_conv1(a, mod, out_scale=1.0):
+    """1x1 convolution of [a | a.second] (UNetBlock.skip_conv)."""
+    w = mod.weight
+    b = a.second
+    C2 = b.C if b is not None else 0
+    key = (w.data_ptr(), w._version, a.C, C2)
+    if getattr(mod, '_brv_h1_key', None) != key:
+        n = hip.lib().brv_nhwc_conv1x1_packed_size(mod.out_channels, a.C, C2)
+        wp = torch.empty(n, dtype=torch.float16, device=w.device)
+        hip.check(hip.lib().brv_nhwc_conv1x1_pack(hip.ptr(w.detach().contiguous()), hip.ptr(wp),
+                                                  mod.out_channels, a.C, C2, hip.stream()),
+                  'brv_nhwc_conv1x1_pack')
+        mod._brv_h1, mod._brv_h1_key = wp, key
+    B, (H, W) = a.t.shape[0], a.hw
+    y = _h_new(B, H, W, mod.out_channels, a.t.device)
+    hip.check(hip.lib().brv_nhwc_conv1x1_forward(
+        hip.ptr(a.t), a.C, a.Cs, hip.ptr(b.t) if b is not None else None, C2,
+        b.Cs if b is not None else 0, hip.ptr(mod._brv_h1), hip.ptr(mod.bias), hip.ptr(y.t), y.Cs,
+        B*H*W, mod.out_channels, float(out_scale), hip.stream()), 'brv_nhwc_conv1x1_forward')
+    return y
+
+
+def _h_affine_act(a, fold, silu=False):
+    a = _h_single(a)
+    B, H, W, Cs = a.t.shape
+    y = _Act(torch.empty_like(a.t), a.C)
+    hip.check(hip.lib().brv_nhwc_affine_act(hip.ptr(a.t), hip.ptr(fold[0]), hip.ptr(fold[1]),
+                                            hip.ptr(y.t), B, a.C, Cs, H*W, int(silu), hip.stream()),
+              'brv_nhwc_affine_act')
+    return y
+
+
+def _h_resample(a, resampler, up_or_down):
+    a = _h_single(a)
+    B, H, W, Cs = a.t.shape
+    K = resampler.kernel.shape[-1]
+    padding, (Ho, Wo), up = resampler.plan((H, W), up_or_down)
+    y = _Act(torch.empty(B, Ho, Wo, Cs, dtype=torch.float16, device=a.t.device), a.C)
+    hip.check(hip.lib().brv_nhwc_fir_resample2d(
+        hip.ptr(a.t), hip.ptr(resampler.kernel.float().contiguous()), hip.ptr(y.t), B, Cs, H, W, Ho, Wo,
+        K, padding[0], padding[1], int(up), 4.0 if up else 1.0, hip.stream()), 'brv_nhwc_fir_resample2d')
+    return y
+
+
+def _h_small_conv(a, mod, fold=None, silu=False, y_in=None):
+    """3x3 convolution to <= 8 channels, (B, Cout, H, W) fp32 = [y_in +] conv(act(a)) + bias."""
+    a = _h_single(a)
+    B, H, W, Cs = a.t.shape
+    y = torch.empty(B, mod.out_channels, H, W, dtype=torch.float32, device=a.t.device)
+    sc, sf = fold if fold is not None else (None, None)
+    hip.check(hip.lib().brv_nhwc_conv3x3_small(
+        hip.ptr(a.t), hip.ptr(mod.weight), hip.ptr(mod.bias), hip.ptr(sc), hip.ptr(sf), int(silu),
+        hip.ptr(y_in.contiguous()) if y_in is not None else None, hip.ptr(y), B, a.C, Cs, H, W,
+        mod.out_channels, hip.stream()), 'brv_nhwc_conv3x3_small')
+    return y
+
+
+def _h_add_pointwise(a, aux, mod, out_scale=1.0):
+    """out_scale*(a + conv1x1(aux)), aux (B, K <= 8, H, W) fp32 (AuxiliaryDown)."""
+    a = _h_single(a)
+    B, H, W, Cs = a.t.shape
+    y = _Act(torch.empty_like(a.t), a.C)
+    hip.check(hip.lib().brv_nhwc_add_pointwise(
+        hip.ptr(a.t), hip.ptr(aux.contiguous()), hip.ptr(mod.weight), hip.ptr(mod.bias), hip.ptr(y.t),
+        B, a.C, Cs, mod.in_channels, H*W, float(out_scale), hip.stream()), 'brv_nhwc_add_pointwise')
+    return y
+
+
+# ------------------------------------------------------------------------------------------
 # U-Net (parameter containers in the reference's construction order + HIP forward)
 # ------------------------------------------------------------------------------------------
 class GroupNorm(nn.GroupNorm):
@@ -250,6 +438,11 @@ class AttentionBlock(nn.Module):
                                    L*L, C*L, 0, 1, 1, 0, 0, None, 0, hip.stream()), 'brv_gemm_f32')
         return _conv(a.view(N, C, H, W), self.conv_out, res=x, out_scale=out_scale)
 
+    def forward_h(self, x, out_scale=1.0):
+        # (self-attention sits at the 16-row resolution and in the bottleneck only: a few thousand
+        # pixels, run on the fp32 layout)
+        return _h_from_nchw(self.forward(_h_to_nchw(x), out_scale=out_scale))
+
 
 class UNetBlock(nn.Module):
     def __init__(self, in_channels, out_channels, emb_channels, block_type, skip_scale, dropout,
@@ -294,6 +487,29 @@ class UNetBlock(nn.Module):
             x = self.attn(x, out_scale=self.skip_scale)
         return x
 
+    def forward_h(self, x, emb):
+        """``forward`` on channels-last fp16 activations (``_Act``)."""
+        if self.resampler is not None:
+            h = _h_resample(_h_affine_act(x, _h_gn_fold(x, self.norm_1), silu=True), self.resampler,
+                            self.up_or_down)
+            x = _h_resample(x, self.resampler, self.up_or_down)
+            h = _h_conv3(h, self.conv_1)
+        else:
+            h = _h_conv3(x, self.conv_1, fold=_h_gn_fold(x, self.norm_1), silu=True)
+        e = self._e if self._e is not None else _linear(emb, self.linear)
+        if e.shape[0] != h.t.shape[0]:
+            e = e.expand(h.t.shape[0], -1).contiguous()
+        if self.block_type == 'adm':
+            fold = _h_gn_fold(h, self.norm_2, adm=e.chunk(2, dim=1))
+        else:
+            fold = _h_gn_fold(h, self.norm_2, add=e)
+        if self.skip_conv is not None:
+            x = _h_conv1(x, self.skip_conv)
+        x = _h_conv3(h, self.conv_2, fold=fold, silu=True, res=x, out_scale=self.skip_scale)
+        if self.attn is not None:
+            x = self.attn.forward_h(x, out_scale=self.skip_scale)
+        return x
+
 
 class EncoderBlock(nn.Module):
     def __init__(self, in_channels, out_channels, emb_channels, block_type, num_blocks,
@@ -309,6 +525,13 @@ class EncoderBlock(nn.Module):
     def forward(self, x, emb, skips):
         for i, blk in enumerate(self.unet_blocks):
             x = blk(x, emb)
+            if i != len(self.unet_blocks) - 1:
+                skips.append(x)
+        return x, skips
+
+    def forward_h(self, x, emb, skips):
+        for i, blk in enumerate(self.unet_blocks):
+            x = blk.forward_h(x, emb)
             if i != len(self.unet_blocks) - 1:
                 skips.append(x)
         return x, skips
@@ -334,6 +557,15 @@ class DecoderBlock(nn.Module):
             x = blk(x, emb)
         return x
 
+    def forward_h(self, x, emb, skips):
+        for blk in self.unet_blocks:
+            if blk.resampler is None:
+                x = _h_single(x)
+                x = _Act(x.t, x.C, second=skips.pop())      # torch.cat([x, skip], dim=1), never copied
+                x.sums = None
+            x = blk.forward_h(x, emb)
+        return x
+
 
 class AuxiliaryDown(nn.Module):
     def __init__(self, in_channels, out_channels, resampler, type_, skip_scale):
@@ -350,6 +582,11 @@ class AuxiliaryDown(nn.Module):
         if self.type_ == 'residual':
             aux = x = _axpby(x, self.skip_scale)
         return x, aux
+
+    def forward_h(self, x, aux):
+        """type 'skip': the trunk ``x`` channels-last fp16, the side branch ``aux`` (B, 4, H, W) fp32."""
+        aux = self.resampler(aux, 'down')
+        return _h_add_pointwise(x, aux, self.conv), aux
 
 
 class AuxiliaryUp(nn.Module):
@@ -369,6 +606,12 @@ class AuxiliaryUp(nn.Module):
             aux = h if aux is None else _axpby(aux, 1.0, h, 1.0)
         else:
             x = aux = _axpby(x, 1.0, _conv(aux, self.conv), 1.0)
+        return x, aux
+
+    def forward_h(self, x, aux):
+        if self.resampler is not None:
+            aux = self.resampler(aux, 'up')
+        aux = _h_small_conv(x, self.conv, fold=_h_gn_fold(x, self.norm), silu=True, y_in=aux)
         return x, aux
 
 
@@ -486,7 +729,58 @@ class DiffusionUNet(nn.Module):
         graph.replay()
         return out
 
+    def _nhwc_ok(self):
+        """The channels-last fp16 form covers the 'standard' / 'skip' encoders and decoders whose
+        convolutions have the channel counts its kernels take; anything else runs the fp32-layout
+        form of ``use_amp``."""
+        ok = getattr(self, '_nhwc_ok_cache', None)
+        if ok is None:
+            ok = os.environ.get('BRV_SGMSE_NCHW', '0') != '1'
+            for m in self.modules():
+                if isinstance(m, (AuxiliaryDown, AuxiliaryUp)) and m.type_ != 'skip':
+                    ok = False
+                if isinstance(m, AuxiliaryDown) and (m.conv.kernel_size != (1, 1) or m.conv.in_channels > 8):
+                    ok = False
+                if isinstance(m, AuxiliaryUp) and m.conv.out_channels > 8:
+                    ok = False
+                if isinstance(m, UNetBlock):
+                    for conv in (m.conv_1, m.conv_2):
+                        if conv.out_channels % 4 or conv.in_channels % 32:
+                            ok = False
+            if self.input_conv.out_channels % 4 or self.input_conv.in_channels > 8:
+                ok = False
+            if isinstance(self.output_conv, nn.Conv2d):
+                ok = ok and self.output_conv.kernel_size == (1, 1)
+            else:
+                ok = ok and self.output_conv[1].out_channels <= 8
+            self._nhwc_ok_cache = ok
+        return ok
+
+    def _forward_nhwc(self, x, sigma):
+        emb = self.emb(sigma)
+        self._block_embeddings(emb)
+        aux = x
+        x = _h_conv3(_h_from_nchw(x), self.input_conv)
+        skips = [x]
+        for enc, aux_block in zip(self.encoder, self.aux_downs):
+            x, skips = enc.forward_h(x, emb, skips)
+            if aux_block is not None:
+                x, aux = aux_block.forward_h(x, aux)
+            skips.append(x)
+        x = self.bottleneck_block_1.forward_h(x, emb)
+        x = self.bottleneck_block_2.forward_h(x, emb)
+        aux = None
+        for dec, aux_block in zip(self.decoder, self.aux_ups):
+            x = dec.forward_h(x, emb, skips)
+            if aux_block is not None:
+                x, aux = aux_block.forward_h(x, aux)
+        if isinstance(self.output_conv, nn.Conv2d):
+            return _conv(aux, self.output_conv)
+        return _h_small_conv(x, self.output_conv[1], fold=_h_gn_fold(x, self.output_conv[0]))
+
     def _forward_impl(self, x, sigma):
+        if _STATE['amp'] and self._nhwc_ok():
+            return self._forward_nhwc(x, sigma)
         emb = self.emb(sigma)
         self._block_embeddings(emb)
         aux = x

@@ -540,6 +540,65 @@ int brv_conv2d_mfma_forward(const float* x, const void* wp, const float* bias, c
                             int64_t ksize, int64_t x_batch_stride, int64_t y_batch_stride,
                             float out_scale, brv_stream_t stream);
 
+/* ---- SGMSE+ score network under use_amp, channels-last fp16 activations ------------------------
+ * The reference runs the score network under fp16 autocast (models/sgmse/sgmse.py:190-193): the
+ * tensors between its convolutions are fp16 there too. Here they are (B, H, W, Cs) fp16, Cs a
+ * multiple of 8, channels >= C zero; the 4-channel progressive branch and the network's input /
+ * output stay (B, C, H, W) fp32.
+ * brv_conv_nhwc_forward: 3x3 stride-1 "same" convolution (UNetBlock.conv_1 / conv_2, net.py:352-422)
+ *   on the fp16 MFMA, fp32 accumulation: y = out_scale*(conv(act([x1 | x2])) + bias + res), act =
+ *   silu?(in_scale[b][ci]*x + in_shift[b][ci]) when in_scale is given (a GroupNorm folded by
+ *   brv_groupnorm_fold_chan; needs Cin % 32 == 0), x2 (nullable) = a second tensor concatenated
+ *   along the channels (the U-Net's skip connections, net.py:330-335; needs C1 % 32 == 0);
+ *   wp from brv_conv_nhwc_pack. Cout % 4 == 0, channel strides % 8 == 0.
+ * brv_nhwc_conv1x1_*: UNetBlock.skip_conv on [x1 | x2].
+ * brv_nhwc_chan_stats: sums[b][c_off + c][0..1] += per-channel (sum, sum of squares) over the
+ *   pixels (fp64; clear `sums` (B, Ctot, 2) first); brv_groupnorm_fold_chan: GroupNorm of x +
+ *   add_bc reduced to scale / shift (B, C) from those sums (same arithmetic as brv_groupnorm_fold).
+ * brv_nhwc_affine_act / _fir_resample2d / _axpby: the channels-last forms of brv_affine_act,
+ *   brv_fir_resample2d, brv_axpby. brv_nhwc_conv3x3_small: 3x3 convolution to <= 8 channels,
+ *   (B, Cout, H, W) fp32 out = [y_in +] conv(act(x)) + bias (AuxiliaryUp.conv, the output
+ *   convolution; net.py:455-477). brv_nhwc_add_pointwise: y = out_scale*(x + bias + W aux), aux
+ *   (B, K <= 8, HW) fp32 (AuxiliaryDown, net.py:425-452). */
+int64_t brv_conv_nhwc_packed_size(int64_t Cout, int64_t Cin, int64_t ksize);
+int brv_conv_nhwc_pack(const float* w, void* wp, int64_t Cout, int64_t Cin, int64_t ksize,
+                       brv_stream_t stream);
+int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                          int64_t C2s, const void* wp, const float* bias, const void* res,
+                          int64_t Crs, const float* in_scale, const float* in_shift, int in_silu,
+                          void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout,
+                          int64_t ksize, float out_scale, brv_stream_t stream);
+int brv_nchw_to_nhwc_f16(const float* x, void* y, int64_t B, int64_t C, int64_t Cs, int64_t HW,
+                         brv_stream_t stream);
+int brv_nhwc_f16_to_nchw(const void* x, float* y, int64_t B, int64_t C, int64_t Cs, int64_t HW,
+                         brv_stream_t stream);
+int brv_nhwc_chan_stats(const void* x, double* sums, int64_t B, int64_t C, int64_t Cs, int64_t HW,
+                        int64_t c_off, int64_t Ctot, brv_stream_t stream);
+int brv_groupnorm_fold_chan(const double* sums, const float* add_bc, const float* gamma,
+                            const float* beta, const float* adm_scale, const float* adm_shift,
+                            float* scale_bc, float* shift_bc, int64_t B, int64_t C, int64_t HW,
+                            int64_t groups, float eps, brv_stream_t stream);
+int brv_nhwc_affine_act(const void* x, const float* scale_bc, const float* shift_bc, void* y,
+                        int64_t B, int64_t C, int64_t Cs, int64_t HW, int act, brv_stream_t stream);
+int brv_nhwc_fir_resample2d(const void* x, const float* kernel, void* y, int64_t B, int64_t Cs,
+                            int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t K, int64_t pad_h,
+                            int64_t pad_w, int up, float gain, brv_stream_t stream);
+int brv_nhwc_axpby(const void* a, float alpha, const void* b, float beta, void* out, int64_t n,
+                   brv_stream_t stream);
+int64_t brv_nhwc_conv1x1_packed_size(int64_t Cout, int64_t C1, int64_t C2);
+int brv_nhwc_conv1x1_pack(const float* w, void* wp, int64_t Cout, int64_t C1, int64_t C2,
+                          brv_stream_t stream);
+int brv_nhwc_conv1x1_forward(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                             int64_t C2s, const void* wp, const float* bias, void* y, int64_t Cys,
+                             int64_t npx, int64_t Cout, float out_scale, brv_stream_t stream);
+int brv_nhwc_conv3x3_small(const void* x, const float* w, const float* bias, const float* scale_bc,
+                           const float* shift_bc, int silu, const float* y_in, float* y, int64_t B,
+                           int64_t C, int64_t Cs, int64_t H, int64_t W, int64_t Cout,
+                           brv_stream_t stream);
+int brv_nhwc_add_pointwise(const void* x, const float* aux, const float* w, const float* bias,
+                           void* y, int64_t B, int64_t C, int64_t Cs, int64_t K, int64_t HW,
+                           float out_scale, brv_stream_t stream);
+
 /* ---- pieces of MultiResYuLoss (criterion.py:135-226) ----------------------------
  * brv_apply_mask: out = x with samples >= lengths[b] zeroed (apply_mask, :229-234),
  *   x/out (B, S, L). brv_l1_*: sums[r] = sum |x - y| over n samples of row r (fp64) and

@@ -1304,6 +1304,97 @@ def test_sgmse_building_blocks_match_torch():
 
 
 @pytest.mark.gpu
+def test_sgmse_channels_last_kernels_match_torch():
+    """The channels-last fp16 kernels of the use_amp score network one by one against torch fp32 on
+    the CPU: layout round trip, the 3x3 MFMA convolution with every fusion (folded GroupNorm +
+    embedding + SiLU on the way in, bias + residual + scale on the way out, two concatenated
+    inputs, ragged sizes, several tiles per workgroup), 1x1 convolution of a concatenation,
+    per-channel statistics -> fold (vs nn.GroupNorm), FIR resampling, the few-channel 3x3
+    convolution and the pointwise side-branch add. fp16 storage: rel-L2 <= 2e-3."""
+    import torch.nn.functional as F
+
+    from brever_amd.models import sgmse as M
+    dev = _cuda()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 20, 9, 11, generator=g)
+    a = M._h_from_nchw(x.to(dev))
+    assert a.t.shape == (2, 9, 11, 24) and a.t.dtype == torch.float16
+    assert float(a.t[..., 20:].abs().max()) == 0.0
+    assert rel(M._h_to_nchw(a), x.half().float()) == 0.0
+    # 3x3 convolutions
+    for (c1, c2, co, H, W, B) in ((32, 0, 128, 16, 32, 1), (64, 32, 136, 17, 33, 2), (96, 64, 256, 8, 16, 3),
+                                  (128, 0, 128, 64, 126, 1), (128, 128, 128, 40, 70, 9)):
+        ci = c1 + c2
+        conv = torch.nn.Conv2d(ci, co, 3, 1, 1)
+        gn = M.GroupNorm(ci)
+        with torch.no_grad():
+            gn.weight.add_(0.2*torch.randn(ci, generator=g)); gn.bias.add_(0.2*torch.randn(ci, generator=g))
+        xx = torch.randn(B, ci, H, W, generator=g) + 0.5
+        ee = torch.randn(B, ci, generator=g)
+        rr = torch.randn(B, co, H, W, generator=g)
+        xh, rh = xx.half().float(), rr.half().float()
+        ref = 0.7*(conv(F.silu(gn(xh + ee[:, :, None, None]))) + rh).detach()
+        ref_plain = conv(xh).detach()
+        conv, gn = conv.to(dev), gn.to(dev)
+        act = M._h_from_nchw(xx[:, :c1].to(dev))
+        if c2:
+            act = M._Act(act.t, act.C, second=M._h_from_nchw(xx[:, c1:].to(dev)))
+        fold = M._h_gn_fold(act, gn, add=ee.to(dev))
+        want_fold = M._gn_fold(xh.to(dev), gn, add=ee.to(dev))
+        assert rel(fold[0], want_fold[0]) <= 1e-5 and rel(fold[1], want_fold[1]) <= 1e-4
+        got = M._h_conv3(act, conv, fold=fold, silu=True, res=M._h_from_nchw(rr.to(dev)), out_scale=0.7)
+        assert rel(M._h_to_nchw(got), ref) <= 2e-3, (c1, c2, co, rel(M._h_to_nchw(got), ref))
+        assert rel(M._h_to_nchw(M._h_conv3(act, conv)), ref_plain) <= 2e-3
+        # 1x1 on the same (concatenated) input
+        c1x1 = torch.nn.Conv2d(ci, co, 1)
+        ref1 = 0.5*c1x1(xh).detach()
+        assert rel(M._h_to_nchw(M._h_conv1(act, c1x1.to(dev), out_scale=0.5)), ref1) <= 2e-3
+        # GroupNorm + SiLU as its own pass
+        if not c2:
+            fold0 = M._h_gn_fold(act, gn)
+            refn = F.silu(gn.cpu()(xh)).detach()
+            assert rel(M._h_to_nchw(M._h_affine_act(act, fold0, silu=True)), refn) <= 2e-3
+    # the input convolution: 4 channels padded to 8
+    conv = torch.nn.Conv2d(4, 128, 3, 1, 1)
+    xx = torch.randn(2, 4, 40, 45, generator=g)
+    ref = conv(xx.half().float()).detach()
+    assert rel(M._h_to_nchw(M._h_conv3(M._h_from_nchw(xx.to(dev)), conv.to(dev))), ref) <= 2e-3
+    # FIR resampling with the reference's padding stack
+    for fir in ([1, 3, 3, 1], [1, 1]):
+        rs = M.Resample(fir, buffer_padding=True)
+        kern = rs.kernel.clone()
+        rs = rs.to(dev)
+        for H, W in ((13, 7), (8, 10)):
+            xx = torch.randn(2, 24, H, W, generator=g)
+            K = kern.shape[-1]
+            pad = tuple(-(-K//2) - 1 if d % 2 == 0 else -(-(K + 1)//2) - 1 for d in (H, W))
+            opad = tuple((d + 2*p - K) % 2 for d, p in zip((H, W), pad))
+            down_ref = F.conv2d(xx.half().float(), kern.tile([24, 1, 1, 1]), padding=pad, groups=24, stride=2)
+            down = M._h_resample(M._h_from_nchw(xx.to(dev)), rs, 'down')
+            assert rel(M._h_to_nchw(down), down_ref) <= 1e-3
+            up_ref = F.conv_transpose2d(M._h_to_nchw(down).cpu(), 4*kern.tile([24, 1, 1, 1]), padding=pad,
+                                        output_padding=opad, groups=24, stride=2)
+            up = M._h_resample(down, rs, 'up')
+            assert up.t.shape[1:3] == (H, W) and rel(M._h_to_nchw(up), up_ref) <= 1e-3
+    # few-channel 3x3 convolution (progressive output branch) and the pointwise add of the input branch
+    for ci, co in ((128, 4), (96, 2)):
+        conv = torch.nn.Conv2d(ci, co, 3, 1, 1)
+        gn = M.GroupNorm(ci)
+        xx = torch.randn(2, ci, 19, 37, generator=g)
+        yin = torch.randn(2, co, 19, 37, generator=g)
+        ref = (yin + conv(F.silu(gn(xx.half().float())))).detach()
+        act = M._h_from_nchw(xx.to(dev))
+        got = M._h_small_conv(act, conv.to(dev), fold=M._h_gn_fold(act, gn.to(dev)), silu=True,
+                              y_in=yin.to(dev))
+        assert rel(got, ref) <= 2e-3, rel(got, ref)
+    pw = torch.nn.Conv2d(4, 128, 1)
+    xx, aux = torch.randn(2, 128, 9, 11, generator=g), torch.randn(2, 4, 9, 11, generator=g)
+    ref = 0.7*(xx.half().float() + pw(aux)).detach()
+    got = M._h_add_pointwise(M._h_from_nchw(xx.to(dev)), aux.to(dev), pw.to(dev), out_scale=0.7)
+    assert rel(M._h_to_nchw(got), ref) <= 1e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('tag', ['pc', 'edm', 'res'])
 def test_sgmse_matches_reference(golden_dir, tag):
     """HIP SGMSE+ vs the oracle and the reference golden at seeded weights: the preconditioned
