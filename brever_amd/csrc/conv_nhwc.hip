@@ -72,6 +72,7 @@ struct ConvNhwcParams {
   const float* bias; const _Float16* res; _Float16* y;
   const float* in_scale; const float* in_shift;   // (B, Cin) each (FOLD only)
   const unsigned char* zeros;                 // >= 16 bytes of zeros
+  double* stats;                              // nullable (B, Cout, 2): += per-channel (sum, sum of squares) of y
   int B, H, W, C1s, C2s, n_chunks1, n_chunks, Cin, Cout, Cys, Crs;
   int n_wt, n_ht, n_cob, n_tiles;
   float out_scale; int in_silu;
@@ -394,6 +395,10 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
     float bv[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { bv[j] = __uint_as_float(b0[j]); bv[4 + j] = __uint_as_float(b1[j]); }
+    // per-channel statistics of the stored values (the next GroupNorm's): 16 pixels per thread
+    float st_s[8], st_q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
 #pragma unroll
     for (int pf = 0; pf < 4; ++pf) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -441,6 +446,11 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (af[j] + bv[j] + rf[j])*p.out_scale;
         const h8 o = __builtin_convertvector(v, h8);
+        if (p.stats && ok[it]) {
+          const f32x8 w = __builtin_convertvector(o, f32x8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { st_s[j] += w[j]; st_q[j] = fmaf(w[j], w[j], st_q[j]); }
+        }
         if (ok[it]) {
           if (co + 8 <= p.Cout) *reinterpret_cast<h8*>(yb + pix[it]*p.Cys + co) = o;
           else {
@@ -457,6 +467,41 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
     if (blockIdx.x == 0 && lane == 0)
       for (int a = 0; a < 13; ++a) p.dbg[300 + wave*13 + a] = es[a];
 #endif
+    if (p.stats) {
+      // threads tv, tv + 16, ... hold the same 8 channels: [32 threads][16 octets][16 values] in
+      // the staging buffer, then one fp64 atomic per (channel, moment) and tile
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const unsigned int sa = stg + ((tv >> 4)*16 + c8)*64;
+      u32x4 w0, w1, w2, w3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w0[j] = __float_as_uint(st_s[j]); w1[j] = __float_as_uint(st_s[4 + j]);
+        w2[j] = __float_as_uint(st_q[j]); w3[j] = __float_as_uint(st_q[4 + j]);
+      }
+      cn_write16(sa, w0); cn_write16(sa + 16, w1); cn_write16(sa + 32, w2); cn_write16(sa + 48, w3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tv < 256) {
+        const int oc = tv >> 4, k = tv & 15;            // octet, value (0-7 sums, 8-15 squares)
+        double a = 0.0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          unsigned int u[16];
+#pragma unroll
+          for (int l = 0; l < 16; ++l)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(u[l]) : "v"(stg + (((half*16 + l)*16 + oc)*16 + k)*4) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]),
+                         "+v"(u[8]), "+v"(u[9]), "+v"(u[10]), "+v"(u[11]), "+v"(u[12]), "+v"(u[13]), "+v"(u[14]), "+v"(u[15])
+                       :: "memory");
+#pragma unroll
+          for (int l = 0; l < 16; ++l) a += (double)__uint_as_float(u[l]);
+        }
+        const int ch = q.cob*128 + oc*8 + (k & 7);
+        if (ch < p.Cout) atomicAdd(&p.stats[(((long long)q.b*p.Cout + ch) << 1) + (k >> 3)], a);
+      }
+    }
   };
 
   // ---- prologue: chunk 0 of the first tile + the first CN_DA taps of weights
@@ -692,7 +737,7 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
                           int64_t C2s, const void* wp, const float* bias, const void* res,
                           int64_t Crs, const float* in_scale, const float* in_shift, int in_silu,
                           void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout,
-                          int64_t ksize, float out_scale, brv_stream_t stream) {
+                          int64_t ksize, float out_scale, double* stats, brv_stream_t stream) {
   if (B < 1 || H < 1 || W < 1 || C1 < 1 || Cout < 1 || ksize != 3) return -1;
   if ((C1s & 7) || C1 > C1s || (Cys & 7) || (res && (Crs & 7)) || (Cout & 3)) return -2;
   if (x2 && ((C2s & 7) || C2 > C2s || C2 < 1 || (C1 % CN_CK) != 0)) return -2;
@@ -707,7 +752,7 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
   ConvNhwcParams p;
   p.x1 = (const _Float16*)x1; p.x2 = (const _Float16*)x2; p.wp = (const unsigned char*)wp;
   p.bias = bias; p.res = (const _Float16*)res; p.y = (_Float16*)y;
-  p.in_scale = in_scale; p.in_shift = in_shift; p.zeros = zeros;
+  p.in_scale = in_scale; p.in_shift = in_shift; p.zeros = zeros; p.stats = stats;
   p.B = (int)B; p.H = (int)H; p.W = (int)W; p.C1s = (int)C1s; p.C2s = (int)C2s;
   p.n_chunks1 = (int)((C1 + CN_CK - 1)/CN_CK);
   p.n_chunks = p.n_chunks1 + (x2 ? (int)((C2 + CN_CK - 1)/CN_CK) : 0);

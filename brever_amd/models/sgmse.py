@@ -245,12 +245,26 @@ def _h_single(a):
     return _Act(torch.cat(parts, dim=3).contiguous(), C)
 
 
+_ZERO_POOL = {'buf': None, 'off': 0}
+
+
+def _zeros_f64(n, device):
+    """n zeroed doubles out of a pooled arena (one fill per ~100 requests instead of one each)."""
+    pool = _ZERO_POOL
+    if pool['buf'] is None or pool['buf'].device != device or pool['off'] + n > pool['buf'].numel():
+        pool['buf'] = torch.zeros(max(1 << 18, 4*n), dtype=torch.float64, device=device)
+        pool['off'] = 0
+    out = pool['buf'][pool['off']:pool['off'] + n]
+    pool['off'] += n
+    return out
+
+
 def _h_sums(a):
     """Per-channel (sum, sum of squares) over the pixels, (B, C, 2) fp64; kept with the tensor: a
     skip connection's are computed once, where the encoder normalises it."""
     if a.sums is None:
         B, H, W, Cs = a.t.shape
-        a.sums = torch.zeros(B, a.C, 2, dtype=torch.float64, device=a.t.device)
+        a.sums = _zeros_f64(B*a.C*2, a.t.device).view(B, a.C, 2)
         hip.check(hip.lib().brv_nhwc_chan_stats(hip.ptr(a.t), hip.ptr(a.sums), B, a.C, Cs, H*W, 0, a.C,
                                                 hip.stream()), 'brv_nhwc_chan_stats')
     return a.sums
@@ -292,6 +306,7 @@ def _h_conv3(a, mod, fold=None, silu=False, res=None, out_scale=1.0):
         a = _h_single(a)
     B, (H, W) = a.t.shape[0], a.hw
     y = _h_new(B, H, W, mod.out_channels, a.t.device)
+    y.sums = _zeros_f64(B*mod.out_channels*2, a.t.device).view(B, mod.out_channels, 2)
     if res is not None:
         res = _h_single(res)
     sc, sf = fold if fold is not None else (None, None)
@@ -301,7 +316,7 @@ def _h_conv3(a, mod, fold=None, silu=False, res=None, out_scale=1.0):
         b.Cs if b is not None else 0, hip.ptr(_h_packed3(mod)), hip.ptr(mod.bias),
         hip.ptr(res.t) if res is not None else None, res.Cs if res is not None else 0, hip.ptr(sc),
         hip.ptr(sf), int(silu), hip.ptr(y.t), y.Cs, B, H, W, mod.out_channels, 3, float(out_scale),
-        hip.stream()), 'brv_conv_nhwc_forward')
+        hip.ptr(y.sums), hip.stream()), 'brv_conv_nhwc_forward')
     return y
 
 
@@ -757,6 +772,7 @@ class DiffusionUNet(nn.Module):
         return ok
 
     def _forward_nhwc(self, x, sigma):
+        _ZERO_POOL['buf'] = None       # the arena is cleared inside this evaluation (and its HIP graph)
         emb = self.emb(sigma)
         self._block_embeddings(emb)
         aux = x

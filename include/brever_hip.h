@@ -550,7 +550,9 @@ int brv_conv2d_mfma_forward(const float* x, const void* wp, const float* bias, c
  *   silu?(in_scale[b][ci]*x + in_shift[b][ci]) when in_scale is given (a GroupNorm folded by
  *   brv_groupnorm_fold_chan; needs Cin % 32 == 0), x2 (nullable) = a second tensor concatenated
  *   along the channels (the U-Net's skip connections, net.py:330-335; needs C1 % 32 == 0);
- *   wp from brv_conv_nhwc_pack. Cout % 4 == 0, channel strides % 8 == 0.
+ *   wp from brv_conv_nhwc_pack. Cout % 4 == 0, channel strides % 8 == 0. stats (nullable, (B, Cout,
+ *   2) fp64, cleared by the caller) += per-channel (sum, sum of squares) of y: the statistics of
+ *   the next GroupNorm come out of the producing convolution's epilogue.
  * brv_nhwc_conv1x1_*: UNetBlock.skip_conv on [x1 | x2].
  * brv_nhwc_chan_stats: sums[b][c_off + c][0..1] += per-channel (sum, sum of squares) over the
  *   pixels (fp64; clear `sums` (B, Ctot, 2) first); brv_groupnorm_fold_chan: GroupNorm of x +
@@ -567,7 +569,7 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
                           int64_t C2s, const void* wp, const float* bias, const void* res,
                           int64_t Crs, const float* in_scale, const float* in_shift, int in_silu,
                           void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout,
-                          int64_t ksize, float out_scale, brv_stream_t stream);
+                          int64_t ksize, float out_scale, double* stats, brv_stream_t stream);
 int brv_nchw_to_nhwc_f16(const float* x, void* y, int64_t B, int64_t C, int64_t Cs, int64_t HW,
                          brv_stream_t stream);
 int brv_nhwc_f16_to_nchw(const void* x, float* y, int64_t B, int64_t C, int64_t Cs, int64_t HW,

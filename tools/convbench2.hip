@@ -43,10 +43,12 @@ static int run_case(const Case& c, bool check, int iters) {
   const long long np = brv_conv_nhwc_packed_size(c.Cout, Cin, 3);
   CK(hipMalloc(&wp, np*2));
   if (brv_conv_nhwc_pack(w, wp, c.Cout, Cin, 3, 0)) { printf("pack failed\n"); exit(1); }
+  double* stats = nullptr;
+  CK(hipMalloc(&stats, (size_t)c.B*c.Cout*16)); CK(hipMemset(stats, 0, (size_t)c.B*c.Cout*16));
   auto launch = [&]() {
     return brv_conv_nhwc_forward(x1, c.C1, c.C1s, x2, c.C2, c.C2s, wp, c.bias ? b : nullptr, res, c.Cout,
                                  c.fold ? sc : nullptr, c.fold ? sh : nullptr, c.silu, y, c.Cout, c.B,
-                                 c.H, c.W, c.Cout, 3, c.scale, 0);
+                                 c.H, c.W, c.Cout, 3, c.scale, stats, 0);
   };
   int rc = launch();
   if (rc) { printf("launch rc %d\n", rc); exit(1); }
@@ -69,6 +71,20 @@ static int run_case(const Case& c, bool check, int iters) {
           }
           act[pi*Cin + k] = v;
         }
+    std::vector<double> hst((size_t)c.B*c.Cout*2);
+    CK(hipMemcpy(hst.data(), stats, hst.size()*8, hipMemcpyDeviceToHost));
+    {
+      double werr = 0.0;
+      for (int bb = 0; bb < c.B; ++bb)
+        for (int co = 0; co < c.Cout; ++co) {
+          double s1 = 0.0, s2 = 0.0;
+          for (size_t i = 0; i < (size_t)c.H*c.W; ++i) { const double v = (float)hy[((size_t)bb*c.H*c.W + i)*c.Cout + co]; s1 += v; s2 += v*v; }
+          const double e1 = fabs(hst[((size_t)bb*c.Cout + co)*2] - s1)/(1.0 + fabs(s1)), e2 = fabs(hst[((size_t)bb*c.Cout + co)*2 + 1] - s2)/(1.0 + s2);
+          if (e1 > werr) werr = e1; if (e2 > werr) werr = e2;
+        }
+      printf("  stats worst rel err %.2e\n", werr);
+      if (!(werr < 1e-4)) ++bad;
+    }
     double worst = 0.0;
     std::vector<int> badmap((size_t)c.B*c.H*c.W, 0);
     for (int bb = 0; bb < c.B; ++bb)
@@ -131,7 +147,7 @@ static int run_case(const Case& c, bool check, int iters) {
     printf("time abl %2d B%d %dx%d %d(+%d)->%d fold%d res%d: %8.1f us %7.1f TFLOP/s (%.1f%% of 2.5 PF)\n", CN_ABL, c.B, c.H, c.W, c.C1, c.C2,
            c.Cout, c.fold, c.res, us, fl/us/1e6, fl/us/1e6/25.0);
   }
-  hipFree(x1); if (x2) hipFree(x2); if (res) hipFree(res); hipFree(y); hipFree(w); hipFree(b); hipFree(sc); hipFree(sh); hipFree(wp);
+  hipFree(stats); hipFree(x1); if (x2) hipFree(x2); if (res) hipFree(res); hipFree(y); hipFree(w); hipFree(b); hipFree(sc); hipFree(sh); hipFree(wp);
   return bad;
 }
 
