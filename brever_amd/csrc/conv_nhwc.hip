@@ -50,7 +50,7 @@ typedef __attribute__((address_space(3))) void* cn_lds_p;
 typedef __attribute__((address_space(1))) const void* cn_glb_p;
 
 constexpr int CN_WAVES = 8, CN_THREADS = 64*CN_WAVES;
-constexpr int CN_ROWS = 16, CN_COLS = 32;     // output pixels of a tile
+constexpr int CN_COLS = 32;                   // output columns of a tile (rows: 4*PF)
 constexpr int CN_CK = 32;                     // input channels per chunk (2 k-steps)
 #ifndef CN_DA
 #define CN_DA 4                               // the weight stream runs this many taps ahead
@@ -160,14 +160,19 @@ struct CnSched {
   static constexpr int piece(int tp) { return ops(tp - 2) + ops(tp - 1) + ops(tp); }
 };
 
-template <int KS, bool FOLD>
+// PF = accumulator rows per wave: the tile is (4*PF rows) x 32 columns x 128 channels. PF = 4 for
+// images with enough tiles to fill the chip; smaller PF gives small images 2-4x the workgroups
+// (each still streams all the weights: their taps are then paced by the DMA, not the MFMAs).
+template <int KS, bool FOLD, int PF>
 __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcParams p) {
   static_assert(KS == 3, "3x3 only");
+  constexpr int CN_ROWS = 4*PF;
   constexpr int TAPS = KS*KS, PADK = KS/2;
   constexpr int PR = CN_ROWS + KS - 1, PC = CN_COLS + KS - 1;
   constexpr int NSLOT = PR*PC*4;
   constexpr int ROUNDS = (NSLOT + CN_THREADS - 1)/CN_THREADS;
-  constexpr int PBYTES = ROUNDS*CN_THREADS*16;
+  // (a patch buffer doubles as the epilogue's staging area: 128 pixel rows of 272 bytes)
+  constexpr int PBYTES = ROUNDS*CN_THREADS*16 > 35*1024 ? ROUNDS*CN_THREADS*16 : 35*1024;
   constexpr int OFF_A = 2*PBYTES;
   constexpr int OFF_TAB = OFF_A + CN_NA*CN_ASLOT;
   constexpr int SMEM = OFF_TAB + 2*CN_WAVES*CN_TAB;
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
   };
 
   // ---- fragment reads
-  // B fragment of (pf, tap (kh, kw), k-step): pixel (wpx*4 + pf + kh, n32 + kw), octet
+  // B fragment of (pf, tap (kh, kw), k-step): pixel (wpx*PF + pf + kh, n32 + kw), octet
   // 2*kstep + khalf at slot octet ^ ((pcol >> 2) & 3): the swizzle depends on the column only, so
   // the address is one of three per-lane column terms (kw) + an immediate row offset, and the
   // second k-step is the first XOR 32 bytes
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
 #pragma unroll
   for (int kw = 0; kw < KS; ++kw) {
     const int pcol = n32 + kw;
-    b_col[kw] = smem_a + ((wpx*4)*PC + pcol)*64 + ((khalf ^ ((pcol >> 2) & 3)) << 4);
+    b_col[kw] = smem_a + ((wpx*PF)*PC + pcol)*64 + ((khalf ^ ((pcol >> 2) & 3)) << 4);
   }
   const unsigned int a_rd = smem_a + OFF_A + wco*2048 + lane*16;
   auto read_frags = [&](auto tapc, auto ksc, int par, int slot, u32x4 (&a)[2], u32x4 (&b)[4]) {
@@ -333,24 +338,26 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
     a[1] = cn_read16<KSTEP*4096 + 1024>(ab);
     const unsigned int bb = (b_col[kw] ^ (KSTEP*32)) + par*PBYTES;
     b[0] = cn_read16<(0 + kh)*PC*64>(bb);
-    b[1] = cn_read16<(1 + kh)*PC*64>(bb);
-    b[2] = cn_read16<(2 + kh)*PC*64>(bb);
-    b[3] = cn_read16<(3 + kh)*PC*64>(bb);
+    if constexpr (PF > 1) b[1] = cn_read16<(1 + kh)*PC*64>(bb);
+    if constexpr (PF > 2) {
+      b[2] = cn_read16<(2 + kh)*PC*64>(bb);
+      b[3] = cn_read16<(3 + kh)*PC*64>(bb);
+    }
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][PF];
   auto zero_acc = [&]() {
 #pragma unroll
     for (int cf = 0; cf < 2; ++cf)
 #pragma unroll
-      for (int pf = 0; pf < 4; ++pf)
+      for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[cf][pf][i] = 0.f;
   };
   auto mfma_step = [&](u32x4 (&a)[2], u32x4 (&b)[4], int pf_lo, int pf_hi) {
     const h8 a0 = __builtin_bit_cast(h8, a[0]), a1 = __builtin_bit_cast(h8, a[1]);
 #pragma unroll
-    for (int pf = 0; pf < 4; ++pf) {
+    for (int pf = 0; pf < PF; ++pf) {
       if (pf < pf_lo || pf >= pf_hi) continue;
       const h8 bv = __builtin_bit_cast(h8, b[pf]);
       if (CN_ABL & 4) { asm volatile("" :: "v"(a0), "v"(a1), "v"(bv)); continue; }
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
 #pragma unroll
       for (int cf = 0; cf < 2; ++cf)
 #pragma unroll
-        for (int pf = 0; pf < 4; ++pf)
+        for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
           for (int i = 0; i < 16; ++i) s += acc[cf][pf][i];
       if (s == 12345.678f) p.y[0] = (_Float16)s;
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
 #pragma unroll
     for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
 #pragma unroll
-    for (int pf = 0; pf < 4; ++pf) {
+    for (int pf = 0; pf < PF; ++pf) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();              // last readers of the buffer / of the previous pass
 #pragma unroll
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
       for (int it = 0; it < 4; ++it) {
         const int px = (it*CN_THREADS + tv) >> 4;             // 0..127: row group px >> 5
         raw[it] = cn_read16<0>(stg + px*ESTRIDE + c8*16);
-        const int h = q.h0 + (px >> 5)*4 + pf, w = q.w0 + (px & 31);
+        const int h = q.h0 + (px >> 5)*PF + pf, w = q.w0 + (px & 31);
         ok[it] = h < p.H && w < p.W && co < p.Cout;
         pix[it] = (long long)h*p.W + w;
         rr[it] = u32x4{0u, 0u, 0u, 0u};
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
       // the next tap's k-step 0 reads (tap 8: first tap of the next chunk)
       if constexpr (TP + 1 < TAPS) read_frags(cn_int<(TP + 1) % TAPS>{}, cn_int<0>{}, par, nring, fa[0], fb[0]);
       else read_frags(cn_int<0>{}, cn_int<0>{}, par ^ 1, nring, fa[0], fb[0]);
-      cn_wait_frags<6>(fa[1], fb[1]);
+      cn_wait_frags<2 + PF>(fa[1], fb[1]);
       if (CN_VAR & 2) __builtin_amdgcn_s_setprio(1);
       mfma_step(fa[1], fb[1], 0, 4);
       if (CN_VAR & 2) __builtin_amdgcn_s_setprio(0);
@@ -637,11 +644,11 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
     asm volatile("s_mov_b32 %0, %1" : "=s"(wsel) : "s"(wco));
     if (wsel != 0) dma_block();
     __builtin_amdgcn_sched_barrier(0);
-    if (CN_VAR & 4) {
+    if constexpr ((CN_VAR & 4) != 0 && PF == 4) {
       mfma_block_fine();
       CN_STAMP(3);
       if (wsel == 0) dma_block();
-    } else if (CN_VAR & 1) {
+    } else if constexpr ((CN_VAR & 1) != 0) {
       mfma_block(wsel == 0);
       CN_STAMP(3);
     } else {
@@ -757,8 +764,15 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
   p.n_chunks1 = (int)((C1 + CN_CK - 1)/CN_CK);
   p.n_chunks = p.n_chunks1 + (x2 ? (int)((C2 + CN_CK - 1)/CN_CK) : 0);
   p.Cin = (int)Cin; p.Cout = (int)Cout; p.Cys = (int)Cys; p.Crs = (int)Crs;
-  p.n_wt = (int)((W + CN_COLS - 1)/CN_COLS); p.n_ht = (int)((H + CN_ROWS - 1)/CN_ROWS);
+  p.n_wt = (int)((W + CN_COLS - 1)/CN_COLS);
   p.n_cob = (int)((Cout + 127)/128);
+  // rows per tile: 16 when that fills the chip, else 8 or 4 (2-4x the workgroups)
+  static int force_pf = -1;
+  if (force_pf < 0) { const char* e = getenv("BRV_CONV_PF"); force_pf = e ? atoi(e) : 0; }
+  int pf = 4;
+  while (pf > 1 && (long long)B*((H + 4*pf - 1)/(4*pf))*p.n_wt*p.n_cob < 192) pf >>= 1;
+  if (force_pf == 1 || force_pf == 2 || force_pf == 4) pf = force_pf;
+  p.n_ht = (int)((H + 4*pf - 1)/(4*pf));
   const long long n_tiles = (long long)B*p.n_ht*p.n_wt*p.n_cob;
   if (n_tiles > 0x7fffffffLL) return -2;
   p.n_tiles = (int)n_tiles;
@@ -772,13 +786,12 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
   p.dbg = dbg;
   brv_conv_nhwc_dbg = dbg;
 #endif
-  const unsigned grid = (unsigned)(n_tiles < 256 ? n_tiles : 256);
-  if (in_scale)
-    hipLaunchKernelGGL((conv_nhwc_kernel<3, true>), dim3(grid), dim3(CN_THREADS), 0,
-                       (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL((conv_nhwc_kernel<3, false>), dim3(grid), dim3(CN_THREADS), 0,
-                       (hipStream_t)stream, p);
+  const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256)), block(CN_THREADS);
+  const hipStream_t st = (hipStream_t)stream;
+#define CN_LAUNCH(F, P) hipLaunchKernelGGL((conv_nhwc_kernel<3, F, P>), grid, block, 0, st, p)
+  if (in_scale) { if (pf == 4) CN_LAUNCH(true, 4); else if (pf == 2) CN_LAUNCH(true, 2); else CN_LAUNCH(true, 1); }
+  else { if (pf == 4) CN_LAUNCH(false, 4); else if (pf == 2) CN_LAUNCH(false, 2); else CN_LAUNCH(false, 1); }
+#undef CN_LAUNCH
   CN_OK(hipGetLastError());
   return 0;
 }
