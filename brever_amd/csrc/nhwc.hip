@@ -321,20 +321,27 @@ __global__ __launch_bounds__(256) void conv1x1_pack_kernel(const float* w, _Floa
 // would re-read every input 9 times from L1; instead a workgroup stages the (8+2) x (32+2) pixel
 // patch of 64-channel slabs in LDS, already activated, and its 256 threads each own one pixel.
 struct SmallCoutParams {
-  const _Float16* x; const float* w; const float* bias; const float* scale; const float* shift;
+  const _Float16* x; const _Float16* w16; const float* bias; const float* scale; const float* shift;
   const float* yin; float* y;
   int C, Cs, Cout, H, W, silu;
 };
+// w16: weights as fp16 [tap 9][Cout][C] (brv_nhwc_conv3x3_small_pack). The 256 threads of a
+// workgroup each own one pixel of an 8 x 32 tile; per 64-channel slab the activated (10 x 34)-
+// pixel patch sits in LDS as fp16, the weights of a (tap, output channel, 8 input channels) are
+// wave-uniform -> scalar loads, and the products are v_dot2_f32_f16 (two MACs per lane and
+// instruction, fp32 accumulation).
+template <int COUT>
 __global__ __launch_bounds__(256) void nhwc_conv3x3_small_kernel(const SmallCoutParams p) {
   constexpr int TR = 8, TC = 32, PR = TR + 2, PC = TC + 2, SLAB = 64;
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   __shared__ _Float16 patch[PR*PC][SLAB + 8];          // +8: rows 144 B apart (bank spread)
-  __shared__ float wl[8][9][SLAB];
+  __shared__ _Float16 wl[9][COUT][SLAB];               // the slab's weights (read as broadcasts)
   const int tid = threadIdx.x;
   const int b = blockIdx.z, h0 = blockIdx.y*TR, w0 = blockIdx.x*TC;
   const int r = tid / TC, c = tid % TC;
-  float acc[8];
+  float acc[COUT];
 #pragma unroll
-  for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
   const long long HW = (long long)p.H*p.W;
   for (int cb = 0; cb < p.C; cb += SLAB) {
     __syncthreads();
@@ -345,48 +352,61 @@ __global__ __launch_bounds__(256) void nhwc_conv3x3_small_kernel(const SmallCout
       f32x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      if (h >= 0 && h < p.H && w >= 0 && w < p.W && ch < p.Cs) {
+      if (h >= 0 && h < p.H && w >= 0 && w < p.W && ch < p.C) {
         v = __builtin_convertvector(*reinterpret_cast<const h8*>(p.x + (b*HW + (long long)h*p.W + w)*p.Cs + ch), f32x8);
         if (p.scale) {
+          const float* sc = p.scale + (long long)b*p.C + ch;
+          const float* sh = p.shift + (long long)b*p.C + ch;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float t = 0.f;
-            if (ch + j < p.C) {
-              t = p.scale[(long long)b*p.C + ch + j]*v[j] + p.shift[(long long)b*p.C + ch + j];
-              if (p.silu) t = nh_silu(t);
-            }
-            v[j] = t;
+            const float t = sc[j]*v[j] + sh[j];
+            v[j] = p.silu ? nh_silu(t) : t;
           }
         }
       }
       *reinterpret_cast<h8*>(&patch[px][o8*8]) = __builtin_convertvector(v, h8);
     }
-    for (int i = tid; i < 8*9*SLAB; i += 256) {
-      const int o = i / (9*SLAB), t = (i / SLAB) % 9, k = i % SLAB;
-      wl[o][t][k] = o < p.Cout && cb + k < p.C ? p.w[((long long)o*p.C + cb + k)*9 + t] : 0.f;
+    for (int i = tid; i < 9*COUT*(SLAB/8); i += 256) {
+      const int k8 = i % (SLAB/8), o = (i / (SLAB/8)) % COUT, t = i / ((SLAB/8)*COUT);
+      h8 wv = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (o < p.Cout && cb + k8*8 < p.C)
+        wv = *reinterpret_cast<const h8*>(p.w16 + ((long long)(t*p.Cout + o))*p.C + cb + k8*8);
+      *reinterpret_cast<h8*>(&wl[t][o][k8*8]) = wv;
     }
     __syncthreads();
+#pragma unroll 1
     for (int t = 0; t < 9; ++t) {
       const _Float16* pp = patch[(r + t/3)*PC + c + t%3];
+#pragma unroll
       for (int k = 0; k < SLAB; k += 8) {
-        const f32x8 v = __builtin_convertvector(*reinterpret_cast<const h8*>(pp + k), f32x8);
+        const h8 v = *reinterpret_cast<const h8*>(pp + k);
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-          if (o >= p.Cout) break;
-          const float* wk = &wl[o][t][k];
+        for (int o = 0; o < COUT; ++o) {
+          const h8 wv = *reinterpret_cast<const h8*>(&wl[t][o][k]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[o] = fmaf(v[j], wk[j], acc[o]);
+          for (int j = 0; j < 4; ++j)
+            acc[o] = __builtin_amdgcn_fdot2(h2{v[2*j], v[2*j + 1]}, h2{wv[2*j], wv[2*j + 1]}, acc[o], false);
         }
       }
     }
   }
   const int h = h0 + r, w = w0 + c;
   if (h >= p.H || w >= p.W) return;
-  for (int o = 0; o < p.Cout; ++o) {
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    if (o >= p.Cout) break;
     const long long idx = ((long long)b*p.Cout + o)*HW + (long long)h*p.W + w;
     float v = acc[o] + (p.bias ? p.bias[o] : 0.f);
     if (p.yin) v += p.yin[idx];
     p.y[idx] = v;
+  }
+}
+// w16[tap][co][ci] <- w[co][ci][tap]
+__global__ __launch_bounds__(256) void small_pack_kernel(const float* w, _Float16* w16, int Cout, int C) {
+  const int n = 9*Cout*C;
+  for (int i = blockIdx.x*256 + threadIdx.x; i < n; i += gridDim.x*256) {
+    const int ci = i % C, co = (i / C) % Cout, t = i / (C*Cout);
+    w16[i] = (_Float16)w[((long long)co*C + ci)*9 + t];
   }
 }
 
@@ -550,17 +570,28 @@ int brv_nhwc_conv1x1_forward(const void* x1, int64_t C1, int64_t C1s, const void
   return 0;
 }
 
-int brv_nhwc_conv3x3_small(const void* x, const float* w, const float* bias, const float* scale_bc,
+int brv_nhwc_conv3x3_small_pack(const float* w, void* w16, int64_t Cout, int64_t C, brv_stream_t stream) {
+  if (Cout < 1 || Cout > 8 || C < 1) return -1;
+  hipLaunchKernelGGL(small_pack_kernel, dim3((unsigned)((9*Cout*C + 255)/256)), dim3(256), 0,
+                     (hipStream_t)stream, w, (_Float16*)w16, (int)Cout, (int)C);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_conv3x3_small(const void* x, const void* w16, const float* bias, const float* scale_bc,
                            const float* shift_bc, int silu, const float* y_in, float* y, int64_t B,
                            int64_t C, int64_t Cs, int64_t H, int64_t W, int64_t Cout,
                            brv_stream_t stream) {
-  if (B < 1 || C < 1 || Cs < C || (Cs & 7) || H < 1 || W < 1 || Cout < 1 || Cout > 8) return -1;
+  if (B < 1 || C < 1 || (C & 7) || Cs < C || (Cs & 7) || H < 1 || W < 1 || Cout < 1 || Cout > 8) return -1;
   SmallCoutParams p;
-  p.x = (const _Float16*)x; p.w = w; p.bias = bias; p.scale = scale_bc; p.shift = shift_bc;
-  p.yin = y_in; p.y = y; p.C = (int)C; p.Cs = (int)Cs; p.Cout = (int)Cout; p.H = (int)H; p.W = (int)W;
-  p.silu = silu;
-  hipLaunchKernelGGL(nhwc_conv3x3_small_kernel, dim3((unsigned)((W + 31)/32), (unsigned)((H + 7)/8), (unsigned)B),
-                     dim3(256), 0, (hipStream_t)stream, p);
+  p.x = (const _Float16*)x; p.w16 = (const _Float16*)w16; p.bias = bias; p.scale = scale_bc;
+  p.shift = shift_bc; p.yin = y_in; p.y = y; p.C = (int)C; p.Cs = (int)Cs; p.Cout = (int)Cout;
+  p.H = (int)H; p.W = (int)W; p.silu = silu;
+  const dim3 grid((unsigned)((W + 31)/32), (unsigned)((H + 7)/8), (unsigned)B);
+  if (Cout <= 4)
+    hipLaunchKernelGGL(nhwc_conv3x3_small_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(nhwc_conv3x3_small_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, p);
   NH_OK(hipGetLastError());
   return 0;
 }

@@ -217,6 +217,7 @@ SIGNATURES = {
     'brv_nhwc_conv1x1_pack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_nhwc_conv1x1_forward': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64,
                                                 _c_ptr, _c_ptr, _c_ptr] + [_c_i64]*3 + [_c_f32, _c_ptr]),
+    'brv_nhwc_conv3x3_small_pack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_nhwc_conv3x3_small': (ctypes.c_int, [_c_ptr]*5 + [ctypes.c_int, _c_ptr, _c_ptr] + [_c_i64]*6
                                + [_c_ptr]),
     'brv_nhwc_add_pointwise': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*5 + [_c_f32, _c_ptr]),

@@ -368,10 +368,18 @@ def _h_small_conv(a, mod, fold=None, silu=False, y_in=None):
     """3x3 convolution to <= 8 channels, (B, Cout, H, W) fp32 = [y_in +] conv(act(a)) + bias."""
     a = _h_single(a)
     B, H, W, Cs = a.t.shape
+    w = mod.weight
+    key = (w.data_ptr(), w._version)
+    if getattr(mod, '_brv_hs_key', None) != key:
+        w16 = torch.empty(9*w.shape[0]*w.shape[1], dtype=torch.float16, device=w.device)
+        hip.check(hip.lib().brv_nhwc_conv3x3_small_pack(hip.ptr(w.detach().contiguous()), hip.ptr(w16),
+                                                        w.shape[0], w.shape[1], hip.stream()),
+                  'brv_nhwc_conv3x3_small_pack')
+        mod._brv_hs, mod._brv_hs_key = w16, key
     y = torch.empty(B, mod.out_channels, H, W, dtype=torch.float32, device=a.t.device)
     sc, sf = fold if fold is not None else (None, None)
     hip.check(hip.lib().brv_nhwc_conv3x3_small(
-        hip.ptr(a.t), hip.ptr(mod.weight), hip.ptr(mod.bias), hip.ptr(sc), hip.ptr(sf), int(silu),
+        hip.ptr(a.t), hip.ptr(mod._brv_hs), hip.ptr(mod.bias), hip.ptr(sc), hip.ptr(sf), int(silu),
         hip.ptr(y_in.contiguous()) if y_in is not None else None, hip.ptr(y), B, a.C, Cs, H, W,
         mod.out_channels, hip.stream()), 'brv_nhwc_conv3x3_small')
     return y

@@ -560,7 +560,7 @@ int brv_conv2d_mfma_forward(const float* x, const void* wp, const float* bias, c
  * brv_nhwc_affine_act / _fir_resample2d / _axpby: the channels-last forms of brv_affine_act,
  *   brv_fir_resample2d, brv_axpby. brv_nhwc_conv3x3_small: 3x3 convolution to <= 8 channels,
  *   (B, Cout, H, W) fp32 out = [y_in +] conv(act(x)) + bias (AuxiliaryUp.conv, the output
- *   convolution; net.py:455-477). brv_nhwc_add_pointwise: y = out_scale*(x + bias + W aux), aux
+ *   convolution; net.py:455-477); w16 = 9*Cout*C halves from brv_nhwc_conv3x3_small_pack, C % 8 == 0. brv_nhwc_add_pointwise: y = out_scale*(x + bias + W aux), aux
  *   (B, K <= 8, HW) fp32 (AuxiliaryDown, net.py:425-452). */
 int64_t brv_conv_nhwc_packed_size(int64_t Cout, int64_t Cin, int64_t ksize);
 int brv_conv_nhwc_pack(const float* w, void* wp, int64_t Cout, int64_t Cin, int64_t ksize,
@@ -593,7 +593,8 @@ int brv_nhwc_conv1x1_pack(const float* w, void* wp, int64_t Cout, int64_t C1, in
 int brv_nhwc_conv1x1_forward(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
                              int64_t C2s, const void* wp, const float* bias, void* y, int64_t Cys,
                              int64_t npx, int64_t Cout, float out_scale, brv_stream_t stream);
-int brv_nhwc_conv3x3_small(const void* x, const float* w, const float* bias, const float* scale_bc,
+int brv_nhwc_conv3x3_small_pack(const float* w, void* w16, int64_t Cout, int64_t C, brv_stream_t stream);
+int brv_nhwc_conv3x3_small(const void* x, const void* w16, const float* bias, const float* scale_bc,
                            const float* shift_bc, int silu, const float* y_in, float* y, int64_t B,
                            int64_t C, int64_t Cs, int64_t H, int64_t W, int64_t Cout,
                            brv_stream_t stream);
