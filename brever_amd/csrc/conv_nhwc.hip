@@ -408,6 +408,22 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
     for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf) {
+      // the residual pieces of this pass first: they travel while the accumulators are staged
+      u32x4 raw[4], rr[4];
+      bool ok[4]; long long pix[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int px = (it*CN_THREADS + tv) >> 4;             // 0..127: row group px >> 5
+        const int h = q.h0 + (px >> 5)*PF + pf, w = q.w0 + (px & 31);
+        ok[it] = h < p.H && w < p.W && co < p.Cout;
+        pix[it] = (long long)h*p.W + w;
+        rr[it] = u32x4{0u, 0u, 0u, 0u};
+      }
+      if (rb) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          if (ok[it]) rr[it] = *reinterpret_cast<const u32x4*>(rb + pix[it]*p.Crs + co);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();              // last readers of the buffer / of the previous pass
 #pragma unroll
@@ -425,21 +441,10 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
 #ifdef CN_DIAG
       es[esn++] = cn_stamp();
 #endif
-      u32x4 raw[4], rr[4];
-      bool ok[4]; long long pix[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int px = (it*CN_THREADS + tv) >> 4;             // 0..127: row group px >> 5
+        const int px = (it*CN_THREADS + tv) >> 4;
         raw[it] = cn_read16<0>(stg + px*ESTRIDE + c8*16);
-        const int h = q.h0 + (px >> 5)*PF + pf, w = q.w0 + (px & 31);
-        ok[it] = h < p.H && w < p.W && co < p.Cout;
-        pix[it] = (long long)h*p.W + w;
-        rr[it] = u32x4{0u, 0u, 0u, 0u};
-      }
-      if (rb) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-          if (ok[it]) rr[it] = *reinterpret_cast<const u32x4*>(rb + pix[it]*p.Crs + co);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) :: "memory");
 #ifdef CN_DIAG
