@@ -43,6 +43,13 @@ struct G32 {
   // gemm64_kernel only: the DFT basis in double precision (replaces A for GA_PLAIN / B for
   // GB_PLAIN and GB_WT); the other operand is fp32 data converted on load
   const double* A64; const double* B64;
+  // gemm_bf16 only: B is the COLUMN MATRIX of an image that is never written out (implicit GEMM of
+  // the DCCRN convolutions). Row r = (c, i, j) of a kh x kw window, column = pixel (y, x) of a
+  // cv_Ho x cv_Wo grid; B points at the image (cv_C, cv_H, cv_W) fp32, b_bs / b_kbs are image strides.
+  //   b_conv 1 (im2col):            image[c][y*sh - ph + i][x*sw - pw + j]
+  //   b_conv 2 (transposed gather): image[c][(y + ph - i)/sh][(x + pw - j)/sw] where divisible
+  // zero outside the image. With TB the roles of B's two axes are swapped as for a real matrix.
+  int b_conv, cv_C, cv_H, cv_W, cv_kh, cv_kw, cv_sh, cv_sw, cv_ph, cv_pw, cv_Ho, cv_Wo;
 };
 
 constexpr int TM = 64, TN = 64, TK = 32;
@@ -281,6 +288,84 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // ---- virtual column matrix (p.b_conv): one element / four consecutive pixels of one row
+  auto col_elem = [&](const float* img, int row, int pix) -> float {
+    const int khw = p.cv_kh*p.cv_kw;
+    const int c = row / khw, t = row - c*khw, i = t / p.cv_kw, j = t - i*p.cv_kw;
+    const int y = pix / p.cv_Wo, x = pix - y*p.cv_Wo;
+    int hi, wi;
+    if (p.b_conv == 1) { hi = y*p.cv_sh - p.cv_ph + i; wi = x*p.cv_sw - p.cv_pw + j; }
+    else {
+      const int hn = y + p.cv_ph - i, wn = x + p.cv_pw - j;
+      if (hn < 0 || wn < 0 || hn % p.cv_sh || wn % p.cv_sw) return 0.f;
+      hi = hn/p.cv_sh; wi = wn/p.cv_sw;
+    }
+    if (hi < 0 || hi >= p.cv_H || wi < 0 || wi >= p.cv_W) return 0.f;
+    return img[((long long)c*p.cv_H + hi)*p.cv_W + wi];
+  };
+  // the vector loader's form: row -> (c, i, j) and pixel -> (y, x) are split off so that whichever
+  // of the two is fixed for a thread is decomposed ONCE per kernel; the divisions are float
+  // multiplications with an exact correction (the loader's instruction stream bounds this kernel)
+  const float inv_khw = 1.f/(float)(p.cv_kh*p.cv_kw), inv_kw = 1.f/(float)(p.b_conv ? p.cv_kw : 1);
+  const float inv_wo = 1.f/(float)(p.b_conv ? p.cv_Wo : 1), inv_sh = 1.f/(float)(p.b_conv ? p.cv_sh : 1);
+  auto fdiv = [](int n, int d, float inv, int& q, int& r) {       // n >= 0
+    q = (int)((float)n*inv);
+    r = n - q*d;
+    if (r < 0) { --q; r += d; } else if (r >= d) { ++q; r -= d; }
+  };
+  struct ColRC { int c, i, j; };
+  struct ColYX { int y, x; };
+  auto dec_row = [&](int row) { ColRC o; int t; fdiv(row, p.cv_kh*p.cv_kw, inv_khw, o.c, t); fdiv(t, p.cv_kw, inv_kw, o.i, o.j); return o; };
+  auto dec_pix = [&](int pix) { ColYX o; fdiv(pix, p.cv_Wo, inv_wo, o.y, o.x); return o; };
+  // one element from its decomposed coordinates (no integer division)
+  auto col_one = [&](const float* img, const ColRC& rc, int y, int x) -> float {
+    int hi, wi;
+    if (p.b_conv == 1) { hi = y*p.cv_sh - p.cv_ph + rc.i; wi = x*p.cv_sw - p.cv_pw + rc.j; }
+    else {
+      const int hn = y + p.cv_ph - rc.i, wn = x + p.cv_pw - rc.j;
+      if (hn < 0 || wn < 0) return 0.f;
+      int r1, r2;
+      fdiv(hn, p.cv_sh, inv_sh, hi, r1);
+      fdiv(wn, p.cv_sw, 1.f/(float)p.cv_sw, wi, r2);
+      if (r1 || r2) return 0.f;
+    }
+    if (hi < 0 || hi >= p.cv_H || wi < 0 || wi >= p.cv_W) return 0.f;
+    return img[((long long)rc.c*p.cv_H + hi)*p.cv_W + wi];
+  };
+  auto col_vec4 = [&](const float* img, const ColRC& rc, const ColYX& yx, int row, int pix0) -> float4 {
+    // unit stride along the image's contiguous axis: 4 pixels of one grid row read 4 consecutive
+    // image elements (one 16-byte load, 4-byte aligned: legal on gfx950) or a row of padding
+    if (p.cv_sw == 1 && yx.x + 3 < p.cv_Wo) {
+      int hi;
+      bool live = true;
+      if (p.b_conv == 1) hi = yx.y*p.cv_sh - p.cv_ph + rc.i;
+      else {
+        const int hn = yx.y + p.cv_ph - rc.i;
+        int rem = 0;
+        hi = 0;
+        if (hn >= 0) fdiv(hn, p.cv_sh, inv_sh, hi, rem);
+        live = hn >= 0 && rem == 0;
+      }
+      if (!live || hi < 0 || hi >= p.cv_H) return make_float4(0.f, 0.f, 0.f, 0.f);
+      const int wi = p.b_conv == 1 ? yx.x - p.cv_pw + rc.j : yx.x + p.cv_pw - rc.j;
+      if (wi >= 0 && wi + 3 < p.cv_W) {
+        float4 v;
+        __builtin_memcpy(&v, img + ((long long)rc.c*p.cv_H + hi)*p.cv_W + wi, 16);
+        return v;
+      }
+    }
+    // image / grid edges: element by element, the pixel coordinates carried (a group may wrap
+    // into the next grid row; a thread that owns such a group takes this path on every tile)
+    float e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int y = yx.y, x = yx.x + q;
+      if (x >= p.cv_Wo) { x -= p.cv_Wo; ++y; }
+      e[q] = y < p.cv_Ho ? col_one(img, rc, y, x) : 0.f;
+    }
+    return make_float4(e[0], e[1], e[2], e[3]);
+  };
+
   // each thread stages 8 (row, k-pair) items per operand: 128 rows x 16 pairs; the fast thread
   // index follows the operand's contiguous axis (rows when transposed, k pairs otherwise)
   constexpr int NP = BM2*(BKL/2)/256;
@@ -312,7 +397,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
       item(tid + r*256, !TB, row, kp);
       const int n = n0 + row;
       v = make_float2(0.f, 0.f);
-      if (n < p.N) {
+      if (n < p.N && p.b_conv) {
+        // (row, pixel) of the virtual matrix: (n, k) with TB, (k, n) without
+        if (k0 + 2*kp < p.K) v.x = TB ? col_elem(B, n, k0 + 2*kp) : col_elem(B, k0 + 2*kp, n);
+        if (k0 + 2*kp + 1 < p.K) v.y = TB ? col_elem(B, n, k0 + 2*kp + 1) : col_elem(B, k0 + 2*kp + 1, n);
+      } else if (n < p.N) {
         if (k0 + 2*kp < p.K)
           v.x = ldb(TB ? (long long)n*p.ldb + k0 + 2*kp : (long long)(k0 + 2*kp)*p.ldb + n);
         if (k0 + 2*kp + 1 < p.K)
@@ -379,10 +468,40 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
       }
     }
   };
+  // per-thread invariants of the column-matrix loader: without TB the thread's 4-pixel group,
+  // with TB its four rows
+  ColYX my_yx = {0, 0};
+  ColRC my_rc[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  if (VEC && p.b_conv) {
+    if (TB) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = n0 + ((tid + r*256) >> 3); if (row < p.N) my_rc[r] = dec_row(row); }
+    } else if (n0 + 4*(tid & 31) < p.N) my_yx = dec_pix(n0 + 4*(tid & 31));
+  }
+  auto vfetch_col = [&](const float* img, int k0) {
+    // the items of vfetch1 with the column matrix behind them: TB -> (row n, 4 pixels along k),
+    // else (4 pixels along n, rows k and k + 1)
+    ColYX yx = my_yx;
+    if (TB && k0 + 4*(tid & 7) < p.K) yx = dec_pix(k0 + 4*(tid & 7));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = tid + (r >> (TB ? 0 : 1))*256;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (TB) {
+        const int kq = e & 7, row = e >> 3;
+        if (n0 + row < p.N && k0 + 4*kq < p.K) q = col_vec4(img, my_rc[r], yx, n0 + row, k0 + 4*kq);
+      } else {
+        const int rq = e & 31, kp = e >> 5, k = k0 + 2*kp + (r & 1);
+        if (n0 + 4*rq < p.N && k < p.K) q = col_vec4(img, dec_row(k), yx, k, n0 + 4*rq);
+      }
+      vb[r] = q;
+    }
+  };
   auto vfetch = [&](long long t) {
     const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BKL;
     vfetch1(p.A, (long long)b*p.a_bs + (long long)kb*p.a_kbs, p.lda, !TA, m0, p.M, k0, va, p.a_bf16 != 0);
-    vfetch1(p.B, (long long)b*p.b_bs + (long long)kb*p.b_kbs, p.ldb, TB, n0, p.N, k0, vb, p.b_bf16 != 0);
+    if (p.b_conv) vfetch_col(p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs, k0);
+    else vfetch1(p.B, (long long)b*p.b_bs + (long long)kb*p.b_kbs, p.ldb, TB, n0, p.N, k0, vb, p.b_bf16 != 0);
   };
   auto vstash = [&]() { vstash1(As, !TA, va); vstash1(Bs, TB, vb); };
   if (t_lo < t_hi) { if (VEC) vfetch(t_lo); else fetch(t_lo); }
@@ -793,8 +912,9 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
                     int64_t a_batch_stride, int64_t b_batch_stride, int64_t d_batch_stride,
                     int trans_a, int trans_b, int64_t kbatch, int64_t a_kbatch_stride,
                     int64_t b_kbatch_stride, const float* row_bias, int accumulate,
-                    brv_stream_t stream, int flags = 0) {
+                    brv_stream_t stream, int flags = 0, const int* conv = nullptr) {
   if (batch < 1 || M < 1 || N < 1 || K < 1) return -1;
+  if (conv && !lowp) return -1;
   if (flags && (!lowp || ((flags & 2) && accumulate == 1))) return -1;
   G32 p; memset(&p, 0, sizeof(p));
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
@@ -804,6 +924,11 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   p.kbatch = (int)kbatch; p.a_kbs = a_kbatch_stride; p.b_kbs = b_kbatch_stride;
   p.col_bias = accumulate == 2;
   p.b_bf16 = flags & 1; p.d_bf16 = (flags >> 1) & 1; p.a_bf16 = (flags >> 2) & 1;
+  if (conv) {
+    p.b_conv = conv[0]; p.cv_C = conv[1]; p.cv_H = conv[2]; p.cv_W = conv[3]; p.cv_kh = conv[4];
+    p.cv_kw = conv[5]; p.cv_sh = conv[6]; p.cv_sw = conv[7]; p.cv_ph = conv[8]; p.cv_pw = conv[9];
+    p.cv_Ho = conv[10]; p.cv_Wo = conv[11];
+  }
   if (accumulate == 2) accumulate = 0;
   p.row_bias = row_bias; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
@@ -832,10 +957,11 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
     // vector loader: strides, bases and the extent along each operand's contiguous axis are
     // multiples of 4 floats
     auto q4 = [](long long v) { return (v & 3) == 0; };
-    const bool vec = q4(lda) && q4(ldb) && q4(a_batch_stride) && q4(b_batch_stride) &&
-                     q4(a_kbatch_stride) && q4(b_kbatch_stride) &&
+    // (a column-matrix B: only its pixel count matters -- its loads are 4-byte aligned by design)
+    const bool vec = q4(lda) && (conv || q4(ldb)) && q4(a_batch_stride) && (conv || q4(b_batch_stride)) &&
+                     q4(a_kbatch_stride) && (conv || q4(b_kbatch_stride)) &&
                      ((uintptr_t)a & ((flags & 4) ? 7 : 15)) == 0 &&
-                     ((uintptr_t)b & ((flags & 1) ? 7 : 15)) == 0 &&
+                     (conv || ((uintptr_t)b & ((flags & 1) ? 7 : 15)) == 0) &&
                      q4(trans_a ? M : K) && q4(trans_b ? K : N) && !getenv("BRV_GEMM_SCALAR");
 #define BRV_BF16_LAUNCH(TA_, TB_) \
     do { if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, p, (int)ksplit); \
@@ -875,6 +1001,24 @@ int brv_gemm_bf16_mixed(const void* a, const void* b, void* d, int64_t batch, in
   return gemm_any(1, (const float*)a, (const float*)b, (float*)d, batch, M, N, K, lda, ldb, ldd, a_batch_stride,
                   b_batch_stride, d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride,
                   b_kbatch_stride, row_bias, accumulate, stream, flags & 7);
+}
+int brv_gemm_bf16_conv(const float* a, const float* image, float* d, int64_t batch, int64_t M,
+                       int64_t N, int64_t K, int64_t lda, int64_t ldd, int64_t a_batch_stride,
+                       int64_t image_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                       int64_t kbatch, int64_t a_kbatch_stride, int64_t image_kbatch_stride,
+                       const float* row_bias, int accumulate, int mode, int64_t C, int64_t H,
+                       int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph,
+                       int64_t pw, int64_t Ho, int64_t Wo, brv_stream_t stream) {
+  if ((mode != 1 && mode != 2) || C < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 ||
+      Ho < 1 || Wo < 1) return -1;
+  // the column matrix is (C*kh*kw) x (Ho*Wo): it is op_b's K x N (trans_b: N x K)
+  const int64_t rows = C*kh*kw, pix = Ho*Wo;
+  if ((trans_b ? N : K) != rows || (trans_b ? K : N) != pix || pix >= (1LL << 31)) return -1;
+  const int conv[12] = {mode, (int)C, (int)H, (int)W, (int)kh, (int)kw, (int)sh, (int)sw, (int)ph,
+                        (int)pw, (int)Ho, (int)Wo};
+  return gemm_any(1, a, image, d, batch, M, N, K, lda, pix, ldd, a_batch_stride, image_batch_stride,
+                  d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride, image_kbatch_stride,
+                  row_bias, accumulate, stream, 0, conv);
 }
 int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
                   int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,

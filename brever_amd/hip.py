@@ -201,6 +201,8 @@ SIGNATURES = {
     'brv_conv2d_pack_f16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_conv2d_mfma_forward': (ctypes.c_int, [_c_ptr]*6 + [ctypes.c_int, _c_ptr] + [_c_i64]*8
                                 + [_c_f32, _c_ptr]),
+    'brv_gemm_bf16_conv': (ctypes.c_int, [_c_ptr]*3 + [_c_i64]*9 + [ctypes.c_int, ctypes.c_int]
+                           + [_c_i64]*3 + [_c_ptr, ctypes.c_int, ctypes.c_int] + [_c_i64]*11 + [_c_ptr]),
     'brv_conv_nhwc_packed_size': (_c_i64, [_c_i64, _c_i64, _c_i64]),
     'brv_conv_nhwc_pack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_conv_nhwc_forward': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr,

@@ -14,6 +14,8 @@ kernels (``brv_im2col / brv_col2im / brv_complex_weight_pack`` around ``brv_gemm
 and transposes between them. fp32 activations throughout; ``use_amp`` runs the matrix products (convolutions, LSTM input
 projections) with bf16 operands and fp32 accumulation, otherwise on the exact-fp32 MFMA.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -148,6 +150,21 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, t
         'brv_gemm_bf16' if lowp else 'brv_gemm_f32')
 
 
+def _gemm_conv(a, img, d, batch, M, N, K, lda, ldd, a_bs, img_bs, d_bs, mode, image, geom, grid,
+               trans_b=0, kbatch=1, a_kbs=0, img_kbs=0, bias=None):
+    """``_gemm(lowp=True)`` whose B operand is the column matrix of ``img`` -- never written out
+    (``brv_gemm_bf16_conv``): ``image`` = (C, H, W) of ``img``, ``grid`` = the pixel grid of the
+    columns; mode 1 = im2col, mode 2 = the gather form of col2im."""
+    (kh, kw), (sh, sw), (ph, pw) = geom
+    hip.check(hip.lib().brv_gemm_bf16_conv(
+        hip.ptr(a), hip.ptr(img), hip.ptr(d), batch, M, N, K, lda, ldd, a_bs, img_bs, d_bs, 0, trans_b,
+        kbatch, a_kbs, img_kbs, hip.ptr(bias), 0, mode, image[0], image[1], image[2], kh, kw, sh, sw,
+        ph, pw, grid[0], grid[1], hip.stream()), 'brv_gemm_bf16_conv')
+
+
+_IMPLICIT = os.environ.get('BRV_DCCRN_IM2COL', '0') != '1'     # use_amp: implicit GEMM convolutions
+
+
 def _im2col(x, geom, grid, lowp=False):
     """``lowp``: the column matrix in bf16 (half the bytes of the largest tensor of the layer)."""
     (kh, kw), (sh, sw), (ph, pw) = geom
@@ -207,7 +224,15 @@ class _ComplexConvFunction(torch.autograd.Function):
                                               hip.ptr(wc), R, Cw, -1.0 if transpose else 1.0,
                                               hip.stream()), 'brv_complex_weight_pack')
         bias = torch.cat([_combine(br, bi, -1.0), _combine(br, bi, 1.0)])
-        if transpose:
+        khw = kh*kw
+        if not transpose and lowp and _IMPLICIT:
+            # the column matrix of x is read in place (brv_gemm_bf16_conv): no im2col pass, no 10x copy
+            Cout = R
+            Ho, Wo = (H + 2*ph - kh)//sh + 1, (W + 2*pw - kw)//sw + 1
+            y = torch.empty(B, 2*Cout, Ho, Wo, dtype=torch.float32, device=x.device)
+            _gemm_conv(wc, x, y, B, 2*Cout, Ho*Wo, 2*Cw, 2*Cw, Ho*Wo, 0, 2*Cin*H*W, 2*Cout*Ho*Wo, 1,
+                       (2*Cin, H, W), geom, (Ho, Wo), bias=bias)
+        elif transpose:
             Cout = wr.shape[1]
             Ho, Wo = (H - 1)*sh - 2*ph + kh + oph, (W - 1)*sw - 2*pw + kw + opw
             col = torch.empty(B, 2*Cw, H*W, dtype=torch.bfloat16 if lowp else torch.float32,
@@ -235,7 +260,23 @@ class _ComplexConvFunction(torch.autograd.Function):
         B = x.shape[0]
         lowp = ctx.lowp
         dwc = torch.empty_like(wc)
-        if transpose:
+        khw = geom[0][0]*geom[0][1]
+        if transpose and lowp and _IMPLICIT:
+            dx = torch.empty_like(x)
+            _gemm_conv(wc, dy, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, 0, 2*Cout*Ho*Wo, 2*Cin*H*W, 1,
+                       (2*Cout, Ho, Wo), geom, (H, W))
+            _gemm_conv(x, dy, dwc, 1, 2*Cin, 2*Cw, H*W, H*W, 2*Cw, 0, 0, 0, 1, (2*Cout, Ho, Wo), geom,
+                       (H, W), trans_b=1, kbatch=B, a_kbs=2*Cin*H*W, img_kbs=2*Cout*Ho*Wo)
+        elif not transpose and lowp and _IMPLICIT:
+            _gemm_conv(dy, x, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, 1, (2*Cin, H, W), geom,
+                       (Ho, Wo), trans_b=1, kbatch=B, a_kbs=2*Cout*Ho*Wo, img_kbs=2*Cin*H*W)
+            # data gradient: product + scatter (the gather form doubles the matrix work at stride 2
+            # and shrinks M to 2*Cin: measured 3.8x slower than this pair)
+            col = torch.empty(B, 2*Cw, Ho*Wo, dtype=torch.bfloat16, device=x.device)
+            _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,
+                  2*Cw*Ho*Wo, trans_a=1, lowp=lowp)
+            dx = _col2im(col, None, 2*Cin, (H, W), geom, (Ho, Wo))
+        elif transpose:
             dcol = _im2col(dy, geom, (H, W), lowp)                 # (B, 2*Cw, H*W)
             dx = torch.empty_like(x)
             _gemm(wc, dcol, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, H*W, 0, 2*Cw*H*W, 2*Cin*H*W,

@@ -252,6 +252,20 @@ int brv_gemm_bf16(const float* a, const float* b, float* d, int64_t batch, int64
                   int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
                   int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
                   const float* row_bias, int accumulate, brv_stream_t stream);
+/* brv_gemm_bf16 with op_b = the COLUMN MATRIX of an image that is never written out (implicit GEMM
+ * of the DCCRN convolutions, reference brever/models/dccrn/dccrn.py:221-290): rows (c, i, j) of a
+ * kh x kw window, columns = the pixels (y, x) of an Ho x Wo grid; mode 1: image[c][y*sh - ph + i]
+ * [x*sw - pw + j] (im2col: convolution forward / weight gradient, transposed-convolution data
+ * gradient); mode 2: image[c][(y + ph - i)/sh][(x + pw - j)/sw] where divisible (the gather form
+ * of col2im: convolution data gradient, transposed-convolution forward); zero outside. image:
+ * (batch | kbatch, C, H, W) fp32 with the given strides. */
+int brv_gemm_bf16_conv(const float* a, const float* image, float* d, int64_t batch, int64_t M,
+                       int64_t N, int64_t K, int64_t lda, int64_t ldd, int64_t a_batch_stride,
+                       int64_t image_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                       int64_t kbatch, int64_t a_kbatch_stride, int64_t image_kbatch_stride,
+                       const float* row_bias, int accumulate, int mode, int64_t C, int64_t H,
+                       int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph,
+                       int64_t pw, int64_t Ho, int64_t Wo, brv_stream_t stream);
 /* brv_gemm_bf16 with bf16 tensors in memory: flags bit 0: b holds bf16 elements, bit 2: a does, bit 1:
  * d is written as bf16 (no accumulate, no split reduction); strides count elements. Used with
  * brv_im2col_bf16 / brv_col2im_bf16 (same arguments as brv_im2col / brv_col2im, the column matrix
