@@ -266,7 +266,9 @@ constexpr int BKL = 32, LDL = BKL + 8;            // k per tile, bf16 elements p
 // VEC: every operand row / column the loader touches is a whole, 16-byte aligned float4 (checked
 // by the host): 4 x 16-byte loads per operand, thread and tile instead of 16 scalar ones -- the
 // instruction stream of the scalar loader, not the MFMA, is what bounds this kernel.
-template <bool TA, bool TB, bool VEC>
+// CV: op_b is the column matrix of an image (p.b_conv); its own instantiation so that the plain
+// kernel keeps its register budget (160 VGPRs = 3 waves per SIMD; the column loader needs 184)
+template <bool TA, bool TB, bool VEC, bool CV = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit) {
   __shared__ __attribute__((aligned(16))) bf16_t As[BM2][LDL];
   __shared__ __attribute__((aligned(16))) bf16_t Bs[BN2][LDL];
@@ -306,8 +308,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
   // the vector loader's form: row -> (c, i, j) and pixel -> (y, x) are split off so that whichever
   // of the two is fixed for a thread is decomposed ONCE per kernel; the divisions are float
   // multiplications with an exact correction (the loader's instruction stream bounds this kernel)
-  const float inv_khw = 1.f/(float)(p.cv_kh*p.cv_kw), inv_kw = 1.f/(float)(p.b_conv ? p.cv_kw : 1);
-  const float inv_wo = 1.f/(float)(p.b_conv ? p.cv_Wo : 1), inv_sh = 1.f/(float)(p.b_conv ? p.cv_sh : 1);
+  const float inv_khw = CV ? 1.f/(float)(p.cv_kh*p.cv_kw) : 1.f, inv_kw = CV ? 1.f/(float)p.cv_kw : 1.f;
+  const float inv_wo = CV ? 1.f/(float)p.cv_Wo : 1.f, inv_sh = CV ? 1.f/(float)p.cv_sh : 1.f;
   auto fdiv = [](int n, int d, float inv, int& q, int& r) {       // n >= 0
     q = (int)((float)n*inv);
     r = n - q*d;
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
       item(tid + r*256, !TB, row, kp);
       const int n = n0 + row;
       v = make_float2(0.f, 0.f);
-      if (n < p.N && p.b_conv) {
+      if (CV && n < p.N) {
         // (row, pixel) of the virtual matrix: (n, k) with TB, (k, n) without
         if (k0 + 2*kp < p.K) v.x = TB ? col_elem(B, n, k0 + 2*kp) : col_elem(B, k0 + 2*kp, n);
         if (k0 + 2*kp + 1 < p.K) v.y = TB ? col_elem(B, n, k0 + 2*kp + 1) : col_elem(B, k0 + 2*kp + 1, n);
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
   // with TB its four rows
   ColYX my_yx = {0, 0};
   ColRC my_rc[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  if (VEC && p.b_conv) {
+  if (VEC && CV) {
     if (TB) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int row = n0 + ((tid + r*256) >> 3); if (row < p.N) my_rc[r] = dec_row(row); }
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
   auto vfetch = [&](long long t) {
     const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BKL;
     vfetch1(p.A, (long long)b*p.a_bs + (long long)kb*p.a_kbs, p.lda, !TA, m0, p.M, k0, va, p.a_bf16 != 0);
-    if (p.b_conv) vfetch_col(p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs, k0);
+    if constexpr (CV) vfetch_col(p.B + (long long)b*p.b_bs + (long long)kb*p.b_kbs, k0);
     else vfetch1(p.B, (long long)b*p.b_bs + (long long)kb*p.b_kbs, p.ldb, TB, n0, p.N, k0, vb, p.b_bf16 != 0);
   };
   auto vstash = [&]() { vstash1(As, !TA, va); vstash1(Bs, TB, vb); };
@@ -964,7 +966,9 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
                      (conv || ((uintptr_t)b & ((flags & 1) ? 7 : 15)) == 0) &&
                      q4(trans_a ? M : K) && q4(trans_b ? K : N) && !getenv("BRV_GEMM_SCALAR");
 #define BRV_BF16_LAUNCH(TA_, TB_) \
-    do { if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, p, (int)ksplit); \
+    do { if (conv && vec) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, true, true>), grid, dim3(256), 0, st, p, (int)ksplit); \
+         else if (conv) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, false, true>), grid, dim3(256), 0, st, p, (int)ksplit); \
+         else if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, p, (int)ksplit); \
          else hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, false>), grid, dim3(256), 0, st, p, (int)ksplit); } while (0)
     if (trans_a && trans_b) BRV_BF16_LAUNCH(true, true);
     else if (trans_a) BRV_BF16_LAUNCH(true, false);

@@ -120,6 +120,14 @@ def main():
     ap.add_argument('--rows', default='convtasnet_fp32,ffnn,dccrn,tfgridnet,sgmse,sgmse_train')
     args = ap.parse_args()
     rows = args.rows.split(',')
+    if len(rows) > 1:
+        # one process per row: a row measured after others in the same process inherits their
+        # caching-allocator state (the SGMSE+ training row read 114 instead of 74 ms that way)
+        import subprocess
+        import sys
+        for r in rows:
+            subprocess.run([sys.executable, __file__, '--rows', r], check=False)
+        return
     if 'convtasnet_fp32' in rows:
         print(json.dumps(convtasnet_fp32_row()), flush=True)
     if 'ffnn' in rows:
