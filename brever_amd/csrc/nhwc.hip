@@ -248,16 +248,33 @@ __global__ __launch_bounds__(256) void nhwc_conv1x1_kernel(const Pw1Params p) {
     for (int i = 0; i < 16; ++i) acc[cf][i] = 0.f;
   const h8* wa = p.wp + (long long)cob*p.n_ks*4*64 + lane;
   const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int ks = 0; ks < p.n_ks; ++ks) {
+  // operands of k-step ks + 1 are requested before the MFMAs of k-step ks (small images run a few
+  // workgroups whose reduction is a chain of load latencies otherwise)
+  auto load_b = [&](int ks) -> h8 {
     const bool second = ks >= p.n_ks1;
     const _Float16* xb = second ? p.x2 : p.x1;
     const int cs = second ? p.C2s : p.C1s;
     const int c0 = (second ? ks - p.n_ks1 : ks)*16 + khalf*8;
     h8 bv = zero;
     if (pok && c0 < cs) bv = *reinterpret_cast<const h8*>(xb + px*cs + c0);
+    return bv;
+  };
+  h8 bn = load_b(0), an[4];
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf) an[cf] = wa[cf*64];
+  for (int ks = 0; ks < p.n_ks; ++ks) {
+    const h8 bv = bn;
+    h8 av[4];
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf) av[cf] = an[cf];
+    if (ks + 1 < p.n_ks) {
+      bn = load_b(ks + 1);
+#pragma unroll
+      for (int cf = 0; cf < 4; ++cf) an[cf] = wa[((ks + 1)*4 + cf)*64];
+    }
 #pragma unroll
     for (int cf = 0; cf < 4; ++cf)
-      acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[(ks*4 + cf)*64], bv, acc[cf], 0, 0, 0);
+      acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[cf], bv, acc[cf], 0, 0, 0);
   }
   // D[co][pixel] -> LDS [pixel][co] -> 16-byte pieces of whole pixel rows
 #pragma unroll

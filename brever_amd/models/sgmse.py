@@ -38,9 +38,12 @@ _GN_SCRATCH = {}
 
 class hip_autocast:
     """``use_amp`` of the HIP path: inside the block the 1x1 / 3x3 convolutions run on the fp16
-    MFMA with fp32 accumulation and fp32 activations (``brv_conv2d_mfma_forward``; the
-    reference autocasts to fp16, sgmse.py:190-193) and the group norms feeding them are folded
-    into their load path; outside, every kernel is fp32."""
+    MFMA with fp32 accumulation and the group norms feeding them are folded into their load
+    path (the reference autocasts to fp16, sgmse.py:190-193). Networks with 'standard' / 'skip'
+    encoders and decoders keep channels-last fp16 activations between the layers
+    (``brv_conv_nhwc_forward`` and the ``brv_nhwc_*`` kernels, ``DiffusionUNet._forward_nhwc``);
+    the others fp32 NCHW activations (``brv_conv2d_mfma_forward``). Outside the block every
+    kernel is fp32."""
 
     def __init__(self, enabled):
         self.enabled = bool(enabled)
