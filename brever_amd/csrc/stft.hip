@@ -480,11 +480,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
       for (int r = 0; r < 4; ++r) { const int row = n0 + ((tid + r*256) >> 3); if (row < p.N) my_rc[r] = dec_row(row); }
     } else if (n0 + 4*(tid & 31) < p.N) my_yx = dec_pix(n0 + 4*(tid & 31));
   }
+  // without TB the thread's four rows advance by one tile (BKL rows) per step: (c, i, j) are
+  // carried instead of re-divided (the loader's instruction count bounds this kernel)
+  ColRC run_rc[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  int run_t[4] = {0, 0, 0, 0}, run_k0 = -0x40000000;
+  const int khw_ = CV ? p.cv_kh*p.cv_kw : 1;
+  const int adv_c = BKL / khw_, adv_t = BKL - adv_c*khw_;
   auto vfetch_col = [&](const float* img, int k0) {
     // the items of vfetch1 with the column matrix behind them: TB -> (row n, 4 pixels along k),
     // else (4 pixels along n, rows k and k + 1)
     ColYX yx = my_yx;
     if (TB && k0 + 4*(tid & 7) < p.K) yx = dec_pix(k0 + 4*(tid & 7));
+    const bool carried = !TB && k0 == run_k0 + BKL;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e = tid + (r >> (TB ? 0 : 1))*256;
@@ -494,10 +501,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const G32 p, int ksplit)
         if (n0 + row < p.N && k0 + 4*kq < p.K) q = col_vec4(img, my_rc[r], yx, n0 + row, k0 + 4*kq);
       } else {
         const int rq = e & 31, kp = e >> 5, k = k0 + 2*kp + (r & 1);
-        if (n0 + 4*rq < p.N && k < p.K) q = col_vec4(img, dec_row(k), yx, k, n0 + 4*rq);
+        if (carried) {
+          run_rc[r].c += adv_c; run_t[r] += adv_t;
+          if (run_t[r] >= khw_) { run_t[r] -= khw_; ++run_rc[r].c; }
+        } else {
+          fdiv(k, khw_, inv_khw, run_rc[r].c, run_t[r]);
+        }
+        fdiv(run_t[r], p.cv_kw, inv_kw, run_rc[r].i, run_rc[r].j);
+        if (n0 + 4*rq < p.N && k < p.K) q = col_vec4(img, run_rc[r], yx, k, n0 + 4*rq);
       }
       vb[r] = q;
     }
+    run_k0 = k0;
   };
   auto vfetch = [&](long long t) {
     const int kb = (int)(t / ktiles), k0 = (int)(t % ktiles)*BKL;
