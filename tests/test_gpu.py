@@ -1397,6 +1397,40 @@ def test_sgmse_channels_last_kernels_match_torch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('block_type,enc,dec', [('ncsn', 'skip', 'skip'), ('adm', 'standard', 'standard'),
+                                                ('adm', 'skip', 'skip'), ('ncsn', 'standard', 'standard')])
+def test_sgmse_channels_last_network_matches_fp32_path(block_type, enc, dec):
+    """The use_amp score network on channels-last fp16 activations (``_forward_nhwc``) against the
+    SAME weights on the fp32 HIP path (itself pinned to the oracle / goldens): small networks of
+    every block / encoder / decoder type the channels-last form covers, with attention, resampling,
+    skip concatenations and ragged sizes; batch 1 (4-row tiles) and batch 3. rel-L2 <= 5e-3."""
+    from brever_amd.models import sgmse as M
+    dev = _cuda()
+    torch.manual_seed(3)
+    net = M.DiffusionUNet(num_freqs=32, base_channels=32, channel_mult=[1, 2, 2], num_blocks_per_res=1,
+                          noise_channel_mult=2, emb_channel_mult=4, fir_kernel=[1, 3, 3, 1],
+                          attn_resolutions=[8], attn_bottleneck=True, encoder_type=enc,
+                          decoder_type=dec, block_type=block_type, skip_scale=0.5**0.5, dropout=0.0,
+                          aux_out_channels=4).to(dev).eval()
+    with torch.no_grad():
+        for prm in net.parameters():            # zero-initialised layers would hide their inputs
+            if float(prm.abs().max()) == 0.0:
+                prm.normal_(0.0, 0.05)
+    assert net._nhwc_ok()
+    g = torch.Generator().manual_seed(4)
+    for B, T in ((1, 37), (3, 50)):
+        x = torch.randn(B, 4, 32, T, generator=g).to(dev)
+        sigma = torch.rand(B, generator=g).to(dev) + 0.1
+        with torch.no_grad():
+            with M.hip_autocast(False):
+                want = net(x, sigma)
+            with M.hip_autocast(True):
+                got = net(x, sigma)
+        assert got.shape == want.shape
+        assert rel(got, want) <= 5e-3, (block_type, enc, dec, B, rel(got, want))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('tag', ['pc', 'edm', 'res'])
 def test_sgmse_matches_reference(golden_dir, tag):
     """HIP SGMSE+ vs the oracle and the reference golden at seeded weights: the preconditioned
