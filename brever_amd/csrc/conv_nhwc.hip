@@ -652,14 +652,16 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
     if constexpr ((CN_VAR & 4) != 0 && PF == 4) {
       mfma_block_fine();
       CN_STAMP(3);
-      if (wsel == 0) dma_block();
+      // (fragments in flight are made real before the long DMA / transform block: a register copy
+      // or spill hipcc might place there would otherwise copy bits that have not arrived)
+      if (wsel == 0) { cn_wait_frags<0>(fa[0], fb[0]); dma_block(); }
     } else if constexpr ((CN_VAR & 1) != 0) {
       mfma_block(wsel == 0);
       CN_STAMP(3);
     } else {
       mfma_block(false);
       CN_STAMP(3);
-      if (wsel == 0) dma_block();
+      if (wsel == 0) { cn_wait_frags<0>(fa[0], fb[0]); dma_block(); }
     }
     // the fragments read for the next chunk are live across the loop back edge (and the epilogue):
     // make them real first -- a register copy hipcc inserts before the wait would copy stale bits
