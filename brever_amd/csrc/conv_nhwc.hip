@@ -55,7 +55,9 @@ constexpr int CN_CK = 32;                     // input channels per chunk (2 k-s
 #ifndef CN_DA
 #define CN_DA 4                               // the weight stream runs this many taps ahead
 #endif
-constexpr int CN_NA = CN_DA + 1;              // weight ring slots (one tap each)
+#ifndef CN_DA_SMALL
+#define CN_DA_SMALL 8                         // ... for the 8- and 4-row tiles: their taps are short, the
+#endif                                       // weight stream is bound by what is in flight
 constexpr int CN_ASLOT = 8192;                // [k-step 2][co fragment 4][lane 64][8 halves]
 constexpr int CN_TAB = 1024;                  // per wave and parity: 32 scales + 32 shifts + 128 biases (fp32)
 #ifndef CN_VAR
@@ -144,16 +146,16 @@ __device__ __forceinline__ unsigned long long cn_stamp() {
 // DMA issue order of one chunk (KS = 3, ROUNDS = 5 patch pieces P, one weight piece A per tap, one
 // table piece T): tap 0: T A P0 | tap 1: A P1 | ... | tap 4: A P4 | taps 5-8: A. The same pattern
 // every chunk, so every wait count below is a compile-time function of the tap.
-template <int ROUNDS>
+template <int ROUNDS, int DA>
 struct CnSched {
   static constexpr int P(int tp) { return tp >= 0 && tp < ROUNDS ? 1 : 0; }
   static constexpr int ops(int tp) { return 1 + P(tp) + (tp == 0 ? 1 : 0); }
   static constexpr int mod9(int tp) { return (tp + 90) % 9; }
-  // top of tap tp: the weights of tap t+1 (issued CN_DA-1 taps ago, followed in their tap only
+  // top of tap tp: the weights of tap t+1 (issued DA-1 taps ago, followed in their tap only
   // by a patch piece) have landed when at most this many younger DMAs are pending
   static constexpr int top(int tp) {
-    int n = P(mod9(tp + 1 - CN_DA));
-    for (int k = tp + 2 - CN_DA; k <= tp - 1; ++k) n += ops(mod9(k));
+    int n = P(mod9(tp + 1 - DA));
+    for (int k = tp + 2 - DA; k <= tp - 1; ++k) n += ops(mod9(k));
     return n;
   }
   // after the issues of tap tp: patch piece r = tp - 3 (last DMA of tap r) has landed
@@ -174,9 +176,10 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
   // (a patch buffer doubles as the epilogue's staging area: 128 pixel rows of 272 bytes)
   constexpr int PBYTES = ROUNDS*CN_THREADS*16 > 35*1024 ? ROUNDS*CN_THREADS*16 : 35*1024;
   constexpr int OFF_A = 2*PBYTES;
-  constexpr int OFF_TAB = OFF_A + CN_NA*CN_ASLOT;
+  constexpr int DA = PF == 4 ? CN_DA : CN_DA_SMALL, NA = DA + 1;   // weight prefetch depth, ring slots
+  constexpr int OFF_TAB = OFF_A + NA*CN_ASLOT;
   constexpr int SMEM = OFF_TAB + 2*CN_WAVES*CN_TAB;
-  using S = CnSched<ROUNDS>;
+  using S = CnSched<ROUNDS, DA>;
   // ONE shared array (a second object makes hipcc drain vmcnt before LDS reads)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) issue_patch(r, 0, 0);
 #pragma unroll
-  for (int d = 0; d < CN_DA; ++d) issue_weights(d);
+  for (int d = 0; d < DA; ++d) issue_weights(d);
   cn_wait_vm<0>();
   if (FOLD && !(CN_ABL & 8)) {
 #pragma unroll
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
     constexpr bool XF = FOLD && !(CN_ABL & 8) && TP >= 3 && TP - 3 < ROUNDS;
     auto dma_block = [&]() {
       if (TP == 0) { advance_prefetch(); issue_table(nx_chunk, par ^ 1); }
-      issue_weights(ring + CN_DA >= CN_NA ? ring + CN_DA - CN_NA : ring + CN_DA);
+      issue_weights(ring + DA >= NA ? ring + DA - NA : ring + DA);
       if (TP < ROUNDS) issue_patch(TP, nx_chunk, par ^ 1);
       if constexpr (XF) {                      // piece TP-3 of the next patch: own DMA landed
         XfRaw xv;
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
         transform_write(TP - 3, par ^ 1, xv);
       }
     };
-    const int nring = ring + 1 == CN_NA ? 0 : ring + 1;
+    const int nring = ring + 1 == NA ? 0 : ring + 1;
     // CN_VAR & 4: the 12 fragment reads of the tap go out ONE per MFMA gap instead of in two bursts
     // of six (a burst stalls the issuing wave on the LDS queue while its MFMA slots pass)
     auto one_mfma = [&](int cf, int pf, u32x4& a, u32x4& b) {
