@@ -32,6 +32,7 @@
 #include <hip/hip_fp16.h>
 
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "../../include/brever_hip.h"
@@ -59,6 +60,7 @@ constexpr int CN_CK = 32;                     // input channels per chunk (2 k-s
 #define CN_DA_SMALL 8                         // ... for the 8- and 4-row tiles: their taps are short, the
 #endif                                       // weight stream is bound by what is in flight
 constexpr int CN_ASLOT = 8192;                // [k-step 2][co fragment 4][lane 64][8 halves]
+constexpr int CN_MAXC = 1024;                 // input channels of a self-folding launch (FOLD == 2)
 constexpr int CN_TAB = 1024;                  // per wave and parity: 32 scales + 32 shifts + 128 biases (fp32)
 #ifndef CN_VAR
 #define CN_VAR 4    // experiment bits: 1 wco-0 waves issue their DMAs between the k-steps, 2 s_setprio around MFMAs
@@ -72,7 +74,12 @@ struct ConvNhwcParams {
   const _Float16* x1; const _Float16* x2;     // (B, H, W, C1s) [, (B, H, W, C2s)]
   const unsigned char* wp;                    // packed weights
   const float* bias; const _Float16* res; _Float16* y;
-  const float* in_scale; const float* in_shift;   // (B, Cin) each (FOLD only)
+  const float* in_scale; const float* in_shift;   // (B, Cin) each (FOLD == 1)
+  // FOLD == 2: the GroupNorm is folded by the workgroup itself from the per-channel sums
+  const double* sums1; const double* sums2;       // (B, C1, 2), (B, C2, 2)
+  const float* gn_add; const float* gn_gamma; const float* gn_beta;
+  const float* adm_scale; const float* adm_shift; // (B, Cin) nullable
+  int C1, C2, groups; float eps;
   const unsigned char* zeros;                 // >= 16 bytes of zeros
   double* stats;                              // nullable (B, Cout, 2): += per-channel (sum, sum of squares) of y
   int B, H, W, C1s, C2s, n_chunks1, n_chunks, Cin, Cout, Cys, Crs;
@@ -165,7 +172,10 @@ struct CnSched {
 // PF = accumulator rows per wave: the tile is (4*PF rows) x 32 columns x 128 channels. PF = 4 for
 // images with enough tiles to fill the chip; smaller PF gives small images 2-4x the workgroups
 // (each still streams all the weights: their taps are then paced by the DMA, not the MFMAs).
-template <int KS, bool FOLD, int PF>
+// FOLD: 0 plain input; 1 scale / shift (B, Cin) from memory (brv_groupnorm_fold_chan); 2 the fold is
+// computed in the prologue from the per-channel sums (every tile of the workgroup belongs to one
+// item): no fold launch between the producing convolution and this one.
+template <int KS, int FOLD, int PF>
 __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcParams p) {
   static_assert(KS == 3, "3x3 only");
   constexpr int CN_ROWS = 4*PF;
@@ -176,9 +186,11 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
   // (a patch buffer doubles as the epilogue's staging area: 128 pixel rows of 272 bytes)
   constexpr int PBYTES = ROUNDS*CN_THREADS*16 > 35*1024 ? ROUNDS*CN_THREADS*16 : 35*1024;
   constexpr int OFF_A = 2*PBYTES;
-  constexpr int DA = PF == 4 ? CN_DA : CN_DA_SMALL, NA = DA + 1;   // weight prefetch depth, ring slots
+  // weight prefetch depth, ring slots (one slot less where the self-fold table needs the LDS)
+  constexpr int DA = PF == 4 ? CN_DA : (FOLD == 2 ? CN_DA_SMALL - 1 : CN_DA_SMALL), NA = DA + 1;
   constexpr int OFF_TAB = OFF_A + NA*CN_ASLOT;
-  constexpr int SMEM = OFF_TAB + 2*CN_WAVES*CN_TAB;
+  constexpr int OFF_FOLD = OFF_TAB + 2*CN_WAVES*CN_TAB;
+  constexpr int SMEM = OFF_FOLD + (FOLD == 2 ? 2*CN_MAXC*4 : 0);
   using S = CnSched<ROUNDS, DA>;
   // ONE shared array (a second object makes hipcc drain vmcnt before LDS reads)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
     const long long hw = (long long)p.H*p.W;
     nx_x1 = p.x1 + (long long)q.b*hw*p.C1s;
     nx_x2 = p.x2 ? p.x2 + (long long)q.b*hw*p.C2s : nullptr;
-    if (FOLD) { nx_sc = p.in_scale + (long long)q.b*p.Cin; nx_sh = p.in_shift + (long long)q.b*p.Cin; }
+    if (FOLD == 1) { nx_sc = p.in_scale + (long long)q.b*p.Cin; nx_sh = p.in_shift + (long long)q.b*p.Cin; }
     nx_bias_co = q.cob*128;
     nx_bias = p.bias + nx_bias_co;
   };
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
   // chunk's tile (no VGPR-destination loads inside the loop: hipcc would wait vmcnt(0) for them)
   auto issue_table = [&](int chunk, int par) {
     const float* src = (const float*)p.zeros;
-    if (FOLD && lane < 16) src = (lane < 8 ? nx_sc : nx_sh) + chunk*CN_CK + (lane & 7)*4;
+    if (FOLD == 1 && lane < 16) src = (lane < 8 ? nx_sc : nx_sh) + chunk*CN_CK + (lane & 7)*4;
     if (lane >= 16 && lane < 48 && p.bias && nx_bias_co + (lane - 16)*4 + 4 <= p.Cout)
       src = nx_bias + (lane - 16)*4;
     cn_glds16(src, smem + OFF_TAB + (par*CN_WAVES + wave)*CN_TAB);
@@ -275,12 +287,18 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
   // Split in two so that the arithmetic sits behind the MFMAs of the tap: reads (5 DS
   // operations), then math + write.
   struct XfRaw { u32x4 raw, s0, s1, t0, t1; };
-  auto transform_reads = [&](int r, int par, XfRaw& v) {
+  auto transform_reads = [&](int r, int par, int chunk, XfRaw& v) {
     const unsigned int sa = smem_a + par*PBYTES + (r*CN_WAVES + wave)*1024 + lane*16;
-    const unsigned int ta = smem_a + OFF_TAB + (par*CN_WAVES + wave)*CN_TAB + (nx_pk[r] & 3)*32;
     v.raw = cn_read16<0>(sa);
-    v.s0 = cn_read16<0>(ta); v.s1 = cn_read16<16>(ta);
-    v.t0 = cn_read16<128>(ta); v.t1 = cn_read16<144>(ta);
+    if (FOLD == 2) {                               // the workgroup's own table: [scale Cin | shift Cin]
+      const unsigned int ta = smem_a + OFF_FOLD + (chunk*CN_CK + (nx_pk[r] & 3)*8)*4;
+      v.s0 = cn_read16<0>(ta); v.s1 = cn_read16<16>(ta);
+      v.t0 = cn_read16<CN_MAXC*4>(ta); v.t1 = cn_read16<CN_MAXC*4 + 16>(ta);
+    } else {                                       // this wave's table piece of the chunk
+      const unsigned int ta = smem_a + OFF_TAB + (par*CN_WAVES + wave)*CN_TAB + (nx_pk[r] & 3)*32;
+      v.s0 = cn_read16<0>(ta); v.s1 = cn_read16<16>(ta);
+      v.t0 = cn_read16<128>(ta); v.t1 = cn_read16<144>(ta);
+    }
   };
   auto transform_write = [&](int r, int par, const XfRaw& v) {
     const unsigned int sa = smem_a + par*PBYTES + (r*CN_WAVES + wave)*1024 + lane*16;
@@ -519,6 +537,38 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
     }
   };
 
+  // ---- FOLD == 2: GroupNorm(x + add) [ADM-modulated] as scale / shift per channel, the arithmetic of
+  // chan_fold_kernel (nhwc.hip), for the ONE item this workgroup's tiles belong to
+  if (FOLD == 2) {
+    float* ftab = reinterpret_cast<float*>(smem + OFF_FOLD);
+    const int b0 = decode(tile_lo).b;
+    const int cpg = p.Cin/p.groups;
+    const double hw = (double)p.H*(double)p.W;
+    for (int c = tid; c < p.Cin; c += CN_THREADS) {
+      const int g0 = (c/cpg)*cpg;
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < cpg; ++k) {
+        const int ch = g0 + k;
+        const double* sp = ch < p.C1 ? p.sums1 + (((long long)b0*p.C1 + ch) << 1)
+                                     : p.sums2 + (((long long)b0*p.C2 + ch - p.C1) << 1);
+        const double e = p.gn_add ? (double)p.gn_add[(long long)b0*p.Cin + ch] : 0.0;
+        const double cs = sp[0], cq = sp[1];
+        s1 += cs + hw*e;
+        s2 += cq + 2.0*e*cs + hw*e*e;
+      }
+      const double n = (double)cpg*hw, mean = s1/n;
+      double var = s2/n - mean*mean;
+      if (var < 0) var = 0;
+      const float rstd = (float)(1.0/sqrt(var + (double)p.eps));
+      const long long idx = (long long)b0*p.Cin + c;
+      float sc = rstd*p.gn_gamma[c];
+      float sh = p.gn_beta[c] + ((p.gn_add ? p.gn_add[idx] : 0.f) - (float)mean)*sc;
+      if (p.adm_scale) { const float m = 1.f + p.adm_scale[idx]; sc *= m; sh = sh*m + p.adm_shift[idx]; }
+      ftab[c] = sc; ftab[CN_MAXC + c] = sh;
+    }
+    __syncthreads();
+  }
+
   // ---- prologue: chunk 0 of the first tile + the first CN_DA taps of weights
   Tile cur = decode(tile_lo);
   Tile nxt = cur;
@@ -533,7 +583,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
       XfRaw v;
-      transform_reads(r, 0, v);
+      transform_reads(r, 0, 0, v);
       cn_wait5<0>(v.raw, v.s0, v.s1, v.t0, v.t1);
       transform_write(r, 0, v);
     }
@@ -586,7 +636,7 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
       if constexpr (XF) {                      // piece TP-3 of the next patch: own DMA landed
         XfRaw xv;
         cn_wait_vm<S::piece(TP)>();
-        transform_reads(TP - 3, par ^ 1, xv);
+        transform_reads(TP - 3, par ^ 1, nx_chunk, xv);
         cn_wait5<0>(xv.raw, xv.s0, xv.s1, xv.t0, xv.t1);
         transform_write(TP - 3, par ^ 1, xv);
       }
@@ -750,16 +800,29 @@ int brv_conv_nhwc_pack(const float* w, void* wp, int64_t Cout, int64_t Cin, int6
   return 0;
 }
 
-int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
-                          int64_t C2s, const void* wp, const float* bias, const void* res,
-                          int64_t Crs, const float* in_scale, const float* in_shift, int in_silu,
-                          void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout,
-                          int64_t ksize, float out_scale, double* stats, brv_stream_t stream) {
+// shared launcher: `gn` selects the self-folding kernel when every workgroup's tiles lie in one item
+struct ConvNhwcNorm {
+  const double* sums1; const double* sums2; const float* add; const float* gamma; const float* beta;
+  const float* adm_scale; const float* adm_shift; int groups; float eps; float* fold_ws;
+};
+}  // extern "C"
+extern "C" int brv_groupnorm_fold_chan2(const double* sums1, int64_t C1, const double* sums2, int64_t C2,
+                                        const float* add_bc, const float* gamma, const float* beta,
+                                        const float* adm_scale, const float* adm_shift, float* scale_bc,
+                                        float* shift_bc, int64_t B, int64_t HW, int64_t groups,
+                                        float eps, brv_stream_t stream);
+namespace {
+int conv_nhwc_launch(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2, int64_t C2s,
+                     const void* wp, const float* bias, const void* res, int64_t Crs,
+                     const float* in_scale, const float* in_shift, const ConvNhwcNorm* gn, int in_silu,
+                     void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout, int64_t ksize,
+                     float out_scale, double* stats, brv_stream_t stream) {
   if (B < 1 || H < 1 || W < 1 || C1 < 1 || Cout < 1 || ksize != 3) return -1;
   if ((C1s & 7) || C1 > C1s || (Cys & 7) || (res && (Crs & 7)) || (Cout & 3)) return -2;
   if (x2 && ((C2s & 7) || C2 > C2s || C2 < 1 || (C1 % CN_CK) != 0)) return -2;
   const int64_t Cin = C1 + (x2 ? C2 : 0);
-  if (in_scale && (Cin % CN_CK) != 0) return -3;
+  if ((in_scale || gn) && (Cin % CN_CK) != 0) return -3;
+  if (gn && (gn->groups < 1 || Cin % gn->groups || !gn->fold_ws)) return -3;
   static const unsigned char* zeros = nullptr;
   if (!zeros) {
     void* z = nullptr;
@@ -767,6 +830,7 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
     zeros = (const unsigned char*)z;
   }
   ConvNhwcParams p;
+  memset(&p, 0, sizeof(p));
   p.x1 = (const _Float16*)x1; p.x2 = (const _Float16*)x2; p.wp = (const unsigned char*)wp;
   p.bias = bias; p.res = (const _Float16*)res; p.y = (_Float16*)y;
   p.in_scale = in_scale; p.in_shift = in_shift; p.zeros = zeros; p.stats = stats;
@@ -774,6 +838,7 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
   p.n_chunks1 = (int)((C1 + CN_CK - 1)/CN_CK);
   p.n_chunks = p.n_chunks1 + (x2 ? (int)((C2 + CN_CK - 1)/CN_CK) : 0);
   p.Cin = (int)Cin; p.Cout = (int)Cout; p.Cys = (int)Cys; p.Crs = (int)Crs;
+  p.C1 = (int)C1; p.C2 = x2 ? (int)C2 : 0;
   p.n_wt = (int)((W + CN_COLS - 1)/CN_COLS);
   p.n_cob = (int)((Cout + 127)/128);
   // rows per tile: 16 when that fills the chip, else 8 or 4 (2-4x the workgroups)
@@ -796,14 +861,66 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
   p.dbg = dbg;
   brv_conv_nhwc_dbg = dbg;
 #endif
-  const dim3 grid((unsigned)(n_tiles < 256 ? n_tiles : 256)), block(CN_THREADS);
+  const long long G = n_tiles < 256 ? n_tiles : 256;
+  int fold = in_scale ? 1 : 0;
+  if (gn) {
+    // self-fold: every workgroup's run of tiles inside one item (the launch's own rank -> range map)
+    static int no_self = -1;
+    if (no_self < 0) { const char* e = getenv("BRV_CONV_NO_SELF_FOLD"); no_self = e ? atoi(e) : 0; }
+    const long long tpi = (long long)p.n_ht*p.n_wt*p.n_cob;
+    bool single = !no_self && Cin <= CN_MAXC;
+    for (long long r = 0; single && r < G; ++r) {
+      const long long lo = r*n_tiles/G, hi = (r + 1)*n_tiles/G;
+      if (hi > lo && lo/tpi != (hi - 1)/tpi) single = false;
+    }
+    if (single) {
+      fold = 2;
+      p.sums1 = gn->sums1; p.sums2 = gn->sums2; p.gn_add = gn->add; p.gn_gamma = gn->gamma;
+      p.gn_beta = gn->beta; p.adm_scale = gn->adm_scale; p.adm_shift = gn->adm_shift;
+      p.groups = gn->groups; p.eps = gn->eps;
+    } else {
+      const int rc = brv_groupnorm_fold_chan2(gn->sums1, C1, gn->sums2, x2 ? C2 : 0, gn->add, gn->gamma,
+                                              gn->beta, gn->adm_scale, gn->adm_shift, gn->fold_ws,
+                                              gn->fold_ws + B*Cin, B, H*W, gn->groups, gn->eps, stream);
+      if (rc) return rc;
+      fold = 1;
+      p.in_scale = gn->fold_ws; p.in_shift = gn->fold_ws + B*Cin;
+    }
+  }
+  const dim3 grid((unsigned)G), block(CN_THREADS);
   const hipStream_t st = (hipStream_t)stream;
 #define CN_LAUNCH(F, P) hipLaunchKernelGGL((conv_nhwc_kernel<3, F, P>), grid, block, 0, st, p)
-  if (in_scale) { if (pf == 4) CN_LAUNCH(true, 4); else if (pf == 2) CN_LAUNCH(true, 2); else CN_LAUNCH(true, 1); }
-  else { if (pf == 4) CN_LAUNCH(false, 4); else if (pf == 2) CN_LAUNCH(false, 2); else CN_LAUNCH(false, 1); }
+#define CN_LAUNCH_PF(F) do { if (pf == 4) CN_LAUNCH(F, 4); else if (pf == 2) CN_LAUNCH(F, 2); else CN_LAUNCH(F, 1); } while (0)
+  if (fold == 2) CN_LAUNCH_PF(2); else if (fold == 1) CN_LAUNCH_PF(1); else CN_LAUNCH_PF(0);
+#undef CN_LAUNCH_PF
 #undef CN_LAUNCH
   CN_OK(hipGetLastError());
   return 0;
+}
+}  // namespace
+extern "C" {
+
+int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                          int64_t C2s, const void* wp, const float* bias, const void* res,
+                          int64_t Crs, const float* in_scale, const float* in_shift, int in_silu,
+                          void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout,
+                          int64_t ksize, float out_scale, double* stats, brv_stream_t stream) {
+  return conv_nhwc_launch(x1, C1, C1s, x2, C2, C2s, wp, bias, res, Crs, in_scale, in_shift, nullptr,
+                          in_silu, y, Cys, B, H, W, Cout, ksize, out_scale, stats, stream);
+}
+
+int brv_conv_nhwc_forward_gn(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                             int64_t C2s, const void* wp, const float* bias, const void* res,
+                             int64_t Crs, const double* sums1, const double* sums2,
+                             const float* add_bc, const float* gamma, const float* beta,
+                             const float* adm_scale, const float* adm_shift, int64_t groups, float eps,
+                             float* fold_ws, int in_silu, void* y, int64_t Cys, int64_t B, int64_t H,
+                             int64_t W, int64_t Cout, int64_t ksize, float out_scale, double* stats,
+                             brv_stream_t stream) {
+  if (!sums1 || !gamma || !beta || (x2 && !sums2)) return -1;
+  ConvNhwcNorm gn = {sums1, sums2, add_bc, gamma, beta, adm_scale, adm_shift, (int)groups, eps, fold_ws};
+  return conv_nhwc_launch(x1, C1, C1s, x2, C2, C2s, wp, bias, res, Crs, nullptr, nullptr, &gn, in_silu,
+                          y, Cys, B, H, W, Cout, ksize, out_scale, stats, stream);
 }
 
 }  // extern "C"

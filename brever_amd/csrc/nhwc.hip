@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const _Float16* x, doub
 // one workgroup (64 threads) per (item, group): statistics of x + add[b][c] from the channel
 // sums, then scale = rstd*gamma*(1 + adm_scale), shift = (beta + (add - mean)*rstd*gamma)*(1 +
 // adm_scale) + adm_shift (the arithmetic of gn_fold_kernel, sgmse.hip)
-__global__ __launch_bounds__(64) void chan_fold_kernel(const double* sums, const float* add,
+__global__ __launch_bounds__(64) void chan_fold_kernel(const double* sums, const double* sums2, int C1,
+                                                       const float* add,
                                                        const float* gamma, const float* beta,
                                                        const float* adm_scale, const float* adm_shift,
                                                        float* scale, float* shift, int C, long long HW,
@@ -113,7 +114,11 @@ __global__ __launch_bounds__(64) void chan_fold_kernel(const double* sums, const
   for (int j = threadIdx.x; j < cpg; j += 64) {
     const long long idx = (long long)b*C + g*cpg + j;
     const double e = add ? (double)add[idx] : 0.0;
-    const double cs = sums[idx << 1], cq = sums[(idx << 1) + 1];
+    // channels [0, C1) from `sums` (B, C1, 2), the rest from `sums2` (B, C - C1, 2)
+    const int ch = g*cpg + j;
+    const double* sp = ch < C1 ? sums + (((long long)b*C1 + ch) << 1)
+                               : sums2 + (((long long)b*(C - C1) + ch - C1) << 1);
+    const double cs = sp[0], cq = sp[1];
     s1 += cs + (double)HW*e;
     s2 += cq + 2.0*e*cs + (double)HW*e*e;
   }
@@ -508,8 +513,22 @@ int brv_groupnorm_fold_chan(const double* sums, const float* add_bc, const float
                             int64_t groups, float eps, brv_stream_t stream) {
   if (B < 1 || C < 1 || groups < 1 || C % groups || HW < 1) return -1;
   hipLaunchKernelGGL(chan_fold_kernel, dim3((unsigned)(B*groups)), dim3(64), 0, (hipStream_t)stream,
-                     sums, add_bc, gamma, beta, adm_scale, adm_shift, scale_bc, shift_bc, (int)C,
-                     (long long)HW, (int)groups, eps);
+                     sums, (const double*)nullptr, (int)C, add_bc, gamma, beta, adm_scale, adm_shift,
+                     scale_bc, shift_bc, (int)C, (long long)HW, (int)groups, eps);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_groupnorm_fold_chan2(const double* sums1, int64_t C1, const double* sums2, int64_t C2,
+                             const float* add_bc, const float* gamma, const float* beta,
+                             const float* adm_scale, const float* adm_shift, float* scale_bc,
+                             float* shift_bc, int64_t B, int64_t HW, int64_t groups, float eps,
+                             brv_stream_t stream) {
+  const int64_t C = C1 + (sums2 ? C2 : 0);
+  if (B < 1 || C1 < 1 || groups < 1 || C % groups || HW < 1) return -1;
+  hipLaunchKernelGGL(chan_fold_kernel, dim3((unsigned)(B*groups)), dim3(64), 0, (hipStream_t)stream,
+                     sums1, sums2, (int)C1, add_bc, gamma, beta, adm_scale, adm_shift, scale_bc,
+                     shift_bc, (int)C, (long long)HW, (int)groups, eps);
   NH_OK(hipGetLastError());
   return 0;
 }

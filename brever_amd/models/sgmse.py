@@ -303,8 +303,11 @@ def _h_packed3(mod):
     return mod._brv_hp
 
 
-def _h_conv3(a, mod, fold=None, silu=False, res=None, out_scale=1.0):
-    """out_scale*(conv3x3(act(fold(a))) + bias + res) on the fp16 MFMA (brv_conv_nhwc_forward)."""
+def _h_conv3(a, mod, fold=None, silu=False, res=None, out_scale=1.0, norm=None, add=None, adm=None):
+    """out_scale*(conv3x3(act(a)) + bias + res) on the fp16 MFMA. act = the folded GroupNorm ``fold`` =
+    (scale, shift) [+ SiLU], or -- ``norm`` = the GroupNorm module, ``add`` its embedding term,
+    ``adm`` its modulation -- the same fold left to the convolution (``brv_conv_nhwc_forward_gn``:
+    computed in the kernel's prologue from the per-channel sums, no launch in between)."""
     if a.second is not None and a.C % 32:
         a = _h_single(a)
     B, (H, W) = a.t.shape[0], a.hw
@@ -312,14 +315,24 @@ def _h_conv3(a, mod, fold=None, silu=False, res=None, out_scale=1.0):
     y.sums = _zeros_f64(B*mod.out_channels*2, a.t.device).view(B, mod.out_channels, 2)
     if res is not None:
         res = _h_single(res)
-    sc, sf = fold if fold is not None else (None, None)
     b = a.second
-    hip.check(hip.lib().brv_conv_nhwc_forward(
-        hip.ptr(a.t), a.C, a.Cs, hip.ptr(b.t) if b is not None else None, b.C if b is not None else 0,
-        b.Cs if b is not None else 0, hip.ptr(_h_packed3(mod)), hip.ptr(mod.bias),
-        hip.ptr(res.t) if res is not None else None, res.Cs if res is not None else 0, hip.ptr(sc),
-        hip.ptr(sf), int(silu), hip.ptr(y.t), y.Cs, B, H, W, mod.out_channels, 3, float(out_scale),
-        hip.ptr(y.sums), hip.stream()), 'brv_conv_nhwc_forward')
+    common = (hip.ptr(a.t), a.C, a.Cs, hip.ptr(b.t) if b is not None else None, b.C if b is not None else 0,
+              b.Cs if b is not None else 0, hip.ptr(_h_packed3(mod)), hip.ptr(mod.bias),
+              hip.ptr(res.t) if res is not None else None, res.Cs if res is not None else 0)
+    tail = (int(silu), hip.ptr(y.t), y.Cs, B, H, W, mod.out_channels, 3, float(out_scale), hip.ptr(y.sums),
+            hip.stream())
+    if norm is not None:
+        ws = torch.empty(2*B*a.channels, dtype=torch.float32, device=a.t.device)
+        a0, a1 = (adm[0].contiguous(), adm[1].contiguous()) if adm is not None else (None, None)
+        hip.check(hip.lib().brv_conv_nhwc_forward_gn(
+            *common, hip.ptr(_h_sums(a)), hip.ptr(_h_sums(b)) if b is not None else None,
+            hip.ptr(add.contiguous()) if add is not None else None, hip.ptr(norm.weight),
+            hip.ptr(norm.bias), hip.ptr(a0), hip.ptr(a1), norm.num_groups, float(norm.eps), hip.ptr(ws),
+            *tail), 'brv_conv_nhwc_forward_gn')
+        return y
+    sc, sf = fold if fold is not None else (None, None)
+    hip.check(hip.lib().brv_conv_nhwc_forward(*common, hip.ptr(sc), hip.ptr(sf), *tail),
+              'brv_conv_nhwc_forward')
     return y
 
 
@@ -521,17 +534,18 @@ class UNetBlock(nn.Module):
             x = _h_resample(x, self.resampler, self.up_or_down)
             h = _h_conv3(h, self.conv_1)
         else:
-            h = _h_conv3(x, self.conv_1, fold=_h_gn_fold(x, self.norm_1), silu=True)
+            h = _h_conv3(x, self.conv_1, norm=self.norm_1, silu=True)
         e = self._e if self._e is not None else _linear(emb, self.linear)
         if e.shape[0] != h.t.shape[0]:
             e = e.expand(h.t.shape[0], -1).contiguous()
-        if self.block_type == 'adm':
-            fold = _h_gn_fold(h, self.norm_2, adm=e.chunk(2, dim=1))
-        else:
-            fold = _h_gn_fold(h, self.norm_2, add=e)
         if self.skip_conv is not None:
             x = _h_conv1(x, self.skip_conv)
-        x = _h_conv3(h, self.conv_2, fold=fold, silu=True, res=x, out_scale=self.skip_scale)
+        if self.block_type == 'adm':
+            x = _h_conv3(h, self.conv_2, norm=self.norm_2, adm=e.chunk(2, dim=1), silu=True, res=x,
+                         out_scale=self.skip_scale)
+        else:
+            x = _h_conv3(h, self.conv_2, norm=self.norm_2, add=e, silu=True, res=x,
+                         out_scale=self.skip_scale)
         if self.attn is not None:
             x = self.attn.forward_h(x, out_scale=self.skip_scale)
         return x

@@ -584,6 +584,24 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
                           int64_t Crs, const float* in_scale, const float* in_shift, int in_silu,
                           void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout,
                           int64_t ksize, float out_scale, double* stats, brv_stream_t stream);
+/* The same convolution with the GroupNorm that feeds it given by its ingredients -- per-channel sums
+ * of the one or two sources (brv_nhwc_chan_stats / the producing convolution's `stats`), the
+ * embedding term add_bc (B, Cin), gamma / beta, the ADM modulation -- instead of a folded scale /
+ * shift: when every workgroup's tiles belong to one item the kernel folds them itself (no launch
+ * between producer and consumer), else brv_groupnorm_fold_chan2 runs into fold_ws (2*B*Cin floats). */
+int brv_conv_nhwc_forward_gn(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                             int64_t C2s, const void* wp, const float* bias, const void* res,
+                             int64_t Crs, const double* sums1, const double* sums2,
+                             const float* add_bc, const float* gamma, const float* beta,
+                             const float* adm_scale, const float* adm_shift, int64_t groups, float eps,
+                             float* fold_ws, int in_silu, void* y, int64_t Cys, int64_t B, int64_t H,
+                             int64_t W, int64_t Cout, int64_t ksize, float out_scale, double* stats,
+                             brv_stream_t stream);
+int brv_groupnorm_fold_chan2(const double* sums1, int64_t C1, const double* sums2, int64_t C2,
+                             const float* add_bc, const float* gamma, const float* beta,
+                             const float* adm_scale, const float* adm_shift, float* scale_bc,
+                             float* shift_bc, int64_t B, int64_t HW, int64_t groups, float eps,
+                             brv_stream_t stream);
 int brv_nchw_to_nhwc_f16(const float* x, void* y, int64_t B, int64_t C, int64_t Cs, int64_t HW,
                          brv_stream_t stream);
 int brv_nhwc_f16_to_nchw(const void* x, float* y, int64_t B, int64_t C, int64_t Cs, int64_t HW,
