@@ -15,6 +15,7 @@
 #include "gemm_rows.cuh"
 #include "gemm_wgrad.cuh"
 #include "gemm_ws.cuh"
+#include "dwpw2_fused.cuh"
 #include "gemm_wgrad_full.cuh"
 
 constexpr int kWgSplit = 4;          // item splits of the [res | skip] weight-gradient launch
@@ -38,10 +39,10 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 inline long long align_up(long long x, long long a) { return (x + a - 1)/a*a; }
 
-// opt-in fused forward (BRV_FWD_FUSE=1, see brv_ctn_forward)
+// fused forward (default; BRV_FWD_FUSE=0 selects the three-launch sequence, see brv_ctn_forward)
 inline bool fwd_fuse_requested() {
   const char* e = getenv("BRV_FWD_FUSE");
-  return e && e[0] == '1' && !getenv("BRV_NO_WS");
+  return !(e && e[0] == '0') && !getenv("BRV_NO_WS");
 }
 
 // ---- optional per-launch event timing (bench / profiling only) ---------------
@@ -81,6 +82,12 @@ struct Layout {
   long long p_enc, p_dec_f, p_dec_b, p_bott_f, p_bott_b, p_out_f, p_out_b, n_prepared;
   std::vector<BlockOff> blk;
   std::vector<long long> tensor_offsets;
+
+  // the fused forward runs for the default widths, non-causal, kernel_size 3 (see brv_ctn_forward)
+  bool fused_fwd() const {
+    return fwd_fuse_requested() && !causal && P == 3 && H == 512 && Bn == 128 && Sc == 128 &&
+           nb <= 24 /* kWgMaxProb */;
+  }
 
   int init(const brv_ctn_config* c) {
     if (!c) return fail(-1, "null config");
@@ -198,7 +205,7 @@ struct Workspace {
     vg = take(vg_bytes);
     wgpart = take((long long)kWgSplit*l.nb*W2_G*l.H*4);
     u_stride = align_up(BT*(l.Bnp + l.Scp)*2, 256);
-    u = fwd_fuse_requested() ? take(u_stride*l.nb) : 0;
+    u = l.fused_fwd() ? take(u_stride*l.nb) : 0;
     h1 = h2 = wn = ctab = cfs = cbt = ident = fake_stats = scratch_stats = 0; ctab_stride = 0;
     if (l.causal) {
       h1 = take(z_stride*l.nb);
@@ -453,22 +460,28 @@ struct LazyPrepBlk { long long res_w, res_b, skip_w, skip_b, beta, wg, out; };
 struct LazyPrepParams { int nb, H, Hp, Bn, Sc, Bnp, Scp; LazyPrepBlk blk[kWgMaxProb]; };
 __global__ __launch_bounds__(256) void lazy_prep_kernel(const float* params, bf16_t* prepped,
                                                         const LazyPrepParams p) {
-  const LazyPrepBlk& b = p.blk[blockIdx.x];
+  // one wave per output row: lanes stride over the H inputs, butterfly reduce
+  const LazyPrepBlk& b = p.blk[blockIdx.y];
   float* out = reinterpret_cast<float*>(prepped + b.out);
   const int NP = p.Bnp + p.Scp;
-  for (int n = threadIdx.x; n < NP; n += 256) {
-    const bool res = n < p.Bnp;
-    const int r = res ? n : n - p.Bnp;
-    const bool ok = res ? (r < p.Bn && b.res_w >= 0) : r < p.Sc;
-    float v0 = 0.f, v1 = 0.f;
-    if (ok) {
-      const float* W = params + (res ? b.res_w : b.skip_w) + (long long)r*p.H;
-      v0 = params[(res ? b.res_b : b.skip_b) + r];
-      for (int k = 0; k < p.H; ++k) v0 = __builtin_fmaf(W[k], params[b.beta + k], v0);
-      const bf16_t* wg = prepped + b.wg + (long long)n*p.Hp;
-      for (int k = 0; k < p.H; ++k) v1 += bf2f(wg[k]);
+  const int n = blockIdx.x*4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= NP) return;
+  const bool res = n < p.Bnp;
+  const int r = res ? n : n - p.Bnp;
+  const bool ok = res ? (r < p.Bn && b.res_w >= 0) : r < p.Sc;
+  float v0 = 0.f, v1 = 0.f;
+  if (ok) {
+    const float* W = params + (res ? b.res_w : b.skip_w) + (long long)r*p.H;
+    const bf16_t* wg = prepped + b.wg + (long long)n*p.Hp;
+    for (int k = lane; k < p.H; k += 64) {
+      v0 = __builtin_fmaf(W[k], params[b.beta + k], v0);
+      v1 += bf2f(wg[k]);
     }
-    out[n] = v0; out[NP + n] = v1;
+  }
+  for (int o = 32; o; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
+  if (lane == 0) {
+    out[n] = ok ? v0 + params[(res ? b.res_b : b.skip_b) + r] : 0.f;
+    out[NP + n] = v1;
   }
 }
 
@@ -945,6 +958,7 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
   Layout l; if (int r = l.init(cfg)) return r;
   hipStream_t st = (hipStream_t)stream;
   std::vector<PrepJob> jobs;
+  const bool fused = l.fused_fwd();
   auto add = [&](long long src, long long dst, int R, int C, int rows, int cols, int ld,
                  int tr) {
     PrepJob j; j.src_off = src; j.dst_off = dst; j.R = R; j.C = C; j.rows = rows;
@@ -961,18 +975,17 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
     const int rs0 = has_res ? l.Bnp : 0, rs = rs0 + l.Scp;
     add(b.conv_w, b.p_c1_f, l.H, l.Bn, l.Hp, l.Bnp, l.Bnp, 0);
     add(b.conv_w, b.p_c1_b, l.H, l.Bn, l.Bnp, l.Hp, l.Hp, 1);
-    if (has_res) {
-      add(b.res_w, b.p_rs_f, l.Bn, l.H, l.Bnp, l.Hp, l.Hp, 0);
-      add(b.res_w, b.p_rs_b, l.Bn, l.H, l.Hp, l.Bnp, rs, 1);
-    }
-    add(b.skip_w, b.p_rs_f + (long long)rs0*l.Hp, l.Sc, l.H, l.Scp, l.Hp, l.Hp, 0);
+    if (has_res) add(b.res_w, b.p_rs_b, l.Bn, l.H, l.Hp, l.Bnp, rs, 1);
     add(b.skip_w, b.p_rs_b + rs0, l.Sc, l.H, l.Hp, l.Scp, rs, 1);
-    if (fwd_fuse_requested()) {
+    if (fused) {
       // gamma_2-folded [res | skip] weights of the fused forward (residual rows zero in the last block)
       add(has_res ? b.res_w : 0, b.p_rs_g, has_res ? l.Bn : 0, l.H, l.Bnp, l.Hp, l.Hp, 0);
       jobs.back().scale_off = b.n2_g;
       add(b.skip_w, b.p_rs_g + (long long)l.Bnp*l.Hp, l.Sc, l.H, l.Scp, l.Hp, l.Hp, 0);
       jobs.back().scale_off = b.n2_g;
+    } else {
+      if (has_res) add(b.res_w, b.p_rs_f, l.Bn, l.H, l.Bnp, l.Hp, l.Hp, 0);
+      add(b.skip_w, b.p_rs_f + (long long)rs0*l.Hp, l.Sc, l.H, l.Scp, l.Hp, l.Hp, 0);
     }
   }
   for (int s = 0; s < l.S; ++s) {
@@ -999,9 +1012,9 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
     const BlockOff& b = l.blk[i];
     const int rs = (i < l.nb - 1 ? l.Bnp : 0) + l.Scp;
     pack(b.p_c1_f, b.p_c1_fp, l.Hp, l.Bnp, 64);
-    pack(b.p_rs_f, b.p_rs_fp, rs, l.Hp, 32);
     pack(b.p_rs_b, b.p_rs_bp, l.Hp, rs, 32);
-    if (fwd_fuse_requested()) pack(b.p_rs_g, b.p_rs_gp, l.Bnp + l.Scp, l.Hp, 32);
+    if (fused) pack(b.p_rs_g, b.p_rs_gp, l.Bnp + l.Scp, l.Hp, 32);
+    else pack(b.p_rs_f, b.p_rs_fp, rs, l.Hp, 32);
   }
   for (size_t i = 0; i < packs.size(); i += 96) {
     PackBatch pb;
@@ -1010,16 +1023,16 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
     hipLaunchKernelGGL(pack_frag_kernel, dim3(16, pb.n), dim3(256), 0, st, (bf16_t*)prepared, pb);
     HIP_OK(hipGetLastError());
   }
-  if (fwd_fuse_requested()) {
+  if (fused) {
     LazyPrepParams lp; memset(&lp, 0, sizeof(lp));
     lp.nb = l.nb; lp.H = l.H; lp.Hp = l.Hp; lp.Bn = l.Bn; lp.Sc = l.Sc; lp.Bnp = l.Bnp; lp.Scp = l.Scp;
-    if (l.nb > kWgMaxProb) return 0;                       // (fused forward is off for such depths)
     for (int i = 0; i < l.nb; ++i) {
       const BlockOff& b = l.blk[i];
       lp.blk[i].res_w = b.res_w; lp.blk[i].res_b = b.res_b; lp.blk[i].skip_w = b.skip_w;
       lp.blk[i].skip_b = b.skip_b; lp.blk[i].beta = b.n2_b; lp.blk[i].wg = b.p_rs_g; lp.blk[i].out = b.p_lazy;
     }
-    hipLaunchKernelGGL(lazy_prep_kernel, dim3(l.nb), dim3(256), 0, st, params, (bf16_t*)prepared, lp);
+    hipLaunchKernelGGL(lazy_prep_kernel, dim3((l.Bnp + l.Scp + 3)/4, l.nb), dim3(256), 0, st, params,
+                       (bf16_t*)prepared, lp);
     HIP_OK(hipGetLastError());
   }
   return 0;
@@ -1077,8 +1090,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   // leaves the second norm to the consumers (gemm_ws.cuh AT == 2 / 3). z2 never comes back from
   // HBM in the forward pass and the fp32 skip accumulation (read + write of 4 B x 128 channels
   // per frame and block) becomes one bf16 write per block and one pass at the end.
-  const bool fused_fwd = fwd_fuse_requested() && l.P == 3 &&
-                         l.H == 512 && l.Bn == 128 && l.Sc == 128 && l.nb <= kWgMaxProb;
+  const bool fused_fwd = l.fused_fwd();
   auto ubuf = [&](int i) { return (bf16_t*)(base + ws.u + ws.u_stride*i); };
   const int NPu = l.Bnp + l.Scp;
   if (fused_fwd) {
@@ -1118,7 +1130,23 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
       g.e.out = ubuf(i); g.e.ldo = NPu; g.e.N = NPu;
       {
         ProfScope prof("dwpw2_fwd", 2.0*BT*l.Hp*(NPu + l.P), 2.0*BT*(2*l.Hp + NPu), st);
-        if (int r = launch_gemm_ws<512, 32, 1, E_STORE, 3, false, 8>(g, B, st)) return r;
+        static const bool old_stage = getenv("BRV_DWPW2_WS") && atoi(getenv("BRV_DWPW2_WS")) == 1;
+        if (old_stage || l.Hp != DP_H || NPu != DP_N) {
+          if (int r = launch_gemm_ws<512, 32, 1, E_STORE, 3, false, 8>(g, B, st)) return r;
+        } else {
+          DwPw2Params dp; memset(&dp, 0, sizeof(dp));
+          dp.z1 = z1buf(i); dp.z2 = z2buf(i); dp.u = ubuf(i);
+          dp.Wp = prep + b.p_rs_gp;
+          dp.slope1 = params + b.prelu1; dp.slope2 = params + b.prelu2;
+          dp.stats1 = stat(1 + 2*i); dp.stats2 = stat(2 + 2*i);
+          dp.gamma1 = params + b.n1_g; dp.beta1 = params + b.n1_b;
+          dp.taps = params + b.dconv_w; dp.dbias = params + b.dconv_b;
+          dp.B = B; dp.T = (int)T; dp.dil = dil; dp.left = ((l.P - 1)*dil)/2; dp.C = l.H;
+          dp.inv_n = 1.0/((double)T*l.H); dp.eps = 1e-8f;
+          const int n_tiles = B*(int)((T + DP_TT - 1)/DP_TT);
+          hipLaunchKernelGGL(dwpw2_fused_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), 0, st, dp);
+          HIP_OK(hipGetLastError());
+        }
       }
     }
     SkipCombineParams sc; memset(&sc, 0, sizeof(sc));

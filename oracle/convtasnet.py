@@ -116,7 +116,8 @@ class OracleConvTasNet(BreverBaseModel):
     """Same constructor signature, parameter names and numerics as the
     reference ``ConvTasNet`` (convtasnet.py:30-64).
 
-    ``emulate_bf16=True`` inserts bf16 rounding at the points where the HIP
+    ``emulate_bf16=True`` (``'fused'``: the rounding points of the fused forward, the
+    default for the default widths) inserts bf16 rounding at the points where the HIP
     path stores bf16 tensors or feeds bf16 MFMA operands (DESIGN.md "numerics")
     so the kernels can be compared at tight tolerance; it is off for everything
     that pins the oracle against the reference.
@@ -181,6 +182,8 @@ class OracleConvTasNet(BreverBaseModel):
         z2 = _rb(F.conv1d(h, blk.d_conv.weight, blk.d_conv.bias,
                           dilation=blk.dilation, groups=h.shape[1]), e)
         self._tap(f'z2.{index}', z2)
+        if e == 'fused' and not blk.causal:
+            return self._block_tail_fused(blk, x, z2)
         h = _rb(blk.norm_2(blk.prelu_2(z2)), e)
         out = None
         if blk.res_conv is not None:
@@ -188,6 +191,28 @@ class OracleConvTasNet(BreverBaseModel):
                                    blk.res_conv.bias), e)
         skip = F.conv1d(h, _rb(blk.skip_conv.weight, e), blk.skip_conv.bias)
         return out, skip
+
+    def _block_tail_fused(self, blk, x, z2):
+        """Rounding points of the fused forward (csrc/dwpw2_fused.cuh + the lazy A staging of
+        gemm_ws.cuh): W gLN(p) = rstd (W gamma) p + (b + W beta - mean rstd (W gamma) 1); the
+        product runs on bf16 p with bf16 gamma-folded weights and is stored as bf16 (u); the
+        consumers apply the per-item scale and offset in fp32."""
+        p = blk.prelu_2(z2)
+        n2 = blk.norm_2
+        mean = p.mean((1, 2), keepdim=True)
+        rstd = (p.var((1, 2), unbiased=False, keepdim=True) + n2.eps).rsqrt()
+        outs = []
+        for conv in (blk.res_conv, blk.skip_conv):
+            if conv is None:
+                outs.append(None)
+                continue
+            wg = _rb(conv.weight*n2.weight.view(1, -1, 1), True)
+            u = _rb(F.conv1d(_rb(p, True), wg), True)
+            v0 = conv.bias + conv.weight[:, :, 0] @ n2.bias
+            v1 = wg.sum((1, 2))
+            outs.append(rstd*u + (v0.view(1, -1, 1) - mean*rstd*v1.view(1, -1, 1)))
+        out = None if outs[0] is None else _rb(x + outs[0], True)
+        return out, outs[1]
 
     def separate(self, w):
         e = self.emulate_bf16

@@ -326,17 +326,19 @@ def test_entry_points_train_and_test(tmp_path):
     assert "val_metrics ['pesq'] need packages that are not installed" in log
 
 
-@pytest.mark.parametrize('causal', [False, True])
-def test_default_width_network_matches_oracle(causal):
+@pytest.mark.parametrize('causal,fuse', [(False, '1'), (False, '0'), (True, '1')])
+def test_default_width_network_matches_oracle(monkeypatch, causal, fuse):
     """Default channel widths (512/128/512/128) with 4 blocks: exercises the persistent
     weight-stationary GEMMs (the small golden configs take the generic tile kernel), for
-    the global and the cumulative layer norm."""
+    the global and the cumulative layer norm. Non-causal: the fused forward (default) and the
+    three-launch sequence (BRV_FWD_FUSE=0), each against the oracle with ITS rounding points."""
     from brever_amd.criterion import snr
     from brever_amd.models import ConvTasNet
     from oracle.convtasnet import OracleConvTasNet
+    monkeypatch.setenv('BRV_FWD_FUSE', fuse)
     cfg = dict(layers=2, repeats=2, causal=causal)
     torch.manual_seed(3)
-    oracle = OracleConvTasNet(**cfg, emulate_bf16=True)
+    oracle = OracleConvTasNet(**cfg, emulate_bf16='fused' if fuse == '1' else True)
     gen = torch.Generator().manual_seed(4)
     with torch.no_grad():
         for name, p in oracle.named_parameters():
@@ -379,10 +381,10 @@ def test_default_width_network_matches_oracle(causal):
 
 
 def test_fused_forward_option_matches_oracle(monkeypatch):
-    """BRV_FWD_FUSE=1 (opt-in; measured slower): depthwise stage inside the [res | skip]
-    product's operand staging, second norm applied lazily by the consumers. Same function, other
-    rounding points: output and gradients vs the fp32 oracle at the bf16 tolerances, next to
-    the default three-launch path."""
+    """The fused forward (default): depthwise stage inside the [res | skip] product's
+    operand staging, second norm applied lazily by the consumers. Same function, other rounding
+    points than the three-launch sequence (BRV_FWD_FUSE=0): output and gradients of both vs the
+    fp32 oracle at the bf16 tolerances."""
     from brever_amd.criterion import snr
     from brever_amd.models import ConvTasNet
     from oracle.convtasnet import OracleConvTasNet
