@@ -1079,17 +1079,13 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   g.e.out = xbuf(0); g.e.ldo = l.Bnp; g.e.bias = params + l.bott_b; g.e.N = l.Bn;
   if (int r = launch_gemm_rows<A_BF16, E_STORE>(g, B, st, "bottleneck_fwd", 2.0*BT*(l.Np + l.Bnp))) return r;
 
-  // Fused forward (opt-in: BRV_FWD_FUSE=1; default widths, non-causal, kernel_size 3): two launches
-  // per block instead of three. MEASURED SLOWER than the three-launch sequence on MI355X (DESIGN.md
-  // section 5c: 79 + 28 us against 29 + 46 + 47 us per block, but + 0.25 ms of per-step table
-  // preparation and the final skip pass; inside one persistent 8-wave workgroup the stencil,
-  // the MFMAs and the loads of a tile run back to back instead of overlapping across many small
-  // workgroups, and the 128 weight registers leave no room for the stencil tables), so the default
-  // stays the three-launch sequence. pw1_fwd finishes the block input lazily (x_i = x_{i-1} + rstd u_{i-1} + c) while staging
-  // it; dwpw2_fwd runs the depthwise stage inside the A staging of the [res | skip] product and
-  // leaves the second norm to the consumers (gemm_ws.cuh AT == 2 / 3). z2 never comes back from
-  // HBM in the forward pass and the fp32 skip accumulation (read + write of 4 B x 128 channels
-  // per frame and block) becomes one bf16 write per block and one pass at the end.
+  // Fused forward (default widths, non-causal, kernel_size 3; BRV_FWD_FUSE=0 selects the three-launch
+  // sequence below): two launches per block instead of three. pw1_fwd
+  // finishes the block input lazily (x_i = x_{i-1} + rstd u_{i-1} + c) while staging it; dwpw2_fwd
+  // (dwpw2_fused.cuh) runs the depthwise stage in front of the [res | skip] product and leaves the
+  // second norm to the consumers. z2 never comes back from HBM in the forward pass and the fp32
+  // skip accumulation (read + write of 4 B x 128 channels per frame and block) becomes one bf16
+  // write per block and one pass at the end.
   const bool fused_fwd = l.fused_fwd();
   auto ubuf = [&](int i) { return (bf16_t*)(base + ws.u + ws.u_stride*i); };
   const int NPu = l.Bnp + l.Scp;
