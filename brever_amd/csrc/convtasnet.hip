@@ -1244,173 +1244,22 @@ int brv_ctn_grad_bucket(const brv_ctn_config* cfg, int32_t part, int32_t nparts,
   return 0;
 }
 
-int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void* prepared,
-                     void* workspace, const float* wave, const float* d_out, float* grads,
-                     int64_t batch, int64_t length, brv_stream_t stream) {
-  return brv_ctn_backward_part(cfg, params, prepared, workspace, wave, d_out, grads, batch, length,
-                               0, 1, stream);
-}
+}  // extern "C"
 
-int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const void* prepared,
-                          void* workspace, const float* wave, const float* d_out, float* grads,
-                          int64_t batch, int64_t length, int32_t part, int32_t nparts,
-                          brv_stream_t stream) {
-  Layout l; if (int r = l.init(cfg)) return r;
-  hipStream_t st = (hipStream_t)stream;
-  const int B = (int)batch; const long long L = length;
-  const long long T = l.frames(L);
-  if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
-  if (nparts < 1 || part < 0 || part >= nparts) return fail(-1, "bad part");
-  if (l.causal) {
-    if (part != nparts - 1) return 0;
-    return backward_causal(l, cfg, params, prepared, workspace, wave, d_out, grads, B, L, T, st);
-  }
-  int blk_lo, blk_hi; part_range(l.nb, part, nparts, blk_lo, blk_hi);
-  const bool head = part == 0, tail = part == nparts - 1;
-  Workspace ws; ws.init(l, B, T);
+// Deferred weight gradients of blocks [blk_lo, blk_hi] (the data-gradient chain of these blocks has
+// run on a stream this one is ordered after): two grouped launches.
+static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, const bf16_t* prep,
+                           const float* params, float* grads, double* stats, int B, long long T,
+                           int blk_lo, int blk_hi, hipStream_t st) {
   const double BT = (double)B*(double)T;
-  char* base = (char*)workspace;
-  const bf16_t* prep = (const bf16_t*)prepared;
-  double* stats = (double*)(base + ws.stats);
-  double* sums = (double*)(base + ws.sums);
   auto stat = [&](int i) { return stats + (long long)i*B*kStatStride; };
-  auto sum = [&](int i) { return sums + (long long)i*B*kStatStride; };
-  bf16_t* w = (bf16_t*)(base + ws.w);
   auto xbuf = [&](int i) { return (bf16_t*)(base + ws.x + ws.x_stride*i); };
-  auto z1buf = [&](int i) { return (bf16_t*)(base + ws.z1 + ws.z_stride*i); };
   auto z2buf = [&](int i) { return (bf16_t*)(base + ws.z2 + ws.z_stride*i); };
-  float* skip = (float*)(base + ws.skip);
-  bf16_t* m = (bf16_t*)(base + ws.m);
-  bf16_t* y = (bf16_t*)(base + ws.y);
-  bf16_t* dpre = (bf16_t*)(base + ws.dpre);
-  bf16_t* dw1 = (bf16_t*)(base + ws.dw1);
-  bf16_t* gskip = (bf16_t*)(base + ws.gskip);
-  bf16_t* gout = (bf16_t*)(base + ws.gout);
-  const int ldg = l.Bnp + l.Scp;           // row stride of [g_out | g_skip]
-  bf16_t* eA = (bf16_t*)(base + ws.eA);
   auto eBbuf = [&](int i) { return (bf16_t*)(base + ws.eB + ws.eB_stride*i); };
   auto gcopy = [&](int i) { return (bf16_t*)(base + ws.gcopy + ws.gcopy_stride*i); };
-  bf16_t* e0 = (bf16_t*)(base + ws.e0);
-  bf16_t* dwt = (bf16_t*)(base + ws.dwt);
-  const int BS = B*l.S;
-  float* vg = (float*)(base + ws.vg);
-  const long long vper = (long long)l.H*(5 + l.P);
-  auto vslot = [&](int i) { return vg + 2LL*l.N + vper*i; };   // block i's vector grads
-  float* vslope = vg + 2LL*l.N + vper*l.nb;    // PReLU slope grads: tcn, then (prelu1, prelu2) per block
-
-  GemmRowsParams g; WgradParams wg;
-  if (head) {
-  HIP_OK(hipMemsetAsync(sums, 0, ws.stats_bytes, st));
-  HIP_OK(hipMemsetAsync(vg, 0, ws.vg_bytes, st));
-  // decoder data gradient (framing of d_out) fused with the mask backward
-  memset(&g, 0, sizeof(g));
-  g.a = frames_of(d_out, L, l.hop, l.K);
-  g.W = prep + l.p_dec_b; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
-  g.e.out = dpre; g.e.ldo = l.Np; g.e.out2 = dw1; g.e.w_in = w; g.e.ld_w = l.Np;
-  g.e.m_in = m; g.e.S = l.S;
-  if (int r = launch_gemm_rows<A_FRAMES, E_MASK_BWD>(g, BS, st, "dec_bwd", 4.0*BS*L + 2.0*BT*l.Np*(1 + 3*l.S))) return r;
-  // decoder weight gradient: y^T * frames(d_out)
-  memset(&wg, 0, sizeof(wg));
-  wg.g = rows_bf16(y, l.Np, T); wg.h = frames_of(d_out, L, l.hop, l.K);
-  wg.B = BS; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
-  wg.out0 = grads + l.dec_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
-  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_dec", 2.0*BT*l.S*l.Np + 4.0*BS*L)) return r;
-  // output conv data gradient, PReLU backward -> gradient wrt skip_sum
-  memset(&g, 0, sizeof(g));
-  g.a = rows_bf16(dpre, l.Np, T); g.a.nsrc = l.S;
-  g.W = prep + l.p_out_b; g.T = (int)T; g.Np = l.Scp; g.Kp = l.S*l.Np;
-  g.e.out = gskip; g.e.ldo = ldg; g.e.src_f32 = skip; g.e.ld_srcf = l.Scp;
-  g.e.src_slope = params + l.tcn_prelu; g.e.dslope = vslope;
-  g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
-  if (int r = launch_gemm_rows<A_BF16, E_PRELU_BWD>(g, B, st, "mask_bwd", 2.0*BT*l.S*l.Np + 6.0*BT*l.Scp)) return r;
-  // output conv weight / bias gradients, one source at a time
-  for (int s = 0; s < l.S; ++s) {
-    memset(&wg, 0, sizeof(wg));
-    wg.g = rows_bf16(dpre + (long long)s*T*l.Np, l.Np, T); wg.g.bs0 = (long long)l.S*T*l.Np;
-    wg.h = rows_bf16(skip, l.Scp, T); wg.h.slope = params + l.tcn_prelu;
-    wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Scp;
-    wg.out0 = grads + l.out_w + (long long)s*l.N*l.Sc; wg.G0p = l.Np; wg.N0 = l.N;
-    wg.Kout = l.Sc; wg.ldo = l.Sc; wg.gbias0 = grads + l.out_b + (long long)s*l.N;
-    if (int r = launch_wgrad<A_F32>(wg, st, "wgrad_out", 2.0*BT*l.Np + 4.0*BT*l.Scp)) return r;
-  }
-  }   // head
-
-  for (int i = blk_hi; i >= blk_lo; --i) {
-    const BlockOff& b = l.blk[i];
-    const bool has_res = i < l.nb - 1;
-    const int dil = 1 << (i % cfg->layers);
-    const int rs0 = has_res ? l.Bnp : 0;
-    // [res | skip] data gradient + gLN_2 backward partials
-    memset(&g, 0, sizeof(g));
-    g.a = rows_bf16(has_res ? gout : gskip, ldg, T);
-    g.W = prep + b.p_rs_b; g.T = (int)T; g.Np = l.Hp; g.Kp = rs0 + l.Scp;
-    g.Wp = prep + b.p_rs_bp; g.wp_nsl = 32;
-    g.e.out = eA; g.e.ldo = l.Hp; g.e.N = l.H;
-    g.e.src = z2buf(i); g.e.ld_src = l.Hp; g.e.src_slope = params + b.prelu2;
-    g.e.src_stats = stat(2 + 2*i); g.e.inv_n = 1.0/((double)T*l.H); g.e.eps = 1e-8f;
-    g.e.gamma = params + b.n2_g;
-    g.e.dgamma = vslot(i) + 2*l.H; g.e.dbeta = vslot(i) + 3*l.H;
-    g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
-    g.e.sums_out = sum(2 + 2*i);
-    if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + 2*l.Hp))) return r;
-    // gLN_2 + prelu_2 backward: fused into the depthwise backward below when its LDS window
-    // (tile + halo rows) fits -- dz2 is then built once per element in LDS and never written
-    // (dwconv_bwd_halo_kernel). BRV_NO_DZ_FUSE keeps the separate pass.
-    const bool fuse_dz2 = !getenv("BRV_NO_DZ_FUSE") && l.Hp % HL_CG == 0 &&
-                          (((l.P - 1)*dil)/2) % dil == 0 && hl_window_rows(dil, l.P) <= HL_MAXROWS;
-    DzParams dz; memset(&dz, 0, sizeof(dz));
-    if (!fuse_dz2) {
-      dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
-      dz.slope = params + b.prelu2; dz.stats = stat(2 + 2*i); dz.sums = sum(2 + 2*i);
-      dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 2 + 2*i; dz.rep_stride = ws.vg_stride;
-      if (int r = launch_dz(dz, st)) return r;
-    }
-    // depthwise conv backward (data, taps, bias) + gLN_1 partials
-    DwParams d; memset(&d, 0, sizeof(d));
-    bf16_t* eB = eBbuf(i);
-    d.z1 = z1buf(i); d.dz2 = eA; d.e1 = eB; d.B = B; d.T = (int)T; d.Cp = l.Hp; d.C = l.H;
-    d.slope1 = params + b.prelu1; d.stats1 = stat(1 + 2*i);
-    d.gamma1 = params + b.n1_g; d.beta1 = params + b.n1_b;
-    d.inv_n = 1.0/((double)T*l.H); d.eps = 1e-8f;
-    d.taps = params + b.dconv_w; d.dil = dil; d.left = ((l.P - 1)*dil)/2;
-    d.dgamma1 = vslot(i); d.dbeta1 = vslot(i) + l.H;
-    d.dtaps = vslot(i) + 4*l.H; d.dbias = vslot(i) + 4*l.H + (long long)l.H*l.P;
-    d.rep_stride = ws.vg_stride; d.sums1 = sum(1 + 2*i);
-    if (fuse_dz2) {
-      d.z2in = z2buf(i); d.stats2 = stat(2 + 2*i); d.sums2 = sum(2 + 2*i);
-      d.slope2 = params + b.prelu2; d.dslope2 = vslope + 2 + 2*i;
-    }
-    if (int r = dispatch_p<DwBwd>(l.P, d, st)) return r;
-    // gLN_1 + prelu_1 backward -> dz1: fused into the A staging of the data-gradient GEMM
-    // below (A_DZ: dz1 is computed from e1 and z1 on load and written back over e1 for the
-    // deferred weight gradient); BRV_NO_DZ1_FUSE keeps the separate pass
-    // (needs one n-tile: the workgroup that stages an A element must be its only reader)
-    const bool fuse_dz1 = !getenv("BRV_NO_DZ1_FUSE") && (l.Bnp == 128 || l.Bnp == 64);
-    if (!fuse_dz1) {
-      memset(&dz, 0, sizeof(dz));
-      dz.e = eB; dz.z = z1buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
-      dz.slope = params + b.prelu1; dz.stats = stat(1 + 2*i); dz.sums = sum(1 + 2*i);
-      dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 1 + 2*i; dz.rep_stride = ws.vg_stride;
-      if (int r = launch_dz(dz, st)) return r;
-    }
-    // first 1x1 conv: data gradient + residual path -> gradient wrt block input
-    memset(&g, 0, sizeof(g));
-    g.a = rows_bf16(eB, l.Hp, T);
-    g.W = prep + b.p_c1_b; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Hp;
-    g.e.out = gout; g.e.ldo = ldg; g.e.add_in = has_res ? gout : nullptr; g.e.ld_add = ldg;
-    // block i-1's deferred [res | skip] weight gradient needs this g_out after gout is
-    // overwritten again: keep a copy (16 MB per block at the BASELINE size)
-    g.e.out2 = i > 0 ? gcopy(i - 1) : nullptr; g.e.ld_srcf = l.Bnp;
-    if (fuse_dz1) {
-      g.a.p1 = z1buf(i); g.a.ld1 = l.Hp; g.a.bs1 = T*l.Hp;
-      g.a.slope = params + b.prelu1; g.a.stats = stat(1 + 2*i); g.a.sums = sum(1 + 2*i);
-      g.a.inv_n = 1.0/((double)T*l.H); g.a.eps = 1e-8f; g.a.C = l.H;
-      g.e.dslope = vslope + 1 + 2*i; g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
-      if (int r = launch_gemm_rows<A_DZ, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(3*l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
-      continue;
-    }
-    if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
-  }
+  bf16_t* gskip = (bf16_t*)(base + ws.gskip);
+  const int ldg = l.Bnp + l.Scp;
+  WgradParams wg;
   // deferred weight gradients of this part's blocks: two grouped launches
   // residual / skip convs of every block in ONE launch when the padded widths are the
   // default 128 | 128 (gemm_wgrad_full.cuh); other architectures use the generic path
@@ -1502,6 +1351,215 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
     gp.nprob = n;
     if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp)))
       return r;
+  }
+  return 0;
+}
+
+extern "C" {
+
+int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void* prepared,
+                     void* workspace, const float* wave, const float* d_out, float* grads,
+                     int64_t batch, int64_t length, brv_stream_t stream) {
+  return brv_ctn_backward_part(cfg, params, prepared, workspace, wave, d_out, grads, batch, length,
+                               0, 1, stream);
+}
+
+int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const void* prepared,
+                          void* workspace, const float* wave, const float* d_out, float* grads,
+                          int64_t batch, int64_t length, int32_t part, int32_t nparts,
+                          brv_stream_t stream) {
+  Layout l; if (int r = l.init(cfg)) return r;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = (int)batch; const long long L = length;
+  const long long T = l.frames(L);
+  if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
+  if (nparts < 1 || part < 0 || part >= nparts) return fail(-1, "bad part");
+  if (l.causal) {
+    if (part != nparts - 1) return 0;
+    return backward_causal(l, cfg, params, prepared, workspace, wave, d_out, grads, B, L, T, st);
+  }
+  int blk_lo, blk_hi; part_range(l.nb, part, nparts, blk_lo, blk_hi);
+  const bool head = part == 0, tail = part == nparts - 1;
+  Workspace ws; ws.init(l, B, T);
+  const double BT = (double)B*(double)T;
+  char* base = (char*)workspace;
+  const bf16_t* prep = (const bf16_t*)prepared;
+  double* stats = (double*)(base + ws.stats);
+  double* sums = (double*)(base + ws.sums);
+  auto stat = [&](int i) { return stats + (long long)i*B*kStatStride; };
+  auto sum = [&](int i) { return sums + (long long)i*B*kStatStride; };
+  bf16_t* w = (bf16_t*)(base + ws.w);
+  auto xbuf = [&](int i) { return (bf16_t*)(base + ws.x + ws.x_stride*i); };
+  auto z1buf = [&](int i) { return (bf16_t*)(base + ws.z1 + ws.z_stride*i); };
+  auto z2buf = [&](int i) { return (bf16_t*)(base + ws.z2 + ws.z_stride*i); };
+  float* skip = (float*)(base + ws.skip);
+  bf16_t* m = (bf16_t*)(base + ws.m);
+  bf16_t* y = (bf16_t*)(base + ws.y);
+  bf16_t* dpre = (bf16_t*)(base + ws.dpre);
+  bf16_t* dw1 = (bf16_t*)(base + ws.dw1);
+  bf16_t* gskip = (bf16_t*)(base + ws.gskip);
+  bf16_t* gout = (bf16_t*)(base + ws.gout);
+  const int ldg = l.Bnp + l.Scp;           // row stride of [g_out | g_skip]
+  bf16_t* eA = (bf16_t*)(base + ws.eA);
+  auto eBbuf = [&](int i) { return (bf16_t*)(base + ws.eB + ws.eB_stride*i); };
+  auto gcopy = [&](int i) { return (bf16_t*)(base + ws.gcopy + ws.gcopy_stride*i); };
+  bf16_t* e0 = (bf16_t*)(base + ws.e0);
+  bf16_t* dwt = (bf16_t*)(base + ws.dwt);
+  const int BS = B*l.S;
+  float* vg = (float*)(base + ws.vg);
+  const long long vper = (long long)l.H*(5 + l.P);
+  auto vslot = [&](int i) { return vg + 2LL*l.N + vper*i; };   // block i's vector grads
+  float* vslope = vg + 2LL*l.N + vper*l.nb;    // PReLU slope grads: tcn, then (prelu1, prelu2) per block
+
+  GemmRowsParams g; WgradParams wg;
+  if (head) {
+  HIP_OK(hipMemsetAsync(sums, 0, ws.stats_bytes, st));
+  HIP_OK(hipMemsetAsync(vg, 0, ws.vg_bytes, st));
+  // decoder data gradient (framing of d_out) fused with the mask backward
+  memset(&g, 0, sizeof(g));
+  g.a = frames_of(d_out, L, l.hop, l.K);
+  g.W = prep + l.p_dec_b; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
+  g.e.out = dpre; g.e.ldo = l.Np; g.e.out2 = dw1; g.e.w_in = w; g.e.ld_w = l.Np;
+  g.e.m_in = m; g.e.S = l.S;
+  if (int r = launch_gemm_rows<A_FRAMES, E_MASK_BWD>(g, BS, st, "dec_bwd", 4.0*BS*L + 2.0*BT*l.Np*(1 + 3*l.S))) return r;
+  // decoder weight gradient: y^T * frames(d_out)
+  memset(&wg, 0, sizeof(wg));
+  wg.g = rows_bf16(y, l.Np, T); wg.h = frames_of(d_out, L, l.hop, l.K);
+  wg.B = BS; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
+  wg.out0 = grads + l.dec_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
+  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_dec", 2.0*BT*l.S*l.Np + 4.0*BS*L)) return r;
+  // output conv data gradient, PReLU backward -> gradient wrt skip_sum
+  memset(&g, 0, sizeof(g));
+  g.a = rows_bf16(dpre, l.Np, T); g.a.nsrc = l.S;
+  g.W = prep + l.p_out_b; g.T = (int)T; g.Np = l.Scp; g.Kp = l.S*l.Np;
+  g.e.out = gskip; g.e.ldo = ldg; g.e.src_f32 = skip; g.e.ld_srcf = l.Scp;
+  g.e.src_slope = params + l.tcn_prelu; g.e.dslope = vslope;
+  g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
+  if (int r = launch_gemm_rows<A_BF16, E_PRELU_BWD>(g, B, st, "mask_bwd", 2.0*BT*l.S*l.Np + 6.0*BT*l.Scp)) return r;
+  // output conv weight / bias gradients, one source at a time
+  for (int s = 0; s < l.S; ++s) {
+    memset(&wg, 0, sizeof(wg));
+    wg.g = rows_bf16(dpre + (long long)s*T*l.Np, l.Np, T); wg.g.bs0 = (long long)l.S*T*l.Np;
+    wg.h = rows_bf16(skip, l.Scp, T); wg.h.slope = params + l.tcn_prelu;
+    wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Scp;
+    wg.out0 = grads + l.out_w + (long long)s*l.N*l.Sc; wg.G0p = l.Np; wg.N0 = l.N;
+    wg.Kout = l.Sc; wg.ldo = l.Sc; wg.gbias0 = grads + l.out_b + (long long)s*l.N;
+    if (int r = launch_wgrad<A_F32>(wg, st, "wgrad_out", 2.0*BT*l.Np + 4.0*BT*l.Scp)) return r;
+  }
+  }   // head
+
+  // Weight gradients overlapped with the data-gradient chain (BRV_WGRAD_OVERLAP=n, n >= 2 chunks):
+  // the blocks of this call are cut into n chunks; a chunk's deferred weight gradients run on a side
+  // stream while the main stream walks the next chunk's chain, so their workgroups could fill the
+  // tails and the gaps between the chain's dependent launches. Joined before this function returns.
+  // MEASURED SLOWER on MI355X (8.02 ms/step off; 8.33 / 8.11 / 8.27 / 8.76 ms with 2 / 3 / 4 / 6
+  // chunks: both kinds of kernel are sized for whole CUs and evict each other's L2 lines), so off
+  // by default.
+  static const int overlap_chunks = [] {
+    const char* e = getenv("BRV_WGRAD_OVERLAP");
+    const int n = e ? atoi(e) : 0;
+    return n < 2 ? 1 : (n > 8 ? 8 : n);
+  }();
+  static hipStream_t side = nullptr;
+  static hipEvent_t ev_chain[8], ev_join;
+  if (overlap_chunks > 1 && !side) {
+    HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    for (auto& e : ev_chain) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+  const int n_blk_call = blk_hi - blk_lo + 1;
+  const int n_chunks = (overlap_chunks > 1 && n_blk_call >= 2*overlap_chunks) ? overlap_chunks : 1;
+  auto wgrads = [&](int blk_lo, int blk_hi, hipStream_t st) -> int {
+    return deferred_wgrads(l, ws, base, prep, params, grads, stats, B, T, blk_lo, blk_hi, st);
+  };
+  for (int ch = n_chunks - 1; ch >= 0; --ch) {
+  const int c_lo = blk_lo + (int)((long long)n_blk_call*ch/n_chunks);
+  const int c_hi = blk_lo + (int)((long long)n_blk_call*(ch + 1)/n_chunks) - 1;
+  for (int i = c_hi; i >= c_lo; --i) {
+    const BlockOff& b = l.blk[i];
+    const bool has_res = i < l.nb - 1;
+    const int dil = 1 << (i % cfg->layers);
+    const int rs0 = has_res ? l.Bnp : 0;
+    // [res | skip] data gradient + gLN_2 backward partials
+    memset(&g, 0, sizeof(g));
+    g.a = rows_bf16(has_res ? gout : gskip, ldg, T);
+    g.W = prep + b.p_rs_b; g.T = (int)T; g.Np = l.Hp; g.Kp = rs0 + l.Scp;
+    g.Wp = prep + b.p_rs_bp; g.wp_nsl = 32;
+    g.e.out = eA; g.e.ldo = l.Hp; g.e.N = l.H;
+    g.e.src = z2buf(i); g.e.ld_src = l.Hp; g.e.src_slope = params + b.prelu2;
+    g.e.src_stats = stat(2 + 2*i); g.e.inv_n = 1.0/((double)T*l.H); g.e.eps = 1e-8f;
+    g.e.gamma = params + b.n2_g;
+    g.e.dgamma = vslot(i) + 2*l.H; g.e.dbeta = vslot(i) + 3*l.H;
+    g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
+    g.e.sums_out = sum(2 + 2*i);
+    if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + 2*l.Hp))) return r;
+    // gLN_2 + prelu_2 backward: fused into the depthwise backward below when its LDS window
+    // (tile + halo rows) fits -- dz2 is then built once per element in LDS and never written
+    // (dwconv_bwd_halo_kernel). BRV_NO_DZ_FUSE keeps the separate pass.
+    const bool fuse_dz2 = !getenv("BRV_NO_DZ_FUSE") && l.Hp % HL_CG == 0 &&
+                          (((l.P - 1)*dil)/2) % dil == 0 && hl_window_rows(dil, l.P) <= HL_MAXROWS;
+    DzParams dz; memset(&dz, 0, sizeof(dz));
+    if (!fuse_dz2) {
+      dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
+      dz.slope = params + b.prelu2; dz.stats = stat(2 + 2*i); dz.sums = sum(2 + 2*i);
+      dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 2 + 2*i; dz.rep_stride = ws.vg_stride;
+      if (int r = launch_dz(dz, st)) return r;
+    }
+    // depthwise conv backward (data, taps, bias) + gLN_1 partials
+    DwParams d; memset(&d, 0, sizeof(d));
+    bf16_t* eB = eBbuf(i);
+    d.z1 = z1buf(i); d.dz2 = eA; d.e1 = eB; d.B = B; d.T = (int)T; d.Cp = l.Hp; d.C = l.H;
+    d.slope1 = params + b.prelu1; d.stats1 = stat(1 + 2*i);
+    d.gamma1 = params + b.n1_g; d.beta1 = params + b.n1_b;
+    d.inv_n = 1.0/((double)T*l.H); d.eps = 1e-8f;
+    d.taps = params + b.dconv_w; d.dil = dil; d.left = ((l.P - 1)*dil)/2;
+    d.dgamma1 = vslot(i); d.dbeta1 = vslot(i) + l.H;
+    d.dtaps = vslot(i) + 4*l.H; d.dbias = vslot(i) + 4*l.H + (long long)l.H*l.P;
+    d.rep_stride = ws.vg_stride; d.sums1 = sum(1 + 2*i);
+    if (fuse_dz2) {
+      d.z2in = z2buf(i); d.stats2 = stat(2 + 2*i); d.sums2 = sum(2 + 2*i);
+      d.slope2 = params + b.prelu2; d.dslope2 = vslope + 2 + 2*i;
+    }
+    if (int r = dispatch_p<DwBwd>(l.P, d, st)) return r;
+    // gLN_1 + prelu_1 backward -> dz1: fused into the A staging of the data-gradient GEMM
+    // below (A_DZ: dz1 is computed from e1 and z1 on load and written back over e1 for the
+    // deferred weight gradient); BRV_NO_DZ1_FUSE keeps the separate pass
+    // (needs one n-tile: the workgroup that stages an A element must be its only reader)
+    const bool fuse_dz1 = !getenv("BRV_NO_DZ1_FUSE") && (l.Bnp == 128 || l.Bnp == 64);
+    if (!fuse_dz1) {
+      memset(&dz, 0, sizeof(dz));
+      dz.e = eB; dz.z = z1buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
+      dz.slope = params + b.prelu1; dz.stats = stat(1 + 2*i); dz.sums = sum(1 + 2*i);
+      dz.inv_n = 1.0/((double)T*l.H); dz.eps = 1e-8f; dz.dslope = vslope + 1 + 2*i; dz.rep_stride = ws.vg_stride;
+      if (int r = launch_dz(dz, st)) return r;
+    }
+    // first 1x1 conv: data gradient + residual path -> gradient wrt block input
+    memset(&g, 0, sizeof(g));
+    g.a = rows_bf16(eB, l.Hp, T);
+    g.W = prep + b.p_c1_b; g.T = (int)T; g.Np = l.Bnp; g.Kp = l.Hp;
+    g.e.out = gout; g.e.ldo = ldg; g.e.add_in = has_res ? gout : nullptr; g.e.ld_add = ldg;
+    // block i-1's deferred [res | skip] weight gradient needs this g_out after gout is
+    // overwritten again: keep a copy (16 MB per block at the BASELINE size)
+    g.e.out2 = i > 0 ? gcopy(i - 1) : nullptr; g.e.ld_srcf = l.Bnp;
+    if (fuse_dz1) {
+      g.a.p1 = z1buf(i); g.a.ld1 = l.Hp; g.a.bs1 = T*l.Hp;
+      g.a.slope = params + b.prelu1; g.a.stats = stat(1 + 2*i); g.a.sums = sum(1 + 2*i);
+      g.a.inv_n = 1.0/((double)T*l.H); g.a.eps = 1e-8f; g.a.C = l.H;
+      g.e.dslope = vslope + 1 + 2*i; g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
+      if (int r = launch_gemm_rows<A_DZ, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(3*l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
+      continue;
+    }
+    if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
+  }
+    if (n_chunks > 1) {
+      HIP_OK(hipEventRecord(ev_chain[ch], st));
+      HIP_OK(hipStreamWaitEvent(side, ev_chain[ch], 0));
+      if (int r = wgrads(c_lo, c_hi, side)) return r;
+    } else if (int r = wgrads(c_lo, c_hi, st)) return r;
+  }   // chunks
+  if (n_chunks > 1) {
+    HIP_OK(hipEventRecord(ev_join, side));
+    HIP_OK(hipStreamWaitEvent(st, ev_join, 0));
   }
   if (tail) {
   // bottleneck conv: data gradient + first gLN backward partials
