@@ -380,6 +380,42 @@ def test_default_width_network_matches_oracle(monkeypatch, causal, fuse):
 
 
 
+@pytest.mark.parametrize('layers,L,B', [(8, 1500, 2), (8, 6000, 1), (5, 250, 3), (3, 40, 2)])
+def test_fused_forward_large_dilations_and_short_items(layers, L, B):
+    """The fused forward stage kernel (dwpw2_fused.cuh) at dilations up to 128 on items shorter
+    than a tile / shorter than the dilation (every tap of some frames outside the item), ragged
+    lengths, one item: output and workspace tensors vs the oracle with the fused rounding points."""
+    from brever_amd.models import ConvTasNet
+    from oracle.convtasnet import OracleConvTasNet
+    cfg = dict(layers=layers, repeats=1)
+    torch.manual_seed(11)
+    oracle = OracleConvTasNet(**cfg, emulate_bf16='fused')
+    gen = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for name, p in oracle.named_parameters():
+            if 'norm' in name or 'prelu' in name:
+                p.add_(0.1*torch.randn(p.shape, generator=gen))
+    net = ConvTasNet(**cfg)
+    net.load_state_dict(oracle.state_dict())
+    net = net.to(_cuda())
+    net._amp = True
+    x = 0.3*torch.randn(B, L, generator=gen)
+    oracle.trace = {}
+    with torch.no_grad():
+        want = oracle(x)
+        out = net(x.cuda())
+    assert torch.isfinite(out).all()
+    assert rel(out, want) <= 1e-2, rel(out, want)
+    T = net.frames(L)
+    for i in range(layers):
+        # two bf16 pipelines with different fp32 summation orders: rounding flips (2^-8 of an
+        # element each) accumulate with depth; a wrong tap or frame would be >= 1e-1
+        z2 = net.workspace_tensor('z2', i, B, L, (B, T, 512), torch.bfloat16).float()
+        assert rel(z2, oracle.trace[f'z2.{i}'].transpose(1, 2)) <= 1e-2, i
+        xi = net.workspace_tensor('x', i, B, L, (B, T, 128), torch.bfloat16).float()
+        assert rel(xi, oracle.trace[f'x.{i}'].transpose(1, 2)) <= 1e-2, i
+
+
 def test_fused_forward_option_matches_oracle(monkeypatch):
     """The fused forward (default): depthwise stage inside the [res | skip] product's
     operand staging, second norm applied lazily by the consumers. Same function, other rounding
