@@ -39,14 +39,14 @@ struct DwPw2Params {
 constexpr int DP_TT = 128, DP_H = 512, DP_N = 256, DP_SLAB = 64, DP_NSLAB = DP_H/DP_SLAB;
 constexpr int DP_LDP = DP_SLAB + 8;                // halves per LDS row (144 B: conflict-free b128 reads)
 constexpr int DP_LDU = DP_N + 8;                   // halves per staged u row (528 B)
-constexpr int DP_OFF_P = 11*DP_H*4;                // after the per-item tables
+constexpr int DP_OFF_P = 8*DP_H*4;                // after the per-item tables
 constexpr int DP_PBYTES = DP_TT*DP_LDP*2;          // one slab buffer
 constexpr int DP_SMEM = DP_OFF_P + 2*DP_PBYTES;
 
 __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[DP_SMEM];
   static_assert(2*DP_PBYTES >= 64*DP_LDU*2, "u staging fits the slab buffers");
-  float* tabs = reinterpret_cast<float*>(smem);                 // [11][512]: wa0-2, wb0-2, wc0-2, bias, bias + wc0-2
+  float* tabs = reinterpret_cast<float*>(smem);                 // [8][512]: wa0-2, wc0-2, bias, bias + wc0-2
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wn = wid;                                           // 32 outputs x all 128 frames per wave
   const int n32 = lane & 31, khalf = lane >> 5;
@@ -55,7 +55,13 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
   const int tpi = (T + DP_TT - 1)/DP_TT;
   const int n_tiles = tpi*p.B;
   const float a1 = *p.slope1, a2 = *p.slope2;
-  const float c1 = 0.5f*(1.f + a1), c2 = 0.5f*(1.f - a1);
+  // PReLU_1 -> gLN_1 -> tap k of a channel: w_k (scale (c1 z + c2 |z|) + shift) with ONE slope for all
+  // channels, so the tables hold w_k scale c1 and the element is z + rho |z|, rho = c2 / c1 (half the
+  // table reads of separate z and |z| coefficients; c1 == 0, a slope of exactly -1, is nudged to
+  // 2^-40: relative error 1e-12)
+  const float c1r = 0.5f*(1.f + a1), c2 = 0.5f*(1.f - a1);
+  const float c1 = __builtin_fabsf(c1r) < 0x1p-40f ? 0x1p-40f : c1r;
+  const float rho = c2/c1;
   const float d1 = 0.5f*(1.f + a2), d2 = 0.5f*(1.f - a2);
   const unsigned int rowb = DP_H*2;
 
@@ -90,10 +96,10 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const float w = ok ? p.taps[c*3 + k] : 0.f;
-          tabs[k*DP_H + c] = w*c1*scv; tabs[(3 + k)*DP_H + c] = w*c2*scv; tabs[(6 + k)*DP_H + c] = w*shv;
+          tabs[k*DP_H + c] = w*c1*scv; tabs[(3 + k)*DP_H + c] = w*shv;
         }
-        tabs[9*DP_H + c] = ok ? p.dbias[c] : 0.f;
-        tabs[10*DP_H + c] = tabs[9*DP_H + c] + tabs[6*DP_H + c] + tabs[7*DP_H + c] + tabs[8*DP_H + c];
+        tabs[6*DP_H + c] = ok ? p.dbias[c] : 0.f;
+        tabs[7*DP_H + c] = tabs[6*DP_H + c] + tabs[3*DP_H + c] + tabs[4*DP_H + c] + tabs[5*DP_H + c];
       }
       cur_item = b;
       __syncthreads();
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
         // constant terms: bias + the taps inside the item -- all three for every frame of an
         // interior tile (workgroup-uniform), else per tap and frame
         float bs[8];
-        ld8(interior ? 10 : 9, bs);
+        ld8(interior ? 7 : 6, bs);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -136,11 +142,11 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
       }
 #pragma unroll
       for (int k = 0; k < ((DP_ABL & 8) ? 1 : 3); ++k) {
-        float wa[8], wb[8];
-        ld8(k, wa); ld8(3 + k, wb);
+        float wa[8];
+        ld8(k, wa);
         if (!interior) {
           float wc[8];
-          ld8(6 + k, wc);
+          ld8(3 + k, wc);
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             const int ti = t0 + rl + 64*r + k*p.dil - p.left;
@@ -155,8 +161,7 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
           unpack8(raw[r][k], f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            acc[r][j] = __builtin_fmaf(wa[j], f[j], acc[r][j]);
-            acc[r][j] = __builtin_fmaf(wb[j], __builtin_fabsf(f[j]), acc[r][j]);
+            acc[r][j] = __builtin_fmaf(wa[j], __builtin_fmaf(rho, __builtin_fabsf(f[j]), f[j]), acc[r][j]);
           }
         }
       }
