@@ -495,17 +495,19 @@ struct SkipCombineParams {
 };
 __global__ __launch_bounds__(256) void skip_combine_kernel(const SkipCombineParams p) {
   __shared__ float rs[kWgMaxProb];
-  __shared__ float cs[kWgMaxProb][128];
+  __shared__ float cs[128];                 // sum over the blocks of the per-item constants
   const int b = blockIdx.y, tid = threadIdx.x;
   const int NP = p.Bnp + p.Scp;
   for (int i = tid; i < p.nb; i += 256)
     rs[i] = norm_stat(p.stats + (2 + 2*i)*p.stats_stride, b, p.inv_n, p.eps).rstd;
-  __syncthreads();
-  for (int e = tid; e < p.nb*p.Scp; e += 256) {
-    const int i = e / p.Scp, n = e % p.Scp;
-    const NormStat ns = norm_stat(p.stats + (2 + 2*i)*p.stats_stride, b, p.inv_n, p.eps);
-    const float* lz = reinterpret_cast<const float*>(p.prepared + p.lazy_off[i]);
-    cs[i][n] = lz[p.Bnp + n] - ns.mean*ns.rstd*lz[NP + p.Bnp + n];
+  for (int n = tid; n < p.Scp; n += 256) {
+    float c = 0.f;
+    for (int i = 0; i < p.nb; ++i) {
+      const NormStat ns = norm_stat(p.stats + (2 + 2*i)*p.stats_stride, b, p.inv_n, p.eps);
+      const float* lz = reinterpret_cast<const float*>(p.prepared + p.lazy_off[i]);
+      c += lz[p.Bnp + n] - ns.mean*ns.rstd*lz[NP + p.Bnp + n];
+    }
+    cs[n] = c;
   }
   __syncthreads();
   const int cpr = p.Scp/8;
@@ -514,14 +516,28 @@ __global__ __launch_bounds__(256) void skip_combine_kernel(const SkipCombinePara
     const int c0 = (int)(e % cpr)*8; const long long t = e / cpr;
     float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < p.nb; ++i) {
+    for (int j = 0; j < 8; ++j) acc[j] = cs[c0 + j];
+    const bf16_t* src = p.u + ((long long)b*p.T + t)*NP + p.Bnp + c0;
+    int i = 0;
+    for (; i + 8 <= p.nb; i += 8) {         // eight 16-byte loads in flight per thread
+      uint4 q[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q[k] = *reinterpret_cast<const uint4*>(src + (i + k)*p.u_stride);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float f[8];
+        unpack8(q[k], f);
+        const float r = rs[i + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(r, f[j], acc[j]);
+      }
+    }
+    for (; i < p.nb; ++i) {
       float f[8];
-      unpack8(*reinterpret_cast<const uint4*>(p.u + i*p.u_stride + ((long long)b*p.T + t)*NP + p.Bnp + c0), f);
+      unpack8(*reinterpret_cast<const uint4*>(src + i*p.u_stride), f);
       const float r = rs[i];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += __builtin_fmaf(r, f[j], cs[i][c0 + j]);
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(r, f[j], acc[j]);
     }
     float* dst = p.skip + ((long long)b*p.T + t)*p.Scp + c0;
     *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
