@@ -335,6 +335,30 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
   const EpiSpec& e = p.e;
   const bool col_ok = ncol < p.Np;
 
+  if (EM == E_OLA && p.n_ntiles == 1 && e.hop > 0) {
+    // Overlap-add inside the tile: output sample s (relative to the tile's first frame) is the sum
+    // of the frames that cover it, read straight from the staged accumulators. Samples whose frames
+    // all lie in this tile are stored (the waveform is zeroed before the launch); the Kf - hop
+    // samples shared with a neighbouring tile are added atomically. (One atomic per product element
+    // made this launch 80 us: ~64 adds serialised on every 128-byte line of the waveform.)
+    const int rows = T - t0 < GR_BM ? T - t0 : GR_BM;
+    const int hop = e.hop, Kf = e.Kf;
+    const int nsamp = (rows - 1)*hop + Kf;
+    float* wo = e.wave_out + (long long)b*e.wave_stride;
+    const bool first = t0 == 0, last = t0 + rows >= T;
+    for (int s = tid; s < nsamp; s += 256) {
+      int r_hi = s / hop; if (r_hi > rows - 1) r_hi = rows - 1;
+      int r_lo = s - Kf + 1 <= 0 ? 0 : (s - Kf + hop)/hop;
+      float acc_s = 0.f;
+      for (int r = r_lo; r <= r_hi; ++r) acc_s += Cs[r*LDC + (s - r*hop)];
+      const long long idx = (long long)t0*hop + s;
+      if (idx >= e.wave_len) continue;
+      const bool owned = (first || s >= Kf - hop) && (last || s < rows*hop);
+      if (owned) wo[idx] = acc_s; else atomic_add_f32(wo + idx, acc_s);
+    }
+    return;
+  }
+
   double st_sum = 0.0, st_sq = 0.0;         // E_STORE stats / E_GLN_BWD sums
   float colA[8], colB[8];                   // per-column partials (E_GLN_BWD)
 #pragma unroll
