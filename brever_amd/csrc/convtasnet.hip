@@ -322,13 +322,25 @@ int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st,
   return launch_gemm_rows_t<64, AK, EM>(p, batch, st);
 }
 
+// Workgroups a weight-gradient launch aims for (tiles x frame splits x problems). More splits fill
+// the CUs but every split adds its partial tile to the output with float atomics, so the best count
+// depends on the output size: measured per label on MI355X (BRV_WG_TARGET[_<label>] override).
+inline int wgrad_target(const char* label, int dflt) {
+  if (label) {
+    char name[64];
+    snprintf(name, sizeof(name), "BRV_WG_TARGET_%s", label);
+    if (const char* e = getenv(name)) return atoi(e);
+  }
+  if (const char* e = getenv("BRV_WG_TARGET")) return atoi(e);
+  return dflt;
+}
+
 template <int BH, int HK>
-int launch_wgrad_t(WgradGroupParams& gp, hipStream_t st) {
+int launch_wgrad_t(WgradGroupParams& gp, hipStream_t st, int target) {
   WgradParams& p = gp.base;
   const int nprob = gp.nprob > 0 ? gp.nprob : 1;
   const int tiles = ceil_div(p.Gp, WG_BG)*(p.Hp/BH);
   const int total = p.B*ceil_div(p.T, WG_BT);
-  static const int target = getenv("BRV_WG_TARGET") ? atoi(getenv("BRV_WG_TARGET")) : 384;
   int ns = ceil_div(target, tiles*nprob);
   if (ns > total) ns = total;
   if (ns < 1) ns = 1;
@@ -342,21 +354,22 @@ int launch_wgrad_t(WgradGroupParams& gp, hipStream_t st) {
 // (nprob == 0: a single problem described entirely by `gp.base`).
 template <int HK>
 int launch_wgrad_group(WgradGroupParams& gp, hipStream_t st, const char* label,
-                       double bytes) {
+                       double bytes, int target_dflt = 384) {
   const WgradParams& p = gp.base;
   if (p.T <= 0 || p.B <= 0) return 0;
   const int nprob = gp.nprob > 0 ? gp.nprob : 1;
   ProfScope prof(label, 2.0*nprob*p.B*p.T*(double)p.Gp*p.Hp, bytes*nprob, st);
   if (p.Hp % 64 != 0) return fail(-1, "wgrad: unpadded dims");
-  if (p.Hp % 128 == 0) return launch_wgrad_t<128, HK>(gp, st);
-  return launch_wgrad_t<64, HK>(gp, st);
+  const int target = wgrad_target(label, target_dflt);
+  if (p.Hp % 128 == 0) return launch_wgrad_t<128, HK>(gp, st, target);
+  return launch_wgrad_t<64, HK>(gp, st, target);
 }
 template <int HK>
 int launch_wgrad(WgradParams& p, hipStream_t st, const char* label = "wgrad",
-                 double bytes = 0) {
+                 double bytes = 0, int target_dflt = 384) {
   WgradGroupParams gp;
   gp.base = p; gp.nprob = 0;
-  return launch_wgrad_group<HK>(gp, st, label, bytes);
+  return launch_wgrad_group<HK>(gp, st, label, bytes, target_dflt);
 }
 
 template <template <int> class F, typename... Args>
@@ -1365,7 +1378,7 @@ static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, con
       pr.out0 = grads + b.conv_w; pr.gbias0 = grads + b.conv_b;
     }
     gp.nprob = n;
-    if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp)))
+    if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp), 1536))
       return r;
   }
   return 0;
@@ -1443,7 +1456,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   wg.g = rows_bf16(y, l.Np, T); wg.h = frames_of(d_out, L, l.hop, l.K);
   wg.B = BS; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
   wg.out0 = grads + l.dec_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
-  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_dec", 2.0*BT*l.S*l.Np + 4.0*BS*L)) return r;
+  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_dec", 2.0*BT*l.S*l.Np + 4.0*BS*L, 768)) return r;
   // output conv data gradient, PReLU backward -> gradient wrt skip_sum
   memset(&g, 0, sizeof(g));
   g.a = rows_bf16(dpre, l.Np, T); g.a.nsrc = l.S;
@@ -1460,7 +1473,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
     wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Scp;
     wg.out0 = grads + l.out_w + (long long)s*l.N*l.Sc; wg.G0p = l.Np; wg.N0 = l.N;
     wg.Kout = l.Sc; wg.ldo = l.Sc; wg.gbias0 = grads + l.out_b + (long long)s*l.N;
-    if (int r = launch_wgrad<A_F32>(wg, st, "wgrad_out", 2.0*BT*l.Np + 4.0*BT*l.Scp)) return r;
+    if (int r = launch_wgrad<A_F32>(wg, st, "wgrad_out", 2.0*BT*l.Np + 4.0*BT*l.Scp, 256)) return r;
   }
   }   // head
 
@@ -1596,7 +1609,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   wg.B = B; wg.T = (int)T; wg.Gp = l.Bnp; wg.Hp = l.Np;
   wg.out0 = grads + l.bott_w; wg.G0p = l.Bnp; wg.N0 = l.Bn; wg.Kout = l.N; wg.ldo = l.N;
   wg.gbias0 = grads + l.bott_b;
-  if (int r = launch_wgrad<A_BF16>(wg, st, "bottleneck_wgrad", 2.0*BT*(l.Bnp + l.Np))) return r;
+  if (int r = launch_wgrad<A_BF16>(wg, st, "bottleneck_wgrad", 2.0*BT*(l.Bnp + l.Np), 256)) return r;
   // total gradient wrt the encoder output
   CombineParams cb; memset(&cb, 0, sizeof(cb));
   cb.e0 = e0; cb.w = w; cb.dw1 = dw1; cb.dw = dwt; cb.B = B; cb.T = (int)T;
@@ -1616,7 +1629,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   wg.g = rows_bf16(dwt, l.Np, T); wg.h = frames_of(wave, L, l.hop, l.K);
   wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
   wg.out0 = grads + l.enc_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
-  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_enc", 2.0*BT*l.Np + 4.0*B*L)) return r;
+  if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_enc", 2.0*BT*l.Np + 4.0*B*L, 768)) return r;
   }   // tail
   // per-channel / slope gradients of this part: fold the replicas into the flat gradient
   return reduce_vector_grads(l, ws, vg, grads, st, blk_lo, blk_hi, tail, head);
