@@ -341,7 +341,15 @@ int launch_wgrad_t(WgradGroupParams& gp, hipStream_t st, int target) {
   const int nprob = gp.nprob > 0 ? gp.nprob : 1;
   const int tiles = ceil_div(p.Gp, WG_BG)*(p.Hp/BH);
   const int total = p.B*ceil_div(p.T, WG_BT);
-  int ns = ceil_div(target, tiles*nprob);
+  int ns = ceil_div(target > 0 ? target : 384, tiles*nprob);
+  if (target < 0) {
+    // item-aligned splits (one item per split measured best for the grouped first-conv gradient at
+    // B = 16, both for 24 blocks in one launch and for 8 per gradient bucket), within 384 .. 2048
+    // workgroups
+    int nb = p.B;
+    while (tiles*nprob*nb > 2048 && nb % 2 == 0) nb /= 2;
+    if (nb > ns) ns = nb;
+  }
   if (ns > total) ns = total;
   if (ns < 1) ns = 1;
   p.nsplit = ns;
@@ -1378,7 +1386,7 @@ static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, con
       pr.out0 = grads + b.conv_w; pr.gbias0 = grads + b.conv_b;
     }
     gp.nprob = n;
-    if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp), 1536))
+    if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp), -1))
       return r;
   }
   return 0;
