@@ -206,6 +206,104 @@ __global__ __launch_bounds__(256) void nhwc_fir_kernel(const _Float16* x, const 
   }
 }
 
+// Both resamplings a UNetBlock needs of one tensor in ONE pass (models/sgmse.py UNetBlock.forward_h):
+//   y_raw = FIR(x)   and   y_act = FIR(act(scale*x + shift))
+// (the GroupNorm fold + SiLU in front of the second one used to be a pass of its own: x read three
+// times and the activated copy written and read back). A workgroup stages the input window of an
+// output tile x 32 channels in LDS, raw and activated (fp16 both: the activated copy has the rounding
+// it had in HBM), then every output is a handful of LDS reads. K <= 4.
+struct FirDualParams {
+  const _Float16* x; const float* scale; const float* shift; const float* k;
+  _Float16* y_raw; _Float16* y_act;
+  int C, Cs, H, W, Ho, Wo, K, ph, pw, act, tiles_w;
+  float gain;
+};
+template <bool UP>
+__global__ __launch_bounds__(256) void nhwc_fir_dual_kernel(const FirDualParams p) {
+  constexpr int TH = UP ? 16 : 8, TW = UP ? 32 : 16;
+  constexpr int MAXPX = UP ? 10*18 : 18*34;          // window of a tile for K <= 4
+  __shared__ h8 raw[MAXPX*4];
+  __shared__ h8 act[MAXPX*4];
+  __shared__ float ks[16];
+  const int tid = threadIdx.x;
+  const int ho0 = (blockIdx.x / p.tiles_w)*TH, wo0 = (blockIdx.x % p.tiles_w)*TW;
+  const int o = tid & 3, oc = blockIdx.y*4 + o;        // channel octet of this thread (fixed: 256 % 4 == 0)
+  const long long b = blockIdx.z;
+  const int K = p.K;
+  if (tid < K*K) ks[tid] = p.k[tid];
+  int hi_lo, hi_hi, wi_lo, wi_hi;
+  if (UP) {
+    const int a = ho0 + p.ph - (K - 1), c = wo0 + p.pw - (K - 1);
+    hi_lo = a <= 0 ? 0 : (a + 1) >> 1; hi_hi = (ho0 + TH - 1 + p.ph) >> 1;
+    wi_lo = c <= 0 ? 0 : (c + 1) >> 1; wi_hi = (wo0 + TW - 1 + p.pw) >> 1;
+  } else {
+    hi_lo = ho0*2 - p.ph; hi_hi = (ho0 + TH - 1)*2 - p.ph + K - 1;
+    wi_lo = wo0*2 - p.pw; wi_hi = (wo0 + TW - 1)*2 - p.pw + K - 1;
+  }
+  const int nrows = hi_hi - hi_lo + 1, ncols = wi_hi - wi_lo + 1;
+  f32x8 sc, sh;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = oc*8 + j;
+    const bool ok = c < p.C;
+    sc[j] = ok ? p.scale[b*p.C + c] : 0.f; sh[j] = ok ? p.shift[b*p.C + c] : 0.f;
+  }
+  const bool oc_ok = oc*8 < p.Cs;
+  for (int idx = tid; idx < nrows*ncols*4; idx += 256) {
+    const int px = idx >> 2;
+    const int hi = hi_lo + px / ncols, wi = wi_lo + px % ncols;
+    h8 v, t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = (_Float16)0.f; t[j] = (_Float16)0.f; }
+    if (oc_ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
+      v = *reinterpret_cast<const h8*>(p.x + ((b*p.H + hi)*p.W + wi)*p.Cs + oc*8);
+      const f32x8 vf = __builtin_convertvector(v, f32x8);
+      f32x8 r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float u = 0.f;
+        if (oc*8 + j < p.C) { u = sc[j]*vf[j] + sh[j]; if (p.act) u = nh_silu(u); }
+        r[j] = u;
+      }
+      t = __builtin_convertvector(r, h8);
+    }
+    raw[idx] = v; act[idx] = t;
+  }
+  __syncthreads();
+  if (!oc_ok) return;
+  for (int item = tid; item < TH*TW*4; item += 256) {
+    const int opx = item >> 2;
+    const int ho = ho0 + opx / TW, wo = wo0 + opx % TW;
+    if (ho >= p.Ho || wo >= p.Wo) continue;
+    f32x8 ar, aa;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ar[j] = 0.f; aa[j] = 0.f; }
+    for (int a = 0; a < K; ++a) {
+      int hi;
+      if (UP) { const int hn = ho + p.ph - a; if (hn < 0 || (hn & 1)) continue; hi = hn >> 1; }
+      else hi = ho*2 - p.ph + a;
+      if (hi < 0 || hi >= p.H) continue;
+      for (int c = 0; c < K; ++c) {
+        int wi;
+        if (UP) { const int wn = wo + p.pw - c; if (wn < 0 || (wn & 1)) continue; wi = wn >> 1; }
+        else wi = wo*2 - p.pw + c;
+        if (wi < 0 || wi >= p.W) continue;
+        const int li = ((hi - hi_lo)*ncols + (wi - wi_lo))*4 + o;
+        const f32x8 v = __builtin_convertvector(raw[li], f32x8);
+        const f32x8 t = __builtin_convertvector(act[li], f32x8);
+        const float kv = ks[a*K + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ar[j] = fmaf(v[j], kv, ar[j]); aa[j] = fmaf(t[j], kv, aa[j]); }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ar[j] *= p.gain; aa[j] *= p.gain; }
+    const long long off = ((b*p.Ho + ho)*p.Wo + wo)*(long long)p.Cs + oc*8;
+    *reinterpret_cast<h8*>(p.y_raw + off) = __builtin_convertvector(ar, h8);
+    *reinterpret_cast<h8*>(p.y_act + off) = __builtin_convertvector(aa, h8);
+  }
+}
+
 // out = alpha*a + beta*b on fp16 tensors (b nullable), fp32 arithmetic
 __global__ __launch_bounds__(256) void nhwc_axpby_kernel(const _Float16* a, float alpha,
                                                          const _Float16* b, float beta, _Float16* out,
@@ -556,6 +654,27 @@ int brv_nhwc_fir_resample2d(const void* x, const float* kernel, void* y, int64_t
     hipLaunchKernelGGL(nhwc_fir_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
                        (const _Float16*)x, kernel, (_Float16*)y, (int)Cs, (int)H, (int)W, (int)Ho,
                        (int)Wo, (int)K, (int)pad_h, (int)pad_w, gain);
+  NH_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_nhwc_fir_resample2d_dual(const void* x, const float* scale_bc, const float* shift_bc, int act,
+                                 const float* kernel, void* y_raw, void* y_act, int64_t B, int64_t C,
+                                 int64_t Cs, int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t K,
+                                 int64_t pad_h, int64_t pad_w, int up, float gain, brv_stream_t stream) {
+  if (B < 1 || (Cs & 7) || Cs < 8 || C < 1 || C > Cs || H < 1 || W < 1 || Ho < 1 || Wo < 1 || K < 1 ||
+      K > 4 || B > 65535 || !scale_bc || !shift_bc)
+    return -1;
+  FirDualParams p;
+  p.x = (const _Float16*)x; p.scale = scale_bc; p.shift = shift_bc; p.k = kernel;
+  p.y_raw = (_Float16*)y_raw; p.y_act = (_Float16*)y_act;
+  p.C = (int)C; p.Cs = (int)Cs; p.H = (int)H; p.W = (int)W; p.Ho = (int)Ho; p.Wo = (int)Wo; p.K = (int)K;
+  p.ph = (int)pad_h; p.pw = (int)pad_w; p.act = act; p.gain = gain;
+  const int TH = up ? 16 : 8, TW = up ? 32 : 16;
+  p.tiles_w = (int)((Wo + TW - 1)/TW);
+  const dim3 grid((unsigned)(p.tiles_w*((Ho + TH - 1)/TH)), (unsigned)((Cs/8 + 3)/4), (unsigned)B);
+  if (up) hipLaunchKernelGGL(nhwc_fir_dual_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(nhwc_fir_dual_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
   NH_OK(hipGetLastError());
   return 0;
 }

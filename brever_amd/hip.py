@@ -219,6 +219,8 @@ SIGNATURES = {
     'brv_groupnorm_fold_chan': (ctypes.c_int, [_c_ptr]*8 + [_c_i64]*4 + [_c_f32, _c_ptr]),
     'brv_nhwc_affine_act': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*4 + [ctypes.c_int, _c_ptr]),
     'brv_nhwc_fir_resample2d': (ctypes.c_int, [_c_ptr]*3 + [_c_i64]*9 + [ctypes.c_int, _c_f32, _c_ptr]),
+    'brv_nhwc_fir_resample2d_dual': (ctypes.c_int, [_c_ptr]*3 + [ctypes.c_int] + [_c_ptr]*3 + [_c_i64]*10
+                                     + [ctypes.c_int, _c_f32, _c_ptr]),
     'brv_nhwc_axpby': (ctypes.c_int, [_c_ptr, _c_f32, _c_ptr, _c_f32, _c_ptr, _c_i64, _c_ptr]),
     'brv_nhwc_conv1x1_packed_size': (_c_i64, [_c_i64, _c_i64, _c_i64]),
     'brv_nhwc_conv1x1_pack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),

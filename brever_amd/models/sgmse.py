@@ -380,6 +380,26 @@ def _h_resample(a, resampler, up_or_down):
     return y
 
 
+def _h_resample_pair(a, fold, resampler, up_or_down, silu=True):
+    """(resample(a), resample(act(scale*a + shift))) in one launch (the two inputs of a resampling
+    UNetBlock); FIR kernels longer than 4 taps take the separate kernels."""
+    a = _h_single(a)
+    B, H, W, Cs = a.t.shape
+    K = resampler.kernel.shape[-1]
+    if K > 4:
+        return (_h_resample(a, resampler, up_or_down),
+                _h_resample(_h_affine_act(a, fold, silu=silu), resampler, up_or_down))
+    padding, (Ho, Wo), up = resampler.plan((H, W), up_or_down)
+    y = _Act(torch.empty(B, Ho, Wo, Cs, dtype=torch.float16, device=a.t.device), a.C)
+    h = _Act(torch.empty_like(y.t), a.C)
+    hip.check(hip.lib().brv_nhwc_fir_resample2d_dual(
+        hip.ptr(a.t), hip.ptr(fold[0]), hip.ptr(fold[1]), int(silu),
+        hip.ptr(resampler.kernel.float().contiguous()), hip.ptr(y.t), hip.ptr(h.t), B, a.C, Cs, H, W,
+        Ho, Wo, K, padding[0], padding[1], int(up), 4.0 if up else 1.0, hip.stream()),
+        'brv_nhwc_fir_resample2d_dual')
+    return y, h
+
+
 def _h_small_conv(a, mod, fold=None, silu=False, y_in=None):
     """3x3 convolution to <= 8 channels, (B, Cout, H, W) fp32 = [y_in +] conv(act(a)) + bias."""
     a = _h_single(a)
@@ -529,9 +549,7 @@ class UNetBlock(nn.Module):
     def forward_h(self, x, emb):
         """``forward`` on channels-last fp16 activations (``_Act``)."""
         if self.resampler is not None:
-            h = _h_resample(_h_affine_act(x, _h_gn_fold(x, self.norm_1), silu=True), self.resampler,
-                            self.up_or_down)
-            x = _h_resample(x, self.resampler, self.up_or_down)
+            x, h = _h_resample_pair(x, _h_gn_fold(x, self.norm_1), self.resampler, self.up_or_down)
             h = _h_conv3(h, self.conv_1)
         else:
             h = _h_conv3(x, self.conv_1, norm=self.norm_1, silu=True)

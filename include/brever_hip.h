@@ -617,6 +617,13 @@ int brv_nhwc_affine_act(const void* x, const float* scale_bc, const float* shift
 int brv_nhwc_fir_resample2d(const void* x, const float* kernel, void* y, int64_t B, int64_t Cs,
                             int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t K, int64_t pad_h,
                             int64_t pad_w, int up, float gain, brv_stream_t stream);
+/* Both resamplings of a UNetBlock input in one pass (/root/reference/brever/models/sgmsep/net.py
+ * UNetBlock.forward: `x = resample(x)` and `h = resample(silu(norm_1(x)))`): y_raw = FIR(x),
+ * y_act = FIR(act(scale_bc*x + shift_bc)); K <= 4. */
+int brv_nhwc_fir_resample2d_dual(const void* x, const float* scale_bc, const float* shift_bc, int act,
+                                 const float* kernel, void* y_raw, void* y_act, int64_t B, int64_t C,
+                                 int64_t Cs, int64_t H, int64_t W, int64_t Ho, int64_t Wo, int64_t K,
+                                 int64_t pad_h, int64_t pad_w, int up, float gain, brv_stream_t stream);
 int brv_nhwc_axpby(const void* a, float alpha, const void* b, float beta, void* out, int64_t n,
                    brv_stream_t stream);
 int64_t brv_nhwc_conv1x1_packed_size(int64_t Cout, int64_t C1, int64_t C2);

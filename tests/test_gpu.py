@@ -1416,6 +1416,25 @@ def test_sgmse_channels_last_kernels_match_torch():
                                         output_padding=opad, groups=24, stride=2)
             up = M._h_resample(down, rs, 'up')
             assert up.t.shape[1:3] == (H, W) and rel(M._h_to_nchw(up), up_ref) <= 1e-3
+    # both resamplings of a block input in one launch == the separate kernels, bit for bit (sizes
+    # crossing the 8 x 16 / 16 x 32 output tiles, odd sizes, channel counts that do not fill a 32-chunk)
+    for fir in ([1, 3, 3, 1], [1, 1]):
+        rs = M.Resample(fir, buffer_padding=True).to(dev)
+        for C, H, W in ((24, 13, 7), (128, 40, 70), (72, 33, 65), (256, 9, 130)):
+            xx = torch.randn(2, C, H, W, generator=g)
+            act = M._h_from_nchw(xx.to(dev))
+            gn = M.GroupNorm(C).to(dev)
+            with torch.no_grad():
+                gn.weight.add_(0.2*torch.randn(C, generator=g).to(dev))
+                gn.bias.add_(0.2*torch.randn(C, generator=g).to(dev))
+            fold = M._h_gn_fold(act, gn)
+            for mode in ('down', 'up'):
+                want_raw = M._h_resample(act, rs, mode)
+                want_act = M._h_resample(M._h_affine_act(act, fold, silu=True), rs, mode)
+                got_raw, got_act = M._h_resample_pair(act, fold, rs, mode)
+                assert got_raw.t.shape == want_raw.t.shape
+                assert torch.equal(got_raw.t[..., :C], want_raw.t[..., :C]), (fir, C, H, W, mode)
+                assert torch.equal(got_act.t[..., :C], want_act.t[..., :C]), (fir, C, H, W, mode)
     # few-channel 3x3 convolution (progressive output branch) and the pointwise add of the input branch
     for ci, co in ((128, 4), (96, 2)):
         conv = torch.nn.Conv2d(ci, co, 3, 1, 1)
