@@ -619,8 +619,9 @@ class DecoderBlock(nn.Module):
         for blk in self.unet_blocks:
             if blk.resampler is None:
                 x = _h_single(x)
-                x = _Act(x.t, x.C, second=skips.pop())      # torch.cat([x, skip], dim=1), never copied
-                x.sums = None
+                cat = _Act(x.t, x.C, second=skips.pop())    # torch.cat([x, skip], dim=1), never copied
+                cat.sums = x.sums                           # (sums describe the first part only)
+                x = cat
             x = blk.forward_h(x, emb)
         return x
 
