@@ -112,7 +112,10 @@ def cpu_baseline():
 KERNEL_OF_LABEL = {
     'gln_prelu_bwd': 'dz_kernel', 'dwconv_bwd': 'dwconv_bwd_halo_kernel',
     'dwconv_fwd': 'dwconv_fwd_kernel', 'pw2_wgrad': 'wgrad_full_kernel',
-    'pw1_fwd': 'gemm_ws_kernel<128, 64, 1, 0,', 'pw2_fwd': 'gemm_ws_kernel<512,',
+    # (fused forward: 23 of the 24 first-conv launches finish the block input while staging it)
+    'pw1_fwd': ['gemm_ws_kernel<128, 64, 1, 0, 2,', 'gemm_ws_kernel<128, 64, 1, 0,'],
+    'pw2_fwd': 'gemm_ws_kernel<512,', 'dwpw2_fwd': 'dwpw2_fused_kernel',
+    'skip_combine': 'skip_combine_kernel',
     'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': 'gemm_rows_kernel<128, 3, 5>',
     'pw1_wgrad': ('gemm_wgrad_kernel<128, 0>', 'largest'), 'clip_adam': 'clip_adam_kernel',
 }
@@ -128,15 +131,17 @@ def pmc_traffic(label):
     field = 'hbm_traffic_MB'
     if isinstance(key, tuple):        # the template also serves smaller launches: take the largest
         key, field = key[0], 'hbm_traffic_MB_largest_launch'
+    keys = key if isinstance(key, list) else [key]      # candidates, most specific first
     for fname in PMC_FILES:
         path = os.path.join(ROOT, 'profiles', fname)
         if key is None or not os.path.exists(path):
             continue
         with open(path) as f:
             kernels = json.load(f)['kernels']
-        for name, v in kernels.items():
-            if key in name and field in v:
-                return v[field]*1e6, f'profiles/{fname}'
+        for k in keys:
+            for name, v in kernels.items():
+                if k in name and field in v:
+                    return v[field]*1e6, f'profiles/{fname}'
     return None, None
 
 
