@@ -1163,7 +1163,8 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
       g.e.out = ubuf(i); g.e.ldo = NPu; g.e.N = NPu;
       {
         ProfScope prof("dwpw2_fwd", 2.0*BT*l.Hp*(NPu + l.P), 2.0*BT*(2*l.Hp + NPu), st);
-        static const bool old_stage = getenv("BRV_DWPW2_WS") && atoi(getenv("BRV_DWPW2_WS")) == 1;
+        const char* ws_env = getenv("BRV_DWPW2_WS");          // first version of the stage (gemm_ws.cuh AT == 3)
+        const bool old_stage = ws_env && atoi(ws_env) == 1;
         if (old_stage || l.Hp != DP_H || NPu != DP_N) {
           if (int r = launch_gemm_ws<512, 32, 1, E_STORE, 3, false, 8>(g, B, st)) return r;
         } else {

@@ -442,8 +442,9 @@ def test_fused_forward_option_matches_oracle(monkeypatch):
     want = want.detach()
     gold = torch.cat([p.grad.reshape(-1) for p in oracle.parameters()])
     grads = {}
-    for fuse in ('0', '1'):
-        monkeypatch.setenv('BRV_FWD_FUSE', fuse)
+    for fuse in ('0', '1', 'ws'):         # 'ws': the fused stage as a mode of the persistent GEMM
+        monkeypatch.setenv('BRV_FWD_FUSE', '0' if fuse == '0' else '1')
+        monkeypatch.setenv('BRV_DWPW2_WS', '1' if fuse == 'ws' else '0')
         net = ConvTasNet(**cfg)
         net.load_state_dict(oracle.state_dict())
         net = net.to(_cuda())
@@ -455,8 +456,9 @@ def test_fused_forward_option_matches_oracle(monkeypatch):
         grads[fuse] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
     # both paths are bf16 approximations of the same fp32 function (8 blocks): the gradient
     # tolerance of the bf16 path, and the fused path no further from the reference than 1.5x
-    e0, e1 = rel(grads['0'], gold), rel(grads['1'], gold)
+    e0, e1, e2 = rel(grads['0'], gold), rel(grads['1'], gold), rel(grads['ws'], gold)
     assert e0 <= 8e-2 and e1 <= 8e-2 and e1 <= 1.5*e0 + 1e-2, (e0, e1)
+    assert e2 <= 8e-2 and e2 <= 1.5*e0 + 1e-2, (e0, e2)
 
 # ---- fp32 path (use_amp=False): the parity protocol of SURVEY.md 8(d) at fp32 tolerances -------
 @pytest.mark.parametrize('tag', ['small', 'small2', 'causal', 'causal2'])
