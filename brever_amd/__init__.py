@@ -3,4 +3,11 @@
 Host code in Python on PyTorch-ROCm; compute in hand-written HIP kernels for
 gfx950 reached through the C ABI declared in ``include/brever_hip.h``.
 """
+import os as _os
+
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL, device tensors shared between
+# processes): the legacy IPC mode fails with `hipIpcGetMemHandle: invalid argument`. Only a default --
+# an exported value wins -- and it must be in place before the HIP runtime initialises.
+_os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 __version__ = '0.1.0'
