@@ -5,9 +5,10 @@
 //   u  = (W gamma_2) p                             (the [res | skip] product on the UN-normalised p;
 //                                                   rstd_2 and the offset are applied by the consumers:
 //                                                   gemm_ws AT == 2, skip_combine_kernel)
-// in ONE kernel: z2 never comes back from HBM in the forward pass (163 MB per launch instead of
-// 229 MB for dwconv_fwd + pw2_fwd). It replaces the gemm_ws AT == 3 variant, whose weight-
-// stationary register tile (128 VGPRs of weights) left the depthwise stage spilling.
+// in ONE kernel: z2 never comes back from HBM in the forward pass and the fp32 skip accumulation
+// is gone (164 MB per launch instead of 131 + 164 MB for dwconv_fwd + pw2_fwd). It supersedes the
+// gemm_ws AT == 3 variant (BRV_DWPW2_WS=1), whose weight-stationary register tile (128 VGPRs of
+// weights) left the depthwise stage spilling. Measurements and rejected variants: DESIGN.md 5f.
 //
 // One workgroup of 8 waves per CU, 128 frames x all 512 channels per tile, channel slabs of 64:
 //   stage(s):  every thread owns one channel octet of the slab and two frames: three dilated taps
