@@ -151,6 +151,11 @@ def kernel_roofline(model, batches, scaler, steps=3):
     """Event-timed steps (HIP events around every launch, on the launch stream):
     roofline of the kernel with the largest total time."""
     lib = hip.lib()
+    # one chain for this pass: the timed region runs the two half-batch chains of
+    # ConvTasNet._train_step_two_chains concurrently, where a launch's wall time includes the other
+    # chain's workgroups; a kernel's own duration and bytes per launch are those of the whole batch
+    chains = os.environ.get('BRV_CTN_STREAMS')
+    os.environ['BRV_CTN_STREAMS'] = '1'
     lib.brv_prof_enable(1)
     for i in range(steps):
         batch, lengths = batches[i % len(batches)]
@@ -158,6 +163,10 @@ def kernel_roofline(model, batches, scaler, steps=3):
     torch.cuda.synchronize()
     prof = hip.profile_collect()
     lib.brv_prof_enable(0)
+    if chains is None:
+        del os.environ['BRV_CTN_STREAMS']
+    else:
+        os.environ['BRV_CTN_STREAMS'] = chains
     if not prof:
         return None, {}
     label, top = max(prof.items(), key=lambda kv: kv[1]['ms'])

@@ -1178,7 +1178,9 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
           dp.B = B; dp.T = (int)T; dp.dil = dil; dp.left = ((l.P - 1)*dil)/2; dp.C = l.H;
           dp.inv_n = 1.0/((double)T*l.H); dp.eps = 1e-8f;
           const int n_tiles = B*(int)((T + DP_TT - 1)/DP_TT);
-          hipLaunchKernelGGL(dwpw2_fused_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(512), 0, st, dp);
+          // (a multiple of 8 workgroups: the kernel deals the tiles to the 8 XCDs in equal runs of slots)
+          const int n_wg = n_tiles < 256 ? (n_tiles + 7)/8*8 : 256;
+          hipLaunchKernelGGL(dwpw2_fused_kernel, dim3(n_wg), dim3(512), 0, st, dp);
           HIP_OK(hipGetLastError());
         }
       }

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
   // XCD k (workgroup ids congruent k mod 8 share an L2) takes the k-th contiguous eighth of the tiles:
   // the dilated taps of neighbouring tiles are then fetched once per L2, not once per XCD
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (n_tiles + 7) >> 3;
-  const int wg_per_xcd = (gridDim.x + 7) >> 3;
+  const int wg_per_xcd = gridDim.x >> 3;                        // gridDim.x is a multiple of 8 (launch site)
   for (int ti_ = slot; ti_ < per_xcd; ti_ += wg_per_xcd) {
     const int tile = xcd*per_xcd + ti_;
     if (tile >= n_tiles) break;

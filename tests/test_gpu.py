@@ -460,6 +460,90 @@ def test_fused_forward_option_matches_oracle(monkeypatch):
     assert e0 <= 8e-2 and e1 <= 8e-2 and e1 <= 1.5*e0 + 1e-2, (e0, e1)
     assert e2 <= 8e-2 and e2 <= 1.5*e0 + 1e-2, (e0, e2)
 
+def test_fused_forward_covers_every_tile(monkeypatch):
+    """Every (batch, length) combination: the fused stage deals its frame tiles to the 8 XCDs in runs
+    of slots (regression: with a workgroup count that was not a multiple of 8 some tiles were never
+    computed -- whole items wrong for e.g. 3 or 4 items x 3 tiles). Fused against the three-launch
+    forward, per item."""
+    from brever_amd.models import ConvTasNet
+    cfg = dict(layers=2, repeats=1)
+    gen = torch.Generator().manual_seed(33)
+    for L in (2100, 6000, 8200, 10500):                  # 2, 3, 4, 6 tiles of 128 frames per item
+        for B in (1, 2, 3, 4, 5, 7, 9, 11):
+            x = (0.3*torch.randn(B, L, generator=gen)).cuda()
+            outs = {}
+            for fuse in ('0', '1'):
+                monkeypatch.setenv('BRV_FWD_FUSE', fuse)
+                torch.manual_seed(5)
+                net = ConvTasNet(**cfg).to(_cuda()).eval()
+                net._amp = True
+                with torch.no_grad():
+                    outs[fuse] = net(x).clone()
+            worst = max(rel(outs['1'][b], outs['0'][b]) for b in range(B))
+            assert worst <= 1e-2, (B, L, worst)
+
+
+def test_two_chain_step_equals_single_chain(monkeypatch):
+    """The fused bf16 step as two half-batch chains on two streams (default for B >= 8) against the
+    single chain (BRV_CTN_STREAMS=1): same per-item losses, the weight gradient is the sum of the two
+    halves' (fp32 summation order differs); the bucketed form (backward in 3 parts, each part's slice
+    handed to the hook after both halves finished it) gives the same buffer and tiles it exactly once."""
+    from brever_amd.models import ConvTasNet
+
+    class Hook:
+        nparts = 3
+
+        def __init__(self):
+            self.seen = []
+
+        def bucket(self, part, grad_slice):
+            self.seen.append((part, grad_slice.data_ptr(), grad_slice.numel()))
+
+        def finish(self):
+            return 1.0
+
+        def __call__(self, grads):
+            return 1.0
+
+    cfg = dict(layers=3, repeats=2)
+    gen = torch.Generator().manual_seed(21)
+    B, L = 8, 6000
+    batch = (0.3*torch.randn(B, 2, L, generator=gen)).cuda()
+    lengths = torch.tensor([L, L - 7, L - 1000, L, L - 2222, L - 1, L - 300, L - 64]).cuda()
+    for b in range(B):
+        batch[b, :, lengths[b]:] = 0
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    got = {}
+    for mode in ('one', 'two', 'two_buckets'):
+        monkeypatch.setenv('BRV_CTN_STREAMS', '1' if mode == 'one' else '2')
+        torch.manual_seed(5)
+        net = ConvTasNet(**cfg).to(_cuda())
+        hook = None
+        if mode == 'two_buckets':
+            hook = Hook()
+            net.set_grad_sync(hook)
+        # ONE step: gradients of the same weights (a second step would start from weights that differ
+        # where Adam's first update, lr*sign(g), amplified a rounding difference of a near-zero g)
+        losses = [float(net.train_step(batch, lengths, True, scaler))]
+        torch.cuda.synchronize()
+        got[mode] = (losses, net.flat_grads().clone().cpu(), net._flat.detach().clone().cpu())
+        if hook is not None:
+            base = net.flat_grads().data_ptr()
+            spans = sorted((p - base)//4 for _, p, _ in hook.seen[-3:])
+            sizes = {(p - base)//4: n for _, p, n in hook.seen[-3:]}
+            assert len(hook.seen) == 3
+            end = 0
+            for off in spans:
+                assert off == end
+                end = off + sizes[off]
+            assert end == net._flat.numel()
+    for mode in ('two', 'two_buckets'):
+        assert max(abs(a - b) for a, b in zip(got[mode][0], got['one'][0])) <= 1e-5, (mode, got[mode][0])
+        assert rel(got[mode][1], got['one'][1]) <= 1e-4, (mode, rel(got[mode][1], got['one'][1]))
+        assert rel(got[mode][2], got['one'][2]) <= 1e-4, mode
+    assert rel(got['two_buckets'][1], got['two'][1]) <= 1e-5
+
+
 # ---- fp32 path (use_amp=False): the parity protocol of SURVEY.md 8(d) at fp32 tolerances -------
 @pytest.mark.parametrize('tag', ['small', 'small2', 'causal', 'causal2'])
 def test_fp32_path_matches_reference(golden_dir, tag):

@@ -1,20 +1,27 @@
-import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# take the last 60% of rows (steady state)
-n = len(rows)
-rows = rows[int(n*0.5):]
-gaps = collections.defaultdict(list); durs = collections.defaultdict(list)
-prev_end = None
-for r in rows:
-    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    name = r['Kernel_Name'][:60]
-    durs[name].append(e - s)
-    if prev_end is not None:
-        gaps[name].append(s - prev_end)
-    prev_end = e
-tot_d = sum(sum(v) for v in durs.values()); tot_g = sum(sum(v) for v in gaps.values())
-print('kernels', len(rows), 'sum dur %.2f ms, sum gaps %.2f ms' % (tot_d/1e6, tot_g/1e6))
-for name, v in sorted(durs.items(), key=lambda kv: -sum(kv[1]))[:25]:
-    g = gaps.get(name, [0])
-    print('%-60s n=%5d dur avg %7.1f us  gap-before avg %6.1f us' % (name, len(v), sum(v)/len(v)/1e3, sum(g)/len(g)/1e3))
+"""Idle time between consecutive dispatches of a rocprofv3 --kernel-trace CSV (last third of the run):
+python3 tools/trace_gaps.py DIR  -> busy / span, gap histogram, the kernels that follow the longest gaps."""
+import csv
+import glob
+import sys
+import collections
+f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+rows = rows[len(rows)*2//3:]
+span = (int(rows[-1]['End_Timestamp']) - int(rows[0]['Start_Timestamp']))/1e3
+busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows)/1e3
+gaps = []
+end = int(rows[0]['End_Timestamp'])
+for r in rows[1:]:
+    s = int(r['Start_Timestamp'])
+    gaps.append(((s - end)/1e3, r['Kernel_Name'][:60]))
+    end = max(end, int(r['End_Timestamp']))
+print(f'launches {len(rows)}  span {span/1e3:.3f} ms  busy {busy/1e3:.3f} ms  idle {sum(max(g, 0) for g, _ in gaps)/1e3:.3f} ms')
+h = collections.Counter()
+for g, _ in gaps:
+    h[min(int(max(g, 0)), 20)] += 1
+print('gap histogram (us: count):', sorted(h.items()))
+by = collections.defaultdict(list)
+for g, k in gaps:
+    by[k].append(g)
+for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:12]:
+    print(f'{sum(v)/1e3:8.3f} ms idle before {len(v):5d} x {k}  (avg {sum(v)/len(v):.1f} us)')
