@@ -23,6 +23,9 @@ import sys
 import time
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC for RCCL (before HIP initialises)
+# the step runs two kernel chains on two streams; with RCCL's streams the default 4 hardware queues
+# are oversubscribed and the chains share one (9.6 instead of 7.7 ms per step)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch                                                  # noqa: E402
 import torch.distributed as dist                              # noqa: E402
@@ -188,6 +191,8 @@ def kernel_roofline(model, batches, scaler, steps=3):
         'frac': (gbs/PEAK_HBM_GBS) if hbm_bound else (tfs/PEAK_MFMA_TFLOPS),
         'traffic': traffic,
         'traffic_source': f'{traffic_src} (rocprofv3 --pmc, bytes per launch)' if traffic_src else None,
+        'mode': 'one kernel chain (BRV_CTN_STREAMS=1): whole-batch launches, the kernel alone on the chip; '
+                'the timed region overlaps two half-batch chains',
         'avg_launch_us': avg_s*1e6,
         'launches_per_step': top['calls']/steps,
         'algorithmic_bytes_per_launch': nbytes,

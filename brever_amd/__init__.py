@@ -9,5 +9,10 @@ import os as _os
 # processes): the legacy IPC mode fails with `hipIpcGetMemHandle: invalid argument`. Only a default --
 # an exported value wins -- and it must be in place before the HIP runtime initialises.
 _os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# Conv-TasNet's training step runs two kernel chains on two streams (models/convtasnet.py); next to
+# RCCL's streams the default 4 hardware queues are oversubscribed and the chains end up sharing one.
+# Read when the HIP runtime loads: effective if this package is imported before torch, as the entry
+# points (bench.py, scripts/) do; otherwise export it.
+_os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 __version__ = '0.1.0'

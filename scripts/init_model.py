@@ -10,6 +10,10 @@ options first, then the architecture and its own options, e.g.
 ``MODELS`` comes from ``config/paths.yaml``. Extension: ``--models_dir DIR`` overrides it."""
 import os
 
+# read when the HIP runtime loads (torch import): see brever_amd/__init__.py
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import yaml
 
 from _common import ROOT  # noqa: F401

@@ -16,6 +16,10 @@ be ``synthetic:<items>:<seconds>``. The HIP models have no CPU path: pass ``--cu
 import argparse
 import logging
 import os
+
+# read when the HIP runtime loads (torch import): see brever_amd/__init__.py
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import pprint
 import re
 import struct

@@ -11,6 +11,10 @@ HBM capacity (``batching.hbm_batch_seconds``)."""
 import argparse
 import logging
 import os
+
+# read when the HIP runtime loads (torch import): see brever_amd/__init__.py
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import pprint
 import random
 

@@ -2,6 +2,8 @@
 `--buckets` parts with one all-reduce per part (bench.py only does this for world > 1).
 usage: python tools/bench_parts.py [--buckets 3] [--steps 20] [--kernel-table]"""
 import argparse, os, sys, time
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')     # before torch loads the HIP runtime (brever_amd/__init__.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist

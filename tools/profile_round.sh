@@ -11,13 +11,24 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-through-trainer"
+# The default step runs two half-batch kernel chains concurrently (a launch's wall time then includes
+# the other chain's workgroups, and a launch covers half the batch). The per-kernel numbers -- this
+# statistics pass, the PMC passes and the `roofline` object of bench.py -- are those of the ONE-chain
+# step (BRV_CTN_STREAMS=1): whole-batch launches, a kernel alone on the chip. The two-chain statistics
+# are kept next to them.
+export BRV_CTN_STREAMS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o main -- python3 $REPO/bench.py $ARGS --kernel-table > $OUT/${TAG}_rocprofv3_bench_line.json 2> $OUT/${TAG}_kernel_table.txt
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv
+unset BRV_CTN_STREAMS
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats2 -o main -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_rocprofv3_bench_line_two_chains.json 2> /dev/null
+cp $(find /tmp/prof_stats2 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats_two_chains.csv
+export BRV_CTN_STREAMS=1
 PMCARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-through-trainer"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
 python3 $REPO/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $OUT/${TAG}_pmc_hbm_traffic.json
 # the complete default line without a profiler attached (what the driver runs)
+unset BRV_CTN_STREAMS
 cd $REPO && python3 bench.py > $OUT/${TAG}_bench_line.json 2> /dev/null
 grep -v "^/opt" $OUT/${TAG}_kernel_table.txt | grep -E "^[a-z_0-9]+ +[0-9]" | head -12
 cut -c1-400 $OUT/${TAG}_bench_line.json
