@@ -326,8 +326,9 @@ def test_entry_points_train_and_test(tmp_path):
     assert "val_metrics ['pesq'] need packages that are not installed" in log
 
 
-@pytest.mark.parametrize('causal,fuse', [(False, '1'), (False, '0'), (True, '1')])
-def test_default_width_network_matches_oracle(monkeypatch, causal, fuse):
+@pytest.mark.parametrize('causal,fuse,B,L', [(False, '1', 3, 2500), (False, '0', 3, 2500), (True, '1', 3, 2500),
+                                             (False, '1', 4, 6000), (False, '1', 5, 4100)])
+def test_default_width_network_matches_oracle(monkeypatch, causal, fuse, B, L):
     """Default channel widths (512/128/512/128) with 4 blocks: exercises the persistent
     weight-stationary GEMMs (the small golden configs take the generic tile kernel), for
     the global and the cumulative layer norm. Non-causal: the fused forward (default) and the
@@ -348,9 +349,8 @@ def test_default_width_network_matches_oracle(monkeypatch, causal, fuse):
     net.load_state_dict(oracle.state_dict())
     net = net.to(_cuda())
     net._amp = True
-    B, L = 3, 2500
     batch = 0.3*torch.randn(B, 2, L, generator=gen)
-    lengths = torch.tensor([L, L - 300, L - 1111])
+    lengths = torch.tensor([L, L - 300, L - 1111, L - 17, L - 2048][:B])
     for b in range(B):
         batch[b, :, lengths[b]:] = 0
     oracle.trace = {}
