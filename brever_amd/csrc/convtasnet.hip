@@ -257,6 +257,11 @@ long long* debug_buffer() {
 }
 #endif
 
+// Workgroups of a persistent launch: one per CU -- or `g_chain_eighths`/8 of that while two kernel
+// chains share the chip (brv_ctn_set_chain_share): with 8 items per chain a full-width launch has
+// exactly one tile per workgroup and both chains' launches start and drain in lockstep; at 7/8 the
+// chains interleave (2085 -> 2132 utt/s). Worse for a single chain (2014 -> 1948), hence a switch.
+int g_chain_eighths = 8;
 int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -266,7 +271,8 @@ int num_cus() {
         n <= 0)
       n = 256;
   }
-  return n;
+  const int m = n*g_chain_eighths/8/8*8;
+  return m >= 8 ? m : n;
 }
 
 // Persistent weight-stationary fast path (gemm_ws.cuh) for the hot TCN shapes.
@@ -1179,7 +1185,8 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
           dp.inv_n = 1.0/((double)T*l.H); dp.eps = 1e-8f;
           const int n_tiles = B*(int)((T + DP_TT - 1)/DP_TT);
           // (a multiple of 8 workgroups: the kernel deals the tiles to the 8 XCDs in equal runs of slots)
-          const int n_wg = n_tiles < 256 ? (n_tiles + 7)/8*8 : 256;
+          const int cap = num_cus() >= 8 ? num_cus()/8*8 : 8;
+          const int n_wg = n_tiles < cap ? (n_tiles + 7)/8*8 : cap;
           hipLaunchKernelGGL(dwpw2_fused_kernel, dim3(n_wg), dim3(512), 0, st, dp);
           HIP_OK(hipGetLastError());
         }
@@ -1396,6 +1403,12 @@ static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, con
 }
 
 extern "C" {
+
+int brv_ctn_set_chain_share(int32_t eighths) {
+  if (eighths < 1 || eighths > 8) return fail(-1, "chain share: 1 .. 8 eighths of the CUs");
+  g_chain_eighths = eighths;
+  return 0;
+}
 
 int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void* prepared,
                      void* workspace, const float* wave, const float* d_out, float* grads,

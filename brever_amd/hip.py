@@ -41,6 +41,7 @@ SIGNATURES = {
     'brv_ctn_workspace_offset': (_c_i64, [_c_ptr, _c_i64, _c_i64,
                                           ctypes.c_char_p, _c_i64]),
     'brv_ctn_prepare': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr]),
+    'brv_ctn_set_chain_share': (ctypes.c_int, [ctypes.c_int32]),
     'brv_ctn_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                        _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_ctn_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,

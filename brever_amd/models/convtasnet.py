@@ -534,6 +534,12 @@ class ConvTasNet(BreverBaseModel):
             return loss_b.mean()
 
     def _train_step_two_chains(self, inputs, labels, lengths):
+        try:
+            return self._two_chains(inputs, labels, lengths)
+        finally:                                  # (also when a launch failed half way)
+            hip.lib().brv_ctn_set_chain_share(8)
+
+    def _two_chains(self, inputs, labels, lengths):
         """The fused bf16 step as TWO independent half-batch chains on two streams. Every launch of
         the TCN depends on the one before it (a layer norm over the whole item sits between them), so
         a single chain leaves the chip idle for the ~4.5 us between dependent launches and in the tail
@@ -571,6 +577,8 @@ class ConvTasNet(BreverBaseModel):
             grads.zero_()
             main, side = torch.cuda.current_stream(dev), t['side']
             side.wait_stream(main)
+            # persistent kernels at 7/8 of the CUs while two chains share the chip (csrc: num_cus)
+            hip.check(lib.brv_ctn_set_chain_share(7), 'brv_ctn_set_chain_share')
             streams = (main, side)
             flat, prep, cfg = hip.ptr(self._flat), hip.ptr(self._prepared), self._cfg_ptr()
 
@@ -611,6 +619,7 @@ class ConvTasNet(BreverBaseModel):
                     grads[off:off + cnt].add_(t['grad2'][off:off + cnt])
                     if nparts > 1:
                         sync.bucket(part, grads[off:off + cnt])
+            hip.check(lib.brv_ctn_set_chain_share(8), 'brv_ctn_set_chain_share')
             if sync is None:
                 grad_scale = 1.0
             else:

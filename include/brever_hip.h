@@ -80,6 +80,12 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params,
                     float* out, int64_t batch, int64_t length,
                     brv_stream_t stream);
 
+/* Persistent kernels of the Conv-TasNet path launch eighths/8 of one workgroup per CU (default 8).
+ * The host side sets 7 while it runs two half-batch kernel chains on two streams
+ * (brever_amd/models/convtasnet.py: _train_step_two_chains) and restores 8 afterwards. Host state,
+ * read at launch time; no reference counterpart (an execution knob of this implementation). */
+int brv_ctn_set_chain_share(int32_t eighths);
+
 /* Autograd of ConvTasNet.forward: d_out (batch, sources, length) fp32 ->
  * gradients ACCUMULATED into `grads` (flat fp32, same layout as params;
  * the caller zeroes it, as optimizer.zero_grad() does). */
