@@ -544,6 +544,29 @@ def test_two_chain_step_equals_single_chain(monkeypatch):
     assert rel(got['two_buckets'][1], got['two'][1]) <= 1e-5
 
 
+def test_two_chain_step_full_size(monkeypatch):
+    """BASELINE size (24 blocks, 16 x 64 000): the two-chain step (persistent kernels at 7/8 of the
+    CUs) against the one-chain step from the same weights: same loss, same clipped gradient."""
+    from brever_amd.models import ConvTasNet
+    gen = torch.Generator().manual_seed(8)
+    B, L = 16, 64000
+    batch = (0.3*torch.randn(B, 2, L, generator=gen)).cuda()
+    lengths = torch.full((B,), L).cuda()
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    got = {}
+    for mode in ('1', '2'):
+        monkeypatch.setenv('BRV_CTN_STREAMS', mode)
+        torch.manual_seed(0)
+        net = ConvTasNet().to(_cuda())
+        loss = float(net.train_step(batch, lengths, True, scaler))
+        torch.cuda.synchronize()
+        got[mode] = (loss, net.flat_grads().clone().cpu(), net._flat.detach().clone().cpu())
+        del net
+    assert abs(got['1'][0] - got['2'][0]) <= 1e-5, (got['1'][0], got['2'][0])
+    assert rel(got['2'][1], got['1'][1]) <= 1e-5
+    assert rel(got['2'][2], got['1'][2]) <= 1e-6
+
+
 # ---- fp32 path (use_amp=False): the parity protocol of SURVEY.md 8(d) at fp32 tolerances -------
 @pytest.mark.parametrize('tag', ['small', 'small2', 'causal', 'causal2'])
 def test_fp32_path_matches_reference(golden_dir, tag):
