@@ -13,6 +13,12 @@ _os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 # RCCL's streams the default 4 hardware queues are oversubscribed and the chains end up sharing one.
 # Read when the HIP runtime loads: effective if this package is imported before torch, as the entry
 # points (bench.py, scripts/) do; otherwise export it.
+import sys as _sys
+
+_q = _os.environ.get('GPU_MAX_HW_QUEUES')
+# False: torch (and with it the HIP runtime) was loaded before this default could be seen; the
+# two-chain step then stays off next to an initialised process group (models/convtasnet.py)
+HW_QUEUES_OK = (_q is not None and _q.isdigit() and int(_q) >= 8) or 'torch' not in _sys.modules
 _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 __version__ = '0.1.0'

@@ -108,6 +108,16 @@ class _TCN(_ParamOnly):
         self.output_conv = nn.Conv1d(skip, filters*sources, 1)
 
 
+def _queues_ok():
+    import brever_amd
+    return brever_amd.HW_QUEUES_OK
+
+
+def _process_group():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 class _ConvTasNetFunction(torch.autograd.Function):
     """wave (B, L) -> (B, S, L) with gradients for every parameter."""
 
@@ -502,7 +512,8 @@ class ConvTasNet(BreverBaseModel):
         S = self.output_sources
         amp = bool(use_amp)
         sync = self._grad_sync
-        if amp and B >= 8 and B % 2 == 0 and os.environ.get('BRV_CTN_STREAMS', '2') != '1':
+        if amp and B >= 8 and B % 2 == 0 and os.environ.get('BRV_CTN_STREAMS', '2') != '1' \
+                and (_queues_ok() or not _process_group()):
             return self._train_step_two_chains(inputs, labels, lengths)
         with torch.no_grad():
             out = self._hip_forward(inputs, amp)
