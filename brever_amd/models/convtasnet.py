@@ -558,7 +558,8 @@ class ConvTasNet(BreverBaseModel):
         tools/trace_gaps.py). Items are independent until the weight gradients are summed, so the two
         halves of the batch run as separate chains whose workgroups fill each other's gaps. Same
         arithmetic per item; the weight gradient is g(first half) + g(second half). Measured
-        7.97 -> 7.65 ms per step (16 x 4 s); four chains: 10.4 ms. ``BRV_CTN_STREAMS=1``: one chain."""
+        7.97 -> 7.65 ms per step (16 x 4 s), 7.45 ms with the persistent kernels at 7/8 of the CUs
+        meanwhile; four chains: 10.4 ms. ``BRV_CTN_STREAMS=1``: one chain."""
         lib = hip.lib()
         B, L = inputs.shape
         S, Bh = self.output_sources, B//2
