@@ -457,7 +457,13 @@ ASpec frames_of(const float* wav, long long L, int hop, int K) {
   return a;
 }
 
-struct PrepBatch { PrepJob jobs[64]; int n; };
+// Jobs travel in the kernel arguments (4 KB): a compact form holds 168 of them, so the ~150 jobs of the
+// default network are ONE launch per step instead of three dependent ones (the step boundary is a
+// serial section: DESIGN.md section 8 item 1e).
+struct PrepJobC { int src_off, dst_off, scale_off; unsigned short R, C, rows, cols, dst_ld, tr; };
+constexpr int kPrepBatch = 168;
+struct PrepBatch { PrepJobC jobs[kPrepBatch]; int n; };
+static_assert(sizeof(PrepBatch) <= 4096, "kernel argument size");
 
 // plain [N][K] bf16 -> fragment order of the persistent GEMMs: slices of nsl rows, then
 // (f = 32-row chunk, s = 16-column step, lane = row % 32 + 32*((col % 16)/8), 8 values)
@@ -478,7 +484,11 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(bf16_t* prepared, const 
 __global__ __launch_bounds__(256) void prep_weights_kernel(const float* params,
                                                            bf16_t* prepped,
                                                            const PrepBatch pb) {
-  prep_job_run(params, prepped, pb.jobs[blockIdx.y], blockIdx.x, gridDim.x);
+  const PrepJobC& c = pb.jobs[blockIdx.y];
+  PrepJob j;
+  j.src_off = c.src_off; j.dst_off = c.dst_off; j.scale_off = c.scale_off;
+  j.R = c.R; j.C = c.C; j.rows = c.rows; j.cols = c.cols; j.dst_ld = c.dst_ld; j.tr = c.tr;
+  prep_job_run(params, prepped, j, blockIdx.x, gridDim.x);
 }
 
 // Constants of the lazily applied second norm (fused forward, gemm_ws.cuh AT == 3): with
@@ -1037,10 +1047,19 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
     add(l.out_w + (long long)s*l.N*l.Sc, l.p_out_b + (long long)s*l.Np,
         l.N, l.Sc, l.Scp, l.Np, l.S*l.Np, 1);
   }
-  for (size_t i = 0; i < jobs.size(); i += 64) {
+  for (size_t i = 0; i < jobs.size(); i += kPrepBatch) {
     PrepBatch pb;
-    pb.n = (int)std::min<size_t>(64, jobs.size() - i);
-    for (int k = 0; k < pb.n; ++k) pb.jobs[k] = jobs[i + k];
+    pb.n = (int)std::min<size_t>(kPrepBatch, jobs.size() - i);
+    for (int k = 0; k < pb.n; ++k) {
+      const PrepJob& j = jobs[i + k];
+      if (j.src_off > 0x7fffffffLL || j.dst_off > 0x7fffffffLL || j.scale_off > 0x7fffffffLL ||
+          (j.R | j.C | j.rows | j.cols | j.dst_ld) > 0xffff)
+        return fail(-1, "prepare: layout too large for the compact job form");
+      PrepJobC& c = pb.jobs[k];
+      c.src_off = (int)j.src_off; c.dst_off = (int)j.dst_off; c.scale_off = (int)j.scale_off;
+      c.R = (unsigned short)j.R; c.C = (unsigned short)j.C; c.rows = (unsigned short)j.rows;
+      c.cols = (unsigned short)j.cols; c.dst_ld = (unsigned short)j.dst_ld; c.tr = (unsigned short)j.tr;
+    }
     hipLaunchKernelGGL(prep_weights_kernel, dim3(8, pb.n), dim3(256), 0, st, params,
                        (bf16_t*)prepared, pb);
     HIP_OK(hipGetLastError());
