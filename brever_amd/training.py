@@ -408,7 +408,7 @@ class BreverTrainer:
         items = [(d, k) for d in tensor_dicts for k in d]
         if not items:
             return
-        packed = torch.stack([d[k].detach().float().reshape(())
+        packed = torch.stack([torch.as_tensor(d[k], device=self.device).detach().float().reshape(())
                               for d, k in items])
         dist.all_reduce(packed)
         packed /= dist.get_world_size()
@@ -426,7 +426,9 @@ class BreverTrainer:
         metrics = {}
         for name in self.val_metrics:
             values = MetricRegistry.get(name)(output, target, lengths=lengths)
-            metrics[name] = values.mean()
+            # (stoi / estoi hand back NumPy arrays: every logged value is a device tensor, as
+            # `reduce` and the loss logger expect)
+            metrics[name] = torch.as_tensor(values, dtype=torch.float32, device=self.device).mean()
         return metrics
 
     # -- checkpoints -------------------------------------------------------------

@@ -174,6 +174,42 @@ def _worker_trainer(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_trainer_numpy_metric(rank, world, port, out_dir):
+    """A validation metric that hands back a NumPy array, as stoi / estoi do (the packed
+    all-reduce of the logged values called .detach() on np.float64 and lost a default `ddp: true`
+    run at its first validation epoch)."""
+    import numpy as np
+
+    from brever_amd.metrics import MetricRegistry
+    from brever_amd.training import BreverTrainer
+    _init(rank, world, port)
+
+    @MetricRegistry.register('np_energy')
+    def np_energy(x, y, lengths=None):
+        return np.asarray([(float(rank) + 1.0)*float(x[i].pow(2).mean()) for i in range(x.shape[0])])
+
+    torch.manual_seed(rank)
+    model = DummyModel(channels=2, output_sources=2)
+    FS = 16000
+    train = DummyDataset(8, 3, 2, FS//2, FS, transform=model.transform)
+    val = DummyDataset(4, 3, 2, FS//2, FS, transform=model.transform)
+    trainer = BreverTrainer(
+        model=model, train_dataset=train, val_dataset=val,
+        model_dirpath=os.path.join(out_dir, 'model'), epochs=1, val_period=1,
+        val_metrics={'np_energy'}, batch_sampler='bucket', batch_size=4.0,
+        dynamic_batch_size=True, device='cpu', preload=True, ddp=True, rank=rank)
+    trainer.run()
+    if rank == 0:
+        logged = trainer.loss_logger.val_metrics[-1]
+        assert 'np_energy' in logged and torch.isfinite(torch.as_tensor(logged['np_energy'])), logged
+    dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_numpy_metric():
+    with tempfile.TemporaryDirectory() as tmp:
+        _spawn(_worker_trainer_numpy_metric, 2, tmp)
+
+
 def test_trainer_two_ranks():
     world = 2
     with tempfile.TemporaryDirectory() as tmp:
