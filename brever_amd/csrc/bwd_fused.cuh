@@ -1,0 +1,414 @@
+// Backward mirror of the fused forward stage (dwpw2_fused.cuh), default widths:
+//
+//   e   = W_rs^T [g_out | g_skip]                     [res | skip] data gradient (MFMA, K = 256)
+//   dz2 = PReLU_2'(z2) rstd_2 (gamma_2 e - m1 - xh_2 m2)   gLN_2 / PReLU_2 backward
+//   e1  = gamma_1 dconv^T(dz2)                        transposed dilated depthwise stencil
+//
+// in ONE kernel: the 512-wide e2 = gamma_2 e tensor that used to cross a launch boundary (written
+// by pw2_dgrad, read by the depthwise backward: 3 passes of 65.5 MB per block at the BASELINE size)
+// never exists. What made the boundary necessary are the item-wide means m1 = mean(e2),
+// m2 = mean(e2 xh_2) of the layer-norm backward; with the fused forward's stored u = (W gamma_2) p
+// they are functions of the 256-wide g and u alone,
+//   sum e2       = sum_t <g_t, v1>,           v1 = (W gamma_2) 1   (lazy-norm table of the forward)
+//   sum e2 xh_2  = rstd_2 (sum_t <g_t, u_t> - mean_2 sum_t <g_t, v1>),
+// so the kernel that PRODUCES g accumulates the two dot products (gemm_rows E_ADD epilogue of the
+// next block's first-conv data gradient; gu_dots_kernel for the last block) and they are known
+// before this kernel starts.
+//
+// Structure = dwconv_bwd_halo_kernel (comb tiles, tcn_kernels.cuh) with a phase 0 in front:
+//   phase 0: e of the window (tile + halo teeth, <= 256 rows x 64 channels) on the matrix pipe:
+//            A = W^T fragments (64 channels x 64 k per chunk, fragment order, staged through a
+//            double-buffered 8 KB LDS ring), B = g rows straight from global memory / L2 (every
+//            wave owns 64 window rows: a g row is fetched by exactly one wave), result -> LDS
+//            window (bf16, 144-byte rows);
+//   phase 1: dz2 of the window in place in LDS (+ d gamma_2, d beta_2, PReLU_2 slope, bias grads);
+//   phase 2: transposed stencil out of LDS, gLN_1 partial sums, tap / gamma_1 / beta_1 gradients.
+// Reference: autograd of brever/models/convtasnet/convtasnet.py:240-260 (Conv1DBlock.forward).
+#pragma once
+#include "tcn_kernels.cuh"
+
+namespace brv {
+
+struct BwdFusedParams {
+  DwParams d;              // as dwconv_bwd_halo_kernel; d.dz2 unused, d.sums2 = {sum <g, v1>, sum <g, u>}
+  const bf16_t* g;         // [B][T][ldg]: first used column of [g_out | g_skip]
+  int ldg, Kg;             // row stride (elements); reduction length (256, or 128 without residual conv)
+  const bf16_t* Wp;        // W^T [Hp][Kg] in fragment order, slices of 32 channels (p_rs_bp)
+  const float* gamma2;
+  float* dgamma2; float* dbeta2;    // replicated like the other per-channel gradients
+  int K;                   // centre teeth per tile (host: balanced over the tooth groups)
+};
+
+constexpr int BF_ROWS = 256;               // window rows (teeth x rows per tooth), 8 MFMA groups of 32
+constexpr int BF_LDW = HL_CG + 8;          // halves per window row: 144 B
+constexpr int BF_WCHUNK = 2*4*64*8;        // halves of one W chunk: 2 slices x 4 k-steps x 64 lanes x 8
+constexpr int BF_LDS = BF_ROWS*BF_LDW*2 + 2*BF_WCHUNK*2;
+
+// centre teeth per tile: as many as the window holds, balanced over the tooth groups
+inline int bf_tile_teeth(int T, int dil, int P) {
+  const int R = hl_rows_per_tooth(dil);
+  const int kmax = BF_ROWS/R - (P - 1);
+  const int n_teeth = (T - 1)/dil + 1;
+  const int n_qt = ceil_div(n_teeth, kmax);
+  return ceil_div(n_teeth, n_qt);
+}
+
+template <int P>
+__global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFusedParams fp) {
+  const DwParams& p = fp.d;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  bf16_t* win = reinterpret_cast<bf16_t*>(dyn_lds);
+  bf16_t* wbuf = reinterpret_cast<bf16_t*>(dyn_lds + BF_ROWS*BF_LDW*2);
+  float* red = reinterpret_cast<float*>(wbuf);           // after phase 0 (32*HL_CG floats = 8 KB)
+  __shared__ double dscr[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int T = p.T, d = p.dil;
+  const int R = hl_rows_per_tooth(d), K = fp.K;
+  const int n_rt = ceil_div(d, R);                       // residue groups
+  const int n_teeth = (T - 1)/d + 1;
+  const int n_qt = ceil_div(n_teeth, K);                 // tooth groups
+  const int n_tt = n_rt*n_qt, n_cg = p.Cp/HL_CG;
+  int id = blockIdx.x;
+  const int cg = id % n_cg; id /= n_cg;
+  const int b = id / n_tt;
+  const int tile = id % n_tt;
+  const int r0 = (tile % n_rt)*R, q0 = (tile / n_rt)*K;
+  const int cl = (tid & 7)*8;                          // channel offset inside the group
+  const int c0 = cg*HL_CG + cl;
+  const int rslot = tid >> 3;                          // 32 row slots per pass
+  const int W = (K + P - 1)*R;                         // rows of the window (<= BF_ROWS)
+  const int KR = K*R;                                  // output rows of the tile
+  const int qbase = q0 - (P - 1) + p.left/d;           // tooth of window row 0
+  // window row r -> frame: tooth qbase + r / R, residue r0 + r % R
+  auto frame_of = [&](int r, bool& ok) {
+    const int qi = r / R, ri = r % R;
+    const int q = qbase + qi;
+    ok = r < W && q >= 0 && r0 + ri < d;
+    return q*d + r0 + ri;
+  };
+
+  // ---- phase 0: e = W^T g of the window -> LDS ---------------------------------------------------
+  {
+    const int n32 = lane & 31, h = lane >> 5;
+    const int ngrp = (W + 31) >> 5;
+    const bool act0 = 2*wid < ngrp, act1 = 2*wid + 1 < ngrp;     // wave-uniform
+    const __amdgpu_buffer_rsrc_t rg =
+        make_rsrc(fp.g + (long long)b*T*fp.ldg, ((long long)(T - 1)*fp.ldg + fp.Kg)*2);
+    unsigned int offB[2]; bool vB[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      bool ok;
+      const int tf = frame_of(64*wid + 32*q + n32, ok);
+      vB[q] = ok && tf < T;
+      offB[q] = (unsigned int)tf*(unsigned int)(fp.ldg*2) + (unsigned int)(h*16);
+    }
+    const int nkc = fp.Kg >> 6;                            // chunks of 64 k (even: Kg % 128 == 0)
+    const bf16_t* wsrc = fp.Wp + (long long)(cg*2)*32*fp.Kg + tid*8;
+    const bf16_t* wsrc1 = wsrc + (long long)32*fp.Kg;
+    uint4 wst0, wst1;                                      // (scalars: an array captured by the lambdas went to scratch)
+    auto wload = [&](int kc) {
+      wst0 = *reinterpret_cast<const uint4*>(wsrc + kc*2048);
+      wst1 = *reinterpret_cast<const uint4*>(wsrc1 + kc*2048);
+    };
+    auto wstore = [&](int buf) {
+      *reinterpret_cast<uint4*>(wbuf + (buf*2 + 0)*2048 + tid*8) = wst0;
+      *reinterpret_cast<uint4*>(wbuf + (buf*2 + 1)*2048 + tid*8) = wst1;
+    };
+    uint4 bq[2][4];                                        // B fragments of the chunk in flight
+    auto bload1 = [&](int kc, int s) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        bq[q][s] = buf_load16(rg, vB[q] ? offB[q] + (unsigned int)((kc*64 + s*16)*2) : kOob);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][ms][i] = 0.f;
+    // k-step s of chunk kc; its B registers are refilled with the next chunk's step right away
+    auto mfma_chunk = [&](int kc, int buf) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(wbuf + (buf*2 + 0)*2048 + (s*64 + lane)*8);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wbuf + (buf*2 + 1)*2048 + (s*64 + lane)*8);
+        if (act0) {
+          const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[0][s]);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[0][1], 0, 0, 0);
+        }
+        if (act1) {
+          const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[1][s]);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[1][1], 0, 0, 0);
+        }
+        if (kc + 1 < nkc) bload1(kc + 1, s);
+      }
+    };
+    wload(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bload1(0, s);
+    wstore(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kc = 0; kc < nkc; kc += 2) {                 // two chunks per trip: static buffer parities
+      wload(kc + 1);
+      mfma_chunk(kc, 0);
+      wstore(1);
+      __syncthreads();
+      const bool more = kc + 2 < nkc;
+      if (more) wload(kc + 2);
+      mfma_chunk(kc + 1, 1);
+      if (more) wstore(0);
+      __syncthreads();
+    }
+    // D[channel][frame]: lane = frame n32, registers = channels 8 (i >> 2) + 4 h + (i & 3)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!(q == 0 ? act0 : act1)) continue;
+      const int wr = 64*wid + 32*q + n32;
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          uint2 v;
+          v.x = pack2(acc[q][ms][4*gq], acc[q][ms][4*gq + 1]);
+          v.y = pack2(acc[q][ms][4*gq + 2], acc[q][ms][4*gq + 3]);
+          *reinterpret_cast<uint2*>(win + wr*BF_LDW + ms*32 + 8*gq + 4*h) = v;
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: dz2 of the window, in place in LDS --------------------------------------------------
+  const double mean2 = p.stats2[stat_sum(b)]*p.inv_n;
+  double var2 = p.stats2[stat_sq(b)]*p.inv_n - mean2*mean2;
+  if (var2 < 0.0) var2 = 0.0;
+  const double rstd2d = 1.0/sqrt(var2 + (double)p.eps);
+  const float mu2 = (float)mean2, rs2 = (float)rstd2d;
+  const double S1 = p.sums2[stat_sum(b)], S2 = p.sums2[stat_sq(b)];
+  const float m1 = (float)(S1*p.inv_n);
+  const float m2 = (float)(rstd2d*(S2 - mean2*S1)*p.inv_n);
+  const float a2 = *p.slope2;
+  const float ya = 0.5f*(1.f + a2)*rs2, yb = 0.5f*(1.f - a2)*rs2, yc = -mu2*rs2;
+  const float R2 = rs2, K0 = -m1*rs2, M2R = -m2*rs2;
+  const __amdgpu_buffer_rsrc_t rz2 = make_rsrc(p.z2in + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+  const unsigned int row = (unsigned int)(p.Cp*2), coff = (unsigned int)(c0*2);
+  float da2 = 0.f;
+  f32x2 dbia[4], dgam2[4], dbet2[4], g2[4];
+  {
+    float g8[8];
+    load8_masked(fp.gamma2, c0, p.C, g8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g2[j] = f32x2{g8[2*j], g8[2*j + 1]};
+      dbia[j] = f32x2{0.f, 0.f}; dgam2[j] = f32x2{0.f, 0.f}; dbet2[j] = f32x2{0.f, 0.f};
+    }
+  }
+  // four rows per thread in flight before any of them is consumed
+  for (int rw = rslot; rw < W; rw += 128) {
+    uint4 qz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bool ok;
+      const int tf = frame_of(rw + 32*u, ok);
+      qz[u] = buf_load16(rz2, (ok && tf < T) ? (unsigned int)tf*row + coff : kOob);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = rw + 32*u;
+      if (r >= W) break;
+      bool ok;
+      const int tf = frame_of(r, ok);
+      const bool in = ok && tf < T;
+      float e[8], z[8], g[8];
+      unpack8(*reinterpret_cast<const uint4*>(win + r*BF_LDW + cl), e);
+      unpack8(qz[u], z);
+      const float on = in ? 1.f : 0.f;
+      const float rr = on*R2, k0 = on*K0, mm = on*M2R;
+      // each element is "owned" by the tile whose teeth [q0, q0 + K) contain it
+      const int q = qbase + r / R;
+      const bool centre = in && q >= q0 && q < q0 + K;
+      const float cen = centre ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh2 = __builtin_fmaf(yb, __builtin_fabsf(z[j]), __builtin_fmaf(ya, z[j], yc));
+        const float gj = (j & 1) ? g2[j >> 1].y : g2[j >> 1].x;
+        const float uu = __builtin_fmaf(mm, xh2, __builtin_fmaf(e[j]*gj, rr, k0));
+        const bool pos = z[j] > 0.f;
+        g[j] = c0 + j < p.C ? (pos ? uu : a2*uu) : 0.f;
+        if (centre && !pos) da2 += uu*z[j];
+        const float ec = cen*e[j];
+        if (j & 1) { dgam2[j >> 1].y = __builtin_fmaf(ec, xh2, dgam2[j >> 1].y); dbet2[j >> 1].y += ec; }
+        else { dgam2[j >> 1].x = __builtin_fmaf(ec, xh2, dgam2[j >> 1].x); dbet2[j >> 1].x += ec; }
+      }
+      const uint4 q4 = pack8(g);
+      *reinterpret_cast<uint4*>(win + r*BF_LDW + cl) = q4;
+      if (centre) {                                      // bias gradient = sum of (rounded) dz2
+        float gr[8]; unpack8(q4, gr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dbia[j] += f32x2{gr[2*j], gr[2*j + 1]};
+      }
+    }
+  }
+  // ---- per-channel reductions (32 row slots share each channel chunk); the phase-1 vectors are folded
+  // right away so that their registers are free during phase 2 (`red` = the W ring of phase 0)
+  auto reduce_cols = [&](const f32x2 (&v)[4], float* dst, int stride, int offset) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[rslot*HL_CG + cl + 2*j] = v[j].x; red[rslot*HL_CG + cl + 2*j + 1] = v[j].y;
+    }
+    __syncthreads();
+    if (tid < HL_CG) {
+      float sum = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) sum += red[r*HL_CG + tid];
+      const int c = cg*HL_CG + tid;
+      float* rdst = dst + (long long)(blockIdx.x % kReplicas)*p.rep_stride;
+      if (c < p.C) atomic_add_f32(rdst + (long long)c*stride + offset, sum);
+    }
+  };
+  reduce_cols(dbia, p.dbias, 1, 0);
+  reduce_cols(dgam2, fp.dgamma2, 1, 0);
+  reduce_cols(dbet2, fp.dbeta2, 1, 0);
+  {
+    __syncthreads();
+    const float sa = block_sum(da2, red);
+    if (tid == 0) atomic_add_f32(p.dslope2 + (long long)(blockIdx.x % kReplicas)*p.rep_stride, sa);
+  }
+  __syncthreads();
+
+  // ---- phase 2: transposed stencil out of LDS -------------------------------------------------
+  const NormStat ns = norm_stat(p.stats1, b, p.inv_n, p.eps);
+  const float a1 = *p.slope1;
+  const float xa = 0.5f*(1.f + a1)*ns.rstd, xb = 0.5f*(1.f - a1)*ns.rstd, xc = -ns.mean*ns.rstd;
+  f32x2 gm[4], be[4], w[P][4];
+  {
+    float g8[8], b8[8], tp[P][8];
+    load8_masked(p.gamma1, c0, p.C, g8);
+    load8_masked(p.beta1, c0, p.C, b8);
+#pragma unroll
+    for (int k = 0; k < P; ++k) load8_masked(p.taps, c0*P + 8*k, p.C*P, tp[k]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gm[j] = f32x2{g8[2*j], g8[2*j + 1]};
+      be[j] = f32x2{b8[2*j], b8[2*j + 1]};
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        w[k][j] = f32x2{tp[(2*j*P + k)/8][(2*j*P + k)%8], tp[((2*j + 1)*P + k)/8][((2*j + 1)*P + k)%8]};
+    }
+  }
+  f32x2 dgam[4], dbet[4], dtap[P][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dgam[j] = f32x2{0.f, 0.f}; dbet[j] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < P; ++k) dtap[k][j] = f32x2{0.f, 0.f};
+  }
+  const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(p.z1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+  const __amdgpu_buffer_rsrc_t re1 = make_rsrc(p.e1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+  float l1 = 0.f, l2 = 0.f;
+  // output row i -> frame: tooth q0 + i / R, residue r0 + i % R
+  auto out_frame = [&](int i, bool& ok) {
+    const int ro = r0 + i % R;
+    ok = i < KR && ro < d;
+    return (q0 + i / R)*d + ro;
+  };
+  for (int i0 = rslot; i0 < KR; i0 += 128) {
+   uint4 qz4[4];
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+     bool ok;
+     const int t = out_frame(i0 + 32*u, ok);
+     qz4[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);   // outside: zeros
+   }
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+    const int i = i0 + 32*u;
+    if (i >= KR) break;
+    bool ok;
+    const int t = out_frame(i, ok);
+    const uint4 qz = qz4[u];
+    const float live = (ok && t < T) ? 1.f : 0.f;
+    float zc[8];
+    unpack8(qz, zc);
+    f32x2 xh[4], hn[4], dh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j].x = __builtin_fmaf(xb, __builtin_fabsf(zc[2*j]), __builtin_fmaf(xa, zc[2*j], xc));
+      xh[j].y = __builtin_fmaf(xb, __builtin_fabsf(zc[2*j + 1]), __builtin_fmaf(xa, zc[2*j + 1], xc));
+      hn[j] = f32x2{live, live}*(gm[j]*xh[j] + be[j]);   // gLN_1 output at frame t (0 past the end)
+      dh[j] = f32x2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      // output frame that reads frame t through tap k: window tooth (i / R) + P - 1 - k, same residue
+      const int r = (i / R + P - 1 - k)*R + i % R;
+      float g[8];
+      unpack8(*reinterpret_cast<const uint4*>(win + r*BF_LDW + cl), g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 gk = {g[2*j], g[2*j + 1]};
+        dh[j] += w[k][j]*gk;
+        dtap[k][j] += gk*hn[j];
+      }
+    }
+    f32x2 o[4], a1s = {0.f, 0.f}, a2s = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 dl = f32x2{live, live}*dh[j];          // frames past the end contribute nothing
+      const f32x2 ev = gm[j]*dl;
+      o[j] = ev;
+      a1s += ev; a2s += ev*xh[j];
+      dgam[j] += dl*xh[j]; dbet[j] += dl;
+    }
+    l1 += a1s.x + a1s.y; l2 += a2s.x + a2s.y;
+    buf_store16(re1, live != 0.f ? (unsigned int)t*row + coff : kOob, pack8v(o));   // outside: dropped
+   }
+  }
+
+  reduce_cols(dgam, p.dgamma1, 1, 0);
+  reduce_cols(dbet, p.dbeta1, 1, 0);
+#pragma unroll
+  for (int k = 0; k < P; ++k) reduce_cols(dtap[k], p.dtaps, P, k);
+  const double tot1 = block_sum((double)l1, dscr);
+  const double tot2 = block_sum((double)l2, dscr + 8);
+  if (tid == 0) {
+    atomic_add_f64(p.sums1 + stat_sum(b), tot1);
+    atomic_add_f64(p.sums1 + stat_sq(b), tot2);
+  }
+}
+
+// sum_t <g_t, v1> and sum_t <g_t, u_t> over `ncols` columns of one item (the block without a producer
+// kernel for its g: the last one, whose g is g_skip alone). out = the item's {stat_sum, stat_sq} slots.
+struct GuDotsParams {
+  const bf16_t* g; int ldg; const bf16_t* u; int ldu; const float* v1; int ncols; int B, T;
+  double* out;
+};
+__global__ __launch_bounds__(256) void gu_dots_kernel(const GuDotsParams p) {
+  __shared__ double dscr[16];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int cpr = p.ncols/8;
+  const long long per_item = (long long)p.T*cpr;
+  double s1 = 0.0, s2 = 0.0;
+  for (long long i = (long long)blockIdx.x*256 + tid; i < per_item; i += (long long)gridDim.x*256) {
+    const int c = (int)(i % cpr)*8; const long long t = i / cpr;
+    float gv[8], uv[8];
+    unpack8(*reinterpret_cast<const uint4*>(p.g + ((long long)b*p.T + t)*p.ldg + c), gv);
+    unpack8(*reinterpret_cast<const uint4*>(p.u + ((long long)b*p.T + t)*p.ldu + c), uv);
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a = __builtin_fmaf(gv[j], p.v1[c + j], a); q = __builtin_fmaf(gv[j], uv[j], q); }
+    s1 += a; s2 += q;
+  }
+  const double r1 = block_sum(s1, dscr);
+  const double r2 = block_sum(s2, dscr + 8);
+  if (tid == 0) {
+    atomic_add_f64(p.out + stat_sum(b), r1);
+    atomic_add_f64(p.out + stat_sq(b), r2);
+  }
+}
+
+}  // namespace brv

@@ -21,6 +21,7 @@
 constexpr int kWgSplit = 4;          // item splits of the [res | skip] weight-gradient launch
 #include "prep.cuh"
 #include "tcn_kernels.cuh"
+#include "bwd_fused.cuh"
 #include "cln_kernels.cuh"
 
 using namespace brv;
@@ -43,6 +44,10 @@ inline long long align_up(long long x, long long a) { return (x + a - 1)/a*a; }
 inline bool fwd_fuse_requested() {
   const char* e = getenv("BRV_FWD_FUSE");
   return !(e && e[0] == '0') && !getenv("BRV_NO_WS");
+}
+inline bool bwd_fuse_requested() {
+  const char* e = getenv("BRV_BWD_FUSE");
+  return !(e && e[0] == '0');
 }
 
 // ---- optional per-launch event timing (bench / profiling only) ---------------
@@ -421,6 +426,25 @@ template <int P> struct DwBwd {
     ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 6.0*p.B*p.T*(double)p.Cp, st);
     dim3 grid(ceil_div(p.T, DW_TT_B)*p.B);
     hipLaunchKernelGGL((dwconv_bwd_kernel<P>), grid, dim3(256), 0, st, p);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+};
+
+// [res | skip] data gradient + gLN_2 / PReLU_2 backward + transposed depthwise stencil in one launch
+// (bwd_fused.cuh); `p.d` as for DwBwd with z2in set
+template <int P> struct DwBwdFused {
+  static int run(const BwdFusedParams& p0, hipStream_t st) {
+    BwdFusedParams p = p0;
+    const DwParams& d = p.d;
+    p.K = bf_tile_teeth(d.T, d.dil, P);
+    const int R = hl_rows_per_tooth(d.dil);
+    const int tiles = ceil_div(d.dil, R)*ceil_div((d.T - 1)/d.dil + 1, p.K);
+    // algorithmic bytes: g (256-wide) + z2 + z1 read, e1 written
+    ProfScope prof("dwpw2_bwd", 2.0*d.B*d.T*(double)d.Cp*(p.Kg + 2*P),
+                   2.0*d.B*d.T*((double)p.Kg + 3.0*d.Cp), st);
+    dim3 grid(tiles*d.B*(d.Cp/HL_CG));
+    hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P>), grid, dim3(256), BF_LDS, st, p);
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -1483,6 +1507,12 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   auto vslot = [&](int i) { return vg + 2LL*l.N + vper*i; };   // block i's vector grads
   float* vslope = vg + 2LL*l.N + vper*l.nb;    // PReLU slope grads: tcn, then (prelu1, prelu2) per block
 
+  auto ubuf = [&](int i) { return (bf16_t*)(base + ws.u + ws.u_stride*i); };
+  // Backward mirror of the fused forward (bwd_fused.cuh; BRV_BWD_FUSE=0: three launches per block):
+  // needs the u tensors the fused forward stored and the default widths
+  const bool bwd_fused = l.fused_fwd() && bwd_fuse_requested() && l.Bnp == 128 && l.Scp == 128 &&
+                         l.Hp % HL_CG == 0 && !getenv("BRV_NO_DZ_FUSE");
+
   GemmRowsParams g; WgradParams wg;
   if (head) {
   HIP_OK(hipMemsetAsync(sums, 0, ws.stats_bytes, st));
@@ -1508,6 +1538,19 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   g.e.src_slope = params + l.tcn_prelu; g.e.dslope = vslope;
   g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
   if (int r = launch_gemm_rows<A_BF16, E_PRELU_BWD>(g, B, st, "mask_bwd", 2.0*BT*l.S*l.Np + 6.0*BT*l.Scp)) return r;
+  if (bwd_fused) {
+    // fused backward: the layer-norm backward means of the LAST block from g_skip and its stored u
+    // (every other block gets them from the kernel that produces its g_out, E_ADD epilogue below)
+    GuDotsParams gu; memset(&gu, 0, sizeof(gu));
+    gu.g = gskip; gu.ldg = ldg; gu.u = ubuf(l.nb - 1) + l.Bnp; gu.ldu = ldg;
+    gu.v1 = reinterpret_cast<const float*>(prep + l.blk[l.nb - 1].p_lazy) + ldg + l.Bnp;
+    gu.ncols = l.Scp; gu.B = B; gu.T = (int)T; gu.out = sum(2 + 2*(l.nb - 1));
+    ProfScope prof("gu_dots", 0, 4.0*BT*l.Scp, st);
+    int gx = (int)((T*(l.Scp/8) + 255)/256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(gu_dots_kernel, dim3(gx, B), dim3(256), 0, st, gu);
+    HIP_OK(hipGetLastError());
+  }
   // output conv weight / bias gradients, one source at a time
   for (int s = 0; s < l.S; ++s) {
     memset(&wg, 0, sizeof(wg));
@@ -1552,6 +1595,8 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
     const bool has_res = i < l.nb - 1;
     const int dil = 1 << (i % cfg->layers);
     const int rs0 = has_res ? l.Bnp : 0;
+    const bool blk_fused = bwd_fused && (((l.P - 1)*dil)/2) % dil == 0;
+    if (!blk_fused) {
     // [res | skip] data gradient + gLN_2 backward partials
     memset(&g, 0, sizeof(g));
     g.a = rows_bf16(has_res ? gout : gskip, ldg, T);
@@ -1565,11 +1610,12 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
     g.e.rep_stride = ws.vg_stride; g.e.n_rep = kReplicas;
     g.e.sums_out = sum(2 + 2*i);
     if (int r = launch_gemm_rows<A_BF16, E_GLN_BWD>(g, B, st, "pw2_dgrad", 2.0*BT*(rs0 + l.Scp + 2*l.Hp))) return r;
+    }
     // gLN_2 + prelu_2 backward: fused into the depthwise backward below when its LDS window
     // (tile + halo rows) fits -- dz2 is then built once per element in LDS and never written
     // (dwconv_bwd_halo_kernel). BRV_NO_DZ_FUSE keeps the separate pass.
-    const bool fuse_dz2 = !getenv("BRV_NO_DZ_FUSE") && l.Hp % HL_CG == 0 &&
-                          (((l.P - 1)*dil)/2) % dil == 0 && hl_window_rows(dil, l.P) <= HL_MAXROWS;
+    const bool fuse_dz2 = blk_fused || (!getenv("BRV_NO_DZ_FUSE") && l.Hp % HL_CG == 0 &&
+                          (((l.P - 1)*dil)/2) % dil == 0 && hl_window_rows(dil, l.P) <= HL_MAXROWS);
     DzParams dz; memset(&dz, 0, sizeof(dz));
     if (!fuse_dz2) {
       dz.e = eA; dz.z = z2buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
@@ -1592,6 +1638,14 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
       d.z2in = z2buf(i); d.stats2 = stat(2 + 2*i); d.sums2 = sum(2 + 2*i);
       d.slope2 = params + b.prelu2; d.dslope2 = vslope + 2 + 2*i;
     }
+    if (blk_fused) {
+      BwdFusedParams bf; memset(&bf, 0, sizeof(bf));
+      bf.d = d; bf.d.dz2 = nullptr;
+      bf.g = has_res ? gout : gskip; bf.ldg = ldg; bf.Kg = rs0 + l.Scp;
+      bf.Wp = prep + b.p_rs_bp; bf.gamma2 = params + b.n2_g;
+      bf.dgamma2 = vslot(i) + 2*l.H; bf.dbeta2 = vslot(i) + 3*l.H;
+      if (int r = DwBwdFused<3>::run(bf, st)) return r;      // (fused_fwd() implies kernel_size 3)
+    } else
     if (int r = dispatch_p<DwBwd>(l.P, d, st)) return r;
     // gLN_1 + prelu_1 backward -> dz1: fused into the A staging of the data-gradient GEMM
     // below (A_DZ: dz1 is computed from e1 and z1 on load and written back over e1 for the
@@ -1613,6 +1667,11 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
     // block i-1's deferred [res | skip] weight gradient needs this g_out after gout is
     // overwritten again: keep a copy (16 MB per block at the BASELINE size)
     g.e.out2 = i > 0 ? gcopy(i - 1) : nullptr; g.e.ld_srcf = l.Bnp;
+    if (bwd_fused && i > 0) {        // block i - 1's layer-norm backward means, from its g and u
+      g.e.gu_u = ubuf(i - 1); g.e.ld_gu = ldg; g.e.gu_gskip = gskip; g.e.ld_gs = ldg;
+      g.e.gu_v1 = reinterpret_cast<const float*>(prep + l.blk[i - 1].p_lazy) + ldg;
+      g.e.gu_out = sum(2 + 2*(i - 1));
+    }
     if (fuse_dz1) {
       g.a.p1 = z1buf(i); g.a.ld1 = l.Hp; g.a.bs1 = T*l.Hp;
       g.a.slope = params + b.prelu1; g.a.stats = stat(1 + 2*i); g.a.sums = sum(1 + 2*i);

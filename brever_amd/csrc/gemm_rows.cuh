@@ -73,6 +73,10 @@ struct EpiSpec {
   const bf16_t* add_in; int ld_add;
   const bf16_t* m_in; bf16_t* out2;
   const float* src_f32; int ld_srcf; float* dslope;
+  // E_ADD, fused backward (bwd_fused.cuh): `out` is the g_out of the PREVIOUS block, whose layer-norm
+  // backward means are functions of g = [g_out | g_skip] and that block's stored u = (W gamma_2) p:
+  // gu_out[item] += {sum <g, v1>, sum <g, u>} over both halves (columns ncol and Np + ncol)
+  const bf16_t* gu_u; int ld_gu; const bf16_t* gu_gskip; int ld_gs; const float* gu_v1; double* gu_out;
 };
 
 struct GemmRowsParams {
@@ -378,6 +382,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
     msrc = ncol / e.Np_src; mf = ncol % e.Np_src;
     load8_masked(e.bias ? e.bias + msrc*e.N : nullptr, mf, e.N, biasv);
   }
+  float guv[(EM == E_ADD) ? 16 : 1];        // E_ADD + gu_out: v1 of this chunk's columns, both halves
+  if (EM == E_ADD && e.gu_out) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      guv[(EM == E_ADD) ? j : 0] = e.gu_v1[ncol + j];
+      guv[(EM == E_ADD) ? 8 + j : 0] = e.gu_v1[p.Np + ncol + j];
+    }
+  }
   NormStat es = {0.f, 1.f};
   float gam[8];
   if (EM == E_GLN_BWD) {
@@ -476,6 +488,22 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
       const uint4 qa = pack8(v);
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(e.out) + rowi*e.ldo + ncol) = qa;
       if (e.out2) *reinterpret_cast<uint4*>(e.out2 + rowi*e.ld_srcf + ncol) = qa;   // copy
+      if (e.gu_out) {
+        float gr[8], gs[8], ur[8], us[8];
+        unpack8(qa, gr);                        // the rounded values the consumer will read
+        unpack8(*reinterpret_cast<const uint4*>(e.gu_gskip + rowi*e.ld_gs + ncol), gs);
+        unpack8(*reinterpret_cast<const uint4*>(e.gu_u + rowi*e.ld_gu + ncol), ur);
+        unpack8(*reinterpret_cast<const uint4*>(e.gu_u + rowi*e.ld_gu + p.Np + ncol), us);
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          d1 = __builtin_fmaf(gr[j], guv[(EM == E_ADD) ? j : 0], d1);
+          d1 = __builtin_fmaf(gs[j], guv[(EM == E_ADD) ? 8 + j : 0], d1);
+          d2 = __builtin_fmaf(gr[j], ur[j], d2);
+          d2 = __builtin_fmaf(gs[j], us[j], d2);
+        }
+        st_sum += d1; st_sq += d2;
+      }
     } else if (EM == E_MASK_BWD) {
       // batch index of this GEMM is bs = b_item*S + s
       const long long wrow = (long long)(b / e.S)*T + t;
@@ -506,12 +534,12 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const GemmRowsParams p) 
   }
 
   // ---- block-level reductions ----------------------------------------------
-  if ((EM == E_STORE && e.stats_out) || EM == E_GLN_BWD) {
+  if ((EM == E_STORE && e.stats_out) || EM == E_GLN_BWD || (EM == E_ADD && e.gu_out)) {
     __syncthreads();
     double* dscr = reinterpret_cast<double*>(smem);
     const double s0 = block_sum(st_sum, dscr);
     const double s1 = block_sum(st_sq, dscr + 8);
-    double* dst = (EM == E_STORE) ? e.stats_out : e.sums_out;
+    double* dst = (EM == E_STORE) ? e.stats_out : (EM == E_ADD ? e.gu_out : e.sums_out);
     if (tid == 0) { atomic_add_f64(dst + stat_sum(b), s0); atomic_add_f64(dst + stat_sq(b), s1); }
   }
   if (AK == A_DZ) {                          // slope gradient of the fused gLN/PReLU backward
