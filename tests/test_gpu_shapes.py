@@ -323,3 +323,38 @@ def test_sgmse_default_denoiser_full_spectrogram():
     err = rel(torch.view_as_real(got16), torch.view_as_real(want))
     print('default SGMSE+ denoiser 256 x 501 use_amp rel', err)
     assert err <= 5e-3, err
+
+
+@pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 2, 3, 5000), (4, 2, 1, 700), (8, 1, 5, 2100),
+                                                (3, 3, 4, 20000)])
+def test_fused_backward_equals_three_launch_backward(monkeypatch, layers, repeats, B, L):
+    """The backward mirror of the fused forward (csrc/bwd_fused.cuh: [res | skip] data gradient + gLN_2 /
+    PReLU_2 backward + transposed depthwise stencil in one launch, layer-norm means from <g, u>) against
+    the three-launch sequence (BRV_BWD_FUSE=0) from the same forward: every gradient, elementwise. Items
+    shorter than the dilation / than a tile, one item, ragged lengths, the block without residual conv."""
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    cfg = dict(layers=layers, repeats=repeats)
+    gen = torch.Generator().manual_seed(7*layers + B)
+    torch.manual_seed(23)
+    ref = ConvTasNet(**cfg)
+    _detrivialise(ref, gen)
+    batch, lengths = _ragged_batch(gen, B, L)
+    grads = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('BRV_BWD_FUSE', mode)
+        net = ConvTasNet(**cfg)
+        net.load_state_dict(ref.state_dict())
+        net = net.to(_cuda())
+        net._amp = True
+        out = net(batch[:, 0].cuda())
+        loss = snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean()
+        loss.backward()
+        grads[mode] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+        assert torch.isfinite(grads[mode]).all()
+        if mode == '1':
+            e = rel(grads['1'], grads['0'])
+            print(f'layers {layers} x {repeats}, B {B}, L {L}: fused vs three-launch backward rel {e:.3e}')
+            assert e <= 1.5e-2, e
+            worst = _per_tensor(net, grads['1'], grads['0'], 5e-2, min_numel=128, min_norm=1e-5)
+            print('   worst tensor', worst)
