@@ -15,10 +15,13 @@ _os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 # points (bench.py, scripts/) do; otherwise export it.
 import sys as _sys
 
-_q = _os.environ.get('GPU_MAX_HW_QUEUES')
-# False: torch (and with it the HIP runtime) was loaded before this default could be seen; the
-# two-chain step then stays off next to an initialised process group (models/convtasnet.py)
-HW_QUEUES_OK = (_q is not None and _q.isdigit() and int(_q) >= 8) or 'torch' not in _sys.modules
+_exported = _os.environ.get('GPU_MAX_HW_QUEUES')
 _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+_eff = _os.environ['GPU_MAX_HW_QUEUES']
+# True when the runtime does (or will) see >= 8 hardware queues: the effective value must be >= 8, and it
+# only takes effect if it was exported by the user or torch (and with it the HIP runtime) has not been
+# loaded yet. Otherwise the two-chain step stays off next to an initialised process group
+# (models/convtasnet.py): an exported GPU_MAX_HW_QUEUES=4 used to slip through as "ok".
+HW_QUEUES_OK = _eff.isdigit() and int(_eff) >= 8 and (_exported is not None or 'torch' not in _sys.modules)
 
 __version__ = '0.1.0'

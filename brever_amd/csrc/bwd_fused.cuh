@@ -17,10 +17,10 @@
 //
 // Structure = dwconv_bwd_halo_kernel (comb tiles, tcn_kernels.cuh) with a phase 0 in front:
 //   phase 0: e of the window (tile + halo teeth, <= 256 rows x 64 channels) on the matrix pipe:
-//            A = W^T fragments (64 channels x 64 k per chunk, fragment order, staged through a
-//            double-buffered 8 KB LDS ring), B = g rows straight from global memory / L2 (every
-//            wave owns 64 window rows: a g row is fetched by exactly one wave), result -> LDS
-//            window (bf16, 144-byte rows);
+//            every wave multiplies its own 64 rows with no workgroup barrier: A = W^T fragments
+//            (fragment order, straight from L1 / L2 to registers), B = the rows' g, chunk by chunk
+//            through the wave's part of the window buffer (whole-line loads), result -> the same
+//            LDS window (bf16, 144-byte rows);
 //   phase 1: dz2 of the window in place in LDS (+ d gamma_2, d beta_2, PReLU_2 slope, bias grads);
 //   phase 2: transposed stencil out of LDS, gLN_1 partial sums, tap / gamma_1 / beta_1 gradients.
 // Reference: autograd of brever/models/convtasnet/convtasnet.py:240-260 (Conv1DBlock.forward).
@@ -28,6 +28,10 @@
 #include "tcn_kernels.cuh"
 
 namespace brv {
+
+#ifndef BF_ABL
+#define BF_ABL 0     // ablation bits (diagnostic builds, results wrong): 1 no MFMAs, 2 no g / W loads, 4 no phase 0,
+#endif               // 8 no phase 1 arithmetic on e (LDS read kept), 16 no per-channel reductions
 
 struct BwdFusedParams {
   DwParams d;              // as dwconv_bwd_halo_kernel; d.dz2 unused, d.sums2 = {sum <g, v1>, sum <g, u>}
@@ -41,8 +45,7 @@ struct BwdFusedParams {
 
 constexpr int BF_ROWS = 256;               // window rows (teeth x rows per tooth), 8 MFMA groups of 32
 constexpr int BF_LDW = HL_CG + 8;          // halves per window row: 144 B
-constexpr int BF_WCHUNK = 2*4*64*8;        // halves of one W chunk: 2 slices x 4 k-steps x 64 lanes x 8
-constexpr int BF_LDS = BF_ROWS*BF_LDW*2 + 2*BF_WCHUNK*2;
+constexpr int BF_LDS = BF_ROWS*BF_LDW*2 + 32*HL_CG*4;   // window + the reduction scratch
 
 // centre teeth per tile: as many as the window holds, balanced over the tooth groups
 inline int bf_tile_teeth(int T, int dil, int P) {
@@ -53,13 +56,15 @@ inline int bf_tile_teeth(int T, int dil, int P) {
   return ceil_div(n_teeth, n_qt);
 }
 
-template <int P>
+// KG: reduction length of phase 0 (compile time: the chunk loop is straight-line code, so every wait of
+// its load pipeline is a counted vmcnt -- as a run-time loop hipcc drained ALL loads, the just-issued
+// prefetch included, in front of the first MFMA of every chunk)
+template <int P, int KG>
 __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFusedParams fp) {
   const DwParams& p = fp.d;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   bf16_t* win = reinterpret_cast<bf16_t*>(dyn_lds);
-  bf16_t* wbuf = reinterpret_cast<bf16_t*>(dyn_lds + BF_ROWS*BF_LDW*2);
-  float* red = reinterpret_cast<float*>(wbuf);           // after phase 0 (32*HL_CG floats = 8 KB)
+  float* red = reinterpret_cast<float*>(dyn_lds + BF_ROWS*BF_LDW*2);   // 32*HL_CG floats
   __shared__ double dscr[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = p.T, d = p.dil;
@@ -88,37 +93,57 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   };
 
   // ---- phase 0: e = W^T g of the window -> LDS ---------------------------------------------------
+  // Every wave works alone on its own 64 window rows (no workgroup barrier before the end of the
+  // phase): the reduction runs in chunks of 64 g columns; a chunk of the wave's rows is fetched by
+  // whole-line loads (8 rows x 128 B per instruction, the next chunk's while this one multiplies),
+  // parked in the wave's part of the (not yet used) window buffer and read back as B fragments; the
+  // A fragments (W^T in fragment order: 1 KB per wave-load, L1 / L2 hits -- every workgroup of the
+  // channel group reads the same 32 KB) go straight to registers, refilled one chunk ahead.
+  // Measured steps (us per launch, BASELINE size): B fragments straight from global memory (32 rows
+  // x 32 B per instruction, every line four times through the L1) 119; g and W chunks through LDS
+  // with two workgroup barriers per chunk 108.
   {
     const int n32 = lane & 31, h = lane >> 5;
+    const int oct = lane & 7, rsub = lane >> 3;
+    const int widu = __builtin_amdgcn_readfirstlane(wid);          // scalar: plain branches, not exec masks
     const int ngrp = (W + 31) >> 5;
-    const bool act0 = 2*wid < ngrp, act1 = 2*wid + 1 < ngrp;     // wave-uniform
+    const bool act0 = 2*widu < ngrp, act1 = 2*widu + 1 < ngrp;
     const __amdgpu_buffer_rsrc_t rg =
-        make_rsrc(fp.g + (long long)b*T*fp.ldg, ((long long)(T - 1)*fp.ldg + fp.Kg)*2);
-    unsigned int offB[2]; bool vB[2];
+        make_rsrc(fp.g + (long long)b*T*fp.ldg, ((long long)(T - 1)*fp.ldg + KG)*2);
+    unsigned int offG[8];                                  // rows 64 wid + 8 i + rsub of the window (kOob: none)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int i = 0; i < 8; ++i) {
       bool ok;
-      const int tf = frame_of(64*wid + 32*q + n32, ok);
-      vB[q] = ok && tf < T;
-      offB[q] = (unsigned int)tf*(unsigned int)(fp.ldg*2) + (unsigned int)(h*16);
+      const int tf = frame_of(64*widu + 8*i + rsub, ok);
+      offG[i] = (ok && tf < T) ? (unsigned int)tf*(unsigned int)(fp.ldg*2) + (unsigned int)(oct*16) : kOob;
     }
-    const int nkc = fp.Kg >> 6;                            // chunks of 64 k (even: Kg % 128 == 0)
-    const bf16_t* wsrc = fp.Wp + (long long)(cg*2)*32*fp.Kg + tid*8;
-    const bf16_t* wsrc1 = wsrc + (long long)32*fp.Kg;
-    uint4 wst0, wst1;                                      // (scalars: an array captured by the lambdas went to scratch)
-    auto wload = [&](int kc) {
-      wst0 = *reinterpret_cast<const uint4*>(wsrc + kc*2048);
-      wst1 = *reinterpret_cast<const uint4*>(wsrc1 + kc*2048);
+    constexpr int nkc = KG >> 6;                           // chunks of 64 k
+    const bf16_t* wsrc0 = fp.Wp + (long long)(cg*2)*32*KG + lane*8;
+    const bf16_t* wsrc1 = wsrc0 + (long long)32*KG;
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    uint4 gq0 = z4, gq1 = z4, gq2 = z4, gq3 = z4, gq4 = z4, gq5 = z4, gq6 = z4, gq7 = z4;
+    auto gl = [&](int i, int kc) {
+      return buf_load16(rg, offG[i] == kOob ? kOob : offG[i] + (unsigned int)(kc*128));
     };
-    auto wstore = [&](int buf) {
-      *reinterpret_cast<uint4*>(wbuf + (buf*2 + 0)*2048 + tid*8) = wst0;
-      *reinterpret_cast<uint4*>(wbuf + (buf*2 + 1)*2048 + tid*8) = wst1;
+    auto gload = [&](int kc) {
+      gq0 = gl(0, kc); gq1 = gl(1, kc); gq2 = gl(2, kc); gq3 = gl(3, kc);
+      gq4 = gl(4, kc); gq5 = gl(5, kc); gq6 = gl(6, kc); gq7 = gl(7, kc);
     };
-    uint4 bq[2][4];                                        // B fragments of the chunk in flight
-    auto bload1 = [&](int kc, int s) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        bq[q][s] = buf_load16(rg, vB[q] ? offB[q] + (unsigned int)((kc*64 + s*16)*2) : kOob);
+    bf16_t* gp = win + (64*widu + rsub)*BF_LDW + oct*8;
+    auto gstore = [&]() {
+      *reinterpret_cast<uint4*>(gp) = gq0;
+      *reinterpret_cast<uint4*>(gp + 8*BF_LDW) = gq1;
+      *reinterpret_cast<uint4*>(gp + 16*BF_LDW) = gq2;
+      *reinterpret_cast<uint4*>(gp + 24*BF_LDW) = gq3;
+      *reinterpret_cast<uint4*>(gp + 32*BF_LDW) = gq4;
+      *reinterpret_cast<uint4*>(gp + 40*BF_LDW) = gq5;
+      *reinterpret_cast<uint4*>(gp + 48*BF_LDW) = gq6;
+      *reinterpret_cast<uint4*>(gp + 56*BF_LDW) = gq7;
+    };
+    // A fragments of k-step s of chunk kc (two 32-channel slices)
+    bf16x8 a0_0, a0_1, a0_2, a0_3, a1_0, a1_1, a1_2, a1_3;
+    auto al = [&](const bf16_t* w, int kc, int s) {
+      return *reinterpret_cast<const bf16x8*>(w + kc*2048 + s*512);
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -127,47 +152,46 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
       for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][ms][i] = 0.f;
-    // k-step s of chunk kc; its B registers are refilled with the next chunk's step right away
-    auto mfma_chunk = [&](int kc, int buf) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(wbuf + (buf*2 + 0)*2048 + (s*64 + lane)*8);
-        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wbuf + (buf*2 + 1)*2048 + (s*64 + lane)*8);
-        if (act0) {
-          const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[0][s]);
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[0][1], 0, 0, 0);
-        }
-        if (act1) {
-          const bf16x8 bv = __builtin_bit_cast(bf16x8, bq[1][s]);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[1][1], 0, 0, 0);
-        }
-        if (kc + 1 < nkc) bload1(kc + 1, s);
+    const bf16_t* brow = win + (64*widu + n32)*BF_LDW + h*8;
+    auto step = [&](int s, const bf16x8& a0, const bf16x8& a1) {
+      if (BF_ABL & 1) return;
+      if (act0) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + s*16);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[0][1], 0, 0, 0);
+      }
+      if (act1) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(brow + 32*BF_LDW + s*16);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bv, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bv, acc[1][1], 0, 0, 0);
       }
     };
-    wload(0);
+    if (act0 && !(BF_ABL & 4)) {
+      if (!(BF_ABL & 2)) {
+        gload(0);
+        a0_0 = al(wsrc0, 0, 0); a1_0 = al(wsrc1, 0, 0); a0_1 = al(wsrc0, 0, 1); a1_1 = al(wsrc1, 0, 1);
+        a0_2 = al(wsrc0, 0, 2); a1_2 = al(wsrc1, 0, 2); a0_3 = al(wsrc0, 0, 3); a1_3 = al(wsrc1, 0, 3);
+      }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) bload1(0, s);
-    wstore(0);
-    __syncthreads();
-#pragma unroll 1
-    for (int kc = 0; kc < nkc; kc += 2) {                 // two chunks per trip: static buffer parities
-      wload(kc + 1);
-      mfma_chunk(kc, 0);
-      wstore(1);
-      __syncthreads();
-      const bool more = kc + 2 < nkc;
-      if (more) wload(kc + 2);
-      mfma_chunk(kc + 1, 1);
-      if (more) wstore(0);
-      __syncthreads();
+      for (int kc = 0; kc < nkc; ++kc) {
+        gstore();                          // own rows: ordered behind this wave's reads of the last chunk
+        const bool more = kc + 1 < nkc && !(BF_ABL & 2);
+        if (more) gload(kc + 1);
+        step(0, a0_0, a1_0);
+        if (more) { a0_0 = al(wsrc0, kc + 1, 0); a1_0 = al(wsrc1, kc + 1, 0); }
+        step(1, a0_1, a1_1);
+        if (more) { a0_1 = al(wsrc0, kc + 1, 1); a1_1 = al(wsrc1, kc + 1, 1); }
+        step(2, a0_2, a1_2);
+        if (more) { a0_2 = al(wsrc0, kc + 1, 2); a1_2 = al(wsrc1, kc + 1, 2); }
+        step(3, a0_3, a1_3);
+        if (more) { a0_3 = al(wsrc0, kc + 1, 3); a1_3 = al(wsrc1, kc + 1, 3); }
+      }
     }
     // D[channel][frame]: lane = frame n32, registers = channels 8 (i >> 2) + 4 h + (i & 3)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (!(q == 0 ? act0 : act1)) continue;
-      const int wr = 64*wid + 32*q + n32;
+      const int wr = 64*widu + 32*q + n32;
 #pragma unroll
       for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
@@ -253,7 +277,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
     }
   }
   // ---- per-channel reductions (32 row slots share each channel chunk); the phase-1 vectors are folded
-  // right away so that their registers are free during phase 2 (`red` = the W ring of phase 0)
+  // right away so that their registers are free during phase 2
   auto reduce_cols = [&](const f32x2 (&v)[4], float* dst, int stride, int offset) {
     __syncthreads();
 #pragma unroll
@@ -270,9 +294,11 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
       if (c < p.C) atomic_add_f32(rdst + (long long)c*stride + offset, sum);
     }
   };
+  if (!(BF_ABL & 16)) {
   reduce_cols(dbia, p.dbias, 1, 0);
   reduce_cols(dgam2, fp.dgamma2, 1, 0);
   reduce_cols(dbet2, fp.dbeta2, 1, 0);
+  }
   {
     __syncthreads();
     const float sa = block_sum(da2, red);
@@ -369,10 +395,12 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
    }
   }
 
+  if (!(BF_ABL & 16)) {
   reduce_cols(dgam, p.dgamma1, 1, 0);
   reduce_cols(dbet, p.dbeta1, 1, 0);
 #pragma unroll
   for (int k = 0; k < P; ++k) reduce_cols(dtap[k], p.dtaps, P, k);
+  }
   const double tot1 = block_sum((double)l1, dscr);
   const double tot2 = block_sum((double)l2, dscr + 8);
   if (tid == 0) {

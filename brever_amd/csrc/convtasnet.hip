@@ -56,6 +56,7 @@ inline bool bwd_fuse_requested() {
 // aggregates them per label together with the algorithmic FLOPs / bytes.
 struct ProfEntry { const char* label; hipEvent_t a, b; double flops, bytes; };
 bool g_prof_on = false;
+bool g_prof_by_dil = false;          // brv_prof_enable(2): the depthwise backward labelled per dilation
 std::vector<ProfEntry> g_prof;
 struct ProfScope {
   hipStream_t st; bool on;
@@ -414,7 +415,10 @@ template <int P> struct DwFwd {
 template <int P> struct DwBwd {
   static int run(const DwParams& p, hipStream_t st) {
     if (p.z2in != nullptr) {      // gLN_2 backward fused: dz2 built once per element in LDS
-      ProfScope prof("dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 8.0*p.B*p.T*(double)p.Cp, st);
+      static const char* by_dil[9] = {"dwconv_bwd_d1", "dwconv_bwd_d2", "dwconv_bwd_d4", "dwconv_bwd_d8", "dwconv_bwd_d16",
+                                      "dwconv_bwd_d32", "dwconv_bwd_d64", "dwconv_bwd_d128", "dwconv_bwd_dx"};
+      int lg = 0; while ((1 << lg) < p.dil && lg < 8) ++lg;
+      ProfScope prof(g_prof_by_dil ? by_dil[lg] : "dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 8.0*p.B*p.T*(double)p.Cp, st);
       const int R = hl_rows_per_tooth(p.dil), K = HL_TT/R;
       const int tiles = ceil_div(p.dil, R)*ceil_div((p.T - 1)/p.dil + 1, K);
       dim3 grid(tiles*p.B*(p.Cp/HL_CG));
@@ -441,10 +445,15 @@ template <int P> struct DwBwdFused {
     const int R = hl_rows_per_tooth(d.dil);
     const int tiles = ceil_div(d.dil, R)*ceil_div((d.T - 1)/d.dil + 1, p.K);
     // algorithmic bytes: g (256-wide) + z2 + z1 read, e1 written
-    ProfScope prof("dwpw2_bwd", 2.0*d.B*d.T*(double)d.Cp*(p.Kg + 2*P),
+    static const char* by_dil[9] = {"dwpw2_bwd_d1", "dwpw2_bwd_d2", "dwpw2_bwd_d4", "dwpw2_bwd_d8", "dwpw2_bwd_d16",
+                                    "dwpw2_bwd_d32", "dwpw2_bwd_d64", "dwpw2_bwd_d128", "dwpw2_bwd_dx"};
+    int lg = 0; while ((1 << lg) < d.dil && lg < 8) ++lg;
+    ProfScope prof(g_prof_by_dil ? by_dil[lg] : "dwpw2_bwd", 2.0*d.B*d.T*(double)d.Cp*(p.Kg + 2*P),
                    2.0*d.B*d.T*((double)p.Kg + 3.0*d.Cp), st);
     dim3 grid(tiles*d.B*(d.Cp/HL_CG));
-    hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P>), grid, dim3(256), BF_LDS, st, p);
+    if (p.Kg == 256) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P, 256>), grid, dim3(256), BF_LDS, st, p);
+    else if (p.Kg == 128) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P, 128>), grid, dim3(256), BF_LDS, st, p);
+    else return fail(-1, "fused backward: unexpected [res | skip] width");
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -953,6 +962,7 @@ int brv_prof_enable(int on) {
   for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   g_prof.clear();
   g_prof_on = on != 0;
+  g_prof_by_dil = on == 2;
   return 0;
 }
 

@@ -296,8 +296,18 @@ def audio_read(f, name):
         out = np.empty((capacity, channels), dtype=np.float32)
         got = hip.lib().brv_flac_decode(data, len(data),
                                         out.ctypes.data_as(ctypes.c_void_p), capacity)
+        if got > capacity:
+            # the decoder counts the frames of the whole stream and stores only what fits: streams
+            # without a length in the header whose frames compress below a byte each (silence:
+            # CONSTANT subframes) need a second pass with the exact size (they used to be truncated)
+            capacity = int(got)
+            out = np.empty((capacity, channels), dtype=np.float32)
+            got = hip.lib().brv_flac_decode(data, len(data),
+                                            out.ctypes.data_as(ctypes.c_void_p), capacity)
         if got < 0:
             raise ValueError(f'{name}: FLAC decoding failed (status {got})')
+        if got > capacity:
+            raise ValueError(f'{name}: FLAC stream longer than its decoded size ({got} > {capacity})')
         out = out[:got]
         return (out if channels > 1 else out[:, 0]), rate
     rate, channels, frames, code, bits, _ = _wav_header(f)

@@ -188,9 +188,7 @@ class ConvTasNet(BreverBaseModel):
         self._ws_version = {True: 0, False: 0}
         self._grad_sync = None
         self._amp = False
-        self._ag_grad = None
         self._step_bufs = None
-        self._two = None
         self._two = None
         self._flatten()
 
@@ -219,8 +217,8 @@ class ConvTasNet(BreverBaseModel):
         self._prepared_dirty = True
         self._workspace = {}
         self._ws_key = {}
-        self._ag_grad = None
         self._step_bufs = None
+        self._two = None
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -348,19 +346,12 @@ class ConvTasNet(BreverBaseModel):
         return self._workspace[amp]
 
     def _autograd_buffer(self):
-        """Zeroed flat buffer for the gradients autograd hands back. Reused across
-        steps while no ``p.grad`` still refers to it (``zero_grad(set_to_none=True)``,
-        the default, or the flat-gradient binding of ``train_step``)."""
-        buf = self._ag_grad
-        if buf is not None and buf.device == self._flat.device \
-                and buf.numel() == self._flat.numel():
-            lo = buf.data_ptr()
-            hi = lo + 4*buf.numel()
-            if all(p.grad is None or not lo <= p.grad.data_ptr() < hi
-                   for p, _ in self._offsets):
-                return buf.zero_()
-        self._ag_grad = torch.zeros_like(self._flat)
-        return self._ag_grad
+        """Fresh zeroed flat buffer for the gradients autograd hands back. Never reused: the tensors
+        returned by ``backward`` are views of it, and a caller of ``torch.autograd.grad`` (or of a
+        second backward with ``retain_graph``) may keep them across the next backward -- a recycled
+        buffer silently overwrote them. The caching allocator recycles the memory once
+        nothing refers to it; the hot path (``train_step``) does not come through here."""
+        return torch.zeros_like(self._flat)
 
     def _hip_forward(self, wave, amp=True):
         hip.require_device(wave, self._flat)
@@ -569,22 +560,7 @@ class ConvTasNet(BreverBaseModel):
             labels = labels.float().contiguous()
             lengths = lengths.to(torch.int64).contiguous()
             self._prepare()
-            key = (B, S, L, dev)
-            if self._two is None or self._two[0] != key:
-                nws = lib.brv_ctn_workspace_bytes(self._cfg_ptr(), Bh, L)
-                if nws < 0:
-                    hip.check(int(nws), 'brv_ctn_workspace_bytes')
-                nscr = lib.brv_loss_scratch_bytes(Bh, S)
-                self._two = (key, dict(
-                    side=torch.cuda.Stream(device=dev),
-                    ws=[torch.empty(nws, dtype=torch.uint8, device=dev) for _ in range(2)],
-                    out=torch.empty(B, S, L, dtype=torch.float32, device=dev),
-                    d_out=torch.empty(B, S, L, dtype=torch.float32, device=dev),
-                    scratch=[torch.empty(nscr, dtype=torch.uint8, device=dev) for _ in range(2)],
-                    loss=torch.empty(B, dtype=torch.float32, device=dev),
-                    gscale=torch.full((B,), 1.0/B, dtype=torch.float32, device=dev),
-                    grad2=torch.empty_like(self._flat)))
-            t = self._two[1]
+            t = self._two_chain_buffers(B, S, L, dev)
             grads = self.flat_grads()
             grads.zero_()
             main, side = torch.cuda.current_stream(dev), t['side']
@@ -638,6 +614,60 @@ class ConvTasNet(BreverBaseModel):
                 grad_scale = sync.finish() if nparts > 1 else sync(grads)
             self.optimizer.step(max_norm=self.grad_clip, grad_scale=grad_scale)
             return t['loss'].mean()
+
+    def _two_chain_buffers(self, B, S, L, dev):
+        """Buffers of the two-chain step. GROW-ONLY (the trainer's dynamic batches change (B, L) almost
+        every step): the two half-batch activation workspaces are slices of the model's one bf16
+        workspace -- the buffer validation / ``enhance`` / odd batches use as a whole -- and the
+        output / loss buffers are views of flat allocations that are replaced only by larger ones (the
+        old reference is dropped first: no 2x peak). The side stream is created once."""
+        lib = hip.lib()
+        Bh = B//2
+        nws = lib.brv_ctn_workspace_bytes(self._cfg_ptr(), Bh, L)
+        if nws < 0:
+            hip.check(int(nws), 'brv_ctn_workspace_bytes')
+        nws = (int(nws) + 255)//256*256
+        nscr = (int(lib.brv_loss_scratch_bytes(Bh, S)) + 255)//256*256
+        t = self._two
+        if t is None or t['dev'] != dev:
+            t = self._two = dict(dev=dev, side=torch.cuda.Stream(device=dev), cap_out=0, cap_scr=0, cap_b=0,
+                                 out_flat=None, d_out_flat=None, scr_flat=None, loss_flat=None,
+                                 gscale_flat=None, grad2=torch.empty_like(self._flat))
+        # both halves inside the shared workspace (invalidates a saved autograd forward, like any forward)
+        ws = self._workspace.get(True)
+        if ws is None or ws.numel() < 2*nws or ws.device != dev:
+            self._workspace[True] = None
+            ws = None
+            self._workspace[True] = ws = torch.empty(2*nws, dtype=torch.uint8, device=dev)
+        self._ws_key[True] = None
+        self._ws_version[True] += 1
+        t['ws'] = [ws[:nws], ws[nws:2*nws]]
+        n_out = B*S*L
+        if t['cap_out'] < n_out:
+            t['out_flat'] = t['d_out_flat'] = None
+            t['out_flat'] = torch.empty(n_out, dtype=torch.float32, device=dev)
+            t['d_out_flat'] = torch.empty(n_out, dtype=torch.float32, device=dev)
+            t['cap_out'] = n_out
+        if t['cap_scr'] < 2*nscr:
+            t['scr_flat'] = None
+            t['scr_flat'] = torch.empty(2*nscr, dtype=torch.uint8, device=dev)
+            t['cap_scr'] = 2*nscr
+        if t['cap_b'] < B:
+            t['loss_flat'] = torch.empty(B, dtype=torch.float32, device=dev)
+            t['gscale_flat'] = torch.empty(B, dtype=torch.float32, device=dev)
+            t['cap_b'] = B
+            t['gscale_B'] = None
+        if t.get('gscale_B') != B:
+            t['gscale_flat'][:B].fill_(1.0/B)
+            t['gscale_B'] = B
+        t['out'] = t['out_flat'][:n_out].view(B, S, L)
+        t['d_out'] = t['d_out_flat'][:n_out].view(B, S, L)
+        t['scratch'] = [t['scr_flat'][:nscr], t['scr_flat'][nscr:2*nscr]]
+        t['loss'] = t['loss_flat'][:B]
+        t['gscale'] = t['gscale_flat'][:B]
+        if t['grad2'].device != dev or t['grad2'].numel() != self._flat.numel():
+            t['grad2'] = torch.empty_like(self._flat)
+        return t
 
     def _step_buffers(self, B, S, L, device):
         """Loss scratch, per-item losses, gradient scales and d_out of the fused

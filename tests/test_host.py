@@ -439,6 +439,26 @@ def test_flac_decoder_round_trips(kw):
     assert len(data) < pcm.size*bps//8 or kw['kind'] == 'verbatim'    # it does compress
 
 
+def test_flac_unknown_length_silence_is_not_truncated():
+    """ADVICE r02: a stream without a length in STREAMINFO gets a capacity guess of 8 frames per byte;
+    silence (CONSTANT subframes) compresses far below that and used to be cut silently. The decoder's
+    frame count now triggers a second pass with the exact size."""
+    import io
+    from brever_amd.data import audio_info, audio_read
+    from helpers import flac_encode
+    n = 300000
+    pcm = np.zeros((n, 1), dtype=np.int64)
+    pcm[-5:] = 7                                           # the tail must survive
+    data = bytearray(flac_encode(pcm, blocksize=4096, kind='fixed', order=0))
+    assert n > 8*len(data)                                 # more than 8 frames per byte
+    data[21] &= 0xf0                                       # total samples (36 bits) := 0 = unknown
+    data[22:26] = bytes(4)
+    x, rate = audio_read(io.BytesIO(bytes(data)), 's.flac')
+    assert len(x) == n and rate == 16000
+    assert np.array_equal(np.round(np.asarray(x[-5:], dtype=np.float64)*32768), np.full(5, 7.0))
+    assert audio_info(io.BytesIO(bytes(data)), 's.flac')[0] == n
+
+
 def test_dataset_reads_flac_members(tmp_path):
     """BreverDataset on the reference layout with FLAC members in audio.tar (data.py:259-268)."""
     import tarfile
