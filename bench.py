@@ -159,25 +159,25 @@ def kernel_roofline(model, batches, scaler, steps=3):
     # chain's workgroups; a kernel's own duration and bytes per launch are those of the whole batch
     chains = os.environ.get('BRV_CTN_STREAMS')
     os.environ['BRV_CTN_STREAMS'] = '1'
-    lib.brv_prof_enable(1)
+    hip.prof_enable(1)
     for i in range(steps):
         batch, lengths = batches[i % len(batches)]
         model.train_step(batch, lengths, True, scaler)
     torch.cuda.synchronize()
     prof = hip.profile_collect()
-    lib.brv_prof_enable(0)
+    hip.prof_enable(0)
     if chains is None:
         del os.environ['BRV_CTN_STREAMS']
     else:
         os.environ['BRV_CTN_STREAMS'] = chains
     # the same kernel as launched inside the timed region (default mode), for the record
-    lib.brv_prof_enable(1)
+    hip.prof_enable(1)
     for i in range(steps):
         batch, lengths = batches[i % len(batches)]
         model.train_step(batch, lengths, True, scaler)
     torch.cuda.synchronize()
     prof_timed = hip.profile_collect()
-    lib.brv_prof_enable(0)
+    hip.prof_enable(0)
     if not prof:
         return None, {}
     label, top = max(prof.items(), key=lambda kv: kv[1]['ms'])

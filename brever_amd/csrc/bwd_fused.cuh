@@ -31,7 +31,7 @@ namespace brv {
 
 #ifndef BF_ABL
 #define BF_ABL 0     // ablation bits (diagnostic builds, results wrong): 1 no MFMAs, 2 no g / W loads, 4 no phase 0,
-#endif               // 8 no phase 1 arithmetic on e (LDS read kept), 16 no per-channel reductions
+#endif               // 16 no per-channel reductions (accumulators die too), 32 no atomics, 64 no folds but live accumulators
 
 struct BwdFusedParams {
   DwParams d;              // as dwconv_bwd_halo_kernel; d.dz2 unused, d.sums2 = {sum <g, v1>, sum <g, u>}
@@ -65,7 +65,6 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   bf16_t* win = reinterpret_cast<bf16_t*>(dyn_lds);
   float* red = reinterpret_cast<float*>(dyn_lds + BF_ROWS*BF_LDW*2);   // 32*HL_CG floats
-  __shared__ double dscr[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = p.T, d = p.dil;
   const int R = hl_rows_per_tooth(d), K = fp.K;
@@ -73,8 +72,15 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   const int n_teeth = (T - 1)/d + 1;
   const int n_qt = ceil_div(n_teeth, K);                 // tooth groups
   const int n_tt = n_rt*n_qt, n_cg = p.Cp/HL_CG;
-  int id = blockIdx.x;
-  const int cg = id % n_cg; id /= n_cg;
+  // Workgroup -> (tile, channel group): the channel groups of one tile all multiply the SAME g rows,
+  // so they must share an L2: ids congruent mod 8 run on one XCD, hence XCD x takes tile 8 j + x of
+  // every run of 8 tiles and the tile's channel groups sit in consecutive slots of that XCD. (With the
+  // channel group fastest in the id every XCD fetched every g row: 8 x 32.8 MB per launch, the kernel
+  // ran at 108 us whatever phase 0 looked like.) The grid is padded to whole runs of 8 tiles.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cg = slot % n_cg;
+  const int id = (slot / n_cg)*8 + xcd;
+  if (id >= n_tt*p.B) return;                          // (whole workgroup: no barrier is skipped by part of it)
   const int b = id / n_tt;
   const int tile = id % n_tt;
   const int r0 = (tile % n_rt)*R, q0 = (tile / n_rt)*K;
@@ -276,35 +282,76 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
       }
     }
   }
-  // ---- per-channel reductions (32 row slots share each channel chunk); the phase-1 vectors are folded
-  // right away so that their registers are free during phase 2
-  auto reduce_cols = [&](const f32x2 (&v)[4], float* dst, int stride, int offset) {
-    __syncthreads();
+  // ---- per-channel reductions. A thread holds 8 channels of its row slot; the 8 row slots of a wave are
+  // folded with lane shuffles (lanes 8 apart share a channel octet), so LDS only carries ONE row per wave
+  // and vector: all vectors of a phase go through it together behind a single barrier pair. (One vector
+  // at a time through a [32 slots][64] image, summed by 64 threads: 9 x 2 barriers and 32 dependent LDS
+  // reads each -- 20 us of the 100 us launch.) The phase-1 vectors are folded right away so that their
+  // registers are free during phase 2.
+  // replica of the per-channel gradient block: by TILE, not by workgroup id -- the id also encodes the
+  // channel group, so `blockIdx % 64` sent all adds of a channel to 8 of the 64 replicas: 1024 - 2048
+  // same-line atomics (~12 ns each, serialised) per line and launch = 24 us (dilation 1) to 44 us (128)
+  const int rep_off = id % kReplicas;
+  // fold8: the wave's sum over its 8 row slots of the 8 channels a lane holds, on the VALU alone. A swap
+  // of lane halves (rows) between TWO registers followed by one add reduces both at once, each result
+  // living in one half (row pair): 8 values -> 4 (v_permlane32_swap) -> 2 (v_permlane16_swap) -> the
+  // DPP rotate by 8 inside a 16-lane row. Afterwards lane L (row r = L >> 4, octet L & 7) holds in `xa`
+  // channel kA[r] of its octet and in `xb` channel 4 + kA[r], kA = {0, 2, 1, 3}. (As 3 ds_bpermute per
+  // value -- 210 LDS-pipe instructions per wave -- the folds cost 9 to 19 us of the launch.)
+  auto swap32 = [](float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+  };
+  auto swap16 = [](float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+  };
+  auto ror8_add = [](float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));
+  };
+  auto fold8 = [&](const f32x2 (&v)[4], float& xa, float& xb) {
+    float p[4], q[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      red[rslot*HL_CG + cl + 2*j] = v[j].x; red[rslot*HL_CG + cl + 2*j + 1] = v[j].y;
-    }
-    __syncthreads();
-    if (tid < HL_CG) {
-      float sum = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < 32; ++r) sum += red[r*HL_CG + tid];
-      const int c = cg*HL_CG + tid;
-      float* rdst = dst + (long long)(blockIdx.x % kReplicas)*p.rep_stride;
-      if (c < p.C) atomic_add_f32(rdst + (long long)c*stride + offset, sum);
+    for (int j = 0; j < 4; ++j) { p[j] = v[j].x; q[j] = v[j].y; swap32(p[j], q[j]); p[j] += q[j]; }
+    // p[j]: lanes 0-31 channel 2j, lanes 32-63 channel 2j + 1 (summed over lane bit 5)
+    swap16(p[0], p[1]); xa = p[0] + p[1];          // rows: channels 0, 2, 1, 3
+    swap16(p[2], p[3]); xb = p[2] + p[3];          // rows: channels 4, 6, 5, 7
+    xa = ror8_add(xa); xb = ror8_add(xb);
+  };
+  const int fold_ch = (lane & 7)*8 + (((lane >> 4) & 1)*2 + (lane >> 5));   // octet * 8 + kA[row]
+  auto put8 = [&](int vec, const f32x2 (&v)[4]) {
+    float xa, xb;
+    fold8(v, xa, xb);
+    if (!(lane & 8)) {
+      float* dst = red + (vec*4 + wid)*HL_CG + fold_ch;
+      dst[0] = xa; dst[4] = xb;
     }
   };
-  if (!(BF_ABL & 16)) {
-  reduce_cols(dbia, p.dbias, 1, 0);
-  reduce_cols(dgam2, fp.dgamma2, 1, 0);
-  reduce_cols(dbet2, fp.dbeta2, 1, 0);
+  auto vec_sum = [&](int vec, int ch) {
+    const float* src = red + vec*4*HL_CG + ch;
+    return (src[0] + src[HL_CG]) + (src[2*HL_CG] + src[3*HL_CG]);
+  };
+  if (BF_ABL & 64) {
+    float keep = da2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) keep += dbia[j].x*dbia[j].y + dgam2[j].x*dgam2[j].y + dbet2[j].x*dbet2[j].y;
+    if (keep == 123.456f) red[tid] = keep;
   }
-  {
+  if (!(BF_ABL & (16 | 64))) {
+    da2 = wave_sum(da2);
+    put8(0, dbia); put8(1, dgam2); put8(2, dbet2);
+    if (lane == 0) red[3*4*HL_CG + wid] = da2;
     __syncthreads();
-    const float sa = block_sum(da2, red);
-    if (tid == 0) atomic_add_f32(p.dslope2 + (long long)(blockIdx.x % kReplicas)*p.rep_stride, sa);
+    if (tid < 3*HL_CG) {
+      const int vec = tid >> 6, ch = tid & 63, c = cg*HL_CG + ch;
+      float* dst = (vec == 0 ? p.dbias : vec == 1 ? fp.dgamma2 : fp.dbeta2) + (long long)rep_off*p.rep_stride;
+      if (c < p.C && !(BF_ABL & 32)) atomic_add_f32(dst + c, vec_sum(vec, ch));
+    } else if (tid == 3*HL_CG && !(BF_ABL & 32)) {
+      const float* sc = red + 3*4*HL_CG;
+      atomic_add_f32(p.dslope2 + (long long)rep_off*p.rep_stride, (sc[0] + sc[1]) + (sc[2] + sc[3]));
+    }
   }
-  __syncthreads();
+  __syncthreads();                                       // dz2 window complete; `red` free again
 
   // ---- phase 2: transposed stencil out of LDS -------------------------------------------------
   const NormStat ns = norm_stat(p.stats1, b, p.inv_n, p.eps);
@@ -395,17 +442,36 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
    }
   }
 
-  if (!(BF_ABL & 16)) {
-  reduce_cols(dgam, p.dgamma1, 1, 0);
-  reduce_cols(dbet, p.dbeta1, 1, 0);
+  if (BF_ABL & 64) {
+    float keep = l1 + l2;
 #pragma unroll
-  for (int k = 0; k < P; ++k) reduce_cols(dtap[k], p.dtaps, P, k);
+    for (int j = 0; j < 4; ++j) {
+      keep += dgam[j].x*dgam[j].y + dbet[j].x*dbet[j].y;
+#pragma unroll
+      for (int k = 0; k < P; ++k) keep += dtap[k][j].x*dtap[k][j].y;
+    }
+    if (keep == 123.456f) red[tid] = keep;
   }
-  const double tot1 = block_sum((double)l1, dscr);
-  const double tot2 = block_sum((double)l2, dscr + 8);
-  if (tid == 0) {
-    atomic_add_f64(p.sums1 + stat_sum(b), tot1);
-    atomic_add_f64(p.sums1 + stat_sq(b), tot2);
+  if (!(BF_ABL & (16 | 64))) {
+    l1 = wave_sum(l1); l2 = wave_sum(l2);
+    put8(0, dgam); put8(1, dbet);
+#pragma unroll
+    for (int k = 0; k < P; ++k) put8(2 + k, dtap[k]);
+    if (lane == 0) { red[(2 + P)*4*HL_CG + wid] = l1; red[(2 + P)*4*HL_CG + 4 + wid] = l2; }
+    __syncthreads();
+    for (int idx = tid; idx < (2 + P)*HL_CG; idx += 256) {
+      const int vec = idx >> 6, ch = idx & 63, c = cg*HL_CG + ch;
+      if (c >= p.C || (BF_ABL & 32)) continue;
+      const float sum = vec_sum(vec, ch);
+      if (vec == 0) atomic_add_f32(p.dgamma1 + (long long)rep_off*p.rep_stride + c, sum);
+      else if (vec == 1) atomic_add_f32(p.dbeta1 + (long long)rep_off*p.rep_stride + c, sum);
+      else atomic_add_f32(p.dtaps + (long long)rep_off*p.rep_stride + (long long)c*P + (vec - 2), sum);
+    }
+    if (tid == 255 && !(BF_ABL & 32)) {
+      const float* sc = red + (2 + P)*4*HL_CG;
+      atomic_add_f64(p.sums1 + stat_sum(b), ((double)sc[0] + (double)sc[1]) + ((double)sc[2] + (double)sc[3]));
+      atomic_add_f64(p.sums1 + stat_sq(b), ((double)sc[4] + (double)sc[5]) + ((double)sc[6] + (double)sc[7]));
+    }
   }
 }
 

@@ -842,8 +842,10 @@ int conv_nhwc_launch(const void* x1, int64_t C1, int64_t C1s, const void* x2, in
   p.n_wt = (int)((W + CN_COLS - 1)/CN_COLS);
   p.n_cob = (int)((Cout + 127)/128);
   // rows per tile: 16 when that fills the chip, else 8 or 4 (2-4x the workgroups)
-  static int force_pf = -1;
-  if (force_pf < 0) { const char* e = getenv("BRV_CONV_PF"); force_pf = e ? atoi(e) : 0; }
+#ifndef BRV_CONV_PF
+#define BRV_CONV_PF 0          // diagnostic builds: force the rows per tile (1, 2 or 4 x 4 rows)
+#endif
+  constexpr int force_pf = BRV_CONV_PF;
   int pf = 4;
   while (pf > 1 && (long long)B*((H + 4*pf - 1)/(4*pf))*p.n_wt*p.n_cob < 192) pf >>= 1;
   if (force_pf == 1 || force_pf == 2 || force_pf == 4) pf = force_pf;
@@ -852,9 +854,10 @@ int conv_nhwc_launch(const void* x1, int64_t C1, int64_t C1s, const void* x2, in
   if (n_tiles > 0x7fffffffLL) return -2;
   p.n_tiles = (int)n_tiles;
   p.out_scale = out_scale; p.in_silu = in_silu;
-  static int stagger = -1;
-  if (stagger < 0) { const char* e = getenv("BRV_CONV_STAGGER"); stagger = e ? atoi(e) : 0; }
-  p.stagger = stagger;
+#ifndef BRV_CONV_STAGGER
+#define BRV_CONV_STAGGER 0     // diagnostic builds: start skew of the workgroups (measured: no effect)
+#endif
+  p.stagger = BRV_CONV_STAGGER;
 #ifdef CN_DIAG
   static unsigned long long* dbg = nullptr;
   if (!dbg) CN_OK(hipMalloc(&dbg, 4096));
@@ -865,8 +868,10 @@ int conv_nhwc_launch(const void* x1, int64_t C1, int64_t C1s, const void* x2, in
   int fold = in_scale ? 1 : 0;
   if (gn) {
     // self-fold: every workgroup's run of tiles inside one item (the launch's own rank -> range map)
-    static int no_self = -1;
-    if (no_self < 0) { const char* e = getenv("BRV_CONV_NO_SELF_FOLD"); no_self = e ? atoi(e) : 0; }
+#ifndef BRV_CONV_NO_SELF_FOLD
+#define BRV_CONV_NO_SELF_FOLD 0   // diagnostic builds: GroupNorm fold always as a launch of its own
+#endif
+    constexpr int no_self = BRV_CONV_NO_SELF_FOLD;
     const long long tpi = (long long)p.n_ht*p.n_wt*p.n_cob;
     bool single = !no_self && Cin <= CN_MAXC;
     for (long long r = 0; single && r < G; ++r) {

@@ -40,35 +40,42 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 inline long long align_up(long long x, long long a) { return (x + a - 1)/a*a; }
 
-// fused forward (default; BRV_FWD_FUSE=0 selects the three-launch sequence, see brv_ctn_forward)
-inline bool fwd_fuse_requested() {
-  const char* e = getenv("BRV_FWD_FUSE");
-  return !(e && e[0] == '0') && !getenv("BRV_NO_WS");
-}
-inline bool bwd_fuse_requested() {
-  const char* e = getenv("BRV_BWD_FUSE");
-  return !(e && e[0] == '0');
-}
+// ---- per-call options (include/brever_hip.h: brv_launch_opts) -------------------------------------
+// The options of the running API call, thread-local for its duration (OptsScope in every entry point):
+// the launch helpers below read them without threading an argument through ~40 call sites. Nothing
+// here outlives a call and nothing is shared between threads: no process-global state.
+const brv_launch_opts kDefaultOpts = {sizeof(brv_launch_opts), 0u, 8, 0, nullptr};
+thread_local const brv_launch_opts* t_opts = &kDefaultOpts;
+struct OptsScope {
+  const brv_launch_opts* prev;
+  explicit OptsScope(const brv_launch_opts* o) : prev(t_opts) {
+    t_opts = (o && o->size >= sizeof(brv_launch_opts)) ? o : &kDefaultOpts;
+  }
+  ~OptsScope() { t_opts = prev; }
+};
+inline bool opt(uint32_t flag) { return (t_opts->flags & flag) != 0; }
+inline bool fwd_fuse_requested() { return !opt(BRV_OPT_NO_FWD_FUSE) && !opt(BRV_OPT_NO_WS); }
+inline bool bwd_fuse_requested() { return !opt(BRV_OPT_NO_BWD_FUSE); }
 
 // ---- optional per-launch event timing (bench / profiling only) ---------------
-// Off by default. When enabled through brv_prof_enable(1) every kernel launch of
-// this file is bracketed by two events on the launch stream; brv_prof_collect()
-// aggregates them per label together with the algorithmic FLOPs / bytes.
+// A profiler object the caller owns (brv_prof_create); launches of calls whose options carry it are
+// bracketed by two events on the launch stream; brv_prof_collect() aggregates them per label
+// together with the algorithmic FLOPs / bytes.
 struct ProfEntry { const char* label; hipEvent_t a, b; double flops, bytes; };
-bool g_prof_on = false;
-bool g_prof_by_dil = false;          // brv_prof_enable(2): the depthwise backward labelled per dilation
-std::vector<ProfEntry> g_prof;
+struct Prof { std::vector<ProfEntry> entries; bool by_dil; };
 struct ProfScope {
-  hipStream_t st; bool on;
-  ProfScope(const char* label, double flops, double bytes, hipStream_t s) : st(s), on(g_prof_on) {
-    if (!on) return;
+  hipStream_t st; Prof* prof;
+  ProfScope(const char* label, double flops, double bytes, hipStream_t s)
+      : st(s), prof(static_cast<Prof*>(t_opts->prof)) {
+    if (!prof) return;
     ProfEntry e; e.label = label; e.flops = flops; e.bytes = bytes;
-    hipEventCreate(&e.a); hipEventCreate(&e.b);
-    hipEventRecord(e.a, st);
-    g_prof.push_back(e);
+    (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+    (void)hipEventRecord(e.a, st);
+    prof->entries.push_back(e);
   }
-  ~ProfScope() { if (on) hipEventRecord(g_prof.back().b, st); }
+  ~ProfScope() { if (prof) (void)hipEventRecord(prof->entries.back().b, st); }
 };
+inline bool prof_by_dil() { return t_opts->prof && static_cast<Prof*>(t_opts->prof)->by_dil; }
 
 struct BlockOff {
   long long conv_w, conv_b, dconv_w, dconv_b, res_w, res_b, skip_w, skip_b,
@@ -89,11 +96,12 @@ struct Layout {
   std::vector<BlockOff> blk;
   std::vector<long long> tensor_offsets;
 
-  // the fused forward runs for the default widths, non-causal, kernel_size 3 (see brv_ctn_forward)
-  bool fused_fwd() const {
-    return fwd_fuse_requested() && !causal && P == 3 && H == 512 && Bn == 128 && Sc == 128 &&
-           nb <= 24 /* kWgMaxProb */;
+  // the fused forward runs for the default widths, non-causal, kernel_size 3 (see brv_ctn_forward);
+  // `fusable` is a property of the architecture (it sizes the workspace), `fused_fwd` of the call
+  bool fusable() const {
+    return !causal && P == 3 && H == 512 && Bn == 128 && Sc == 128 && nb <= 24 /* kWgMaxProb */;
   }
+  bool fused_fwd() const { return fusable() && fwd_fuse_requested(); }
 
   int init(const brv_ctn_config* c) {
     if (!c) return fail(-1, "null config");
@@ -211,7 +219,7 @@ struct Workspace {
     vg = take(vg_bytes);
     wgpart = take((long long)kWgSplit*l.nb*W2_G*l.H*4);
     u_stride = align_up(BT*(l.Bnp + l.Scp)*2, 256);
-    u = l.fused_fwd() ? take(u_stride*l.nb) : 0;
+    u = l.fusable() ? take(u_stride*l.nb) : 0;
     h1 = h2 = wn = ctab = cfs = cbt = ident = fake_stats = scratch_stats = 0; ctab_stride = 0;
     if (l.causal) {
       h1 = take(z_stride*l.nb);
@@ -263,21 +271,24 @@ long long* debug_buffer() {
 }
 #endif
 
-// Workgroups of a persistent launch: one per CU -- or `g_chain_eighths`/8 of that while two kernel
-// chains share the chip (brv_ctn_set_chain_share): with 8 items per chain a full-width launch has
-// exactly one tile per workgroup and both chains' launches start and drain in lockstep; at 7/8 the
-// chains interleave (2085 -> 2132 utt/s). Worse for a single chain (2014 -> 1948), hence a switch.
-int g_chain_eighths = 8;
-int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
+// Workgroups of a persistent launch: one per CU -- or opts.cu_eighths/8 of that while two kernel
+// chains share the chip: with 8 items per chain a full-width launch has exactly one tile per workgroup
+// and both chains' launches start and drain in lockstep; at 7/8 the chains interleave (2085 -> 2132
+// utt/s). Worse for a single chain (2014 -> 1948), hence an option of the call.
+int device_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        n <= 0)
-      n = 256;
-  }
-  const int m = n*g_chain_eighths/8/8*8;
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();                                  // (a constant of the machine, not state)
+  return n;
+}
+int num_cus() {
+  const int n = device_cus();
+  const int e = t_opts->cu_eighths >= 1 && t_opts->cu_eighths <= 8 ? t_opts->cu_eighths : 8;
+  const int m = n*e/8/8*8;
   return m >= 8 ? m : n;
 }
 
@@ -318,7 +329,7 @@ int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st,
                      const char* label = "gemm_rows", double bytes = 0) {
   if (p.T <= 0 || batch <= 0) return 0;
   ProfScope prof(label, 2.0*batch*p.T*(double)p.Np*p.Kp, bytes, st);
-  if (AK == A_BF16 && p.a.nsrc <= 1 && !getenv("BRV_NO_WS")) {
+  if (AK == A_BF16 && p.a.nsrc <= 1 && !opt(BRV_OPT_NO_WS)) {
     const bool plain = p.a.slope == nullptr && p.a.stats == nullptr;
     const bool full = p.a.slope != nullptr && p.a.stats != nullptr;
     const bool one_src = p.a.K0 >= p.Kp || p.a.K0 <= 0;
@@ -338,13 +349,8 @@ int launch_gemm_rows(const GemmRowsParams& p, int batch, hipStream_t st,
 // the CUs but every split adds its partial tile to the output with float atomics, so the best count
 // depends on the output size: measured per label on MI355X (BRV_WG_TARGET[_<label>] override).
 inline int wgrad_target(const char* label, int dflt) {
-  if (label) {
-    char name[64];
-    snprintf(name, sizeof(name), "BRV_WG_TARGET_%s", label);
-    if (const char* e = getenv(name)) return atoi(e);
-  }
-  if (const char* e = getenv("BRV_WG_TARGET")) return atoi(e);
-  return dflt;
+  (void)label;
+  return t_opts->wg_target != 0 ? t_opts->wg_target : dflt;
 }
 
 template <int BH, int HK>
@@ -418,7 +424,7 @@ template <int P> struct DwBwd {
       static const char* by_dil[9] = {"dwconv_bwd_d1", "dwconv_bwd_d2", "dwconv_bwd_d4", "dwconv_bwd_d8", "dwconv_bwd_d16",
                                       "dwconv_bwd_d32", "dwconv_bwd_d64", "dwconv_bwd_d128", "dwconv_bwd_dx"};
       int lg = 0; while ((1 << lg) < p.dil && lg < 8) ++lg;
-      ProfScope prof(g_prof_by_dil ? by_dil[lg] : "dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 8.0*p.B*p.T*(double)p.Cp, st);
+      ProfScope prof(prof_by_dil() ? by_dil[lg] : "dwconv_bwd", 4.0*P*p.B*p.T*(double)p.Cp, 8.0*p.B*p.T*(double)p.Cp, st);
       const int R = hl_rows_per_tooth(p.dil), K = HL_TT/R;
       const int tiles = ceil_div(p.dil, R)*ceil_div((p.T - 1)/p.dil + 1, K);
       dim3 grid(tiles*p.B*(p.Cp/HL_CG));
@@ -448,9 +454,9 @@ template <int P> struct DwBwdFused {
     static const char* by_dil[9] = {"dwpw2_bwd_d1", "dwpw2_bwd_d2", "dwpw2_bwd_d4", "dwpw2_bwd_d8", "dwpw2_bwd_d16",
                                     "dwpw2_bwd_d32", "dwpw2_bwd_d64", "dwpw2_bwd_d128", "dwpw2_bwd_dx"};
     int lg = 0; while ((1 << lg) < d.dil && lg < 8) ++lg;
-    ProfScope prof(g_prof_by_dil ? by_dil[lg] : "dwpw2_bwd", 2.0*d.B*d.T*(double)d.Cp*(p.Kg + 2*P),
+    ProfScope prof(prof_by_dil() ? by_dil[lg] : "dwpw2_bwd", 2.0*d.B*d.T*(double)d.Cp*(p.Kg + 2*P),
                    2.0*d.B*d.T*((double)p.Kg + 3.0*d.Cp), st);
-    dim3 grid(tiles*d.B*(d.Cp/HL_CG));
+    dim3 grid(ceil_div(tiles*d.B, 8)*8*(d.Cp/HL_CG));     // whole runs of 8 tiles (XCD map of the kernel)
     if (p.Kg == 256) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P, 256>), grid, dim3(256), BF_LDS, st, p);
     else if (p.Kg == 128) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P, 128>), grid, dim3(256), BF_LDS, st, p);
     else return fail(-1, "fused backward: unexpected [res | skip] width");
@@ -958,23 +964,29 @@ int brv_debug_read(long long* out, int64_t n) {
 }
 #endif
 
-int brv_prof_enable(int on) {
-  for (auto& e : g_prof) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  g_prof.clear();
-  g_prof_on = on != 0;
-  g_prof_by_dil = on == 2;
-  return 0;
+void* brv_prof_create(int by_dilation) {
+  Prof* p = new Prof();
+  p->by_dil = by_dilation != 0;
+  return p;
+}
+void brv_prof_destroy(void* prof) {
+  Prof* p = static_cast<Prof*>(prof);
+  if (!p) return;
+  for (auto& e : p->entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  delete p;
 }
 
-// Writes one line per label: "label calls total_ms flops bytes\n". Returns the
-// number of bytes needed (call again with a larger buffer if > buflen).
-int64_t brv_prof_collect(char* buf, int64_t buflen) {
+// Writes one line per label: "label calls total_ms flops bytes\n" and clears the records. Returns the
+// number of bytes needed (a call with a too small or null buffer keeps the records).
+int64_t brv_prof_collect(void* prof, char* buf, int64_t buflen) {
+  Prof* p = static_cast<Prof*>(prof);
+  if (!p) return 0;
   struct Agg { std::string label; long long calls; double ms, flops, bytes; };
   std::vector<Agg> agg;
-  for (auto& e : g_prof) {
-    hipEventSynchronize(e.b);
+  for (auto& e : p->entries) {
+    (void)hipEventSynchronize(e.b);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e.a, e.b);
+    (void)hipEventElapsedTime(&ms, e.a, e.b);
     Agg* a = nullptr;
     for (auto& x : agg) if (x.label == e.label) { a = &x; break; }
     if (!a) { agg.push_back({e.label, 0, 0, 0, 0}); a = &agg.back(); }
@@ -987,12 +999,16 @@ int64_t brv_prof_collect(char* buf, int64_t buflen) {
              a.flops, a.bytes);
     out += line;
   }
-  if ((int64_t)out.size() + 1 <= buflen && buf) memcpy(buf, out.c_str(), out.size() + 1);
+  if ((int64_t)out.size() + 1 <= buflen && buf) {
+    memcpy(buf, out.c_str(), out.size() + 1);
+    for (auto& e : p->entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    p->entries.clear();
+  }
   return (int64_t)out.size() + 1;
 }
 const char* brv_last_error(void) { return g_err.c_str(); }
-// other translation units of the library report through the same thread-local message
-void brv_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
+// other translation units of the library report through the same thread-local message (not exported)
+__attribute__((visibility("hidden"))) void brv_internal_set_error(const char* msg) { g_err = msg ? msg : ""; }
 
 int64_t brv_ctn_param_count(const brv_ctn_config* cfg) {
   Layout l; if (l.init(cfg)) return -1; return l.n_params;
@@ -1041,7 +1057,8 @@ int64_t brv_ctn_workspace_offset(const brv_ctn_config* cfg, int64_t batch, int64
 }
 
 int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepared,
-                    brv_stream_t stream) {
+                    const brv_launch_opts* opts, brv_stream_t stream) {
+  OptsScope scope(opts);
   Layout l; if (int r = l.init(cfg)) return r;
   hipStream_t st = (hipStream_t)stream;
   std::vector<PrepJob> jobs;
@@ -1136,7 +1153,8 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
 
 int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* prepared,
                     void* workspace, const float* wave, float* out, int64_t batch,
-                    int64_t length, brv_stream_t stream) {
+                    int64_t length, const brv_launch_opts* opts, brv_stream_t stream) {
+  OptsScope scope(opts);
   Layout l; if (int r = l.init(cfg)) return r;
   hipStream_t st = (hipStream_t)stream;
   const int B = (int)batch; const long long L = length;
@@ -1222,8 +1240,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
       g.e.out = ubuf(i); g.e.ldo = NPu; g.e.N = NPu;
       {
         ProfScope prof("dwpw2_fwd", 2.0*BT*l.Hp*(NPu + l.P), 2.0*BT*(2*l.Hp + NPu), st);
-        const char* ws_env = getenv("BRV_DWPW2_WS");          // first version of the stage (gemm_ws.cuh AT == 3)
-        const bool old_stage = ws_env && atoi(ws_env) == 1;
+        const bool old_stage = opt(BRV_OPT_DWPW2_WS);         // first version of the stage (gemm_ws.cuh AT == 3)
         if (old_stage || l.Hp != DP_H || NPu != DP_N) {
           if (int r = launch_gemm_ws<512, 32, 1, E_STORE, 3, false, 8>(g, B, st)) return r;
         } else {
@@ -1364,7 +1381,7 @@ static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, con
   // residual / skip convs of every block in ONE launch when the padded widths are the
   // default 128 | 128 (gemm_wgrad_full.cuh); other architectures use the generic path
   const bool full_rs = l.Bnp == 128 && l.Scp == 128 && l.Hp % W2_BH == 0 && l.nb <= kWgMaxProb &&
-                       !getenv("BRV_NO_WGRAD_FULL");
+                       !opt(BRV_OPT_NO_WGRAD_FULL);
   if (full_rs && blk_lo <= blk_hi) {
     WgradFullParams fp; memset(&fp, 0, sizeof(fp));
     const int nblk = blk_hi - blk_lo + 1;
@@ -1390,7 +1407,7 @@ static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, con
 #endif
     // 24 blocks x 8 H slices = 192 owners would leave a quarter of the CUs idle: the items are
     // divided over kWgSplit workgroups each (768 = 3 full rounds) when the batch allows
-    fp.n_split = (B >= kWgSplit && !getenv("BRV_NO_WGRAD_SPLIT")) ? kWgSplit : 1;
+    fp.n_split = (B >= kWgSplit && !opt(BRV_OPT_NO_WGRAD_SPLIT)) ? kWgSplit : 1;
     fp.part = reinterpret_cast<float*>(base + ws.wgpart);
     const int grid = 8*ceil_div(nblk, 8)*fp.n_htiles*fp.n_split;
     hipLaunchKernelGGL(wgrad_full_kernel, dim3(grid), dim3(64*W2_NW), 0, st, fp);
@@ -1457,23 +1474,18 @@ static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, con
 
 extern "C" {
 
-int brv_ctn_set_chain_share(int32_t eighths) {
-  if (eighths < 1 || eighths > 8) return fail(-1, "chain share: 1 .. 8 eighths of the CUs");
-  g_chain_eighths = eighths;
-  return 0;
-}
-
 int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void* prepared,
                      void* workspace, const float* wave, const float* d_out, float* grads,
-                     int64_t batch, int64_t length, brv_stream_t stream) {
+                     int64_t batch, int64_t length, const brv_launch_opts* opts, brv_stream_t stream) {
   return brv_ctn_backward_part(cfg, params, prepared, workspace, wave, d_out, grads, batch, length,
-                               0, 1, stream);
+                               0, 1, opts, stream);
 }
 
 int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const void* prepared,
                           void* workspace, const float* wave, const float* d_out, float* grads,
                           int64_t batch, int64_t length, int32_t part, int32_t nparts,
-                          brv_stream_t stream) {
+                          const brv_launch_opts* opts, brv_stream_t stream) {
+  OptsScope scope(opts);
   Layout l; if (int r = l.init(cfg)) return r;
   hipStream_t st = (hipStream_t)stream;
   const int B = (int)batch; const long long L = length;
@@ -1521,7 +1533,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   // Backward mirror of the fused forward (bwd_fused.cuh; BRV_BWD_FUSE=0: three launches per block):
   // needs the u tensors the fused forward stored and the default widths
   const bool bwd_fused = l.fused_fwd() && bwd_fuse_requested() && l.Bnp == 128 && l.Scp == 128 &&
-                         l.Hp % HL_CG == 0 && !getenv("BRV_NO_DZ_FUSE");
+                         l.Hp % HL_CG == 0 && !opt(BRV_OPT_NO_DZ_FUSE);
 
   GemmRowsParams g; WgradParams wg;
   if (head) {
@@ -1573,30 +1585,13 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   }
   }   // head
 
-  // Weight gradients overlapped with the data-gradient chain (BRV_WGRAD_OVERLAP=n, n >= 2 chunks):
-  // the blocks of this call are cut into n chunks; a chunk's deferred weight gradients run on a side
-  // stream while the main stream walks the next chunk's chain, so their workgroups could fill the
-  // tails and the gaps between the chain's dependent launches. Joined before this function returns.
-  // MEASURED SLOWER on MI355X (8.02 ms/step off; 8.33 / 8.11 / 8.27 / 8.76 ms with 2 / 3 / 4 / 6
-  // chunks: both kinds of kernel are sized for whole CUs and evict each other's L2 lines), so off
-  // by default.
-  static const int overlap_chunks = [] {
-    const char* e = getenv("BRV_WGRAD_OVERLAP");
-    const int n = e ? atoi(e) : 0;
-    return n < 2 ? 1 : (n > 8 ? 8 : n);
-  }();
-  static hipStream_t side = nullptr;
-  static hipEvent_t ev_chain[8], ev_join;
-  if (overlap_chunks > 1 && !side) {
-    HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    for (auto& e : ev_chain) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  }
-  const int n_blk_call = blk_hi - blk_lo + 1;
-  const int n_chunks = (overlap_chunks > 1 && n_blk_call >= 2*overlap_chunks) ? overlap_chunks : 1;
+  // (Running the deferred weight gradients of block chunks on a side stream next to the data-gradient
+  // chain was measured slower at every chunk count -- DESIGN.md 5g -- and is gone.)
+  const int n_chunks = 1;
   auto wgrads = [&](int blk_lo, int blk_hi, hipStream_t st) -> int {
     return deferred_wgrads(l, ws, base, prep, params, grads, stats, B, T, blk_lo, blk_hi, st);
   };
+  const int n_blk_call = blk_hi - blk_lo + 1;
   for (int ch = n_chunks - 1; ch >= 0; --ch) {
   const int c_lo = blk_lo + (int)((long long)n_blk_call*ch/n_chunks);
   const int c_hi = blk_lo + (int)((long long)n_blk_call*(ch + 1)/n_chunks) - 1;
@@ -1624,7 +1619,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
     // gLN_2 + prelu_2 backward: fused into the depthwise backward below when its LDS window
     // (tile + halo rows) fits -- dz2 is then built once per element in LDS and never written
     // (dwconv_bwd_halo_kernel). BRV_NO_DZ_FUSE keeps the separate pass.
-    const bool fuse_dz2 = blk_fused || (!getenv("BRV_NO_DZ_FUSE") && l.Hp % HL_CG == 0 &&
+    const bool fuse_dz2 = blk_fused || (!opt(BRV_OPT_NO_DZ_FUSE) && l.Hp % HL_CG == 0 &&
                           (((l.P - 1)*dil)/2) % dil == 0 && hl_window_rows(dil, l.P) <= HL_MAXROWS);
     DzParams dz; memset(&dz, 0, sizeof(dz));
     if (!fuse_dz2) {
@@ -1661,7 +1656,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
     // below (A_DZ: dz1 is computed from e1 and z1 on load and written back over e1 for the
     // deferred weight gradient); BRV_NO_DZ1_FUSE keeps the separate pass
     // (needs one n-tile: the workgroup that stages an A element must be its only reader)
-    const bool fuse_dz1 = !getenv("BRV_NO_DZ1_FUSE") && (l.Bnp == 128 || l.Bnp == 64);
+    const bool fuse_dz1 = !opt(BRV_OPT_NO_DZ1_FUSE) && (l.Bnp == 128 || l.Bnp == 64);
     if (!fuse_dz1) {
       memset(&dz, 0, sizeof(dz));
       dz.e = eB; dz.z = z1buf(i); dz.B = B; dz.T = (int)T; dz.Cp = l.Hp; dz.C = l.H;
@@ -1692,16 +1687,8 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
     }
     if (int r = launch_gemm_rows<A_BF16, E_ADD>(g, B, st, "pw1_dgrad", 2.0*BT*(l.Hp + l.Bnp*(has_res ? 2 : 1)))) return r;
   }
-    if (n_chunks > 1) {
-      HIP_OK(hipEventRecord(ev_chain[ch], st));
-      HIP_OK(hipStreamWaitEvent(side, ev_chain[ch], 0));
-      if (int r = wgrads(c_lo, c_hi, side)) return r;
-    } else if (int r = wgrads(c_lo, c_hi, st)) return r;
+    if (int r = wgrads(c_lo, c_hi, st)) return r;
   }   // chunks
-  if (n_chunks > 1) {
-    HIP_OK(hipEventRecord(ev_join, side));
-    HIP_OK(hipStreamWaitEvent(st, ev_join, 0));
-  }
   if (tail) {
   // bottleneck conv: data gradient + first gLN backward partials
   memset(&g, 0, sizeof(g));

@@ -28,7 +28,7 @@ using namespace brv;
 namespace {
 
 }  // namespace
-extern "C" void brv_internal_set_error(const char* msg);     // convtasnet.hip: feeds brv_last_error()
+extern "C" __attribute__((visibility("hidden"))) void brv_internal_set_error(const char* msg);   // convtasnet.hip: feeds brv_last_error()
 namespace {
 int fail32(int code, const std::string& msg) { brv_internal_set_error(msg.c_str()); return code; }
 

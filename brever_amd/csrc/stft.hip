@@ -971,6 +971,9 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   const dim3 grid((unsigned)((N + BN2 - 1)/BN2), (unsigned)((M + BM2 - 1)/BM2),
                   (unsigned)(batch*ksplit));
   if (lowp) {
+#ifndef BRV_GEMM_SCALAR
+#define BRV_GEMM_SCALAR 0      // diagnostic builds: general bf16 GEMM without the vector loaders
+#endif
     // vector loader: strides, bases and the extent along each operand's contiguous axis are
     // multiples of 4 floats
     auto q4 = [](long long v) { return (v & 3) == 0; };
@@ -979,7 +982,7 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
                      q4(a_kbatch_stride) && (conv || q4(b_kbatch_stride)) &&
                      ((uintptr_t)a & ((flags & 4) ? 7 : 15)) == 0 &&
                      (conv || ((uintptr_t)b & ((flags & 1) ? 7 : 15)) == 0) &&
-                     q4(trans_a ? M : K) && q4(trans_b ? K : N) && !getenv("BRV_GEMM_SCALAR");
+                     q4(trans_a ? M : K) && q4(trans_b ? K : N) && !BRV_GEMM_SCALAR;
 #define BRV_BF16_LAUNCH(TA_, TB_) \
     do { if (conv && vec) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, true, true>), grid, dim3(256), 0, st, p, (int)ksplit); \
          else if (conv) hipLaunchKernelGGL((gemm_bf16_kernel<TA_, TB_, false, true>), grid, dim3(256), 0, st, p, (int)ksplit); \

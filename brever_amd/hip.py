@@ -26,12 +26,48 @@ class CtnConfig(ctypes.Structure):
         'causal')]
 
 
+class LaunchOpts(ctypes.Structure):
+    """``brv_launch_opts`` -- per-call options of the Conv-TasNet entry points."""
+    _fields_ = [('size', ctypes.c_uint32), ('flags', ctypes.c_uint32), ('cu_eighths', ctypes.c_int32),
+                ('wg_target', ctypes.c_int32), ('prof', ctypes.c_void_p)]
+
+
+OPT_NO_FWD_FUSE, OPT_NO_BWD_FUSE, OPT_NO_WS, OPT_DWPW2_WS = 0x001, 0x002, 0x004, 0x008
+OPT_NO_DZ_FUSE, OPT_NO_DZ1_FUSE, OPT_NO_WGRAD_FULL, OPT_NO_WGRAD_SPLIT = 0x010, 0x020, 0x040, 0x080
+# environment switch -> option flag (read by the HOST at call time; the library itself reads no
+# environment). '0' selects the flag for the *_FUSE switches, any value for the BRV_NO_* ones.
+_ENV_FLAGS = (('BRV_FWD_FUSE', OPT_NO_FWD_FUSE, '0'), ('BRV_BWD_FUSE', OPT_NO_BWD_FUSE, '0'),
+              ('BRV_NO_WS', OPT_NO_WS, None), ('BRV_DWPW2_WS', OPT_DWPW2_WS, '1'),
+              ('BRV_NO_DZ_FUSE', OPT_NO_DZ_FUSE, None), ('BRV_NO_DZ1_FUSE', OPT_NO_DZ1_FUSE, None),
+              ('BRV_NO_WGRAD_FULL', OPT_NO_WGRAD_FULL, None), ('BRV_NO_WGRAD_SPLIT', OPT_NO_WGRAD_SPLIT, None))
+_prof = None            # profiler handle of this process's calls (prof_enable)
+
+
+def launch_opts(cu_eighths=8):
+    """Options for one Conv-TasNet call: A/B switches from the environment, the share of
+    the chip the persistent kernels take, the active profiler. Returns the struct (keep it alive for
+    the duration of the call) -- pass ``ctypes.byref`` of it."""
+    flags = 0
+    for name, flag, on_value in _ENV_FLAGS:
+        v = os.environ.get(name)
+        if v is not None and (on_value is None or v == on_value):
+            flags |= flag
+    target = os.environ.get('BRV_WG_TARGET')
+    return LaunchOpts(ctypes.sizeof(LaunchOpts), flags, int(cu_eighths),
+                      int(target) if target else 0, _prof)
+
+
+def opts_ptr(opts):
+    return ctypes.byref(opts)
+
+
 # name -> (restype, argtypes); the export test checks every name resolves.
 SIGNATURES = {
     'brv_version': (ctypes.c_int, []),
     'brv_last_error': (ctypes.c_char_p, []),
-    'brv_prof_enable': (ctypes.c_int, [ctypes.c_int]),
-    'brv_prof_collect': (_c_i64, [ctypes.c_char_p, _c_i64]),
+    'brv_prof_create': (_c_ptr, [ctypes.c_int]),
+    'brv_prof_collect': (_c_i64, [_c_ptr, ctypes.c_char_p, _c_i64]),
+    'brv_prof_destroy': (None, [_c_ptr]),
     'brv_ctn_param_count': (_c_i64, [_c_ptr]),
     'brv_ctn_param_tensors': (_c_i64, [_c_ptr]),
     'brv_ctn_param_offset': (_c_i64, [_c_ptr, _c_i64]),
@@ -40,16 +76,15 @@ SIGNATURES = {
     'brv_ctn_workspace_bytes': (_c_i64, [_c_ptr, _c_i64, _c_i64]),
     'brv_ctn_workspace_offset': (_c_i64, [_c_ptr, _c_i64, _c_i64,
                                           ctypes.c_char_p, _c_i64]),
-    'brv_ctn_prepare': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr]),
-    'brv_ctn_set_chain_share': (ctypes.c_int, [ctypes.c_int32]),
+    'brv_ctn_prepare': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'brv_ctn_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
-                                       _c_ptr, _c_i64, _c_i64, _c_ptr]),
+                                       _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
     'brv_ctn_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                         _c_ptr, _c_ptr, _c_i64, _c_i64,
-                                        _c_ptr]),
+                                        _c_ptr, _c_ptr]),
     'brv_ctn_backward_part': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                              _c_ptr, _c_ptr, _c_i64, _c_i64,
-                                             ctypes.c_int32, ctypes.c_int32, _c_ptr]),
+                                             ctypes.c_int32, ctypes.c_int32, _c_ptr, _c_ptr]),
     'brv_ctn_grad_bucket': (ctypes.c_int, [_c_ptr, ctypes.c_int32, ctypes.c_int32,
                                            _c_ptr, _c_ptr]),
     'brv_ctn_f32_backward_part': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
@@ -287,12 +322,25 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def prof_enable(mode):
+    """0: off; 1: event-time every launch of the Conv-TasNet calls made through ``launch_opts``;
+    2: the same with the depthwise backward kernels labelled per dilation."""
+    global _prof
+    if _prof is not None:
+        lib().brv_prof_destroy(_prof)
+        _prof = None
+    if mode:
+        _prof = ctypes.c_void_p(lib().brv_prof_create(1 if mode == 2 else 0))
+
+
 def profile_collect():
-    """Per-label aggregate of the event-timed launches since ``brv_prof_enable(1)``:
+    """Per-label aggregate of the event-timed launches since ``prof_enable`` / the last collect:
     ``{label: dict(calls, ms, flops, bytes)}``."""
-    n = lib().brv_prof_collect(None, 0)
+    if _prof is None:
+        return {}
+    n = lib().brv_prof_collect(_prof, None, 0)
     buf = ctypes.create_string_buffer(int(n) + 16)
-    lib().brv_prof_collect(buf, len(buf))
+    lib().brv_prof_collect(_prof, buf, len(buf))
     out = {}
     for line in buf.value.decode().splitlines():
         label, calls, ms, flops, nbytes = line.split()

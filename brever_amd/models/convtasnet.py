@@ -322,9 +322,10 @@ class ConvTasNet(BreverBaseModel):
                                          device=self._flat.device)
             self._prepared_dirty = True
         if self._prepared_dirty:
+            opts = hip.launch_opts()
             hip.check(lib.brv_ctn_prepare(
                 self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
-                hip.stream()), 'brv_ctn_prepare')
+                hip.opts_ptr(opts), hip.stream()), 'brv_ctn_prepare')
             self._prepared_dirty = False
 
     def _get_workspace(self, B, L, amp=True):
@@ -365,9 +366,10 @@ class ConvTasNet(BreverBaseModel):
                           device=wave.device)
         if amp:
             self._prepare()
+            opts = hip.launch_opts()
             hip.check(hip.lib().brv_ctn_forward(
                 self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
-                hip.ptr(ws), hip.ptr(wave), hip.ptr(out), B, L, hip.stream()),
+                hip.ptr(ws), hip.ptr(wave), hip.ptr(out), B, L, hip.opts_ptr(opts), hip.stream()),
                 'brv_ctn_forward')
         else:
             self._check_layout()
@@ -402,12 +404,13 @@ class ConvTasNet(BreverBaseModel):
         ws = self._get_workspace(B, L, amp)
         buckets = self.grad_buckets(nparts) if after_part is not None else None
         lib = hip.lib()
+        opts = hip.launch_opts()
         for part in range(nparts):
             if amp:
                 hip.check(lib.brv_ctn_backward_part(
                     self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
                     hip.ptr(ws), hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad),
-                    B, L, part, nparts, hip.stream()), 'brv_ctn_backward_part')
+                    B, L, part, nparts, hip.opts_ptr(opts), hip.stream()), 'brv_ctn_backward_part')
             else:
                 hip.check(lib.brv_ctn_f32_backward_part(
                     self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(ws),
@@ -536,12 +539,6 @@ class ConvTasNet(BreverBaseModel):
             return loss_b.mean()
 
     def _train_step_two_chains(self, inputs, labels, lengths):
-        try:
-            return self._two_chains(inputs, labels, lengths)
-        finally:                                  # (also when a launch failed half way)
-            hip.lib().brv_ctn_set_chain_share(8)
-
-    def _two_chains(self, inputs, labels, lengths):
         """The fused bf16 step as TWO independent half-batch chains on two streams. Every launch of
         the TCN depends on the one before it (a layer norm over the whole item sits between them), so
         a single chain leaves the chip idle for the ~4.5 us between dependent launches and in the tail
@@ -565,8 +562,10 @@ class ConvTasNet(BreverBaseModel):
             grads.zero_()
             main, side = torch.cuda.current_stream(dev), t['side']
             side.wait_stream(main)
-            # persistent kernels at 7/8 of the CUs while two chains share the chip (csrc: num_cus)
-            hip.check(lib.brv_ctn_set_chain_share(7), 'brv_ctn_set_chain_share')
+            # persistent kernels at 7/8 of the CUs while two chains share the chip (csrc: num_cus) --
+            # an option of these calls, not a state of the library
+            opts = hip.launch_opts(cu_eighths=7)
+            po = hip.opts_ptr(opts)
             streams = (main, side)
             flat, prep, cfg = hip.ptr(self._flat), hip.ptr(self._prepared), self._cfg_ptr()
 
@@ -581,7 +580,7 @@ class ConvTasNet(BreverBaseModel):
                     if h == 1:
                         t['grad2'].zero_()
                     hip.check(lib.brv_ctn_forward(cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x),
-                                                  hip.ptr(out), Bh, L, st), 'brv_ctn_forward')
+                                                  hip.ptr(out), Bh, L, po, st), 'brv_ctn_forward')
                     hip.check(lib.brv_snr_forward(hip.ptr(out), hip.ptr(y), hip.ptr(ln), Bh, S, L, L,
                                                   hip.ptr(t['scratch'][h]), hip.ptr(loss_b), st),
                               'brv_snr_forward')
@@ -597,7 +596,7 @@ class ConvTasNet(BreverBaseModel):
                     with torch.cuda.stream(streams[h]):
                         hip.check(lib.brv_ctn_backward_part(
                             cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x), hip.ptr(d_out),
-                            hip.ptr(grads if h == 0 else t['grad2']), Bh, L, part, nparts, hip.stream()),
+                            hip.ptr(grads if h == 0 else t['grad2']), Bh, L, part, nparts, po, hip.stream()),
                             'brv_ctn_backward_part')
                 # this part's slice of the gradient is final in both halves: sum it (and hand it to the
                 # bucketed all-reduce) while the next part's chains run
@@ -607,7 +606,6 @@ class ConvTasNet(BreverBaseModel):
                     grads[off:off + cnt].add_(t['grad2'][off:off + cnt])
                     if nparts > 1:
                         sync.bucket(part, grads[off:off + cnt])
-            hip.check(lib.brv_ctn_set_chain_share(8), 'brv_ctn_set_chain_share')
             if sync is None:
                 grad_scale = 1.0
             else:

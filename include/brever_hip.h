@@ -31,12 +31,39 @@ typedef void* brv_stream_t;          /* hipStream_t */
 int brv_version(void);
 const char* brv_last_error(void);
 
-/* Optional per-launch timing with HIP events on the launch stream (bench.py's
- * roofline measurement; off by default, process-global, not thread-safe).
- * brv_prof_collect writes "label calls total_ms flops bytes" lines (algorithmic
- * FLOPs / HBM bytes as stated in DESIGN.md) and returns the buffer size needed. */
-int brv_prof_enable(int on);
-int64_t brv_prof_collect(char* buf, int64_t buflen);
+/* Optional per-launch timing with HIP events on the launch stream (bench.py's roofline
+ * measurement). A profiler is an object the CALLER owns: launches made with
+ * brv_launch_opts.prof = handle are bracketed by two events each; brv_prof_collect writes
+ * "label calls total_ms flops bytes" lines (algorithmic FLOPs / HBM bytes as stated in DESIGN.md)
+ * for them, returns the buffer size needed and clears the handle's records. by_dilation != 0
+ * labels the depthwise backward kernels per dilation. One handle per thread of calls. */
+void* brv_prof_create(int by_dilation);
+int64_t brv_prof_collect(void* prof, char* buf, int64_t buflen);
+void brv_prof_destroy(void* prof);
+
+/* Per-call launch options of the Conv-TasNet entry points (brv_ctn_prepare / _forward /
+ * _backward / _backward_part). NULL or a zeroed struct = the measured-best path on the whole
+ * chip. The library keeps NO process-global state (SURVEY.md 8b "Threading / streams"): what used
+ * to be a global switch (the share of the chip a kernel chain takes), a global profiler and
+ * environment reads inside the library is an argument, so two models may step from two host
+ * threads on two streams. The switches exist for A/B measurements and tests; the
+ * Python host fills them from the environment (brever_amd/hip.py: launch_opts). */
+#define BRV_OPT_NO_FWD_FUSE     0x001u  /* forward as three launches per block instead of the fused stage */
+#define BRV_OPT_NO_BWD_FUSE     0x002u  /* backward as three launches per block (bwd_fused.cuh off) */
+#define BRV_OPT_NO_WS           0x004u  /* generic tile GEMM instead of the persistent kernels */
+#define BRV_OPT_DWPW2_WS        0x008u  /* fused forward stage as a mode of the persistent GEMM */
+#define BRV_OPT_NO_DZ_FUSE      0x010u  /* gLN_2 / PReLU_2 backward as a pass of its own */
+#define BRV_OPT_NO_DZ1_FUSE     0x020u  /* gLN_1 / PReLU_1 backward as a pass of its own */
+#define BRV_OPT_NO_WGRAD_FULL   0x040u  /* grouped generic kernel for the [res | skip] weight gradient */
+#define BRV_OPT_NO_WGRAD_SPLIT  0x080u  /* no item split of that launch */
+typedef struct brv_launch_opts {
+  uint32_t size;          /* sizeof(brv_launch_opts), for forward compatibility */
+  uint32_t flags;         /* BRV_OPT_* */
+  int32_t cu_eighths;     /* persistent kernels launch cu_eighths/8 of one workgroup per CU; 0 = 8 = all.
+                             The host passes 7 while two half-batch chains share the chip */
+  int32_t wg_target;      /* workgroups a weight-gradient launch aims for; 0 = per-shape defaults */
+  void* prof;             /* brv_prof_create handle or NULL */
+} brv_launch_opts;
 
 /* ---- Conv-TasNet ---------------------------------------------------------
  * Hyper-parameters of brever.models.convtasnet.ConvTasNet.__init__
@@ -68,9 +95,11 @@ int64_t brv_ctn_workspace_bytes(const brv_ctn_config* cfg, int64_t batch,
 int64_t brv_ctn_workspace_offset(const brv_ctn_config* cfg, int64_t batch,
                                  int64_t length, const char* name, int64_t index);
 
-/* fp32 parameters -> prepared bf16 operands. Call after every parameter update. */
+/* fp32 parameters -> prepared bf16 operands. Call after every parameter update (with the options
+ * the forward / backward calls will get: BRV_OPT_NO_FWD_FUSE selects which [res | skip] operand
+ * forms are prepared). */
 int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params,
-                    void* prepared, brv_stream_t stream);
+                    void* prepared, const brv_launch_opts* opts, brv_stream_t stream);
 
 /* ConvTasNet.forward (convtasnet.py:66-72): wave (batch, length) fp32 ->
  * out (batch, sources, length) fp32. Leaves the activations needed by
@@ -78,13 +107,7 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params,
 int brv_ctn_forward(const brv_ctn_config* cfg, const float* params,
                     const void* prepared, void* workspace, const float* wave,
                     float* out, int64_t batch, int64_t length,
-                    brv_stream_t stream);
-
-/* Persistent kernels of the Conv-TasNet path launch eighths/8 of one workgroup per CU (default 8).
- * The host side sets 7 while it runs two half-batch kernel chains on two streams
- * (brever_amd/models/convtasnet.py: _train_step_two_chains) and restores 8 afterwards. Host state,
- * read at launch time; no reference counterpart (an execution knob of this implementation). */
-int brv_ctn_set_chain_share(int32_t eighths);
+                    const brv_launch_opts* opts, brv_stream_t stream);
 
 /* Autograd of ConvTasNet.forward: d_out (batch, sources, length) fp32 ->
  * gradients ACCUMULATED into `grads` (flat fp32, same layout as params;
@@ -92,7 +115,7 @@ int brv_ctn_set_chain_share(int32_t eighths);
 int brv_ctn_backward(const brv_ctn_config* cfg, const float* params,
                      const void* prepared, void* workspace, const float* wave,
                      const float* d_out, float* grads, int64_t batch,
-                     int64_t length, brv_stream_t stream);
+                     int64_t length, const brv_launch_opts* opts, brv_stream_t stream);
 
 /* The backward pass in `nparts` parts, for overlapping the data-parallel gradient all-reduce
  * with the rest of backward (the reference wraps the model in
@@ -107,7 +130,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params,
                           const void* prepared, void* workspace, const float* wave,
                           const float* d_out, float* grads, int64_t batch,
                           int64_t length, int32_t part, int32_t nparts,
-                          brv_stream_t stream);
+                          const brv_launch_opts* opts, brv_stream_t stream);
 int brv_ctn_grad_bucket(const brv_ctn_config* cfg, int32_t part, int32_t nparts,
                         int64_t* offset, int64_t* count);
 

@@ -44,12 +44,12 @@ lengths = torch.full((16,), 64000).cuda()
 for _ in range(3):
     net.train_step(batch, lengths, True, None)
 torch.cuda.synchronize()
-hip.lib().brv_prof_enable({2 if by_dil else 1})
+hip.prof_enable({2 if by_dil else 1})
 for _ in range(4):
     net.train_step(batch, lengths, True, None)
 torch.cuda.synchronize()
 prof = hip.profile_collect()
-hip.lib().brv_prof_enable(0)
+hip.prof_enable(0)
 keys = [k for k in prof if k.startswith(('dwpw2_bwd', 'dwconv_bwd', 'pw2_dgrad', 'pw1_dgrad', 'gu_dots'))]
 print(' '.join(f"{{k}}={{prof[k]['ms']/prof[k]['calls']*1e3:.1f}}" for k in sorted(keys)))
 '''
@@ -62,4 +62,4 @@ if __name__ == '__main__':
     print('three launches, per dilation:', measure(base, '0', True))
     print('fused, per dilation        :', measure(base, '1', True))
     for bits in [int(a) for a in sys.argv[1:]]:
-        print(f'BF_ABL={bits:2d}:', measure(build(bits), '1', False))
+        print(f'BF_ABL={bits:2d}:', measure(build(bits), '1', True))

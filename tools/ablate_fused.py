@@ -15,11 +15,11 @@ for flags in [0, 1, 2, 4, 8, 12, 13]:
         for _ in range(2):
             net(x)
         torch.cuda.synchronize()
-        hip.lib().brv_prof_enable(1)
+        hip.prof_enable(1)
         for _ in range(3):
             net(x)
         torch.cuda.synchronize()
     prof = hip.profile_collect()
-    hip.lib().brv_prof_enable(0)
+    hip.prof_enable(0)
     row = ' '.join(f'{k}={prof[k]["ms"]/prof[k]["calls"]*1e3:6.1f}us' for k in prof if k in ('pw1_fwd', 'dwpw2_fwd', 'pw2_fwd', 'dwconv_fwd'))
     print(f'dbg={flags:2d}: {row}')

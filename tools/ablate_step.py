@@ -16,10 +16,10 @@ for flags in [0, 1, 2, 4, 8, 12, 1024]:
     for _ in range(2):
         net.train_step(batch, lengths, True, None)
     torch.cuda.synchronize()
-    hip.lib().brv_prof_enable(1)
+    hip.prof_enable(1)
     for _ in range(3):
         net.train_step(batch, lengths, True, None)
     torch.cuda.synchronize()
     prof = hip.profile_collect()
-    hip.lib().brv_prof_enable(0)
+    hip.prof_enable(0)
     print(f'dbg={flags:4d}: ' + ' '.join(f'{k}={prof[k]["ms"]/prof[k]["calls"]*1e3:6.1f}' for k in labels if k in prof))

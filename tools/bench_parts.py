@@ -42,12 +42,12 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0)/args.steps
 print(f'buckets {args.buckets}: {dt*1e3:.3f} ms/step, {16/dt:.1f} utt/s')
 if args.kernel_table:
-    hip.lib().brv_prof_enable(1)
+    hip.prof_enable(1)
     for i in range(5):
         step(i)
     torch.cuda.synchronize()
     prof = hip.profile_collect()
-    hip.lib().brv_prof_enable(0)
+    hip.prof_enable(0)
     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:10]:
         print(f"{k:20s} {v['calls']/5:5.1f} calls/step {v['ms']/5:7.3f} ms/step")
 dist.destroy_process_group()

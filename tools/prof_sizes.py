@@ -14,12 +14,12 @@ for L in [int(x) for x in sys.argv[1:]] or [5200, 64000]:
     for _ in range(3):
         net.train_step(batch, lengths, True, None)
     torch.cuda.synchronize()
-    hip.lib().brv_prof_enable(1)
+    hip.prof_enable(1)
     for _ in range(3):
         net.train_step(batch, lengths, True, None)
     torch.cuda.synchronize()
     prof = hip.profile_collect()
-    hip.lib().brv_prof_enable(0)
+    hip.prof_enable(0)
     print(f'--- L={L} T={net.frames(L)}')
     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:12]:
         print(f'{k:18s} {v["ms"]/v["calls"]*1e3:8.1f} us/call  {v["bytes"]/v["ms"]/1e6:8.1f} GB/s')
