@@ -59,7 +59,8 @@ inline int bf_tile_teeth(int T, int dil, int P) {
 // KG: reduction length of phase 0 (compile time: the chunk loop is straight-line code, so every wait of
 // its load pipeline is a counted vmcnt -- as a run-time loop hipcc drained ALL loads, the just-issued
 // prefetch included, in front of the first MFMA of every chunk)
-template <int P, int KG>
+// FULLC: the channel count is a multiple of 64 (no padded channels to mask)
+template <int P, int KG, bool FULLC>
 __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFusedParams fp) {
   const DwParams& p = fp.d;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = p.T, d = p.dil;
   const int R = hl_rows_per_tooth(d), K = fp.K;
+  const int lgR = 31 - __builtin_clz(R);                // R is a power of two: shifts, not divisions
   const int n_rt = ceil_div(d, R);                       // residue groups
   const int n_teeth = (T - 1)/d + 1;
   const int n_qt = ceil_div(n_teeth, K);                 // tooth groups
@@ -92,11 +94,29 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   const int qbase = q0 - (P - 1) + p.left/d;           // tooth of window row 0
   // window row r -> frame: tooth qbase + r / R, residue r0 + r % R
   auto frame_of = [&](int r, bool& ok) {
-    const int qi = r / R, ri = r % R;
+    const int qi = r >> lgR, ri = r & (R - 1);
     const int q = qbase + qi;
     ok = r < W && q >= 0 && r0 + ri < d;
     return q*d + r0 + ri;
   };
+
+  // Per-channel parameters of the group (gamma_2, gamma_1, beta_1, the P taps): requested now, parked
+  // in LDS behind the barrier that ends phase 0 and read from there by phases 1 and 2. (Loaded by every
+  // thread where they are used -- 8 + 40 dependent scalar loads -- they put two L2 round trips into
+  // every workgroup's critical path.)
+  __shared__ float ptab[(3 + P)*HL_CG];
+  float pv0 = 0.f, pv1 = 0.f;
+  auto ptab_src = [&](int idx) -> const float* {
+    const int which = idx >> 6, c = cg*HL_CG + (idx & 63);
+    if (!FULLC && c >= p.C) return nullptr;
+    return which == 0 ? fp.gamma2 + c : which == 1 ? p.gamma1 + c : which == 2 ? p.beta1 + c
+                      : p.taps + (long long)c*P + (which - 3);
+  };
+  {
+    const float* s0 = ptab_src(tid);
+    if (s0) pv0 = *s0;
+    if (tid + 256 < (3 + P)*HL_CG) { const float* s1 = ptab_src(tid + 256); if (s1) pv1 = *s1; }
+  }
 
   // ---- phase 0: e = W^T g of the window -> LDS ---------------------------------------------------
   // Every wave works alone on its own 64 window rows (no workgroup barrier before the end of the
@@ -209,6 +229,8 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
         }
     }
   }
+  ptab[tid] = pv0;
+  if (tid + 256 < (3 + P)*HL_CG) ptab[tid + 256] = pv1;
   __syncthreads();
 
   // ---- phase 1: dz2 of the window, in place in LDS --------------------------------------------------
@@ -228,11 +250,9 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   float da2 = 0.f;
   f32x2 dbia[4], dgam2[4], dbet2[4], g2[4];
   {
-    float g8[8];
-    load8_masked(fp.gamma2, c0, p.C, g8);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      g2[j] = f32x2{g8[2*j], g8[2*j + 1]};
+      g2[j] = f32x2{ptab[cl + 2*j], ptab[cl + 2*j + 1]};
       dbia[j] = f32x2{0.f, 0.f}; dgam2[j] = f32x2{0.f, 0.f}; dbet2[j] = f32x2{0.f, 0.f};
     }
   }
@@ -258,27 +278,33 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
       const float on = in ? 1.f : 0.f;
       const float rr = on*R2, k0 = on*K0, mm = on*M2R;
       // each element is "owned" by the tile whose teeth [q0, q0 + K) contain it
-      const int q = qbase + r / R;
+      const int q = qbase + (r >> lgR);
       const bool centre = in && q >= q0 && q < q0 + K;
-      const float cen = centre ? 1.f : 0.f;
+      float uz = 0.f;                                    // sum over the row's 8 channels of uu min(z, 0)
+      f32x2 xg[4], ee[4];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xh2 = __builtin_fmaf(yb, __builtin_fabsf(z[j]), __builtin_fmaf(ya, z[j], yc));
         const float gj = (j & 1) ? g2[j >> 1].y : g2[j >> 1].x;
         const float uu = __builtin_fmaf(mm, xh2, __builtin_fmaf(e[j]*gj, rr, k0));
-        const bool pos = z[j] > 0.f;
-        g[j] = c0 + j < p.C ? (pos ? uu : a2*uu) : 0.f;
-        if (centre && !pos) da2 += uu*z[j];
-        const float ec = cen*e[j];
-        if (j & 1) { dgam2[j >> 1].y = __builtin_fmaf(ec, xh2, dgam2[j >> 1].y); dbet2[j >> 1].y += ec; }
-        else { dgam2[j >> 1].x = __builtin_fmaf(ec, xh2, dgam2[j >> 1].x); dbet2[j >> 1].x += ec; }
+        g[j] = uu*(z[j] > 0.f ? 1.f : a2);               // PReLU_2'
+        uz = __builtin_fmaf(uu, z[j] - __builtin_fabsf(z[j]), uz);    // 2 min(z, 0) (fminf canonicalises first)
+        if (j & 1) { xg[j >> 1].y = xh2; ee[j >> 1].y = e[j]; } else { xg[j >> 1].x = xh2; ee[j >> 1].x = e[j]; }
+      }
+      if (!FULLC) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (c0 + j >= p.C) g[j] = 0.f;
       }
       const uint4 q4 = pack8(g);
       *reinterpret_cast<uint4*>(win + r*BF_LDW + cl) = q4;
-      if (centre) {                                      // bias gradient = sum of (rounded) dz2
-        float gr[8]; unpack8(q4, gr);
+      if (centre) {                                      // (row-uniform per thread: one branch, packed math)
+        float gr[8]; unpack8(q4, gr);                    // bias gradient = sum of (rounded) dz2
+        da2 = __builtin_fmaf(0.5f, uz, da2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dbia[j] += f32x2{gr[2*j], gr[2*j + 1]};
+        for (int j = 0; j < 4; ++j) {
+          dbia[j] += f32x2{gr[2*j], gr[2*j + 1]};
+          dgam2[j] += ee[j]*xg[j]; dbet2[j] += ee[j];
+        }
       }
     }
   }
@@ -358,20 +384,13 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   const float a1 = *p.slope1;
   const float xa = 0.5f*(1.f + a1)*ns.rstd, xb = 0.5f*(1.f - a1)*ns.rstd, xc = -ns.mean*ns.rstd;
   f32x2 gm[4], be[4], w[P][4];
-  {
-    float g8[8], b8[8], tp[P][8];
-    load8_masked(p.gamma1, c0, p.C, g8);
-    load8_masked(p.beta1, c0, p.C, b8);
 #pragma unroll
-    for (int k = 0; k < P; ++k) load8_masked(p.taps, c0*P + 8*k, p.C*P, tp[k]);
+  for (int j = 0; j < 4; ++j) {
+    gm[j] = f32x2{ptab[HL_CG + cl + 2*j], ptab[HL_CG + cl + 2*j + 1]};
+    be[j] = f32x2{ptab[2*HL_CG + cl + 2*j], ptab[2*HL_CG + cl + 2*j + 1]};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      gm[j] = f32x2{g8[2*j], g8[2*j + 1]};
-      be[j] = f32x2{b8[2*j], b8[2*j + 1]};
-#pragma unroll
-      for (int k = 0; k < P; ++k)
-        w[k][j] = f32x2{tp[(2*j*P + k)/8][(2*j*P + k)%8], tp[((2*j + 1)*P + k)/8][((2*j + 1)*P + k)%8]};
-    }
+    for (int k = 0; k < P; ++k)
+      w[k][j] = f32x2{ptab[(3 + k)*HL_CG + cl + 2*j], ptab[(3 + k)*HL_CG + cl + 2*j + 1]};
   }
   f32x2 dgam[4], dbet[4], dtap[P][4];
 #pragma unroll
@@ -385,9 +404,9 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   float l1 = 0.f, l2 = 0.f;
   // output row i -> frame: tooth q0 + i / R, residue r0 + i % R
   auto out_frame = [&](int i, bool& ok) {
-    const int ro = r0 + i % R;
+    const int ro = r0 + (i & (R - 1));
     ok = i < KR && ro < d;
-    return (q0 + i / R)*d + ro;
+    return (q0 + (i >> lgR))*d + ro;
   };
   for (int i0 = rslot; i0 < KR; i0 += 128) {
    uint4 qz4[4];
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       // output frame that reads frame t through tap k: window tooth (i / R) + P - 1 - k, same residue
-      const int r = (i / R + P - 1 - k)*R + i % R;
+      const int r = (((i >> lgR) + P - 1 - k) << lgR) + (i & (R - 1));
       float g[8];
       unpack8(*reinterpret_cast<const uint4*>(win + r*BF_LDW + cl), g);
 #pragma unroll
