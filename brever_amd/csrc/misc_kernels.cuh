@@ -243,6 +243,43 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long long n,
   if (threadIdx.x == 0) atomic_add_f64(acc, s);
 }
 
+// g += g2, g2 = 0, and the squared norm of the sum: the step end of two kernel chains that wrote their
+// weight gradients to two buffers (one pass instead of add + norm passes; the second buffer is left
+// zeroed for the next step, so it is never memset)
+__global__ __launch_bounds__(256) void sum_sumsq_kernel(float* g, float* g2, long long n,
+                                                        double* acc) {
+  __shared__ double dscr[8];
+  double a = 0;
+  const long long n4 = n/4;
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* h4 = reinterpret_cast<float4*>(g2);
+  for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n4;
+       i += (long long)gridDim.x*256) {
+    float4 v = g4[i];
+    const float4 w = h4[i];
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    g4[i] = v;
+    h4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    a += (double)v.x*v.x + (double)v.y*v.y + (double)v.z*v.z + (double)v.w*v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - n4*4) {
+    const long long i = n4*4 + threadIdx.x;
+    const float v = g[i] + g2[i];
+    g[i] = v; g2[i] = 0.f;
+    a += (double)v*v;
+  }
+  const double s = block_sum(a, dscr);
+  if (threadIdx.x == 0) atomic_add_f64(acc, s);
+}
+
+// out[0] = mean of x[0 .. n) (n small: the per-item losses of a batch)
+__global__ __launch_bounds__(64) void mean_small_kernel(const float* x, int n, float* out) {
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) a += x[i];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) out[0] = a/(float)n;
+}
+
 struct AdamParams {
   float* p; float* g; float* m; float* v; long long n;
   const double* sumsq;     // squared global gradient norm (after grad_scale)
@@ -251,6 +288,7 @@ struct AdamParams {
   float lr, beta1, beta2, eps;
   float bc1, bc2;          // 1 - beta^step
   float* norm_out;         // nullable: total norm
+  double* zero_next;       // nullable: accumulator of the NEXT step's squared norm, zeroed here
 };
 __global__ __launch_bounds__(256) void clip_adam_kernel(const AdamParams a) {
   const double total = sqrt(*a.sumsq)*(double)a.grad_scale;
@@ -259,7 +297,10 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const AdamParams a) {
     const float c = a.max_norm/((float)total + 1e-6f);   // clip_grad_norm_
     clip = c < 1.f ? c : 1.f;
   }
-  if (a.norm_out && blockIdx.x == 0 && threadIdx.x == 0) *a.norm_out = (float)total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.norm_out) *a.norm_out = (float)total;
+    if (a.zero_next) *a.zero_next = 0.0;       // (nobody reads that slot in this launch)
+  }
   const float gs = a.grad_scale*clip;
   const float step_size = a.lr/a.bc1;
   const float rbc2 = 1.f/sqrtf(a.bc2);

@@ -226,10 +226,55 @@ int brv_clip_adam_step(float* params, float* grads, float* exp_avg, float* exp_a
   a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
   a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
-  a.norm_out = norm_out;
+  a.norm_out = norm_out; a.zero_next = nullptr;
   int ga = (int)((n + 255)/256);
   if (ga > 2048) ga = 2048;
   hipLaunchKernelGGL(clip_adam_kernel, dim3(ga), dim3(256), 0, st, a);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+// The same step in two launches instead of up to five (memset, [add], norm, clip + Adam): `scratch`
+// holds TWO fp64 accumulators, both zero before the first call; call number `slot` (0 / 1, alternating)
+// accumulates into its own and the Adam kernel zeroes the other one for the next call. `grads2`
+// (nullable): a second gradient buffer that is added into `grads` first and left zeroed.
+int brv_clip_adam_step2(float* params, float* grads, float* grads2, float* exp_avg,
+                        float* exp_avg_sq, int64_t n, float grad_scale, float max_norm, float lr,
+                        float beta1, float beta2, float eps, int64_t step, void* scratch,
+                        int32_t slot, float* norm_out, brv_stream_t stream) {
+  if (n < 1 || step < 1 || (slot != 0 && slot != 1)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  double* acc = (double*)scratch + slot;
+  int gx = (int)((n/4 + 255)/256);
+  if (gx < 1) gx = 1;
+  if (gx > 1024) gx = 1024;
+  if (grads2) hipLaunchKernelGGL(sum_sumsq_kernel, dim3(gx), dim3(256), 0, st, grads, grads2, (long long)n, acc);
+  else hipLaunchKernelGGL(sumsq_kernel, dim3(gx), dim3(256), 0, st, grads, (long long)n, acc);
+  OPS_OK(hipGetLastError());
+  AdamParams a;
+  a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+  a.sumsq = acc; a.grad_scale = grad_scale; a.max_norm = max_norm;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  a.norm_out = norm_out; a.zero_next = (double*)scratch + (1 - slot);
+  int ga = (int)((n + 255)/256);
+  if (ga > 2048) ga = 2048;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(ga), dim3(256), 0, st, a);
+  OPS_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_memset_zero(void* ptr, int64_t bytes, brv_stream_t stream) {
+  if (bytes < 0) return -1;
+  if (bytes == 0) return 0;
+  OPS_OK(hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream));
+  return 0;
+}
+
+int brv_mean_f32(const float* x, int64_t n, float* out, brv_stream_t stream) {
+  if (n < 1 || n > (1 << 20)) return -1;
+  hipLaunchKernelGGL(mean_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, x, (int)n, out);
   OPS_OK(hipGetLastError());
   return 0;
 }

@@ -269,6 +269,10 @@ SIGNATURES = {
     'brv_si_scale_forward': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*3 + [_c_f32, _c_ptr]),
     'brv_si_scale_backward': (ctypes.c_int, [_c_ptr]*6 + [_c_i64]*3 + [_c_ptr]),
     'brv_ema_update': (ctypes.c_int, [_c_ptr, _c_ptr, _c_f32, _c_i64, _c_ptr]),
+    'brv_clip_adam_step2': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64] + [_c_f32]*6
+                            + [_c_i64, _c_ptr, ctypes.c_int32, _c_ptr, _c_ptr]),
+    'brv_memset_zero': (ctypes.c_int, [_c_ptr, _c_i64, _c_ptr]),
+    'brv_mean_f32': (ctypes.c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr]),
     'brv_clip_adam_step': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr,
                                           _c_i64, _c_f32, _c_f32, _c_f32,
                                           _c_f32, _c_f32, _c_f32, _c_i64,

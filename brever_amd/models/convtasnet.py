@@ -523,7 +523,7 @@ class ConvTasNet(BreverBaseModel):
                 hip.ptr(scratch), hip.ptr(gscale), hip.ptr(d_out), hip.stream()),
                 'brv_snr_backward')
             grads = self.flat_grads()
-            grads.zero_()
+            hip.check(lib.brv_memset_zero(hip.ptr(grads), 4*grads.numel(), hip.stream()), 'brv_memset_zero')
             sync = self._grad_sync
             grad_scale = 1.0
             if sync is not None and getattr(sync, 'nparts', 1) > 1:
@@ -536,7 +536,9 @@ class ConvTasNet(BreverBaseModel):
                 if sync is not None:
                     grad_scale = sync(grads)
             self.optimizer.step(max_norm=self.grad_clip, grad_scale=grad_scale)
-            return loss_b.mean()
+            loss = torch.empty((), dtype=torch.float32, device=out.device)
+            hip.check(lib.brv_mean_f32(hip.ptr(loss_b), B, hip.ptr(loss), hip.stream()), 'brv_mean_f32')
+            return loss
 
     def _train_step_two_chains(self, inputs, labels, lengths):
         """The fused bf16 step as TWO independent half-batch chains on two streams. Every launch of
@@ -559,7 +561,9 @@ class ConvTasNet(BreverBaseModel):
             self._prepare()
             t = self._two_chain_buffers(B, S, L, dev)
             grads = self.flat_grads()
-            grads.zero_()
+            # (no PyTorch kernel between here and the end of the step: memsets, the sum of the two
+            # chains' gradients, the loss mean and the optimizer are library launches)
+            hip.check(lib.brv_memset_zero(hip.ptr(grads), 4*grads.numel(), hip.stream()), 'brv_memset_zero')
             main, side = torch.cuda.current_stream(dev), t['side']
             side.wait_stream(main)
             # persistent kernels at 7/8 of the CUs while two chains share the chip (csrc: num_cus) --
@@ -578,7 +582,10 @@ class ConvTasNet(BreverBaseModel):
                 with torch.cuda.stream(streams[h]):
                     st = hip.stream()
                     if h == 1:
-                        t['grad2'].zero_()
+                        if not t['grad2_zero']:
+                            hip.check(lib.brv_memset_zero(hip.ptr(t['grad2']), 4*t['grad2'].numel(), st),
+                                      'brv_memset_zero')
+                        t['grad2_zero'] = False        # (until this step's sum pass has re-zeroed it)
                     hip.check(lib.brv_ctn_forward(cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x),
                                                   hip.ptr(out), Bh, L, po, st), 'brv_ctn_forward')
                     hip.check(lib.brv_snr_forward(hip.ptr(out), hip.ptr(y), hip.ptr(ln), Bh, S, L, L,
@@ -598,20 +605,34 @@ class ConvTasNet(BreverBaseModel):
                             cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x), hip.ptr(d_out),
                             hip.ptr(grads if h == 0 else t['grad2']), Bh, L, part, nparts, po, hip.stream()),
                             'brv_ctn_backward_part')
-                # this part's slice of the gradient is final in both halves: sum it (and hand it to the
-                # bucketed all-reduce) while the next part's chains run
+                # this part's slice of the gradient is final in both halves
                 main.wait_stream(side)
                 off, cnt = buckets[part]
-                if cnt:
-                    grads[off:off + cnt].add_(t['grad2'][off:off + cnt])
-                    if nparts > 1:
-                        sync.bucket(part, grads[off:off + cnt])
-            if sync is None:
-                grad_scale = 1.0
+                if cnt and nparts > 1:
+                    # bucketed all-reduce: sum the slice now and hand it over while the next part's
+                    # chains run (the second buffer is re-zeroed at the next step's start)
+                    hip.check(lib.brv_axpby(hip.ptr(grads[off:]), 1.0, hip.ptr(t['grad2'][off:]), 1.0,
+                                            hip.ptr(grads[off:]), cnt, hip.stream()), 'brv_axpby')
+                    sync.bucket(part, grads[off:off + cnt])
+            if nparts > 1:
+                grad_scale, second = sync.finish(), None
+                t['grad2_zero'] = False
             else:
-                grad_scale = sync.finish() if nparts > 1 else sync(grads)
-            self.optimizer.step(max_norm=self.grad_clip, grad_scale=grad_scale)
-            return t['loss'].mean()
+                # one pass: grads += grad2, grad2 = 0, squared norm -- then [all-reduce] clip + Adam
+                second = t['grad2']
+                t['grad2_zero'] = True
+                if sync is None:
+                    grad_scale = 1.0
+                else:
+                    hip.check(lib.brv_axpby(hip.ptr(grads), 1.0, hip.ptr(second), 1.0, hip.ptr(grads),
+                                            grads.numel(), hip.stream()), 'brv_axpby')
+                    hip.check(lib.brv_memset_zero(hip.ptr(second), 4*second.numel(), hip.stream()),
+                              'brv_memset_zero')
+                    grad_scale, second = sync(grads), None
+            self.optimizer.step(max_norm=self.grad_clip, grad_scale=grad_scale, grads2=second)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            hip.check(lib.brv_mean_f32(hip.ptr(t['loss']), B, hip.ptr(loss), hip.stream()), 'brv_mean_f32')
+            return loss
 
     def _two_chain_buffers(self, B, S, L, dev):
         """Buffers of the two-chain step. GROW-ONLY (the trainer's dynamic batches change (B, L) almost
@@ -630,7 +651,7 @@ class ConvTasNet(BreverBaseModel):
         if t is None or t['dev'] != dev:
             t = self._two = dict(dev=dev, side=torch.cuda.Stream(device=dev), cap_out=0, cap_scr=0, cap_b=0,
                                  out_flat=None, d_out_flat=None, scr_flat=None, loss_flat=None,
-                                 gscale_flat=None, grad2=torch.empty_like(self._flat))
+                                 gscale_flat=None, grad2=torch.zeros_like(self._flat), grad2_zero=True)
         # both halves inside the shared workspace (invalidates a saved autograd forward, like any forward)
         ws = self._workspace.get(True)
         if ws is None or ws.numel() < 2*nws or ws.device != dev:
@@ -664,7 +685,8 @@ class ConvTasNet(BreverBaseModel):
         t['loss'] = t['loss_flat'][:B]
         t['gscale'] = t['gscale_flat'][:B]
         if t['grad2'].device != dev or t['grad2'].numel() != self._flat.numel():
-            t['grad2'] = torch.empty_like(self._flat)
+            t['grad2'] = torch.zeros_like(self._flat)
+            t['grad2_zero'] = True
         return t
 
     def _step_buffers(self, B, S, L, device):

@@ -24,6 +24,7 @@ class FlatAdam(torch.optim.Adam):
         self._exp_avg_sq = None
         self._step_count = 0
         self._scratch = None
+        self._slot = 0
         self.last_grad_norm = None
 
     # -- flat state ------------------------------------------------------------
@@ -39,6 +40,7 @@ class FlatAdam(torch.optim.Adam):
             self._exp_avg.copy_(old_m)
             self._exp_avg_sq.copy_(old_v)
         self._scratch = torch.zeros(64, dtype=torch.uint8, device=flat.device)
+        self._slot = 0
         self.last_grad_norm = torch.zeros(1, dtype=torch.float32,
                                           device=flat.device)
         self._bind_state()
@@ -68,18 +70,21 @@ class FlatAdam(torch.optim.Adam):
             self._exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
             self._step_count = int(float(st['step']))
         self._scratch = torch.zeros(64, dtype=torch.uint8, device=flat.device)
+        self._slot = 0
         self.last_grad_norm = torch.zeros(1, dtype=torch.float32,
                                           device=flat.device)
         self._bind_state()
 
     # -- step --------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, closure=None, max_norm=0.0, grad_scale=1.0):
+    def step(self, closure=None, max_norm=0.0, grad_scale=1.0, grads2=None):
         """One Adam step on the flat buffers.
 
         ``max_norm > 0`` folds ``clip_grad_norm_(max_norm)`` into the same
         launch; ``grad_scale`` multiplies the gradient first (``1/world_size``
-        after a summing all-reduce).
+        after a summing all-reduce); ``grads2``: a second flat gradient buffer (the
+        other kernel chain's) that is added in the norm pass and left zeroed.
+        Two launches in all (``brv_clip_adam_step2``).
         """
         loss = None
         if closure is not None:
@@ -93,11 +98,13 @@ class FlatAdam(torch.optim.Adam):
         self._step_count += 1
         next(iter(self.state.values()))['step'].fill_(float(self._step_count))
         beta1, beta2 = group['betas']
-        hip.check(hip.lib().brv_clip_adam_step(
-            hip.ptr(flat), hip.ptr(grads), hip.ptr(self._exp_avg),
+        slot = self._slot
+        self._slot = 1 - slot           # the kernel zeroes the other accumulator for the next call
+        hip.check(hip.lib().brv_clip_adam_step2(
+            hip.ptr(flat), hip.ptr(grads), hip.ptr(grads2), hip.ptr(self._exp_avg),
             hip.ptr(self._exp_avg_sq), flat.numel(), float(grad_scale),
             float(max_norm), float(group['lr']), float(beta1), float(beta2),
-            float(group['eps']), self._step_count, hip.ptr(self._scratch),
-            hip.ptr(self.last_grad_norm), hip.stream()), 'brv_clip_adam_step')
+            float(group['eps']), self._step_count, hip.ptr(self._scratch), slot,
+            hip.ptr(self.last_grad_norm), hip.stream()), 'brv_clip_adam_step2')
         self._owner.mark_params_changed()
         return loss

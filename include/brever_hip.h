@@ -746,6 +746,19 @@ int brv_clip_adam_step(float* params, float* grads, float* exp_avg,
                        float max_norm, float lr, float beta1, float beta2,
                        float eps, int64_t step, void* scratch, float* norm_out,
                        brv_stream_t stream);
+/* The same step in two launches (no memset, no separate add): `scratch` holds two fp64 accumulators,
+ * both zero before the first call; call `slot` (0 / 1, alternating between consecutive calls)
+ * accumulates the squared norm into its own and the Adam kernel zeroes the other for the next call.
+ * `grads2` (nullable): the weight gradient of a second kernel chain (brever_amd/models/convtasnet.py:
+ * two half-batch chains), added into `grads` in the norm pass and left ZEROED for the next step. */
+int brv_clip_adam_step2(float* params, float* grads, float* grads2, float* exp_avg,
+                        float* exp_avg_sq, int64_t n, float grad_scale, float max_norm,
+                        float lr, float beta1, float beta2, float eps, int64_t step,
+                        void* scratch, int32_t slot, float* norm_out, brv_stream_t stream);
+/* hipMemsetAsync(ptr, 0, bytes) and the mean of n <= 2^20 floats (per-item losses -> the step's
+ * loss): the host's training step issues no PyTorch kernel between forward and optimizer. */
+int brv_memset_zero(void* ptr, int64_t bytes, brv_stream_t stream);
+int brv_mean_f32(const float* x, int64_t n, float* out, brv_stream_t stream);
 
 /* Exponential moving average of the parameters (EMA / EMAKarras.update,
  * brever/modules/ema.py:36-39): ema += (1 - beta)*(param - ema), rounded as the reference. */
