@@ -85,37 +85,47 @@ def physical_cores():
 
 
 def cpu_baseline():
-    """Oracle (pure-PyTorch CPU restatement of the reference path) timed on the host cores on
-    the benchmark configuration itself: ONE train step of 16 x 4 s utterances in fp32 and one
-    under CPU bf16 autocast (the reference's CPU autocast dtype, convtasnet.py:81), after a
-    2-utterance warm-up step each; threads = physical cores. `value` is the fp32 figure."""
+    """Oracle (pure-PyTorch CPU restatement of the reference path) timed on the host cores (SURVEY.md
+    8d), bounded to about a minute: the thread count is scanned over {8, 32, physical cores} on train
+    steps of 4 x 4 s utterances (one warm-up step on 2 utterances each), then ONE train step of the
+    benchmark batch itself (16 x 4 s, fp32) is timed at the best count = `value`; `by_threads` holds
+    the scan (all physical cores oversubscribe the host: VERDICT r02 item 9), `value_cpu_bf16` a
+    4-utterance step under CPU bf16 autocast (the reference's CPU autocast dtype, convtasnet.py:81)."""
     from oracle.convtasnet import OracleConvTasNet
     cores = physical_cores()
-    torch.set_num_threads(cores)
     model_transform = lambda s: s.mean(axis=-2)   # noqa: E731
     dset = SyntheticMixtureDataset(BATCH, int(SECONDS*FS), transform=model_transform)
     batch, lengths = BreverDataLoader._collate_fn([dset[i] for i in range(BATCH)])
     scaler = torch.amp.GradScaler('cuda', enabled=False)
-    out = {}
-    for name, amp in (('fp32', False), ('bf16', True)):
+
+    def run(threads, amp, items):
+        torch.set_num_threads(threads)
         torch.manual_seed(0)
         model = OracleConvTasNet()
         model.train_step(batch[:2], lengths[:2], amp, scaler)      # warm-up (threads, allocator)
         t0 = time.perf_counter()
-        model.train_step(batch, lengths, amp, scaler)
-        out[name] = BATCH/(time.perf_counter() - t0)
+        model.train_step(batch[:items], lengths[:items], amp, scaler)
+        return items/(time.perf_counter() - t0)
+
+    counts = sorted({min(8, cores), min(32, cores), cores})
+    by_threads = {n: run(n, False, 4) for n in counts}
+    best = max(by_threads, key=by_threads.get)
+    value = run(best, False, BATCH)
+    bf16 = run(best, True, 4)
     return {
-        'value': out['fp32'], 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
-        'value_cpu_bf16': out['bf16'],
-        'sample': f'1 train step of {BATCH} x 4 s utterances (after a 2-utterance warm-up step), '
-                  'Conv-TasNet defaults, torch CPU oracle, fp32 (value) and CPU bf16 autocast '
-                  f'(value_cpu_bf16), {cores} threads = physical cores',
+        'value': value, 'unit': 'utterances/s', 'cores': best, 'kind': 'port',
+        'physical_cores': cores, 'by_threads': {str(k): v for k, v in by_threads.items()},
+        'value_cpu_bf16': bf16,
+        'sample': f'value: 1 train step of {BATCH} x 4 s utterances, Conv-TasNet defaults, torch CPU oracle, '
+                  f'fp32, {best} threads = the best of {counts} (by_threads: 1 step of 4 utterances each; a '
+                  '2-utterance warm-up step before every timed step); value_cpu_bf16: 1 step of 4 utterances '
+                  f'under CPU bf16 autocast at {best} threads',
     }
 
 
 # bench label -> substring of the HIP kernel name in the rocprofv3 output
 KERNEL_OF_LABEL = {
-    'gln_prelu_bwd': 'dz_kernel', 'dwconv_bwd': 'dwconv_bwd_halo_kernel',
+    'gln_prelu_bwd': 'dz_kernel', 'dwconv_bwd': 'dwconv_bwd_halo_kernel', 'dwpw2_bwd': 'dwconv_bwd_fused_kernel',
     'dwconv_fwd': 'dwconv_fwd_kernel', 'pw2_wgrad': 'wgrad_full_kernel',
     # (fused forward: 23 of the 24 first-conv launches finish the block input while staging it)
     'pw1_fwd': ['gemm_ws_kernel<128, 64, 1, 0, 2,', 'gemm_ws_kernel<128, 64, 1, 0,'],
@@ -286,8 +296,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        from brever_amd.parallel import init_process_group
+        init_process_group('nccl', device_id=device)      # 120 s timeout: a bad rendezvous exits non-zero
 
     torch.manual_seed(0)
     model = ConvTasNet().to(device)          # defaults = BASELINE config
@@ -304,6 +314,18 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    fallback = None
+    if sync is not None and args.buckets > 1:
+        # the bucketed all-reduce must hide behind backward; if the warm-up shows more than 0.5 ms of
+        # it exposed on any rank (xGMI ring latency x buckets), use ONE all-reduce after backward
+        t = torch.tensor([sync.exposed_ms()], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t) > 0.5:
+            fallback = (f'one all-reduce after backward: {args.buckets} buckets left {float(t):.2f} ms '
+                        'exposed per step in the warm-up')
+            sync = GradSynchronizer(model, nparts=1)
+            for i in range(max(2, args.warmup//2)):
+                step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -357,9 +379,14 @@ def main():
                 'ms_per_step': trainer_ms,
                 'path': 'host items -> BucketBatchSampler -> BreverDataLoader collate -> pinned '
                         'double-buffered async H2D (DevicePrefetcher) -> train_step'}
+        line['two_chain'] = bool(ConvTasNet.uses_two_chains(BATCH, True))
         if exposed is not None:
             line['allreduce_exposed_ms'] = exposed
-            line['allreduce_buckets'] = args.buckets
+            line['allreduce_buckets'] = sync.nparts
+            line['rccl_world_size'] = dist.get_world_size()
+            line['hw_queues_ok'] = bool(__import__('brever_amd').HW_QUEUES_OK)
+            if fallback:
+                line['allreduce_fallback'] = fallback
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         if args.kernel_table:

@@ -506,8 +506,7 @@ class ConvTasNet(BreverBaseModel):
         S = self.output_sources
         amp = bool(use_amp)
         sync = self._grad_sync
-        if amp and B >= 8 and B % 2 == 0 and os.environ.get('BRV_CTN_STREAMS', '2') != '1' \
-                and (_queues_ok() or not _process_group()):
+        if self.uses_two_chains(B, amp):
             return self._train_step_two_chains(inputs, labels, lengths)
         with torch.no_grad():
             out = self._hip_forward(inputs, amp)
@@ -539,6 +538,17 @@ class ConvTasNet(BreverBaseModel):
             loss = torch.empty((), dtype=torch.float32, device=out.device)
             hip.check(lib.brv_mean_f32(hip.ptr(loss_b), B, hip.ptr(loss), hip.stream()), 'brv_mean_f32')
             return loss
+
+    @staticmethod
+    def uses_two_chains(B, amp):
+        """Whether the fused bf16 step of a batch of ``B`` runs as two half-batch kernel chains on two
+        streams: even batches of >= 8, unless ``BRV_CTN_STREAMS=1`` -- and never next
+        to an initialised process group when the HIP runtime cannot have seen >= 8 hardware queues
+        (``brever_amd.HW_QUEUES_OK``: torch imported before the package and ``GPU_MAX_HW_QUEUES`` not
+        exported): with the default 4 queues RCCL's streams and the two chains share queues and the
+        step is slower than one chain (9.6 vs 7.7 ms)."""
+        return bool(amp) and B >= 8 and B % 2 == 0 and os.environ.get('BRV_CTN_STREAMS', '2') != '1' \
+            and (_queues_ok() or not _process_group())
 
     def _train_step_two_chains(self, inputs, labels, lengths):
         """The fused bf16 step as TWO independent half-batch chains on two streams. Every launch of

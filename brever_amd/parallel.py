@@ -19,8 +19,21 @@ here explicitly:
 * any other model gets post-accumulate-grad hooks that average each ``.grad``
   over ranks during backward, i.e. before clipping and the optimizer step.
 """
+import datetime
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def init_process_group(backend, timeout_s=None, **kwargs):
+    """``dist.init_process_group`` with a SHORT rendezvous / collective timeout (120 s, or
+    ``BRV_DIST_TIMEOUT_S``): a rank that cannot reach the others exits non-zero instead of hanging for
+    torch's default half hour. Rendezvous on 127.0.0.1 unless MASTER_ADDR says otherwise (one node)."""
+    if timeout_s is None:
+        timeout_s = float(os.environ.get('BRV_DIST_TIMEOUT_S', '120'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    return dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
 
 
 def broadcast_parameters(model, src=0):

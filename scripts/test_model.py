@@ -196,7 +196,8 @@ def main(i_input, input_, args):
     device = 'cuda' if args.cuda else 'cpu'
     if args.ddp and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl' if args.cuda else 'gloo')
+        from brever_amd.parallel import init_process_group
+        init_process_group('nccl' if args.cuda else 'gloo')
     if dist.is_initialized():
         rank = dist.get_rank()
         if args.cuda:

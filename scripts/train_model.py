@@ -68,7 +68,8 @@ def main(args):
     if cfg.trainer.ddp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # nccl == RCCL on ROCm
-        dist.init_process_group(backend)
+        from brever_amd.parallel import init_process_group
+        init_process_group(backend)
         rank = dist.get_rank()
         if torch.cuda.is_available():
             device = rank % torch.cuda.device_count()

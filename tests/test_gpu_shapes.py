@@ -358,3 +358,55 @@ def test_fused_backward_equals_three_launch_backward(monkeypatch, layers, repeat
             assert e <= 1.5e-2, e
             worst = _per_tensor(net, grads['1'], grads['0'], 5e-2, min_numel=128, min_norm=1e-5)
             print('   worst tensor', worst)
+
+
+def test_two_models_step_from_two_threads():
+    """SURVEY 8b "no global mutable state; re-entrant": two models stepped concurrently from two host
+    threads on two streams (one taking the two-chain step with its persistent kernels at 7/8 of the CUs,
+    the other the one-chain step at 8/8 -- what used to be a process-global switch) end where the same
+    steps run one after the other from one thread end."""
+    import threading
+
+    from brever_amd.models import ConvTasNet
+    dev = _cuda()
+    cfg = dict(layers=3, repeats=2)
+    gen = torch.Generator().manual_seed(5)
+    data = {}
+    for name, B in (('a', 8), ('b', 3)):
+        batch, lengths = _ragged_batch(gen, B, 6000)
+        data[name] = (batch.to(dev), lengths.to(dev))
+
+    def make(seed):
+        torch.manual_seed(seed)
+        return ConvTasNet(**cfg).to(dev)
+
+    def run(net, name, stream, out):
+        batch, lengths = data[name]
+        with torch.cuda.stream(stream):
+            out[name] = [float(net.train_step(batch, lengths, True, None)) for _ in range(4)]
+        stream.synchronize()
+
+    # reference: one thread, one after the other
+    ref_nets = {'a': make(1), 'b': make(2)}
+    ref = {}
+    for name in ('a', 'b'):
+        run(ref_nets[name], name, torch.cuda.current_stream(dev), ref)
+    torch.cuda.synchronize()
+    # two threads, two streams, at the same time
+    nets = {'a': make(1), 'b': make(2)}
+    got = {}
+    streams = {'a': torch.cuda.Stream(device=dev), 'b': torch.cuda.Stream(device=dev)}
+    for s in streams.values():
+        s.wait_stream(torch.cuda.current_stream(dev))
+    threads = [threading.Thread(target=run, args=(nets[n], n, streams[n], got)) for n in ('a', 'b')]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for name in ('a', 'b'):
+        # (not bitwise: the statistics accumulate with atomics, and Adam's first updates lr*sign(g) turn a
+        # rounding difference of a near-zero gradient into a 2e-3 step of that weight)
+        assert abs(got[name][0] - ref[name][0]) <= 1e-5, (name, got[name], ref[name])
+        assert max(abs(x - y) for x, y in zip(got[name], ref[name])) <= 5e-3, (name, got[name], ref[name])
+        assert rel(nets[name].flat_params(), ref_nets[name].flat_params()) <= 2e-2, name

@@ -518,3 +518,44 @@ def test_dynamic_mixing_through_an_installed_mixture_maker(tmp_path):
         assert seg[0].shape == (2, 2, 8000)
     finally:
         data.set_mixture_maker(None)
+
+
+def test_two_chain_gating(monkeypatch):
+    """the two-chain step must fall back to one chain next to a process group when
+    the HIP runtime cannot have seen GPU_MAX_HW_QUEUES >= 8 (torch imported before brever_amd without
+    the variable exported), and for odd / small batches, fp32 and BRV_CTN_STREAMS=1."""
+    import brever_amd
+    from brever_amd.models import convtasnet as M
+    two = M.ConvTasNet.uses_two_chains
+    monkeypatch.delenv('BRV_CTN_STREAMS', raising=False)
+    monkeypatch.setattr(M, '_process_group', lambda: False)
+    monkeypatch.setattr(brever_amd, 'HW_QUEUES_OK', False)
+    assert two(16, True) and two(8, True)                # no process group: the queues do not matter
+    assert not two(16, False) and not two(7, True) and not two(6, True) and not two(9, True)
+    monkeypatch.setattr(M, '_process_group', lambda: True)
+    assert not two(16, True)                             # RCCL next to it, queues not guaranteed
+    monkeypatch.setattr(brever_amd, 'HW_QUEUES_OK', True)
+    assert two(16, True)
+    monkeypatch.setenv('BRV_CTN_STREAMS', '1')
+    assert not two(16, True)
+
+
+def test_hw_queues_flag_follows_the_effective_value():
+    """ADVICE r02: an exported GPU_MAX_HW_QUEUES below 8 must switch the two-chain step off next to RCCL;
+    the package default only counts when torch was not loaded first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = 'import brever_amd; print(int(brever_amd.HW_QUEUES_OK))'
+    code_torch_first = 'import torch; import brever_amd; print(int(brever_amd.HW_QUEUES_OK))'
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    env['PYTHONPATH'] = root
+
+    def run(c, **extra):
+        return subprocess.run([sys.executable, '-c', c], env=dict(env, **extra), capture_output=True,
+                              text=True, check=True).stdout.strip()
+    assert run(code) == '1'                                   # default 8 set before the runtime loads
+    assert run(code, GPU_MAX_HW_QUEUES='4') == '0'            # exported too small
+    assert run(code, GPU_MAX_HW_QUEUES='16') == '1'
+    assert run(code_torch_first) == '0'                       # default came too late
+    assert run(code_torch_first, GPU_MAX_HW_QUEUES='8') == '1'
