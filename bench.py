@@ -134,7 +134,7 @@ KERNEL_OF_LABEL = {
     'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': 'gemm_rows_kernel<128, 3, 5>',
     'pw1_wgrad': ('gemm_wgrad_kernel<128, 0>', 'largest'), 'clip_adam': 'clip_adam_kernel',
 }
-PMC_FILES = ('r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
+PMC_FILES = ('r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
 
 
 def pmc_traffic(label):

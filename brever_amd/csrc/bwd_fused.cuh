@@ -40,20 +40,31 @@ struct BwdFusedParams {
   const bf16_t* Wp;        // W^T [Hp][Kg] in fragment order, slices of 32 channels (p_rs_bp)
   const float* gamma2;
   float* dgamma2; float* dbeta2;    // replicated like the other per-channel gradients
-  int K;                   // centre teeth per tile (host: balanced over the tooth groups)
+  int K, R;                // centre teeth per tile, rows per tooth (host: bf_tile_shape)
 };
 
 constexpr int BF_ROWS = 256;               // window rows (teeth x rows per tooth), 8 MFMA groups of 32
 constexpr int BF_LDW = HL_CG + 8;          // halves per window row: 144 B
 constexpr int BF_LDS = BF_ROWS*BF_LDW*2 + 32*HL_CG*4;   // window + the reduction scratch
 
-// centre teeth per tile: as many as the window holds, balanced over the tooth groups
-inline int bf_tile_teeth(int T, int dil, int P) {
-  const int R = hl_rows_per_tooth(dil);
-  const int kmax = BF_ROWS/R - (P - 1);
+// Tile shape (K centre teeth x R rows per tooth, window (K + P - 1) R <= BF_ROWS rows): the pair with the
+// fewest tiles per item, teeth balanced over the tooth groups. R need not be a power of two: at dilation
+// 128 and T = 3999 (32 teeth) 7 rows x 32 teeth give 19 tiles where 8 x 16 gave 32 -- the per-workgroup
+// costs (parameter table, folds, atomics) made that dilation 94 us against 73 us at dilation 1.
+inline void bf_tile_shape(int T, int dil, int P, int& K, int& R) {
   const int n_teeth = (T - 1)/dil + 1;
-  const int n_qt = ceil_div(n_teeth, kmax);
-  return ceil_div(n_teeth, n_qt);
+  long long best = -1;
+  K = 1; R = 1;
+  for (int r = 1; r <= HL_RMAX*2 && r <= dil; ++r) {
+    const int kmax = BF_ROWS/r - (P - 1);
+    if (kmax < 1) break;
+    const int n_qt = ceil_div(n_teeth, kmax);
+    const int k = ceil_div(n_teeth, n_qt);
+    const long long tiles = (long long)n_qt*ceil_div(dil, r);
+    // fewest tiles; among equals the fewest window rows in total (halo), then the longer runs of frames
+    const long long cost = tiles*100000 + tiles*(k + P - 1)*r;
+    if (best < 0 || cost <= best) { best = cost; K = k; R = r; }
+  }
 }
 
 // KG: reduction length of phase 0 (compile time: the chunk loop is straight-line code, so every wait of
@@ -68,8 +79,9 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   float* red = reinterpret_cast<float*>(dyn_lds + BF_ROWS*BF_LDW*2);   // 32*HL_CG floats
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = p.T, d = p.dil;
-  const int R = hl_rows_per_tooth(d), K = fp.K;
-  const int lgR = 31 - __builtin_clz(R);                // R is a power of two: shifts, not divisions
+  const int R = fp.R, K = fp.K;
+  const float invR = 1.f/(float)R;                      // r / R for r < 512 (exact: (r + 0.5) / R is never within 1e-3 of an integer)
+  auto divR = [&](int r, int& rem) { const int q = (int)(((float)r + 0.5f)*invR); rem = r - q*R; return q; };
   const int n_rt = ceil_div(d, R);                       // residue groups
   const int n_teeth = (T - 1)/d + 1;
   const int n_qt = ceil_div(n_teeth, K);                 // tooth groups
@@ -94,7 +106,8 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   const int qbase = q0 - (P - 1) + p.left/d;           // tooth of window row 0
   // window row r -> frame: tooth qbase + r / R, residue r0 + r % R
   auto frame_of = [&](int r, bool& ok) {
-    const int qi = r >> lgR, ri = r & (R - 1);
+    int ri;
+    const int qi = divR(r, ri);
     const int q = qbase + qi;
     ok = r < W && q >= 0 && r0 + ri < d;
     return q*d + r0 + ri;
@@ -278,7 +291,8 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
       const float on = in ? 1.f : 0.f;
       const float rr = on*R2, k0 = on*K0, mm = on*M2R;
       // each element is "owned" by the tile whose teeth [q0, q0 + K) contain it
-      const int q = qbase + (r >> lgR);
+      int rem_;
+      const int q = qbase + divR(r, rem_);
       const bool centre = in && q >= q0 && q < q0 + K;
       float uz = 0.f;                                    // sum over the row's 8 channels of uu min(z, 0)
       f32x2 xg[4], ee[4];
@@ -404,9 +418,11 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   float l1 = 0.f, l2 = 0.f;
   // output row i -> frame: tooth q0 + i / R, residue r0 + i % R
   auto out_frame = [&](int i, bool& ok) {
-    const int ro = r0 + (i & (R - 1));
+    int ri;
+    const int qi = divR(i, ri);
+    const int ro = r0 + ri;
     ok = i < KR && ro < d;
-    return (q0 + (i >> lgR))*d + ro;
+    return (q0 + qi)*d + ro;
   };
   for (int i0 = rslot; i0 < KR; i0 += 128) {
    uint4 qz4[4];
@@ -437,7 +453,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       // output frame that reads frame t through tap k: window tooth (i / R) + P - 1 - k, same residue
-      const int r = (((i >> lgR) + P - 1 - k) << lgR) + (i & (R - 1));
+      const int r = i + (P - 1 - k)*R;                 // same residue, tooth + P - 1 - k
       float g[8];
       unpack8(*reinterpret_cast<const uint4*>(win + r*BF_LDW + cl), g);
 #pragma unroll

@@ -447,9 +447,8 @@ template <int P> struct DwBwdFused {
   static int run(const BwdFusedParams& p0, hipStream_t st) {
     BwdFusedParams p = p0;
     const DwParams& d = p.d;
-    p.K = bf_tile_teeth(d.T, d.dil, P);
-    const int R = hl_rows_per_tooth(d.dil);
-    const int tiles = ceil_div(d.dil, R)*ceil_div((d.T - 1)/d.dil + 1, p.K);
+    bf_tile_shape(d.T, d.dil, P, p.K, p.R);
+    const int tiles = ceil_div(d.dil, p.R)*ceil_div((d.T - 1)/d.dil + 1, p.K);
     // algorithmic bytes: g (256-wide) + z2 + z1 read, e1 written
     static const char* by_dil[9] = {"dwpw2_bwd_d1", "dwpw2_bwd_d2", "dwpw2_bwd_d4", "dwpw2_bwd_d8", "dwpw2_bwd_d16",
                                     "dwpw2_bwd_d32", "dwpw2_bwd_d64", "dwpw2_bwd_d128", "dwpw2_bwd_dx"};
@@ -492,9 +491,9 @@ void set_affine(ASpec& a, const double* stats, const float* g, const float* b, i
   a.stats = stats; a.gamma = g; a.beta = b; a.C = C;
   a.inv_n = 1.0/((double)T*(double)C); a.eps = 1e-8f;
 }
-ASpec frames_of(const float* wav, long long L, int hop, int K) {
+ASpec frames_of(const float* wav, long long L, int hop, int K, long long stride = 0) {
   ASpec a; memset(&a, 0, sizeof(a));
-  a.p0 = wav; a.hop = hop; a.Kf = K; a.wav_stride = L; a.wav_len = (int)L;
+  a.p0 = wav; a.hop = hop; a.Kf = K; a.wav_stride = stride > 0 ? stride : L; a.wav_len = (int)L;
   a.K0 = 1 << 30; a.nsrc = 1;
   return a;
 }
@@ -732,8 +731,8 @@ int cln_backward(const CausalCtx& cx, const bf16_t* g, const bf16_t* z, const fl
 }
 
 int forward_causal(const Layout& l, const brv_ctn_config* cfg, const float* params,
-                   const void* prepared, void* workspace, const float* wave, float* out, int B,
-                   long long L, long long T, hipStream_t st) {
+                   const void* prepared, void* workspace, const float* wave, long long wave_stride,
+                   float* out, int B, long long L, long long T, hipStream_t st) {
   Workspace ws; ws.init(l, B, T);
   const double BT = (double)B*(double)T;
   char* base = (char*)workspace;
@@ -753,7 +752,7 @@ int forward_causal(const Layout& l, const brv_ctn_config* cfg, const float* para
 
   GemmRowsParams g;
   memset(&g, 0, sizeof(g));                                // encoder
-  g.a = frames_of(wave, L, l.hop, l.K);
+  g.a = frames_of(wave, L, l.hop, l.K, wave_stride);
   g.W = prep + l.p_enc; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
   g.e.out = w; g.e.ldo = l.Np; g.e.N = l.N;
   if (int r = launch_gemm_rows<A_FRAMES, E_STORE>(g, B, st, "enc_fwd", 4.0*B*L + 2.0*BT*l.Np)) return r;
@@ -816,8 +815,8 @@ int forward_causal(const Layout& l, const brv_ctn_config* cfg, const float* para
 }
 
 int backward_causal(const Layout& l, const brv_ctn_config* cfg, const float* params,
-                    const void* prepared, void* workspace, const float* wave, const float* d_out,
-                    float* grads, int B, long long L, long long T, hipStream_t st) {
+                    const void* prepared, void* workspace, const float* wave, long long wave_stride,
+                    const float* d_out, float* grads, int B, long long L, long long T, hipStream_t st) {
   Workspace ws; ws.init(l, B, T);
   const double BT = (double)B*(double)T;
   char* base = (char*)workspace;
@@ -946,7 +945,7 @@ int backward_causal(const Layout& l, const brv_ctn_config* cfg, const float* par
   if (int r = cln_backward(cx, e0, w, nullptr, params + l.ln_g, cx.tab(0), dwt, dw1, l.S, vg,
                            vg + l.N, nullptr, ws.vg_stride, B, T, l.Np, l.N, st)) return r;
   memset(&wg, 0, sizeof(wg));                              // encoder weight gradient
-  wg.g = rows_bf16(dwt, l.Np, T); wg.h = frames_of(wave, L, l.hop, l.K);
+  wg.g = rows_bf16(dwt, l.Np, T); wg.h = frames_of(wave, L, l.hop, l.K, wave_stride);
   wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
   wg.out0 = grads + l.enc_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
   if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_enc", 2.0*BT*l.Np + 4.0*B*L)) return r;
@@ -1155,15 +1154,16 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
 }
 
 int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* prepared,
-                    void* workspace, const float* wave, float* out, int64_t batch,
+                    void* workspace, const float* wave, int64_t wave_stride, float* out, int64_t batch,
                     int64_t length, const brv_launch_opts* opts, brv_stream_t stream) {
   OptsScope scope(opts);
+  if (wave_stride != 0 && wave_stride < length) return fail(-1, "wave_stride shorter than the rows");
   Layout l; if (int r = l.init(cfg)) return r;
   hipStream_t st = (hipStream_t)stream;
   const int B = (int)batch; const long long L = length;
   const long long T = l.frames(L);
   if (B < 1 || T < 1) return fail(-1, "empty batch or input shorter than one frame");
-  if (l.causal) return forward_causal(l, cfg, params, prepared, workspace, wave, out, B, L, T, st);
+  if (l.causal) return forward_causal(l, cfg, params, prepared, workspace, wave, wave_stride, out, B, L, T, st);
   Workspace ws; ws.init(l, B, T);
   const double BT = (double)B*(double)T;
   char* base = (char*)workspace;
@@ -1184,7 +1184,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   GemmRowsParams g;
   // encoder: framed filterbank analysis, statistics for the first gLN
   memset(&g, 0, sizeof(g));
-  g.a = frames_of(wave, L, l.hop, l.K);
+  g.a = frames_of(wave, L, l.hop, l.K, wave_stride);
   g.W = prep + l.p_enc; g.T = (int)T; g.Np = l.Np; g.Kp = l.Kfp;
   g.e.out = w; g.e.ldo = l.Np; g.e.N = l.N; g.e.stats_out = stat(0);
   if (int r = launch_gemm_rows<A_FRAMES, E_STORE>(g, B, st, "enc_fwd", 4.0*B*L + 2.0*BT*l.Np)) return r;
@@ -1478,14 +1478,16 @@ static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, con
 extern "C" {
 
 int brv_ctn_backward(const brv_ctn_config* cfg, const float* params, const void* prepared,
-                     void* workspace, const float* wave, const float* d_out, float* grads,
-                     int64_t batch, int64_t length, const brv_launch_opts* opts, brv_stream_t stream) {
-  return brv_ctn_backward_part(cfg, params, prepared, workspace, wave, d_out, grads, batch, length,
-                               0, 1, opts, stream);
+                     void* workspace, const float* wave, int64_t wave_stride, const float* d_out,
+                     float* grads, int64_t batch, int64_t length, const brv_launch_opts* opts,
+                     brv_stream_t stream) {
+  return brv_ctn_backward_part(cfg, params, prepared, workspace, wave, wave_stride, d_out, grads, batch,
+                               length, 0, 1, opts, stream);
 }
 
 int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const void* prepared,
-                          void* workspace, const float* wave, const float* d_out, float* grads,
+                          void* workspace, const float* wave, int64_t wave_stride, const float* d_out,
+                          float* grads,
                           int64_t batch, int64_t length, int32_t part, int32_t nparts,
                           const brv_launch_opts* opts, brv_stream_t stream) {
   OptsScope scope(opts);
@@ -1497,7 +1499,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   if (nparts < 1 || part < 0 || part >= nparts) return fail(-1, "bad part");
   if (l.causal) {
     if (part != nparts - 1) return 0;
-    return backward_causal(l, cfg, params, prepared, workspace, wave, d_out, grads, B, L, T, st);
+    return backward_causal(l, cfg, params, prepared, workspace, wave, wave_stride, d_out, grads, B, L, T, st);
   }
   int blk_lo, blk_hi; part_range(l.nb, part, nparts, blk_lo, blk_hi);
   const bool head = part == 0, tail = part == nparts - 1;
@@ -1728,7 +1730,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   }
   // encoder weight gradient: dw^T * frames(wave)
   memset(&wg, 0, sizeof(wg));
-  wg.g = rows_bf16(dwt, l.Np, T); wg.h = frames_of(wave, L, l.hop, l.K);
+  wg.g = rows_bf16(dwt, l.Np, T); wg.h = frames_of(wave, L, l.hop, l.K, wave_stride);
   wg.B = B; wg.T = (int)T; wg.Gp = l.Np; wg.Hp = l.Kfp;
   wg.out0 = grads + l.enc_w; wg.G0p = l.Np; wg.N0 = l.N; wg.Kout = l.K; wg.ldo = l.K;
   if (int r = launch_wgrad<A_FRAMES>(wg, st, "wgrad_enc", 2.0*BT*l.Np + 4.0*B*L, 768)) return r;

@@ -16,6 +16,7 @@ namespace brv {
 // mom[r] = {sum x, sum y, sum x^2, sum y^2, sum x*y, sum (x-y)^2}
 struct MomentsParams {
   const float* x; const float* y; long long stride; int L;
+  long long ybs, yss;                       // y row (item b, source s) starts at y + b*ybs + s*yss
   const long long* lengths; int S;          // rows per batch item
   double* mom;                              // [rows][6]
 };
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(256) void masked_moments_kernel(const MomentsParams
   long long len = p.lengths[r / p.S];
   if (len > p.L) len = p.L;
   const float* x = p.x + (long long)r*p.stride;
-  const float* y = p.y + (long long)r*p.stride;
+  const float* y = p.y + (long long)(r / p.S)*p.ybs + (long long)(r % p.S)*p.yss;
   double a[6] = {0, 0, 0, 0, 0, 0};
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < len;
        i += (long long)gridDim.x*256) {
@@ -89,6 +90,7 @@ __global__ void snr_finalize_kernel(const double* mom, int B, int S, float* loss
 
 struct SnrBwdParams {
   const float* x; const float* y; float* dx; long long stride; int L;
+  long long ybs, yss;
   const long long* lengths; int S; const float* coef; const float* gscale;  // [B]
 };
 __global__ __launch_bounds__(256) void snr_bwd_kernel(const SnrBwdParams p) {
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void snr_bwd_kernel(const SnrBwdParams p) {
   if (len > p.L) len = p.L;
   const float c = p.coef[r]*p.gscale[b];
   const float* x = p.x + (long long)r*p.stride;
-  const float* y = p.y + (long long)r*p.stride;
+  const float* y = p.y + (long long)b*p.ybs + (long long)(r % p.S)*p.yss;
   float* dx = p.dx + (long long)r*p.stride;
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < p.L;
        i += (long long)gridDim.x*256)

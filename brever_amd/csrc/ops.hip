@@ -32,10 +32,12 @@ struct LossScratch {
 };
 
 int moments(const float* x, const float* y, const int64_t* lengths, int64_t B, int64_t S,
-            int64_t L, int64_t stride, const LossScratch& sc, hipStream_t st) {
+            int64_t L, int64_t stride, const LossScratch& sc, hipStream_t st, int64_t ybs = -1,
+            int64_t yss = -1) {
   OPS_OK(hipMemsetAsync(sc.mom, 0, sc.zero_bytes, st));
   MomentsParams p;
   p.x = x; p.y = y; p.stride = stride; p.L = (int)L;
+  p.ybs = ybs < 0 ? S*stride : ybs; p.yss = yss < 0 ? stride : yss;
   p.lengths = (const long long*)lengths; p.S = (int)S; p.mom = sc.mom;
   int gx = (int)((L + 256*16 - 1)/(256*16));
   if (gx < 1) gx = 1;
@@ -55,10 +57,17 @@ int64_t brv_loss_scratch_bytes(int64_t B, int64_t S) {
 int brv_snr_forward(const float* x, const float* y, const int64_t* lengths, int64_t B,
                     int64_t S, int64_t L, int64_t stride, void* scratch, float* loss,
                     brv_stream_t stream) {
+  return brv_snr_forward_strided(x, y, S*stride, stride, lengths, B, S, L, stride, scratch, loss, stream);
+}
+
+int brv_snr_forward_strided(const float* x, const float* y, int64_t y_batch_stride,
+                            int64_t y_source_stride, const int64_t* lengths, int64_t B, int64_t S,
+                            int64_t L, int64_t stride, void* scratch, float* loss,
+                            brv_stream_t stream) {
   if (B < 1 || S < 1 || L < 1) return -1;
   hipStream_t st = (hipStream_t)stream;
   LossScratch sc(scratch, B, S);
-  if (int r = moments(x, y, lengths, B, S, L, stride, sc, st)) return r;
+  if (int r = moments(x, y, lengths, B, S, L, stride, sc, st, y_batch_stride, y_source_stride)) return r;
   hipLaunchKernelGGL(snr_finalize_kernel, dim3((unsigned)((B + 63)/64)), dim3(64), 0, st,
                      sc.mom, (int)B, (int)S, loss, sc.coef);
   OPS_OK(hipGetLastError());
@@ -68,12 +77,21 @@ int brv_snr_forward(const float* x, const float* y, const int64_t* lengths, int6
 int brv_snr_backward(const float* x, const float* y, const int64_t* lengths, int64_t B,
                      int64_t S, int64_t L, int64_t stride, const void* scratch,
                      const float* gscale, float* dx, brv_stream_t stream) {
+  return brv_snr_backward_strided(x, y, S*stride, stride, lengths, B, S, L, stride, scratch, gscale, dx,
+                                  stream);
+}
+
+int brv_snr_backward_strided(const float* x, const float* y, int64_t y_batch_stride,
+                             int64_t y_source_stride, const int64_t* lengths, int64_t B, int64_t S,
+                             int64_t L, int64_t stride, const void* scratch, const float* gscale,
+                             float* dx, brv_stream_t stream) {
   if (B < 1 || S < 1 || L < 1) return -1;
   hipStream_t st = (hipStream_t)stream;
   LossScratch sc(const_cast<void*>(scratch), B, S);
   SnrBwdParams p;
   p.x = x; p.y = y; p.dx = dx; p.stride = stride; p.L = (int)L;
   p.lengths = (const long long*)lengths; p.S = (int)S; p.coef = sc.coef; p.gscale = gscale;
+  p.ybs = y_batch_stride; p.yss = y_source_stride;
   int gx = (int)((L + 256*8 - 1)/(256*8));
   if (gx < 1) gx = 1;
   if (gx > 512) gx = 512;

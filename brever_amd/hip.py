@@ -77,12 +77,12 @@ SIGNATURES = {
     'brv_ctn_workspace_offset': (_c_i64, [_c_ptr, _c_i64, _c_i64,
                                           ctypes.c_char_p, _c_i64]),
     'brv_ctn_prepare': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
-    'brv_ctn_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+    'brv_ctn_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                        _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr]),
-    'brv_ctn_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+    'brv_ctn_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                         _c_ptr, _c_ptr, _c_i64, _c_i64,
                                         _c_ptr, _c_ptr]),
-    'brv_ctn_backward_part': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+    'brv_ctn_backward_part': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64,
                                              _c_ptr, _c_ptr, _c_i64, _c_i64,
                                              ctypes.c_int32, ctypes.c_int32, _c_ptr, _c_ptr]),
     'brv_ctn_grad_bucket': (ctypes.c_int, [_c_ptr, ctypes.c_int32, ctypes.c_int32,
@@ -106,6 +106,10 @@ SIGNATURES = {
     'brv_flac_info': (ctypes.c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'brv_flac_decode': (_c_i64, [_c_ptr, _c_i64, _c_ptr, _c_i64]),
     'brv_loss_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
+    'brv_snr_forward_strided': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64,
+                                                _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),
+    'brv_snr_backward_strided': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64,
+                                                 _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'brv_snr_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,
                                        _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),
     'brv_snr_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64,

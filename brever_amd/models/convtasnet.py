@@ -354,12 +354,33 @@ class ConvTasNet(BreverBaseModel):
         nothing refers to it; the hot path (``train_step``) does not come through here."""
         return torch.zeros_like(self._flat)
 
+    @staticmethod
+    def _rows(x, amp):
+        """``(tensor, row stride)`` of a (batch, length) fp32 input for the kernels: the bf16 path reads
+        rows in place at any row stride (``batch[:, 0]`` of the trainer's (B, 1 + S, L) tensor: as a
+        strided torch copy that is one small device copy per row, 32 per step); the fp32 path and
+        anything else get a contiguous copy."""
+        if amp and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 \
+                and x.stride(0) >= x.shape[1]:
+            return x, x.stride(0)
+        x = x.float().contiguous()
+        return x, x.shape[1]
+
+    @staticmethod
+    def _label_rows(labels):
+        """``(tensor, item stride, source stride)`` of the (batch, sources, length) labels, in place when
+        the samples are contiguous fp32 (``batch[:, 1:]``), else of a contiguous copy."""
+        if labels.dtype == torch.float32 and labels.dim() == 3 and labels.stride(2) == 1:
+            return labels, labels.stride(0), labels.stride(1)
+        labels = labels.float().contiguous()
+        return labels, labels.stride(0), labels.stride(1)
+
     def _hip_forward(self, wave, amp=True):
         hip.require_device(wave, self._flat)
         if wave.ndim != 2:
             raise ValueError(f'input must be (batch, length), got {wave.shape}')
         amp = bool(amp)
-        wave = wave.float().contiguous()
+        wave, wstride = self._rows(wave, amp)
         B, L = wave.shape
         ws = self._get_workspace(B, L, amp)
         out = torch.empty(B, self.output_sources, L, dtype=torch.float32,
@@ -369,8 +390,8 @@ class ConvTasNet(BreverBaseModel):
             opts = hip.launch_opts()
             hip.check(hip.lib().brv_ctn_forward(
                 self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
-                hip.ptr(ws), hip.ptr(wave), hip.ptr(out), B, L, hip.opts_ptr(opts), hip.stream()),
-                'brv_ctn_forward')
+                hip.ptr(ws), hip.ptr(wave), wstride, hip.ptr(out), B, L, hip.opts_ptr(opts),
+                hip.stream()), 'brv_ctn_forward')
         else:
             self._check_layout()
             hip.check(hip.lib().brv_ctn_f32_forward(
@@ -398,7 +419,7 @@ class ConvTasNet(BreverBaseModel):
         ``after_part(part, flat_grad[offset:offset + count])`` is called after each one
         with the gradient slice that part finished (bucketed all-reduce hook)."""
         amp = bool(amp)
-        wave = wave.float().contiguous()
+        wave, wstride = self._rows(wave, amp)
         d_out = d_out.float().contiguous()
         B, L = wave.shape
         ws = self._get_workspace(B, L, amp)
@@ -409,7 +430,7 @@ class ConvTasNet(BreverBaseModel):
             if amp:
                 hip.check(lib.brv_ctn_backward_part(
                     self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
-                    hip.ptr(ws), hip.ptr(wave), hip.ptr(d_out), hip.ptr(flat_grad),
+                    hip.ptr(ws), hip.ptr(wave), wstride, hip.ptr(d_out), hip.ptr(flat_grad),
                     B, L, part, nparts, hip.opts_ptr(opts), hip.stream()), 'brv_ctn_backward_part')
             else:
                 hip.check(lib.brv_ctn_f32_backward_part(
@@ -510,17 +531,17 @@ class ConvTasNet(BreverBaseModel):
             return self._train_step_two_chains(inputs, labels, lengths)
         with torch.no_grad():
             out = self._hip_forward(inputs, amp)
-            labels = labels.float().contiguous()
+            labels, ybs, yss = self._label_rows(labels)
             lengths = lengths.to(torch.int64).contiguous()
             scratch, loss_b, gscale, d_out = self._step_buffers(B, S, L, out.device)
-            hip.check(lib.brv_snr_forward(
-                hip.ptr(out), hip.ptr(labels), hip.ptr(lengths), B, S, L, L,
+            hip.check(lib.brv_snr_forward_strided(
+                hip.ptr(out), hip.ptr(labels), ybs, yss, hip.ptr(lengths), B, S, L, L,
                 hip.ptr(scratch), hip.ptr(loss_b), hip.stream()),
-                'brv_snr_forward')
-            hip.check(lib.brv_snr_backward(
-                hip.ptr(out), hip.ptr(labels), hip.ptr(lengths), B, S, L, L,
+                'brv_snr_forward_strided')
+            hip.check(lib.brv_snr_backward_strided(
+                hip.ptr(out), hip.ptr(labels), ybs, yss, hip.ptr(lengths), B, S, L, L,
                 hip.ptr(scratch), hip.ptr(gscale), hip.ptr(d_out), hip.stream()),
-                'brv_snr_backward')
+                'brv_snr_backward_strided')
             grads = self.flat_grads()
             hip.check(lib.brv_memset_zero(hip.ptr(grads), 4*grads.numel(), hip.stream()), 'brv_memset_zero')
             sync = self._grad_sync
@@ -565,8 +586,8 @@ class ConvTasNet(BreverBaseModel):
         S, Bh = self.output_sources, B//2
         dev = inputs.device
         with torch.no_grad():
-            wave = inputs.float().contiguous()
-            labels = labels.float().contiguous()
+            wave, wstride = self._rows(inputs, True)        # read in place: no strided copies
+            labels, ybs, yss = self._label_rows(labels)
             lengths = lengths.to(torch.int64).contiguous()
             self._prepare()
             t = self._two_chain_buffers(B, S, L, dev)
@@ -596,14 +617,15 @@ class ConvTasNet(BreverBaseModel):
                             hip.check(lib.brv_memset_zero(hip.ptr(t['grad2']), 4*t['grad2'].numel(), st),
                                       'brv_memset_zero')
                         t['grad2_zero'] = False        # (until this step's sum pass has re-zeroed it)
-                    hip.check(lib.brv_ctn_forward(cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x),
+                    hip.check(lib.brv_ctn_forward(cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x), wstride,
                                                   hip.ptr(out), Bh, L, po, st), 'brv_ctn_forward')
-                    hip.check(lib.brv_snr_forward(hip.ptr(out), hip.ptr(y), hip.ptr(ln), Bh, S, L, L,
-                                                  hip.ptr(t['scratch'][h]), hip.ptr(loss_b), st),
-                              'brv_snr_forward')
-                    hip.check(lib.brv_snr_backward(hip.ptr(out), hip.ptr(y), hip.ptr(ln), Bh, S, L, L,
-                                                   hip.ptr(t['scratch'][h]), hip.ptr(gscale),
-                                                   hip.ptr(d_out), st), 'brv_snr_backward')
+                    hip.check(lib.brv_snr_forward_strided(
+                        hip.ptr(out), hip.ptr(y), ybs, yss, hip.ptr(ln), Bh, S, L, L,
+                        hip.ptr(t['scratch'][h]), hip.ptr(loss_b), st), 'brv_snr_forward_strided')
+                    hip.check(lib.brv_snr_backward_strided(
+                        hip.ptr(out), hip.ptr(y), ybs, yss, hip.ptr(ln), Bh, S, L, L,
+                        hip.ptr(t['scratch'][h]), hip.ptr(gscale), hip.ptr(d_out), st),
+                        'brv_snr_backward_strided')
             sync = self._grad_sync
             nparts = getattr(sync, 'nparts', 1) if sync is not None else 1
             buckets = self.grad_buckets(nparts) if nparts > 1 else [(0, grads.numel())]
@@ -612,7 +634,7 @@ class ConvTasNet(BreverBaseModel):
                     x, y, ln, out, d_out, loss_b, gscale = half(h)
                     with torch.cuda.stream(streams[h]):
                         hip.check(lib.brv_ctn_backward_part(
-                            cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x), hip.ptr(d_out),
+                            cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x), wstride, hip.ptr(d_out),
                             hip.ptr(grads if h == 0 else t['grad2']), Bh, L, part, nparts, po, hip.stream()),
                             'brv_ctn_backward_part')
                 # this part's slice of the gradient is final in both halves

@@ -101,12 +101,13 @@ int64_t brv_ctn_workspace_offset(const brv_ctn_config* cfg, int64_t batch,
 int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params,
                     void* prepared, const brv_launch_opts* opts, brv_stream_t stream);
 
-/* ConvTasNet.forward (convtasnet.py:66-72): wave (batch, length) fp32 ->
- * out (batch, sources, length) fp32. Leaves the activations needed by
- * brv_ctn_backward in `workspace`. */
+/* ConvTasNet.forward (convtasnet.py:66-72): wave (batch, length) fp32, rows `wave_stride` floats
+ * apart (0 = length; the trainer's batch[:, 0] of a (batch, 1 + sources, length) tensor is read in
+ * place with wave_stride = (1 + sources)*length) -> out (batch, sources, length) fp32. Leaves the
+ * activations needed by brv_ctn_backward in `workspace`. */
 int brv_ctn_forward(const brv_ctn_config* cfg, const float* params,
                     const void* prepared, void* workspace, const float* wave,
-                    float* out, int64_t batch, int64_t length,
+                    int64_t wave_stride, float* out, int64_t batch, int64_t length,
                     const brv_launch_opts* opts, brv_stream_t stream);
 
 /* Autograd of ConvTasNet.forward: d_out (batch, sources, length) fp32 ->
@@ -114,7 +115,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params,
  * the caller zeroes it, as optimizer.zero_grad() does). */
 int brv_ctn_backward(const brv_ctn_config* cfg, const float* params,
                      const void* prepared, void* workspace, const float* wave,
-                     const float* d_out, float* grads, int64_t batch,
+                     int64_t wave_stride, const float* d_out, float* grads, int64_t batch,
                      int64_t length, const brv_launch_opts* opts, brv_stream_t stream);
 
 /* The backward pass in `nparts` parts, for overlapping the data-parallel gradient all-reduce
@@ -128,7 +129,7 @@ int brv_ctn_backward(const brv_ctn_config* cfg, const float* params,
  * Calling parts 0 .. nparts-1 in order equals one brv_ctn_backward call. */
 int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params,
                           const void* prepared, void* workspace, const float* wave,
-                          const float* d_out, float* grads, int64_t batch,
+                          int64_t wave_stride, const float* d_out, float* grads, int64_t batch,
                           int64_t length, int32_t part, int32_t nparts,
                           const brv_launch_opts* opts, brv_stream_t stream);
 int brv_ctn_grad_bucket(const brv_ctn_config* cfg, int32_t part, int32_t nparts,
@@ -169,6 +170,17 @@ int brv_snr_backward(const float* x, const float* y, const int64_t* lengths,
                      int64_t batch, int64_t sources, int64_t length,
                      int64_t stride, const void* scratch, const float* gscale,
                      float* dx, brv_stream_t stream);
+/* The same with the labels read in place from the trainer's (batch, 1 + sources, length) tensor:
+ * row (item b, source s) of y starts at y + b*y_batch_stride + s*y_source_stride (no copy of
+ * batch[:, 1:] -- as a strided torch copy it was 16 small device copies per step). */
+int brv_snr_forward_strided(const float* x, const float* y, int64_t y_batch_stride,
+                            int64_t y_source_stride, const int64_t* lengths, int64_t batch,
+                            int64_t sources, int64_t length, int64_t stride, void* scratch,
+                            float* loss, brv_stream_t stream);
+int brv_snr_backward_strided(const float* x, const float* y, int64_t y_batch_stride,
+                             int64_t y_source_stride, const int64_t* lengths, int64_t batch,
+                             int64_t sources, int64_t length, int64_t stride, const void* scratch,
+                             const float* gscale, float* dx, brv_stream_t stream);
 /* sisnr with PIT (criterion.py:21-72), sources <= 4. The forward leaves the winning
  * permutation and the gradient coefficients in scratch for the backward. */
 int brv_sisnr_forward(const float* x, const float* y, const int64_t* lengths,
