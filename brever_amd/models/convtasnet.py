@@ -563,12 +563,12 @@ class ConvTasNet(BreverBaseModel):
     @staticmethod
     def uses_two_chains(B, amp):
         """Whether the fused bf16 step of a batch of ``B`` runs as two half-batch kernel chains on two
-        streams: even batches of >= 8, unless ``BRV_CTN_STREAMS=1`` -- and never next
+        streams (DESIGN.md 5h): batches of >= 8 (odd ones split 1 + B//2 | B//2), unless ``BRV_CTN_STREAMS=1`` -- and never next
         to an initialised process group when the HIP runtime cannot have seen >= 8 hardware queues
         (``brever_amd.HW_QUEUES_OK``: torch imported before the package and ``GPU_MAX_HW_QUEUES`` not
         exported): with the default 4 queues RCCL's streams and the two chains share queues and the
         step is slower than one chain (9.6 vs 7.7 ms)."""
-        return bool(amp) and B >= 8 and B % 2 == 0 and os.environ.get('BRV_CTN_STREAMS', '2') != '1' \
+        return bool(amp) and B >= 8 and os.environ.get('BRV_CTN_STREAMS', '2') != '1' \
             and (_queues_ok() or not _process_group())
 
     def _train_step_two_chains(self, inputs, labels, lengths):
@@ -583,7 +583,8 @@ class ConvTasNet(BreverBaseModel):
         meanwhile; four chains: 10.4 ms. ``BRV_CTN_STREAMS=1``: one chain."""
         lib = hip.lib()
         B, L = inputs.shape
-        S, Bh = self.output_sources, B//2
+        S = self.output_sources
+        nB = ((B + 1)//2, B//2)                   # items per chain (odd batches: the first takes one more)
         dev = inputs.device
         with torch.no_grad():
             wave, wstride = self._rows(inputs, True)        # read in place: no strided copies
@@ -605,7 +606,7 @@ class ConvTasNet(BreverBaseModel):
             flat, prep, cfg = hip.ptr(self._flat), hip.ptr(self._prepared), self._cfg_ptr()
 
             def half(h):
-                sl = slice(h*Bh, (h + 1)*Bh)
+                sl = slice(0, nB[0]) if h == 0 else slice(nB[0], B)
                 return (wave[sl], labels[sl], lengths[sl], t['out'][sl], t['d_out'][sl], t['loss'][sl],
                         t['gscale'][sl])
             for h in (0, 1):                     # forward + loss of both halves, then both backwards
@@ -618,12 +619,12 @@ class ConvTasNet(BreverBaseModel):
                                       'brv_memset_zero')
                         t['grad2_zero'] = False        # (until this step's sum pass has re-zeroed it)
                     hip.check(lib.brv_ctn_forward(cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x), wstride,
-                                                  hip.ptr(out), Bh, L, po, st), 'brv_ctn_forward')
+                                                  hip.ptr(out), nB[h], L, po, st), 'brv_ctn_forward')
                     hip.check(lib.brv_snr_forward_strided(
-                        hip.ptr(out), hip.ptr(y), ybs, yss, hip.ptr(ln), Bh, S, L, L,
+                        hip.ptr(out), hip.ptr(y), ybs, yss, hip.ptr(ln), nB[h], S, L, L,
                         hip.ptr(t['scratch'][h]), hip.ptr(loss_b), st), 'brv_snr_forward_strided')
                     hip.check(lib.brv_snr_backward_strided(
-                        hip.ptr(out), hip.ptr(y), ybs, yss, hip.ptr(ln), Bh, S, L, L,
+                        hip.ptr(out), hip.ptr(y), ybs, yss, hip.ptr(ln), nB[h], S, L, L,
                         hip.ptr(t['scratch'][h]), hip.ptr(gscale), hip.ptr(d_out), st),
                         'brv_snr_backward_strided')
             sync = self._grad_sync
@@ -635,7 +636,7 @@ class ConvTasNet(BreverBaseModel):
                     with torch.cuda.stream(streams[h]):
                         hip.check(lib.brv_ctn_backward_part(
                             cfg, flat, prep, hip.ptr(t['ws'][h]), hip.ptr(x), wstride, hip.ptr(d_out),
-                            hip.ptr(grads if h == 0 else t['grad2']), Bh, L, part, nparts, po, hip.stream()),
+                            hip.ptr(grads if h == 0 else t['grad2']), nB[h], L, part, nparts, po, hip.stream()),
                             'brv_ctn_backward_part')
                 # this part's slice of the gradient is final in both halves
                 main.wait_stream(side)
@@ -673,7 +674,7 @@ class ConvTasNet(BreverBaseModel):
         output / loss buffers are views of flat allocations that are replaced only by larger ones (the
         old reference is dropped first: no 2x peak). The side stream is created once."""
         lib = hip.lib()
-        Bh = B//2
+        Bh = (B + 1)//2                            # the larger half sizes both workspaces
         nws = lib.brv_ctn_workspace_bytes(self._cfg_ptr(), Bh, L)
         if nws < 0:
             hip.check(int(nws), 'brv_ctn_workspace_bytes')

@@ -410,3 +410,20 @@ def test_two_models_step_from_two_threads():
         assert abs(got[name][0] - ref[name][0]) <= 1e-5, (name, got[name], ref[name])
         assert max(abs(x - y) for x, y in zip(got[name], ref[name])) <= 5e-3, (name, got[name], ref[name])
         assert rel(nets[name].flat_params(), ref_nets[name].flat_params()) <= 2e-2, name
+
+
+def test_two_chain_step_odd_batch(monkeypatch):
+    """odd batches take the two-chain step too (5 + 4 items of a batch of 9): same
+    losses and the same gradient as the one-chain step from the same weights."""
+    from brever_amd.models import ConvTasNet
+    cfg = dict(layers=3, repeats=2)
+    gen = torch.Generator().manual_seed(31)
+    batch, lengths = _ragged_batch(gen, 9, 5000)
+    got = {}
+    for mode in ('1', '2'):
+        torch.manual_seed(5)
+        net = ConvTasNet(**cfg).to(_cuda())
+        loss, grads = _fused_step_grads(net, batch, lengths, True, mode, monkeypatch)
+        got[mode] = (loss, grads)
+    assert abs(got['1'][0] - got['2'][0]) <= 1e-5, (got['1'][0], got['2'][0])
+    assert rel(got['2'][1], got['1'][1]) <= 1e-4, rel(got['2'][1], got['1'][1])

@@ -531,7 +531,7 @@ def test_two_chain_gating(monkeypatch):
     monkeypatch.setattr(M, '_process_group', lambda: False)
     monkeypatch.setattr(brever_amd, 'HW_QUEUES_OK', False)
     assert two(16, True) and two(8, True)                # no process group: the queues do not matter
-    assert not two(16, False) and not two(7, True) and not two(6, True) and not two(9, True)
+    assert not two(16, False) and not two(7, True) and not two(6, True) and two(9, True)
     monkeypatch.setattr(M, '_process_group', lambda: True)
     assert not two(16, True)                             # RCCL next to it, queues not guaranteed
     monkeypatch.setattr(brever_amd, 'HW_QUEUES_OK', True)
