@@ -33,6 +33,13 @@ namespace brv {
 #define BF_ABL 0     // ablation bits (diagnostic builds, results wrong): 1 no MFMAs, 2 no g / W loads, 4 no phase 0,
 #endif               // 16 no per-channel reductions (accumulators die too), 32 no atomics, 64 no folds but live accumulators
 
+#ifndef BF_AHEAD1
+#define BF_AHEAD1 4        // rows of a thread whose z2 loads are in flight together in phase 1 (4 or 8)
+#endif
+#ifndef BF_AHEAD2
+#define BF_AHEAD2 4        // the same for the z1 loads of phase 2
+#endif
+
 struct BwdFusedParams {
   DwParams d;              // as dwconv_bwd_halo_kernel; d.dz2 unused, d.sums2 = {sum <g, v1>, sum <g, u>}
   const bf16_t* g;         // [B][T][ldg]: first used column of [g_out | g_skip]
@@ -269,17 +276,18 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
       dbia[j] = f32x2{0.f, 0.f}; dgam2[j] = f32x2{0.f, 0.f}; dbet2[j] = f32x2{0.f, 0.f};
     }
   }
-  // four rows per thread in flight before any of them is consumed
-  for (int rw = rslot; rw < W; rw += 128) {
-    uint4 qz[4];
+  // BF_AHEAD1 rows of a thread requested before the first is consumed
+  constexpr int NU = BF_AHEAD1;
+  for (int rw = rslot; rw < W; rw += 32*NU) {
+    uint4 qz[NU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       bool ok;
       const int tf = frame_of(rw + 32*u, ok);
       qz[u] = buf_load16(rz2, (ok && tf < T) ? (unsigned int)tf*row + coff : kOob);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NU; ++u) {
       const int r = rw + 32*u;
       if (r >= W) break;
       bool ok;
@@ -424,16 +432,17 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
     ok = i < KR && ro < d;
     return (q0 + qi)*d + ro;
   };
-  for (int i0 = rslot; i0 < KR; i0 += 128) {
-   uint4 qz4[4];
+  constexpr int NU2 = BF_AHEAD2;
+  for (int i0 = rslot; i0 < KR; i0 += 32*NU2) {
+   uint4 qz4[NU2];
 #pragma unroll
-   for (int u = 0; u < 4; ++u) {
+   for (int u = 0; u < NU2; ++u) {
      bool ok;
      const int t = out_frame(i0 + 32*u, ok);
      qz4[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);   // outside: zeros
    }
 #pragma unroll
-   for (int u = 0; u < 4; ++u) {
+   for (int u = 0; u < NU2; ++u) {
     const int i = i0 + 32*u;
     if (i >= KR) break;
     bool ok;
