@@ -224,6 +224,11 @@ def kernel_roofline(model, batches, scaler, steps=3):
         'tflops': tfs, 'gbs': gbs,
         'share_of_kernel_time': top['ms']/sum(v['ms'] for v in prof.values()),
     }
+    if label == 'dwpw2_bwd':
+        roof['note'] = ('fused backward stage (csrc/bwd_fused.cuh, round 3): one launch does the work of '
+                        'pw2_dgrad + dwconv_bwd (round 2: 163 + 262 MB algorithmic in 48 + 66 us = 3.7 TB/s) '
+                        'with 229 MB algorithmic: fewer bytes AND less time per block, hence a lower '
+                        'bytes-per-second fraction than the kernel pair it replaces')
     total_ms = sum(v['ms'] for v in prof.values())
     kernels = []
     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms']):

@@ -87,8 +87,17 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = p.T, d = p.dil;
   const int R = fp.R, K = fp.K;
-  const float invR = 1.f/(float)R;                      // r / R for r < 512 (exact: (r + 0.5) / R is never within 1e-3 of an integer)
-  auto divR = [&](int r, int& rem) { const int q = (int)(((float)r + 0.5f)*invR); rem = r - q*R; return q; };
+  // r / R and r % R for r < 512: shifts when R is a power of two (dilations <= 32 at the BASELINE length),
+  // else a float multiplication ((r + 0.5) / R is never within 1e-3 of an integer: exact)
+  const float invR = 1.f/(float)R;
+  const bool r_pow2 = (R & (R - 1)) == 0;
+  const int lgR = 31 - __builtin_clz(R);
+  auto divR = [&](int r, int& rem) {
+    if (r_pow2) { rem = r & (R - 1); return r >> lgR; }
+    const int q = (int)(((float)r + 0.5f)*invR);
+    rem = r - q*R;
+    return q;
+  };
   const int n_rt = ceil_div(d, R);                       // residue groups
   const int n_teeth = (T - 1)/d + 1;
   const int n_qt = ceil_div(n_teeth, K);                 // tooth groups
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
     bool ok;
     const int t = out_frame(i, ok);
     const uint4 qz = qz4[u];
-    const float live = (ok && t < T) ? 1.f : 0.f;
+    if (!(ok && t < T)) continue;                        // frames past the end: nothing to store or add
     float zc[8];
     unpack8(qz, zc);
     f32x2 xh[4], hn[4], dh[4];
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
     for (int j = 0; j < 4; ++j) {
       xh[j].x = __builtin_fmaf(xb, __builtin_fabsf(zc[2*j]), __builtin_fmaf(xa, zc[2*j], xc));
       xh[j].y = __builtin_fmaf(xb, __builtin_fabsf(zc[2*j + 1]), __builtin_fmaf(xa, zc[2*j + 1], xc));
-      hn[j] = f32x2{live, live}*(gm[j]*xh[j] + be[j]);   // gLN_1 output at frame t (0 past the end)
+      hn[j] = gm[j]*xh[j] + be[j];                       // gLN_1 output at frame t
       dh[j] = f32x2{0.f, 0.f};
     }
 #pragma unroll
@@ -475,14 +484,14 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
     f32x2 o[4], a1s = {0.f, 0.f}, a2s = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x2 dl = f32x2{live, live}*dh[j];          // frames past the end contribute nothing
+      const f32x2 dl = dh[j];
       const f32x2 ev = gm[j]*dl;
       o[j] = ev;
       a1s += ev; a2s += ev*xh[j];
       dgam[j] += dl*xh[j]; dbet[j] += dl;
     }
     l1 += a1s.x + a1s.y; l2 += a2s.x + a2s.y;
-    buf_store16(re1, live != 0.f ? (unsigned int)t*row + coff : kOob, pack8v(o));   // outside: dropped
+    buf_store16(re1, (unsigned int)t*row + coff, pack8v(o));
    }
   }
 
