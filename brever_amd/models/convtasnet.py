@@ -357,8 +357,8 @@ class ConvTasNet(BreverBaseModel):
     @staticmethod
     def _rows(x, amp):
         """``(tensor, row stride)`` of a (batch, length) fp32 input for the kernels: the bf16 path reads
-        rows in place at any row stride (``batch[:, 0]`` of the trainer's (B, 1 + S, L) tensor: as a
-        strided torch copy that is one small device copy per row, 32 per step); the fp32 path and
+        rows in place at any row stride (``batch[:, 0]`` of the trainer's (B, 1 + S, L) tensor: no strided
+        torch copy kernel in front of every step); the fp32 path and
         anything else get a contiguous copy."""
         if amp and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 \
                 and x.stride(0) >= x.shape[1]:

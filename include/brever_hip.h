@@ -172,7 +172,7 @@ int brv_snr_backward(const float* x, const float* y, const int64_t* lengths,
                      float* dx, brv_stream_t stream);
 /* The same with the labels read in place from the trainer's (batch, 1 + sources, length) tensor:
  * row (item b, source s) of y starts at y + b*y_batch_stride + s*y_source_stride (no copy of
- * batch[:, 1:] -- as a strided torch copy it was 16 small device copies per step). */
+ * batch[:, 1:], which was a strided torch copy kernel per step). */
 int brv_snr_forward_strided(const float* x, const float* y, int64_t y_batch_stride,
                             int64_t y_source_stride, const int64_t* lengths, int64_t batch,
                             int64_t sources, int64_t length, int64_t stride, void* scratch,
