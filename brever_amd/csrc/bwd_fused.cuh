@@ -77,8 +77,8 @@ inline void bf_tile_shape(int T, int dil, int P, int& K, int& R) {
 // KG: reduction length of phase 0 (compile time: the chunk loop is straight-line code, so every wait of
 // its load pipeline is a counted vmcnt -- as a run-time loop hipcc drained ALL loads, the just-issued
 // prefetch included, in front of the first MFMA of every chunk)
-// FULLC: the channel count is a multiple of 64 (no padded channels to mask)
-template <int P, int KG, bool FULLC>
+// (The channel count is a multiple of 64 on this path -- hidden_channels = 512 -- so no channel masks.)
+template <int P, int KG>
 __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFusedParams fp) {
   const DwParams& p = fp.d;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
@@ -137,7 +137,6 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   float pv0 = 0.f, pv1 = 0.f;
   auto ptab_src = [&](int idx) -> const float* {
     const int which = idx >> 6, c = cg*HL_CG + (idx & 63);
-    if (!FULLC && c >= p.C) return nullptr;
     return which == 0 ? fp.gamma2 + c : which == 1 ? p.gamma1 + c : which == 2 ? p.beta1 + c
                       : p.taps + (long long)c*P + (which - 3);
   };
@@ -321,10 +320,6 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
         g[j] = uu*(z[j] > 0.f ? 1.f : a2);               // PReLU_2'
         uz = __builtin_fmaf(uu, z[j] - __builtin_fabsf(z[j]), uz);    // 2 min(z, 0) (fminf canonicalises first)
         if (j & 1) { xg[j >> 1].y = xh2; ee[j >> 1].y = e[j]; } else { xg[j >> 1].x = xh2; ee[j >> 1].x = e[j]; }
-      }
-      if (!FULLC) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (c0 + j >= p.C) g[j] = 0.f;
       }
       const uint4 q4 = pack8(g);
       *reinterpret_cast<uint4*>(win + r*BF_LDW + cl) = q4;

@@ -456,11 +456,9 @@ template <int P> struct DwBwdFused {
     ProfScope prof(prof_by_dil() ? by_dil[lg] : "dwpw2_bwd", 2.0*d.B*d.T*(double)d.Cp*(p.Kg + 2*P),
                    2.0*d.B*d.T*((double)p.Kg + 3.0*d.Cp), st);
     dim3 grid(ceil_div(tiles*d.B, 8)*8*(d.Cp/HL_CG));     // whole runs of 8 tiles (XCD map of the kernel)
-    const bool full = d.C == d.Cp;
-#define BRV_BF_LAUNCH(KG, F) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P, KG, F>), grid, dim3(256), BF_LDS, st, p)
-    if (p.Kg == 256) { if (full) BRV_BF_LAUNCH(256, true); else BRV_BF_LAUNCH(256, false); }
-    else if (p.Kg == 128) { if (full) BRV_BF_LAUNCH(128, true); else BRV_BF_LAUNCH(128, false); }
-#undef BRV_BF_LAUNCH
+    if (d.C != d.Cp) return fail(-1, "fused backward: channel count must be a multiple of 64");
+    if (p.Kg == 256) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P, 256>), grid, dim3(256), BF_LDS, st, p);
+    else if (p.Kg == 128) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P, 128>), grid, dim3(256), BF_LDS, st, p);
     else return fail(-1, "fused backward: unexpected [res | skip] width");
     HIP_OK(hipGetLastError());
     return 0;

@@ -427,3 +427,38 @@ def test_two_chain_step_odd_batch(monkeypatch):
         got[mode] = (loss, grads)
     assert abs(got['1'][0] - got['2'][0]) <= 1e-5, (got['1'][0], got['2'][0])
     assert rel(got['2'][1], got['1'][1]) <= 1e-4, rel(got['2'][1], got['1'][1])
+
+
+def test_clip_adam_step2_matches_torch():
+    """`brv_clip_adam_step2` (two launches, no memset): clip_grad_norm_ + Adam.step of torch on g + g2
+    (`brever/models/base.py:296-301`), the second buffer left zeroed, the two norm accumulators used in
+    turn (the Adam kernel of one call zeroes the other call's), with and without a second buffer."""
+    from brever_amd import hip
+    dev = _cuda()
+    n = 100_003
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.clone().to(dev)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    scratch = torch.zeros(64, dtype=torch.uint8, device=dev)          # both accumulators zero
+    norm = torch.zeros(1, device=dev)
+    for step in range(1, 7):
+        ga = torch.randn(n, generator=g)*(10.0 if step % 2 else 0.001)
+        gb = torch.randn(n, generator=g)*(3.0 if step % 3 else 0.0005)
+        two = step % 3 != 0                                           # every third call: one buffer only
+        ref.grad = (ga + gb).clone() if two else ga.clone()
+        total = torch.nn.utils.clip_grad_norm_([ref], 5.0)
+        opt.step()
+        gd, g2 = ga.clone().to(dev), gb.clone().to(dev)
+        hip.check(hip.lib().brv_clip_adam_step2(
+            hip.ptr(p), hip.ptr(gd), hip.ptr(g2) if two else None, hip.ptr(m), hip.ptr(v), n, 1.0, 5.0,
+            1e-3, 0.9, 0.999, 1e-8, step, hip.ptr(scratch), (step - 1) % 2, hip.ptr(norm), hip.stream()),
+            'brv_clip_adam_step2')
+        assert abs(float(norm) - float(total)) <= 1e-4*float(total), (step, float(norm), float(total))
+        assert torch.allclose(gd.cpu(), ref.grad, rtol=1e-5, atol=1e-8)
+        assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+        if two:
+            assert float(g2.abs().max()) == 0.0                      # left zeroed for the next step
