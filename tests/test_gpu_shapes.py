@@ -326,7 +326,7 @@ def test_sgmse_default_denoiser_full_spectrogram():
 
 
 @pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 2, 3, 5000), (4, 2, 1, 700), (8, 1, 5, 2100),
-                                                (3, 3, 4, 20000)])
+                                                (3, 3, 4, 20000), (8, 1, 2, 300), (8, 1, 1, 64000)])
 def test_fused_backward_equals_three_launch_backward(monkeypatch, layers, repeats, B, L):
     """The backward mirror of the fused forward (csrc/bwd_fused.cuh: [res | skip] data gradient + gLN_2 /
     PReLU_2 backward + transposed depthwise stencil in one launch, layer-norm means from <g, u>) against
