@@ -324,11 +324,10 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
       const uint4 q4 = pack8(g);
       *reinterpret_cast<uint4*>(win + r*BF_LDW + cl) = q4;
       if (centre) {                                      // (row-uniform per thread: one branch, packed math)
-        float gr[8]; unpack8(q4, gr);                    // bias gradient = sum of (rounded) dz2
         da2 = __builtin_fmaf(0.5f, uz, da2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          dbia[j] += f32x2{gr[2*j], gr[2*j + 1]};
+          dbia[j] += f32x2{g[2*j], g[2*j + 1]};          // bias gradient = sum of dz2 (before its bf16 rounding)
           dgam2[j] += ee[j]*xg[j]; dbet2[j] += ee[j];
         }
       }
