@@ -7,8 +7,9 @@
 Every mixture of a test set is enhanced (``model.enhance(mixture, use_amp=cfg.trainer.use_amp)``)
 and the input and the output are scored against the clean target with the registered metrics;
 the scores go to ``<model>/scores.hdf5`` under ``<checkpoint>/<test set>`` as a
-``[mixture, metric, {input, output}]`` array with the reference's dimension scales when ``h5py``
-is importable -- otherwise to ``<model>/scores.npz`` with the same keys (``metrics``, ``which``,
+``[mixture, metric, {input, output}]`` array with the reference's dimension scales -- through ``h5py``
+when importable, else through the HDF5 C library (``brever_amd/h5lite.py``); only without both to
+``<model>/scores.npz`` with the same keys (``metrics``, ``which``,
 ``<checkpoint>/<test set>``). With ``--ddp`` (one process per GPU) the batches of the sorted
 sampler are sharded over the ranks and gathered on rank 0 with ``gather_object``. A test set may
 be ``synthetic:<items>:<seconds>``. The HIP models have no CPU path: pass ``--cuda``.
@@ -38,6 +39,8 @@ from brever_amd.logger import set_logger
 from brever_amd.metrics import MetricRegistry
 from brever_amd.models import ModelRegistry
 
+from brever_amd import h5lite
+
 try:
     import h5py
 except ImportError:
@@ -65,11 +68,13 @@ def write_wav(path, x, fs):
 
 
 class ScoreFile:
-    """``scores.hdf5`` (h5py) or ``scores.npz`` with the same logical layout
-    (scripts/test_model.py:245-263)."""
+    """``scores.hdf5`` with the reference's layout (scripts/test_model.py:245-263): through ``h5py`` when
+    it is importable, else through the HDF5 C library itself (``brever_amd.h5lite``: the same H5D / H5DS
+    calls ``h5py`` makes); only when neither is there, ``scores.npz`` with the same keys."""
 
     def __init__(self, model_dir):
-        self.path = os.path.join(model_dir, 'scores.hdf5' if h5py is not None else 'scores.npz')
+        self.backend = 'h5py' if h5py is not None else ('h5lite' if h5lite.available() else 'npz')
+        self.path = os.path.join(model_dir, 'scores.npz' if self.backend == 'npz' else 'scores.hdf5')
 
     def _load_npz(self):
         if not os.path.exists(self.path):
@@ -80,19 +85,31 @@ class ScoreFile:
     def contains(self, key):
         if not os.path.exists(self.path):
             return False
-        if h5py is not None:
+        if self.backend == 'h5py':
             with h5py.File(self.path, 'r') as f:
+                return key in f
+        if self.backend == 'h5lite':
+            with h5lite.File(self.path, 'r') as f:
                 return key in f
         return key in self._load_npz()
 
     def write(self, key, scores, metrics):
-        if h5py is None:
+        if self.backend == 'npz':
             content = self._load_npz()
             content.update({key: scores, 'metrics': np.array(metrics),
                             'which': np.array(['input', 'output'])})
             np.savez(self.path, **content)
             return
         new = not os.path.exists(self.path)
+        labels = ('mixture', 'metric', 'which')
+        if self.backend == 'h5lite':
+            with h5lite.File(self.path, 'w' if new else 'a') as f:
+                if new:
+                    f.write_strings('metrics', list(metrics))
+                    f.write_strings('which', ['input', 'output'])
+                f.write_array(key, scores)
+                f.set_dims(key, labels, {1: 'metrics', 2: 'which'})
+            return
         with h5py.File(self.path, 'w' if new else 'a') as f:
             if new:
                 f['metrics'] = list(metrics)
@@ -102,7 +119,7 @@ class ScoreFile:
                 dset = f[key]
             else:
                 dset = f.create_dataset(key, data=scores)
-            for axis, label in enumerate(('mixture', 'metric', 'which')):
+            for axis, label in enumerate(labels):
                 dset.dims[axis].label = label
             dset.dims[1].attach_scale(f['metrics'])
             dset.dims[2].attach_scale(f['which'])

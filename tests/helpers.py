@@ -158,9 +158,16 @@ def run_entry_points(tmp_path, arch, model_args=(), trainer_args=(), train='synt
         assert list(f['metrics']) == list(metrics) and list(f['which']) == ['input', 'output']
         scores = f[key]
     else:
-        import h5py
-        with h5py.File(os.path.join(model_dir, name), 'r') as f:
-            scores = f[key][...]
+        try:
+            import h5py
+            with h5py.File(os.path.join(model_dir, name), 'r') as f:
+                scores = f[key][...]
+        except ImportError:
+            from brever_amd import h5lite
+            with h5lite.File(os.path.join(model_dir, name), 'r') as f:
+                assert f.read_strings('metrics') == list(metrics)
+                assert f.read_strings('which') == ['input', 'output']
+                scores = f.read_array(key)
     return model_dir, losses, scores
 
 
