@@ -1,0 +1,473 @@
+// Large fp32 products on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 256 FLOP / clk / CU):
+// the 1x1 convolutions, data gradients and weight gradients of the fp32 Conv-TasNet path
+// (reference: brever/models/convtasnet/convtasnet.py:225-262 run without autocast) and every
+// brv_gemm_f32 call whose operands are 16-byte aligned.
+//
+// One workgroup = 8 wavefronts = a 256 x 128 (or 128 x 256) tile of D, 64 x 64 per wavefront
+// (2 x 2 MFMA accumulators); the reduction runs in tiles of 32 through two LDS stages: 16-byte
+// global loads into registers while the MFMAs of the previous tile run, one barrier per tile.
+// An operand whose storage is contiguous in k sits in LDS as [row][32 + 4] and is read as 16-byte
+// fragments (a lane takes 4 consecutive k: MFMA step i of a group of 8 multiplies k = 8j + 4h + i
+// of both operands, h = lane / 32 -- any pairing of k works as long as both operands use the
+// same one); an operand contiguous along its rows sits as [k][rows + 8] and is read by dword.
+// Both layouts are bank-conflict free for these reads. The MFMA is 64 clocks, so LDS traffic is
+// a few per cent of the pipe's time; what matters is that the global loads, the prologue and
+// the epilogue of one tile hide behind another tile's MFMAs: workgroups are persistent and walk
+// a flat (tile, k-tile) sequence, the first loads of the next tile are issued before the
+// epilogue of the present one.
+// Long reductions over few output tiles (weight gradients) are split over workgroups: partial
+// tiles go to a scratch buffer and are added in split order by a second kernel (no atomics: the
+// result does not depend on the order of arrival).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.cuh"
+#include "gemm_f32_big.h"
+
+// Compile-time ablations of tools/gemm_f32_bench.py (bit mask): 1 no MFMA, 2 no global loads,
+// 4 no epilogue stores, 8 no LDS operand reads
+#ifndef BRV_BIG_ABL
+#define BRV_BIG_ABL 0
+#endif
+
+namespace brv {
+namespace {
+
+struct BigDev {
+  BigGemm g;
+  int m_tiles, n_tiles, mn_padded, xcd_perm, ksplit, ktiles, n_work, b_scalar;
+  long long total_t, per_t;
+};
+
+constexpr int kBK = 32;          // reduction tile
+constexpr int kLDK = kBK + 4;    // floats per LDS row of a k-contiguous operand
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+__device__ __forceinline__ float4 norm_pro(const NormPro& q, long long frame, int ch, float4 v) {
+  const float mean = q.table[2*frame], rstd = q.table[2*frame + 1];
+  const float a = q.slope ? *q.slope : 1.f;
+  const bool act = q.slope != nullptr;
+  const float* g = q.gain + ch; const float* b = q.bias + ch;
+  float4 o;
+  o.x = (((v.x > 0.f || !act) ? v.x : a*v.x) - mean)*rstd*g[0] + b[0];
+  o.y = (((v.y > 0.f || !act) ? v.y : a*v.y) - mean)*rstd*g[1] + b[1];
+  o.z = (((v.z > 0.f || !act) ? v.z : a*v.z) - mean)*rstd*g[2] + b[2];
+  o.w = (((v.w > 0.f || !act) ? v.w : a*v.w) - mean)*rstd*g[3] + b[3];
+  return o;
+}
+
+struct Work { int valid, z, split, m0, n0, kb, k0, left, fresh; int q; };
+
+template <int WM, int WN, bool TA, bool TB, int PRO>
+__global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
+  constexpr int TM = 64*WM, TN = 64*WN;
+  constexpr int LDA = TA ? TM + 8 : kLDK, LDB = TB ? kLDK : TN + 8;
+  constexpr int A_FLOATS = TA ? kBK*LDA : TM*LDA;
+  constexpr int B_FLOATS = TB ? TN*LDB : kBK*LDB;
+  constexpr int STAGE = A_FLOATS + B_FLOATS;
+  constexpr int NA = TM/64, NB = TN/64;       // 16-byte loads per thread and k-tile
+  __shared__ __attribute__((aligned(16))) float lds[2*STAGE];
+  const BigGemm& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int r32 = lane & 31, kh = lane >> 5;
+
+  // work item q -> (batch item, reduction split, tile); all integers are 32-bit (checked on the host)
+  auto decode = [&](int q) {
+    Work w; w.valid = 0; w.q = q; w.z = 0; w.split = 0; w.m0 = 0; w.n0 = 0; w.kb = 0; w.k0 = 0; w.left = 0; w.fresh = 1;
+    for (; q < p.n_work; q += gridDim.x) {
+      const int zs = q / p.mn_padded, r = q % p.mn_padded;
+      int mt, nt;
+      if (p.xcd_perm) { const int xcd = r & 7, slot = r >> 3; mt = (slot / p.n_tiles)*8 + xcd; nt = slot % p.n_tiles; }
+      else { mt = r / p.n_tiles; nt = r % p.n_tiles; }
+      if (mt >= p.m_tiles) continue;
+      w.split = zs % p.ksplit; w.z = zs / p.ksplit;
+      const int t_lo = w.split*(int)p.per_t;
+      const int t_hi = t_lo + (int)p.per_t < (int)p.total_t ? t_lo + (int)p.per_t : (int)p.total_t;
+      if (t_lo >= t_hi) continue;
+      w.left = t_hi - t_lo;
+      w.kb = t_lo / p.ktiles; w.k0 = (t_lo % p.ktiles)*kBK;
+      w.m0 = mt*TM; w.n0 = nt*TN; w.q = q; w.valid = 1;
+      return w;
+    }
+    w.q = q;
+    return w;
+  };
+  // the k-tile after w (same tile), or the first one of this workgroup's next work item
+  auto advance = [&](const Work& w) {
+    if (w.left > 1) {
+      Work n = w; n.left = w.left - 1; n.k0 = w.k0 + kBK; n.fresh = 0;
+      if (n.k0 >= g.K) { n.k0 = 0; n.kb = w.kb + 1; n.fresh = 1; }
+      return n;
+    }
+    return decode(w.q + (int)gridDim.x);
+  };
+
+  // per-thread constants of the staging maps: element (row-ish, k) of load i inside the tile
+  int a_r[NA], a_k[NA], b_r[NB], b_k[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int f = tid + 512*i;
+    if (TA) { a_k[i] = f/(TM/4); a_r[i] = 4*(f % (TM/4)); } else { a_r[i] = f >> 3; a_k[i] = 4*(f & 7); }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int f = tid + 512*i;
+    if (TB) { b_r[i] = f >> 3; b_k[i] = 4*(f & 7); } else { b_k[i] = f/(TN/4); b_r[i] = 4*(f % (TN/4)); }
+  }
+  const float* pa[NA]; const float* pb[NB];
+  bool oka[NA], okb[NB];
+  float4 ra[NA], rb[NB];
+  auto fetch = [&](const Work& w) {
+    if (BRV_BIG_ABL & 2) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = make_float4((float)tid, 1.f, 2.f, (float)w.k0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb[i] = make_float4((float)tid, 1.f, 2.f, (float)w.k0);
+      return;
+    }
+    const float* A = g.A + (long long)w.z*g.a_bs + (long long)w.kb*g.a_kbs;
+    const float* B = g.B + (long long)w.z*g.b_bs + (long long)w.kb*g.b_kbs;
+    if (w.fresh) {
+      // first k-tile of a tile (or of the next operand pair): pointers from scratch; afterwards
+      // they advance by one k-tile per call
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int m = w.m0 + a_r[i];
+        oka[i] = m < g.M;
+        pa[i] = TA ? A + (long long)(w.k0 + a_k[i])*g.lda + m : A + (long long)m*g.lda + (w.k0 + a_k[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int n = w.n0 + b_r[i];
+        okb[i] = n < g.N;
+        pb[i] = TB ? B + (long long)n*g.ldb + (w.k0 + b_k[i]) : B + (long long)(w.k0 + b_k[i])*g.ldb + n;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const bool ok = oka[i] && w.k0 + a_k[i] < g.K;
+      float4 v = *reinterpret_cast<const float4*>(ok ? pa[i] : A);
+      if (PRO == 1 && ok) v = norm_pro(g.pa, w.m0 + a_r[i], w.k0 + a_k[i], v);
+      ra[i] = ok ? v : zero4();
+      pa[i] += TA ? (long long)kBK*g.lda : kBK;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (p.b_scalar) {
+        // weights inside a flat parameter buffer: any alignment, any extent; 4 dwords with
+        // element-wise bounds (small, L2-resident operand)
+        const int lim = TB ? g.K - (w.k0 + b_k[i]) : g.N - (w.n0 + b_r[i]);     // elements left along the contiguous axis
+        const bool rowok = TB ? okb[i] : w.k0 + b_k[i] < g.K;
+        float e[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bool okc = rowok && c < lim;
+          const float t = (okc ? pb[i] : B)[okc ? c : 0];
+          e[c] = okc ? t : 0.f;
+        }
+        rb[i] = make_float4(e[0], e[1], e[2], e[3]);
+      } else {
+        const bool ok = okb[i] && w.k0 + b_k[i] < g.K;
+        float4 v = *reinterpret_cast<const float4*>(ok ? pb[i] : B);
+        if (PRO == 2 && ok) v = norm_pro(g.pb, w.k0 + b_k[i], w.n0 + b_r[i], v);
+        rb[i] = ok ? v : zero4();
+      }
+      pb[i] += TB ? kBK : (long long)kBK*g.ldb;
+    }
+  };
+  // LDS staging addresses are per-thread constants
+  int sa[NA], sb[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) sa[i] = TA ? a_k[i]*LDA + a_r[i] : a_r[i]*LDA + a_k[i];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) sb[i] = A_FLOATS + (TB ? b_r[i]*LDB + b_k[i] : b_k[i]*LDB + b_r[i]);
+  auto stash = [&](int buf) {
+    float* S = lds + buf*STAGE;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(S + sa[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(S + sb[i]) = rb[i];
+  };
+
+  f32x16 acc[2][2];
+  auto clear = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  // operand fragment addresses inside a stage (per-thread constants)
+  const int fa = TA ? 4*kh*LDA + 64*wm + r32 : (64*wm + r32)*LDA + 4*kh;
+  const int fb = A_FLOATS + (TB ? (64*wn + r32)*LDB + 4*kh : 4*kh*LDB + 64*wn + r32);
+  auto compute = [&](int buf) {
+    const float* S = lds + buf*STAGE;
+#pragma unroll
+    for (int j = 0; j < kBK/8; ++j) {
+      float a[2][4], b[2][4];
+      if (BRV_BIG_ABL & 8) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { a[f][i] = (float)(lane + i + j); b[f][i] = (float)(lane - i + f); }
+      } else {
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {
+          if (TA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[fi][i] = S[fa + (8*j + i)*LDA + 32*fi];
+          } else {
+            const float4 v = *reinterpret_cast<const float4*>(S + fa + 32*fi*LDA + 8*j);
+            a[fi][0] = v.x; a[fi][1] = v.y; a[fi][2] = v.z; a[fi][3] = v.w;
+          }
+        }
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) {
+          if (TB) {
+            const float4 v = *reinterpret_cast<const float4*>(S + fb + 32*fj*LDB + 8*j);
+            b[fj][0] = v.x; b[fj][1] = v.y; b[fj][2] = v.z; b[fj][3] = v.w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[fj][i] = S[fb + (8*j + i)*LDB + 32*fj];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+          for (int fj = 0; fj < 2; ++fj)
+            if (BRV_BIG_ABL & 1) acc[fi][fj][i] += a[fi][i]*b[fj][i];
+            else acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[fi][i], b[fj][i], acc[fi][fj], 0, 0, 0);
+    }
+  };
+  auto epilogue = [&](const Work& w) {
+    // D element (row, col) of a 32 x 32 block: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5).
+    // Loads of the bias / addend are issued as one batch per block (rows clamped instead of
+    // predicated: a branch around a load costs a full memory round trip per element); offsets
+    // inside one batch item are 32-bit.
+    float* D1 = g.D + (long long)w.z*g.d_bs; float* D2 = g.D2 + (long long)w.z*g.d_bs;
+    const float* A1 = g.add ? g.add + (long long)w.z*g.add_bs : nullptr;
+    const float* A2 = g.add ? g.add2 + (long long)w.z*g.add_bs : nullptr;
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+      for (int fj = 0; fj < 2; ++fj) {
+        const int col = w.n0 + 64*wn + 32*fj + r32;
+        const bool colok = col < g.N;
+        const int colc = colok ? col : g.N - 1;
+        const int rbase = w.m0 + 64*wm + 32*fi + 4*kh;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = acc[fi][fj][i];
+        if (p.ksplit > 1) {
+          float* sc = g.scratch + ((long long)w.split*g.batch + w.z)*g.M*g.N + colc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = rbase + (i & 3) + 8*(i >> 2);
+            if (colok && row < g.M) sc[row*g.N] = v[i];
+          }
+          continue;
+        }
+        if (g.bias) {
+          if (g.col_bias) {
+            const float bc = g.bias[colc];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += bc;
+          } else {
+            float br[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int row = rbase + (i & 3) + 8*(i >> 2);
+              br[i] = g.bias[row < g.M ? row : g.M - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += br[i];
+          }
+        }
+        // a 32-row block lies on one side of m_split when m_split is a multiple of 32 (the general
+        // case is handled per row)
+        if (A1) {
+          float ad[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            int row = rbase + (i & 3) + 8*(i >> 2);
+            if (row >= g.M) row = g.M - 1;
+            const bool second = row >= g.m_split;
+            ad[i] = (second ? A2 : A1)[(second ? row - g.m_split : row)*g.ldadd + colc];
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] += ad[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = rbase + (i & 3) + 8*(i >> 2);
+          const bool second = row >= g.m_split;
+          if (colok && row < g.M && (!(BRV_BIG_ABL & 4) || v[i] == 1.2345f))
+            (second ? D2 : D1)[(second ? row - g.m_split : row)*g.ldd + colc] = v[i];
+        }
+      }
+  };
+
+  Work cur = decode(blockIdx.x);
+  if (!cur.valid) return;
+  clear();
+  fetch(cur);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  while (true) {
+    const Work nxt = advance(cur);
+    if (nxt.valid) fetch(nxt);
+    compute(buf);
+    if (cur.left == 1) { epilogue(cur); clear(); }
+    if (!nxt.valid) break;
+    stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    cur = nxt;
+  }
+}
+
+// D = bias + add + partial[0] + partial[1] + ... : a workgroup owns 64 elements, its 4 wavefronts
+// take the splits s = w, w + 4, ... (4 loads in flight each), the 4 sums are added in wavefront
+// order -- the association is fixed by the shape, not by the order of arrival
+__global__ __launch_bounds__(256) void gemm_f32_big_reduce_kernel(const BigDev p) {
+  __shared__ float part[4][64];
+  const BigGemm& g = p.g;
+  const long long per = (long long)g.M*g.N;
+  const long long n = (long long)g.batch*per;
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x*64 + c;
+  const long long ic = i < n ? i : n - 1;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = w;
+  for (; s + 12 < p.ksplit; s += 16) {
+    const float v0 = g.scratch[(long long)s*n + ic], v1 = g.scratch[(long long)(s + 4)*n + ic];
+    const float v2 = g.scratch[(long long)(s + 8)*n + ic], v3 = g.scratch[(long long)(s + 12)*n + ic];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; s < p.ksplit; s += 4) s0 += g.scratch[(long long)s*n + ic];
+  part[w][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w != 0 || i >= n) return;
+  float v = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+  const int z = (int)(i / per); const long long r = i % per;
+  const int row = (int)(r / g.N), col = (int)(r % g.N);
+  if (g.bias) v += g.bias[g.col_bias ? col : row];
+  const bool second = row >= g.m_split;
+  const int rr = second ? row - g.m_split : row;
+  const float* ad = second ? g.add2 : g.add;
+  if (ad) v += ad[(long long)z*g.add_bs + (long long)rr*g.ldadd + col];
+  (second ? g.D2 : g.D)[(long long)z*g.d_bs + (long long)rr*g.ldd + col] = v;
+}
+
+inline bool q4(long long v) { return (v & 3) == 0; }
+inline bool a16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+inline bool b_vector(const BigGemm& g) {
+  return a16(g.B) && q4(g.ldb) && q4(g.b_bs) && q4(g.b_kbs) && q4(g.tb ? g.K : g.N);
+}
+
+struct Plan { int wm, wn, m_tiles, n_tiles, mn_padded, xcd_perm, ksplit, ktiles; long long total_t, per_t; };
+
+int device_cus() {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 256;
+  return cus;
+}
+
+Plan make_plan(const BigGemm& g) {
+  Plan pl;
+  auto waste = [&](long long tm, long long tn) {
+    return ((g.M + tm - 1)/tm*tm)*((g.N + tn - 1)/tn*tn);
+  };
+  const bool tall = waste(256, 128) <= waste(128, 256);
+  pl.wm = tall ? 4 : 2; pl.wn = tall ? 2 : 4;
+  const int tm = 64*pl.wm, tn = 64*pl.wn;
+  pl.m_tiles = (int)((g.M + tm - 1)/tm); pl.n_tiles = (int)((g.N + tn - 1)/tn);
+  pl.xcd_perm = pl.m_tiles >= 16 && pl.n_tiles > 1;
+  pl.mn_padded = pl.xcd_perm ? (pl.m_tiles + 7)/8*8*pl.n_tiles : pl.m_tiles*pl.n_tiles;
+  pl.ktiles = (g.K + kBK - 1)/kBK;
+  pl.total_t = (long long)(g.kbatch > 1 ? g.kbatch : 1)*pl.ktiles;
+  const long long tiles = (long long)g.batch*pl.m_tiles*pl.n_tiles;
+  long long ks = 1;
+  const int cus = device_cus();
+  if (tiles*2 <= cus && pl.total_t >= 32) {
+    ks = cus/tiles;
+    if (ks > pl.total_t/8) ks = pl.total_t/8;
+    if (ks < 1) ks = 1;
+  }
+  pl.per_t = (pl.total_t + ks - 1)/ks;
+  pl.ksplit = (int)((pl.total_t + pl.per_t - 1)/pl.per_t);
+  return pl;
+}
+
+}  // namespace
+
+bool gemm_f32_big_ok(const BigGemm& g) {
+  if (g.M < 1 || g.N < 1 || g.K < 1 || g.batch < 1) return false;
+  // A: 16-byte loads (aligned base and strides, the extent along its contiguous axis a whole number
+  // of 16-byte pieces); B takes the dword loader when it does not qualify (b_vector)
+  if (!a16(g.A) || !q4(g.lda) || !q4(g.a_bs) || !q4(g.a_kbs) || !q4(g.ta ? g.M : g.K)) return false;
+  if (g.pb.table && !b_vector(g)) return false;
+  if ((g.pa.table && g.ta) || (g.pb.table && (g.tb || g.kbatch > 1)) || (g.pa.table && g.pb.table)) return false;
+  if ((g.pa.table && !g.tb) || (g.pb.table && !g.ta)) return false;       // instantiated pairs only
+  if ((g.pa.table || g.pb.table) && g.batch != 1) return false;            // frame index = row / k index
+  // 32-bit offsets inside one batch item of the result / addend, 32-bit work-item counts
+  if ((long long)g.M*g.ldd >= (1LL << 31) || (g.add && (long long)g.M*g.ldadd >= (1LL << 31)) ||
+      (long long)g.M*g.N >= (1LL << 31)) return false;
+  if (g.D2 && (g.m_split < 1 || g.m_split >= g.M)) return false;
+  return true;
+}
+
+long long gemm_f32_big_scratch(const BigGemm& g) {
+  const Plan pl = make_plan(g);
+  return pl.ksplit > 1 ? (long long)pl.ksplit*g.batch*g.M*g.N : 0;
+}
+
+int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
+  if (!gemm_f32_big_ok(g_in)) return -1;
+  BigDev p;
+  p.g = g_in;
+  if (!p.g.D2) { p.g.m_split = p.g.M; p.g.D2 = p.g.D; p.g.add2 = p.g.add; }
+  if (p.g.kbatch < 1) p.g.kbatch = 1;
+  const Plan pl = make_plan(p.g);
+  p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles; p.mn_padded = pl.mn_padded; p.xcd_perm = pl.xcd_perm;
+  p.ksplit = pl.ksplit; p.ktiles = pl.ktiles; p.total_t = pl.total_t; p.per_t = pl.per_t;
+  if (p.ksplit > 1 && (!p.g.scratch || p.g.scratch_floats < (long long)p.ksplit*p.g.batch*p.g.M*p.g.N)) {
+    // no scratch from the caller: one workgroup per tile walks the whole reduction
+    p.ksplit = 1; p.per_t = p.total_t;
+  }
+  p.n_work = p.g.batch*p.ksplit*p.mn_padded;
+  p.b_scalar = b_vector(p.g) ? 0 : 1;
+  const int cus = device_cus();
+  const int grid = p.n_work < cus ? p.n_work : cus;
+  const int pro = p.g.pa.table ? 1 : (p.g.pb.table ? 2 : 0);
+#define BRV_BIG(WM_, WN_, TA_, TB_, PRO_) \
+  hipLaunchKernelGGL((gemm_f32_big_kernel<WM_, WN_, TA_, TB_, PRO_>), dim3(grid), dim3(512), 0, st, p)
+#define BRV_BIG_SHAPE(WM_, WN_)                                       \
+  do {                                                                \
+    if (pro == 1) BRV_BIG(WM_, WN_, false, true, 1);                  \
+    else if (pro == 2) BRV_BIG(WM_, WN_, true, false, 2);             \
+    else if (p.g.ta && p.g.tb) BRV_BIG(WM_, WN_, true, true, 0);      \
+    else if (p.g.ta) BRV_BIG(WM_, WN_, true, false, 0);               \
+    else if (p.g.tb) BRV_BIG(WM_, WN_, false, true, 0);               \
+    else BRV_BIG(WM_, WN_, false, false, 0);                          \
+  } while (0)
+  if (pl.wm == 4) BRV_BIG_SHAPE(4, 2); else BRV_BIG_SHAPE(2, 4);
+#undef BRV_BIG_SHAPE
+#undef BRV_BIG
+  if (p.ksplit > 1) {
+    const long long n = (long long)p.g.batch*p.g.M*p.g.N;
+    hipLaunchKernelGGL(gemm_f32_big_reduce_kernel, dim3((unsigned)((n + 63)/64)), dim3(256), 0, st, p);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace brv

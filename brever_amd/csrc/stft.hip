@@ -13,6 +13,7 @@
 
 #include "../../include/brever_hip.h"
 #include "common.cuh"
+#include "gemm_f32_big.h"
 
 using namespace brv;
 
@@ -949,6 +950,31 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   if (accumulate == 2) accumulate = 0;
   p.row_bias = row_bias; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
+#ifndef BRV_GEMM_F32_SMALL       // diagnostic builds: every fp32 product on the 128 x 128 kernel below
+  if (!lowp && M >= 64 && N >= 64 &&
+      (double)M*(double)N*(double)K*(double)batch*(kbatch > 1 ? kbatch : 1) >= 3.0e7) {
+    // 16-byte aligned operands of a product worth a 256 x 128 tile: gemm_f32_big.hip
+    brv::BigGemm g; memset(&g, 0, sizeof(g));
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.kbatch = kbatch > 1 ? (int)kbatch : 1; g.batch = (int)batch;
+    g.A = a; g.a_bs = a_batch_stride; g.a_kbs = a_kbatch_stride; g.lda = (int)lda; g.ta = trans_a != 0;
+    g.B = b; g.b_bs = b_batch_stride; g.b_kbs = b_kbatch_stride; g.ldb = (int)ldb; g.tb = trans_b != 0;
+    g.D = d; g.d_bs = d_batch_stride; g.ldd = (int)ldd;
+    g.bias = row_bias; g.col_bias = p.col_bias;
+    if (accumulate) { g.add = d; g.add_bs = d_batch_stride; g.ldadd = (int)ldd; }
+    if (brv::gemm_f32_big_ok(g)) {
+      const long long need = brv::gemm_f32_big_scratch(g);
+      void* scratch = nullptr;
+      if (need > 0) {
+        // partial tiles of a split reduction: stream-ordered allocation, released behind the product
+        if (hipMallocAsync(&scratch, (size_t)need*4, st) != hipSuccess) { scratch = nullptr; (void)hipGetLastError(); }
+        g.scratch = (float*)scratch; g.scratch_floats = scratch ? need : 0;
+      }
+      const int r = brv::gemm_f32_big(g, st);
+      if (scratch) (void)hipFreeAsync(scratch, st);
+      return r;
+    }
+  }
+#endif
   // reduction split: fill the chip when the output has few tiles and the reduction is long
   const long long tiles = ((M + BM2 - 1)/BM2)*((N + BN2 - 1)/BN2)*batch;
   const long long red = (kbatch > 1 ? kbatch : 1)*((K + BK2 - 1)/BK2);

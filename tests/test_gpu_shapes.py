@@ -462,3 +462,58 @@ def test_clip_adam_step2_matches_torch():
         assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
         if two:
             assert float(g2.abs().max()) == 0.0                      # left zeroed for the next step
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_f32_big_tiles_all_layouts(ta, tb):
+    """brv_gemm_f32 on the 256 x 128 / 128 x 256 tile kernel (csrc/gemm_f32_big.hip: 16-byte aligned
+    operands, M, N >= 64) vs the float64 product: both storage orders of both operands, row and column
+    tails, leading dimensions larger than the extent, batches, a reduction over operand pairs, row / column
+    bias, accumulation, and the split reduction of weight-gradient shapes (long K, few tiles) -- whose
+    result must be bitwise repeatable (partial tiles added in split order, no atomics). rel-L2 <= 2e-6."""
+    import torch
+    from brever_amd import hip
+    lib = hip.lib()
+    gen = torch.Generator().manual_seed(7 + 2*ta + tb)
+    dev = torch.device('cuda')
+    #        batch M    N    K     kbatch  bias  acc
+    cases = [(1, 1000, 512, 128, 1, 'col', 0),      # 1x1 convolution: 4 row tiles (one partial) x 4 column tiles
+             (1, 700, 128, 512, 1, None, 1),        # accumulate into d, N = one tile
+             (2, 260, 132, 96, 1, 'row', 0),        # batch, tails in M, N, K tile (96 = 3 x 32)
+             (1, 128, 512, 20000, 1, None, 1),      # weight gradient: 128 x 256 tiles, split reduction
+             (1, 512, 128, 4100, 3, 'row', 0),      # reduction over 3 operand pairs, split, K tail (4100 = 128 x 32 + 4)
+             (3, 64, 64, 4096, 1, None, 0)]         # smallest tile shape the kernel takes
+    for batch, M, N, K, kbatch, bias, acc in cases:
+        lda = (M if ta else K) + 4
+        ldb = (K if tb else N) + 8
+        ldd = N + 3
+        a = torch.randn(batch, kbatch, (K if ta else M), lda, generator=gen)
+        b = torch.randn(batch, kbatch, (N if tb else K), ldb, generator=gen)
+        d0 = torch.randn(batch, M, ldd, generator=gen)
+        bv = torch.randn(M if bias == 'row' else N, generator=gen) if bias else None
+        opa = a[..., :M].transpose(-1, -2) if ta else a[..., :K]
+        opb = b[..., :K].transpose(-1, -2) if tb else b[..., :N]
+        want = torch.einsum('zkmr,zkrn->zmn', opa.double(), opb.double())
+        if bias == 'row':
+            want = want + bv.double()[None, :, None]
+        elif bias == 'col':
+            want = want + bv.double()[None, None, :]
+        if acc:
+            want = want + d0[..., :N].double()
+        ad, bd = a.to(dev), b.to(dev)
+        bvd = bv.to(dev) if bias else None
+        outs = []
+        for rep in range(2):
+            d = d0.to(dev).clone()
+            hip.check(lib.brv_gemm_f32(
+                hip.ptr(ad), hip.ptr(bd), hip.ptr(d), batch, M, N, K, lda, ldb, ldd,
+                ad.stride(0), bd.stride(0), d.stride(0), ta, tb, kbatch, ad.stride(1), bd.stride(1),
+                hip.ptr(bvd) if bias else None, (2 if bias == 'col' else acc), hip.stream()), 'brv_gemm_f32')
+            torch.cuda.synchronize()
+            outs.append(d.cpu())
+        got = outs[0]
+        assert torch.equal(outs[0], outs[1]), (batch, M, N, K, 'not repeatable')
+        assert torch.equal(got[..., N:], d0[..., N:]), 'wrote outside the N columns'
+        rel = float((got[..., :N].double() - want).norm()/want.norm())
+        assert rel <= 2e-6, (batch, M, N, K, kbatch, bias, acc, rel)
