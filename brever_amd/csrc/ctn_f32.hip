@@ -22,6 +22,7 @@
 
 #include "../../include/brever_hip.h"
 #include "common.cuh"
+#include "gemm_f32_big.h"
 
 using namespace brv;
 
@@ -89,12 +90,13 @@ struct Lay32 {
   }
 };
 
-constexpr int kSliceRows = 256;         // rows per workgroup of the per-channel reductions
+constexpr int kSliceRows = 256;         // rows per workgroup of the per-channel reductions (plain path)
+#include "ctn_f32_fused.cuh"
 
 // workspace offsets in floats
 struct Ws32 {
   long long Lp, wavep, w, wn, x, x_stride, z1, z2, z_stride, tab, tab_stride, skip, h, pre, dpre,
-      y, fr, dop, dy, dwm, act, G, e, dz, fsum, btab, part, part_floats, scalars, total;
+      y, fr, dop, dy, dwm, act, G, e, dz, fsum, btab, part, part_floats, scalars, gscratch, gscratch_floats, total;
   void init(const Lay32& l, long long B, long long T, long long L) {
     long long o = 0;
     auto take = [&](long long n) { long long r = o; o += up(n, 64); return r; };
@@ -123,13 +125,16 @@ struct Ws32 {
     e = take(BT*cmax); dz = take(BT*cmax);
     fsum = take(BT*2); btab = take(BT*2);
     // partial sums of the per-channel reductions: slices x quantities (<= 2 + P + 1) x channels
-    const long long slices = (BT + kSliceRows - 1)/kSliceRows;
-    long long cq = (long long)(l.P + 1)*l.H;
+    const long long slices = (BT + kFusedRows - 1)/kFusedRows;      // >= the 256-row slices of the plain path
+    long long cq = (long long)(l.P + 2)*l.H;
     if (2*cmax > cq) cq = 2*cmax;
     if ((long long)l.S*l.N > cq) cq = (long long)l.S*l.N;
     part_floats = slices*cq;
     part = take(part_floats);
-    scalars = take(4096);
+    scalars = take(4096 > slices ? 4096 : slices);
+    // partial tiles of split reductions (weight gradients): at most one 256 x 128 tile per compute unit
+    gscratch_floats = 32768LL*320;
+    gscratch = take(gscratch_floats);
     total = o;
   }
 };
@@ -684,6 +689,122 @@ int norm_backward(const Ctx32& c, const float* e, const float* z, const float* s
   return 0;
 }
 
+// ---- fused path (ctn_f32_fused.cuh + the operand transforms of gemm_f32_big.hip) -------------------
+// Taken when every channel count is a multiple of 4 (16-byte accesses) and <= 1024; other
+// configurations run the plain kernels above.
+bool fused_ok(const Lay32& l, const void* workspace) {
+  auto q = [](int v) { return v % 4 == 0; };
+  return q(l.N) && q(l.Bn) && q(l.H) && q(l.Sc) && l.H <= 256*kMaxNJ && l.N <= 256*kMaxNJ &&
+         (((uintptr_t)workspace) & 15) == 0;
+}
+int nj_of(int C) { return (C/4 + 63)/64; }
+
+#define BRV_NJ_LAUNCH(KERNEL, C_, grid, st, arg)                                                        \
+  do {                                                                                                  \
+    switch (nj_of(C_)) {                                                                                \
+      case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(256), 0, st, arg); break;                      \
+      case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, st, arg); break;                      \
+      case 3: hipLaunchKernelGGL((KERNEL<3>), grid, dim3(256), 0, st, arg); break;                      \
+      default: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, st, arg); break;                     \
+    }                                                                                                   \
+  } while (0)
+#define BRV_NJP_LAUNCH(KERNEL, C_, P_, grid, st, arg)                                                   \
+  do {                                                                                                  \
+    const int nj_ = nj_of(C_);                                                                          \
+    if ((P_) <= 3) {                                                                                    \
+      if (nj_ == 1) hipLaunchKernelGGL((KERNEL<1, 3>), grid, dim3(256), 0, st, arg);                    \
+      else if (nj_ == 2) hipLaunchKernelGGL((KERNEL<2, 3>), grid, dim3(256), 0, st, arg);               \
+      else if (nj_ == 3) hipLaunchKernelGGL((KERNEL<3, 3>), grid, dim3(256), 0, st, arg);               \
+      else hipLaunchKernelGGL((KERNEL<4, 3>), grid, dim3(256), 0, st, arg);                             \
+    } else {                                                                                            \
+      if (nj_ == 1) hipLaunchKernelGGL((KERNEL<1, 7>), grid, dim3(256), 0, st, arg);                    \
+      else if (nj_ == 2) hipLaunchKernelGGL((KERNEL<2, 7>), grid, dim3(256), 0, st, arg);               \
+      else if (nj_ == 3) hipLaunchKernelGGL((KERNEL<3, 7>), grid, dim3(256), 0, st, arg);               \
+      else hipLaunchKernelGGL((KERNEL<4, 7>), grid, dim3(256), 0, st, arg);                             \
+    }                                                                                                   \
+  } while (0)
+
+inline unsigned fused_slices(const Ctx32& c) { return (unsigned)((c.BT + kFusedRows - 1)/kFusedRows); }
+
+// one product on the big-tile kernel with this workspace's scratch for split reductions
+int big(const Ctx32& c, BigGemm g) {
+  g.batch = 1; if (g.kbatch < 1) g.kbatch = 1;
+  g.scratch = c.f(c.ws.gscratch); g.scratch_floats = c.ws.gscratch_floats;
+  const int r = gemm_f32_big(g, c.st);
+  if (r) return fail32(r, "fp32 Conv-TasNet path: gemm_f32_big refused a product");
+  return 0;
+}
+// d[rows][n] = op(a)[rows][k] W[n][k]^T + bias[n] (+ add), op = identity or the norm transform `pro`
+int conv1x1_f(const Ctx32& c, const float* a, int lda, const NormPro* pro, const float* W, int N, int K,
+              float* d, int ldd, const float* bias, const float* add, int ldadd) {
+  BigGemm g; memset(&g, 0, sizeof(g));
+  g.M = (int)c.BT; g.N = N; g.K = K;
+  g.A = a; g.lda = lda; g.B = W; g.ldb = K; g.tb = 1;
+  g.D = d; g.ldd = ldd; g.bias = bias; g.col_bias = 1;
+  g.add = add; g.ldadd = ldadd;
+  if (pro) g.pa = *pro;
+  return big(c, g);
+}
+// dW[n][k] += sum_rows g[rows][n] op(a)[rows][k]; rows >= m_split of dW go to dW2
+int wgrad_f(const Ctx32& c, const float* gr, int ldg, int Nrows, const float* a, int lda, const NormPro* pro,
+            int K, float* dW, float* dW2, int m_split) {
+  BigGemm g; memset(&g, 0, sizeof(g));
+  g.M = Nrows; g.N = K; g.K = (int)c.BT;
+  g.A = gr; g.lda = ldg; g.ta = 1; g.B = a; g.ldb = lda;
+  g.D = dW; g.ldd = K; g.add = dW; g.ldadd = K;
+  if (dW2) { g.D2 = dW2; g.add2 = dW2; g.m_split = m_split; }
+  if (pro) g.pb = *pro;
+  return big(c, g);
+}
+// d[rows][k] = sum over `pairs` operand pairs of g[rows][n] W[n][k] (+ add)
+int dgrad_f(const Ctx32& c, const float* gr, int ldg, const float* W, int N, int K, float* d, int ldd,
+            const float* add, int ldadd, int pairs, long long g_pair_stride, long long w_pair_stride) {
+  BigGemm g; memset(&g, 0, sizeof(g));
+  g.M = (int)c.BT; g.N = K; g.K = N; g.kbatch = pairs; g.a_kbs = g_pair_stride; g.b_kbs = w_pair_stride;
+  g.A = gr; g.lda = ldg; g.B = W; g.ldb = K;
+  g.D = d; g.ldd = ldd; g.add = add; g.ldadd = ldadd;
+  return big(c, g);
+}
+int fold(const Ctx32& c, int nq, int C, float* const* dst, const int* stride) {
+  FoldJob j; memset(&j, 0, sizeof(j));
+  j.part = c.f(c.ws.part); j.slices = (int)fused_slices(c); j.nq = nq; j.C = C;
+  for (int k = 0; k < nq; ++k) { j.dst[k] = dst[k]; j.stride[k] = stride[k]; }
+  hipLaunchKernelGGL(f32_fold_kernel, dim3((nq*C + 15)/16), dim3(1024), 0, c.st, j);
+  HIP_OK32(hipGetLastError());
+  return 0;
+}
+int fwd_table(const Ctx32& c, float* table, int C) {
+  hipLaunchKernelGGL(f32_fwd_table_kernel, dim3((unsigned)c.B), dim3(256), 0, c.st, c.f(c.ws.fsum), table,
+                     (int)c.T, C, 1e-8f, c.l.causal);
+  HIP_OK32(hipGetLastError());
+  return 0;
+}
+// gradient through y = norm(prelu(z)) in two passes (+ tables); `presummed`: pass 1 (frame sums in
+// ws.fsum, dgain / dbias already folded) was done by the producer of e
+int norm_backward_f(const Ctx32& c, const float* e, const float* z, const float* slope_p, const float* table,
+                    const float* gain, int C, const float* add, float* dz, float* dgain, float* dbias,
+                    float* dslope, float* dchan, bool presummed) {
+  const FusedCommon fc{c.BT, (int)c.T, C};
+  const unsigned slices = fused_slices(c);
+  if ((long long)slices*2*C > c.ws.part_floats) return fail32(-1, "fp32 path: reduction scratch too small");
+  float* fsum = c.f(c.ws.fsum); float* btab = c.f(c.ws.btab);
+  if (!presummed) {
+    BwdSums q{fc, e, z, table, slope_p, gain, fsum, c.f(c.ws.part)};
+    BRV_NJ_LAUNCH(f32_bwd_sums_kernel, C, dim3(slices), c.st, q);
+    float* dst[2] = {dgain, dbias}; const int stride[2] = {1, 1};
+    OK32(fold(c, 2, C, dst, stride));
+  }
+  hipLaunchKernelGGL(f32_bwd_table_kernel, dim3((unsigned)c.B), dim3(256), 0, c.st, fsum, table, btab,
+                     (int)c.T, C, c.l.causal);
+  BwdApply a{fc, e, z, slope_p, table, btab, gain, add, dz, dslope ? c.f(c.ws.scalars) : nullptr,
+             dchan ? c.f(c.ws.part) : nullptr};
+  BRV_NJ_LAUNCH(f32_bwd_apply_fused_kernel, C, dim3(slices), c.st, a);
+  if (dslope) hipLaunchKernelGGL(f32_fold_scalar_kernel, dim3(1), dim3(256), 0, c.st, c.f(c.ws.scalars), (int)slices, dslope);
+  if (dchan) { float* dst[1] = {dchan}; const int stride[1] = {1}; OK32(fold(c, 1, C, dst, stride)); }
+  HIP_OK32(hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -710,15 +831,38 @@ int brv_ctn_f32_forward(const brv_ctn_config* cfg, const float* params, void* wo
                      B, L, ws.Lp);
   OK32(gemm32(c, c.f(ws.wavep), params + l.enc_w, w, B, T, l.N, l.K, l.hop, l.K, l.N, ws.Lp, 0,
               T*l.N, 0, 1, 1, 0, 0, nullptr, 0));
+  const bool fused = fused_ok(l, workspace);
   OK32(norm_forward(c, w, nullptr, c.tab(0), l.N));
-  OK32(norm_apply(c, w, nullptr, c.tab(0), params + l.ln_g, params + l.ln_b, wn, l.N));
-  OK32(conv1x1(c, wn, l.N, params + l.bott_w, l.Bn, l.N, c.xb(0), l.Bn, params + l.bott_b, 2));
+  if (fused) {
+    const NormPro n0{c.tab(0), params + l.ln_g, params + l.ln_b, nullptr};
+    OK32(conv1x1_f(c, w, l.N, &n0, params + l.bott_w, l.Bn, l.N, c.xb(0), l.Bn, params + l.bott_b, nullptr, 0));
+  } else {
+    OK32(norm_apply(c, w, nullptr, c.tab(0), params + l.ln_g, params + l.ln_b, wn, l.N));
+    OK32(conv1x1(c, wn, l.N, params + l.bott_w, l.Bn, l.N, c.xb(0), l.Bn, params + l.bott_b, 2));
+  }
   for (int i = 0; i < l.nb; ++i) {
     const Blk32& b = l.blk[i];
     const bool has_res = i < l.nb - 1;
     const int dil = 1 << (i % l.layers);
     const int total = (l.P - 1)*dil;
     const int left = l.causal ? total : total/2;
+    if (fused) {
+      // z1 = conv(x); statistics of prelu(z1); z2 = dconv(norm(prelu(z1))) with the statistics of
+      // prelu(z2) from the same kernel; the second norm is applied inside the [res | skip] products
+      OK32(conv1x1_f(c, c.xb(i), l.Bn, nullptr, params + b.conv_w, l.H, l.Bn, c.z1b(i), l.H, params + b.conv_b, nullptr, 0));
+      OK32(norm_forward(c, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), l.H));
+      DwFwd d{{BT, (int)T, l.H}, c.z1b(i), c.tab(1 + 2*i), params + b.prelu1, params + b.n1_g, params + b.n1_b,
+              params + b.dconv_w, params + b.dconv_b, c.z2b(i), params + b.prelu2, c.f(ws.fsum), l.P, dil, left};
+      BRV_NJP_LAUNCH(f32_dw_fwd_fused_kernel, l.H, l.P, dim3(fused_slices(c)), st, d);
+      OK32(fwd_table(c, c.tab(2 + 2*i), l.H));
+      const NormPro n2{c.tab(2 + 2*i), params + b.n2_g, params + b.n2_b, params + b.prelu2};
+      if (has_res)
+        OK32(conv1x1_f(c, c.z2b(i), l.H, &n2, params + b.res_w, l.Bn, l.H, c.xb(i + 1), l.Bn, params + b.res_b,
+                       c.xb(i), l.Bn));
+      OK32(conv1x1_f(c, c.z2b(i), l.H, &n2, params + b.skip_w, l.Sc, l.H, skip, l.Sc, params + b.skip_b,
+                     i == 0 ? nullptr : skip, l.Sc));
+      continue;
+    }
     OK32(conv1x1(c, c.xb(i), l.Bn, params + b.conv_w, l.H, l.Bn, c.z1b(i), l.H, params + b.conv_b, 2));
     OK32(norm_forward(c, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), l.H));
     OK32(norm_apply(c, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), params + b.n1_g, params + b.n1_b, h, l.H));
@@ -789,6 +933,7 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
   float* G = c.f(ws.G); float* e = c.f(ws.e); float* dz = c.f(ws.dz);
   const int ldg = l.Bn + l.Sc;
   float* spart = c.f(ws.scalars);
+  const bool fused = fused_ok(l, workspace);
   if (head) {
   // decoder: d frames = framing of the padded d_out; dy = d frames x dec_w^T; dec_w gradient
   hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(BS*ws.Lp)), dim3(256), 0, st, d_out, dop, BS, L, ws.Lp);
@@ -816,6 +961,42 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
     const int dil = 1 << (i % l.layers);
     const int total = (l.P - 1)*dil;
     const int left = l.causal ? total : total/2;
+    if (fused) {
+      // [res | skip] weight gradients in one product against norm2(prelu2(z2)) rebuilt on load
+      const NormPro n2{c.tab(2 + 2*i), params + b.n2_g, params + b.n2_b, params + b.prelu2};
+      if (has_res)
+        OK32(wgrad_f(c, G, ldg, l.Bn + l.Sc, c.z2b(i), l.H, &n2, l.H, grads + b.res_w, grads + b.skip_w, l.Bn));
+      else
+        OK32(wgrad_f(c, G + l.Bn, ldg, l.Sc, c.z2b(i), l.H, &n2, l.H, grads + b.skip_w, nullptr, 0));
+      OK32(col_sum(c, G + l.Bn, ldg, l.Sc, grads + b.skip_b));
+      if (has_res) OK32(col_sum(c, G, ldg, l.Bn, grads + b.res_b));
+      // data gradient wrt h2: one product over the (res, skip) operand pairs when they have one shape
+      if (has_res && l.Bn == l.Sc) {
+        OK32(dgrad_f(c, G, ldg, params + b.res_w, l.Bn, l.H, e, l.H, nullptr, 0, 2, l.Bn, b.skip_w - b.res_w));
+      } else {
+        OK32(dgrad_f(c, G + l.Bn, ldg, params + b.skip_w, l.Sc, l.H, e, l.H, nullptr, 0, 1, 0, 0));
+        if (has_res) OK32(dgrad_f(c, G, ldg, params + b.res_w, l.Bn, l.H, e, l.H, e, l.H, 1, 0, 0));
+      }
+      OK32(norm_backward_f(c, e, c.z2b(i), params + b.prelu2, c.tab(2 + 2*i), params + b.n2_g, l.H, nullptr, dz,
+                           grads + b.n2_g, grads + b.n2_b, grads + b.prelu2, grads + b.dconv_b, false));
+      // depthwise conv: tap gradients against h1 rebuilt from z1, transposed stencil -> e (wrt h1), and
+      // pass 1 of the first norm's backward on that e
+      {
+        if ((long long)fused_slices(c)*(l.P + 2)*l.H > ws.part_floats) return fail32(-1, "fp32 path: reduction scratch too small");
+        DwBwd d{{BT, (int)T, l.H}, dz, c.z1b(i), c.tab(1 + 2*i), params + b.prelu1, params + b.n1_g, params + b.n1_b,
+                params + b.dconv_w, e, c.f(ws.fsum), c.f(ws.part), l.P, dil, left};
+        BRV_NJP_LAUNCH(f32_dw_bwd_fused_kernel, l.H, l.P, dim3(fused_slices(c)), st, d);
+        float* dst[9]; int stride[9];
+        for (int k = 0; k < l.P; ++k) { dst[k] = grads + b.dconv_w + k; stride[k] = l.P; }
+        dst[l.P] = grads + b.n1_g; stride[l.P] = 1; dst[l.P + 1] = grads + b.n1_b; stride[l.P + 1] = 1;
+        OK32(fold(c, l.P + 2, l.H, dst, stride));
+      }
+      OK32(norm_backward_f(c, e, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), params + b.n1_g, l.H, nullptr, dz,
+                           nullptr, nullptr, grads + b.prelu1, grads + b.conv_b, true));
+      OK32(wgrad_f(c, dz, l.H, l.H, c.xb(i), l.Bn, nullptr, l.Bn, grads + b.conv_w, nullptr, 0));
+      OK32(dgrad_f(c, dz, l.H, params + b.conv_w, l.H, l.Bn, G, ldg, has_res ? G : nullptr, ldg, 1, 0, 0));
+      continue;
+    }
     // h2 again; [res | skip] weight / bias gradients; data gradient -> e (wrt h2)
     OK32(norm_apply(c, c.z2b(i), params + b.prelu2, c.tab(2 + 2*i), params + b.n2_g, params + b.n2_b, h, l.H));
     OK32(conv1x1_wgrad(c, G + l.Bn, ldg, h, l.H, l.Sc, l.H, grads + b.skip_w));
@@ -852,11 +1033,20 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
   }
   if (tail) {
   // bottleneck conv, first layer norm, encoder
+  if (fused) {
+    const NormPro n0{c.tab(0), params + l.ln_g, params + l.ln_b, nullptr};
+    OK32(wgrad_f(c, G, ldg, l.Bn, w, l.N, &n0, l.N, grads + l.bott_w, nullptr, 0));
+    OK32(col_sum(c, G, ldg, l.Bn, grads + l.bott_b));
+    OK32(dgrad_f(c, G, ldg, params + l.bott_w, l.Bn, l.N, e, l.N, nullptr, 0, 1, 0, 0));
+    OK32(norm_backward_f(c, e, w, nullptr, c.tab(0), params + l.ln_g, l.N, dwm, dz, grads + l.ln_g,
+                         grads + l.ln_b, nullptr, nullptr, false));
+  } else {
   OK32(conv1x1_wgrad(c, G, ldg, wn, l.N, l.Bn, l.N, grads + l.bott_w));
   OK32(col_sum(c, G, ldg, l.Bn, grads + l.bott_b));
   OK32(conv1x1_dgrad(c, G, ldg, params + l.bott_w, l.Bn, l.N, e, l.N, 0));
   OK32(norm_backward(c, e, w, nullptr, c.tab(0), params + l.ln_g, l.N, dwm, dz, grads + l.ln_g,
                      grads + l.ln_b, nullptr));
+  }
   OK32(gemm32(c, dz, c.f(ws.wavep), grads + l.enc_w, 1, l.N, l.K, T, l.N, l.hop, l.K, 0, 0, 0, 1, 0, B,
               T*l.N, ws.Lp, nullptr, 1));
   }   // tail

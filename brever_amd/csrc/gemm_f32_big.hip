@@ -44,18 +44,17 @@ constexpr int kLDK = kBK + 4;    // floats per LDS row of a k-contiguous operand
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-__device__ __forceinline__ float4 norm_pro(const NormPro& q, long long frame, int ch, float4 v) {
-  const float mean = q.table[2*frame], rstd = q.table[2*frame + 1];
-  const float a = q.slope ? *q.slope : 1.f;
-  const bool act = q.slope != nullptr;
-  const float* g = q.gain + ch; const float* b = q.bias + ch;
+// y = (prelu(z) - mean) rstd gain + bias on 4 consecutive channels
+__device__ __forceinline__ float4 norm_pro(float4 v, float mean, float rstd, float a, bool act,
+                                           const float4& g, const float4& b) {
   float4 o;
-  o.x = (((v.x > 0.f || !act) ? v.x : a*v.x) - mean)*rstd*g[0] + b[0];
-  o.y = (((v.y > 0.f || !act) ? v.y : a*v.y) - mean)*rstd*g[1] + b[1];
-  o.z = (((v.z > 0.f || !act) ? v.z : a*v.z) - mean)*rstd*g[2] + b[2];
-  o.w = (((v.w > 0.f || !act) ? v.w : a*v.w) - mean)*rstd*g[3] + b[3];
+  o.x = (((v.x > 0.f || !act) ? v.x : a*v.x) - mean)*rstd*g.x + b.x;
+  o.y = (((v.y > 0.f || !act) ? v.y : a*v.y) - mean)*rstd*g.y + b.y;
+  o.z = (((v.z > 0.f || !act) ? v.z : a*v.z) - mean)*rstd*g.z + b.z;
+  o.w = (((v.w > 0.f || !act) ? v.w : a*v.w) - mean)*rstd*g.w + b.w;
   return o;
 }
+__device__ __forceinline__ float4 ld4s(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }
 
 struct Work { int valid, z, split, m0, n0, kb, k0, left, fresh; int q; };
 
@@ -119,6 +118,12 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
   const float* pa[NA]; const float* pb[NB];
   bool oka[NA], okb[NB];
   float4 ra[NA], rb[NB];
+  // operand transform: what does not change over the k-tiles of a tile is loaded once per tile
+  float pm[PRO == 1 ? NA : 1], pr[PRO == 1 ? NA : 1];      // PRO 1: (mean, rstd) of the thread's rows
+  float4 pg = zero4(), pbias = zero4();                    // PRO 2: gain / bias of the thread's columns
+  const NormPro& np = PRO == 2 ? g.pb : g.pa;
+  const bool pact = PRO != 0 && np.slope != nullptr;
+  const float pslope = pact ? *np.slope : 1.f;
   auto fetch = [&](const Work& w) {
     if (BRV_BIG_ABL & 2) {
 #pragma unroll
@@ -137,6 +142,12 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
         const int m = w.m0 + a_r[i];
         oka[i] = m < g.M;
         pa[i] = TA ? A + (long long)(w.k0 + a_k[i])*g.lda + m : A + (long long)m*g.lda + (w.k0 + a_k[i]);
+        if (PRO == 1) { const int mc = oka[i] ? m : 0; pm[i] = np.table[2*mc]; pr[i] = np.table[2*mc + 1]; }
+      }
+      if (PRO == 2) {
+        const int n = w.n0 + b_r[0];            // the same columns for all of the thread's B loads
+        const int nc = n < g.N ? n : 0;
+        pg = ld4s(np.gain + nc); pbias = ld4s(np.bias + nc);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -145,11 +156,16 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
         pb[i] = TB ? B + (long long)n*g.ldb + (w.k0 + b_k[i]) : B + (long long)(w.k0 + b_k[i])*g.ldb + n;
       }
     }
+    if (PRO == 1) {
+      const int kc = w.k0 + a_k[0];             // the same 4 channels for all of the thread's A loads
+      const int kcc = kc < g.K ? kc : 0;
+      pg = ld4s(np.gain + kcc); pbias = ld4s(np.bias + kcc);
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const bool ok = oka[i] && w.k0 + a_k[i] < g.K;
       float4 v = *reinterpret_cast<const float4*>(ok ? pa[i] : A);
-      if (PRO == 1 && ok) v = norm_pro(g.pa, w.m0 + a_r[i], w.k0 + a_k[i], v);
+      if (PRO == 1) v = norm_pro(v, pm[i], pr[i], pslope, pact, pg, pbias);
       ra[i] = ok ? v : zero4();
       pa[i] += TA ? (long long)kBK*g.lda : kBK;
     }
@@ -171,7 +187,10 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
       } else {
         const bool ok = okb[i] && w.k0 + b_k[i] < g.K;
         float4 v = *reinterpret_cast<const float4*>(ok ? pb[i] : B);
-        if (PRO == 2 && ok) v = norm_pro(g.pb, w.k0 + b_k[i], w.n0 + b_r[i], v);
+        if (PRO == 2) {
+          const int kc = w.k0 + b_k[i] < g.K ? w.k0 + b_k[i] : 0;
+          v = norm_pro(v, np.table[2*kc], np.table[2*kc + 1], pslope, pact, pg, pbias);
+        }
         rb[i] = ok ? v : zero4();
       }
       pb[i] += TB ? kBK : (long long)kBK*g.ldb;
