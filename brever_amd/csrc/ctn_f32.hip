@@ -96,7 +96,7 @@ constexpr int kSliceRows = 256;         // rows per workgroup of the per-channel
 // workspace offsets in floats
 struct Ws32 {
   long long Lp, wavep, w, wn, x, x_stride, z1, z2, z_stride, tab, tab_stride, skip, h, pre, dpre,
-      y, fr, dop, dy, dwm, act, G, e, dz, fsum, btab, part, part_floats, scalars, gscratch, gscratch_floats, total;
+      y, fr, dop, dy, dwm, act, G, e, dz, fsum, btab, part, part_floats, scalars, gscratch, gscratch_floats, skipb, total;
   void init(const Lay32& l, long long B, long long T, long long L) {
     long long o = 0;
     auto take = [&](long long n) { long long r = o; o += up(n, 64); return r; };
@@ -135,6 +135,7 @@ struct Ws32 {
     // partial tiles of split reductions (weight gradients): at most one 256 x 128 tile per compute unit
     gscratch_floats = 32768LL*320;
     gscratch = take(gscratch_floats);
+    skipb = take(l.Sc);          // column sums of the skip gradient: the same for every block
     total = o;
   }
 };
@@ -856,6 +857,18 @@ int brv_ctn_f32_forward(const brv_ctn_config* cfg, const float* params, void* wo
       BRV_NJP_LAUNCH(f32_dw_fwd_fused_kernel, l.H, l.P, dim3(fused_slices(c)), st, d);
       OK32(fwd_table(c, c.tab(2 + 2*i), l.H));
       const NormPro n2{c.tab(2 + 2*i), params + b.n2_g, params + b.n2_b, params + b.prelu2};
+      if (has_res && l.Bn == l.Sc && l.Bn % 128 == 0 && i > 0) {
+        // [res | skip] as one product: the normalised input is rebuilt once for both
+        BigGemm g; memset(&g, 0, sizeof(g));
+        g.M = (int)BT; g.N = l.Bn + l.Sc; g.K = l.H;
+        g.A = c.z2b(i); g.lda = l.H; g.pa = n2;
+        g.B = params + b.res_w; g.B2 = params + b.skip_w; g.ldb = l.H; g.tb = 1; g.n_split = l.Bn;
+        g.D = c.xb(i + 1); g.D2 = skip; g.ldd = l.Bn;
+        g.add = c.xb(i); g.add2 = skip; g.ldadd = l.Bn;
+        g.bias = params + b.res_b; g.bias2 = params + b.skip_b; g.col_bias = 1;
+        OK32(big(c, g));
+        continue;
+      }
       if (has_res)
         OK32(conv1x1_f(c, c.z2b(i), l.H, &n2, params + b.res_w, l.Bn, l.H, c.xb(i + 1), l.Bn, params + b.res_b,
                        c.xb(i), l.Bn));
@@ -954,6 +967,10 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
                        G + l.Bn, ldg, spart, BT, l.Sc);
     hipLaunchKernelGGL(f32_fold_scalar_kernel, dim3(1), dim3(256), 0, st, spart, g, grads + l.tcn_prelu);
   }
+  // every block's skip convolution receives this same gradient (the skip outputs are summed,
+  // convtasnet.py:199-203): its column sums = the gradient of every skip bias, taken once
+  HIP_OK32(hipMemsetAsync(c.f(ws.skipb), 0, (size_t)l.Sc*4, st));
+  OK32(col_sum(c, G + l.Bn, ldg, l.Sc, c.f(ws.skipb)));
   }   // head
   for (int i = blk_hi; i >= blk_lo; --i) {
     const Blk32& b = l.blk[i];
@@ -968,7 +985,7 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
         OK32(wgrad_f(c, G, ldg, l.Bn + l.Sc, c.z2b(i), l.H, &n2, l.H, grads + b.res_w, grads + b.skip_w, l.Bn));
       else
         OK32(wgrad_f(c, G + l.Bn, ldg, l.Sc, c.z2b(i), l.H, &n2, l.H, grads + b.skip_w, nullptr, 0));
-      OK32(col_sum(c, G + l.Bn, ldg, l.Sc, grads + b.skip_b));
+      hipLaunchKernelGGL(f32_add_kernel, dim3(grid_for(l.Sc)), dim3(256), 0, st, grads + b.skip_b, c.f(ws.skipb), (long long)l.Sc);
       if (has_res) OK32(col_sum(c, G, ldg, l.Bn, grads + b.res_b));
       // data gradient wrt h2: one product over the (res, skip) operand pairs when they have one shape
       if (has_res && l.Bn == l.Sc) {
@@ -1000,7 +1017,7 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
     // h2 again; [res | skip] weight / bias gradients; data gradient -> e (wrt h2)
     OK32(norm_apply(c, c.z2b(i), params + b.prelu2, c.tab(2 + 2*i), params + b.n2_g, params + b.n2_b, h, l.H));
     OK32(conv1x1_wgrad(c, G + l.Bn, ldg, h, l.H, l.Sc, l.H, grads + b.skip_w));
-    OK32(col_sum(c, G + l.Bn, ldg, l.Sc, grads + b.skip_b));
+    hipLaunchKernelGGL(f32_add_kernel, dim3(grid_for(l.Sc)), dim3(256), 0, st, grads + b.skip_b, c.f(ws.skipb), (long long)l.Sc);
     OK32(conv1x1_dgrad(c, G + l.Bn, ldg, params + b.skip_w, l.Sc, l.H, e, l.H, 0));
     if (has_res) {
       OK32(conv1x1_wgrad(c, G, ldg, h, l.H, l.Bn, l.H, grads + b.res_w));

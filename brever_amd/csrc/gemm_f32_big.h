@@ -27,6 +27,10 @@ struct BigGemm {
   const float* add; long long add_bs; int ldadd;            // may alias D (accumulate)
   const float* add2;                                        // for the D2 rows
   const float* bias; int col_bias;                          // per row m, or per column n
+  // columns >= n_split of the result come from a second B (column n - n_split of B2) and go to D2 /
+  // add2 / bias2 (column n - n_split): two 1x1 convolutions of one input ([res | skip]) in one pass
+  // over A. n_split must be a multiple of the tile width; excludes m_split.
+  const float* B2; const float* bias2; int n_split;
   NormPro pa;              // on A, !ta: frame = m, channel = k
   NormPro pb;              // on B, !tb: frame = k (kbatch == 1), channel = n
   // reduction split over workgroups (long-K, small M x N): partial tiles in `scratch`

@@ -132,8 +132,10 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
       for (int i = 0; i < NB; ++i) rb[i] = make_float4((float)tid, 1.f, 2.f, (float)w.k0);
       return;
     }
+    const bool csec = g.n_split > 0 && w.n0 >= g.n_split;       // tile of the second B (uniform)
+    const int cshift = csec ? g.n_split : 0;
     const float* A = g.A + (long long)w.z*g.a_bs + (long long)w.kb*g.a_kbs;
-    const float* B = g.B + (long long)w.z*g.b_bs + (long long)w.kb*g.b_kbs;
+    const float* B = (csec ? g.B2 : g.B) + (long long)w.z*g.b_bs + (long long)w.kb*g.b_kbs;
     if (w.fresh) {
       // first k-tile of a tile (or of the next operand pair): pointers from scratch; afterwards
       // they advance by one k-tile per call
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int n = w.n0 + b_r[i];
-        okb[i] = n < g.N;
+        const int n = w.n0 + b_r[i] - cshift;
+        okb[i] = n + cshift < g.N;
         pb[i] = TB ? B + (long long)n*g.ldb + (w.k0 + b_k[i]) : B + (long long)(w.k0 + b_k[i])*g.ldb + n;
       }
     }
@@ -269,9 +271,16 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
     // Loads of the bias / addend are issued as one batch per block (rows clamped instead of
     // predicated: a branch around a load costs a full memory round trip per element); offsets
     // inside one batch item are 32-bit.
-    float* D1 = g.D + (long long)w.z*g.d_bs; float* D2 = g.D2 + (long long)w.z*g.d_bs;
-    const float* A1 = g.add ? g.add + (long long)w.z*g.add_bs : nullptr;
-    const float* A2 = g.add ? g.add2 + (long long)w.z*g.add_bs : nullptr;
+    // column split: the whole tile belongs to one side; base pointers shifted so that the global
+    // column index addresses the side's own columns
+    const bool csec = g.n_split > 0 && w.n0 >= g.n_split;
+    const int cshift = csec ? g.n_split : 0;
+    float* D1 = (csec ? g.D2 : g.D) + (long long)w.z*g.d_bs - cshift;
+    float* D2 = g.n_split > 0 ? D1 : g.D2 + (long long)w.z*g.d_bs;
+    const float* addc = csec ? g.add2 : g.add;
+    const float* A1 = addc ? addc + (long long)w.z*g.add_bs - cshift : nullptr;
+    const float* A2 = g.n_split > 0 ? A1 : (g.add ? g.add2 + (long long)w.z*g.add_bs : nullptr);
+    const float* biasc = csec ? g.bias2 : g.bias;
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
@@ -292,9 +301,9 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
           }
           continue;
         }
-        if (g.bias) {
+        if (biasc) {
           if (g.col_bias) {
-            const float bc = g.bias[colc];
+            const float bc = biasc[colc - cshift];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] += bc;
           } else {
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               const int row = rbase + (i & 3) + 8*(i >> 2);
-              br[i] = g.bias[row < g.M ? row : g.M - 1];
+              br[i] = biasc[row < g.M ? row : g.M - 1];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] += br[i];
@@ -389,7 +398,8 @@ inline bool q4(long long v) { return (v & 3) == 0; }
 inline bool a16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 inline bool b_vector(const BigGemm& g) {
-  return a16(g.B) && q4(g.ldb) && q4(g.b_bs) && q4(g.b_kbs) && q4(g.tb ? g.K : g.N);
+  return a16(g.B) && (!g.B2 || a16(g.B2)) && q4(g.ldb) && q4(g.b_bs) && q4(g.b_kbs) &&
+         q4(g.tb ? g.K : g.N) && (g.tb || q4(g.n_split));
 }
 
 struct Plan { int wm, wn, m_tiles, n_tiles, mn_padded, xcd_perm, ksplit, ktiles; long long total_t, per_t; };
@@ -441,6 +451,13 @@ bool gemm_f32_big_ok(const BigGemm& g) {
   // 32-bit offsets inside one batch item of the result / addend, 32-bit work-item counts
   if ((long long)g.M*g.ldd >= (1LL << 31) || (g.add && (long long)g.M*g.ldadd >= (1LL << 31)) ||
       (long long)g.M*g.N >= (1LL << 31)) return false;
+  if (g.n_split > 0) {
+    // second B: whole tiles on either side, no row split, no reduction split (long-M shapes only)
+    if (!g.B2 || !g.D2 || g.m_split > 0 || g.n_split >= g.N || g.pb.table) return false;
+    const Plan pl = make_plan(g);
+    if (g.n_split % (64*pl.wn) != 0 || pl.ksplit > 1) return false;
+    return true;
+  }
   if (g.D2 && (g.m_split < 1 || g.m_split >= g.M)) return false;
   return true;
 }
@@ -454,7 +471,7 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
   if (!gemm_f32_big_ok(g_in)) return -1;
   BigDev p;
   p.g = g_in;
-  if (!p.g.D2) { p.g.m_split = p.g.M; p.g.D2 = p.g.D; p.g.add2 = p.g.add; }
+  if (!p.g.D2 || p.g.n_split > 0) { p.g.m_split = p.g.M; if (!p.g.D2) { p.g.D2 = p.g.D; p.g.add2 = p.g.add; } }
   if (p.g.kbatch < 1) p.g.kbatch = 1;
   const Plan pl = make_plan(p.g);
   p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles; p.mn_padded = pl.mn_padded; p.xcd_perm = pl.xcd_perm;
