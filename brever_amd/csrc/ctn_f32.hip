@@ -96,7 +96,7 @@ constexpr int kSliceRows = 256;         // rows per workgroup of the per-channel
 // workspace offsets in floats
 struct Ws32 {
   long long Lp, wavep, w, wn, x, x_stride, z1, z2, z_stride, tab, tab_stride, skip, h, pre, dpre,
-      y, fr, dop, dy, dwm, act, G, e, dz, fsum, btab, part, part_floats, scalars, gscratch, gscratch_floats, skipb, total;
+      y, fr, dop, dy, dwm, act, G, e, dz, fsum, btab, part, part_floats, scalars, gscratch, gscratch_floats, skipb, wt, total;
   void init(const Lay32& l, long long B, long long T, long long L) {
     long long o = 0;
     auto take = [&](long long n) { long long r = o; o += up(n, 64); return r; };
@@ -135,7 +135,15 @@ struct Ws32 {
     // partial tiles of split reductions (weight gradients): at most one 256 x 128 tile per compute unit
     gscratch_floats = 32768LL*320;
     gscratch = take(gscratch_floats);
-    skipb = take(l.Sc);          // column sums of the skip gradient: the same for every block
+    skipb = take(l.Sc);
+    {
+      // transposed copies of the weights a data-gradient product reads ([k][n] -> [n][k]: both operands of
+      // the split-bf16 product are then contiguous in the reduction index)
+      long long m = 2LL*l.H*(l.Bn > l.Sc ? l.Bn : l.Sc);
+      if ((long long)l.N*l.Bn > m) m = (long long)l.N*l.Bn;
+      if ((long long)l.S*l.N*l.Sc > m) m = (long long)l.S*l.N*l.Sc;
+      wt = take(m);
+    }          // column sums of the skip gradient: the same for every block
     total = o;
   }
 };
@@ -570,6 +578,19 @@ __global__ void f32_ola_kernel(const float* fr, float* out, long long BS, int T,
     out[i] = acc;
   }
 }
+// dst[c][r] = src[r][c] for `pairs` matrices (R x C each): small weight matrices only
+__global__ __launch_bounds__(256) void f32_transpose_kernel(const float* src, float* dst, int R, int C,
+                                                            long long src_pair_stride, int pairs) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = blockIdx.x*32, r0 = blockIdx.y*32, z = blockIdx.z;
+  const float* s = src + (long long)z*src_pair_stride; float* d = dst + (long long)z*R*C;
+  for (int j = ty; j < 32; j += 8)
+    tile[j][tx] = (r0 + j < R && c0 + tx < C) ? s[(long long)(r0 + j)*C + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < C && r0 + tx < R) d[(long long)(c0 + j)*R + r0 + tx] = tile[tx][j];
+}
 __global__ void f32_add_kernel(float* dst, const float* a, long long n) {
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n; i += (long long)gridDim.x*256)
     dst[i] += a[i];
@@ -744,6 +765,7 @@ int conv1x1_f(const Ctx32& c, const float* a, int lda, const NormPro* pro, const
   g.D = d; g.ldd = ldd; g.bias = bias; g.col_bias = 1;
   g.add = add; g.ldadd = ldadd;
   if (pro) g.pa = *pro;
+  g.x3 = 1;
   return big(c, g);
 }
 // dW[n][k] += sum_rows g[rows][n] op(a)[rows][k]; rows >= m_split of dW go to dW2
@@ -761,9 +783,20 @@ int wgrad_f(const Ctx32& c, const float* gr, int ldg, int Nrows, const float* a,
 int dgrad_f(const Ctx32& c, const float* gr, int ldg, const float* W, int N, int K, float* d, int ldd,
             const float* add, int ldadd, int pairs, long long g_pair_stride, long long w_pair_stride) {
   BigGemm g; memset(&g, 0, sizeof(g));
-  g.M = (int)c.BT; g.N = K; g.K = N; g.kbatch = pairs; g.a_kbs = g_pair_stride; g.b_kbs = w_pair_stride;
-  g.A = gr; g.lda = ldg; g.B = W; g.ldb = K;
+  g.M = (int)c.BT; g.N = K; g.K = N; g.kbatch = pairs; g.a_kbs = g_pair_stride;
+  g.A = gr; g.lda = ldg;
   g.D = d; g.ldd = ldd; g.add = add; g.ldadd = ldadd;
+#ifndef BRV_GEMM_NO_X3
+  if (N % 4 == 0) {
+    // W (N x K) -> Wt (K x N): the product then has the layout of a forward 1x1 convolution
+    float* wt = c.f(c.ws.wt);
+    hipLaunchKernelGGL(f32_transpose_kernel, dim3((K + 31)/32, (N + 31)/32, pairs), dim3(256), 0, c.st, W, wt, N, K,
+                       w_pair_stride, pairs);
+    g.B = wt; g.ldb = N; g.tb = 1; g.b_kbs = (long long)N*K; g.x3 = 1;
+    return big(c, g);
+  }
+#endif
+  g.B = W; g.ldb = K; g.b_kbs = w_pair_stride;
   return big(c, g);
 }
 int fold(const Ctx32& c, int nq, int C, float* const* dst, const int* stride) {
@@ -865,7 +898,7 @@ int brv_ctn_f32_forward(const brv_ctn_config* cfg, const float* params, void* wo
         g.B = params + b.res_w; g.B2 = params + b.skip_w; g.ldb = l.H; g.tb = 1; g.n_split = l.Bn;
         g.D = c.xb(i + 1); g.D2 = skip; g.ldd = l.Bn;
         g.add = c.xb(i); g.add2 = skip; g.ldadd = l.Bn;
-        g.bias = params + b.res_b; g.bias2 = params + b.skip_b; g.col_bias = 1;
+        g.bias = params + b.res_b; g.bias2 = params + b.skip_b; g.col_bias = 1; g.x3 = 1;
         OK32(big(c, g));
         continue;
       }

@@ -36,6 +36,9 @@ struct BigGemm {
   // reduction split over workgroups (long-K, small M x N): partial tiles in `scratch`
   // ([split][batch][M][N] floats), summed in split order by a second kernel -- no atomics
   float* scratch; long long scratch_floats;
+  // take the split-bf16 kernel (three bf16 pieces per operand, six MFMAs per k-step: fp32 accuracy at
+  // 2.7x the rate) when the layout allows it (!ta, tb)
+  int x3;
 };
 
 // true when the shape / alignment qualify for the big-tile kernel

@@ -58,15 +58,25 @@ __device__ __forceinline__ float4 ld4s(const float* p) { return make_float4(p[0]
 
 struct Work { int valid, z, split, m0, n0, kb, k0, left, fresh; int q; };
 
-template <int WM, int WN, bool TA, bool TB, int PRO>
-__global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
-  constexpr int TM = 64*WM, TN = 64*WN;
+// X3: the product runs on the bf16 matrix pipe with every fp32 operand split into three bf16 pieces
+// (x = hi + mid + lo exactly: 3 x 8 significand bits) and six MFMAs per k-step (hi hi, hi mid,
+// mid hi, hi lo, lo hi, mid mid: every bf16 x bf16 product is exact in the fp32 accumulator, the
+// dropped terms are below 2^-24 of |x||y|) -- fp32 accuracy at 2.7x the rate of the fp32 MFMA.
+// Both operands contiguous in k only (!TA, TB); 128 x 128 tile per 4-wavefront workgroup, two
+// workgroups per compute unit (one splits / stages while the other multiplies), one LDS stage of
+// six bf16 planes [row][32 + 8].
+template <int WM, int WN, bool TA, bool TB, int PRO, bool X3 = false>
+__global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) {
+  constexpr int TM = 64*WM, TN = 64*WN, NT = 64*WM*WN;
   constexpr int LDA = TA ? TM + 8 : kLDK, LDB = TB ? kLDK : TN + 8;
   constexpr int A_FLOATS = TA ? kBK*LDA : TM*LDA;
   constexpr int B_FLOATS = TB ? TN*LDB : kBK*LDB;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
-  constexpr int NA = TM/64, NB = TN/64;       // 16-byte loads per thread and k-tile
-  __shared__ __attribute__((aligned(16))) float lds[2*STAGE];
+  constexpr int NA = TM*8/NT, NB = TN*8/NT;   // 16-byte loads per thread and k-tile
+  constexpr int LDH = kBK + 8;                // X3: bf16 elements per LDS row (80 bytes)
+  constexpr int LDS_FLOATS = X3 ? 3*(TM + TN)*LDH/2 : 2*STAGE;
+  static_assert(!X3 || (!TA && TB), "X3: both operands contiguous in k");
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const BigGemm& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
@@ -107,12 +117,12 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
   int a_r[NA], a_k[NA], b_r[NB], b_k[NB];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int f = tid + 512*i;
+    const int f = tid + NT*i;
     if (TA) { a_k[i] = f/(TM/4); a_r[i] = 4*(f % (TM/4)); } else { a_r[i] = f >> 3; a_k[i] = 4*(f & 7); }
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int f = tid + 512*i;
+    const int f = tid + NT*i;
     if (TB) { b_r[i] = f >> 3; b_k[i] = 4*(f & 7); } else { b_k[i] = f/(TN/4); b_r[i] = 4*(f % (TN/4)); }
   }
   const float* pa[NA]; const float* pb[NB];
@@ -341,6 +351,74 @@ __global__ __launch_bounds__(512) void gemm_f32_big_kernel(const BigDev p) {
       }
   };
 
+  if constexpr (X3) {
+    bf16_t* H = reinterpret_cast<bf16_t*>(lds);
+    // planes: A hi, mid, lo ([TM][LDH] each), then B hi, mid, lo ([TN][LDH])
+    constexpr int PA = TM*LDH, PB = TN*LDH;
+    auto split_store = [&](bf16_t* plane0, int plane_stride, int off, const float4& v) {
+      // three bf16 pieces of 4 values -> one 8-byte store per plane
+      const uint32_t h01 = pack2(v.x, v.y), h23 = pack2(v.z, v.w);
+      const float r0 = v.x - __uint_as_float(h01 << 16), r1 = v.y - __uint_as_float(h01 & 0xffff0000u);
+      const float r2 = v.z - __uint_as_float(h23 << 16), r3 = v.w - __uint_as_float(h23 & 0xffff0000u);
+      const uint32_t m01 = pack2(r0, r1), m23 = pack2(r2, r3);
+      const float s0 = r0 - __uint_as_float(m01 << 16), s1 = r1 - __uint_as_float(m01 & 0xffff0000u);
+      const float s2 = r2 - __uint_as_float(m23 << 16), s3 = r3 - __uint_as_float(m23 & 0xffff0000u);
+      const uint32_t l01 = pack2(s0, s1), l23 = pack2(s2, s3);
+      *reinterpret_cast<uint2*>(plane0 + off) = make_uint2(h01, h23);
+      *reinterpret_cast<uint2*>(plane0 + plane_stride + off) = make_uint2(m01, m23);
+      *reinterpret_cast<uint2*>(plane0 + 2*plane_stride + off) = make_uint2(l01, l23);
+    };
+    auto stash3 = [&]() {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) split_store(H, PA, a_r[i]*LDH + a_k[i], ra[i]);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) split_store(H + 3*PA, PB, b_r[i]*LDH + b_k[i], rb[i]);
+    };
+    const int ha = (64*wm + r32)*LDH + 8*kh, hb = 3*PA + (64*wn + r32)*LDH + 8*kh;
+    auto compute3 = [&]() {
+#pragma unroll
+      for (int ks = 0; ks < kBK/16; ++ks) {
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            a[f][pl] = *reinterpret_cast<const bf16x8*>(H + ha + pl*PA + 32*f*LDH + 16*ks);
+            b[f][pl] = *reinterpret_cast<const bf16x8*>(H + hb + pl*PB + 32*f*LDH + 16*ks);
+          }
+        // small terms first
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+          for (int fj = 0; fj < 2; ++fj) {
+            f32x16 c = acc[fi][fj];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][2], b[fj][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][0], b[fj][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][1], b[fj][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][1], b[fj][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][0], b[fj][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][0], b[fj][0], c, 0, 0, 0);
+            acc[fi][fj] = c;
+          }
+      }
+    };
+    Work cur = decode(blockIdx.x);
+    if (!cur.valid) return;
+    clear();
+    fetch(cur);
+    while (true) {
+      stash3();
+      __syncthreads();
+      const Work nxt = advance(cur);
+      if (nxt.valid) fetch(nxt);
+      compute3();
+      if (cur.left == 1) { epilogue(cur); clear(); }
+      if (!nxt.valid) break;
+      __syncthreads();
+      cur = nxt;
+    }
+    return;
+  }
   Work cur = decode(blockIdx.x);
   if (!cur.valid) return;
   clear();
@@ -402,6 +480,17 @@ inline bool b_vector(const BigGemm& g) {
          q4(g.tb ? g.K : g.N) && (g.tb || q4(g.n_split));
 }
 
+// the split-bf16 kernel takes the products with both operands contiguous in k and a long M
+inline bool use_x3(const BigGemm& g) {
+#ifdef BRV_GEMM_NO_X3
+  return false;
+#else
+  // enough 128 x 128 tiles to fill the chip without splitting the reduction
+  const long long tiles = (long long)((g.M + 127)/128)*((g.N + 127)/128)*(g.batch > 0 ? g.batch : 1);
+  return g.x3 && !g.ta && g.tb && !g.pb.table && tiles >= 192;
+#endif
+}
+
 struct Plan { int wm, wn, m_tiles, n_tiles, mn_padded, xcd_perm, ksplit, ktiles; long long total_t, per_t; };
 
 int device_cus() {
@@ -416,8 +505,10 @@ Plan make_plan(const BigGemm& g) {
   auto waste = [&](long long tm, long long tn) {
     return ((g.M + tm - 1)/tm*tm)*((g.N + tn - 1)/tn*tn);
   };
-  const bool tall = waste(256, 128) <= waste(128, 256);
+  bool tall = waste(256, 128) <= waste(128, 256);
+  if (g.n_split > 0 && g.n_split % 256 != 0) tall = true;      // whole 128-wide tiles on either side of the split
   pl.wm = tall ? 4 : 2; pl.wn = tall ? 2 : 4;
+  if (use_x3(g)) { pl.wm = 2; pl.wn = 2; }
   const int tm = 64*pl.wm, tn = 64*pl.wn;
   pl.m_tiles = (int)((g.M + tm - 1)/tm); pl.n_tiles = (int)((g.N + tn - 1)/tn);
   pl.xcd_perm = pl.m_tiles >= 16 && pl.n_tiles > 1;
@@ -427,7 +518,7 @@ Plan make_plan(const BigGemm& g) {
   const long long tiles = (long long)g.batch*pl.m_tiles*pl.n_tiles;
   long long ks = 1;
   const int cus = device_cus();
-  if (tiles*2 <= cus && pl.total_t >= 32) {
+  if (tiles*2 <= cus && pl.total_t >= 32 && !use_x3(g)) {
     ks = cus/tiles;
     if (ks > pl.total_t/8) ks = pl.total_t/8;
     if (ks < 1) ks = 1;
@@ -482,11 +573,12 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
   }
   p.n_work = p.g.batch*p.ksplit*p.mn_padded;
   p.b_scalar = b_vector(p.g) ? 0 : 1;
-  const int cus = device_cus();
-  const int grid = p.n_work < cus ? p.n_work : cus;
+  const bool x3 = use_x3(p.g) && p.ksplit == 1;
+  const int wgs = device_cus()*(x3 ? 2 : 1);
+  const int grid = p.n_work < wgs ? p.n_work : wgs;
   const int pro = p.g.pa.table ? 1 : (p.g.pb.table ? 2 : 0);
 #define BRV_BIG(WM_, WN_, TA_, TB_, PRO_) \
-  hipLaunchKernelGGL((gemm_f32_big_kernel<WM_, WN_, TA_, TB_, PRO_>), dim3(grid), dim3(512), 0, st, p)
+  hipLaunchKernelGGL((gemm_f32_big_kernel<WM_, WN_, TA_, TB_, PRO_>), dim3(grid), dim3(64*WM_*WN_), 0, st, p)
 #define BRV_BIG_SHAPE(WM_, WN_)                                       \
   do {                                                                \
     if (pro == 1) BRV_BIG(WM_, WN_, false, true, 1);                  \
@@ -496,7 +588,10 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
     else if (p.g.tb) BRV_BIG(WM_, WN_, false, true, 0);               \
     else BRV_BIG(WM_, WN_, false, false, 0);                          \
   } while (0)
-  if (pl.wm == 4) BRV_BIG_SHAPE(4, 2); else BRV_BIG_SHAPE(2, 4);
+  if (x3) {
+    if (pro == 1) hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, false, true, 1, true>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, false, true, 0, true>), dim3(grid), dim3(256), 0, st, p);
+  } else if (pl.wm == 4) BRV_BIG_SHAPE(4, 2); else BRV_BIG_SHAPE(2, 4);
 #undef BRV_BIG_SHAPE
 #undef BRV_BIG
   if (p.ksplit > 1) {

@@ -961,6 +961,7 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
     g.D = d; g.d_bs = d_batch_stride; g.ldd = (int)ldd;
     g.bias = row_bias; g.col_bias = p.col_bias;
     if (accumulate) { g.add = d; g.add_bs = d_batch_stride; g.ldadd = (int)ldd; }
+    g.x3 = 1;          // split-bf16 kernel where the layout allows it (a row-major, b stored N x K)
     if (brv::gemm_f32_big_ok(g)) {
       const long long need = brv::gemm_f32_big_scratch(g);
       void* scratch = nullptr;
