@@ -779,6 +779,16 @@ int wgrad_f(const Ctx32& c, const float* gr, int ldg, int Nrows, const float* a,
   if (pro) g.pb = *pro;
   return big(c, g);
 }
+// dW[m][n] += sum over `pairs` items and their T frames of a[t][m] b[t][n] (filterbank gradients: b = frames
+// of a waveform, row stride hop); split reduction in fixed order like every weight gradient here
+int wgrad_pairs_f(const Ctx32& c, const float* a, int lda, int M, const float* b, int ldb, int N, int T,
+                  long long pairs, long long a_pair_stride, long long b_pair_stride, float* dW) {
+  BigGemm g; memset(&g, 0, sizeof(g));
+  g.M = M; g.N = N; g.K = T; g.kbatch = (int)pairs; g.a_kbs = a_pair_stride; g.b_kbs = b_pair_stride;
+  g.A = a; g.lda = lda; g.ta = 1; g.B = b; g.ldb = ldb;
+  g.D = dW; g.ldd = N; g.add = dW; g.ldadd = N;
+  return big(c, g);
+}
 // d[rows][k] = sum over `pairs` operand pairs of g[rows][n] W[n][k] (+ add)
 int dgrad_f(const Ctx32& c, const float* gr, int ldg, const float* W, int N, int K, float* d, int ldd,
             const float* add, int ldadd, int pairs, long long g_pair_stride, long long w_pair_stride) {
@@ -985,6 +995,9 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
   hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for(BS*ws.Lp)), dim3(256), 0, st, d_out, dop, BS, L, ws.Lp);
   OK32(gemm32(c, dop, params + l.dec_w, dy, BS, T, l.N, l.K, l.hop, l.K, l.N, ws.Lp, 0, T*l.N, 0, 1,
               1, 0, 0, nullptr, 0));
+  if (fused)
+    OK32(wgrad_pairs_f(c, y, l.N, l.N, dop, l.hop, l.K, (int)T, BS, T*l.N, ws.Lp, grads + l.dec_w));
+  else
   OK32(gemm32(c, y, dop, grads + l.dec_w, 1, l.N, l.K, T, l.N, l.hop, l.K, 0, 0, 0, 1, 0, BS, T*l.N,
               ws.Lp, nullptr, 1));
   // mask backward: gradient wrt the mask logits and the mask-path term of the gradient wrt w
@@ -1097,6 +1110,9 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
   OK32(norm_backward(c, e, w, nullptr, c.tab(0), params + l.ln_g, l.N, dwm, dz, grads + l.ln_g,
                      grads + l.ln_b, nullptr));
   }
+  if (fused)
+    OK32(wgrad_pairs_f(c, dz, l.N, l.N, c.f(ws.wavep), l.hop, l.K, (int)T, B, T*l.N, ws.Lp, grads + l.enc_w));
+  else
   OK32(gemm32(c, dz, c.f(ws.wavep), grads + l.enc_w, 1, l.N, l.K, T, l.N, l.hop, l.K, 0, 0, 0, 1, 0, B,
               T*l.N, ws.Lp, nullptr, 1));
   }   // tail

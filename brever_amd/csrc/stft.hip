@@ -950,9 +950,13 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   if (accumulate == 2) accumulate = 0;
   p.row_bias = row_bias; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
+  // the 128 x 128 kernel below splits a long reduction over workgroups that add with atomics (order of
+  // arrival): such shapes also go to gemm_f32_big.hip, whose split reduction is added in a fixed order
+  const bool old_splits = ((M + BM2 - 1)/BM2)*((N + BN2 - 1)/BN2)*batch < 128 &&
+                          (kbatch > 1 ? kbatch : 1)*((K + BK2 - 1)/BK2) >= 16;
 #ifndef BRV_GEMM_F32_SMALL       // diagnostic builds: every fp32 product on the 128 x 128 kernel below
-  if (!lowp && M >= 64 && N >= 64 &&
-      (double)M*(double)N*(double)K*(double)batch*(kbatch > 1 ? kbatch : 1) >= 3.0e7) {
+  if (!lowp && ((M >= 64 && N >= 64 &&
+                 (double)M*(double)N*(double)K*(double)batch*(kbatch > 1 ? kbatch : 1) >= 3.0e7) || old_splits)) {
     // 16-byte aligned operands of a product worth a 256 x 128 tile: gemm_f32_big.hip
     brv::BigGemm g; memset(&g, 0, sizeof(g));
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.kbatch = kbatch > 1 ? (int)kbatch : 1; g.batch = (int)batch;

@@ -517,3 +517,33 @@ def test_gemm_f32_big_tiles_all_layouts(ta, tb):
         assert torch.equal(got[..., N:], d0[..., N:]), 'wrote outside the N columns'
         rel = float((got[..., :N].double() - want).norm()/want.norm())
         assert rel <= 2e-6, (batch, M, N, K, kbatch, bias, acc, rel)
+
+
+@pytest.mark.gpu
+def test_fp32_training_is_bitwise_repeatable():
+    """the fp32 path sums in fixed orders (split reductions of the weight gradients added
+    in split order, per-channel and per-frame sums by slice, no floating-point atomics on a result that
+    depends on their order of arrival): the same 6 training steps from the same initial weights give
+    bit-identical parameters and losses, default channel widths, ragged batch."""
+    import torch
+    from brever_amd.models import ConvTasNet
+    dev = torch.device('cuda')
+
+    def run():
+        torch.manual_seed(3)
+        net = ConvTasNet(layers=4, repeats=1).to(dev)
+        scaler = torch.amp.GradScaler('cuda', enabled=False)
+        gen = torch.Generator().manual_seed(5)
+        losses = []
+        for _ in range(6):
+            batch = (0.1*torch.randn(3, 2, 9000, generator=gen)).to(dev)
+            lengths = torch.tensor([9000, 7777, 5003], device=dev)
+            for b in range(3):
+                batch[b, :, int(lengths[b]):] = 0
+            losses.append(float(net.train_step(batch, lengths, False, scaler)))
+        return losses, net.flat_params().detach().cpu().clone()
+
+    l0, p0 = run()
+    l1, p1 = run()
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
