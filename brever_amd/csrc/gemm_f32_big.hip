@@ -25,7 +25,7 @@
 #include "gemm_f32_big.h"
 
 // Compile-time ablations of tools/gemm_f32_bench.py (bit mask): 1 no MFMA, 2 no global loads,
-// 4 no epilogue stores, 8 no LDS operand reads
+// 4 no epilogue stores, 8 no LDS operand reads, 16 (split-bf16 kernel) no operand split
 #ifndef BRV_BIG_ABL
 #define BRV_BIG_ABL 0
 #endif
@@ -369,6 +369,13 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
       *reinterpret_cast<uint2*>(plane0 + 2*plane_stride + off) = make_uint2(l01, l23);
     };
     auto stash3 = [&]() {
+      if (BRV_BIG_ABL & 16) {          // no split: one plane written, the others left as they are
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint2*>(H + a_r[i]*LDH + a_k[i]) = make_uint2(__float_as_uint(ra[i].x), __float_as_uint(ra[i].y));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint2*>(H + 3*PA + b_r[i]*LDH + b_k[i]) = make_uint2(__float_as_uint(rb[i].x), __float_as_uint(rb[i].y));
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < NA; ++i) split_store(H, PA, a_r[i]*LDH + a_k[i], ra[i]);
 #pragma unroll
@@ -383,23 +390,33 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
         for (int f = 0; f < 2; ++f)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
+            if (BRV_BIG_ABL & 8) {
+              const uint4 q = make_uint4(lane + pl, f, ks, 1);
+              a[f][pl] = __builtin_bit_cast(bf16x8, q); b[f][pl] = __builtin_bit_cast(bf16x8, q);
+              continue;
+            }
             a[f][pl] = *reinterpret_cast<const bf16x8*>(H + ha + pl*PA + 32*f*LDH + 16*ks);
             b[f][pl] = *reinterpret_cast<const bf16x8*>(H + hb + pl*PB + 32*f*LDH + 16*ks);
           }
-        // small terms first
+        if (BRV_BIG_ABL & 1) {
 #pragma unroll
-        for (int fi = 0; fi < 2; ++fi)
+          for (int fi = 0; fi < 2; ++fi)
 #pragma unroll
-          for (int fj = 0; fj < 2; ++fj) {
-            f32x16 c = acc[fi][fj];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][2], b[fj][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][0], b[fj][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][1], b[fj][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][1], b[fj][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][0], b[fj][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][0], b[fj][0], c, 0, 0, 0);
-            acc[fi][fj] = c;
-          }
+            for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl) acc[fi][fj][pl] += (float)a[fi][pl][0]*(float)b[fj][pl][1];
+          continue;
+        }
+        // small terms first; consecutive MFMAs go to different accumulators (a dependent MFMA waits for
+        // the whole pass count of its predecessor)
+        constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj)
+              acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[fi][PA_[t]], b[fj][PB_[t]], acc[fi][fj], 0, 0, 0);
       }
     };
     Work cur = decode(blockIdx.x);
