@@ -20,7 +20,7 @@ Compute dtype follows ``use_amp`` like the reference's autocast switch
 (convtasnet.py:78-97): ``use_amp=True`` = bf16 storage / MFMA operands with fp32
 accumulation, statistics and master weights (``brv_ctn_*``; the reference's GPU
 branch would use fp16 + GradScaler, convtasnet.py:81 -- bf16 needs no scaler);
-``use_amp=False`` = fp32 activations and exact-fp32 MFMA products
+``use_amp=False`` = fp32 activations and products of fp32 accuracy (fp32 MFMA / split-bf16)
 (``brv_ctn_f32_*``), the precision of ``enhance(x)`` in scripts/test_model.py
 and of ``BreverTrainer(use_amp=False)``. A bare ``model(x)`` is fp32 unless it
 runs under ``torch.autocast``.

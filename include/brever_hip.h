@@ -135,7 +135,10 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params,
 int brv_ctn_grad_bucket(const brv_ctn_config* cfg, int32_t part, int32_t nparts,
                         int64_t* offset, int64_t* count);
 
-/* The same model with fp32 activations and exact-fp32 products: ConvTasNet.forward WITHOUT
+/* The same model with fp32 activations and products of fp32 accuracy (the fp32 MFMA, or -- long
+ * products contiguous in the reduction index -- three bf16 pieces per fp32 operand and six bf16
+ * MFMAs with fp32 accumulation: csrc/gemm_f32_big.hip; every sum in a fixed order, so results are
+ * bitwise repeatable): ConvTasNet.forward WITHOUT
  * autocast (convtasnet.py:78-97 with use_amp=False -- `enhance(x, use_amp=False)` of
  * scripts/test_model.py:173-175, BreverTrainer(use_amp=False)). No prepared operands: the flat
  * fp32 parameters are read directly. Own workspace layout (brv_ctn_f32_workspace_bytes);
@@ -274,8 +277,12 @@ int brv_spec_compress_backward(const float* x, const float* gy, float* gx, int64
 int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int64_t M,
                    int64_t N, int64_t K, int64_t a_batch_stride, brv_stream_t stream);
 
-/* General fp32 GEMM on the exact-fp32 MFMA (nn.Linear of the FFNN model and its gradients,
- * models/ffnn/ffnn.py:151-171): d[z] (M x N) (+)= sum_kb op_a(a[z,kb]) @ op_b(b[z,kb]) +
+/* General fp32 GEMM at fp32 accuracy (nn.Linear of the FFNN model and its gradients,
+ * models/ffnn/ffnn.py:151-171). 16-byte aligned operands of a product worth a 256 x 128 tile run on
+ * csrc/gemm_f32_big.hip: the fp32 MFMA, or, for a row-major and b stored N x K with >= 192 tiles,
+ * the split-bf16 form (x = hi + mid + lo in bf16, six MFMAs, error below fp32 rounding of the
+ * products); split reductions are added in a fixed order. Other calls: the 128 x 128 fp32-MFMA kernel.
+ * d[z] (M x N) (+)= sum_kb op_a(a[z,kb]) @ op_b(b[z,kb]) +
  * row_bias[m]; trans_a: a stored (K x M); trans_b: b stored (N x K); kbatch extends the
  * reduction over kbatch operand pairs a/b_kbatch_stride apart (weight gradients summed over
  * the batch). accumulate: 0 overwrite, 1 add to d, 2 overwrite with row_bias read per output
