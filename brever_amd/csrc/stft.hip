@@ -956,7 +956,8 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
                           (kbatch > 1 ? kbatch : 1)*((K + BK2 - 1)/BK2) >= 16;
 #ifndef BRV_GEMM_F32_SMALL       // diagnostic builds: every fp32 product on the 128 x 128 kernel below
   if (!lowp && ((M >= 64 && N >= 64 &&
-                 (double)M*(double)N*(double)K*(double)batch*(kbatch > 1 ? kbatch : 1) >= 3.0e7) || old_splits)) {
+                 (double)M*(double)N*(double)K*(double)batch*(kbatch > 1 ? kbatch : 1) >= 3.0e7) ||
+                (old_splits && M >= 32 && N >= 32))) {       // (matrix x vector shapes stay below: a 256 x 128 tile is 99 % padding there)
     // 16-byte aligned operands of a product worth a 256 x 128 tile: gemm_f32_big.hip
     brv::BigGemm g; memset(&g, 0, sizeof(g));
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.kbatch = kbatch > 1 ? (int)kbatch : 1; g.batch = (int)batch;

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Kernel statistics and PMC HBM traffic of the widened rows on the GPU box (through gpurun from the repo
+# root):  bash tools/profile_rows.sh r03
+#   DCCRN training under use_amp (tools/prof_dccrn.py 1), SGMSE+ use_amp inference at batch 1 and 8
+#   (tools/prof_sgmse.py): rocprofv3 --kernel-trace --stats, then FETCH_SIZE and WRITE_SIZE in separate
+#   --pmc passes (never combined with other trace domains); tools/rows_roofline.py turns each triple into
+#   a `roofline` object of the row's dominant kernel (measured traffic per launch / average duration).
+set -u
+TAG=${1:-r03}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() {   # name, program, args...
+  local name=$1; shift
+  rm -rf /tmp/rw_$name /tmp/rwf_$name /tmp/rww_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rw_$name -o s -- python3 "$@" > /dev/null 2>&1
+  cp $(find /tmp/rw_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rows_${name}_kernel_stats.csv
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/rwf_$name -o f -- python3 "$@" > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/rww_$name -o w -- python3 "$@" > /dev/null 2>&1
+  python3 $REPO/tools/pmc_traffic.py /tmp/rwf_$name /tmp/rww_$name $OUT/${TAG}_rows_${name}_pmc_hbm_traffic.json > /dev/null
+  python3 $REPO/tools/rows_roofline.py $name $OUT/${TAG}_rows_${name}_kernel_stats.csv $OUT/${TAG}_rows_${name}_pmc_hbm_traffic.json >> $OUT/${TAG}_rows_roofline.json
+}
+rm -f $OUT/${TAG}_rows_roofline.json
+run dccrn_bf16 $REPO/tools/prof_dccrn.py 1
+run sgmse_b1 $REPO/tools/prof_sgmse.py 1
+run sgmse_b8 $REPO/tools/prof_sgmse.py 8
+cat $OUT/${TAG}_rows_roofline.json | cut -c1-600
