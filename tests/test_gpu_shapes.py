@@ -547,3 +547,39 @@ def test_fp32_training_is_bitwise_repeatable():
     l1, p1 = run()
     assert l0 == l1, (l0, l1)
     assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('causal,kernel_size,widths', [
+    (False, 3, (64, 32, 72, 36)), (True, 3, (64, 32, 72, 36)), (False, 5, (48, 24, 40, 16)),
+    (True, 5, (48, 24, 40, 16)), (False, 3, (128, 128, 320, 128))])
+def test_fp32_fused_kernels_causal_and_tap_counts(causal, kernel_size, widths):
+    """The fused streaming kernels and operand transforms of the fp32 path (csrc/ctn_f32_fused.cuh: taken
+    when every channel count is a multiple of 4) on what the reference goldens do not reach: cumulative
+    layer norms (causal: per-frame tables, one-sided stencil), 5 taps (the 7-tap instantiation), channel
+    counts that leave lanes idle (72 = 18 float4) or need two groups per lane (320), the [res | skip]
+    product with a column split (128 | 128). Forward, loss and every gradient vs the CPU fp32 oracle
+    (reference: brever/models/convtasnet/convtasnet.py:154-281): 1e-5 / 1e-4 like the golden tests."""
+    from brever_amd.models import ConvTasNet
+    from oracle.convtasnet import OracleConvTasNet
+    N, Bn, H, Sc = widths
+    cfg = dict(filters=N, filter_length=16, bottleneck_channels=Bn, hidden_channels=H, skip_channels=Sc,
+               kernel_size=kernel_size, layers=3, repeats=2, causal=causal)
+    torch.manual_seed(21)
+    gen = torch.Generator().manual_seed(4)
+    oracle = OracleConvTasNet(**cfg)
+    _detrivialise(oracle, gen)
+    net = ConvTasNet(**cfg)
+    net.load_state_dict(oracle.state_dict())
+    net = net.cuda()
+    batch, lengths = _ragged_batch(gen, 3, 2500)
+    want_out, want_loss, want = _oracle_grads(oracle, batch, lengths)
+    net.zero_grad(set_to_none=True)
+    out = net(batch[:, 0].cuda())
+    loss = net.criterion(out, batch[:, 1:].cuda(), lengths.cuda()).mean()
+    loss.backward()
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+    assert rel(out.detach().cpu(), want_out) <= 1e-5, rel(out.detach().cpu(), want_out)
+    assert abs(float(loss) - want_loss) <= 1e-5*max(1.0, abs(want_loss))
+    assert rel(got, want) <= 1e-4, rel(got, want)
+    _per_tensor(net, got, want, 1e-3, min_numel=64)
