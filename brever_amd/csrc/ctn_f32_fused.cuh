@@ -28,6 +28,17 @@ __device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v
 // p = prelu(z), xhat = (p - mean) rstd
 __device__ __forceinline__ float prelu1(float v, float a, bool act) { return (v > 0.f || !act) ? v : a*v; }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8): the slice a workgroup takes is chosen
+// so that every XCD walks ONE contiguous range of frames in order -- the frames t +- k dil a stencil
+// reads besides its own slice were then read (or are about to be) by the same XCD's L2 (stencil forward
+// 73.8 -> 70 us; the backward stencil is bound by its per-frame latency chain, not by traffic).
+__device__ __forceinline__ int fused_slice() {
+  const int nwg = gridDim.x, id = blockIdx.x;
+  const int xcd = id & 7, slot = id >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd*(q + 1) : r*(q + 1) + (xcd - r)*q) + slot;
+}
+
 struct FusedCommon {
   long long rows; int T, C;          // rows = B*T frames of C channels (C % 4 == 0, 16-byte aligned)
 };
@@ -51,7 +62,7 @@ __device__ __forceinline__ void write_chan_partials(float4 (&q)[NQ][NJ], int nq,
         float4 t = q[k][j];
 #pragma unroll
         for (int s = 0; s < 3; ++s) { t.x += red[s][lane][0]; t.y += red[s][lane][1]; t.z += red[s][lane][2]; t.w += red[s][lane][3]; }
-        *reinterpret_cast<float4*>(part + ((long long)blockIdx.x*nq + k)*C + c) = t;
+        *reinterpret_cast<float4*>(part + ((long long)fused_slice()*nq + k)*C + c) = t;
       }
     }
   }
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(256) void f32_dw_fwd_fused_kernel(const DwFwd p) {
       tp[k][j] = k < p.P ? make_float4(p.taps[(cc + 0)*p.P + k], p.taps[(cc + 1)*p.P + k], p.taps[(cc + 2)*p.P + k],
                                        p.taps[(cc + 3)*p.P + k]) : f4(0.f);
   }
-  const long long r0 = (long long)blockIdx.x*kFusedRows;
+  const long long r0 = (long long)fused_slice()*kFusedRows;
   for (int it = w; it < kFusedRows; it += 4) {
     const long long row = r0 + it;
     if (row >= p.s.rows) break;
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) void f32_bwd_sums_kernel(const BwdSums p) {
     gn[j] = ld4u(p.gain + (c < C ? c : 0));
     q[0][j] = f4(0.f); q[1][j] = f4(0.f);
   }
-  const long long r0 = (long long)blockIdx.x*kFusedRows;
+  const long long r0 = (long long)fused_slice()*kFusedRows;
   for (int it = w; it < kFusedRows; it += 4) {
     const long long row = r0 + it;
     if (row >= p.s.rows) break;
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256) void f32_bwd_apply_fused_kernel(const BwdApply
     q[0][j] = f4(0.f);
   }
   float da = 0.f;
-  const long long r0 = (long long)blockIdx.x*kFusedRows;
+  const long long r0 = (long long)fused_slice()*kFusedRows;
   for (int it = w; it < kFusedRows; it += 4) {
     const long long row = r0 + it;
     if (row >= p.s.rows) break;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(256) void f32_bwd_apply_fused_kernel(const BwdApply
     da = wave_sum(da);
     if (lane == 0) sred[w] = da;
     __syncthreads();
-    if (threadIdx.x == 0) p.slope_part[blockIdx.x] = ((sred[0] + sred[1]) + sred[2]) + sred[3];
+    if (threadIdx.x == 0) p.slope_part[fused_slice()] = ((sred[0] + sred[1]) + sred[2]) + sred[3];
   }
   if (p.part) write_chan_partials<1, NJ>(q, 1, C, p.part, red);
 }
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(256) void f32_dw_bwd_fused_kernel(const DwBwd p) {
 #pragma unroll
     for (int k = 0; k < PM + 2; ++k) q[k][j] = f4(0.f);
   }
-  const long long r0 = (long long)blockIdx.x*kFusedRows;
+  const long long r0 = (long long)fused_slice()*kFusedRows;
   for (int it = w; it < kFusedRows; it += 4) {
     const long long row = r0 + it;
     if (row >= p.s.rows) break;
