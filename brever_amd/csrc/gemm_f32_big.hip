@@ -35,7 +35,7 @@ namespace {
 
 struct BigDev {
   BigGemm g;
-  int m_tiles, n_tiles, mn_padded, xcd_perm, ksplit, ktiles, n_work, b_scalar;
+  int m_tiles, n_tiles, mn_padded, xcd_perm, ksplit, ktiles, n_work, b_scalar, fast_epi;
   long long total_t, per_t;
 };
 
@@ -55,6 +55,11 @@ __device__ __forceinline__ float4 norm_pro(float4 v, float mean, float rstd, flo
   return o;
 }
 __device__ __forceinline__ float4 ld4s(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }
+
+// Barrier of the product kernels: LDS traffic of this wavefront complete, then s_barrier. The barriers
+// here only order LDS stages; __syncthreads() also waits for every global access in flight (vmcnt(0)
+// counts loads AND stores on gfx9), i.e. for the epilogue's stores at every tile end.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct Work { int valid, z, split, m0, n0, kb, k0, left, fresh; int q; };
 
@@ -181,22 +186,29 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
       ra[i] = ok ? v : zero4();
       pa[i] += TA ? (long long)kBK*g.lda : kBK;
     }
+    if (p.b_scalar) {
+      // weights inside a flat parameter buffer: any alignment, any extent; 4 dwords per 16-byte piece with
+      // element-wise bounds (small, L2-resident operand); the 4 NB loads are issued together
+      float e[NB][4]; bool okc[NB][4];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      if (p.b_scalar) {
-        // weights inside a flat parameter buffer: any alignment, any extent; 4 dwords with
-        // element-wise bounds (small, L2-resident operand)
+      for (int i = 0; i < NB; ++i) {
         const int lim = TB ? g.K - (w.k0 + b_k[i]) : g.N - (w.n0 + b_r[i]);     // elements left along the contiguous axis
         const bool rowok = TB ? okb[i] : w.k0 + b_k[i] < g.K;
-        float e[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const bool okc = rowok && c < lim;
-          const float t = (okc ? pb[i] : B)[okc ? c : 0];
-          e[c] = okc ? t : 0.f;
+          okc[i][c] = rowok && c < lim;
+          e[i][c] = (okc[i][c] ? pb[i] : B)[okc[i][c] ? c : 0];
         }
-        rb[i] = make_float4(e[0], e[1], e[2], e[3]);
-      } else {
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        rb[i] = make_float4(okc[i][0] ? e[i][0] : 0.f, okc[i][1] ? e[i][1] : 0.f, okc[i][2] ? e[i][2] : 0.f,
+                            okc[i][3] ? e[i][3] : 0.f);
+        pb[i] += TB ? kBK : (long long)kBK*g.ldb;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
         const bool ok = okb[i] && w.k0 + b_k[i] < g.K;
         float4 v = *reinterpret_cast<const float4*>(ok ? pb[i] : B);
         if (PRO == 2) {
@@ -204,8 +216,8 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
           v = norm_pro(v, np.table[2*kc], np.table[2*kc + 1], pslope, pact, pg, pbias);
         }
         rb[i] = ok ? v : zero4();
+        pb[i] += TB ? kBK : (long long)kBK*g.ldb;
       }
-      pb[i] += TB ? kBK : (long long)kBK*g.ldb;
     }
   };
   // LDS staging addresses are per-thread constants
@@ -278,18 +290,19 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
   };
   auto epilogue = [&](const Work& w) {
     // D element (row, col) of a 32 x 32 block: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5).
-    // Loads of the bias / addend are issued as one batch per block (rows clamped instead of
-    // predicated: a branch around a load costs a full memory round trip per element); offsets
-    // inside one batch item are 32-bit.
-    // column split: the whole tile belongs to one side; base pointers shifted so that the global
-    // column index addresses the side's own columns
+    // Fast path (every block that does not straddle m_split, results below 2 GB): one buffer descriptor
+    // per side, the lane's byte offset computed once per block, ONE add per element -- rows past the end
+    // fall outside the descriptor's range and are dropped / read as zero by the hardware. The
+    // first version spent ~20 instructions per element on 64-bit address arithmetic: 4 us per tile,
+    // more than the MFMAs of a K = 128 tile (without global memory: 58 -> 47 us per 8.4 GFLOP product).
+    // Column split: the whole tile belongs to one side (columns local to the side).
     const bool csec = g.n_split > 0 && w.n0 >= g.n_split;
     const int cshift = csec ? g.n_split : 0;
-    float* D1 = (csec ? g.D2 : g.D) + (long long)w.z*g.d_bs - cshift;
-    float* D2 = g.n_split > 0 ? D1 : g.D2 + (long long)w.z*g.d_bs;
+    float* Da = (csec ? g.D2 : g.D) + (long long)w.z*g.d_bs;                 // rows below m_split
+    float* Db = g.n_split > 0 ? Da : g.D2 + (long long)w.z*g.d_bs;           // rows from m_split on
     const float* addc = csec ? g.add2 : g.add;
-    const float* A1 = addc ? addc + (long long)w.z*g.add_bs - cshift : nullptr;
-    const float* A2 = g.n_split > 0 ? A1 : (g.add ? g.add2 + (long long)w.z*g.add_bs : nullptr);
+    const float* Aa = addc ? addc + (long long)w.z*g.add_bs : nullptr;
+    const float* Ab = g.n_split > 0 ? Aa : (g.add ? g.add2 + (long long)w.z*g.add_bs : nullptr);
     const float* biasc = csec ? g.bias2 : g.bias;
 #pragma unroll
     for (int fi = 0; fi < 2; ++fi)
@@ -297,13 +310,14 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
       for (int fj = 0; fj < 2; ++fj) {
         const int col = w.n0 + 64*wn + 32*fj + r32;
         const bool colok = col < g.N;
-        const int colc = colok ? col : g.N - 1;
-        const int rbase = w.m0 + 64*wm + 32*fi + 4*kh;
+        const int cl = (colok ? col : g.N - 1) - cshift;            // column inside the side
+        const int rb0 = w.m0 + 64*wm + 32*fi;
+        const int rbase = rb0 + 4*kh;
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = acc[fi][fj][i];
         if (p.ksplit > 1) {
-          float* sc = g.scratch + ((long long)w.split*g.batch + w.z)*g.M*g.N + colc;
+          float* sc = g.scratch + ((long long)w.split*g.batch + w.z)*g.M*g.N + (colok ? col : g.N - 1);
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int row = rbase + (i & 3) + 8*(i >> 2);
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
         }
         if (biasc) {
           if (g.col_bias) {
-            const float bc = biasc[colc - cshift];
+            const float bc = biasc[cl];
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] += bc;
           } else {
@@ -327,16 +341,42 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
             for (int i = 0; i < 16; ++i) v[i] += br[i];
           }
         }
-        // a 32-row block lies on one side of m_split when m_split is a multiple of 32 (the general
-        // case is handled per row)
-        if (A1) {
+        const bool cross = g.m_split < g.M && rb0 < g.m_split && rb0 + 32 > g.m_split;
+        if (p.fast_epi && !cross) {
+          const bool sec = rb0 >= g.m_split;                           // uniform over the block
+          const int rl0 = rbase - (sec ? g.m_split : 0);
+          const int m_side = sec ? g.M - g.m_split : (g.m_split < g.M ? g.m_split : g.M);
+          const __amdgpu_buffer_rsrc_t rd = make_rsrc(sec ? Db : Da, (long long)m_side*g.ldd*4);
+          // a lane outside the columns gets an offset past every range (and cannot wrap: ranges < 2 GB)
+          const unsigned int vo = colok ? (unsigned int)(rl0*g.ldd + cl)*4u : 0x80000000u;
+          if (Aa) {
+            const __amdgpu_buffer_rsrc_t rad = make_rsrc(sec ? Ab : Aa, (long long)m_side*g.ldadd*4);
+            const unsigned int va = colok ? (unsigned int)(rl0*g.ldadd + cl)*4u : 0x80000000u;
+            float ad[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              ad[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                          rad, (int)(va + (unsigned int)(((i & 3) + 8*(i >> 2))*g.ldadd)*4u), 0, 0));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += ad[i];
+          }
+          if (!(BRV_BIG_ABL & 4)) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v[i]), rd,
+                                                    (int)(vo + (unsigned int)(((i & 3) + 8*(i >> 2))*g.ldd)*4u), 0, 0);
+          }
+          continue;
+        }
+        // general path: a block that straddles m_split (or a result too large for 32-bit byte offsets)
+        if (Aa) {
           float ad[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             int row = rbase + (i & 3) + 8*(i >> 2);
             if (row >= g.M) row = g.M - 1;
             const bool second = row >= g.m_split;
-            ad[i] = (second ? A2 : A1)[(second ? row - g.m_split : row)*g.ldadd + colc];
+            ad[i] = (second ? Ab : Aa)[(long long)(second ? row - g.m_split : row)*g.ldadd + cl];
           }
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[i] += ad[i];
@@ -345,8 +385,8 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
         for (int i = 0; i < 16; ++i) {
           const int row = rbase + (i & 3) + 8*(i >> 2);
           const bool second = row >= g.m_split;
-          if (colok && row < g.M && (!(BRV_BIG_ABL & 4) || v[i] == 1.2345f))
-            (second ? D2 : D1)[(second ? row - g.m_split : row)*g.ldd + colc] = v[i];
+          if (colok && row < g.M && !(BRV_BIG_ABL & 4))
+            (second ? Db : Da)[(long long)(second ? row - g.m_split : row)*g.ldd + cl] = v[i];
         }
       }
   };
@@ -425,13 +465,13 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
     fetch(cur);
     while (true) {
       stash3();
-      __syncthreads();
+      lds_barrier();
       const Work nxt = advance(cur);
       if (nxt.valid) fetch(nxt);
       compute3();
       if (cur.left == 1) { epilogue(cur); clear(); }
       if (!nxt.valid) break;
-      __syncthreads();
+      lds_barrier();
       cur = nxt;
     }
     return;
@@ -441,7 +481,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
   clear();
   fetch(cur);
   stash(0);
-  __syncthreads();
+  lds_barrier();
   int buf = 0;
   while (true) {
     const Work nxt = advance(cur);
@@ -450,7 +490,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
     if (cur.left == 1) { epilogue(cur); clear(); }
     if (!nxt.valid) break;
     stash(buf ^ 1);
-    __syncthreads();
+    lds_barrier();
     buf ^= 1;
     cur = nxt;
   }
@@ -590,6 +630,7 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
   }
   p.n_work = p.g.batch*p.ksplit*p.mn_padded;
   p.b_scalar = b_vector(p.g) ? 0 : 1;
+  p.fast_epi = (long long)p.g.M*p.g.ldd*4 < (1LL << 31) && (!p.g.add || (long long)p.g.M*p.g.ldadd*4 < (1LL << 31));
   const bool x3 = use_x3(p.g) && p.ksplit == 1;
   const int wgs = device_cus()*(x3 ? 2 : 1);
   const int grid = p.n_work < wgs ? p.n_work : wgs;
