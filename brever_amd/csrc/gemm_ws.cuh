@@ -526,11 +526,14 @@ __global__ __launch_bounds__(64*NW) void gemm_ws_kernel(const GemmRowsParams p) 
         } else {
           const uint4 c0 = comp0[pass];
           const uint4 c1q = comp1[(EM == E_RES_SKIP) ? pass : 0];
-          const f32x2 keep = {skip_keep, skip_keep};
-          v[0] += keep*f32x2{__uint_as_float(c0.x), __uint_as_float(c0.y)};
-          v[1] += keep*f32x2{__uint_as_float(c0.z), __uint_as_float(c0.w)};
-          v[2] += keep*f32x2{__uint_as_float(c1q.x), __uint_as_float(c1q.y)};
-          v[3] += keep*f32x2{__uint_as_float(c1q.z), __uint_as_float(c1q.w)};
+          // first block: the skip buffer is uninitialised memory -- a SELECT, not a product with zero
+          // (0 x NaN = NaN: whole outputs were NaN when the workspace reused freed memory holding NaNs)
+          if (skip_keep != 0.f) {
+            v[0] += f32x2{__uint_as_float(c0.x), __uint_as_float(c0.y)};
+            v[1] += f32x2{__uint_as_float(c0.z), __uint_as_float(c0.w)};
+            v[2] += f32x2{__uint_as_float(c1q.x), __uint_as_float(c1q.y)};
+            v[3] += f32x2{__uint_as_float(c1q.z), __uint_as_float(c1q.w)};
+          }
           const unsigned int so = (t*(unsigned int)e.ld_skip + (unsigned int)(ncol - e.Nsplit))*4u;
           buf_store16(rc1, so, make_uint4(__float_as_uint(v[0].x), __float_as_uint(v[0].y),
                                           __float_as_uint(v[1].x), __float_as_uint(v[1].y)));

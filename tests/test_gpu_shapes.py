@@ -583,3 +583,43 @@ def test_fp32_fused_kernels_causal_and_tap_counts(causal, kernel_size, widths):
     assert abs(float(loss) - want_loss) <= 1e-5*max(1.0, abs(want_loss))
     assert rel(got, want) <= 1e-4, rel(got, want)
     _per_tensor(net, got, want, 1e-3, min_numel=64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['bf16', 'bf16_three_launch_forward', 'bf16_causal', 'fp32', 'fp32_causal'])
+def test_no_path_reads_uninitialised_memory(monkeypatch, mode):
+    """The workspaces and prepared operands are `torch.empty` memory. Regression (round 3): the first block's
+    skip accumulation of the three-launch forward multiplied the uninitialised skip buffer by zero --
+    0 x NaN = NaN whenever the caching allocator handed back freed memory that held NaNs. Every path runs
+    forward + backward on freshly POISONED memory (gigabytes of NaN allocated and freed right before the
+    buffers are created) and must give finite results equal to its own run on ordinary memory."""
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    dev = torch.device('cuda')
+    amp = mode.startswith('bf16')
+    if mode == 'bf16_three_launch_forward':
+        monkeypatch.setenv('BRV_FWD_FUSE', '0')
+    cfg = dict(layers=3, repeats=2, causal=mode.endswith('causal'))
+    gen = torch.Generator().manual_seed(17)
+    batch, lengths = _ragged_batch(gen, 5, 6000)
+    batch, lengths = batch.cuda(), lengths.cuda()
+
+    def run(poison):
+        torch.manual_seed(2)
+        net = ConvTasNet(**cfg).to(dev)
+        net._amp = amp
+        if poison:
+            torch.cuda.empty_cache()
+            junk = [torch.full((1 << 27,), float('nan'), device=dev) for _ in range(12)]     # 6 GB of NaN
+            del junk                                      # back to the caching allocator, contents intact
+        out = net(batch[:, 0])
+        loss = snr(out, batch[:, 1:], lengths).mean()
+        loss.backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        return out.detach().clone(), grads.detach().clone()
+
+    out0, g0 = run(False)
+    out1, g1 = run(True)
+    assert torch.isfinite(out1).all() and torch.isfinite(g1).all()
+    assert rel(out1, out0) <= (2e-2 if amp else 1e-5), rel(out1, out0)
+    assert rel(g1, g0) <= (5e-2 if amp else 1e-4), rel(g1, g0)
