@@ -252,6 +252,30 @@ def kernel_roofline(model, batches, scaler, steps=3):
     return roof, table
 
 
+def fp32_path(device, steps=8, warmup=2):
+    """The same step with `use_amp=False` (the trainer's and `enhance()`'s default precision; fp32
+    activations, products of fp32 accuracy: DESIGN.md 5a) -- reported beside the headline, never as
+    `value`. A fresh model on the same synthetic batch shape."""
+    torch.manual_seed(1)
+    model = ConvTasNet().to(device)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    batch = 0.1*torch.randn(BATCH, 2, int(SECONDS*FS), device=device)
+    lengths = torch.full((BATCH,), int(SECONDS*FS), device=device)
+    for _ in range(warmup):
+        model.train_step(batch, lengths, False, scaler)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.train_step(batch, lengths, False, scaler)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0)/steps
+    del model
+    return {'value': BATCH/dt, 'unit': 'utterances/s', 'ms_per_step': dt*1e3, 'dtype': 'fp32', 'steps': steps,
+            'tflops': BATCH/dt*FLOP_PER_UTT_TRAIN/1e12,
+            'note': 'use_amp=False path (brv_ctn_f32_*): fp32 activations, fp32-MFMA and split-bf16 products, '
+                    'bitwise repeatable; round 2: 278 utterances/s'}
+
+
 def through_trainer(model, scaler, rank, device, steps, warmup):
     """The same train step fed by the trainer's data path instead of resident batches: items of
     a host-side SyntheticMixtureDataset (what BreverDataset.__getitem__ + model.transform
@@ -284,6 +308,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32-path', action='store_true', help='skip the use_amp=False step reported beside the headline')
     ap.add_argument('--no-through-trainer', action='store_true')
     ap.add_argument('--buckets', type=int, default=3,
                     help='gradient buckets of the overlapped all-reduce (N > 1)')
@@ -394,6 +419,8 @@ def main():
             line['hw_queues_ok'] = bool(__import__('brever_amd').HW_QUEUES_OK)
             if fallback:
                 line['allreduce_fallback'] = fallback
+        if world == 1 and not args.no_fp32_path:
+            line['fp32_path'] = fp32_path(device)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         if args.kernel_table:
