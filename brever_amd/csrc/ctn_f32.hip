@@ -777,6 +777,7 @@ int wgrad_f(const Ctx32& c, const float* gr, int ldg, int Nrows, const float* a,
   g.D = dW; g.ldd = K; g.add = dW; g.ldadd = K;
   if (dW2) { g.D2 = dW2; g.add2 = dW2; g.m_split = m_split; }
   if (pro) g.pb = *pro;
+  g.x3 = 1;
   return big(c, g);
 }
 // dW[m][n] += sum over `pairs` items and their T frames of a[t][m] b[t][n] (filterbank gradients: b = frames
@@ -787,6 +788,7 @@ int wgrad_pairs_f(const Ctx32& c, const float* a, int lda, int M, const float* b
   g.M = M; g.N = N; g.K = T; g.kbatch = (int)pairs; g.a_kbs = a_pair_stride; g.b_kbs = b_pair_stride;
   g.A = a; g.lda = lda; g.ta = 1; g.B = b; g.ldb = ldb;
   g.D = dW; g.ldd = N; g.add = dW; g.ldadd = N;
+  g.x3 = 1;
   return big(c, g);
 }
 // d[rows][k] = sum over `pairs` operand pairs of g[rows][n] W[n][k] (+ add)

@@ -61,6 +61,21 @@ __device__ __forceinline__ float4 ld4s(const float* p) { return make_float4(p[0]
 // counts loads AND stores on gfx9), i.e. for the epilogue's stores at every tile end.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// MFMA fragment from a k-major LDS plane [k][rows] (bf16, row stride ld): lane (r = lane & 31, h = lane >> 5)
+// gets plane[k0 + 8h + j][c0 + r], j = 0 .. 7, through two transposing reads (ds_read_b64_tr_b16: 4 rows x
+// 16 columns per 16-lane group) -- the operands of a weight gradient are contiguous along their rows, the
+// reduction index is the strided one
+typedef __attribute__((ext_vector_type(8))) short big_s16x8;
+__device__ __forceinline__ bf16x8 tr_frag16(const bf16_t* plane, int ld, int k0, int c0, int lane) {
+  const int g4 = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+  const bf16_t* p0 = plane + (k0 + 8*(g4 >> 1) + q)*ld + c0 + 16*(g4 & 1) + 4*pp;
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0 + 4*ld));
+  const big_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 struct Work { int valid, z, split, m0, n0, kb, k0, left, fresh; int q; };
 
 // X3: the product runs on the bf16 matrix pipe with every fp32 operand split into three bf16 pieces
@@ -79,8 +94,9 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
   constexpr int STAGE = A_FLOATS + B_FLOATS;
   constexpr int NA = TM*8/NT, NB = TN*8/NT;   // 16-byte loads per thread and k-tile
   constexpr int LDH = kBK + 8;                // X3: bf16 elements per LDS row (80 bytes)
-  constexpr int LDS_FLOATS = X3 ? 3*(TM + TN)*LDH/2 : 2*STAGE;
-  static_assert(!X3 || (!TA && TB), "X3: both operands contiguous in k");
+  constexpr int LDT = TM + 8;                 // X3 weight-gradient form: bf16 elements per LDS row of a [k][rows] plane
+  constexpr int LDS_FLOATS = X3 ? (TA ? 3*kBK*(LDT + TN + 8)/2 : 3*(TM + TN)*LDH/2) : 2*STAGE;
+  static_assert(!X3 || (!TA && TB) || (TA && !TB), "X3: both operands contiguous in k, or both along their rows");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const BigGemm& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -394,7 +410,9 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
   if constexpr (X3) {
     bf16_t* H = reinterpret_cast<bf16_t*>(lds);
     // planes: A hi, mid, lo ([TM][LDH] each), then B hi, mid, lo ([TN][LDH])
-    constexpr int PA = TM*LDH, PB = TN*LDH;
+    // (weight-gradient form, TA && !TB: planes are k-major, [kBK][rows + 8])
+    constexpr int LDTB = TN + 8;
+    constexpr int PA = TA ? kBK*LDT : TM*LDH, PB = TA ? kBK*LDTB : TN*LDH;
     auto split_store = [&](bf16_t* plane0, int plane_stride, int off, const float4& v) {
       // three bf16 pieces of 4 values -> one 8-byte store per plane
       const uint32_t h01 = pack2(v.x, v.y), h23 = pack2(v.z, v.w);
@@ -417,9 +435,9 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
         return;
       }
 #pragma unroll
-      for (int i = 0; i < NA; ++i) split_store(H, PA, a_r[i]*LDH + a_k[i], ra[i]);
+      for (int i = 0; i < NA; ++i) split_store(H, PA, TA ? a_k[i]*LDT + a_r[i] : a_r[i]*LDH + a_k[i], ra[i]);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) split_store(H + 3*PA, PB, b_r[i]*LDH + b_k[i], rb[i]);
+      for (int i = 0; i < NB; ++i) split_store(H + 3*PA, PB, TA ? b_k[i]*LDTB + b_r[i] : b_r[i]*LDH + b_k[i], rb[i]);
     };
     const int ha = (64*wm + r32)*LDH + 8*kh, hb = 3*PA + (64*wn + r32)*LDH + 8*kh;
     auto compute3 = [&]() {
@@ -435,8 +453,13 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
               a[f][pl] = __builtin_bit_cast(bf16x8, q); b[f][pl] = __builtin_bit_cast(bf16x8, q);
               continue;
             }
-            a[f][pl] = *reinterpret_cast<const bf16x8*>(H + ha + pl*PA + 32*f*LDH + 16*ks);
-            b[f][pl] = *reinterpret_cast<const bf16x8*>(H + hb + pl*PB + 32*f*LDH + 16*ks);
+            if (TA) {
+              a[f][pl] = tr_frag16(H + pl*PA, LDT, 16*ks, 64*wm + 32*f, lane);
+              b[f][pl] = tr_frag16(H + 3*PA + pl*PB, LDTB, 16*ks, 64*wn + 32*f, lane);
+            } else {
+              a[f][pl] = *reinterpret_cast<const bf16x8*>(H + ha + pl*PA + 32*f*LDH + 16*ks);
+              b[f][pl] = *reinterpret_cast<const bf16x8*>(H + hb + pl*PB + 32*f*LDH + 16*ks);
+            }
           }
         if (BRV_BIG_ABL & 1) {
 #pragma unroll
@@ -544,7 +567,11 @@ inline bool use_x3(const BigGemm& g) {
 #else
   // enough 128 x 128 tiles to fill the chip without splitting the reduction
   const long long tiles = (long long)((g.M + 127)/128)*((g.N + 127)/128)*(g.batch > 0 ? g.batch : 1);
-  return g.x3 && !g.ta && g.tb && !g.pb.table && tiles >= 192;
+  if (!g.x3) return false;
+  if (!g.ta && g.tb) return !g.pb.table && tiles >= 192;
+  // weight-gradient form (both operands contiguous along their rows): a long reduction split over the chip
+  if (g.ta && !g.tb) return !g.pa.table && b_vector(g) && (long long)g.K*(g.kbatch > 1 ? g.kbatch : 1) >= 8192;
+  return false;
 #endif
 }
 
@@ -575,8 +602,9 @@ Plan make_plan(const BigGemm& g) {
   const long long tiles = (long long)g.batch*pl.m_tiles*pl.n_tiles;
   long long ks = 1;
   const int cus = device_cus();
-  if (tiles*2 <= cus && pl.total_t >= 32 && !use_x3(g)) {
-    ks = cus/tiles;
+  const bool x3w = use_x3(g) && g.ta;          // two 4-wavefront workgroups per CU
+  if (tiles*2 <= cus*(x3w ? 2 : 1) && pl.total_t >= 32 && (!use_x3(g) || x3w)) {
+    ks = cus*(x3w ? 2 : 1)/tiles;
     if (ks > pl.total_t/8) ks = pl.total_t/8;
     if (ks < 1) ks = 1;
   }
@@ -631,7 +659,7 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
   p.n_work = p.g.batch*p.ksplit*p.mn_padded;
   p.b_scalar = b_vector(p.g) ? 0 : 1;
   p.fast_epi = (long long)p.g.M*p.g.ldd*4 < (1LL << 31) && (!p.g.add || (long long)p.g.M*p.g.ldadd*4 < (1LL << 31));
-  const bool x3 = use_x3(p.g) && p.ksplit == 1;
+  const bool x3 = use_x3(p.g) && (p.ksplit == 1 || p.g.ta);
   const int wgs = device_cus()*(x3 ? 2 : 1);
   const int grid = p.n_work < wgs ? p.n_work : wgs;
   const int pro = p.g.pa.table ? 1 : (p.g.pb.table ? 2 : 0);
@@ -646,7 +674,10 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
     else if (p.g.tb) BRV_BIG(WM_, WN_, false, true, 0);               \
     else BRV_BIG(WM_, WN_, false, false, 0);                          \
   } while (0)
-  if (x3) {
+  if (x3 && p.g.ta) {
+    if (pro == 2) hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, true, false, 2, true>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, true, false, 0, true>), dim3(grid), dim3(256), 0, st, p);
+  } else if (x3) {
     if (pro == 1) hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, false, true, 1, true>), dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, false, true, 0, true>), dim3(grid), dim3(256), 0, st, p);
   } else if (pl.wm == 4) BRV_BIG_SHAPE(4, 2); else BRV_BIG_SHAPE(2, 4);
