@@ -39,6 +39,22 @@ __device__ __forceinline__ int fused_slice() {
   return (xcd < r ? xcd*(q + 1) : r*(q + 1) + (xcd - r)*q) + slot;
 }
 
+// Sums of TWO per-lane values over the wavefront in 6 cross-lane steps instead of 12 (wave_sum is six
+// ds_bpermute per value): v_permlane32_swap packs (a: lanes 0-31 + lanes 32-63) into the lower half and the
+// same of b into the upper half, one bpermute folds the two 16-lane rows of each half, row rotations and
+// quad permutes (DPP, no LDS traffic) fold the 16 lanes of a row. Lanes 0-31 return sum(a), lanes 32-63
+// sum(b). The association is fixed: results stay bitwise repeatable.
+__device__ __forceinline__ float wave_sum2(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  float c = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  c += __shfl_xor(c, 16, 64);
+  c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x128, 0xf, 0xf, false));   // row_ror:8
+  c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x124, 0xf, 0xf, false));   // row_ror:4
+  c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  c += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  return c;
+}
+
 struct FusedCommon {
   long long rows; int T, C;          // rows = B*T frames of C channels (C % 4 == 0, 16-byte aligned)
 };
@@ -129,8 +145,8 @@ __global__ __launch_bounds__(256) void f32_dw_fwd_fused_kernel(const DwFwd p) {
       s1 += sum4(q);
       s2 += (q.x*q.x + q.y*q.y) + (q.z*q.z + q.w*q.w);
     }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { p.fsum2[2*row] = s1; p.fsum2[2*row + 1] = s2; }
+    const float s12 = wave_sum2(s1, s2);
+    if ((lane & 31) == 0) p.fsum2[2*row + (lane >> 5)] = s12;
   }
 }
 
@@ -175,8 +191,8 @@ __global__ __launch_bounds__(256) void f32_bwd_sums_kernel(const BwdSums p) {
       BRV_ONE(x) BRV_ONE(y) BRV_ONE(z) BRV_ONE(w)
 #undef BRV_ONE
     }
-    A = wave_sum(A); Bq = wave_sum(Bq);
-    if (lane == 0) { p.fsum[2*row] = A; p.fsum[2*row + 1] = Bq; }
+    const float ab = wave_sum2(A, Bq);
+    if ((lane & 31) == 0) p.fsum[2*row + (lane >> 5)] = ab;
   }
   write_chan_partials<2, NJ>(q, 2, C, p.part, red);
 }
@@ -335,8 +351,8 @@ __global__ __launch_bounds__(256) void f32_dw_bwd_fused_kernel(const DwBwd p) {
       BRV_ONE(x) BRV_ONE(y) BRV_ONE(z) BRV_ONE(w)
 #undef BRV_ONE
     }
-    A = wave_sum(A); Bq = wave_sum(Bq);
-    if (lane == 0) { p.fsum[2*row] = A; p.fsum[2*row + 1] = Bq; }
+    const float ab = wave_sum2(A, Bq);
+    if ((lane & 31) == 0) p.fsum[2*row + (lane >> 5)] = ab;
   }
   // quantities 0 .. P-1: taps, P: dgain1, P + 1: dbias1 (accumulated at PM, PM + 1)
   if (p.P < PM) {
