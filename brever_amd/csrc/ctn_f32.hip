@@ -611,6 +611,7 @@ constexpr int kSlopeBlocks = 1024;
 struct Ctx32 {
   const Lay32& l; const Ws32& ws; float* base; const float* params; float* grads;
   long long B, T, L, BT; hipStream_t st;
+  bool fused;               // every product on gemm_f32_big.hip with this workspace's scratch (fixed-order sums)
   float* f(long long off) const { return base + off; }
   float* tab(int i) const { return base + ws.tab + ws.tab_stride*i; }
   float* xb(int i) const { return base + ws.x + ws.x_stride*i; }
@@ -622,6 +623,25 @@ int gemm32(const Ctx32& c, const float* a, const float* b, float* d, long long b
            long long N, long long K, long long lda, long long ldb, long long ldd, long long abs_,
            long long bbs, long long dbs, int ta, int tb, long long kbatch, long long akbs,
            long long bkbs, const float* bias, int acc) {
+  if (c.fused) {
+    // the fused path keeps every product on gemm_f32_big.hip: its split reductions take their scratch from
+    // this workspace and add in a fixed order (brv_gemm_f32 has no scratch: long reductions over few tiles
+    // would run on the 128 x 128 kernel, whose split adds with atomics)
+    BigGemm g; memset(&g, 0, sizeof(g));
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.kbatch = kbatch > 1 ? (int)kbatch : 1; g.batch = (int)batch;
+    g.A = a; g.a_bs = abs_; g.a_kbs = akbs; g.lda = (int)lda; g.ta = ta != 0;
+    g.B = b; g.b_bs = bbs; g.b_kbs = bkbs; g.ldb = (int)ldb; g.tb = tb != 0;
+    g.D = d; g.d_bs = dbs; g.ldd = (int)ldd;
+    g.bias = bias; g.col_bias = acc == 2;
+    if (acc == 1) { g.add = d; g.add_bs = dbs; g.ldadd = (int)ldd; }
+    g.x3 = 1;
+    g.scratch = c.f(c.ws.gscratch); g.scratch_floats = c.ws.gscratch_floats;
+    if (gemm_f32_big_ok(g)) {
+      const int rb = gemm_f32_big(g, c.st);
+      if (rb) return fail32(rb, "fp32 Conv-TasNet path: gemm_f32_big failed");
+      return 0;
+    }
+  }
   const int r = brv_gemm_f32(a, b, d, batch, M, N, K, lda, ldb, ldd, abs_, bbs, dbs, ta, tb, kbatch,
                              akbs, bkbs, bias, acc, (brv_stream_t)c.st);
   if (r) return fail32(r, "brv_gemm_f32 failed inside the fp32 Conv-TasNet path");
@@ -868,7 +888,7 @@ int brv_ctn_f32_forward(const brv_ctn_config* cfg, const float* params, void* wo
   const long long B = batch, L = length, T = l.frames(L);
   if (B < 1 || T < 1) return fail32(-1, "empty batch or input shorter than one frame");
   Ws32 ws; ws.init(l, B, T, L);
-  Ctx32 c{l, ws, (float*)workspace, params, nullptr, B, T, L, B*T, (hipStream_t)stream};
+  Ctx32 c{l, ws, (float*)workspace, params, nullptr, B, T, L, B*T, (hipStream_t)stream, fused_ok(l, workspace)};
   const long long BT = c.BT;
   hipStream_t st = c.st;
   float* w = c.f(ws.w); float* wn = c.f(ws.wn); float* h = c.f(ws.h); float* skip = c.f(ws.skip);
@@ -981,7 +1001,7 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
   const int blk_hi = (int)((long long)l.nb*(nparts - part)/nparts) - 1;
   const bool head = part == 0, tail = part == nparts - 1;
   Ws32 ws; ws.init(l, B, T, L);
-  Ctx32 c{l, ws, (float*)workspace, params, grads, B, T, L, B*T, (hipStream_t)stream};
+  Ctx32 c{l, ws, (float*)workspace, params, grads, B, T, L, B*T, (hipStream_t)stream, fused_ok(l, workspace)};
   const long long BT = c.BT, BS = B*l.S;
   hipStream_t st = c.st;
   float* w = c.f(ws.w); float* wn = c.f(ws.wn); float* h = c.f(ws.h); float* skip = c.f(ws.skip);
@@ -1006,6 +1026,8 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
   hipLaunchKernelGGL(f32_mask_bwd_kernel, dim3(grid_for(BT*l.N)), dim3(256), 0, st, dy, m, w, dpre, dwm,
                      B, (int)T, l.S, l.N);
   // output conv: weight / bias gradients against prelu(skip), data gradient, PReLU backward
+  if (fused) OK32(wgrad_f(c, dpre, l.S*l.N, l.S*l.N, act, l.Sc, nullptr, l.Sc, grads + l.out_w, nullptr, 0));
+  else
   OK32(conv1x1_wgrad(c, dpre, l.S*l.N, act, l.Sc, l.S*l.N, l.Sc, grads + l.out_w));
   OK32(col_sum(c, dpre, l.S*l.N, l.S*l.N, grads + l.out_b));
   OK32(conv1x1_dgrad(c, dpre, l.S*l.N, params + l.out_w, l.S*l.N, l.Sc, e, l.Sc, 0));

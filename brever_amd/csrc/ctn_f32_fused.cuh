@@ -45,6 +45,10 @@ __device__ __forceinline__ int fused_slice() {
 // quad permutes (DPP, no LDS traffic) fold the 16 lanes of a row. Lanes 0-31 return sum(a), lanes 32-63
 // sum(b). The association is fixed: results stay bitwise repeatable.
 __device__ __forceinline__ float wave_sum2(float a, float b) {
+#ifdef BRV_F32_WAVESUM_PLAIN      // comparison builds: the two sums as 2 x 6 ds_bpermute
+  const float sa = wave_sum(a), sb = wave_sum(b);
+  return (threadIdx.x & 32) ? sb : sa;
+#endif
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   float c = __uint_as_float(r[0]) + __uint_as_float(r[1]);
   c += __shfl_xor(c, 16, 64);

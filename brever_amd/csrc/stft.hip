@@ -950,15 +950,15 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   if (accumulate == 2) accumulate = 0;
   p.row_bias = row_bias; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
-  // the 128 x 128 kernel below splits a long reduction over workgroups that add with atomics (order of
-  // arrival): such shapes also go to gemm_f32_big.hip, whose split reduction is added in a fixed order
-  const bool old_splits = ((M + BM2 - 1)/BM2)*((N + BN2 - 1)/BN2)*batch < 128 &&
-                          (kbatch > 1 ? kbatch : 1)*((K + BK2 - 1)/BK2) >= 16;
 #ifndef BRV_GEMM_F32_SMALL       // diagnostic builds: every fp32 product on the 128 x 128 kernel below
-  if (!lowp && ((M >= 64 && N >= 64 &&
-                 (double)M*(double)N*(double)K*(double)batch*(kbatch > 1 ? kbatch : 1) >= 3.0e7) ||
-                (old_splits && M >= 32 && N >= 32))) {       // (matrix x vector shapes stay below: a 256 x 128 tile is 99 % padding there)
-    // 16-byte aligned operands of a product worth a 256 x 128 tile: gemm_f32_big.hip
+  if (!lowp && M >= 32 && N >= 32 &&
+      (double)M*(double)N*(double)K*(double)batch*(kbatch > 1 ? kbatch : 1) >= 3.0e7) {
+    // 16-byte aligned operands of a product worth 256 x 128 tiles: gemm_f32_big.hip -- when it fills the
+    // chip WITHOUT splitting the reduction. A split there needs scratch for the partial tiles; this entry
+    // point has none (a stream-ordered allocation per call cost the SGMSE+ fp32 training step 8 %), so
+    // long reductions over few tiles stay on the 128 x 128 kernel below, whose split adds with atomics.
+    // (The fp32 Conv-TasNet path calls gemm_f32_big directly with scratch from its workspace: its
+    // weight gradients are split in a fixed order.)
     brv::BigGemm g; memset(&g, 0, sizeof(g));
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.kbatch = kbatch > 1 ? (int)kbatch : 1; g.batch = (int)batch;
     g.A = a; g.a_bs = a_batch_stride; g.a_kbs = a_kbatch_stride; g.lda = (int)lda; g.ta = trans_a != 0;
@@ -967,18 +967,7 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
     g.bias = row_bias; g.col_bias = p.col_bias;
     if (accumulate) { g.add = d; g.add_bs = d_batch_stride; g.ldadd = (int)ldd; }
     g.x3 = 1;          // split-bf16 kernel where the layout allows it (a row-major, b stored N x K)
-    if (brv::gemm_f32_big_ok(g)) {
-      const long long need = brv::gemm_f32_big_scratch(g);
-      void* scratch = nullptr;
-      if (need > 0) {
-        // partial tiles of a split reduction: stream-ordered allocation, released behind the product
-        if (hipMallocAsync(&scratch, (size_t)need*4, st) != hipSuccess) { scratch = nullptr; (void)hipGetLastError(); }
-        g.scratch = (float*)scratch; g.scratch_floats = scratch ? need : 0;
-      }
-      const int r = brv::gemm_f32_big(g, st);
-      if (scratch) (void)hipFreeAsync(scratch, st);
-      return r;
-    }
+    if (brv::gemm_f32_big_ok(g) && brv::gemm_f32_big_scratch(g) == 0) return brv::gemm_f32_big(g, st);
   }
 #endif
   // reduction split: fill the chip when the output has few tiles and the reduction is long
