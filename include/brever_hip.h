@@ -278,10 +278,12 @@ int brv_matmul_f32(const float* a, const float* b, float* d, int64_t batch, int6
                    int64_t N, int64_t K, int64_t a_batch_stride, brv_stream_t stream);
 
 /* General fp32 GEMM at fp32 accuracy (nn.Linear of the FFNN model and its gradients,
- * models/ffnn/ffnn.py:151-171). 16-byte aligned operands of a product worth a 256 x 128 tile run on
- * csrc/gemm_f32_big.hip: the fp32 MFMA, or, for a row-major and b stored N x K with >= 192 tiles,
- * the split-bf16 form (x = hi + mid + lo in bf16, six MFMAs, error below fp32 rounding of the
- * products); split reductions are added in a fixed order. Other calls: the 128 x 128 fp32-MFMA kernel.
+ * models/ffnn/ffnn.py:151-171). 16-byte aligned operands of a product that fills the chip with
+ * 256 x 128 tiles run on csrc/gemm_f32_big.hip: the fp32 MFMA, or, for a row-major and b stored N x K
+ * with >= 192 tiles, the split-bf16 form (x = hi + mid + lo in bf16, six MFMAs, error below fp32
+ * rounding of the products). Other calls run on the 128 x 128 fp32-MFMA kernel; long reductions over few
+ * tiles are split there over workgroups that add with atomics (order of arrival: not bitwise
+ * repeatable; brv_ctn_f32_* keeps its own weight gradients on a fixed-order split).
  * d[z] (M x N) (+)= sum_kb op_a(a[z,kb]) @ op_b(b[z,kb]) +
  * row_bias[m]; trans_a: a stored (K x M); trans_b: b stored (N x K); kbatch extends the
  * reduction over kbatch operand pairs a/b_kbatch_stride apart (weight gradients summed over
