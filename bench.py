@@ -127,7 +127,7 @@ def cpu_baseline():
 
 # bench label -> substring of the HIP kernel name in the rocprofv3 output
 KERNEL_OF_LABEL = {
-    'gln_prelu_bwd': 'dz_kernel', 'dwconv_bwd': 'dwconv_bwd_halo_kernel', 'dwpw2_bwd': 'dwconv_bwd_fused_kernel',
+    'gln_prelu_bwd': 'dz_kernel', 'dwconv_bwd': 'dwconv_bwd_halo_kernel', 'dwpw2_bwd': ['dwconv_bwd_fused_kernel<3, 256>', 'dwconv_bwd_fused_kernel'],
     'dwconv_fwd': 'dwconv_fwd_kernel', 'pw2_wgrad': 'wgrad_full_kernel',
     # (fused forward: 23 of the 24 first-conv launches finish the block input while staging it)
     'pw1_fwd': ['gemm_ws_kernel<128, 64, 1, 0, 2,', 'gemm_ws_kernel<128, 64, 1, 0,'],
