@@ -19,6 +19,9 @@
 #pragma once
 
 constexpr int kFusedRows = 64;      // frames per workgroup
+#ifndef BRV_DWB_ABL                 // ablations of the fp32 stencil backward (timing experiments): 1 no tap-gradient
+#define BRV_DWB_ABL 0               // arithmetic, 2 no shifted dz2 loads, 4 no shifted z1 loads, 8 no wavefront sums
+#endif
 constexpr int kMaxNJ = 4;           // channels <= 1024
 
 __device__ __forceinline__ float4 ld4u(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }
@@ -319,8 +322,8 @@ __global__ __launch_bounds__(256) void f32_dw_bwd_fused_kernel(const DwBwd p) {
       for (int j = 0; j < NJ; ++j) {
         const int c = 4*(lane + 64*j);
         const int cc = c < C ? c : 0;
-        zt[k][j] = *reinterpret_cast<const float4*>(p.z1 + rr1*C + cc);
-        dt[k][j] = *reinterpret_cast<const float4*>(p.dz2 + rr2*C + cc);
+        zt[k][j] = (BRV_DWB_ABL & 4) ? zc[j] : *reinterpret_cast<const float4*>(p.z1 + rr1*C + cc);
+        dt[k][j] = (BRV_DWB_ABL & 2) ? d0[j] : *reinterpret_cast<const float4*>(p.dz2 + rr2*C + cc);
       }
     }
     float4 e1[NJ];
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(256) void f32_dw_bwd_fused_kernel(const DwBwd p) {
       for (int j = 0; j < NJ; ++j) {
         const float4 v = zt[k][j];
         const float sx = d0[j].x*w1[k], sy = d0[j].y*w1[k], sz = d0[j].z*w1[k], sw = d0[j].w*w1[k];
+        if (BRV_DWB_ABL & 1) { q[k][j].x += sx*v.x; continue; }
         q[k][j].x = __builtin_fmaf(sx, (prelu1(v.x, a1, true) - m2[k])*r2[k]*g1[j].x + b1[j].x, q[k][j].x);
         q[k][j].y = __builtin_fmaf(sy, (prelu1(v.y, a1, true) - m2[k])*r2[k]*g1[j].y + b1[j].y, q[k][j].y);
         q[k][j].z = __builtin_fmaf(sz, (prelu1(v.z, a1, true) - m2[k])*r2[k]*g1[j].z + b1[j].z, q[k][j].z);
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void f32_dw_bwd_fused_kernel(const DwBwd p) {
       BRV_ONE(x) BRV_ONE(y) BRV_ONE(z) BRV_ONE(w)
 #undef BRV_ONE
     }
-    const float ab = wave_sum2(A, Bq);
+    const float ab = (BRV_DWB_ABL & 8) ? A + Bq : wave_sum2(A, Bq);
     if ((lane & 31) == 0) p.fsum[2*row + (lane >> 5)] = ab;
   }
   // quantities 0 .. P-1: taps, P: dgain1, P + 1: dbias1 (accumulated at PM, PM + 1)
