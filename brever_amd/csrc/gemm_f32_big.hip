@@ -1,23 +1,31 @@
-// Large fp32 products on the exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 256 FLOP / clk / CU):
-// the 1x1 convolutions, data gradients and weight gradients of the fp32 Conv-TasNet path
-// (reference: brever/models/convtasnet/convtasnet.py:225-262 run without autocast) and every
-// brv_gemm_f32 call whose operands are 16-byte aligned.
+// Large products of fp32 matrices at fp32 accuracy: the 1x1 convolutions, data gradients and weight
+// gradients of the fp32 Conv-TasNet path (reference: brever/models/convtasnet/convtasnet.py:225-262
+// run without autocast) and the brv_gemm_f32 calls with 16-byte aligned operands that fill the chip
+// without a reduction split. One kernel template, two arithmetic forms:
 //
-// One workgroup = 8 wavefronts = a 256 x 128 (or 128 x 256) tile of D, 64 x 64 per wavefront
-// (2 x 2 MFMA accumulators); the reduction runs in tiles of 32 through two LDS stages: 16-byte
-// global loads into registers while the MFMAs of the previous tile run, one barrier per tile.
-// An operand whose storage is contiguous in k sits in LDS as [row][32 + 4] and is read as 16-byte
-// fragments (a lane takes 4 consecutive k: MFMA step i of a group of 8 multiplies k = 8j + 4h + i
-// of both operands, h = lane / 32 -- any pairing of k works as long as both operands use the
-// same one); an operand contiguous along its rows sits as [k][rows + 8] and is read by dword.
-// Both layouts are bank-conflict free for these reads. The MFMA is 64 clocks, so LDS traffic is
-// a few per cent of the pipe's time; what matters is that the global loads, the prologue and
-// the epilogue of one tile hide behind another tile's MFMAs: workgroups are persistent and walk
-// a flat (tile, k-tile) sequence, the first loads of the next tile are issued before the
-// epilogue of the present one.
-// Long reductions over few output tiles (weight gradients) are split over workgroups: partial
-// tiles go to a scratch buffer and are added in split order by a second kernel (no atomics: the
-// result does not depend on the order of arrival).
+// fp32 MFMA (v_mfma_f32_32x32x2_f32, 256 FLOP / clk / CU). One workgroup = 8 wavefronts = a 256 x 128
+// (or 128 x 256) tile of D, 64 x 64 per wavefront (2 x 2 MFMA accumulators); the reduction runs in
+// tiles of 32 through two LDS stages: 16-byte global loads into registers while the MFMAs of the
+// previous tile run, one barrier per tile. An operand whose storage is contiguous in k sits in LDS as
+// [row][32 + 4] and is read as 16-byte fragments (a lane takes 4 consecutive k: MFMA step i of a group
+// of 8 multiplies k = 8j + 4h + i of both operands, h = lane / 32 -- any pairing of k works as long
+// as both operands use the same one); an operand contiguous along its rows sits as [k][rows + 8] and
+// is read by dword. Both layouts are bank-conflict free for these reads.
+//
+// Split bf16 (X3; v_mfma_f32_32x32x16_bf16, 4096 FLOP / clk / CU): every fp32 operand is split on its way
+// into LDS into three bf16 pieces and a k-step is six MFMAs -- fp32 accuracy at 2.7x the matrix rate.
+// 128 x 128 tile per 4-wavefront workgroup, two workgroups per CU, one LDS stage of six bf16 planes:
+// [row][32 + 8] for operands contiguous in k (forward, data gradients), [k][rows + 8] read through
+// ds_read_b64_tr_b16 for operands contiguous along their rows (weight gradients).
+//
+// Common: workgroups are persistent and walk a flat (tile, k-tile) sequence, the first loads of the
+// next tile are issued before the epilogue of the present one; tiles are dealt XCD-aware; an operand
+// can be transformed while it is staged (norm + PReLU of a layer whose normalised tensor is never
+// stored), a second B can serve the columns past n_split, the rows past m_split can go elsewhere;
+// the epilogue addresses through buffer descriptors (one add per element). Long reductions over few
+// output tiles (weight gradients) are split over workgroups: partial tiles go to a scratch buffer
+// and are added in split order by a second kernel (no atomics: the result does not depend on the
+// order of arrival). Measurements and what was tried: DESIGN.md section 5a.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
