@@ -4,8 +4,14 @@
 // (`enhance(x, use_amp=False)` of scripts/test_model.py, `BreverTrainer(use_amp=False)`), i.e.
 // every tensor and every product in fp32. The bf16 path of convtasnet.hip is the throughput
 // path; this one is the precision path: channels-last fp32 tensors [item][frame][channel] with
-// no channel padding, every 1x1 convolution one product on the exact-fp32 MFMA (brv_gemm_f32,
-// v_mfma_f32_32x32x2_f32), everything between the products as plain HBM-bound fp32 kernels.
+// no channel padding. Two forms of the same arithmetic:
+//  * fused (channel counts multiples of 4, <= 1024; `fused_ok`): every product on gemm_f32_big.hip
+//    (fp32 MFMA or split-bf16 MFMAs of fp32 accuracy, split reductions added in a fixed order with
+//    scratch from this workspace), the work between the products as the streaming kernels of
+//    ctn_f32_fused.cuh -- a layer norm's normalised tensor is never stored, its consumers rebuild
+//    it from z; every frame / channel sum is taken where the operands are in registers;
+//  * plain (any channel counts): one brv_gemm_f32 product per 1x1 convolution, one kernel per
+//    mathematical step in between (the round-2 implementation, kept as the general fallback).
 // Global (non-causal) and cumulative (causal) layer norms share one formulation: a per-frame
 // table (mean_t, rstd_t) in the forward pass and (U_t, V_t) in the backward pass with
 //   d prelu_out[t][c] = e[t][c] gain[c] rstd_t + U_t + p[t][c] V_t,
@@ -13,8 +19,7 @@
 // convtasnet.py:267) or prefix / suffix sums (cLN: modules/normalization.py:5-62). Frame sums
 // are fp32 over the channels of one frame, the scans over frames fp64.
 // Per-channel parameter gradients are reduced in two deterministic stages (row slices, then
-// a fold in slice order); the weight gradients are brv_gemm_f32 products accumulated into
-// the flat gradient.
+// a fold in slice order); the weight gradients are products accumulated into the flat gradient.
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <string>

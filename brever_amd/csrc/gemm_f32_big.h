@@ -1,4 +1,4 @@
-// Large fp32 products on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): host-side interface of
+// Large products of fp32 matrices at fp32 accuracy (fp32 MFMA, or split-bf16 MFMAs): host-side interface of
 // gemm_f32_big.hip, shared by brv_gemm_f32 (stft.hip) and the fp32 Conv-TasNet path (ctn_f32.hip).
 // Internal to libbrever_hip.so (hidden visibility): the C ABI stays include/brever_hip.h.
 #pragma once
