@@ -556,15 +556,18 @@ def test_fp32_training_is_bitwise_repeatable():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('causal,kernel_size,widths', [
-    (False, 3, (64, 32, 72, 36)), (True, 3, (64, 32, 72, 36)), (False, 5, (48, 24, 40, 16)),
-    (True, 5, (48, 24, 40, 16)), (False, 3, (128, 128, 320, 128))])
-def test_fp32_fused_kernels_causal_and_tap_counts(causal, kernel_size, widths):
+@pytest.mark.parametrize('causal,kernel_size,widths,L', [
+    (False, 3, (64, 32, 72, 36), 2500), (True, 3, (64, 32, 72, 36), 2500), (False, 5, (48, 24, 40, 16), 2500),
+    (True, 5, (48, 24, 40, 16), 2500), (False, 3, (128, 128, 320, 128), 2500),
+    (False, 3, (128, 128, 320, 136), 60000)])
+def test_fp32_fused_kernels_causal_and_tap_counts(causal, kernel_size, widths, L):
     """The fused streaming kernels and operand transforms of the fp32 path (csrc/ctn_f32_fused.cuh: taken
     when every channel count is a multiple of 4) on what the reference goldens do not reach: cumulative
     layer norms (causal: per-frame tables, one-sided stencil), 5 taps (the 7-tap instantiation), channel
     counts that leave lanes idle (72 = 18 float4) or need two groups per lane (320), the [res | skip]
-    product with a column split (128 | 128). Forward, loss and every gradient vs the CPU fp32 oracle
+    product with a column split (128 | 128); and, with 3 x 60 000 samples (11 247 frames), the split-bf16
+    kernels on partial tiles -- 320 and 136 columns, a last row tile of 111 frames, weight gradients whose
+    reduction is split over the chip. Forward, loss and every gradient vs the CPU fp32 oracle
     (reference: brever/models/convtasnet/convtasnet.py:154-281): 1e-5 / 1e-4 like the golden tests."""
     from brever_amd.models import ConvTasNet
     from oracle.convtasnet import OracleConvTasNet
@@ -578,7 +581,7 @@ def test_fp32_fused_kernels_causal_and_tap_counts(causal, kernel_size, widths):
     net = ConvTasNet(**cfg)
     net.load_state_dict(oracle.state_dict())
     net = net.cuda()
-    batch, lengths = _ragged_batch(gen, 3, 2500)
+    batch, lengths = _ragged_batch(gen, 3, L)
     want_out, want_loss, want = _oracle_grads(oracle, batch, lengths)
     net.zero_grad(set_to_none=True)
     out = net(batch[:, 0].cuda())
@@ -596,18 +599,21 @@ def test_fp32_fused_kernels_causal_and_tap_counts(causal, kernel_size, widths):
     o64 = OracleConvTasNet(**cfg).double()
     o64.load_state_dict({k: v.double() for k, v in oracle.state_dict().items()})
     _, _, want64 = _oracle_grads(o64, batch.double(), lengths)
-    errs, off = [], 0
+    errs, errs_cpu, off = [], [], 0
     for name, p in net.named_parameters():
         n = p.numel()
         ref = want64[off:off + n]
         if n >= 64 and float(ref.norm()) > 1e-6:
             errs.append(rel(got[off:off + n].double(), ref))
+            errs_cpu.append(rel(want[off:off + n].double(), ref))
         off += n
-    errs.sort()
+    errs.sort(); errs_cpu.sort()
+    med, med_cpu = errs[len(errs)//2], errs_cpu[len(errs_cpu)//2]
     e_hip, e_cpu = rel(got.double(), want64), rel(want.double(), want64)
-    print(f'fp32 fused path gradient vs fp64: hip {e_hip:.2e} (median tensor {errs[len(errs)//2]:.2e}, worst {errs[-1]:.2e}), '
-          f'cpu fp32 oracle {e_cpu:.2e}')
-    assert errs[len(errs)//2] <= 5e-6, errs[len(errs)//2]
+    print(f'fp32 fused path gradient vs fp64: hip {e_hip:.2e} (median tensor {med:.2e}, worst {errs[-1]:.2e}), '
+          f'cpu fp32 oracle {e_cpu:.2e} (median tensor {med_cpu:.2e})')
+    # (sums over 11 247 frames: the CPU oracle's own fp32 rounding reaches 6e-5 there -- the bound follows it)
+    assert med <= max(5e-6, 1.5*med_cpu), (med, med_cpu)
     assert errs[-1] <= 5e-3 and e_hip <= 1e-3, (errs[-1], e_hip)
 
 
