@@ -47,7 +47,14 @@ struct BigDev {
   long long total_t, per_t;
 };
 
-constexpr int kBK = 32;          // reduction tile
+constexpr int kBK = 32;          // reduction tile of the fp32-MFMA form
+#ifndef BRV_X3_BK
+// Reduction tile of the split-bf16 form: 32 = two workgroups per CU (61 KB of LDS, ~240 registers each).
+// 16 (three workgroups per CU at <= 168 registers) was measured: the 128 -> 512 product 84 -> 75 us, the
+// 512 -> 128 one 78 -> 85, the weight-gradient form 83 -> 115 (its transposing reads spill at 168
+// registers), and the whole fp32 step 16x slower because the spilling instantiations need scratch.
+#define BRV_X3_BK 32
+#endif
 constexpr int kLDK = kBK + 4;    // floats per LDS row of a k-contiguous operand
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -94,16 +101,18 @@ struct Work { int valid, z, split, m0, n0, kb, k0, left, fresh; int q; };
 // workgroups per compute unit (one splits / stages while the other multiplies), one LDS stage of
 // six bf16 planes [row][32 + 8].
 template <int WM, int WN, bool TA, bool TB, int PRO, bool X3 = false>
-__global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) {
+__global__ __launch_bounds__(64*WM*WN, (X3 && BRV_X3_BK == 16) ? 3 : 1) void gemm_f32_big_kernel(const BigDev p) {
   constexpr int TM = 64*WM, TN = 64*WN, NT = 64*WM*WN;
+  constexpr int BK = X3 ? BRV_X3_BK : kBK;    // reduction tile
+  constexpr int KQ = BK/4;                    // 16-byte pieces per row of a k-contiguous operand
   constexpr int LDA = TA ? TM + 8 : kLDK, LDB = TB ? kLDK : TN + 8;
-  constexpr int A_FLOATS = TA ? kBK*LDA : TM*LDA;
-  constexpr int B_FLOATS = TB ? TN*LDB : kBK*LDB;
+  constexpr int A_FLOATS = TA ? BK*LDA : TM*LDA;
+  constexpr int B_FLOATS = TB ? TN*LDB : BK*LDB;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
-  constexpr int NA = TM*8/NT, NB = TN*8/NT;   // 16-byte loads per thread and k-tile
-  constexpr int LDH = kBK + 8;                // X3: bf16 elements per LDS row (80 bytes)
+  constexpr int NA = TM*KQ/NT, NB = TN*KQ/NT;   // 16-byte loads per thread and k-tile
+  constexpr int LDH = BK + 8;                 // X3: bf16 elements per LDS row (80 or 48 bytes: conflict-free 16-byte reads)
   constexpr int LDT = TM + 8;                 // X3 weight-gradient form: bf16 elements per LDS row of a [k][rows] plane
-  constexpr int LDS_FLOATS = X3 ? (TA ? 3*kBK*(LDT + TN + 8)/2 : 3*(TM + TN)*LDH/2) : 2*STAGE;
+  constexpr int LDS_FLOATS = X3 ? (TA ? 3*BK*(LDT + TN + 8)/2 : 3*(TM + TN)*LDH/2) : 2*STAGE;
   static_assert(!X3 || (!TA && TB) || (TA && !TB), "X3: both operands contiguous in k, or both along their rows");
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const BigGemm& g = p.g;
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
       const int t_hi = t_lo + (int)p.per_t < (int)p.total_t ? t_lo + (int)p.per_t : (int)p.total_t;
       if (t_lo >= t_hi) continue;
       w.left = t_hi - t_lo;
-      w.kb = t_lo / p.ktiles; w.k0 = (t_lo % p.ktiles)*kBK;
+      w.kb = t_lo / p.ktiles; w.k0 = (t_lo % p.ktiles)*BK;
       w.m0 = mt*TM; w.n0 = nt*TN; w.q = q; w.valid = 1;
       return w;
     }
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
   // the k-tile after w (same tile), or the first one of this workgroup's next work item
   auto advance = [&](const Work& w) {
     if (w.left > 1) {
-      Work n = w; n.left = w.left - 1; n.k0 = w.k0 + kBK; n.fresh = 0;
+      Work n = w; n.left = w.left - 1; n.k0 = w.k0 + BK; n.fresh = 0;
       if (n.k0 >= g.K) { n.k0 = 0; n.kb = w.kb + 1; n.fresh = 1; }
       return n;
     }
@@ -147,12 +156,12 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int f = tid + NT*i;
-    if (TA) { a_k[i] = f/(TM/4); a_r[i] = 4*(f % (TM/4)); } else { a_r[i] = f >> 3; a_k[i] = 4*(f & 7); }
+    if (TA) { a_k[i] = f/(TM/4); a_r[i] = 4*(f % (TM/4)); } else { a_r[i] = f / KQ; a_k[i] = 4*(f % KQ); }
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int f = tid + NT*i;
-    if (TB) { b_r[i] = f >> 3; b_k[i] = 4*(f & 7); } else { b_k[i] = f/(TN/4); b_r[i] = 4*(f % (TN/4)); }
+    if (TB) { b_r[i] = f / KQ; b_k[i] = 4*(f % KQ); } else { b_k[i] = f/(TN/4); b_r[i] = 4*(f % (TN/4)); }
   }
   const float* pa[NA]; const float* pb[NB];
   bool oka[NA], okb[NB];
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
       float4 v = *reinterpret_cast<const float4*>(ok ? pa[i] : A);
       if (PRO == 1) v = norm_pro(v, pm[i], pr[i], pslope, pact, pg, pbias);
       ra[i] = ok ? v : zero4();
-      pa[i] += TA ? (long long)kBK*g.lda : kBK;
+      pa[i] += TA ? (long long)BK*g.lda : BK;
     }
     if (p.b_scalar) {
       // weights inside a flat parameter buffer: any alignment, any extent; 4 dwords per 16-byte piece with
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
       for (int i = 0; i < NB; ++i) {
         rb[i] = make_float4(okc[i][0] ? e[i][0] : 0.f, okc[i][1] ? e[i][1] : 0.f, okc[i][2] ? e[i][2] : 0.f,
                             okc[i][3] ? e[i][3] : 0.f);
-        pb[i] += TB ? kBK : (long long)kBK*g.ldb;
+        pb[i] += TB ? BK : (long long)BK*g.ldb;
       }
     } else {
 #pragma unroll
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
           v = norm_pro(v, np.table[2*kc], np.table[2*kc + 1], pslope, pact, pg, pbias);
         }
         rb[i] = ok ? v : zero4();
-        pb[i] += TB ? kBK : (long long)kBK*g.ldb;
+        pb[i] += TB ? BK : (long long)BK*g.ldb;
       }
     }
   };
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
   auto compute = [&](int buf) {
     const float* S = lds + buf*STAGE;
 #pragma unroll
-    for (int j = 0; j < kBK/8; ++j) {
+    for (int j = 0; j < BK/8; ++j) {
       float a[2][4], b[2][4];
       if (BRV_BIG_ABL & 8) {
 #pragma unroll
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
     // planes: A hi, mid, lo ([TM][LDH] each), then B hi, mid, lo ([TN][LDH])
     // (weight-gradient form, TA && !TB: planes are k-major, [kBK][rows + 8])
     constexpr int LDTB = TN + 8;
-    constexpr int PA = TA ? kBK*LDT : TM*LDH, PB = TA ? kBK*LDTB : TN*LDH;
+    constexpr int PA = TA ? BK*LDT : TM*LDH, PB = TA ? BK*LDTB : TN*LDH;
     auto split_store = [&](bf16_t* plane0, int plane_stride, int off, const float4& v) {
       // three bf16 pieces of 4 values -> one 8-byte store per plane
       const uint32_t h01 = pack2(v.x, v.y), h23 = pack2(v.z, v.w);
@@ -450,7 +459,7 @@ __global__ __launch_bounds__(64*WM*WN) void gemm_f32_big_kernel(const BigDev p) 
     const int ha = (64*wm + r32)*LDH + 8*kh, hb = 3*PA + (64*wn + r32)*LDH + 8*kh;
     auto compute3 = [&]() {
 #pragma unroll
-      for (int ks = 0; ks < kBK/16; ++ks) {
+      for (int ks = 0; ks < BK/16; ++ks) {
         bf16x8 a[2][3], b[2][3];
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -605,14 +614,16 @@ Plan make_plan(const BigGemm& g) {
   pl.m_tiles = (int)((g.M + tm - 1)/tm); pl.n_tiles = (int)((g.N + tn - 1)/tn);
   pl.xcd_perm = pl.m_tiles >= 16 && pl.n_tiles > 1;
   pl.mn_padded = pl.xcd_perm ? (pl.m_tiles + 7)/8*8*pl.n_tiles : pl.m_tiles*pl.n_tiles;
-  pl.ktiles = (g.K + kBK - 1)/kBK;
+  const int bk = use_x3(g) ? BRV_X3_BK : kBK;
+  pl.ktiles = (g.K + bk - 1)/bk;
   pl.total_t = (long long)(g.kbatch > 1 ? g.kbatch : 1)*pl.ktiles;
   const long long tiles = (long long)g.batch*pl.m_tiles*pl.n_tiles;
   long long ks = 1;
   const int cus = device_cus();
-  const bool x3w = use_x3(g) && g.ta;          // two 4-wavefront workgroups per CU
-  if (tiles*2 <= cus*(x3w ? 2 : 1) && pl.total_t >= 32 && (!use_x3(g) || x3w)) {
-    ks = cus*(x3w ? 2 : 1)/tiles;
+  const bool x3w = use_x3(g) && g.ta;          // several 4-wavefront workgroups per CU
+  constexpr int kX3Wgs = BRV_X3_BK == 16 ? 3 : 2;
+  if (tiles*2 <= cus*(x3w ? kX3Wgs : 1) && pl.total_t >= 32 && (!use_x3(g) || x3w)) {
+    ks = cus*(x3w ? kX3Wgs : 1)/tiles;
     if (ks > pl.total_t/8) ks = pl.total_t/8;
     if (ks < 1) ks = 1;
   }
@@ -668,7 +679,7 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
   p.b_scalar = b_vector(p.g) ? 0 : 1;
   p.fast_epi = (long long)p.g.M*p.g.ldd*4 < (1LL << 31) && (!p.g.add || (long long)p.g.M*p.g.ldadd*4 < (1LL << 31));
   const bool x3 = use_x3(p.g) && (p.ksplit == 1 || p.g.ta);
-  const int wgs = device_cus()*(x3 ? 2 : 1);
+  const int wgs = device_cus()*(x3 ? (BRV_X3_BK == 16 ? 3 : 2) : 1);
   const int grid = p.n_work < wgs ? p.n_work : wgs;
   const int pro = p.g.pa.table ? 1 : (p.g.pb.table ? 2 : 0);
 #define BRV_BIG(WM_, WN_, TA_, TB_, PRO_) \
