@@ -43,7 +43,7 @@ namespace {
 
 struct BigDev {
   BigGemm g;
-  int m_tiles, n_tiles, mn_padded, xcd_perm, ksplit, ktiles, n_work, b_scalar, fast_epi;
+  int m_tiles, n_tiles, mn_padded, xcd_perm, ksplit, ktiles, n_work, b_scalar, fast_epi, split_xcd;
   long long total_t, per_t;
 };
 
@@ -124,7 +124,17 @@ __global__ __launch_bounds__(64*WM*WN, (X3 && BRV_X3_BK == 16) ? 3 : 1) void gem
   auto decode = [&](int q) {
     Work w; w.valid = 0; w.q = q; w.z = 0; w.split = 0; w.m0 = 0; w.n0 = 0; w.kb = 0; w.k0 = 0; w.left = 0; w.fresh = 1;
     for (; q < p.n_work; q += gridDim.x) {
-      const int zs = q / p.mn_padded, r = q % p.mn_padded;
+      int zs = q / p.mn_padded, r = q % p.mn_padded;
+      if (p.split_xcd) {
+        // split reductions: the tiles of ONE split read the same rows of both operands, so they take
+        // consecutive slots of one XCD (work items congruent mod 8 run on one XCD and share its L2; with
+        // the tiles of a split dealt round-robin every XCD fetched every operand row: 541 MB instead of
+        // 196 MB per [res | skip] weight gradient, PMC)
+        const int xcd = q & 7, slot = q >> 3;
+        zs = (slot / p.mn_padded)*8 + xcd;
+        r = slot % p.mn_padded;
+        if (zs >= p.ksplit) continue;
+      }
       int mt, nt;
       if (p.xcd_perm) { const int xcd = r & 7, slot = r >> 3; mt = (slot / p.n_tiles)*8 + xcd; nt = slot % p.n_tiles; }
       else { mt = r / p.n_tiles; nt = r % p.n_tiles; }
@@ -675,7 +685,8 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
     // no scratch from the caller: one workgroup per tile walks the whole reduction
     p.ksplit = 1; p.per_t = p.total_t;
   }
-  p.n_work = p.g.batch*p.ksplit*p.mn_padded;
+  p.split_xcd = p.ksplit >= 8 && p.g.batch == 1 && !p.xcd_perm;
+  p.n_work = p.split_xcd ? (p.ksplit + 7)/8*8*p.mn_padded : p.g.batch*p.ksplit*p.mn_padded;
   p.b_scalar = b_vector(p.g) ? 0 : 1;
   p.fast_epi = (long long)p.g.M*p.g.ldd*4 < (1LL << 31) && (!p.g.add || (long long)p.g.M*p.g.ldadd*4 < (1LL << 31));
   const bool x3 = use_x3(p.g) && (p.ksplit == 1 || p.g.ta);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Kernel statistics and PMC HBM traffic of the widened rows on the GPU box (through gpurun from the repo
 # root):  bash tools/profile_rows.sh r03
-#   DCCRN training under use_amp (tools/prof_dccrn.py 1), SGMSE+ use_amp inference at batch 1 and 8
+#   fp32 Conv-TasNet training (tools/prof_ctn_f32.py), DCCRN training under use_amp (tools/prof_dccrn.py 1), SGMSE+ use_amp inference at batch 1 and 8
 #   (tools/prof_sgmse.py): rocprofv3 --kernel-trace --stats, then FETCH_SIZE and WRITE_SIZE in separate
 #   --pmc passes (never combined with other trace domains); tools/rows_roofline.py turns each triple into
 #   a `roofline` object of the row's dominant kernel (measured traffic per launch / average duration).
@@ -22,6 +22,7 @@ run() {   # name, program, args...
   python3 $REPO/tools/rows_roofline.py $name $OUT/${TAG}_rows_${name}_kernel_stats.csv $OUT/${TAG}_rows_${name}_pmc_hbm_traffic.json >> $OUT/${TAG}_rows_roofline.json
 }
 rm -f $OUT/${TAG}_rows_roofline.json
+run ctn_fp32 $REPO/tools/prof_ctn_f32.py
 run dccrn_bf16 $REPO/tools/prof_dccrn.py 1
 run sgmse_b1 $REPO/tools/prof_sgmse.py 1
 run sgmse_b8 $REPO/tools/prof_sgmse.py 8
