@@ -130,7 +130,8 @@ struct Ws32 {
     e = take(BT*cmax); dz = take(BT*cmax);
     fsum = take(BT*2); btab = take(BT*2);
     // partial sums of the per-channel reductions: slices x quantities (<= 2 + P + 1) x channels
-    const long long slices = (BT + kFusedRows - 1)/kFusedRows;      // >= the 256-row slices of the plain path
+    // (comb slices of the stencil kernels, ctn_f32_fused.cuh: at most ~4x the contiguous count)
+    const long long slices = 5*((BT + kFusedRows - 1)/kFusedRows);   // >= the 256-row slices of the plain path
     long long cq = (long long)(l.P + 2)*l.H;
     if (2*cmax > cq) cq = 2*cmax;
     if ((long long)l.S*l.N > cq) cq = (long long)l.S*l.N;
@@ -836,9 +837,9 @@ int dgrad_f(const Ctx32& c, const float* gr, int ldg, const float* W, int N, int
   g.B = W; g.ldb = K; g.b_kbs = w_pair_stride;
   return big(c, g);
 }
-int fold(const Ctx32& c, int nq, int C, float* const* dst, const int* stride) {
+int fold(const Ctx32& c, int nq, int C, float* const* dst, const int* stride, long long slices = -1) {
   FoldJob j; memset(&j, 0, sizeof(j));
-  j.part = c.f(c.ws.part); j.slices = (int)fused_slices(c); j.nq = nq; j.C = C;
+  j.part = c.f(c.ws.part); j.slices = (int)(slices < 0 ? fused_slices(c) : slices); j.nq = nq; j.C = C;
   for (int k = 0; k < nq; ++k) { j.dst[k] = dst[k]; j.stride[k] = stride[k]; }
   hipLaunchKernelGGL(f32_fold_kernel, dim3((nq*C + 15)/16), dim3(1024), 0, c.st, j);
   HIP_OK32(hipGetLastError());
@@ -924,7 +925,7 @@ int brv_ctn_f32_forward(const brv_ctn_config* cfg, const float* params, void* wo
       OK32(norm_forward(c, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), l.H));
       DwFwd d{{BT, (int)T, l.H}, c.z1b(i), c.tab(1 + 2*i), params + b.prelu1, params + b.n1_g, params + b.n1_b,
               params + b.dconv_w, params + b.dconv_b, c.z2b(i), params + b.prelu2, c.f(ws.fsum), l.P, dil, left};
-      BRV_NJP_LAUNCH(f32_dw_fwd_fused_kernel, l.H, l.P, dim3(fused_slices(c)), st, d);
+      BRV_NJP_LAUNCH(f32_dw_fwd_fused_kernel, l.H, l.P, dim3((unsigned)slice_count(slice_map((int)T, dil), B, (int)T)), st, d);
       OK32(fwd_table(c, c.tab(2 + 2*i), l.H));
       const NormPro n2{c.tab(2 + 2*i), params + b.n2_g, params + b.n2_b, params + b.prelu2};
       if (has_res && l.Bn == l.Sc && l.Bn % 128 == 0 && i > 0) {
@@ -1074,14 +1075,15 @@ int brv_ctn_f32_backward_part(const brv_ctn_config* cfg, const float* params, vo
       // depthwise conv: tap gradients against h1 rebuilt from z1, transposed stencil -> e (wrt h1), and
       // pass 1 of the first norm's backward on that e
       {
-        if ((long long)fused_slices(c)*(l.P + 2)*l.H > ws.part_floats) return fail32(-1, "fp32 path: reduction scratch too small");
+        const long long dw_slices = slice_count(slice_map((int)T, dil), B, (int)T);
+        if (dw_slices*(l.P + 2)*l.H > ws.part_floats) return fail32(-1, "fp32 path: reduction scratch too small");
         DwBwd d{{BT, (int)T, l.H}, dz, c.z1b(i), c.tab(1 + 2*i), params + b.prelu1, params + b.n1_g, params + b.n1_b,
                 params + b.dconv_w, e, c.f(ws.fsum), c.f(ws.part), l.P, dil, left};
-        BRV_NJP_LAUNCH(f32_dw_bwd_fused_kernel, l.H, l.P, dim3(fused_slices(c)), st, d);
+        BRV_NJP_LAUNCH(f32_dw_bwd_fused_kernel, l.H, l.P, dim3((unsigned)dw_slices), st, d);
         float* dst[9]; int stride[9];
         for (int k = 0; k < l.P; ++k) { dst[k] = grads + b.dconv_w + k; stride[k] = l.P; }
         dst[l.P] = grads + b.n1_g; stride[l.P] = 1; dst[l.P + 1] = grads + b.n1_b; stride[l.P + 1] = 1;
-        OK32(fold(c, l.P + 2, l.H, dst, stride));
+        OK32(fold(c, l.P + 2, l.H, dst, stride, dw_slices));
       }
       OK32(norm_backward_f(c, e, c.z1b(i), params + b.prelu1, c.tab(1 + 2*i), params + b.n1_g, l.H, nullptr, dz,
                            nullptr, nullptr, grads + b.prelu1, grads + b.conv_b, true));

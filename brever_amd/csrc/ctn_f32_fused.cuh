@@ -66,6 +66,39 @@ struct FusedCommon {
   long long rows; int T, C;          // rows = B*T frames of C channels (C % 4 == 0, 16-byte aligned)
 };
 
+// Which frames a stencil workgroup takes. Contiguous slices (frames r0 .. r0 + 63) make every frame's taps
+// at +- k dil somebody else's frames once dil exceeds the slice: PMC showed the stencil backward moving 591
+// MB per launch for 393 MB of tensors. COMB slices (dil >= 4 and >= 16 teeth per item): wavefront w walks
+// the frames of ONE residue class, t = (16 tg + j) dil + 4 rg + w for j = 0 .. 15 -- the taps of a frame
+// are the frames the same wavefront visits next to it (PMC: 591 -> 507 MB for the backward stencil, 352 -> 294
+// for the forward one; the launch times did not move -- the stencils are bound by their per-frame chain of
+// loads and arithmetic, not by these bytes). The
+// per-frame outputs are indexed by frame and the per-channel sums are folded over all slices, so the
+// order of the frames changes nothing else.
+struct SliceMap { int comb, dil, n_rg, spi; };       // spi: slices per item (comb only)
+__host__ __device__ inline SliceMap slice_map(int T, int dil) {
+  SliceMap m; m.dil = dil;
+  const int teeth = (T + dil - 1)/dil;
+  m.comb = dil >= 4 && teeth >= 16;
+  m.n_rg = (dil + 3)/4;
+  m.spi = m.n_rg*((teeth + 15)/16);
+  return m;
+}
+__host__ __device__ inline long long slice_count(const SliceMap& m, long long B, int T) {
+  return m.comb ? B*m.spi : (B*T + kFusedRows - 1)/kFusedRows;
+}
+// frame `it` (0 .. 63; wavefront w takes it = w, w + 4, ...) of slice `s` -> global row, or -1
+__device__ __forceinline__ long long slice_row(const SliceMap& m, int s, int it, long long rows, int T) {
+  if (!m.comb) {
+    const long long row = (long long)s*kFusedRows + it;
+    return row < rows ? row : -1;
+  }
+  const int b = s / m.spi, rem = s % m.spi;
+  const int rg = rem % m.n_rg, tg = rem / m.n_rg;
+  const int res = 4*rg + (it & 3), t = (16*tg + (it >> 2))*m.dil + res;
+  return (res < m.dil && t < T) ? (long long)b*T + t : -1;
+}
+
 // per-channel sums of one workgroup: q[nq][4] per lane and j -> part[(slice*nq + k)*C + c], wavefront order
 template <int NQ, int NJ>
 __device__ __forceinline__ void write_chan_partials(float4 (&q)[NQ][NJ], int nq, int C, float* part,
@@ -115,10 +148,11 @@ __global__ __launch_bounds__(256) void f32_dw_fwd_fused_kernel(const DwFwd p) {
       tp[k][j] = k < p.P ? make_float4(p.taps[(cc + 0)*p.P + k], p.taps[(cc + 1)*p.P + k], p.taps[(cc + 2)*p.P + k],
                                        p.taps[(cc + 3)*p.P + k]) : f4(0.f);
   }
-  const long long r0 = (long long)fused_slice()*kFusedRows;
+  const SliceMap sm = slice_map(T, p.dil);
+  const int sl = fused_slice();
   for (int it = w; it < kFusedRows; it += 4) {
-    const long long row = r0 + it;
-    if (row >= p.s.rows) break;
+    const long long row = slice_row(sm, sl, it, p.s.rows, T);
+    if (row < 0) continue;
     const int t = (int)(row % T);
     float4 acc[NJ];
 #pragma unroll
@@ -293,10 +327,11 @@ __global__ __launch_bounds__(256) void f32_dw_bwd_fused_kernel(const DwBwd p) {
 #pragma unroll
     for (int k = 0; k < PM + 2; ++k) q[k][j] = f4(0.f);
   }
-  const long long r0 = (long long)fused_slice()*kFusedRows;
+  const SliceMap sm = slice_map(T, p.dil);
+  const int sl = fused_slice();
   for (int it = w; it < kFusedRows; it += 4) {
-    const long long row = r0 + it;
-    if (row >= p.s.rows) break;
+    const long long row = slice_row(sm, sl, it, p.s.rows, T);
+    if (row < 0) continue;
     const int t = (int)(row % T);
     const float mean = p.tab1[2*row], rstd = p.tab1[2*row + 1];
     // all loads of the frame first (rows outside the item are replaced by the frame itself and
