@@ -703,3 +703,51 @@ def test_other_models_do_not_read_uninitialised_memory(arch, use_amp):
     assert rel(g1, g0) <= tol, rel(g1, g0)
     if o1 is not None:
         assert torch.isfinite(o1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('amp', [True, False])
+def test_strided_and_offset_inputs_equal_contiguous_ones(amp):
+    """The batch a caller hands over need not be a fresh contiguous tensor: a window of a longer buffer (row
+    stride > length, storage offset not a multiple of 16 bytes), lengths given as int32 (host tensors are
+    refused loudly: there is no CPU fallback). The
+    fused step and the autograd path must give what they give on a contiguous copy."""
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    dev = torch.device('cuda')
+    gen = torch.Generator().manual_seed(31)
+    B, L = 9, 7001
+    big = (0.2*torch.randn(B, 2, L + 37, generator=gen)).to(dev)
+    view = big[:, :, 3:3 + L]                            # row stride L + 37, offset 3 floats
+    assert not view.is_contiguous()
+    lengths = torch.tensor([L - 11*i for i in range(B)])
+    for b in range(B):
+        big[b, :, 3 + int(lengths[b]):] = 0
+    cfg = dict(layers=3, repeats=2)
+
+    def step_params(batch, lens):
+        torch.manual_seed(4)
+        net = ConvTasNet(**cfg).to(dev)
+        scaler = torch.amp.GradScaler('cuda', enabled=False)
+        losses = [float(net.train_step(batch, lens, amp, scaler)) for _ in range(2)]
+        return losses, net.flat_params().detach().clone()
+
+    def autograd_grads(batch, lens):
+        torch.manual_seed(4)
+        net = ConvTasNet(**cfg).to(dev)
+        net._amp = amp
+        out = net(batch[:, 0])
+        snr(out, batch[:, 1:], lens).mean().backward()
+        return torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+
+    ref_l, ref_p = step_params(view.contiguous(), lengths.to(dev))
+    tol = 2e-2 if amp else 1e-6
+    with pytest.raises(RuntimeError):
+        step_params(view, lengths)
+    for lens in (lengths.to(dev), lengths.to(dev).int()):
+        got_l, got_p = step_params(view, lens)
+        assert max(abs(a - b) for a, b in zip(got_l, ref_l)) <= (1e-2 if amp else 1e-5), (got_l, ref_l)
+        assert rel(got_p, ref_p) <= tol, rel(got_p, ref_p)
+    g_ref = autograd_grads(view.contiguous(), lengths.to(dev))
+    g_view = autograd_grads(view, lengths.to(dev))
+    assert rel(g_view, g_ref) <= (5e-2 if amp else 1e-6), rel(g_view, g_ref)
