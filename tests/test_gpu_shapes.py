@@ -751,3 +751,39 @@ def test_strided_and_offset_inputs_equal_contiguous_ones(amp):
     g_ref = autograd_grads(view.contiguous(), lengths.to(dev))
     g_view = autograd_grads(view, lengths.to(dev))
     assert rel(g_view, g_ref) <= (5e-2 if amp else 1e-6), rel(g_view, g_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('amp', [True, False])
+def test_changing_batch_shapes_reuse_the_buffers_correctly(amp):
+    """An epoch's batches change shape (dynamic batching, the last partial batch): 16 x 3000, 5 x 5000,
+    9 x 2100, 16 x 3000, 3 x 800, 12 x 5000 samples in a row through ONE model -- the workspaces grow and are
+    re-carved (two chains for B >= 8, one below) -- against a model whose cached buffers are dropped and whose
+    memory is poisoned before every step. Same losses; same parameters at the end (bf16: atomics -> 3e-2)."""
+    from brever_amd.models import ConvTasNet
+    dev = torch.device('cuda')
+    shapes = [(16, 3000), (5, 5000), (9, 2100), (16, 3000), (3, 800), (12, 5000)]
+    cfg = dict(layers=3, repeats=2)
+
+    def run(fresh_buffers):
+        torch.manual_seed(6)
+        net = ConvTasNet(**cfg).to(dev)
+        scaler = torch.amp.GradScaler('cuda', enabled=False)
+        gen = torch.Generator().manual_seed(40)
+        losses = []
+        for B, L in shapes:
+            batch, lengths = _ragged_batch(gen, B, L)
+            if fresh_buffers:
+                net._workspace, net._ws_key = {}, {}
+                net._two, net._step_bufs = None, None
+                torch.cuda.empty_cache()
+                junk = [torch.full((1 << 27,), float('nan'), device=dev) for _ in range(8)]
+                del junk
+            losses.append(float(net.train_step(batch.to(dev), lengths.to(dev), amp, scaler)))
+        return losses, net.flat_params().detach().clone()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert all(math.isfinite(v) for v in l0 + l1), (l0, l1)
+    assert max(abs(a - b) for a, b in zip(l0, l1)) <= (3e-2 if amp else 1e-5), (l0, l1)
+    assert rel(p0, p1) <= (3e-2 if amp else 1e-6), rel(p0, p1)
