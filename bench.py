@@ -85,13 +85,14 @@ def physical_cores():
 
 
 def cpu_baseline():
-    """Oracle (pure-PyTorch CPU restatement of the reference path) timed on the host cores (SURVEY.md
-    8d), bounded to about a minute: the thread count is scanned over {8, 32, physical cores} on train
-    steps of 4 x 4 s utterances (one warm-up step on 2 utterances each), then ONE train step of the
-    benchmark batch itself (16 x 4 s, fp32) is timed at the best count (`value_batch16`); `value` is the
-    best of the scan (`by_threads`; all physical cores oversubscribe the host: VERDICT r02 item 9),
-    `value_cpu_bf16` a 4-utterance step under CPU bf16 autocast (the reference's CPU autocast dtype,
-    convtasnet.py:81)."""
+    """Oracle (pure-PyTorch CPU restatement of the reference path) timed on the host cores,
+    bounded to about a minute and a half: the thread count is scanned over {8, 32, physical cores} on train
+    steps of 4 x 4 s utterances (one warm-up step on 2 utterances each; all physical cores oversubscribe the
+    host: VERDICT r02 item 9), then the benchmark batch itself (16 x 4 s, fp32) runs at the best count:
+    1 warm-up step + 3 timed steps -> `value` (SURVEY 8d asks 3 + 5: that is 2 minutes of host time on
+    this box, the warm step is what matters -- the first pass over ~30 GB of fresh activation memory is
+    30 % slower). `value_cpu_bf16`: a 4-utterance step under CPU bf16 autocast (the reference's CPU autocast
+    dtype, convtasnet.py:81)."""
     from oracle.convtasnet import OracleConvTasNet
     cores = physical_cores()
     model_transform = lambda s: s.mean(axis=-2)   # noqa: E731
@@ -99,29 +100,32 @@ def cpu_baseline():
     batch, lengths = BreverDataLoader._collate_fn([dset[i] for i in range(BATCH)])
     scaler = torch.amp.GradScaler('cuda', enabled=False)
 
-    def run(threads, amp, items):
+    def run(threads, amp, items, warm_items=2, steps=1):
         torch.set_num_threads(threads)
         torch.manual_seed(0)
         model = OracleConvTasNet()
-        model.train_step(batch[:2], lengths[:2], amp, scaler)      # warm-up (threads, allocator)
-        t0 = time.perf_counter()
-        model.train_step(batch[:items], lengths[:items], amp, scaler)
-        return items/(time.perf_counter() - t0)
+        model.train_step(batch[:warm_items], lengths[:warm_items], amp, scaler)   # warm-up (threads, allocator)
+        times = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            model.train_step(batch[:items], lengths[:items], amp, scaler)
+            times.append(time.perf_counter() - t0)
+        return items*steps/sum(times), times
 
     counts = sorted({min(8, cores), min(32, cores), cores})
-    by_threads = {n: run(n, False, 4) for n in counts}
+    by_threads = {n: run(n, False, 4)[0] for n in counts}
     best = max(by_threads, key=by_threads.get)
-    full = run(best, False, BATCH)
-    bf16 = run(best, True, 4)
+    full, step_times = run(best, False, BATCH, warm_items=BATCH, steps=3)
+    bf16 = run(best, True, 4)[0]
     return {
-        'value': by_threads[best], 'unit': 'utterances/s', 'cores': best, 'kind': 'port',
-        'physical_cores': cores, 'by_threads': {str(k): v for k, v in by_threads.items()},
-        'value_batch16': full, 'value_cpu_bf16': bf16,
-        'sample': 'value: 1 train step of 4 x 4 s utterances (after a 2-utterance warm-up step), Conv-TasNet '
-                  f'defaults, torch CPU oracle, fp32, {best} threads = the best of {counts} (by_threads); '
-                  f'value_batch16: 1 step of the whole benchmark batch ({BATCH} x 4 s) at {best} threads -- its '
-                  'first and only pass over ~30 GB of fresh activation memory, hence slower per utterance; '
-                  f'value_cpu_bf16: 1 step of 4 utterances under CPU bf16 autocast at {best} threads',
+        'value': full, 'unit': 'utterances/s', 'cores': best, 'kind': 'port',
+        'physical_cores': cores, 'by_threads_4_utterances': {str(k): v for k, v in by_threads.items()},
+        'step_seconds': step_times, 'value_cpu_bf16_4_utterances': bf16,
+        'sample': f'value: 3 timed train steps of the benchmark batch ({BATCH} x 4 s, fp32) after 1 warm-up step of '
+                  f'the same batch, Conv-TasNet defaults, torch CPU oracle, {best} threads = the best of {counts} '
+                  'on a 4-utterance step (by_threads_4_utterances; a 4-utterance step runs ~2.8x the per-'
+                  'utterance rate of the 16-utterance one: its activations stay in the last-level cache); '
+                  f'value_cpu_bf16_4_utterances: 1 step of 4 utterances under CPU bf16 autocast at {best} threads',
     }
 
 
@@ -133,10 +137,10 @@ KERNEL_OF_LABEL = {
     'pw1_fwd': ['gemm_ws_kernel<128, 64, 1, 0, 2,', 'gemm_ws_kernel<128, 64, 1, 0,'],
     'pw2_fwd': 'gemm_ws_kernel<512,', 'dwpw2_fwd': 'dwpw2_fused_kernel',
     'skip_combine': 'skip_combine_kernel',
-    'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': 'gemm_rows_kernel<128, 3, 5>',
+    'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': ['pw1_dgrad_ws_kernel', 'gemm_rows_kernel<128, 3, 5>'],
     'pw1_wgrad': ('gemm_wgrad_kernel<128, 0>', 'largest'), 'clip_adam': 'clip_adam_kernel',
 }
-PMC_FILES = ('r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
+PMC_FILES = ('r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
 
 
 def pmc_traffic(label):
@@ -276,19 +280,34 @@ def fp32_path(device, steps=8, warmup=2):
                     'bitwise repeatable; round 2: 278 utterances/s'}
 
 
-def through_trainer(model, scaler, rank, device, steps, warmup):
+def trainer_sampler(rank, world, n_steps):
+    """Dataset and batch sampler of `through_trainer`: ONE synthetic dataset of world x 16 x n_steps items (the
+    same on every rank), bucket batches of 64 s, and for world > 1 the reference's DistributedBatchSamplerWrapper
+    (brever/training.py:119-125, batching.py:279-290): every rank takes a disjoint share of the SAME batch list and
+    runs the same number of steps."""
+    from brever_amd.batching import DistributedBatchSamplerWrapper
+    dset = SyntheticMixtureDataset(world*BATCH*n_steps, int(SECONDS*FS),
+                                   transform=lambda s: s.mean(axis=-2), seed=100)
+    sampler = BucketBatchSampler(dset, batch_size=BATCH*SECONDS, dynamic=True, fs=FS, seed=0)
+    if world > 1:
+        sampler = DistributedBatchSamplerWrapper(sampler, num_replicas=world, rank=rank, shuffle=False)
+    sampler.set_epoch(0)
+    return dset, sampler
+
+
+def through_trainer(model, scaler, rank, world, device, steps, warmup):
     """The same train step fed by the trainer's data path instead of resident batches: items of
     a host-side SyntheticMixtureDataset (what BreverDataset.__getitem__ + model.transform
-    return) -> BucketBatchSampler (dynamic, 64 s = 16 utterances) -> BreverDataLoader collate
-    -> DevicePrefetcher (pinned double-buffered async H2D) -> train_step. ms per step."""
+    return) -> BucketBatchSampler (dynamic, 64 s = 16 utterances) -> [DistributedBatchSamplerWrapper,
+    world > 1: ONE dataset shared by all ranks, every rank takes its disjoint share of the batch list, as
+    brever/training.py:119-125 + batching.py:279-290 do] -> BreverDataLoader collate -> DevicePrefetcher
+    (pinned double-buffered async H2D) -> train_step. Returns (ms per step, batches this rank consumed)."""
     # as BreverTrainer does on a GPU: few host threads (collate is small copies; 128 spinning
     # OpenMP workers cost 40+ ms per step on this host, tools/trainer_path_debug.py)
     torch.set_num_threads(min(torch.get_num_threads(), int(os.environ.get('BREVER_HOST_THREADS', '4'))))
-    n_items = BATCH*(steps + warmup)
-    dset = SyntheticMixtureDataset(n_items, int(SECONDS*FS),
-                                   transform=lambda s: s.mean(axis=-2), seed=100 + rank)
-    dset.preload('cpu')               # synthesis is not part of the path being timed
-    sampler = BucketBatchSampler(dset, batch_size=BATCH*SECONDS, dynamic=True, fs=FS)
+    dset, sampler = trainer_sampler(rank, world, steps + warmup)
+    mine = sorted({i for batch in sampler for i in batch})
+    dset.preload_indices(mine)        # synthesis is not part of the path being timed (this rank's items only)
     loader = BreverDataLoader(dataset=dset, batch_sampler=sampler, num_workers=0)
     t0 = None
     done = 0
@@ -299,7 +318,7 @@ def through_trainer(model, scaler, rank, device, steps, warmup):
         model.train_step(batch, lengths, True, scaler)
         done += 1
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0)/max(done - warmup, 1)*1e3
+    return (time.perf_counter() - t0)/max(done - warmup, 1)*1e3, done
 
 
 def main():
@@ -329,7 +348,8 @@ def main():
     device = torch.device('cuda', local_rank)
     if world > 1:
         from brever_amd.parallel import init_process_group
-        init_process_group('nccl', device_id=device)      # 120 s timeout: a bad rendezvous exits non-zero
+        init_process_group('nccl', timeout_s=float(os.environ.get('BRV_DIST_TIMEOUT_S', '120')),
+                           device_id=device)         # short timeout: a bad rendezvous exits non-zero
 
     torch.manual_seed(0)
     model = ConvTasNet().to(device)          # defaults = BASELINE config
@@ -375,12 +395,19 @@ def main():
     final_loss = float(loss)
     exposed = sync.exposed_ms() if sync is not None else None
     trainer_ms = None
+    trainer_batches = None
     if not args.no_through_trainer:
-        trainer_ms = through_trainer(model, scaler, rank, device, min(args.steps, 40), 6)
+        trainer_ms, trainer_batches = through_trainer(model, scaler, rank, world, device, min(args.steps, 40), 6)
         if world > 1:
             t = torch.tensor([trainer_ms], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             trainer_ms = float(t)
+            n = torch.tensor([trainer_batches], dtype=torch.int64, device=device)
+            lo, hi = n.clone(), n.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if int(lo) != int(hi):      # the wrapper pads by repetition: every rank must run the same steps
+                raise SystemExit(f'ranks consumed different batch counts: {int(lo)} .. {int(hi)}')
 
     roof, table = kernel_roofline(model, batches, scaler)
     if world > 1:
@@ -409,8 +436,11 @@ def main():
             line['through_trainer'] = {
                 'value': world*BATCH/(trainer_ms*1e-3), 'unit': 'utterances/s',
                 'ms_per_step': trainer_ms,
-                'path': 'host items -> BucketBatchSampler -> BreverDataLoader collate -> pinned '
-                        'double-buffered async H2D (DevicePrefetcher) -> train_step'}
+                'batches_per_rank': trainer_batches,
+                'path': 'host items of ONE dataset -> BucketBatchSampler'
+                        + (' -> DistributedBatchSamplerWrapper (disjoint batches per rank)' if world > 1 else '')
+                        + ' -> BreverDataLoader collate -> pinned double-buffered async H2D (DevicePrefetcher) '
+                          '-> train_step'}
         line['two_chain'] = bool(ConvTasNet.uses_two_chains(BATCH, True))
         if exposed is not None:
             line['allreduce_exposed_ms'] = exposed

@@ -22,6 +22,7 @@ constexpr int kWgSplit = 4;          // item splits of the [res | skip] weight-g
 #include "prep.cuh"
 #include "tcn_kernels.cuh"
 #include "bwd_fused.cuh"
+#include "pw1_bwd.cuh"
 #include "cln_kernels.cuh"
 
 using namespace brv;
@@ -56,6 +57,9 @@ struct OptsScope {
 inline bool opt(uint32_t flag) { return (t_opts->flags & flag) != 0; }
 inline bool fwd_fuse_requested() { return !opt(BRV_OPT_NO_FWD_FUSE) && !opt(BRV_OPT_NO_WS); }
 inline bool bwd_fuse_requested() { return !opt(BRV_OPT_NO_BWD_FUSE); }
+inline bool pw1_rc_requested() { return !opt(BRV_OPT_NO_PW1_RC) && !opt(BRV_OPT_NO_DZ1_FUSE); }
+// the weight gradient rebuilds dz1 too (nothing stored) -- else the data-gradient kernel stores dz1
+inline bool pw1_rc_wgrad() { return opt(BRV_OPT_PW1_RC_WGRAD) || opt(BRV_OPT_PW1_RC_TILES); }
 
 // ---- optional per-launch event timing (bench / profiling only) ---------------
 // A profiler object the caller owns (brv_prof_create); launches of calls whose options carry it are
@@ -102,6 +106,8 @@ struct Layout {
     return !causal && P == 3 && H == 512 && Bn == 128 && Sc == 128 && nb <= 24 /* kWgMaxProb */;
   }
   bool fused_fwd() const { return fusable() && fwd_fuse_requested(); }
+  // first-conv backward without the stored z1 / dz1 (pw1_bwd.cuh): default widths of that layer
+  bool pw1_rc() const { return !causal && Hp == RC_H && Bnp == RC_N && pw1_rc_requested(); }
 
   int init(const brv_ctn_config* c) {
     if (!c) return fail(-1, "null config");
@@ -1367,7 +1373,7 @@ int brv_ctn_grad_bucket(const brv_ctn_config* cfg, int32_t part, int32_t nparts,
 // Deferred weight gradients of blocks [blk_lo, blk_hi] (the data-gradient chain of these blocks has
 // run on a stream this one is ordered after): two grouped launches.
 static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, const bf16_t* prep,
-                           const float* params, float* grads, double* stats, int B, long long T,
+                           const float* params, float* grads, double* stats, double* sums, int B, long long T,
                            int blk_lo, int blk_hi, hipStream_t st) {
   const double BT = (double)B*(double)T;
   auto stat = [&](int i) { return stats + (long long)i*B*kStatStride; };
@@ -1467,6 +1473,31 @@ static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, con
       pr.out0 = grads + b.conv_w; pr.gbias0 = grads + b.conv_b;
     }
     gp.nprob = n;
+    if (l.pw1_rc() && pw1_rc_wgrad()) {
+      // dz1 was never written: rebuilt from e1 (kept per block in eB) and x inside the product
+      Pw1WgradRcParams rp; memset(&rp, 0, sizeof(rp));
+      rp.B = B; rp.T = (int)T; rp.nprob = n; rp.C = l.H; rp.Kout = l.Bn; rp.ldo = l.Bn;
+      rp.lde = l.Hp; rp.ldx = l.Bnp; rp.bse = T*l.Hp; rp.bsx = T*l.Bnp;
+      rp.inv_n = 1.0/((double)T*l.H); rp.eps = 1e-8f;
+      for (int i = i0; i < i0 + n; ++i) {
+        const BlockOff& b = l.blk[i];
+        Pw1WgradRcProb& pr = rp.prob[i - i0];
+        pr.e1 = eBbuf(i); pr.x = xbuf(i); pr.Wfp = prep + b.p_c1_fp; pr.bias = params + b.conv_b;
+        pr.out = grads + b.conv_w; pr.gbias = grads + b.conv_b;
+        pr.stats = stat(1 + 2*i); pr.sums = sums + (long long)(1 + 2*i)*B*kStatStride; pr.slope = params + b.prelu1;
+      }
+      const int tiles = l.Hp/WG_BG;
+      int ns = B;                                  // item-aligned splits (as the stored-dz1 launch)
+      while (tiles*n*ns > 2048 && ns % 2 == 0) ns /= 2;
+      if (t_opts->wg_target > 0) ns = ceil_div(t_opts->wg_target, tiles*n);
+      const int total = B*ceil_div((int)T, WG_BT);
+      if (ns > total) ns = total;
+      if (ns < 1) ns = 1;
+      rp.nsplit = ns;
+      ProfScope prof("pw1_wgrad", 2.0*n*BT*(double)l.Hp*l.Bnp*2, 2.0*BT*(l.Hp + l.Bnp)*n, st);
+      hipLaunchKernelGGL(pw1_wgrad_rc_kernel, dim3(tiles, ns, n), dim3(256), 0, st, rp);
+      HIP_OK(hipGetLastError());
+    } else
     if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp), -1))
       return r;
   }
@@ -1592,7 +1623,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   // chain was measured slower at every chunk count -- DESIGN.md 5g -- and is gone.)
   const int n_chunks = 1;
   auto wgrads = [&](int blk_lo, int blk_hi, hipStream_t st) -> int {
-    return deferred_wgrads(l, ws, base, prep, params, grads, stats, B, T, blk_lo, blk_hi, st);
+    return deferred_wgrads(l, ws, base, prep, params, grads, stats, sums, B, T, blk_lo, blk_hi, st);
   };
   const int n_blk_call = blk_hi - blk_lo + 1;
   for (int ch = n_chunks - 1; ch >= 0; --ch) {
@@ -1679,6 +1710,34 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
       g.e.gu_u = ubuf(i - 1); g.e.ld_gu = ldg; g.e.gu_gskip = gskip; g.e.ld_gs = ldg;
       g.e.gu_v1 = reinterpret_cast<const float*>(prep + l.blk[i - 1].p_lazy) + ldg;
       g.e.gu_out = sum(2 + 2*(i - 1));
+    }
+    if (fuse_dz1 && l.pw1_rc()) {
+      Pw1DgradRcParams rp; memset(&rp, 0, sizeof(rp));
+      rp.e1 = eB; rp.lde = l.Hp; rp.bse = T*l.Hp;
+      rp.x = xbuf(i); rp.ldx = l.Bnp; rp.bsx = T*l.Bnp;
+      rp.Wfp = prep + b.p_c1_fp; rp.bias = params + b.conv_b; rp.Wb = prep + b.p_c1_b;
+      rp.stats = stat(1 + 2*i); rp.sums = sum(1 + 2*i); rp.slope = params + b.prelu1;
+      rp.inv_n = 1.0/((double)T*l.H); rp.eps = 1e-8f; rp.C = l.H;
+      rp.T = (int)T; rp.n_ttiles = ceil_div((int)T, RC_BM); rp.batch = B;
+      rp.e = g.e;
+      rp.e.dslope = vslope + 1 + 2*i; rp.e.rep_stride = ws.vg_stride; rp.e.n_rep = kReplicas;
+      if (opt(BRV_OPT_PW1_RC_TILES)) {        // first form: one tile per workgroup, weights re-read per tile
+        ProfScope prof("pw1_dgrad", 2.0*BT*(double)l.Hp*l.Bnp*2,
+                       2.0*BT*(l.Hp + l.Bnp*(has_res ? 3 : 2)), st);
+        hipLaunchKernelGGL(pw1_dgrad_rc_kernel, dim3(rp.n_ttiles*B), dim3(256), 0, st, rp);
+      } else {
+        Pw1DgradWsParams wp; wp.r = rp;
+        wp.dz_out = pw1_rc_wgrad() ? nullptr : eB;      // stored-dz1 weight gradient: dz1 over e1, in place
+        ProfScope prof("pw1_dgrad", 2.0*BT*(double)l.Hp*l.Bnp*2,
+                       2.0*BT*(l.Hp*(wp.dz_out ? 2 : 1) + l.Bnp*(has_res ? 3 : 2)), st);
+        int grid = num_cus();
+        const int total = ceil_div((int)T, WSD_TF)*B;
+        if (grid > total) grid = total;
+        if (l.H == RC_H) hipLaunchKernelGGL(pw1_dgrad_ws_kernel<true>, dim3(grid), dim3(512), 0, st, wp);
+        else hipLaunchKernelGGL(pw1_dgrad_ws_kernel<false>, dim3(grid), dim3(512), 0, st, wp);
+      }
+      HIP_OK(hipGetLastError());
+      continue;
     }
     if (fuse_dz1) {
       g.a.p1 = z1buf(i); g.a.ld1 = l.Hp; g.a.bs1 = T*l.Hp;

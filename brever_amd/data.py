@@ -222,6 +222,19 @@ class SyntheticMixtureDataset(torch.utils.data.Dataset):
             data.append(item)
         self.preloaded_data = data
 
+    def preload_indices(self, indices, device='cpu'):
+        """Keep only ``indices`` in memory (one rank's share of a dataset every rank indexes the same
+        way: ``bench.py --gpus N``); other items are still synthesised on demand."""
+        class _Cache(dict):
+            def __missing__(cache, i):
+                item = self.make_item(i)
+                return self.transform(item) if self.transform is not None else item
+        self.preloaded_data = None
+        data = _Cache()
+        for i in indices:
+            data[i] = self[i].to(device)
+        self.preloaded_data = data
+
     def set_epoch(self, epoch):
         pass
 

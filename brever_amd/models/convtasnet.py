@@ -108,6 +108,9 @@ class _TCN(_ParamOnly):
         self.output_conv = nn.Conv1d(skip, filters*sources, 1)
 
 
+_warned_queues = False
+
+
 def _queues_ok():
     import brever_amd
     return brever_amd.HW_QUEUES_OK
@@ -321,12 +324,15 @@ class ConvTasNet(BreverBaseModel):
             self._prepared = torch.empty(nbytes, dtype=torch.uint8,
                                          device=self._flat.device)
             self._prepared_dirty = True
-        if self._prepared_dirty:
-            opts = hip.launch_opts()
+        # the prepared operands depend on the mode switches of the call (fused forward: gamma-folded
+        # [res | skip] weights, else the plain ones): a switch toggled on a live model prepares again
+        opts = hip.launch_opts()
+        if self._prepared_dirty or getattr(self, '_prepared_flags', None) != opts.flags:
             hip.check(lib.brv_ctn_prepare(
                 self._cfg_ptr(), hip.ptr(self._flat), hip.ptr(self._prepared),
                 hip.opts_ptr(opts), hip.stream()), 'brv_ctn_prepare')
             self._prepared_dirty = False
+            self._prepared_flags = opts.flags
 
     def _get_workspace(self, B, L, amp=True):
         """Activation workspace of one precision (``amp``: bf16 path, else fp32)."""
@@ -568,8 +574,29 @@ class ConvTasNet(BreverBaseModel):
         (``brever_amd.HW_QUEUES_OK``: torch imported before the package and ``GPU_MAX_HW_QUEUES`` not
         exported): with the default 4 queues RCCL's streams and the two chains share queues and the
         step is slower than one chain (9.6 vs 7.7 ms)."""
-        return bool(amp) and B >= 8 and os.environ.get('BRV_CTN_STREAMS', '2') != '1' \
-            and (_queues_ok() or not _process_group())
+        if not (bool(amp) and B >= 8 and os.environ.get('BRV_CTN_STREAMS', '2') != '1'):
+            return False
+        if _queues_ok() or not _process_group():
+            return True
+        # next to a process group without >= 8 hardware queues. An EXPORTED value below 8 is a
+        # configuration error of the launch (a 20 % slower step): fail loudly; BRV_CTN_STREAMS=1 opts
+        # into the one-chain step. A default that came too late (torch imported before this package)
+        # falls back to one chain with a warning, once.
+        import brever_amd
+        exported = getattr(brever_amd, '_exported', None)
+        if exported is not None:
+            raise RuntimeError(
+                f'GPU_MAX_HW_QUEUES={exported} is exported, but the two-chain Conv-TasNet step next to RCCL '
+                'needs >= 8 hardware queues (DESIGN.md 5h): export GPU_MAX_HW_QUEUES=8 (or unset it before '
+                'importing brever_amd), or set BRV_CTN_STREAMS=1 to run the one-chain step')
+        global _warned_queues
+        if not _warned_queues:
+            import warnings
+            warnings.warn('brever_amd was imported after torch and GPU_MAX_HW_QUEUES is not exported: the HIP '
+                          'runtime has 4 hardware queues, the Conv-TasNet step runs ONE kernel chain next to '
+                          'the process group (export GPU_MAX_HW_QUEUES=8 for the two-chain step)')
+            _warned_queues = True
+        return False
 
     def _train_step_two_chains(self, inputs, labels, lengths):
         """The fused bf16 step as TWO independent half-batch chains on two streams. Every launch of
@@ -653,7 +680,6 @@ class ConvTasNet(BreverBaseModel):
             else:
                 # one pass: grads += grad2, grad2 = 0, squared norm -- then [all-reduce] clip + Adam
                 second = t['grad2']
-                t['grad2_zero'] = True
                 if sync is None:
                     grad_scale = 1.0
                 else:
@@ -663,6 +689,8 @@ class ConvTasNet(BreverBaseModel):
                               'brv_memset_zero')
                     grad_scale, second = sync(grads), None
             self.optimizer.step(max_norm=self.grad_clip, grad_scale=grad_scale, grads2=second)
+            # (only now: a failed launch above must not leave the buffer marked as zeroed)
+            t['grad2_zero'] = nparts == 1
             loss = torch.empty((), dtype=torch.float32, device=dev)
             hip.check(lib.brv_mean_f32(hip.ptr(t['loss']), B, hip.ptr(loss), hip.stream()), 'brv_mean_f32')
             return loss

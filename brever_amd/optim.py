@@ -99,12 +99,18 @@ class FlatAdam(torch.optim.Adam):
         next(iter(self.state.values()))['step'].fill_(float(self._step_count))
         beta1, beta2 = group['betas']
         slot = self._slot
-        self._slot = 1 - slot           # the kernel zeroes the other accumulator for the next call
-        hip.check(hip.lib().brv_clip_adam_step2(
-            hip.ptr(flat), hip.ptr(grads), hip.ptr(grads2), hip.ptr(self._exp_avg),
-            hip.ptr(self._exp_avg_sq), flat.numel(), float(grad_scale),
-            float(max_norm), float(group['lr']), float(beta1), float(beta2),
-            float(group['eps']), self._step_count, hip.ptr(self._scratch), slot,
-            hip.ptr(self.last_grad_norm), hip.stream()), 'brv_clip_adam_step2')
+        try:
+            hip.check(hip.lib().brv_clip_adam_step2(
+                hip.ptr(flat), hip.ptr(grads), hip.ptr(grads2), hip.ptr(self._exp_avg),
+                hip.ptr(self._exp_avg_sq), flat.numel(), float(grad_scale),
+                float(max_norm), float(group['lr']), float(beta1), float(beta2),
+                float(group['eps']), self._step_count, hip.ptr(self._scratch), slot,
+                hip.ptr(self.last_grad_norm), hip.stream()), 'brv_clip_adam_step2')
+        except Exception:
+            # the accumulators' zero / non-zero state is unknown after a failed launch: start over
+            self._scratch.zero_()
+            self._slot = 0
+            raise
+        self._slot = 1 - slot           # the kernel zeroed the other accumulator for the next call
         self._owner.mark_params_changed()
         return loss

@@ -27,13 +27,20 @@ import torch.distributed as dist
 
 
 def init_process_group(backend, timeout_s=None, **kwargs):
-    """``dist.init_process_group`` with a SHORT rendezvous / collective timeout (120 s, or
-    ``BRV_DIST_TIMEOUT_S``): a rank that cannot reach the others exits non-zero instead of hanging for
-    torch's default half hour. Rendezvous on 127.0.0.1 unless MASTER_ADDR says otherwise (one node)."""
-    if timeout_s is None:
-        timeout_s = float(os.environ.get('BRV_DIST_TIMEOUT_S', '120'))
+    """``dist.init_process_group`` on 127.0.0.1 unless MASTER_ADDR says otherwise (one node).
+
+    ``timeout_s`` is the timeout of EVERY collective of the group (NCCL watchdog, gloo operations), not only
+    of the rendezvous: the train / test scripts leave it at torch's defaults (10 min NCCL, 30 min gloo, as the
+    reference) -- a rank that scores its whole test shard before the final gather, or rank 0 writing a
+    checkpoint before a barrier, may keep the others waiting for minutes. ``bench.py`` passes a short one
+    (120 s, or ``BRV_DIST_TIMEOUT_S``) so that a bad rendezvous on a fresh node exits non-zero instead of
+    hanging."""
+    if timeout_s is None and 'BRV_DIST_TIMEOUT_S' in os.environ:
+        timeout_s = float(os.environ['BRV_DIST_TIMEOUT_S'])
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    return dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+    if timeout_s is not None:
+        kwargs['timeout'] = datetime.timedelta(seconds=float(timeout_s))
+    return dist.init_process_group(backend, **kwargs)
 
 
 def broadcast_parameters(model, src=0):
@@ -70,8 +77,16 @@ class GradSynchronizer:
     # -- flat-gradient models -------------------------------------------------
     def __call__(self, flat_grad):
         """Single-bucket hook: sum over ranks, the mean is taken inside the optimizer
-        kernel (``grad_scale``)."""
+        kernel (``grad_scale``). Nothing overlaps this collective: all of it is exposed, and it is
+        timed with the same event pair as ``finish`` so that ``exposed_ms`` says so."""
+        timed = torch.cuda.is_available() and flat_grad.is_cuda and dist.get_backend() == 'nccl'
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
         dist.all_reduce(flat_grad)
+        if timed:
+            b.record()
+            self._waits.append((a, b))
         return 1.0/self.world
 
     def bucket(self, part, grad_slice):

@@ -56,6 +56,9 @@ void brv_prof_destroy(void* prof);
 #define BRV_OPT_NO_DZ1_FUSE     0x020u  /* gLN_1 / PReLU_1 backward as a pass of its own */
 #define BRV_OPT_NO_WGRAD_FULL   0x040u  /* grouped generic kernel for the [res | skip] weight gradient */
 #define BRV_OPT_NO_WGRAD_SPLIT  0x080u  /* no item split of that launch */
+#define BRV_OPT_NO_PW1_RC       0x100u  /* first-conv data gradient reads the stored z1 (pw1_bwd.cuh off) */
+#define BRV_OPT_PW1_RC_WGRAD    0x200u  /* first-conv weight gradient rebuilds dz1 from e1 and x too: dz1 is never stored */
+#define BRV_OPT_PW1_RC_TILES    0x400u  /* recompute in the one-tile-per-workgroup form (weights re-read per tile; implies _WGRAD) */
 typedef struct brv_launch_opts {
   uint32_t size;          /* sizeof(brv_launch_opts), for forward compatibility */
   uint32_t flags;         /* BRV_OPT_* */

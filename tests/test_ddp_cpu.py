@@ -234,3 +234,42 @@ def test_distributed_sampler_partitions_batches():
     union = sorted(i for part in seen for b in part for i in b)
     assert set(union) == set(range(40))
     assert len(seen[0]) == len(seen[1])   # equal step counts (padding by repetition)
+
+
+def _worker_bench_loop(rank, world, port, out_dir):
+    """bench.py's N > 1 data path on two gloo ranks: the batches each rank's loader yields."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from brever_amd.data import BreverDataLoader
+    _init(rank, world, port)
+    dset, sampler = bench.trainer_sampler(rank, world, 5)
+    batches = [list(b) for b in sampler]
+    dset.preload_indices(sorted({i for b in batches for i in b}))
+    loader = BreverDataLoader(dataset=dset, batch_sampler=sampler, num_workers=0)
+    shapes = [(tuple(batch.shape), lengths.tolist()) for batch, lengths in loader]
+    n = torch.tensor([len(batches)])
+    lo, hi = n.clone(), n.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    torch.save({'batches': batches, 'shapes': shapes, 'lo': int(lo), 'hi': int(hi)},
+               os.path.join(out_dir, f'bench_{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_loop_takes_disjoint_batches_of_one_dataset():
+    """for world > 1 `bench.py`'s trainer path feeds every rank from ONE dataset through
+    BucketBatchSampler -> DistributedBatchSamplerWrapper (BASELINE config 3's path, brever/training.py:119-125,
+    batching.py:279-290): the ranks' batches are disjoint, cover the batch list, and every rank runs the same
+    number of steps of 16 x 4 s."""
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        _spawn(_worker_bench_loop, world, tmp)
+        res = [torch.load(os.path.join(tmp, f'bench_{r}.pt')) for r in range(world)]
+    assert res[0]['lo'] == res[0]['hi'] == len(res[0]['batches']) == len(res[1]['batches']) == 5
+    items = [sorted(i for b in r['batches'] for i in b) for r in res]
+    assert not set(items[0]) & set(items[1])
+    assert sorted(items[0] + items[1]) == list(range(world*16*5))
+    for r in res:
+        for shape, lengths in r['shapes']:
+            assert shape == (16, 2, 64000) and lengths == [64000]*16

@@ -61,7 +61,7 @@ def _oracle_grads(oracle, batch, lengths):
 
 
 def _per_tensor(net, got, want, bound, min_numel=512, min_norm=1e-4):
-    worst = (0.0, None)
+    worst = (-1.0, '')
     for (name, p), off in zip(net.named_parameters(), [o for _, o in net.param_offsets()]):
         n = p.numel()
         ref = want[off:off + n]
@@ -360,6 +360,51 @@ def test_fused_backward_equals_three_launch_backward(monkeypatch, layers, repeat
             assert e <= 1.5e-2, e
             worst = _per_tensor(net, grads['1'], grads['0'], 5e-2, min_numel=128, min_norm=1e-5)
             print('   worst tensor', worst)
+
+
+@pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 2, 3, 5000), (4, 2, 1, 700), (8, 1, 5, 2100),
+                                                (8, 1, 2, 300), (2, 1, 1, 64000)])
+def test_first_conv_backward_with_recomputed_z1_equals_stored_path(monkeypatch, layers, repeats, B, L):
+    """csrc/pw1_bwd.cuh: the first 1x1 convolution's data gradient rebuilds z1 = W1 x + b1 on the matrix pipe
+    instead of reading the stored z1 (default: the weight-stationary kernel with specialised waves; it still
+    stores dz1 for the weight gradient); BRV_PW1_RC_WGRAD=1: the weight gradient rebuilds dz1 too and dz1 is
+    never stored; BRV_PW1_RC_TILES=1: both in their one-tile-per-workgroup form. The recompute repeats
+    pw1_fwd's instruction sequence, so z1 is the same bf16 tensor; the first form also keeps the round-3
+    arithmetic of dz1 (gradients equal to the order of fp32 partial sums, 1e-7), the default kernels fold it
+    into fewer fused multiply-adds (dz1 differs in the last bf16 bit of some elements: 1e-3 per tensor)."""
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    cfg = dict(layers=layers, repeats=repeats)
+    gen = torch.Generator().manual_seed(11*layers + B)
+    torch.manual_seed(29)
+    ref = ConvTasNet(**cfg)
+    _detrivialise(ref, gen)
+    batch, lengths = _ragged_batch(gen, B, L)
+    modes = {'stored': {'BRV_PW1_RC': '0'}, 'ws': {}, 'ws+wgrad': {'BRV_PW1_RC_WGRAD': '1'},
+             'tiles': {'BRV_PW1_RC_TILES': '1'}}
+    grads = {}
+    for mode, env in modes.items():
+        for k in ('BRV_PW1_RC', 'BRV_PW1_RC_WGRAD', 'BRV_PW1_RC_TILES'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = ConvTasNet(**cfg)
+        net.load_state_dict(ref.state_dict())
+        net = net.to(_cuda())
+        net._amp = True
+        out = net(batch[:, 0].cuda())
+        loss = snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean()
+        loss.backward()
+        grads[mode] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+        assert torch.isfinite(grads[mode]).all()
+        if mode != 'stored':
+            e = rel(grads[mode], grads['stored'])
+            exact = mode == 'tiles'
+            # (scalars -- the PReLU slope gradients -- are sums with heavy cancellation: compared in the global norm only)
+            worst = _per_tensor(net, grads[mode], grads['stored'], 1e-3 if exact else 2e-2, min_numel=1 if exact else 128,
+                                min_norm=1e-6)
+            print(f'layers {layers} x {repeats}, B {B}, L {L}: {mode} vs stored-z1 backward rel {e:.3e}, worst {worst}')
+            assert e <= (1e-4 if exact else 3e-3), (mode, e)
 
 
 def test_two_models_step_from_two_threads():

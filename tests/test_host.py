@@ -533,7 +533,16 @@ def test_two_chain_gating(monkeypatch):
     assert two(16, True) and two(8, True)                # no process group: the queues do not matter
     assert not two(16, False) and not two(7, True) and not two(6, True) and two(9, True)
     monkeypatch.setattr(M, '_process_group', lambda: True)
-    assert not two(16, True)                             # RCCL next to it, queues not guaranteed
+    monkeypatch.setattr(brever_amd, '_exported', None)
+    with pytest.warns(UserWarning, match='ONE kernel chain'):
+        assert not two(16, True)                         # RCCL next to it, the default came too late: one chain
+    # an EXPORTED value below 8 under a process group fails loudly ...
+    monkeypatch.setattr(brever_amd, '_exported', '4')
+    with pytest.raises(RuntimeError, match='GPU_MAX_HW_QUEUES=4'):
+        two(16, True)
+    monkeypatch.setenv('BRV_CTN_STREAMS', '1')           # ... unless the one-chain step is asked for
+    assert not two(16, True)
+    monkeypatch.delenv('BRV_CTN_STREAMS')
     monkeypatch.setattr(brever_amd, 'HW_QUEUES_OK', True)
     assert two(16, True)
     monkeypatch.setenv('BRV_CTN_STREAMS', '1')
@@ -566,7 +575,7 @@ def test_launch_opts_come_from_the_environment_on_the_host(monkeypatch):
     DESIGN 5c into `brv_launch_opts` flags at call time."""
     import ctypes
     for name in ('BRV_FWD_FUSE', 'BRV_BWD_FUSE', 'BRV_NO_WS', 'BRV_DWPW2_WS', 'BRV_NO_DZ_FUSE', 'BRV_NO_DZ1_FUSE',
-                 'BRV_NO_WGRAD_FULL', 'BRV_NO_WGRAD_SPLIT', 'BRV_WG_TARGET'):
+                 'BRV_NO_WGRAD_FULL', 'BRV_NO_WGRAD_SPLIT', 'BRV_WG_TARGET', 'BRV_PW1_RC'):
         monkeypatch.delenv(name, raising=False)
     o = hip.launch_opts()
     assert o.size == ctypes.sizeof(hip.LaunchOpts) == 24 and o.flags == 0 and o.cu_eighths == 8
