@@ -307,6 +307,9 @@ def through_trainer(model, scaler, rank, world, device, steps, warmup):
     torch.set_num_threads(min(torch.get_num_threads(), int(os.environ.get('BREVER_HOST_THREADS', '4'))))
     dset, sampler = trainer_sampler(rank, world, steps + warmup)
     mine = sorted({i for batch in sampler for i in batch})
+    sampler.set_epoch(0)              # (a shuffling sampler composes its batches once per set_epoch call)
+    inner = getattr(sampler, 'sampler', sampler)
+    inner._previous_epoch = None      # the same epoch again: the loader must see the batches listed above
     dset.preload_indices(mine)        # synthesis is not part of the path being timed (this rank's items only)
     loader = BreverDataLoader(dataset=dset, batch_sampler=sampler, num_workers=0)
     t0 = None

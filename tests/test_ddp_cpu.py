@@ -246,6 +246,7 @@ def _worker_bench_loop(rank, world, port, out_dir):
     dset, sampler = bench.trainer_sampler(rank, world, 5)
     batches = [list(b) for b in sampler]
     dset.preload_indices(sorted({i for b in batches for i in b}))
+    getattr(sampler, 'sampler', sampler)._previous_epoch = None      # as bench.through_trainer: same epoch again
     loader = BreverDataLoader(dataset=dset, batch_sampler=sampler, num_workers=0)
     shapes = [(tuple(batch.shape), lengths.tolist()) for batch, lengths in loader]
     n = torch.tensor([len(batches)])

@@ -832,3 +832,38 @@ def test_changing_batch_shapes_reuse_the_buffers_correctly(amp):
     assert all(math.isfinite(v) for v in l0 + l1), (l0, l1)
     assert max(abs(a - b) for a, b in zip(l0, l1)) <= (3e-2 if amp else 1e-5), (l0, l1)
     assert rel(p0, p1) <= (3e-2 if amp else 1e-6), rel(p0, p1)
+
+
+def test_sixty_four_ragged_utterances_equal_four_steps_of_sixteen(monkeypatch):
+    """A dynamic bucket batch larger than anything `bench.py` steps: 64 ragged utterances
+    (0.5 - 4 s) through the two-chain fused step give the loss and the gradient of the same items taken as four
+    batches of 16 (the mean over the batch: gradient = mean of the four), summation order aside."""
+    from brever_amd.models import ConvTasNet
+    gen = torch.Generator().manual_seed(5)
+    B, L = 64, 64000
+    batch = 0.1*torch.randn(B, 2, L, generator=gen)
+    lengths = torch.randint(8000, L + 1, (B,), generator=gen)
+    lengths[0] = L
+    for b in range(B):
+        batch[b, :, lengths[b]:] = 0
+    torch.manual_seed(3)
+    ref = ConvTasNet()
+
+    def fresh():                       # (train_step also takes the optimizer step: every run starts from `ref`)
+        net = ConvTasNet()
+        net.load_state_dict(ref.state_dict())
+        return net.to(_cuda())
+    net = fresh()
+    loss64, g64 = _fused_step_grads(net, batch, lengths, True, '2', monkeypatch)
+    parts, losses = [], []
+    for k in range(4):
+        sl = slice(16*k, 16*k + 16)
+        lk, gk = _fused_step_grads(fresh(), batch[sl], lengths[sl], True, '2', monkeypatch)
+        parts.append(gk)
+        losses.append(lk)
+    g_ref = torch.stack(parts).mean(0)
+    assert abs(loss64 - sum(losses)/4) <= 2e-4, (loss64, losses)
+    e = rel(g64, g_ref)
+    print(f'64 ragged utterances in one step vs 4 x 16: loss {loss64:.5f}, gradient rel {e:.3e}')
+    assert e <= 2e-3, e
+    _per_tensor(net, g64, g_ref, 2e-2)

@@ -115,6 +115,81 @@ def convtasnet_fp32_row(steps=5):
                        'exact-fp32 MFMA products (brv_ctn_f32_*)', tflops=16/dt*116.46e9/1e12)
 
 
+def convtasnet_bigbatch_row(budget_s, n_batches=5, seed=0):
+    """The Conv-TasNet bf16 training step on HBM-sized DYNAMIC batches (north_star: "bucket batcher sized for
+    288 GB HBM3E"; reference brever/batching.py:191-204,248-251): ragged synthetic mixtures of 0.5 - 4 s through
+    BucketBatchSampler(dynamic=True, batch_size=budget_s seconds of padded audio) -> collate -> pinned async H2D
+    -> train_step. budget_s <= 0: the automatic size of `trainer.batch_size: 0` (batching.hbm_batch_seconds)."""
+    from brever_amd.batching import BucketBatchSampler
+    from brever_amd.data import BreverDataLoader, DevicePrefetcher, SyntheticMixtureDataset
+    from brever_amd.models import ConvTasNet
+    from brever_amd.training import BreverTrainer
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    model = ConvTasNet().to(dev)
+    auto = budget_s <= 0
+    if auto:
+        budget_s = BreverTrainer.auto_batch_seconds(model, 0, 16000)
+    mean_len = 0.5*(0.5 + 4.0)
+    n_items = int(budget_s/mean_len*(n_batches + 0.5))
+    dset = SyntheticMixtureDataset(n_items, 64000, min_length=8000, transform=lambda s: s.mean(axis=-2), seed=seed)
+    dset.preload('cpu')
+    sampler = BucketBatchSampler(dset, batch_size=budget_s, dynamic=True, fs=16000, seed=seed)
+    sampler.set_epoch(0)
+    loader = BreverDataLoader(dataset=dset, batch_sampler=sampler, num_workers=0)
+    torch.set_num_threads(4)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    torch.cuda.reset_peak_memory_stats()
+    items = seconds = padded = 0.0
+    sizes = []
+    t0 = None
+    losses = []
+    for i, (batch, lengths) in enumerate(DevicePrefetcher(loader, dev)):
+        if i == 1:                       # the first batch pays the allocations
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        loss = model.train_step(batch, lengths, True, scaler)
+        if i >= 1:
+            items += batch.shape[0]
+            seconds += float(lengths.sum())/16000
+            padded += batch.shape[0]*batch.shape[-1]/16000
+        sizes.append(int(batch.shape[0]))
+        losses.append(loss)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    losses = [float(x) for x in losses]
+    assert all(x == x and abs(x) < 1e4 for x in losses), losses
+    # the same batches resident in HBM (bench.py's `value` convention): what the device does per step
+    sampler._previous_epoch = None       # the same epoch again (same batches)
+    resident = [(b.to(dev), n.to(dev)) for b, n in loader][1:-1] or None
+    res = None
+    if resident:
+        for b, n in resident[:1]:
+            model.train_step(b, n, True, scaler)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for b, n in resident:
+            model.train_step(b, n, True, scaler)
+        torch.cuda.synchronize()
+        dtr = time.perf_counter() - t1
+        rs = sum(float(n.sum())/16000 for _, n in resident)
+        res = {'ms_per_step': dtr/len(resident)*1e3, 'utterances_per_s': sum(b.shape[0] for b, _ in resident)/dtr,
+               'audio_seconds_per_s': rs/dtr, 'equiv_4s_utterances_per_s': rs/dtr/4.0,
+               'padded_equiv_4s_utterances_per_s': sum(b.shape[0]*b.shape[-1] for b, _ in resident)/16000/dtr/4.0}
+    row = {'row': f"convtasnet train, dynamic bucket batches of {budget_s:.0f} s{' (automatic: HBM-sized)' if auto else ''}",
+           'budget_seconds': budget_s, 'batches_timed': len(sizes) - 1, 'utterances_per_batch': sizes,
+           'ms_per_step': dt/max(len(sizes) - 1, 1)*1e3, 'audio_seconds_per_s': seconds/dt,
+           'padded_seconds_per_s': padded/dt, 'equiv_4s_utterances_per_s': seconds/dt/4.0,
+           'peak_memory_GB': torch.cuda.max_memory_allocated()/1e9,
+           'total_memory_GB': torch.cuda.get_device_properties(0).total_memory/1e9, 'losses': losses,
+           'resident_in_hbm': res}
+    return driver_line(row, 'utterances/sec Conv-TasNet train on ragged 0.5-4 s mixtures, dynamic bucket batches',
+                       items/dt, 'utterances/s', 'bf16',
+                       f'Conv-TasNet defaults, bucket batches of {budget_s:.0f} s of padded audio (ragged 0.5 - 4 s items), '
+                       'fwd + SNR loss + bwd + clip + Adam through the trainer data path',
+                       tflops=seconds/dt/4.0*116.46e9/1e12)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rows', default='convtasnet_fp32,ffnn,dccrn,tfgridnet,sgmse,sgmse_train')
@@ -130,6 +205,10 @@ def main():
         return
     if 'convtasnet_fp32' in rows:
         print(json.dumps(convtasnet_fp32_row()), flush=True)
+    for r in rows:
+        if r.startswith('convtasnet_bigbatch'):          # convtasnet_bigbatch:<seconds> (0 = automatic)
+            budget = float(r.split(':')[1]) if ':' in r else 0.0
+            print(json.dumps(convtasnet_bigbatch_row(budget)), flush=True)
     if 'ffnn' in rows:
         print(json.dumps(train_row('ffnn', 32, 2.0, 20, False)), flush=True)
     if 'dccrn' in rows:
