@@ -1134,6 +1134,9 @@ class PCSolver:
             else:                                              # probability flow, no noise
                 step = _axpby(drift, dt, score, -0.5*g*g*dt)
                 x = _axpby(x, 1.0, step, 1.0)
+            hook = getattr(owner, '_step_hook', None)          # tests: the state after every reverse step
+            if hook is not None:
+                hook(i, x)
         return x, self.num_steps*(self.corrector_steps + 1)
 
 

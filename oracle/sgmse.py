@@ -162,8 +162,9 @@ def score(net, sde, x, y, sigma, t, **kw):
     return (denoise(net, sde, x, y, sigma, t, **kw) - x)/(sde.s(t)*sigma**2)
 
 
-def pc_sample(net, sde, y, noise, num_steps, corrector_steps, corrector_snr, **kw):
-    """Predictor-corrector sampler (solvers.py:48-77); noise(shape, complex) -> tensor."""
+def pc_sample(net, sde, y, noise, num_steps, corrector_steps, corrector_snr, on_step=None, **kw):
+    """Predictor-corrector sampler (solvers.py:48-77); noise(shape, complex) -> tensor;
+    ``on_step(i, x)``: the state after every reverse step (tests)."""
     dt = -1/num_steps
     t = torch.arange(1, 0, dt)
     sigma = sde.sigma(t)
@@ -180,6 +181,8 @@ def pc_sample(net, sde, y, noise, num_steps, corrector_steps, corrector_snr, **k
             x = x + (drift - sde.g(t[i])**2*sc)*dt + sde.g(t[i])*(-dt)**0.5*noise(x.shape, False)
         else:
             x = x + dt*(drift - 0.5*sde.g(t[i])**2*sc)
+        if on_step is not None:
+            on_step(i, x)
     return x
 
 

@@ -187,7 +187,7 @@ def test_full_size_gradients_vs_oracle(monkeypatch):
     assert abs(loss16 - loss_ref) <= 1e-2, (loss16, loss_ref)
     e16 = rel(g16, g_ref)
     print(f'full size bf16 two-chain: loss {loss16:.5f} vs {loss_ref:.5f}, grad rel {e16:.3e}')
-    assert e16 <= 8e-2, e16
+    assert e16 <= 1.5e-2, e16                   # 2 x the measured 7.4e-3: a regression of one kernel shows
     worst = _per_tensor(net, g16, g_ref, 0.25)
     print('   worst tensor', worst)
     del net
