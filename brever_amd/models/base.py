@@ -44,11 +44,70 @@ class BreverBaseModel(nn.Module):
     # -- optimizers ----------------------------------------------------------
     def init_optimizer(self, optimizer, net=None, **kwargs):
         """``optimizer`` is a ``torch.optim`` class or its name
-        (brever/models/base.py:55-79)."""
+        (brever/models/base.py:55-79). Plain Adam over the whole model becomes ``FlatAdam``: the
+        parameters are packed into ONE flat fp32 buffer (every ``nn.Parameter`` a view of it, same
+        ``state_dict``) and ``update`` runs ``clip_grad_norm_`` + ``Adam.step`` as the two launches of
+        ``brv_clip_adam_step2`` instead of PyTorch's multi-tensor kernels (K11; every model, not only
+        Conv-TasNet). Anything else (other optimizers, options FlatAdam does not implement, a
+        sub-network) is constructed as the reference does."""
         if isinstance(optimizer, str):
             optimizer = getattr(torch.optim, optimizer)
+        if self._fused_adam and optimizer is torch.optim.Adam and net is None \
+                and set(kwargs) <= {'lr', 'betas', 'eps'} \
+                and all(p.dtype == torch.float32 for p in self.parameters()) \
+                and any(True for _ in self.parameters()):
+            from ..optim import FlatAdam
+            self._flat_base = True
+            self._flatten_base()
+            return FlatAdam(self.parameters(), owner=self, **kwargs)
         target = self if net is None else net
         return optimizer(target.parameters(), **kwargs)
+
+    # flat parameter storage of the generic FlatAdam path (Conv-TasNet brings its own: models/convtasnet.py).
+    # Opt-in per model class: the HIP models (which only step on a ROCm device) set `_fused_adam = True`
+    _fused_adam = False
+    _flat_base = False
+
+    def _flatten_base(self):
+        params = list(self.parameters())
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
+        offsets, off = [], 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            offsets.append((p, off))
+            off += n
+        self._flat, self._offsets, self._flat_grad = flat, offsets, None
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if self._flat_base:
+            self._flatten_base()             # (.to(device) gave every parameter a storage of its own again)
+        return out
+
+    def flat_params(self):
+        return self._flat
+
+    def param_offsets(self):
+        return self._offsets
+
+    def mark_params_changed(self):
+        pass
+
+    def gather_grads(self):
+        """Flat gradient for ``FlatAdam``: the ``.grad`` tensors autograd left (separate allocations) are
+        copied into one buffer by a single multi-tensor copy; parameters without a gradient count as zero."""
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            self._flat_grad = torch.zeros_like(self._flat)
+            self._grad_slices = [self._flat_grad[off:off + p.numel()].view(p.shape) for p, off in self._offsets]
+        have = [(v, p.grad) for v, (p, _) in zip(self._grad_slices, self._offsets) if p.grad is not None]
+        if len(have) != len(self._offsets):
+            self._flat_grad.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        return self._flat_grad
 
     def optimizers(self):
         return self.optimizer
@@ -89,9 +148,16 @@ class BreverBaseModel(nn.Module):
                retain_graph=None):
         """backward -> [unscale + clip_grad_norm_] -> optimizer step -> scaler
         update (brever/models/base.py:270-301)."""
+        whole = net is None
         net = self if net is None else net
         optimizer = self.optimizer if optimizer is None else optimizer
         scaler.scale(loss).backward(retain_graph=retain_graph)
+        from ..optim import FlatAdam
+        if whole and isinstance(optimizer, FlatAdam) and getattr(optimizer, '_owner', None) is self \
+                and not scaler.is_enabled():
+            # clip_grad_norm_(grad_clip) + Adam.step fused on the flat buffers (two HIP launches)
+            optimizer.step(max_norm=float(grad_clip))
+            return
         if grad_clip != 0.0:
             scaler.unscale_(optimizer)
             torch.nn.utils.clip_grad_norm_(net.parameters(), grad_clip)

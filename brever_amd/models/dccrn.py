@@ -577,6 +577,8 @@ class _ApplyMaskFunction(torch.autograd.Function):
 
 @ModelRegistry.register('dccrn')
 class DCCRN(BreverBaseModel):
+    _fused_adam = True       # clip + Adam as brv_clip_adam_step2 on one flat buffer (models/base.py)
+
     def __init__(
         self,
         stft_frame_length: int = 512,

@@ -187,6 +187,8 @@ class CumulativeNormalizer(nn.Module):
 
 @ModelRegistry.register('ffnn')
 class FFNN(BreverBaseModel):
+    _fused_adam = True       # clip + Adam as brv_clip_adam_step2 on one flat buffer (models/base.py)
+
     def __init__(
         self,
         fs: int = 16000,

@@ -1181,6 +1181,8 @@ class EDMSolver:
 # ------------------------------------------------------------------------------------------
 @ModelRegistry.register('sgmsep')
 class SGMSEp(BreverBaseModel):
+    _fused_adam = True       # clip + Adam as brv_clip_adam_step2 on one flat buffer (models/base.py)
+
     def __init__(
         self,
         stft_frame_length: int = 512,

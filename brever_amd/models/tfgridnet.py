@@ -398,6 +398,8 @@ def _bilstm(x, rnn):
 
 @ModelRegistry.register('tfgridnet')
 class TFGridNet(BreverBaseModel):
+    _fused_adam = True       # clip + Adam as brv_clip_adam_step2 on one flat buffer (models/base.py)
+
     def __init__(
         self,
         n_srcs: int = 1,

@@ -188,3 +188,54 @@ def test_convtasnet_bf16_ten_step_trajectory_at_default_widths(monkeypatch):
     # reference's own CPU-bf16 autocast run shows, and small in absolute terms
     assert d32.max() <= max(3.0*dcpu.max(), 2e-2), (d32.max(), dcpu.max())
     assert d32.max() <= 5e-2, d32.max()
+
+
+@pytest.mark.parametrize('arch,kwargs,clip', [
+    ('dccrn', {}, 5.0), ('ffnn', {}, 0.0), ('tfgridnet', dict(n_layers=2, lstm_hidden_units=32, attn_n_head=2), 1.0),
+    ('sgmsepm', {}, 0.0)])
+def test_fused_clip_adam_of_every_model_matches_torch(arch, kwargs, clip):
+    """K11 for every model: DCCRN / FFNN / TF-GridNet / SGMSE+ step through
+    `brv_clip_adam_step2` on ONE flat parameter buffer (models/base.py) instead of `clip_grad_norm_` +
+    `torch.optim.Adam` (brever/models/base.py:296-301). Three steps on fabricated gradients against torch's own
+    clip + Adam on copies; the optimizer `state_dict` keeps torch's format both ways."""
+    from brever_amd.models import ModelRegistry
+    from brever_amd.optim import FlatAdam
+    dev = _cuda()
+    torch.manual_seed(0)
+    model = ModelRegistry.get(arch)(**kwargs).to(dev)
+    assert isinstance(model.optimizer, FlatAdam)
+    params = list(model.parameters())
+    # every parameter is a view of the flat buffer, in parameters() order, also after .to(device)
+    off = 0
+    for p in params:
+        assert p.data_ptr() == model.flat_params().data_ptr() + 4*off
+        off += p.numel()
+    ref_params = [p.detach().clone().requires_grad_(True) for p in params]
+    ref_opt = torch.optim.Adam(ref_params, lr=model.optimizer.param_groups[0]['lr'])
+    gen = torch.Generator(device='cpu').manual_seed(1)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    for step in range(3):
+        grads = [(0.3*torch.randn(p.shape, generator=gen)).to(dev) for p in params]
+        for p, q, g in zip(params, ref_params, grads):
+            p.grad = g.clone()
+            q.grad = g.clone()
+        if clip:
+            torch.nn.utils.clip_grad_norm_(ref_params, clip)
+        ref_opt.step()
+        # the model's own update path (autograd leaves separate .grad tensors: gathered by one multi-tensor copy)
+        loss = sum((p*0).sum() for p in params[:1])         # a graph whose backward adds zeros to params[0].grad
+        model.update(loss, scaler, grad_clip=clip) if arch in ('ffnn', 'sgmsepm') else model.update(loss, scaler)
+    for p, q in zip(params, ref_params):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), float((p - q).abs().max())
+    # state_dict: torch's format, loadable by torch.optim.Adam and back
+    sd = model.optimizer.state_dict()
+    other = torch.optim.Adam([q.detach().clone().requires_grad_(True) for q in ref_params])
+    other.load_state_dict(sd)
+    ref_sd = ref_opt.state_dict()
+    for k in range(len(params)):
+        a, b = sd['state'][k], ref_sd['state'][k]
+        assert float(a['step']) == float(b['step']) == 3
+        assert torch.allclose(a['exp_avg'], b['exp_avg'], rtol=1e-4, atol=1e-6)
+        assert torch.allclose(a['exp_avg_sq'], b['exp_avg_sq'], rtol=1e-4, atol=1e-10)     # (fused multiply-adds)
+    model.optimizer.load_state_dict(ref_sd)
+    assert torch.allclose(model.optimizer._exp_avg[:params[0].numel()].view(params[0].shape), ref_sd['state'][0]['exp_avg'])
