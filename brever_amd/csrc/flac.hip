@@ -279,3 +279,149 @@ int64_t brv_flac_decode(const uint8_t* data, int64_t size, float* out, int64_t c
 }
 
 }  // extern "C"
+
+// ---- encoder (host code): what scripts/test_model.py --output_dir writes ------------------------
+// Reference: torchaudio.save(path, x, fs) with a .flac name (scripts/test_model.py:201-209). Mono,
+// 16 bits per sample, blocks of 4096 samples; per block the FIXED predictor (order 0-4) with the
+// smallest sum of |residual|, residuals Rice-coded in 2^p partitions (p <= 3 where the block divides)
+// with the parameter that minimises each partition's length; CONSTANT subframes for constant blocks,
+// VERBATIM when prediction does not pay. Lossless by construction; the decoder above reads it back
+// bit for bit (tests/test_host.py). Which block size / predictor torchaudio's back end would have
+// chosen does not change the decoded samples.
+namespace {
+struct BitWriter {
+  std::vector<uint8_t>& out; uint64_t acc; int n;
+  explicit BitWriter(std::vector<uint8_t>& o) : out(o), acc(0), n(0) {}
+  void write(uint64_t v, int bits) {                       // MSB first, bits <= 32
+    if (bits <= 0) return;
+    acc = (acc << bits) | (v & ((bits >= 64) ? ~0ull : ((1ull << bits) - 1)));
+    n += bits;
+    while (n >= 8) { n -= 8; out.push_back((uint8_t)(acc >> n)); }
+    acc &= (n ? ((1ull << n) - 1) : 0);
+  }
+  void unary(uint32_t q) { while (q >= 32) { write(0, 32); q -= 32; } write(1, (int)q + 1); }
+  void align() { if (n) write(0, 8 - n); }
+};
+inline uint32_t zigzag(int64_t v) { return v >= 0 ? (uint32_t)(v << 1) : (uint32_t)(((-v) << 1) - 1); }
+// bits of `count` residuals with Rice parameter k
+inline uint64_t rice_bits(const int64_t* r, int count, int k) {
+  uint64_t b = 0;
+  for (int i = 0; i < count; ++i) b += (zigzag(r[i]) >> k) + 1 + k;
+  return b;
+}
+}  // namespace
+
+extern "C" int64_t brv_flac_encode16(const int16_t* pcm, int64_t frames, int32_t sample_rate, uint8_t* out,
+                                     int64_t capacity) {
+  if (!pcm || frames < 0 || sample_rate <= 0 || sample_rate >= (1 << 20)) return -1;
+  const int BS = 4096;
+  std::vector<uint8_t> buf;
+  buf.reserve((size_t)frames*2 + 1024);
+  const uint8_t magic[4] = {'f', 'L', 'a', 'C'};
+  buf.insert(buf.end(), magic, magic + 4);
+  {
+    const uint8_t hdr[4] = {0x80, 0, 0, 34};               // last metadata block: STREAMINFO, 34 bytes
+    buf.insert(buf.end(), hdr, hdr + 4);
+    BitWriter bw(buf);
+    bw.write(BS, 16); bw.write(BS, 16); bw.write(0, 24); bw.write(0, 24);
+    bw.write((uint64_t)sample_rate, 20); bw.write(0, 3); bw.write(15, 5);
+    bw.write((uint64_t)frames >> 32, 4); bw.write((uint64_t)frames & 0xffffffffull, 32);
+    for (int i = 0; i < 4; ++i) bw.write(0, 32);           // MD5 unset
+  }
+  std::vector<int64_t> x(BS), res(BS);
+  int64_t fno = 0;
+  for (int64_t start = 0; start < frames; start += BS, ++fno) {
+    const int n = (int)((frames - start) < BS ? (frames - start) : BS);
+    for (int i = 0; i < n; ++i) x[i] = pcm[start + i];
+    const size_t f0 = buf.size();
+    BitWriter bw(buf);
+    bw.write(0xfff8 >> 2, 14); bw.write(0, 1); bw.write(0, 1);     // sync, reserved, fixed block size
+    bw.write(7, 4);                                        // 16-bit (block size - 1) at the end of the header
+    bw.write(0, 4);                                        // sample rate: STREAMINFO
+    bw.write(0, 4);                                        // mono
+    bw.write(4, 3); bw.write(0, 1);                        // 16 bits per sample
+    {                                                      // frame number, UTF-8 coded
+      uint64_t v = (uint64_t)fno;
+      if (v < 0x80) bw.write(v, 8);
+      else {
+        int extra = v < 0x800 ? 1 : v < 0x10000 ? 2 : v < 0x200000 ? 3 : v < 0x4000000 ? 4 : 5;
+        bw.write(((0xff00u >> extra) & 0xff) | (v >> (6*extra)), 8);
+        for (int e = extra - 1; e >= 0; --e) bw.write(0x80 | ((v >> (6*e)) & 0x3f), 8);
+      }
+    }
+    bw.write((uint64_t)(n - 1), 16);
+    buf.push_back(crc8(buf.data() + f0, buf.size() - f0));
+    // ---- the subframe
+    bool constant = true;
+    for (int i = 1; i < n; ++i) if (x[i] != x[0]) { constant = false; break; }
+    if (constant) {
+      bw.write(0, 8); bw.write((uint64_t)x[0], 16);
+    } else {
+      // best fixed order by the sum of |residual| (orders above n - 1 are not available)
+      int best_o = 0; uint64_t best_s = ~0ull;
+      for (int o = 0; o <= 4 && o < n; ++o) {
+        uint64_t sum = 0;
+        for (int i = o; i < n; ++i) {
+          int64_t r = x[i];
+          if (o == 1) r = x[i] - x[i - 1];
+          else if (o == 2) r = x[i] - 2*x[i - 1] + x[i - 2];
+          else if (o == 3) r = x[i] - 3*x[i - 1] + 3*x[i - 2] - x[i - 3];
+          else if (o == 4) r = x[i] - 4*x[i - 1] + 6*x[i - 2] - 4*x[i - 3] + x[i - 4];
+          sum += (uint64_t)(r < 0 ? -r : r);
+        }
+        if (sum < best_s) { best_s = sum; best_o = o; }
+      }
+      const int o = best_o;
+      for (int i = o; i < n; ++i) {
+        int64_t r = x[i];
+        if (o == 1) r = x[i] - x[i - 1];
+        else if (o == 2) r = x[i] - 2*x[i - 1] + x[i - 2];
+        else if (o == 3) r = x[i] - 3*x[i - 1] + 3*x[i - 2] - x[i - 3];
+        else if (o == 4) r = x[i] - 4*x[i - 1] + 6*x[i - 2] - 4*x[i - 3] + x[i - 4];
+        res[i - o] = r;
+      }
+      int po = 3;
+      while (po > 0 && (n % (1 << po) != 0 || (n >> po) <= o)) --po;
+      // per partition the best 4-bit Rice parameter (0..14)
+      uint64_t total = 6 + 2 + 4;
+      std::vector<int> ks(1 << po);
+      int pos = 0;
+      for (int part = 0; part < (1 << po); ++part) {
+        const int count = po == 0 ? n - o : (n >> po) - (part == 0 ? o : 0);
+        int bk = 0; uint64_t bb = ~0ull;
+        for (int k = 0; k <= 14; ++k) {
+          const uint64_t b = rice_bits(res.data() + pos, count, k);
+          if (b < bb) { bb = b; bk = k; }
+        }
+        ks[part] = bk; total += 4 + bb; pos += count;
+      }
+      if (total + 16ull*o >= 16ull*n) {                    // prediction does not pay: VERBATIM
+        bw.write(0, 1); bw.write(1, 6); bw.write(0, 1);
+        for (int i = 0; i < n; ++i) bw.write((uint64_t)x[i], 16);
+      } else {
+        bw.write(0, 1); bw.write(8 + o, 6); bw.write(0, 1);
+        for (int i = 0; i < o; ++i) bw.write((uint64_t)x[i], 16);
+        bw.write(0, 2); bw.write(po, 4);
+        pos = 0;
+        for (int part = 0; part < (1 << po); ++part) {
+          const int count = po == 0 ? n - o : (n >> po) - (part == 0 ? o : 0);
+          const int k = ks[part];
+          bw.write(k, 4);
+          for (int i = 0; i < count; ++i) {
+            const uint32_t u = zigzag(res[pos + i]);
+            bw.unary(u >> k);
+            bw.write(u & ((1u << k) - 1), k);
+          }
+          pos += count;
+        }
+      }
+    }
+    bw.align();
+    const uint16_t c16 = crc16(buf.data() + f0, buf.size() - f0);
+    buf.push_back((uint8_t)(c16 >> 8)); buf.push_back((uint8_t)(c16 & 0xff));
+  }
+  if (out == nullptr) return (int64_t)buf.size();          // size query
+  if ((int64_t)buf.size() > capacity) return -2;
+  memcpy(out, buf.data(), buf.size());
+  return (int64_t)buf.size();
+}

@@ -297,6 +297,29 @@ def audio_info(f, name):
     return frames, rate
 
 
+def write_flac(path, x, fs):
+    """Mono 16-bit FLAC file of the float signal ``x`` (what ``torchaudio.save(<name>.flac, x, fs)`` of the
+    reference's ``scripts/test_model.py:201-209`` produces for a float tensor: samples clipped to [-1, 1),
+    scaled by 2^15 and rounded) through the native encoder ``brv_flac_encode16`` (csrc/flac.hip)."""
+    import ctypes
+
+    import numpy as np
+
+    from . import hip
+    pcm = np.clip(np.rint(np.asarray(x, dtype=np.float64).reshape(-1)*32768.0), -32768, 32767).astype(np.int16)
+    lib = hip.lib()
+    src = pcm.ctypes.data_as(ctypes.c_void_p)
+    size = lib.brv_flac_encode16(src, pcm.size, int(fs), None, 0)
+    if size < 0:
+        raise RuntimeError(f'brv_flac_encode16 failed ({size})')
+    buf = (ctypes.c_uint8*size)()
+    got = lib.brv_flac_encode16(src, pcm.size, int(fs), buf, size)
+    if got != size:
+        raise RuntimeError(f'brv_flac_encode16 failed ({got})')
+    with open(path, 'wb') as f:
+        f.write(bytes(buf))
+
+
 def audio_read(f, name):
     """float32 array (frames,) or (frames, channels) and the sample rate (``sf.read`` in
     data.py:265). FLAC goes through the native decoder ``brv_flac_decode`` (csrc/flac.hip)."""

@@ -108,6 +108,7 @@ SIGNATURES = {
                                           ctypes.c_int, _c_f32, _c_ptr]),
     'brv_flac_info': (ctypes.c_int, [_c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr]),
     'brv_flac_decode': (_c_i64, [_c_ptr, _c_i64, _c_ptr, _c_i64]),
+    'brv_flac_encode16': (_c_i64, [_c_ptr, _c_i64, ctypes.c_int32, _c_ptr, _c_i64]),
     'brv_loss_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_snr_forward_strided': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64,
                                                 _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr]),

@@ -758,6 +758,12 @@ int brv_stoi_correlate(const float* tob_clean, const float* tob_proc, const int3
 int brv_flac_info(const uint8_t* data, int64_t size, int64_t* frames, int32_t* sample_rate,
                   int32_t* channels, int32_t* bits_per_sample);
 int64_t brv_flac_decode(const uint8_t* data, int64_t size, float* out, int64_t capacity_frames);
+/* flac_encode16 (HOST pointers): mono 16-bit FLAC stream of `frames` samples -- what
+ * scripts/test_model.py --output_dir writes per signal (reference: torchaudio.save(<name>.flac),
+ * scripts/test_model.py:201-209). Fixed predictors of order 0-4, partitioned Rice residuals, frame
+ * CRCs. out == NULL: returns the size of the stream; else the bytes written, or < 0 (-2: capacity). */
+int64_t brv_flac_encode16(const int16_t* pcm, int64_t frames, int32_t sample_rate, uint8_t* out,
+                          int64_t capacity);
 
 /* ---- optimizer --------------------------------------------------------------
  * clip_grad_norm_(max_norm) + Adam.step (base.py:296-301, torch.optim.Adam with

@@ -13,7 +13,8 @@ when importable, else through the HDF5 C library (``brever_amd/h5lite.py``); onl
 ``<checkpoint>/<test set>``). With ``--ddp`` (one process per GPU) the batches of the sorted
 sampler are sharded over the ranks and gathered on rank 0 with ``gather_object``. A test set may
 be ``synthetic:<items>:<seconds>``. The HIP models have no CPU path: pass ``--cuda``.
-``--output_dir`` writes 32-bit float WAV files (the reference writes FLAC through torchaudio)."""
+``--output_dir`` writes ``NNNNN_{input,output}.flac`` as the reference does (mono 16-bit FLAC through the native
+encoder ``brv_flac_encode16`` instead of ``torchaudio.save``; ``BRV_OUTPUT_WAV=1``: 32-bit float WAV)."""
 import argparse
 import logging
 import os
@@ -33,7 +34,7 @@ from _common import ROOT, is_synthetic, make_dataset  # noqa: F401
 
 from brever_amd.batching import DistributedBatchSamplerWrapper, SortedBatchSampler
 from brever_amd.config import get_config
-from brever_amd.data import BreverDataLoader
+from brever_amd.data import BreverDataLoader, write_flac
 from brever_amd.inspect import Path
 from brever_amd.logger import set_logger
 from brever_amd.metrics import MetricRegistry
@@ -171,8 +172,12 @@ def test_model(i_test, model, cfg, test_path, scores, checkpoint_path, rank, dev
             os.makedirs(args.output_dir, exist_ok=True)
             for x, name in ((input_, 'input'), (output, 'output')):
                 for i in range(n):
-                    write_wav(os.path.join(args.output_dir, f'{i_mix + i:05d}_{name}.wav'),
-                              x[i, :int(lengths[i])].float().cpu().numpy(), cfg.dataset.fs)
+                    sig = x[i, :int(lengths[i])].float().cpu().numpy()
+                    stem = os.path.join(args.output_dir, f'{i_mix + i:05d}_{name}')
+                    if os.environ.get('BRV_OUTPUT_WAV') == '1':
+                        write_wav(stem + '.wav', sig, cfg.dataset.fs)
+                    else:                      # scripts/test_model.py:201-209 of the reference
+                        write_flac(stem + '.flac', sig, cfg.dataset.fs)
         i_mix += n
 
     if dist.is_initialized():

@@ -1236,9 +1236,17 @@ def test_entry_points_ffnn(tmp_path):
         tmp_path, 'ffnn', model_args=['--hidden_layers', '128,128'],
         trainer_args=['--epochs', '2', '--val_period', '1', '--batch_size', '16',
                       '--val_metrics', 'snr'],
-        train='synthetic:32:2.0:1.0', val='synthetic:8:2.0', test='synthetic:4:2.0')
+        train='synthetic:32:2.0:1.0', val='synthetic:8:2.0', test='synthetic:4:2.0',
+        extra_test_args=['--output_dir', str(tmp_path/'signals')])
     assert np.isfinite(losses['train_loss']).all()
     assert np.isfinite(scores).all()
+    # --output_dir: NNNNN_{input,output}.flac per test mixture, as the reference (scripts/test_model.py:201-209)
+    import io
+    from brever_amd.data import audio_read
+    names = sorted(os.listdir(tmp_path/'signals'))
+    assert names == [f'{i:05d}_{k}.flac' for i in range(4) for k in ('input', 'output')]
+    x, rate = audio_read(io.BytesIO((tmp_path/'signals'/names[1]).read_bytes()), names[1])
+    assert rate == 16000 and len(x) == 32000 and np.isfinite(np.asarray(x)).all()
 
 
 @pytest.mark.gpu

@@ -439,6 +439,34 @@ def test_flac_decoder_round_trips(kw):
     assert len(data) < pcm.size*bps//8 or kw['kind'] == 'verbatim'    # it does compress
 
 
+@pytest.mark.parametrize('n', [1, 3, 4095, 4096, 4097, 20000, 64000])
+def test_flac_encoder_round_trips_through_the_decoder(tmp_path, n):
+    """`scripts/test_model.py --output_dir` writes NNNNN_{input,output}.flac like the reference
+    (scripts/test_model.py:201-209, torchaudio.save): the native encoder `brv_flac_encode16` (fixed predictors,
+    partitioned Rice residuals, CONSTANT / VERBATIM blocks, frame CRCs) is lossless for the 16-bit samples it is
+    handed -- decoded by the package's own decoder bit for bit -- and compresses speech-like signals."""
+    from brever_amd.data import write_flac
+    rng = np.random.default_rng(n)
+    t = np.arange(n)
+    x = 0.4*np.sin(2*np.pi*180*t/16000)*(0.5 + 0.5*np.sin(2*np.pi*2*t/16000)) + 0.01*rng.standard_normal(n)
+    if n > 6000:
+        x[5000:5600] = 0.25                                   # a constant block inside
+        x[100:200] = 3.0                                       # clipped to full scale
+        x[300:400] = rng.uniform(-1, 1, 100)                   # white noise: prediction does not pay
+    path = tmp_path/'00000_output.flac'
+    write_flac(str(path), x, 16000)
+    data = path.read_bytes()
+    got, rate = _flac_decode(data)
+    want = np.clip(np.rint(x*32768.0), -32768, 32767)
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    assert rate == 16000 and got.shape == (n,)
+    assert np.array_equal(np.round(got*32768.0), want)
+    if n >= 20000:
+        assert len(data) < 0.8*2*n
+    # the test suite's independent bit reader agrees on the header
+    assert data[:4] == b'fLaC' and data[4] == 0x80 and int.from_bytes(data[8:10], 'big') == 4096
+
+
 def test_flac_unknown_length_silence_is_not_truncated():
     """ADVICE r02: a stream without a length in STREAMINFO gets a capacity guess of 8 frames per byte;
     silence (CONSTANT subframes) compresses far below that and used to be cut silently. The decoder's
