@@ -166,6 +166,35 @@ def pmc_traffic(label):
     return None, None
 
 
+SQ_FILES = ('r04_sq_counters.json',)
+
+
+def sq_counters(label):
+    """MFMA-busy and the other SQ shares of the kernel behind `label` from the committed rocprofv3 --pmc passes
+    (profiles/rNN_sq_counters.json, tools/profile_sq.sh + tools/sq_counters.py: SQ_VALU_MFMA_BUSY_CYCLES /
+    (1024 SIMDs x GRBM_GUI_ACTIVE / 8), VALU issue cycles likewise, wait / issue-stall shares of SQ_WAVE_CYCLES).
+    None when the file or the kernel is missing."""
+    key = KERNEL_OF_LABEL.get(label)
+    if isinstance(key, tuple):
+        key = key[0]
+    keys = key if isinstance(key, list) else [key]
+    for fname in SQ_FILES:
+        path = os.path.join(ROOT, 'profiles', fname)
+        if key is None or not os.path.exists(path):
+            continue
+        with open(path) as f:
+            kernels = json.load(f)['kernels']
+        for k in keys:
+            for name, v in kernels.items():
+                if k in name and 'mfma_busy_frac' in v:
+                    out = {n: v[n] for n in ('mfma_busy_frac', 'valu_busy_frac', 'lds_array_busy_frac',
+                                             'wait_any_share', 'issue_stall_share', 'waves_resident_per_simd',
+                                             'lds_bank_conflict_frac') if n in v}
+                    out['source'] = f'profiles/{fname} (rocprofv3 --pmc SQ_*, one-chain step)'
+                    return out
+    return None
+
+
 def kernel_roofline(model, batches, scaler, steps=3):
     """Event-timed steps (HIP events around every launch, on the launch stream):
     roofline of the kernel with the largest total time."""
@@ -215,6 +244,8 @@ def kernel_roofline(model, batches, scaler, steps=3):
         'frac': (gbs/PEAK_HBM_GBS) if hbm_bound else (tfs/PEAK_MFMA_TFLOPS),
         'traffic': traffic,
         'traffic_source': f'{traffic_src} (rocprofv3 --pmc, bytes per launch)' if traffic_src else None,
+        'sq_counters': sq_counters(label),
+        'mfma_busy_frac': (sq_counters(label) or {}).get('mfma_busy_frac'),
         'mode': 'one kernel chain (BRV_CTN_STREAMS=1): whole-batch launches, the kernel alone on the chip; '
                 'the timed region overlaps two half-batch chains',
         'timed_region': None if label not in prof_timed else {
@@ -246,7 +277,9 @@ def kernel_roofline(model, batches, scaler, steps=3):
             'kernel': k, 'launches_per_step': v['calls']/steps, 'avg_launch_us': per*1e6,
             'share_of_kernel_time': v['ms']/total_ms,
             'algorithmic_bytes_per_launch': kb, 'achieved_GBs': kb/per/1e9,
-            'frac_of_hbm_peak': kb/per/1e9/PEAK_HBM_GBS, 'traffic': pmc_traffic(k)[0]})
+            'frac_of_hbm_peak': kb/per/1e9/PEAK_HBM_GBS, 'traffic': pmc_traffic(k)[0],
+            'mfma_busy_frac': (sq_counters(k) or {}).get('mfma_busy_frac'),
+            'valu_busy_frac': (sq_counters(k) or {}).get('valu_busy_frac')})
     roof['kernels_over_5pct'] = kernels
     table = {k: {'calls_per_step': v['calls']/steps,
                  'ms_per_step': v['ms']/steps,

@@ -27,6 +27,16 @@ PMCARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-through-trainer --no-fp32-p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
 python3 $REPO/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $OUT/${TAG}_pmc_hbm_traffic.json
+# the same two PMC passes for the switchable variants of the first-conv backward (csrc/pw1_bwd.cuh):
+# stored z1 / dz1 (round-3 kernels) and dz1 never stored (weight gradient rebuilds it too)
+for V in stored:BRV_PW1_RC=0 rc_wgrad:BRV_PW1_RC_WGRAD=1; do
+  NAME=${V%%:*}; export ${V#*:}
+  rm -rf /tmp/pmc_fv /tmp/pmc_wv
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fv -o f -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_wv -o w -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
+  python3 $REPO/tools/pmc_traffic.py /tmp/pmc_fv /tmp/pmc_wv $OUT/${TAG}_pmc_hbm_traffic_${NAME}.json
+  VAR=${V#*:}; unset ${VAR%%=*}
+done
 # the complete default line without a profiler attached (what the driver runs)
 unset BRV_CTN_STREAMS
 cd $REPO && python3 bench.py > $OUT/${TAG}_bench_line.json 2> /dev/null
