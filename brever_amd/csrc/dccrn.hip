@@ -336,6 +336,13 @@ __device__ __forceinline__ float fast_sigm(float x) { return __builtin_amdgcn_rc
 __device__ __forceinline__ float fast_tanh(float x) {
   return 2.f*__builtin_amdgcn_rcpf(1.f + __expf(-2.f*x)) - 1.f;
 }
+// Workgroup barrier that orders LDS traffic only. `__syncthreads()` also waits for every outstanding
+// global store and load of the wave (s_waitcnt vmcnt(0)): inside a recurrence that puts one HBM round trip
+// (the step's y / activation stores, the prefetch of the next step's input) into EVERY time step. The
+// outputs of a step are not read by this kernel again, so only the LDS hand-over needs the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __global__ __launch_bounds__(512) void lstm_fwd_reg_kernel(const float* gates_in, const float* w_hh,
                                                            const float* bias, float* y, float* act,
                                                            float* cs, int T, int H, int per_group) {
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_reg_kernel(const float* gates_in
       }
     }
     gt[r] = acc;
-    __syncthreads();
+    lds_barrier();
     if (r < H) {
       const float ig = fast_sigm(gt[r]);
       const float fg = fast_sigm(gt[H + r]);
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_reg_kernel(const float* gates_in
         cs[((long long)b*T + t)*H + r] = c;
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -401,16 +408,28 @@ __global__ __launch_bounds__(512) void lstm_bwd_reg_kernel(const float* act, con
   for (int i = 0; i < kLstmRegH; ++i) w[i] = i < H ? w_hh[(long long)(q*H + i)*H + k] : 0.f;
   part[q][k] = 0.f;
   float dc = 0.f;
+  // the saved activations are requested TWO steps ahead (step t needs c of step t - 1 as well): they used
+  // to open every step with a dependent HBM round trip
+  struct Saved { float ig, fg, gg, og, c, dy; };
+  auto fetch = [&](int t) {
+    Saved v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (j < H && t >= 0) {
+      const float* a = act + ((long long)b*T + t)*4*H;
+      v.ig = a[j]; v.fg = a[H + j]; v.gg = a[2*H + j]; v.og = a[3*H + j];
+      v.c = cs[((long long)b*T + t)*H + j];
+      v.dy = dy[((long long)b*T + t)*H + j];
+    }
+    return v;
+  };
+  Saved cur = fetch(T - 1), nxt = fetch(T - 2);
   __syncthreads();
   for (int t = T - 1; t >= 0; --t) {
+    const Saved far = fetch(t - 2);
     if (j < H) {
-      const float* a = act + ((long long)b*T + t)*4*H;
-      const float ig = a[j], fg = a[H + j], gg = a[2*H + j], og = a[3*H + j];
-      const float c = cs[((long long)b*T + t)*H + j];
-      const float cprev = t > 0 ? cs[((long long)b*T + t - 1)*H + j] : 0.f;
+      const float ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og, c = cur.c, dyt = cur.dy;
+      const float cprev = t > 0 ? nxt.c : 0.f;
       const float tc = fast_tanh(c);
-      const float dht = part[0][j] + part[1][j] + part[2][j] + part[3][j]
-                        + dy[((long long)b*T + t)*H + j];
+      const float dht = part[0][j] + part[1][j] + part[2][j] + part[3][j] + dyt;
       const float dct = dc + dht*og*(1.f - tc*tc);
       const float d0 = dct*gg*ig*(1.f - ig), d1 = dct*cprev*fg*(1.f - fg);
       const float d2 = dct*ig*(1.f - gg*gg), d3 = dht*tc*og*(1.f - og);
@@ -419,7 +438,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_reg_kernel(const float* act, con
       out[j] = d0; out[H + j] = d1; out[2*H + j] = d2; out[3*H + j] = d3;
       dc = dct*fg;
     }
-    __syncthreads();
+    cur = nxt; nxt = far;
+    lds_barrier();
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < kLstmRegH; i += 4) {
@@ -429,8 +449,163 @@ __global__ __launch_bounds__(512) void lstm_bwd_reg_kernel(const float* act, con
       }
     }
     part[q][k] = acc;
-    __syncthreads();
+    lds_barrier();
   }
+}
+
+// ---- quad layout (H == 128): ONE barrier per time step ---------------------------------------------------
+// The kernels above give every gate row its own thread, so the four gates of a unit meet through LDS (two
+// barriers per step, 1.35 / 1.75 us per step of a 641-step chain: 14 % of a DCCRN training step). Here the
+// four threads of a QUAD (lanes 4u .. 4u + 3) own hidden unit u together:
+//   forward : lane q holds W_hh[g H + u][32 q .. 32 q + 31] for all four gates g (128 VGPRs), multiplies its
+//             quarter of h, and the four partial sums of each gate meet in two DPP steps -- every lane of the
+//             quad then holds the four gate pre-activations of its unit, the cell state stays in registers;
+//   backward: lane q holds W_hh[q H + i][u], i < 128 (gate q's rows, column u): its dot product with gate q's
+//             gradients is one of the four partial sums of dh_{t-1}[u], again reduced by DPP; lane q then
+//             computes gate q's gradient of the NEXT step.
+// h / the gate gradients are double-buffered in LDS: a step ends with ONE LDS-only barrier.
+// Loads whose completion the compiler does not track: hipcc's s_waitcnt insertion is conservative at the head
+// of these loops (it waited for the load it had JUST issued: vmcnt(0) / vmcnt(1) in every step, i.e. one
+// memory round trip per time step). The loads below are invisible to it; the kernel waits by hand with a
+// counted vmcnt (loads, stores and their order are fixed per step), tied to the registers it releases.
+__device__ __forceinline__ float load_untracked(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+template <bool HAS_ACT>
+__global__ __launch_bounds__(512) void lstm_fwd_quad_kernel(const float* gates_in, const float* w_hh,
+                                                            const float* bias, float* y, float* act,
+                                                            float* cs, int T, int per_group) {
+  constexpr int H = 128;
+  // h in quarters of 32 at a stride of 36 floats: the four lanes of a quad read four different 16-byte pieces
+  // per instruction, which must fall on different banks (at 32 floats quarters 0 / 2 and 1 / 3 collided)
+  constexpr int QS = 36;
+  __shared__ __attribute__((aligned(16))) float h[2][4*QS];
+  const int b = blockIdx.x, r = threadIdx.x;
+  const int u = r >> 2, q = r & 3;
+  w_hh += (long long)(b / per_group)*4*H*H;
+  if (bias) bias += (long long)(b / per_group)*4*H;
+  float w[4][32];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[g][i] = w_hh[(long long)(g*H + u)*H + 32*q + i];
+  // lane q adds gate q's input projection (+ bias) to ITS partial sum of that gate
+  const float bq = bias ? bias[q*H + u] : 0.f;
+  if (r < 4*QS) { h[0][r] = 0.f; h[1][r] = 0.f; }
+  float c = 0.f;
+  const float* gi = gates_in + (long long)b*T*4*H + q*H + u;
+  float g_next = gi[0];
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    // (a hand-counted wait on an untracked load, as in the backward kernel, measured SLOWER here: 531 against
+    // 409 us per launch -- the asm statements pin the schedule of the whole step)
+    const float gin = g_next + bq;
+    if (t + 1 < T) g_next = gi[(long long)(t + 1)*4*H];
+    const float* hb = h[t & 1] + QS*q;
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(hb + i);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        p[g] += w[g][i]*hv.x + w[g][i + 1]*hv.y + w[g][i + 2]*hv.z + w[g][i + 3]*hv.w;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) p[g] = quad_sum(p[g] + (q == g ? gin : 0.f));
+    const float ig = fast_sigm(p[0]), fg = fast_sigm(p[1]), gg = fast_tanh(p[2]), og = fast_sigm(p[3]);
+    c = fg*c + ig*gg;
+    const float hn = og*fast_tanh(c);
+    const long long row = (long long)b*T + t;
+    if (q == 0) h[(t + 1) & 1][(u >> 5)*QS + (u & 31)] = hn;
+    // exactly 1 + 2 HAS_ACT store instructions per step (the counted wait above relies on it)
+    if (q == 0) y[row*H + u] = hn;
+    if (HAS_ACT) {
+      if (q == 0) cs[row*H + u] = c;
+      act[row*4*H + q*H + u] = q == 0 ? ig : q == 1 ? fg : q == 2 ? gg : og;
+    }
+    lds_barrier();
+  }
+}
+
+__global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(const float* act, const float* cs,
+                                                            const float* w_hh, const float* dy,
+                                                            float* dgates, int T, int per_group) {
+  constexpr int H = 128;
+  // gate q's gradients at q (H + 4) floats: the four lanes of a quad read four DIFFERENT 16-byte pieces per
+  // instruction; at a stride of H floats (512 B) they fell on the same banks (4-way conflict on all 32 reads)
+  constexpr int GS = H + 4;
+  __shared__ __attribute__((aligned(16))) float dg[2][4*GS];
+  const int b = blockIdx.x, j = threadIdx.x;
+  const int u = j >> 2, q = j & 3;
+  w_hh += (long long)(b / per_group)*4*H*H;
+  float w[H];
+#pragma unroll
+  for (int i = 0; i < H; ++i) w[i] = w_hh[(long long)(q*H + i)*H + u];
+  dg[0][q*GS + u] = 0.f; dg[1][q*GS + u] = 0.f;
+  float dc = 0.f;
+  // what step t needs of the forward pass, requested TWO steps ahead (7 untracked loads; out-of-range steps
+  // read step 0 and are ignored): ig, fg, gg, og, c_t, c_{t-1}, dy_t
+  struct Saved { float ig, fg, gg, og, c, cp, dy; };
+  auto fetch = [&](int t) {
+    const int tt = t > 0 ? t : 0;
+    const float* a = act + ((long long)b*T + tt)*4*H + u;
+    Saved v;
+    v.ig = load_untracked(a); v.fg = load_untracked(a + H); v.gg = load_untracked(a + 2*H);
+    v.og = load_untracked(a + 3*H);
+    v.c = load_untracked(cs + ((long long)b*T + tt)*H + u);
+    v.cp = load_untracked(cs + ((long long)b*T + (tt > 0 ? tt - 1 : 0))*H + u);
+    v.dy = load_untracked(dy + ((long long)b*T + tt)*H + u);
+    return v;
+  };
+  // wait until at most N vector-memory operations are outstanding; releases the 7 values of `v`
+  auto wait16 = [](Saved& v) {
+    asm volatile("s_waitcnt vmcnt(16)" : "+v"(v.ig), "+v"(v.fg), "+v"(v.gg), "+v"(v.og), "+v"(v.c), "+v"(v.cp),
+                 "+v"(v.dy) :: "memory");
+  };
+  // Three register sets take the roles (this step, next step, being fetched) in turn -- the loop is unrolled
+  // three times so that every load has a FIXED destination. Per step, in order: 7 loads (step t - 2), then ONE
+  // store; the set used by step t was requested two steps ago, so 1 + 7 + 1 + 7 = 16 younger operations may
+  // stay in flight.
+  auto step = [&](Saved& cur, int t) {
+    wait16(cur);
+    // dh_t[u] from the gate gradients of step t + 1 (zeros for the last step): this lane's gate rows
+    const float* gb = dg[(t + 1) & 1] + q*GS;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < H; i += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(gb + i);
+      a0 = __builtin_fmaf(w[i], v.x, a0); a1 = __builtin_fmaf(w[i + 1], v.y, a1);
+      a2 = __builtin_fmaf(w[i + 2], v.z, a2); a3 = __builtin_fmaf(w[i + 3], v.w, a3);
+    }
+    const float dht = quad_sum((a0 + a1) + (a2 + a3)) + cur.dy;
+    const float ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og;
+    const float cprev = t > 0 ? cur.cp : 0.f;
+    const float tc = fast_tanh(cur.c);
+    const float dct = dc + dht*og*(1.f - tc*tc);
+    const float dq = q == 0 ? dct*gg*ig*(1.f - ig) : q == 1 ? dct*cprev*fg*(1.f - fg)
+                   : q == 2 ? dct*ig*(1.f - gg*gg) : dht*tc*og*(1.f - og);
+    dg[t & 1][q*GS + u] = dq;
+    dgates[((long long)b*T + t)*4*H + q*H + u] = dq;
+    dc = dct*fg;
+    lds_barrier();
+  };
+  Saved sa = fetch(T - 1), sb = fetch(T - 2), sc;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the counted wait needs full queues behind it)
+  __syncthreads();
+  int t = T - 1;
+  while (t >= 0) {
+    sc = fetch(t - 2); step(sa, t); if (--t < 0) break;
+    sa = fetch(t - 2); step(sb, t); if (--t < 0) break;
+    sb = fetch(t - 2); step(sc, t); --t;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // out = a - b  /  a + b  (the real / imaginary recombination of ComplexWrapper)
@@ -828,7 +1003,14 @@ int brv_lstm_recurrent_forward(const float* gates_in, const float* w_hh, const f
                                int64_t groups, brv_stream_t stream) {
   if (B < 1 || T < 1 || H < 1 || groups < 1 || B % groups) return -1;
   const int per_group = (int)(B/groups);
-  if (H <= kLstmRegH && H % 16 == 0)
+  if (H == 128) {
+    if (act && cs)
+      hipLaunchKernelGGL(lstm_fwd_quad_kernel<true>, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream,
+                         gates_in, w_hh, bias, y, act, cs, (int)T, per_group);
+    else
+      hipLaunchKernelGGL(lstm_fwd_quad_kernel<false>, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream,
+                         gates_in, w_hh, bias, y, act, cs, (int)T, per_group);
+  } else if (H <= kLstmRegH && H % 16 == 0)
     hipLaunchKernelGGL(lstm_fwd_reg_kernel, dim3((unsigned)B), dim3((unsigned)(4*H)), 0,
                        (hipStream_t)stream, gates_in, w_hh, bias, y, act, cs, (int)T, (int)H,
                        per_group);
@@ -907,7 +1089,10 @@ int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* 
                                 int64_t groups, brv_stream_t stream) {
   if (B < 1 || T < 1 || H < 1 || groups < 1 || B % groups) return -1;
   const int per_group = (int)(B/groups);
-  if (H <= kLstmRegH && H % 16 == 0)
+  if (H == 128)
+    hipLaunchKernelGGL(lstm_bwd_quad_kernel, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, act, cs,
+                       w_hh, dy, dgates, (int)T, per_group);
+  else if (H <= kLstmRegH && H % 16 == 0)
     hipLaunchKernelGGL(lstm_bwd_reg_kernel, dim3((unsigned)B), dim3((unsigned)(4*H)), 0,
                        (hipStream_t)stream, act, cs, w_hh, dy, dgates, (int)T, (int)H, per_group);
   else
