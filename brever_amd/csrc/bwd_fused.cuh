@@ -475,18 +475,22 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
         dtap[k][j] += gk*hn[j];
       }
     }
-    f32x2 o[4], a1s = {0.f, 0.f}, a2s = {0.f, 0.f};
+    f32x2 o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x2 dl = dh[j];
-      const f32x2 ev = gm[j]*dl;
-      o[j] = ev;
-      a1s += ev; a2s += ev*xh[j];
+      o[j] = gm[j]*dl;
       dgam[j] += dl*xh[j]; dbet[j] += dl;
     }
-    l1 += a1s.x + a1s.y; l2 += a2s.x + a2s.y;
     buf_store16(re1, (unsigned int)t*row + coff, pack8v(o));
    }
+  }
+  // the tile's sums of e1 and e1 xh_1 (layer-norm backward means of the first norm) from the per-channel
+  // partials: sum_t gamma_1 dl = gamma_1 sum_t dl -- a tile lies inside one item, so no per-element adds
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    l1 += gm[j].x*dbet[j].x + gm[j].y*dbet[j].y;
+    l2 += gm[j].x*dgam[j].x + gm[j].y*dgam[j].y;
   }
 
   if (BF_ABL & 64) {

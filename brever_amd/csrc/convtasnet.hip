@@ -96,7 +96,7 @@ struct Layout {
   int N, K, Bn, H, Sc, P, nb, S, hop, causal;
   int Np, Kfp, Bnp, Hp, Scp;
   long long enc_w, dec_w, ln_g, ln_b, bott_w, bott_b, tcn_prelu, out_w, out_b, n_params;
-  long long p_enc, p_dec_f, p_dec_b, p_bott_f, p_bott_b, p_out_f, p_out_b, n_prepared;
+  long long p_enc, p_dec_f, p_dec_b, p_bott_f, p_bott_b, p_out_f, p_out_b, p_stamp, n_prepared;
   std::vector<BlockOff> blk;
   std::vector<long long> tensor_offsets;
 
@@ -165,6 +165,7 @@ struct Layout {
     }
     p_out_f = ptake((long long)S*Np*Scp);
     p_out_b = ptake((long long)Scp*S*Np);
+    p_stamp = ptake(128);                              // mode stamp (one int): see mode_stamp()
     n_prepared = q;
     return 0;
   }
@@ -188,6 +189,7 @@ struct Workspace {
   long long vg_stride, vg_bytes;      // replicated vector-gradient block (floats / bytes)
   long long x_stride, z_stride;       // bytes between consecutive blocks' buffers
   long long u, u_stride;              // fused forward: unfinished [res | skip] products per block
+  long long stamp;                    // mode of the forward call that filled the workspace (mode_stamp())
   long long stats_bytes;
   void init(const Layout& l, long long B, long long T) {
     long long o = 0;
@@ -226,6 +228,7 @@ struct Workspace {
     wgpart = take((long long)kWgSplit*l.nb*W2_G*l.H*4);
     u_stride = align_up(BT*(l.Bnp + l.Scp)*2, 256);
     u = l.fusable() ? take(u_stride*l.nb) : 0;
+    stamp = take(256);
     h1 = h2 = wn = ctab = cfs = cbt = ident = fake_stats = scratch_stats = 0; ctab_stride = 0;
     if (l.causal) {
       h1 = take(z_stride*l.nb);
@@ -276,6 +279,21 @@ long long* debug_buffer() {
   return buf;
 }
 #endif
+
+// ---- mode stamps -----------------------------------------------------------------------
+// prepare / forward / backward decide between the fused and the three-launch kernels from the options of
+// THEIR OWN call; operands prepared for one mode (gamma-folded or plain [res | skip] weights) and a workspace
+// filled in one mode (u tensors or a finished skip sum) are garbage to the other. prepare stamps `prepared`,
+// forward checks that stamp and stamps the workspace, backward checks the workspace: a mismatch (a C-ABI
+// caller passing BRV_OPT_NO_FWD_FUSE to one call and not to the next) poisons the results with NaN instead
+// of returning plausible numbers. One-thread kernels on the call's stream: no host synchronisation.
+inline int mode_stamp(bool fused_fwd) { return fused_fwd ? 0x46555345 : 0x504c4149; }    // 'FUSE' / 'PLAI'
+__global__ void stamp_write_kernel(int* dst, int value) { *dst = value; }
+__global__ void stamp_check_f64_kernel(const int* stamp, int expect, double* poison, long long n) {
+  if (*stamp == expect) return;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) poison[i] = nan;
+}
 
 // Workgroups of a persistent launch: one per CU -- or opts.cu_eighths/8 of that while two kernel
 // chains share the chip: with 8 items per chain a full-width launch has exactly one tile per workgroup
@@ -1154,6 +1172,9 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
                        (bf16_t*)prepared, lp);
     HIP_OK(hipGetLastError());
   }
+  hipLaunchKernelGGL(stamp_write_kernel, dim3(1), dim3(1), 0, st,
+                     reinterpret_cast<int*>((bf16_t*)prepared + l.p_stamp), mode_stamp(fused));
+  HIP_OK(hipGetLastError());
   return 0;
 }
 
@@ -1184,6 +1205,13 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
 
   HIP_OK(hipMemsetAsync(stats, 0, ws.stats_bytes, st));
   HIP_OK(hipMemsetAsync(out, 0, (size_t)B*l.S*L*sizeof(float), st));
+  // operands prepared for the other mode -> NaN statistics (and with them a NaN output); then this call's mode
+  hipLaunchKernelGGL(stamp_check_f64_kernel, dim3(1), dim3(256), 0, st,
+                     reinterpret_cast<const int*>(prep + l.p_stamp), mode_stamp(l.fused_fwd()), stats,
+                     (long long)(ws.stats_bytes/8));
+  hipLaunchKernelGGL(stamp_write_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<int*>(base + ws.stamp),
+                     mode_stamp(l.fused_fwd()));
+  HIP_OK(hipGetLastError());
 
   GemmRowsParams g;
   // encoder: framed filterbank analysis, statistics for the first gLN
@@ -1573,6 +1601,11 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   if (head) {
   HIP_OK(hipMemsetAsync(sums, 0, ws.stats_bytes, st));
   HIP_OK(hipMemsetAsync(vg, 0, ws.vg_bytes, st));
+  // a workspace filled by a forward call in the other mode -> NaN sums (and with them NaN gradients)
+  hipLaunchKernelGGL(stamp_check_f64_kernel, dim3(1), dim3(256), 0, st,
+                     reinterpret_cast<const int*>(base + ws.stamp), mode_stamp(l.fused_fwd()), sums,
+                     (long long)(ws.stats_bytes/8));
+  HIP_OK(hipGetLastError());
   // decoder data gradient (framing of d_out) fused with the mask backward
   memset(&g, 0, sizeof(g));
   g.a = frames_of(d_out, L, l.hop, l.K);

@@ -867,3 +867,31 @@ def test_sixty_four_ragged_utterances_equal_four_steps_of_sixteen(monkeypatch):
     print(f'64 ragged utterances in one step vs 4 x 16: loss {loss64:.5f}, gradient rel {e:.3e}')
     assert e <= 2e-3, e
     _per_tensor(net, g64, g_ref, 2e-2)
+
+
+def test_mode_mismatch_between_calls_is_loud(monkeypatch):
+    """prepare / forward / backward pick the fused or the three-launch kernels from the options of
+    their OWN call. A caller that changes BRV_OPT_NO_FWD_FUSE between forward and backward (workspace filled in
+    one mode, read in the other) used to get plausible wrong gradients; the calls now stamp `prepared` and the
+    workspace with their mode and poison the results with NaN on a mismatch."""
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    gen = torch.Generator().manual_seed(3)
+    batch, lengths = _ragged_batch(gen, 2, 4000)
+    torch.manual_seed(1)
+    net = ConvTasNet(layers=2, repeats=1).to(_cuda())
+    net._amp = True
+    monkeypatch.delenv('BRV_FWD_FUSE', raising=False)
+    out = net(batch[:, 0].cuda())
+    assert torch.isfinite(out).all()
+    loss = snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean()
+    monkeypatch.setenv('BRV_FWD_FUSE', '0')            # the backward call now asks for the other mode
+    loss.backward()
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.isnan(got).any(), 'a mode mismatch between forward and backward must not pass silently'
+    # consistent calls in the other mode are fine (the host prepares again: the cache is keyed on the flags)
+    net.zero_grad(set_to_none=True)
+    out = net(batch[:, 0].cuda())
+    snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean().backward()
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.isfinite(got).all()
