@@ -48,9 +48,18 @@ struct BwdFusedParams {
   const float* gamma2;
   float* dgamma2; float* dbeta2;    // replicated like the other per-channel gradients
   int K, R;                // centre teeth per tile, rows per tooth (host: bf_tile_shape)
+#ifdef BF_STAMP
+  long long* dbg;          // diagnostic build: 8 cycle stamps per workgroup (tools/stamp_bwd.py)
+#endif
 };
 
-constexpr int BF_ROWS = 256;               // window rows (teeth x rows per tooth), 8 MFMA groups of 32
+#ifndef BF_ROWS_N
+#define BF_ROWS_N 256
+#endif
+#ifndef BF_WPS
+#define BF_WPS 3     // resident workgroups per CU the register budget is set for (diagnostic builds: 4)
+#endif
+constexpr int BF_ROWS = BF_ROWS_N;         // window rows (teeth x rows per tooth), 8 MFMA groups of 32
 constexpr int BF_LDW = HL_CG + 8;          // halves per window row: 144 B
 constexpr int BF_LDS = BF_ROWS*BF_LDW*2 + 32*HL_CG*4;   // window + the reduction scratch
 
@@ -78,8 +87,14 @@ inline void bf_tile_shape(int T, int dil, int P, int& K, int& R) {
 // its load pipeline is a counted vmcnt -- as a run-time loop hipcc drained ALL loads, the just-issued
 // prefetch included, in front of the first MFMA of every chunk)
 // (The channel count is a multiple of 64 on this path -- hidden_channels = 512 -- so no channel masks.)
+#ifdef BF_STAMP
+#define BF_MARK(i) do { long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                        if (threadIdx.x == 0 && fp.dbg) fp.dbg[(long long)blockIdx.x*8 + (i)] = t_; } while (0)
+#else
+#define BF_MARK(i) do { } while (0)
+#endif
 template <int P, int KG>
-__global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFusedParams fp) {
+__global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const BwdFusedParams fp) {
   const DwParams& p = fp.d;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   bf16_t* win = reinterpret_cast<bf16_t*>(dyn_lds);
@@ -114,6 +129,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
   const int b = id / n_tt;
   const int tile = id % n_tt;
   const int r0 = (tile % n_rt)*R, q0 = (tile / n_rt)*K;
+  BF_MARK(0);
   const int cl = (tid & 7)*8;                          // channel offset inside the group
   const int c0 = cg*HL_CG + cl;
   const int rslot = tid >> 3;                          // 32 row slots per pass
@@ -257,9 +273,11 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
         }
     }
   }
+  BF_MARK(1);
   ptab[tid] = pv0;
   if (tid + 256 < (3 + P)*HL_CG) ptab[tid + 256] = pv1;
   __syncthreads();
+  BF_MARK(2);
 
   // ---- phase 1: dz2 of the window, in place in LDS --------------------------------------------------
   const double mean2 = p.stats2[stat_sum(b)]*p.inv_n;
@@ -333,6 +351,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
       }
     }
   }
+  BF_MARK(3);
   // ---- per-channel reductions. A thread holds 8 channels of its row slot; the 8 row slots of a wave are
   // folded with lane shuffles (lanes 8 apart share a channel octet), so LDS only carries ONE row per wave
   // and vector: all vectors of a phase go through it together behind a single barrier pair. (One vector
@@ -403,6 +422,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
     }
   }
   __syncthreads();                                       // dz2 window complete; `red` free again
+  BF_MARK(4);
 
   // ---- phase 2: transposed stencil out of LDS -------------------------------------------------
   const NormStat ns = norm_stat(p.stats1, b, p.inv_n, p.eps);
@@ -485,6 +505,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
     buf_store16(re1, (unsigned int)t*row + coff, pack8v(o));
    }
   }
+  BF_MARK(5);
   // the tile's sums of e1 and e1 xh_1 (layer-norm backward means of the first norm) from the per-channel
   // partials: sum_t gamma_1 dl = gamma_1 sum_t dl -- a tile lies inside one item, so no per-element adds
 #pragma unroll
@@ -524,6 +545,7 @@ __global__ __launch_bounds__(256, 3) void dwconv_bwd_fused_kernel(const BwdFused
       atomic_add_f64(p.sums1 + stat_sq(b), ((double)sc[4] + (double)sc[5]) + ((double)sc[6] + (double)sc[7]));
     }
   }
+  BF_MARK(6);
 }
 
 // sum_t <g_t, v1> and sum_t <g_t, u_t> over `ncols` columns of one item (the block without a producer

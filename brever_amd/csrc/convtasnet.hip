@@ -471,6 +471,9 @@ template <int P> struct DwBwdFused {
   static int run(const BwdFusedParams& p0, hipStream_t st) {
     BwdFusedParams p = p0;
     const DwParams& d = p.d;
+#ifdef BF_STAMP
+    p.dbg = debug_buffer();
+#endif
     bf_tile_shape(d.T, d.dil, P, p.K, p.R);
     const int tiles = ceil_div(d.dil, p.R)*ceil_div((d.T - 1)/d.dil + 1, p.K);
     // algorithmic bytes: g (256-wide) + z2 + z1 read, e1 written

@@ -26,7 +26,16 @@ def build(tag, flags):
 
 
 if __name__ == '__main__':
-    for arg in sys.argv[1:]:
+    args = sys.argv[1:]
+    if args and args[0] == '--ab':          # launch times per label through tools/ab_step.py instead of bench.py
+        labels = args[1]
+        ab = []
+        for arg in args[2:]:
+            tag, _, flags = arg.partition('=')
+            ab.append(f'{tag}=BRV_LIB_PATH={build(tag, flags.split() if flags else [])}')
+        subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'ab_step.py')] + ab + ['--labels', labels])
+        sys.exit(0)
+    for arg in args:
         tag, _, flags = arg.partition('=')
         lib = build(tag, flags.split() if flags else [])
         env = dict(os.environ, BRV_LIB_PATH=lib)
