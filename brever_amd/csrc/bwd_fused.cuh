@@ -39,6 +39,9 @@ namespace brv {
 #ifndef BF_AHEAD2
 #define BF_AHEAD2 4        // the same for the z1 loads of phase 2
 #endif
+#ifndef BF_PIPE
+#define BF_PIPE 1          // z2 / z1 rows requested across the phase boundaries in two batches of four (0: per phase)
+#endif
 
 struct BwdFusedParams {
   DwParams d;              // as dwconv_bwd_halo_kernel; d.dz2 unused, d.sums2 = {sum <g, v1>, sum <g, u>}
@@ -162,6 +165,22 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
     if (tid + 256 < (3 + P)*HL_CG) { const float* s1 = ptab_src(tid + 256); if (s1) pv1 = *s1; }
   }
 
+  // z2 rows of phase 1 (BF_PIPE: requested across the phase boundaries, two batches of four rows per thread;
+  // the window has at most 256 rows = 8 per thread)
+  const __amdgpu_buffer_rsrc_t rz2 = make_rsrc(p.z2in + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+  const unsigned int row = (unsigned int)(p.Cp*2), coff = (unsigned int)(c0*2);
+  uint4 qzA[4];
+  // z1 rows of phase 2 (centre rows of the tile), first batch requested inside phase 1
+  const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(p.z1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
+  uint4 qz1A[4];
+  // output row i -> frame: tooth q0 + i / R, residue r0 + i % R
+  auto out_frame = [&](int i, bool& ok) {
+    int ri;
+    const int qi = divR(i, ri);
+    const int ro = r0 + ri;
+    ok = i < KR && ro < d;
+    return (q0 + qi)*d + ro;
+  };
   // ---- phase 0: e = W^T g of the window -> LDS ---------------------------------------------------
   // Every wave works alone on its own 64 window rows (no workgroup barrier before the end of the
   // phase): the reduction runs in chunks of 64 g columns; a chunk of the wave's rows is fetched by
@@ -257,6 +276,15 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
         if (more) { a0_3 = al(wsrc0, kc + 1, 3); a1_3 = al(wsrc1, kc + 1, 3); }
       }
     }
+    // the first four z2 rows of this thread (phase 1) are requested now: they arrive behind the barrier
+    if (BF_PIPE) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bool ok;
+        const int tf = frame_of(rslot + 32*u, ok);
+        qzA[u] = buf_load16(rz2, (ok && tf < T) ? (unsigned int)tf*row + coff : kOob);
+      }
+    }
     // D[channel][frame]: lane = frame n32, registers = channels 8 (i >> 2) + 4 h + (i & 3)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -291,8 +319,6 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
   const float a2 = *p.slope2;
   const float ya = 0.5f*(1.f + a2)*rs2, yb = 0.5f*(1.f - a2)*rs2, yc = -mu2*rs2;
   const float R2 = rs2, K0 = -m1*rs2, M2R = -m2*rs2;
-  const __amdgpu_buffer_rsrc_t rz2 = make_rsrc(p.z2in + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
-  const unsigned int row = (unsigned int)(p.Cp*2), coff = (unsigned int)(c0*2);
   float da2 = 0.f;
   f32x2 dbia[4], dgam2[4], dbet2[4], g2[4];
   {
@@ -302,26 +328,14 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
       dbia[j] = f32x2{0.f, 0.f}; dgam2[j] = f32x2{0.f, 0.f}; dbet2[j] = f32x2{0.f, 0.f};
     }
   }
-  // BF_AHEAD1 rows of a thread requested before the first is consumed
-  constexpr int NU = BF_AHEAD1;
-  for (int rw = rslot; rw < W; rw += 32*NU) {
-    uint4 qz[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      bool ok;
-      const int tf = frame_of(rw + 32*u, ok);
-      qz[u] = buf_load16(rz2, (ok && tf < T) ? (unsigned int)tf*row + coff : kOob);
-    }
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int r = rw + 32*u;
-      if (r >= W) break;
+  // one window row of this thread (8 channels): dz2 in place + the per-channel sums
+  auto phase1_row = [&](int r, const uint4& qzv) {
       bool ok;
       const int tf = frame_of(r, ok);
       const bool in = ok && tf < T;
       float e[8], z[8], g[8];
       unpack8(*reinterpret_cast<const uint4*>(win + r*BF_LDW + cl), e);
-      unpack8(qz[u], z);
+      unpack8(qzv, z);
       const float on = in ? 1.f : 0.f;
       const float rr = on*R2, k0 = on*K0, mm = on*M2R;
       // each element is "owned" by the tile whose teeth [q0, q0 + K) contain it
@@ -349,9 +363,47 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
           dgam2[j] += ee[j]*xg[j]; dbet2[j] += ee[j];
         }
       }
+  };
+  if (BF_PIPE) {
+    // rows rslot + 32 u: the first four were requested before the barrier, the other four go out now and
+    // arrive while the first four are worked on
+    uint4 qzB[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bool ok;
+      const int tf = frame_of(rslot + 128 + 32*u, ok);
+      qzB[u] = buf_load16(rz2, (ok && tf < T) ? (unsigned int)tf*row + coff : kOob);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int r = rslot + 32*u; if (r < W) phase1_row(r, qzA[u]); }
+    // the first z1 rows of phase 2 are requested before the second half and the folds
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bool ok;
+      const int t = out_frame(rslot + 32*u, ok);
+      qz1A[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int r = rslot + 128 + 32*u; if (r < W) phase1_row(r, qzB[u]); }
+  } else {
+  // BF_AHEAD1 rows of a thread requested before the first is consumed
+  constexpr int NU = BF_AHEAD1;
+  for (int rw = rslot; rw < W; rw += 32*NU) {
+    uint4 qz[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      bool ok;
+      const int tf = frame_of(rw + 32*u, ok);
+      qz[u] = buf_load16(rz2, (ok && tf < T) ? (unsigned int)tf*row + coff : kOob);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int r = rw + 32*u;
+      if (r >= W) break;
+      phase1_row(r, qz[u]);
     }
   }
-  BF_MARK(3);
+  }
   // ---- per-channel reductions. A thread holds 8 channels of its row slot; the 8 row slots of a wave are
   // folded with lane shuffles (lanes 8 apart share a channel octet), so LDS only carries ONE row per wave
   // and vector: all vectors of a phase go through it together behind a single barrier pair. (One vector
@@ -444,34 +496,13 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
 #pragma unroll
     for (int k = 0; k < P; ++k) dtap[k][j] = f32x2{0.f, 0.f};
   }
-  const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(p.z1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
   const __amdgpu_buffer_rsrc_t re1 = make_rsrc(p.e1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
   float l1 = 0.f, l2 = 0.f;
-  // output row i -> frame: tooth q0 + i / R, residue r0 + i % R
-  auto out_frame = [&](int i, bool& ok) {
-    int ri;
-    const int qi = divR(i, ri);
-    const int ro = r0 + ri;
-    ok = i < KR && ro < d;
-    return (q0 + qi)*d + ro;
-  };
-  constexpr int NU2 = BF_AHEAD2;
-  for (int i0 = rslot; i0 < KR; i0 += 32*NU2) {
-   uint4 qz4[NU2];
-#pragma unroll
-   for (int u = 0; u < NU2; ++u) {
-     bool ok;
-     const int t = out_frame(i0 + 32*u, ok);
-     qz4[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);   // outside: zeros
-   }
-#pragma unroll
-   for (int u = 0; u < NU2; ++u) {
-    const int i = i0 + 32*u;
-    if (i >= KR) break;
+  // one centre row of this thread (8 channels): transposed stencil out of the window + the per-channel sums
+  auto phase2_row = [&](int i, const uint4& qz) {
     bool ok;
     const int t = out_frame(i, ok);
-    const uint4 qz = qz4[u];
-    if (!(ok && t < T)) continue;                        // frames past the end: nothing to store or add
+    if (!(ok && t < T)) return;                          // frames past the end: nothing to store or add
     float zc[8];
     unpack8(qz, zc);
     f32x2 xh[4], hn[4], dh[4];
@@ -503,7 +534,36 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
       dgam[j] += dl*xh[j]; dbet[j] += dl;
     }
     buf_store16(re1, (unsigned int)t*row + coff, pack8v(o));
+  };
+  if (BF_PIPE) {
+    uint4 qz1B[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bool ok;
+      const int t = out_frame(rslot + 128 + 32*u, ok);
+      qz1B[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = rslot + 32*u; if (i < KR) phase2_row(i, qz1A[u]); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = rslot + 128 + 32*u; if (i < KR) phase2_row(i, qz1B[u]); }
+  } else {
+  constexpr int NU2 = BF_AHEAD2;
+  for (int i0 = rslot; i0 < KR; i0 += 32*NU2) {
+   uint4 qz4[NU2];
+#pragma unroll
+   for (int u = 0; u < NU2; ++u) {
+     bool ok;
+     const int t = out_frame(i0 + 32*u, ok);
+     qz4[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);   // outside: zeros
    }
+#pragma unroll
+   for (int u = 0; u < NU2; ++u) {
+    const int i = i0 + 32*u;
+    if (i >= KR) break;
+    phase2_row(i, qz4[u]);
+   }
+  }
   }
   BF_MARK(5);
   // the tile's sums of e1 and e1 xh_1 (layer-norm backward means of the first norm) from the per-channel
