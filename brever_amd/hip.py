@@ -247,6 +247,9 @@ SIGNATURES = {
                                 + [_c_f32, _c_ptr]),
     'brv_gemm_bf16_conv': (ctypes.c_int, [_c_ptr]*3 + [_c_i64]*9 + [ctypes.c_int, ctypes.c_int]
                            + [_c_i64]*3 + [_c_ptr, ctypes.c_int, ctypes.c_int] + [_c_i64]*11 + [_c_ptr]),
+    'brv_cconv_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
+    'brv_cconv_pack': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*4 + [_c_ptr]),
+    'brv_cconv_rows': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*5 + [ctypes.c_int32, _c_ptr]),
     'brv_conv_nhwc_packed_size': (_c_i64, [_c_i64, _c_i64, _c_i64]),
     'brv_conv_nhwc_pack': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_conv_nhwc_forward': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr,

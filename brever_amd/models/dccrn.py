@@ -165,6 +165,25 @@ def _gemm_conv(a, img, d, batch, M, N, K, lda, ldd, a_bs, img_bs, d_bs, mode, im
 _IMPLICIT = os.environ.get('BRV_DCCRN_IM2COL', '0') != '1'     # use_amp: implicit GEMM convolutions
 
 
+_ROWS = os.environ.get('BRV_DCCRN_ROWS', '1') != '0'      # use_amp: one-launch row convolutions (csrc/cconv.hip)
+_ROWS_GEOM = ((5, 2), (2, 1), (2, 0), (1, 0))
+
+
+def _cconv_rows(x, wc, bias, M, m_stride, c_stride, transposed):
+    """``brv_cconv_rows``: the (5, 2) / (2, 1) / (2, 0) convolution (``transposed`` = 0) or transposed
+    convolution (1) of ``x`` (B, C, H, W) with W[m][c][i][j] = wc.flat[m*m_stride + c*c_stride + 2i + j]."""
+    lib = hip.lib()
+    B, C, H, W = x.shape
+    wp = torch.empty(lib.brv_cconv_packed_bytes(M, C), dtype=torch.uint8, device=x.device)
+    hip.check(lib.brv_cconv_pack(hip.ptr(wc), hip.ptr(wp), M, C, m_stride, c_stride, hip.stream()),
+              'brv_cconv_pack')
+    out = torch.empty((B, M, 2*H, W + 1) if transposed else (B, M, H//2, W - 1), dtype=torch.float32,
+                      device=x.device)
+    hip.check(lib.brv_cconv_rows(hip.ptr(x), hip.ptr(wp), hip.ptr(bias), hip.ptr(out), B, C, M, H, W,
+                                 int(transposed), hip.stream()), 'brv_cconv_rows')
+    return out
+
+
 def _im2col(x, geom, grid, lowp=False):
     """``lowp``: the column matrix in bf16 (half the bytes of the largest tensor of the layer)."""
     (kh, kw), (sh, sw), (ph, pw) = geom
@@ -225,7 +244,17 @@ class _ComplexConvFunction(torch.autograd.Function):
                                               hip.stream()), 'brv_complex_weight_pack')
         bias = torch.cat([_combine(br, bi, -1.0), _combine(br, bi, 1.0)])
         khw = kh*kw
-        if not transpose and lowp and _IMPLICIT:
+        rows = ctx.rows = bool(lowp and _ROWS and tuple(map(tuple, geom4)) == _ROWS_GEOM
+                               and (transpose or (H % 2 == 0 and W >= 2)))
+        if rows and not transpose:
+            Cout = R
+            Ho, Wo = H//2, W - 1
+            y = _cconv_rows(x, wc, bias, 2*Cout, 2*Cw, khw, 0)
+        elif rows:
+            Cout = wr.shape[1]
+            Ho, Wo = 2*H, W + 1
+            y = _cconv_rows(x, wc, bias, 2*Cout, khw, 2*Cw, 1)
+        elif not transpose and lowp and _IMPLICIT:
             # the column matrix of x is read in place (brv_gemm_bf16_conv): no im2col pass, no 10x copy
             Cout = R
             Ho, Wo = (H + 2*ph - kh)//sh + 1, (W + 2*pw - kw)//sw + 1
@@ -262,20 +291,26 @@ class _ComplexConvFunction(torch.autograd.Function):
         dwc = torch.empty_like(wc)
         khw = geom[0][0]*geom[0][1]
         if transpose and lowp and _IMPLICIT:
-            dx = torch.empty_like(x)
-            _gemm_conv(wc, dy, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, 0, 2*Cout*Ho*Wo, 2*Cin*H*W, 1,
-                       (2*Cout, Ho, Wo), geom, (H, W))
+            if ctx.rows:
+                dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0)
+            else:
+                dx = torch.empty_like(x)
+                _gemm_conv(wc, dy, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, 0, 2*Cout*Ho*Wo, 2*Cin*H*W, 1,
+                           (2*Cout, Ho, Wo), geom, (H, W))
             _gemm_conv(x, dy, dwc, 1, 2*Cin, 2*Cw, H*W, H*W, 2*Cw, 0, 0, 0, 1, (2*Cout, Ho, Wo), geom,
                        (H, W), trans_b=1, kbatch=B, a_kbs=2*Cin*H*W, img_kbs=2*Cout*Ho*Wo)
         elif not transpose and lowp and _IMPLICIT:
             _gemm_conv(dy, x, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, 1, (2*Cin, H, W), geom,
                        (Ho, Wo), trans_b=1, kbatch=B, a_kbs=2*Cout*Ho*Wo, img_kbs=2*Cin*H*W)
-            # data gradient: product + scatter (the gather form doubles the matrix work at stride 2
-            # and shrinks M to 2*Cin: measured 3.8x slower than this pair)
-            col = torch.empty(B, 2*Cw, Ho*Wo, dtype=torch.bfloat16, device=x.device)
-            _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,
-                  2*Cw*Ho*Wo, trans_a=1, lowp=lowp)
-            dx = _col2im(col, None, 2*Cin, (H, W), geom, (Ho, Wo))
+            if ctx.rows:
+                dx = _cconv_rows(dy, wc, None, 2*Cin, khw, 2*Cw, 1)
+            else:
+                # data gradient: product + scatter (the generic gather form doubles the matrix work at
+                # stride 2 and shrinks M to 2*Cin: measured 3.8x slower than this pair)
+                col = torch.empty(B, 2*Cw, Ho*Wo, dtype=torch.bfloat16, device=x.device)
+                _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,
+                      2*Cw*Ho*Wo, trans_a=1, lowp=lowp)
+                dx = _col2im(col, None, 2*Cin, (H, W), geom, (Ho, Wo))
         elif transpose:
             dcol = _im2col(dy, geom, (H, W), lowp)                 # (B, 2*Cw, H*W)
             dx = torch.empty_like(x)

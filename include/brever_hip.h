@@ -319,6 +319,23 @@ int brv_gemm_bf16_conv(const float* a, const float* image, float* d, int64_t bat
                        const float* row_bias, int accumulate, int mode, int64_t C, int64_t H,
                        int64_t W, int64_t kh, int64_t kw, int64_t sh, int64_t sw, int64_t ph,
                        int64_t pw, int64_t Ho, int64_t Wo, brv_stream_t stream);
+/* The DCCRN convolutions themselves (ComplexWrapper(nn.Conv2d | nn.ConvTranspose2d) with the
+ * model's fixed geometry kernel (5, 2), stride (2, 1), padding (2, 0), output_padding (1, 0):
+ * reference brever/models/dccrn/dccrn.py:225-235, 238-292, config/models/dccrn.yaml) as one
+ * launch on fp32 (B, C, Hin, Win) images: no column matrix, no scatter pass (csrc/cconv.hip).
+ *   transposed = 0: out[m][r][w] = bias[m] + sum_{c,i,j} W[m][c][i][j] in[c][2r - 2 + i][w + j],
+ *                   out (B, M, Hin/2, Win - 1) (Hin even): Conv2d forward, ConvTranspose2d data gradient;
+ *   transposed = 1: out[m][r][w] = bias[m] + sum_{c,j, i = r mod 2} W[m][c][i][j] in[c][(r + 2 - i)/2][w - j],
+ *                   out (B, M, 2 Hin, Win + 1): ConvTranspose2d forward, Conv2d data gradient.
+ * Rows / frames outside the image read as zero. Operands are rounded to bf16, sums are fp32 (the
+ * use_amp path). brv_cconv_pack turns a fp32 weight matrix with W[m][c][i][j] = wc[m*m_stride +
+ * c*c_stride + 2 i + j] into the MFMA operand fragments brv_cconv_rows reads (buffer of
+ * brv_cconv_packed_bytes(M, C) bytes); bias may be NULL. */
+int64_t brv_cconv_packed_bytes(int64_t M, int64_t C);
+int brv_cconv_pack(const float* wc, void* wp, int64_t M, int64_t C, int64_t m_stride, int64_t c_stride,
+                   brv_stream_t stream);
+int brv_cconv_rows(const float* in, const void* wp, const float* bias, float* out, int64_t B, int64_t C,
+                   int64_t M, int64_t Hin, int64_t Win, int32_t transposed, brv_stream_t stream);
 /* brv_gemm_bf16 with bf16 tensors in memory: flags bit 0: b holds bf16 elements, bit 2: a does, bit 1:
  * d is written as bf16 (no accumulate, no split reduction); strides count elements. Used with
  * brv_im2col_bf16 / brv_col2im_bf16 (same arguments as brv_im2col / brv_col2im, the column matrix

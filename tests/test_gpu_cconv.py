@@ -1,0 +1,98 @@
+"""brv_cconv_rows (csrc/cconv.hip): the DCCRN convolution / transposed convolution in one launch, against
+torch's CPU float64 convolutions of the SAME bf16-rounded operands (reference geometry
+brever/models/dccrn/dccrn.py:225-292: kernel (5, 2), stride (2, 1), padding (2, 0), output_padding (1, 0)).
+With identical operands only the order of the fp32 sums differs: the bound is 2e-5 of the output norm.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cuda():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a ROCm device')
+    return torch.device('cuda:0')
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def _run(x, w_mcij, bias, transposed):
+    """w_mcij: (M, C, 5, 2) logical weight; stored as a (M, C*10) matrix (m_stride = 10 C, c_stride = 10)."""
+    from brever_amd.models.dccrn import _cconv_rows
+    M, C = w_mcij.shape[:2]
+    wc = w_mcij.reshape(M, C*10).contiguous()
+    return _cconv_rows(x.contiguous(), wc, bias, M, C*10, 10, transposed)
+
+
+# (B, C, M, Hin, Win): every workgroup shape of the launcher (M <= 32, <= 64, <= 128, > 128 with few and many
+# workgroups), channel counts off the chunk of 8, output rows off the fragment of 32, frame counts around the
+# 128- / 256-frame tiles, the smallest images
+CASES = [
+    (2, 2, 32, 16, 37), (1, 32, 64, 8, 129), (2, 64, 128, 8, 300), (1, 128, 256, 4, 257),
+    (16, 24, 256, 8, 131), (1, 5, 3, 4, 9), (1, 13, 70, 2, 2), (3, 40, 130, 6, 513), (1, 256, 512, 4, 64),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'B%d_C%d_M%d_H%d_W%d' % c)
+@pytest.mark.parametrize('transposed', [0, 1])
+def test_rows_convolution_equals_float64_convolution_of_the_rounded_operands(case, transposed):
+    dev = _cuda()
+    B, C, M, H, W = case
+    g = torch.Generator().manual_seed(B*1000 + C*10 + M + H + W + transposed)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(M, C, 5, 2, generator=g)/(C*10)**0.5
+    bias = torch.randn(M, generator=g)
+    y = _run(x.to(dev), w.to(dev), bias.to(dev), transposed).cpu().double()
+    if transposed:
+        ref = torch.nn.functional.conv_transpose2d(_bf(x), _bf(w).transpose(0, 1).contiguous(), bias.double(),
+                                                   stride=(2, 1), padding=(2, 0), output_padding=(1, 0))
+    else:
+        ref = torch.nn.functional.conv2d(_bf(x), _bf(w), bias.double(), stride=(2, 1), padding=(2, 0))
+    assert y.shape == ref.shape
+    err = float((y - ref).norm()/ref.norm())
+    assert err < 2e-5, err
+    assert float((y - ref).abs().max()) < 1e-4*float(ref.abs().max()) + 1e-5
+
+
+def test_rows_convolution_without_bias_and_strided_weight_matrix():
+    """The data-gradient call pattern: no bias, W[m][c][i][j] taken from a (C, M*10) matrix (m_stride = 10)."""
+    dev = _cuda()
+    g = torch.Generator().manual_seed(5)
+    B, C, M, H, W = 2, 48, 96, 6, 200
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(M, C, 5, 2, generator=g)/(C*10)**0.5
+    wc = w.permute(1, 0, 2, 3).reshape(C, M*10).contiguous()          # [c][(m, i, j)]
+    from brever_amd.models.dccrn import _cconv_rows
+    for transposed in (0, 1):
+        y = _cconv_rows(x.to(dev), wc.to(dev), None, M, 10, M*10, transposed).cpu().double()
+        if transposed:
+            ref = torch.nn.functional.conv_transpose2d(_bf(x), _bf(w).transpose(0, 1).contiguous(), None,
+                                                       stride=(2, 1), padding=(2, 0), output_padding=(1, 0))
+        else:
+            ref = torch.nn.functional.conv2d(_bf(x), _bf(w), None, stride=(2, 1), padding=(2, 0))
+        assert float((y - ref).norm()/ref.norm()) < 2e-5
+
+
+def test_rows_and_column_matrix_paths_give_the_same_dccrn_gradients():
+    """use_amp DCCRN step at a small size: loss and every gradient with BRV_DCCRN_ROWS on and off."""
+    import brever_amd.models.dccrn as D
+    dev = _cuda()
+    torch.manual_seed(0)
+    model = D.DCCRN(channels=[8, 16, 32], lstm_channels=32).to(dev)
+    batch = 0.1*torch.randn(2, 2, 8000, generator=torch.Generator().manual_seed(1)).to(dev)
+    lengths = torch.tensor([8000, 7000], device=dev)
+    out = {}
+    for rows in (True, False):
+        D._ROWS = rows
+        model.zero_grad(set_to_none=True)
+        loss = model.loss(batch, lengths, True)
+        loss.backward()
+        out[rows] = (float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    D._ROWS = True
+    assert abs(out[True][0] - out[False][0]) < 2e-2*abs(out[False][0]) + 1e-3
+    num = sum(float((out[True][1][n].double() - out[False][1][n].double()).norm()**2) for n in out[True][1])
+    den = sum(float(out[False][1][n].double().norm()**2) for n in out[True][1])
+    assert (num/den)**0.5 < 3e-2, (num/den)**0.5
