@@ -225,6 +225,197 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParam
   }
 }
 
+// ---- weight gradient of both forms: dW[a][c][i][j] = sum_{b,h,w} small[b][a][h][w] big[b][c][2h - 2 + i][w + j]
+// (Conv2d: small = dy, big = x; ConvTranspose2d: small = x, big = dy; big is (B, C, 2 Hs, Ws + 1)), written as
+// the fp32 matrix out[a][10 c + 2 i + j] the complex weight unpacking reads. A GEMM whose k axis is the FRAME
+// axis both images are contiguous along: per stage of 64 frames of one (b, h) the 128 rows of `small` (twice:
+// as they are and shifted by one frame, which is the j = 1 tap -- every fragment read stays 16-byte aligned)
+// and the 5 x 64 rows of `big` are rounded to bf16 into LDS images with 128-byte rows (16-byte chunk ^ (row >> 1) & 7:
+// conflict-free ds_read_b128 fragments). Wave (a half, c half, j) keeps 2 x 5 accumulator tiles (its 64 rows of
+// `small`, 32 channels of `big`, 5 rows i): 7 fragment reads per 10 MFMAs. A workgroup walks a contiguous
+// range of (b, h) pairs and adds its tile to the gradient once at the end.
+struct CWgradParams {
+  const float* small; const float* small2; const float* big; float* part;
+  int B, A, C, Hs, Ws, Hb, Wb;
+  int seg;                       // small = [s[:seg] | s2[:seg] | s[seg:] | s2[seg:]] along the channels (0: one source)
+  long long small_bs, small2_bs, big_bs;
+  int atiles, ctiles, npairs, pairs_per, nstage, ldo;
+};
+
+constexpr int WG_A = 128, WG_C = 32, WG_F = 64;
+constexpr int WG_THREADS = 512, WG_NS = WG_A*16/WG_THREADS, WG_NB = CC_KH*WG_C*16/WG_THREADS;
+constexpr int WG_SMALLB = WG_A*128, WG_BIGB = CC_KH*WG_C*128, WG_BUFB = 2*WG_SMALLB + WG_BIGB;
+
+__device__ __forceinline__ int wg_swz(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int wg_off(int row, int q) { return 128*row + 16*((q >> 1) ^ wg_swz(row)) + 8*(q & 1); }
+
+__global__ __launch_bounds__(WG_THREADS) void cconv_wgrad_kernel(const CWgradParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2*WG_BUFB];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int j = wid & 1, afr = wid >> 1;
+  const int atile = blockIdx.x % p.atiles, ctile = blockIdx.x / p.atiles;
+  const int pair0 = blockIdx.y*p.pairs_per;
+  const int pair1 = pair0 + p.pairs_per < p.npairs ? pair0 + p.pairs_per : p.npairs;
+  const int nitems = (pair1 - pair0)*p.nstage;
+  const int q = tid & 15;
+
+  // ---- staging rows of this thread: 4 of `small` (row = channel), 10 of `big` (row = (i, channel))
+  const float* s_ptr[WG_NS]; long long s_bs[WG_NS];
+#pragma unroll
+  for (int r = 0; r < WG_NS; ++r) {
+    const int a = atile*WG_A + ((tid + WG_THREADS*r) >> 4);
+    s_ptr[r] = nullptr; s_bs[r] = 0;
+    if (a < p.A) {
+      if (p.seg > 0) {
+        const int sg = a / p.seg, ch = (sg >> 1)*p.seg + a % p.seg;
+        s_ptr[r] = ((sg & 1) ? p.small2 : p.small) + (long long)ch*p.Hs*p.Ws;
+        s_bs[r] = (sg & 1) ? p.small2_bs : p.small_bs;
+      } else { s_ptr[r] = p.small + (long long)a*p.Hs*p.Ws; s_bs[r] = p.small_bs; }
+    }
+  }
+  float4 sv[WG_NS]; float sl[WG_NS];          // frames 4q .. 4q+3 of the stage and the frame before the stage
+  float4 bv[WG_NB];
+  auto load_small = [&](int it) {
+    const int pr = pair0 + it / p.nstage, stg = it % p.nstage;
+    const int b = pr / p.Hs, h = pr % p.Hs, f = stg*WG_F + 4*q;
+#pragma unroll
+    for (int r = 0; r < WG_NS; ++r) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float left = 0.f;
+      if (s_ptr[r]) {
+        const float* src = s_ptr[r] + b*s_bs[r] + (long long)h*p.Ws;
+        if (f + 3 < p.Ws) __builtin_memcpy(&v, src + f, 16);
+        else {
+          if (f < p.Ws) v.x = src[f];
+          if (f + 1 < p.Ws) v.y = src[f + 1];
+          if (f + 2 < p.Ws) v.z = src[f + 2];
+        }
+        if (q == 0 && f > 0 && f - 1 < p.Ws) left = src[f - 1];
+      }
+      sv[r] = v; sl[r] = left;
+    }
+  };
+  auto load_big = [&](int it) {
+    const int pr = pair0 + it / p.nstage, stg = it % p.nstage;
+    const int b = pr / p.Hs, h = pr % p.Hs, f = stg*WG_F + 4*q;
+#pragma unroll
+    for (int r = 0; r < WG_NB; ++r) {
+      const int rs = (tid + WG_THREADS*r) >> 4, i = rs >> 5, c = ctile*WG_C + (rs & 31);
+      const int row = 2*h - 2 + i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < p.C && row >= 0 && row < p.Hb) {
+        const float* src = p.big + b*p.big_bs + ((long long)c*p.Hb + row)*p.Wb;
+        if (f + 3 < p.Wb) __builtin_memcpy(&v, src + f, 16);
+        else {
+          if (f < p.Wb) v.x = src[f];
+          if (f + 1 < p.Wb) v.y = src[f + 1];
+          if (f + 2 < p.Wb) v.z = src[f + 2];
+        }
+      }
+      bv[r] = v;
+    }
+  };
+  auto store_small = [&](int buf) {
+    unsigned char* base = lds + buf*WG_BUFB;
+#pragma unroll
+    for (int r = 0; r < WG_NS; ++r) {
+      const int row = (tid + WG_THREADS*r) >> 4;
+      const float4 v = sv[r];
+      // the frame before this quad: lane q - 1 of the same row (16 lanes = one DPP row), or the stage's left neighbour
+      float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.w), 0x111, 0xf, 0xf, false));
+      if (q == 0) prev = sl[r];
+      *reinterpret_cast<uint2*>(base + wg_off(row, q)) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+      *reinterpret_cast<uint2*>(base + WG_SMALLB + wg_off(row, q)) = make_uint2(pack2(prev, v.x), pack2(v.y, v.z));
+    }
+  };
+  auto store_big = [&](int buf) {
+    unsigned char* base = lds + buf*WG_BUFB + 2*WG_SMALLB;
+#pragma unroll
+    for (int r = 0; r < WG_NB; ++r) {
+      const int rs = (tid + WG_THREADS*r) >> 4;
+      *reinterpret_cast<uint2*>(base + wg_off(rs, q)) = make_uint2(pack2(bv[r].x, bv[r].y), pack2(bv[r].z, bv[r].w));
+    }
+  };
+
+  f32x16 acc[CC_KH];
+#pragma unroll
+  for (int i = 0; i < CC_KH; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  if (nitems > 0) { load_small(0); load_big(0); store_small(0); store_big(0); }
+  __syncthreads();
+  const int m = lane & 31, g = lane >> 5;
+  for (int it = 0; it < nitems; ++it) {
+    const unsigned char* cur = lds + (it & 1)*WG_BUFB;
+    const bool more = it + 1 < nitems;
+    if (more) { load_big(it + 1); load_small(it + 1); }
+#pragma unroll
+    for (int ks = 0; ks < WG_F/16; ++ks) {
+      const int ch = 2*ks + g;
+      bf16x8 bf[CC_KH];
+      const int arow = 32*afr + m;
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(cur + j*WG_SMALLB + 128*arow + 16*(ch ^ wg_swz(arow)));
+#pragma unroll
+      for (int i = 0; i < CC_KH; ++i) {
+        const int row = 32*i + m;
+        bf[i] = *reinterpret_cast<const bf16x8*>(cur + 2*WG_SMALLB + 128*row + 16*(ch ^ wg_swz(row)));
+      }
+#pragma unroll
+      for (int i = 0; i < CC_KH; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[i], acc[i], 0, 0, 0);
+    }
+    if (more) { store_big((it + 1) & 1); store_small((it + 1) & 1); }
+    __syncthreads();
+  }
+
+  // ---- D[a][c] of tap (i, j) -> part[split][2 i + j][a][c]: plain stores, 128 bytes per 32 lanes; the splits
+  // are summed in order by cconv_wgrad_reduce_kernel (device-scope atomics cost more than the products here)
+  const int c = ctile*WG_C + m;
+  if (c < p.C) {
+    float* part = p.part + (long long)blockIdx.y*10*p.A*p.C;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = atile*WG_A + 32*afr + (e & 3) + 8*(e >> 2) + 4*g;
+      if (row < p.A) {
+#pragma unroll
+        for (int i = 0; i < CC_KH; ++i) part[((long long)(2*i + j)*p.A + row)*p.C + c] = acc[i][e];
+      }
+    }
+  }
+}
+
+// out[a][10 c + tap] = sum_split part[split][tap][a][c]: 64 outputs per workgroup, the splits dealt to 4 thread
+// groups with 8 loads in flight each, partial sums combined in a fixed order
+__global__ __launch_bounds__(256) void cconv_wgrad_reduce_kernel(const float* part, float* out, int A, int C,
+                                                                  int nsplit) {
+  __shared__ float sh[4][64];
+  const long long n = (long long)10*A*C;
+  const long long e = (long long)blockIdx.x*64 + (threadIdx.x & 63);
+  const int grp = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < n) {
+    int k = grp;
+    for (; k + 28 < nsplit; k += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(k + 4*u)*n + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nsplit; k += 4) s += part[k*n + e];
+  }
+  sh[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && e < n) {
+    s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    const int c = (int)(e % C);
+    const long long t = e / C;
+    const int a = (int)(t % A), tap = (int)(t / A);
+    out[(long long)a*10*C + 10*c + tap] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -268,6 +459,44 @@ int brv_cconv_rows(const float* in, const void* wp, const float* bias, float* ou
   else if (M > 32) CC_LAUNCH(2, 1, 1, 8);
   else CC_LAUNCH(1, 1, 1, 8);
 #undef CC_LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+static void cconv_wgrad_plan(int64_t B, int64_t A, int64_t C, int64_t Hs, int& atiles, int& ctiles, int& nsplit,
+                             int& pairs_per) {
+  atiles = (int)((A + WG_A - 1)/WG_A); ctiles = (int)((C + WG_C - 1)/WG_C);
+  const int tiles = atiles*ctiles, npairs = (int)(B*Hs);
+  nsplit = (2*256 + tiles - 1)/tiles;
+  if (nsplit > npairs) nsplit = npairs;
+  pairs_per = (npairs + nsplit - 1)/nsplit;
+  nsplit = (npairs + pairs_per - 1)/pairs_per;
+}
+
+int64_t brv_cconv_wgrad_workspace_bytes(int64_t B, int64_t A, int64_t C, int64_t Hs) {
+  if (B < 1 || A < 1 || C < 1 || Hs < 1) return -1;
+  int atiles, ctiles, nsplit, pairs_per;
+  cconv_wgrad_plan(B, A, C, Hs, atiles, ctiles, nsplit, pairs_per);
+  return (int64_t)nsplit*10*A*C*4;
+}
+
+int brv_cconv_wgrad(const float* small, const float* small2, const float* big, float* out, void* workspace,
+                    int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream) {
+  if (!small || !big || !out || !workspace || B < 1 || A < 1 || C < 1 || Hs < 1 || Ws < 1) return -1;
+  if (seg < 0 || (seg > 0 && (!small2 || A != 4*seg))) return -1;
+  CWgradParams p;
+  p.small = small; p.small2 = small2; p.big = big; p.part = (float*)workspace;
+  p.B = (int)B; p.A = (int)A; p.C = (int)C; p.Hs = (int)Hs; p.Ws = (int)Ws; p.Hb = (int)(2*Hs); p.Wb = (int)(Ws + 1);
+  p.seg = (int)seg;
+  p.small_bs = (seg > 0 ? 2*seg : A)*Hs*Ws; p.small2_bs = p.small_bs; p.big_bs = C*(long long)p.Hb*p.Wb;
+  int nsplit;
+  cconv_wgrad_plan(B, A, C, Hs, p.atiles, p.ctiles, nsplit, p.pairs_per);
+  p.npairs = (int)(B*Hs); p.nstage = (p.Wb + WG_F - 1)/WG_F; p.ldo = (int)(10*C);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cconv_wgrad_kernel, dim3((unsigned)(p.atiles*p.ctiles), (unsigned)nsplit), dim3(WG_THREADS), 0,
+                     st, p);
+  const long long n = 10*A*C;
+  hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3((unsigned)((n + 63)/64)), dim3(256), 0, st,
+                     (const float*)workspace, out, (int)A, (int)C, nsplit);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -184,6 +184,21 @@ def _cconv_rows(x, wc, bias, M, m_stride, c_stride, transposed):
     return out
 
 
+def _cconv_wgrad(small, big, small2=None):
+    """``brv_cconv_wgrad``: (A, 10 C) weight-gradient matrix of the row convolutions; ``small2``: the second
+    source of a skip concatenation that was never materialised."""
+    B, C, Hb, Wb = big.shape
+    seg = small.shape[1]//2 if small2 is not None else 0
+    A = 4*seg if seg else small.shape[1]
+    Hs, Ws = small.shape[2:]
+    assert Hb == 2*Hs and Wb == Ws + 1
+    out = torch.empty(A, 10*C, dtype=torch.float32, device=big.device)
+    ws = torch.empty(hip.lib().brv_cconv_wgrad_workspace_bytes(B, A, C, Hs), dtype=torch.uint8, device=big.device)
+    hip.check(hip.lib().brv_cconv_wgrad(hip.ptr(small), hip.ptr(small2), hip.ptr(big), hip.ptr(out), hip.ptr(ws),
+                                        B, A, C, Hs, Ws, seg, hip.stream()), 'brv_cconv_wgrad')
+    return out
+
+
 def _im2col(x, geom, grid, lowp=False):
     """``lowp``: the column matrix in bf16 (half the bytes of the largest tensor of the layer)."""
     (kh, kw), (sh, sw), (ph, pw) = geom
@@ -288,29 +303,29 @@ class _ComplexConvFunction(torch.autograd.Function):
         dy = dy.contiguous()
         B = x.shape[0]
         lowp = ctx.lowp
-        dwc = torch.empty_like(wc)
         khw = geom[0][0]*geom[0][1]
-        if transpose and lowp and _IMPLICIT:
-            if ctx.rows:
-                dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0)
-            else:
-                dx = torch.empty_like(x)
-                _gemm_conv(wc, dy, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, 0, 2*Cout*Ho*Wo, 2*Cin*H*W, 1,
-                           (2*Cout, Ho, Wo), geom, (H, W))
+        dwc = None if ctx.rows else torch.empty_like(wc)
+        if ctx.rows and transpose:
+            dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0)
+            dwc = _cconv_wgrad(x, dy)
+        elif ctx.rows:
+            dx = _cconv_rows(dy, wc, None, 2*Cin, khw, 2*Cw, 1)
+            dwc = _cconv_wgrad(dy, x)
+        elif transpose and lowp and _IMPLICIT:
+            dx = torch.empty_like(x)
+            _gemm_conv(wc, dy, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, 0, 2*Cout*Ho*Wo, 2*Cin*H*W, 1,
+                       (2*Cout, Ho, Wo), geom, (H, W))
             _gemm_conv(x, dy, dwc, 1, 2*Cin, 2*Cw, H*W, H*W, 2*Cw, 0, 0, 0, 1, (2*Cout, Ho, Wo), geom,
                        (H, W), trans_b=1, kbatch=B, a_kbs=2*Cin*H*W, img_kbs=2*Cout*Ho*Wo)
         elif not transpose and lowp and _IMPLICIT:
             _gemm_conv(dy, x, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, 1, (2*Cin, H, W), geom,
                        (Ho, Wo), trans_b=1, kbatch=B, a_kbs=2*Cout*Ho*Wo, img_kbs=2*Cin*H*W)
-            if ctx.rows:
-                dx = _cconv_rows(dy, wc, None, 2*Cin, khw, 2*Cw, 1)
-            else:
-                # data gradient: product + scatter (the generic gather form doubles the matrix work at
-                # stride 2 and shrinks M to 2*Cin: measured 3.8x slower than this pair)
-                col = torch.empty(B, 2*Cw, Ho*Wo, dtype=torch.bfloat16, device=x.device)
-                _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,
-                      2*Cw*Ho*Wo, trans_a=1, lowp=lowp)
-                dx = _col2im(col, None, 2*Cin, (H, W), geom, (Ho, Wo))
+            # data gradient: product + scatter (the generic gather form doubles the matrix work at
+            # stride 2 and shrinks M to 2*Cin: measured 3.8x slower than this pair)
+            col = torch.empty(B, 2*Cw, Ho*Wo, dtype=torch.bfloat16, device=x.device)
+            _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,
+                  2*Cw*Ho*Wo, trans_a=1, lowp=lowp)
+            dx = _col2im(col, None, 2*Cin, (H, W), geom, (Ho, Wo))
         elif transpose:
             dcol = _im2col(dy, geom, (H, W), lowp)                 # (B, 2*Cw, H*W)
             dx = torch.empty_like(x)

@@ -336,6 +336,16 @@ int brv_cconv_pack(const float* wc, void* wp, int64_t M, int64_t C, int64_t m_st
                    brv_stream_t stream);
 int brv_cconv_rows(const float* in, const void* wp, const float* bias, float* out, int64_t B, int64_t C,
                    int64_t M, int64_t Hin, int64_t Win, int32_t transposed, brv_stream_t stream);
+/* Weight gradient of both forms of brv_cconv_rows: out[a][10 c + 2 i + j] = sum_{b,h,w} small[b][a][h][w] *
+ * big[b][c][2h - 2 + i][w + j], small (B, A, Hs, Ws), big (B, C, 2 Hs, Ws + 1), out (A, 10 C) fp32 (overwritten).
+ * Conv2d: small = dy, big = x; ConvTranspose2d: small = x, big = dy (brever/models/dccrn/dccrn.py:225-235
+ * under autograd). seg > 0: `small` is the channel concatenation [small[:, :seg], small2[:, :seg], small[:, seg:],
+ * small2[:, seg:]] of two (B, 2 seg, Hs, Ws) tensors (the decoder's skip concatenation, dccrn.py:213-217),
+ * A = 4 seg; seg = 0: small2 is ignored. bf16 operands, fp32 sums: the (b, h) range is split over workgroups whose
+ * partial matrices (workspace of brv_cconv_wgrad_workspace_bytes bytes) a second launch adds in split order. */
+int64_t brv_cconv_wgrad_workspace_bytes(int64_t B, int64_t A, int64_t C, int64_t Hs);
+int brv_cconv_wgrad(const float* small, const float* small2, const float* big, float* out, void* workspace,
+                    int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream);
 /* brv_gemm_bf16 with bf16 tensors in memory: flags bit 0: b holds bf16 elements, bit 2: a does, bit 1:
  * d is written as bf16 (no accumulate, no split reduction); strides count elements. Used with
  * brv_im2col_bf16 / brv_col2im_bf16 (same arguments as brv_im2col / brv_col2im, the column matrix

@@ -76,6 +76,44 @@ def test_rows_convolution_without_bias_and_strided_weight_matrix():
         assert float((y - ref).norm()/ref.norm()) < 2e-5
 
 
+WG_CASES = [  # (B, A, C, Hs, Ws)
+    (2, 32, 2, 8, 37), (1, 64, 32, 4, 129), (3, 128, 64, 2, 63), (2, 256, 40, 3, 64), (1, 130, 33, 1, 1),
+    (16, 96, 256, 2, 200), (1, 5, 3, 4, 500),
+]
+
+
+@pytest.mark.parametrize('case', WG_CASES, ids=lambda c: 'B%d_A%d_C%d_H%d_W%d' % c)
+def test_rows_weight_gradient_equals_float64_autograd_of_the_rounded_operands(case):
+    """brv_cconv_wgrad against d/dw of conv2d(big, w) . small in float64 (bf16-rounded images)."""
+    from brever_amd.models.dccrn import _cconv_wgrad
+    dev = _cuda()
+    B, A, C, Hs, Ws = case
+    g = torch.Generator().manual_seed(sum(case))
+    small = torch.randn(B, A, Hs, Ws, generator=g)
+    big = torch.randn(B, C, 2*Hs, Ws + 1, generator=g)
+    out = _cconv_wgrad(small.to(dev), big.to(dev)).cpu().double()
+    w = torch.zeros(A, C, 5, 2, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(_bf(big), w, None, stride=(2, 1), padding=(2, 0))
+    (ref,) = torch.autograd.grad(y, w, _bf(small))
+    ref = ref.reshape(A, C*10)
+    assert out.shape == ref.shape
+    assert float((out - ref).norm()/ref.norm()) < 3e-5
+
+
+def test_rows_weight_gradient_reads_a_skip_concatenation_from_its_two_sources():
+    from brever_amd.models.dccrn import _cconv_wgrad
+    dev = _cuda()
+    g = torch.Generator().manual_seed(9)
+    B, seg, C, Hs, Ws = 2, 24, 20, 4, 150
+    s1 = torch.randn(B, 2*seg, Hs, Ws, generator=g).to(dev)
+    s2 = torch.randn(B, 2*seg, Hs, Ws, generator=g).to(dev)
+    big = torch.randn(B, C, 2*Hs, Ws + 1, generator=g).to(dev)
+    cat = torch.cat([s1[:, :seg], s2[:, :seg], s1[:, seg:], s2[:, seg:]], dim=1).contiguous()
+    one = _cconv_wgrad(cat, big)
+    two = _cconv_wgrad(s1, big, small2=s2)
+    assert float((one - two).norm()/one.norm()) < 1e-6        # same products, atomics in another order
+
+
 def test_rows_and_column_matrix_paths_give_the_same_dccrn_gradients():
     """use_amp DCCRN step at a small size: loss and every gradient with BRV_DCCRN_ROWS on and off."""
     import brever_amd.models.dccrn as D

@@ -55,6 +55,22 @@ def main():
         f = timed(lambda: D._ComplexConvFunction.apply(x, wr, br, wi, bi, GEOM, tr))
         b = timed(lambda: torch.autograd.grad(y, (x, wr, wi, br, bi), dy, retain_graph=True))
         flops = 2.0*B*(2*cin)*(2*cout)*10*(y.shape[2]*y.shape[3] if not tr else H*W)
+        if os.environ.get('WGRAD'):
+            # the two weight-gradient paths alone
+            geom = GEOM[:3]
+            Cw = 10*(cout if tr else cin)
+            dwc = torch.empty(2*(cin if tr else cout), 2*Cw, device=dev)
+            xd, Ho, Wo = x.detach(), y.shape[2], y.shape[3]
+            if tr:
+                new = timed(lambda: D._cconv_wgrad(xd, dy))
+                old = timed(lambda: D._gemm_conv(xd, dy, dwc, 1, 2*cin, 2*Cw, H*W, H*W, 2*Cw, 0, 0, 0, 1, (2*cout, Ho, Wo),
+                                                 geom, (H, W), trans_b=1, kbatch=B, a_kbs=2*cin*H*W, img_kbs=2*cout*Ho*Wo))
+            else:
+                new = timed(lambda: D._cconv_wgrad(dy, xd))
+                old = timed(lambda: D._gemm_conv(dy, xd, dwc, 1, 2*cout, 2*Cw, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, 1, (2*cin, H, W),
+                                                 geom, (Ho, Wo), trans_b=1, kbatch=B, a_kbs=2*cout*Ho*Wo, img_kbs=2*cin*H*W))
+            print(f'{name} wgrad rows {new:7.1f} us ({flops/new/1e6:6.1f} TF/s)   column-matrix {old:7.1f} us', flush=True)
+            continue
         tot_f += f
         tot_b += b
         print(f'{name} {2*cin:4d}->{2*cout:4d} in {H:3d}x{W:3d} out {y.shape[2]:3d}x{y.shape[3]:3d}: fwd {f:7.1f} us '
