@@ -27,12 +27,13 @@ constexpr int CC_THREADS = 512;
 constexpr int CC_KH = 5;
 
 struct CConvParams {
-  const float* in; const uint4* wp; const float* bias; float* out;
+  const float* in; const float* in2; const uint4* wp; const float* bias; float* out; float* out2;
+  int in_seg, out_seg;         // > 0: channels = [t[:seg] | t2[:seg] | t[seg:] | t2[seg:]] of two (B, 2 seg, H, W) tensors
   int B, C, M, Hin, Win, Hout, Wout;
   long long in_bs, out_bs;
   int mode;                    // 0 strided, 1 transposed
   int ncc;                     // chunks of 8 input channels
-  int mtiles, ftiles;
+  int mtiles, ftiles, mfrags;   // mfrags: 32-row groups the packed weights hold
 };
 
 __device__ __forceinline__ int cc_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void cconv_pack_kernel(const float* wc, uint4*
   wp[e] = pack8(v);
 }
 
-template <int MF, int NF, int WM, int WN, int NTAP>
+template <int MF, int NF, int WM, int WN, int NTAP, bool SEG>
 __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* lds, int b, int r, int ftile,
                                            int mtile, const int (&tap_i)[NTAP], const int (&tap_row)[NTAP],
                                            int shift) {
@@ -87,6 +88,7 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
   const int wm = wid / WN, wn = wid % WN;
   const int f0 = ftile*NT;
   const float* in_b = p.in + (long long)b*p.in_bs;
+  const float* in2_b = SEG && p.in_seg > 0 ? p.in2 + (long long)b*p.in_bs : nullptr;
 
   // ---- staging items: (image, channel, frame quad) -> source frame and LDS byte offset
   int s_c[IT], s_f[IT], s_off[IT];
@@ -102,15 +104,23 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
   }
   float4 st[NTAP][IT];
   auto stage_load = [&](int cc) {
+    // source tensor and channel offset of this chunk of 8 (never straddles two segments: seg % 8 == 0)
+    const float* base = in_b;
+    int ch0 = 8*cc;
+    if (SEG && p.in_seg > 0) {
+      const int sg = (ch0 >= p.in_seg) + (ch0 >= 2*p.in_seg) + (ch0 >= 3*p.in_seg);
+      ch0 -= ((sg + 1) >> 1)*p.in_seg;
+      if (sg & 1) base = in2_b;
+    }
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
       const int row = tap_row[t];
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
-        const int ch = 8*cc + s_c[it], f = s_f[it];
+        const int f = s_f[it];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row >= 0 && row < p.Hin && ch < p.C) {
-          const float* src = in_b + ((long long)ch*p.Hin + row)*p.Win;
+        if (row >= 0 && row < p.Hin && 8*cc + s_c[it] < p.C) {
+          const float* src = base + ((long long)(ch0 + s_c[it])*p.Hin + row)*p.Win;
           if (f >= 0 && f + 3 < p.Win) __builtin_memcpy(&v, src + f, 16);
           else {
             if (f >= 0 && f < p.Win) v.x = src[f];
@@ -136,7 +146,10 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
   const int mfrag0 = (mtile*WM + wm)*MF;
   const uint4* wq[MF];
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf) wq[mf] = p.wp + (long long)(mfrag0 + mf)*p.ncc*CC_KH*64 + lane;
+  for (int mf = 0; mf < MF; ++mf) {         // row groups past M: any packed group (their outputs are not stored)
+    const int fr = mfrag0 + mf < p.mfrags ? mfrag0 + mf : p.mfrags - 1;
+    wq[mf] = p.wp + (long long)fr*p.ncc*CC_KH*64 + lane;
+  }
   auto a_load = [&](int cc, int t, uint4 (&dst)[MF]) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) dst[mf] = wq[mf][(cc*CC_KH + tap_i[t])*64];
@@ -187,6 +200,7 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
 
   // ---- D[m][frame] -> out[b][m][r][frame] (+ bias)
   float* out_b = p.out + (long long)b*p.out_bs;
+  float* out2_b = SEG && p.out_seg > 0 ? p.out2 + (long long)b*p.out_bs : nullptr;
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -198,13 +212,20 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
         if (m < p.M && w < p.Wout) {
           float v = acc[mf][nf][i];
           if (p.bias) v += p.bias[m];
-          out_b[((long long)m*p.Hout + r)*p.Wout + w] = v;
+          float* dst = out_b;
+          int mc = m;
+          if (SEG && p.out_seg > 0) {
+            const int sg = (m >= p.out_seg) + (m >= 2*p.out_seg) + (m >= 3*p.out_seg);
+            mc -= ((sg + 1) >> 1)*p.out_seg;
+            if (sg & 1) dst = out2_b;
+          }
+          dst[((long long)mc*p.Hout + r)*p.Wout + w] = v;
         }
       }
     }
 }
 
-template <int MF, int NF, int WM, int WN>
+template <int MF, int NF, int WM, int WN, bool SEG>
 __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParams p) {
   constexpr int NT = 32*NF*WN;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2*CC_KH*(NT/128)*4096];
@@ -213,15 +234,15 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParam
   if (p.mode == 0) {
     const int ti[5] = {0, 1, 2, 3, 4};
     const int tr[5] = {2*r - 2, 2*r - 1, 2*r, 2*r + 1, 2*r + 2};
-    cconv_tile<MF, NF, WM, WN, 5>(p, lds, b, r, ftile, mtile, ti, tr, 1);
+    cconv_tile<MF, NF, WM, WN, 5, SEG>(p, lds, b, r, ftile, mtile, ti, tr, 1);
   } else if (r & 1) {
     const int ti[2] = {1, 3};
     const int tr[2] = {(r + 1) >> 1, (r - 1) >> 1};
-    cconv_tile<MF, NF, WM, WN, 2>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    cconv_tile<MF, NF, WM, WN, 2, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
   } else {
     const int ti[3] = {0, 2, 4};
     const int tr[3] = {(r >> 1) + 1, r >> 1, (r >> 1) - 1};
-    cconv_tile<MF, NF, WM, WN, 3>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    cconv_tile<MF, NF, WM, WN, 3, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
   }
 }
 
@@ -434,24 +455,29 @@ int brv_cconv_pack(const float* wc, void* wp, int64_t M, int64_t C, int64_t m_st
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-int brv_cconv_rows(const float* in, const void* wp, const float* bias, float* out, int64_t B, int64_t C,
-                   int64_t M, int64_t Hin, int64_t Win, int32_t transposed, brv_stream_t stream) {
+int brv_cconv_rows(const float* in, const float* in2, int64_t in_seg, const void* wp, const float* bias, float* out,
+                   float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
+                   int32_t transposed, brv_stream_t stream) {
   if (!in || !wp || !out || B < 1 || C < 1 || M < 1 || Hin < 1 || Win < 1) return -1;
   if (!transposed && ((Hin & 1) || Win < 2)) return -1;
+  if (in_seg < 0 || (in_seg > 0 && (!in2 || C != 4*in_seg || (in_seg & 7)))) return -1;
+  if (out_seg < 0 || (out_seg > 0 && (!out2 || M != 4*out_seg))) return -1;
   CConvParams p;
-  p.in = in; p.wp = (const uint4*)wp; p.bias = bias; p.out = out;
+  p.in = in; p.in2 = in2; p.wp = (const uint4*)wp; p.bias = bias; p.out = out; p.out2 = out2;
+  p.in_seg = (int)in_seg; p.out_seg = (int)out_seg;
   p.B = (int)B; p.C = (int)C; p.M = (int)M; p.Hin = (int)Hin; p.Win = (int)Win;
   p.Hout = transposed ? (int)(2*Hin) : (int)(Hin/2);
   p.Wout = transposed ? (int)(Win + 1) : (int)(Win - 1);
-  p.in_bs = C*Hin*Win; p.out_bs = M*(long long)p.Hout*p.Wout;
+  p.in_bs = (in_seg > 0 ? 2*in_seg : C)*Hin*Win; p.out_bs = (out_seg > 0 ? 2*out_seg : M)*(long long)p.Hout*p.Wout;
   p.mode = transposed ? 1 : 0;
-  p.ncc = (int)((C + 7)/8);
+  p.ncc = (int)((C + 7)/8); p.mfrags = (int)((M + 31)/32);
   hipStream_t st = (hipStream_t)stream;
 #define CC_LAUNCH(MF_, NF_, WM_, WN_) do { \
     constexpr int MT = 32*MF_*WM_, NT = 32*NF_*WN_; \
     p.mtiles = (int)((M + MT - 1)/MT); p.ftiles = (p.Wout + NT - 1)/NT; \
-    hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_>), dim3(p.ftiles, p.Hout, (unsigned)(B*p.mtiles)), \
-                       dim3(CC_THREADS), 0, st, p); } while (0)
+    const dim3 grid(p.ftiles, p.Hout, (unsigned)(B*p.mtiles)); \
+    if (in_seg > 0 || out_seg > 0) hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, true>), grid, dim3(CC_THREADS), 0, st, p); \
+    else hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, false>), grid, dim3(CC_THREADS), 0, st, p); } while (0)
   if (M > 128) {
     const long long wgs = (long long)((p.Wout + 255)/256)*p.Hout*B*((M + 255)/256);
     if (wgs < 256) CC_LAUNCH(2, 2, 4, 2); else CC_LAUNCH(2, 4, 4, 2);

@@ -249,7 +249,8 @@ SIGNATURES = {
                            + [_c_i64]*3 + [_c_ptr, ctypes.c_int, ctypes.c_int] + [_c_i64]*11 + [_c_ptr]),
     'brv_cconv_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_cconv_pack': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*4 + [_c_ptr]),
-    'brv_cconv_rows': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*5 + [ctypes.c_int32, _c_ptr]),
+    'brv_cconv_rows': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_i64]*6
+                       + [ctypes.c_int32, _c_ptr]),
     'brv_cconv_wgrad_workspace_bytes': (_c_i64, [_c_i64]*4),
     'brv_cconv_wgrad': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*6 + [_c_ptr]),
     'brv_conv_nhwc_packed_size': (_c_i64, [_c_i64, _c_i64, _c_i64]),

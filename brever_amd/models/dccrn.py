@@ -169,19 +169,27 @@ _ROWS = os.environ.get('BRV_DCCRN_ROWS', '1') != '0'      # use_amp: one-launch 
 _ROWS_GEOM = ((5, 2), (2, 1), (2, 0), (1, 0))
 
 
-def _cconv_rows(x, wc, bias, M, m_stride, c_stride, transposed):
+def _cconv_rows(x, wc, bias, M, m_stride, c_stride, transposed, x2=None, split_out=False):
     """``brv_cconv_rows``: the (5, 2) / (2, 1) / (2, 0) convolution (``transposed`` = 0) or transposed
-    convolution (1) of ``x`` (B, C, H, W) with W[m][c][i][j] = wc.flat[m*m_stride + c*c_stride + 2i + j]."""
+    convolution (1) of ``x`` (B, C, H, W) with W[m][c][i][j] = wc.flat[m*m_stride + c*c_stride + 2i + j].
+    ``x2``: the input is the skip concatenation [x[:, :s], x2[:, :s], x[:, s:], x2[:, s:]] read from its two
+    sources; ``split_out``: the M output channels are dealt the same way to two (B, M/2, ..) tensors."""
     lib = hip.lib()
     B, C, H, W = x.shape
+    seg = 0
+    if x2 is not None:
+        assert x2.shape == x.shape and C % 16 == 0
+        seg, C = C//2, 2*C
     wp = torch.empty(lib.brv_cconv_packed_bytes(M, C), dtype=torch.uint8, device=x.device)
     hip.check(lib.brv_cconv_pack(hip.ptr(wc), hip.ptr(wp), M, C, m_stride, c_stride, hip.stream()),
               'brv_cconv_pack')
-    out = torch.empty((B, M, 2*H, W + 1) if transposed else (B, M, H//2, W - 1), dtype=torch.float32,
-                      device=x.device)
-    hip.check(lib.brv_cconv_rows(hip.ptr(x), hip.ptr(wp), hip.ptr(bias), hip.ptr(out), B, C, M, H, W,
-                                 int(transposed), hip.stream()), 'brv_cconv_rows')
-    return out
+    shape = (B, M//2 if split_out else M) + ((2*H, W + 1) if transposed else (H//2, W - 1))
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    out2 = torch.empty_like(out) if split_out else None
+    hip.check(lib.brv_cconv_rows(hip.ptr(x), hip.ptr(x2), seg, hip.ptr(wp), hip.ptr(bias), hip.ptr(out),
+                                 hip.ptr(out2), M//4 if split_out else 0, B, C, M, H, W, int(transposed),
+                                 hip.stream()), 'brv_cconv_rows')
+    return (out, out2) if split_out else out
 
 
 def _cconv_wgrad(small, big, small2=None):
@@ -242,13 +250,26 @@ class _ComplexConvFunction(torch.autograd.Function):
     rebuilt there instead of being kept."""
 
     @staticmethod
-    def forward(ctx, x, wr, br, wi, bi, geom4, transpose):
+    def forward(ctx, x, wr, br, wi, bi, geom4, transpose, skip=None):
+        """``skip``: the convolution input is torch.cat([x_real, skip_real, x_imag, skip_imag], dim=1)
+        (dccrn.py:213-217); the row kernels read the two tensors in place."""
         (kh, kw), (sh, sw), (ph, pw), (oph, opw) = geom4
         geom = geom4[:3]
         lib = hip.lib()
         lowp = ctx.lowp = _AMP['on']
         x = x.contiguous()
         B, C2, H, W = x.shape
+        rows = ctx.rows = bool(lowp and _ROWS and tuple(map(tuple, geom4)) == _ROWS_GEOM
+                               and (transpose or (H % 2 == 0 and W >= 2)))
+        ctx.seg = 0
+        if skip is not None:
+            ctx.seg = C2//2
+            if rows and transpose and ctx.seg % 8 == 0:
+                skip = skip.contiguous()
+            else:                                  # the other paths work on the concatenated tensor
+                s = ctx.seg
+                x, skip = torch.cat([x[:, :s], skip[:, :s], x[:, s:], skip[:, s:]], dim=1), None
+            C2 *= 2
         Cin = C2//2
         R = wr.shape[0]
         Cw = wr[0].numel()
@@ -259,8 +280,6 @@ class _ComplexConvFunction(torch.autograd.Function):
                                               hip.stream()), 'brv_complex_weight_pack')
         bias = torch.cat([_combine(br, bi, -1.0), _combine(br, bi, 1.0)])
         khw = kh*kw
-        rows = ctx.rows = bool(lowp and _ROWS and tuple(map(tuple, geom4)) == _ROWS_GEOM
-                               and (transpose or (H % 2 == 0 and W >= 2)))
         if rows and not transpose:
             Cout = R
             Ho, Wo = H//2, W - 1
@@ -268,7 +287,7 @@ class _ComplexConvFunction(torch.autograd.Function):
         elif rows:
             Cout = wr.shape[1]
             Ho, Wo = 2*H, W + 1
-            y = _cconv_rows(x, wc, bias, 2*Cout, khw, 2*Cw, 1)
+            y = _cconv_rows(x, wc, bias, 2*Cout, khw, 2*Cw, 1, x2=skip)
         elif not transpose and lowp and _IMPLICIT:
             # the column matrix of x is read in place (brv_gemm_bf16_conv): no im2col pass, no 10x copy
             Cout = R
@@ -291,26 +310,37 @@ class _ComplexConvFunction(torch.autograd.Function):
             y = torch.empty(B, 2*Cout, Ho, Wo, dtype=torch.float32, device=x.device)
             _gemm(wc, col, y, B, 2*Cout, Ho*Wo, 2*Cw, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cw*Ho*Wo,
                   2*Cout*Ho*Wo, bias=bias, lowp=lowp)
-        ctx.save_for_backward(x, wc)
+        ctx.two = skip is not None
+        ctx.save_for_backward(x, wc, *((skip,) if ctx.two else ()))
         ctx.cfg = (geom, transpose, (H, W), (Ho, Wo), Cin, Cout, R, Cw, wr.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = hip.lib()
-        x, wc = ctx.saved_tensors
+        x, wc = ctx.saved_tensors[:2]
+        skip = ctx.saved_tensors[2] if ctx.two else None
         geom, transpose, (H, W), (Ho, Wo), Cin, Cout, R, Cw, wshape = ctx.cfg
         dy = dy.contiguous()
         B = x.shape[0]
         lowp = ctx.lowp
         khw = geom[0][0]*geom[0][1]
         dwc = None if ctx.rows else torch.empty_like(wc)
+        dskip = None
         if ctx.rows and transpose:
-            dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0)
-            dwc = _cconv_wgrad(x, dy)
+            dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0, split_out=ctx.two)
+            if ctx.two:
+                dx, dskip = dx
+            dwc = _cconv_wgrad(x, dy, small2=skip)
         elif ctx.rows:
             dx = _cconv_rows(dy, wc, None, 2*Cin, khw, 2*Cw, 1)
-            dwc = _cconv_wgrad(dy, x)
+            # (2 real input channels of the first encoder: the column-matrix kernel wastes less there)
+            if 2*Cin >= 8:
+                dwc = _cconv_wgrad(dy, x)
+            else:
+                dwc = torch.empty_like(wc)
+                _gemm_conv(dy, x, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, 1, (2*Cin, H, W), geom,
+                           (Ho, Wo), trans_b=1, kbatch=B, a_kbs=2*Cout*Ho*Wo, img_kbs=2*Cin*H*W)
         elif transpose and lowp and _IMPLICIT:
             dx = torch.empty_like(x)
             _gemm_conv(wc, dy, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, 0, 2*Cout*Ho*Wo, 2*Cin*H*W, 1,
@@ -350,7 +380,11 @@ class _ComplexConvFunction(torch.autograd.Function):
         hip.check(lib.brv_row_sum(hip.ptr(dy), hip.ptr(sums), B, 2*Cout, Ho*Wo, hip.stream()),
                   'brv_row_sum')
         sr, si = sums[:Cout].contiguous(), sums[Cout:].contiguous()
-        return dx, dwr, _combine(sr, si, 1.0), dwi, _combine(si, sr, -1.0), None, None
+        if ctx.seg and not ctx.two:          # the concatenation was materialised: deal its gradient back
+            s = ctx.seg
+            dx, dskip = (torch.cat([dx[:, :s], dx[:, 2*s:3*s]], dim=1),
+                         torch.cat([dx[:, s:2*s], dx[:, 3*s:]], dim=1))
+        return dx, dwr, _combine(sr, si, 1.0), dwi, _combine(si, sr, -1.0), None, None, dskip
 
 
 class _CombineFunction(torch.autograd.Function):
@@ -660,10 +694,10 @@ class DCCRN(BreverBaseModel):
         self.optimizer = self.init_optimizer(optimizer, lr=learning_rate)
 
     # ---- layers ------------------------------------------------------------------------
-    def _complex_conv(self, x, wrap, transpose):
+    def _complex_conv(self, x, wrap, transpose, skip=None):
         mr, mi = wrap.module_real, wrap.module_imag
         return _ComplexConvFunction.apply(x, mr.weight, mr.bias, mi.weight, mi.bias,
-                                          self.mask_net.geom, transpose)
+                                          self.mask_net.geom, transpose, skip)
 
     def _norm_act(self, x, norm, act):
         if norm is None:
@@ -710,10 +744,8 @@ class DCCRN(BreverBaseModel):
             encoder_outputs.append(x)
         x = self._lstm_block(x)
         for blk, enc in zip(net.decoder, reversed(encoder_outputs)):
-            real, imag = x.chunk(2, dim=1)
-            skip_real, skip_imag = enc.chunk(2, dim=1)
-            x = torch.cat([real, skip_real, imag, skip_imag], dim=1)
-            x = self._complex_conv(x, blk.conv, True)
+            # torch.cat([real, skip_real, imag, skip_imag], dim=1) (dccrn.py:213-217) inside the function
+            x = self._complex_conv(x, blk.conv, True, skip=enc)
             x = self._norm_act(x, blk.norm, blk.activation)
         return x
 

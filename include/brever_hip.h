@@ -334,8 +334,13 @@ int brv_gemm_bf16_conv(const float* a, const float* image, float* d, int64_t bat
 int64_t brv_cconv_packed_bytes(int64_t M, int64_t C);
 int brv_cconv_pack(const float* wc, void* wp, int64_t M, int64_t C, int64_t m_stride, int64_t c_stride,
                    brv_stream_t stream);
-int brv_cconv_rows(const float* in, const void* wp, const float* bias, float* out, int64_t B, int64_t C,
-                   int64_t M, int64_t Hin, int64_t Win, int32_t transposed, brv_stream_t stream);
+/* in_seg > 0: the input is the channel concatenation [in[:, :seg], in2[:, :seg], in[:, seg:], in2[:, seg:]] of two
+ * (B, 2 seg, Hin, Win) tensors (the decoder's skip concatenation torch.cat([real, skip_real, imag, skip_imag]),
+ * dccrn.py:213-217, never materialised), C = 4 seg, seg a multiple of 8; out_seg > 0: the output channels are dealt
+ * the same way to out and out2 (the gradient of that concatenation), M = 4 seg. 0: in2 / out2 are ignored. */
+int brv_cconv_rows(const float* in, const float* in2, int64_t in_seg, const void* wp, const float* bias, float* out,
+                   float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
+                   int32_t transposed, brv_stream_t stream);
 /* Weight gradient of both forms of brv_cconv_rows: out[a][10 c + 2 i + j] = sum_{b,h,w} small[b][a][h][w] *
  * big[b][c][2h - 2 + i][w + j], small (B, A, Hs, Ws), big (B, C, 2 Hs, Ws + 1), out (A, 10 C) fp32 (overwritten).
  * Conv2d: small = dy, big = x; ConvTranspose2d: small = x, big = dy (brever/models/dccrn/dccrn.py:225-235

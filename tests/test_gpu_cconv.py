@@ -76,6 +76,26 @@ def test_rows_convolution_without_bias_and_strided_weight_matrix():
         assert float((y - ref).norm()/ref.norm()) < 2e-5
 
 
+def test_rows_convolution_reads_and_writes_a_skip_concatenation_in_place():
+    """Input from two sources == input concatenated; output dealt to two tensors == output split."""
+    from brever_amd.models.dccrn import _cconv_rows
+    dev = _cuda()
+    g = torch.Generator().manual_seed(11)
+    B, seg, M, H, W = 2, 16, 72, 6, 140
+    x1 = torch.randn(B, 2*seg, H, W, generator=g).to(dev)
+    x2 = torch.randn(B, 2*seg, H, W, generator=g).to(dev)
+    wc = (torch.randn(M, 4*seg*10, generator=g)/(40*seg)**0.5).to(dev)
+    cat = torch.cat([x1[:, :seg], x2[:, :seg], x1[:, seg:], x2[:, seg:]], dim=1).contiguous()
+    for transposed in (0, 1):
+        one = _cconv_rows(cat, wc, None, M, 4*seg*10, 10, transposed)
+        two = _cconv_rows(x1, wc, None, M, 4*seg*10, 10, transposed, x2=x2)
+        assert torch.equal(one, two)
+        a, b = _cconv_rows(cat, wc, None, M, 4*seg*10, 10, transposed, split_out=True)
+        q = M//4
+        assert torch.equal(a, torch.cat([one[:, :q], one[:, 2*q:3*q]], dim=1))
+        assert torch.equal(b, torch.cat([one[:, q:2*q], one[:, 3*q:]], dim=1))
+
+
 WG_CASES = [  # (B, A, C, Hs, Ws)
     (2, 32, 2, 8, 37), (1, 64, 32, 4, 129), (3, 128, 64, 2, 63), (2, 256, 40, 3, 64), (1, 130, 33, 1, 1),
     (16, 96, 256, 2, 200), (1, 5, 3, 4, 500),

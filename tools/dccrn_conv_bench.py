@@ -44,16 +44,22 @@ def main():
         H, W = (H - 1)*2 - 4 + 5 + 1, W + 1
     tot_f = tot_b = 0.0
     for name, tr, cin, cout, H, W in layers:
-        x = torch.randn(B, 2*cin, H, W, device=dev, requires_grad=True)
+        skip = None
+        if tr and os.environ.get('SKIP'):        # decoder input read from its two sources (no concatenation)
+            x = torch.randn(B, cin, H, W, device=dev, requires_grad=True)
+            skip = torch.randn(B, cin, H, W, device=dev, requires_grad=True)
+        else:
+            x = torch.randn(B, 2*cin, H, W, device=dev, requires_grad=True)
         wshape = (cin, cout, 5, 2) if tr else (cout, cin, 5, 2)
         wr = (0.05*torch.randn(wshape, device=dev)).requires_grad_()
         wi = (0.05*torch.randn(wshape, device=dev)).requires_grad_()
         br = torch.zeros(cout, device=dev, requires_grad=True)
         bi = torch.zeros(cout, device=dev, requires_grad=True)
-        y = D._ComplexConvFunction.apply(x, wr, br, wi, bi, GEOM, tr)
+        y = D._ComplexConvFunction.apply(x, wr, br, wi, bi, GEOM, tr, skip)
         dy = torch.randn_like(y)
-        f = timed(lambda: D._ComplexConvFunction.apply(x, wr, br, wi, bi, GEOM, tr))
-        b = timed(lambda: torch.autograd.grad(y, (x, wr, wi, br, bi), dy, retain_graph=True))
+        f = timed(lambda: D._ComplexConvFunction.apply(x, wr, br, wi, bi, GEOM, tr, skip))
+        wrt = (x, wr, wi, br, bi) + ((skip,) if skip is not None else ())
+        b = timed(lambda: torch.autograd.grad(y, wrt, dy, retain_graph=True))
         flops = 2.0*B*(2*cin)*(2*cout)*10*(y.shape[2]*y.shape[3] if not tr else H*W)
         if os.environ.get('WGRAD'):
             # the two weight-gradient paths alone
