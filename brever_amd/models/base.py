@@ -88,7 +88,8 @@ class BreverBaseModel(nn.Module):
         return out
 
     def flat_params(self):
-        return self._flat
+        """The one buffer every parameter lives in, or None for a model that keeps separate parameters."""
+        return self._flat if self._flat_base else None
 
     def param_offsets(self):
         return self._offsets

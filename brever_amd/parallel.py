@@ -48,8 +48,9 @@ def broadcast_parameters(model, src=0):
     does in the reference, brever/training.py:63)."""
     with torch.no_grad():
         flat = getattr(model, 'flat_params', None)
-        if callable(flat):
-            dist.broadcast(model.flat_params(), src)
+        flat = flat() if callable(flat) else None
+        if flat is not None:
+            dist.broadcast(flat, src)
             model.mark_params_changed()
         else:
             for p in model.parameters():
