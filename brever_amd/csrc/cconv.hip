@@ -225,7 +225,211 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
     }
 }
 
-template <int MF, int NF, int WM, int WN, bool SEG>
+// ---- the same tile with a leaner loader (LEAN): every staging item is ONE unconditional 16-byte load (quads that
+// meet the row end load the last four frames of the row and are moved into place at store time, rows and quads
+// outside the image are never stored: their LDS slots keep the zeros of the prologue), so that there is no
+// second load path into the same registers and no control flow between loads -- either makes hipcc drain the
+// whole load queue (s_waitcnt vmcnt(0)) in front of every load. Measured per launch shape (tools/dccrn_conv_bench.py):
+// faster wherever the input comes from two tensors or M <= 64, slower on the 256-row tiles.
+template <int MF, int NF, int WM, int WN, int NTAP, bool SEG, bool TINY>
+__device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned char* lds, int b, int r, int ftile,
+                                           int mtile, const int (&tap_i)[NTAP], const int (&tap_row)[NTAP],
+                                           int shift) {
+  constexpr int NT = 32*NF*WN;               // output frames per workgroup
+  constexpr int TILES = NT/128;              // 128-column images side by side
+  constexpr int IT = NT/128;                 // 16-byte staging items per thread and tap
+  constexpr int TAPB = TILES*4096, BUFB = CC_KH*TAPB;
+  static_assert(WM*WN == 8 && NT % 128 == 0, "8 waves, whole images");
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int f0 = ftile*NT;
+  const float* in_b = p.in + (long long)b*p.in_bs;
+  const float* in2_b = SEG && p.in_seg > 0 ? p.in2 + (long long)b*p.in_bs : nullptr;
+
+  // ---- staging items: (image, channel, frame quad). Everything that does not depend on the chunk or the tap
+  // is computed once, and every item is ONE 16-byte load under its lane mask: a second (element-wise) path
+  // into the same registers makes hipcc drain the load queue (s_waitcnt vmcnt(0)) in front of every load.
+  // kind 0: no frame of the quad exists (its LDS slot keeps the zeros of the prologue); 1: the whole quad;
+  // 2 + d: the row ends inside the quad: the last four frames of the row are loaded and moved down by d at
+  // store time; 6: the quad starts at frame -1 (transposed form): frames 0..3 are loaded and moved up by one.
+  const int plane = p.Hin*p.Win;
+  int s_c[IT], s_off[IT], s_voff[IT], s_kind[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int e = tid + CC_THREADS*it;
+    const int img = e / (2*NT), rem = e % (2*NT);
+    const int c = rem / (NT/4), q = rem % (NT/4);
+    const int col = 4*q, cw = col & 127;
+    const int f = f0 + col + shift*img;
+    int kind = 0, fl = 0;
+    if (TINY) { kind = 1; fl = f; }
+    else if (f >= 0 && f + 3 < p.Win) { kind = 1; fl = f; }
+    else if (f >= 0 && f < p.Win) { kind = 2 + f - (p.Win - 4); fl = p.Win - 4; }
+    else if (f == -1) { kind = 6; fl = 0; }
+    s_c[it] = c;
+    s_kind[it] = kind;
+    s_voff[it] = kind ? (c*plane + fl)*4 : 0;       // lanes with nothing to load read the row base (ignored)
+    s_off[it] = (col >> 7)*4096 + cc_off(8*img + c, cw >> 3) + 8*((cw >> 2) & 1);
+  }
+  bool tap_ok[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) tap_ok[t] = tap_row[t] >= 0 && tap_row[t] < p.Hin;
+  // rows / quads that are never written hold zeros
+  for (int e = tid; e < 2*BUFB/16; e += CC_THREADS) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+
+  float4 st[NTAP][IT];
+  auto stage_load = [&](int cc) {
+    // source tensor and channel offset of this chunk of 8 (never straddles two segments: seg % 8 == 0)
+    const float* base = in_b;
+    int ch0 = 8*cc;
+    if (SEG && p.in_seg > 0) {
+      const int sg = (ch0 >= p.in_seg) + (ch0 >= 2*p.in_seg) + (ch0 >= 3*p.in_seg);
+      ch0 -= ((sg + 1) >> 1)*p.in_seg;
+      if (sg & 1) base = in2_b;
+    }
+    const int nch = p.C - 8*cc;                     // channels of this chunk that exist (>= 8 but for the last one)
+    const char* cbase = reinterpret_cast<const char*>(base + (long long)ch0*plane);
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      // no branch around a load (rows outside the image read row 0 and are not stored): with control flow
+      // between loads hipcc falls back to s_waitcnt vmcnt(0) in front of each of them
+      const char* rbase = cbase + (long long)(tap_ok[t] ? tap_row[t] : 0)*p.Win*4;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        if (TINY) {                                 // images narrower than a quad: element by element
+          const float* src = reinterpret_cast<const float*>(rbase + (long long)s_c[it]*plane*4);
+          const int f = (s_voff[it] >> 2) - s_c[it]*plane;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (s_c[it] < nch) {
+            if (f >= 0 && f < p.Win) v.x = src[f];
+            if (f + 1 >= 0 && f + 1 < p.Win) v.y = src[f + 1];
+            if (f + 2 >= 0 && f + 2 < p.Win) v.z = src[f + 2];
+            if (f + 3 >= 0 && f + 3 < p.Win) v.w = src[f + 3];
+          }
+          st[t][it] = v;
+        } else {
+          typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+          const int vo = s_c[it] < nch ? s_voff[it] : 0;
+          const f32x4u w = *reinterpret_cast<const f32x4u*>(rbase + vo);
+          st[t][it] = make_float4(w.x, w.y, w.z, w.w);
+        }
+      }
+    }
+  };
+  auto stage_store = [&](int buf, int cc) {
+    const int nch = p.C - 8*cc;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      if (!tap_ok[t]) continue;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        if (s_kind[it] == 0) continue;
+        float4 v = st[t][it];
+        if (!TINY) {
+          if (s_kind[it] > 1) {                     // a lane or two per row
+            const int k = s_kind[it];
+            if (k == 6) v = make_float4(0.f, v.x, v.y, v.z);
+            else if (k == 3) v = make_float4(v.y, v.z, v.w, 0.f);
+            else if (k == 4) v = make_float4(v.z, v.w, 0.f, 0.f);
+            else v = make_float4(v.w, 0.f, 0.f, 0.f);
+          }
+          if (nch < 8 && s_c[it] >= nch) v = make_float4(0.f, 0.f, 0.f, 0.f);   // last chunk of an odd channel count
+        }
+        *reinterpret_cast<uint2*>(lds + buf*BUFB + t*TAPB + s_off[it]) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+      }
+    }
+  };
+
+  // ---- weights: fragments of this wave's MF row groups, (chunk, tap) two k steps ahead
+  const int mfrag0 = (mtile*WM + wm)*MF;
+  const uint4* wq[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {         // row groups past M: any packed group (their outputs are not stored)
+    const int fr = mfrag0 + mf < p.mfrags ? mfrag0 + mf : p.mfrags - 1;
+    wq[mf] = p.wp + (long long)fr*p.ncc*CC_KH*64 + lane;
+  }
+  auto a_load = [&](int cc, int t, uint4 (&dst)[MF]) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) dst[mf] = wq[mf][(cc*CC_KH + tap_i[t])*64];
+  };
+
+  f32x16 acc[MF][NF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+
+  // weight fragments of tap t live in slot t: the slot is refilled with the NEXT chunk's fragment as soon as
+  // its MFMAs are issued, i.e. NTAP k steps (one chunk) ahead of its use -- L2 latency, not bandwidth, is what
+  // the MFMAs wait for otherwise (and a rotating ring costs 16 v_mov per k step)
+  uint4 a0[MF], a1[MF], a2[MF];
+  a_load(0, 0, a0);
+  if (NTAP > 1) a_load(0, 1 % NTAP, a1); else if (p.ncc > 1) a_load(1, 0, a1);
+  stage_load(0);
+  stage_store(0, 0);
+  __syncthreads();
+
+  for (int cc = 0; cc < p.ncc; ++cc) {
+    const unsigned char* cur = lds + (cc & 1)*BUFB;
+    const bool more = cc + 1 < p.ncc;
+    const int nxt = more ? cc + 1 : cc;            // the last chunk is requested once more instead of branching
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      if (t + 2 < NTAP) a_load(cc, (t + 2) % NTAP, a2);
+      else a_load(nxt, (t + 2) % NTAP, a2);
+      if (t == 0) stage_load(nxt);
+      bf16x8 bq[NF];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int col0 = 32*(wn*NF + nf);
+        bq[nf] = cc_frag(cur + t*TAPB + (col0 >> 7)*4096, col0 & 127, lane);
+      }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, a0[mf]);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[nf], acc[mf][nf], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) { a0[mf] = a1[mf]; a1[mf] = a2[mf]; }
+    }
+    if (more) stage_store((cc + 1) & 1, cc + 1);
+    __syncthreads();
+  }
+
+  // ---- D[m][frame] -> out[b][m][r][frame] (+ bias)
+  float* out_b = p.out + (long long)b*p.out_bs;
+  float* out2_b = SEG && p.out_seg > 0 ? p.out2 + (long long)b*p.out_bs : nullptr;
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int w = f0 + 32*(wn*NF + nf) + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = 32*(mfrag0 + mf) + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
+        if (m < p.M && w < p.Wout) {
+          float v = acc[mf][nf][i];
+          if (p.bias) v += p.bias[m];
+          float* dst = out_b;
+          int mc = m;
+          if (SEG && p.out_seg > 0) {
+            const int sg = (m >= p.out_seg) + (m >= 2*p.out_seg) + (m >= 3*p.out_seg);
+            mc -= ((sg + 1) >> 1)*p.out_seg;
+            if (sg & 1) dst = out2_b;
+          }
+          dst[((long long)mc*p.Hout + r)*p.Wout + w] = v;
+        }
+      }
+    }
+}
+
+
+template <int MF, int NF, int WM, int WN, bool SEG, bool LEAN, bool TINY = false>
 __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParams p) {
   constexpr int NT = 32*NF*WN;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2*CC_KH*(NT/128)*4096];
@@ -234,15 +438,18 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParam
   if (p.mode == 0) {
     const int ti[5] = {0, 1, 2, 3, 4};
     const int tr[5] = {2*r - 2, 2*r - 1, 2*r, 2*r + 1, 2*r + 2};
-    cconv_tile<MF, NF, WM, WN, 5, SEG>(p, lds, b, r, ftile, mtile, ti, tr, 1);
+    if (LEAN) cconv_tile_lean<MF, NF, WM, WN, 5, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, 1);
+    else cconv_tile<MF, NF, WM, WN, 5, SEG>(p, lds, b, r, ftile, mtile, ti, tr, 1);
   } else if (r & 1) {
     const int ti[2] = {1, 3};
     const int tr[2] = {(r + 1) >> 1, (r - 1) >> 1};
-    cconv_tile<MF, NF, WM, WN, 2, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    if (LEAN) cconv_tile_lean<MF, NF, WM, WN, 2, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    else cconv_tile<MF, NF, WM, WN, 2, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
   } else {
     const int ti[3] = {0, 2, 4};
     const int tr[3] = {(r >> 1) + 1, r >> 1, (r >> 1) - 1};
-    cconv_tile<MF, NF, WM, WN, 3, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    if (LEAN) cconv_tile_lean<MF, NF, WM, WN, 3, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    else cconv_tile<MF, NF, WM, WN, 3, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
   }
 }
 
@@ -476,9 +683,15 @@ int brv_cconv_rows(const float* in, const float* in2, int64_t in_seg, const void
     constexpr int MT = 32*MF_*WM_, NT = 32*NF_*WN_; \
     p.mtiles = (int)((M + MT - 1)/MT); p.ftiles = (p.Wout + NT - 1)/NT; \
     const dim3 grid(p.ftiles, p.Hout, (unsigned)(B*p.mtiles)); \
-    if (in_seg > 0 || out_seg > 0) hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, true>), grid, dim3(CC_THREADS), 0, st, p); \
-    else hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, false>), grid, dim3(CC_THREADS), 0, st, p); } while (0)
-  if (M > 128) {
+    if (in_seg > 0 || out_seg > 0) hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, true, true>), grid, dim3(CC_THREADS), 0, st, p); \
+    else if (MT <= 64) hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, false, true>), grid, dim3(CC_THREADS), 0, st, p); \
+    else hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, false, false>), grid, dim3(CC_THREADS), 0, st, p); } while (0)
+  if (Win < 4) {            // narrower than a staging quad: the element-wise loader, one workgroup shape
+    constexpr int MT = 64, NT = 256;
+    p.mtiles = (int)((M + MT - 1)/MT); p.ftiles = (p.Wout + NT - 1)/NT;
+    hipLaunchKernelGGL((cconv_rows_kernel<2, 1, 1, 8, true, true, true>), dim3(p.ftiles, p.Hout, (unsigned)(B*p.mtiles)),
+                       dim3(CC_THREADS), 0, st, p);
+  } else if (M > 128) {
     const long long wgs = (long long)((p.Wout + 255)/256)*p.Hout*B*((M + 255)/256);
     if (wgs < 256) CC_LAUNCH(2, 2, 4, 2); else CC_LAUNCH(2, 4, 4, 2);
   } else if (M > 64) CC_LAUNCH(2, 2, 2, 4);
