@@ -6,7 +6,7 @@
 #   --pmc passes (never combined with other trace domains); tools/rows_roofline.py turns each triple into
 #   a `roofline` object of the row's dominant kernel (measured traffic per launch / average duration).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
