@@ -24,6 +24,9 @@ namespace {
 using namespace brv;
 
 constexpr int CC_THREADS = 512;
+#ifndef CC_PAIR
+#define CC_PAIR 1      // transposed form with M <= 128: two output rows per workgroup (0: one, for A/B runs)
+#endif
 constexpr int CC_KH = 5;
 
 struct CConvParams {
@@ -231,10 +234,15 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
 // second load path into the same registers and no control flow between loads -- either makes hipcc drain the
 // whole load queue (s_waitcnt vmcnt(0)) in front of every load. Measured per launch shape (tools/dccrn_conv_bench.py):
 // faster wherever the input comes from two tensors or M <= 64, slower on the 256-row tiles.
-template <int MF, int NF, int WM, int WN, int NTAP, bool SEG, bool TINY>
+// PAIR (transposed form, M <= 128): one workgroup computes BOTH output rows 2r and 2r + 1 from the three input
+// rows r + 1, r, r - 1 they share (slots 0..2; products t = 0..4 = weight taps 0..4, tap t reads slot t >> 1 and
+// adds to the accumulator set t & 1): 1.5 staged rows per output row instead of 2.5.
+template <int MF, int NF, int WM, int WN, int NTAP, bool SEG, bool TINY, bool PAIR = false>
 __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned char* lds, int b, int r, int ftile,
-                                           int mtile, const int (&tap_i)[NTAP], const int (&tap_row)[NTAP],
+                                           int mtile, const int (&tap_i)[NTAP], const int (&tap_row)[PAIR ? 3 : NTAP],
                                            int shift) {
+  constexpr int NSLOT = PAIR ? 3 : NTAP, NSET = PAIR ? 2 : 1;
+  static_assert(!PAIR || NTAP == 5, "pair form: five taps");
   constexpr int NT = 32*NF*WN;               // output frames per workgroup
   constexpr int TILES = NT/128;              // 128-column images side by side
   constexpr int IT = NT/128;                 // 16-byte staging items per thread and tap
@@ -271,14 +279,14 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
     s_voff[it] = kind ? (c*plane + fl)*4 : 0;       // lanes with nothing to load read the row base (ignored)
     s_off[it] = (col >> 7)*4096 + cc_off(8*img + c, cw >> 3) + 8*((cw >> 2) & 1);
   }
-  bool tap_ok[NTAP];
+  bool tap_ok[NSLOT];
 #pragma unroll
-  for (int t = 0; t < NTAP; ++t) tap_ok[t] = tap_row[t] >= 0 && tap_row[t] < p.Hin;
+  for (int t = 0; t < NSLOT; ++t) tap_ok[t] = tap_row[t] >= 0 && tap_row[t] < p.Hin;
   // rows / quads that are never written hold zeros
   for (int e = tid; e < 2*BUFB/16; e += CC_THREADS) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
 
-  float4 st[NTAP][IT];
+  float4 st[NSLOT][IT];
   auto stage_load = [&](int cc) {
     // source tensor and channel offset of this chunk of 8 (never straddles two segments: seg % 8 == 0)
     const float* base = in_b;
@@ -291,7 +299,7 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
     const int nch = p.C - 8*cc;                     // channels of this chunk that exist (>= 8 but for the last one)
     const char* cbase = reinterpret_cast<const char*>(base + (long long)ch0*plane);
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t) {
+    for (int t = 0; t < NSLOT; ++t) {
       // no branch around a load (rows outside the image read row 0 and are not stored): with control flow
       // between loads hipcc falls back to s_waitcnt vmcnt(0) in front of each of them
       const char* rbase = cbase + (long long)(tap_ok[t] ? tap_row[t] : 0)*p.Win*4;
@@ -320,7 +328,7 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
   auto stage_store = [&](int buf, int cc) {
     const int nch = p.C - 8*cc;
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t) {
+    for (int t = 0; t < NSLOT; ++t) {
       if (!tap_ok[t]) continue;
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
@@ -354,13 +362,15 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
     for (int mf = 0; mf < MF; ++mf) dst[mf] = wq[mf][(cc*CC_KH + tap_i[t])*64];
   };
 
-  f32x16 acc[MF][NF];
+  f32x16 acc[NSET][MF][NF];
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
+  for (int st_ = 0; st_ < NSET; ++st_)
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[st_][mf][nf][i] = 0.f;
 
   // weight fragments of tap t live in slot t: the slot is refilled with the NEXT chunk's fragment as soon as
   // its MFMAs are issued, i.e. NTAP k steps (one chunk) ahead of its use -- L2 latency, not bandwidth, is what
@@ -376,23 +386,26 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
     const unsigned char* cur = lds + (cc & 1)*BUFB;
     const bool more = cc + 1 < p.ncc;
     const int nxt = more ? cc + 1 : cc;            // the last chunk is requested once more instead of branching
+    bf16x8 bq[NF];
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
       if (t + 2 < NTAP) a_load(cc, (t + 2) % NTAP, a2);
       else a_load(nxt, (t + 2) % NTAP, a2);
       if (t == 0) stage_load(nxt);
-      bf16x8 bq[NF];
+      const int slot = PAIR ? (t >> 1) : t, set = PAIR ? (t & 1) : 0;
+      if (!PAIR || (t & 1) == 0) {                  // (the odd tap of a pair reads the fragments of the even one)
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const int col0 = 32*(wn*NF + nf);
-        bq[nf] = cc_frag(cur + t*TAPB + (col0 >> 7)*4096, col0 & 127, lane);
+        for (int nf = 0; nf < NF; ++nf) {
+          const int col0 = 32*(wn*NF + nf);
+          bq[nf] = cc_frag(cur + slot*TAPB + (col0 >> 7)*4096, col0 & 127, lane);
+        }
       }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
         const bf16x8 af = __builtin_bit_cast(bf16x8, a0[mf]);
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[nf], acc[mf][nf], 0, 0, 0);
+          acc[set][mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[nf], acc[set][mf][nf], 0, 0, 0);
       }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) { a0[mf] = a1[mf]; a1[mf] = a2[mf]; }
@@ -401,35 +414,38 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
     __syncthreads();
   }
 
-  // ---- D[m][frame] -> out[b][m][r][frame] (+ bias)
+  // ---- D[m][frame] -> out[b][m][row][frame] (+ bias)
   float* out_b = p.out + (long long)b*p.out_bs;
   float* out2_b = SEG && p.out_seg > 0 ? p.out2 + (long long)b*p.out_bs : nullptr;
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf)
+  for (int set = 0; set < NSET; ++set) {
+    const int orow = PAIR ? 2*r + set : r;
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const int w = f0 + 32*(wn*NF + nf) + (lane & 31);
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int m = 32*(mfrag0 + mf) + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
-        if (m < p.M && w < p.Wout) {
-          float v = acc[mf][nf][i];
-          if (p.bias) v += p.bias[m];
-          float* dst = out_b;
-          int mc = m;
-          if (SEG && p.out_seg > 0) {
-            const int sg = (m >= p.out_seg) + (m >= 2*p.out_seg) + (m >= 3*p.out_seg);
-            mc -= ((sg + 1) >> 1)*p.out_seg;
-            if (sg & 1) dst = out2_b;
+      for (int nf = 0; nf < NF; ++nf) {
+        const int w = f0 + 32*(wn*NF + nf) + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = 32*(mfrag0 + mf) + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
+          if (m < p.M && w < p.Wout) {
+            float v = acc[set][mf][nf][i];
+            if (p.bias) v += p.bias[m];
+            float* dst = out_b;
+            int mc = m;
+            if (SEG && p.out_seg > 0) {
+              const int sg = (m >= p.out_seg) + (m >= 2*p.out_seg) + (m >= 3*p.out_seg);
+              mc -= ((sg + 1) >> 1)*p.out_seg;
+              if (sg & 1) dst = out2_b;
+            }
+            dst[((long long)mc*p.Hout + orow)*p.Wout + w] = v;
           }
-          dst[((long long)mc*p.Hout + r)*p.Wout + w] = v;
         }
       }
-    }
+  }
 }
 
-
-template <int MF, int NF, int WM, int WN, bool SEG, bool LEAN, bool TINY = false>
+template <int MF, int NF, int WM, int WN, bool SEG, bool LEAN, bool TINY = false, bool PAIR = false>
 __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParams p) {
   constexpr int NT = 32*NF*WN;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2*CC_KH*(NT/128)*4096];
@@ -453,6 +469,10 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParam
     const int tr[5] = {2*r - 2, 2*r - 1, 2*r, 2*r + 1, 2*r + 2};
     if (LEAN) cconv_tile_lean<MF, NF, WM, WN, 5, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, 1);
     else cconv_tile<MF, NF, WM, WN, 5, SEG>(p, lds, b, r, ftile, mtile, ti, tr, 1);
+  } else if (PAIR) {                 // output rows 2r and 2r + 1 from input rows r + 1, r, r - 1
+    const int ti[5] = {0, 1, 2, 3, 4};
+    const int tr[3] = {r + 1, r, r - 1};
+    cconv_tile_lean<MF, NF, WM, WN, 5, SEG, TINY, true>(p, lds, b, r, ftile, mtile, ti, tr, -1);
   } else if (r & 1) {
     const int ti[2] = {1, 3};
     const int tr[2] = {(r + 1) >> 1, (r - 1) >> 1};
@@ -667,6 +687,27 @@ __global__ __launch_bounds__(256) void cconv_wgrad_reduce_kernel(const float* pa
   }
 }
 
+// which tile function a launch shape runs (measured per layer, tools/dccrn_conv_bench.py): the lean loader for
+// two-source inputs / split outputs and for M <= 64; the pair form of the transposed convolution for M <= 128
+template <int MF, int NF, int WM, int WN>
+static void cconv_launch(CConvParams& p, int64_t B, int64_t M, bool transposed, bool seg, hipStream_t st) {
+  constexpr int MT = 32*MF*WM, NT = 32*NF*WN;
+  p.mtiles = (int)((M + MT - 1)/MT); p.ftiles = (p.Wout + NT - 1)/NT;
+  const dim3 grid(p.ftiles, p.Hout, (unsigned)(B*p.mtiles)), block(CC_THREADS);
+  if constexpr (MT <= 128 && CC_PAIR) {
+    // (measured exceptions: M = 128 from one source and M = 64 from two sources are as fast / faster row by row)
+    if (transposed && (MT <= 32 || (MT == 64) != seg)) {
+      const dim3 gp(p.ftiles, p.Hout/2, (unsigned)(B*p.mtiles));
+      if (seg) hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, true, true, false, true>), gp, block, 0, st, p);
+      else hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, false, true, false, true>), gp, block, 0, st, p);
+      return;
+    }
+  }
+  if (seg) hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, true, true>), grid, block, 0, st, p);
+  else if (MT <= 64) hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, false, true>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, false, false>), grid, block, 0, st, p);
+}
+
 }  // namespace
 
 extern "C" {
@@ -702,13 +743,7 @@ int brv_cconv_rows(const float* in, const float* in2, int64_t in_seg, const void
   p.mode = transposed ? 1 : 0;
   p.ncc = (int)((C + 7)/8); p.mfrags = (int)((M + 31)/32);
   hipStream_t st = (hipStream_t)stream;
-#define CC_LAUNCH(MF_, NF_, WM_, WN_) do { \
-    constexpr int MT = 32*MF_*WM_, NT = 32*NF_*WN_; \
-    p.mtiles = (int)((M + MT - 1)/MT); p.ftiles = (p.Wout + NT - 1)/NT; \
-    const dim3 grid(p.ftiles, p.Hout, (unsigned)(B*p.mtiles)); \
-    if (in_seg > 0 || out_seg > 0) hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, true, true>), grid, dim3(CC_THREADS), 0, st, p); \
-    else if (MT <= 64) hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, false, true>), grid, dim3(CC_THREADS), 0, st, p); \
-    else hipLaunchKernelGGL((cconv_rows_kernel<MF_, NF_, WM_, WN_, false, false>), grid, dim3(CC_THREADS), 0, st, p); } while (0)
+#define CC_LAUNCH(MF_, NF_, WM_, WN_) cconv_launch<MF_, NF_, WM_, WN_>(p, B, M, transposed != 0, in_seg > 0 || out_seg > 0, st)
   if (Win < 4) {            // narrower than a staging quad: the element-wise loader, one workgroup shape
     constexpr int MT = 64, NT = 256;
     p.mtiles = (int)((M + MT - 1)/MT); p.ftiles = (p.Wout + NT - 1)/NT;

@@ -33,6 +33,7 @@ def _run(x, w_mcij, bias, transposed):
 CASES = [
     (2, 2, 32, 16, 37), (1, 32, 64, 8, 129), (2, 64, 128, 8, 300), (1, 128, 256, 4, 257),
     (16, 24, 256, 8, 131), (1, 5, 3, 4, 9), (1, 13, 70, 2, 2), (3, 40, 130, 6, 513), (1, 256, 512, 4, 64),
+    (2, 20, 64, 5, 70), (1, 9, 100, 3, 260),      # odd input heights: first / last row pairs of the pair form
 ]
 
 
@@ -41,6 +42,8 @@ CASES = [
 def test_rows_convolution_equals_float64_convolution_of_the_rounded_operands(case, transposed):
     dev = _cuda()
     B, C, M, H, W = case
+    if not transposed and H % 2:
+        H += 1                      # the strided form is defined on even heights (brv_cconv_rows)
     g = torch.Generator().manual_seed(B*1000 + C*10 + M + H + W + transposed)
     x = torch.randn(B, C, H, W, generator=g)
     w = torch.randn(M, C, 5, 2, generator=g)/(C*10)**0.5
