@@ -452,7 +452,7 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParam
   // XCD-aware order: workgroups are dealt to the 8 XCDs (one L2 each) round-robin by linear id; the remap gives
   // every XCD a CONTIGUOUS run of (frame tile, output row) pairs, so that the input rows neighbouring output
   // rows share (5 of them per row in the transposed form) are fetched into one L2 once instead of into several
-  // (measured fabric traffic was 2 - 4.5x the algorithmic bytes without it: profiles/r04_rows_dccrn_bf16_*)
+  // (measured fabric traffic was 2 - 4.5x the algorithmic bytes without it: profiles/r04_rows_dccrn_bf16_pmc_hbm_traffic_before_xcd_order.json)
   int ftile = blockIdx.x, r = blockIdx.y, bz = blockIdx.z;
   {
     const unsigned total = gridDim.x*gridDim.y*gridDim.z;
