@@ -404,6 +404,22 @@ class _CombineFunction(torch.autograd.Function):
         return g, ctx.sign*g if ctx.sign != 1.0 else g, None
 
 
+class _ForkFunction(torch.autograd.Function):
+    """One tensor, two consumers (an encoder output feeds the next block AND the decoder's skip input,
+    dccrn.py:205-217): the two gradients are summed by ``brv_combine`` instead of the autograd engine's
+    ``at::add``."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view(x.shape), x.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        return _combine(g1.contiguous(), g2.contiguous(), 1.0)
+
+
 class _BatchNormActFunction(torch.autograd.Function):
     """nn.BatchNorm2d followed by an optional scalar nn.PReLU (dccrn.py:251-254, 284-289)."""
 
@@ -741,7 +757,10 @@ class DCCRN(BreverBaseModel):
         encoder_outputs = []
         for blk in net.encoder:
             x = self._norm_act(self._complex_conv(x, blk.conv, False), blk.norm, blk.activation)
-            encoder_outputs.append(x)
+            skip = x
+            if x.requires_grad:
+                x, skip = _ForkFunction.apply(x)
+            encoder_outputs.append(skip)
         x = self._lstm_block(x)
         for blk, enc in zip(net.decoder, reversed(encoder_outputs)):
             # torch.cat([real, skip_real, imag, skip_imag], dim=1) (dccrn.py:213-217) inside the function
