@@ -55,7 +55,7 @@ def sgmse_row(seconds, steps):
     torch.manual_seed(0)
     model = ModelRegistry.get('sgmsep')(solver_num_steps=steps).to(dev).eval()
     out = {}
-    for amp, batch in ((True, 1), (True, 8), (False, 1)):
+    for amp, batch in ((True, 1), (True, 8), (True, 32), (False, 1)):
         wav = 0.1*torch.randn(batch, 2, int(seconds*16000), device=dev)
         model.enhance(wav, use_amp=amp)                  # captures the HIP graph of this shape
         dt = timed(lambda: model.enhance(wav, use_amp=amp), 0, 1)
