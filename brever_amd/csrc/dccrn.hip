@@ -663,8 +663,10 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* a, const floa
 // DCCRN.apply_mask (dccrn.py:96-109): polar product with a tanh-bounded mask magnitude
 __global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* xr, const float* xi,
                                                          const float* mr, const float* mi,
-                                                         float2* out, long long n) {
-  GRID_STRIDE(i, n) {
+                                                         float2* out, long long n, long long bs) {
+  // blockIdx.y = batch item: (real | imaginary) planes of x and of the mask are bs floats apart per item
+  xr += blockIdx.y*bs; xi += blockIdx.y*bs; mr += blockIdx.y*bs; mi += blockIdx.y*bs; out += blockIdx.y*n;
+  for (long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x) {
     const float a = xr[i], b = xi[i];
     const float in_mag = sqrtf(a*a + b*b), in_phase = atan2f(b, a);
     float pr = mr[i];
@@ -996,8 +998,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* act, const f
 __global__ __launch_bounds__(256) void dccrn_mask_bwd_kernel(const float* xr, const float* xi,
                                                              const float* mr, const float* mi,
                                                              const float2* gout, float* dmr,
-                                                             float* dmi, long long n) {
-  GRID_STRIDE(i, n) {
+                                                             float* dmi, long long n, long long bs) {
+  xr += blockIdx.y*bs; xi += blockIdx.y*bs; mr += blockIdx.y*bs; mi += blockIdx.y*bs; gout += blockIdx.y*n;
+  dmr += blockIdx.y*bs; dmi += blockIdx.y*bs;
+  for (long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x*blockDim.x) {
     const float a = xr[i], b = xi[i];
     const float in_mag = sqrtf(a*a + b*b), in_phase = atan2f(b, a);
     const float pr0 = mr[i], pi = mi[i];
@@ -1036,6 +1040,17 @@ __global__ __launch_bounds__(256) void env_divide_kernel(const float* dy, const 
   }
 }
 
+// bias of the packed complex layer: [br - bi | br + bi] (dccrn.py:231-235: real = M_r(x_r) - M_i(x_i), imag = M_r(x_i) +
+// M_i(x_r), each module adds its own bias), and its adjoint on the channel sums s = [s_r | s_i] of the output gradient:
+// d br = s_r + s_i, d bi = s_i - s_r
+__global__ __launch_bounds__(256) void cbias_pack_kernel(const float* br, const float* bi, float* out, int C) {
+  const int c = blockIdx.x*256 + threadIdx.x;
+  if (c < C) { out[c] = br[c] - bi[c]; out[C + c] = br[c] + bi[c]; }
+}
+__global__ __launch_bounds__(256) void cbias_unpack_kernel(const float* s, float* dbr, float* dbi, int C) {
+  const int c = blockIdx.x*256 + threadIdx.x;
+  if (c < C) { dbr[c] = s[c] + s[C + c]; dbi[c] = s[C + c] - s[c]; }
+}
 int red_slices(long long n) {
   long long s = (n + 16383)/16384;
   return (int)(s < 1 ? 1 : (s > kRedSlices ? kRedSlices : s));
@@ -1155,7 +1170,19 @@ int brv_dccrn_apply_mask(const float* xr, const float* xi, const float* mr, cons
                          float* out, int64_t n, brv_stream_t stream) {
   if (n < 1) return -1;
   hipLaunchKernelGGL(dccrn_mask_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, xr, xi,
-                     mr, mi, (float2*)out, (long long)n);
+                     mr, mi, (float2*)out, (long long)n, 0LL);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_dccrn_apply_mask_batched(const float* x, const float* mask, float* out, int64_t B, int64_t n,
+                                 brv_stream_t stream) {
+  if (!x || !mask || !out || B < 1 || B > 65535 || n < 1) return -1;
+  dim3 grid = flat_grid(n);
+  if (grid.x > 4096) grid.x = 4096;
+  grid.y = (unsigned)B;
+  hipLaunchKernelGGL(dccrn_mask_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x + n, mask, mask + n,
+                     (float2*)out, (long long)n, (long long)(2*n));
   DC_OK(hipGetLastError());
   return 0;
 }
@@ -1240,7 +1267,19 @@ int brv_dccrn_apply_mask_backward(const float* xr, const float* xi, const float*
                                   int64_t n, brv_stream_t stream) {
   if (n < 1) return -1;
   hipLaunchKernelGGL(dccrn_mask_bwd_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, xr,
-                     xi, mr, mi, (const float2*)gout, dmr, dmi, (long long)n);
+                     xi, mr, mi, (const float2*)gout, dmr, dmi, (long long)n, 0LL);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_dccrn_apply_mask_backward_batched(const float* x, const float* mask, const float* gout, float* dmask,
+                                          int64_t B, int64_t n, brv_stream_t stream) {
+  if (!x || !mask || !gout || !dmask || B < 1 || B > 65535 || n < 1) return -1;
+  dim3 grid = flat_grid(n);
+  if (grid.x > 4096) grid.x = 4096;
+  grid.y = (unsigned)B;
+  hipLaunchKernelGGL(dccrn_mask_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x + n, mask, mask + n,
+                     (const float2*)gout, dmask, dmask + n, (long long)n, (long long)(2*n));
   DC_OK(hipGetLastError());
   return 0;
 }
@@ -1322,6 +1361,21 @@ int brv_complex_weight_unpack(const float* dwc, float* dwr, float* dwi, int64_t 
   if (R < 1 || C < 1) return -1;
   hipLaunchKernelGGL(cweight_unpack_kernel, flat_grid(R*C), dim3(256), 0, (hipStream_t)stream, dwc,
                      dwr, dwi, (int)R, (int)C, sign);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_complex_bias_pack(const float* br, const float* bi, float* out, int64_t C, brv_stream_t stream) {
+  if (!br || !bi || !out || C < 1) return -1;
+  hipLaunchKernelGGL(cbias_pack_kernel, dim3((unsigned)((C + 255)/256)), dim3(256), 0, (hipStream_t)stream, br, bi,
+                     out, (int)C);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+int brv_complex_bias_unpack(const float* sums, float* dbr, float* dbi, int64_t C, brv_stream_t stream) {
+  if (!sums || !dbr || !dbi || C < 1) return -1;
+  hipLaunchKernelGGL(cbias_unpack_kernel, dim3((unsigned)((C + 255)/256)), dim3(256), 0, (hipStream_t)stream, sums,
+                     dbr, dbi, (int)C);
   DC_OK(hipGetLastError());
   return 0;
 }

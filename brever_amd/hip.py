@@ -247,6 +247,10 @@ SIGNATURES = {
                                 + [_c_f32, _c_ptr]),
     'brv_gemm_bf16_conv': (ctypes.c_int, [_c_ptr]*3 + [_c_i64]*9 + [ctypes.c_int, ctypes.c_int]
                            + [_c_i64]*3 + [_c_ptr, ctypes.c_int, ctypes.c_int] + [_c_i64]*11 + [_c_ptr]),
+    'brv_dccrn_apply_mask_batched': (ctypes.c_int, [_c_ptr]*3 + [_c_i64, _c_i64, _c_ptr]),
+    'brv_dccrn_apply_mask_backward_batched': (ctypes.c_int, [_c_ptr]*4 + [_c_i64, _c_i64, _c_ptr]),
+    'brv_complex_bias_pack': (ctypes.c_int, [_c_ptr]*3 + [_c_i64, _c_ptr]),
+    'brv_complex_bias_unpack': (ctypes.c_int, [_c_ptr]*3 + [_c_i64, _c_ptr]),
     'brv_cconv_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_cconv_pack': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*4 + [_c_ptr]),
     'brv_cconv_rows': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_i64]*6

@@ -278,7 +278,10 @@ class _ComplexConvFunction(torch.autograd.Function):
         hip.check(lib.brv_complex_weight_pack(hip.ptr(wr_c), hip.ptr(wi_c),
                                               hip.ptr(wc), R, Cw, -1.0 if transpose else 1.0,
                                               hip.stream()), 'brv_complex_weight_pack')
-        bias = torch.cat([_combine(br, bi, -1.0), _combine(br, bi, 1.0)])
+        bias = torch.empty(2*br.numel(), dtype=torch.float32, device=x.device)
+        br_c, bi_c = br.contiguous(), bi.contiguous()
+        hip.check(lib.brv_complex_bias_pack(hip.ptr(br_c), hip.ptr(bi_c), hip.ptr(bias), br.numel(), hip.stream()),
+                  'brv_complex_bias_pack')
         khw = kh*kw
         if rows and not transpose:
             Cout = R
@@ -379,12 +382,15 @@ class _ComplexConvFunction(torch.autograd.Function):
         sums = torch.empty(2*Cout, dtype=torch.float32, device=dy.device)
         hip.check(lib.brv_row_sum(hip.ptr(dy), hip.ptr(sums), B, 2*Cout, Ho*Wo, hip.stream()),
                   'brv_row_sum')
-        sr, si = sums[:Cout].contiguous(), sums[Cout:].contiguous()
+        dbr = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+        dbi = torch.empty_like(dbr)
+        hip.check(lib.brv_complex_bias_unpack(hip.ptr(sums), hip.ptr(dbr), hip.ptr(dbi), Cout, hip.stream()),
+                  'brv_complex_bias_unpack')
         if ctx.seg and not ctx.two:          # the concatenation was materialised: deal its gradient back
             s = ctx.seg
             dx, dskip = (torch.cat([dx[:, :s], dx[:, 2*s:3*s]], dim=1),
                          torch.cat([dx[:, s:2*s], dx[:, 3*s:]], dim=1))
-        return dx, dwr, _combine(sr, si, 1.0), dwi, _combine(si, sr, -1.0), None, None, dskip
+        return dx, dwr, dbr, dwi, dbi, None, None, dskip
 
 
 class _CombineFunction(torch.autograd.Function):
@@ -651,11 +657,8 @@ class _ApplyMaskFunction(torch.autograd.Function):
         B, _, Fq, T = x.shape
         n = Fq*T
         out = torch.empty(B, n, 2, dtype=torch.float32, device=x.device)
-        x2, m2 = x.view(B, 2*n), mask.view(B, 2*n)
-        for b in range(B):
-            hip.check(hip.lib().brv_dccrn_apply_mask(
-                hip.ptr(x2[b]), hip.ptr(x2[b, n:]), hip.ptr(m2[b]), hip.ptr(m2[b, n:]),
-                hip.ptr(out[b]), n, hip.stream()), 'brv_dccrn_apply_mask')
+        hip.check(hip.lib().brv_dccrn_apply_mask_batched(hip.ptr(x), hip.ptr(mask), hip.ptr(out), B, n,
+                                                         hip.stream()), 'brv_dccrn_apply_mask_batched')
         ctx.save_for_backward(x, mask)
         return torch.view_as_complex(out.view(B, 1, Fq, T, 2))
 
@@ -666,12 +669,9 @@ class _ApplyMaskFunction(torch.autograd.Function):
         n = Fq*T
         gr = torch.view_as_real(g.to(torch.complex64).contiguous()).view(B, n, 2)
         dm = torch.empty_like(mask)
-        x2, m2, d2 = x.view(B, 2*n), mask.view(B, 2*n), dm.view(B, 2*n)
-        for b in range(B):
-            hip.check(hip.lib().brv_dccrn_apply_mask_backward(
-                hip.ptr(x2[b]), hip.ptr(x2[b, n:]), hip.ptr(m2[b]), hip.ptr(m2[b, n:]),
-                hip.ptr(gr[b]), hip.ptr(d2[b]), hip.ptr(d2[b, n:]), n, hip.stream()),
-                'brv_dccrn_apply_mask_backward')
+        hip.check(hip.lib().brv_dccrn_apply_mask_backward_batched(
+            hip.ptr(x), hip.ptr(mask), hip.ptr(gr), hip.ptr(dm), B, n, hip.stream()),
+            'brv_dccrn_apply_mask_backward_batched')
         return None, dm
 
 

@@ -468,6 +468,12 @@ int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* 
 int brv_dccrn_apply_mask_backward(const float* xr, const float* xi, const float* mr,
                                   const float* mi, const float* gout, float* dmr, float* dmi,
                                   int64_t n, brv_stream_t stream);
+/* the same two maps for a whole batch in one launch: x, mask, dmask (B, 2 n) with the real plane first, out / gout
+ * (B, n, 2) */
+int brv_dccrn_apply_mask_batched(const float* x, const float* mask, float* out, int64_t B, int64_t n,
+                                 brv_stream_t stream);
+int brv_dccrn_apply_mask_backward_batched(const float* x, const float* mask, const float* gout, float* dmask,
+                                          int64_t B, int64_t n, brv_stream_t stream);
 int brv_istft_env_divide(const float* dy, const float* window, float* out, int64_t rows,
                          int64_t length, int64_t frame_length, int64_t hop_length, int64_t frames,
                          brv_stream_t stream);
@@ -492,6 +498,11 @@ int brv_complex_weight_pack(const float* wr, const float* wi, float* wc, int64_t
                             float sign, brv_stream_t stream);
 int brv_complex_weight_unpack(const float* dwc, float* dwr, float* dwi, int64_t R, int64_t C,
                               float sign, brv_stream_t stream);
+/* the bias of that packed layer, out (2C) = [br - bi | br + bi] (each module of ComplexWrapper adds its own bias,
+ * dccrn.py:231-235), and its adjoint on the channel sums [s_r | s_i] of the output gradient: d br = s_r + s_i,
+ * d bi = s_i - s_r */
+int brv_complex_bias_pack(const float* br, const float* bi, float* out, int64_t C, brv_stream_t stream);
+int brv_complex_bias_unpack(const float* sums, float* dbr, float* dbi, int64_t C, brv_stream_t stream);
 
 /* ComplexBatchNorm2d (models/dccrn/complex_batchnorm.py:29-215) on x (B, 2C, HW), real half
  * first: cplx_moments writes the five per-channel means (5, C) = E[xr], E[xi], E[xr^2],
