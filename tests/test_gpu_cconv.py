@@ -79,12 +79,16 @@ def test_rows_convolution_without_bias_and_strided_weight_matrix():
         assert float((y - ref).norm()/ref.norm()) < 2e-5
 
 
-def test_rows_convolution_reads_and_writes_a_skip_concatenation_in_place():
-    """Input from two sources == input concatenated; output dealt to two tensors == output split."""
+@pytest.mark.parametrize('shape', [(2, 16, 72, 6, 140), (1, 8, 24, 4, 300), (2, 24, 200, 4, 129), (1, 8, 64, 2, 70),
+                                   (1, 40, 520, 2, 33)],
+                         ids=lambda c: 'B%d_seg%d_M%d_H%d_W%d' % c)
+def test_rows_convolution_reads_and_writes_a_skip_concatenation_in_place(shape):
+    """Input from two sources == input concatenated; output dealt to two tensors == output split (every
+    workgroup shape: M <= 32 / 64 / 128 / 256 rows, pair and single-row forms)."""
     from brever_amd.models.dccrn import _cconv_rows
     dev = _cuda()
     g = torch.Generator().manual_seed(11)
-    B, seg, M, H, W = 2, 16, 72, 6, 140
+    B, seg, M, H, W = shape
     x1 = torch.randn(B, 2*seg, H, W, generator=g).to(dev)
     x2 = torch.randn(B, 2*seg, H, W, generator=g).to(dev)
     wc = (torch.randn(M, 4*seg*10, generator=g)/(40*seg)**0.5).to(dev)
