@@ -627,7 +627,7 @@ class ConvTasNet(BreverBaseModel):
             side.wait_stream(main)
             # persistent kernels at 7/8 of the CUs while two chains share the chip (csrc: num_cus) --
             # an option of these calls, not a state of the library
-            opts = hip.launch_opts(cu_eighths=7)
+            opts = hip.launch_opts(cu_eighths=int(os.environ.get('BRV_CTN_CU_EIGHTHS', '7')))
             po = hip.opts_ptr(opts)
             streams = (main, side)
             flat, prep, cfg = hip.ptr(self._flat), hip.ptr(self._prepared), self._cfg_ptr()
