@@ -207,6 +207,27 @@ def _cconv_wgrad(small, big, small2=None):
     return out
 
 
+# Weight and bias gradients of the row convolutions on a side stream (use_amp training): nothing on the way back to
+# the input depends on them, and the backward pass has a long stretch -- the recurrences' BPTT, 64 chains = a quarter
+# of the CUs for 0.9 ms -- that the decoder's weight gradients fill. BRV_DCCRN_WGRAD_SIDE=0: everything in order.
+_WGRAD_SIDE = os.environ.get('BRV_DCCRN_WGRAD_SIDE', '1') != '0'
+_side = {'streams': {}, 'pending': False}
+
+
+def _side_stream(device):
+    st = _side['streams'].get(device.index)
+    if st is None:
+        st = _side['streams'][device.index] = torch.cuda.Stream(device)
+    return st
+
+
+def _join_side(device):
+    """Queued once per backward pass (autograd engine callback, runs when the pass ends): the stream the gradients
+    are consumed on waits for the side stream."""
+    _side['pending'] = False
+    torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+
+
 def _im2col(x, geom, grid, lowp=False):
     """``lowp``: the column matrix in bf16 (half the bytes of the largest tensor of the layer)."""
     (kh, kw), (sh, sw), (ph, pw) = geom
@@ -319,6 +340,24 @@ class _ComplexConvFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    def _unpack_param_grads(dwc, dy, wshape, R, Cw, Cout, B, HoWo, transpose):
+        """dwc (2R, 2Cw) -> (d Wr, d Wi); channel sums of dy -> (d br, d bi) (bias = [br - bi | br + bi])."""
+        lib = hip.lib()
+        dwr = torch.empty(wshape, dtype=torch.float32, device=dy.device)
+        dwi = torch.empty_like(dwr)
+        hip.check(lib.brv_complex_weight_unpack(hip.ptr(dwc), hip.ptr(dwr), hip.ptr(dwi), R, Cw,
+                                                -1.0 if transpose else 1.0, hip.stream()),
+                  'brv_complex_weight_unpack')
+        sums = torch.empty(2*Cout, dtype=torch.float32, device=dy.device)
+        hip.check(lib.brv_row_sum(hip.ptr(dy), hip.ptr(sums), B, 2*Cout, HoWo, hip.stream()),
+                  'brv_row_sum')
+        dbr = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+        dbi = torch.empty_like(dbr)
+        hip.check(lib.brv_complex_bias_unpack(hip.ptr(sums), hip.ptr(dbr), hip.ptr(dbi), Cout, hip.stream()),
+                  'brv_complex_bias_unpack')
+        return dwr, dwi, dbr, dbi
+
+    @staticmethod
     def backward(ctx, dy):
         lib = hip.lib()
         x, wc = ctx.saved_tensors[:2]
@@ -330,20 +369,44 @@ class _ComplexConvFunction(torch.autograd.Function):
         khw = geom[0][0]*geom[0][1]
         dwc = None if ctx.rows else torch.empty_like(wc)
         dskip = None
-        if ctx.rows and transpose:
-            dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0, split_out=ctx.two)
-            if ctx.two:
-                dx, dskip = dx
-            dwc = _cconv_wgrad(x, dy, small2=skip)
-        elif ctx.rows:
-            dx = _cconv_rows(dy, wc, None, 2*Cin, khw, 2*Cw, 1)
-            # (2 real input channels of the first encoder: the column-matrix kernel wastes less there)
-            if 2*Cin >= 8:
-                dwc = _cconv_wgrad(dy, x)
+        if ctx.rows:
+            def param_grads():
+                """dW (complex pair) and the bias gradients: only dy, x (and skip) go in."""
+                if transpose:
+                    dwc_ = _cconv_wgrad(x, dy, small2=skip)
+                elif 2*Cin >= 8:
+                    dwc_ = _cconv_wgrad(dy, x)
+                else:        # (2 real input channels of the first encoder: the column-matrix kernel wastes less there)
+                    dwc_ = torch.empty_like(wc)
+                    _gemm_conv(dy, x, dwc_, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, 1, (2*Cin, H, W), geom,
+                               (Ho, Wo), trans_b=1, kbatch=B, a_kbs=2*Cout*Ho*Wo, img_kbs=2*Cin*H*W)
+                return _ComplexConvFunction._unpack_param_grads(dwc_, dy, wshape, R, Cw, Cout, B, Ho*Wo, transpose)
+            side = _side_stream(dy.device) if _WGRAD_SIDE else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(dy.device))      # dy, x exist; dx is not waited for
+            if transpose:
+                dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0, split_out=ctx.two)
+                if ctx.two:
+                    dx, dskip = dx
             else:
-                dwc = torch.empty_like(wc)
-                _gemm_conv(dy, x, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, 1, (2*Cin, H, W), geom,
-                           (Ho, Wo), trans_b=1, kbatch=B, a_kbs=2*Cout*Ho*Wo, img_kbs=2*Cin*H*W)
+                dx = _cconv_rows(dy, wc, None, 2*Cin, khw, 2*Cw, 1)
+            if side is None:
+                dwr, dwi, dbr, dbi = param_grads()
+            else:
+                with torch.cuda.stream(side):
+                    dwr, dwi, dbr, dbi = param_grads()
+                for t in (x, dy, skip):
+                    if t is not None:
+                        t.record_stream(side)
+                if not _side['pending']:
+                    _side['pending'] = True
+                    dev = dy.device
+                    torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev))
+            if ctx.seg and not ctx.two:      # the concatenation was materialised (segments off the chunk of 8)
+                s = ctx.seg
+                dx, dskip = (torch.cat([dx[:, :s], dx[:, 2*s:3*s]], dim=1),
+                             torch.cat([dx[:, s:2*s], dx[:, 3*s:]], dim=1))
+            return dx, dwr, dbr, dwi, dbi, None, None, dskip
         elif transpose and lowp and _IMPLICIT:
             dx = torch.empty_like(x)
             _gemm_conv(wc, dy, dx, B, 2*Cin, H*W, 2*Cw, 2*Cw, H*W, 0, 2*Cout*Ho*Wo, 2*Cin*H*W, 1,
@@ -373,19 +436,8 @@ class _ComplexConvFunction(torch.autograd.Function):
             _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,
                   2*Cw*Ho*Wo, trans_a=1, lowp=lowp)                           # the buffer now holds dcol
             dx = _col2im(col, None, 2*Cin, (H, W), geom, (Ho, Wo))
-        dwr = torch.empty(wshape, dtype=torch.float32, device=dy.device)
-        dwi = torch.empty_like(dwr)
-        hip.check(lib.brv_complex_weight_unpack(hip.ptr(dwc), hip.ptr(dwr), hip.ptr(dwi), R, Cw,
-                                                -1.0 if transpose else 1.0, hip.stream()),
-                  'brv_complex_weight_unpack')
-        # bias gradients: channel sums of the output gradient, bias = [br - bi | br + bi]
-        sums = torch.empty(2*Cout, dtype=torch.float32, device=dy.device)
-        hip.check(lib.brv_row_sum(hip.ptr(dy), hip.ptr(sums), B, 2*Cout, Ho*Wo, hip.stream()),
-                  'brv_row_sum')
-        dbr = torch.empty(Cout, dtype=torch.float32, device=dy.device)
-        dbi = torch.empty_like(dbr)
-        hip.check(lib.brv_complex_bias_unpack(hip.ptr(sums), hip.ptr(dbr), hip.ptr(dbi), Cout, hip.stream()),
-                  'brv_complex_bias_unpack')
+        dwr, dwi, dbr, dbi = _ComplexConvFunction._unpack_param_grads(dwc, dy, wshape, R, Cw, Cout, B, Ho*Wo,
+                                                                      transpose)
         if ctx.seg and not ctx.two:          # the concatenation was materialised: deal its gradient back
             s = ctx.seg
             dx, dskip = (torch.cat([dx[:, :s], dx[:, 2*s:3*s]], dim=1),

@@ -161,3 +161,33 @@ def test_rows_and_column_matrix_paths_give_the_same_dccrn_gradients():
     num = sum(float((out[True][1][n].double() - out[False][1][n].double()).norm()**2) for n in out[True][1])
     den = sum(float(out[False][1][n].double().norm()**2) for n in out[True][1])
     assert (num/den)**0.5 < 3e-2, (num/den)**0.5
+
+
+def test_parameter_gradients_on_the_side_stream_equal_the_in_order_ones():
+    """use_amp DCCRN with the weight / bias gradients queued on the side stream against the same work in order on
+    one stream: every gradient of one backward pass, and the losses of five training steps. Two in-order runs are
+    not bitwise equal themselves (split reductions of the generic products add with atomics: up to 3e-3 of a
+    tensor's norm on the recurrent weights between two identical in-order passes, 1e-4 between the two orders on
+    the convolution weights, parameters 6e-4 apart after five Adam steps), so the bounds are a multiple of that
+    run-to-run spread, not zero: a read of freed or unwritten memory shows up as O(1)."""
+    import brever_amd.models.dccrn as D
+    dev = _cuda()
+    batch = 0.1*torch.randn(3, 2, 12000, generator=torch.Generator().manual_seed(2)).to(dev)
+    lengths = torch.tensor([12000, 11000, 9000], device=dev)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    grads, losses = {}, {}
+    for side in (True, False):
+        D._WGRAD_SIDE = side
+        torch.manual_seed(7)
+        model = D.DCCRN(channels=[8, 16, 32, 32], lstm_channels=32).to(dev)
+        model.loss(batch, lengths, True).backward()
+        grads[side] = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        model.zero_grad(set_to_none=True)
+        losses[side] = [float(model.train_step(batch, lengths, True, scaler).detach()) for _ in range(5)]
+        torch.cuda.synchronize()
+    D._WGRAD_SIDE = True
+    top = max(float(g.double().norm()) for g in grads[False].values())
+    for n in grads[True]:          # (the biases in front of a batch norm have gradients of pure rounding noise)
+        a, b = grads[True][n].double(), grads[False][n].double()
+        assert float((a - b).norm()) <= 1e-2*float(b.norm()) + 1e-6*top, n
+    assert max(abs(x - y) for x, y in zip(losses[True], losses[False])) < 2e-3
