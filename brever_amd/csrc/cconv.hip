@@ -16,7 +16,10 @@
 // transposing LDS reads (cdna_hip_programming.md T10) that turn the frame-contiguous rows into B
 // operands. The weights are prepacked into A-operand fragments (cconv_pack_kernel) and go from L2
 // straight into registers, two k steps ahead of their use. LDS images are double-buffered: one
-// barrier per chunk (5 / 3 / 2 k steps of MF x NF MFMAs per wave).
+// barrier per chunk (5 / 3 / 2 k steps of MF x NF MFMAs per wave). Two loaders (cconv_tile, cconv_tile_lean) and,
+// for the transposed form with M <= 128, a pair form (both output rows of a pair from the three input rows they
+// share) are selected per launch shape in cconv_launch; workgroups are dealt to the 8 XCDs in contiguous runs.
+// Weight gradient: cconv_wgrad_kernel below. Measurements and what was tried: DESIGN.md 5b.
 #include "common.cuh"
 #include "../../include/brever_hip.h"
 
