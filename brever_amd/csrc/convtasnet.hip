@@ -1764,6 +1764,10 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
       } else {
         Pw1DgradWsParams wp; wp.r = rp;
         wp.dz_out = pw1_rc_wgrad() ? nullptr : eB;      // stored-dz1 weight gradient: dz1 over e1, in place
+        wp.dbg = nullptr;
+#ifdef WSD_STAMP
+        wp.dbg = debug_buffer();
+#endif
         ProfScope prof("pw1_dgrad", 2.0*BT*(double)l.Hp*l.Bnp*2,
                        2.0*BT*(l.Hp*(wp.dz_out ? 2 : 1) + l.Bnp*(has_res ? 3 : 2)), st);
         int grid = num_cus();

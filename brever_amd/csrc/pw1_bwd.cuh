@@ -268,7 +268,14 @@ __global__ __launch_bounds__(256, 2) void pw1_dgrad_rc_kernel(const Pw1DgradRcPa
 struct Pw1DgradWsParams {
   Pw1DgradRcParams r;            // tensors as for the tile kernel (n_ttiles unused)
   bf16_t* dz_out;                // nullable: dz1 (B, T, 512), row stride r.lde
+  long long* dbg;                // -DWSD_STAMP: s_memtime stamps of wave 0 (producer) / 4 (consumer), 64 per workgroup
 };
+#ifdef WSD_STAMP
+#define WSD_MARK(role, idx) do { long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (lane == 0 && pp.dbg && (idx) < 32) pp.dbg[(long long)blockIdx.x*64 + (role)*32 + (idx)] = t_; } while (0)
+#else
+#define WSD_MARK(role, idx) do { } while (0)
+#endif
 
 constexpr int WSD_TF = 32;                         // frames per tile
 constexpr int WSD_LDX = RC_KX + 8;                 // halves per x row (272 B)
@@ -320,6 +327,7 @@ __global__ __launch_bounds__(512) void pw1_dgrad_ws_kernel(const Pw1DgradWsParam
   // iteration i + 1, which every consumer reaches after its reads; the staged images likewise.
   if (wid < 4) {
     // ======================= producers: z1^T, norm backward -> dz1 =======================
+    if (wid == 0) WSD_MARK(0, 0);
     bf16x8 wf[4][8];
     {
       const bf16_t* src = p.Wfp + (long long)wid*128*RC_KX + (long long)lane*8;
@@ -345,14 +353,18 @@ __global__ __launch_bounds__(512) void pw1_dgrad_ws_kernel(const Pw1DgradWsParam
     };
     int b_ld = b0, t_ld = tf0;                     // tile whose operands are in the staging registers
     load_e(b_ld, t_ld, true);
+    if (wid == 0) WSD_MARK(0, 1);
 #pragma unroll 1
     for (int i = 0; i <= n_tiles; ++i) {
       const int buf = i & 1;
       const int b = b_ld, t0 = t_ld;               // tile i (meaningless for i == n_tiles)
+      if (wid == 0) WSD_MARK(0, 2 + 3*i);
 #pragma unroll
       for (int ci = 0; ci < 8; ++ci)               // own image: ordered behind this wave's reads of tile i - 1
         *reinterpret_cast<uint4*>(es + (er + 4*ci)*WSD_LDE + ec*8) = eraw[ci];
+      if (wid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WSD_MARK(0, 3 + 3*i); }
       __syncthreads();                             // x image of tile i complete, Ds[buf] free
+      if (wid == 0) WSD_MARK(0, 4 + 3*i);
       if (i == n_tiles) break;
       advance(b_ld, t_ld);
       load_e(b_ld, t_ld, i + 1 < n_tiles);
@@ -450,9 +462,11 @@ __global__ __launch_bounds__(512) void pw1_dgrad_ws_kernel(const Pw1DgradWsParam
     int b_ld = b0, t_ld = tf0;
     int b_pv = b0, t_pv = tf0;                     // tile i - 1
     load_x(b_ld, t_ld, true);
+    if (wid == 4) { WSD_MARK(1, 0); WSD_MARK(1, 1); }
 #pragma unroll 1
     for (int i = 0; i <= n_tiles; ++i) {
       const int buf = i & 1;
+      if (wid == 4) WSD_MARK(1, 2 + 3*i);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int id = ctid + 256*k;
@@ -476,7 +490,9 @@ __global__ __launch_bounds__(512) void pw1_dgrad_ws_kernel(const Pw1DgradWsParam
           }
         }
       }
+      if (wid == 4) WSD_MARK(1, 3 + 3*i);
       __syncthreads();
+      if (wid == 4) WSD_MARK(1, 4 + 3*i);
       if (i < n_tiles) {
         advance(b_ld, t_ld);
         load_x(b_ld, t_ld, i + 1 < n_tiles);
