@@ -632,43 +632,65 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const G32 p) {
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
   const float* A = p.A + (long long)b*p.a_bs;
   const float* B = p.B + (long long)b*p.b_bs;
-  for (int k0 = 0; k0 < p.K; k0 += TK) {
-    for (int e = tid; e < TM*TK; e += 256) {
-      const int i = e / TK, k = e % TK;
-      const int m = m0 + i, kk = k0 + k;
-      double v = 0.0;
-      if (m < p.M && kk < p.K) {
-        if (AM == GA_PLAIN) {
-          v = p.A64 ? p.A64[(long long)m*p.lda + kk] : (double)A[(long long)m*p.lda + kk];
-        } else {                                   // GA_SPEC_T
-          const int bin = kk >> 1, part = kk & 1;
-          const float2 z = *reinterpret_cast<const float2*>(A + ((long long)bin*p.frames + m)*2);
-          double re = (double)z.x*p.inv_scale, im = (double)z.y*p.inv_scale;
-          if (p.inv_comp != 1.f) {
-            const double mag = sqrt(re*re + im*im);
-            const double f = mag > 0.0 ? pow(mag, (double)p.inv_comp - 1.0) : 0.0;
-            re *= f; im *= f;
+  // The operands of k tile k0 + TK are requested into registers before the MFMAs of k tile k0 and written to
+  // LDS behind them: without it every k tile was a global round trip with the matrix pipe idle (18 TFLOP/s).
+  constexpr int NE = TM*TK/256;
+  double ra[NE], rb[NE];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < NE; ++r) {
+      const int e = tid + 256*r;
+      {
+        const int i = e / TK, k = e % TK;
+        const int m = m0 + i, kk = k0 + k;
+        double v = 0.0;
+        if (m < p.M && kk < p.K) {
+          if (AM == GA_PLAIN) {
+            v = p.A64 ? p.A64[(long long)m*p.lda + kk] : (double)A[(long long)m*p.lda + kk];
+          } else {                                   // GA_SPEC_T
+            const int bin = kk >> 1, part = kk & 1;
+            const float2 z = *reinterpret_cast<const float2*>(A + ((long long)bin*p.frames + m)*2);
+            double re = (double)z.x*p.inv_scale, im = (double)z.y*p.inv_scale;
+            if (p.inv_comp != 1.f) {
+              const double mag = sqrt(re*re + im*im);
+              const double f = mag > 0.0 ? pow(mag, (double)p.inv_comp - 1.0) : 0.0;
+              re *= f; im *= f;
+            }
+            v = part ? im : re;
           }
-          v = part ? im : re;
         }
+        ra[r] = v;
       }
-      As[i][k] = v;
-    }
-    for (int e = tid; e < TK*TN; e += 256) {
-      const int k = e / TN, j = e % TN;
-      const int kk = k0 + k, n = n0 + j;
-      double v = 0.0;
-      if (kk < p.K && n < p.N) {
-        if (BM == GB_PLAIN) v = p.B64 ? p.B64[(long long)kk*p.ldb + n] : (double)B[(long long)kk*p.ldb + n];
-        else if (BM == GB_WT) v = p.B64 ? p.B64[(long long)n*p.ldb + kk] : (double)B[(long long)n*p.ldb + kk];
-        else {
-          const long long idx = (long long)n*p.hop + kk - p.pad_left;
-          if (idx >= 0 && idx < p.len) v = (double)B[idx];
+      {
+        const int k = e / TN, j = e % TN;
+        const int kk = k0 + k, n = n0 + j;
+        double v = 0.0;
+        if (kk < p.K && n < p.N) {
+          if (BM == GB_PLAIN) v = p.B64 ? p.B64[(long long)kk*p.ldb + n] : (double)B[(long long)kk*p.ldb + n];
+          else if (BM == GB_WT) v = p.B64 ? p.B64[(long long)n*p.ldb + kk] : (double)B[(long long)n*p.ldb + kk];
+          else {
+            const long long idx = (long long)n*p.hop + kk - p.pad_left;
+            if (idx >= 0 && idx < p.len) v = (double)B[idx];
+          }
         }
+        rb[r] = v;
       }
-      Bs[k][j] = v;
     }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int r = 0; r < NE; ++r) {
+      const int e = tid + 256*r;
+      As[e / TK][e % TK] = ra[r];
+      Bs[e / TN][e % TN] = rb[r];
+    }
+  };
+  static_assert(TM*TK == TK*TN, "one item count for both operands");
+  fetch(0);
+  for (int k0 = 0; k0 < p.K; k0 += TK) {
+    stash();
     __syncthreads();
+    if (k0 + TK < p.K) fetch(k0 + TK);
 #pragma unroll
     for (int s = 0; s < TK/4; ++s) {
       const int kk = 4*s + (lane >> 4), c = lane & 15;
