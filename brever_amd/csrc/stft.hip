@@ -662,7 +662,8 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const G32 p) {
         ra[r] = v;
       }
       {
-        const int k = e / TN, j = e % TN;
+        // lanes follow the operand's contiguous axis: columns for GB_PLAIN, k for the framed signal / W^T
+        const int k = BM == GB_PLAIN ? e / TN : e % TK, j = BM == GB_PLAIN ? e % TN : e / TK;
         const int kk = k0 + k, n = n0 + j;
         double v = 0.0;
         if (kk < p.K && n < p.N) {
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const G32 p) {
     for (int r = 0; r < NE; ++r) {
       const int e = tid + 256*r;
       As[e / TK][e % TK] = ra[r];
-      Bs[e / TN][e % TN] = rb[r];
+      if (BM == GB_PLAIN) Bs[e / TN][e % TN] = rb[r]; else Bs[e % TK][e / TK] = rb[r];
     }
   };
   static_assert(TM*TK == TK*TN, "one item count for both operands");
