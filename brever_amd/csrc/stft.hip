@@ -13,6 +13,7 @@
 
 #include "../../include/brever_hip.h"
 #include "common.cuh"
+#include <type_traits>
 #include "gemm_f32_big.h"
 
 using namespace brv;
@@ -632,24 +633,31 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const G32 p) {
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0;
   const float* A = p.A + (long long)b*p.a_bs;
   const float* B = p.B + (long long)b*p.b_bs;
-  // The operands of k tile k0 + TK are requested into registers before the MFMAs of k tile k0 and written to
-  // LDS behind them: without it every k tile was a global round trip with the matrix pipe idle (18 TFLOP/s).
+  // The operands of k tile k0 + TK are requested into registers before the MFMAs of k tile k0 and written to LDS
+  // behind them. Every load is UNCONDITIONAL (indices clamped into the operand, the value replaced by zero
+  // afterwards) and the fp64 / fp32 form of each operand is chosen once, outside the loop: with a load under a
+  // lane condition, or two alternative loads into one register, hipcc waits for every single load before it
+  // issues the next one (s_waitcnt vmcnt(0) x 24 per k tile: 18 TFLOP/s).
   constexpr int NE = TM*TK/256;
-  double ra[NE], rb[NE];
-  auto fetch = [&](int k0) {
+  static_assert(TM*TK == TK*TN, "one item count for both operands");
+  auto run = [&](auto a64_, auto b64_) {
+    constexpr bool A64 = decltype(a64_)::value, B64 = decltype(b64_)::value;
+    double ra[NE], rb[NE];
+    auto fetch = [&](int k0) {
 #pragma unroll
-    for (int r = 0; r < NE; ++r) {
-      const int e = tid + 256*r;
-      {
-        const int i = e / TK, k = e % TK;
-        const int m = m0 + i, kk = k0 + k;
-        double v = 0.0;
-        if (m < p.M && kk < p.K) {
+      for (int r = 0; r < NE; ++r) {
+        const int e = tid + 256*r;
+        {
+          const int i = e / TK, k = e % TK;
+          const int m = m0 + i, kk = k0 + k;
+          const bool ok = m < p.M && kk < p.K;
+          const int mc = m < p.M ? m : p.M - 1, kc = kk < p.K ? kk : p.K - 1;
+          double v;
           if (AM == GA_PLAIN) {
-            v = p.A64 ? p.A64[(long long)m*p.lda + kk] : (double)A[(long long)m*p.lda + kk];
+            if (A64) v = p.A64[(long long)mc*p.lda + kc]; else v = (double)A[(long long)mc*p.lda + kc];
           } else {                                   // GA_SPEC_T
-            const int bin = kk >> 1, part = kk & 1;
-            const float2 z = *reinterpret_cast<const float2*>(A + ((long long)bin*p.frames + m)*2);
+            const int bin = kc >> 1, part = kc & 1;
+            const float2 z = *reinterpret_cast<const float2*>(A + ((long long)bin*p.frames + mc)*2);
             double re = (double)z.x*p.inv_scale, im = (double)z.y*p.inv_scale;
             if (p.inv_comp != 1.f) {
               const double mag = sqrt(re*re + im*im);
@@ -658,52 +666,58 @@ __global__ __launch_bounds__(256) void gemm64_kernel(const G32 p) {
             }
             v = part ? im : re;
           }
+          ra[r] = ok ? v : 0.0;
         }
-        ra[r] = v;
-      }
-      {
-        // lanes follow the operand's contiguous axis: columns for GB_PLAIN, k for the framed signal / W^T
-        const int k = BM == GB_PLAIN ? e / TN : e % TK, j = BM == GB_PLAIN ? e % TN : e / TK;
-        const int kk = k0 + k, n = n0 + j;
-        double v = 0.0;
-        if (kk < p.K && n < p.N) {
-          if (BM == GB_PLAIN) v = p.B64 ? p.B64[(long long)kk*p.ldb + n] : (double)B[(long long)kk*p.ldb + n];
-          else if (BM == GB_WT) v = p.B64 ? p.B64[(long long)n*p.ldb + kk] : (double)B[(long long)n*p.ldb + kk];
-          else {
-            const long long idx = (long long)n*p.hop + kk - p.pad_left;
-            if (idx >= 0 && idx < p.len) v = (double)B[idx];
+        {
+          // lanes follow the operand's contiguous axis: columns for GB_PLAIN, k for the framed signal / W^T
+          const int k = BM == GB_PLAIN ? e / TN : e % TK, j = BM == GB_PLAIN ? e % TN : e / TK;
+          const int kk = k0 + k, n = n0 + j;
+          bool ok = kk < p.K && n < p.N;
+          const int kc = kk < p.K ? kk : p.K - 1, nc = n < p.N ? n : p.N - 1;
+          double v;
+          if (BM == GB_PLAIN) {
+            if (B64) v = p.B64[(long long)kc*p.ldb + nc]; else v = (double)B[(long long)kc*p.ldb + nc];
+          } else if (BM == GB_WT) {
+            if (B64) v = p.B64[(long long)nc*p.ldb + kc]; else v = (double)B[(long long)nc*p.ldb + kc];
+          } else {
+            long long idx = (long long)nc*p.hop + kc - p.pad_left;
+            ok = ok && idx >= 0 && idx < p.len;
+            idx = idx < 0 ? 0 : (idx >= p.len ? p.len - 1 : idx);
+            v = (double)B[idx];
           }
+          rb[r] = ok ? v : 0.0;
         }
-        rb[r] = v;
       }
+    };
+    auto stash = [&]() {
+#pragma unroll
+      for (int r = 0; r < NE; ++r) {
+        const int e = tid + 256*r;
+        As[e / TK][e % TK] = ra[r];
+        if (BM == GB_PLAIN) Bs[e / TN][e % TN] = rb[r]; else Bs[e % TK][e / TK] = rb[r];
+      }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < p.K; k0 += TK) {
+      stash();
+      __syncthreads();
+      fetch(k0 + TK < p.K ? k0 + TK : k0);          // (the last tile is requested once more: no branch around loads)
+#pragma unroll
+      for (int s = 0; s < TK/4; ++s) {
+        const int kk = 4*s + (lane >> 4), c = lane & 15;
+        const double a0 = As[32*wm + c][kk], a1 = As[32*wm + 16 + c][kk];
+        const double b0 = Bs[kk][32*wn + c], b1 = Bs[kk][32*wn + 16 + c];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      __syncthreads();
     }
   };
-  auto stash = [&]() {
-#pragma unroll
-    for (int r = 0; r < NE; ++r) {
-      const int e = tid + 256*r;
-      As[e / TK][e % TK] = ra[r];
-      if (BM == GB_PLAIN) Bs[e / TN][e % TN] = rb[r]; else Bs[e % TK][e / TK] = rb[r];
-    }
-  };
-  static_assert(TM*TK == TK*TN, "one item count for both operands");
-  fetch(0);
-  for (int k0 = 0; k0 < p.K; k0 += TK) {
-    stash();
-    __syncthreads();
-    if (k0 + TK < p.K) fetch(k0 + TK);
-#pragma unroll
-    for (int s = 0; s < TK/4; ++s) {
-      const int kk = 4*s + (lane >> 4), c = lane & 15;
-      const double a0 = As[32*wm + c][kk], a1 = As[32*wm + 16 + c][kk];
-      const double b0 = Bs[kk][32*wn + c], b1 = Bs[kk][32*wn + 16 + c];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    __syncthreads();
-  }
+  if (p.A64) run(std::true_type{}, std::false_type{});
+  else if (p.B64) run(std::false_type{}, std::true_type{});
+  else run(std::false_type{}, std::false_type{});
   // accumulators -> LDS tile (rows of one (re, im) pair sit in different lanes), then row-wise out
   double (*Cs)[TK + 1] = As;                        // 64 x 33 doubles: half a tile at a time
   float* D = p.D + (long long)b*p.d_bs;
