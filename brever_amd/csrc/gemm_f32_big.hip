@@ -595,7 +595,10 @@ inline bool use_x3(const BigGemm& g) {
   // enough 128 x 128 tiles to fill the chip without splitting the reduction
   const long long tiles = (long long)((g.M + 127)/128)*((g.N + 127)/128)*(g.batch > 0 ? g.batch : 1);
   if (!g.x3) return false;
-  if (!g.ta && g.tb) return !g.pb.table && tiles >= 192;
+  // (x3 == 2: the caller brings scratch for an ordered reduction split -- long reductions over few tiles, the
+  // weight gradients of convolutions whose column matrix and output gradient are both contiguous in k)
+  if (!g.ta && g.tb)
+    return !g.pb.table && (tiles >= 192 || (g.x3 == 2 && (long long)g.K*(g.kbatch > 1 ? g.kbatch : 1) >= 8192));
   // weight-gradient form (both operands contiguous along their rows): a long reduction split over the chip
   if (g.ta && !g.tb) return !g.pa.table && b_vector(g) && (long long)g.K*(g.kbatch > 1 ? g.kbatch : 1) >= 8192;
   return false;
@@ -630,7 +633,7 @@ Plan make_plan(const BigGemm& g) {
   const long long tiles = (long long)g.batch*pl.m_tiles*pl.n_tiles;
   long long ks = 1;
   const int cus = device_cus();
-  const bool x3w = use_x3(g) && g.ta;          // several 4-wavefront workgroups per CU
+  const bool x3w = use_x3(g) && (g.ta || g.x3 == 2);          // several 4-wavefront workgroups per CU
   constexpr int kX3Wgs = BRV_X3_BK == 16 ? 3 : 2;
   if (tiles*2 <= cus*(x3w ? kX3Wgs : 1) && pl.total_t >= 32 && (!use_x3(g) || x3w)) {
     ks = cus*(x3w ? kX3Wgs : 1)/tiles;
@@ -689,7 +692,7 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
   p.n_work = p.split_xcd ? (p.ksplit + 7)/8*8*p.mn_padded : p.g.batch*p.ksplit*p.mn_padded;
   p.b_scalar = b_vector(p.g) ? 0 : 1;
   p.fast_epi = (long long)p.g.M*p.g.ldd*4 < (1LL << 31) && (!p.g.add || (long long)p.g.M*p.g.ldadd*4 < (1LL << 31));
-  const bool x3 = use_x3(p.g) && (p.ksplit == 1 || p.g.ta);
+  const bool x3 = use_x3(p.g) && (p.ksplit == 1 || p.g.ta || p.g.x3 == 2);
   const int wgs = device_cus()*(x3 ? (BRV_X3_BK == 16 ? 3 : 2) : 1);
   const int grid = p.n_work < wgs ? p.n_work : wgs;
   const int pro = p.g.pa.table ? 1 : (p.g.pb.table ? 2 : 0);

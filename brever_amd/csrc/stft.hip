@@ -967,7 +967,8 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
                     int64_t a_batch_stride, int64_t b_batch_stride, int64_t d_batch_stride,
                     int trans_a, int trans_b, int64_t kbatch, int64_t a_kbatch_stride,
                     int64_t b_kbatch_stride, const float* row_bias, int accumulate,
-                    brv_stream_t stream, int flags = 0, const int* conv = nullptr) {
+                    brv_stream_t stream, int flags = 0, const int* conv = nullptr,
+                    float* ws = nullptr, long long ws_floats = 0) {
   if (batch < 1 || M < 1 || N < 1 || K < 1) return -1;
   if (conv && !lowp) return -1;
   if (flags && (!lowp || ((flags & 2) && accumulate == 1))) return -1;
@@ -1004,6 +1005,19 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
     g.bias = row_bias; g.col_bias = p.col_bias;
     if (accumulate) { g.add = d; g.add_bs = d_batch_stride; g.ldadd = (int)ldd; }
     g.x3 = 1;          // split-bf16 kernel where the layout allows it (a row-major, b stored N x K)
+    if (ws) {
+      // brv_gemm_f32_ws: the caller's scratch takes the partial tiles of a reduction split (summed in split
+      // order by a second kernel), which also opens the split-bf16 form to long reductions over few tiles
+      g.x3 = 2;
+      if (brv::gemm_f32_big_ok(g)) {
+        const long long need = brv::gemm_f32_big_scratch(g);
+        if (need <= ws_floats) {
+          if (need > 0) { g.scratch = ws; g.scratch_floats = ws_floats; }
+          return brv::gemm_f32_big(g, st);
+        }
+      }
+      g.x3 = 1;
+    }
     if (brv::gemm_f32_big_ok(g) && brv::gemm_f32_big_scratch(g) == 0) return brv::gemm_f32_big(g, st);
   }
 #endif
@@ -1072,6 +1086,27 @@ int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_
   return gemm_any(0, a, b, d, batch, M, N, K, lda, ldb, ldd, a_batch_stride, b_batch_stride,
                   d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride, b_kbatch_stride,
                   row_bias, accumulate, stream);
+}
+int64_t brv_gemm_f32_workspace_bytes(int64_t batch, int64_t M, int64_t N, int64_t K, int trans_a, int trans_b,
+                                     int64_t kbatch) {
+  if (batch < 1 || M < 32 || N < 32 || K < 1) return 0;
+  if ((double)M*(double)N*(double)K*(double)batch*(kbatch > 1 ? kbatch : 1) < 3.0e7) return 0;
+  brv::BigGemm g; memset(&g, 0, sizeof(g));
+  g.M = (int)M; g.N = (int)N; g.K = (int)K; g.kbatch = kbatch > 1 ? (int)kbatch : 1; g.batch = (int)batch;
+  g.ta = trans_a != 0; g.tb = trans_b != 0; g.lda = (int)(trans_a ? M : K); g.ldb = (int)(trans_b ? K : N);
+  g.ldd = (int)N; g.x3 = 2;
+  return 4*brv::gemm_f32_big_scratch(g);
+}
+int brv_gemm_f32_ws(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
+                    int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
+                    int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                    int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
+                    const float* row_bias, int accumulate, float* workspace, int64_t workspace_bytes,
+                    brv_stream_t stream) {
+  if (workspace && (((uintptr_t)workspace & 15) || workspace_bytes < 0)) return -1;
+  return gemm_any(0, a, b, d, batch, M, N, K, lda, ldb, ldd, a_batch_stride, b_batch_stride,
+                  d_batch_stride, trans_a, trans_b, kbatch, a_kbatch_stride, b_kbatch_stride,
+                  row_bias, accumulate, stream, 0, nullptr, workspace, workspace ? workspace_bytes/4 : 0);
 }
 int brv_gemm_bf16_mixed(const void* a, const void* b, void* d, int64_t batch, int64_t M, int64_t N,
                         int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,

@@ -163,6 +163,10 @@ SIGNATURES = {
     'brv_gemm_f32': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*10
                      + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_ptr,
                         ctypes.c_int, _c_ptr]),
+    'brv_gemm_f32_workspace_bytes': (ctypes.c_int64, [_c_i64]*4 + [ctypes.c_int, ctypes.c_int, _c_i64]),
+    'brv_gemm_f32_ws': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*10
+                        + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_ptr,
+                           ctypes.c_int, _c_ptr, _c_i64, _c_ptr]),
     'brv_gemm_bf16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr] + [_c_i64]*10
                       + [ctypes.c_int, ctypes.c_int, _c_i64, _c_i64, _c_i64, _c_ptr,
                          ctypes.c_int, _c_ptr]),
@@ -342,6 +346,24 @@ def ptr(t):
 
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gemm_f32(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a, trans_b, kbatch, a_kbs, b_kbs,
+             bias, mode):
+    """``brv_gemm_f32``; a long reduction (a weight gradient summed over the batch, or K >= 8192) goes through
+    ``brv_gemm_f32_ws`` with scratch from the caching allocator when the shape asks for it (ordered reduction
+    split, split-bf16 form: csrc/gemm_f32_big.hip)."""
+    if kbatch > 1 or K >= 8192:
+        nbytes = lib().brv_gemm_f32_workspace_bytes(batch, M, N, K, trans_a, trans_b, kbatch)
+        if nbytes > 0:
+            ws = torch.empty(nbytes//4, dtype=torch.float32, device=d.device)
+            check(lib().brv_gemm_f32_ws(
+                ptr(a), ptr(b), ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a, trans_b,
+                kbatch, a_kbs, b_kbs, ptr(bias), mode, ptr(ws), nbytes, stream()), 'brv_gemm_f32_ws')
+            return
+    check(lib().brv_gemm_f32(
+        ptr(a), ptr(b), ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a, trans_b,
+        kbatch, a_kbs, b_kbs, ptr(bias), mode, stream()), 'brv_gemm_f32')
 
 
 def prof_enable(mode):

@@ -143,11 +143,13 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, t
             trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, flags, hip.stream()),
             'brv_gemm_bf16_mixed')
         return
-    fn = hip.lib().brv_gemm_bf16 if lowp else hip.lib().brv_gemm_f32
-    hip.check(fn(
+    if not lowp:
+        hip.gemm_f32(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a, trans_b, kbatch, a_kbs,
+                     b_kbs, bias, 0)
+        return
+    hip.check(hip.lib().brv_gemm_bf16(
         hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
-        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()),
-        'brv_gemm_bf16' if lowp else 'brv_gemm_f32')
+        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_bf16')
 
 
 def _gemm_conv(a, img, d, batch, M, N, K, lda, ldd, a_bs, img_bs, d_bs, mode, image, geom, grid,

@@ -19,11 +19,13 @@ AMP = {'on': False}       # set by SGMSEp.loss around the forward pass (use_amp)
 def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, trans_b=0,
           kbatch=1, a_kbs=0, b_kbs=0, bias=None, lowp=False):
     """``lowp``: bf16 operands with fp32 accumulation (the convolutions under ``use_amp``)."""
-    fn = hip.lib().brv_gemm_bf16 if lowp else hip.lib().brv_gemm_f32
-    hip.check(fn(
+    if not lowp:
+        hip.gemm_f32(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a, trans_b, kbatch, a_kbs,
+                     b_kbs, bias, 0)
+        return
+    hip.check(hip.lib().brv_gemm_bf16(
         hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
-        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()),
-        'brv_gemm_bf16' if lowp else 'brv_gemm_f32')
+        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_bf16')
 
 
 def _empty(*shape, like):

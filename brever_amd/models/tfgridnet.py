@@ -214,10 +214,13 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_
             trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), mode, flags, hip.stream()),
             'brv_gemm_bf16_mixed')
         return
-    fn = hip.lib().brv_gemm_bf16 if lowp else hip.lib().brv_gemm_f32
-    hip.check(fn(hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
-                 trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), mode, hip.stream()),
-              'brv_gemm_bf16' if lowp else 'brv_gemm_f32')
+    if not lowp:
+        hip.gemm_f32(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a, trans_b, kbatch, a_kbs,
+                     b_kbs, bias, mode)
+        return
+    hip.check(hip.lib().brv_gemm_bf16(
+        hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
+        trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), mode, hip.stream()), 'brv_gemm_bf16')
 
 
 def _column_sums(x, rows, cols, batch=1, lowp=False):

@@ -297,6 +297,20 @@ int brv_gemm_f32(const float* a, const float* b, float* d, int64_t batch, int64_
                  int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
                  int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
                  const float* row_bias, int accumulate, brv_stream_t stream);
+/* brv_gemm_f32 with caller-provided scratch (16-byte aligned, brv_gemm_f32_workspace_bytes of the same shape;
+ * 0 = the shape needs none): a long reduction over few output tiles -- the weight gradients of the fp32
+ * convolutions (reference: autograd of nn.Conv2d / nn.ConvTranspose2d, models/dccrn/dccrn.py:225-292) -- is
+ * split over workgroups whose partial tiles are summed IN SPLIT ORDER by a second kernel (bitwise repeatable,
+ * no atomics), and with a row-major / b stored N x K such a product runs in the split-bf16 form (fp32 accuracy
+ * at 2.7x the rate of the fp32 MFMA). workspace == NULL: exactly brv_gemm_f32. */
+int64_t brv_gemm_f32_workspace_bytes(int64_t batch, int64_t M, int64_t N, int64_t K, int trans_a, int trans_b,
+                                     int64_t kbatch);
+int brv_gemm_f32_ws(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
+                    int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int64_t a_batch_stride,
+                    int64_t b_batch_stride, int64_t d_batch_stride, int trans_a, int trans_b,
+                    int64_t kbatch, int64_t a_kbatch_stride, int64_t b_kbatch_stride,
+                    const float* row_bias, int accumulate, float* workspace, int64_t workspace_bytes,
+                    brv_stream_t stream);
 /* The same product with the operands rounded to bf16 on their way into LDS and fp32
  * accumulation (v_mfma_f32_32x32x16_bf16): the use_amp path of DCCRN's convolutions, LSTM
  * projections and Linear layers (the reference autocasts them, models/dccrn/dccrn.py:113-121). */

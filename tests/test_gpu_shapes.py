@@ -571,6 +571,72 @@ def test_gemm_f32_big_tiles_all_layouts(ta, tb):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_f32_with_workspace_splits_long_reductions_in_a_fixed_order(ta, tb):
+    """brv_gemm_f32_ws: the same product with scratch of brv_gemm_f32_workspace_bytes -- long reductions over few
+    tiles are split over workgroups whose partial tiles are summed in split order (every result bitwise
+    repeatable, unlike the atomics of the entry point without scratch), in the split-bf16 form when a is row-major
+    and b stored N x K (the weight gradients of the fp32 DCCRN / SGMSE+ convolutions: column matrix and output
+    gradient both contiguous along the pixels, summed over the batch). vs float64, rel-L2 <= 2e-6."""
+    import torch
+    from brever_amd import hip
+    lib = hip.lib()
+    gen = torch.Generator().manual_seed(17 + 2*ta + tb)
+    dev = torch.device('cuda')
+    #        batch M    N    K      kbatch bias   acc
+    cases = [(1, 64, 320, 32000, 4, None, 0),       # DCCRN enc2 weight gradient over 4 items
+             (1, 256, 1280, 7952, 3, None, 0),      # deeper layer: more tiles, shorter rows
+             (1, 128, 512, 20000, 1, None, 1),      # accumulate
+             (1, 512, 128, 4100, 3, 'row', 0),      # K tail (4100 = 128 x 32 + 4), bias
+             (2, 132, 72, 9000, 2, 'col', 0),       # batch, tails in M and N (whole 16-byte pieces: the big kernel's rule)
+             (1, 1000, 512, 128, 1, 'col', 0),      # no split needed: workspace unused
+             (1, 40, 36, 50000, 1, None, 0)]        # one partial tile, 1563 k-tiles
+    used = 0
+    for batch, M, N, K, kbatch, bias, acc in cases:
+        lda = (M if ta else K) + 4
+        ldb = (K if tb else N) + 8
+        ldd = N + 3
+        a = torch.randn(batch, kbatch, (K if ta else M), lda, generator=gen)
+        b = torch.randn(batch, kbatch, (N if tb else K), ldb, generator=gen)
+        d0 = torch.randn(batch, M, ldd, generator=gen)
+        bv = torch.randn(M if bias == 'row' else N, generator=gen) if bias else None
+        opa = a[..., :M].transpose(-1, -2) if ta else a[..., :K]
+        opb = b[..., :K].transpose(-1, -2) if tb else b[..., :N]
+        want = torch.einsum('zkmr,zkrn->zmn', opa.double(), opb.double())
+        if bias == 'row':
+            want = want + bv.double()[None, :, None]
+        elif bias == 'col':
+            want = want + bv.double()[None, None, :]
+        if acc:
+            want = want + d0[..., :N].double()
+        ad, bd = a.to(dev), b.to(dev)
+        bvd = bv.to(dev) if bias else None
+        nbytes = lib.brv_gemm_f32_workspace_bytes(batch, M, N, K, ta, tb, kbatch)
+        assert nbytes >= 0
+        used += nbytes > 0
+        # poisoned scratch with a guard behind it: partial tiles are written before they are read, and only inside
+        ws = torch.full((nbytes//4 + 64,), float('nan'), device=dev)
+        outs = []
+        for rep in range(2):
+            d = d0.to(dev).clone()
+            hip.check(lib.brv_gemm_f32_ws(
+                hip.ptr(ad), hip.ptr(bd), hip.ptr(d), batch, M, N, K, lda, ldb, ldd,
+                ad.stride(0), bd.stride(0), d.stride(0), ta, tb, kbatch, ad.stride(1), bd.stride(1),
+                hip.ptr(bvd) if bias else None, (2 if bias == 'col' else acc),
+                hip.ptr(ws) if nbytes else None, nbytes, hip.stream()), 'brv_gemm_f32_ws')
+            torch.cuda.synchronize()
+            outs.append(d.cpu())
+        got = outs[0]
+        if nbytes or K < 4000:
+            assert torch.equal(outs[0], outs[1]), (batch, M, N, K, 'not repeatable')
+        assert bool(torch.isnan(ws[nbytes//4:]).all()), 'wrote behind the scratch'
+        assert torch.equal(got[..., N:], d0[..., N:]), 'wrote outside the N columns'
+        rel = float((got[..., :N].double() - want).norm()/want.norm())
+        assert rel <= 2e-6, (batch, M, N, K, kbatch, bias, acc, rel)
+    assert used >= 3
+
+
+@pytest.mark.gpu
 def test_fp32_training_is_bitwise_repeatable():
     """the fp32 path sums in fixed orders (split reductions of the weight gradients added
     in split order, per-channel and per-frame sums by slice, no floating-point atomics on a result that
