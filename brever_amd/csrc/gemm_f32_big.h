@@ -38,7 +38,8 @@ struct BigGemm {
   float* scratch; long long scratch_floats;
   // take the split-bf16 kernel (three bf16 pieces per operand, six MFMAs per k-step: fp32 accuracy at
   // 2.7x the rate) when the layout allows it (!ta, tb)
-  // 2: also for the (!ta, tb) form with a long reduction over few tiles, split over workgroups through `scratch`
+  // bit 1 (2): also for the (!ta, tb) form with a long reduction over few tiles, split over workgroups through
+  // `scratch`; bit 2 (4): also for (!ta, !tb) and short-K (ta, !tb) products that fill the chip without a split
   int x3;
 };
 

@@ -112,8 +112,10 @@ __global__ __launch_bounds__(64*WM*WN, (X3 && BRV_X3_BK == 16) ? 3 : 1) void gem
   constexpr int NA = TM*KQ/NT, NB = TN*KQ/NT;   // 16-byte loads per thread and k-tile
   constexpr int LDH = BK + 8;                 // X3: bf16 elements per LDS row (80 or 48 bytes: conflict-free 16-byte reads)
   constexpr int LDT = TM + 8;                 // X3 weight-gradient form: bf16 elements per LDS row of a [k][rows] plane
-  constexpr int LDS_FLOATS = X3 ? (TA ? 3*BK*(LDT + TN + 8)/2 : 3*(TM + TN)*LDH/2) : 2*STAGE;
-  static_assert(!X3 || (!TA && TB) || (TA && !TB), "X3: both operands contiguous in k, or both along their rows");
+  // X3 planes: an operand contiguous in k is staged row-major ([rows][LDH]), one contiguous along its rows k-major
+  // ([BK][rows + 8], fragments through the transposing LDS read) -- each operand by its own storage order
+  constexpr int X3_PA = TA ? BK*LDT : TM*LDH, X3_PB = TB ? TN*LDH : BK*(TN + 8);
+  constexpr int LDS_FLOATS = X3 ? 3*(X3_PA + X3_PB)/2 : 2*STAGE;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const BigGemm& g = p.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -436,10 +438,10 @@ __global__ __launch_bounds__(64*WM*WN, (X3 && BRV_X3_BK == 16) ? 3 : 1) void gem
 
   if constexpr (X3) {
     bf16_t* H = reinterpret_cast<bf16_t*>(lds);
-    // planes: A hi, mid, lo ([TM][LDH] each), then B hi, mid, lo ([TN][LDH])
-    // (weight-gradient form, TA && !TB: planes are k-major, [kBK][rows + 8])
+    // planes: A hi, mid, lo, then B hi, mid, lo; row-major [rows][LDH] for an operand contiguous in k (!TA / TB),
+    // k-major [BK][rows + 8] for one contiguous along its rows (TA / !TB)
     constexpr int LDTB = TN + 8;
-    constexpr int PA = TA ? BK*LDT : TM*LDH, PB = TA ? BK*LDTB : TN*LDH;
+    constexpr int PA = X3_PA, PB = X3_PB;
     auto split_store = [&](bf16_t* plane0, int plane_stride, int off, const float4& v) {
       // three bf16 pieces of 4 values -> one 8-byte store per plane
       const uint32_t h01 = pack2(v.x, v.y), h23 = pack2(v.z, v.w);
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(64*WM*WN, (X3 && BRV_X3_BK == 16) ? 3 : 1) void gem
 #pragma unroll
       for (int i = 0; i < NA; ++i) split_store(H, PA, TA ? a_k[i]*LDT + a_r[i] : a_r[i]*LDH + a_k[i], ra[i]);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) split_store(H + 3*PA, PB, TA ? b_k[i]*LDTB + b_r[i] : b_r[i]*LDH + b_k[i], rb[i]);
+      for (int i = 0; i < NB; ++i) split_store(H + 3*PA, PB, TB ? b_r[i]*LDH + b_k[i] : b_k[i]*LDTB + b_r[i], rb[i]);
     };
     const int ha = (64*wm + r32)*LDH + 8*kh, hb = 3*PA + (64*wn + r32)*LDH + 8*kh;
     auto compute3 = [&]() {
@@ -480,13 +482,10 @@ __global__ __launch_bounds__(64*WM*WN, (X3 && BRV_X3_BK == 16) ? 3 : 1) void gem
               a[f][pl] = __builtin_bit_cast(bf16x8, q); b[f][pl] = __builtin_bit_cast(bf16x8, q);
               continue;
             }
-            if (TA) {
-              a[f][pl] = tr_frag16(H + pl*PA, LDT, 16*ks, 64*wm + 32*f, lane);
-              b[f][pl] = tr_frag16(H + 3*PA + pl*PB, LDTB, 16*ks, 64*wn + 32*f, lane);
-            } else {
-              a[f][pl] = *reinterpret_cast<const bf16x8*>(H + ha + pl*PA + 32*f*LDH + 16*ks);
-              b[f][pl] = *reinterpret_cast<const bf16x8*>(H + hb + pl*PB + 32*f*LDH + 16*ks);
-            }
+            if (TA) a[f][pl] = tr_frag16(H + pl*PA, LDT, 16*ks, 64*wm + 32*f, lane);
+            else a[f][pl] = *reinterpret_cast<const bf16x8*>(H + ha + pl*PA + 32*f*LDH + 16*ks);
+            if (!TB) b[f][pl] = tr_frag16(H + 3*PA + pl*PB, LDTB, 16*ks, 64*wn + 32*f, lane);
+            else b[f][pl] = *reinterpret_cast<const bf16x8*>(H + hb + pl*PB + 32*f*LDH + 16*ks);
           }
         if (BRV_BIG_ABL & 1) {
 #pragma unroll
@@ -595,12 +594,16 @@ inline bool use_x3(const BigGemm& g) {
   // enough 128 x 128 tiles to fill the chip without splitting the reduction
   const long long tiles = (long long)((g.M + 127)/128)*((g.N + 127)/128)*(g.batch > 0 ? g.batch : 1);
   if (!g.x3) return false;
-  // (x3 == 2: the caller brings scratch for an ordered reduction split -- long reductions over few tiles, the
+  // (x3 & 2: the caller brings scratch for an ordered reduction split -- long reductions over few tiles, the
   // weight gradients of convolutions whose column matrix and output gradient are both contiguous in k)
   if (!g.ta && g.tb)
-    return !g.pb.table && (tiles >= 192 || (g.x3 == 2 && (long long)g.K*(g.kbatch > 1 ? g.kbatch : 1) >= 8192));
+    return !g.pb.table && (tiles >= 192 || ((g.x3 & 2) && (long long)g.K*(g.kbatch > 1 ? g.kbatch : 1) >= 8192));
   // weight-gradient form (both operands contiguous along their rows): a long reduction split over the chip
-  if (g.ta && !g.tb) return !g.pa.table && b_vector(g) && (long long)g.K*(g.kbatch > 1 ? g.kbatch : 1) >= 8192;
+  if (g.ta && !g.tb)
+    return !g.pa.table && b_vector(g) && ((long long)g.K*(g.kbatch > 1 ? g.kbatch : 1) >= 8192 ||
+                                          ((g.x3 & 4) && tiles >= 192 && !g.pb.table));
+  // a contiguous in k, b along its rows (a convolution as weights x column matrix): no split
+  if (!g.ta && !g.tb) return (g.x3 & 4) && !g.pa.table && !g.pb.table && b_vector(g) && tiles >= 192;
   return false;
 #endif
 }
@@ -633,7 +636,7 @@ Plan make_plan(const BigGemm& g) {
   const long long tiles = (long long)g.batch*pl.m_tiles*pl.n_tiles;
   long long ks = 1;
   const int cus = device_cus();
-  const bool x3w = use_x3(g) && (g.ta || g.x3 == 2);          // several 4-wavefront workgroups per CU
+  const bool x3w = use_x3(g) && (g.ta || (g.x3 & 2));          // several 4-wavefront workgroups per CU
   constexpr int kX3Wgs = BRV_X3_BK == 16 ? 3 : 2;
   if (tiles*2 <= cus*(x3w ? kX3Wgs : 1) && pl.total_t >= 32 && (!use_x3(g) || x3w)) {
     ks = cus*(x3w ? kX3Wgs : 1)/tiles;
@@ -692,7 +695,7 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
   p.n_work = p.split_xcd ? (p.ksplit + 7)/8*8*p.mn_padded : p.g.batch*p.ksplit*p.mn_padded;
   p.b_scalar = b_vector(p.g) ? 0 : 1;
   p.fast_epi = (long long)p.g.M*p.g.ldd*4 < (1LL << 31) && (!p.g.add || (long long)p.g.M*p.g.ldadd*4 < (1LL << 31));
-  const bool x3 = use_x3(p.g) && (p.ksplit == 1 || p.g.ta || p.g.x3 == 2);
+  const bool x3 = use_x3(p.g) && (p.ksplit == 1 || p.g.ta || (p.g.x3 & 2));
   const int wgs = device_cus()*(x3 ? (BRV_X3_BK == 16 ? 3 : 2) : 1);
   const int grid = p.n_work < wgs ? p.n_work : wgs;
   const int pro = p.g.pa.table ? 1 : (p.g.pb.table ? 2 : 0);
@@ -710,6 +713,8 @@ int gemm_f32_big(const BigGemm& g_in, hipStream_t st) {
   if (x3 && p.g.ta) {
     if (pro == 2) hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, true, false, 2, true>), dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, true, false, 0, true>), dim3(grid), dim3(256), 0, st, p);
+  } else if (x3 && !p.g.tb) {
+    hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, false, false, 0, true>), dim3(grid), dim3(256), 0, st, p);
   } else if (x3) {
     if (pro == 1) hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, false, true, 1, true>), dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gemm_f32_big_kernel<2, 2, false, true, 0, true>), dim3(grid), dim3(256), 0, st, p);

@@ -1004,11 +1004,11 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
     g.D = d; g.d_bs = d_batch_stride; g.ldd = (int)ldd;
     g.bias = row_bias; g.col_bias = p.col_bias;
     if (accumulate) { g.add = d; g.add_bs = d_batch_stride; g.ldadd = (int)ldd; }
-    g.x3 = 1;          // split-bf16 kernel where the layout allows it (a row-major, b stored N x K)
+    g.x3 = 1 | 4;      // split-bf16 kernel where the layout allows it (every pair but a stored K x M with b stored N x K)
     if (ws) {
       // brv_gemm_f32_ws: the caller's scratch takes the partial tiles of a reduction split (summed in split
       // order by a second kernel), which also opens the split-bf16 form to long reductions over few tiles
-      g.x3 = 2;
+      g.x3 = 1 | 2 | 4;
       if (brv::gemm_f32_big_ok(g)) {
         const long long need = brv::gemm_f32_big_scratch(g);
         if (need <= ws_floats) {
@@ -1016,7 +1016,7 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
           return brv::gemm_f32_big(g, st);
         }
       }
-      g.x3 = 1;
+      g.x3 = 1 | 4;
     }
     if (brv::gemm_f32_big_ok(g) && brv::gemm_f32_big_scratch(g) == 0) return brv::gemm_f32_big(g, st);
   }
@@ -1094,7 +1094,7 @@ int64_t brv_gemm_f32_workspace_bytes(int64_t batch, int64_t M, int64_t N, int64_
   brv::BigGemm g; memset(&g, 0, sizeof(g));
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.kbatch = kbatch > 1 ? (int)kbatch : 1; g.batch = (int)batch;
   g.ta = trans_a != 0; g.tb = trans_b != 0; g.lda = (int)(trans_a ? M : K); g.ldb = (int)(trans_b ? K : N);
-  g.ldd = (int)N; g.x3 = 2;
+  g.ldd = (int)N; g.x3 = 1 | 2 | 4;
   return 4*brv::gemm_f32_big_scratch(g);
 }
 int brv_gemm_f32_ws(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,

@@ -533,7 +533,8 @@ def test_gemm_f32_big_tiles_all_layouts(ta, tb):
              (1, 128, 512, 20000, 1, None, 1),      # weight gradient: 128 x 256 tiles, split reduction
              (1, 512, 128, 4100, 3, 'row', 0),      # reduction over 3 operand pairs, split, K tail (4100 = 128 x 32 + 4)
              (3, 64, 64, 4096, 1, None, 0),         # smallest tile shape the kernel takes
-             (3, 4096, 256, 64, 1, 'col', 0)]       # 192 tiles over a batch: the split-bf16 kernel when tb
+             (3, 4096, 256, 64, 1, 'col', 0),       # 192 tiles over a batch: the split-bf16 kernel (not for ta and tb)
+             (2, 1300, 1100, 200, 1, 'row', 1)]     # 198 tiles with tails in M, N and the k-tile, accumulate: same
     for batch, M, N, K, kbatch, bias, acc in cases:
         lda = (M if ta else K) + 4
         ldb = (K if tb else N) + 8
