@@ -235,6 +235,39 @@ __global__ __launch_bounds__(256) void col_sum_part_kernel(const float* __restri
     part[((long long)blockIdx.z*kColSlices + slice)*cols + j] =
         (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
+// the same partial sums with 16-byte loads (cols % 4 == 0, 16-byte aligned x): a thread owns 4 consecutive columns,
+// the lanes of a wavefront run over consecutive column groups and then consecutive rows -- 1 KB of contiguous memory
+// per load instruction whatever the width (cw = column groups per workgroup <= 64, 256 / cw row lanes), four
+// independent loads in flight per thread; the row lanes are folded through LDS in a fixed order
+__global__ __launch_bounds__(256) void col_sum_part4_kernel(const float* __restrict__ x,
+                                                            float* __restrict__ part, long long rows,
+                                                            int cols) {
+  __shared__ float4 red[256];
+  const int c4 = cols >> 2;
+  const int g0 = blockIdx.x*64, cw = min(64, c4 - g0), RL = 256/cw;
+  const int t = threadIdx.x, gl = t % cw, rl = t / cw, slice = blockIdx.y;
+  const float4* xb = reinterpret_cast<const float4*>(x + (long long)blockIdx.z*rows*cols) + g0 + gl;
+  const long long chunk = (rows + kColSlices - 1)/kColSlices;
+  const long long r0 = slice*chunk, r1 = min(rows, r0 + chunk);
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  auto add = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+  if (rl < RL) {
+    long long r = r0 + rl;
+    for (; r + 3*RL < r1; r += 4*RL) {
+      const float4 v0 = xb[r*c4], v1 = xb[(r + RL)*c4], v2 = xb[(r + 2*RL)*c4], v3 = xb[(r + 3*RL)*c4];
+      add(a0, v0); add(a1, v1); add(a2, v2); add(a3, v3);
+    }
+    for (; r < r1; r += RL) add(a0, xb[r*c4]);
+    add(a0, a1); add(a2, a3); add(a0, a2);
+    red[t] = a0;
+  }
+  __syncthreads();
+  if (t < cw) {
+    float4 acc = red[t];
+    for (int q = 1; q < RL; ++q) add(acc, red[q*cw + t]);
+    reinterpret_cast<float4*>(part + ((long long)blockIdx.z*kColSlices + slice)*cols)[g0 + t] = acc;
+  }
+}
 __global__ __launch_bounds__(256) void col_sum_fold_kernel(const float* __restrict__ part,
                                                            float* __restrict__ out, int cols) {
   const int j = blockIdx.x*256 + threadIdx.x;
@@ -338,8 +371,12 @@ int brv_col_sum(const float* x, float* out, void* scratch, int64_t batch, int64_
                 brv_stream_t stream) {
   if (batch < 1 || rows < 1 || cols < 1 || batch > 65535) return -1;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(col_sum_part_kernel, dim3((unsigned)((cols + 63)/64), kColSlices, (unsigned)batch),
-                     dim3(256), 0, st, x, (float*)scratch, (long long)rows, (int)cols);
+  if (cols % 4 == 0 && (((uintptr_t)x | (uintptr_t)scratch) & 15) == 0)
+    hipLaunchKernelGGL(col_sum_part4_kernel, dim3((unsigned)((cols/4 + 63)/64), kColSlices, (unsigned)batch),
+                       dim3(256), 0, st, x, (float*)scratch, (long long)rows, (int)cols);
+  else
+    hipLaunchKernelGGL(col_sum_part_kernel, dim3((unsigned)((cols + 63)/64), kColSlices, (unsigned)batch),
+                       dim3(256), 0, st, x, (float*)scratch, (long long)rows, (int)cols);
   hipLaunchKernelGGL(col_sum_fold_kernel, dim3((unsigned)((cols + 255)/256), (unsigned)batch), dim3(256),
                      0, st, (const float*)scratch, out, (int)cols);
   TG_OK(hipGetLastError());

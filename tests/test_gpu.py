@@ -2091,6 +2091,23 @@ def test_rownorm_kernels_match_torch():
     hip.check(hip.lib().brv_col_sum(hip.ptr(md), hip.ptr(cs), hip.ptr(scratch), 2, 3001, 130,
                                     hip.stream()), 'brv_col_sum')
     assert torch.allclose(cs.cpu(), m.double().sum(1).float(), rtol=1e-5, atol=1e-4)
+    # widths that take the 16-byte form (cols % 4 == 0): fewer / exactly / more column groups than one workgroup's
+    # 64, a width that does not divide 256 threads, fewer rows than row lanes, and an offset (unaligned) view
+    for rows, cols in ((3001, 48), (777, 256), (5000, 300), (2, 8), (130, 1024), (40001, 64)):
+        m = torch.randn(2, rows, cols, generator=gen)
+        scratch = torch.empty(hip.lib().brv_col_sum_scratch_bytes(2, cols), dtype=torch.uint8, device=dev)
+        for off in (0, 1):
+            buf = torch.empty(2*rows*cols + 1, device=dev)
+            md = buf[off:off + 2*rows*cols].view(2, rows, cols)
+            md.copy_(m)
+            outs = []
+            for rep in range(2):
+                cs = torch.empty(2, cols, device=dev)
+                hip.check(hip.lib().brv_col_sum(hip.ptr(md), hip.ptr(cs), hip.ptr(scratch), 2, rows, cols,
+                                                hip.stream()), 'brv_col_sum')
+                outs.append(cs.cpu())
+            assert torch.equal(outs[0], outs[1])                      # fixed order
+            assert torch.allclose(outs[0], m.double().sum(1).float(), rtol=1e-5, atol=2e-4), (rows, cols, off)
 
 
 @pytest.mark.gpu
