@@ -350,10 +350,10 @@ def stream():
 
 def gemm_f32(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a, trans_b, kbatch, a_kbs, b_kbs,
              bias, mode):
-    """``brv_gemm_f32``; a long reduction (a weight gradient summed over the batch, or K >= 8192) goes through
-    ``brv_gemm_f32_ws`` with scratch from the caching allocator when the shape asks for it (ordered reduction
-    split, split-bf16 form: csrc/gemm_f32_big.hip)."""
-    if kbatch > 1 or K >= 8192:
+    """``brv_gemm_f32``; a product whose output has too few tiles to fill the chip (weight gradients summed over the
+    batch, convolutions at the low resolutions) goes through ``brv_gemm_f32_ws`` with scratch from the caching
+    allocator: ordered reduction split, split-bf16 form where the layout allows (csrc/gemm_f32_big.hip)."""
+    if M >= 32 and N >= 32:
         nbytes = lib().brv_gemm_f32_workspace_bytes(batch, M, N, K, trans_a, trans_b, kbatch)
         if nbytes > 0:
             ws = torch.empty(nbytes//4, dtype=torch.float32, device=d.device)
