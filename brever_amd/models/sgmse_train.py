@@ -8,6 +8,8 @@ matrix + exact-fp32 MFMA products for the convolutions and their weight / data g
 brever/models/sgmse/net.py:232-452 exactly as the inference path does; torch only
 concatenates, slices and carries the autograd graph.
 """
+import os
+
 import torch
 
 from .. import hip
@@ -28,6 +30,22 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, t
         trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_bf16')
 
 
+# use_amp convolutions with the column matrix read in place (no 9x copy in HBM: memory for larger batches). Off by
+# default: measured 73.3 against 69.7 ms per step at 4 x 1 s -- the virtual-column loader of gemm_bf16_kernel costs
+# more than the im2col / col2im passes it removes (155 us per product against 59 + 59)
+_IMPLICIT = os.environ.get('BRV_SGMSE_TRAIN_IMPLICIT', '0') == '1'
+
+
+def _gemm_conv(a, img, d, batch, M, N, K, lda, ldd, a_bs, img_bs, d_bs, C, H, W, k, trans_b=0, kbatch=1, a_kbs=0,
+               img_kbs=0, bias=None):
+    """``_gemm(lowp=True)`` whose B operand is the im2col matrix of ``img`` (C, H, W per item; k x k window,
+    stride 1, padding k//2) -- never written out (``brv_gemm_bf16_conv``)."""
+    hip.check(hip.lib().brv_gemm_bf16_conv(
+        hip.ptr(a), hip.ptr(img), hip.ptr(d), batch, M, N, K, lda, ldd, a_bs, img_bs, d_bs, 0, trans_b,
+        kbatch, a_kbs, img_kbs, hip.ptr(bias), 0, 1, C, H, W, k, k, 1, 1, k//2, k//2, H, W, hip.stream()),
+        'brv_gemm_bf16_conv')
+
+
 def _empty(*shape, like):
     return torch.empty(*shape, dtype=torch.float32, device=like.device)
 
@@ -41,11 +59,14 @@ class ConvFn(torch.autograd.Function):
         B, Cin, H, W = x.shape
         Cout, _, k, _ = w.shape
         K, HW = Cin*k*k, H*W
-        col = ConvFn._col(x, k)
         y = _empty(B, Cout, H, W, like=x)
         ctx.lowp = AMP['on']
-        _gemm(w, col, y, B, Cout, HW, K, K, HW, HW, 0, K*HW, Cout*HW, bias=bias, lowp=ctx.lowp)
         ctx.save_for_backward(x, w)
+        if ctx.lowp and k > 1 and _IMPLICIT:
+            _gemm_conv(w, x, y, B, Cout, HW, K, K, HW, 0, Cin*HW, Cout*HW, Cin, H, W, k, bias=bias)
+            return y
+        col = ConvFn._col(x, k)
+        _gemm(w, col, y, B, Cout, HW, K, K, HW, HW, 0, K*HW, Cout*HW, bias=bias, lowp=ctx.lowp)
         return y
 
     @staticmethod
@@ -65,13 +86,25 @@ class ConvFn(torch.autograd.Function):
         B, Cin, H, W = x.shape
         Cout, _, k, _ = w.shape
         K, HW = Cin*k*k, H*W
+        db = _empty(Cout, like=x)
+        hip.check(hip.lib().brv_row_sum(hip.ptr(dy), hip.ptr(db), B, Cout, HW, hip.stream()),
+                  'brv_row_sum')
+        if ctx.lowp and k > 1 and _IMPLICIT:
+            # both gradients as products with a column matrix read in place: dW = dy @ col(x)^T summed over the
+            # batch; dx = the same convolution of dy with the window rotated by 180 degrees and (Cout, Cin) swapped
+            dw = torch.empty_like(w)
+            _gemm_conv(dy, x, dw, 1, Cout, K, HW, HW, K, 0, 0, 0, Cin, H, W, k, trans_b=1, kbatch=B,
+                       a_kbs=Cout*HW, img_kbs=Cin*HW)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                wt = w.flip(2, 3).transpose(0, 1).reshape(Cin, Cout*k*k).contiguous()
+                dx = torch.empty_like(x)
+                _gemm_conv(wt, dy, dx, B, Cin, HW, Cout*k*k, Cout*k*k, HW, 0, Cout*HW, Cin*HW, Cout, H, W, k)
+            return dx, dw, db
         col = ConvFn._col(x, k)
         dw = torch.empty_like(w)
         _gemm(dy, col, dw, 1, Cout, K, HW, HW, HW, K, 0, 0, 0, trans_b=1, kbatch=B,
               a_kbs=Cout*HW, b_kbs=K*HW, lowp=ctx.lowp)
-        db = _empty(Cout, like=x)
-        hip.check(hip.lib().brv_row_sum(hip.ptr(dy), hip.ptr(db), B, Cout, HW, hip.stream()),
-                  'brv_row_sum')
         dx = None
         if ctx.needs_input_grad[0]:
             dcol = col if k != 1 else _empty(B, K, HW, like=x)

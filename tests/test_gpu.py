@@ -2322,3 +2322,44 @@ def test_bf16_column_matrix_kernels():
                                           K, K, N, N, 0, K*N, M*N, 0, 0, 1, 0, 0, None, 0, 3,
                                           hip.stream()), 'brv_gemm_bf16_mixed')
         assert rel(d.float(), ref) <= 4e-3, (M, K, N, rel(d.float(), ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 8, 12, 16, 24, 3), (1, 36, 20, 8, 12, 3), (3, 4, 130, 32, 20, 3), (2, 16, 16, 4, 8, 5)],
+                         ids=lambda c: 'B%d_Cin%d_Cout%d_%dx%d_k%d' % c)
+def test_sgmse_training_convolution_reads_the_column_matrix_in_place(shape):
+    """use_amp SGMSE+ training convolution (models/sgmse_train.py ConvFn; reference nn.Conv2d of net.py under
+    autocast): forward, weight, bias and data gradient with the column matrix read in place
+    (brv_gemm_bf16_conv; the data gradient as the convolution of dy with the rotated, transposed window)
+    against the explicit im2col / col2im form on the same bf16-rounded operands, and against torch's float64
+    convolution of the rounded operands."""
+    import brever_amd.models.sgmse_train as T
+    dev = torch.device('cuda')
+    B, Cin, Cout, H, W, k = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x0 = torch.randn(B, Cin, H, W, generator=g)
+    w0 = torch.randn(Cout, Cin, k, k, generator=g)/(Cin*k*k)**0.5
+    b0 = torch.randn(Cout, generator=g)
+    dy0 = torch.randn(B, Cout, H, W, generator=g)
+    res = {}
+    T.AMP['on'] = True
+    try:
+        for implicit in (True, False):
+            T._IMPLICIT = implicit
+            x, w, b = (t.to(dev).requires_grad_() for t in (x0, w0, b0))
+            y = T.ConvFn.apply(x, w, b)
+            gx, gw, gb = torch.autograd.grad(y, (x, w, b), dy0.to(dev))
+            res[implicit] = [t.detach().cpu().double() for t in (y, gx, gw, gb)]
+    finally:
+        T.AMP['on'] = False
+        T._IMPLICIT = False
+    bf = lambda t: t.to(torch.bfloat16).double()      # noqa: E731
+    xr, wr = bf(x0).requires_grad_(), bf(w0).requires_grad_()
+    yr = torch.nn.functional.conv2d(xr, wr, b0.double(), padding=k//2)
+    # the gradients of the amp path round dy (and w / x) to bf16 as operands too
+    gxr = torch.autograd.grad(torch.nn.functional.conv2d(xr, wr, None, padding=k//2), xr, bf(dy0))[0]
+    gwr = torch.autograd.grad(torch.nn.functional.conv2d(xr, wr, None, padding=k//2), wr, bf(dy0))[0]
+    want = [yr.detach(), gxr, gwr, dy0.double().sum((0, 2, 3))]
+    for name, a, b_, ref in zip(('y', 'dx', 'dw', 'db'), res[True], res[False], want):
+        assert float((a - b_).norm()) <= 1e-5*float(b_.norm()), name
+        assert float((a - ref).norm()) <= 2e-5*float(ref.norm()), name
