@@ -691,12 +691,11 @@ class _LSTMFunction(torch.autograd.Function):
         dw_hh = torch.empty_like(w_hh)
         _gemm(dg, h_prev, dw_hh, G, 4*H, H, BT, 4*H, H, H, BT*4*H, BT*H, 4*H*H, trans_a=1,
               lowp=lowp)
-        # bias gradients: column sums of dg (BT, 4H) per group = row sums of its transpose
+        # bias gradients: column sums of dg (BT, 4H) per group, in a fixed order (no transposed copy)
         db = torch.empty(G, 4*H, dtype=torch.float32, device=x.device)
-        dgt = dg.view(G, BT, 4*H).transpose(1, 2).contiguous()
-        for g in range(G):
-            hip.check(lib.brv_row_sum(hip.ptr(dgt[g]), hip.ptr(db[g]), 1, 4*H, BT, hip.stream()),
-                      'brv_row_sum')
+        scratch = torch.empty(lib.brv_col_sum_scratch_bytes(G, 4*H), dtype=torch.uint8, device=x.device)
+        hip.check(lib.brv_col_sum(hip.ptr(dg), hip.ptr(db), hip.ptr(scratch), G, BT, 4*H, hip.stream()),
+                  'brv_col_sum')
         if ctx.tiled:
             dw_ih, dw_hh, db = (_LSTMFunction._deinterleave(t, H) for t in (dw_ih, dw_hh, db))
         return dx, dw_ih, dw_hh, db, db.clone()

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Kernel statistics and PMC HBM traffic of the widened rows on the GPU box (through gpurun from the repo
 # root):  bash tools/profile_rows.sh r03
-#   fp32 Conv-TasNet training (tools/prof_ctn_f32.py), DCCRN training under use_amp (tools/prof_dccrn.py 1), SGMSE+ use_amp inference at batch 1 and 8
+#   fp32 Conv-TasNet training (tools/prof_ctn_f32.py), DCCRN training under use_amp and in fp32 (tools/prof_dccrn.py 1 / 0),
+#   TF-GridNet training under use_amp (tools/prof_train.py), SGMSE+ use_amp inference at batch 1 and 8
 #   (tools/prof_sgmse.py): rocprofv3 --kernel-trace --stats, then FETCH_SIZE and WRITE_SIZE in separate
 #   --pmc passes (never combined with other trace domains); tools/rows_roofline.py turns each triple into
 #   a `roofline` object of the row's dominant kernel (measured traffic per launch / average duration).
@@ -23,7 +24,13 @@ run() {   # name, program, args...
 }
 rm -f $OUT/${TAG}_rows_roofline.json
 run ctn_fp32 $REPO/tools/prof_ctn_f32.py
+# (per-kernel durations of the DCCRN use_amp step are taken IN ORDER on one stream: with the parameter gradients on
+# the side stream, overlapping kernels share the chip and each reads up to twice its own duration)
+export BRV_DCCRN_WGRAD_SIDE=0
 run dccrn_bf16 $REPO/tools/prof_dccrn.py 1
+unset BRV_DCCRN_WGRAD_SIDE
+run dccrn_fp32 $REPO/tools/prof_dccrn.py 0
+run tfgridnet_bf16 $REPO/tools/prof_train.py tfgridnet 1 3
 run sgmse_b1 $REPO/tools/prof_sgmse.py 1
 run sgmse_b8 $REPO/tools/prof_sgmse.py 8
 cat $OUT/${TAG}_rows_roofline.json | cut -c1-600
