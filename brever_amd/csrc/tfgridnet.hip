@@ -278,6 +278,56 @@ __global__ __launch_bounds__(256) void col_sum_fold_kernel(const float* __restri
   out[(long long)blockIdx.y*cols + j] = acc;
 }
 
+// y (M x N) (+)= x (M x K) @ op(w) (+ bias[n]) for the narrow layers of the grid blocks (M = batch x frames x
+// bands ~ 2.6e5, K and N of 16 - 64: the band / frame linear layers of GridNetBlock, reference
+// brever/models/tfgridnet/tfgridnet.py intra / inter linear + their data gradients): 66 MB of traffic against
+// 0.5 GFLOP -- a 128 x 128 MFMA tile wastes 3/4 of its rows and columns on them. One thread per row: the row in
+// 16-byte loads, the weights through the scalar cache (uniform addresses -> s_load, SGPR operands of the FMAs),
+// N accumulators in registers, fp32 throughout (use_amp included: more than the reference's fp16 keeps).
+template <int N, int KT, bool TB>          // KT: K when it is 16 / 32 / 64 (the row is requested at once), else 0
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           long long M, int K, long long lda, int ldw, long long ldd,
+                                                           int accumulate) {
+  const long long row = (long long)blockIdx.x*256 + threadIdx.x;
+  const long long r = row < M ? row : M - 1;                 // unconditional loads; the store is conditional
+  const float4* xr = reinterpret_cast<const float4*>(x + r*lda);
+  float4* yr = reinterpret_cast<float4*>(y + r*ldd);
+  float acc[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) acc[j] = bias ? bias[j] : 0.f;
+  if (accumulate) {
+#pragma unroll
+    for (int j = 0; j < N/4; ++j) {
+      const float4 o = yr[j];
+      acc[4*j] += o.x; acc[4*j + 1] += o.y; acc[4*j + 2] += o.z; acc[4*j + 3] += o.w;
+    }
+  }
+  auto step = [&](int k4, const float4& xv) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float w0 = TB ? w[j*ldw + k4] : w[k4*ldw + j];
+      const float w1 = TB ? w[j*ldw + k4 + 1] : w[(k4 + 1)*ldw + j];
+      const float w2 = TB ? w[j*ldw + k4 + 2] : w[(k4 + 2)*ldw + j];
+      const float w3 = TB ? w[j*ldw + k4 + 3] : w[(k4 + 3)*ldw + j];
+      acc[j] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[j]))));
+    }
+  };
+  if constexpr (KT > 0) {
+    float4 xv[KT/4];
+#pragma unroll
+    for (int q = 0; q < KT/4; ++q) xv[q] = xr[q];
+#pragma unroll
+    for (int q = 0; q < KT/4; ++q) step(4*q, xv[q]);
+  } else {
+    for (int k4 = 0; k4 < K; k4 += 4) step(k4, xr[k4 >> 2]);
+  }
+  if (row < M) {
+#pragma unroll
+    for (int j = 0; j < N/4; ++j) yr[j] = make_float4(acc[4*j], acc[4*j + 1], acc[4*j + 2], acc[4*j + 3]);
+  }
+}
+
 // unbiased standard deviation of each row (two passes, fp64 accumulators)
 __global__ __launch_bounds__(256) void row_std_kernel(const float* __restrict__ x,
                                                       float* __restrict__ out, long long n) {
@@ -379,6 +429,29 @@ int brv_col_sum(const float* x, float* out, void* scratch, int64_t batch, int64_
                        dim3(256), 0, st, x, (float*)scratch, (long long)rows, (int)cols);
   hipLaunchKernelGGL(col_sum_fold_kernel, dim3((unsigned)((cols + 255)/256), (unsigned)batch), dim3(256),
                      0, st, (const float*)scratch, out, (int)cols);
+  TG_OK(hipGetLastError());
+  return 0;
+}
+int brv_linear_small_supported(int64_t M, int64_t N, int64_t K) {
+  return (N == 16 || N == 32 || N == 64) && K >= 4 && K <= 64 && K % 4 == 0 && M >= 4096;
+}
+int brv_linear_small(const float* x, const float* w, const float* bias, float* y, int64_t M, int64_t N, int64_t K,
+                     int64_t lda, int64_t ldw, int64_t ldd, int trans_b, int accumulate, brv_stream_t stream) {
+  if (!brv_linear_small_supported(M, N, K) || (lda & 3) || (ldd & 3) || lda < K || ldd < N ||
+      (((uintptr_t)x | (uintptr_t)y) & 15) || ldw < (trans_b ? K : N) || M > (1LL << 38))
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((M + 255)/256));
+#define BRV_LS2(N_, K_) do { \
+    if (trans_b) hipLaunchKernelGGL((linear_small_kernel<N_, K_, true>), grid, dim3(256), 0, st, x, w, bias, y, \
+                                    (long long)M, (int)K, (long long)lda, (int)ldw, (long long)ldd, accumulate); \
+    else hipLaunchKernelGGL((linear_small_kernel<N_, K_, false>), grid, dim3(256), 0, st, x, w, bias, y, \
+                            (long long)M, (int)K, (long long)lda, (int)ldw, (long long)ldd, accumulate); } while (0)
+#define BRV_LS(N_) do { if (K == 16) BRV_LS2(N_, 16); else if (K == 32) BRV_LS2(N_, 32); \
+                        else if (K == 64) BRV_LS2(N_, 64); else BRV_LS2(N_, 0); } while (0)
+  if (N == 16) BRV_LS(16); else if (N == 32) BRV_LS(32); else BRV_LS(64);
+#undef BRV_LS2
+#undef BRV_LS
   TG_OK(hipGetLastError());
   return 0;
 }

@@ -219,6 +219,8 @@ SIGNATURES = {
     'brv_rownorm_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_rownorm_backward': (ctypes.c_int, [_c_ptr]*10 + [_c_i64]*4 + [_c_ptr]),
     'brv_col_sum_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
+    'brv_linear_small_supported': (ctypes.c_int, [_c_i64, _c_i64, _c_i64]),
+    'brv_linear_small': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*6 + [ctypes.c_int, ctypes.c_int, _c_ptr]),
     'brv_col_sum': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_row_std': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_row_scale': (ctypes.c_int, [_c_ptr]*3 + [_c_i64, _c_i64, ctypes.c_int, _c_ptr]),

@@ -22,6 +22,8 @@ torch only pads, slices, permutes, concatenates and carries the autograd graph.
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -202,12 +204,22 @@ class _AttentionFn(torch.autograd.Function):
         return dq, dk, dv
 
 
+_SMALL = os.environ.get('BRV_TFG_LINEAR_SMALL', '1') != '0'     # narrow linear layers on brv_linear_small
+
+
 def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_a=0, trans_b=0,
           kbatch=1, a_kbs=0, b_kbs=0, bias=None, mode=0, lowp=False):
     """brv_gemm_f32 / brv_gemm_bf16 (bf16 operands, fp32 accumulation: ``use_amp``); ``mode`` 1
     adds to d, 2 reads ``bias`` per output column; a bf16 ``d`` tensor is written directly."""
     half = torch.bfloat16
     flags = int(b.dtype == half) | int(d.dtype == half) << 1 | int(a.dtype == half) << 2
+    if _SMALL and not flags and batch == 1 and kbatch == 1 and not trans_a and (bias is None or mode == 2) \
+            and lda % 4 == 0 and ldd % 4 == 0 and (a.data_ptr() | d.data_ptr()) % 16 == 0 \
+            and hip.lib().brv_linear_small_supported(M, N, K):
+        # narrow layers (K, N <= 64 over ~2.6e5 rows): one thread per row in fp32 instead of a 128 x 128 MFMA tile
+        hip.check(hip.lib().brv_linear_small(hip.ptr(a), hip.ptr(b), hip.ptr(bias), hip.ptr(d), M, N, K, lda, ldb,
+                                             ldd, trans_b, int(mode == 1), hip.stream()), 'brv_linear_small')
+        return
     if flags:
         hip.check(hip.lib().brv_gemm_bf16_mixed(
             hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
@@ -224,10 +236,11 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_
 
 
 def _column_sums(x, rows, cols, batch=1, lowp=False):
-    """(batch, rows, cols) -> (batch, cols). fp32: ``brv_col_sum`` (fixed order); bf16 tensors or
-    ``lowp``: a ones-vector product on the bf16 MFMA."""
+    """(batch, rows, cols) -> (batch, cols). fp32 tensors: ``brv_col_sum`` (fixed order, 16-byte loads: 17 us for
+    258 516 x 32 -- also under ``lowp``, where round 3 used a ones-vector product with split atomics); bf16
+    tensors: a ones-vector product on the bf16 MFMA."""
     out = torch.empty(batch, cols, dtype=torch.float32, device=x.device)
-    if not lowp and x.dtype == torch.float32:
+    if x.dtype == torch.float32:
         lib = hip.lib()
         scratch = torch.empty(lib.brv_col_sum_scratch_bytes(batch, cols), dtype=torch.uint8,
                               device=x.device)

@@ -594,6 +594,15 @@ int brv_rownorm_backward(const float* x, const float* dy, const float* slope, co
 /* out (batch, cols) = column sums of x (batch, rows, cols), fp32, fixed summation order (the bias
  * gradients of nn.Linear / nn.LSTM on row-major activations); scratch: brv_col_sum_scratch_bytes(). */
 int64_t brv_col_sum_scratch_bytes(int64_t batch, int64_t cols);
+/* y (M x N) = x (M x K) @ op(w) + bias[n] (bias may be NULL; accumulate: y += instead) for the narrow linear
+ * layers of the TF-GridNet grid blocks and their data gradients (reference tfgridnet.py GridNetBlock intra / inter
+ * linear: M = batch x frames x bands, K, N in 16 .. 64): one thread per row, fp32 FMAs, weights through the scalar
+ * cache. op(w)[k][n] = w[k*ldw + n], or w[n*ldw + k] with trans_b (nn.Linear's (out, in) weight). Supported:
+ * N in {16, 32, 64}, K a multiple of 4 up to 64, M >= 4096, 16-byte aligned x / y with lda, ldd multiples of 4
+ * (brv_linear_small_supported tells the shape part); -1 otherwise. */
+int brv_linear_small_supported(int64_t M, int64_t N, int64_t K);
+int brv_linear_small(const float* x, const float* w, const float* bias, float* y, int64_t M, int64_t N, int64_t K,
+                     int64_t lda, int64_t ldw, int64_t ldd, int trans_b, int accumulate, brv_stream_t stream);
 int brv_col_sum(const float* x, float* out, void* scratch, int64_t batch, int64_t rows, int64_t cols,
                 brv_stream_t stream);
 int brv_row_std(const float* x, float* out, int64_t rows, int64_t n, brv_stream_t stream);

@@ -2363,3 +2363,44 @@ def test_sgmse_training_convolution_reads_the_column_matrix_in_place(shape):
     for name, a, b_, ref in zip(('y', 'dx', 'dw', 'db'), res[True], res[False], want):
         assert float((a - b_).norm()) <= 1e-5*float(b_.norm()), name
         assert float((a - ref).norm()) <= 2e-5*float(ref.norm()), name
+
+
+@pytest.mark.gpu
+def test_linear_small_matches_float64():
+    """brv_linear_small (narrow linear layers of the TF-GridNet grid blocks, one thread per row in fp32) against the
+    float64 product: every (N, K) form incl. a K off the unrolled sizes, both weight orders, bias / accumulate / plain,
+    leading dimensions larger than the extents, a row count off the workgroup size; unsupported shapes are refused."""
+    from brever_amd import hip
+    lib = hip.lib()
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(3)
+    M = 4096*3 + 77
+    for N, K in ((16, 32), (32, 16), (32, 32), (64, 64), (32, 24), (16, 64), (64, 8)):
+        for tb in (0, 1):
+            for mode in ('plain', 'bias', 'acc'):
+                lda, ldd, ldw = K + 4, N + 8, (K if tb else N) + 3
+                x = torch.randn(M, lda, generator=g)
+                w = torch.randn((N if tb else K), ldw, generator=g)
+                b = torch.randn(N, generator=g)
+                y0 = torch.randn(M, ldd, generator=g)
+                opw = w[:, :K].t() if tb else w[:, :N]
+                want = x[:, :K].double() @ opw.double()
+                if mode == 'bias':
+                    want = want + b.double()
+                if mode == 'acc':
+                    want = want + y0[:, :N].double()
+                xd, wd, bd, yd = x.to(dev), w.to(dev), b.to(dev), y0.to(dev).clone()
+                assert lib.brv_linear_small_supported(M, N, K)
+                hip.check(lib.brv_linear_small(hip.ptr(xd), hip.ptr(wd), hip.ptr(bd) if mode == 'bias' else None,
+                                               hip.ptr(yd), M, N, K, lda, ldw, ldd, tb, int(mode == 'acc'), hip.stream()),
+                          'brv_linear_small')
+                got = yd.cpu()
+                assert torch.equal(got[:, N:], y0[:, N:]), 'wrote outside the N columns'
+                rel = float((got[:, :N].double() - want).norm()/want.norm())
+                assert rel <= 1e-6, (N, K, tb, mode, rel)
+    assert not lib.brv_linear_small_supported(M, 48, 32) and not lib.brv_linear_small_supported(M, 32, 30)
+    assert not lib.brv_linear_small_supported(100, 32, 32)
+    xd = torch.randn(M, 32, device=dev)
+    yd = torch.empty(M, 32, device=dev)
+    wd = torch.randn(32, 32, device=dev)
+    assert lib.brv_linear_small(hip.ptr(xd), hip.ptr(wd), None, hip.ptr(yd), M, 32, 32, 30, 32, 32, 0, 0, hip.stream()) == -1
