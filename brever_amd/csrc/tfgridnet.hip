@@ -328,6 +328,82 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
   }
 }
 
+// d (MI x NJ) = sum over rows r of a[r][i] b[r][j] for the same narrow layers (their weight gradients: 2.6e5 rows,
+// MI, NJ of 16 / 32): the rows are cut into slices, a workgroup stages 64 rows of both operands in LDS (16-byte
+// loads) and every thread owns one i and four consecutive j; partial matrices are folded in slice order
+// (fixed order, no atomics). 66 MB of traffic per call; the 128 x 128 product with 512 atomic splits took ~80 us.
+constexpr int kWgSlices = 512, kWgChunk = 64;
+template <int MI, int NJ>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ part, long long R, long long lda,
+                                                          long long ldb) {
+  static_assert(MI*NJ/4 <= 256 && kWgChunk*MI/4 % 256 == 0 && kWgChunk*NJ/4 % 256 == 0, "tile");
+  __shared__ __attribute__((aligned(16))) float As[kWgChunk][MI];
+  __shared__ __attribute__((aligned(16))) float Bs[kWgChunk][NJ];
+  const int t = threadIdx.x;
+  const int i = t / (NJ/4), j4 = t % (NJ/4);
+  const bool owner = t < MI*NJ/4;
+  const long long per = ((R + kWgSlices - 1)/kWgSlices + kWgChunk - 1)/kWgChunk*kWgChunk;
+  const long long r0 = (long long)blockIdx.x*per, r1 = min(R, r0 + per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long rc = r0; rc < r1; rc += kWgChunk) {
+    // unconditional loads at clamped rows, zeroed by a mask (rows past the slice add nothing)
+#pragma unroll
+    for (int q = 0; q < kWgChunk*MI/4/256; ++q) {
+      const int e = t + 256*q, rr = e / (MI/4), c4 = e % (MI/4);
+      const long long r = rc + rr;
+      float4 v = *reinterpret_cast<const float4*>(a + (r < r1 ? r : r1 - 1)*lda + 4*c4);
+      if (r >= r1) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&As[rr][4*c4]) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < kWgChunk*NJ/4/256; ++q) {
+      const int e = t + 256*q, rr = e / (NJ/4), c4 = e % (NJ/4);
+      const long long r = rc + rr;
+      const float4 v = *reinterpret_cast<const float4*>(b + (r < r1 ? r : r1 - 1)*ldb + 4*c4);
+      *reinterpret_cast<float4*>(&Bs[rr][4*c4]) = v;
+    }
+    __syncthreads();
+    if (owner) {
+#pragma unroll 16
+      for (int rr = 0; rr < kWgChunk; ++rr) {
+        const float x = As[rr][i];
+        const float4 y = *reinterpret_cast<const float4*>(&Bs[rr][4*j4]);
+        acc.x = fmaf(x, y.x, acc.x); acc.y = fmaf(x, y.y, acc.y);
+        acc.z = fmaf(x, y.z, acc.z); acc.w = fmaf(x, y.w, acc.w);
+      }
+    }
+    __syncthreads();
+  }
+  if (owner) *reinterpret_cast<float4*>(part + ((long long)blockIdx.x*MI + i)*NJ + 4*j4) = acc;
+}
+// fold: 32 outputs per workgroup, eight threads per output over the slices (eight loads in flight each), the eight
+// partial sums added in lane order through LDS
+__global__ __launch_bounds__(256) void wgrad_small_fold_kernel(const float* __restrict__ part, float* __restrict__ d,
+                                                               int MI, int NJ, long long ldd, int slices) {
+  __shared__ float red[8][32];
+  const int t = threadIdx.x, el = t & 31, ln = t >> 5;
+  const int e = blockIdx.x*32 + el;                     // MI*NJ is a multiple of 32
+  const long long n = (long long)MI*NJ;
+  float s[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s[u] = 0.f;
+  int q = ln;
+  for (; q + 56 < slices; q += 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += part[(long long)(q + 8*u)*n + e];
+  }
+  for (; q < slices; q += 8) s[0] += part[(long long)q*n + e];
+  red[ln][el] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (ln == 0) {
+    float v = red[0][el];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) v += red[u][el];
+    d[(long long)(e / NJ)*ldd + e % NJ] = v;
+  }
+}
+
 // unbiased standard deviation of each row (two passes, fp64 accumulators)
 __global__ __launch_bounds__(256) void row_std_kernel(const float* __restrict__ x,
                                                       float* __restrict__ out, long long n) {
@@ -452,6 +528,31 @@ int brv_linear_small(const float* x, const float* w, const float* bias, float* y
   if (N == 16) BRV_LS(16); else if (N == 32) BRV_LS(32); else BRV_LS(64);
 #undef BRV_LS2
 #undef BRV_LS
+  TG_OK(hipGetLastError());
+  return 0;
+}
+int brv_linear_small_wgrad_supported(int64_t rows, int64_t MI, int64_t NJ) {
+  return (MI == 16 || MI == 32) && (NJ == 16 || NJ == 32) && rows >= 4096;
+}
+int64_t brv_linear_small_wgrad_scratch_bytes(int64_t MI, int64_t NJ) { return (int64_t)kWgSlices*MI*NJ*4; }
+int brv_linear_small_wgrad(const float* a, const float* b, float* d, void* scratch, int64_t rows, int64_t MI,
+                           int64_t NJ, int64_t lda, int64_t ldb, int64_t ldd, brv_stream_t stream) {
+  if (!brv_linear_small_wgrad_supported(rows, MI, NJ) || (lda & 3) || (ldb & 3) || lda < MI || ldb < NJ ||
+      ldd < NJ || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)scratch) & 15) || !scratch)
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const long long per = ((rows + kWgSlices - 1)/kWgSlices + kWgChunk - 1)/kWgChunk*kWgChunk;
+  const int slices = (int)((rows + per - 1)/per);
+  float* part = (float*)scratch;
+#define BRV_WS(MI_, NJ_) hipLaunchKernelGGL((wgrad_small_kernel<MI_, NJ_>), dim3(slices), dim3(256), 0, st, a, b, \
+                                            part, (long long)rows, (long long)lda, (long long)ldb)
+  if (MI == 16 && NJ == 16) BRV_WS(16, 16);
+  else if (MI == 16) BRV_WS(16, 32);
+  else if (NJ == 16) BRV_WS(32, 16);
+  else BRV_WS(32, 32);
+#undef BRV_WS
+  hipLaunchKernelGGL(wgrad_small_fold_kernel, dim3((unsigned)(MI*NJ/32)), dim3(256), 0, st, part, d,
+                     (int)MI, (int)NJ, (long long)ldd, slices);
   TG_OK(hipGetLastError());
   return 0;
 }

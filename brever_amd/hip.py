@@ -221,6 +221,9 @@ SIGNATURES = {
     'brv_col_sum_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_linear_small_supported': (ctypes.c_int, [_c_i64, _c_i64, _c_i64]),
     'brv_linear_small': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*6 + [ctypes.c_int, ctypes.c_int, _c_ptr]),
+    'brv_linear_small_wgrad_supported': (ctypes.c_int, [_c_i64, _c_i64, _c_i64]),
+    'brv_linear_small_wgrad_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
+    'brv_linear_small_wgrad': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*6 + [_c_ptr]),
     'brv_col_sum': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_row_std': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_row_scale': (ctypes.c_int, [_c_ptr]*3 + [_c_i64, _c_i64, ctypes.c_int, _c_ptr]),

@@ -220,6 +220,15 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_
         hip.check(hip.lib().brv_linear_small(hip.ptr(a), hip.ptr(b), hip.ptr(bias), hip.ptr(d), M, N, K, lda, ldb,
                                              ldd, trans_b, int(mode == 1), hip.stream()), 'brv_linear_small')
         return
+    if _SMALL and not flags and batch == 1 and kbatch == 1 and trans_a and not trans_b and bias is None and mode == 0 \
+            and lda % 4 == 0 and ldb % 4 == 0 and (a.data_ptr() | b.data_ptr()) % 16 == 0 \
+            and hip.lib().brv_linear_small_wgrad_supported(K, M, N):
+        # their weight gradients: (rows x M)^T (rows x N) over ~2.6e5 rows, slices added in a fixed order
+        lib = hip.lib()
+        scratch = torch.empty(lib.brv_linear_small_wgrad_scratch_bytes(M, N), dtype=torch.uint8, device=d.device)
+        hip.check(lib.brv_linear_small_wgrad(hip.ptr(a), hip.ptr(b), hip.ptr(d), hip.ptr(scratch), K, M, N, lda, ldb,
+                                             ldd, hip.stream()), 'brv_linear_small_wgrad')
+        return
     if flags:
         hip.check(hip.lib().brv_gemm_bf16_mixed(
             hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,

@@ -601,6 +601,15 @@ int64_t brv_col_sum_scratch_bytes(int64_t batch, int64_t cols);
  * N in {16, 32, 64}, K a multiple of 4 up to 64, M >= 4096, 16-byte aligned x / y with lda, ldd multiples of 4
  * (brv_linear_small_supported tells the shape part); -1 otherwise. */
 int brv_linear_small_supported(int64_t M, int64_t N, int64_t K);
+/* The weight gradient of those layers: d (MI x NJ, row stride ldd) = sum over rows r of a[r][i] * b[r][j]
+ * (a rows x MI, b rows x NJ, row-major with strides lda / ldb: a = dy, b = x for nn.Linear's (out, in) weight).
+ * MI, NJ in {16, 32}, rows >= 4096, 16-byte aligned operands with strides multiples of 4; the rows are cut into
+ * slices whose partial matrices (scratch: brv_linear_small_wgrad_scratch_bytes) are added in slice order --
+ * bitwise repeatable. -1 for anything else. */
+int brv_linear_small_wgrad_supported(int64_t rows, int64_t MI, int64_t NJ);
+int64_t brv_linear_small_wgrad_scratch_bytes(int64_t MI, int64_t NJ);
+int brv_linear_small_wgrad(const float* a, const float* b, float* d, void* scratch, int64_t rows, int64_t MI,
+                           int64_t NJ, int64_t lda, int64_t ldb, int64_t ldd, brv_stream_t stream);
 int brv_linear_small(const float* x, const float* w, const float* bias, float* y, int64_t M, int64_t N, int64_t K,
                      int64_t lda, int64_t ldw, int64_t ldd, int trans_b, int accumulate, brv_stream_t stream);
 int brv_col_sum(const float* x, float* out, void* scratch, int64_t batch, int64_t rows, int64_t cols,

@@ -2404,3 +2404,33 @@ def test_linear_small_matches_float64():
     yd = torch.empty(M, 32, device=dev)
     wd = torch.randn(32, 32, device=dev)
     assert lib.brv_linear_small(hip.ptr(xd), hip.ptr(wd), None, hip.ptr(yd), M, 32, 32, 30, 32, 32, 0, 0, hip.stream()) == -1
+
+
+@pytest.mark.gpu
+def test_linear_small_weight_gradient_matches_float64_and_repeats():
+    """brv_linear_small_wgrad (d = a^T b over ~1e5 rows, 16 / 32 wide) against float64, every width pair, strides
+    larger than the widths, a row count off the slice / chunk sizes, bitwise repeatable, row stride of d honoured."""
+    from brever_amd import hip
+    lib = hip.lib()
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(4)
+    for rows in (4096, 70001):
+        for MI in (16, 32):
+            for NJ in (16, 32):
+                lda, ldb, ldd = MI + 4, NJ + 8, NJ + 3
+                a = torch.randn(rows, lda, generator=g)
+                b = torch.randn(rows, ldb, generator=g)
+                want = a[:, :MI].double().t() @ b[:, :NJ].double()
+                ad, bd = a.to(dev), b.to(dev)
+                scratch = torch.full((lib.brv_linear_small_wgrad_scratch_bytes(MI, NJ)//4,), float('nan'), device=dev)
+                outs = []
+                for rep in range(2):
+                    d = torch.full((MI, ldd), 7.0, device=dev)
+                    hip.check(lib.brv_linear_small_wgrad(hip.ptr(ad), hip.ptr(bd), hip.ptr(d), hip.ptr(scratch), rows,
+                                                         MI, NJ, lda, ldb, ldd, hip.stream()), 'brv_linear_small_wgrad')
+                    outs.append(d.cpu())
+                assert torch.equal(outs[0], outs[1])
+                assert bool((outs[0][:, NJ:] == 7.0).all())
+                rel = float((outs[0][:, :NJ].double() - want).norm()/want.norm())
+                assert rel <= 2e-6, (rows, MI, NJ, rel)
+    assert not lib.brv_linear_small_wgrad_supported(70001, 64, 32) and not lib.brv_linear_small_wgrad_supported(100, 32, 32)
