@@ -268,6 +268,49 @@ __global__ __launch_bounds__(256) void col_sum_part4_kernel(const float* __restr
     reinterpret_cast<float4*>(part + ((long long)blockIdx.z*kColSlices + slice)*cols)[g0 + t] = acc;
   }
 }
+// bf16 input (the saved gate gradients of the use_amp recurrences): a thread owns 8 consecutive columns (one 16-byte
+// load = 8 values), otherwise as col_sum_part4_kernel; sums in fp32
+__global__ __launch_bounds__(256) void col_sum_part8h_kernel(const unsigned short* __restrict__ x,
+                                                             float* __restrict__ part, long long rows, int cols) {
+  __shared__ float red[256][8];
+  const int c8 = cols >> 3;
+  const int g0 = blockIdx.x*64, cw = min(64, c8 - g0), RL = 256/cw;
+  const int t = threadIdx.x, gl = t % cw, rl = t / cw, slice = blockIdx.y;
+  const uint4* xb = reinterpret_cast<const uint4*>(x + (long long)blockIdx.z*rows*cols) + g0 + gl;
+  const long long chunk = (rows + kColSlices - 1)/kColSlices;
+  const long long r0 = slice*chunk, r1 = min(rows, r0 + chunk);
+  float a0[8], a1[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a0[u] = a1[u] = 0.f;
+  auto add = [](float* a, const uint4& v) {
+    a[0] += __uint_as_float(v.x << 16); a[1] += __uint_as_float(v.x & 0xffff0000u);
+    a[2] += __uint_as_float(v.y << 16); a[3] += __uint_as_float(v.y & 0xffff0000u);
+    a[4] += __uint_as_float(v.z << 16); a[5] += __uint_as_float(v.z & 0xffff0000u);
+    a[6] += __uint_as_float(v.w << 16); a[7] += __uint_as_float(v.w & 0xffff0000u);
+  };
+  if (rl < RL) {
+    long long r = r0 + rl;
+    for (; r + 3*RL < r1; r += 4*RL) {
+      const uint4 v0 = xb[r*c8], v1 = xb[(r + RL)*c8], v2 = xb[(r + 2*RL)*c8], v3 = xb[(r + 3*RL)*c8];
+      add(a0, v0); add(a1, v1); add(a0, v2); add(a1, v3);
+    }
+    for (; r < r1; r += RL) add(a0, xb[r*c8]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) red[t][u] = a0[u] + a1[u];
+  }
+  __syncthreads();
+  if (t < cw) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = red[t][u];
+    for (int q = 1; q < RL; ++q)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += red[q*cw + t][u];
+    float4* o = reinterpret_cast<float4*>(part + ((long long)blockIdx.z*kColSlices + slice)*cols) + 2*(g0 + t);
+    o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  }
+}
 __global__ __launch_bounds__(256) void col_sum_fold_kernel(const float* __restrict__ part,
                                                            float* __restrict__ out, int cols) {
   const int j = blockIdx.x*256 + threadIdx.x;
@@ -553,6 +596,19 @@ int brv_linear_small_wgrad(const float* a, const float* b, float* d, void* scrat
 #undef BRV_WS
   hipLaunchKernelGGL(wgrad_small_fold_kernel, dim3((unsigned)(MI*NJ/32)), dim3(256), 0, st, part, d,
                      (int)MI, (int)NJ, (long long)ldd, slices);
+  TG_OK(hipGetLastError());
+  return 0;
+}
+int brv_col_sum_bf16(const void* x, float* out, void* scratch, int64_t batch, int64_t rows, int64_t cols,
+                     brv_stream_t stream) {
+  if (batch < 1 || rows < 1 || cols < 8 || batch > 65535 || cols % 8 != 0 ||
+      (((uintptr_t)x | (uintptr_t)scratch) & 15))
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(col_sum_part8h_kernel, dim3((unsigned)((cols/8 + 63)/64), kColSlices, (unsigned)batch),
+                     dim3(256), 0, st, (const unsigned short*)x, (float*)scratch, (long long)rows, (int)cols);
+  hipLaunchKernelGGL(col_sum_fold_kernel, dim3((unsigned)((cols + 255)/256), (unsigned)batch), dim3(256),
+                     0, st, (const float*)scratch, out, (int)cols);
   TG_OK(hipGetLastError());
   return 0;
 }

@@ -225,6 +225,7 @@ SIGNATURES = {
     'brv_linear_small_wgrad_scratch_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_linear_small_wgrad': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*6 + [_c_ptr]),
     'brv_col_sum': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_col_sum_bf16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_row_std': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_row_scale': (ctypes.c_int, [_c_ptr]*3 + [_c_i64, _c_i64, ctypes.c_int, _c_ptr]),
     'brv_cplx_moments': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),

@@ -256,6 +256,13 @@ def _column_sums(x, rows, cols, batch=1, lowp=False):
         hip.check(lib.brv_col_sum(hip.ptr(x), hip.ptr(out), hip.ptr(scratch), batch, rows, cols,
                                   hip.stream()), 'brv_col_sum')
         return out
+    if x.dtype == torch.bfloat16 and cols % 8 == 0 and x.data_ptr() % 16 == 0:
+        lib = hip.lib()
+        scratch = torch.empty(lib.brv_col_sum_scratch_bytes(batch, cols), dtype=torch.uint8,
+                              device=x.device)
+        hip.check(lib.brv_col_sum_bf16(hip.ptr(x), hip.ptr(out), hip.ptr(scratch), batch, rows, cols,
+                                       hip.stream()), 'brv_col_sum_bf16')
+        return out
     ones = torch.ones(rows, dtype=torch.float32, device=x.device)
     _gemm(ones, x, out, batch, 1, cols, rows, rows, cols, cols, 0, rows*cols, cols, lowp=True)
     return out

@@ -614,6 +614,10 @@ int brv_linear_small(const float* x, const float* w, const float* bias, float* y
                      int64_t lda, int64_t ldw, int64_t ldd, int trans_b, int accumulate, brv_stream_t stream);
 int brv_col_sum(const float* x, float* out, void* scratch, int64_t batch, int64_t rows, int64_t cols,
                 brv_stream_t stream);
+/* The same sums of a bf16 (rows x cols) matrix (cols a multiple of 8, 16-byte aligned; the gate gradients the use_amp
+ * recurrences keep in bf16), fp32 accumulation and output, same scratch; -1 for other shapes. */
+int brv_col_sum_bf16(const void* x, float* out, void* scratch, int64_t batch, int64_t rows, int64_t cols,
+                     brv_stream_t stream);
 int brv_row_std(const float* x, float* out, int64_t rows, int64_t n, brv_stream_t stream);
 int brv_row_scale(const float* x, const float* s, float* y, int64_t rows, int64_t n, int divide,
                   brv_stream_t stream);

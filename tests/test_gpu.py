@@ -2108,6 +2108,20 @@ def test_rownorm_kernels_match_torch():
                 outs.append(cs.cpu())
             assert torch.equal(outs[0], outs[1])                      # fixed order
             assert torch.allclose(outs[0], m.double().sum(1).float(), rtol=1e-5, atol=2e-4), (rows, cols, off)
+    # bf16 matrices (the gate gradients of the use_amp recurrences): 8 columns per 16-byte load, fp32 sums
+    for rows, cols in ((3001, 48), (777, 512), (5000, 1000), (2, 8), (40001, 64)):
+        m = torch.randn(2, rows, cols, generator=gen).to(torch.bfloat16)
+        md = m.to(dev)
+        scratch = torch.empty(hip.lib().brv_col_sum_scratch_bytes(2, cols), dtype=torch.uint8, device=dev)
+        outs = []
+        for rep in range(2):
+            cs = torch.empty(2, cols, device=dev)
+            hip.check(hip.lib().brv_col_sum_bf16(hip.ptr(md), hip.ptr(cs), hip.ptr(scratch), 2, rows, cols,
+                                                 hip.stream()), 'brv_col_sum_bf16')
+            outs.append(cs.cpu())
+        assert torch.equal(outs[0], outs[1])
+        assert torch.allclose(outs[0], m.double().sum(1).float(), rtol=1e-5, atol=2e-4), (rows, cols)
+    assert hip.lib().brv_col_sum_bf16(hip.ptr(md), hip.ptr(cs), hip.ptr(scratch), 2, 100, 12, hip.stream()) == -1
 
 
 @pytest.mark.gpu
