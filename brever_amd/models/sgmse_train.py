@@ -46,6 +46,13 @@ def _gemm_conv(a, img, d, batch, M, N, K, lda, ldd, a_bs, img_bs, d_bs, C, H, W,
         'brv_gemm_bf16_conv')
 
 
+# Column matrices kept from the forward pass for the weight gradient (instead of a second im2col in backward): up to
+# this many bytes per network evaluation -- the device has 288 GB, the default network at 4 x 1 s keeps 9 GB; past
+# the budget (long inputs, large batches) a convolution falls back to rebuilding its column matrix
+_COL_BUDGET = int(float(os.environ.get('BRV_SGMSE_COL_CACHE_GB', '48'))*2**30)
+_col_kept = [0]
+
+
 def _empty(*shape, like):
     return torch.empty(*shape, dtype=torch.float32, device=like.device)
 
@@ -67,6 +74,12 @@ class ConvFn(torch.autograd.Function):
             return y
         col = ConvFn._col(x, k)
         _gemm(w, col, y, B, Cout, HW, K, K, HW, HW, 0, K*HW, Cout*HW, bias=bias, lowp=ctx.lowp)
+        ctx.col = None
+        if k > 1 and any(ctx.needs_input_grad[:2]):
+            nbytes = col.numel()*col.element_size()
+            if _col_kept[0] + nbytes <= _COL_BUDGET:
+                _col_kept[0] += nbytes
+                ctx.col = col
         return y
 
     @staticmethod
@@ -101,7 +114,11 @@ class ConvFn(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 _gemm_conv(wt, dy, dx, B, Cin, HW, Cout*k*k, Cout*k*k, HW, 0, Cout*HW, Cin*HW, Cout, H, W, k)
             return dx, dw, db
-        col = ConvFn._col(x, k)
+        col = getattr(ctx, 'col', None)
+        if col is None:
+            col = ConvFn._col(x, k)
+        else:
+            ctx.col = None                       # (its memory becomes dcol below and is released with this call)
         dw = torch.empty_like(w)
         _gemm(dy, col, dw, 1, Cout, K, HW, HW, HW, K, 0, 0, 0, trans_b=1, kbatch=B,
               a_kbs=Cout*HW, b_kbs=K*HW, lowp=ctx.lowp)
@@ -411,6 +428,7 @@ def unet_block(blk, x, emb):
 def unet(net, x, sigma):
     """DiffusionUNet.forward (net.py:232-262) with gradients."""
     from .sgmse import AuxiliaryDown, AuxiliaryUp  # noqa: F401
+    _col_kept[0] = 0                             # column-matrix budget of this evaluation (ConvFn.forward)
     emb = net.emb.fourier_proj(sigma.reshape(-1))
     emb = SiluFn.apply(LinearFn.apply(emb, net.emb.linear_1.weight, net.emb.linear_1.bias))
     emb = SiluFn.apply(LinearFn.apply(emb, net.emb.linear_2.weight, net.emb.linear_2.bias))
