@@ -165,6 +165,7 @@ def _gemm_conv(a, img, d, batch, M, N, K, lda, ldd, a_bs, img_bs, d_bs, mode, im
 
 
 _IMPLICIT = os.environ.get('BRV_DCCRN_IM2COL', '0') != '1'     # use_amp: implicit GEMM convolutions
+_COL_KEEP_BYTES = int(float(os.environ.get('BRV_DCCRN_COL_KEEP_GB', '8'))*2**30)   # per column matrix kept for backward
 
 
 _ROWS = os.environ.get('BRV_DCCRN_ROWS', '1') != '0'      # use_amp: one-launch row convolutions (csrc/cconv.hip)
@@ -280,6 +281,7 @@ class _ComplexConvFunction(torch.autograd.Function):
         geom = geom4[:3]
         lib = hip.lib()
         lowp = ctx.lowp = _AMP['on']
+        kept_col = None
         x = x.contiguous()
         B, C2, H, W = x.shape
         rows = ctx.rows = bool(lowp and _ROWS and tuple(map(tuple, geom4)) == _ROWS_GEOM
@@ -336,7 +338,12 @@ class _ComplexConvFunction(torch.autograd.Function):
             y = torch.empty(B, 2*Cout, Ho, Wo, dtype=torch.float32, device=x.device)
             _gemm(wc, col, y, B, 2*Cout, Ho*Wo, 2*Cw, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cw*Ho*Wo,
                   2*Cout*Ho*Wo, bias=bias, lowp=lowp)
+            # kept for the weight gradient (no second im2col in backward; 3 GB over the six encoder layers at
+            # 16 x 4 s -- the device has 288), unless one matrix alone is out of proportion
+            if any(ctx.needs_input_grad[:5]) and col.numel()*col.element_size() <= _COL_KEEP_BYTES:
+                kept_col = col
         ctx.two = skip is not None
+        ctx.col = kept_col
         ctx.save_for_backward(x, wc, *((skip,) if ctx.two else ()))
         ctx.cfg = (geom, transpose, (H, W), (Ho, Wo), Cin, Cout, R, Cw, wr.shape)
         return y
@@ -432,7 +439,9 @@ class _ComplexConvFunction(torch.autograd.Function):
             _gemm(x, dcol, dwc, 1, 2*Cin, 2*Cw, H*W, H*W, H*W, 2*Cw, 0, 0, 0, trans_b=1,
                   kbatch=B, a_kbs=2*Cin*H*W, b_kbs=2*Cw*H*W, lowp=lowp)
         else:
-            col = _im2col(x, geom, (Ho, Wo), lowp)                 # (B, 2*Cw, Ho*Wo)
+            col, ctx.col = ctx.col, None                           # the forward pass's column matrix, if kept
+            if col is None:
+                col = _im2col(x, geom, (Ho, Wo), lowp)             # (B, 2*Cw, Ho*Wo)
             _gemm(dy, col, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, trans_b=1,
                   kbatch=B, a_kbs=2*Cout*Ho*Wo, b_kbs=2*Cw*Ho*Wo, lowp=lowp)
             _gemm(wc, dy, col, B, 2*Cw, Ho*Wo, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 0, 2*Cout*Ho*Wo,
