@@ -20,7 +20,15 @@ AMP = {'on': False}       # set by SGMSEp.loss around the forward pass (use_amp)
 
 def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, trans_b=0,
           kbatch=1, a_kbs=0, b_kbs=0, bias=None, lowp=False):
-    """``lowp``: bf16 operands with fp32 accumulation (the convolutions under ``use_amp``)."""
+    """``lowp``: bf16 operands with fp32 accumulation (the convolutions under ``use_amp``); a bf16 ``b`` or ``d``
+    tensor (the column matrices of those convolutions) selects ``brv_gemm_bf16_mixed``."""
+    flags = int(b.dtype == torch.bfloat16) | int(d.dtype == torch.bfloat16) << 1
+    if flags:
+        assert lowp
+        hip.check(hip.lib().brv_gemm_bf16_mixed(
+            hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
+            trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, flags, hip.stream()), 'brv_gemm_bf16_mixed')
+        return
     if not lowp:
         hip.gemm_f32(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a, trans_b, kbatch, a_kbs,
                      b_kbs, bias, 0)
@@ -29,6 +37,11 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs, trans_a=0, t
         hip.ptr(a), hip.ptr(b), hip.ptr(d), batch, M, N, K, lda, ldb, ldd, a_bs, b_bs, d_bs,
         trans_a, trans_b, kbatch, a_kbs, b_kbs, hip.ptr(bias), 0, hip.stream()), 'brv_gemm_bf16')
 
+
+# use_amp: the explicit column matrices (and the column-matrix gradient) in bf16 -- the products round them to bf16
+# anyway; half the bytes (and half the kept memory) of the largest tensors of a convolution. Off by default: measured
+# 65.9 against 61.9 ms per step at 4 x 1 s (the mixed-type product's loader costs more than the bytes it saves)
+_COL_BF16 = os.environ.get('BRV_SGMSE_COL_BF16', '0') == '1'
 
 # use_amp convolutions with the column matrix read in place (no 9x copy in HBM: memory for larger batches). Off by
 # default: measured 73.3 against 69.7 ms per step at 4 x 1 s -- the virtual-column loader of gemm_bf16_kernel costs
@@ -72,7 +85,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.lowp and k > 1 and _IMPLICIT:
             _gemm_conv(w, x, y, B, Cout, HW, K, K, HW, 0, Cin*HW, Cout*HW, Cin, H, W, k, bias=bias)
             return y
-        col = ConvFn._col(x, k)
+        col = ConvFn._col(x, k, ctx.lowp)
         _gemm(w, col, y, B, Cout, HW, K, K, HW, HW, 0, K*HW, Cout*HW, bias=bias, lowp=ctx.lowp)
         ctx.col = None
         if k > 1 and any(ctx.needs_input_grad[:2]):
@@ -83,13 +96,14 @@ class ConvFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def _col(x, k):
+    def _col(x, k, lowp=False):
         if k == 1:
             return x
         B, Cin, H, W = x.shape
-        col = _empty(B, Cin*k*k, H*W, like=x)
-        hip.check(hip.lib().brv_im2col(hip.ptr(x), hip.ptr(col), B, Cin, H, W, k, k, 1, 1, k//2,
-                                       k//2, H, W, hip.stream()), 'brv_im2col')
+        half = lowp and _COL_BF16
+        col = torch.empty(B, Cin*k*k, H*W, dtype=torch.bfloat16 if half else torch.float32, device=x.device)
+        fn, name = (hip.lib().brv_im2col_bf16, 'brv_im2col_bf16') if half else (hip.lib().brv_im2col, 'brv_im2col')
+        hip.check(fn(hip.ptr(x), hip.ptr(col), B, Cin, H, W, k, k, 1, 1, k//2, k//2, H, W, hip.stream()), name)
         return col
 
     @staticmethod
@@ -116,7 +130,7 @@ class ConvFn(torch.autograd.Function):
             return dx, dw, db
         col = getattr(ctx, 'col', None)
         if col is None:
-            col = ConvFn._col(x, k)
+            col = ConvFn._col(x, k, ctx.lowp)
         else:
             ctx.col = None                       # (its memory becomes dcol below and is released with this call)
         dw = torch.empty_like(w)
@@ -131,8 +145,10 @@ class ConvFn(torch.autograd.Function):
                 dx = dcol.view(B, Cin, H, W)
             else:
                 dx = torch.empty_like(x)
-                hip.check(hip.lib().brv_col2im(hip.ptr(dcol), None, hip.ptr(dx), B, Cin, H, W, k, k,
-                                               1, 1, k//2, k//2, H, W, hip.stream()), 'brv_col2im')
+                fn, name = (hip.lib().brv_col2im_bf16, 'brv_col2im_bf16') if dcol.dtype == torch.bfloat16 else \
+                    (hip.lib().brv_col2im, 'brv_col2im')
+                hip.check(fn(hip.ptr(dcol), None, hip.ptr(dx), B, Cin, H, W, k, k, 1, 1, k//2, k//2, H, W,
+                             hip.stream()), name)
         return dx, dw, db
 
 

@@ -2358,6 +2358,7 @@ def test_sgmse_training_convolution_reads_the_column_matrix_in_place(shape):
     res = {}
     T.AMP['on'] = True
     try:
+        T._COL_BF16 = True                # the explicit form with bf16 column matrices (switch BRV_SGMSE_COL_BF16)
         for implicit in (True, False):
             T._IMPLICIT = implicit
             x, w, b = (t.to(dev).requires_grad_() for t in (x0, w0, b0))
@@ -2367,6 +2368,7 @@ def test_sgmse_training_convolution_reads_the_column_matrix_in_place(shape):
     finally:
         T.AMP['on'] = False
         T._IMPLICIT = False
+        T._COL_BF16 = False
     bf = lambda t: t.to(torch.bfloat16).double()      # noqa: E731
     xr, wr = bf(x0).requires_grad_(), bf(w0).requires_grad_()
     yr = torch.nn.functional.conv2d(xr, wr, b0.double(), padding=k//2)
@@ -2375,8 +2377,12 @@ def test_sgmse_training_convolution_reads_the_column_matrix_in_place(shape):
     gwr = torch.autograd.grad(torch.nn.functional.conv2d(xr, wr, None, padding=k//2), wr, bf(dy0))[0]
     want = [yr.detach(), gxr, gwr, dy0.double().sum((0, 2, 3))]
     for name, a, b_, ref in zip(('y', 'dx', 'dw', 'db'), res[True], res[False], want):
-        assert float((a - b_).norm()) <= 1e-5*float(b_.norm()), name
+        # (the explicit form keeps the column-matrix gradient in bf16 before col2im sums its nine terms:
+        # one more bf16 rounding on dx, as the reference's fp16 autocast has)
+        tol = 5e-3 if name == 'dx' else 1e-5
+        assert float((a - b_).norm()) <= tol*float(b_.norm()), name
         assert float((a - ref).norm()) <= 2e-5*float(ref.norm()), name
+        assert float((b_ - ref).norm()) <= (5e-3 if name == 'dx' else 2e-5)*float(ref.norm()), name
 
 
 @pytest.mark.gpu
