@@ -109,6 +109,9 @@ __device__ __forceinline__ float group_sum(float v, int npad) {
   for (int off = npad >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// (kSmallIt row sets per wavefront, their loads requested together at clamped indices: with one element per
+// thread and launch a 258 516 x 32 layer norm was 32 K workgroups of a single load each, 46 us for 66 MB)
+constexpr int kSmallIt = 4;
 __global__ __launch_bounds__(256) void rownorm_small_fwd_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ slope,
                                                                 const float* __restrict__ gain,
@@ -117,18 +120,29 @@ __global__ __launch_bounds__(256) void rownorm_small_fwd_kernel(const float* __r
                                                                 long long rows, int n, int npad,
                                                                 int inner, int G, float eps) {
   const int lane = threadIdx.x & 63, rpw = 64/npad;
-  const int sub = lane / npad, j = lane % npad;
-  const long long r = ((long long)blockIdx.x*4 + (threadIdx.x >> 6))*rpw + sub;
-  const bool live = r < rows && j < n;
-  const long long rr = r < rows ? r : rows - 1;
-  const int g = (int)((rr / inner) % G);
-  const float a = slope ? slope[g] : 1.f;
-  const float v = live ? prelu(x[rr*n + j], a) : 0.f;
-  const float mean = group_sum(v, npad)/n;
-  const float d = live ? v - mean : 0.f;
-  const float rstd = 1.f/sqrtf(group_sum(d*d, npad)/n + eps);
-  if (live) y[rr*n + j] = d*rstd*gain[(long long)g*n + j] + bias[(long long)g*n + j];
-  if (j == 0 && r < rows) stats[r] = make_float2(mean, rstd);
+  const int sub = lane / npad, j = lane % npad, jc = j < n ? j : n - 1;
+  const long long base = ((long long)blockIdx.x*4 + (threadIdx.x >> 6))*rpw*kSmallIt + sub;
+  float xv[kSmallIt], gv[kSmallIt], bv[kSmallIt], av[kSmallIt];
+#pragma unroll
+  for (int it = 0; it < kSmallIt; ++it) {
+    const long long r = base + (long long)it*rpw, rr = r < rows ? r : rows - 1;
+    const int g = G == 1 ? 0 : (int)((rr / inner) % G);      // (a 64-bit division per element otherwise)
+    xv[it] = x[rr*n + jc];
+    gv[it] = gain[(long long)g*n + jc];
+    bv[it] = bias[(long long)g*n + jc];
+    av[it] = slope ? slope[g] : 1.f;
+  }
+#pragma unroll
+  for (int it = 0; it < kSmallIt; ++it) {
+    const long long r = base + (long long)it*rpw;
+    const bool live = r < rows && j < n;
+    const float v = live ? prelu(xv[it], av[it]) : 0.f;
+    const float mean = group_sum(v, npad)/n;
+    const float d = live ? v - mean : 0.f;
+    const float rstd = 1.f/sqrtf(group_sum(d*d, npad)/n + eps);
+    if (live) y[r*n + j] = d*rstd*gv[it] + bv[it];
+    if (j == 0 && r < rows) stats[r] = make_float2(mean, rstd);
+  }
 }
 __global__ __launch_bounds__(256) void rownorm_small_bwd_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ dy,
@@ -140,22 +154,36 @@ __global__ __launch_bounds__(256) void rownorm_small_bwd_kernel(const float* __r
                                                                 long long rows, int n, int npad,
                                                                 int inner, int G) {
   const int lane = threadIdx.x & 63, rpw = 64/npad;
-  const int sub = lane / npad, j = lane % npad;
-  const long long r = ((long long)blockIdx.x*4 + (threadIdx.x >> 6))*rpw + sub;
-  const bool live = r < rows && j < n;
-  const long long rr = r < rows ? r : rows - 1;
-  const int g = (int)((rr / inner) % G);
-  const float a = slope ? slope[g] : 1.f;
-  const float2 st = stats[rr];
-  const float v = live ? x[rr*n + j] : 0.f;
-  const float xh = live ? (prelu(v, a) - st.x)*st.y : 0.f;
-  const float dg = live ? dy[rr*n + j]*gain[(long long)g*n + j] : 0.f;
-  const float m1 = group_sum(dg, npad)/n, m2 = group_sum(dg*xh, npad)/n;
-  const float dp = st.y*(dg - m1 - xh*m2);
-  if (live) dx[rr*n + j] = v > 0.f ? dp : a*dp;
-  if (dslope_rows) {
-    const float da = group_sum(live && !(v > 0.f) ? dp*v : 0.f, npad);
-    if (j == 0 && r < rows) dslope_rows[r] = da;
+  const int sub = lane / npad, j = lane % npad, jc = j < n ? j : n - 1;
+  const long long base = ((long long)blockIdx.x*4 + (threadIdx.x >> 6))*rpw*kSmallIt + sub;
+  float xv[kSmallIt], dv[kSmallIt], gv[kSmallIt], av[kSmallIt];
+  float2 sv[kSmallIt];
+#pragma unroll
+  for (int it = 0; it < kSmallIt; ++it) {
+    const long long r = base + (long long)it*rpw, rr = r < rows ? r : rows - 1;
+    const int g = G == 1 ? 0 : (int)((rr / inner) % G);      // (a 64-bit division per element otherwise)
+    xv[it] = x[rr*n + jc];
+    dv[it] = dy[rr*n + jc];
+    sv[it] = stats[rr];
+    gv[it] = gain[(long long)g*n + jc];
+    av[it] = slope ? slope[g] : 1.f;
+  }
+#pragma unroll
+  for (int it = 0; it < kSmallIt; ++it) {
+    const long long r = base + (long long)it*rpw;
+    const bool live = r < rows && j < n;
+    const float a = av[it];
+    const float2 st = sv[it];
+    const float v = live ? xv[it] : 0.f;
+    const float xh = live ? (prelu(v, a) - st.x)*st.y : 0.f;
+    const float dg = live ? dv[it]*gv[it] : 0.f;
+    const float m1 = group_sum(dg, npad)/n, m2 = group_sum(dg*xh, npad)/n;
+    const float dp = st.y*(dg - m1 - xh*m2);
+    if (live) dx[r*n + j] = v > 0.f ? dp : a*dp;
+    if (dslope_rows) {
+      const float da = group_sum(live && !(v > 0.f) ? dp*v : 0.f, npad);
+      if (j == 0 && r < rows) dslope_rows[r] = da;
+    }
   }
 }
 
@@ -176,14 +204,31 @@ __global__ __launch_bounds__(256) void rownorm_pgrad_kernel(const float* __restr
   const long long chunk = (per_group + kSlices - 1)/kSlices;
   const long long k0 = slice*chunk, k1 = min(per_group, k0 + chunk);
   float sg = 0.f, sb = 0.f;
-  if (j < n) {
-    for (long long k = k0 + rl; k < k1; k += 4) {
-      const long long r = (k / inner)*((long long)inner*G) + (long long)g*inner + k % inner;
+  {
+    // four rows per lane in flight: unconditional loads at a clamped column (lanes past n add nothing)
+    const int jc = j < n ? j : n - 1;
+    auto row_of = [&](long long k) { return G == 1 ? k : (k / inner)*((long long)inner*G) + (long long)g*inner + k % inner; };
+    float sg1 = 0.f, sb1 = 0.f, sg2 = 0.f, sb2 = 0.f, sg3 = 0.f, sb3 = 0.f;
+    long long k = k0 + rl;
+    for (; k + 12 < k1; k += 16) {
+      const long long r0 = row_of(k), r1 = row_of(k + 4), r2 = row_of(k + 8), r3 = row_of(k + 12);
+      const float2 s0 = stats[r0], s1 = stats[r1], s2 = stats[r2], s3 = stats[r3];
+      const float d0 = dy[r0*n + jc], d1 = dy[r1*n + jc], d2 = dy[r2*n + jc], d3 = dy[r3*n + jc];
+      const float x0 = x[r0*n + jc], x1 = x[r1*n + jc], x2 = x[r2*n + jc], x3 = x[r3*n + jc];
+      sg += d0*((prelu(x0, a) - s0.x)*s0.y); sb += d0;
+      sg1 += d1*((prelu(x1, a) - s1.x)*s1.y); sb1 += d1;
+      sg2 += d2*((prelu(x2, a) - s2.x)*s2.y); sb2 += d2;
+      sg3 += d3*((prelu(x3, a) - s3.x)*s3.y); sb3 += d3;
+    }
+    for (; k < k1; k += 4) {
+      const long long r = row_of(k);
       const float2 st = stats[r];
-      const float d = dy[r*n + j];
-      sg += d*((prelu(x[r*n + j], a) - st.x)*st.y);
+      const float d = dy[r*n + jc];
+      sg += d*((prelu(x[r*n + jc], a) - st.x)*st.y);
       sb += d;
     }
+    sg = (sg + sg1) + (sg2 + sg3); sb = (sb + sb1) + (sb2 + sb3);
+    if (j >= n) sg = sb = 0.f;
   }
   red[rl][col] = make_float2(sg, sb);
   __syncthreads();
@@ -199,18 +244,29 @@ __global__ __launch_bounds__(256) void rownorm_pgrad_fold_kernel(const float2* _
                                                                  float* __restrict__ dgain,
                                                                  float* __restrict__ dbias,
                                                                  long long total, int kSlices) {
-  // 64 columns per workgroup, the slices dealt to 4 row lanes, fixed summation order
-  __shared__ float2 red[4][64];
-  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const long long i = (long long)blockIdx.x*64 + col;
-  float sg = 0.f, sb = 0.f;
-  if (i < total)
-    for (int s = rl; s < kSlices; s += 4) { const float2 t = part[s*total + i]; sg += t.x; sb += t.y; }
-  red[rl][col] = make_float2(sg, sb);
+  // 32 columns per workgroup, the slices dealt to 8 slice lanes with eight loads in flight each (up to 1 024
+  // slices for 32 outputs: four lanes walking 256 slices one load at a time took 24 us), fixed summation order
+  __shared__ float2 red[8][32];
+  const int col = threadIdx.x & 31, ln = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x*32 + col, ic = i < total ? i : total - 1;
+  float sg[8], sb[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) sg[u] = sb[u] = 0.f;
+  int s = ln;
+  for (; s + 56 < kSlices; s += 64) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const float2 t = part[(long long)(s + 8*u)*total + ic]; sg[u] += t.x; sb[u] += t.y; }
+  }
+  for (; s < kSlices; s += 8) { const float2 t = part[(long long)s*total + ic]; sg[0] += t.x; sb[0] += t.y; }
+  red[ln][col] = make_float2(((sg[0] + sg[1]) + (sg[2] + sg[3])) + ((sg[4] + sg[5]) + (sg[6] + sg[7])),
+                             ((sb[0] + sb[1]) + (sb[2] + sb[3])) + ((sb[4] + sb[5]) + (sb[6] + sb[7])));
   __syncthreads();
-  if (rl == 0 && i < total) {
-    dgain[i] = (red[0][col].x + red[1][col].x) + (red[2][col].x + red[3][col].x);
-    dbias[i] = (red[0][col].y + red[1][col].y) + (red[2][col].y + red[3][col].y);
+  if (ln == 0 && i < total) {
+    float2 t = red[0][col];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) { t.x += red[u][col].x; t.y += red[u][col].y; }
+    dgain[i] = t.x;
+    dbias[i] = t.y;
   }
 }
 
@@ -487,7 +543,7 @@ int brv_rownorm_forward(const float* x, const float* slope, const float* gain, c
   if (n <= 64) {
     int npad = 1;
     while (npad < n) npad <<= 1;
-    const long long rows_per_wg = 4*(64/npad);
+    const long long rows_per_wg = 4*(64/npad)*kSmallIt;
     hipLaunchKernelGGL(rownorm_small_fwd_kernel, dim3((unsigned)((rows + rows_per_wg - 1)/rows_per_wg)),
                        dim3(256), 0, st, x, slope, gain, bias, y, reinterpret_cast<float2*>(stats),
                        (long long)rows, (int)n, npad, (int)inner, (int)groups, eps);
@@ -513,7 +569,7 @@ int brv_rownorm_backward(const float* x, const float* dy, const float* slope, co
   if (n <= 64) {
     int npad = 1;
     while (npad < n) npad <<= 1;
-    const long long rows_per_wg = 4*(64/npad);
+    const long long rows_per_wg = 4*(64/npad)*kSmallIt;
     hipLaunchKernelGGL(rownorm_small_bwd_kernel, dim3((unsigned)((rows + rows_per_wg - 1)/rows_per_wg)),
                        dim3(256), 0, st, x, dy, slope, gain, stp, dx, slope ? dslope_rows : nullptr,
                        (long long)rows, (int)n, npad, (int)inner, (int)groups);
@@ -527,7 +583,7 @@ int brv_rownorm_backward(const float* x, const float* dy, const float* slope, co
                      dim3(256), 0, st, x, dy, slope, stp, part, (long long)rows, (int)n, (int)inner,
                      (int)groups);
   const long long total = (long long)groups*n;
-  hipLaunchKernelGGL(rownorm_pgrad_fold_kernel, dim3((unsigned)((total + 63)/64)), dim3(256), 0,
+  hipLaunchKernelGGL(rownorm_pgrad_fold_kernel, dim3((unsigned)((total + 31)/32)), dim3(256), 0,
                      st, part, dgain, dbias, total, kSlices);
   TG_OK(hipGetLastError());
   return 0;
