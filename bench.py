@@ -369,6 +369,12 @@ def main():
                     help='gradient buckets of the overlapped all-reduce (N > 1)')
     ap.add_argument('--kernel-table', action='store_true',
                     help='also print the per-kernel table (stderr)')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='nccl = RCCL (the measured configuration). gloo exists for the test that runs the N > 1 '
+                         'code of this file with two ranks on ONE GPU (ranks share cuda:0, gradients move through '
+                         'the host): its numbers mean nothing')
+    ap.add_argument('--dist', action='store_true',
+                    help='initialise the process group even at --gpus 1 (world-1 RCCL: every N > 1 branch runs)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -380,17 +386,24 @@ def main():
                          '(one rank per GPU) or pass --gpus 1')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device (no CPU fallback)')
+    if args.dist_backend == 'gloo':
+        local_rank %= torch.cuda.device_count()      # (test mode: the ranks share the GPUs there are)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    single = world == 1 and not args.dist            # no process group: the driver's N = 1 run
+    if not single:
         from brever_amd.parallel import init_process_group
-        init_process_group('nccl', timeout_s=float(os.environ.get('BRV_DIST_TIMEOUT_S', '120')),
-                           device_id=device)         # short timeout: a bad rendezvous exits non-zero
+        kw = {'device_id': device} if args.dist_backend == 'nccl' else {}
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', '29533')
+            kw.update(rank=0, world_size=1)
+        init_process_group(args.dist_backend, timeout_s=float(os.environ.get('BRV_DIST_TIMEOUT_S', '120')),
+                           **kw)                     # short timeout: a bad rendezvous exits non-zero
 
     torch.manual_seed(0)
     model = ConvTasNet().to(device)          # defaults = BASELINE config
     sync = None
-    if world > 1:
+    if not single:
         broadcast_parameters(model)
         sync = GradSynchronizer(model, nparts=args.buckets)
     scaler = torch.amp.GradScaler('cuda', enabled=False)   # bf16: no loss scaling
@@ -408,23 +421,24 @@ def main():
         # it exposed on any rank (xGMI ring latency x buckets), use ONE all-reduce after backward
         t = torch.tensor([sync.exposed_ms()], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        if float(t) > 0.5:
+        forced = os.environ.get('BRV_FORCE_AR_FALLBACK', '0') == '1'      # (tests: take the branch once)
+        if float(t) > 0.5 or forced:
             fallback = (f'one all-reduce after backward: {args.buckets} buckets left {float(t):.2f} ms '
-                        'exposed per step in the warm-up')
+                        'exposed per step in the warm-up' + (' (forced by BRV_FORCE_AR_FALLBACK)' if forced else ''))
             sync = GradSynchronizer(model, nparts=1)
             for i in range(max(2, args.warmup//2)):
                 step(i)
-    if world > 1:
+    if not single:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if not single:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if not single:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -434,7 +448,7 @@ def main():
     trainer_batches = None
     if not args.no_through_trainer:
         trainer_ms, trainer_batches = through_trainer(model, scaler, rank, world, device, min(args.steps, 40), 6)
-        if world > 1:
+        if not single:
             t = torch.tensor([trainer_ms], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             trainer_ms = float(t)
@@ -446,7 +460,7 @@ def main():
                 raise SystemExit(f'ranks consumed different batch counts: {int(lo)} .. {int(hi)}')
 
     roof, table = kernel_roofline(model, batches, scaler)
-    if world > 1:
+    if not single:
         dist.barrier()
     if rank == 0:
         value = world*BATCH*args.steps/dt
@@ -464,6 +478,7 @@ def main():
                 'global_batch': world*BATCH, 'seq_len': int(SECONDS*FS),
                 'parallelism': f'dp{world}',
             },
+            'value_includes_h2d': False,        # (timed on batches resident in HBM; `through_trainer` includes H2D)
             'final_loss': final_loss,
             'whole_step_mfma_frac': value/world*FLOP_PER_UTT_TRAIN/(PEAK_MFMA_TFLOPS*1e12),
             'roofline': roof,
@@ -473,6 +488,7 @@ def main():
                 'value': world*BATCH/(trainer_ms*1e-3), 'unit': 'utterances/s',
                 'ms_per_step': trainer_ms,
                 'batches_per_rank': trainer_batches,
+                'includes_h2d': True,            # SURVEY 8(d)'s "incl. H2D of the batch" is THIS number
                 'path': 'host items of ONE dataset -> BucketBatchSampler'
                         + (' -> DistributedBatchSamplerWrapper (disjoint batches per rank)' if world > 1 else '')
                         + ' -> BreverDataLoader collate -> pinned double-buffered async H2D (DevicePrefetcher) '
@@ -485,9 +501,9 @@ def main():
             line['hw_queues_ok'] = bool(__import__('brever_amd').HW_QUEUES_OK)
             if fallback:
                 line['allreduce_fallback'] = fallback
-        if world == 1 and not args.no_fp32_path:
+        if single and not args.no_fp32_path:
             line['fp32_path'] = fp32_path(device)
-        if world == 1 and not args.no_cpu_baseline:
+        if single and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         if args.kernel_table:
             for k, v in table.items():
@@ -495,7 +511,7 @@ def main():
                       f'{v["ms_per_step"]:8.3f} ms/step {v["gbs"]:8.1f} GB/s '
                       f'{v["tflops"]:8.1f} TFLOP/s', file=sys.stderr)
         print(json.dumps(line))
-    if world > 1:
+    if not single:
         dist.destroy_process_group()
 
 

@@ -67,6 +67,19 @@ class BreverBaseModel(nn.Module):
     # Opt-in per model class: the HIP models (which only step on a ROCm device) set `_fused_adam = True`
     _fused_adam = False
     _flat_base = False
+    _grad_sync = None
+
+    def set_grad_sync(self, fn):
+        """Data parallelism (brever_amd.parallel.GradSynchronizer; the reference wraps any model in DDP,
+        brever/training.py:62-63). ``fn(flat_grad)`` sums the buffer over ranks and returns the factor that turns
+        the sum into the mean. Every ``update`` of this model calls it after backward has ended (and after
+        whatever side streams the backward pass used were joined): ONE collective per step on the flat gradient
+        instead of one blocking collective per parameter from inside backward. ``False`` = this model keeps
+        separate parameters (no flat buffer): the caller installs per-parameter hooks instead."""
+        if not self._flat_base:
+            return False
+        self._grad_sync = fn
+        return True
 
     def _flatten_base(self):
         params = list(self.parameters())
@@ -154,11 +167,21 @@ class BreverBaseModel(nn.Module):
         optimizer = self.optimizer if optimizer is None else optimizer
         scaler.scale(loss).backward(retain_graph=retain_graph)
         from ..optim import FlatAdam
+        sync = self._grad_sync
         if whole and isinstance(optimizer, FlatAdam) and getattr(optimizer, '_owner', None) is self \
                 and not scaler.is_enabled():
-            # clip_grad_norm_(grad_clip) + Adam.step fused on the flat buffers (two HIP launches)
-            optimizer.step(max_norm=float(grad_clip))
+            # clip_grad_norm_(grad_clip) + Adam.step fused on the flat buffers (two HIP launches); under a process
+            # group the flat gradient is summed over ranks first and the mean taken inside the kernel
+            if sync is None:
+                optimizer.step(max_norm=float(grad_clip))
+            else:
+                grads = self.gather_grads()
+                optimizer.step(max_norm=float(grad_clip), grad_scale=sync(grads), grads=grads)
             return
+        if sync is not None:
+            # a sub-network, another optimizer or a live scaler: the same mean, written back to the .grad tensors
+            from ..parallel import all_reduce_mean_grads
+            all_reduce_mean_grads(net.parameters(), sync)
         if grad_clip != 0.0:
             scaler.unscale_(optimizer)
             torch.nn.utils.clip_grad_norm_(net.parameters(), grad_clip)

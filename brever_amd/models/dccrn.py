@@ -214,7 +214,7 @@ def _cconv_wgrad(small, big, small2=None):
 # the input depends on them, and the backward pass has a long stretch -- the recurrences' BPTT, 64 chains = a quarter
 # of the CUs for 0.9 ms -- that the decoder's weight gradients fill. BRV_DCCRN_WGRAD_SIDE=0: everything in order.
 _WGRAD_SIDE = os.environ.get('BRV_DCCRN_WGRAD_SIDE', '1') != '0'
-_side = {'streams': {}, 'pending': False}
+_side = {'streams': {}, 'pending': {}}     # both keyed by device index
 
 
 def _side_stream(device):
@@ -225,10 +225,23 @@ def _side_stream(device):
 
 
 def _join_side(device):
-    """Queued once per backward pass (autograd engine callback, runs when the pass ends): the stream the gradients
-    are consumed on waits for the side stream."""
-    _side['pending'] = False
-    torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+    """The stream the gradients are consumed on waits for the side stream. Queued once per backward pass (autograd
+    engine callback, runs when the pass ends) AND called by ``DCCRN.gather_grads`` / ``update`` before anything
+    reads a gradient -- the callback alone is not enough: a backward pass that raises never runs it."""
+    _side['pending'][device.index] = False
+    st = _side['streams'].get(device.index)
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
+
+
+def _side_allowed(params):
+    """Parameter gradients may only come off the side stream when nothing looks at them before the end of the
+    backward pass: no ``.grad`` to accumulate into in place (``zero_grad(set_to_none=False)``, gradient
+    accumulation) and no post-accumulate hook (the per-parameter all-reduce of ``GradSynchronizer`` for models
+    without a flat buffer runs on the main stream DURING backward)."""
+    if not _WGRAD_SIDE:
+        return False
+    return all(p.grad is None and not getattr(p, '_post_accumulate_grad_hooks', None) for p in params)
 
 
 def _im2col(x, geom, grid, lowp=False):
@@ -281,6 +294,7 @@ class _ComplexConvFunction(torch.autograd.Function):
         geom = geom4[:3]
         lib = hip.lib()
         lowp = ctx.lowp = _AMP['on']
+        ctx.side_ok = _side_allowed((wr, br, wi, bi))
         kept_col = None
         x = x.contiguous()
         B, C2, H, W = x.shape
@@ -390,7 +404,7 @@ class _ComplexConvFunction(torch.autograd.Function):
                     _gemm_conv(dy, x, dwc_, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, 1, (2*Cin, H, W), geom,
                                (Ho, Wo), trans_b=1, kbatch=B, a_kbs=2*Cout*Ho*Wo, img_kbs=2*Cin*H*W)
                 return _ComplexConvFunction._unpack_param_grads(dwc_, dy, wshape, R, Cw, Cout, B, Ho*Wo, transpose)
-            side = _side_stream(dy.device) if _WGRAD_SIDE else None
+            side = _side_stream(dy.device) if ctx.side_ok else None
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(dy.device))      # dy, x exist; dx is not waited for
             if transpose:
@@ -407,8 +421,8 @@ class _ComplexConvFunction(torch.autograd.Function):
                 for t in (x, dy, skip):
                     if t is not None:
                         t.record_stream(side)
-                if not _side['pending']:
-                    _side['pending'] = True
+                if not _side['pending'].get(dy.device.index):
+                    _side['pending'][dy.device.index] = True
                     dev = dy.device
                     torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev))
             if ctx.seg and not ctx.two:      # the concatenation was materialised (segments off the chunk of 8)
@@ -855,6 +869,12 @@ class DCCRN(BreverBaseModel):
         finally:
             _AMP['on'] = False
         return self.criterion(outputs, labels, lengths).mean()
+
+    def gather_grads(self):
+        dev = next(self.parameters()).device
+        if dev.type == 'cuda':
+            _join_side(dev)              # (unconditional: cheap, and right after a backward pass that raised)
+        return super().gather_grads()
 
     def update(self, loss, scaler):
         super().update(loss, scaler, grad_clip=5.0)

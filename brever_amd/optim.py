@@ -77,13 +77,14 @@ class FlatAdam(torch.optim.Adam):
 
     # -- step --------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, closure=None, max_norm=0.0, grad_scale=1.0, grads2=None):
+    def step(self, closure=None, max_norm=0.0, grad_scale=1.0, grads2=None, grads=None):
         """One Adam step on the flat buffers.
 
         ``max_norm > 0`` folds ``clip_grad_norm_(max_norm)`` into the same
         launch; ``grad_scale`` multiplies the gradient first (``1/world_size``
         after a summing all-reduce); ``grads2``: a second flat gradient buffer (the
-        other kernel chain's) that is added in the norm pass and left zeroed.
+        other kernel chain's) that is added in the norm pass and left zeroed; ``grads``: the
+        flat gradient if the caller has gathered (and all-reduced) it already.
         Two launches in all (``brv_clip_adam_step2``).
         """
         loss = None
@@ -93,24 +94,26 @@ class FlatAdam(torch.optim.Adam):
         flat = self._owner.flat_params()
         hip.require_device(flat)
         self._ensure_state()
-        grads = self._owner.gather_grads()
+        if grads is None:
+            grads = self._owner.gather_grads()
         group = self.param_groups[0]
-        self._step_count += 1
-        next(iter(self.state.values()))['step'].fill_(float(self._step_count))
         beta1, beta2 = group['betas']
         slot = self._slot
+        step = self._step_count + 1      # (committed after the launch: a failed step retried keeps its bias correction)
         try:
             hip.check(hip.lib().brv_clip_adam_step2(
                 hip.ptr(flat), hip.ptr(grads), hip.ptr(grads2), hip.ptr(self._exp_avg),
                 hip.ptr(self._exp_avg_sq), flat.numel(), float(grad_scale),
                 float(max_norm), float(group['lr']), float(beta1), float(beta2),
-                float(group['eps']), self._step_count, hip.ptr(self._scratch), slot,
+                float(group['eps']), step, hip.ptr(self._scratch), slot,
                 hip.ptr(self.last_grad_norm), hip.stream()), 'brv_clip_adam_step2')
         except Exception:
             # the accumulators' zero / non-zero state is unknown after a failed launch: start over
             self._scratch.zero_()
             self._slot = 0
             raise
+        self._step_count = step
+        next(iter(self.state.values()))['step'].fill_(float(step))
         self._slot = 1 - slot           # the kernel zeroed the other accumulator for the next call
         self._owner.mark_params_changed()
         return loss

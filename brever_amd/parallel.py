@@ -16,8 +16,13 @@ here explicitly:
   fused clip + Adam (``grad_scale = 1/world``). Buckets are views of the flat buffer:
   no packing copies. The generic ``loss -> update`` sequence of the same model (other
   criteria / optimizers) calls the hook once with the whole buffer;
-* any other model gets post-accumulate-grad hooks that average each ``.grad``
-  over ranks during backward, i.e. before clipping and the optimizer step.
+* every other model whose parameters live in one flat buffer (``BreverBaseModel._flat_base``: DCCRN, TF-GridNet,
+  SGMSE+, FFNN under plain Adam) hands its flat gradient to ``__call__`` from ``update``, AFTER backward has ended
+  and after the side streams of that backward pass were joined (DCCRN's weight gradients): one summing all-reduce
+  per step, the mean taken inside the fused clip + Adam kernel. No collective is issued from inside backward;
+* a model without a flat buffer (another optimizer, a foreign ``nn.Module``) gets post-accumulate-grad hooks that
+  average each ``.grad`` over ranks during backward, i.e. before clipping and the optimizer step. Kernels that
+  produce parameter gradients off the main stream look for such hooks and stay in order (models/dccrn.py).
 """
 import datetime
 import os
@@ -67,12 +72,13 @@ class GradSynchronizer:
     def __init__(self, model, nparts=3):
         self.world = dist.get_world_size()
         self.nparts = max(1, int(nparts))
-        self.flat_model = callable(getattr(model, 'set_grad_sync', None))
         self._pending = []
         self._waits = []
-        if self.flat_model:
-            model.set_grad_sync(self)
-        else:
+        self.calls = 0                     # collectives issued so far (tests, bench line)
+        setter = getattr(model, 'set_grad_sync', None)
+        # (Conv-TasNet's setter returns None; the base class answers False when there is no flat buffer)
+        self.flat_model = callable(setter) and setter(self) is not False
+        if not self.flat_model:
             self._install_hooks(model)
 
     # -- flat-gradient models -------------------------------------------------
@@ -85,6 +91,7 @@ class GradSynchronizer:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
         dist.all_reduce(flat_grad)
+        self.calls += 1
         if timed:
             b.record()
             self._waits.append((a, b))
@@ -93,6 +100,7 @@ class GradSynchronizer:
     def bucket(self, part, grad_slice):
         """Called after backward part ``part``: start the all-reduce of its slice."""
         self._pending.append(dist.all_reduce(grad_slice, async_op=True))
+        self.calls += 1
 
     def finish(self):
         """Make the compute stream wait for the outstanding collectives."""
@@ -126,6 +134,7 @@ class GradSynchronizer:
 
         def hook(param):
             dist.all_reduce(param.grad)
+            self.calls += 1
             param.grad /= world
 
         for p in model.parameters():
@@ -134,3 +143,19 @@ class GradSynchronizer:
 
     def train_step(self, model, batch, lengths, use_amp, scaler):
         return model.train_step(batch, lengths, use_amp, scaler)
+
+
+def all_reduce_mean_grads(params, sync):
+    """Mean over ranks of the ``.grad`` tensors of ``params`` as ONE collective on a packed copy (the generic
+    branch of ``BreverBaseModel.update`` for a flat model: a sub-network, another optimizer). ``sync`` is the
+    ``GradSynchronizer`` (sums, returns 1/world)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat.mul_(sync(flat))
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view(g.shape))
+        off += n

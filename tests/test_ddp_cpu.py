@@ -81,6 +81,49 @@ def test_gradient_allreduce_equals_union_batch():
         assert torch.allclose(a, ref.detach(), rtol=1e-5, atol=1e-6)
 
 
+def _worker_flat_base_generic(rank, world, port, out_dir):
+    """A base-class model WITH a flat buffer whose optimizer is not FlatAdam: `set_grad_sync` accepts, no hooks,
+    and the generic branch of `update` averages the .grad tensors through ONE packed collective per step."""
+    from brever_amd.parallel import GradSynchronizer, broadcast_parameters
+    _init(rank, world, port)
+    torch.manual_seed(100 + rank)
+    model = DummyModel(channels=2, output_sources=2)
+    model._flat_base = True
+    model._flatten_base()
+    model.optimizer = torch.optim.Adam(model.parameters())
+    broadcast_parameters(model)                          # (one broadcast of the flat buffer)
+    sync = GradSynchronizer(model)
+    assert sync.flat_model and model._grad_sync is sync
+    assert not any(getattr(p, '_post_accumulate_grad_hooks', None) for p in model.parameters())
+    batch, lengths = _make_batch()
+    lo, hi = rank*2, rank*2 + 2
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    for _ in range(3):
+        sync.train_step(model, batch[lo:hi], lengths[lo:hi], False, scaler)
+    assert sync.calls == 3
+    torch.save([p.detach().clone() for p in model.parameters()],
+               os.path.join(out_dir, f'params{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_flat_base_model_generic_branch_equals_union_batch():
+    """models with `_flat_base` get one collective per step, not one per parameter."""
+    world = 2
+    with tempfile.TemporaryDirectory() as tmp:
+        _spawn(_worker_flat_base_generic, world, tmp)
+        p0 = torch.load(os.path.join(tmp, 'params0.pt'))
+        p1 = torch.load(os.path.join(tmp, 'params1.pt'))
+    torch.manual_seed(100)
+    model = DummyModel(channels=2, output_sources=2)
+    batch, lengths = _make_batch()
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    for _ in range(3):
+        model.train_step(batch, lengths, False, scaler)
+    for a, b, ref in zip(p0, p1, model.parameters()):
+        assert torch.equal(a, b)
+        assert torch.allclose(a, ref.detach(), rtol=1e-5, atol=1e-6)
+
+
 class _FlatStub(torch.nn.Module):
     """Mimics the flat-gradient protocol of the HIP Conv-TasNet on CPU."""
 
