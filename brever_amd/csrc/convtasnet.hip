@@ -16,6 +16,7 @@
 #include "gemm_wgrad.cuh"
 #include "gemm_ws.cuh"
 #include "dwpw2_fused.cuh"
+#include "dwpw2_fused_v2.cuh"
 #include "gemm_wgrad_full.cuh"
 
 constexpr int kWgSplit = 4;          // item splits of the [res | skip] weight-gradient launch
@@ -1291,11 +1292,19 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
           dp.taps = params + b.dconv_w; dp.dbias = params + b.dconv_b;
           dp.B = B; dp.T = (int)T; dp.dil = dil; dp.left = ((l.P - 1)*dil)/2; dp.C = l.H;
           dp.inv_n = 1.0/((double)T*l.H); dp.eps = 1e-8f;
-          const int n_tiles = B*(int)((T + DP_TT - 1)/DP_TT);
+          const bool v2 = opt(BRV_OPT_DWPW2_V2);
+          const int n_tiles = B*(int)((T + (v2 ? D2_TT : DP_TT) - 1)/(v2 ? D2_TT : DP_TT));
           // (a multiple of 8 workgroups: the kernel deals the tiles to the 8 XCDs in equal runs of slots)
           const int cap = num_cus() >= 8 ? num_cus()/8*8 : 8;
           const int n_wg = n_tiles < cap ? (n_tiles + 7)/8*8 : cap;
-          hipLaunchKernelGGL(dwpw2_fused_kernel, dim3(n_wg), dim3(512), 0, st, dp);
+#ifndef D2V_NW
+#define D2V_NW 4
+#endif
+#ifndef D2V_AHEAD
+#define D2V_AHEAD 8
+#endif
+          if (v2) hipLaunchKernelGGL((dwpw2_v2_kernel<D2V_NW, D2V_AHEAD>), dim3(n_wg), dim3(64*D2V_NW), 0, st, dp);
+          else hipLaunchKernelGGL(dwpw2_fused_kernel, dim3(n_wg), dim3(512), 0, st, dp);
           HIP_OK(hipGetLastError());
         }
       }

@@ -82,10 +82,41 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
   // the dilated taps of neighbouring tiles are then fetched once per L2, not once per XCD
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (n_tiles + 7) >> 3;
   const int wg_per_xcd = gridDim.x >> 3;                        // gridDim.x is a multiple of 8 (launch site)
-  for (int ti_ = slot; ti_ < per_xcd; ti_ += wg_per_xcd) {
+#ifndef DP_CONTIG
+#define DP_CONTIG 1
+#endif
+  // ... and (round 5) a workgroup takes a contiguous RUN of its XCD's tiles: its second tile is then nearly always
+  // in the same item, so the per-item tables below are built once per workgroup instead of once per tile (with the
+  // strided deal -- tiles 32 apart = the same frames of the NEXT item at the BASELINE size -- every tile paid the
+  // dependent global loads and two barriers of the table build: ~2 us of a 55 us launch)
+  // (runs as even as the counts allow, the LONGER ones on the lowest slots: those workgroups are dispatched first.
+  // With the extra tiles spread over the slots -- so that the last-dispatched workgroup had two -- the two-chain step,
+  // where a launch waits for CUs the other chain still holds, lost 0.19 ms.)
+  const int run_lo = per_xcd/wg_per_xcd, run_rem = per_xcd % wg_per_xcd;
+  const int ti_lo = DP_CONTIG ? slot*run_lo + min(slot, run_rem) : slot;
+  const int ti_hi = DP_CONTIG ? ti_lo + run_lo + (slot < run_rem ? 1 : 0) : per_xcd;
+  for (int ti_ = ti_lo; ti_ < ti_hi; ti_ += DP_CONTIG ? 1 : wg_per_xcd) {
     const int tile = xcd*per_xcd + ti_;
     if (tile >= n_tiles) break;
     const int b = tile / tpi, t0 = (tile % tpi)*DP_TT;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.z1 + (long long)b*T*DP_H, (long long)T*DP_H*2);
+    const __amdgpu_buffer_rsrc_t rz2 = make_rsrc(p.z2 + (long long)b*T*DP_H, (long long)T*DP_H*2);
+
+    // three taps of the thread's two frames, channel octet o of slab s (taps outside [0, T) wrap to
+    // offsets beyond the descriptor: zeros)
+    auto load_raw = [&](int s, uint4 (&raw)[2][3]) {
+      const unsigned int coff = (unsigned int)((s*DP_SLAB + o*8)*2);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const unsigned int ti = (unsigned int)(t0 + rl + 64*r + k*p.dil - p.left);
+          raw[r][k] = buf_load16(rin, ti*rowb + coff);
+        }
+    };
+    // the first slab's taps go out BEFORE the table build: its loads, barriers and the HBM latency of the taps overlap
+    uint4 raw[2][3];
+    load_raw(0, raw);
     if (b != cur_item) {
       flush_stats();
       __syncthreads();
@@ -105,21 +136,6 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
       cur_item = b;
       __syncthreads();
     }
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.z1 + (long long)b*T*DP_H, (long long)T*DP_H*2);
-    const __amdgpu_buffer_rsrc_t rz2 = make_rsrc(p.z2 + (long long)b*T*DP_H, (long long)T*DP_H*2);
-
-    // three taps of the thread's two frames, channel octet o of slab s (taps outside [0, T) wrap to
-    // offsets beyond the descriptor: zeros)
-    auto load_raw = [&](int s, uint4 (&raw)[2][3]) {
-      const unsigned int coff = (unsigned int)((s*DP_SLAB + o*8)*2);
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const unsigned int ti = (unsigned int)(t0 + rl + 64*r + k*p.dil - p.left);
-          raw[r][k] = buf_load16(rin, ti*rowb + coff);
-        }
-    };
     float ts = 0.f, tq = 0.f;
     const bool interior = t0 - p.left >= 0 && t0 + DP_TT - 1 + 2*p.dil - p.left < T;
     auto stage = [&](int s, const uint4 (&raw)[2][3], int buf) {
@@ -219,8 +235,6 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
     // ---- slab pipeline: z1 taps, weight fragments and the stage one slab ahead of the MFMAs.
     // Measured alternatives: z1 taps two slabs ahead (13 spills, +8 %), one frame per
     // thread with the taps four slabs ahead (+12 %), 64-frame tiles with two workgroups per CU (equal).
-    uint4 raw[2][3];
-    load_raw(0, raw);
     load_w(0, wcur);
     stage(0, raw, 0);
     load_raw(1, raw);
