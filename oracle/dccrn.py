@@ -7,6 +7,13 @@ backward of brever/modules/stft.py:59-138 (hann, normalized). Only ``tests/`` im
 Pinning: tests/golden/dccrn.npz from the imported reference (tests/golden/make_golden.py):
 parameter count, forward output in train mode (batch statistics, running estimates after
 the step) and in eval mode on a seeded input.
+
+``OracleDCCRN(emulate_bf16=True)`` restates the arithmetic of the HIP path under ``use_amp`` (brever_amd/models/
+dccrn.py): the operands of the convolutions' three matrix products (y from x and W, dx from dy and W, dW from dy and
+x) and of the LSTM input projections (gates from x and W_ih, dx and dW_ih from the gate gradients) are rounded to
+bf16, everything else -- accumulation, bias sums, batch norms, the recurrences, the Linear layers -- stays fp32. It is
+the yardstick of tests/test_gpu_sizes.py (HIP error <= 2.5 x this emulation's own error); with the flag off the module
+is the pinned fp32 restatement, bit for bit.
 """
 import math
 
@@ -32,13 +39,58 @@ def _istft(X, n, hop):
                        normalized=False, onesided=True)
 
 
+class _RoundForward(torch.autograd.Function):
+    """bf16 rounding of a matrix-product operand; the gradient passes unchanged."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBackward(torch.autograd.Function):
+    """Identity whose incoming gradient is rounded to bf16 (the dy operand of the two backward products)."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+_qf, _qb = _RoundForward.apply, _RoundBackward.apply
+
+
 class ComplexWrapper(nn.Module):                                   # dccrn.py:221-231
+    emulate_bf16 = False
+
     def __init__(self, module_cls, *args, **kwargs):
         super().__init__()
         self.module_real = module_cls(*args, **kwargs)
         self.module_imag = module_cls(*args, **kwargs)
 
+    def _emulated(self, x):
+        """The four real convolutions with bf16-rounded operands; the biases join in fp32 behind the point where
+        the gradient is rounded (the bias gradient of the HIP path sums the unrounded dy)."""
+        mr, mi = self.module_real, self.module_imag
+        xr, xi = (_qf(t) for t in torch.chunk(x, 2, dim=1))
+        wr, wi = _qf(mr.weight), _qf(mi.weight)
+        if isinstance(mr, nn.ConvTranspose2d):
+            def f(t, w):
+                return F.conv_transpose2d(t, w, None, mr.stride, mr.padding, mr.output_padding)
+        else:
+            def f(t, w):
+                return F.conv2d(t, w, None, mr.stride, mr.padding)
+        prod = _qb(torch.cat([f(xr, wr) - f(xi, wi), f(xi, wr) + f(xr, wi)], dim=1))
+        bias = torch.cat([mr.bias - mi.bias, mr.bias + mi.bias]).view(1, -1, 1, 1)
+        return prod + bias
+
     def forward(self, x):
+        if self.emulate_bf16:
+            return self._emulated(x)
         in_real, in_imag = torch.chunk(x, 2, dim=1)
         out_real = self.module_real(in_real) - self.module_imag(in_imag)
         out_imag = self.module_real(in_imag) + self.module_imag(in_real)
@@ -106,7 +158,22 @@ class _Block(nn.Module):                                           # dccrn.py:23
 
 
 class _ComplexLSTMLayer(ComplexWrapper):                           # dccrn.py:330-358
+    @staticmethod
+    def _lstm_emulated(m, x):
+        """nn.LSTM whose input projection runs on bf16-rounded operands: the projection is formed here and handed
+        to the same LSTM through an identity input matrix (exact in fp32: one non-zero term per sum)."""
+        gates = _qb(_qf(x) @ _qf(m.weight_ih_l0).t())
+        eye = torch.eye(gates.shape[-1], dtype=gates.dtype)
+        out, _, _ = torch._VF.lstm(gates, (gates.new_zeros(1, x.shape[0], m.hidden_size),
+                                        gates.new_zeros(1, x.shape[0], m.hidden_size)),
+                                [eye, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0], True, 1, 0.0, m.training, False,
+                                True)
+        return out
+
     def forward(self, real, imag):
+        if self.emulate_bf16:
+            mr, mi, f = self.module_real, self.module_imag, self._lstm_emulated
+            return f(mr, real) - f(mi, imag), f(mr, imag) + f(mi, real)
         rr, _ = self.module_real(real)
         ii, _ = self.module_imag(imag)
         ri, _ = self.module_real(imag)
@@ -174,9 +241,10 @@ class _MaskNet(nn.Module):                                         # dccrn.py:14
 class OracleDCCRN(nn.Module):
     def __init__(self, n=512, hop=128, channels=(16, 32, 64, 128, 128, 128), kernel_size=(5, 2),
                  stride=(2, 1), padding=(2, 0), output_padding=(1, 0), lstm_channels=128,
-                 lstm_layers=2, use_complex_batchnorm=False):
+                 lstm_layers=2, use_complex_batchnorm=False, emulate_bf16=False):
         super().__init__()
         self.n, self.hop = n, hop
+        self.emulate_bf16 = emulate_bf16
         self.mask_net = _MaskNet(n//2, list(channels), kernel_size, stride, padding,
                                  output_padding, lstm_channels, lstm_layers,
                                  complex_bn=use_complex_batchnorm)
@@ -195,6 +263,9 @@ class OracleDCCRN(nn.Module):
         return torch.complex(out_mag*out_phase.cos(), out_mag*out_phase.sin())
 
     def forward(self, x):                                          # dccrn.py:83-94
+        for m in self.modules():
+            if isinstance(m, ComplexWrapper):
+                m.emulate_bf16 = self.emulate_bf16
         length = x.shape[-1]
         x = _stft(x, self.n, self.hop)[..., 1:, :]
         x = torch.stack([x.real, x.imag], dim=1)

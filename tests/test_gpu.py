@@ -1250,7 +1250,7 @@ def test_entry_points_ffnn(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,L', [(1, 200), (2, 1100), (5, 16*70 + 5)])
+@pytest.mark.parametrize('B,L', [(1, 200), (2, 1100), (5, 16*70 + 5), (16, 3100), (9, 16*64*3)])
 def test_fused_backward_paths_match_generic_kernels(B, L):
     """The specialised backward kernels of the default widths (atomics-free res/skip weight
     gradient, gLN/PReLU backward fused into the first conv's data gradient and into the depthwise
@@ -1267,7 +1267,7 @@ def test_fused_backward_paths_match_generic_kernels(B, L):
     lengths = torch.tensor([L - 13*i for i in range(B)], device=dev)
 
     def grads(env):
-        for k in ('BRV_NO_WGRAD_FULL', 'BRV_NO_DZ1_FUSE', 'BRV_NO_DZ_FUSE'):
+        for k in ('BRV_NO_WGRAD_FULL', 'BRV_NO_DZ1_FUSE', 'BRV_NO_DZ_FUSE', 'BRV_WGRAD_128'):
             os.environ.pop(k, None)
         os.environ.update(env)
         try:
@@ -1281,7 +1281,10 @@ def test_fused_backward_paths_match_generic_kernels(B, L):
 
     base = grads({'BRV_NO_WGRAD_FULL': '1', 'BRV_NO_DZ1_FUSE': '1', 'BRV_NO_DZ_FUSE': '1'})
     assert torch.isfinite(base).all()
-    for env in ({}, {'BRV_NO_DZ1_FUSE': '1'}, {'BRV_NO_WGRAD_FULL': '1'}, {'BRV_NO_DZ_FUSE': '1'}):
+    # (default: the [res | skip] weight gradient with 128 H channels per workgroup, gemm_wgrad_full128.cuh, BRV_WGRAD_128=0: 64;
+    # 8 / 4 / 1 item splits at B = 16 / 9, 5 / 1, 2)
+    for env in ({}, {'BRV_NO_DZ1_FUSE': '1'}, {'BRV_NO_WGRAD_FULL': '1'}, {'BRV_NO_DZ_FUSE': '1'}, {'BRV_WGRAD_128': '0'},
+                {'BRV_NO_WGRAD_SPLIT': '1'}, {'BRV_WGRAD_128': '0', 'BRV_NO_WGRAD_SPLIT': '1'}):
         got = grads(env)
         assert torch.isfinite(got).all(), env
         assert rel(got, base) <= 2e-3, (env, rel(got, base))

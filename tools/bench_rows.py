@@ -46,6 +46,10 @@ def train_row(arch, batch, seconds, steps, use_amp):
     if arch == 'dccrn' and seconds == 4.0:
         # 51.2 GFLOP per 4 s utterance forward, x3 for a training step
         row['tflops'] = batch/dt*3*51.2e9/1e12
+    if arch == 'tfgridnet' and seconds == 4.0:
+        # 138.98 GFLOP per 4 s utterance forward (torch.utils.flop_counter over oracle/tfgridnet.py: the mm / bmm /
+        # addmm / conv products, recurrences included), x3 for a training step
+        row['tflops'] = batch/dt*3*138.98e9/1e12
     return row
 
 
@@ -77,9 +81,15 @@ def sgmse_train_row(batch, frames, steps, use_amp=False):
     lengths = torch.full((batch,), frames, device=dev)
     scaler = torch.amp.GradScaler('cuda', enabled=False)
     dt = timed(lambda: model.train_step(x, lengths, use_amp, scaler), 1, steps)
-    return {'row': f"sgmsep train ({'bf16 convolutions' if use_amp else 'fp32'}, default 65.6 M-param network)", 'batch': batch,
-            'frames': frames, 'seconds_per_item': (frames - 1)*128/16000, 'ms_per_step': dt*1e3,
-            'items_per_s': batch/dt}
+    row = {'row': f"sgmsep train ({'bf16 convolutions' if use_amp else 'fp32'}, default 65.6 M-param network)", 'batch': batch,
+           'frames': frames, 'seconds_per_item': (frames - 1)*128/16000, 'ms_per_step': dt*1e3,
+           'items_per_s': batch/dt}
+    # 1.04 TFLOP per network evaluation of a 501-frame spectrogram; a training step = 3 x the forward
+    tflops = batch/dt*3*1.04*frames/501
+    return driver_line(row, 'items/sec SGMSE+ score-network training (SURVEY 8f rank 4)', batch/dt, 'items/s',
+                       'bf16' if use_amp else 'fp32',
+                       f'SGMSE+ defaults (65.6 M params), {batch} x {frames} frames, denoising-score-matching loss + backward '
+                       '+ Adam', tflops=tflops)
 
 
 PEAK = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}     # dense MFMA TFLOP/s (MI355X guide)
@@ -95,7 +105,7 @@ def driver_line(row, metric, value, unit, dtype, workload, tflops=None, higher=T
         row['roofline'] = {'bound': 'mfma', 'achieved': tflops, 'peak': PEAK[dtype],
                            'unit': 'TFLOP/s', 'frac': tflops/PEAK[dtype], 'traffic': None,
                            'scope': 'whole workload: algorithmic FLOPs of SURVEY.md 8(d) over the '
-                                    'measured wall time (per-kernel tables: profiles/r02_rows_*.csv)'}
+                                    'measured wall time (per-kernel tables of the same round: profiles/rNN_rows_<row>_kernel_stats.csv)'}
     return row
 
 
@@ -216,24 +226,29 @@ def main():
             row = train_row('dccrn', 16, 4.0, 5, amp)
             if amp:
                 row['row'] += ' (use_amp: bf16 matrix products)'
-            driver_line(row, 'utterances/sec (4 s @16 kHz) DCCRN train (BASELINE config 3)',
+            driver_line(row, 'utterances/sec (4 s @16 kHz) DCCRN train (BASELINE.json configs[3], the 4th: DCCRN bf16 1 x MI355X)',
                         row['utt_per_s'], 'utterances/s', 'bf16' if amp else 'fp32',
                         'DCCRN defaults (3 671 053 params), 16 x 4 s, STFT 512/128 -> complex '
                         'Conv2d + LSTM -> iSTFT, fwd + SNR loss + bwd + clip 5.0 + Adam',
                         tflops=row['tflops'])
             print(json.dumps(row), flush=True)
     if 'tfgridnet' in rows:
-        print(json.dumps(train_row('tfgridnet', 4, 4.0, 3, False)), flush=True)
-        row = train_row('tfgridnet', 4, 4.0, 3, True)
-        row['row'] += ' (use_amp: bf16 matrix products)'
-        print(json.dumps(row), flush=True)
+        for amp in (False, True):
+            row = train_row('tfgridnet', 4, 4.0, 3, amp)
+            if amp:
+                row['row'] += ' (use_amp: bf16 matrix products)'
+            driver_line(row, 'utterances/sec (4 s @16 kHz) TF-GridNet train (SURVEY 8f rank 4)', row['utt_per_s'],
+                        'utterances/s', 'bf16' if amp else 'fp32',
+                        'TF-GridNet defaults (3 735 344 params), 4 x 4 s, STFT 256/128 -> 6 grid blocks (BLSTMs, attention) '
+                        '-> iSTFT, multiresyu loss + bwd + clip + Adam', tflops=row['tflops'])
+            print(json.dumps(row), flush=True)
     if 'sgmse_train' in rows:
         print(json.dumps(sgmse_train_row(4, 128, 3)), flush=True)
         print(json.dumps(sgmse_train_row(4, 128, 3, True)), flush=True)
     if 'sgmse' in rows:
         row = sgmse_row(4.0, 30)
         b8 = row['fp16_mfma_b8']
-        driver_line(row, 'utterances/sec SGMSE+ enhance (BASELINE config 4)', b8['utt_per_s'],
+        driver_line(row, 'utterances/sec SGMSE+ enhance (BASELINE.json configs[4], the 5th: SGMSE+ fp16 inference)', b8['utt_per_s'],
                     'utterances/s', 'fp16',
                     'SGMSE+ defaults (65.6 M params), 30-step reverse SDE (PC sampler, 60 network '
                     'evaluations), 8 x 4 s utterances, fp16-MFMA convolutions, iSTFT overlap-add',
