@@ -1548,38 +1548,12 @@ static int deferred_wgrads(const Layout& l, const Workspace& ws, char* base, con
       ProfScope prof("pw1_wgrad", 2.0*n*BT*(double)l.Hp*l.Bnp*2, 2.0*BT*(l.Hp + l.Bnp)*n, st);
       hipLaunchKernelGGL(pw1_wgrad_rc_kernel, dim3(tiles, ns, n), dim3(256), 0, st, rp);
       HIP_OK(hipGetLastError());
-    } else if (!opt(BRV_OPT_NO_WGRAD_128) && l.Bnp == W3_BH && l.Hp % W2_G == 0 && n <= kWgMaxProb) {
-      // the same owner-computes kernel as the [res | skip] gradient (gemm_wgrad_full128.cuh) with the roles of this
-      // product: "G" = 256 of dz1's channels (two 128-wide halves of one tensor) by LDS-DMA, "H" = all 128 columns of
-      // x, untransformed; one launch per 256 channels (24 problems fit the kernel arguments, not 48). No atomics
-      // on the weight gradient: [split][block][256][128] partial tiles, reduced in split order.
-      ProfScope prof("pw1_wgrad", 2.0*n*BT*(double)l.Hp*l.Bnp, 2.0*BT*(l.Hp + l.Bnp)*n, st);
-      for (int half = 0; half < l.Hp/W2_G; ++half) {
-        WgradFullParams fp; memset(&fp, 0, sizeof(fp));
-        fp.B = B; fp.T = (int)T; fp.nprob = n; fp.n_htiles = 1;
-        fp.ldg0 = fp.ldg1 = l.Hp; fp.bsg0 = fp.bsg1 = T*l.Hp;
-        fp.ldh = l.Bnp; fp.bsh = T*l.Bnp;
-        const int c0 = half*W2_G;
-        fp.N0 = std::max(0, std::min(128, l.H - c0)); fp.N1 = std::max(0, std::min(128, l.H - c0 - 128));
-        fp.Kout = l.Bn; fp.ldo = l.Bn;
-        fp.inv_n = 1.0; fp.eps = 0.f;
-        for (int i = i0; i < i0 + n; ++i) {
-          const BlockOff& b = l.blk[i];
-          WgradProb& pr = fp.prob[i - i0];
-          pr.g0 = eBbuf(i) + c0; pr.g1 = eBbuf(i) + c0 + 128; pr.h = xbuf(i);
-          pr.out0 = grads + b.conv_w + (long long)c0*l.Bn; pr.out1 = grads + b.conv_w + (long long)(c0 + 128)*l.Bn;
-          pr.gbias0 = grads + b.conv_b + c0; pr.gbias1 = grads + b.conv_b + c0 + 128;
-        }
-        // 24 problems x 16 / 8 / 4 item splits = 384 / 192 / 96 workgroups per launch (two launches; two chains)
-        fp.n_split = opt(BRV_OPT_NO_WGRAD_SPLIT) ? 1 : (B >= 4*kWgSplit ? 4*kWgSplit : (B >= 2*kWgSplit ? 2*kWgSplit : (B >= kWgSplit ? kWgSplit : 1)));
-        fp.part = reinterpret_cast<float*>(base + ws.wgpart);
-        const int grid = 8*ceil_div(n, 8)*fp.n_split;
-        hipLaunchKernelGGL(wgrad_full128_kernel, dim3(grid), dim3(64*W2_NW), 0, st, fp);
-        if (fp.n_split > 1)
-          hipLaunchKernelGGL(wgrad_full_reduce_kernel, dim3(32, (unsigned)n), dim3(256), 0, st, fp);
-      }
-      HIP_OK(hipGetLastError());
-    } else
+    }
+    // (The owner-computes kernel of the [res | skip] gradient was tried for this product too -- 256 of dz1's channels
+    // as its DMA'd operand, x as the 128-wide one, two launches of 24 problems: 580 us against the 429 us of the
+    // grouped 128 x 128 tiles below: with one item per workgroup its 136 KB zero fill and 128 KB partial tile are
+    // no longer amortised. profiles/r05_wgrad128.txt)
+    else
     if (int r = launch_wgrad_group<A_BF16>(gp, st, "pw1_wgrad", 2.0*BT*(l.Hp + l.Bnp), -1))
       return r;
   }

@@ -12,7 +12,7 @@ the step) and in eval mode on a seeded input.
 dccrn.py): the operands of the convolutions' three matrix products (y from x and W, dx from dy and W, dW from dy and
 x) and of the LSTM input projections (gates from x and W_ih, dx and dW_ih from the gate gradients) are rounded to
 bf16, everything else -- accumulation, bias sums, batch norms, the recurrences, the Linear layers -- stays fp32. It is
-the yardstick of tests/test_gpu_sizes.py (HIP error <= 2.5 x this emulation's own error); with the flag off the module
+the yardstick of tests/test_gpu_sizes.py (HIP error <= 1.5 x this emulation's own error, per tensor); with the flag off the module
 is the pinned fp32 restatement, bit for bit.
 """
 import math

@@ -138,7 +138,9 @@ def test_dccrn_default_size_gradients_fp32_and_use_amp():
         out, o = {}, 0
         for n, k in zip(names, sizes):
             ref = g_ref[o:o + k]
-            if float(ref.norm()) > floor:
+            # (tensors of a handful of elements -- the PReLU slopes are scalars -- are sums with heavy cancellation:
+            # their relative error is that of ONE rounding pattern, not an average; they count in the global bound)
+            if float(ref.norm()) > floor and k >= 64:
                 out[n] = rel(g[o:o + k], ref)
             o += k
         return out
@@ -161,12 +163,15 @@ def test_dccrn_default_size_gradients_fp32_and_use_amp():
             assert e <= 2e-3, e
             assert worst[0] <= 2e-2, worst
             continue
-        # use_amp: no further from the fp32 oracle than 2.5 x the emulation (+ 1e-3), globally and for EVERY tensor
+        # use_amp: no further from the fp32 oracle than 1.5 x the emulation (+ 1e-3), globally and for EVERY tensor of
+        # 64 elements or more. Measured (round 5): global 3.34e-2 against the emulation's 3.31e-2; the tensor that sat
+        # at 0.20 / 0.12 in round 4 (encoder.5 conv weights) is at 0.1247 against the emulation's 0.1243: what bf16
+        # operands cost there by themselves, not a kernel defect; the largest HIP / emulation ratio of any tensor is 1.11
         assert abs(float(loss.detach()) - float(loss_ref.detach())) <= \
-            2.5*abs(float(loss_emu.detach()) - float(loss_ref.detach())) + 1e-3, (float(loss), float(loss_emu), float(loss_ref))
-        assert e <= 2.5*e_emu + 1e-3, (e, e_emu)
-        ratios = sorted(((t_hip[k]/(2.5*t_emu[k] + 1e-3), k, t_hip[k], t_emu[k]) for k in t_hip), reverse=True)
-        print('   largest HIP / (2.5 emulation + 1e-3) ratios:', ratios[:3])
+            1.5*abs(float(loss_emu.detach()) - float(loss_ref.detach())) + 1e-3, (float(loss), float(loss_emu), float(loss_ref))
+        assert e <= 1.5*e_emu + 1e-3, (e, e_emu)
+        ratios = sorted(((t_hip[k]/(1.5*t_emu[k] + 1e-3), k, t_hip[k], t_emu[k]) for k in t_hip), reverse=True)
+        print('   largest HIP / (1.5 emulation + 1e-3) ratios:', [(round(r, 3), k, round(h, 4), round(e_, 4)) for r, k, h, e_ in ratios[:4]])
         assert ratios[0][0] <= 1.0, ratios[:5]
 
 
