@@ -140,7 +140,7 @@ KERNEL_OF_LABEL = {
     'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': ['pw1_dgrad_ws_kernel', 'gemm_rows_kernel<128, 3, 5>'],
     'pw1_wgrad': ('gemm_wgrad_kernel<128, 0>', 'largest'), 'clip_adam': 'clip_adam_kernel',
 }
-PMC_FILES = ('r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
+PMC_FILES = ('r05_pmc_hbm_traffic.json', 'r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
 
 
 def pmc_traffic(label):
@@ -166,7 +166,7 @@ def pmc_traffic(label):
     return None, None
 
 
-SQ_FILES = ('r04_sq_counters.json',)
+SQ_FILES = ('r05_sq_counters.json', 'r04_sq_counters.json')
 
 
 def sq_counters(label):

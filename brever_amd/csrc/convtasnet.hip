@@ -1265,7 +1265,11 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
         const float* lz = reinterpret_cast<const float*>(prep + pb.p_lazy);
         g.a.lazy_v0 = lz; g.a.lazy_v1 = lz + NPu;
         ProfScope prof("pw1_fwd", 2.0*BT*l.Hp*l.Bnp, 2.0*BT*(3*l.Bnp + l.Hp), st);
-        if (int r = launch_gemm_ws<128, 64, 1, E_STORE, 2, false, 8>(g, B, st)) return r;
+#ifndef PW1F_NSL
+#define PW1F_NSL 64
+#define PW1F_WM 1
+#endif
+        if (int r = launch_gemm_ws<128, PW1F_NSL, PW1F_WM, E_STORE, 2, false, 8>(g, B, st)) return r;
       }
       memset(&g, 0, sizeof(g));
       g.a = rows_bf16(z1buf(i), l.Hp, T);
