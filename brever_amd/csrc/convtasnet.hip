@@ -1301,6 +1301,8 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
           const int n_tiles = B*(int)((T + (v2 ? D2_TT : DP_TT) - 1)/(v2 ? D2_TT : DP_TT));
           // (a multiple of 8 workgroups: the kernel deals the tiles to the 8 XCDs in equal runs of slots)
           const int cap = num_cus() >= 8 ? num_cus()/8*8 : 8;
+          // (one workgroup per tile for the half-batch launches of the two-chain step -- 256 tiles on 256 instead of 224
+          // workgroups, so that none walks two tiles -- measured no change: 6.49 ms either way, profiles/r05_dwpw2_ablation.txt)
           const int n_wg = n_tiles < cap ? (n_tiles + 7)/8*8 : cap;
 #ifndef D2V_NW
 #define D2V_NW 4
