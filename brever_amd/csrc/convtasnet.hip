@@ -1324,7 +1324,7 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
     {
       ProfScope prof("skip_combine", 0, 2.0*BT*l.Scp*l.nb + 4.0*BT*l.Scp, st);
       int gx = (int)((T*(l.Scp/8) + 255)/256);
-      if (gx > 128) gx = 128;
+      if (gx > 128) gx = 128;      // (64 / 32 / 16: 136 - 137 us as well, round 5: not the per-workgroup prologue)
       hipLaunchKernelGGL(skip_combine_kernel, dim3(gx, B), dim3(256), 0, st, sc);
       HIP_OK(hipGetLastError());
     }

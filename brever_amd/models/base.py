@@ -118,6 +118,14 @@ class BreverBaseModel(nn.Module):
             self._grad_slices = [self._flat_grad[off:off + p.numel()].view(p.shape) for p, off in self._offsets]
         have = [(v, p.grad) for v, (p, _) in zip(self._grad_slices, self._offsets) if p.grad is not None]
         if len(have) != len(self._offsets):
+            # (differs from torch.optim.Adam, which SKIPS a parameter without a gradient: here it steps on a zero
+            # gradient, i.e. its moments decay and it keeps moving on old momentum -- ADVICE r4; said once)
+            if not getattr(self, '_warned_missing_grads', False):
+                import logging
+                logging.getLogger(__name__).warning(
+                    '%d of %d parameters have no gradient: FlatAdam treats them as zero gradients (torch.optim.Adam '
+                    'would skip them)', len(self._offsets) - len(have), len(self._offsets))
+                self._warned_missing_grads = True
             self._flat_grad.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])

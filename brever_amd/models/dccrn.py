@@ -407,7 +407,13 @@ class _ComplexConvFunction(torch.autograd.Function):
             side = _side_stream(dy.device) if ctx.side_ok else None
             if side is not None:
                 side.wait_stream(torch.cuda.current_stream(dy.device))      # dy, x exist; dx is not waited for
-            if transpose:
+            # (the input of the first encoder layer -- the spectrogram, built under no_grad -- needs no
+            # gradient: its transposed row convolution at the largest resolution, H = 256, was computed and dropped)
+            need_dx = ctx.needs_input_grad[0] or (ctx.two and ctx.needs_input_grad[7]) or bool(ctx.seg)
+            dx = None
+            if not need_dx:
+                pass
+            elif transpose:
                 dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0, split_out=ctx.two)
                 if ctx.two:
                     dx, dskip = dx
@@ -425,7 +431,7 @@ class _ComplexConvFunction(torch.autograd.Function):
                     _side['pending'][dy.device.index] = True
                     dev = dy.device
                     torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev))
-            if ctx.seg and not ctx.two:      # the concatenation was materialised (segments off the chunk of 8)
+            if ctx.seg and not ctx.two and dx is not None:      # the concatenation was materialised (segments off the chunk of 8)
                 s = ctx.seg
                 dx, dskip = (torch.cat([dx[:, :s], dx[:, 2*s:3*s]], dim=1),
                              torch.cat([dx[:, s:2*s], dx[:, 3*s:]], dim=1))
@@ -667,6 +673,11 @@ class _LSTMFunction(torch.autograd.Function):
         lib = hip.lib()
         x, w_ih, w_hh = x.contiguous(), w_ih.contiguous(), w_hh.contiguous()
         G, B, T, I = x.shape
+        # x of shape (1, B, T, I) with several weight sets: ONE input shared by all groups (batch stride 0 in the
+        # products; its gradient is the sum over the groups) -- DCCRN's complex LSTM feeds [real; imag] to both modules
+        shared = ctx.shared = G == 1 and w_hh.shape[0] > 1
+        if shared:
+            G = w_hh.shape[0]
         H = w_hh.shape[-1]
         lowp = ctx.lowp = _AMP['on']
         # many short chains (TF-GridNet): 16 chains per workgroup on the exact-fp32 MFMA, gates
@@ -676,7 +687,7 @@ class _LSTMFunction(torch.autograd.Function):
         if tiled:
             w_ih = _LSTMFunction._interleave(w_ih, H)
         gates = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
-        _gemm(x, w_ih, gates, G, B*T, 4*H, I, I, I, 4*H, B*T*I, 4*H*I, B*T*4*H, trans_b=1,
+        _gemm(x, w_ih, gates, G, B*T, 4*H, I, I, I, 4*H, 0 if shared else B*T*I, 4*H*I, B*T*4*H, trans_b=1,
               lowp=lowp)
         bias = _combine(b_ih.detach().contiguous(), b_hh.detach().contiguous(), 1.0)
         y = torch.empty(G, B, T, H, dtype=torch.float32, device=x.device)
@@ -695,6 +706,9 @@ class _LSTMFunction(torch.autograd.Function):
         lib = hip.lib()
         x, w_ih, w_hh, y, act, cs = ctx.saved_tensors          # w_ih interleaved when tiled
         G, B, T, I = x.shape
+        shared = ctx.shared
+        if shared:
+            G = w_hh.shape[0]
         H = w_hh.shape[-1]
         lowp = ctx.lowp
         dy = dy.contiguous()
@@ -706,14 +720,21 @@ class _LSTMFunction(torch.autograd.Function):
                      G, *extra, hip.stream()), name)
         BT = B*T
         dx = torch.empty_like(x)                                   # dg (BT, 4H) @ W_ih (4H, I)
-        _gemm(dg, w_ih, dx, G, BT, I, 4*H, 4*H, I, I, BT*4*H, 4*H*I, BT*I, lowp=lowp)
+        if shared:                                                 # (summed over the groups: they are the k-batches)
+            _gemm(dg, w_ih, dx, 1, BT, I, 4*H, 4*H, I, I, 0, 0, 0, kbatch=G, a_kbs=BT*4*H, b_kbs=4*H*I, lowp=lowp)
+        else:
+            _gemm(dg, w_ih, dx, G, BT, I, 4*H, 4*H, I, I, BT*4*H, 4*H*I, BT*I, lowp=lowp)
         dw_ih = torch.empty_like(w_ih)                             # dg^T (4H, BT) @ x (BT, I)
-        _gemm(dg, x, dw_ih, G, 4*H, I, BT, 4*H, I, I, BT*4*H, BT*I, 4*H*I, trans_a=1, lowp=lowp)
-        h_prev = torch.zeros_like(y)                               # hidden state entering step t
-        h_prev[:, :, 1:] = y[:, :, :-1]
-        dw_hh = torch.empty_like(w_hh)
-        _gemm(dg, h_prev, dw_hh, G, 4*H, H, BT, 4*H, H, H, BT*4*H, BT*H, 4*H*H, trans_a=1,
-              lowp=lowp)
+        _gemm(dg, x, dw_ih, G, 4*H, I, BT, 4*H, I, I, BT*4*H, 0 if shared else BT*I, 4*H*I, trans_a=1, lowp=lowp)
+        # recurrent weight gradient: the gate gradients of frames 1.. against the hidden states of frames 0..T-2 of the
+        # same chain, through shifted views (round 5: a zero-filled shifted copy of y was built per call -- a 16 MB fill
+        # and a 16 MB copy in front of every product; the chains are the k-batches of the product instead)
+        dw_hh = torch.zeros_like(w_hh) if T == 1 else torch.empty_like(w_hh)
+        if T > 1:
+            flat_dg, flat_y = dg.view(G, -1), y.view(G, -1)
+            for g in range(G):
+                _gemm(flat_dg[g, 4*H:], flat_y[g], dw_hh[g], 1, 4*H, H, T - 1, 4*H, H, H, 0, 0, 0, trans_a=1,
+                      kbatch=B, a_kbs=T*4*H, b_kbs=T*H, lowp=lowp)
         # bias gradients: column sums of dg (BT, 4H) per group, in a fixed order (no transposed copy)
         db = torch.empty(G, 4*H, dtype=torch.float32, device=x.device)
         scratch = torch.empty(lib.brv_col_sum_scratch_bytes(G, 4*H), dtype=torch.uint8, device=x.device)
@@ -804,7 +825,7 @@ class DCCRN(BreverBaseModel):
     def _lstm(lstms, xs):
         """The single-layer LSTMs ``lstms`` on their inputs ``xs`` (same shapes), concurrently."""
         stack = lambda name: torch.stack([getattr(m, name) for m in lstms])  # noqa: E731
-        return _LSTMFunction.apply(torch.stack(xs), stack('weight_ih_l0'), stack('weight_hh_l0'),
+        return _LSTMFunction.apply(xs if torch.is_tensor(xs) else torch.stack(xs), stack('weight_ih_l0'), stack('weight_hh_l0'),
                                    stack('bias_ih_l0'), stack('bias_hh_l0'))
 
     def _lstm_block(self, x):
@@ -816,9 +837,9 @@ class DCCRN(BreverBaseModel):
         real, imag = rows.chunk(2, dim=-1)
         for layer in blk.lstm.layers:
             # each module sees both halves; both modules run in one set of launches (4B chains)
-            out = self._lstm((layer.module_real, layer.module_imag),
-                             (torch.cat([real, imag], dim=0), torch.cat([imag, real], dim=0)))
-            (rr, ri), (ii, ir) = out[0].chunk(2, dim=0), out[1].chunk(2, dim=0)
+            # (round 5: ONE concatenation [real; imag] shared by both modules instead of two concatenations and a stack)
+            out = self._lstm((layer.module_real, layer.module_imag), torch.cat([real, imag], dim=0).unsqueeze(0))
+            (rr, ri), (ir, ii) = out[0].chunk(2, dim=0), out[1].chunk(2, dim=0)
             real, imag = _CombineFunction.apply(rr, ii, -1.0), _CombineFunction.apply(ri, ir, 1.0)
         # Linear applied on the feature axis of (B, features, T): the output is already in the
         # (channels*freqs, frames) layout of the decoder input

@@ -205,6 +205,12 @@ class _AttentionFn(torch.autograd.Function):
 
 
 _SMALL = os.environ.get('BRV_TFG_LINEAR_SMALL', '1') != '0'     # narrow linear layers on brv_linear_small
+_SMALL_SCRATCH = {}
+# NOTE: the two narrow-layer paths below are taken BEFORE ``lowp`` is looked at, so under use_amp the
+# layers with K, N <= 64 (and their weight gradients) run in full fp32 while every other product rounds its operands
+# to bf16: closer to the fp32 oracle than the bf16 emulation assumes, never further (the use_amp tolerances of
+# tests/test_gpu.py are upper bounds on the distance from the fp32 reference). The cut-over is a size rule of the
+# library (`brv_linear_small_supported`), so results change at that size by bf16-rounding level, not more.
 
 
 def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_a=0, trans_b=0,
@@ -225,7 +231,13 @@ def _gemm(a, b, d, batch, M, N, K, lda, ldb, ldd, a_bs=0, b_bs=0, d_bs=0, trans_
             and hip.lib().brv_linear_small_wgrad_supported(K, M, N):
         # their weight gradients: (rows x M)^T (rows x N) over ~2.6e5 rows, slices added in a fixed order
         lib = hip.lib()
-        scratch = torch.empty(lib.brv_linear_small_wgrad_scratch_bytes(M, N), dtype=torch.uint8, device=d.device)
+        # (one scratch buffer per device and size, not an allocation per call: up to 48 calls per step -- ADVICE r4; the
+        # launches of a stream run in order, so consecutive products may share it)
+        nbytes = lib.brv_linear_small_wgrad_scratch_bytes(M, N)
+        key = (d.device.index, torch.cuda.current_stream(d.device).cuda_stream)
+        scratch = _SMALL_SCRATCH.get(key)
+        if scratch is None or scratch.numel() < nbytes:
+            scratch = _SMALL_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=d.device)
         hip.check(lib.brv_linear_small_wgrad(hip.ptr(a), hip.ptr(b), hip.ptr(d), hip.ptr(scratch), K, M, N, lda, ldb,
                                              ldd, hip.stream()), 'brv_linear_small_wgrad')
         return

@@ -616,6 +616,15 @@ def test_launch_opts_come_from_the_environment_on_the_host(monkeypatch):
     monkeypatch.setenv('BRV_FWD_FUSE', '1')                  # '1' = default: only '0' switches the fusion off
     monkeypatch.setenv('BRV_BWD_FUSE', '0')
     assert hip.launch_opts().flags == hip.OPT_NO_BWD_FUSE | hip.OPT_NO_DZ1_FUSE
+    # round 5: the 128-wide [res | skip] weight gradient is the default ('0' selects the 64-wide kernel), the whole-row
+    # fused forward is opt-in
+    monkeypatch.setenv('BRV_WGRAD_128', '1')
+    monkeypatch.setenv('BRV_DWPW2_V2', '0')
+    assert hip.launch_opts().flags == hip.OPT_NO_BWD_FUSE | hip.OPT_NO_DZ1_FUSE
+    monkeypatch.setenv('BRV_WGRAD_128', '0')
+    monkeypatch.setenv('BRV_DWPW2_V2', '1')
+    assert hip.launch_opts().flags == hip.OPT_NO_BWD_FUSE | hip.OPT_NO_DZ1_FUSE | hip.OPT_NO_WGRAD_128 | hip.OPT_DWPW2_V2
+    assert (hip.OPT_NO_WGRAD_128, hip.OPT_DWPW2_V2) == (0x1000, 0x800)
     # the shared library itself has no getenv among its undefined symbols' users on the product path:
     # (checked at the source level -- diagnostic builds only, behind BRV_DIAG)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
