@@ -34,7 +34,7 @@ class LaunchOpts(ctypes.Structure):
 
 OPT_NO_FWD_FUSE, OPT_NO_BWD_FUSE, OPT_NO_WS, OPT_DWPW2_WS = 0x001, 0x002, 0x004, 0x008
 OPT_NO_DZ_FUSE, OPT_NO_DZ1_FUSE, OPT_NO_WGRAD_FULL, OPT_NO_WGRAD_SPLIT = 0x010, 0x020, 0x040, 0x080
-OPT_NO_PW1_RC, OPT_PW1_RC_WGRAD, OPT_PW1_RC_TILES, OPT_DWPW2_V2, OPT_NO_WGRAD_128 = 0x100, 0x200, 0x400, 0x800, 0x1000
+OPT_NO_PW1_RC, OPT_PW1_RC_WGRAD, OPT_PW1_RC_TILES, OPT_DWPW2_V2, OPT_NO_WGRAD_128, OPT_BWD_PERSIST = 0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000
 # environment switch -> option flag (read by the HOST at call time; the library itself reads no
 # environment). '0' selects the flag for the *_FUSE switches, any value for the BRV_NO_* ones.
 _ENV_FLAGS = (('BRV_FWD_FUSE', OPT_NO_FWD_FUSE, '0'), ('BRV_BWD_FUSE', OPT_NO_BWD_FUSE, '0'),
@@ -43,7 +43,7 @@ _ENV_FLAGS = (('BRV_FWD_FUSE', OPT_NO_FWD_FUSE, '0'), ('BRV_BWD_FUSE', OPT_NO_BW
               ('BRV_NO_WGRAD_FULL', OPT_NO_WGRAD_FULL, None), ('BRV_NO_WGRAD_SPLIT', OPT_NO_WGRAD_SPLIT, None),
               ('BRV_PW1_RC', OPT_NO_PW1_RC, '0'), ('BRV_PW1_RC_WGRAD', OPT_PW1_RC_WGRAD, '1'),
               ('BRV_PW1_RC_TILES', OPT_PW1_RC_TILES, '1'), ('BRV_DWPW2_V2', OPT_DWPW2_V2, '1'),
-              ('BRV_WGRAD_128', OPT_NO_WGRAD_128, '0'))
+              ('BRV_WGRAD_128', OPT_NO_WGRAD_128, '0'), ('BRV_BWD_PERSIST', OPT_BWD_PERSIST, '1'))
 _prof = None            # profiler handle of this process's calls (prof_enable)
 
 

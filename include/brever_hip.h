@@ -58,6 +58,7 @@ void brv_prof_destroy(void* prof);
 #define BRV_OPT_NO_WGRAD_SPLIT  0x080u  /* no item split of that launch */
 #define BRV_OPT_NO_PW1_RC       0x100u  /* first-conv data gradient reads the stored z1 (pw1_bwd.cuh off) */
 #define BRV_OPT_PW1_RC_WGRAD    0x200u  /* first-conv weight gradient rebuilds dz1 from e1 and x too: dz1 is never stored */
+#define BRV_OPT_BWD_PERSIST    0x2000u  /* fused backward stage in its persistent form (bwd_fused_p.cuh: two tiles per workgroup; measured slower) */
 #define BRV_OPT_NO_WGRAD_128   0x1000u  /* [res | skip] weight gradient with 64 instead of 128 H channels per workgroup (gemm_wgrad_full.cuh) */
 #define BRV_OPT_DWPW2_V2        0x800u  /* fused forward stage in its whole-row form (dwpw2_fused_v2.cuh) */
 #define BRV_OPT_PW1_RC_TILES    0x400u  /* recompute in the one-tile-per-workgroup form (weights re-read per tile; implies _WGRAD) */

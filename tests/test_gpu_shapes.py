@@ -401,6 +401,36 @@ def test_fused_backward_equals_three_launch_backward(monkeypatch, layers, repeat
             print('   worst tensor', worst)
 
 
+@pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 2, 3, 5000), (4, 2, 1, 700), (8, 1, 9, 2100), (8, 1, 2, 300)])
+def test_persistent_fused_backward_equals_one_tile_per_workgroup(monkeypatch, layers, repeats, B, L):
+    """csrc/bwd_fused_p.cuh (BRV_BWD_PERSIST=1: a workgroup walks two tiles, per-channel partial sums kept in LDS over the
+    range, atomics once per workgroup) against the default one-tile-per-workgroup kernel: the same arithmetic per
+    element, the per-channel sums in another order. Odd tile counts (the second tile of the last workgroup missing),
+    items shorter than a tile, tile ranges that cross items."""
+    from brever_amd.criterion import snr
+    from brever_amd.models import ConvTasNet
+    cfg = dict(layers=layers, repeats=repeats)
+    gen = torch.Generator().manual_seed(13*layers + B)
+    torch.manual_seed(31)
+    ref = ConvTasNet(**cfg)
+    _detrivialise(ref, gen)
+    batch, lengths = _ragged_batch(gen, B, L)
+    grads = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('BRV_BWD_PERSIST', mode)
+        net = ConvTasNet(**cfg)
+        net.load_state_dict(ref.state_dict())
+        net = net.to(_cuda())
+        net._amp = True
+        out = net(batch[:, 0].cuda())
+        snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean().backward()
+        grads[mode] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+        assert torch.isfinite(grads[mode]).all()
+    e = rel(grads['1'], grads['0'])
+    print(f'layers {layers} x {repeats}, B {B}, L {L}: persistent vs one-tile backward rel {e:.3e}')
+    assert e <= 2e-3, e
+
+
 @pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 2, 3, 5000), (4, 2, 1, 700), (8, 1, 5, 2100),
                                                 (8, 1, 2, 300), (2, 1, 1, 64000)])
 def test_first_conv_backward_with_recomputed_z1_equals_stored_path(monkeypatch, layers, repeats, B, L):

@@ -603,7 +603,7 @@ def test_launch_opts_come_from_the_environment_on_the_host(monkeypatch):
     DESIGN 5c into `brv_launch_opts` flags at call time."""
     import ctypes
     for name in ('BRV_FWD_FUSE', 'BRV_BWD_FUSE', 'BRV_NO_WS', 'BRV_DWPW2_WS', 'BRV_NO_DZ_FUSE', 'BRV_NO_DZ1_FUSE',
-                 'BRV_NO_WGRAD_FULL', 'BRV_NO_WGRAD_SPLIT', 'BRV_WG_TARGET', 'BRV_PW1_RC', 'BRV_DWPW2_V2', 'BRV_WGRAD_128'):
+                 'BRV_NO_WGRAD_FULL', 'BRV_NO_WGRAD_SPLIT', 'BRV_WG_TARGET', 'BRV_PW1_RC', 'BRV_DWPW2_V2', 'BRV_WGRAD_128', 'BRV_BWD_PERSIST'):
         monkeypatch.delenv(name, raising=False)
     o = hip.launch_opts()
     assert o.size == ctypes.sizeof(hip.LaunchOpts) == 24 and o.flags == 0 and o.cu_eighths == 8
