@@ -851,6 +851,10 @@ class DCCRN(BreverBaseModel):
 
     def _mask_net(self, x):
         net = self.mask_net
+        if x.is_cuda:
+            # a backward pass that raised never ran its end-of-pass callback: the "join queued" mark of this device must
+            # not survive into the next pass, or that pass would queue no join at all
+            _side['pending'][x.device.index] = False
         encoder_outputs = []
         for blk in net.encoder:
             x = self._norm_act(self._complex_conv(x, blk.conv, False), blk.norm, blk.activation)
