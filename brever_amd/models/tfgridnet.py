@@ -545,11 +545,21 @@ class TFGridNet(BreverBaseModel):
         a = a.view(B, H, old_T, Ev, old_Q).permute(0, 2, 4, 1, 3).reshape(B, old_T, old_Q, H*Ev)
         conv, act, norm = blk.attn_concat_proj
         a = _linear(a, conv)                                                 # (B, T, Q, C)
-        rows = a.transpose(2, 3).reshape(B*old_T, C*old_Q)                   # (channel, band) rows
         slope = act.weight if isinstance(act, nn.PReLU) else None
         if slope is None and not isinstance(act, nn.Identity):
             raise NotImplementedError(f'activation {type(act).__name__} is not built on the HIP '
                                       'path (PReLU and Identity are)')
+        if slope is None or slope.numel() == 1:
+            # the normalisation runs over the whole (channel, band) plane of a frame: the order of the plane inside a
+            # row does not matter to its statistics, so the rows stay in the (band, channel) order the projection wrote
+            # and the (tiny) gain / bias planes are transposed instead -- round 5: two 33 MB activation copies per block
+            # (the transpose in front and the one inside the residual add) and their two mirror images in backward
+            rows = a.reshape(B*old_T, old_Q*C)
+            gam = norm.gamma.view(C, old_Q).t().reshape(1, old_Q*C)
+            bet = norm.beta.view(C, old_Q).t().reshape(1, old_Q*C)
+            rows = _RowNormFn.apply(rows, slope, gam, bet, 1, norm.eps)
+            return _add(rows.view(B, old_T, old_Q, C), x)
+        rows = a.transpose(2, 3).reshape(B*old_T, C*old_Q)                   # (channel, band) rows
         rows = _RowNormFn.apply(rows, slope, norm.gamma.view(1, C*old_Q), norm.beta.view(1, C*old_Q),
                                 1, norm.eps)
         a = rows.view(B, old_T, C, old_Q).transpose(2, 3)
