@@ -611,7 +611,7 @@ class ConvTasNet(BreverBaseModel):
         lib = hip.lib()
         B, L = inputs.shape
         S = self.output_sources
-        nB = ((B + 1)//2, B//2)                   # items per chain (odd batches: the first takes one more)
+        nB = self._chain_split(B)                 # items per chain (odd batches: the first takes one more)
         dev = inputs.device
         with torch.no_grad():
             wave, wstride = self._rows(inputs, True)        # read in place: no strided copies
@@ -695,6 +695,15 @@ class ConvTasNet(BreverBaseModel):
             hip.check(lib.brv_mean_f32(hip.ptr(t['loss']), B, hip.ptr(loss), hip.stream()), 'brv_mean_f32')
             return loss
 
+    @staticmethod
+    def _chain_split(B):
+        """Items of the two chains: halves. ``BRV_CTN_SPLIT=n`` (A/B runs): n items on the first chain -- measured at
+        16 x 4 s (round 5, profiles/r05_chain_split.txt): uneven chains do not interleave better than halves."""
+        n = os.environ.get('BRV_CTN_SPLIT')
+        if n is not None and 1 <= int(n) < B:
+            return (int(n), B - int(n))
+        return ((B + 1)//2, B//2)
+
     def _two_chain_buffers(self, B, S, L, dev):
         """Buffers of the two-chain step. GROW-ONLY (the trainer's dynamic batches change (B, L) almost
         every step): the two half-batch activation workspaces are slices of the model's one bf16
@@ -702,7 +711,7 @@ class ConvTasNet(BreverBaseModel):
         output / loss buffers are views of flat allocations that are replaced only by larger ones (the
         old reference is dropped first: no 2x peak). The side stream is created once."""
         lib = hip.lib()
-        Bh = (B + 1)//2                            # the larger half sizes both workspaces
+        Bh = max(self._chain_split(B))             # the larger part sizes both workspaces
         nws = lib.brv_ctn_workspace_bytes(self._cfg_ptr(), Bh, L)
         if nws < 0:
             hip.check(int(nws), 'brv_ctn_workspace_bytes')
