@@ -1,6 +1,6 @@
 // [res | skip] weight gradient of all TCN blocks, second tiling (round 5): a workgroup owns the full G width (256)
 // and a 128-channel slice of H (gemm_wgrad_full.cuh: 64). Why: the ablations of the 64-wide form
-// (profiles/r05_dwpw2_ablation.txt, last table) show its loop is not bound by what it loads -- without any LDS-DMA it
+// (profiles/r05_dwpw2_ablation.txt, section "wgrad_full (pw2_wgrad) ablations") show its loop is not bound by what it loads -- without any LDS-DMA it
 // still takes 589 of its 850 us: a chunk of 64 frames is 8 MFMAs per wave (256 matrix-pipe cycles) between two
 // barriers, and the fragment-read latencies, the DMA issue and the barrier hand-over around them take three times
 // that. Here a chunk is 16 MFMAs per wave on FIVE fragments per k-step (1 G + 4 H) instead of 8 on three, and G (the
