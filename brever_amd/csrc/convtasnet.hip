@@ -1313,14 +1313,18 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
           const int cap = num_cus() >= 8 ? num_cus()/8*8 : 8;
           // (one workgroup per tile for the half-batch launches of the two-chain step -- 256 tiles on 256 instead of 224
           // workgroups, so that none walks two tiles -- measured no change: 6.49 ms either way, profiles/r05_dwpw2_ablation.txt)
-          const int n_wg = n_tiles < cap ? (n_tiles + 7)/8*8 : cap;
+#ifndef D2V_SEQ
+#define D2V_SEQ 0
+#endif
+          const int cap2 = (v2 && D2V_SEQ) ? 2*cap : cap;
+          const int n_wg = n_tiles < cap2 ? (n_tiles + 7)/8*8 : cap2;
 #ifndef D2V_NW
 #define D2V_NW 4
 #endif
 #ifndef D2V_AHEAD
 #define D2V_AHEAD 8
 #endif
-          if (v2) hipLaunchKernelGGL((dwpw2_v2_kernel<D2V_NW, D2V_AHEAD>), dim3(n_wg), dim3(64*D2V_NW), 0, st, dp);
+          if (v2) hipLaunchKernelGGL((dwpw2_v2_kernel<D2V_NW, D2V_AHEAD, (bool)D2V_SEQ>), dim3(n_wg), dim3(64*D2V_NW), 0, st, dp);
           else hipLaunchKernelGGL(dwpw2_fused_kernel, dim3(n_wg), dim3(512), 0, st, dp);
           HIP_OK(hipGetLastError());
         }

@@ -40,14 +40,21 @@ __device__ __forceinline__ void buf_store8(__amdgpu_buffer_rsrc_t r, unsigned in
 
 // NW = 8: two waves per SIMD (256 registers each); NW = 4: one wave per SIMD with the whole register file (no
 // spills with eight frames of taps in flight), every wave two 32-output slices.
-template <int NW, int AHEAD>
-__global__ __launch_bounds__(64*NW) void dwpw2_v2_kernel(const DwPw2Params p) {
+//
+// SEQ (diagnostic, NW = 4): ONE p buffer (the u patches reuse it), the stencil and the product of a tile one after the
+// other, 75 KB of LDS and 256 registers, so that TWO workgroups share a CU and one's product runs beside the other's
+// stencil -- the phases overlap between workgroups instead of inside one instruction stream.
+template <int NW, int AHEAD, bool SEQ = false>
+__global__ __launch_bounds__(64*NW) __attribute__((amdgpu_waves_per_eu(SEQ ? 2 : 1, SEQ ? 2 : NW/4)))
+void dwpw2_v2_kernel(const DwPw2Params p) {
   constexpr int D2_FPW = D2_TT/NW;                 // frames per wave and tile
   constexpr int NSL = 8/NW;                        // 32-output slices per wave
   constexpr int KPJ = 32/D2_FPW;                   // k-steps beside one frame of the stencil
   constexpr int D2_AHEAD = AHEAD;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[D2_SMEM];
-  float* tabs = reinterpret_cast<float*>(smem + D2_OFF_TAB);      // [4][512]
+  static_assert(!SEQ || NW == 4, "the sequential form is written for four waves");
+  constexpr int OFF_TAB = SEQ ? D2_PBYTES : D2_OFF_TAB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SEQ ? D2_PBYTES + 4*DP_H*4 : D2_SMEM];
+  float* tabs = reinterpret_cast<float*>(smem + OFF_TAB);         // [4][512]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n32 = lane & 31, khalf = lane >> 5;
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(64*NW) void dwpw2_v2_kernel(const DwPw2Params p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[sl][f][i] = 0.f;
   };
-  zero_acc();
+  if (!SEQ) zero_acc();
   // weight fragments by buffer loads: ONE offset register (lane * 16) for all of them, the fragment's place as the
   // scalar offset (as global loads every fragment 4 KB apart needed an address pair of its own: 60 registers)
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.Wp + (long long)wid*NSL*32*DP_H, (long long)NSL*32*DP_H*2);
@@ -250,19 +257,20 @@ __global__ __launch_bounds__(64*NW) void dwpw2_v2_kernel(const DwPw2Params p) {
   TilePos qm = qs;                                 // tile being multiplied
 #pragma unroll
   for (int j = 0; j < D2_AHEAD; ++j) request(qs, j, ring[j]);
-  load_w(0, wfr[0]);
+  if (!SEQ) load_w(0, wfr[0]);
 
   // one pass over the wave's frames: the product of tile `qm` (MF) beside the stencil of tile `qs` (ST)
   auto pass = [&](auto mf_tag, auto st_tag, int par) {
     constexpr bool MF = decltype(mf_tag)::value, ST = decltype(st_tag)::value;
     if (ST && qs.b != coef_item && !((D2_ABL & 64) && coef_item >= 0)) load_coefs(qs.b);
     if (ST && qs.b != stat_item) { flush_stats(); stat_item = qs.b; }
-    bf16_t* pst = reinterpret_cast<bf16_t*>(smem + (par ^ 1)*D2_PBYTES);
-    const bf16_t* pmm = reinterpret_cast<const bf16_t*>(smem + par*D2_PBYTES) + n32*D2_LDP + khalf*8;
+    bf16_t* pst = reinterpret_cast<bf16_t*>(smem + (SEQ ? 0 : (par ^ 1)*D2_PBYTES));
+    const bf16_t* pmm = reinterpret_cast<const bf16_t*>(smem + (SEQ ? 0 : par*D2_PBYTES)) + n32*D2_LDP + khalf*8;
+    if (SEQ && MF) { zero_acc(); load_w(0, wfr[0]); }      // (neither lives through the stencil pass)
 #pragma unroll
     for (int j = 0; j < D2_FPW; ++j) {
       if (MF) {
-        load_w((j + 1) % D2_FPW, wfr[(j + 1) & 1]);         // (last j: k-group 0 again, for the next tile)
+        if (!SEQ || j + 1 < D2_FPW) load_w((j + 1) % D2_FPW, wfr[(j + 1) & 1]);   // (last j: k-group 0 again, for the next tile)
         if (!(D2_ABL & 1)) {
 #pragma unroll
           for (int ks = 0; ks < KPJ; ++ks) {
@@ -296,7 +304,8 @@ __global__ __launch_bounds__(64*NW) void dwpw2_v2_kernel(const DwPw2Params p) {
       constexpr int UROW = 64*NSL + 16;            // bytes per staged frame (padded)
       constexpr int PPR = 4*NSL;                   // 16-byte pieces per frame
       constexpr int FPI = 64/PPR;                  // frames per store instruction
-      unsigned char* ust = smem + D2_OFF_TAB + 4*DP_H*4 + wid*(32*UROW);
+      unsigned char* ust = SEQ ? smem + wid*(32*UROW) : smem + D2_OFF_TAB + 4*DP_H*4 + wid*(32*UROW);
+      if (SEQ) __syncthreads();                    // (every wave is done reading p before the patches overwrite it)
       if (!(D2_ABL & 4)) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
@@ -317,11 +326,22 @@ __global__ __launch_bounds__(64*NW) void dwpw2_v2_kernel(const DwPw2Params p) {
           }
         }
       }
-      zero_acc();
+      if (!SEQ) zero_acc();
     }
     if (!(D2_ABL & 32)) __syncthreads();
   };
   using T_ = std::true_type; using F_ = std::false_type;
+  if (SEQ) {
+#pragma unroll 1
+    for (int n = 0; n < n_my; ++n) {
+      pass(F_{}, T_{}, 0);
+      qm = qs;
+      pass(T_{}, F_{}, 0);
+      qs = qn; advance(qn, n + 2);
+    }
+    flush_stats();
+    return;
+  }
   // tile 0 is staged alone, the last tile multiplied alone; in between both streams run side by side
   pass(F_{}, T_{}, 1);                             // stages into buffer 0
   int par = 0;
