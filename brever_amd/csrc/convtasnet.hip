@@ -297,6 +297,42 @@ __global__ void stamp_check_f64_kernel(const int* stamp, int expect, double* poi
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
   for (long long i = threadIdx.x; i < n; i += blockDim.x) poison[i] = nan;
 }
+// The start of a forward / backward call in ONE launch instead of two fills and two one-thread kernels in a row
+// (each ~5 us of an otherwise idle chip at the step boundary: profiles/r05_step_boundary.txt): region `a` (doubles)
+// <- 0, or NaN when the stamp at `check` is not `expect`; region `b` <- 0; `write` <- value.
+struct CallInitParams {
+  double* a; long long a_n; void* b; long long b_bytes;
+  const int* check; int expect; int* write; int value;
+};
+__global__ __launch_bounds__(256) void call_init_kernel(const CallInitParams p) {
+  const bool bad = *p.check != p.expect;
+  const double fill = bad ? __longlong_as_double(0x7ff8000000000000LL) : 0.0;
+  const long long tid = (long long)blockIdx.x*256 + threadIdx.x, nth = (long long)gridDim.x*256;
+  for (long long i = tid; i < p.a_n; i += nth) p.a[i] = fill;
+  if (p.b) {
+    unsigned char* b = (unsigned char*)p.b;
+    // (sizes are multiples of 4: fp32 / fp64 tensors) 16-byte stores over the aligned middle, words at the ends
+    long long head = (16 - ((unsigned long long)b & 15)) & 15;
+    if (head > p.b_bytes) head = p.b_bytes;
+    const long long n16 = (p.b_bytes - head) >> 4, tail0 = head + (n16 << 4);
+    uint4* mid = reinterpret_cast<uint4*>(b + head);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (long long i = tid; i < n16; i += nth) mid[i] = z;
+    for (long long i = tid*4; i < head; i += nth*4) *reinterpret_cast<unsigned int*>(b + i) = 0u;
+    for (long long i = tail0 + tid*4; i < p.b_bytes; i += nth*4) *reinterpret_cast<unsigned int*>(b + i) = 0u;
+  }
+  if (tid == 0 && p.write) *p.write = p.value;
+}
+inline int launch_call_init(double* a, long long a_n, void* b, long long b_bytes, const int* check, int expect,
+                            int* write, int value, hipStream_t st) {
+  CallInitParams ip; ip.a = a; ip.a_n = a_n; ip.b = b; ip.b_bytes = b_bytes; ip.check = check; ip.expect = expect;
+  ip.write = write; ip.value = value;
+  const long long units = a_n + (b_bytes >> 4);
+  int gx = (int)std::min<long long>(512, (units + 1023)/1024);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(call_init_kernel, dim3(gx), dim3(256), 0, st, ip);
+  return (int)hipGetLastError();
+}
 
 // Workgroups of a persistent launch: one per CU -- or opts.cu_eighths/8 of that while two kernel
 // chains share the chip: with 8 items per chain a full-width launch has exactly one tile per workgroup
@@ -572,7 +608,11 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* params,
 // Constants of the lazily applied second norm (fused forward, gemm_ws.cuh AT == 3): with
 // u = (W gamma) p the finished convolution output is rstd u + v0 - mean rstd v1.
 struct LazyPrepBlk { long long res_w, res_b, skip_w, skip_b, beta, wg, out; };
-struct LazyPrepParams { int nb, H, Hp, Bn, Sc, Bnp, Scp; LazyPrepBlk blk[kWgMaxProb]; };
+struct LazyPrepParams {
+  int nb, H, Hp, Bn, Sc, Bnp, Scp;
+  int* stamp; int stamp_value;             // the mode stamp of `prepared` (last launch of prepare: no launch of its own)
+  LazyPrepBlk blk[kWgMaxProb];
+};
 __global__ __launch_bounds__(256) void lazy_prep_kernel(const float* params, bf16_t* prepped,
                                                         const LazyPrepParams p) {
   // one wave per output row: lanes stride over the H inputs, butterfly reduce
@@ -580,6 +620,7 @@ __global__ __launch_bounds__(256) void lazy_prep_kernel(const float* params, bf1
   float* out = reinterpret_cast<float*>(prepped + b.out);
   const int NP = p.Bnp + p.Scp;
   const int n = blockIdx.x*4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.stamp = p.stamp_value;
   if (n >= NP) return;
   const bool res = n < p.Bnp;
   const int r = res ? n : n - p.Bnp;
@@ -1183,13 +1224,15 @@ int brv_ctn_prepare(const brv_ctn_config* cfg, const float* params, void* prepar
       lp.blk[i].res_w = b.res_w; lp.blk[i].res_b = b.res_b; lp.blk[i].skip_w = b.skip_w;
       lp.blk[i].skip_b = b.skip_b; lp.blk[i].beta = b.n2_b; lp.blk[i].wg = b.p_rs_g; lp.blk[i].out = b.p_lazy;
     }
+    lp.stamp = reinterpret_cast<int*>((bf16_t*)prepared + l.p_stamp); lp.stamp_value = mode_stamp(fused);
     hipLaunchKernelGGL(lazy_prep_kernel, dim3((l.Bnp + l.Scp + 3)/4, l.nb), dim3(256), 0, st, params,
                        (bf16_t*)prepared, lp);
     HIP_OK(hipGetLastError());
+  } else {
+    hipLaunchKernelGGL(stamp_write_kernel, dim3(1), dim3(1), 0, st,
+                       reinterpret_cast<int*>((bf16_t*)prepared + l.p_stamp), mode_stamp(fused));
+    HIP_OK(hipGetLastError());
   }
-  hipLaunchKernelGGL(stamp_write_kernel, dim3(1), dim3(1), 0, st,
-                     reinterpret_cast<int*>((bf16_t*)prepared + l.p_stamp), mode_stamp(fused));
-  HIP_OK(hipGetLastError());
   return 0;
 }
 
@@ -1218,15 +1261,12 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
   bf16_t* m = (bf16_t*)(base + ws.m);
   bf16_t* y = (bf16_t*)(base + ws.y);
 
-  HIP_OK(hipMemsetAsync(stats, 0, ws.stats_bytes, st));
-  HIP_OK(hipMemsetAsync(out, 0, (size_t)B*l.S*L*sizeof(float), st));
-  // operands prepared for the other mode -> NaN statistics (and with them a NaN output); then this call's mode
-  hipLaunchKernelGGL(stamp_check_f64_kernel, dim3(1), dim3(256), 0, st,
-                     reinterpret_cast<const int*>(prep + l.p_stamp), mode_stamp(l.fused_fwd()), stats,
-                     (long long)(ws.stats_bytes/8));
-  hipLaunchKernelGGL(stamp_write_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<int*>(base + ws.stamp),
-                     mode_stamp(l.fused_fwd()));
-  HIP_OK(hipGetLastError());
+  // statistics and output <- 0; operands prepared for the other mode -> NaN statistics (and with them a NaN
+  // output); then this call's mode stamped on the workspace
+  if (int r = launch_call_init(stats, (long long)(ws.stats_bytes/8), out, (long long)B*l.S*L*(long long)sizeof(float),
+                               reinterpret_cast<const int*>(prep + l.p_stamp), mode_stamp(l.fused_fwd()),
+                               reinterpret_cast<int*>(base + ws.stamp), mode_stamp(l.fused_fwd()), st))
+    return fail(r, "forward: call_init launch");
 
   GemmRowsParams g;
   // encoder: framed filterbank analysis, statistics for the first gLN
@@ -1647,13 +1687,11 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
 
   GemmRowsParams g; WgradParams wg;
   if (head) {
-  HIP_OK(hipMemsetAsync(sums, 0, ws.stats_bytes, st));
-  HIP_OK(hipMemsetAsync(vg, 0, ws.vg_bytes, st));
-  // a workspace filled by a forward call in the other mode -> NaN sums (and with them NaN gradients)
-  hipLaunchKernelGGL(stamp_check_f64_kernel, dim3(1), dim3(256), 0, st,
-                     reinterpret_cast<const int*>(base + ws.stamp), mode_stamp(l.fused_fwd()), sums,
-                     (long long)(ws.stats_bytes/8));
-  HIP_OK(hipGetLastError());
+  // sums and replica block <- 0; a workspace filled by a forward call in the other mode -> NaN sums (and with
+  // them NaN gradients)
+  if (int r = launch_call_init(sums, (long long)(ws.stats_bytes/8), vg, (long long)ws.vg_bytes,
+                               reinterpret_cast<const int*>(base + ws.stamp), mode_stamp(l.fused_fwd()), nullptr, 0, st))
+    return fail(r, "backward: call_init launch");
   // decoder data gradient (framing of d_out) fused with the mask backward
   memset(&g, 0, sizeof(g));
   g.a = frames_of(d_out, L, l.hop, l.K);

@@ -622,7 +622,6 @@ class ConvTasNet(BreverBaseModel):
             grads = self.flat_grads()
             # (no PyTorch kernel between here and the end of the step: memsets, the sum of the two
             # chains' gradients, the loss mean and the optimizer are library launches)
-            hip.check(lib.brv_memset_zero(hip.ptr(grads), 4*grads.numel(), hip.stream()), 'brv_memset_zero')
             main, side = torch.cuda.current_stream(dev), t['side']
             side.wait_stream(main)
             # persistent kernels at 7/8 of the CUs while two chains share the chip (csrc: num_cus) --
@@ -654,6 +653,10 @@ class ConvTasNet(BreverBaseModel):
                         hip.ptr(out), hip.ptr(y), ybs, yss, hip.ptr(ln), nB[h], S, L, L,
                         hip.ptr(t['scratch'][h]), hip.ptr(gscale), hip.ptr(d_out), st),
                         'brv_snr_backward_strided')
+                    if h == 0:
+                        # the first chain's gradient buffer, zeroed behind ITS forward (the other chain's kernels
+                        # fill the chip meanwhile) instead of in the serial section in front of both chains
+                        hip.check(lib.brv_memset_zero(hip.ptr(grads), 4*grads.numel(), st), 'brv_memset_zero')
             sync = self._grad_sync
             nparts = getattr(sync, 'nparts', 1) if sync is not None else 1
             buckets = self.grad_buckets(nparts) if nparts > 1 else [(0, grads.numel())]
