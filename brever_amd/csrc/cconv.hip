@@ -20,6 +20,8 @@
 // for the transposed form with M <= 128, a pair form (both output rows of a pair from the three input rows they
 // share) are selected per launch shape in cconv_launch; workgroups are dealt to the 8 XCDs in contiguous runs.
 // Weight gradient: cconv_wgrad_kernel below. Measurements and what was tried: DESIGN.md 5b.
+#include <string.h>
+
 #include "common.cuh"
 #include "../../include/brever_hip.h"
 
@@ -79,6 +81,48 @@ __global__ __launch_bounds__(256) void cconv_pack_kernel(const float* wc, uint4*
     v[k] = (m < M && c < C) ? wc[m*sm + c*sk + 2*i + j] : 0.f;
   }
   wp[e] = pack8(v);
+}
+
+// One launch for everything a complex layer's forward AND backward need of its weights (three launches in front of
+// every forward and one in front of every data gradient before -- 44 one-wave-sized launches per DCCRN step,
+// profiles/r05_dccrn_trace.txt): the real matrix wc (2R x 2C) = [[wr, -s wi], [s wi, wr]] of
+// brv_complex_weight_pack, the bias [br - bi | br + bi] of brv_complex_bias_pack, and the operand fragments of
+// brv_cconv_pack for up to two (M, C, m_stride, c_stride) readings of wc, built from wr / wi directly.
+struct CPackJob { uint4* wp; int M, C, ncc; unsigned int sm, sk, total; };
+struct CPackAllParams {
+  const float* wr; const float* wi; const float* br; const float* bi;
+  float* wc; float* bias; int R, C, Cb; float s;
+  CPackJob job[2];
+};
+__device__ __forceinline__ float cpack_wc(const CPackAllParams& p, unsigned int idx) {
+  const unsigned int ld = 2u*p.C;
+  const unsigned int row = idx / ld, col = idx - row*ld;
+  const unsigned int r = row >= (unsigned)p.R ? row - p.R : row, c = col >= (unsigned)p.C ? col - p.C : col;
+  const bool lower = row >= (unsigned)p.R, right = col >= (unsigned)p.C;
+  const unsigned int src = r*p.C + c;
+  return lower == right ? p.wr[src] : (right ? -p.s : p.s)*p.wi[src];
+}
+__global__ __launch_bounds__(256) void cconv_pack_all_kernel(const CPackAllParams p) {
+  const unsigned int e = blockIdx.x*256u + threadIdx.x;
+  if (e < 4u*p.R*p.C) p.wc[e] = cpack_wc(p, e);
+  if (e < (unsigned)p.Cb) { p.bias[e] = p.br[e] - p.bi[e]; p.bias[p.Cb + e] = p.br[e] + p.bi[e]; }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const CPackJob& j = p.job[q];
+    if (!j.wp || e >= j.total) continue;
+    const unsigned int lane = e & 63u;
+    unsigned int t = e >> 6;
+    const unsigned int i = t % CC_KH; t /= CC_KH;
+    const unsigned int cc = t % (unsigned)j.ncc, mf = t / (unsigned)j.ncc;
+    const unsigned int m = 32u*mf + (lane & 31u), jj = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned int c = 8u*cc + k;
+      v[k] = (m < (unsigned)j.M && c < (unsigned)j.C) ? cpack_wc(p, m*j.sm + c*j.sk + 2u*i + jj) : 0.f;
+    }
+    j.wp[e] = pack8(v);
+  }
 }
 
 template <int MF, int NF, int WM, int WN, int NTAP, bool SEG>
@@ -726,6 +770,35 @@ int brv_cconv_pack(const float* wc, void* wp, int64_t M, int64_t C, int64_t m_st
   const long long total = ((M + 31)/32)*(long long)ncc*CC_KH*64;
   hipLaunchKernelGGL(cconv_pack_kernel, dim3((unsigned)((total + 255)/256)), dim3(256), 0, (hipStream_t)stream,
                      wc, (uint4*)wp, (int)M, (int)C, (long long)m_stride, (long long)c_stride, ncc, total);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+int brv_cconv_pack_complex(const float* wr, const float* wi, const float* br, const float* bi, int64_t R, int64_t C,
+                           int64_t Cb, float sign, float* wc, float* bias, void* wp1, int64_t M1, int64_t C1,
+                           int64_t m_stride1, int64_t c_stride1, void* wp2, int64_t M2, int64_t C2,
+                           int64_t m_stride2, int64_t c_stride2, brv_stream_t stream) {
+  if (!wr || !wi || !br || !bi || !wc || !bias || !wp1 || R < 1 || C < 1 || Cb < 1 || M1 < 1 || C1 < 1) return -1;
+  if (wp2 && (M2 < 1 || C2 < 1)) return -1;
+  if (4*R*C >= (1LL << 31)) return -1;
+  CPackAllParams p; memset(&p, 0, sizeof(p));
+  p.wr = wr; p.wi = wi; p.br = br; p.bi = bi; p.wc = wc; p.bias = bias;
+  p.R = (int)R; p.C = (int)C; p.Cb = (int)Cb; p.s = sign;
+  long long most = 4*R*C > Cb ? 4*R*C : Cb;
+  const int64_t Ms[2] = {M1, M2}, Cs[2] = {C1, C2}, sm[2] = {m_stride1, m_stride2}, sk[2] = {c_stride1, c_stride2};
+  void* wps[2] = {wp1, wp2};
+  for (int q = 0; q < 2; ++q) {
+    if (!wps[q]) continue;
+    // every index the job forms stays inside wc
+    if ((Ms[q] - 1)*sm[q] + (Cs[q] - 1)*sk[q] + 2*(CC_KH - 1) + 1 >= 4*R*C) return -1;
+    CPackJob& j = p.job[q];
+    j.wp = (uint4*)wps[q]; j.M = (int)Ms[q]; j.C = (int)Cs[q]; j.ncc = (int)((Cs[q] + 7)/8);
+    j.sm = (unsigned int)sm[q]; j.sk = (unsigned int)sk[q];
+    const long long total = ((Ms[q] + 31)/32)*(long long)j.ncc*CC_KH*64;
+    if (total >= (1LL << 31)) return -1;
+    j.total = (unsigned int)total;
+    if (total > most) most = total;
+  }
+  hipLaunchKernelGGL(cconv_pack_all_kernel, dim3((unsigned)((most + 255)/256)), dim3(256), 0, (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

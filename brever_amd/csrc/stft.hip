@@ -1031,7 +1031,11 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
     if (ksplit < 1) ksplit = 1;
   }
   if (ksplit > 1 && !accumulate) {
-    if (ldd == N) {
+    if (ldd == N && (batch == 1 || d_batch_stride == M*N)) {
+      // (one fill for a contiguous batch: sixteen 5-us fills in a row stood in front of the LSTM weight-gradient
+      // products of the DCCRN step -- profiles/r05_dccrn_trace.txt)
+      if (hipMemsetAsync(d, 0, (size_t)batch*M*N*4, st) != hipSuccess) return -2;
+    } else if (ldd == N) {
       for (int64_t z = 0; z < batch; ++z)
         if (hipMemsetAsync(d + z*d_batch_stride, 0, (size_t)M*N*4, st) != hipSuccess) return -2;
     } else {

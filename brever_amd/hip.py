@@ -264,6 +264,8 @@ SIGNATURES = {
     'brv_complex_bias_unpack': (ctypes.c_int, [_c_ptr]*3 + [_c_i64, _c_ptr]),
     'brv_cconv_packed_bytes': (_c_i64, [_c_i64, _c_i64]),
     'brv_cconv_pack': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*4 + [_c_ptr]),
+    'brv_cconv_pack_complex': (ctypes.c_int, [_c_ptr]*4 + [_c_i64]*3 + [_c_f32] + [_c_ptr]*3 + [_c_i64]*4 + [_c_ptr]
+                               + [_c_i64]*4 + [_c_ptr]),
     'brv_cconv_rows': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_i64]*6
                        + [ctypes.c_int32, _c_ptr]),
     'brv_cconv_wgrad_workspace_bytes': (_c_i64, [_c_i64]*4),

@@ -172,7 +172,7 @@ _ROWS = os.environ.get('BRV_DCCRN_ROWS', '1') != '0'      # use_amp: one-launch 
 _ROWS_GEOM = ((5, 2), (2, 1), (2, 0), (1, 0))
 
 
-def _cconv_rows(x, wc, bias, M, m_stride, c_stride, transposed, x2=None, split_out=False):
+def _cconv_rows(x, wc, bias, M, m_stride, c_stride, transposed, x2=None, split_out=False, wp=None):
     """``brv_cconv_rows``: the (5, 2) / (2, 1) / (2, 0) convolution (``transposed`` = 0) or transposed
     convolution (1) of ``x`` (B, C, H, W) with W[m][c][i][j] = wc.flat[m*m_stride + c*c_stride + 2i + j].
     ``x2``: the input is the skip concatenation [x[:, :s], x2[:, :s], x[:, s:], x2[:, s:]] read from its two
@@ -183,9 +183,10 @@ def _cconv_rows(x, wc, bias, M, m_stride, c_stride, transposed, x2=None, split_o
     if x2 is not None:
         assert x2.shape == x.shape and C % 16 == 0
         seg, C = C//2, 2*C
-    wp = torch.empty(lib.brv_cconv_packed_bytes(M, C), dtype=torch.uint8, device=x.device)
-    hip.check(lib.brv_cconv_pack(hip.ptr(wc), hip.ptr(wp), M, C, m_stride, c_stride, hip.stream()),
-              'brv_cconv_pack')
+    if wp is None:       # (``wp``: the fragments of this reading of ``wc``, packed already -- _pack_complex_layer)
+        wp = torch.empty(lib.brv_cconv_packed_bytes(M, C), dtype=torch.uint8, device=x.device)
+        hip.check(lib.brv_cconv_pack(hip.ptr(wc), hip.ptr(wp), M, C, m_stride, c_stride, hip.stream()),
+                  'brv_cconv_pack')
     shape = (B, M//2 if split_out else M) + ((2*H, W + 1) if transposed else (H//2, W - 1))
     out = torch.empty(shape, dtype=torch.float32, device=x.device)
     out2 = torch.empty_like(out) if split_out else None
@@ -193,6 +194,24 @@ def _cconv_rows(x, wc, bias, M, m_stride, c_stride, transposed, x2=None, split_o
                                  hip.ptr(out2), M//4 if split_out else 0, B, C, M, H, W, int(transposed),
                                  hip.stream()), 'brv_cconv_rows')
     return (out, out2) if split_out else out
+
+
+def _pack_complex_layer(wr, wi, br, bi, sign, fwd, bwd):
+    """One launch (``brv_cconv_pack_complex``) for the packed real matrix, the packed bias and the operand fragments of
+    the forward reading ``fwd`` = (M, C, m_stride, c_stride) of it and, if asked for, the data gradient's ``bwd``."""
+    lib = hip.lib()
+    R, Cw = wr.shape[0], wr[0].numel()
+    dev = wr.device
+    wc = torch.empty(2*R, 2*Cw, dtype=torch.float32, device=dev)
+    bias = torch.empty(2*br.numel(), dtype=torch.float32, device=dev)
+    wp1 = torch.empty(lib.brv_cconv_packed_bytes(fwd[0], fwd[1]), dtype=torch.uint8, device=dev)
+    wp2 = torch.empty(lib.brv_cconv_packed_bytes(bwd[0], bwd[1]), dtype=torch.uint8, device=dev) if bwd else None
+    wr_c, wi_c, br_c, bi_c = wr.contiguous(), wi.contiguous(), br.contiguous(), bi.contiguous()
+    hip.check(lib.brv_cconv_pack_complex(
+        hip.ptr(wr_c), hip.ptr(wi_c), hip.ptr(br_c), hip.ptr(bi_c), R, Cw, br.numel(), float(sign), hip.ptr(wc),
+        hip.ptr(bias), hip.ptr(wp1), *fwd, hip.ptr(wp2), *(bwd or (0, 0, 0, 0)), hip.stream()),
+        'brv_cconv_pack_complex')
+    return wc, bias, wp1, wp2
 
 
 def _cconv_wgrad(small, big, small2=None):
@@ -312,24 +331,32 @@ class _ComplexConvFunction(torch.autograd.Function):
         Cin = C2//2
         R = wr.shape[0]
         Cw = wr[0].numel()
-        wc = torch.empty(2*R, 2*Cw, dtype=torch.float32, device=x.device)
-        wr_c, wi_c = wr.contiguous(), wi.contiguous()      # alive until the launch is queued
-        hip.check(lib.brv_complex_weight_pack(hip.ptr(wr_c), hip.ptr(wi_c),
-                                              hip.ptr(wc), R, Cw, -1.0 if transpose else 1.0,
-                                              hip.stream()), 'brv_complex_weight_pack')
-        bias = torch.empty(2*br.numel(), dtype=torch.float32, device=x.device)
-        br_c, bi_c = br.contiguous(), bi.contiguous()
-        hip.check(lib.brv_complex_bias_pack(hip.ptr(br_c), hip.ptr(bi_c), hip.ptr(bias), br.numel(), hip.stream()),
-                  'brv_complex_bias_pack')
         khw = kh*kw
+        ctx.wp_bwd = None
+        if rows:
+            # packed matrix, bias, and the fragments of both readings of the matrix (this forward's, the data
+            # gradient's) in one launch; the data gradient's only if something upstream wants it
+            Cout = wr.shape[1] if transpose else R
+            need_dx = ctx.needs_input_grad[0] or (skip is not None and ctx.needs_input_grad[7]) or bool(ctx.seg)
+            fwd = (2*Cout, C2, khw, 2*Cw) if transpose else (2*Cout, C2, 2*Cw, khw)
+            bwd = ((2*Cin, 2*Cout, 2*Cw, khw) if transpose else (2*Cin, 2*Cout, khw, 2*Cw)) if need_dx else None
+            wc, bias, wp_fwd, ctx.wp_bwd = _pack_complex_layer(wr, wi, br, bi, -1.0 if transpose else 1.0, fwd, bwd)
+        else:
+            wc = torch.empty(2*R, 2*Cw, dtype=torch.float32, device=x.device)
+            wr_c, wi_c = wr.contiguous(), wi.contiguous()      # alive until the launch is queued
+            hip.check(lib.brv_complex_weight_pack(hip.ptr(wr_c), hip.ptr(wi_c),
+                                                  hip.ptr(wc), R, Cw, -1.0 if transpose else 1.0,
+                                                  hip.stream()), 'brv_complex_weight_pack')
+            bias = torch.empty(2*br.numel(), dtype=torch.float32, device=x.device)
+            br_c, bi_c = br.contiguous(), bi.contiguous()
+            hip.check(lib.brv_complex_bias_pack(hip.ptr(br_c), hip.ptr(bi_c), hip.ptr(bias), br.numel(),
+                                                hip.stream()), 'brv_complex_bias_pack')
         if rows and not transpose:
-            Cout = R
             Ho, Wo = H//2, W - 1
-            y = _cconv_rows(x, wc, bias, 2*Cout, 2*Cw, khw, 0)
+            y = _cconv_rows(x, wc, bias, 2*Cout, 2*Cw, khw, 0, wp=wp_fwd)
         elif rows:
-            Cout = wr.shape[1]
             Ho, Wo = 2*H, W + 1
-            y = _cconv_rows(x, wc, bias, 2*Cout, khw, 2*Cw, 1, x2=skip)
+            y = _cconv_rows(x, wc, bias, 2*Cout, khw, 2*Cw, 1, x2=skip, wp=wp_fwd)
         elif not transpose and lowp and _IMPLICIT:
             # the column matrix of x is read in place (brv_gemm_bf16_conv): no im2col pass, no 10x copy
             Cout = R
@@ -414,11 +441,11 @@ class _ComplexConvFunction(torch.autograd.Function):
             if not need_dx:
                 pass
             elif transpose:
-                dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0, split_out=ctx.two)
+                dx = _cconv_rows(dy, wc, None, 2*Cin, 2*Cw, khw, 0, split_out=ctx.two, wp=ctx.wp_bwd)
                 if ctx.two:
                     dx, dskip = dx
             else:
-                dx = _cconv_rows(dy, wc, None, 2*Cin, khw, 2*Cw, 1)
+                dx = _cconv_rows(dy, wc, None, 2*Cin, khw, 2*Cw, 1, wp=ctx.wp_bwd)
             if side is None:
                 dwr, dwi, dbr, dbi = param_grads()
             else:
@@ -509,6 +536,18 @@ class _ForkFunction(torch.autograd.Function):
         return _combine(g1.contiguous(), g2.contiguous(), 1.0)
 
 
+# nn.BatchNorm2d.num_batches_tracked of the layers a training forward has passed: one multi-tensor add at the end of the
+# mask network instead of a one-element launch per layer (eleven in the default network)
+_BN_COUNTERS = []
+
+
+def _flush_bn_counters():
+    if _BN_COUNTERS:
+        with torch.no_grad():
+            torch._foreach_add_(list(_BN_COUNTERS), 1)
+        _BN_COUNTERS.clear()
+
+
 class _BatchNormActFunction(torch.autograd.Function):
     """nn.BatchNorm2d followed by an optional scalar nn.PReLU (dccrn.py:251-254, 284-289)."""
 
@@ -525,7 +564,7 @@ class _BatchNormActFunction(torch.autograd.Function):
             B, C, H*W, float(norm.eps), float(norm.momentum), int(training), hip.stream()),
             'brv_batchnorm2d_forward')
         if training:
-            norm.num_batches_tracked += 1
+            _BN_COUNTERS.append(norm.num_batches_tracked)      # (+= 1 for all layers in one launch: _flush_bn_counters)
         ctx.save_for_backward(x, gamma, beta, slope if slope is not None else gamma.new_zeros(0),
                               mean, invstd)
         ctx.training = training
@@ -731,10 +770,9 @@ class _LSTMFunction(torch.autograd.Function):
         # and a 16 MB copy in front of every product; the chains are the k-batches of the product instead)
         dw_hh = torch.zeros_like(w_hh) if T == 1 else torch.empty_like(w_hh)
         if T > 1:
-            flat_dg, flat_y = dg.view(G, -1), y.view(G, -1)
-            for g in range(G):
-                _gemm(flat_dg[g, 4*H:], flat_y[g], dw_hh[g], 1, 4*H, H, T - 1, 4*H, H, H, 0, 0, 0, trans_a=1,
-                      kbatch=B, a_kbs=T*4*H, b_kbs=T*H, lowp=lowp)
+            # (one launch: the groups are the batch, the chains of a group the k-batches)
+            _gemm(dg.view(-1)[4*H:], y, dw_hh, G, 4*H, H, T - 1, 4*H, H, H, B*T*4*H, B*T*H, 4*H*H, trans_a=1,
+                  kbatch=B, a_kbs=T*4*H, b_kbs=T*H, lowp=lowp)
         # bias gradients: column sums of dg (BT, 4H) per group, in a fixed order (no transposed copy)
         db = torch.empty(G, 4*H, dtype=torch.float32, device=x.device)
         scratch = torch.empty(lib.brv_col_sum_scratch_bytes(G, 4*H), dtype=torch.uint8, device=x.device)
@@ -855,6 +893,7 @@ class DCCRN(BreverBaseModel):
             # a backward pass that raised never ran its end-of-pass callback: the "join queued" mark of this device must
             # not survive into the next pass, or that pass would queue no join at all
             _side['pending'][x.device.index] = False
+        _BN_COUNTERS.clear()                          # (a forward that raised: its counts are dropped)
         encoder_outputs = []
         for blk in net.encoder:
             x = self._norm_act(self._complex_conv(x, blk.conv, False), blk.norm, blk.activation)
@@ -867,6 +906,7 @@ class DCCRN(BreverBaseModel):
             # torch.cat([real, skip_real, imag, skip_imag], dim=1) (dccrn.py:213-217) inside the function
             x = self._complex_conv(x, blk.conv, True, skip=enc)
             x = self._norm_act(x, blk.norm, blk.activation)
+        _flush_bn_counters()
         return x
 
     def forward(self, x):

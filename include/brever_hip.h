@@ -351,6 +351,13 @@ int brv_gemm_bf16_conv(const float* a, const float* image, float* d, int64_t bat
 int64_t brv_cconv_packed_bytes(int64_t M, int64_t C);
 int brv_cconv_pack(const float* wc, void* wp, int64_t M, int64_t C, int64_t m_stride, int64_t c_stride,
                    brv_stream_t stream);
+/* brv_complex_weight_pack + brv_complex_bias_pack + up to two brv_cconv_pack readings of the packed matrix (the
+ * forward's and the data gradient's) in ONE launch: wc (2R x 2C), bias (2 Cb), wp1 (M1, C1, strides) and, when wp2 is
+ * not NULL, wp2 (M2, C2, strides) -- the same values the separate calls produce. */
+int brv_cconv_pack_complex(const float* wr, const float* wi, const float* br, const float* bi, int64_t R, int64_t C,
+                           int64_t Cb, float sign, float* wc, float* bias, void* wp1, int64_t M1, int64_t C1,
+                           int64_t m_stride1, int64_t c_stride1, void* wp2, int64_t M2, int64_t C2,
+                           int64_t m_stride2, int64_t c_stride2, brv_stream_t stream);
 /* in_seg > 0: the input is the channel concatenation [in[:, :seg], in2[:, :seg], in[:, seg:], in2[:, seg:]] of two
  * (B, 2 seg, Hin, Win) tensors (the decoder's skip concatenation torch.cat([real, skip_real, imag, skip_imag]),
  * dccrn.py:213-217, never materialised), C = 4 seg, seg a multiple of 8; out_seg > 0: the output channels are dealt
