@@ -612,7 +612,8 @@ __global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(const float* act, co
   };
   // wait until at most N vector-memory operations are outstanding; releases the 7 values of `v`
   auto wait16 = [](Saved& v) {
-    asm volatile("s_waitcnt vmcnt(16)" : "+v"(v.ig), "+v"(v.fg), "+v"(v.gg), "+v"(v.og), "+v"(v.c), "+v"(v.cp),
+    // (14, not 16: the two younger stores may retire ahead of older loads -- see lstm_fwd_mv_kernel)
+    asm volatile("s_waitcnt vmcnt(14)" : "+v"(v.ig), "+v"(v.fg), "+v"(v.gg), "+v"(v.og), "+v"(v.c), "+v"(v.cp),
                  "+v"(v.dy) :: "memory");
   };
   // Three register sets take the roles (this step, next step, being fetched) in turn -- the loop is unrolled
@@ -650,6 +651,207 @@ __global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(const float* act, co
     sc = fetch(t - 2); step(sa, t); if (--t < 0) break;
     sa = fetch(t - 2); step(sb, t); if (--t < 0) break;
     sb = fetch(t - 2); step(sc, t); --t;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- matrix-pipe layout (H == 128, use_amp): the step's matrix-vector product on the bf16 MFMA -------------------
+// The quad kernels above spend a step on 128 fp32 FMAs and 8 (forward) / 32 (backward) 16-byte LDS reads PER THREAD:
+// 0.94 us per step either way, 4 x 0.47 ms of a DCCRN training step. Under use_amp the recurrent product may run on
+// bf16 operands like every other product of that path (the reference's autocast hands nn.LSTM bf16 weights and a
+// bf16 hidden state); accumulation, gate math, cell state and every tensor in HBM stay fp32. One workgroup per
+// chain as before; lane (j = lane >> 4, n = lane & 15) of wave w owns hidden unit u = 16 w + n.
+//   forward : D (16 x 16) = A (16 x 32) B (32 x 16), v_mfma_f32_16x16x32_bf16, with A = h (every row the same
+//             vector: a lane reads the 8 values k = 32 kq + 8 j .. from LDS), B[k][n] = W_hh[g H + u][k] kept in
+//             registers (4 gates x 4 k-steps = 64 VGPRs): 16 instructions per wave and step; every lane then holds
+//             the four gate pre-activations of its unit in register 0 of the four accumulators;
+//   backward: A = the gate gradients of step t + 1 (K = 4 H: 16 k-steps), B[k][n] = W_hh[k][u] (64 VGPRs);
+//             lane j computes gate j's gradient of its unit.
+// Only the A rows m = 0, 4, 8, 12 are loaded (lanes with n % 4 == 0; the other rows are zero): row 4 j is the one
+// whose result register 0 of lane group j holds, and a 16-byte LDS read costs by the lanes that take part.
+// The per-step global loads are invisible to hipcc's wait insertion (load_untracked above) and requested THREE steps
+// ahead into four register sets in rotation; the kernels wait with a counted vmcnt -- loads and stores per step are
+// fixed in number and order.
+__device__ __forceinline__ bf16x8 lstm_frag8(const float* p, long long stride) {
+  uint4 q;
+  q.x = pack2(p[0], p[stride]); q.y = pack2(p[2*stride], p[3*stride]);
+  q.z = pack2(p[4*stride], p[5*stride]); q.w = pack2(p[6*stride], p[7*stride]);
+  return __builtin_bit_cast(bf16x8, q);
+}
+#ifndef LSTM_MV_MASK
+#define LSTM_MV_MASK 1
+#endif
+// A fragments straight from LDS: NR 16-byte reads 64 bytes apart and one wait, as inline assembly under the lanes'
+// own branch (written as a select, hipcc turned `take ? *p : 0` into a FLAT load through a pointer that is either
+// the LDS address or a zeroed scratch slot, with a full vmcnt(0) lgkmcnt(0) wait per fragment)
+__device__ __forceinline__ unsigned int lstm_lds_addr(const void* p) { return (unsigned int)(unsigned long long)p; }
+__device__ __forceinline__ void lstm_read4(unsigned int a, u32x4 (&q)[4]) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %4 offset:128\n\t"
+               "ds_read_b128 %3, %4 offset:192\n\ts_waitcnt lgkmcnt(0)"
+               : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "v"(a) : "memory");
+}
+template <bool HAS_ACT>
+__global__ __launch_bounds__(512) void lstm_fwd_mv_kernel(const float* gates_in, const float* w_hh,
+                                                          const float* bias, float* y, float* act,
+                                                          float* cs, int T, int per_group) {
+  constexpr int H = 128;
+  __shared__ __attribute__((aligned(16))) uint16_t hb[2][H];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, j = lane >> 4, u = 16*w + n;
+  const bool take = (n & 3) == 0;
+  w_hh += (long long)(b / per_group)*4*H*H;
+  if (bias) bias += (long long)(b / per_group)*4*H;
+  bf16x8 wf[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) wf[g][kq] = lstm_frag8(w_hh + (long long)(g*H + u)*H + 32*kq + 8*j, 1);
+  float bq[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bq[g] = bias ? bias[g*H + u] : 0.f;
+  if (tid < 2*H) (&hb[0][0])[tid] = 0;
+  float c = 0.f;
+  const float* gi = gates_in + (long long)b*T*4*H + u;
+  struct In { float g0, g1, g2, g3; };
+  auto fetch = [&](int t) {
+    const float* p = gi + (long long)(t < T ? t : T - 1)*4*H;
+    In v;
+    v.g0 = load_untracked(p); v.g1 = load_untracked(p + H); v.g2 = load_untracked(p + 2*H);
+    v.g3 = load_untracked(p + 3*H);
+    return v;
+  };
+  // per step, in order: 4 loads (step t + 3), then 1 + 2 HAS_ACT stores; the set of step t was requested three
+  // steps ago, 12 loads and 3 or 9 stores are younger. Loads return in order among themselves, but a store may retire
+  // ahead of an older load: only the 12 younger LOADS are allowed to be outstanding (counting the stores too --
+  // vmcnt(21) -- let a step start on values still in flight when the side stream's products kept HBM busy: one
+  // wrong gradient in a few runs)
+  auto wait_set = [](In& v) {
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(v.g0), "+v"(v.g1), "+v"(v.g2), "+v"(v.g3) :: "memory");
+  };
+  auto step = [&](In& cur, int t) {
+    wait_set(cur);
+    u32x4 aq[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) aq[kq] = u32x4{0u, 0u, 0u, 0u};
+    if (!LSTM_MV_MASK || take) lstm_read4(lstm_lds_addr(hb[t & 1] + 8*j), aq);
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // two gates at a time: the first pair's exponentials run beside the second pair's products
+#pragma unroll
+    for (int gp = 0; gp < 4; gp += 2)
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, aq[kq]);
+        acc[gp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[gp][kq], acc[gp], 0, 0, 0);
+        acc[gp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[gp + 1][kq], acc[gp + 1], 0, 0, 0);
+      }
+    const float ig = fast_sigm(acc[0][0] + cur.g0 + bq[0]), fg = fast_sigm(acc[1][0] + cur.g1 + bq[1]);
+    const float gg = fast_tanh(acc[2][0] + cur.g2 + bq[2]), og = fast_sigm(acc[3][0] + cur.g3 + bq[3]);
+    c = fg*c + ig*gg;
+    const float hn = og*fast_tanh(c);
+    if (j == 0) hb[(t + 1) & 1][u] = f2bf(hn);
+    const long long row = (long long)b*T + t;
+    // exactly 1 + 2 HAS_ACT store instructions per step (the counted wait relies on it): lane group 0 stores y,
+    // group 1 the cell state, group j gate j's activation
+    if (j == 0) y[row*H + u] = hn;
+    if (HAS_ACT) {
+      if (j == 1) cs[row*H + u] = c;
+      act[row*4*H + j*H + u] = j == 0 ? ig : j == 1 ? fg : j == 2 ? gg : og;
+    }
+    lds_barrier();
+  };
+  In s0 = fetch(0), s1 = fetch(1), s2 = fetch(2), s3;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the counted wait needs full queues behind it)
+  __syncthreads();
+  int t = 0;
+  while (true) {
+    s3 = fetch(t + 3); step(s0, t); if (++t >= T) break;
+    s0 = fetch(t + 3); step(s1, t); if (++t >= T) break;
+    s1 = fetch(t + 3); step(s2, t); if (++t >= T) break;
+    s2 = fetch(t + 3); step(s3, t); if (++t >= T) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void lstm_bwd_mv_kernel(const float* act, const float* cs, const float* w_hh,
+                                                          const float* dy, float* dgates, int T, int per_group) {
+  constexpr int H = 128, K = 4*H;
+  // The reduction (K = 4 H) is SPLIT over the eight waves: wave w multiplies the 64 gradients k = 64 w .. against all
+  // 128 units (8 column blocks x 2 k-steps = 16 instructions, two 16-byte LDS reads) and the eight partial sums of
+  // a unit meet through LDS. (Every wave reducing the whole K for its own 16 units read the complete gradient
+  // vector per wave -- sixteen 16-byte reads per lane and step, 1024 LDS clocks per step whether or not lanes were
+  // masked off: 0.88 us per step, as slow as the fp32 kernel.)
+  __shared__ __attribute__((aligned(16))) uint16_t dgb[2][K];      // bf16 gate gradients, k = q H + i
+  __shared__ float part[8][H];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, q = lane >> 4, u = 16*w + n;            // this lane: gate q of unit u
+  w_hh += (long long)(b / per_group)*4*H*H;
+  bf16x8 wf[8][2];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      wf[nb][ks] = lstm_frag8(w_hh + (long long)(64*w + 32*ks + 8*q)*H + 16*nb + n, H);
+  (&dgb[0][0])[tid] = 0; (&dgb[0][0])[tid + 512] = 0;
+  float dc = 0.f;
+  struct Saved { float ig, fg, gg, og, c, cp, dy; };
+  auto fetch = [&](int t) {
+    const int tt = t > 0 ? t : 0;
+    const float* a = act + ((long long)b*T + tt)*4*H + u;
+    Saved v;
+    v.ig = load_untracked(a); v.fg = load_untracked(a + H); v.gg = load_untracked(a + 2*H);
+    v.og = load_untracked(a + 3*H);
+    v.c = load_untracked(cs + ((long long)b*T + tt)*H + u);
+    v.cp = load_untracked(cs + ((long long)b*T + (tt > 0 ? tt - 1 : 0))*H + u);
+    v.dy = load_untracked(dy + ((long long)b*T + tt)*H + u);
+    return v;
+  };
+  // per step: 7 loads (step t - 3), then ONE store; the set of step t was requested three steps ago: 21 younger
+  // loads may stay in flight (the 3 younger stores are not counted on: see the forward kernel)
+  auto wait24 = [](Saved& v) {
+    asm volatile("s_waitcnt vmcnt(21)" : "+v"(v.ig), "+v"(v.fg), "+v"(v.gg), "+v"(v.og), "+v"(v.c), "+v"(v.cp),
+                 "+v"(v.dy) :: "memory");
+  };
+  auto step = [&](Saved& cur, int t) {
+    // this wave's slice of the gate gradients of step t + 1 (zeros for the last step)
+    const uint16_t* gp = dgb[(t + 1) & 1] + 64*w + 8*q;
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(gp), a1 = *reinterpret_cast<const bf16x8*>(gp + 32);
+    f32x4 p[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+      p[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[nb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) p[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[nb][1], p[nb], 0, 0, 0);
+    // every lane group holds all eight blocks (the rows of D are equal): group q hands over blocks 2 q, 2 q + 1
+    const float e0 = q == 0 ? p[0][0] : q == 1 ? p[2][0] : q == 2 ? p[4][0] : p[6][0];
+    const float e1 = q == 0 ? p[1][0] : q == 1 ? p[3][0] : q == 2 ? p[5][0] : p[7][0];
+    part[w][32*q + n] = e0; part[w][32*q + 16 + n] = e1;
+    lds_barrier();
+    wait24(cur);
+    float dht = cur.dy;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dht += part[i][u];
+    const float ig = cur.ig, fg = cur.fg, gg = cur.gg, og = cur.og;
+    const float cprev = t > 0 ? cur.cp : 0.f;
+    const float tc = fast_tanh(cur.c);
+    const float dct = dc + dht*og*(1.f - tc*tc);
+    const float dq = q == 0 ? dct*gg*ig*(1.f - ig) : q == 1 ? dct*cprev*fg*(1.f - fg)
+                   : q == 2 ? dct*ig*(1.f - gg*gg) : dht*tc*og*(1.f - og);
+    dgb[t & 1][q*H + u] = f2bf(dq);
+    dgates[((long long)b*T + t)*4*H + q*H + u] = dq;
+    dc = dct*fg;
+    lds_barrier();
+  };
+  Saved s0 = fetch(T - 1), s1 = fetch(T - 2), s2 = fetch(T - 3), s3;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int t = T - 1;
+  while (true) {
+    s3 = fetch(t - 3); step(s0, t); if (--t < 0) break;
+    s0 = fetch(t - 3); step(s1, t); if (--t < 0) break;
+    s1 = fetch(t - 3); step(s2, t); if (--t < 0) break;
+    s2 = fetch(t - 3); step(s3, t); if (--t < 0) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1156,6 +1358,35 @@ int brv_lstm_recurrent_forward(const float* gates_in, const float* w_hh, const f
   DC_OK(hipGetLastError());
   return 0;
 }
+
+int brv_lstm_recurrent_forward_bf16(const float* gates_in, const float* w_hh, const float* bias,
+                                    float* y, float* act, float* cs, int64_t B, int64_t T, int64_t H,
+                                    int64_t groups, brv_stream_t stream) {
+  if (B < 1 || T < 1 || groups < 1 || B % groups) return -1;
+  if (H != 128) return -1;                               // (brv_lstm_recurrent_bf16_supported)
+  const int per_group = (int)(B/groups);
+  if (act && cs)
+    hipLaunchKernelGGL(lstm_fwd_mv_kernel<true>, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream,
+                       gates_in, w_hh, bias, y, act, cs, (int)T, per_group);
+  else
+    hipLaunchKernelGGL(lstm_fwd_mv_kernel<false>, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream,
+                       gates_in, w_hh, bias, y, act, cs, (int)T, per_group);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_lstm_recurrent_backward_bf16(const float* act, const float* cs, const float* w_hh,
+                                     const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
+                                     int64_t groups, brv_stream_t stream) {
+  if (B < 1 || T < 1 || groups < 1 || B % groups) return -1;
+  if (H != 128) return -1;
+  hipLaunchKernelGGL(lstm_bwd_mv_kernel, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, act, cs,
+                     w_hh, dy, dgates, (int)T, (int)(B/groups));
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_lstm_recurrent_bf16_supported(int64_t H) { return H == 128; }
 
 int brv_combine(const float* a, const float* b, float* out, int64_t n, float sign,
                 brv_stream_t stream) {

@@ -205,6 +205,9 @@ SIGNATURES = {
                          + [ctypes.c_int, _c_f32, _c_ptr]),
     'brv_batchnorm2d_backward': (ctypes.c_int, [_c_ptr]*11 + [_c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_lstm_recurrent_backward': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*4 + [_c_ptr]),
+    'brv_lstm_recurrent_bf16_supported': (ctypes.c_int, [_c_i64]),
+    'brv_lstm_recurrent_forward_bf16': (ctypes.c_int, [_c_ptr]*6 + [_c_i64]*4 + [_c_ptr]),
+    'brv_lstm_recurrent_backward_bf16': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*4 + [_c_ptr]),
     'brv_lstm_tile_supported': (ctypes.c_int, [_c_i64]),
     'brv_lstm_tile_forward': (ctypes.c_int, [_c_ptr]*6 + [_c_i64]*7 + [ctypes.c_int, _c_ptr]),
     'brv_lstm_tile_backward': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*7 + [ctypes.c_int, _c_ptr]),

@@ -233,6 +233,8 @@ def _cconv_wgrad(small, big, small2=None):
 # the input depends on them, and the backward pass has a long stretch -- the recurrences' BPTT, 64 chains = a quarter
 # of the CUs for 0.9 ms -- that the decoder's weight gradients fill. BRV_DCCRN_WGRAD_SIDE=0: everything in order.
 _WGRAD_SIDE = os.environ.get('BRV_DCCRN_WGRAD_SIDE', '1') != '0'
+# BRV_LSTM_MV=0: the fp32 recurrence kernels under use_amp too (round 4)
+_LSTM_MV = os.environ.get('BRV_LSTM_MV', '1') != '0'
 _side = {'streams': {}, 'pending': {}}     # both keyed by device index
 
 
@@ -695,6 +697,9 @@ class _LSTMFunction(torch.autograd.Function):
     all G*B chains concurrently, one workgroup each."""
 
     TILE_MIN_CHAINS = 256       # below this the one-chain-per-workgroup kernels have more parallelism
+    # use_amp: the tile kernels multiply on the bf16 MFMA (a step of 16 chains = 16 instructions per wave); DCCRN's 64
+    # long chains then run as 4 workgroups
+    TILE_MIN_CHAINS_LOWP = int(os.environ.get('BRV_LSTM_TILE_MIN_LOWP', '256'))
 
     @staticmethod
     def _interleave(w, H):
@@ -722,7 +727,7 @@ class _LSTMFunction(torch.autograd.Function):
         # many short chains (TF-GridNet): 16 chains per workgroup on the exact-fp32 MFMA, gates
         # interleaved; few long chains (DCCRN): one workgroup per chain
         tiled = ctx.tiled = bool(lib.brv_lstm_tile_supported(H)) and \
-            G*B >= _LSTMFunction.TILE_MIN_CHAINS
+            G*B >= (_LSTMFunction.TILE_MIN_CHAINS_LOWP if lowp else _LSTMFunction.TILE_MIN_CHAINS)
         if tiled:
             w_ih = _LSTMFunction._interleave(w_ih, H)
         gates = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
@@ -732,7 +737,10 @@ class _LSTMFunction(torch.autograd.Function):
         y = torch.empty(G, B, T, H, dtype=torch.float32, device=x.device)
         act = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
         cs = torch.empty(G, B, T, H, dtype=torch.float32, device=x.device)
+        # use_amp, few long chains: the step's matrix-vector product on the bf16 MFMA (csrc/dccrn.hip lstm_*_mv_kernel)
+        mv = ctx.mv = bool(lowp and not tiled and _LSTM_MV and lib.brv_lstm_recurrent_bf16_supported(H))
         fn, name = (lib.brv_lstm_tile_forward, 'brv_lstm_tile_forward') if tiled else \
+            (lib.brv_lstm_recurrent_forward_bf16, 'brv_lstm_recurrent_forward_bf16') if mv else \
             (lib.brv_lstm_recurrent_forward, 'brv_lstm_recurrent_forward')
         extra = (0, H, B*T*H, int(lowp)) if tiled else ()   # no reversed group, (G, B, T, H) output
         hip.check(fn(hip.ptr(gates), hip.ptr(w_hh), hip.ptr(bias), hip.ptr(y), hip.ptr(act),
@@ -753,6 +761,7 @@ class _LSTMFunction(torch.autograd.Function):
         dy = dy.contiguous()
         dg = torch.empty(G, B, T, 4*H, dtype=torch.float32, device=x.device)
         fn, name = (lib.brv_lstm_tile_backward, 'brv_lstm_tile_backward') if ctx.tiled else \
+            (lib.brv_lstm_recurrent_backward_bf16, 'brv_lstm_recurrent_backward_bf16') if ctx.mv else \
             (lib.brv_lstm_recurrent_backward, 'brv_lstm_recurrent_backward')
         extra = (0, H, B*T*H, int(lowp)) if ctx.tiled else ()
         hip.check(fn(hip.ptr(act), hip.ptr(cs), hip.ptr(w_hh), hip.ptr(dy), hip.ptr(dg), G*B, T, H,

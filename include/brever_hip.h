@@ -489,6 +489,17 @@ int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_
 int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* w_hh,
                                 const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
                                 int64_t groups, brv_stream_t stream);
+/* The same recurrences with the step's matrix-vector product on the bf16 MFMA (use_amp: W_hh and the hidden state /
+ * the gate gradients are rounded to bf16 as operands, fp32 accumulation; gate math, cell state and all tensors fp32 --
+ * reference: nn.LSTM under torch.autocast, brever/models/dccrn/dccrn.py:293-311 with training.use_amp). Same arguments
+ * and layouts; H must satisfy brv_lstm_recurrent_bf16_supported (128). */
+int brv_lstm_recurrent_bf16_supported(int64_t H);
+int brv_lstm_recurrent_forward_bf16(const float* gates_in, const float* w_hh, const float* bias,
+                                    float* y, float* act, float* cs, int64_t B, int64_t T, int64_t H,
+                                    int64_t groups, brv_stream_t stream);
+int brv_lstm_recurrent_backward_bf16(const float* act, const float* cs, const float* w_hh,
+                                     const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
+                                     int64_t groups, brv_stream_t stream);
 int brv_dccrn_apply_mask_backward(const float* xr, const float* xi, const float* mr,
                                   const float* mi, const float* gout, float* dmr, float* dmi,
                                   int64_t n, brv_stream_t stream);

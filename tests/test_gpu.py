@@ -1714,6 +1714,77 @@ def test_lstm_kernels_match_torch(H):
 
 
 @pytest.mark.gpu
+def test_lstm_bf16_matrix_pipe_recurrence_matches_rounded_operand_loop():
+    """use_amp, H = 128, few long chains: the recurrence whose step runs on the bf16 MFMA (csrc/dccrn.hip
+    lstm_fwd_mv_kernel / lstm_bwd_mv_kernel) vs an fp32 torch loop with the SAME operand rounding -- the hidden state and
+    W_hh rounded to bf16 in the recurrent product, the gate gradients and W_hh in its adjoint (rel-L2 2e-4: summation
+    order and the hardware exp / rcp) -- and vs the fp32 kernels (the bf16 rounding itself: 2e-2). Two parameter
+    groups of three chains, 41 steps."""
+    from brever_amd import hip
+    dev = _cuda()
+    lib = hip.lib()
+    torch.manual_seed(5)
+    G, B, T, H = 2, 3, 41, 128
+    gates = torch.randn(G, B, T, 4*H)
+    w_hh = torch.randn(G, 4*H, H)/H**0.5
+    bias = 0.1*torch.randn(G, 4*H)
+    gy = torch.randn(G, B, T, H)
+
+    def qb(v):
+        return v.to(torch.bfloat16).to(torch.float32)
+
+    # reference loop: forward with rounded operands, saved activations
+    y = torch.zeros(G, B, T, H); act = torch.zeros(G, B, T, 4*H); cs = torch.zeros(G, B, T, H)
+    for g in range(G):
+        h = torch.zeros(B, H); c = torch.zeros(B, H)
+        for t in range(T):
+            pre = gates[g, :, t] + bias[g] + qb(h) @ qb(w_hh[g]).t()
+            i, f, gg, o = pre.chunk(4, dim=-1)
+            i, f, gg, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)
+            c = f*c + i*gg
+            h = o*torch.tanh(c)
+            y[g, :, t] = h; cs[g, :, t] = c; act[g, :, t] = torch.cat([i, f, gg, o], dim=-1)
+    # ... and the adjoint: gate gradients from the saved activations, dh through the rounded product
+    dg = torch.zeros(G, B, T, 4*H)
+    for g in range(G):
+        dh_next = torch.zeros(B, H); dc = torch.zeros(B, H)
+        for t in range(T - 1, -1, -1):
+            i, f, gg, o = act[g, :, t].chunk(4, dim=-1)
+            c = cs[g, :, t]; cp = cs[g, :, t - 1] if t > 0 else torch.zeros(B, H)
+            dh = gy[g, :, t] + dh_next
+            tc = torch.tanh(c)
+            dct = dc + dh*o*(1 - tc*tc)
+            d = torch.cat([dct*gg*i*(1 - i), dct*cp*f*(1 - f), dct*i*(1 - gg*gg), dh*tc*o*(1 - o)], dim=-1)
+            dg[g, :, t] = d
+            dc = dct*f
+            dh_next = qb(d) @ qb(w_hh[g])
+
+    def run(fwd, bwd):
+        d = [v.to(dev).contiguous() for v in (gates, w_hh, bias, gy)]
+        yd = torch.empty(G, B, T, H, device=dev); ad = torch.empty(G, B, T, 4*H, device=dev)
+        cd = torch.empty(G, B, T, H, device=dev); dgd = torch.empty(G, B, T, 4*H, device=dev)
+        hip.check(getattr(lib, fwd)(hip.ptr(d[0]), hip.ptr(d[1]), hip.ptr(d[2]), hip.ptr(yd), hip.ptr(ad), hip.ptr(cd),
+                                    G*B, T, H, G, hip.stream()), fwd)
+        hip.check(getattr(lib, bwd)(hip.ptr(ad), hip.ptr(cd), hip.ptr(d[1]), hip.ptr(d[3]), hip.ptr(dgd),
+                                    G*B, T, H, G, hip.stream()), bwd)
+        torch.cuda.synchronize()
+        return yd.cpu(), ad.cpu(), cd.cpu(), dgd.cpu()
+    assert lib.brv_lstm_recurrent_bf16_supported(H) and not lib.brv_lstm_recurrent_bf16_supported(64)
+    got = run('brv_lstm_recurrent_forward_bf16', 'brv_lstm_recurrent_backward_bf16')
+    for name, a, b in zip(('y', 'act', 'cs', 'dgates'), got, (y, act, cs, dg)):
+        assert rel(a, b) <= 2e-4, (name, rel(a, b))
+    full = run('brv_lstm_recurrent_forward', 'brv_lstm_recurrent_backward')
+    for name, a, b in zip(('y', 'act', 'cs', 'dgates'), got, full):
+        assert rel(a, b) <= 2e-2, (name, rel(a, b))
+    # without saved activations (inference): the same hidden states
+    d = [v.to(dev).contiguous() for v in (gates, w_hh, bias)]
+    yd = torch.empty(G, B, T, H, device=dev)
+    hip.check(lib.brv_lstm_recurrent_forward_bf16(hip.ptr(d[0]), hip.ptr(d[1]), hip.ptr(d[2]), hip.ptr(yd), None, None,
+                                                  G*B, T, H, G, hip.stream()), 'brv_lstm_recurrent_forward_bf16')
+    assert torch.equal(yd.cpu(), got[0])
+
+
+@pytest.mark.gpu
 def test_entry_points_on_a_dataset_directory(tmp_path):
     """init -> train -> test on a dataset directory in the reference's layout
     (audio/NNNNN_<source>.wav, no tar) read by ``BreverDataset`` with segmentation from the
