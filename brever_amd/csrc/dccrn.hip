@@ -679,8 +679,20 @@ __device__ __forceinline__ bf16x8 lstm_frag8(const float* p, long long stride) {
   return __builtin_bit_cast(bf16x8, q);
 }
 #ifndef LSTM_MV_MASK
-#define LSTM_MV_MASK 1
+#define LSTM_MV_MASK 0    // 1: only the lanes of rows 0, 4, 8, 12 read the A fragments (measured no faster: a 16-byte LDS
+#endif                    // read costs the same with 16 or 64 lanes taking part; the unmasked form needs no assembly)
+#ifndef LSTM_MV_ABL
+#define LSTM_MV_ABL 0     // diagnostic builds of the forward kernel (results wrong): 1 no products, 2 no exponentials,
+#endif                    // 4 no global stores, 8 no fragment reads, 16 no barrier
+#ifndef LSTM_MV_PRIO
+#define LSTM_MV_PRIO 1
 #endif
+// Waves w and w + 4 share a SIMD and run the same step in lockstep (one barrier per step): both issue their 16
+// products, then both their gate math -- matrix pipe and vector ALUs take turns. With the first four waves at a higher
+// priority their products go first and their gate math runs beside the other wave's products.
+__device__ __forceinline__ void lstm_mv_prio(int w) {
+  if (LSTM_MV_PRIO) { if (w < 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+}
 // A fragments straight from LDS: NR 16-byte reads 64 bytes apart and one wait, as inline assembly under the lanes'
 // own branch (written as a select, hipcc turned `take ? *p : 0` into a FLAT load through a pointer that is either
 // the LDS address or a zeroed scratch slot, with a full vmcnt(0) lgkmcnt(0) wait per fragment)
@@ -699,6 +711,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_mv_kernel(const float* gates_in,
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, j = lane >> 4, u = 16*w + n;
   const bool take = (n & 3) == 0;
+  lstm_mv_prio(__builtin_amdgcn_readfirstlane(w));
   w_hh += (long long)(b / per_group)*4*H*H;
   if (bias) bias += (long long)(b / per_group)*4*H;
   bf16x8 wf[4][4];
@@ -731,9 +744,16 @@ __global__ __launch_bounds__(512) void lstm_fwd_mv_kernel(const float* gates_in,
   auto step = [&](In& cur, int t) {
     wait_set(cur);
     u32x4 aq[4];
+    if (LSTM_MV_MASK) {
 #pragma unroll
-    for (int kq = 0; kq < 4; ++kq) aq[kq] = u32x4{0u, 0u, 0u, 0u};
-    if (!LSTM_MV_MASK || take) lstm_read4(lstm_lds_addr(hb[t & 1] + 8*j), aq);
+      for (int kq = 0; kq < 4; ++kq) aq[kq] = u32x4{0u, 0u, 0u, 0u};
+      if (take && !(LSTM_MV_ABL & 8)) lstm_read4(lstm_lds_addr(hb[t & 1] + 8*j), aq);
+    } else {
+      // every lane reads (rows of A all equal): plain loads, the compiler waits fragment by fragment
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq)
+        aq[kq] = (LSTM_MV_ABL & 8) ? u32x4{0u, 0u, 0u, 0u} : *reinterpret_cast<const u32x4*>(hb[t & 1] + 8*j + 32*kq);
+    }
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -743,23 +763,33 @@ __global__ __launch_bounds__(512) void lstm_fwd_mv_kernel(const float* gates_in,
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) {
         const bf16x8 a = __builtin_bit_cast(bf16x8, aq[kq]);
+        if (LSTM_MV_ABL & 1) { acc[gp][0] += __uint_as_float(aq[kq].x); continue; }
         acc[gp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[gp][kq], acc[gp], 0, 0, 0);
         acc[gp + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[gp + 1][kq], acc[gp + 1], 0, 0, 0);
       }
-    const float ig = fast_sigm(acc[0][0] + cur.g0 + bq[0]), fg = fast_sigm(acc[1][0] + cur.g1 + bq[1]);
-    const float gg = fast_tanh(acc[2][0] + cur.g2 + bq[2]), og = fast_sigm(acc[3][0] + cur.g3 + bq[3]);
-    c = fg*c + ig*gg;
-    const float hn = og*fast_tanh(c);
+    float ig, fg, gg, og, hn;
+    if (LSTM_MV_ABL & 2) {
+      ig = acc[0][0] + cur.g0 + bq[0]; fg = acc[1][0] + cur.g1 + bq[1]; gg = acc[2][0] + cur.g2 + bq[2];
+      og = acc[3][0] + cur.g3 + bq[3];
+      c = fg*c + ig*gg; hn = og*c;
+    } else {
+      ig = fast_sigm(acc[0][0] + cur.g0 + bq[0]); fg = fast_sigm(acc[1][0] + cur.g1 + bq[1]);
+      gg = fast_tanh(acc[2][0] + cur.g2 + bq[2]); og = fast_sigm(acc[3][0] + cur.g3 + bq[3]);
+      c = fg*c + ig*gg;
+      hn = og*fast_tanh(c);
+    }
     if (j == 0) hb[(t + 1) & 1][u] = f2bf(hn);
     const long long row = (long long)b*T + t;
     // exactly 1 + 2 HAS_ACT store instructions per step (the counted wait relies on it): lane group 0 stores y,
     // group 1 the cell state, group j gate j's activation
-    if (j == 0) y[row*H + u] = hn;
-    if (HAS_ACT) {
-      if (j == 1) cs[row*H + u] = c;
-      act[row*4*H + j*H + u] = j == 0 ? ig : j == 1 ? fg : j == 2 ? gg : og;
-    }
-    lds_barrier();
+    if (!(LSTM_MV_ABL & 4)) {
+      if (j == 0) y[row*H + u] = hn;
+      if (HAS_ACT) {
+        if (j == 1) cs[row*H + u] = c;
+        act[row*4*H + j*H + u] = j == 0 ? ig : j == 1 ? fg : j == 2 ? gg : og;
+      }
+    } else if (hn == 123.456f) y[row*H + u] = ig + fg + gg + og;
+    if (!(LSTM_MV_ABL & 16)) lds_barrier();
   };
   In s0 = fetch(0), s1 = fetch(1), s2 = fetch(2), s3;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the counted wait needs full queues behind it)
@@ -786,6 +816,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_mv_kernel(const float* act, cons
   __shared__ float part[8][H];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, q = lane >> 4, u = 16*w + n;            // this lane: gate q of unit u
+  lstm_mv_prio(__builtin_amdgcn_readfirstlane(w));
   w_hh += (long long)(b / per_group)*4*H*H;
   bf16x8 wf[8][2];
 #pragma unroll
