@@ -12,8 +12,10 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# ROWS="dccrn_bf16 sgmse_b8" bash tools/profile_rows.sh r05: only those rows (their roofline lines are appended)
 run() {   # name, program, args...
   local name=$1; shift
+  if [ -n "${ROWS:-}" ] && [[ " $ROWS " != *" $name "* ]]; then return; fi
   rm -rf /tmp/rw_$name /tmp/rwf_$name /tmp/rww_$name
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rw_$name -o s -- python3 "$@" > /dev/null 2>&1
   cp $(find /tmp/rw_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rows_${name}_kernel_stats.csv
@@ -22,7 +24,7 @@ run() {   # name, program, args...
   python3 $REPO/tools/pmc_traffic.py /tmp/rwf_$name /tmp/rww_$name $OUT/${TAG}_rows_${name}_pmc_hbm_traffic.json > /dev/null
   python3 $REPO/tools/rows_roofline.py $name $OUT/${TAG}_rows_${name}_kernel_stats.csv $OUT/${TAG}_rows_${name}_pmc_hbm_traffic.json >> $OUT/${TAG}_rows_roofline.json
 }
-rm -f $OUT/${TAG}_rows_roofline.json
+[ -z "${ROWS:-}" ] && rm -f $OUT/${TAG}_rows_roofline.json
 run ctn_fp32 $REPO/tools/prof_ctn_f32.py
 # (per-kernel durations of the DCCRN use_amp step are taken IN ORDER on one stream: with the parameter gradients on
 # the side stream, overlapping kernels share the chip and each reads up to twice its own duration)
