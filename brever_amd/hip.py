@@ -232,6 +232,8 @@ SIGNATURES = {
     'brv_col_sum_bf16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_row_std': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_ptr]),
     'brv_row_scale': (ctypes.c_int, [_c_ptr]*3 + [_c_i64, _c_i64, ctypes.c_int, _c_ptr]),
+    'brv_head_permute_supported': (ctypes.c_int, [_c_i64]*3),
+    'brv_head_permute': (ctypes.c_int, [_c_ptr]*2 + [_c_i64]*5 + [ctypes.c_int, _c_ptr]),
     'brv_cplx_moments': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_cplx_affine_forward': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*3 + [_c_ptr]),
     'brv_cplx_affine_backward': (ctypes.c_int, [_c_ptr]*9 + [_c_i64]*3 + [_c_ptr]),

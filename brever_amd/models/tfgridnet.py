@@ -427,6 +427,53 @@ def _add(a, b):
     return T.AxpbyFn.apply(a, 1.0, b, 1.0)
 
 
+_HEAD_PERMUTE = os.environ.get('BRV_TFG_HEAD_PERMUTE', '1') != '0'     # 0: torch permute + copy (round 4)
+
+
+class _HeadPermuteFn(torch.autograd.Function):
+    """``merge`` False: x (B, T, F, H*E) channels-last -> (B, H, T, E, F); True: x (B, H, T, E, F) -> (B, T, F, H*E).
+    ``brv_head_permute`` (one launch through LDS) where a torch permute + copy ran a five-dimensional strided copy;
+    the gradient is the opposite permutation."""
+
+    @staticmethod
+    def _run(x, B, Tn, Fq, H, E, merge):
+        x = x.contiguous()
+        out = torch.empty((B, Tn, Fq, H*E) if merge else (B, H, Tn, E, Fq), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_head_permute(hip.ptr(x), hip.ptr(out), B, Tn, Fq, H, E, int(merge), hip.stream()),
+                  'brv_head_permute')
+        return out
+
+    @staticmethod
+    def forward(ctx, x, H, E, merge):
+        if merge:
+            B, _, Tn, _, Fq = x.shape
+        else:
+            B, Tn, Fq, _ = x.shape
+        ctx.cfg = (B, Tn, Fq, H, E, merge)
+        return _HeadPermuteFn._run(x, B, Tn, Fq, H, E, merge)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Tn, Fq, H, E, merge = ctx.cfg
+        return _HeadPermuteFn._run(g, B, Tn, Fq, H, E, not merge), None, None, None
+
+
+def _head_split(x, H, E):
+    """(B, T, F, H*E) -> (B, H, T, E, F)."""
+    B, Tn, Fq, _ = x.shape
+    if _HEAD_PERMUTE and x.dtype == torch.float32 and hip.lib().brv_head_permute_supported(Fq, H, E):
+        return _HeadPermuteFn.apply(x, H, E, False)
+    return x.view(B, Tn, Fq, H, E).permute(0, 3, 1, 4, 2).contiguous()
+
+
+def _head_merge(a, B, H, Tn, E, Fq):
+    """(B*H, T, E*F) -> (B, T, F, H*E)."""
+    a = a.view(B, H, Tn, E, Fq)
+    if _HEAD_PERMUTE and a.dtype == torch.float32 and hip.lib().brv_head_permute_supported(Fq, H, E):
+        return _HeadPermuteFn.apply(a, H, E, True)
+    return a.permute(0, 2, 4, 1, 3).reshape(B, Tn, Fq, H*E)
+
+
 def _bilstm(x, rnn):
     """Bidirectional single-layer nn.LSTM (batch_first) on (N, S, I) -> (N, S, 2H): the sequence
     and its reversal are two groups of one launch set."""
@@ -498,7 +545,7 @@ class TFGridNet(BreverBaseModel):
         which is the (items, frames, features) layout the attention products read."""
         B, Tn, Fq, _ = x.shape
         H, E = norm.H, norm.E
-        rows = x.view(B, Tn, Fq, H, E).permute(0, 3, 1, 4, 2).reshape(B*H*Tn, E*Fq)
+        rows = _head_split(x, H, E).view(B*H*Tn, E*Fq)
         y = _RowNormFn.apply(rows, norm.act.weight, norm.gamma.view(H, E*Fq), norm.beta.view(H, E*Fq),
                              Tn, norm.eps)
         return y.view(B*H, Tn, E*Fq)
@@ -542,7 +589,7 @@ class TFGridNet(BreverBaseModel):
         v = self._head_norm(_linear(x, blk.attn_conv_V), blk.attn_norm_V)
         a = _AttentionFn.apply(q, k, v)                                      # (B*H, T, Ev*Q)
         H, Ev = blk.n_head, blk.attn_norm_V.E
-        a = a.view(B, H, old_T, Ev, old_Q).permute(0, 2, 4, 1, 3).reshape(B, old_T, old_Q, H*Ev)
+        a = _head_merge(a, B, H, old_T, Ev, old_Q)                           # (B, T, Q, H*Ev)
         conv, act, norm = blk.attn_concat_proj
         a = _linear(a, conv)                                                 # (B, T, Q, C)
         slope = act.weight if isinstance(act, nn.PReLU) else None

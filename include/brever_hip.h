@@ -640,6 +640,13 @@ int brv_col_sum(const float* x, float* out, void* scratch, int64_t batch, int64_
 int brv_col_sum_bf16(const void* x, float* out, void* scratch, int64_t batch, int64_t rows, int64_t cols,
                      brv_stream_t stream);
 int brv_row_std(const float* x, float* out, int64_t rows, int64_t n, brv_stream_t stream);
+/* Head split / merge of TF-GridNet's attention (reference brever/models/tfgridnet/tfgridnet.py:315-353; there a
+ * view + permute on (B, C, T, F) tensors): merge = 0: in (B, T, F, H, E) channels-last -> out (B, H, T, E, F), the
+ * (items, frames, features) rows of the head norms and attention products; merge = 1: the inverse. One launch, both
+ * sides in contiguous runs; H E (F | 1) floats of LDS (brv_head_permute_supported). */
+int brv_head_permute_supported(int64_t F, int64_t H, int64_t E);
+int brv_head_permute(const float* in, float* out, int64_t B, int64_t T, int64_t F, int64_t H, int64_t E, int merge,
+                     brv_stream_t stream);
 int brv_row_scale(const float* x, const float* s, float* y, int64_t rows, int64_t n, int divide,
                   brv_stream_t stream);
 

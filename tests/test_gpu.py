@@ -1714,6 +1714,29 @@ def test_lstm_kernels_match_torch(H):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 7, 129, 4, 8), (1, 3, 65, 4, 4), (3, 5, 16, 1, 3), (2, 2, 300, 2, 5)])
+def test_head_permute_equals_torch_permute(shape):
+    """``brv_head_permute`` (TF-GridNet's head split / merge, one launch through LDS) is the permutation
+    (B, T, F, H, E) <-> (B, H, T, E, F) bit for bit, both directions, and its autograd pair is each other's inverse."""
+    from brever_amd.models.tfgridnet import _head_split, _head_merge
+    dev = _cuda()
+    B, Tn, Fq, H, E = shape
+    torch.manual_seed(sum(shape))
+    x = torch.randn(B, Tn, Fq, H*E, device=dev, requires_grad=True)
+    want = x.detach().view(B, Tn, Fq, H, E).permute(0, 3, 1, 4, 2).contiguous()
+    got = _head_split(x, H, E)
+    assert got.shape == want.shape and torch.equal(got.detach(), want)
+    g = torch.randn_like(want)
+    got.backward(g)
+    assert torch.equal(x.grad, g.permute(0, 2, 4, 1, 3).reshape(B, Tn, Fq, H*E))
+    a = want.reshape(B*H, Tn, E*Fq).clone().requires_grad_(True)
+    back = _head_merge(a, B, H, Tn, E, Fq)
+    assert torch.equal(back.detach(), x.detach())
+    back.backward(x.detach())
+    assert torch.equal(a.grad, want.reshape(B*H, Tn, E*Fq))
+
+
+@pytest.mark.gpu
 def test_lstm_bf16_matrix_pipe_recurrence_matches_rounded_operand_loop():
     """use_amp, H = 128, few long chains: the recurrence whose step runs on the bf16 MFMA (csrc/dccrn.hip
     lstm_fwd_mv_kernel / lstm_bwd_mv_kernel) vs an fp32 torch loop with the SAME operand rounding -- the hidden state and

@@ -1,27 +1,27 @@
-"""Idle time between consecutive dispatches of a rocprofv3 --kernel-trace CSV (last third of the run):
-python3 tools/trace_gaps.py DIR  -> busy / span, gap histogram, the kernels that follow the longest gaps."""
-import csv
-import glob
+"""Idle gaps of the device in the last step of a kernel trace listing (tools/trace_row.sh output: start us, duration us, queue,
+grid, kernel): wall time, time with at least one kernel running, and the largest gaps with the kernel that ended them.
+    python tools/trace_gaps.py gpurun_out/trace_dccrn.txt"""
 import sys
-import collections
-f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
-rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-rows = rows[len(rows)*2//3:]
-span = (int(rows[-1]['End_Timestamp']) - int(rows[0]['Start_Timestamp']))/1e3
-busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rows)/1e3
+rows = []
+for line in open(sys.argv[1]):
+    p = line.split()
+    try:
+        s, d = float(p[0]), float(p[1])
+    except (ValueError, IndexError):
+        continue
+    rows.append((s, s + d, ' '.join(p[4:])[:90]))
+rows.sort()
+end = busy = 0.0
 gaps = []
-end = int(rows[0]['End_Timestamp'])
-for r in rows[1:]:
-    s = int(r['Start_Timestamp'])
-    gaps.append(((s - end)/1e3, r['Kernel_Name'][:60]))
-    end = max(end, int(r['End_Timestamp']))
-print(f'launches {len(rows)}  span {span/1e3:.3f} ms  busy {busy/1e3:.3f} ms  idle {sum(max(g, 0) for g, _ in gaps)/1e3:.3f} ms')
-h = collections.Counter()
-for g, _ in gaps:
-    h[min(int(max(g, 0)), 20)] += 1
-print('gap histogram (us: count):', sorted(h.items()))
-by = collections.defaultdict(list)
-for g, k in gaps:
-    by[k].append(g)
-for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:12]:
-    print(f'{sum(v)/1e3:8.3f} ms idle before {len(v):5d} x {k}  (avg {sum(v)/len(v):.1f} us)')
+for s, e, name in rows:
+    if s > end:
+        if end > 0:
+            gaps.append((s - end, end, name))
+        busy += e - s
+    elif e > end:
+        busy += e - end
+    end = max(end, e)
+wall = rows[-1][1] - rows[0][0]
+print(f'{len(rows)} launches, wall {wall:.0f} us, busy {busy:.0f} us, idle {wall - busy:.0f} us in {len(gaps)} gaps')
+for g in sorted(gaps, reverse=True)[:int(sys.argv[2]) if len(sys.argv) > 2 else 8]:
+    print(f'  {g[0]:8.1f} us idle at {g[1]:9.1f}, then {g[2]}')

@@ -3,7 +3,7 @@
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trace_row
-rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_row -o t -- python3 $REPO/tools/trace_row.py $1 ${2:-amp} 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_row -o t -- python3 $REPO/tools/trace_row.py $1 ${2:-amp} ${3:-3} > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/trace_row/**/*kernel_trace.csv', recursive=True)[0]
