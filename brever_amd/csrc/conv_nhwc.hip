@@ -846,13 +846,13 @@ int conv_nhwc_launch(const void* x1, int64_t C1, int64_t C1s, const void* x2, in
 #define BRV_CONV_PF 0          // diagnostic builds: force the rows per tile (1, 2 or 4 x 4 rows)
 #endif
   constexpr int force_pf = BRV_CONV_PF;
-  // (BRV_CONV_MIN_TILES: the tile count below which the rows per tile are halved -- every workgroup streams the whole
-  // weight set of its channel block from L2 per TILE, so more, smaller tiles buy occupancy with weight traffic)
-  static const long long min_tiles = [] {
-    const char* e = getenv("BRV_CONV_MIN_TILES");
-    const long long v = e ? atoll(e) : 0;
-    return v > 0 ? v : 192LL;
-  }();
+  // (BRV_CONV_MIN_TILES, diagnostic builds: the tile count below which the rows per tile are halved -- every workgroup
+  // streams the whole weight set of its channel block from L2 per TILE, so more, smaller tiles buy occupancy with
+  // weight traffic; swept 32 .. 1 024 at batch 1 and 8: 192 is the optimum, profiles/r05_sgmse_tiles.txt)
+#ifndef BRV_CONV_MIN_TILES
+#define BRV_CONV_MIN_TILES 192
+#endif
+  constexpr long long min_tiles = BRV_CONV_MIN_TILES;
   int pf = 4;
   while (pf > 1 && (long long)B*((H + 4*pf - 1)/(4*pf))*p.n_wt*p.n_cob < min_tiles) pf >>= 1;
   if (force_pf == 1 || force_pf == 2 || force_pf == 4) pf = force_pf;

@@ -1,5 +1,5 @@
 """SGMSE+ use_amp enhance at batch 1 and 8 (10-step sampler = 20 network evaluations; ms per evaluation is what counts):
-   [BRV_CONV_MIN_TILES=n] python tools/sgmse_quick.py"""
+   [BRV_LIB_PATH=tools/_v/<tag>/libbrever_hip.so] python tools/sgmse_quick.py     (variants: tools/mkvariant.sh <tag> conv_nhwc.hip -DBRV_CONV_MIN_TILES=n)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,4 +19,4 @@ for batch in (1, 8):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0)/2
     res.append(f'b{batch}: {dt/(2*steps)*1e3:6.2f} ms per evaluation')
-print(os.environ.get('BRV_CONV_MIN_TILES', 'default'), ' | '.join(res))
+print(os.environ.get('BRV_LIB_PATH', 'default library'), ' | '.join(res))
