@@ -335,21 +335,44 @@ struct Pw1Params {
   int C1, C1s, C2, C2s, Cout, Cys, n_ks1, n_ks;
   long long npx; float out_scale;
 };
-__global__ __launch_bounds__(256) void nhwc_conv1x1_kernel(const Pw1Params p) {
-  constexpr int ESTRIDE = 272;
+// NB = 128-channel output blocks per workgroup. With NB = 1 and Cout = 256 the two blocks of a pixel tile were two
+// workgroups far apart in the dispatch order (blockIdx.y): the input was fetched from HBM twice -- 790 MB per launch
+// at full resolution where 527 MB are algorithmic (profiles/r05_rows_sgmse_b8_pmc_hbm_traffic.json). NB = 2: one
+// workgroup multiplies its 128 pixels against both blocks (8 accumulators per wave), the input is read once.
+#ifndef PW1_ABL
+#define PW1_ABL 0      // diagnostic builds (results wrong): 1 no weight loads, 2 no MFMAs, 4 no stores, 8 no input loads
+#endif
+template <int NB>
+__global__ __launch_bounds__(256, 2) void nhwc_conv1x1_kernel(const Pw1Params p) {
+  constexpr int ESTRIDE = 272, CF = 4*NB;
   __shared__ __attribute__((aligned(16))) unsigned char stage[128*ESTRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n32 = lane & 31, khalf = lane >> 5;
-  const long long px0 = (long long)blockIdx.x*128;
-  const int cob = blockIdx.y;
+  const int n_cob = (p.Cout + 127)/128;
+  // 1-D grid (gridDim.y == 1): ids congruent mod 8 run on one XCD (one L2): XCD x takes the pixel tiles 8 j + x and
+  // walks the output blocks of a tile in consecutive slots, so that a tile's input is fetched into that L2 once
+  long long ptile = blockIdx.x;
+  int cob0 = blockIdx.y*NB;
+  if (gridDim.y == 1 && n_cob > NB) {
+    const int nyb = (n_cob + NB - 1)/NB;
+    const unsigned int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    cob0 = (int)(slot % nyb)*NB;
+    ptile = (long long)(slot / nyb)*8 + xcd;
+    if (ptile*128 >= p.npx) return;                // (padding of the grid: whole workgroups, before any barrier)
+  }
+  const long long px0 = ptile*128;
   const long long px = px0 + wave*32 + n32;
   const bool pok = px < p.npx;
-  f32x16 acc[4];
+  f32x16 acc[CF];
 #pragma unroll
-  for (int cf = 0; cf < 4; ++cf)
+  for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[cf][i] = 0.f;
-  const h8* wa = p.wp + (long long)cob*p.n_ks*4*64 + lane;
+  // (a second block past the last one reads the first block's weights again: its results are not stored)
+  const h8* wa[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    wa[nb] = p.wp + (long long)(cob0 + nb < n_cob ? cob0 + nb : cob0)*p.n_ks*4*64 + lane;
   const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   // operands of k-step ks + 1 are requested before the MFMAs of k-step ks (small images run a few
   // workgroups whose reduction is a chain of load latencies otherwise)
@@ -359,27 +382,251 @@ __global__ __launch_bounds__(256) void nhwc_conv1x1_kernel(const Pw1Params p) {
     const int cs = second ? p.C2s : p.C1s;
     const int c0 = (second ? ks - p.n_ks1 : ks)*16 + khalf*8;
     h8 bv = zero;
-    if (pok && c0 < cs) bv = *reinterpret_cast<const h8*>(xb + px*cs + c0);
+    if (pok && c0 < cs && !(PW1_ABL & 8)) bv = *reinterpret_cast<const h8*>(xb + px*cs + c0);
     return bv;
   };
-  h8 bn = load_b(0), an[4];
+  h8 bn = load_b(0), an[CF];
 #pragma unroll
-  for (int cf = 0; cf < 4; ++cf) an[cf] = wa[cf*64];
+  for (int cf = 0; cf < CF; ++cf) an[cf] = (PW1_ABL & 1) ? zero : wa[cf >> 2][(cf & 3)*64];
   for (int ks = 0; ks < p.n_ks; ++ks) {
     const h8 bv = bn;
-    h8 av[4];
+    h8 av[CF];
 #pragma unroll
-    for (int cf = 0; cf < 4; ++cf) av[cf] = an[cf];
+    for (int cf = 0; cf < CF; ++cf) av[cf] = an[cf];
     if (ks + 1 < p.n_ks) {
       bn = load_b(ks + 1);
 #pragma unroll
-      for (int cf = 0; cf < 4; ++cf) an[cf] = wa[((ks + 1)*4 + cf)*64];
+      for (int cf = 0; cf < CF; ++cf) if (!(PW1_ABL & 1)) an[cf] = wa[cf >> 2][((ks + 1)*4 + (cf & 3))*64];
     }
 #pragma unroll
-    for (int cf = 0; cf < 4; ++cf)
+    for (int cf = 0; cf < CF; ++cf) {
+      if (PW1_ABL & 2) { acc[cf][0] += (float)av[cf][0]*(float)bv[cf & 7]; continue; }
       acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[cf], bv, acc[cf], 0, 0, 0);
+    }
   }
-  // D[co][pixel] -> LDS [pixel][co] -> 16-byte pieces of whole pixel rows
+  // D[co][pixel] -> LDS [pixel][co] -> 16-byte pieces of whole pixel rows, one 128-channel block at a time
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int cob = cob0 + nb;
+    if (nb > 0) __syncthreads();                   // (the staging buffer's readers of the previous block)
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (_Float16)acc[nb*4 + cq][g*4 + j];
+        *reinterpret_cast<h4*>(stage + (wave*32 + n32)*ESTRIDE + (cq*32 + g*8 + khalf*4)*2) = o;
+      }
+    __syncthreads();
+    if (cob >= n_cob) continue;
+    const int c8 = tid & 15, co = cob*128 + c8*8;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = p.bias && co + j < p.Cout ? p.bias[co + j] : 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = (it*256 + tid) >> 4;
+      const long long q = px0 + r;
+      if (q >= p.npx || co >= p.Cout) continue;
+      const f32x8 v = __builtin_convertvector(*reinterpret_cast<const h8*>(stage + r*ESTRIDE + c8*16), f32x8);
+      f32x8 w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = (v[j] + bv[j])*p.out_scale;
+      const h8 o = __builtin_convertvector(w, h8);
+      if (PW1_ABL & 4) { if (w[0] == 123.456f) p.y[q] = o[0]; continue; }
+      if (co + 8 <= p.Cout) *reinterpret_cast<h8*>(p.y + q*p.Cys + co) = o;
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (co + j < p.Cout) p.y[q*p.Cys + co + j] = o[j];
+      }
+    }
+  }
+}
+// The same product with the WEIGHTS staged through LDS (round 5). In the kernel above every wave fetches its own A
+// fragments: 4 KB per k-step and wave against 1 KB of input, all through the vector memory path -- the ablations of
+// tools/pw1_bench.py price them at 155 of the 433 us of the 512 -> 256 channel launch (no weight loads: 278 us; no
+// input loads: 198; neither, no MFMAs: 60 = the stores alone). Here the 256 threads of a workgroup copy the weights of
+// four k-steps (16 KB, contiguous in the packed layout) into one of two LDS buffers while the previous four are
+// multiplied; the four waves read their A fragments from LDS (lane-linear 16-byte reads), one barrier per four
+// k-steps. The epilogue's staging area reuses the weight buffers: 34 KB of LDS as before, same occupancy.
+__global__ __launch_bounds__(256, 2) void nhwc_conv1x1_lds_kernel(const Pw1Params p) {
+  constexpr int ESTRIDE = 272, KC = 4, WB = KC*4096;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2*WB > 128*ESTRIDE ? 2*WB : 128*ESTRIDE];
+  unsigned char* stage = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n32 = lane & 31, khalf = lane >> 5;
+  const int n_cob = (p.Cout + 127)/128;
+  long long ptile = blockIdx.x;
+  int cob = blockIdx.y;
+  if (gridDim.y == 1 && n_cob > 1) {               // XCD-aware 1-D grid, as above
+    const unsigned int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    cob = (int)(slot % n_cob);
+    ptile = (long long)(slot / n_cob)*8 + xcd;
+    if (ptile*128 >= p.npx) return;
+  }
+  const long long px0 = ptile*128;
+  const long long px = px0 + wave*32 + n32;
+  const bool pok = px < p.npx;
+  f32x16 acc[4];
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[cf][i] = 0.f;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wp) + (long long)cob*p.n_ks*4096 + tid*16;
+  const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto load_b = [&](int ks) -> h8 {
+    const bool second = ks >= p.n_ks1;
+    const _Float16* xb = second ? p.x2 : p.x1;
+    const int cs = second ? p.C2s : p.C1s;
+    const int c0 = (second ? ks - p.n_ks1 : ks)*16 + khalf*8;
+    h8 bv = zero;
+    if (pok && ks < p.n_ks && c0 < cs) bv = *reinterpret_cast<const h8*>(xb + px*cs + c0);
+    return bv;
+  };
+  const int n_chunks = (p.n_ks + KC - 1)/KC;
+  uint4 wr[KC];
+  auto load_w = [&](int c) {                       // the chunk's four k-steps: piece i = k-step KC c + i
+#pragma unroll
+    for (int i = 0; i < KC; ++i)
+      wr[i] = KC*c + i < p.n_ks ? *reinterpret_cast<const uint4*>(wsrc + (long long)(KC*c + i)*4096) : make_uint4(0, 0, 0, 0);
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < KC; ++i) *reinterpret_cast<uint4*>(lds + buf*WB + i*4096 + tid*16) = wr[i];
+  };
+  load_w(0);
+  h8 bn = load_b(0), bn2 = load_b(1);              // input fragments two k-steps ahead
+  store_w(0);
+  __syncthreads();
+  for (int c = 0; c < n_chunks; ++c) {
+    if (c + 1 < n_chunks) load_w(c + 1);
+    const unsigned char* wb = lds + (c & 1)*WB + lane*16;
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      const int ks = KC*c + i;
+      const h8 bv = bn;
+      bn = bn2; bn2 = load_b(ks + 2);
+      if (ks < p.n_ks) {
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          const h8 av = *reinterpret_cast<const h8*>(wb + i*4096 + cf*1024);
+          acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[cf], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < n_chunks) store_w((c + 1) & 1);
+    __syncthreads();
+  }
+  // D[co][pixel] -> LDS [pixel][co] -> 16-byte pieces of whole pixel rows (the weight buffers are free now)
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      h4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (_Float16)acc[cf][g*4 + j];
+      *reinterpret_cast<h4*>(stage + (wave*32 + n32)*ESTRIDE + (cf*32 + g*8 + khalf*4)*2) = o;
+    }
+  __syncthreads();
+  const int c8 = tid & 15, co = cob*128 + c8*8;
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = p.bias && co + j < p.Cout ? p.bias[co + j] : 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int r = (it*256 + tid) >> 4;
+    const long long q = px0 + r;
+    if (q >= p.npx || co >= p.Cout) continue;
+    const f32x8 v = __builtin_convertvector(*reinterpret_cast<const h8*>(stage + r*ESTRIDE + c8*16), f32x8);
+    f32x8 w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = (v[j] + bv[j])*p.out_scale;
+    const h8 o = __builtin_convertvector(w, h8);
+    if (co + 8 <= p.Cout) *reinterpret_cast<h8*>(p.y + q*p.Cys + co) = o;
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (co + j < p.Cout) p.y[q*p.Cys + co + j] = o[j];
+    }
+  }
+}
+// ... and the INPUT through LDS as well: per chunk of four k-steps (64 channels) a pixel row contributes 128
+// contiguous bytes, fetched by eight threads (a wave-load = eight whole cache lines instead of 32-byte pieces of 32
+// rows); rows sit 144 bytes apart in LDS (the 32 lanes of a B-fragment read fall on distinct bank groups).
+__global__ __launch_bounds__(256, 2) void nhwc_conv1x1_lds2_kernel(const Pw1Params p) {
+  constexpr int ESTRIDE = 272, KC = 4, WB = KC*4096, XS = 144, XB = 128*XS;
+  constexpr int LDS = 2*WB + 2*XB > 128*ESTRIDE ? 2*WB + 2*XB : 128*ESTRIDE;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS];
+  unsigned char* stage = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n32 = lane & 31, khalf = lane >> 5;
+  const int n_cob = (p.Cout + 127)/128;
+  long long ptile = blockIdx.x;
+  int cob = blockIdx.y;
+  if (gridDim.y == 1 && n_cob > 1) {
+    const unsigned int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    cob = (int)(slot % n_cob);
+    ptile = (long long)(slot / n_cob)*8 + xcd;
+    if (ptile*128 >= p.npx) return;
+  }
+  const long long px0 = ptile*128;
+  f32x16 acc[4];
+#pragma unroll
+  for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[cf][i] = 0.f;
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wp) + (long long)cob*p.n_ks*4096 + tid*16;
+  const int n_chunks = (p.n_ks + KC - 1)/KC;
+  uint4 wr[KC], xr[4];
+  auto load_w = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < KC; ++i)
+      wr[i] = KC*c + i < p.n_ks ? *reinterpret_cast<const uint4*>(wsrc + (long long)(KC*c + i)*4096) : make_uint4(0, 0, 0, 0);
+  };
+  // piece j of this thread: pixel row (tid >> 3) + 32 j, bytes 16 (tid & 7) of the chunk's 128 (k-steps KC c ..: the
+  // k-step of a piece is (tid & 7) >> 1 -- the two sources never share a chunk's k-step, but may share a chunk)
+  auto load_x = [&](int c) {
+    const int ks = KC*c + ((tid & 7) >> 1);
+    const bool second = ks >= p.n_ks1;
+    const _Float16* xb = second ? p.x2 : p.x1;
+    const int cs = second ? p.C2s : p.C1s;
+    const int c0 = (second ? ks - p.n_ks1 : ks)*16 + (tid & 1)*8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long q = px0 + (tid >> 3) + 32*j;
+      xr[j] = (q < p.npx && ks < p.n_ks && c0 < cs) ? *reinterpret_cast<const uint4*>(xb + q*cs + c0) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_wx = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < KC; ++i) *reinterpret_cast<uint4*>(lds + buf*WB + i*4096 + tid*16) = wr[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<uint4*>(lds + 2*WB + buf*XB + ((tid >> 3) + 32*j)*XS + (tid & 7)*16) = xr[j];
+  };
+  load_w(0); load_x(0);
+  store_wx(0);
+  __syncthreads();
+  for (int c = 0; c < n_chunks; ++c) {
+    if (c + 1 < n_chunks) { load_w(c + 1); load_x(c + 1); }
+    const unsigned char* wb = lds + (c & 1)*WB + lane*16;
+    const unsigned char* xb = lds + 2*WB + (c & 1)*XB + (wave*32 + n32)*XS + khalf*16;
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      if (KC*c + i < p.n_ks) {
+        const h8 bv = *reinterpret_cast<const h8*>(xb + i*32);
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+          const h8 av = *reinterpret_cast<const h8*>(wb + i*4096 + cf*1024);
+          acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[cf], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < n_chunks) store_wx((c + 1) & 1);
+    __syncthreads();
+  }
 #pragma unroll
   for (int cf = 0; cf < 4; ++cf)
 #pragma unroll
@@ -719,8 +966,31 @@ int brv_nhwc_conv1x1_forward(const void* x1, int64_t C1, int64_t C1s, const void
   p.Cout = (int)Cout; p.Cys = (int)Cys;
   p.n_ks1 = (int)((C1 + 15)/16); p.n_ks = p.n_ks1 + (x2 ? (int)((C2 + 15)/16) : 0);
   p.npx = npx; p.out_scale = out_scale;
-  hipLaunchKernelGGL(nhwc_conv1x1_kernel, dim3((unsigned)((npx + 127)/128), (unsigned)((Cout + 127)/128)),
-                     dim3(256), 0, (hipStream_t)stream, p);
+#ifndef BRV_PW1_NB
+#define BRV_PW1_NB 1           // diagnostic builds: 2 = both 128-channel blocks of a pixel tile in one workgroup
+#endif
+  const unsigned n_cob = (unsigned)((Cout + 127)/128);
+  const unsigned n_pt = (unsigned)((npx + 127)/128);
+#ifndef BRV_PW1_XCD
+#define BRV_PW1_XCD 1          // diagnostic builds: 0 = (pixel tile, output block) grid of round 4
+#endif
+#ifndef BRV_PW1_LDS
+#define BRV_PW1_LDS 1          // diagnostic builds: 0 = every wave fetches its own weight fragments (round 4)
+#endif
+  // (input through LDS too from 256 input channels on: 99 / 126 / 329 against 106 / 144 / 355 us at 128 + 128 -> 128,
+  // 256 + 128 -> 128, 256 + 256 -> 256 channels and 8 x 256 x 251 pixels; 143 against 136 us at 128 -> 256)
+  if (BRV_PW1_LDS == 2 || (BRV_PW1_LDS == 1 && p.n_ks >= 16)) {
+    if (n_cob >= 2) hipLaunchKernelGGL(nhwc_conv1x1_lds2_kernel, dim3((n_pt + 7)/8*8*n_cob), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(nhwc_conv1x1_lds2_kernel, dim3(n_pt, 1), dim3(256), 0, (hipStream_t)stream, p);
+  } else if (BRV_PW1_LDS) {
+    if (n_cob >= 2) hipLaunchKernelGGL(nhwc_conv1x1_lds_kernel, dim3((n_pt + 7)/8*8*n_cob), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(nhwc_conv1x1_lds_kernel, dim3(n_pt, 1), dim3(256), 0, (hipStream_t)stream, p);
+  } else if (BRV_PW1_NB == 2 && n_cob >= 2)
+    hipLaunchKernelGGL(nhwc_conv1x1_kernel<2>, dim3(n_pt, (n_cob + 1)/2), dim3(256), 0, (hipStream_t)stream, p);
+  else if (BRV_PW1_XCD && n_cob >= 2)
+    hipLaunchKernelGGL(nhwc_conv1x1_kernel<1>, dim3((n_pt + 7)/8*8*n_cob), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(nhwc_conv1x1_kernel<1>, dim3(n_pt, n_cob), dim3(256), 0, (hipStream_t)stream, p);
   NH_OK(hipGetLastError());
   return 0;
 }
