@@ -712,26 +712,48 @@ __global__ __launch_bounds__(256) void nhwc_conv3x3_small_kernel(const SmallCout
   const long long HW = (long long)p.H*p.W;
   for (int cb = 0; cb < p.C; cb += SLAB) {
     __syncthreads();
-    for (int i = tid; i < PR*PC*(SLAB/8); i += 256) {
+    // all of the thread's patch pieces are requested before the first is transformed (one piece at a time the staging
+    // loop was a chain of eleven memory round trips per slab: 304 us per launch at full resolution)
+    constexpr int NPC = (PR*PC*(SLAB/8) + 255)/256;
+    h8 raw[NPC];
+    bool rok[NPC];
+#pragma unroll
+    for (int q = 0; q < NPC; ++q) {
+      const int i = tid + 256*q;
       const int px = i / (SLAB/8), o8 = i % (SLAB/8);
       const int h = h0 + px / PC - 1, w = w0 + px % PC - 1;
       const int ch = cb + o8*8;
-      f32x8 v;
+      rok[q] = i < PR*PC*(SLAB/8) && h >= 0 && h < p.H && w >= 0 && w < p.W && ch < p.C;
+      const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      raw[q] = z;
+      if (rok[q]) raw[q] = *reinterpret_cast<const h8*>(p.x + (b*HW + (long long)h*p.W + w)*p.Cs + ch);
+    }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      if (h >= 0 && h < p.H && w >= 0 && w < p.W && ch < p.C) {
-        v = __builtin_convertvector(*reinterpret_cast<const h8*>(p.x + (b*HW + (long long)h*p.W + w)*p.Cs + ch), f32x8);
-        if (p.scale) {
-          const float* sc = p.scale + (long long)b*p.C + ch;
-          const float* sh = p.shift + (long long)b*p.C + ch;
+    for (int q = 0; q < NPC; ++q) {
+      const int i = tid + 256*q;
+      const int px = i / (SLAB/8), o8 = i % (SLAB/8);
+      const int ch = cb + o8*8;
+      f32x8 v = __builtin_convertvector(raw[q], f32x8);        // (zeros where the piece lies outside)
+      if (rok[q] && p.scale) {
+        const float* scp = p.scale + (long long)b*p.C + ch;        // (ch, C: multiples of 8)
+        const float* shp = p.shift + (long long)b*p.C + ch;
+        float sc[8], sh[8];
+        if (((reinterpret_cast<unsigned long long>(p.scale) | reinterpret_cast<unsigned long long>(p.shift)) & 15) == 0) {
+          const float4 s0 = reinterpret_cast<const float4*>(scp)[0], s1 = reinterpret_cast<const float4*>(scp)[1];
+          const float4 t0 = reinterpret_cast<const float4*>(shp)[0], t1 = reinterpret_cast<const float4*>(shp)[1];
+          sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+          sh[0] = t0.x; sh[1] = t0.y; sh[2] = t0.z; sh[3] = t0.w; sh[4] = t1.x; sh[5] = t1.y; sh[6] = t1.z; sh[7] = t1.w;
+        } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float t = sc[j]*v[j] + sh[j];
-            v[j] = p.silu ? nh_silu(t) : t;
-          }
+          for (int j = 0; j < 8; ++j) { sc[j] = scp[j]; sh[j] = shp[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = sc[j]*v[j] + sh[j];
+          v[j] = p.silu ? nh_silu(t) : t;
         }
       }
-      *reinterpret_cast<h8*>(&patch[px][o8*8]) = __builtin_convertvector(v, h8);
+      if (i < PR*PC*(SLAB/8)) *reinterpret_cast<h8*>(&patch[px][o8*8]) = __builtin_convertvector(v, h8);
     }
     for (int i = tid; i < 9*COUT*(SLAB/8); i += 256) {
       const int k8 = i % (SLAB/8), o = (i / (SLAB/8)) % COUT, t = i / ((SLAB/8)*COUT);
@@ -741,18 +763,42 @@ __global__ __launch_bounds__(256) void nhwc_conv3x3_small_kernel(const SmallCout
       *reinterpret_cast<h8*>(&wl[t][o][k8*8]) = wv;
     }
     __syncthreads();
+#ifndef SMALL_W_LDS
+#define SMALL_W_LDS 0          // diagnostic builds: 1 = the weights as per-thread LDS reads (round 4)
+#endif
+    // the weights of a (tap, output channel, octet) are the same for every thread: wave-uniform global addresses
+    // (scalar loads, the products take them as scalar operands) instead of 288 16-byte LDS reads per thread and slab
+    if (!SMALL_W_LDS && cb + SLAB <= p.C && COUT <= p.Cout) {
 #pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      const _Float16* pp = patch[(r + t/3)*PC + c + t%3];
+      for (int t = 0; t < 9; ++t) {
+        const _Float16* pp = patch[(r + t/3)*PC + c + t%3];
+        const _Float16* wg = p.w16 + (long long)t*p.Cout*p.C + cb;
 #pragma unroll
-      for (int k = 0; k < SLAB; k += 8) {
-        const h8 v = *reinterpret_cast<const h8*>(pp + k);
+        for (int k = 0; k < SLAB; k += 8) {
+          const h8 v = *reinterpret_cast<const h8*>(pp + k);
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) {
-          const h8 wv = *reinterpret_cast<const h8*>(&wl[t][o][k]);
+          for (int o = 0; o < COUT; ++o) {
+            const h8 wv = *reinterpret_cast<const h8*>(wg + (long long)o*p.C + k);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[o] = __builtin_amdgcn_fdot2(h2{v[2*j], v[2*j + 1]}, h2{wv[2*j], wv[2*j + 1]}, acc[o], false);
+            for (int j = 0; j < 4; ++j)
+              acc[o] = __builtin_amdgcn_fdot2(h2{v[2*j], v[2*j + 1]}, h2{wv[2*j], wv[2*j + 1]}, acc[o], false);
+          }
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int t = 0; t < 9; ++t) {
+        const _Float16* pp = patch[(r + t/3)*PC + c + t%3];
+#pragma unroll
+        for (int k = 0; k < SLAB; k += 8) {
+          const h8 v = *reinterpret_cast<const h8*>(pp + k);
+#pragma unroll
+          for (int o = 0; o < COUT; ++o) {
+            const h8 wv = *reinterpret_cast<const h8*>(&wl[t][o][k]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[o] = __builtin_amdgcn_fdot2(h2{v[2*j], v[2*j + 1]}, h2{wv[2*j], wv[2*j + 1]}, acc[o], false);
+          }
         }
       }
     }
