@@ -689,6 +689,7 @@ class DiffusionUNet(nn.Module):
         assert decoder_type in ['standard', 'residual', 'skip']
         assert block_type in ['ncsn', 'adm']
         self._blocks, self._emb_key = None, None
+        self._emb_gidx, self._emb_gidx_key = None, None
         self._graphs = {}
         self.resampler = Resample(fir_kernel, buffer_padding=True)
         emb_channels = base_channels*emb_channel_mult
@@ -738,7 +739,7 @@ class DiffusionUNet(nn.Module):
         else:
             self.output_conv = nn.Conv2d(aux_out_channels, out_channels, 1)
 
-    def _block_embeddings(self, emb):
+    def _block_embeddings(self, emb, batch=None):
         """``linear(emb)`` of every U-Net block in ONE matrix product per network evaluation
         (they depend on the noise level only); each block reads its slice."""
         if self._blocks is None:
@@ -755,6 +756,29 @@ class DiffusionUNet(nn.Module):
         hip.check(hip.lib().brv_gemm_f32(
             hip.ptr(self._emb_w), hip.ptr(emb.contiguous()), hip.ptr(d), 1, O, N, K, K, K, N, 0, 0,
             0, 0, 1, 1, 0, 0, hip.ptr(self._emb_b), 0, hip.stream()), 'brv_gemm_f32')
+        if batch is not None and batch % N == 0 and not torch.cuda.is_current_stream_capturing() \
+                and self._emb_gidx_key != (N, batch, key):
+            # source index of every element of the blocks' (batch, out_features) slices laid out back to back: built on
+            # the host once per (noise-level batch, input batch) -- in the eager warm-up evaluation, never inside a
+            # HIP-graph capture
+            parts, o = [], 0
+            rows = (torch.arange(batch) % N).view(batch, 1)
+            for b in self._blocks:
+                n = b.linear.out_features
+                parts.append(((o + torch.arange(n).view(1, n))*N + rows).reshape(-1))
+                o += n
+            self._emb_gidx = torch.cat(parts).to(emb.device)
+            self._emb_gidx_key = (N, batch, key)
+        if batch is not None and self._emb_gidx_key == (N, batch, key):
+            # ONE gather for all blocks: transposed, expanded to the input batch, contiguous per block (a transpose-copy
+            # and an expand-copy per block before: 74 launches of an evaluation)
+            e_all = d.view(-1).index_select(0, self._emb_gidx)
+            o = 0
+            for b in self._blocks:
+                n = b.linear.out_features
+                b._e = e_all[o:o + batch*n].view(batch, n)
+                o += batch*n
+            return
         o = 0
         for b in self._blocks:
             n = b.linear.out_features
@@ -818,7 +842,7 @@ class DiffusionUNet(nn.Module):
     def _forward_nhwc(self, x, sigma):
         _ZERO_POOL['buf'] = None       # the arena is cleared inside this evaluation (and its HIP graph)
         emb = self.emb(sigma)
-        self._block_embeddings(emb)
+        self._block_embeddings(emb, x.shape[0])
         aux = x
         x = _h_conv3(_h_from_nchw(x), self.input_conv)
         skips = [x]
@@ -842,7 +866,7 @@ class DiffusionUNet(nn.Module):
         if _STATE['amp'] and self._nhwc_ok():
             return self._forward_nhwc(x, sigma)
         emb = self.emb(sigma)
-        self._block_embeddings(emb)
+        self._block_embeddings(emb, x.shape[0])
         aux = x
         x = _conv(x, self.input_conv)
         skips = [x]
