@@ -504,21 +504,42 @@ __global__ __launch_bounds__(256) void wgrad_small_fold_kernel(const float* __re
 }
 
 // unbiased standard deviation of each row (two passes, fp64 accumulators)
-__global__ __launch_bounds__(256) void row_std_kernel(const float* __restrict__ x,
-                                                      float* __restrict__ out, long long n) {
-  __shared__ double scr[8];
+// (1024 threads and 16-byte loads: one workgroup per row -- four rows at the benchmark batch -- with 256 threads and
+// scalar loads was two chains of 500 dependent loads per thread: 172 us per launch)
+__global__ __launch_bounds__(1024) void row_std_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ out, long long n) {
+  __shared__ double scr[16];
   __shared__ double mean_s;
   const float* xr = x + (long long)blockIdx.x*n;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  auto block_sum16 = [&](double v) {               // sum over the 16 waves; result valid in thread 0
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) scr[tid >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (tid == 0) for (int i = 0; i < 16; ++i) r += scr[i];
+    return r;
+  };
+  const bool vec = (n & 3) == 0 && (reinterpret_cast<unsigned long long>(xr) & 15) == 0;
+  const long long n4 = vec ? n >> 2 : 0;
+  const float4* x4 = reinterpret_cast<const float4*>(xr);
   double s = 0.0;
-  for (long long j = threadIdx.x; j < n; j += 256) s += xr[j];
-  const double tot = block_sum(s, scr);
-  if (threadIdx.x == 0) mean_s = tot/(double)n;
+  for (long long j = tid; j < n4; j += nt) { const float4 v = x4[j]; s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w); }
+  for (long long j = 4*n4 + tid; j < n; j += nt) s += xr[j];
+  const double tot = block_sum16(s);
+  if (tid == 0) mean_s = tot/(double)n;
   __syncthreads();
   const double mean = mean_s;
   double q = 0.0;
-  for (long long j = threadIdx.x; j < n; j += 256) { const double d = xr[j] - mean; q += d*d; }
-  const double var = block_sum(q, scr);
-  if (threadIdx.x == 0) out[blockIdx.x] = (float)sqrt(var/(double)(n - 1));
+  for (long long j = tid; j < n4; j += nt) {
+    const float4 v = x4[j];
+    const double a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+    q += (a*a + b*b) + (c*c + d*d);
+  }
+  for (long long j = 4*n4 + tid; j < n; j += nt) { const double d = xr[j] - mean; q += d*d; }
+  const double var = block_sum16(q);
+  if (tid == 0) out[blockIdx.x] = (float)sqrt(var/(double)(n - 1));
 }
 
 template <bool DIV>
@@ -737,7 +758,7 @@ int brv_col_sum_bf16(const void* x, float* out, void* scratch, int64_t batch, in
 }
 int brv_row_std(const float* x, float* out, int64_t rows, int64_t n, brv_stream_t stream) {
   if (rows < 1 || n < 2) return -1;
-  hipLaunchKernelGGL(row_std_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(row_std_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, x,
                      out, (long long)n);
   TG_OK(hipGetLastError());
   return 0;
