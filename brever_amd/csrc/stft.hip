@@ -1025,8 +1025,11 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
   const long long tiles = ((M + BM2 - 1)/BM2)*((N + BN2 - 1)/BN2)*batch;
   const long long red = (kbatch > 1 ? kbatch : 1)*((K + BK2 - 1)/BK2);
   long long ksplit = 1;
+#ifndef BRV_GEMM_SPLIT_TARGET
+#define BRV_GEMM_SPLIT_TARGET 512    // workgroups a split reduction aims for (diagnostic builds: 1024, 2048)
+#endif
   if (tiles < 128 && red >= 16 && !(flags & 2)) {
-    ksplit = 512/tiles;
+    ksplit = BRV_GEMM_SPLIT_TARGET/tiles;
     if (ksplit > red/4) ksplit = red/4;
     if (ksplit < 1) ksplit = 1;
   }
