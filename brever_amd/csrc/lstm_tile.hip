@@ -431,6 +431,239 @@ __global__ __launch_bounds__(512) void lstm_tile_bwd_bf16_kernel(const float* __
   }
 }
 
+// ---- four chains per workgroup (use_amp, round 5) ---------------------------------------------------------------
+// The 16-chain kernels above are bound by their gate math: a lane owns four (chain, unit) pairs -- 40 exponentials
+// and reciprocals per step and wave, 2.2 us per forward step -- and TF-GridNet's 1 056 .. 4 032 chains make only 66 ..
+// 252 workgroups. Here the roles of the MFMA operands are swapped (as in dccrn.hip's lstm_*_mv_kernel): A = the hidden
+// states, row m = chain m % 4 (every chain four times), B = 16 weight rows per instruction held in registers; lane
+// (j = lane >> 4, n = lane & 15) of wave w then finds the pre-activations of ALL four chains of unit 16 w + n in the four
+// registers of an accumulator and keeps chain j: ONE (chain, unit) pair per lane, the same 16 instructions per wave
+// and step, four times the workgroups. Interleaved gate layout as above (one 16- or 8-byte load / store per lane and
+// tensor); per-step loads invisible to hipcc's wait insertion, requested three steps ahead, counted vmcnt (only the
+// younger LOADS may be outstanding), LDS-only step barrier.
+constexpr int QC = 4;                 // chains per workgroup
+typedef unsigned int q4_u32x2 __attribute__((ext_vector_type(2)));
+template <bool IO16> struct Q4Raw { typedef f32x4 type; };
+template <> struct Q4Raw<true> { typedef q4_u32x2 type; };
+__device__ __forceinline__ void q4_load(f32x4& v, const float* p, long long i) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p + i) : "memory");
+}
+__device__ __forceinline__ void q4_load(q4_u32x2& v, const float* p, long long i) {
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(reinterpret_cast<const uint16_t*>(p) + i) : "memory");
+}
+__device__ __forceinline__ void q4_load1(float& v, const float* p, long long i) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p + i) : "memory");
+}
+__device__ __forceinline__ f32x4 q4_value(const f32x4& v) { return v; }
+__device__ __forceinline__ f32x4 q4_value(const q4_u32x2& u) {
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+               __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ void q4_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float q4_pick(const f32x4& v, int j) {
+  return j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : v[3];
+}
+
+template <bool IO16>
+__global__ __launch_bounds__(512) void lstm_q4_fwd_kernel(const float* __restrict__ gates_in,
+                                                          const float* __restrict__ w_hh,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ y, float* __restrict__ act,
+                                                          float* __restrict__ cs, int per_group, int T,
+                                                          int reverse_mask, long long y_ld, long long y_goff) {
+  typedef typename Q4Raw<IO16>::type Raw;
+  __shared__ __attribute__((aligned(16))) uint16_t hb[2][QC*HROW];
+  const int tiles = (per_group + QC - 1)/QC;
+  const int grp = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, j = lane >> 4, u = 16*w + n;            // this lane: chain j of the tile, unit u
+  const int cl = tile*QC + j;
+  const bool live = cl < per_group;
+  const long long chain = (long long)grp*per_group + (live ? cl : per_group - 1);
+  w_hh += (long long)grp*4*LH*LH;
+  // B[k = 32 kq + 8 j + i][n] = W_hh[g H + u][k]
+  bf16x8 wf[4][LH/32];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int kq = 0; kq < LH/32; ++kq) wf[g][kq] = load_frag(w_hh + (long long)(g*LH + u)*LH + 32*kq + 8*j, 1);
+  f32x4 bs;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bs[g] = bias ? bias[(long long)grp*4*LH + g*LH + u] : 0.f;
+  float c = 0.f;
+  for (int i = tid; i < 2*QC*HROW; i += 512) (&hb[0][0])[i] = 0;
+  const bool rev = (reverse_mask >> grp) & 1;
+  const int t_first = rev ? T - 1 : 0, t_inc = rev ? -1 : 1;
+  const long long gbase = chain*T*4*LH + 4*u;
+  float* yrow = y + (long long)(live ? cl : per_group - 1)*T*y_ld + grp*y_goff + u;
+  auto fetch = [&](int t, Raw& r) {
+    const int tt = t_first + (t < T ? t : T - 1)*t_inc;
+    q4_load(r, gates_in, gbase + (long long)tt*4*LH);
+  };
+  // per step: 1 load (step t + 3), then the stores: 3 younger loads may stay in flight
+  auto wait_set = [](Raw& r) { asm volatile("s_waitcnt vmcnt(3)" : "+v"(r) :: "memory"); };
+  // A fragment row m = chain m % 4: lane (m = lane & 15, j) reads 16 bytes of chain (lane & 3)
+  const int arow = (lane & 3)*HROW + 8*j;
+  auto step = [&](Raw& r, int t) {
+    wait_set(r);
+    const int tt = t_first + t*t_inc;
+    const uint16_t* hp = hb[t & 1] + arow;
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kq = 0; kq < LH/32; ++kq) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(hp + 32*kq);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wf[g][kq], acc[g], 0, 0, 0);
+    }
+    const f32x4 gin = q4_value(r);
+    const float ig = sigm(q4_pick(acc[0], j) + gin[0] + bs[0]), fg = sigm(q4_pick(acc[1], j) + gin[1] + bs[1]);
+    const float gg = tanh_fast(q4_pick(acc[2], j) + gin[2] + bs[2]), og = sigm(q4_pick(acc[3], j) + gin[3] + bs[3]);
+    c = fg*c + ig*gg;
+    const float hn = og*tanh_fast(c);
+    hb[(t + 1) & 1][j*HROW + u] = brv::f2bf(hn);
+    if (live) {
+      const long long st = chain*T + t;
+      yrow[tt*y_ld] = hn;
+      if (act) {
+        cs[st*LH + u] = c;
+        store4(act, st*4*LH + 4*u, f32x4{ig, fg, gg, og}, IO16);
+      }
+    }
+    q4_barrier();
+  };
+  Raw s0, s1, s2, s3;
+  fetch(0, s0); fetch(1, s1); fetch(2, s2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the counted wait needs full queues behind it)
+  __syncthreads();
+  int t = 0;
+  while (true) {
+    fetch(t + 3, s3); step(s0, t); if (++t >= T) break;
+    fetch(t + 3, s0); step(s1, t); if (++t >= T) break;
+    fetch(t + 3, s1); step(s2, t); if (++t >= T) break;
+    fetch(t + 3, s2); step(s3, t); if (++t >= T) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool IO16>
+__global__ __launch_bounds__(512) void lstm_q4_bwd_kernel(const float* __restrict__ act,
+                                                          const float* __restrict__ cs,
+                                                          const float* __restrict__ w_hh,
+                                                          const float* __restrict__ dy,
+                                                          float* __restrict__ dgates, int per_group, int T,
+                                                          int reverse_mask, long long dy_ld, long long dy_goff) {
+  typedef typename Q4Raw<IO16>::type Raw;
+  constexpr int K = 4*LH, GR = K + 8;              // gate gradients of a chain, k = gate H + unit (rows 16 B apart in banks)
+  __shared__ __attribute__((aligned(16))) uint16_t dgb[2][QC*GR];
+  __shared__ float part[8][QC][LH];
+  const int tiles = (per_group + QC - 1)/QC;
+  const int grp = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = lane & 15, j = lane >> 4, u = 16*w + n;            // this lane: chain j of the tile, unit u
+  const int cl = tile*QC + j;
+  const bool live = cl < per_group;
+  const long long chain = (long long)grp*per_group + (live ? cl : per_group - 1);
+  w_hh += (long long)grp*4*LH*LH;
+  // the reduction (K = 4 H) is split over the waves: wave w multiplies k = 64 w .. 64 w + 63 against all 128 units;
+  // B[k = 64 w + 32 ks + 8 j + i][n] = W_hh[k][16 nb + n]
+  bf16x8 wf[8][2];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      wf[nb][ks] = load_frag(w_hh + (long long)(64*w + 32*ks + 8*j)*LH + 16*nb + n, LH);
+  for (int i = tid; i < 2*QC*GR; i += 512) (&dgb[0][0])[i] = 0;
+  float dc = 0.f;
+  const bool rev = (reverse_mask >> grp) & 1;
+  const float* dyrow = dy + (long long)(live ? cl : per_group - 1)*T*dy_ld + grp*dy_goff + u;
+  struct Saved { Raw a; float cv, cp, dyv; };
+  auto fetch = [&](int t, Saved& v) {
+    const int tc = t > 0 ? t : 0;
+    const long long st = chain*T + tc;
+    const int tt = rev ? T - 1 - tc : tc;
+    q4_load(v.a, act, st*4*LH + 4*u);
+    q4_load1(v.cv, cs, st*LH + u);
+    q4_load1(v.cp, cs, (tc > 0 ? st - 1 : st)*LH + u);
+    q4_load1(v.dyv, dyrow, (long long)tt*dy_ld);
+  };
+  // per step: 4 loads (step t - 3), then one store: 12 younger loads may stay in flight
+  auto wait_set = [](Saved& v) {
+    asm volatile("s_waitcnt vmcnt(12)" : "+v"(v.a), "+v"(v.cv), "+v"(v.cp), "+v"(v.dyv) :: "memory");
+  };
+  const int arow = (lane & 3)*GR + 64*w + 8*j;
+  auto step = [&](Saved& cur, int t) {
+    // this wave's slice of the gate gradients of step t + 1 (zeros for the last step), all four chains
+    const uint16_t* gp = dgb[(t + 1) & 1] + arow;
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(gp), a1 = *reinterpret_cast<const bf16x8*>(gp + 32);
+    f32x4 p[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+      p[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[nb][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) p[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[nb][1], p[nb], 0, 0, 0);
+    // every lane group holds all eight blocks and (registers 0 .. 3) all four chains: group j hands over blocks
+    // 2 j, 2 j + 1
+    const f32x4 e0 = j == 0 ? p[0] : j == 1 ? p[2] : j == 2 ? p[4] : p[6];
+    const f32x4 e1 = j == 0 ? p[1] : j == 1 ? p[3] : j == 2 ? p[5] : p[7];
+#pragma unroll
+    for (int cc = 0; cc < QC; ++cc) { part[w][cc][32*j + n] = e0[cc]; part[w][cc][32*j + 16 + n] = e1[cc]; }
+    q4_barrier();
+    wait_set(cur);
+    const int tt = rev ? T - 1 - t : t;
+    float dht = cur.dyv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dht += part[i][j][u];
+    const f32x4 a = q4_value(cur.a);
+    const float ig = a[0], fg = a[1], gg = a[2], og = a[3];
+    const float cprev = t > 0 ? cur.cp : 0.f;
+    const float tc = tanh_fast(cur.cv);
+    const float dct = dc + dht*og*(1.f - tc*tc);
+    const f32x4 d = {dct*gg*ig*(1.f - ig), dct*cprev*fg*(1.f - fg), dct*ig*(1.f - gg*gg), dht*tc*og*(1.f - og)};
+    uint16_t* gw = dgb[t & 1] + j*GR + u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gw[g*LH] = brv::f2bf(d[g]);
+    if (live) store4(dgates, (chain*T + tt)*4*LH + 4*u, d, IO16);
+    dc = dct*fg;
+    q4_barrier();
+  };
+  Saved s0, s1, s2, s3;
+  fetch(T - 1, s0); fetch(T - 2, s1); fetch(T - 3, s2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int t = T - 1;
+  while (true) {
+    fetch(t - 3, s3); step(s0, t); if (--t < 0) break;
+    fetch(t - 3, s0); step(s1, t); if (--t < 0) break;
+    fetch(t - 3, s1); step(s2, t); if (--t < 0) break;
+    fetch(t - 3, s2); step(s3, t); if (--t < 0) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+#ifndef BRV_LSTM_Q4
+#define BRV_LSTM_Q4 1          // diagnostic builds: 0 = always the 16-chain kernels, 2 = always four chains per workgroup
+#endif
+// Four chains per workgroup or sixteen? One workgroup per CU either way (8 waves at 150 - 190 registers); a step
+// costs ~0.72 us with four chains and ~2.4 us with sixteen (measured on TF-GridNet's two shapes: 1 056 chains x 126
+// steps: 181 against 277 us forward; 4 032 chains x 33 steps: 144 against 103 us), and a launch runs
+// ceil(workgroups / CUs) rounds of T steps.
+int q4_pays(int64_t B, int64_t groups) {
+  if (BRV_LSTM_Q4 != 1) return BRV_LSTM_Q4 == 2;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n < 1) n = 256;
+    cus = n;
+  }
+  const int64_t per_group = B/groups;
+  const int64_t wg4 = groups*((per_group + QC - 1)/QC), wg16 = groups*((per_group + LC - 1)/LC);
+  const int64_t r4 = (wg4 + cus - 1)/cus, r16 = (wg16 + cus - 1)/cus;
+  return 0.72*(double)r4 < 2.4*(double)r16;
+}
+
 }  // namespace
 
 extern "C" {
@@ -444,6 +677,16 @@ int brv_lstm_tile_forward(const float* gates_in, const float* w_hh, const float*
   if (H != LH || B < 1 || T < 1 || groups < 1 || groups > 30 || B % groups) return -1;
   const int per_group = (int)(B/groups);
   const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
+  if (q4_pays(B, groups) && lowp) {
+    const unsigned g4 = (unsigned)(groups*((per_group + QC - 1)/QC));
+    if (lowp == 2)
+      hipLaunchKernelGGL(lstm_q4_fwd_kernel<true>, dim3(g4), dim3(512), 0, (hipStream_t)stream, gates_in, w_hh, bias,
+                         y, act, cs, per_group, (int)T, (int)reverse_mask, (long long)y_ld, (long long)y_group_offset);
+    else
+      hipLaunchKernelGGL(lstm_q4_fwd_kernel<false>, dim3(g4), dim3(512), 0, (hipStream_t)stream, gates_in, w_hh, bias,
+                         y, act, cs, per_group, (int)T, (int)reverse_mask, (long long)y_ld, (long long)y_group_offset);
+    return (int)hipGetLastError();
+  }
   if (lowp == 2)
     hipLaunchKernelGGL(lstm_tile_fwd_bf16_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream,
                        gates_in, w_hh, bias, y, act, cs, per_group, (int)T, (int)reverse_mask,
@@ -466,6 +709,16 @@ int brv_lstm_tile_backward(const float* act, const float* cs, const float* w_hh,
   if (H != LH || B < 1 || T < 1 || groups < 1 || groups > 30 || B % groups) return -1;
   const int per_group = (int)(B/groups);
   const unsigned grid = (unsigned)(groups*((per_group + LC - 1)/LC));
+  if (q4_pays(B, groups) && lowp) {
+    const unsigned g4 = (unsigned)(groups*((per_group + QC - 1)/QC));
+    if (lowp == 2)
+      hipLaunchKernelGGL(lstm_q4_bwd_kernel<true>, dim3(g4), dim3(512), 0, (hipStream_t)stream, act, cs, w_hh, dy,
+                         dgates, per_group, (int)T, (int)reverse_mask, (long long)dy_ld, (long long)dy_group_offset);
+    else
+      hipLaunchKernelGGL(lstm_q4_bwd_kernel<false>, dim3(g4), dim3(512), 0, (hipStream_t)stream, act, cs, w_hh, dy,
+                         dgates, per_group, (int)T, (int)reverse_mask, (long long)dy_ld, (long long)dy_group_offset);
+    return (int)hipGetLastError();
+  }
   if (lowp == 2)
     hipLaunchKernelGGL(lstm_tile_bwd_bf16_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream,
                        act, cs, w_hh, dy, dgates, per_group, (int)T, (int)reverse_mask,
