@@ -361,14 +361,13 @@ class _BiLSTMFn(torch.autograd.Function):
               lowp=lowp)
         dw_ih = torch.empty_like(w_ih)                # dg_g^T @ x
         _gemm(dg, x, dw_ih, 2, 4*H, I, NS, 4*H, I, I, NS*4*H, 0, 4*H*I, trans_a=1, lowp=lowp)
-        dw_hh = torch.zeros_like(w_hh)
+        dw_hh = torch.zeros_like(w_hh) if S == 1 else torch.empty_like(w_hh)
         if S > 1:
-            flat_dg, flat_y = dg.view(2, -1), y.view(-1)
             # forward direction: gate gradients of frames 1.. against hidden states of frames 0..;
-            # backward direction: frames ..S-2 against hidden states of frames 1..
-            for g, (dg_off, y_off) in enumerate(((4*H, 0), (0, 2*H + H))):
-                _gemm(flat_dg[g, dg_off:], flat_y[y_off:], dw_hh[g], 1, 4*H, H, S - 1, 4*H, 2*H, H,
-                      trans_a=1, kbatch=N, a_kbs=S*4*H, b_kbs=S*2*H, lowp=lowp)
+            # backward direction: frames ..S-2 against hidden states of frames 1.. -- ONE launch: the directions are the
+            # batch (from the forward direction's operands the backward one's lie NS 4H - 4H / 3H elements further)
+            _gemm(dg.view(-1)[4*H:], y.view(-1), dw_hh, 2, 4*H, H, S - 1, 4*H, 2*H, H, NS*4*H - 4*H, 3*H, 4*H*H,
+                  trans_a=1, kbatch=N, a_kbs=S*4*H, b_kbs=S*2*H, lowp=lowp)
         db = _column_sums(dg, NS, 4*H, batch=2)
         dw_ih, dw_hh, db = (_LSTMFunction._deinterleave(t, H) for t in (dw_ih, dw_hh, db))
         return dx, dw_ih, dw_hh, db, db.clone()
