@@ -110,6 +110,9 @@ class BreverBaseModel(nn.Module):
     def mark_params_changed(self):
         pass
 
+    def _after_backward(self):
+        """Hook of ``update`` between ``backward`` and the first read of a gradient (DCCRN joins its side stream)."""
+
     def gather_grads(self):
         """Flat gradient for ``FlatAdam``: the ``.grad`` tensors autograd left (separate allocations) are
         copied into one buffer by a single multi-tensor copy; parameters without a gradient count as zero."""
@@ -174,6 +177,7 @@ class BreverBaseModel(nn.Module):
         net = self if net is None else net
         optimizer = self.optimizer if optimizer is None else optimizer
         scaler.scale(loss).backward(retain_graph=retain_graph)
+        self._after_backward()
         from ..optim import FlatAdam
         sync = self._grad_sync
         if whole and isinstance(optimizer, FlatAdam) and getattr(optimizer, '_owner', None) is self \

@@ -950,8 +950,17 @@ class DCCRN(BreverBaseModel):
             _join_side(dev)              # (unconditional: cheap, and right after a backward pass that raised)
         return super().gather_grads()
 
-    def update(self, loss, scaler):
-        super().update(loss, scaler, grad_clip=5.0)
+    def update(self, loss, scaler, **kwargs):
+        kwargs.setdefault('grad_clip', 5.0)
+        super().update(loss, scaler, **kwargs)
+
+    def _after_backward(self):
+        """Called by ``BreverBaseModel.update`` right behind ``backward``: whichever branch reads the gradients next
+        (the flat gather, the packed all-reduce of a sub-network optimizer, ``clip_grad_norm_``) finds the side
+        stream's weight gradients complete -- also after a backward pass whose engine callback never ran."""
+        dev = next(self.parameters()).device
+        if dev.type == 'cuda':
+            _join_side(dev)
 
     @property
     def latency(self):

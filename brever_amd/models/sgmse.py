@@ -34,6 +34,11 @@ SolverRegistry = Registry('solver')
 # ------------------------------------------------------------------------------------------
 _STATE = {'amp': False, 'graph': False, 'pver': None}
 _GN_SCRATCH = {}
+# Parameters of these models are also written through raw pointers (FlatAdam's fused clip + Adam launch) and through
+# ``param.data`` (EMA), neither of which moves ``Tensor._version``: every derived copy of a weight (packed fp16
+# convolution weights, the stacked q / k / v and embedding matrices, captured HIP graphs) is keyed on this counter
+# too. ``SGMSEp.mark_params_changed`` -- called by FlatAdam.step, EMA and the trainer's checkpoint loads -- bumps it.
+_PARAM_EPOCH = [0]
 
 
 class hip_autocast:
@@ -58,7 +63,7 @@ class hip_autocast:
 
 def _packed_weight(mod):
     w = mod.weight
-    key = (w.data_ptr(), w._version)
+    key = (w.data_ptr(), w._version, _PARAM_EPOCH[0])
     if getattr(mod, '_brv_wp_key', None) != key:
         Cout, Cin, k, _ = w.shape
         n = hip.lib().brv_conv2d_packed_size(Cout, Cin, k)
@@ -292,7 +297,7 @@ def _h_gn_fold(a, mod, add=None, adm=None):
 
 def _h_packed3(mod):
     w = mod.weight
-    key = (w.data_ptr(), w._version)
+    key = (w.data_ptr(), w._version, _PARAM_EPOCH[0])
     if getattr(mod, '_brv_hp_key', None) != key:
         Cout, Cin, k, _ = w.shape
         n = hip.lib().brv_conv_nhwc_packed_size(Cout, Cin, k)
@@ -341,7 +346,7 @@ def _h_conv1(a, mod, out_scale=1.0):
     w = mod.weight
     b = a.second
     C2 = b.C if b is not None else 0
-    key = (w.data_ptr(), w._version, a.C, C2)
+    key = (w.data_ptr(), w._version, _PARAM_EPOCH[0], a.C, C2)
     if getattr(mod, '_brv_h1_key', None) != key:
         n = hip.lib().brv_nhwc_conv1x1_packed_size(mod.out_channels, a.C, C2)
         wp = torch.empty(n, dtype=torch.float16, device=w.device)
@@ -405,7 +410,7 @@ def _h_small_conv(a, mod, fold=None, silu=False, y_in=None):
     a = _h_single(a)
     B, H, W, Cs = a.t.shape
     w = mod.weight
-    key = (w.data_ptr(), w._version)
+    key = (w.data_ptr(), w._version, _PARAM_EPOCH[0])
     if getattr(mod, '_brv_hs_key', None) != key:
         w16 = torch.empty(9*w.shape[0]*w.shape[1], dtype=torch.float16, device=w.device)
         hip.check(hip.lib().brv_nhwc_conv3x3_small_pack(hip.ptr(w.detach().contiguous()), hip.ptr(w16),
@@ -503,7 +508,7 @@ class AttentionBlock(nn.Module):
     def _qkv_module(self):
         """conv_query / conv_key / conv_value stacked along the output channels (rebuilt when a weight changes)."""
         mods = (self.conv_query, self.conv_key, self.conv_value)
-        key = tuple((t.data_ptr(), t._version) for m in mods for t in (m.weight, m.bias))
+        key = tuple((t.data_ptr(), t._version) for m in mods for t in (m.weight, m.bias)) + (_PARAM_EPOCH[0],)
         if getattr(self, '_qkv_key', None) != key:
             import types
             self._qkv = types.SimpleNamespace(
@@ -705,7 +710,7 @@ class DiffusionUNet(nn.Module):
         assert decoder_type in ['standard', 'residual', 'skip']
         assert block_type in ['ncsn', 'adm']
         self._blocks, self._emb_key = None, None
-        self._emb_gidx, self._emb_gidx_key = None, None
+        self._emb_gidx = {}             # (N, batch) -> index tensor; lives as long as any graph that captured it
         self._graphs = {}
         self.resampler = Resample(fir_kernel, buffer_padding=True)
         emb_channels = base_channels*emb_channel_mult
@@ -761,7 +766,7 @@ class DiffusionUNet(nn.Module):
         if self._blocks is None:
             self._blocks = [m for m in self.modules() if isinstance(m, UNetBlock)]
         key = tuple((b.linear.weight.data_ptr(), b.linear.weight._version, b.linear.bias._version)
-                    for b in self._blocks)
+                    for b in self._blocks) + (_PARAM_EPOCH[0],)
         if self._emb_key != key:
             self._emb_w = torch.cat([b.linear.weight.detach() for b in self._blocks]).contiguous()
             self._emb_b = torch.cat([b.linear.bias.detach() for b in self._blocks]).contiguous()
@@ -772,23 +777,26 @@ class DiffusionUNet(nn.Module):
         hip.check(hip.lib().brv_gemm_f32(
             hip.ptr(self._emb_w), hip.ptr(emb.contiguous()), hip.ptr(d), 1, O, N, K, K, K, N, 0, 0,
             0, 0, 1, 1, 0, 0, hip.ptr(self._emb_b), 0, hip.stream()), 'brv_gemm_f32')
-        if batch is not None and batch % N == 0 and not torch.cuda.is_current_stream_capturing() \
-                and self._emb_gidx_key != (N, batch, key):
+        gidx = self._emb_gidx.get((N, batch)) if batch is not None else None
+        if gidx is None and batch is not None and batch % N == 0 and not torch.cuda.is_current_stream_capturing():
             # source index of every element of the blocks' (batch, out_features) slices laid out back to back: built on
             # the host once per (noise-level batch, input batch) -- in the eager warm-up evaluation, never inside a
-            # HIP-graph capture
+            # HIP-graph capture. The index depends on the block widths only (fixed at construction), and a captured
+            # graph bakes the tensor's address in: entries are never replaced, only dropped together with the graphs.
             parts, o = [], 0
             rows = (torch.arange(batch) % N).view(batch, 1)
             for b in self._blocks:
                 n = b.linear.out_features
                 parts.append(((o + torch.arange(n).view(1, n))*N + rows).reshape(-1))
                 o += n
-            self._emb_gidx = torch.cat(parts).to(emb.device)
-            self._emb_gidx_key = (N, batch, key)
-        if batch is not None and self._emb_gidx_key == (N, batch, key):
+            if len(self._emb_gidx) >= 8:
+                self._emb_gidx.clear()
+                self._graphs.clear()
+            gidx = self._emb_gidx[(N, batch)] = torch.cat(parts).to(emb.device)
+        if gidx is not None:
             # ONE gather for all blocks: transposed, expanded to the input batch, contiguous per block (a transpose-copy
             # and an expand-copy per block before: 74 launches of an evaluation)
-            e_all = d.view(-1).index_select(0, self._emb_gidx)
+            e_all = d.view(-1).index_select(0, gidx)
             o = 0
             for b in self._blocks:
                 n = b.linear.out_features
@@ -1223,6 +1231,11 @@ class EDMSolver:
 class SGMSEp(BreverBaseModel):
     _fused_adam = True       # clip + Adam as brv_clip_adam_step2 on one flat buffer (models/base.py)
 
+    def mark_params_changed(self):
+        """Parameters were written without touching ``Tensor._version`` (FlatAdam's raw-pointer launch, EMA's
+        ``param.data.copy_``): every cached copy derived from a weight and every captured graph is stale."""
+        _PARAM_EPOCH[0] += 1
+
     def __init__(
         self,
         stft_frame_length: int = 512,
@@ -1370,7 +1383,7 @@ class SGMSEp(BreverBaseModel):
             x = x[..., :-1, :]
         net = self.model.net
         first = next(net.parameters())
-        _STATE['pver'] = (first.data_ptr(), sum(p._version for p in net.parameters()))
+        _STATE['pver'] = (first.data_ptr(), sum(p._version for p in net.parameters()), _PARAM_EPOCH[0])
         _STATE['graph'] = os.environ.get('BRV_NO_GRAPH', '0') != '1'
         try:
             with hip_autocast(use_amp):

@@ -148,14 +148,36 @@ class GradSynchronizer:
 def all_reduce_mean_grads(params, sync):
     """Mean over ranks of the ``.grad`` tensors of ``params`` as ONE collective on a packed copy (the generic
     branch of ``BreverBaseModel.update`` for a flat model: a sub-network, another optimizer). ``sync`` is the
-    ``GradSynchronizer`` (sums, returns 1/world)."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    ``GradSynchronizer`` (sums, returns 1/world).
+
+    EVERY parameter that requires a gradient takes its slot of the packed buffer, in ``params`` order, zeros where
+    this rank has no ``.grad`` (a data-dependent branch, a sub-network unused on this rank): the ranks' buffers then
+    have the same length and layout whatever their None sets are -- packing only the existing gradients made
+    ``all_reduce`` hang or sum misaligned slices. A parameter without a gradient here receives the mean
+    of the others' (as DDP does with ``find_unused_parameters``) when any rank had one."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    flat.mul_(sync(flat))
+    ref = next((p.grad for p in params if p.grad is not None), None)
+    dtype = ref.dtype if ref is not None else params[0].dtype
+    device = ref.device if ref is not None else params[0].device
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=dtype, device=device)
     off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view(g.shape))
+    have = torch.zeros(len(params), dtype=dtype, device=device)
+    for i, p in enumerate(params):
+        n = p.numel()
+        if p.grad is not None:
+            flat[off:off + n].copy_(p.grad.reshape(-1))
+            have[i] = 1
+        off += n
+    packed = torch.cat([flat, have])             # (the presence flags ride in the same collective)
+    packed.mul_(sync(packed))
+    any_rank = (packed[flat.numel():] > 0).tolist()
+    off = 0
+    for i, p in enumerate(params):
+        n = p.numel()
+        if p.grad is not None:
+            p.grad.copy_(packed[off:off + n].view(p.shape))
+        elif any_rank[i]:
+            p.grad = packed[off:off + n].view(p.shape).clone()
         off += n

@@ -11,7 +11,9 @@ the step) and in eval mode on a seeded input.
 ``OracleDCCRN(emulate_bf16=True)`` restates the arithmetic of the HIP path under ``use_amp`` (brever_amd/models/
 dccrn.py): the operands of the convolutions' three matrix products (y from x and W, dx from dy and W, dW from dy and
 x) and of the LSTM input projections (gates from x and W_ih, dx and dW_ih from the gate gradients) are rounded to
-bf16, everything else -- accumulation, bias sums, batch norms, the recurrences, the Linear layers -- stays fp32. It is
+bf16, and for lstm_channels = 128 (the width the HIP path runs on the bf16 matrix pipe) the hidden state and W_hh in
+the recurrent product of every step and the gate gradients and W_hh in its adjoint; everything else -- accumulation, bias
+sums, batch norms, the gate math and cell state, the recurrences of other widths, the Linear layers -- stays fp32. It is
 the yardstick of tests/test_gpu_sizes.py (HIP error <= 1.5 x this emulation's own error, per tensor); with the flag off the module
 is the pinned fp32 restatement, bit for bit.
 """
@@ -163,6 +165,25 @@ class _ComplexLSTMLayer(ComplexWrapper):                           # dccrn.py:33
         """nn.LSTM whose input projection runs on bf16-rounded operands: the projection is formed here and handed
         to the same LSTM through an identity input matrix (exact in fp32: one non-zero term per sum)."""
         gates = _qb(_qf(x) @ _qf(m.weight_ih_l0).t())
+        if m.hidden_size == 128:
+            # H = 128 is the width whose recurrent product the HIP path runs on the bf16 matrix pipe under use_amp
+            # (csrc/dccrn.hip lstm_fwd_mv_kernel / lstm_bwd_mv_kernel, round 5): the hidden state and W_hh are
+            # rounded as operands of the step's product, the gate gradients and W_hh in its adjoint; accumulation,
+            # gate math and the cell state stay fp32. An explicit loop (the same one tests/test_gpu.py checks the
+            # kernels against), differentiated by autograd: _qb rounds the gradient that enters the product.
+            B, T, H = x.shape[0], x.shape[1], m.hidden_size
+            w = _qf(m.weight_hh_l0)
+            bias = m.bias_ih_l0 + m.bias_hh_l0
+            h = gates.new_zeros(B, H)
+            c = gates.new_zeros(B, H)
+            ys = []
+            for t in range(T):
+                pre = gates[:, t] + bias + _qb(_qf(h) @ w.t())
+                i, f, g, o = pre.chunk(4, dim=-1)
+                c = torch.sigmoid(f)*c + torch.sigmoid(i)*torch.tanh(g)
+                h = torch.sigmoid(o)*torch.tanh(c)
+                ys.append(h)
+            return torch.stack(ys, dim=1)
         eye = torch.eye(gates.shape[-1], dtype=gates.dtype)
         out, _, _ = torch._VF.lstm(gates, (gates.new_zeros(1, x.shape[0], m.hidden_size),
                                         gates.new_zeros(1, x.shape[0], m.hidden_size)),

@@ -1885,6 +1885,55 @@ def test_sgmse_training_matches_reference(golden_dir, tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('use_amp', [False, True])
+def test_sgmse_enhance_follows_weights_written_by_the_fused_optimizer(golden_dir, use_amp):
+    """FlatAdam writes the parameters through a raw pointer and EMA through ``param.data``,
+    neither moves ``Tensor._version``; the packed fp16 weights, the stacked q / k / v matrix, the stacked embedding
+    matrix and the captured HIP graph of ``enhance`` were keyed on it and stayed at the first call's weights.
+    ``enhance`` after train steps must equal ``enhance`` of a FRESH model (no caches) holding the same weights, in
+    fp32 and under ``use_amp``, and differ from the output before the steps."""
+    from helpers import sgmse_case
+    g = np.load(os.path.join(golden_dir, 'sgmse.npz'))
+    dev = _cuda()
+    tag = 'pc'
+    model, *_rest, draws = sgmse_case(g, tag)
+    model = model.to(dev).eval()
+    wav = torch.from_numpy(g[f'{tag}_wav']).to(dev)
+
+    def enhance(m):
+        it = iter(draws)
+        m._noise_source = lambda shape, complex_: next(it)
+        return m.enhance(wav, use_amp=use_amp).clone()
+    tol = 2e-2 if use_amp else 1e-5
+    before = enhance(model)
+    assert rel(enhance(model), before) <= tol                 # (replayed graph, cached operands: same weights)
+    model.train()
+    model._draw_t = lambda n, device: torch.from_numpy(g[f'{tag}_train_t']).to(device)
+    model._draw_noise = lambda x0: torch.from_numpy(g[f'{tag}_train_noise']).to(x0.device)
+    batch = torch.from_numpy(g[f'{tag}_train_batch']).to(dev)
+    lengths = torch.from_numpy(g[f'{tag}_train_lengths']).to(dev)
+    for group in model.optimizers().param_groups:
+        group['lr'] = 1e-2                                     # far enough to be visible through the fp16 path
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    for _ in range(3):
+        model.train_step(batch, lengths, False, scaler)
+    model.eval()
+    after = enhance(model)
+    fresh = sgmse_case(g, tag)[0].to(dev).eval()
+    fresh.load_state_dict(model.state_dict())
+    want = enhance(fresh)
+    assert rel(after, want) <= tol, rel(after, want)
+    assert rel(after, before) > 10*tol, rel(after, before)
+    # EMA-style write through ``param.data`` + the hook the EMA module calls
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data.mul_(0.9)
+    model.mark_params_changed()
+    fresh.load_state_dict(model.state_dict())
+    assert rel(enhance(model), enhance(fresh)) <= tol
+
+
+@pytest.mark.gpu
 def test_entry_points_sgmse(tmp_path):
     """SGMSE+ (BASELINE config 4, narrow network, 4 sampler steps) through init -> train ->
     test: training on the HIP score network, validation / test through the reverse sampler."""

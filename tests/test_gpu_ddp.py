@@ -29,9 +29,15 @@ def _free_port():
 def _build(kind, dev, hooks):
     if kind == 'dccrn':
         from brever_amd.models.dccrn import DCCRN
+        prev = DCCRN._fused_adam
         if hooks:             # a model without the flat buffer: GradSynchronizer installs per-parameter hooks
             DCCRN._fused_adam = False
-        net = DCCRN(channels=[8, 16, 32, 32], lstm_channels=32).to(dev)
+        try:                  # (the class attribute is restored whatever construction does: ADVICE r5)
+            net = DCCRN(channels=[8, 16, 32, 32], lstm_channels=32).to(dev)
+        finally:
+            DCCRN._fused_adam = prev
+        if hooks:
+            net._fused_adam = False
         n = 12000
     else:
         from brever_amd.models import TFGridNet
@@ -107,9 +113,6 @@ def test_two_ranks_equal_the_mean_of_the_half_batch_gradients(tmp_path, kind, am
     dev = torch.device('cuda', 0)
     torch.manual_seed(100)
     net, batch, lengths = _build(kind, dev, hooks)
-    if hooks:
-        from brever_amd.models.dccrn import DCCRN
-        DCCRN._fused_adam = True
     scaler = torch.amp.GradScaler('cuda', enabled=False)
     first = None
     for _ in range(2):

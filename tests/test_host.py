@@ -635,3 +635,40 @@ def test_launch_opts_come_from_the_environment_on_the_host(monkeypatch):
         src = open(os.path.join(root, 'brever_amd', 'csrc', fname)).read()
         src = re.sub(r'#ifdef BRV_DIAG.*?#endif', '', src, flags=re.S)
         assert 'getenv' not in src, fname
+
+
+def test_side_stream_is_refused_once_a_post_accumulate_hook_is_registered():
+    """`_side_allowed` reads torch's private `_post_accumulate_grad_hooks`; if torch renames it the
+    per-parameter all-reduce of GradSynchronizer would run beside unfinished side-stream gradients again."""
+    from brever_amd.models import dccrn as D
+    p = torch.nn.Parameter(torch.zeros(3))
+    q = torch.nn.Parameter(torch.zeros(3))
+    if not D._WGRAD_SIDE:
+        pytest.skip('side stream switched off by the environment')
+    assert D._side_allowed([p, q])
+    p.register_post_accumulate_grad_hook(lambda t: None)
+    assert not D._side_allowed([p, q])
+    q.grad = torch.zeros(3)                      # a gradient to accumulate into in place
+    assert not D._side_allowed([q])
+
+
+def test_all_reduce_mean_grads_packs_every_parameter_in_a_fixed_order():
+    """ranks with different sets of missing `.grad` tensors must still pack buffers of one length and
+    layout. `sync` here is a stand-in that records the buffer and plays a second rank."""
+    from brever_amd.parallel import all_reduce_mean_grads
+    a, b, c = (torch.nn.Parameter(torch.zeros(n)) for n in (2, 3, 4))
+    a.grad = torch.tensor([1., 2.])
+    c.grad = torch.tensor([1., 1., 1., 1.])
+    seen = {}
+
+    def sync(flat):
+        seen['n'] = flat.numel()
+        # the other rank: gradient of b = 4s, none for a and c (flags 0, 1, 0)
+        other = torch.cat([torch.zeros(2), torch.full((3,), 4.), torch.zeros(4), torch.tensor([0., 1., 0.])])
+        flat.add_(other)
+        return 0.5
+    all_reduce_mean_grads([a, b, c], sync)
+    assert seen['n'] == 2 + 3 + 4 + 3
+    assert torch.equal(a.grad, torch.tensor([0.5, 1.0]))
+    assert torch.equal(b.grad, torch.full((3,), 2.))          # missing here, present elsewhere: receives the mean
+    assert torch.equal(c.grad, torch.full((4,), 0.5))
