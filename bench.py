@@ -15,6 +15,13 @@ sampler -> BreverDataLoader collate -> pinned double-buffered async H2D), `roofl
 kernel with the largest share plus `kernels` (every launch label >= 5 % of the step with its
 algorithmic and measured HBM bytes), `allreduce_exposed_ms` for N > 1, and `cpu_baseline`
 (N = 1 only): the CPU oracle (oracle/) on the same configuration, B = 16, fp32 and CPU-bf16.
+
+Measurement hygiene: whatever --warmup says, the warm-up runs for at least MIN_WARMUP_S
+seconds of steps (`warmup_effective`: the clocks and the power state have settled when the timed region starts);
+`value` is the --steps block as before; `value_repeats` are five further blocks of --steps (min / median /
+max); `clock` holds sclk / mclk / power / temperature read from sysfs before and after the timed region.
+`other_configs` (N = 1 only, --no-other-configs to skip): BASELINE.json configs[3] (DCCRN bf16 train step,
+16 x 4 s) and configs[4] (SGMSE+ fp16 30-step enhance, batch 1 and 8) timed in the same run.
 """
 import argparse
 import json
@@ -46,6 +53,68 @@ BATCH = 16
 FLOP_PER_UTT_TRAIN = 116.46e9       # 3 x 38.82 GFLOP forward
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_MFMA_TFLOPS = 2500.0           # dense bf16 MFMA
+MIN_WARMUP_S = 1.5                  # seconds of steps before the timed region, whatever --warmup says
+N_REPEATS = 5                       # further blocks of --steps behind the one `value` is taken from
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _sysfs_device(index):
+    """sysfs directory of the amdgpu device behind cuda:<index> (matched by PCI address), or None."""
+    import glob
+    want = None
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        want = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}'
+    except Exception:           # noqa: BLE001  (older torch: no PCI fields)
+        pass
+    cards = [d for d in sorted(glob.glob('/sys/class/drm/card*/device')) if os.path.exists(d + '/pp_dpm_sclk')]
+    if want is not None:
+        for d in cards:
+            if os.path.basename(os.path.realpath(d)).startswith(want):
+                return d
+    return cards[index] if len(cards) > index else (cards[0] if cards else None)
+
+
+def read_clock(index):
+    """Clock / power / temperature of the device right now, from sysfs (no subprocess: microseconds, so it can sit
+    directly in front of and behind the timed region): the active level of pp_dpm_sclk / pp_dpm_mclk, hwmon's
+    instantaneous sclk (freq1_input), board power and its cap, edge / junction / memory temperatures. Fields the
+    box does not expose are left out; {} when there is no amdgpu sysfs node at all."""
+    import glob
+    d = _sysfs_device(index)
+    if d is None:
+        return {}
+    out = {'sysfs': os.path.basename(os.path.realpath(d))}
+    for key, name in (('sclk_mhz', 'pp_dpm_sclk'), ('mclk_mhz', 'pp_dpm_mclk')):
+        txt = _read(f'{d}/{name}')
+        if txt:
+            levels = [ln for ln in txt.splitlines() if ln.strip()]
+            act = [ln for ln in levels if ln.rstrip().endswith('*')]
+            try:
+                out[key] = float((act or levels[-1:])[0].split(':')[1].lower().replace('mhz', '').replace('*', ''))
+                out[key + '_max'] = max(float(ln.split(':')[1].lower().replace('mhz', '').replace('*', ''))
+                                        for ln in levels)
+            except (IndexError, ValueError):
+                pass
+    for hw in glob.glob(f'{d}/hwmon/hwmon*'):
+        for key, name, scale in (('sclk_now_mhz', 'freq1_input', 1e-6), ('power_w', 'power1_average', 1e-6),
+                                 ('power_w', 'power1_input', 1e-6), ('power_cap_w', 'power1_cap', 1e-6),
+                                 ('temp_edge_c', 'temp1_input', 1e-3), ('temp_junction_c', 'temp2_input', 1e-3),
+                                 ('temp_mem_c', 'temp3_input', 1e-3)):
+            txt = _read(f'{hw}/{name}')
+            if txt and key not in out:
+                try:
+                    out[key] = float(txt)*scale
+                except ValueError:
+                    pass
+    return out
 
 
 def make_batches(n_batches, rank, device):
@@ -140,7 +209,7 @@ KERNEL_OF_LABEL = {
     'pw2_dgrad': 'gemm_ws_kernel<256,', 'pw1_dgrad': ['pw1_dgrad_ws_kernel', 'gemm_rows_kernel<128, 3, 5>'],
     'pw1_wgrad': ('gemm_wgrad_kernel<128, 0>', 'largest'), 'clip_adam': 'clip_adam_kernel',
 }
-PMC_FILES = ('r05_pmc_hbm_traffic.json', 'r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
+PMC_FILES = ('r06_pmc_hbm_traffic.json', 'r05_pmc_hbm_traffic.json', 'r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json', 'r01_pmc_hbm_traffic.json')
 
 
 def pmc_traffic(label):
@@ -166,7 +235,7 @@ def pmc_traffic(label):
     return None, None
 
 
-SQ_FILES = ('r05_sq_counters.json', 'r04_sq_counters.json')
+SQ_FILES = ('r06_sq_counters.json', 'r05_sq_counters.json', 'r04_sq_counters.json')
 
 
 def sq_counters(label):
@@ -313,6 +382,113 @@ def fp32_path(device, steps=8, warmup=2):
                     'bitwise repeatable; round 2: 278 utterances/s'}
 
 
+ROWS_ROOFLINE_FILES = ('r06_rows_roofline.json', 'r05_rows_roofline.json')
+
+
+def rows_dominant_kernel(row):
+    """`roofline` object of the dominant kernel of a widened row from the committed per-round profile
+    (profiles/rNN_rows_roofline.json, one JSON line per row: tools/profile_rows.sh -> tools/rows_roofline.py: PMC
+    bytes per launch over the rocprofv3 --stats average duration). bench.py cannot run the profiler on itself."""
+    for fname in ROWS_ROOFLINE_FILES:
+        path = os.path.join(ROOT, 'profiles', fname)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            for ln in f:
+                ln = ln.strip()
+                if not ln:
+                    continue
+                rec = json.loads(ln)
+                if rec.get('row') == row and rec.get('roofline'):
+                    return dict(rec['roofline'], source=f'profiles/{fname} (rocprofv3 --kernel-trace --stats + --pmc '
+                                                        'FETCH_SIZE / WRITE_SIZE passes of the same workload)')
+    return None
+
+
+def _timed_steps(fn, steps, min_warm_s=1.0, warm_steps=3):
+    """(seconds per call, warm-up calls): `warm_steps` calls, then more until `min_warm_s` seconds have run, then
+    `steps` timed calls between two synchronisations."""
+    t0 = time.perf_counter()
+    n = 0
+    while n < warm_steps or time.perf_counter() - t0 < min_warm_s:
+        fn()
+        torch.cuda.synchronize()
+        n += 1
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0)/steps, n
+
+
+def other_configs(device, dccrn_steps=30, sgmse_repeats=3):
+    """BASELINE.json configs[3] and configs[4] in the driver-run line (the Conv-TasNet step
+    stays the headline `value`). Each entry has the fields of the top-level line: value / unit / ms_per_step /
+    dtype / config.workload, and `roofline` = whole-workload MFMA fraction (algorithmic FLOPs of SURVEY.md 8d over
+    the measured wall time) with the row's dominant kernel from the committed profile of the round.
+
+    * configs[3] DCCRN (brever/models/dccrn/dccrn.py:28-142), defaults, 3 671 053 parameters, bf16 matrix products
+      (`use_amp`), train step = STFT -> complex Conv2d encoder -> complex LSTM -> decoder -> mask -> iSTFT -> SNR
+      loss -> backward -> clip 5.0 + Adam on 16 x 4 s utterances resident in HBM;
+    * configs[4] SGMSE+ (brever/models/sgmse/sgmse.py:178-193), defaults, 65.6 M parameters, fp16-MFMA convolutions
+      (`use_amp`): `enhance` = STFT -> 30-step reverse SDE with the predictor-corrector sampler (60 network
+      evaluations) -> iSTFT overlap-add, at batch 1 (latency) and batch 8 (throughput)."""
+    from brever_amd.models import ModelRegistry
+    out = []
+    L = int(SECONDS*FS)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    # ---- DCCRN ------------------------------------------------------------------------------------
+    torch.manual_seed(0)
+    model = ModelRegistry.get('dccrn')().to(device)
+    model.train()
+    wav = 0.1*torch.randn(BATCH, 2, 2, L, device=device)                    # (B, sources, channels, L)
+    x = torch.stack([model.transform(w) for w in wav])
+    lengths = torch.full((BATCH,), x.shape[-1], device=device)
+    dt, nwarm = _timed_steps(lambda: model.train_step(x, lengths, True, scaler), dccrn_steps)
+    tflops = BATCH/dt*3*51.2e9/1e12                 # SURVEY.md 8(d): 51.2 GFLOP per 4 s utterance forward, x 3
+    out.append({
+        'metric': 'utterances/sec (4 s @16 kHz) DCCRN train', 'value': BATCH/dt, 'unit': 'utterances/s',
+        'n_gpus': 1, 'steps': dccrn_steps, 'warmup': nwarm, 'ms_per_step': dt*1e3, 'higher_is_better': True,
+        'dtype': 'bf16', 'data': 'synthetic', 'vs_baseline': None,
+        'config': {'baseline_config': 'configs[3]: DCCRN (complex STFT Conv2d+LSTM) bf16, 1xMI355X, STFT/iSTFT HIP kernels',
+                   'workload': 'DCCRN defaults (3 671 053 params) train step: STFT 512/128 -> complex Conv2d + LSTM -> '
+                               'iSTFT, fwd + SNR loss + bwd + clip 5.0 + Adam, 16 x 4 s @ 16 kHz utterances resident in HBM',
+                   'global_batch': BATCH, 'seq_len': L},
+        'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': tflops/PEAK_MFMA_TFLOPS, 'traffic': None,
+                     'scope': 'whole workload: 3 x 51.2 GFLOP per utterance (SURVEY.md 8d) over the measured wall time',
+                     'dominant_kernel': rows_dominant_kernel('dccrn_bf16')}})
+    del model, x, wav
+    torch.cuda.empty_cache()
+    # ---- SGMSE+ -----------------------------------------------------------------------------------
+    torch.manual_seed(0)
+    nsteps = 30
+    model = ModelRegistry.get('sgmsep')(solver_num_steps=nsteps).to(device).eval()
+    for batch in (1, 8):
+        wav = 0.1*torch.randn(batch, 2, L, device=device)
+        dt, nwarm = _timed_steps(lambda: model.enhance(wav, use_amp=True), sgmse_repeats, min_warm_s=0.0, warm_steps=2)
+        tflops = batch*2*nsteps*1.04/dt             # SURVEY.md 8(d): 1.04 TFLOP per network evaluation and 4 s utterance
+        out.append({
+            'metric': 'utterances/sec SGMSE+ enhance (30-step reverse SDE)', 'value': batch/dt, 'unit': 'utterances/s',
+            'n_gpus': 1, 'steps': sgmse_repeats, 'warmup': nwarm, 'ms_per_step': dt*1e3, 'higher_is_better': True,
+            'dtype': 'fp16', 'data': 'synthetic', 'vs_baseline': None,
+            's_per_utterance': dt/batch, 'ms_per_network_evaluation': dt/(2*nsteps)*1e3, 'rtf': dt/batch/SECONDS,
+            'config': {'baseline_config': 'configs[4]: SGMSE+ score-model inference (30-step reverse SDE) fp16, 1xMI355X, '
+                                          'iSTFT overlap-add kernel',
+                       'workload': f'SGMSE+ defaults (65.6 M params) enhance: STFT -> 30-step reverse SDE, PC sampler = 60 '
+                                   f'network evaluations (HIP-graph replay) -> iSTFT overlap-add, {batch} x 4 s @ 16 kHz, '
+                                   'fp16-MFMA convolutions; one step = one enhance call',
+                       'global_batch': batch, 'seq_len': L},
+            'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': tflops/PEAK_MFMA_TFLOPS, 'traffic': None,
+                         'scope': 'whole workload: 60 evaluations x 1.04 TFLOP per utterance (SURVEY.md 8d) over the measured '
+                                  'wall time',
+                         'dominant_kernel': rows_dominant_kernel(f'sgmse_b{batch}')}})
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def trainer_sampler(rank, world, n_steps):
     """Dataset and batch sampler of `through_trainer`: ONE synthetic dataset of world x 16 x n_steps items (the
     same on every rank), bucket batches of 64 s, and for world > 1 the reference's DistributedBatchSamplerWrapper
@@ -365,6 +541,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-path', action='store_true', help='skip the use_amp=False step reported beside the headline')
     ap.add_argument('--no-through-trainer', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip BASELINE configs[3] / configs[4] (DCCRN train, SGMSE+ enhance) behind the headline; '
+                         'they are N = 1 rows and never run with a process group')
     ap.add_argument('--buckets', type=int, default=3,
                     help='gradient buckets of the overlapped all-reduce (N > 1)')
     ap.add_argument('--kernel-table', action='store_true',
@@ -413,6 +592,7 @@ def main():
         batch, lengths = batches[i % len(batches)]
         return model.train_step(batch, lengths, True, scaler)
 
+    t_first = time.perf_counter()
     for i in range(args.warmup):
         step(i)
     fallback = None
@@ -428,20 +608,52 @@ def main():
             sync = GradSynchronizer(model, nparts=1)
             for i in range(max(2, args.warmup//2)):
                 step(i)
-    if not single:
-        dist.barrier()
+    # warm-up by TIME: the --warmup steps above are 33 ms of work -- the chip is still climbing out of its idle
+    # power state when they end (round 5: the driver's box read 4 % under the builder's with nothing to attribute
+    # it to). Steps continue until MIN_WARMUP_S seconds of steady steps have run; the count is agreed over the
+    # ranks first (every step holds collectives: all ranks must run the same number).
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
+    probe = 5
+    t_p = time.perf_counter()
+    for i in range(probe):
+        step(i)
     torch.cuda.synchronize()
+    per_step = (time.perf_counter() - t_p)/probe
+    extra = max(0, int(MIN_WARMUP_S/max(per_step, 1e-4)) + 1 - probe)
     if not single:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if not single:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([extra], dtype=torch.int64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        extra = int(t)
+    for i in range(extra):
+        step(i)
+    torch.cuda.synchronize()
+    warm = {'steps': args.warmup + probe + extra, 'seconds': time.perf_counter() - t_first,
+            'min_seconds_of_steady_steps': MIN_WARMUP_S,
+            'note': f'--warmup {args.warmup} (incl. first-step allocations) + {probe} probe steps + {extra} more until '
+                    f'{MIN_WARMUP_S} s of steps had run'}
+
+    def timed_block():
+        if not single:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = step(i)
+        torch.cuda.synchronize()
+        if not single:
+            dist.barrier()
+        dt_ = time.perf_counter() - t0
+        if not single:
+            t = torch.tensor([dt_], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t)
+        return dt_, last
+
+    clock_before = read_clock(local_rank)
+    dt, loss = timed_block()                       # THE timed region: exactly --steps steps -> `value`
+    clock_after = read_clock(local_rank)
+    repeats = [timed_block()[0] for _ in range(N_REPEATS)]
+    clock_end = read_clock(local_rank)
     final_loss = float(loss)
     exposed = sync.exposed_ms() if sync is not None else None
     trainer_ms = None
@@ -479,6 +691,17 @@ def main():
                 'parallelism': f'dp{world}',
             },
             'value_includes_h2d': False,        # (timed on batches resident in HBM; `through_trainer` includes H2D)
+            'warmup_effective': warm,
+            'value_repeats': {
+                'blocks': N_REPEATS, 'steps_per_block': args.steps,
+                'min': world*BATCH*args.steps/max(repeats), 'median': world*BATCH*args.steps/sorted(repeats)[len(repeats)//2],
+                'max': world*BATCH*args.steps/min(repeats), 'unit': 'utterances/s',
+                'ms_per_step': [r/args.steps*1e3 for r in repeats],
+                'note': 'further blocks of --steps timed like `value`, right behind it; `value` is the first block'},
+            'clock': {'before_timed_region': clock_before, 'after_timed_region': clock_after,
+                      'after_repeats': clock_end,
+                      'source': 'sysfs (pp_dpm_sclk / pp_dpm_mclk active level, hwmon freq1_input, power1_*, temp*_input) '
+                                'of the device behind cuda:<local rank>, rank 0'},
             'final_loss': final_loss,
             'whole_step_mfma_frac': value/world*FLOP_PER_UTT_TRAIN/(PEAK_MFMA_TFLOPS*1e12),
             'roofline': roof,
@@ -503,6 +726,10 @@ def main():
                 line['allreduce_fallback'] = fallback
         if single and not args.no_fp32_path:
             line['fp32_path'] = fp32_path(device)
+        if single and not args.no_other_configs:
+            t_oc = time.perf_counter()
+            line['other_configs'] = other_configs(device)
+            line['other_configs_wall_s'] = time.perf_counter() - t_oc
         if single and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         if args.kernel_table:

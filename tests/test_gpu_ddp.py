@@ -146,7 +146,7 @@ def test_two_ranks_equal_the_mean_of_the_half_batch_gradients(tmp_path, kind, am
     assert _rel(r0['params'], _flat(net).cpu()) <= 1e-3
 
 
-def _run_bench(extra, env_extra=None, nproc=1):
+def _run_bench(extra, env_extra=None, nproc=1, single=False):   # (`single`: no process group, as the driver's N = 1 run)
     env = dict(os.environ, BRV_DIST_TIMEOUT_S='300', **(env_extra or {}))
     if nproc > 1:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
@@ -184,3 +184,24 @@ def test_bench_two_ranks_on_one_gpu(forced):
     assert ('allreduce_fallback' in line) == forced
     assert line['allreduce_buckets'] == (1 if forced else 3)
     assert line['value_includes_h2d'] is False and line['through_trainer']['includes_h2d'] is True
+
+
+def test_bench_single_process_line_carries_other_configs_repeats_and_clock():
+    """the driver's own command (`bench.py --gpus 1`, no process group) reports BASELINE
+    configs[3] (DCCRN bf16 train step) and configs[4] (SGMSE+ fp16 enhance, batch 1 and 8) beside the headline, a
+    time-based warm-up, five repeat blocks and the device clocks around the timed region."""
+    line = _run_bench(['--no-through-trainer'], single=True)
+    assert line['n_gpus'] == 1 and 'rccl_world_size' not in line
+    assert line['warmup'] == 3 and line['warmup_effective']['steps'] > 3
+    assert line['warmup_effective']['seconds'] >= line['warmup_effective']['min_seconds_of_steady_steps']
+    rep = line['value_repeats']
+    assert rep['blocks'] == 5 and len(rep['ms_per_step']) == 5 and rep['min'] <= rep['median'] <= rep['max']
+    assert set(line['clock']) >= {'before_timed_region', 'after_timed_region', 'after_repeats'}
+    oc = line['other_configs']
+    assert [c['dtype'] for c in oc] == ['bf16', 'fp16', 'fp16']
+    assert [c['config']['global_batch'] for c in oc] == [16, 1, 8]
+    for c in oc:
+        assert c['value'] > 0 and c['ms_per_step'] > 0 and c['unit'] == 'utterances/s'
+        assert c['roofline']['bound'] == 'mfma' and 0 < c['roofline']['frac'] < 1
+        assert 'workload' in c['config'] and 'baseline_config' in c['config']
+    assert line['other_configs_wall_s'] < 180
