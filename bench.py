@@ -541,6 +541,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-path', action='store_true', help='skip the use_amp=False step reported beside the headline')
     ap.add_argument('--no-through-trainer', action='store_true')
+    ap.add_argument('--min-warmup-s', type=float, default=MIN_WARMUP_S,
+                    help='seconds of steps before the timed region whatever --warmup says (the profiler passes of '
+                         'tools/profile_*.sh pass 0: under --pmc every launch is serialised)')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip BASELINE configs[3] / configs[4] (DCCRN train, SGMSE+ enhance) behind the headline; '
                          'they are N = 1 rows and never run with a process group')
@@ -619,7 +622,7 @@ def main():
         step(i)
     torch.cuda.synchronize()
     per_step = (time.perf_counter() - t_p)/probe
-    extra = max(0, int(MIN_WARMUP_S/max(per_step, 1e-4)) + 1 - probe)
+    extra = max(0, int(args.min_warmup_s/max(per_step, 1e-4)) + 1 - probe) if args.min_warmup_s > 0 else 0
     if not single:
         t = torch.tensor([extra], dtype=torch.int64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -628,9 +631,9 @@ def main():
         step(i)
     torch.cuda.synchronize()
     warm = {'steps': args.warmup + probe + extra, 'seconds': time.perf_counter() - t_first,
-            'min_seconds_of_steady_steps': MIN_WARMUP_S,
+            'min_seconds_of_steady_steps': args.min_warmup_s,
             'note': f'--warmup {args.warmup} (incl. first-step allocations) + {probe} probe steps + {extra} more until '
-                    f'{MIN_WARMUP_S} s of steps had run'}
+                    f'{args.min_warmup_s} s of steps had run'}
 
     def timed_block():
         if not single:

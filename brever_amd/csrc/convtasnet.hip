@@ -16,7 +16,14 @@
 #include "gemm_wgrad.cuh"
 #include "gemm_ws.cuh"
 #include "dwpw2_fused.cuh"
+// Two kernel organisations that were built, measured slower and rejected are NOT part of the
+// default library (round 6): `tools/mkvariant.sh <tag> -DBRV_WITH_VARIANTS` builds a library that holds them, the
+// default one answers BRV_OPT_DWPW2_V2 / BRV_OPT_BWD_PERSIST with an error.
+#ifdef BRV_WITH_VARIANTS
 #include "dwpw2_fused_v2.cuh"
+#else
+constexpr int D2_TT = 64;            // (tile of the whole-row form; only its launch arithmetic needs the name)
+#endif
 #include "gemm_wgrad_full.cuh"
 #include "gemm_wgrad_full128.cuh"
 
@@ -24,7 +31,9 @@ constexpr int kWgSplit = 4;          // item splits of the [res | skip] weight-g
 #include "prep.cuh"
 #include "tcn_kernels.cuh"
 #include "bwd_fused.cuh"
+#ifdef BRV_WITH_VARIANTS
 #include "bwd_fused_p.cuh"
+#endif
 #include "pw1_bwd.cuh"
 #include "cln_kernels.cuh"
 
@@ -528,9 +537,13 @@ template <int P> struct DwBwdFused {
 #endif
     const int nt = opt(BRV_OPT_BWD_PERSIST) ? BF_NT : 1;       // (opt-in: 83 against 73 us per launch)
     if (nt > 1 && p.Kg == 256) {
+#ifdef BRV_WITH_VARIANTS
       // persistent form (bwd_fused_p.cuh): a workgroup walks `nt` tiles of its channel group
       dim3 gridp(ceil_div(ceil_div(tiles*d.B, 8), nt)*8*(d.Cp/HL_CG));
       hipLaunchKernelGGL((dwconv_bwd_fused_p_kernel<P, 256>), gridp, dim3(256), BF_LDS, st, p, nt);
+#else
+      return fail(-1, "BRV_OPT_BWD_PERSIST: the persistent fused backward is not in this build (tools/mkvariant.sh <tag> -DBRV_WITH_VARIANTS)");
+#endif
     } else
     if (p.Kg == 256) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P, 256>), grid, dim3(256), BF_LDS, st, p);
     else if (p.Kg == 128) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<P, 128>), grid, dim3(256), BF_LDS, st, p);
@@ -1364,8 +1377,13 @@ int brv_ctn_forward(const brv_ctn_config* cfg, const float* params, const void* 
 #ifndef D2V_AHEAD
 #define D2V_AHEAD 8
 #endif
+#ifdef BRV_WITH_VARIANTS
           if (v2) hipLaunchKernelGGL((dwpw2_v2_kernel<D2V_NW, D2V_AHEAD, (bool)D2V_SEQ>), dim3(n_wg), dim3(64*D2V_NW), 0, st, dp);
-          else hipLaunchKernelGGL(dwpw2_fused_kernel, dim3(n_wg), dim3(512), 0, st, dp);
+          else
+#else
+          if (v2) return fail(-1, "BRV_OPT_DWPW2_V2: the whole-row fused forward is not in this build (tools/mkvariant.sh <tag> -DBRV_WITH_VARIANTS)");
+#endif
+          hipLaunchKernelGGL(dwpw2_fused_kernel, dim3(n_wg), dim3(512), 0, st, dp);
           HIP_OK(hipGetLastError());
         }
       }
@@ -1851,8 +1869,13 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
 #ifdef WSD_STAMP
         wp.dbg = debug_buffer();
 #endif
+        // algorithmic bytes: e1 and x in (+ the residual g_out), dz1 and the new g_out out -- and the companions the
+        // row-wise epilogue streams: the copy of g_out kept for block i - 1's weight gradient and, for that block's
+        // layer-norm backward means, its u ([res | skip] wide) and g_skip rows (the line understated
+        // the kernel by 2 BT 384; PMC 244.8 MB per launch = this count)
+        const double companions = (i > 0 ? l.Bnp : 0) + (bwd_fused && i > 0 ? (double)l.Bnp + 2.0*l.Scp : 0.0);
         ProfScope prof("pw1_dgrad", 2.0*BT*(double)l.Hp*l.Bnp*2,
-                       2.0*BT*(l.Hp*(wp.dz_out ? 2 : 1) + l.Bnp*(has_res ? 3 : 2)), st);
+                       2.0*BT*(l.Hp*(wp.dz_out ? 2 : 1) + l.Bnp*(has_res ? 3 : 2) + companions), st);
         int grid = num_cus();
         const int total = ceil_div((int)T, WSD_TF)*B;
         if (grid > total) grid = total;

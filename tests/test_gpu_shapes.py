@@ -327,43 +327,60 @@ def test_sgmse_default_denoiser_full_spectrogram():
     assert err <= 5e-3, err
 
 
-@pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 2, 3, 5000), (4, 2, 1, 700), (8, 1, 5, 2100),
-                                                (3, 3, 4, 20000), (8, 1, 2, 300), (8, 1, 1, 64000), (8, 1, 11, 10500)])
-def test_whole_row_fused_forward_equals_slab_fused_forward(monkeypatch, layers, repeats, B, L):
-    """The two organisations of the fused forward stage (csrc/dwpw2_fused.cuh: channel slabs; dwpw2_fused_v2.cuh:
-    whole rows per wave, p of a 64-frame tile in LDS) compute the same z2 / u / statistics: network output and every
-    gradient of the step that follows. Same arithmetic per element except the constant term of frames near an
-    item's ends (summed in another order: fp32 rounding before the bf16 rounding of z2). Items shorter than a
-    tile / than the dilation, ragged lengths, tile counts that do not divide over the XCDs."""
+def _variant_library():
+    """tools/_v/variants/libbrever_hip.so: the library with the two rejected kernel organisations compiled in
+    (`__graft_entry__.build()` makes it; built here when missing -- hipcc cross-compiles in ~30 s)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, 'tools', '_v', 'variants', 'libbrever_hip.so')
+    if not os.path.exists(lib):
+        subprocess.run(['bash', os.path.join(root, 'tools', 'mkvariant.sh'), 'variants', '-DBRV_WITH_VARIANTS'],
+                       check=True, capture_output=True, timeout=900)
+    return root, lib
+
+
+def _variant_check(switch, layers, repeats, B, L):
+    import json
+    import os
+    import subprocess
+    import sys
+    root, lib = _variant_library()
+    env = dict(os.environ, BRV_LIB_PATH=lib)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'variant_check.py'), switch, str(layers), str(repeats),
+                          str(B), str(L)], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+
+
+def test_default_library_refuses_the_rejected_kernel_variants(monkeypatch):
+    """Round 6: csrc/dwpw2_fused_v2.cuh and csrc/bwd_fused_p.cuh are compiled only with -DBRV_WITH_VARIANTS; the
+    default library must fail loudly (no silent fall-through to the default kernel) when their switches are set."""
     from brever_amd.criterion import snr
     from brever_amd.models import ConvTasNet
-    cfg = dict(layers=layers, repeats=repeats)
-    gen = torch.Generator().manual_seed(11*layers + B)
-    torch.manual_seed(29)
-    ref = ConvTasNet(**cfg)
-    _detrivialise(ref, gen)
-    batch, lengths = _ragged_batch(gen, B, L)
-    outs, grads = {}, {}
-    for mode in ('0', '1'):
-        monkeypatch.setenv('BRV_DWPW2_V2', mode)
-        net = ConvTasNet(**cfg)
-        net.load_state_dict(ref.state_dict())
-        net = net.to(_cuda())
+    gen = torch.Generator().manual_seed(3)
+    batch, lengths = _ragged_batch(gen, 2, 4000)
+    for switch in ('BRV_DWPW2_V2', 'BRV_BWD_PERSIST'):
+        monkeypatch.setenv(switch, '1')
+        net = ConvTasNet(layers=2, repeats=1).to(_cuda())
         net._amp = True
-        out = net(batch[:, 0].cuda())
-        loss = snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean()
-        loss.backward()
-        outs[mode] = out.detach().float().cpu()
-        grads[mode] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
-        assert torch.isfinite(grads[mode]).all() and torch.isfinite(outs[mode]).all()
-    eo, eg = rel(outs['1'], outs['0']), rel(grads['1'], grads['0'])
-    print(f'layers {layers} x {repeats}, B {B}, L {L}: whole-row vs slab forward: output rel {eo:.3e}, gradients rel {eg:.3e}')
-    # (bf16 rounding of z2 flips where the constant term was summed in another order; the slab form against the
-    # three-launch forward sits at the same distance: test_fused_forward_covers_every_tile allows 1e-2)
-    # gradients: both forms sit 2e-2 from the bf16-emulating oracle (test_default_width_gradients_at_all_dilations
-    # passes with either), which itself is 3e-2 from the fp32 one
-    assert eo <= 5e-3, eo
-    assert eg <= 4e-2, eg
+        with pytest.raises(RuntimeError, match='not in this build'):
+            out = net(batch[:, 0].cuda())
+            snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean().backward()
+        monkeypatch.delenv(switch)
+
+
+@pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (4, 2, 1, 700), (8, 1, 11, 10500)])
+def test_whole_row_fused_forward_variant_against_the_oracle(layers, repeats, B, L):
+    """The whole-row organisation of the fused forward stage (csrc/dwpw2_fused_v2.cuh; variant library only, DESIGN
+    5m: 64 against 50 us per launch) against the bf16-emulating ORACLE -- output, loss and every gradient of the
+    step that follows, with the bounds of the default kernels -- and against the slab form of the same library.
+    Items shorter than a tile / than the dilation, ragged lengths, tile counts that do not divide over the XCDs."""
+    r = _variant_check('BRV_DWPW2_V2', layers, repeats, B, L)
+    print(f'layers {layers} x {repeats}, B {B}, L {L}: whole-row forward', r)
+    assert r['finite']
+    assert r['out_vs_oracle'] <= 1e-2 and r['loss_vs_oracle'] <= 2e-3 and r['grad_vs_oracle'] <= 6e-2, r
+    assert r['out_vs_default'] <= 5e-3 and r['grad_vs_default'] <= 4e-2, r
 
 
 @pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 2, 3, 5000), (4, 2, 1, 700), (8, 1, 5, 2100),
@@ -401,34 +418,18 @@ def test_fused_backward_equals_three_launch_backward(monkeypatch, layers, repeat
             print('   worst tensor', worst)
 
 
-@pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 2, 3, 5000), (4, 2, 1, 700), (8, 1, 9, 2100), (8, 1, 2, 300)])
-def test_persistent_fused_backward_equals_one_tile_per_workgroup(monkeypatch, layers, repeats, B, L):
-    """csrc/bwd_fused_p.cuh (BRV_BWD_PERSIST=1: a workgroup walks two tiles, per-channel partial sums kept in LDS over the
-    range, atomics once per workgroup) against the default one-tile-per-workgroup kernel: the same arithmetic per
-    element, the per-channel sums in another order. Odd tile counts (the second tile of the last workgroup missing),
-    items shorter than a tile, tile ranges that cross items."""
-    from brever_amd.criterion import snr
-    from brever_amd.models import ConvTasNet
-    cfg = dict(layers=layers, repeats=repeats)
-    gen = torch.Generator().manual_seed(13*layers + B)
-    torch.manual_seed(31)
-    ref = ConvTasNet(**cfg)
-    _detrivialise(ref, gen)
-    batch, lengths = _ragged_batch(gen, B, L)
-    grads = {}
-    for mode in ('0', '1'):
-        monkeypatch.setenv('BRV_BWD_PERSIST', mode)
-        net = ConvTasNet(**cfg)
-        net.load_state_dict(ref.state_dict())
-        net = net.to(_cuda())
-        net._amp = True
-        out = net(batch[:, 0].cuda())
-        snr(out, batch[:, 1:].cuda(), lengths.cuda()).mean().backward()
-        grads[mode] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
-        assert torch.isfinite(grads[mode]).all()
-    e = rel(grads['1'], grads['0'])
-    print(f'layers {layers} x {repeats}, B {B}, L {L}: persistent vs one-tile backward rel {e:.3e}')
-    assert e <= 2e-3, e
+@pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 1, 9, 2100), (8, 1, 2, 300)])
+def test_persistent_fused_backward_variant_against_the_oracle(layers, repeats, B, L):
+    """csrc/bwd_fused_p.cuh (variant library only, DESIGN 5n: 83 against 73 us per launch; a workgroup walks two
+    tiles, per-channel partial sums kept in LDS over the range, atomics once per workgroup) against the
+    bf16-emulating ORACLE with the default kernel's bounds, and against the one-tile-per-workgroup kernel of the same
+    library (same arithmetic per element, per-channel sums in another order). Odd tile counts, items shorter than
+    a tile, tile ranges that cross items."""
+    r = _variant_check('BRV_BWD_PERSIST', layers, repeats, B, L)
+    print(f'layers {layers} x {repeats}, B {B}, L {L}: persistent backward', r)
+    assert r['finite']
+    assert r['loss_vs_oracle'] <= 2e-3 and r['grad_vs_oracle'] <= 6e-2, r
+    assert r['grad_vs_default'] <= 2e-3, r
 
 
 @pytest.mark.parametrize('layers,repeats,B,L', [(8, 1, 2, 16000), (8, 2, 3, 5000), (4, 2, 1, 700), (8, 1, 5, 2100),

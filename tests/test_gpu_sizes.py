@@ -269,3 +269,48 @@ def test_fused_clip_adam_of_every_model_matches_torch(arch, kwargs, clip):
         assert torch.allclose(a['exp_avg_sq'], b['exp_avg_sq'], rtol=1e-4, atol=1e-10)     # (fused multiply-adds)
     model.optimizer.load_state_dict(ref_sd)
     assert torch.allclose(model.optimizer._exp_avg[:params[0].numel()].view(params[0].shape), ref_sd['state'][0]['exp_avg'])
+
+
+def test_fp32_trajectory_20_steps_at_the_default_depth():
+    """VERDICT r05 item 6a / SURVEY 8(d)(ii) / north_star "loss curves matching reference to 1e-3": the 20-step
+    protocol of tests/test_gpu.py::test_fp32_trajectory_20_steps on the DEFAULT network -- 8 layers x 3 repeats =
+    24 blocks, dilations 1 .. 128, 4 935 217 parameters (that test runs 4 blocks) -- with 2 x 1 s ragged items so
+    that the CPU fp32 AND fp64 oracles stay within a few minutes. Fused HIP steps (fp32 path, Adam lr 1e-3, clip
+    5) against the CPU fp32 oracle from identical init and data order, reference convtasnet.py:78-89.
+
+    Same fp64-anchored bound: |d loss| <= 1e-3 dB over the first 10 steps and <= 3e-3 over all 20 against the CPU
+    fp32 oracle, and against the fp64 trajectory (which both fp32 runs approximate) the HIP run may be no further
+    away than 3 x the CPU fp32 run's own worst distance (+ 1e-4)."""
+    from brever_amd.models import ConvTasNet
+    from oracle.convtasnet import OracleConvTasNet
+    torch.manual_seed(7)
+    oracle = OracleConvTasNet()
+    assert sum(p.numel() for p in oracle.parameters()) == 4935217
+    o64 = OracleConvTasNet().double()
+    o64.load_state_dict({k: v.double() for k, v in oracle.state_dict().items()})
+    net = ConvTasNet()
+    net.load_state_dict(oracle.state_dict())
+    net = net.to(_cuda())
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    gen = torch.Generator().manual_seed(11)
+    L = 16000
+    d32, d64, c64 = [], [], []
+    for step in range(20):
+        clean = 0.1*torch.randn(2, L, generator=gen)
+        noise = 0.1*torch.randn(2, L, generator=gen)
+        snr_db = -5 + 15*torch.rand(2, 1, generator=gen)
+        batch = torch.stack([clean + 10**(-snr_db/20)*noise, clean], dim=1)
+        lengths = torch.tensor([L, L - 3500])
+        batch[1, :, lengths[1]:] = 0
+        want = float(oracle.train_step(batch, lengths, False, scaler).detach())
+        truth = float(o64.train_step(batch.double(), lengths, False, scaler).detach())
+        got = float(net.train_step(batch.cuda(), lengths.cuda(), False, scaler))
+        d32.append(abs(got - want)); d64.append(abs(got - truth)); c64.append(abs(want - truth))
+    print('default-depth fp32 trajectory |hip - cpu32|:', ['%.1e' % d for d in d32])
+    print('                            |cpu32 - cpu64|:', ['%.1e' % d for d in c64])
+    print('                              |hip - cpu64|:', ['%.1e' % d for d in d64])
+    assert max(d32[:10]) <= 1e-3, d32
+    assert max(d32) <= 3e-3, d32
+    assert max(d64) <= 3*max(c64) + 1e-4, (d64, c64)
+    ref = torch.cat([p.detach().reshape(-1) for p in oracle.parameters()])
+    assert rel(net.flat_params(), ref) <= 1e-2, rel(net.flat_params(), ref)

@@ -10,7 +10,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-through-trainer --no-fp32-path"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-through-trainer --no-fp32-path --no-other-configs --min-warmup-s 0"
 # The default step runs two half-batch kernel chains concurrently (a launch's wall time then includes
 # the other chain's workgroups, and a launch covers half the batch). The per-kernel numbers -- this
 # statistics pass, the PMC passes and the `roofline` object of bench.py -- are those of the ONE-chain
@@ -23,7 +23,7 @@ unset BRV_CTN_STREAMS
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats2 -o main -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_rocprofv3_bench_line_two_chains.json 2> /dev/null
 cp $(find /tmp/prof_stats2 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats_two_chains.csv
 export BRV_CTN_STREAMS=1
-PMCARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-through-trainer --no-fp32-path"
+PMCARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-through-trainer --no-fp32-path --no-other-configs --min-warmup-s 0"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -o f -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -o w -- python3 $REPO/bench.py $PMCARGS > /dev/null 2>&1
 python3 $REPO/tools/pmc_traffic.py /tmp/pmc_f /tmp/pmc_w $OUT/${TAG}_pmc_hbm_traffic.json

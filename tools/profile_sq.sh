@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export BRV_CTN_STREAMS=1
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-through-trainer --no-fp32-path"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-through-trainer --no-fp32-path --no-other-configs --min-warmup-s 0"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d /tmp/sq_a -o a -- python3 $REPO/bench.py $ARGS > $OUT/${TAG}_sq_pass_a.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES \
