@@ -63,6 +63,9 @@ struct BwdFusedParams {
 #define BF_WPS 3     // resident workgroups per CU the register budget is set for (diagnostic builds: 4)
 #endif
 constexpr int BF_ROWS = BF_ROWS_N;         // window rows (teeth x rows per tooth), 8 MFMA groups of 32
+#ifndef BF_ROWCAP
+#define BF_ROWCAP BF_ROWS_N                // output rows a tile may hold (<= BF_ROWS_N)
+#endif
 constexpr int BF_LDW = HL_CG + 8;          // halves per window row: 144 B
 constexpr int BF_LDS = BF_ROWS*BF_LDW*2 + 32*HL_CG*4;   // window + the reduction scratch
 
@@ -75,7 +78,8 @@ inline void bf_tile_shape(int T, int dil, int P, int& K, int& R) {
   long long best = -1;
   K = 1; R = 1;
   for (int r = 1; r <= HL_RMAX*2 && r <= dil; ++r) {
-    const int kmax = BF_ROWS/r - (P - 1);
+    int kmax = BF_ROWS/r - (P - 1);
+    if (BF_ROWCAP/r < kmax) kmax = BF_ROWCAP/r;          // (diagnostic builds: fewer output rows per tile, more tiles)
     if (kmax < 1) break;
     const int n_qt = ceil_div(n_teeth, kmax);
     const int k = ceil_div(n_teeth, n_qt);
@@ -96,6 +100,13 @@ inline void bf_tile_shape(int T, int dil, int P, int& K, int& R) {
 #else
 #define BF_MARK(i) do { } while (0)
 #endif
+// Row -> frame tables (round 6): see the kernel. A row outside the item / the window maps to kRowBad, a frame
+// index whose byte offset (x 512 B for g, x 1 KB for z2 / z1 / e1) lies beyond every descriptor of this kernel.
+constexpr int kRowBad = 1 << 21;
+constexpr int kRowCentre = 1 << 30;
+constexpr int kRowFrame = kRowCentre - 1;
+inline bool bf_frames_ok(long long T) { return T < kRowBad; }      // host: longer items take the three-launch path
+
 template <int P, int KG>
 __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const BwdFusedParams fp) {
   const DwParams& p = fp.d;
@@ -105,17 +116,6 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int T = p.T, d = p.dil;
   const int R = fp.R, K = fp.K;
-  // r / R and r % R for r < 512: shifts when R is a power of two (dilations <= 32 at the BASELINE length),
-  // else a float multiplication ((r + 0.5) / R is never within 1e-3 of an integer: exact)
-  const float invR = 1.f/(float)R;
-  const bool r_pow2 = (R & (R - 1)) == 0;
-  const int lgR = 31 - __builtin_clz(R);
-  auto divR = [&](int r, int& rem) {
-    if (r_pow2) { rem = r & (R - 1); return r >> lgR; }
-    const int q = (int)(((float)r + 0.5f)*invR);
-    rem = r - q*R;
-    return q;
-  };
   const int n_rt = ceil_div(d, R);                       // residue groups
   const int n_teeth = (T - 1)/d + 1;
   const int n_qt = ceil_div(n_teeth, K);                 // tooth groups
@@ -139,15 +139,31 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
   const int W = (K + P - 1)*R;                         // rows of the window (<= BF_ROWS)
   const int KR = K*R;                                  // output rows of the tile
   const int qbase = q0 - (P - 1) + p.left/d;           // tooth of window row 0
-  // window row r -> frame: tooth qbase + r / R, residue r0 + r % R
-  auto frame_of = [&](int r, bool& ok) {
-    int ri;
-    const int qi = divR(r, ri);
+  // ---- row -> frame tables. A thread visits 8 window rows and 8 output rows, once to load and once to
+  // compute; until round 6 every visit mapped its row to a frame again (a division by R behind a run-time
+  // branch on R being a power of two, two range tests, a 64-bit multiply-add for the offset): ~550 of the
+  // kernel's 3 165 vector instructions per thread and ~60 branches that cut the stream into small blocks.
+  // Thread r maps window row r and output row r ONCE; every later visit is one LDS word (8 lanes of a row
+  // slot read the same word: no conflicts):
+  //   wtab[r] = frame of window row r: tooth qbase + r / R, residue r0 + r % R (| kRowCentre when the tooth
+  //             is one of this tile's own K), or kRowBad for rows outside the item / the window: loads of
+  //             such rows are out of range of their descriptors and return zeros by themselves;
+  //   otab[i] = frame of output row i: tooth q0 + i / R, same residue; or kRowBad.
+  __shared__ int wtab[BF_ROWS];
+  __shared__ int otab[BF_ROWS];
+  {
+    int qi, ri;
+    if ((R & (R - 1)) == 0) { ri = tid & (R - 1); qi = tid >> (31 - __builtin_clz(R)); }
+    else {     // ((r + 0.5) / R is never within 1e-3 of an integer for r < 512: exact)
+      qi = (int)(((float)tid + 0.5f)*(1.f/(float)R)); ri = tid - qi*R;
+    }
     const int q = qbase + qi;
-    ok = r < W && q >= 0 && r0 + ri < d;
-    return q*d + r0 + ri;
-  };
-
+    const int tf = q*d + r0 + ri;
+    const bool in = tid < W && q >= 0 && r0 + ri < d && tf < T;
+    wtab[tid] = in ? (tf | ((q >= q0 && q < q0 + K) ? kRowCentre : 0)) : kRowBad;
+    const int to = (q0 + qi)*d + r0 + ri;
+    otab[tid] = (tid < KR && r0 + ri < d && to < T) ? to : kRowBad;
+  }
   // Per-channel parameters of the group (gamma_2, gamma_1, beta_1, the P taps): requested now, parked
   // in LDS behind the barrier that ends phase 0 and read from there by phases 1 and 2. (Loaded by every
   // thread where they are used -- 8 + 40 dependent scalar loads -- they put two L2 round trips into
@@ -164,23 +180,16 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
     if (s0) pv0 = *s0;
     if (tid + 256 < (3 + P)*HL_CG) { const float* s1 = ptab_src(tid + 256); if (s1) pv1 = *s1; }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tables visible; LDS only: pv0 / pv1 stay in flight
 
-  // z2 rows of phase 1 (BF_PIPE: requested across the phase boundaries, two batches of four rows per thread;
-  // the window has at most 256 rows = 8 per thread)
+  // z2 rows of phase 1 and z1 rows of phase 2: requested across the phase boundaries in two batches of four
+  // rows per thread (the window has at most 256 rows = 8 per thread)
   const __amdgpu_buffer_rsrc_t rz2 = make_rsrc(p.z2in + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
-  const unsigned int row = (unsigned int)(p.Cp*2), coff = (unsigned int)(c0*2);
-  uint4 qzA[4];
-  // z1 rows of phase 2 (centre rows of the tile), first batch requested inside phase 1
   const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(p.z1 + (long long)b*T*p.Cp, (long long)T*p.Cp*2);
-  uint4 qz1A[4];
-  // output row i -> frame: tooth q0 + i / R, residue r0 + i % R
-  auto out_frame = [&](int i, bool& ok) {
-    int ri;
-    const int qi = divR(i, ri);
-    const int ro = r0 + ri;
-    ok = i < KR && ro < d;
-    return (q0 + qi)*d + ro;
-  };
+  const unsigned int row = (unsigned int)(p.Cp*2), coff = (unsigned int)(c0*2);
+  // (24-bit multiply: one full-rate v_mad_u32_u24 -- frames < 2^22, row = 1 KB; kRowBad lands out of range)
+  auto row_off = [&](int v) { return __umul24((unsigned int)(v & kRowFrame), row) + coff; };
+  uint4 qzA[4], qz1A[4];
   // ---- phase 0: e = W^T g of the window -> LDS ---------------------------------------------------
   // Every wave works alone on its own 64 window rows (no workgroup barrier before the end of the
   // phase): the reduction runs in chunks of 64 g columns; a chunk of the wave's rows is fetched by
@@ -199,21 +208,16 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
     const bool act0 = 2*widu < ngrp, act1 = 2*widu + 1 < ngrp;
     const __amdgpu_buffer_rsrc_t rg =
         make_rsrc(fp.g + (long long)b*T*fp.ldg, ((long long)(T - 1)*fp.ldg + KG)*2);
-    unsigned int offG[8];                                  // rows 64 wid + 8 i + rsub of the window (kOob: none)
+    unsigned int offG[8];                                  // rows 64 wid + 8 i + rsub of the window
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      bool ok;
-      const int tf = frame_of(64*widu + 8*i + rsub, ok);
-      offG[i] = (ok && tf < T) ? (unsigned int)tf*(unsigned int)(fp.ldg*2) + (unsigned int)(oct*16) : kOob;
-    }
+    for (int i = 0; i < 8; ++i)
+      offG[i] = __umul24((unsigned int)(wtab[64*widu + 8*i + rsub] & kRowFrame), (unsigned int)(fp.ldg*2)) + (unsigned int)(oct*16);
     constexpr int nkc = KG >> 6;                           // chunks of 64 k
     const bf16_t* wsrc0 = fp.Wp + (long long)(cg*2)*32*KG + lane*8;
     const bf16_t* wsrc1 = wsrc0 + (long long)32*KG;
     const uint4 z4 = make_uint4(0, 0, 0, 0);
     uint4 gq0 = z4, gq1 = z4, gq2 = z4, gq3 = z4, gq4 = z4, gq5 = z4, gq6 = z4, gq7 = z4;
-    auto gl = [&](int i, int kc) {
-      return buf_load16(rg, offG[i] == kOob ? kOob : offG[i] + (unsigned int)(kc*128));
-    };
+    auto gl = [&](int i, int kc) { return buf_load16(rg, offG[i] + (unsigned int)(kc*128)); };
     auto gload = [&](int kc) {
       gq0 = gl(0, kc); gq1 = gl(1, kc); gq2 = gl(2, kc); gq3 = gl(3, kc);
       gq4 = gl(4, kc); gq5 = gl(5, kc); gq6 = gl(6, kc); gq7 = gl(7, kc);
@@ -277,14 +281,8 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
       }
     }
     // the first four z2 rows of this thread (phase 1) are requested now: they arrive behind the barrier
-    if (BF_PIPE) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        bool ok;
-        const int tf = frame_of(rslot + 32*u, ok);
-        qzA[u] = buf_load16(rz2, (ok && tf < T) ? (unsigned int)tf*row + coff : kOob);
-      }
-    }
+    for (int u = 0; u < 4; ++u) qzA[u] = buf_load16(rz2, row_off(wtab[rslot + 32*u]));
     // D[channel][frame]: lane = frame n32, registers = channels 8 (i >> 2) + 4 h + (i & 3)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -308,102 +306,82 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
   BF_MARK(2);
 
   // ---- phase 1: dz2 of the window, in place in LDS --------------------------------------------------
+  // Per-item constants: the variance (a difference of two nearly equal sums) in fp64, its inverse square root
+  // in fp32 (rstd_f32: the fp64 square root + division were ~45 half-rate instructions in every thread).
   const double mean2 = p.stats2[stat_sum(b)]*p.inv_n;
   double var2 = p.stats2[stat_sq(b)]*p.inv_n - mean2*mean2;
   if (var2 < 0.0) var2 = 0.0;
-  const double rstd2d = 1.0/sqrt(var2 + (double)p.eps);
-  const float mu2 = (float)mean2, rs2 = (float)rstd2d;
+  const float rs2 = rstd_f32(var2 + (double)p.eps);
+  const float mu2 = (float)mean2;
   const double S1 = p.sums2[stat_sum(b)], S2 = p.sums2[stat_sq(b)];
   const float m1 = (float)(S1*p.inv_n);
-  const float m2 = (float)(rstd2d*(S2 - mean2*S1)*p.inv_n);
+  const float m2 = rs2*(float)((S2 - mean2*S1)*p.inv_n);
   const float a2 = *p.slope2;
-  const float ya = 0.5f*(1.f + a2)*rs2, yb = 0.5f*(1.f - a2)*rs2, yc = -mu2*rs2;
+  // PReLU_2 through the sign s = +-1 of z (one v_and_or per element): |z| = s z, PReLU' = c0 + c1 s, so
+  //   xh_2 = rstd (PReLU(z) - mean) = (ya + yb s) z + yc,   dz2 = uu (c0 + c1 s),
+  //   slope gradient = sum uu min(z, 0) = 0.5 sum (uu - uu s) z     -- all packed two-channel operations
+  // (PReLU'(+0) is 1 here where torch's is the slope: a set of measure zero that carries no gradient mass).
+  const float c0s = 0.5f*(1.f + a2), c1s = 0.5f*(1.f - a2);
+  const float ya = c0s*rs2, yb = c1s*rs2, yc = -mu2*rs2;
   const float R2 = rs2, K0 = -m1*rs2, M2R = -m2*rs2;
-  float da2 = 0.f;
+  f32x2 daz = {0.f, 0.f};
   f32x2 dbia[4], dgam2[4], dbet2[4], g2[4];
-  {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      g2[j] = f32x2{ptab[cl + 2*j], ptab[cl + 2*j + 1]};
-      dbia[j] = f32x2{0.f, 0.f}; dgam2[j] = f32x2{0.f, 0.f}; dbet2[j] = f32x2{0.f, 0.f};
-    }
+  for (int j = 0; j < 4; ++j) {
+    g2[j] = f32x2{ptab[cl + 2*j], ptab[cl + 2*j + 1]};
+    dbia[j] = f32x2{0.f, 0.f}; dgam2[j] = f32x2{0.f, 0.f}; dbet2[j] = f32x2{0.f, 0.f};
   }
   // one window row of this thread (8 channels): dz2 in place + the per-channel sums
   auto phase1_row = [&](int r, const uint4& qzv) {
-      bool ok;
-      const int tf = frame_of(r, ok);
-      const bool in = ok && tf < T;
-      float e[8], z[8], g[8];
+      const int v = wtab[r];
+      const float on = (v & kRowBad) ? 0.f : 1.f;        // rows outside the item: dz2 = 0
+      const bool centre = v >= kRowCentre;                // owned by this tile's teeth [q0, q0 + K)
+      const f32x2 rr = {on*R2, on*R2}, k0 = {on*K0, on*K0}, mm = {on*M2R, on*M2R};
+      const f32x2 yav = {ya, ya}, ybv = {yb, yb}, ycv = {yc, yc}, c0v = {c0s, c0s}, c1v = {c1s, c1s};
+      float e[8], z[8];
       unpack8(*reinterpret_cast<const uint4*>(win + r*BF_LDW + cl), e);
       unpack8(qzv, z);
-      const float on = in ? 1.f : 0.f;
-      const float rr = on*R2, k0 = on*K0, mm = on*M2R;
-      // each element is "owned" by the tile whose teeth [q0, q0 + K) contain it
-      int rem_;
-      const int q = qbase + divR(r, rem_);
-      const bool centre = in && q >= q0 && q < q0 + K;
-      float uz = 0.f;                                    // sum over the row's 8 channels of uu min(z, 0)
-      f32x2 xg[4], ee[4];
+      f32x2 gg[4], xg[4], ee[4], dd[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xh2 = __builtin_fmaf(yb, __builtin_fabsf(z[j]), __builtin_fmaf(ya, z[j], yc));
-        const float gj = (j & 1) ? g2[j >> 1].y : g2[j >> 1].x;
-        const float uu = __builtin_fmaf(mm, xh2, __builtin_fmaf(e[j]*gj, rr, k0));
-        g[j] = uu*(z[j] > 0.f ? 1.f : a2);               // PReLU_2'
-        uz = __builtin_fmaf(uu, z[j] - __builtin_fabsf(z[j]), uz);    // 2 min(z, 0) (fminf canonicalises first)
-        if (j & 1) { xg[j >> 1].y = xh2; ee[j >> 1].y = e[j]; } else { xg[j >> 1].x = xh2; ee[j >> 1].x = e[j]; }
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 zz = {z[2*j], z[2*j + 1]};
+        ee[j] = f32x2{e[2*j], e[2*j + 1]};
+        const f32x2 sg = {__uint_as_float((__float_as_uint(zz.x) & 0x80000000u) | 0x3f800000u),
+                          __uint_as_float((__float_as_uint(zz.y) & 0x80000000u) | 0x3f800000u)};
+        xg[j] = (yav + ybv*sg)*zz + ycv;                 // xh_2
+        const f32x2 uu = mm*xg[j] + ((ee[j]*g2[j])*rr + k0);
+        const f32x2 us = uu*sg;
+        gg[j] = c0v*uu + c1v*us;                         // dz2 = PReLU_2' uu
+        dd[j] = (uu - us)*zz;                            // 2 uu min(z, 0)
       }
-      const uint4 q4 = pack8(g);
+      uint4 q4;
+      q4.x = pack2(gg[0].x, gg[0].y); q4.y = pack2(gg[1].x, gg[1].y);
+      q4.z = pack2(gg[2].x, gg[2].y); q4.w = pack2(gg[3].x, gg[3].y);
       *reinterpret_cast<uint4*>(win + r*BF_LDW + cl) = q4;
       if (centre) {                                      // (row-uniform per thread: one branch, packed math)
-        da2 = __builtin_fmaf(0.5f, uz, da2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          dbia[j] += f32x2{g[2*j], g[2*j + 1]};          // bias gradient = sum of dz2 (before its bf16 rounding)
+          daz += dd[j];
+          dbia[j] += gg[j];                              // bias gradient = sum of dz2 (before its bf16 rounding)
           dgam2[j] += ee[j]*xg[j]; dbet2[j] += ee[j];
         }
       }
   };
-  if (BF_PIPE) {
+  {
     // rows rslot + 32 u: the first four were requested before the barrier, the other four go out now and
     // arrive while the first four are worked on
     uint4 qzB[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      bool ok;
-      const int tf = frame_of(rslot + 128 + 32*u, ok);
-      qzB[u] = buf_load16(rz2, (ok && tf < T) ? (unsigned int)tf*row + coff : kOob);
-    }
+    for (int u = 0; u < 4; ++u) qzB[u] = buf_load16(rz2, row_off(wtab[rslot + 128 + 32*u]));
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int r = rslot + 32*u; if (r < W) phase1_row(r, qzA[u]); }
     // the first z1 rows of phase 2 are requested before the second half and the folds
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      bool ok;
-      const int t = out_frame(rslot + 32*u, ok);
-      qz1A[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);
-    }
+    for (int u = 0; u < 4; ++u) qz1A[u] = buf_load16(rz1, row_off(otab[rslot + 32*u]));
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int r = rslot + 128 + 32*u; if (r < W) phase1_row(r, qzB[u]); }
-  } else {
-  // BF_AHEAD1 rows of a thread requested before the first is consumed
-  constexpr int NU = BF_AHEAD1;
-  for (int rw = rslot; rw < W; rw += 32*NU) {
-    uint4 qz[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      bool ok;
-      const int tf = frame_of(rw + 32*u, ok);
-      qz[u] = buf_load16(rz2, (ok && tf < T) ? (unsigned int)tf*row + coff : kOob);
-    }
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int r = rw + 32*u;
-      if (r >= W) break;
-      phase1_row(r, qz[u]);
-    }
   }
-  }
+  float da2 = 0.5f*(daz.x + daz.y);
   // ---- per-channel reductions. A thread holds 8 channels of its row slot; the 8 row slots of a wave are
   // folded with lane shuffles (lanes 8 apart share a channel octet), so LDS only carries ONE row per wave
   // and vector: all vectors of a phase go through it together behind a single barrier pair. (One vector
@@ -500,9 +478,8 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
   float l1 = 0.f, l2 = 0.f;
   // one centre row of this thread (8 channels): transposed stencil out of the window + the per-channel sums
   auto phase2_row = [&](int i, const uint4& qz) {
-    bool ok;
-    const int t = out_frame(i, ok);
-    if (!(ok && t < T)) return;                          // frames past the end: nothing to store or add
+    const int v = otab[i];
+    if (v & kRowBad) return;                             // frames past the end: nothing to store or add
     float zc[8];
     unpack8(qz, zc);
     f32x2 xh[4], hn[4], dh[4];
@@ -516,7 +493,7 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       // output frame that reads frame t through tap k: window tooth (i / R) + P - 1 - k, same residue
-      const int r = i + (P - 1 - k)*R;                 // same residue, tooth + P - 1 - k
+      const int r = i + (P - 1 - k)*R;
       float g[8];
       unpack8(*reinterpret_cast<const uint4*>(win + r*BF_LDW + cl), g);
 #pragma unroll
@@ -533,37 +510,16 @@ __global__ __launch_bounds__(256, BF_WPS) void dwconv_bwd_fused_kernel(const Bwd
       o[j] = gm[j]*dl;
       dgam[j] += dl*xh[j]; dbet[j] += dl;
     }
-    buf_store16(re1, (unsigned int)t*row + coff, pack8v(o));
+    buf_store16(re1, __umul24((unsigned int)v, row) + coff, pack8v(o));
   };
-  if (BF_PIPE) {
+  {
     uint4 qz1B[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      bool ok;
-      const int t = out_frame(rslot + 128 + 32*u, ok);
-      qz1B[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);
-    }
+    for (int u = 0; u < 4; ++u) qz1B[u] = buf_load16(rz1, row_off(otab[rslot + 128 + 32*u]));
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int i = rslot + 32*u; if (i < KR) phase2_row(i, qz1A[u]); }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int i = rslot + 128 + 32*u; if (i < KR) phase2_row(i, qz1B[u]); }
-  } else {
-  constexpr int NU2 = BF_AHEAD2;
-  for (int i0 = rslot; i0 < KR; i0 += 32*NU2) {
-   uint4 qz4[NU2];
-#pragma unroll
-   for (int u = 0; u < NU2; ++u) {
-     bool ok;
-     const int t = out_frame(i0 + 32*u, ok);
-     qz4[u] = buf_load16(rz1, (ok && t < T) ? (unsigned int)t*row + coff : kOob);   // outside: zeros
-   }
-#pragma unroll
-   for (int u = 0; u < NU2; ++u) {
-    const int i = i0 + 32*u;
-    if (i >= KR) break;
-    phase2_row(i, qz4[u]);
-   }
-  }
   }
   BF_MARK(5);
   // the tile's sums of e1 and e1 xh_1 (layer-norm backward means of the first norm) from the per-channel

@@ -137,6 +137,14 @@ constexpr int kStatStride = 32;
 __host__ __device__ __forceinline__ constexpr long long stat_sum(long long b) { return b*kStatStride; }
 __host__ __device__ __forceinline__ constexpr long long stat_sq(long long b) { return b*kStatStride + kStatStride/2; }
 struct NormStat { float mean, rstd; };
+// 1/sqrt(v) to fp32 accuracy: hardware v_rsq_f32 (1 ulp) + one Newton step. The fp64 square root and division
+// this replaces (round 6) are ~45 half-rate VALU instructions that EVERY thread of every normalising kernel
+// executed for a per-item constant; the variance itself (a difference of two nearly equal sums) stays in fp64.
+__device__ __forceinline__ float rstd_f32(double v) {
+  const float x = (float)v;
+  const float r = __builtin_amdgcn_rsqf(x);
+  return r*__builtin_fmaf(-0.5f*x*r, r, 1.5f);
+}
 __device__ __forceinline__ NormStat norm_stat(const double* stats, int b,
                                               double inv_n, float eps) {
   const double s = stats[stat_sum(b)], ss = stats[stat_sq(b)];
@@ -145,7 +153,7 @@ __device__ __forceinline__ NormStat norm_stat(const double* stats, int b,
   if (var < 0.0) var = 0.0;
   NormStat r;
   r.mean = (float)mean;
-  r.rstd = (float)(1.0/sqrt(var + (double)eps));
+  r.rstd = rstd_f32(var + (double)eps);
   return r;
 }
 

@@ -1701,7 +1701,7 @@ int brv_ctn_backward_part(const brv_ctn_config* cfg, const float* params, const 
   // Backward mirror of the fused forward (bwd_fused.cuh; BRV_BWD_FUSE=0: three launches per block):
   // needs the u tensors the fused forward stored and the default widths
   const bool bwd_fused = l.fused_fwd() && bwd_fuse_requested() && l.Bnp == 128 && l.Scp == 128 &&
-                         l.Hp % HL_CG == 0 && !opt(BRV_OPT_NO_DZ_FUSE);
+                         l.Hp % HL_CG == 0 && !opt(BRV_OPT_NO_DZ_FUSE) && bf_frames_ok(T);
 
   GemmRowsParams g; WgradParams wg;
   if (head) {

@@ -514,11 +514,27 @@ __global__ __launch_bounds__(512) void lstm_bwd_reg_kernel(const float* act, con
 // of these loops (it waited for the load it had JUST issued: vmcnt(0) / vmcnt(1) in every step, i.e. one
 // memory round trip per time step). The loads below are invisible to it; the kernel waits by hand with a
 // counted vmcnt (loads, stores and their order are fixed per step), tied to the registers it releases.
-__device__ __forceinline__ float load_untracked(const float* p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
+// Round 6: those loads are plain (compiler-tracked) loads again, and the two kernels DCCRN's use_amp step runs
+// (lstm_fwd_mv_kernel / lstm_bwd_mv_kernel) prefetch through LDS instead (dma_dword below). What went wrong with
+// register destinations the compiler does not know to be in flight: it may COPY such a register (the phi copies of
+// the rotating register sets at the loop's back edge: `v_mov_b32 v135, v136` one step after `global_load_dword
+// v136` was issued, three steps before the counted wait) or park a temporary in it -- correct as long as the
+// load happens to have landed, garbage when HBM is busy (the side stream's weight gradients): one run in three of
+// tests/test_gpu_sizes.py::test_dccrn_default_size_gradients_fp32_and_use_amp had LSTM gradients 10^3 off.
+__device__ __forceinline__ float load_untracked(const float* p) { return *p; }
+// Asynchronous global -> LDS copy, one dword per lane (LDS-DMA): lane l of the wave writes LDS byte address
+// `lds_wave_base` (wave-uniform) + 4 l. There is NO register destination, so nothing the compiler does with
+// registers can touch a load in flight; the issuing wave waits with a counted vmcnt, other waves read behind a
+// barrier. Issued as assembly: a DMA the compiler can see makes it drain vmcnt(0) in front of every LDS read.
+// (m0 is reserved for exactly this use; the kernels below contain no other user of it.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma_dword(const float* lane_src, unsigned int lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+               :: "v"(lane_src), "s"(lds_wave_base) : "memory", "m0");
 }
+#pragma clang diagnostic pop
+__device__ __forceinline__ unsigned int lds_u32(const void* p) { return (unsigned int)(unsigned long long)p; }
 __device__ __forceinline__ float quad_sum(float v) {
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
@@ -596,32 +612,32 @@ __global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(const float* act, co
   for (int i = 0; i < H; ++i) w[i] = w_hh[(long long)(q*H + i)*H + u];
   dg[0][q*GS + u] = 0.f; dg[1][q*GS + u] = 0.f;
   float dc = 0.f;
-  // what step t needs of the forward pass, requested TWO steps ahead (7 untracked loads; out-of-range steps
-  // read step 0 and are ignored): ig, fg, gg, og, c_t, c_{t-1}, dy_t
-  struct Saved { float ig, fg, gg, og, c, cp, dy; };
-  auto fetch = [&](int t) {
+  // What step t needs of the forward pass -- ig, fg, gg, og, c_t, c_{t-1}, dy_t -- through an LDS ring (round 6: see
+  // dma_dword; the layout and the counts are those of lstm_bwd_mv_kernel). Slot t & 7 = [activations 4 H | c_t | c_{t-1}
+  // | dy_t]; per wave and step two LDS-DMAs kPre = 4 steps ahead, then ONE store. This kernel has ONE barrier per step:
+  // the wave's DMAs of step t - 1 (issued at step t + 3; 10 younger operations) land before the barrier ending step t.
+  constexpr int kRing = 8, kPre = 4, kSlot = 7*H;
+  __shared__ float ring[kRing][kSlot];
+  const int wu = __builtin_amdgcn_readfirstlane(j >> 6), lane = j & 63;
+  const unsigned int ring_a = lds_u32(&ring[0][0]) + 256u*(unsigned int)wu;
+  const int part2 = wu < 6 ? wu >> 1 : 2;                         // 0: c_t, 1: c_{t-1}, 2: dy_t
+  const unsigned int ring_b = lds_u32(&ring[0][0]) + (unsigned int)((4 + part2)*H*4 + 256*(wu & 1));
+  const float* src_a = act + (long long)b*T*4*H + 64*wu + lane;
+  const float* src_b = (part2 == 2 ? dy : cs) + (long long)b*T*H + 64*(wu & 1) + lane;
+  auto issue = [&](int t) {
     const int tt = t > 0 ? t : 0;
-    const float* a = act + ((long long)b*T + tt)*4*H + u;
-    Saved v;
-    v.ig = load_untracked(a); v.fg = load_untracked(a + H); v.gg = load_untracked(a + 2*H);
-    v.og = load_untracked(a + 3*H);
-    v.c = load_untracked(cs + ((long long)b*T + tt)*H + u);
-    v.cp = load_untracked(cs + ((long long)b*T + (tt > 0 ? tt - 1 : 0))*H + u);
-    v.dy = load_untracked(dy + ((long long)b*T + tt)*H + u);
-    return v;
+    const int tb = part2 == 1 ? (tt > 0 ? tt - 1 : 0) : tt;
+    const unsigned int slot = (unsigned int)((t & (kRing - 1))*kSlot*4);
+    dma_dword(src_a + (long long)tt*4*H, ring_a + slot);
+    dma_dword(src_b + (long long)tb*H, ring_b + slot);
   };
-  // wait until at most N vector-memory operations are outstanding; releases the 7 values of `v`
-  auto wait16 = [](Saved& v) {
-    // (14, not 16: the two younger stores may retire ahead of older loads -- see lstm_fwd_mv_kernel)
-    asm volatile("s_waitcnt vmcnt(14)" : "+v"(v.ig), "+v"(v.fg), "+v"(v.gg), "+v"(v.og), "+v"(v.c), "+v"(v.cp),
-                 "+v"(v.dy) :: "memory");
-  };
-  // Three register sets take the roles (this step, next step, being fetched) in turn -- the loop is unrolled
-  // three times so that every load has a FIXED destination. Per step, in order: 7 loads (step t - 2), then ONE
-  // store; the set used by step t was requested two steps ago, so 1 + 7 + 1 + 7 = 16 younger operations may
-  // stay in flight.
-  auto step = [&](Saved& cur, int t) {
-    wait16(cur);
+  struct Saved { float ig, fg, gg, og, c, cp, dy; };
+  auto step = [&](int t) {
+    issue(t - kPre);
+    const float* sv = ring[t & (kRing - 1)] + u;
+    Saved cur;
+    cur.ig = sv[0]; cur.fg = sv[H]; cur.gg = sv[2*H]; cur.og = sv[3*H];
+    cur.c = sv[4*H]; cur.cp = sv[5*H]; cur.dy = sv[6*H];
     // dh_t[u] from the gate gradients of step t + 1 (zeros for the last step): this lane's gate rows
     const float* gb = dg[(t + 1) & 1] + q*GS;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -641,17 +657,13 @@ __global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(const float* act, co
     dg[t & 1][q*GS + u] = dq;
     dgates[((long long)b*T + t)*4*H + q*H + u] = dq;
     dc = dct*fg;
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");            // this wave's pieces of step t - 1 are in LDS
     lds_barrier();
   };
-  Saved sa = fetch(T - 1), sb = fetch(T - 2), sc;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the counted wait needs full queues behind it)
+  for (int t = T - 1; t > T - 1 - kPre; --t) issue(t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int t = T - 1;
-  while (t >= 0) {
-    sc = fetch(t - 2); step(sa, t); if (--t < 0) break;
-    sa = fetch(t - 2); step(sb, t); if (--t < 0) break;
-    sb = fetch(t - 2); step(sc, t); --t;
-  }
+  for (int t = T - 1; t >= 0; --t) step(t);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -724,25 +736,25 @@ __global__ __launch_bounds__(512) void lstm_fwd_mv_kernel(const float* gates_in,
   for (int g = 0; g < 4; ++g) bq[g] = bias ? bias[g*H + u] : 0.f;
   if (tid < 2*H) (&hb[0][0])[tid] = 0;
   float c = 0.f;
-  const float* gi = gates_in + (long long)b*T*4*H + u;
+  // Input rows through an LDS ring (round 6: see dma_dword). Slot t & 7 holds the 4 H gate inputs of step t; wave
+  // w copies dwords 64 w .. 64 w + 63 of a row (one LDS-DMA per wave and step), kPre = 4 steps ahead. Per wave and
+  // step, in order: 1 DMA, then 1 + 2 HAS_ACT stores. The wave's DMA of step t + 1 (issued at step t - 3) must have
+  // landed before the barrier that ends step t: younger than it are the stores of step t - 3 and everything of
+  // steps t - 2 .. t = S + 3 (1 + S) operations (vector-memory operations of a wave retire in issue order).
+  constexpr int kRing = 8, kPre = 4, S = HAS_ACT ? 3 : 1;
+  __shared__ float ring[kRing][4*H];
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned int ring0 = lds_u32(&ring[0][0]) + 256u*(unsigned int)wu;
+  const float* gi = gates_in + (long long)b*T*4*H + 64*w + lane;
+  auto issue = [&](int t) {
+    dma_dword(gi + (long long)(t < T ? t : T - 1)*4*H, ring0 + (unsigned int)((t & (kRing - 1))*4*H*4));
+  };
   struct In { float g0, g1, g2, g3; };
-  auto fetch = [&](int t) {
-    const float* p = gi + (long long)(t < T ? t : T - 1)*4*H;
-    In v;
-    v.g0 = load_untracked(p); v.g1 = load_untracked(p + H); v.g2 = load_untracked(p + 2*H);
-    v.g3 = load_untracked(p + 3*H);
-    return v;
-  };
-  // per step, in order: 4 loads (step t + 3), then 1 + 2 HAS_ACT stores; the set of step t was requested three
-  // steps ago, 12 loads and 3 or 9 stores are younger. Loads return in order among themselves, but a store may retire
-  // ahead of an older load: only the 12 younger LOADS are allowed to be outstanding (counting the stores too --
-  // vmcnt(21) -- let a step start on values still in flight when the side stream's products kept HBM busy: one
-  // wrong gradient in a few runs)
-  auto wait_set = [](In& v) {
-    asm volatile("s_waitcnt vmcnt(12)" : "+v"(v.g0), "+v"(v.g1), "+v"(v.g2), "+v"(v.g3) :: "memory");
-  };
-  auto step = [&](In& cur, int t) {
-    wait_set(cur);
+  auto step = [&](int t) {
+    issue(t + kPre);
+    const float* in = ring[t & (kRing - 1)] + u;
+    In cur;
+    cur.g0 = in[0]; cur.g1 = in[H]; cur.g2 = in[2*H]; cur.g3 = in[3*H];
     u32x4 aq[4];
     if (LSTM_MV_MASK) {
 #pragma unroll
@@ -789,18 +801,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_mv_kernel(const float* gates_in,
         act[row*4*H + j*H + u] = j == 0 ? ig : j == 1 ? fg : j == 2 ? gg : og;
       }
     } else if (hn == 123.456f) y[row*H + u] = ig + fg + gg + og;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(S + 3*(1 + S)) : "memory");     // this wave's piece of row t + 1 is in LDS
     if (!(LSTM_MV_ABL & 16)) lds_barrier();
   };
-  In s0 = fetch(0), s1 = fetch(1), s2 = fetch(2), s3;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the counted wait needs full queues behind it)
+  for (int t = 0; t < kPre; ++t) issue(t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int t = 0;
-  while (true) {
-    s3 = fetch(t + 3); step(s0, t); if (++t >= T) break;
-    s0 = fetch(t + 3); step(s1, t); if (++t >= T) break;
-    s1 = fetch(t + 3); step(s2, t); if (++t >= T) break;
-    s2 = fetch(t + 3); step(s3, t); if (++t >= T) break;
-  }
+  for (int t = 0; t < T; ++t) step(t);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -826,25 +833,31 @@ __global__ __launch_bounds__(512) void lstm_bwd_mv_kernel(const float* act, cons
       wf[nb][ks] = lstm_frag8(w_hh + (long long)(64*w + 32*ks + 8*q)*H + 16*nb + n, H);
   (&dgb[0][0])[tid] = 0; (&dgb[0][0])[tid + 512] = 0;
   float dc = 0.f;
-  struct Saved { float ig, fg, gg, og, c, cp, dy; };
-  auto fetch = [&](int t) {
+  // Saved tensors through an LDS ring (round 6: see dma_dword). Slot t & 7 = [activations of step t: 4 H | c_t: H |
+  // c_{t-1}: H | dy_t: H]; per wave and step TWO LDS-DMAs, kPre = 4 steps ahead: wave w copies dwords 64 w .. of the
+  // activation row, and waves (0, 1) / (2, 3) / (4, 5) the halves of c_t / c_{t-1} / dy_t (waves 6, 7 repeat 4, 5:
+  // the same bytes to the same place, so that every wave issues the same number of operations). Per wave and
+  // step, in order: 2 DMAs, then ONE store. The wave's DMAs of step t - 1 (issued at step t + 3) must have landed
+  // before the barrier that ends step t: younger than them are the store of step t + 3 and the three operations of
+  // each of the steps t + 2 .. t = 10 (vector-memory operations of a wave retire in issue order).
+  constexpr int kRing = 8, kPre = 4, kSlot = 7*H;
+  __shared__ float ring[kRing][kSlot];
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned int ring_a = lds_u32(&ring[0][0]) + 256u*(unsigned int)wu;
+  const int part2 = wu < 6 ? wu >> 1 : 2;                         // 0: c_t, 1: c_{t-1}, 2: dy_t
+  const unsigned int ring_b = lds_u32(&ring[0][0]) + (unsigned int)((4 + part2)*H*4 + 256*(wu & 1));
+  const float* src_a = act + (long long)b*T*4*H + 64*w + lane;
+  const float* src_b = (part2 == 2 ? dy : cs) + (long long)b*T*H + 64*(w & 1) + lane;
+  auto issue = [&](int t) {
     const int tt = t > 0 ? t : 0;
-    const float* a = act + ((long long)b*T + tt)*4*H + u;
-    Saved v;
-    v.ig = load_untracked(a); v.fg = load_untracked(a + H); v.gg = load_untracked(a + 2*H);
-    v.og = load_untracked(a + 3*H);
-    v.c = load_untracked(cs + ((long long)b*T + tt)*H + u);
-    v.cp = load_untracked(cs + ((long long)b*T + (tt > 0 ? tt - 1 : 0))*H + u);
-    v.dy = load_untracked(dy + ((long long)b*T + tt)*H + u);
-    return v;
+    const int tb = part2 == 1 ? (tt > 0 ? tt - 1 : 0) : tt;
+    const unsigned int slot = (unsigned int)((t & (kRing - 1))*kSlot*4);
+    dma_dword(src_a + (long long)tt*4*H, ring_a + slot);
+    dma_dword(src_b + (long long)tb*H, ring_b + slot);
   };
-  // per step: 7 loads (step t - 3), then ONE store; the set of step t was requested three steps ago: 21 younger
-  // loads may stay in flight (the 3 younger stores are not counted on: see the forward kernel)
-  auto wait24 = [](Saved& v) {
-    asm volatile("s_waitcnt vmcnt(21)" : "+v"(v.ig), "+v"(v.fg), "+v"(v.gg), "+v"(v.og), "+v"(v.c), "+v"(v.cp),
-                 "+v"(v.dy) :: "memory");
-  };
-  auto step = [&](Saved& cur, int t) {
+  struct Saved { float ig, fg, gg, og, c, cp, dy; };
+  auto step = [&](int t) {
+    issue(t - kPre);
     // this wave's slice of the gate gradients of step t + 1 (zeros for the last step)
     const uint16_t* gp = dgb[(t + 1) & 1] + 64*w + 8*q;
     const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(gp), a1 = *reinterpret_cast<const bf16x8*>(gp + 32);
@@ -858,8 +871,11 @@ __global__ __launch_bounds__(512) void lstm_bwd_mv_kernel(const float* act, cons
     const float e0 = q == 0 ? p[0][0] : q == 1 ? p[2][0] : q == 2 ? p[4][0] : p[6][0];
     const float e1 = q == 0 ? p[1][0] : q == 1 ? p[3][0] : q == 2 ? p[5][0] : p[7][0];
     part[w][32*q + n] = e0; part[w][32*q + 16 + n] = e1;
+    const float* sv = ring[t & (kRing - 1)] + u;
+    Saved cur;
+    cur.ig = sv[0]; cur.fg = sv[H]; cur.gg = sv[2*H]; cur.og = sv[3*H];
+    cur.c = sv[4*H]; cur.cp = sv[5*H]; cur.dy = sv[6*H];
     lds_barrier();
-    wait24(cur);
     float dht = cur.dy;
 #pragma unroll
     for (int i = 0; i < 8; ++i) dht += part[i][u];
@@ -872,18 +888,13 @@ __global__ __launch_bounds__(512) void lstm_bwd_mv_kernel(const float* act, cons
     dgb[t & 1][q*H + u] = f2bf(dq);
     dgates[((long long)b*T + t)*4*H + q*H + u] = dq;
     dc = dct*fg;
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");            // this wave's pieces of step t - 1 are in LDS
     lds_barrier();
   };
-  Saved s0 = fetch(T - 1), s1 = fetch(T - 2), s2 = fetch(T - 3), s3;
+  for (int t = T - 1; t > T - 1 - kPre; --t) issue(t);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int t = T - 1;
-  while (true) {
-    s3 = fetch(t - 3); step(s0, t); if (--t < 0) break;
-    s0 = fetch(t - 3); step(s1, t); if (--t < 0) break;
-    s1 = fetch(t - 3); step(s2, t); if (--t < 0) break;
-    s2 = fetch(t - 3); step(s3, t); if (--t < 0) break;
-  }
+  for (int t = T - 1; t >= 0; --t) step(t);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

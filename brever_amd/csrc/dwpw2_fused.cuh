@@ -95,8 +95,19 @@ __global__ __launch_bounds__(512) void dwpw2_fused_kernel(const DwPw2Params p) {
   const int run_lo = per_xcd/wg_per_xcd, run_rem = per_xcd % wg_per_xcd;
   const int ti_lo = DP_CONTIG ? slot*run_lo + min(slot, run_rem) : slot;
   const int ti_hi = DP_CONTIG ? ti_lo + run_lo + (slot < run_rem ? 1 : 0) : per_xcd;
+  // Round 6 (94 MB read per launch against 70 MB in round 4): with a run of ADJACENT tiles per workgroup
+  // all workgroups of an XCD start on every second tile and come back for the tiles in between ~25 us later, when
+  // the dilated taps those share with their neighbours (up to 2 x 128 rows per 128-row tile) have left the 4 MB L2
+  // again: the halo rows were fetched from HBM twice. When the counts divide evenly (the whole-batch launch:
+  // 64 tiles = 2 items per XCD on 32 workgroups) a workgroup's tiles now lie `gap` = tiles-per-item / run apart
+  // INSIDE one item -- the workgroups of an item walk a contiguous range of its tiles together in every round
+  // (halo rows shared in time, as under the strided deal) and still build the item's tables once.
+  const bool even_deal = DP_CONTIG && run_rem == 0 && run_lo > 1 && (n_tiles & 7) == 0 && per_xcd % tpi == 0 &&
+                         tpi % run_lo == 0;
+  const int gap = even_deal ? tpi/run_lo : 1;
+  const int tile0 = xcd*per_xcd + (even_deal ? (slot/gap)*tpi + slot % gap : ti_lo);
   for (int ti_ = ti_lo; ti_ < ti_hi; ti_ += DP_CONTIG ? 1 : wg_per_xcd) {
-    const int tile = xcd*per_xcd + ti_;
+    const int tile = DP_CONTIG ? tile0 + (ti_ - ti_lo)*gap : xcd*per_xcd + ti_;
     if (tile >= n_tiles) break;
     const int b = tile / tpi, t0 = (tile % tpi)*DP_TT;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.z1 + (long long)b*T*DP_H, (long long)T*DP_H*2);

@@ -445,15 +445,18 @@ constexpr int QC = 4;                 // chains per workgroup
 typedef unsigned int q4_u32x2 __attribute__((ext_vector_type(2)));
 template <bool IO16> struct Q4Raw { typedef f32x4 type; };
 template <> struct Q4Raw<true> { typedef q4_u32x2 type; };
+// Round 6: plain, compiler-tracked loads. Until then these were assembly loads the compiler could not see, waited for
+// by a hand-counted vmcnt three steps later -- but a register the compiler does not know to be in flight may be copied
+// (the rotating register sets need phi copies at the loop's back edge) or reused before the load has landed: see
+// csrc/dccrn.hip `dma_dword`, where the same scheme produced wrong LSTM gradients in one run of three under HBM load.
+// The hand-counted waits below stay (they are no-ops behind the compiler's own).
 __device__ __forceinline__ void q4_load(f32x4& v, const float* p, long long i) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p + i) : "memory");
+  v = *reinterpret_cast<const f32x4*>(p + i);
 }
 __device__ __forceinline__ void q4_load(q4_u32x2& v, const float* p, long long i) {
-  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(reinterpret_cast<const uint16_t*>(p) + i) : "memory");
+  v = *reinterpret_cast<const q4_u32x2*>(reinterpret_cast<const uint16_t*>(p) + i);
 }
-__device__ __forceinline__ void q4_load1(float& v, const float* p, long long i) {
-  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p + i) : "memory");
-}
+__device__ __forceinline__ void q4_load1(float& v, const float* p, long long i) { v = p[i]; }
 __device__ __forceinline__ f32x4 q4_value(const f32x4& v) { return v; }
 __device__ __forceinline__ f32x4 q4_value(const q4_u32x2& u) {
   return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),

@@ -169,9 +169,9 @@ def test_dccrn_default_size_gradients_fp32_and_use_amp():
         # operands cost there by themselves, not a kernel defect; the largest HIP / emulation ratio of any tensor is 1.11
         assert abs(float(loss.detach()) - float(loss_ref.detach())) <= \
             1.5*abs(float(loss_emu.detach()) - float(loss_ref.detach())) + 1e-3, (float(loss), float(loss_emu), float(loss_ref))
-        assert e <= 1.5*e_emu + 1e-3, (e, e_emu)
         ratios = sorted(((t_hip[k]/(1.5*t_emu[k] + 1e-3), k, t_hip[k], t_emu[k]) for k in t_hip), reverse=True)
-        print('   largest HIP / (1.5 emulation + 1e-3) ratios:', [(round(r, 3), k, round(h, 4), round(e_, 4)) for r, k, h, e_ in ratios[:4]])
+        print('   largest HIP / (1.5 emulation + 1e-3) ratios:', [(round(r, 3), k, round(h, 4), round(e_, 4)) for r, k, h, e_ in ratios[:6]])
+        assert e <= 1.5*e_emu + 1e-3, (e, e_emu)
         assert ratios[0][0] <= 1.0, ratios[:5]
 
 
