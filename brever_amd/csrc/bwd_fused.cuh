@@ -63,14 +63,13 @@ struct BwdFusedParams {
 #define BF_WPS 3     // resident workgroups per CU the register budget is set for (diagnostic builds: 4)
 #endif
 constexpr int BF_ROWS = BF_ROWS_N;         // window rows (teeth x rows per tooth), 8 MFMA groups of 32
-#ifndef BF_ROWCAP
-#define BF_ROWCAP BF_ROWS_N                // output rows a tile may hold (<= BF_ROWS_N)
-#endif
 constexpr int BF_LDW = HL_CG + 8;          // halves per window row: 144 B
 constexpr int BF_LDS = BF_ROWS*BF_LDW*2 + 32*HL_CG*4;   // window + the reduction scratch
 
 // Tile shape (K centre teeth x R rows per tooth, window (K + P - 1) R <= BF_ROWS rows): the pair with the
-// fewest tiles per item, teeth balanced over the tooth groups. R need not be a power of two: at dilation
+// fewest tiles per item, teeth balanced over the tooth groups. (Round 6: MORE, smaller tiles -- so that the launch's
+// 2 048 workgroups become a whole number of rounds of the 768 resident ones -- measured slower: 224 / 200 / 168 output
+// rows per tile 70.9 / 71.3 / 75.5 us against 68.8 at 250.) R need not be a power of two: at dilation
 // 128 and T = 3999 (32 teeth) 7 rows x 32 teeth give 19 tiles where 8 x 16 gave 32 -- the per-workgroup
 // costs (parameter table, folds, atomics) made that dilation 94 us against 73 us at dilation 1.
 inline void bf_tile_shape(int T, int dil, int P, int& K, int& R) {
@@ -78,8 +77,7 @@ inline void bf_tile_shape(int T, int dil, int P, int& K, int& R) {
   long long best = -1;
   K = 1; R = 1;
   for (int r = 1; r <= HL_RMAX*2 && r <= dil; ++r) {
-    int kmax = BF_ROWS/r - (P - 1);
-    if (BF_ROWCAP/r < kmax) kmax = BF_ROWCAP/r;          // (diagnostic builds: fewer output rows per tile, more tiles)
+    const int kmax = BF_ROWS/r - (P - 1);
     if (kmax < 1) break;
     const int n_qt = ceil_div(n_teeth, kmax);
     const int k = ceil_div(n_teeth, n_qt);
