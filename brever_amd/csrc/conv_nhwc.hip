@@ -751,6 +751,8 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_kernel(const ConvNhwcPar
 #endif
 }
 
+#include "conv_nhwc_splitk.cuh"
+
 // wp[co block of 128][chunk][tap][k-step 2][co fragment 4][lane 64][8] <- w[co][ci][tap]
 __global__ __launch_bounds__(256) void conv_nhwc_pack_kernel(const float* w, _Float16* wp, int Cout,
                                                              int Cin, int taps, int n_chunks,
@@ -816,7 +818,8 @@ int conv_nhwc_launch(const void* x1, int64_t C1, int64_t C1s, const void* x2, in
                      const void* wp, const float* bias, const void* res, int64_t Crs,
                      const float* in_scale, const float* in_shift, const ConvNhwcNorm* gn, int in_silu,
                      void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout, int64_t ksize,
-                     float out_scale, double* stats, brv_stream_t stream) {
+                     float out_scale, double* stats, brv_stream_t stream,
+                     float* split_ws = nullptr, long long split_floats = 0) {
   if (B < 1 || H < 1 || W < 1 || C1 < 1 || Cout < 1 || ksize != 3) return -1;
   if ((C1s & 7) || C1 > C1s || (Cys & 7) || (res && (Crs & 7)) || (Cout & 3)) return -2;
   if (x2 && ((C2s & 7) || C2 > C2s || C2 < 1 || (C1 % CN_CK) != 0)) return -2;
@@ -841,6 +844,40 @@ int conv_nhwc_launch(const void* x1, int64_t C1, int64_t C1s, const void* x2, in
   p.C1 = (int)C1; p.C2 = x2 ? (int)C2 : 0;
   p.n_wt = (int)((W + CN_COLS - 1)/CN_COLS);
   p.n_cob = (int)((Cout + 127)/128);
+  // Low-resolution launches (few tiles): the reduction split over workgroups, partial sums through the caller's
+  // scratch (conv_nhwc_splitk.cuh). Without scratch -- the entry points of rounds 2 - 5 -- the pixel-parallel kernel.
+  if (split_ws) {
+    int cpw = 0, n_split = 1;
+    const long long need = conv_split_plan(B, H, W, p.n_chunks, p.n_cob, cpw, n_split);
+    if (need > 0 && need <= split_floats && (!gn || (Cin % gn->groups) == 0)) {
+      ConvSplitParams sp;
+      memset(&sp, 0, sizeof(sp));
+      sp.x1 = p.x1; sp.x2 = p.x2; sp.wp = p.wp; sp.in_scale = in_scale; sp.in_shift = in_shift;
+      if (gn) {
+        sp.sums1 = gn->sums1; sp.sums2 = gn->sums2; sp.gn_add = gn->add; sp.gn_gamma = gn->gamma; sp.gn_beta = gn->beta;
+        sp.adm_scale = gn->adm_scale; sp.adm_shift = gn->adm_shift; sp.groups = gn->groups; sp.eps = gn->eps;
+      }
+      sp.C1 = p.C1; sp.C2 = p.C2; sp.part = split_ws;
+      sp.B = p.B; sp.H = p.H; sp.W = p.W; sp.C1s = p.C1s; sp.C2s = p.C2s; sp.n_chunks1 = p.n_chunks1;
+      sp.n_chunks = p.n_chunks; sp.Cin = p.Cin; sp.n_wt = p.n_wt; sp.n_ht = (int)((H + CS_ROWS - 1)/CS_ROWS);
+      sp.n_cob = p.n_cob; sp.cpw = cpw; sp.in_silu = in_silu;
+      const dim3 sgrid((unsigned)(B*sp.n_ht*sp.n_wt), (unsigned)p.n_cob, (unsigned)n_split);
+      const hipStream_t sst = (hipStream_t)stream;
+      if (gn) hipLaunchKernelGGL((conv_nhwc_splitk_kernel<2>), sgrid, dim3(CN_THREADS), 0, sst, sp);
+      else if (in_scale) hipLaunchKernelGGL((conv_nhwc_splitk_kernel<1>), sgrid, dim3(CN_THREADS), 0, sst, sp);
+      else hipLaunchKernelGGL((conv_nhwc_splitk_kernel<0>), sgrid, dim3(CN_THREADS), 0, sst, sp);
+      CN_OK(hipGetLastError());
+      ConvCombineParams cp;
+      memset(&cp, 0, sizeof(cp));
+      cp.part = split_ws; cp.n_split = n_split; cp.cq_n = p.n_cob*32; cp.npix = (long long)B*H*W; cp.hw = (long long)H*W;
+      cp.bias = bias; cp.res = (const _Float16*)res; cp.y = (_Float16*)y; cp.stats = stats;
+      cp.Cout = (int)Cout; cp.Crs = (int)Crs; cp.Cys = (int)Cys; cp.out_scale = out_scale;
+      const dim3 cgrid((unsigned)((H*W + 255)/256), (unsigned)(B*cp.cq_n));
+      hipLaunchKernelGGL(conv_nhwc_combine_kernel, cgrid, dim3(256), 0, sst, cp);
+      CN_OK(hipGetLastError());
+      return 0;
+    }
+  }
   // rows per tile: 16 when that fills the chip, else 8 or 4 (2-4x the workgroups)
 #ifndef BRV_CONV_PF
 #define BRV_CONV_PF 0          // diagnostic builds: force the rows per tile (1, 2 or 4 x 4 rows)
@@ -919,6 +956,41 @@ int brv_conv_nhwc_forward(const void* x1, int64_t C1, int64_t C1s, const void* x
                           int64_t ksize, float out_scale, double* stats, brv_stream_t stream) {
   return conv_nhwc_launch(x1, C1, C1s, x2, C2, C2s, wp, bias, res, Crs, in_scale, in_shift, nullptr,
                           in_silu, y, Cys, B, H, W, Cout, ksize, out_scale, stats, stream);
+}
+
+// The same two entry points with a caller-provided scratch for the launches whose reduction is split over workgroups
+// (conv_nhwc_splitk.cuh): brv_conv_nhwc_split_ws_bytes says how much a launch of these sizes would use (0: none).
+int64_t brv_conv_nhwc_split_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t Cout) {
+  if (B < 1 || H < 1 || W < 1 || C1 < 1 || Cout < 1) return 0;
+  int cpw = 0, n_split = 1;
+  const long long n_chunks = (C1 + CN_CK - 1)/CN_CK + (C2 > 0 ? (C2 + CN_CK - 1)/CN_CK : 0);
+  return 4*conv_split_plan(B, H, W, n_chunks, (Cout + 127)/128, cpw, n_split);
+}
+
+int brv_conv_nhwc_forward_ws(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                             int64_t C2s, const void* wp, const float* bias, const void* res,
+                             int64_t Crs, const float* in_scale, const float* in_shift, int in_silu,
+                             void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout,
+                             int64_t ksize, float out_scale, double* stats, void* split_ws,
+                             int64_t split_ws_bytes, brv_stream_t stream) {
+  return conv_nhwc_launch(x1, C1, C1s, x2, C2, C2s, wp, bias, res, Crs, in_scale, in_shift, nullptr,
+                          in_silu, y, Cys, B, H, W, Cout, ksize, out_scale, stats, stream,
+                          (float*)split_ws, split_ws_bytes/4);
+}
+
+int brv_conv_nhwc_forward_gn_ws(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                                int64_t C2s, const void* wp, const float* bias, const void* res,
+                                int64_t Crs, const double* sums1, const double* sums2,
+                                const float* add_bc, const float* gamma, const float* beta,
+                                const float* adm_scale, const float* adm_shift, int64_t groups, float eps,
+                                float* fold_ws, int in_silu, void* y, int64_t Cys, int64_t B, int64_t H,
+                                int64_t W, int64_t Cout, int64_t ksize, float out_scale, double* stats,
+                                void* split_ws, int64_t split_ws_bytes, brv_stream_t stream) {
+  if (!sums1 || !gamma || !beta || (x2 && !sums2)) return -1;
+  ConvNhwcNorm gn = {sums1, sums2, add_bc, gamma, beta, adm_scale, adm_shift, (int)groups, eps, fold_ws};
+  return conv_nhwc_launch(x1, C1, C1s, x2, C2, C2s, wp, bias, res, Crs, nullptr, nullptr, &gn, in_silu,
+                          y, Cys, B, H, W, Cout, ksize, out_scale, stats, stream,
+                          (float*)split_ws, split_ws_bytes/4);
 }
 
 int brv_conv_nhwc_forward_gn(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,

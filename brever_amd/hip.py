@@ -283,6 +283,14 @@ SIGNATURES = {
     'brv_conv_nhwc_forward_gn': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr,
                                                 _c_ptr, _c_ptr, _c_i64] + [_c_ptr]*7 + [_c_i64, _c_f32, _c_ptr,
                                                 ctypes.c_int, _c_ptr] + [_c_i64]*6 + [_c_f32, _c_ptr, _c_ptr]),
+    'brv_conv_nhwc_split_ws_bytes': (_c_i64, [_c_i64]*6),
+    'brv_conv_nhwc_forward_ws': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr,
+                                                _c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, ctypes.c_int,
+                                                _c_ptr] + [_c_i64]*6 + [_c_f32, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
+    'brv_conv_nhwc_forward_gn_ws': (ctypes.c_int, [_c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr,
+                                                   _c_ptr, _c_ptr, _c_i64] + [_c_ptr]*7 + [_c_i64, _c_f32, _c_ptr,
+                                                   ctypes.c_int, _c_ptr] + [_c_i64]*6
+                                    + [_c_f32, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
     'brv_groupnorm_fold_chan2': (ctypes.c_int, [_c_ptr, _c_i64, _c_ptr, _c_i64] + [_c_ptr]*7
                                  + [_c_i64]*3 + [_c_f32, _c_ptr]),
     'brv_nchw_to_nhwc_f16': (ctypes.c_int, [_c_ptr, _c_ptr] + [_c_i64]*4 + [_c_ptr]),

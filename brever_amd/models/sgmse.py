@@ -39,6 +39,7 @@ _GN_SCRATCH = {}
 # convolution weights, the stacked q / k / v and embedding matrices, captured HIP graphs) is keyed on this counter
 # too. ``SGMSEp.mark_params_changed`` -- called by FlatAdam.step, EMA and the trainer's checkpoint loads -- bumps it.
 _PARAM_EPOCH = [0]
+_CONV_SPLIT = os.environ.get('BRV_CONV_SPLIT', '1') != '0'
 
 
 class hip_autocast:
@@ -324,20 +325,25 @@ def _h_conv3(a, mod, fold=None, silu=False, res=None, out_scale=1.0, norm=None, 
     common = (hip.ptr(a.t), a.C, a.Cs, hip.ptr(b.t) if b is not None else None, b.C if b is not None else 0,
               b.Cs if b is not None else 0, hip.ptr(_h_packed3(mod)), hip.ptr(mod.bias),
               hip.ptr(res.t) if res is not None else None, res.Cs if res is not None else 0)
+    # scratch of the launches that split their reduction over workgroups (the inner U-Net levels: csrc/conv_nhwc_splitk.cuh);
+    # BRV_CONV_SPLIT=0: the pixel-parallel kernel for every launch (rounds 2 - 5)
+    nsplit = hip.lib().brv_conv_nhwc_split_ws_bytes(B, H, W, a.C, b.C if b is not None else 0, mod.out_channels) \
+        if _CONV_SPLIT else 0
+    split_ws = torch.empty(nsplit, dtype=torch.uint8, device=a.t.device) if nsplit > 0 else None
     tail = (int(silu), hip.ptr(y.t), y.Cs, B, H, W, mod.out_channels, 3, float(out_scale), hip.ptr(y.sums),
-            hip.stream())
+            hip.ptr(split_ws), nsplit, hip.stream())
     if norm is not None:
         ws = torch.empty(2*B*a.channels, dtype=torch.float32, device=a.t.device)
         a0, a1 = (adm[0].contiguous(), adm[1].contiguous()) if adm is not None else (None, None)
-        hip.check(hip.lib().brv_conv_nhwc_forward_gn(
+        hip.check(hip.lib().brv_conv_nhwc_forward_gn_ws(
             *common, hip.ptr(_h_sums(a)), hip.ptr(_h_sums(b)) if b is not None else None,
             hip.ptr(add.contiguous()) if add is not None else None, hip.ptr(norm.weight),
             hip.ptr(norm.bias), hip.ptr(a0), hip.ptr(a1), norm.num_groups, float(norm.eps), hip.ptr(ws),
-            *tail), 'brv_conv_nhwc_forward_gn')
+            *tail), 'brv_conv_nhwc_forward_gn_ws')
         return y
     sc, sf = fold if fold is not None else (None, None)
-    hip.check(hip.lib().brv_conv_nhwc_forward(*common, hip.ptr(sc), hip.ptr(sf), *tail),
-              'brv_conv_nhwc_forward')
+    hip.check(hip.lib().brv_conv_nhwc_forward_ws(*common, hip.ptr(sc), hip.ptr(sf), *tail),
+              'brv_conv_nhwc_forward_ws')
     return y
 
 

@@ -757,6 +757,27 @@ int brv_conv_nhwc_forward_gn(const void* x1, int64_t C1, int64_t C1s, const void
                              float* fold_ws, int in_silu, void* y, int64_t Cys, int64_t B, int64_t H,
                              int64_t W, int64_t Cout, int64_t ksize, float out_scale, double* stats,
                              brv_stream_t stream);
+/* Round 6: the same two convolutions with a caller-provided scratch. Launches with few tiles (the inner levels of
+ * the U-Net: up to 128 (4-row tile, 128-channel block) pairs) split the REDUCTION over workgroups -- partial sums in
+ * fp32 through `split_ws`, added in split order by a second launch together with bias, residual, scale and the
+ * GroupNorm statistics (csrc/conv_nhwc_splitk.cuh) -- instead of leaving most of the chip idle.
+ * brv_conv_nhwc_split_ws_bytes: bytes such a launch uses (0: the launch does not split; any smaller scratch, or
+ * NULL, selects the pixel-parallel kernel of the entry points above). */
+int64_t brv_conv_nhwc_split_ws_bytes(int64_t B, int64_t H, int64_t W, int64_t C1, int64_t C2, int64_t Cout);
+int brv_conv_nhwc_forward_ws(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                             int64_t C2s, const void* wp, const float* bias, const void* res,
+                             int64_t Crs, const float* in_scale, const float* in_shift, int in_silu,
+                             void* y, int64_t Cys, int64_t B, int64_t H, int64_t W, int64_t Cout,
+                             int64_t ksize, float out_scale, double* stats, void* split_ws,
+                             int64_t split_ws_bytes, brv_stream_t stream);
+int brv_conv_nhwc_forward_gn_ws(const void* x1, int64_t C1, int64_t C1s, const void* x2, int64_t C2,
+                                int64_t C2s, const void* wp, const float* bias, const void* res,
+                                int64_t Crs, const double* sums1, const double* sums2,
+                                const float* add_bc, const float* gamma, const float* beta,
+                                const float* adm_scale, const float* adm_shift, int64_t groups, float eps,
+                                float* fold_ws, int in_silu, void* y, int64_t Cys, int64_t B, int64_t H,
+                                int64_t W, int64_t Cout, int64_t ksize, float out_scale, double* stats,
+                                void* split_ws, int64_t split_ws_bytes, brv_stream_t stream);
 int brv_groupnorm_fold_chan2(const double* sums1, int64_t C1, const double* sums2, int64_t C2,
                              const float* add_bc, const float* gamma, const float* beta,
                              const float* adm_scale, const float* adm_shift, float* scale_bc,

@@ -1580,6 +1580,67 @@ def test_sgmse_channels_last_kernels_match_torch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('c1,c2,co,H,W,B', [(256, 0, 256, 32, 63, 1), (256, 256, 256, 16, 32, 1), (256, 0, 256, 4, 8, 1),
+                                            (128, 128, 256, 8, 16, 2), (256, 0, 256, 64, 126, 1), (96, 64, 136, 9, 33, 3),
+                                            (256, 256, 128, 16, 32, 8)])
+def test_sgmse_low_resolution_convolution_with_split_reduction(c1, c2, co, H, W, B):
+    """csrc/conv_nhwc_splitk.cuh (round 6): the 3x3 convolution of the inner U-Net levels with its reduction split
+    over workgroups (fp32 partial sums through a scratch, combined in split order with bias, residual, scale and the
+    GroupNorm statistics) against torch fp32 on the fp16-rounded operands -- the bound of the pixel-parallel kernel,
+    2e-3 -- for the three forms of its input: plain, a folded GroupNorm given as scale / shift, and the GroupNorm
+    given by its ingredients (folded by the kernel itself: `norm=`, the form the network uses), with SiLU, embedding
+    term, skip concatenation, residual and scale; the statistics it leaves for the next GroupNorm against those of
+    the pixel-parallel kernel (BRV_CONV_SPLIT=0) and against the output itself. Shapes: the levels of the default
+    network at batch 1 (64 x 126 ... 4 x 8, 256 and 256 + 256 channels), odd sizes with a channel tail, batch 8."""
+    import torch.nn.functional as F
+    import brever_amd.models.sgmse as M
+    from brever_amd import hip
+    dev = _cuda()
+    g = torch.Generator().manual_seed(c1 + 3*c2 + H)
+    ci = c1 + c2
+    assert hip.lib().brv_conv_nhwc_split_ws_bytes(B, H, W, c1, c2, co) > 0         # these launches do split
+    conv = torch.nn.Conv2d(ci, co, 3, 1, 1)
+    gn = M.GroupNorm(ci)
+    with torch.no_grad():
+        gn.weight.add_(0.2*torch.randn(ci, generator=g)); gn.bias.add_(0.2*torch.randn(ci, generator=g))
+    xx = torch.randn(B, ci, H, W, generator=g) + 0.5
+    ee = torch.randn(B, ci, generator=g)
+    rr = torch.randn(B, co, H, W, generator=g)
+    xh, rh = xx.half().float(), rr.half().float()
+    ref = 0.7*(conv(F.silu(gn(xh + ee[:, :, None, None]))) + rh).detach()
+    ref_plain = conv(xh).detach()
+    conv, gn = conv.to(dev), gn.to(dev)
+
+    def run(split):
+        M._CONV_SPLIT = split
+        try:
+            act = M._h_from_nchw(xx[:, :c1].to(dev))
+            if c2:
+                act = M._Act(act.t, act.C, second=M._h_from_nchw(xx[:, c1:].to(dev)))
+            fold = M._h_gn_fold(act, gn, add=ee.to(dev))
+            res = M._h_from_nchw(rr.to(dev))
+            y1 = M._h_conv3(act, conv, fold=fold, silu=True, res=res, out_scale=0.7)
+            y2 = M._h_conv3(act, conv, norm=gn, add=ee.to(dev), silu=True, res=res, out_scale=0.7)
+            y0 = M._h_conv3(act, conv)
+            torch.cuda.synchronize()
+            return [(M._h_to_nchw(y), y.sums.clone()) for y in (y1, y2, y0)]
+        finally:
+            M._CONV_SPLIT = True
+    new, old = run(True), run(False)
+    for k, want in enumerate((ref, ref, ref_plain)):
+        out, sums = new[k]
+        e = rel(out, want)
+        print(f'({c1}+{c2}) -> {co}, {B} x {H} x {W}, form {k}: split rel {e:.2e}, pixel-parallel rel {rel(old[k][0], want):.2e}')
+        assert e <= 2e-3, (k, e)
+        assert rel(out, old[k][0]) <= 2e-3
+        # statistics of the rounded output: (sum, sum of squares) per item and channel
+        o16 = out.double()
+        direct = torch.stack([o16.sum(dim=(2, 3)), (o16*o16).sum(dim=(2, 3))], dim=-1)
+        assert rel(sums.cpu(), direct.cpu()) <= 1e-6, rel(sums.cpu(), direct.cpu())
+        assert rel(sums, old[k][1]) <= 5e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('block_type,enc,dec', [('ncsn', 'skip', 'skip'), ('adm', 'standard', 'standard'),
                                                 ('adm', 'skip', 'skip'), ('ncsn', 'standard', 'standard')])
 def test_sgmse_channels_last_network_matches_fp32_path(block_type, enc, dec):
