@@ -621,16 +621,25 @@ def main():
     for i in range(probe):
         step(i)
     torch.cuda.synchronize()
-    per_step = (time.perf_counter() - t_p)/probe
-    extra = max(0, int(args.min_warmup_s/max(per_step, 1e-4)) + 1 - probe) if args.min_warmup_s > 0 else 0
-    if not single:
-        t = torch.tensor([extra], dtype=torch.int64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        extra = int(t)
-    for i in range(extra):
-        step(i)
-    torch.cuda.synchronize()
+    extra = 0
+    while args.min_warmup_s > 0:
+        # (rounds of steps until the time is reached: the first estimate of a step comes from a chip that is still
+        # warming up and is too long; every round's count is the maximum over the ranks)
+        done_s = time.perf_counter() - t_p
+        per_step = done_s/(probe + extra)
+        more = int((args.min_warmup_s - done_s)/max(per_step, 1e-4)) + 1 if done_s < args.min_warmup_s else 0
+        if not single:
+            t = torch.tensor([more], dtype=torch.int64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            more = int(t)
+        if more <= 0:
+            break
+        for i in range(more):
+            step(i)
+        torch.cuda.synchronize()
+        extra += more
     warm = {'steps': args.warmup + probe + extra, 'seconds': time.perf_counter() - t_first,
+            'seconds_of_steady_steps': time.perf_counter() - t_p,
             'min_seconds_of_steady_steps': args.min_warmup_s,
             'note': f'--warmup {args.warmup} (incl. first-step allocations) + {probe} probe steps + {extra} more until '
                     f'{args.min_warmup_s} s of steps had run'}

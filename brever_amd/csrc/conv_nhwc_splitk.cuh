@@ -15,9 +15,9 @@
 // statistics of the next GroupNorm.
 //
 // Same operand conventions as conv_nhwc_kernel (the packed weights of brv_conv_nhwc_pack are read as they are):
-// A = weight fragments [k-step 2][co fragment 4][lane 64][8] straight from L2 to registers, one tap ahead (each
-// wave fetches its own 2 x 2 fragments of a tap: 4 KB per wave and tap; the four waves that share a channel half
-// hit the same lines in L1); B = the (6 x 34)-pixel patch of the chunk in LDS, pixel-major, the four 16-byte channel
+// A = weight fragments [k-step 2][co fragment 4][lane 64][8] straight from L2 to registers, a whole chunk (9 taps) in
+// flight (each wave fetches its own 2 x 2 fragments of a tap: 4 KB per wave and tap; the four waves that share a
+// channel half hit the same lines in L1); B = the (6 x 34)-pixel patch of the chunk in LDS, pixel-major, the four 16-byte channel
 // octets of a pixel XOR-swizzled by ((column >> 2) & 3). The patch goes through REGISTERS here (two 16-byte pieces
 // per thread, the next chunk's requested before this chunk's products): the folded GroupNorm (+ SiLU) and the
 // zero padding are applied on the way, one pass, no LDS rewrite; two patch buffers, one barrier per chunk.
@@ -38,6 +38,16 @@ struct ConvSplitParams {
 
 constexpr int CS_ROWS = 4, CS_PR = CS_ROWS + 2, CS_PC = CN_COLS + 2, CS_NPX = CS_PR*CS_PC, CS_NSLOT = CS_NPX*4;
 constexpr int CS_MAXCPW = 8;                              // chunks per workgroup (size of the fold table)
+#ifndef BRV_CONV_SPLIT_MAX_BASE
+#define BRV_CONV_SPLIT_MAX_BASE 64      // (tiles x channel blocks) of the launch up to which the reduction is split (128 takes
+                                        // in the 64 x 126 level at batch 1: 25 MB of partial sums, 56 us against 47: 5.18 against 4.96 ms per evaluation)
+#endif
+#ifndef BRV_CONV_SPLIT_TARGET
+#define BRV_CONV_SPLIT_TARGET 256       // workgroups a split launch aims for (384 / 768: no faster)
+#endif
+#ifndef BRV_CONV_SPLIT_MAX
+#define BRV_CONV_SPLIT_MAX 8            // splits at most (scratch traffic: 1 KB per pixel, split and 256 channels)
+#endif
 
 template <int FOLD>
 __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_splitk_kernel(const ConvSplitParams p) {
@@ -55,42 +65,6 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_splitk_kernel(const Conv
   const int c_lo = split*p.cpw, c_hi = c_lo + p.cpw < p.n_chunks ? c_lo + p.cpw : p.n_chunks;
   const int n_my = c_hi - c_lo;
   const long long hw = (long long)p.H*p.W;
-
-  // ---- the folded GroupNorm of this workgroup's n_my x 32 input channels: scale | shift
-  if (FOLD != 0) {
-    if (tid < n_my*CN_CK) {
-      const int c = c_lo*CN_CK + tid;
-      float sc = 0.f, sh = 0.f;
-      if (c < p.Cin) {
-        const long long idx = (long long)b*p.Cin + c;
-        if (FOLD == 1) { sc = p.in_scale[idx]; sh = p.in_shift[idx]; }
-        else {                                            // the arithmetic of chan_fold_kernel (nhwc.hip) / conv_nhwc_kernel
-          const int cpg = p.Cin/p.groups;
-          const int g0 = (c/cpg)*cpg;
-          const double n_px = (double)p.H*(double)p.W;
-          double s1 = 0.0, s2 = 0.0;
-          for (int k = 0; k < cpg; ++k) {
-            const int ch = g0 + k;
-            const double* sp = ch < p.C1 ? p.sums1 + (((long long)b*p.C1 + ch) << 1)
-                                         : p.sums2 + (((long long)b*p.C2 + ch - p.C1) << 1);
-            const double e = p.gn_add ? (double)p.gn_add[(long long)b*p.Cin + ch] : 0.0;
-            const double cs = sp[0], cq = sp[1];
-            s1 += cs + n_px*e;
-            s2 += cq + 2.0*e*cs + n_px*e*e;
-          }
-          const double n = (double)cpg*n_px, mean = s1/n;
-          double var = s2/n - mean*mean;
-          if (var < 0) var = 0;
-          const float rstd = (float)(1.0/sqrt(var + (double)p.eps));
-          sc = rstd*p.gn_gamma[c];
-          sh = p.gn_beta[c] + ((p.gn_add ? p.gn_add[idx] : 0.f) - (float)mean)*sc;
-          if (p.adm_scale) { const float m = 1.f + p.adm_scale[idx]; sc *= m; sh = sh*m + p.adm_shift[idx]; }
-        }
-      }
-      ftab[0][tid] = sc; ftab[1][tid] = sh;
-    }
-    __syncthreads();
-  }
 
   // ---- patch pieces of this thread: slot = r*512 + tid = 4*pixel + position; position q holds channel octet
   // q ^ ((pcol >> 2) & 3) of patch pixel (prow, pcol)
@@ -161,10 +135,71 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_splitk_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[cf][i] = 0.f;
 
-  u32x4 raw[2], a_cur[2][2], a_nxt[2][2];
-  load_a(c_lo, 0, a_cur);
+  // All 36 weight fragments of a chunk are requested together (144 registers): with one tap in flight ahead of the
+  // products a chunk was nine dependent L2 / Infinity-Cache round trips -- 10 us for the 16 workgroups of a 4 x 8 image.
+  u32x4 raw[2], a[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) load_a(c_lo, tap, a[tap]);
 #pragma unroll
   for (int r = 0; r < 2; ++r) raw[r] = load_piece(r, c_lo);
+  // (the weight fragments and the first patch are in flight while the table below is built)
+  // ---- the folded GroupNorm of this workgroup's n_my x 32 input channels: scale | shift
+  if (FOLD != 0) {
+    const int cpg = FOLD == 2 ? p.Cin/p.groups : 1;
+    // the group sums: every thread brings the two moments of ITS channel (one memory round trip for the whole table),
+    // the channels of a group meet in LDS. (Each thread walking its group's channels itself was a chain of up to 16
+    // dependent round trips in front of everything else: 5 us of the 10 us a 4 x 8 image took.) Groups that do not
+    // tile a 32-channel chunk fall back to that walk.
+    __shared__ double gmom[2][CS_MAXCPW*CN_CK];
+    const bool fast = FOLD == 2 && (CN_CK % cpg) == 0;
+    const int c = c_lo*CN_CK + tid;
+    const bool mine = tid < n_my*CN_CK && c < p.Cin;
+    const long long idx = (long long)b*p.Cin + (mine ? c : 0);
+    const double n_px = (double)p.H*(double)p.W;
+    float e_c = 0.f;
+    if (FOLD == 2 && mine) {
+      const double* sp = c < p.C1 ? p.sums1 + (((long long)b*p.C1 + c) << 1)
+                                  : p.sums2 + (((long long)b*p.C2 + c - p.C1) << 1);
+      e_c = p.gn_add ? p.gn_add[idx] : 0.f;
+      const double e = (double)e_c, cs = sp[0], cq = sp[1];
+      if (fast) { gmom[0][tid] = cs + n_px*e; gmom[1][tid] = cq + 2.0*e*cs + n_px*e*e; }
+    }
+    if (fast) __syncthreads();
+    if (tid < n_my*CN_CK) {
+      float sc = 0.f, sh = 0.f;
+      if (mine) {
+        if (FOLD == 1) { sc = p.in_scale[idx]; sh = p.in_shift[idx]; }
+        else {                                            // the arithmetic of chan_fold_kernel (nhwc.hip) / conv_nhwc_kernel
+          const int g0 = (c/cpg)*cpg;
+          double s1 = 0.0, s2 = 0.0;
+          if (fast) {
+            const int l0 = g0 - c_lo*CN_CK;
+            for (int k = 0; k < cpg; ++k) { s1 += gmom[0][l0 + k]; s2 += gmom[1][l0 + k]; }
+          } else {
+            for (int k = 0; k < cpg; ++k) {
+              const int ch = g0 + k;
+              const double* sp = ch < p.C1 ? p.sums1 + (((long long)b*p.C1 + ch) << 1)
+                                           : p.sums2 + (((long long)b*p.C2 + ch - p.C1) << 1);
+              const double e = p.gn_add ? (double)p.gn_add[(long long)b*p.Cin + ch] : 0.0;
+              const double cs = sp[0], cq = sp[1];
+              s1 += cs + n_px*e;
+              s2 += cq + 2.0*e*cs + n_px*e*e;
+            }
+          }
+          const double n = (double)cpg*n_px, mean = s1/n;
+          double var = s2/n - mean*mean;
+          if (var < 0) var = 0;
+          const float rstd = (float)(1.0/sqrt(var + (double)p.eps));
+          sc = rstd*p.gn_gamma[c];
+          sh = p.gn_beta[c] + (e_c - (float)mean)*sc;
+          if (p.adm_scale) { const float m = 1.f + p.adm_scale[idx]; sc *= m; sh = sh*m + p.adm_shift[idx]; }
+        }
+      }
+      ftab[0][tid] = sc; ftab[1][tid] = sh;
+    }
+    __syncthreads();
+  }
+
 #pragma unroll
   for (int r = 0; r < 2; ++r) store_piece(r, 0, 0, raw[r]);
   __syncthreads();
@@ -179,20 +214,15 @@ __global__ __launch_bounds__(CN_THREADS) void conv_nhwc_splitk_kernel(const Conv
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap/3, kw = tap % 3;
-      // the next tap's weights (the next chunk's first tap behind the last one; past the end: a harmless reload)
-      if (tap + 1 < 9) load_a(c_lo + ci, tap + 1, a_nxt);
-      else load_a(more ? c_lo + ci + 1 : c_lo + ci, 0, a_nxt);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const h8 bv = *reinterpret_cast<const h8*>(pb + ((b_off[kw] ^ (unsigned int)(ks*32)) + (unsigned int)(kh*CS_PC*64)));
 #pragma unroll
         for (int cf = 0; cf < 2; ++cf)
-          acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a_cur[ks][cf]), bv, acc[cf], 0, 0, 0);
+          acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a[tap][ks][cf]), bv, acc[cf], 0, 0, 0);
       }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int cf = 0; cf < 2; ++cf) a_cur[ks][cf] = a_nxt[ks][cf];
+      // the next chunk's fragments of this tap go out as soon as this tap's registers are free
+      if (more) load_a(c_lo + ci + 1, tap, a[tap]);
     }
     if (more) {
 #pragma unroll
@@ -236,10 +266,19 @@ __global__ __launch_bounds__(256) void conv_nhwc_combine_kernel(const ConvCombin
   float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
   if (i < p.hw) {
     const long long pix = (long long)b*p.hw + i;
-    f32x4 v = *reinterpret_cast<const f32x4*>(p.part + ((long long)cq*p.npix + pix)*4);
-    for (int k = 1; k < p.n_split; ++k) {
-      const f32x4 u = *reinterpret_cast<const f32x4*>(p.part + (((long long)k*p.cq_n + cq)*p.npix + pix)*4);
-      v += u;
+    // all splits requested together (a run-time loop waited for each load in turn: 8 L2 round trips), added in order
+    static_assert(BRV_CONV_SPLIT_MAX <= 8, "combine reads at most 8 splits");
+    f32x4 u[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int kk = k < p.n_split ? k : 0;
+      u[k] = *reinterpret_cast<const f32x4*>(p.part + (((long long)kk*p.cq_n + cq)*p.npix + pix)*4);
+    }
+    f32x4 v = u[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float on = k < p.n_split ? 1.f : 0.f;
+      v += u[k]*on;
     }
     float r[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.res) {
@@ -275,15 +314,6 @@ __global__ __launch_bounds__(256) void conv_nhwc_combine_kernel(const ConvCombin
 
 // Plan of a launch: the split path pays when the pixel-parallel kernel would leave most of the chip idle.
 // Returns the scratch floats needed (0: use conv_nhwc_kernel).
-#ifndef BRV_CONV_SPLIT_MAX_BASE
-#define BRV_CONV_SPLIT_MAX_BASE 128     // (tiles x channel blocks) of the launch up to which the reduction is split
-#endif
-#ifndef BRV_CONV_SPLIT_TARGET
-#define BRV_CONV_SPLIT_TARGET 384       // workgroups a split launch aims for
-#endif
-#ifndef BRV_CONV_SPLIT_MAX
-#define BRV_CONV_SPLIT_MAX 8            // splits at most (scratch traffic: 1 KB per pixel, split and 256 channels)
-#endif
 inline long long conv_split_plan(long long B, long long H, long long W, long long n_chunks, long long n_cob,
                                  int& cpw, int& n_split) {
   cpw = (int)n_chunks; n_split = 1;

@@ -825,16 +825,29 @@ class DiffusionUNet(nn.Module):
         key = (tuple(x.shape), tuple(sigma.shape), _STATE['amp'], _STATE['pver'])
         entry = self._graphs.get(key)
         if entry is None:
+            import gc
             sx, ss = x.clone(), sigma.clone()
-            side = torch.cuda.Stream(device=x.device)
-            side.wait_stream(torch.cuda.current_stream(x.device))
-            with torch.cuda.stream(side):                 # warm-up: packs weights, fills caches
-                self._forward_impl(sx, ss)
-            torch.cuda.current_stream(x.device).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._forward_impl(sx, ss)
+            # Old graphs (this model's previous shape, other models that became garbage) are released HERE, with the
+            # device idle, and the cyclic collector stays off until the capture has ended: a collection that ran inside
+            # the warm-up pass -- finalisers of captured graphs and of their memory pools beside a busy side stream --
+            # aborted the process once in three runs of the GPU test suite (round 6)
             self._graphs.clear()                          # one shape at a time: bound the memory
+            torch.cuda.synchronize(x.device)
+            gc.collect()
+            was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(torch.cuda.current_stream(x.device))
+                with torch.cuda.stream(side):             # warm-up: packs weights, fills caches
+                    self._forward_impl(sx, ss)
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self._forward_impl(sx, ss)
+            finally:
+                if was_enabled:
+                    gc.enable()
             entry = self._graphs[key] = (graph, sx, ss, out)
         graph, sx, ss, out = entry
         sx.copy_(x)

@@ -1636,7 +1636,7 @@ def test_sgmse_low_resolution_convolution_with_split_reduction(c1, c2, co, H, W,
         # statistics of the rounded output: (sum, sum of squares) per item and channel
         o16 = out.double()
         direct = torch.stack([o16.sum(dim=(2, 3)), (o16*o16).sum(dim=(2, 3))], dim=-1)
-        assert rel(sums.cpu(), direct.cpu()) <= 1e-6, rel(sums.cpu(), direct.cpu())
+        assert rel(sums.cpu(), direct.cpu()) <= 5e-5, rel(sums.cpu(), direct.cpu())     # (fp32 sums of <= 256 pixels, then fp64)
         assert rel(sums, old[k][1]) <= 5e-3
 
 
