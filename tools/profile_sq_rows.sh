@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ-counter passes over a widened row (as tools/profile_sq.sh does for the headline step): --pmc only with
 # --kernel-trace, 8 SQ slots per pass. usage (through gpurun, from the repo root):
-#   bash tools/profile_sq_rows.sh r04 dccrn_bf16 tools/prof_dccrn.py 1
+#   bash tools/profile_sq_rows.sh r04 dccrn_bf16 $PWD/tools/prof_dccrn.py 1   (absolute path: the passes run from /tmp)
 set -u
 TAG=$1; NAME=$2; shift 2
 REPO=$(pwd)
