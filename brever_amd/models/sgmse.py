@@ -499,16 +499,16 @@ class AttentionBlock(nn.Module):
         q, k, v = qkv[:, :C], qkv[:, C:2*C], qkv[:, 2*C:]
         # weights (L, L) = q^T (L, C) @ k (C, L) / sqrt(C), softmax over the last dim
         w = torch.empty(N, L, L, dtype=torch.float32, device=x.device)
-        hip.check(lib.brv_gemm_f32(hip.ptr(q), hip.ptr(k), hip.ptr(w), N, L, L, C, L, L, L, 3*C*L,
-                                   3*C*L, L*L, 1, 0, 1, 0, 0, None, 0, hip.stream()), 'brv_gemm_f32')
+        # (hip.gemm_f32: with scratch for an ordered reduction split -- a 512 x 512 x 256 product is 8 tiles of the big
+        # kernel, 77 us on 8 workgroups without it)
+        hip.gemm_f32(q, k, w, N, L, L, C, L, L, L, 3*C*L, 3*C*L, L*L, 1, 0, 1, 0, 0, None, 0)
         w = _axpby(w, 1.0/C**0.5)
         p = torch.empty_like(w)
         hip.check(lib.brv_softmax_rows(hip.ptr(w), hip.ptr(p), N*L, L, hip.stream()),
                   'brv_softmax_rows')
         # attention^T (C, L) = v (C, L) @ weights^T (L, L)
         a = torch.empty(N, C, L, dtype=torch.float32, device=x.device)
-        hip.check(lib.brv_gemm_f32(hip.ptr(v), hip.ptr(p), hip.ptr(a), N, C, L, L, L, L, L, 3*C*L,
-                                   L*L, C*L, 0, 1, 1, 0, 0, None, 0, hip.stream()), 'brv_gemm_f32')
+        hip.gemm_f32(v, p, a, N, C, L, L, L, L, L, 3*C*L, L*L, C*L, 0, 1, 1, 0, 0, None, 0)
         return _conv(a.view(N, C, H, W), self.conv_out, res=x, out_scale=out_scale)
 
     def _qkv_module(self):

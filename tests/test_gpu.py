@@ -1581,7 +1581,7 @@ def test_sgmse_channels_last_kernels_match_torch():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('c1,c2,co,H,W,B', [(256, 0, 256, 32, 63, 1), (256, 256, 256, 16, 32, 1), (256, 0, 256, 4, 8, 1),
-                                            (128, 128, 256, 8, 16, 2), (256, 0, 256, 64, 126, 1), (96, 64, 136, 9, 33, 3),
+                                            (128, 128, 256, 8, 16, 2), (256, 0, 256, 32, 126, 1), (96, 64, 136, 9, 33, 3),
                                             (256, 256, 128, 16, 32, 8)])
 def test_sgmse_low_resolution_convolution_with_split_reduction(c1, c2, co, H, W, B):
     """csrc/conv_nhwc_splitk.cuh (round 6): the 3x3 convolution of the inner U-Net levels with its reduction split
@@ -1591,7 +1591,8 @@ def test_sgmse_low_resolution_convolution_with_split_reduction(c1, c2, co, H, W,
     given by its ingredients (folded by the kernel itself: `norm=`, the form the network uses), with SiLU, embedding
     term, skip concatenation, residual and scale; the statistics it leaves for the next GroupNorm against those of
     the pixel-parallel kernel (BRV_CONV_SPLIT=0) and against the output itself. Shapes: the levels of the default
-    network at batch 1 (64 x 126 ... 4 x 8, 256 and 256 + 256 channels), odd sizes with a channel tail, batch 8."""
+    network at batch 1 that split (32 x 63 ... 4 x 8, 256 and 256 + 256 channels; 32 x 126 = the largest launch that
+    does: 64 (tile, channel block) pairs), odd sizes with a channel tail, batch 8."""
     import torch.nn.functional as F
     import brever_amd.models.sgmse as M
     from brever_amd import hip
