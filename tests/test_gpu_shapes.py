@@ -334,7 +334,10 @@ def _variant_library():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, 'tools', '_v', 'variants', 'libbrever_hip.so')
-    if not os.path.exists(lib):
+    csrc = os.path.join(root, 'brever_amd', 'csrc')
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith(('.hip', '.cuh', '.h')))
+    newest = max(newest, os.path.getmtime(os.path.join(root, 'include', 'brever_hip.h')))
+    if not os.path.exists(lib) or os.path.getmtime(lib) < newest:      # (stale: built before the last source change)
         subprocess.run(['bash', os.path.join(root, 'tools', 'mkvariant.sh'), 'variants', '-DBRV_WITH_VARIANTS'],
                        check=True, capture_output=True, timeout=900)
     return root, lib
