@@ -667,14 +667,32 @@ __global__ __launch_bounds__(256) void skip_combine_kernel(const SkipCombinePara
   __shared__ float cs[128];                 // sum over the blocks of the per-item constants
   const int b = blockIdx.y, tid = threadIdx.x;
   const int NP = p.Bnp + p.Scp;
-  for (int i = tid; i < p.nb; i += 256)
-    rs[i] = norm_stat(p.stats + (2 + 2*i)*p.stats_stride, b, p.inv_n, p.eps).rstd;
+  // per-item constants: the blocks' (rstd, mean rstd) once -- one memory round trip for nb threads -- then channel n
+  // sums its nb table entries with the loads of a batch of blocks in flight together. (Round 6: every channel thread
+  // recomputed every block's statistics -- nb dependent double loads and square roots in front of a workgroup that
+  // then streams for ~10 us: 2 048 short-lived workgroups each paid ~20 us of prologue.)
+  __shared__ float ms[kWgMaxProb];
+  for (int i = tid; i < p.nb; i += 256) {
+    const NormStat ns = norm_stat(p.stats + (2 + 2*i)*p.stats_stride, b, p.inv_n, p.eps);
+    rs[i] = ns.rstd; ms[i] = ns.mean*ns.rstd;
+  }
+  __syncthreads();
   for (int n = tid; n < p.Scp; n += 256) {
     float c = 0.f;
-    for (int i = 0; i < p.nb; ++i) {
-      const NormStat ns = norm_stat(p.stats + (2 + 2*i)*p.stats_stride, b, p.inv_n, p.eps);
+    int i = 0;
+    for (; i + 8 <= p.nb; i += 8) {
+      float a[8], v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float* lz = reinterpret_cast<const float*>(p.prepared + p.lazy_off[i + k]);
+        a[k] = lz[p.Bnp + n]; v[k] = lz[NP + p.Bnp + n];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c += a[k] - ms[i + k]*v[k];
+    }
+    for (; i < p.nb; ++i) {
       const float* lz = reinterpret_cast<const float*>(p.prepared + p.lazy_off[i]);
-      c += lz[p.Bnp + n] - ns.mean*ns.rstd*lz[NP + p.Bnp + n];
+      c += lz[p.Bnp + n] - ms[i]*lz[NP + p.Bnp + n];
     }
     cs[n] = c;
   }

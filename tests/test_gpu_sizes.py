@@ -278,9 +278,10 @@ def test_fp32_trajectory_20_steps_at_the_default_depth():
     that the CPU fp32 AND fp64 oracles stay within a few minutes. Fused HIP steps (fp32 path, Adam lr 1e-3, clip
     5) against the CPU fp32 oracle from identical init and data order, reference convtasnet.py:78-89.
 
-    Same fp64-anchored bound: |d loss| <= 1e-3 dB over the first 10 steps and <= 3e-3 over all 20 against the CPU
-    fp32 oracle, and against the fp64 trajectory (which both fp32 runs approximate) the HIP run may be no further
-    away than 3 x the CPU fp32 run's own worst distance (+ 1e-4)."""
+    The fp64-anchored bound of that test: against the fp64 trajectory (which both fp32 runs approximate) the HIP run
+    may be no further away than 3 x the CPU fp32 run's own worst distance so far (+ 1e-4), at every step; against the
+    CPU fp32 oracle |d loss| <= 1e-3 dB over the first three steps and no more than 1.5 x the oracle's own distance
+    to its fp64 run afterwards (see the comment at the assertions for why not 1e-3 / 3e-3 throughout)."""
     from brever_amd.models import ConvTasNet
     from oracle.convtasnet import OracleConvTasNet
     torch.manual_seed(7)
@@ -309,8 +310,16 @@ def test_fp32_trajectory_20_steps_at_the_default_depth():
     print('default-depth fp32 trajectory |hip - cpu32|:', ['%.1e' % d for d in d32])
     print('                            |cpu32 - cpu64|:', ['%.1e' % d for d in c64])
     print('                              |hip - cpu64|:', ['%.1e' % d for d in d64])
-    assert max(d32[:10]) <= 1e-3, d32
-    assert max(d32) <= 3e-3, d32
+    # Measured on MI355X (round 6): at this depth the CPU fp32 oracle ITSELF leaves its fp64 run by 1.9e-3 at step 3
+    # and 1.2e-2 at step 10 (24 blocks amplify a rounding difference far more than the 4 blocks of the other test:
+    # 7e-4 there), the HIP run stays within 8.4e-3 of the fp64 run and is closer to it than the CPU fp32 run at 17 of
+    # the 20 steps. The absolute 1e-3 / 3e-3 of the 4-block test are therefore asserted where fp32 arithmetic can hold
+    # them -- the first three steps -- and beyond that against the oracle's own distance to the truth:
+    assert max(d32[:3]) <= 1e-3, d32
+    assert max(d32[:10]) <= max(1e-3, 1.5*max(c64[:10])), (d32, c64)
+    assert max(d32) <= max(3e-3, 1.5*max(c64)), (d32, c64)
     assert max(d64) <= 3*max(c64) + 1e-4, (d64, c64)
+    for i in range(20):                                  # ... step by step, not only at the worst step
+        assert d64[i] <= 3*max(c64[:i + 1]) + 1e-4, (i, d64, c64)
     ref = torch.cat([p.detach().reshape(-1) for p in oracle.parameters()])
     assert rel(net.flat_params(), ref) <= 1e-2, rel(net.flat_params(), ref)
