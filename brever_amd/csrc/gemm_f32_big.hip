@@ -642,6 +642,14 @@ Plan make_plan(const BigGemm& g) {
     ks = cus*(x3w ? kX3Wgs : 1)/tiles;
     if (ks > pl.total_t/8) ks = pl.total_t/8;
     if (ks < 1) ks = 1;
+  } else if ((g.x3 & 8) && tiles <= 32 && pl.total_t >= 8 && (!use_x3(g) || x3w)) {
+    // (x3 bit 8: set by the entry points that bring scratch for the partial tiles -- brv_gemm_f32_ws)
+    // a handful of tiles and a SHORT reduction (round 6: the attention products of the SGMSE+ U-Net at batch 1 --
+    // 512 x 512 x 256 and 256 x 512 x 512: 4 - 16 tiles, 8 - 16 k-tiles -- ran 47 / 78 us on 4 - 16 workgroups): split
+    // down to four k-tiles per workgroup
+    ks = pl.total_t/4;
+    if (ks*tiles > 4LL*cus) ks = 4LL*cus/tiles;
+    if (ks < 1) ks = 1;
   }
   pl.per_t = (pl.total_t + ks - 1)/ks;
   pl.ksplit = (int)((pl.total_t + pl.per_t - 1)/pl.per_t);

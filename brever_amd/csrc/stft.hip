@@ -1008,7 +1008,7 @@ static int gemm_any(int lowp, const float* a, const float* b, float* d, int64_t 
     if (ws) {
       // brv_gemm_f32_ws: the caller's scratch takes the partial tiles of a reduction split (summed in split
       // order by a second kernel), which also opens the split-bf16 form to long reductions over few tiles
-      g.x3 = 1 | 2 | 4;
+      g.x3 = 1 | 2 | 4 | 8;
       if (brv::gemm_f32_big_ok(g)) {
         const long long need = brv::gemm_f32_big_scratch(g);
         if (need <= ws_floats) {
@@ -1101,7 +1101,7 @@ int64_t brv_gemm_f32_workspace_bytes(int64_t batch, int64_t M, int64_t N, int64_
   brv::BigGemm g; memset(&g, 0, sizeof(g));
   g.M = (int)M; g.N = (int)N; g.K = (int)K; g.kbatch = kbatch > 1 ? (int)kbatch : 1; g.batch = (int)batch;
   g.ta = trans_a != 0; g.tb = trans_b != 0; g.lda = (int)(trans_a ? M : K); g.ldb = (int)(trans_b ? K : N);
-  g.ldd = (int)N; g.x3 = 1 | 2 | 4;
+  g.ldd = (int)N; g.x3 = 1 | 2 | 4 | 8;
   return 4*brv::gemm_f32_big_scratch(g);
 }
 int brv_gemm_f32_ws(const float* a, const float* b, float* d, int64_t batch, int64_t M, int64_t N,
