@@ -22,6 +22,8 @@
 // Weight gradient: cconv_wgrad_kernel below. Measurements and what was tried: DESIGN.md 5b.
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.cuh"
 #include "../../include/brever_hip.h"
 
@@ -29,13 +31,21 @@ namespace {
 using namespace brv;
 
 constexpr int CC_THREADS = 512;
+#ifndef CC_DMA
+#define CC_DMA 1       // bf16 images staged by LDS-DMA (0: through registers, cconv_tile_lean -- for A/B runs)
+#endif
+#ifndef CC_ABL
+#define CC_ABL 0       // diagnostic builds (tools/cconv_bench.py): 1 no image loads, 2 no weight loads, 4 no MFMAs, 8 no stores,
+                       // 16 image loads from addresses rounded down to 16 bytes, 32 every chunk re-reads the first rows of the item
+#endif
 #ifndef CC_PAIR
 #define CC_PAIR 1      // transposed form with M <= 128: two output rows per workgroup (0: one, for A/B runs)
 #endif
 constexpr int CC_KH = 5;
 
 struct CConvParams {
-  const float* in; const float* in2; const uint4* wp; const float* bias; float* out; float* out2;
+  const void* in; const void* in2;   // fp32 or bf16 elements (the kernel's TI)
+  const uint4* wp; const float* bias; float* out; float* out2;
   int in_seg, out_seg;         // > 0: channels = [t[:seg] | t2[:seg] | t[seg:] | t2[seg:]] of two (B, 2 seg, H, W) tensors
   int B, C, M, Hin, Win, Hout, Wout;
   long long in_bs, out_bs;
@@ -61,6 +71,71 @@ __device__ __forceinline__ bf16x8 cc_frag(const unsigned char* img, int col0, in
   const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
+
+// ---- four neighbouring frames of one input row in registers, for both element types the images come in: fp32
+// (rounded to bf16 on the way into LDS) or bf16 as the batch-norm passes store them under use_amp
+// (brv_batchnorm2d_forward_bf16 / brv_batchnorm2d_backward_bf16: the values the fp32 form rounds to here, at half
+// the bytes -- these kernels are bound by what a CU can take in, DESIGN.md 5b "Round 6, DCCRN")
+template <typename T> struct CQuad;
+template <> struct CQuad<float> {
+  typedef float4 type;
+  typedef float vec_u __attribute__((ext_vector_type(4), aligned(4)));
+  static __device__ __forceinline__ type zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ type load(const void* p) {
+    const vec_u w = *reinterpret_cast<const vec_u*>(p);
+    return make_float4(w.x, w.y, w.z, w.w);
+  }
+  // frames f .. f + 3 of a row of n frames, those outside as zeros
+  static __device__ __forceinline__ type gather(const float* src, int f, int n) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f >= 0 && f < n) v.x = src[f];
+    if (f + 1 >= 0 && f + 1 < n) v.y = src[f + 1];
+    if (f + 2 >= 0 && f + 2 < n) v.z = src[f + 2];
+    if (f + 3 >= 0 && f + 3 < n) v.w = src[f + 3];
+    return v;
+  }
+  // kind 6: up by one frame; 3 / 4 / 5: down by one / two / three (cconv_tile_lean)
+  static __device__ __forceinline__ type moved(type v, int k) {
+    if (k == 6) return make_float4(0.f, v.x, v.y, v.z);
+    if (k == 3) return make_float4(v.y, v.z, v.w, 0.f);
+    if (k == 4) return make_float4(v.z, v.w, 0.f, 0.f);
+    return make_float4(v.w, 0.f, 0.f, 0.f);
+  }
+  static __device__ __forceinline__ uint2 packed(type v) { return make_uint2(pack2(v.x, v.y), pack2(v.z, v.w)); }
+  // (frame before the quad, x, y, z) as bf16: that frame is the last one of lane - 1's quad (DPP row_shr:1), or
+  // `left` where `edge` says the neighbouring lane holds another row
+  static __device__ __forceinline__ uint2 shifted(type v, float left, bool edge) {
+    float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.w), 0x111, 0xf, 0xf, false));
+    if (edge) prev = left;
+    return make_uint2(pack2(prev, v.x), pack2(v.y, v.z));
+  }
+};
+template <> struct CQuad<bf16_t> {
+  typedef uint2 type;
+  typedef unsigned int vec_u __attribute__((ext_vector_type(2), aligned(2)));
+  static __device__ __forceinline__ type zero() { return make_uint2(0u, 0u); }
+  static __device__ __forceinline__ type load(const void* p) {
+    const vec_u w = *reinterpret_cast<const vec_u*>(p);
+    return make_uint2(w.x, w.y);
+  }
+  static __device__ __forceinline__ type gather(const bf16_t* src, int f, int n) {
+    unsigned int e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = (f + k >= 0 && f + k < n) ? (unsigned int)src[f + k] : 0u;
+    return make_uint2(e[0] | e[1] << 16, e[2] | e[3] << 16);
+  }
+  static __device__ __forceinline__ type moved(type v, int k) {
+    const unsigned long long w = (unsigned long long)v.x | (unsigned long long)v.y << 32;
+    const unsigned long long r = k == 6 ? w << 16 : k == 3 ? w >> 16 : k == 4 ? w >> 32 : w >> 48;
+    return make_uint2((unsigned int)r, (unsigned int)(r >> 32));
+  }
+  static __device__ __forceinline__ uint2 packed(type v) { return v; }
+  static __device__ __forceinline__ uint2 shifted(type v, bf16_t left, bool edge) {
+    unsigned int prev = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x111, 0xf, 0xf, false) >> 16;
+    if (edge) prev = left;
+    return make_uint2(prev | v.x << 16, v.x >> 16 | v.y << 16);
+  }
+};
 
 // wc: fp32 matrix with W[m][c][i][j] = wc[m*sm + c*sk + 2 i + j]; wp[((mf*ncc + cc)*5 + i)*64 + lane] =
 // the 8 channels 8 cc .. 8 cc + 7 of output row 32 mf + (lane & 31), frame tap j = lane >> 5
@@ -125,7 +200,7 @@ __global__ __launch_bounds__(256) void cconv_pack_all_kernel(const CPackAllParam
   }
 }
 
-template <int MF, int NF, int WM, int WN, int NTAP, bool SEG>
+template <typename TI, int MF, int NF, int WM, int WN, int NTAP, bool SEG>
 __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* lds, int b, int r, int ftile,
                                            int mtile, const int (&tap_i)[NTAP], const int (&tap_row)[NTAP],
                                            int shift) {
@@ -137,8 +212,9 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int f0 = ftile*NT;
-  const float* in_b = p.in + (long long)b*p.in_bs;
-  const float* in2_b = SEG && p.in_seg > 0 ? p.in2 + (long long)b*p.in_bs : nullptr;
+  typedef CQuad<TI> Q;
+  const TI* in_b = static_cast<const TI*>(p.in) + (long long)b*p.in_bs;
+  const TI* in2_b = SEG && p.in_seg > 0 ? static_cast<const TI*>(p.in2) + (long long)b*p.in_bs : nullptr;
 
   // ---- staging items: (image, channel, frame quad) -> source frame and LDS byte offset
   int s_c[IT], s_f[IT], s_off[IT];
@@ -152,10 +228,10 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
     s_f[it] = f0 + col + shift*img;
     s_off[it] = (col >> 7)*4096 + cc_off(8*img + c, cw >> 3) + 8*((cw >> 2) & 1);
   }
-  float4 st[NTAP][IT];
+  typename Q::type st[NTAP][IT];
   auto stage_load = [&](int cc) {
     // source tensor and channel offset of this chunk of 8 (never straddles two segments: seg % 8 == 0)
-    const float* base = in_b;
+    const TI* base = in_b;
     int ch0 = 8*cc;
     if (SEG && p.in_seg > 0) {
       const int sg = (ch0 >= p.in_seg) + (ch0 >= 2*p.in_seg) + (ch0 >= 3*p.in_seg);
@@ -168,16 +244,11 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
         const int f = s_f[it];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        typename Q::type v = Q::zero();
         if (row >= 0 && row < p.Hin && 8*cc + s_c[it] < p.C) {
-          const float* src = base + ((long long)(ch0 + s_c[it])*p.Hin + row)*p.Win;
-          if (f >= 0 && f + 3 < p.Win) __builtin_memcpy(&v, src + f, 16);
-          else {
-            if (f >= 0 && f < p.Win) v.x = src[f];
-            if (f + 1 >= 0 && f + 1 < p.Win) v.y = src[f + 1];
-            if (f + 2 >= 0 && f + 2 < p.Win) v.z = src[f + 2];
-            if (f + 3 >= 0 && f + 3 < p.Win) v.w = src[f + 3];
-          }
+          const TI* src = base + ((long long)(ch0 + s_c[it])*p.Hin + row)*p.Win;
+          if (f >= 0 && f + 3 < p.Win) v = Q::load(src + f);
+          else v = Q::gather(src, f, p.Win);
         }
         st[t][it] = v;
       }
@@ -188,8 +259,7 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
     for (int t = 0; t < NTAP; ++t)
 #pragma unroll
       for (int it = 0; it < IT; ++it)
-        *reinterpret_cast<uint2*>(lds + buf*BUFB + t*TAPB + s_off[it]) =
-            make_uint2(pack2(st[t][it].x, st[t][it].y), pack2(st[t][it].z, st[t][it].w));
+        *reinterpret_cast<uint2*>(lds + buf*BUFB + t*TAPB + s_off[it]) = Q::packed(st[t][it]);
   };
 
   // ---- weights: fragments of this wave's MF row groups, (chunk, tap) two k steps ahead
@@ -202,7 +272,10 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
   }
   auto a_load = [&](int cc, int t, uint4 (&dst)[MF]) {
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) dst[mf] = wq[mf][(cc*CC_KH + tap_i[t])*64];
+    for (int mf = 0; mf < MF; ++mf) {
+      if (CC_ABL & 2) dst[mf] = make_uint4(cc, t, mf, 0); else
+      dst[mf] = wq[mf][(cc*CC_KH + tap_i[t])*64];
+    }
   };
 
   f32x16 acc[MF][NF];
@@ -284,7 +357,7 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
 // PAIR (transposed form, M <= 128): one workgroup computes BOTH output rows 2r and 2r + 1 from the three input
 // rows r + 1, r, r - 1 they share (slots 0..2; products t = 0..4 = weight taps 0..4, tap t reads slot t >> 1 and
 // adds to the accumulator set t & 1): 1.5 staged rows per output row instead of 2.5.
-template <int MF, int NF, int WM, int WN, int NTAP, bool SEG, bool TINY, bool PAIR = false>
+template <typename TI, int MF, int NF, int WM, int WN, int NTAP, bool SEG, bool TINY, bool PAIR = false>
 __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned char* lds, int b, int r, int ftile,
                                            int mtile, const int (&tap_i)[NTAP], const int (&tap_row)[PAIR ? 3 : NTAP],
                                            int shift) {
@@ -298,8 +371,10 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int f0 = ftile*NT;
-  const float* in_b = p.in + (long long)b*p.in_bs;
-  const float* in2_b = SEG && p.in_seg > 0 ? p.in2 + (long long)b*p.in_bs : nullptr;
+  typedef CQuad<TI> Q;
+  constexpr int ES = (int)sizeof(TI);
+  const TI* in_b = static_cast<const TI*>(p.in) + (long long)b*p.in_bs;
+  const TI* in2_b = SEG && p.in_seg > 0 ? static_cast<const TI*>(p.in2) + (long long)b*p.in_bs : nullptr;
 
   // ---- staging items: (image, channel, frame quad). Everything that does not depend on the chunk or the tap
   // is computed once, and every item is ONE 16-byte load under its lane mask: a second (element-wise) path
@@ -323,7 +398,7 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
     else if (f == -1) { kind = 6; fl = 0; }
     s_c[it] = c;
     s_kind[it] = kind;
-    s_voff[it] = kind ? (c*plane + fl)*4 : 0;       // lanes with nothing to load read the row base (ignored)
+    s_voff[it] = kind ? (c*plane + fl)*ES : 0;      // lanes with nothing to load read the row base (ignored)
     s_off[it] = (col >> 7)*4096 + cc_off(8*img + c, cw >> 3) + 8*((cw >> 2) & 1);
   }
   bool tap_ok[NSLOT];
@@ -333,10 +408,14 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
   for (int e = tid; e < 2*BUFB/16; e += CC_THREADS) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
 
-  float4 st[NSLOT][IT];
-  auto stage_load = [&](int cc) {
+  // bf16 images on the 256-row tile: the staged quads are half the registers, so TWO chunks are kept in flight there
+  // (235 against 271 us on the decoder's 512 -> 256 layers; set = chunk & 1)
+  constexpr int DEPTH = sizeof(TI) == 2 && MF*NF >= 8 ? 2 : 1;     // (the smaller tiles lose more to the lower occupancy)
+  typename Q::type st[DEPTH][NSLOT][IT];
+  auto stage_load = [&](int cc, auto set_tag) {
+    constexpr int set = decltype(set_tag)::value;
     // source tensor and channel offset of this chunk of 8 (never straddles two segments: seg % 8 == 0)
-    const float* base = in_b;
+    const TI* base = in_b;
     int ch0 = 8*cc;
     if (SEG && p.in_seg > 0) {
       const int sg = (ch0 >= p.in_seg) + (ch0 >= 2*p.in_seg) + (ch0 >= 3*p.in_seg);
@@ -349,30 +428,25 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
     for (int t = 0; t < NSLOT; ++t) {
       // no branch around a load (rows outside the image read row 0 and are not stored): with control flow
       // between loads hipcc falls back to s_waitcnt vmcnt(0) in front of each of them
-      const char* rbase = cbase + (long long)(tap_ok[t] ? tap_row[t] : 0)*p.Win*4;
+      const char* rbase = cbase + (long long)(tap_ok[t] ? tap_row[t] : 0)*p.Win*ES;
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
         if (TINY) {                                 // images narrower than a quad: element by element
-          const float* src = reinterpret_cast<const float*>(rbase + (long long)s_c[it]*plane*4);
-          const int f = (s_voff[it] >> 2) - s_c[it]*plane;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (s_c[it] < nch) {
-            if (f >= 0 && f < p.Win) v.x = src[f];
-            if (f + 1 >= 0 && f + 1 < p.Win) v.y = src[f + 1];
-            if (f + 2 >= 0 && f + 2 < p.Win) v.z = src[f + 2];
-            if (f + 3 >= 0 && f + 3 < p.Win) v.w = src[f + 3];
-          }
-          st[t][it] = v;
+          const TI* src = reinterpret_cast<const TI*>(rbase + (long long)s_c[it]*plane*ES);
+          const int f = s_voff[it]/ES - s_c[it]*plane;
+          st[set][t][it] = s_c[it] < nch ? Q::gather(src, f, p.Win) : Q::zero();
         } else {
-          typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
           const int vo = s_c[it] < nch ? s_voff[it] : 0;
-          const f32x4u w = *reinterpret_cast<const f32x4u*>(rbase + vo);
-          st[t][it] = make_float4(w.x, w.y, w.z, w.w);
+          if (CC_ABL & 1) st[set][t][it] = Q::zero(); else
+          if (CC_ABL & 32) st[set][t][it] = Q::load(reinterpret_cast<const char*>(in_b) + s_voff[it]); else   // every chunk re-reads chunk 0, row 0
+          if (CC_ABL & 16) st[set][t][it] = Q::load(rbase + (vo & ~15)); else                                  // 16-byte aligned addresses
+          st[set][t][it] = Q::load(rbase + vo);
         }
       }
     }
   };
-  auto stage_store = [&](int buf, int cc) {
+  auto stage_store = [&](int buf, int cc, auto set_tag) {
+    constexpr int set = decltype(set_tag)::value;
     const int nch = p.C - 8*cc;
 #pragma unroll
     for (int t = 0; t < NSLOT; ++t) {
@@ -380,18 +454,12 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
         if (s_kind[it] == 0) continue;
-        float4 v = st[t][it];
+        typename Q::type v = st[set][t][it];
         if (!TINY) {
-          if (s_kind[it] > 1) {                     // a lane or two per row
-            const int k = s_kind[it];
-            if (k == 6) v = make_float4(0.f, v.x, v.y, v.z);
-            else if (k == 3) v = make_float4(v.y, v.z, v.w, 0.f);
-            else if (k == 4) v = make_float4(v.z, v.w, 0.f, 0.f);
-            else v = make_float4(v.w, 0.f, 0.f, 0.f);
-          }
-          if (nch < 8 && s_c[it] >= nch) v = make_float4(0.f, 0.f, 0.f, 0.f);   // last chunk of an odd channel count
+          if (s_kind[it] > 1) v = Q::moved(v, s_kind[it]);                      // a lane or two per row
+          if (nch < 8 && s_c[it] >= nch) v = Q::zero();                         // last chunk of an odd channel count
         }
-        *reinterpret_cast<uint2*>(lds + buf*BUFB + t*TAPB + s_off[it]) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+        *reinterpret_cast<uint2*>(lds + buf*BUFB + t*TAPB + s_off[it]) = Q::packed(v);
       }
     }
   };
@@ -406,7 +474,10 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
   }
   auto a_load = [&](int cc, int t, uint4 (&dst)[MF]) {
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) dst[mf] = wq[mf][(cc*CC_KH + tap_i[t])*64];
+    for (int mf = 0; mf < MF; ++mf) {
+      if (CC_ABL & 2) dst[mf] = make_uint4(cc, t, mf, 0); else
+      dst[mf] = wq[mf][(cc*CC_KH + tap_i[t])*64];
+    }
   };
 
   f32x16 acc[NSET][MF][NF];
@@ -425,20 +496,26 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
   uint4 a0[MF], a1[MF], a2[MF];
   a_load(0, 0, a0);
   if (NTAP > 1) a_load(0, 1 % NTAP, a1); else if (p.ncc > 1) a_load(1, 0, a1);
-  stage_load(0);
-  stage_store(0, 0);
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, DEPTH - 1>;
+  stage_load(0, S0{});
+  if (DEPTH == 2) stage_load(p.ncc > 1 ? 1 : 0, S1{});
+  stage_store(0, 0, S0{});
   __syncthreads();
 
-  for (int cc = 0; cc < p.ncc; ++cc) {
+  // one chunk: its MFMAs on LDS buffer cc & 1; the loads of chunk cc + DEPTH go out behind the first tap's weights,
+  // chunk cc + 1 (register set `nx`) moves into the other buffer at the end
+  auto body = [&](int cc, auto ld_tag, auto nx_tag) {
     const unsigned char* cur = lds + (cc & 1)*BUFB;
     const bool more = cc + 1 < p.ncc;
     const int nxt = more ? cc + 1 : cc;            // the last chunk is requested once more instead of branching
+    const int far = cc + DEPTH < p.ncc ? cc + DEPTH : cc;
     bf16x8 bq[NF];
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
       if (t + 2 < NTAP) a_load(cc, (t + 2) % NTAP, a2);
       else a_load(nxt, (t + 2) % NTAP, a2);
-      if (t == 0) stage_load(nxt);
+      if (t == 0) stage_load(far, ld_tag);
       const int slot = PAIR ? (t >> 1) : t, set = PAIR ? (t & 1) : 0;
       if (!PAIR || (t & 1) == 0) {                  // (the odd tap of a pair reads the fragments of the even one)
 #pragma unroll
@@ -451,14 +528,26 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
       for (int mf = 0; mf < MF; ++mf) {
         const bf16x8 af = __builtin_bit_cast(bf16x8, a0[mf]);
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf)
+        for (int nf = 0; nf < NF; ++nf) {
+          if (CC_ABL & 4) { acc[set][mf][nf][0] += __builtin_bit_cast(float, (int)af[0]) + __builtin_bit_cast(float, (int)bq[nf][0]); continue; }
           acc[set][mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[nf], acc[set][mf][nf], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) { a0[mf] = a1[mf]; a1[mf] = a2[mf]; }
     }
-    if (more) stage_store((cc + 1) & 1, cc + 1);
+    if (more) stage_store((cc + 1) & 1, cc + 1, nx_tag);
     __syncthreads();
+  };
+  if (DEPTH == 2) {
+#pragma unroll 1
+    for (int cc = 0; cc < p.ncc; cc += 2) {
+      body(cc, S0{}, S1{});                        // chunk cc + 2 -> set 0 (chunk cc's, stored already), chunk cc + 1 from set 1
+      if (cc + 1 < p.ncc) body(cc + 1, S1{}, S0{});
+    }
+  } else {
+#pragma unroll 1
+    for (int cc = 0; cc < p.ncc; ++cc) body(cc, S0{}, S0{});
   }
 
   // ---- D[m][frame] -> out[b][m][row][frame] (+ bias)
@@ -475,7 +564,7 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int m = 32*(mfrag0 + mf) + (i & 3) + 8*(i >> 2) + 4*(lane >> 5);
-          if (m < p.M && w < p.Wout) {
+          if (m < p.M && w < p.Wout && (!(CC_ABL & 8) || acc[set][mf][nf][i] == 1234.5f)) {
             float v = acc[set][mf][nf][i];
             if (p.bias) v += p.bias[m];
             float* dst = out_b;
@@ -492,7 +581,7 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
   }
 }
 
-template <int MF, int NF, int WM, int WN, bool SEG, bool LEAN, bool TINY = false, bool PAIR = false>
+template <int MF, int NF, int WM, int WN, bool SEG, bool LEAN, bool TINY = false, bool PAIR = false, typename TI = float>
 __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParams p) {
   constexpr int NT = 32*NF*WN;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2*CC_KH*(NT/128)*4096];
@@ -514,22 +603,22 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParam
   if (p.mode == 0) {
     const int ti[5] = {0, 1, 2, 3, 4};
     const int tr[5] = {2*r - 2, 2*r - 1, 2*r, 2*r + 1, 2*r + 2};
-    if (LEAN) cconv_tile_lean<MF, NF, WM, WN, 5, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, 1);
-    else cconv_tile<MF, NF, WM, WN, 5, SEG>(p, lds, b, r, ftile, mtile, ti, tr, 1);
+    if (LEAN) cconv_tile_lean<TI, MF, NF, WM, WN, 5, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, 1);
+    else cconv_tile<TI, MF, NF, WM, WN, 5, SEG>(p, lds, b, r, ftile, mtile, ti, tr, 1);
   } else if (PAIR) {                 // output rows 2r and 2r + 1 from input rows r + 1, r, r - 1
     const int ti[5] = {0, 1, 2, 3, 4};
     const int tr[3] = {r + 1, r, r - 1};
-    cconv_tile_lean<MF, NF, WM, WN, 5, SEG, TINY, true>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    cconv_tile_lean<TI, MF, NF, WM, WN, 5, SEG, TINY, true>(p, lds, b, r, ftile, mtile, ti, tr, -1);
   } else if (r & 1) {
     const int ti[2] = {1, 3};
     const int tr[2] = {(r + 1) >> 1, (r - 1) >> 1};
-    if (LEAN) cconv_tile_lean<MF, NF, WM, WN, 2, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, -1);
-    else cconv_tile<MF, NF, WM, WN, 2, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    if (LEAN) cconv_tile_lean<TI, MF, NF, WM, WN, 2, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    else cconv_tile<TI, MF, NF, WM, WN, 2, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
   } else {
     const int ti[3] = {0, 2, 4};
     const int tr[3] = {(r >> 1) + 1, r >> 1, (r >> 1) - 1};
-    if (LEAN) cconv_tile_lean<MF, NF, WM, WN, 3, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, -1);
-    else cconv_tile<MF, NF, WM, WN, 3, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    if (LEAN) cconv_tile_lean<TI, MF, NF, WM, WN, 3, SEG, TINY>(p, lds, b, r, ftile, mtile, ti, tr, -1);
+    else cconv_tile<TI, MF, NF, WM, WN, 3, SEG>(p, lds, b, r, ftile, mtile, ti, tr, -1);
   }
 }
 
@@ -543,7 +632,8 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_rows_kernel(const CConvParam
 // `small`, 32 channels of `big`, 5 rows i): 7 fragment reads per 10 MFMAs. A workgroup walks a contiguous
 // range of (b, h) pairs and adds its tile to the gradient once at the end.
 struct CWgradParams {
-  const float* small; const float* small2; const float* big; float* part;
+  const void* small; const void* small2; const void* big;   // fp32 or bf16 elements (the kernel's T), all three alike
+  float* part;
   int B, A, C, Hs, Ws, Hb, Wb;
   int seg;                       // small = [s[:seg] | s2[:seg] | s[seg:] | s2[seg:]] along the channels (0: one source)
   long long small_bs, small2_bs, big_bs;
@@ -557,7 +647,9 @@ constexpr int WG_SMALLB = WG_A*128, WG_BIGB = CC_KH*WG_C*128, WG_BUFB = 2*WG_SMA
 __device__ __forceinline__ int wg_swz(int row) { return (row >> 1) & 7; }
 __device__ __forceinline__ int wg_off(int row, int q) { return 128*row + 16*((q >> 1) ^ wg_swz(row)) + 8*(q & 1); }
 
+template <typename T>
 __global__ __launch_bounds__(WG_THREADS) void cconv_wgrad_kernel(const CWgradParams p) {
+  typedef CQuad<T> Q;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2*WG_BUFB];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int j = wid & 1, afr = wid >> 1;
@@ -578,7 +670,7 @@ __global__ __launch_bounds__(WG_THREADS) void cconv_wgrad_kernel(const CWgradPar
   const int q = tid & 15;
 
   // ---- staging rows of this thread: 4 of `small` (row = channel), 10 of `big` (row = (i, channel))
-  const float* s_ptr[WG_NS]; long long s_bs[WG_NS];
+  const T* s_ptr[WG_NS]; long long s_bs[WG_NS];
 #pragma unroll
   for (int r = 0; r < WG_NS; ++r) {
     const int a = atile*WG_A + ((tid + WG_THREADS*r) >> 4);
@@ -586,72 +678,67 @@ __global__ __launch_bounds__(WG_THREADS) void cconv_wgrad_kernel(const CWgradPar
     if (a < p.A) {
       if (p.seg > 0) {
         const int sg = a / p.seg, ch = (sg >> 1)*p.seg + a % p.seg;
-        s_ptr[r] = ((sg & 1) ? p.small2 : p.small) + (long long)ch*p.Hs*p.Ws;
+        s_ptr[r] = static_cast<const T*>((sg & 1) ? p.small2 : p.small) + (long long)ch*p.Hs*p.Ws;
         s_bs[r] = (sg & 1) ? p.small2_bs : p.small_bs;
-      } else { s_ptr[r] = p.small + (long long)a*p.Hs*p.Ws; s_bs[r] = p.small_bs; }
+      } else { s_ptr[r] = static_cast<const T*>(p.small) + (long long)a*p.Hs*p.Ws; s_bs[r] = p.small_bs; }
     }
   }
-  float4 sv[WG_NS]; float sl[WG_NS];          // frames 4q .. 4q+3 of the stage and the frame before the stage
-  float4 bv[WG_NB];
-  auto load_small = [&](int it) {
+  // (bf16 images: two stages in flight in the registers one stage of fp32 quads takes -- as cconv_tile_lean)
+  constexpr int DEPTH = sizeof(T) == 2 ? 2 : 1;
+  typename Q::type sv[DEPTH][WG_NS]; T sl[DEPTH][WG_NS];    // frames 4q .. 4q+3 of the stage and the frame before the stage
+  typename Q::type bv[DEPTH][WG_NB];
+  auto load_small = [&](int it, auto set_tag) {
+    constexpr int set = decltype(set_tag)::value;
     const int pr = pair0 + it / p.nstage, stg = it % p.nstage;
     const int b = pr / p.Hs, h = pr % p.Hs, f = stg*WG_F + 4*q;
 #pragma unroll
     for (int r = 0; r < WG_NS; ++r) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      float left = 0.f;
+      typename Q::type v = Q::zero();
+      T left = 0;
       if (s_ptr[r]) {
-        const float* src = s_ptr[r] + b*s_bs[r] + (long long)h*p.Ws;
-        if (f + 3 < p.Ws) __builtin_memcpy(&v, src + f, 16);
-        else {
-          if (f < p.Ws) v.x = src[f];
-          if (f + 1 < p.Ws) v.y = src[f + 1];
-          if (f + 2 < p.Ws) v.z = src[f + 2];
-        }
+        const T* src = s_ptr[r] + b*s_bs[r] + (long long)h*p.Ws;
+        if (f + 3 < p.Ws) v = Q::load(src + f);
+        else v = Q::gather(src, f, p.Ws);
         if (q == 0 && f > 0 && f - 1 < p.Ws) left = src[f - 1];
       }
-      sv[r] = v; sl[r] = left;
+      sv[set][r] = v; sl[set][r] = left;
     }
   };
-  auto load_big = [&](int it) {
+  auto load_big = [&](int it, auto set_tag) {
+    constexpr int set = decltype(set_tag)::value;
     const int pr = pair0 + it / p.nstage, stg = it % p.nstage;
     const int b = pr / p.Hs, h = pr % p.Hs, f = stg*WG_F + 4*q;
 #pragma unroll
     for (int r = 0; r < WG_NB; ++r) {
       const int rs = (tid + WG_THREADS*r) >> 4, i = rs >> 5, c = ctile*WG_C + (rs & 31);
       const int row = 2*h - 2 + i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      typename Q::type v = Q::zero();
       if (c < p.C && row >= 0 && row < p.Hb) {
-        const float* src = p.big + b*p.big_bs + ((long long)c*p.Hb + row)*p.Wb;
-        if (f + 3 < p.Wb) __builtin_memcpy(&v, src + f, 16);
-        else {
-          if (f < p.Wb) v.x = src[f];
-          if (f + 1 < p.Wb) v.y = src[f + 1];
-          if (f + 2 < p.Wb) v.z = src[f + 2];
-        }
+        const T* src = static_cast<const T*>(p.big) + b*p.big_bs + ((long long)c*p.Hb + row)*p.Wb;
+        if (f + 3 < p.Wb) v = Q::load(src + f);
+        else v = Q::gather(src, f, p.Wb);
       }
-      bv[r] = v;
+      bv[set][r] = v;
     }
   };
-  auto store_small = [&](int buf) {
+  auto store_small = [&](int buf, auto set_tag) {
+    constexpr int set = decltype(set_tag)::value;
     unsigned char* base = lds + buf*WG_BUFB;
 #pragma unroll
     for (int r = 0; r < WG_NS; ++r) {
       const int row = (tid + WG_THREADS*r) >> 4;
-      const float4 v = sv[r];
       // the frame before this quad: lane q - 1 of the same row (16 lanes = one DPP row), or the stage's left neighbour
-      float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.w), 0x111, 0xf, 0xf, false));
-      if (q == 0) prev = sl[r];
-      *reinterpret_cast<uint2*>(base + wg_off(row, q)) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
-      *reinterpret_cast<uint2*>(base + WG_SMALLB + wg_off(row, q)) = make_uint2(pack2(prev, v.x), pack2(v.y, v.z));
+      *reinterpret_cast<uint2*>(base + wg_off(row, q)) = Q::packed(sv[set][r]);
+      *reinterpret_cast<uint2*>(base + WG_SMALLB + wg_off(row, q)) = Q::shifted(sv[set][r], sl[set][r], q == 0);
     }
   };
-  auto store_big = [&](int buf) {
+  auto store_big = [&](int buf, auto set_tag) {
+    constexpr int set = decltype(set_tag)::value;
     unsigned char* base = lds + buf*WG_BUFB + 2*WG_SMALLB;
 #pragma unroll
     for (int r = 0; r < WG_NB; ++r) {
       const int rs = (tid + WG_THREADS*r) >> 4;
-      *reinterpret_cast<uint2*>(base + wg_off(rs, q)) = make_uint2(pack2(bv[r].x, bv[r].y), pack2(bv[r].z, bv[r].w));
+      *reinterpret_cast<uint2*>(base + wg_off(rs, q)) = Q::packed(bv[set][r]);
     }
   };
 
@@ -661,13 +748,21 @@ __global__ __launch_bounds__(WG_THREADS) void cconv_wgrad_kernel(const CWgradPar
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-  if (nitems > 0) { load_small(0); load_big(0); store_small(0); store_big(0); }
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, DEPTH - 1>;
+  if (nitems > 0) {
+    load_small(0, S0{}); load_big(0, S0{});
+    if (DEPTH == 2 && nitems > 1) { load_big(1, S1{}); load_small(1, S1{}); }
+    store_small(0, S0{}); store_big(0, S0{});
+  }
   __syncthreads();
   const int m = lane & 31, g = lane >> 5;
-  for (int it = 0; it < nitems; ++it) {
+  // one stage: its MFMAs on LDS buffer it & 1; stage it + DEPTH is requested first, stage it + 1 (register set `nx`)
+  // moves into the other buffer at the end
+  auto body = [&](int it, auto ld_tag, auto nx_tag) {
     const unsigned char* cur = lds + (it & 1)*WG_BUFB;
     const bool more = it + 1 < nitems;
-    if (more) { load_big(it + 1); load_small(it + 1); }
+    if (it + DEPTH < nitems) { load_big(it + DEPTH, ld_tag); load_small(it + DEPTH, ld_tag); }
 #pragma unroll
     for (int ks = 0; ks < WG_F/16; ++ks) {
       const int ch = 2*ks + g;
@@ -683,8 +778,18 @@ __global__ __launch_bounds__(WG_THREADS) void cconv_wgrad_kernel(const CWgradPar
       for (int i = 0; i < CC_KH; ++i)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[i], acc[i], 0, 0, 0);
     }
-    if (more) { store_big((it + 1) & 1); store_small((it + 1) & 1); }
+    if (more) { store_big((it + 1) & 1, nx_tag); store_small((it + 1) & 1, nx_tag); }
     __syncthreads();
+  };
+  if (DEPTH == 2) {
+#pragma unroll 1
+    for (int it = 0; it < nitems; it += 2) {
+      body(it, S0{}, S1{});
+      if (it + 1 < nitems) body(it + 1, S1{}, S0{});
+    }
+  } else {
+#pragma unroll 1
+    for (int it = 0; it < nitems; ++it) body(it, S0{}, S0{});
   }
 
   // ---- D[a][c] of tap (i, j) -> part[split][2 i + j][a][c]: plain stores, 128 bytes per 32 lanes; the splits
@@ -734,25 +839,85 @@ __global__ __launch_bounds__(256) void cconv_wgrad_reduce_kernel(const float* pa
   }
 }
 
+#include "cconv_dma.cuh"
+
 // which tile function a launch shape runs (measured per layer, tools/dccrn_conv_bench.py): the lean loader for
 // two-source inputs / split outputs and for M <= 64; the pair form of the transposed convolution for M <= 128
-template <int MF, int NF, int WM, int WN>
+template <typename TI, int MF, int NF, int WM, int WN>
 static void cconv_launch(CConvParams& p, int64_t B, int64_t M, bool transposed, bool seg, hipStream_t st) {
   constexpr int MT = 32*MF*WM, NT = 32*NF*WN;
   p.mtiles = (int)((M + MT - 1)/MT); p.ftiles = (p.Wout + NT - 1)/NT;
   const dim3 grid(p.ftiles, p.Hout, (unsigned)(B*p.mtiles)), block(CC_THREADS);
+  if constexpr (sizeof(TI) == 2 && NT == 256) {
+    // bf16 images in whole chunks of 8 channels: staged by LDS-DMA (cconv_dma.cuh); pair form as below
+    // (measured per layer, tools/cconv_bench.py / profiles/r06_cconv_ablation.txt: every transposed launch and the
+    // 128-row strided tile; the 256-row strided tile keeps its weights for five taps twice over and spills, the 64- and
+    // 32-row strided tiles are as fast through registers)
+    if (CC_DMA && p.C % 8 == 0 && (long long)B*p.in_bs < (1LL << 29) && (transposed || MT == 128)) {
+      if (!transposed) {
+        if (seg) hipLaunchKernelGGL((cconv_rows_dma_kernel<MF, NF, WM, WN, true, 0>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((cconv_rows_dma_kernel<MF, NF, WM, WN, false, 0>), grid, block, 0, st, p);
+        return;
+      }
+      if constexpr (MT <= 128 && CC_PAIR) {
+        if (MT <= 32 || (MT == 64) != seg) {
+          const dim3 gp(p.ftiles, p.Hout/2, (unsigned)(B*p.mtiles));
+          if (seg) hipLaunchKernelGGL((cconv_rows_dma_kernel<MF, NF, WM, WN, true, 2>), gp, block, 0, st, p);
+          else hipLaunchKernelGGL((cconv_rows_dma_kernel<MF, NF, WM, WN, false, 2>), gp, block, 0, st, p);
+          return;
+        }
+      }
+      if (seg) hipLaunchKernelGGL((cconv_rows_dma_kernel<MF, NF, WM, WN, true, 1>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((cconv_rows_dma_kernel<MF, NF, WM, WN, false, 1>), grid, block, 0, st, p);
+      return;
+    }
+  }
   if constexpr (MT <= 128 && CC_PAIR) {
     // (measured exceptions: M = 128 from one source and M = 64 from two sources are as fast / faster row by row)
     if (transposed && (MT <= 32 || (MT == 64) != seg)) {
       const dim3 gp(p.ftiles, p.Hout/2, (unsigned)(B*p.mtiles));
-      if (seg) hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, true, true, false, true>), gp, block, 0, st, p);
-      else hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, false, true, false, true>), gp, block, 0, st, p);
+      if (seg) hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, true, true, false, true, TI>), gp, block, 0, st, p);
+      else hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, false, true, false, true, TI>), gp, block, 0, st, p);
       return;
     }
   }
-  if (seg) hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, true, true>), grid, block, 0, st, p);
-  else if (MT <= 64) hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, false, true>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, false, false>), grid, block, 0, st, p);
+  if (seg) hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, true, true, false, false, TI>), grid, block, 0, st, p);
+  else if (MT <= 64) hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, false, true, false, false, TI>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((cconv_rows_kernel<MF, NF, WM, WN, false, sizeof(TI) == 2 && MF*NF >= 8, false, false, TI>), grid, block, 0, st, p);
+}
+
+template <typename TI>
+static int cconv_rows_any(const void* in, const void* in2, int64_t in_seg, const void* wp, const float* bias, float* out,
+                          float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
+                          int32_t transposed, brv_stream_t stream) {
+  if (!in || !wp || !out || B < 1 || C < 1 || M < 1 || Hin < 1 || Win < 1) return -1;
+  if (!transposed && ((Hin & 1) || Win < 2)) return -1;
+  if (in_seg < 0 || (in_seg > 0 && (!in2 || C != 4*in_seg || (in_seg & 7)))) return -1;
+  if (out_seg < 0 || (out_seg > 0 && (!out2 || M != 4*out_seg))) return -1;
+  CConvParams p;
+  p.in = in; p.in2 = in2; p.wp = (const uint4*)wp; p.bias = bias; p.out = out; p.out2 = out2;
+  p.in_seg = (int)in_seg; p.out_seg = (int)out_seg;
+  p.B = (int)B; p.C = (int)C; p.M = (int)M; p.Hin = (int)Hin; p.Win = (int)Win;
+  p.Hout = transposed ? (int)(2*Hin) : (int)(Hin/2);
+  p.Wout = transposed ? (int)(Win + 1) : (int)(Win - 1);
+  p.in_bs = (in_seg > 0 ? 2*in_seg : C)*Hin*Win; p.out_bs = (out_seg > 0 ? 2*out_seg : M)*(long long)p.Hout*p.Wout;
+  p.mode = transposed ? 1 : 0;
+  p.ncc = (int)((C + 7)/8); p.mfrags = (int)((M + 31)/32);
+  hipStream_t st = (hipStream_t)stream;
+#define CC_LAUNCH(MF_, NF_, WM_, WN_) cconv_launch<TI, MF_, NF_, WM_, WN_>(p, B, M, transposed != 0, in_seg > 0 || out_seg > 0, st)
+  if (Win < 4) {            // narrower than a staging quad: the element-wise loader, one workgroup shape
+    constexpr int MT = 64, NT = 256;
+    p.mtiles = (int)((M + MT - 1)/MT); p.ftiles = (p.Wout + NT - 1)/NT;
+    hipLaunchKernelGGL((cconv_rows_kernel<2, 1, 1, 8, true, true, true, false, TI>), dim3(p.ftiles, p.Hout, (unsigned)(B*p.mtiles)),
+                       dim3(CC_THREADS), 0, st, p);
+  } else if (M > 128) {
+    const long long wgs = (long long)((p.Wout + 255)/256)*p.Hout*B*((M + 255)/256);
+    if (wgs < 256) CC_LAUNCH(2, 2, 4, 2); else CC_LAUNCH(2, 4, 4, 2);
+  } else if (M > 64) CC_LAUNCH(2, 2, 2, 4);
+  else if (M > 32) CC_LAUNCH(2, 1, 1, 8);
+  else CC_LAUNCH(1, 1, 1, 8);
+#undef CC_LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 }  // namespace
@@ -805,34 +970,13 @@ int brv_cconv_pack_complex(const float* wr, const float* wi, const float* br, co
 int brv_cconv_rows(const float* in, const float* in2, int64_t in_seg, const void* wp, const float* bias, float* out,
                    float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
                    int32_t transposed, brv_stream_t stream) {
-  if (!in || !wp || !out || B < 1 || C < 1 || M < 1 || Hin < 1 || Win < 1) return -1;
-  if (!transposed && ((Hin & 1) || Win < 2)) return -1;
-  if (in_seg < 0 || (in_seg > 0 && (!in2 || C != 4*in_seg || (in_seg & 7)))) return -1;
-  if (out_seg < 0 || (out_seg > 0 && (!out2 || M != 4*out_seg))) return -1;
-  CConvParams p;
-  p.in = in; p.in2 = in2; p.wp = (const uint4*)wp; p.bias = bias; p.out = out; p.out2 = out2;
-  p.in_seg = (int)in_seg; p.out_seg = (int)out_seg;
-  p.B = (int)B; p.C = (int)C; p.M = (int)M; p.Hin = (int)Hin; p.Win = (int)Win;
-  p.Hout = transposed ? (int)(2*Hin) : (int)(Hin/2);
-  p.Wout = transposed ? (int)(Win + 1) : (int)(Win - 1);
-  p.in_bs = (in_seg > 0 ? 2*in_seg : C)*Hin*Win; p.out_bs = (out_seg > 0 ? 2*out_seg : M)*(long long)p.Hout*p.Wout;
-  p.mode = transposed ? 1 : 0;
-  p.ncc = (int)((C + 7)/8); p.mfrags = (int)((M + 31)/32);
-  hipStream_t st = (hipStream_t)stream;
-#define CC_LAUNCH(MF_, NF_, WM_, WN_) cconv_launch<MF_, NF_, WM_, WN_>(p, B, M, transposed != 0, in_seg > 0 || out_seg > 0, st)
-  if (Win < 4) {            // narrower than a staging quad: the element-wise loader, one workgroup shape
-    constexpr int MT = 64, NT = 256;
-    p.mtiles = (int)((M + MT - 1)/MT); p.ftiles = (p.Wout + NT - 1)/NT;
-    hipLaunchKernelGGL((cconv_rows_kernel<2, 1, 1, 8, true, true, true>), dim3(p.ftiles, p.Hout, (unsigned)(B*p.mtiles)),
-                       dim3(CC_THREADS), 0, st, p);
-  } else if (M > 128) {
-    const long long wgs = (long long)((p.Wout + 255)/256)*p.Hout*B*((M + 255)/256);
-    if (wgs < 256) CC_LAUNCH(2, 2, 4, 2); else CC_LAUNCH(2, 4, 4, 2);
-  } else if (M > 64) CC_LAUNCH(2, 2, 2, 4);
-  else if (M > 32) CC_LAUNCH(2, 1, 1, 8);
-  else CC_LAUNCH(1, 1, 1, 8);
-#undef CC_LAUNCH
-  return hipGetLastError() == hipSuccess ? 0 : -3;
+  return cconv_rows_any<float>(in, in2, in_seg, wp, bias, out, out2, out_seg, B, C, M, Hin, Win, transposed, stream);
+}
+
+int brv_cconv_rows_bf16(const void* in, const void* in2, int64_t in_seg, const void* wp, const float* bias, float* out,
+                        float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
+                        int32_t transposed, brv_stream_t stream) {
+  return cconv_rows_any<bf16_t>(in, in2, in_seg, wp, bias, out, out2, out_seg, B, C, M, Hin, Win, transposed, stream);
 }
 
 static void cconv_wgrad_plan(int64_t B, int64_t A, int64_t C, int64_t Hs, int& atiles, int& ctiles, int& nsplit,
@@ -852,8 +996,11 @@ int64_t brv_cconv_wgrad_workspace_bytes(int64_t B, int64_t A, int64_t C, int64_t
   return (int64_t)nsplit*10*A*C*4;
 }
 
-int brv_cconv_wgrad(const float* small, const float* small2, const float* big, float* out, void* workspace,
-                    int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream) {
+}  // extern "C"
+
+template <typename T>
+static int cconv_wgrad_any(const void* small, const void* small2, const void* big, float* out, void* workspace,
+                           int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream) {
   if (!small || !big || !out || !workspace || B < 1 || A < 1 || C < 1 || Hs < 1 || Ws < 1) return -1;
   if (seg < 0 || (seg > 0 && (!small2 || A != 4*seg))) return -1;
   CWgradParams p;
@@ -865,12 +1012,24 @@ int brv_cconv_wgrad(const float* small, const float* small2, const float* big, f
   cconv_wgrad_plan(B, A, C, Hs, p.atiles, p.ctiles, nsplit, p.pairs_per);
   p.npairs = (int)(B*Hs); p.nstage = (p.Wb + WG_F - 1)/WG_F; p.ldo = (int)(10*C);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(cconv_wgrad_kernel, dim3((unsigned)(p.atiles*p.ctiles), (unsigned)nsplit), dim3(WG_THREADS), 0,
+  hipLaunchKernelGGL(cconv_wgrad_kernel<T>, dim3((unsigned)(p.atiles*p.ctiles), (unsigned)nsplit), dim3(WG_THREADS), 0,
                      st, p);
   const long long n = 10*A*C;
   hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3((unsigned)((n + 63)/64)), dim3(256), 0, st,
                      (const float*)workspace, out, (int)A, (int)C, nsplit);
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+extern "C" {
+
+int brv_cconv_wgrad(const float* small, const float* small2, const float* big, float* out, void* workspace,
+                    int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream) {
+  return cconv_wgrad_any<float>(small, small2, big, out, workspace, B, A, C, Hs, Ws, seg, stream);
+}
+
+int brv_cconv_wgrad_bf16(const void* small, const void* small2, const void* big, float* out, void* workspace,
+                         int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream) {
+  return cconv_wgrad_any<bf16_t>(small, small2, big, out, workspace, B, A, C, Hs, Ws, seg, stream);
 }
 
 }  // extern "C"

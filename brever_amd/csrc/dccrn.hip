@@ -189,14 +189,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
 }
 // the two element-wise passes when HW % 4 == 0: blockIdx = (piece of the plane, channel, batch item): the channel
 // scalars are loaded once per block, the plane is walked with 16-byte accesses, no division per element
+// (TO = bf16_t: the output as the bf16 values the use_amp row convolutions round it to anyway -- its only readers on
+// that path, csrc/cconv.hip -- at half the bytes)
+__device__ __forceinline__ void store4(float* base, long long i, float4 v) { reinterpret_cast<float4*>(base)[i] = v; }
+__device__ __forceinline__ void store4(bf16_t* base, long long i, float4 v) {
+  reinterpret_cast<uint2*>(base)[i] = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+}
+template <typename TO>
 __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* x, const float* mean, const float* invstd,
                                                         const float* gamma, const float* beta, const float* slope,
-                                                        float* y, int C, long long HW) {
+                                                        TO* y, int C, long long HW) {
   const int c = blockIdx.y, b = blockIdx.z;
   const float a = slope ? *slope : 1.f;
   const long long n4 = HW >> 2, base = ((long long)b*C + c)*HW;
   const float4* src = reinterpret_cast<const float4*>(x + base);
-  float4* dst = reinterpret_cast<float4*>(y + base);
+  TO* dst = y + base;
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n4; i += (long long)gridDim.x*256) {
     float4 v = src[i];
     // (x - mean)*invstd*gamma + beta with the reference's rounding order kept: two multiplies, then the add
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(const float* x, const fl
       v.x = v.x > 0.f ? v.x : a*v.x; v.y = v.y > 0.f ? v.y : a*v.y;
       v.z = v.z > 0.f ? v.z : a*v.z; v.w = v.w > 0.f ? v.w : a*v.w;
     }
-    dst[i] = v;
+    store4(dst, i, v);
   }
 }
 __global__ __launch_bounds__(256) void invstd_from_var_kernel(const float* var, float* invstd,
@@ -1170,18 +1177,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
   }
 }
 
+// (TO = bf16_t: dx as bf16 -- the gradient with respect to a row convolution's output, which its data and weight
+// gradient kernels round to bf16 anyway; `sums`: per-block sums of the UNROUNDED dx, what the convolution's bias
+// gradient is made of: [channel][batch item x gridDim.x] partials, added up by row_sum_final-style bn_dxsum_kernel)
+template <typename TO>
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* x, const float* dy, const float* mean,
                                                             const float* invstd, const float* gamma,
                                                             const float* beta, const float* slope,
-                                                            const float* dgamma, const float* dbeta, float* dx,
-                                                            int C, long long HW, float inv_n) {
+                                                            const float* dgamma, const float* dbeta, TO* dx,
+                                                            int C, long long HW, float inv_n, double* sums) {
+  __shared__ double scr[8];
   const int c = blockIdx.y, b = blockIdx.z;
   const float a = slope ? *slope : 1.f;
   const float mu = mean[c], is = invstd[c], gm = gamma[c], bt = beta[c], db = dbeta[c]*inv_n, dg = dgamma[c]*inv_n;
   const long long n4 = HW >> 2, base = ((long long)b*C + c)*HW;
   const float4* xs = reinterpret_cast<const float4*>(x + base);
   const float4* ds = reinterpret_cast<const float4*>(dy + base);
-  float4* dst = reinterpret_cast<float4*>(dx + base);
+  TO* dst = dx + base;
+  double tot = 0.0;
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n4; i += (long long)gridDim.x*256) {
     const float4 xv = xs[i], dv = ds[i];
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -1194,8 +1207,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* x, cons
       if (slope && u <= 0.f) d *= a;
       o[k] = gm*is*(d - db - xh*dg);
     }
-    dst[i] = make_float4(o[0], o[1], o[2], o[3]);
+    store4(dst, i, make_float4(o[0], o[1], o[2], o[3]));
+    tot += (double)((o[0] + o[1]) + (o[2] + o[3]));
   }
+  if (sums) {
+    tot = block_sum(tot, scr);
+    if (threadIdx.x == 0) sums[((long long)c*gridDim.z + b)*gridDim.x + blockIdx.x] = tot;
+  }
+}
+__global__ __launch_bounds__(256) void bn_dxsum_kernel(const double* part, int slices, int C, float* out) {
+  const int c = blockIdx.x*256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < slices; ++i) s += part[(long long)c*slices + i];
+  out[c] = (float)s;
 }
 // LSTM backward through time for one layer and one batch item per workgroup.
 // Saved by the forward: act (B, T, 4H) gate activations (i, f, g, o), cs (B, T, H) cell states,
@@ -1338,12 +1363,18 @@ int brv_conv_transpose2d_forward(const float* x, const float* w, const float* bi
   return 0;
 }
 
-int brv_batchnorm2d_forward(const float* x, const float* gamma, const float* beta,
+}  // extern "C"
+
+template <typename TO>
+static int bn_forward_any(const float* x, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, const float* prelu_slope,
-                            float* y, float* save_mean, float* save_invstd, int64_t B, int64_t C,
+                            TO* y, float* save_mean, float* save_invstd, int64_t B, int64_t C,
                             int64_t HW, float eps, float momentum, int training,
                             brv_stream_t stream) {
   if (B < 1 || C < 1 || HW < 1) return -1;
+  constexpr bool kF32 = sizeof(TO) == 4;
+  if (!kF32 && ((HW & 3) || C > 65535 || B > 65535 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)))
+    return -1;                                  // the bf16 output exists in the 16-byte form only
   hipStream_t st = (hipStream_t)stream;
   if (training) {
     const bool vec = (HW & 3) == 0 && B <= 1024 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
@@ -1368,13 +1399,33 @@ int brv_batchnorm2d_forward(const float* x, const float* gamma, const float* bet
   if ((HW & 3) == 0 && C <= 65535 && B <= 65535 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
     long long gx = (HW/4 + 1023)/1024;                 // four 16-byte accesses per thread
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(bn_apply4_kernel, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, save_mean,
+    hipLaunchKernelGGL(bn_apply4_kernel<TO>, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, save_mean,
                        save_invstd, gamma, beta, prelu_slope, y, (int)C, (long long)HW);
-  } else
+  } else if constexpr (kF32)
   hipLaunchKernelGGL(bn_apply_kernel, flat_grid(total), dim3(256), 0, st, x, save_mean,
                      save_invstd, gamma, beta, prelu_slope, y, (int)C, (long long)HW, total);
   DC_OK(hipGetLastError());
   return 0;
+}
+
+extern "C" {
+
+int brv_batchnorm2d_forward(const float* x, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, const float* prelu_slope,
+                            float* y, float* save_mean, float* save_invstd, int64_t B, int64_t C,
+                            int64_t HW, float eps, float momentum, int training,
+                            brv_stream_t stream) {
+  return bn_forward_any<float>(x, gamma, beta, running_mean, running_var, prelu_slope, y, save_mean, save_invstd, B, C,
+                               HW, eps, momentum, training, stream);
+}
+
+int brv_batchnorm2d_forward_bf16(const float* x, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, const float* prelu_slope,
+                                 void* y16, float* save_mean, float* save_invstd, int64_t B, int64_t C,
+                                 int64_t HW, float eps, float momentum, int training,
+                                 brv_stream_t stream) {
+  return bn_forward_any<bf16_t>(x, gamma, beta, running_mean, running_var, prelu_slope, (bf16_t*)y16, save_mean,
+                                save_invstd, B, C, HW, eps, momentum, training, stream);
 }
 
 int brv_lstm_recurrent_forward(const float* gates_in, const float* w_hh, const float* bias,
@@ -1480,12 +1531,19 @@ int brv_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, i
   return 0;
 }
 
-int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_mean,
+}  // extern "C"
+
+template <typename TO>
+static int bn_backward_any(const float* x, const float* dy, const float* save_mean,
                              const float* save_invstd, const float* gamma, const float* beta,
-                             const float* prelu_slope, float* dx, float* dgamma, float* dbeta,
-                             float* dslope_partial, int64_t B, int64_t C, int64_t HW,
+                             const float* prelu_slope, TO* dx, float* dgamma, float* dbeta,
+                             float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
                              brv_stream_t stream) {
   if (B < 1 || C < 1 || HW < 1) return -1;
+  constexpr bool kF32 = sizeof(TO) == 4;
+  if ((!kF32 || dx_sums) && ((HW & 3) || C > 65535 || B > 65535 ||
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15)))
+    return -1;                                  // bf16 output / dx sums: the 16-byte form only
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (HW & 3) == 0 && B <= 1024 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
   const int pieces = vec ? (int)(red_slices(HW) > 4 ? 4 : red_slices(HW)) : 0;
@@ -1506,15 +1564,42 @@ int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
     long long gx = (HW/4 + 1023)/1024;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, dy,
+    double* sums = nullptr;
+    if (dx_sums) DC_OK(hipMallocAsync((void**)&sums, (size_t)C*B*gx*sizeof(double), st));
+    hipLaunchKernelGGL(bn_bwd_apply4_kernel<TO>, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, dy,
                        save_mean, save_invstd, gamma, beta, prelu_slope, dgamma, dbeta, dx, (int)C, (long long)HW,
-                       1.f/(float)(B*HW));
-  } else
+                       1.f/(float)(B*HW), sums);
+    if (dx_sums) {
+      hipLaunchKernelGGL(bn_dxsum_kernel, dim3((unsigned)((C + 255)/256)), dim3(256), 0, st, sums, (int)(B*gx), (int)C,
+                         dx_sums);
+      DC_OK(hipFreeAsync(sums, st));
+    }
+  } else if constexpr (kF32)
   hipLaunchKernelGGL(bn_bwd_apply_kernel, flat_grid(total), dim3(256), 0, st, x, dy, save_mean,
                      save_invstd, gamma, beta, prelu_slope, dgamma, dbeta, dx, (int)C,
                      (long long)HW, total, 1.f/(float)(B*HW));
   DC_OK(hipGetLastError());
   return 0;
+}
+
+extern "C" {
+
+int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_mean,
+                             const float* save_invstd, const float* gamma, const float* beta,
+                             const float* prelu_slope, float* dx, float* dgamma, float* dbeta,
+                             float* dslope_partial, int64_t B, int64_t C, int64_t HW,
+                             brv_stream_t stream) {
+  return bn_backward_any<float>(x, dy, save_mean, save_invstd, gamma, beta, prelu_slope, dx, dgamma, dbeta,
+                                dslope_partial, nullptr, B, C, HW, stream);
+}
+
+int brv_batchnorm2d_backward_bf16(const float* x, const float* dy, const float* save_mean,
+                                  const float* save_invstd, const float* gamma, const float* beta,
+                                  const float* prelu_slope, void* dx16, float* dgamma, float* dbeta,
+                                  float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
+                                  brv_stream_t stream) {
+  return bn_backward_any<bf16_t>(x, dy, save_mean, save_invstd, gamma, beta, prelu_slope, (bf16_t*)dx16, dgamma, dbeta,
+                                 dslope_partial, dx_sums, B, C, HW, stream);
 }
 
 int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* w_hh,

@@ -224,8 +224,12 @@ def _cconv_wgrad(small, big, small2=None):
     assert Hb == 2*Hs and Wb == Ws + 1
     out = torch.empty(A, 10*C, dtype=torch.float32, device=big.device)
     ws = torch.empty(hip.lib().brv_cconv_wgrad_workspace_bytes(B, A, C, Hs), dtype=torch.uint8, device=big.device)
-    hip.check(hip.lib().brv_cconv_wgrad(hip.ptr(small), hip.ptr(small2), hip.ptr(big), hip.ptr(out), hip.ptr(ws),
-                                        B, A, C, Hs, Ws, seg, hip.stream()), 'brv_cconv_wgrad')
+    lowp = big.dtype == torch.bfloat16          # (all three images alike: _BlockFunction)
+    assert small.dtype == big.dtype and (small2 is None or small2.dtype == big.dtype)
+    fn, name = (hip.lib().brv_cconv_wgrad_bf16, 'brv_cconv_wgrad_bf16') if lowp else \
+        (hip.lib().brv_cconv_wgrad, 'brv_cconv_wgrad')
+    hip.check(fn(hip.ptr(small), hip.ptr(small2), hip.ptr(big), hip.ptr(out), hip.ptr(ws),
+                 B, A, C, Hs, Ws, seg, hip.stream()), name)
     return out
 
 
@@ -597,6 +601,201 @@ class _BatchNormActFunction(torch.autograd.Function):
         return dx, dgamma, dbeta, dslope, None, None
 
 
+# use_amp with the row kernels: the activations BETWEEN the layers live in HBM as bf16 -- the tensors the reference's
+# autocast holds there too. Exactly the values the fp32 form of the row kernels rounds its operands to on the way in,
+# so the products are bit-identical; what changes is the bytes: the convolutions and their weight gradients are bound
+# by what a CU takes in per cycle (DESIGN.md 5b "Round 6, DCCRN"). BRV_DCCRN_BF16_ACT=0: fp32 tensors, round-5 path.
+_BF16_ACT = os.environ.get('BRV_DCCRN_BF16_ACT', '1') != '0'
+
+
+def _token(shape, device):
+    """What autograd tracks in place of a bf16 activation: an fp32 tensor of the logical shape that owns ONE element
+    (stride 0). The engine checks gradients against the dtype and shape of the forward tensor -- a bf16 output would
+    have its fp32 gradient cast to bf16 -- so every block returns (token, bf16 data) and reads its inputs' data from
+    the second member; only gradients travel along the first."""
+    return torch.empty(1, dtype=torch.float32, device=device).expand(shape)
+
+
+def _bf16_empty(shape, device):
+    """A bf16 image for the row kernels: 16 readable bytes in front of and behind it (their LDS-DMA descriptors reach
+    that far: csrc/cconv_dma.cuh, include/brever_hip.h)."""
+    n = 1
+    for d in shape:
+        n *= d
+    return torch.empty(n + 16, dtype=torch.bfloat16, device=device)[8:8 + n].view(shape)
+
+
+def _as_bf16(t):
+    with torch.no_grad():
+        out = _bf16_empty(t.shape, t.device)
+        out.copy_(t)
+        return out
+
+
+class _BlockFunction(torch.autograd.Function):
+    """EncoderBlock / DecoderBlock (dccrn.py:238-292) as ONE autograd node under ``use_amp``: complex (transposed)
+    convolution by the row kernels on bf16 images, nn.BatchNorm2d (+ scalar nn.PReLU) with the bf16 output the next
+    block reads; backward: the norm's pass writes the gradient with respect to the convolution output as bf16 (and
+    its channel sums = the bias gradient), the data / weight gradient kernels read it. Arithmetic and rounding points
+    are those of ``_ComplexConvFunction`` + ``_BatchNormActFunction`` on the rows path."""
+
+    @staticmethod
+    def forward(ctx, x, x16, skip, skip16, wr, br, wi, bi, gamma, beta, slope, norm, training, geom4, transpose,
+                out_bf16):
+        lib = hip.lib()
+        (kh, kw) = geom4[0]
+        khw = kh*kw
+        dev = x.device
+        ctx.side_ok = _side_allowed((wr, br, wi, bi))
+        B, C2, H, W = x.shape
+        ctx.x_f32 = None
+        first = x16 is None and not transpose and C2 < 8      # the first encoder block: its fp32 image as it is
+        if x16 is None:
+            x = x.contiguous()
+            # (its weight gradient runs on the column-matrix kernel, which wants the fp32 image too)
+            if first and any(ctx.needs_input_grad[4:8]):
+                ctx.x_f32 = x
+            x16 = x if first else _as_bf16(x)
+        two = skip is not None
+        if two and skip16 is None:
+            skip16 = _as_bf16(skip)
+        seg = C2//2 if two else 0
+        Cin2 = 2*C2 if two else C2                 # real input channels of the convolution
+        R, Cw = wr.shape[0], wr[0].numel()
+        Cout = wr.shape[1] if transpose else R
+        need_dx = ctx.needs_input_grad[0] or (two and ctx.needs_input_grad[2])
+        fwd = (2*Cout, Cin2, khw, 2*Cw) if transpose else (2*Cout, Cin2, 2*Cw, khw)
+        bwd = ((Cin2, 2*Cout, 2*Cw, khw) if transpose else (Cin2, 2*Cout, khw, 2*Cw)) if need_dx else None
+        wc, bias, wp_fwd, ctx.wp_bwd = _pack_complex_layer(wr, wi, br, bi, -1.0 if transpose else 1.0, fwd, bwd)
+        Ho, Wo = (2*H, W + 1) if transpose else (H//2, W - 1)
+        y = torch.empty(B, 2*Cout, Ho, Wo, dtype=torch.float32, device=dev)
+        rows = lib.brv_cconv_rows if first else lib.brv_cconv_rows_bf16
+        hip.check(rows(hip.ptr(x16), hip.ptr(skip16), seg, hip.ptr(wp_fwd), hip.ptr(bias),
+                       hip.ptr(y), None, 0, B, Cin2, 2*Cout, H, W, int(transpose), hip.stream()),
+                  'brv_cconv_rows' if first else 'brv_cconv_rows_bf16')
+        ctx.cfg = (geom4, transpose, (H, W), (Ho, Wo), Cin2, Cout, R, Cw, wr.shape, seg, two)
+        ctx.has_norm = norm is not None
+        ctx.training = training
+        if norm is None:
+            ctx.save_for_backward(x16, wc, *((skip16,) if two else ()))
+            ctx.has_slope = False
+            return y, None
+        mean = torch.empty(2*Cout, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        args = (hip.ptr(y), hip.ptr(gamma), hip.ptr(beta), hip.ptr(norm.running_mean), hip.ptr(norm.running_var),
+                hip.ptr(slope))
+        tail = (hip.ptr(mean), hip.ptr(invstd), B, 2*Cout, Ho*Wo, float(norm.eps), float(norm.momentum),
+                int(training), hip.stream())
+        if out_bf16:
+            a16 = _bf16_empty((B, 2*Cout, Ho, Wo), dev)
+            hip.check(lib.brv_batchnorm2d_forward_bf16(*args, hip.ptr(a16), *tail), 'brv_batchnorm2d_forward_bf16')
+            out = (_token(y.shape, dev), a16)
+            ctx.mark_non_differentiable(a16)
+        else:
+            a = torch.empty_like(y)
+            hip.check(lib.brv_batchnorm2d_forward(*args, hip.ptr(a), *tail), 'brv_batchnorm2d_forward')
+            out = (a, None)
+        if training:
+            _BN_COUNTERS.append(norm.num_batches_tracked)
+        ctx.has_slope = slope is not None
+        ctx.save_for_backward(x16, wc, *((skip16,) if two else ()), y, gamma, beta, mean, invstd,
+                              *((slope,) if slope is not None else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g, _g16=None):
+        lib = hip.lib()
+        geom4, transpose, (H, W), (Ho, Wo), Cin2, Cout, R, Cw, wshape, seg, two = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        x16, wc = saved[:2]
+        skip16 = saved[2] if two else None
+        rest = saved[2 + int(two):]
+        khw = geom4[0][0]*geom4[0][1]
+        dev = g.device
+        g = g.contiguous()
+        B = x16.shape[0]
+        small_cin = ctx.x_f32 is not None
+        dgamma = dbeta = dslope = None
+        sums = torch.empty(2*Cout, dtype=torch.float32, device=dev)       # channel sums of d(conv output)
+        if ctx.has_norm:
+            if not ctx.training:
+                raise NotImplementedError('gradient of eval-mode batch norm is not built on the HIP path')
+            y, gamma, beta, mean, invstd = rest[:5]
+            slope = rest[5] if ctx.has_slope else None
+            dgamma, dbeta, dsl = (torch.empty(2*Cout, dtype=torch.float32, device=dev) for _ in range(3))
+            args = (hip.ptr(y), hip.ptr(g), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta),
+                    hip.ptr(slope))
+            if small_cin:
+                dy = torch.empty_like(y)
+                hip.check(lib.brv_batchnorm2d_backward(*args, hip.ptr(dy), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl),
+                                                       B, 2*Cout, Ho*Wo, hip.stream()), 'brv_batchnorm2d_backward')
+                dy16 = None
+            else:
+                dy = None
+                dy16 = _bf16_empty(y.shape, dev)
+                hip.check(lib.brv_batchnorm2d_backward_bf16(*args, hip.ptr(dy16), hip.ptr(dgamma), hip.ptr(dbeta),
+                                                            hip.ptr(dsl), hip.ptr(sums), B, 2*Cout, Ho*Wo,
+                                                            hip.stream()), 'brv_batchnorm2d_backward_bf16')
+            if ctx.has_slope:
+                dslope = torch.empty(1, dtype=torch.float32, device=dev)
+                hip.check(lib.brv_row_sum(hip.ptr(dsl), hip.ptr(dslope), 1, 1, 2*Cout, hip.stream()), 'brv_row_sum')
+        else:
+            dy, dy16 = g, _as_bf16(g)
+
+        def param_grads():
+            """dW (complex pair) and the bias gradients: only dy, x (and skip) go in."""
+            if small_cin:
+                geom = geom4[:3]
+                dwc = torch.empty_like(wc)
+                _gemm_conv(dy, ctx.x_f32, dwc, 1, 2*Cout, 2*Cw, Ho*Wo, Ho*Wo, 2*Cw, 0, 0, 0, 1, (Cin2, H, W), geom,
+                           (Ho, Wo), trans_b=1, kbatch=B, a_kbs=2*Cout*Ho*Wo, img_kbs=Cin2*H*W)
+                return _ComplexConvFunction._unpack_param_grads(dwc, dy, wshape, R, Cw, Cout, B, Ho*Wo, transpose)
+            if transpose:
+                dwc = _cconv_wgrad(x16, dy16, small2=skip16)
+            else:
+                dwc = _cconv_wgrad(dy16, x16)
+            if dy is not None:          # (no norm behind the convolution: the sums of the fp32 gradient)
+                hip.check(lib.brv_row_sum(hip.ptr(dy), hip.ptr(sums), B, 2*Cout, Ho*Wo, hip.stream()), 'brv_row_sum')
+            dwr = torch.empty(wshape, dtype=torch.float32, device=dev)
+            dwi = torch.empty_like(dwr)
+            hip.check(lib.brv_complex_weight_unpack(hip.ptr(dwc), hip.ptr(dwr), hip.ptr(dwi), R, Cw,
+                                                    -1.0 if transpose else 1.0, hip.stream()),
+                      'brv_complex_weight_unpack')
+            dbr = torch.empty(Cout, dtype=torch.float32, device=dev)
+            dbi = torch.empty_like(dbr)
+            hip.check(lib.brv_complex_bias_unpack(hip.ptr(sums), hip.ptr(dbr), hip.ptr(dbi), Cout, hip.stream()),
+                      'brv_complex_bias_unpack')
+            return dwr, dwi, dbr, dbi
+
+        side = _side_stream(dev) if ctx.side_ok else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(dev))
+        need_dx = ctx.needs_input_grad[0] or (two and ctx.needs_input_grad[2])
+        dx = dskip = None
+        if need_dx:
+            src = dy16 if dy16 is not None else _as_bf16(dy)
+            M = Cin2
+            shape = (B, M//2 if two else M) + ((H, W))
+            dx = torch.empty(shape, dtype=torch.float32, device=dev)
+            dskip = torch.empty_like(dx) if two else None
+            # the data gradient of a (transposed) convolution is the other form with the same weights
+            hip.check(lib.brv_cconv_rows_bf16(hip.ptr(src), None, 0, hip.ptr(ctx.wp_bwd), None, hip.ptr(dx),
+                                              hip.ptr(dskip), M//4 if two else 0, B, 2*Cout, M, Ho, Wo,
+                                              int(not transpose), hip.stream()), 'brv_cconv_rows_bf16')
+        if side is None:
+            dwr, dwi, dbr, dbi = param_grads()
+        else:
+            with torch.cuda.stream(side):
+                dwr, dwi, dbr, dbi = param_grads()
+            for t in (x16, skip16, dy, dy16, sums, ctx.x_f32):
+                if t is not None:
+                    t.record_stream(side)
+            if not _side['pending'].get(dev.index):
+                _side['pending'][dev.index] = True
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev))
+        return (dx, None, dskip, None, dwr, dbr, dwi, dbi, dgamma, dbeta, dslope, None, None, None, None, None)
+
+
 class _CplxMomentsFunction(torch.autograd.Function):
     """x (B, 2C, H, W) -> (5, C): per-channel means of xr, xi, xr^2, xi^2, xr*xi."""
 
@@ -896,8 +1095,58 @@ class DCCRN(BreverBaseModel):
                                       blk.linear_i.bias)
         return torch.cat([out_r, out_i], dim=1).view(B, C2, Fq, T)
 
+    def _blocks_ok(self, x):
+        """Every encoder / decoder block on the bf16-activation path (``_BlockFunction``): use_amp, the row kernels'
+        geometry, plain batch norms, skip segments in whole chunks of 8 channels, planes the 16-byte norm passes take."""
+        net = self.mask_net
+        if not (_AMP['on'] and _ROWS and _BF16_ACT and x.is_cuda and tuple(map(tuple, net.geom)) == _ROWS_GEOM):
+            return False
+        H, W = x.shape[-2:]
+        for blk in net.encoder:
+            if isinstance(blk.norm, ComplexBatchNorm2d) or H % 2 or W < 2:
+                return False
+            H, W = H//2, W - 1
+            if (H*W) % 4 or (blk.norm.num_features//2) % 8:
+                return False
+        for blk in net.decoder:
+            H, W = 2*H, W + 1
+            if isinstance(blk.norm, ComplexBatchNorm2d) or (blk.norm is not None and (H*W) % 4):
+                return False
+        return net.decoder[-1].norm is None       # (the mask leaves the network as fp32 data)
+
+    def _block(self, x, x16, skip, skip16, blk, transpose, out_bf16):
+        mr, mi = blk.conv.module_real, blk.conv.module_imag
+        norm, act = blk.norm, blk.activation
+        training = norm is not None and norm.training and norm.track_running_stats
+        return _BlockFunction.apply(x, x16, skip, skip16, mr.weight, mr.bias, mi.weight, mi.bias,
+                                    norm.weight if norm is not None else None, norm.bias if norm is not None else None,
+                                    act.weight if act is not None else None, norm, training, self.mask_net.geom,
+                                    transpose, out_bf16)
+
+    def _mask_net_blocks(self, x):
+        """``_mask_net`` with bf16 activations between the blocks: every block returns (token, data) -- ``_token``."""
+        net = self.mask_net
+        _side['pending'][x.device.index] = False
+        _BN_COUNTERS.clear()
+        tok, a16 = x, None
+        skips = []
+        for k, blk in enumerate(net.encoder):
+            # (the last encoder output feeds the recurrent block: fp32)
+            tok, a16 = self._block(tok, a16, None, None, blk, False, k + 1 < len(net.encoder))
+            s_tok = tok
+            if tok.requires_grad:
+                tok, s_tok = _ForkFunction.apply(tok)
+            skips.append((s_tok, a16))
+        tok, a16 = self._lstm_block(tok), None
+        for blk, (s_tok, s16) in zip(net.decoder, reversed(skips)):
+            tok, a16 = self._block(tok, a16, s_tok, s16, blk, True, blk.norm is not None)
+        _flush_bn_counters()
+        return tok
+
     def _mask_net(self, x):
         net = self.mask_net
+        if self._blocks_ok(x):
+            return self._mask_net_blocks(x)
         if x.is_cuda:
             # a backward pass that raised never ran its end-of-pass callback: the "join queued" mark of this device must
             # not survive into the next pass (ADVICE r4 medium), or that pass would queue no join at all

@@ -375,6 +375,16 @@ int brv_cconv_rows(const float* in, const float* in2, int64_t in_seg, const void
 int64_t brv_cconv_wgrad_workspace_bytes(int64_t B, int64_t A, int64_t C, int64_t Hs);
 int brv_cconv_wgrad(const float* small, const float* small2, const float* big, float* out, void* workspace,
                     int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream);
+/* The same two products with the IMAGES stored as bf16 (in / in2; small / small2 / big -- all alike): the values the
+ * fp32 forms round their operands to on the way into LDS, read at half the bytes (these kernels are bound by what a
+ * CU takes in per cycle). Results are bit-identical to the fp32 forms given images that hold bf16-representable
+ * values. Producers: brv_batchnorm2d_forward_bf16 / brv_batchnorm2d_backward_bf16 below; reference: what
+ * torch.autocast holds between the layers of brever/models/dccrn/dccrn.py:238-292. Outputs stay fp32. */
+int brv_cconv_rows_bf16(const void* in, const void* in2, int64_t in_seg, const void* wp, const float* bias, float* out,
+                        float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
+                        int32_t transposed, brv_stream_t stream);
+int brv_cconv_wgrad_bf16(const void* small, const void* small2, const void* big, float* out, void* workspace,
+                         int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream);
 /* brv_gemm_bf16 with bf16 tensors in memory: flags bit 0: b holds bf16 elements, bit 2: a does, bit 1:
  * d is written as bf16 (no accumulate, no split reduction); strides count elements. Used with
  * brv_im2col_bf16 / brv_col2im_bf16 (same arguments as brv_im2col / brv_col2im, the column matrix
@@ -486,6 +496,21 @@ int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_
                              const float* prelu_slope, float* dx, float* dgamma, float* dbeta,
                              float* dslope_partial, int64_t B, int64_t C, int64_t HW,
                              brv_stream_t stream);
+/* The two batch-norm passes with their element-wise OUTPUT written as bf16 (use_amp: the only readers are the row
+ * convolutions above, which round to bf16 anyway -- nn.BatchNorm2d + nn.PReLU of EncoderBlock / DecoderBlock,
+ * dccrn.py:238-292, under torch.autocast). HW must be a multiple of 4 (-1 otherwise). Statistics, parameter gradients
+ * and all arithmetic are the fp32 forms'. backward: dx_sums (C) or NULL: per-channel sums of the UNROUNDED dx (the
+ * bias gradient of the convolution in front of the norm; replaces a brv_row_sum pass over dx). */
+int brv_batchnorm2d_forward_bf16(const float* x, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, const float* prelu_slope,
+                                 void* y16, float* save_mean, float* save_invstd, int64_t B, int64_t C,
+                                 int64_t HW, float eps, float momentum, int training,
+                                 brv_stream_t stream);
+int brv_batchnorm2d_backward_bf16(const float* x, const float* dy, const float* save_mean,
+                                  const float* save_invstd, const float* gamma, const float* beta,
+                                  const float* prelu_slope, void* dx16, float* dgamma, float* dbeta,
+                                  float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
+                                  brv_stream_t stream);
 int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* w_hh,
                                 const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
                                 int64_t groups, brv_stream_t stream);

@@ -191,3 +191,180 @@ def test_parameter_gradients_on_the_side_stream_equal_the_in_order_ones():
         a, b = grads[True][n].double(), grads[False][n].double()
         assert float((a - b).norm()) <= 1e-2*float(b.norm()) + 1e-6*top, n
     assert max(abs(x - y) for x, y in zip(losses[True], losses[False])) < 2e-3
+
+
+# ---- bf16 images (round 6): the same products on images stored as bf16 ---------------------------------------------
+def _as_bf16(t):
+    """bf16 copy with the readable slack behind it the LDS-DMA row kernels ask for (include/brever_hip.h)."""
+    from brever_amd.models.dccrn import _as_bf16 as f
+    return f(t)
+
+
+def _rows_raw(x, x2, seg, wc, M, C, m_stride, c_stride, transposed, split_out=False):
+    """brv_cconv_rows / brv_cconv_rows_bf16 by the dtype of ``x`` (outputs fp32)."""
+    from brever_amd import hip
+    lib = hip.lib()
+    B, _, H, W = x.shape
+    wp = torch.empty(lib.brv_cconv_packed_bytes(M, C), dtype=torch.uint8, device=x.device)
+    hip.check(lib.brv_cconv_pack(hip.ptr(wc), hip.ptr(wp), M, C, m_stride, c_stride, hip.stream()), 'brv_cconv_pack')
+    shape = (B, M//2 if split_out else M) + ((2*H, W + 1) if transposed else (H//2, W - 1))
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    out2 = torch.empty_like(out) if split_out else None
+    fn = lib.brv_cconv_rows_bf16 if x.dtype == torch.bfloat16 else lib.brv_cconv_rows
+    hip.check(fn(hip.ptr(x), hip.ptr(x2), seg, hip.ptr(wp), None, hip.ptr(out), hip.ptr(out2), M//4 if split_out else 0,
+                 B, C, M, H, W, int(transposed), hip.stream()), 'brv_cconv_rows*')
+    return (out, out2) if split_out else out
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'B%d_C%d_M%d_H%d_W%d' % c)
+@pytest.mark.parametrize('transposed', [0, 1])
+def test_rows_convolution_on_bf16_images_is_bit_identical(case, transposed):
+    """An image of bf16-representable values gives the same bits whether it is stored as fp32 or as bf16 (every
+    workgroup shape and both loaders; odd frame counts put the bf16 rows on 2-byte boundaries)."""
+    dev = _cuda()
+    B, C, M, H, W = case
+    if not transposed and H % 2:
+        H += 1
+    g = torch.Generator().manual_seed(B*1000 + C*10 + M + H + W + transposed)
+    x16 = _as_bf16(torch.randn(B, C, H, W, generator=g).to(dev))
+    wc = (torch.randn(M, C*10, generator=g)/(C*10)**0.5).to(dev)
+    a = _rows_raw(x16.float(), None, 0, wc, M, C, C*10, 10, transposed)
+    b = _rows_raw(x16, None, 0, wc, M, C, C*10, 10, transposed)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 72, 6, 140), (1, 8, 24, 4, 301), (2, 24, 200, 4, 129), (1, 8, 64, 2, 70),
+                                   (1, 40, 520, 2, 33)],
+                         ids=lambda c: 'B%d_seg%d_M%d_H%d_W%d' % c)
+def test_rows_convolution_on_bf16_images_two_sources_and_split_output(shape):
+    dev = _cuda()
+    g = torch.Generator().manual_seed(12)
+    B, seg, M, H, W = shape
+    x1 = _as_bf16(torch.randn(B, 2*seg, H, W, generator=g).to(dev))
+    x2 = _as_bf16(torch.randn(B, 2*seg, H, W, generator=g).to(dev))
+    wc = (torch.randn(M, 4*seg*10, generator=g)/(40*seg)**0.5).to(dev)
+    for transposed in (0, 1):
+        a = _rows_raw(x1.float(), x2.float(), seg, wc, M, 4*seg, 4*seg*10, 10, transposed)
+        b = _rows_raw(x1, x2, seg, wc, M, 4*seg, 4*seg*10, 10, transposed)
+        assert torch.equal(a, b)
+        cat = _as_bf16(torch.cat([x1[:, :seg], x2[:, :seg], x1[:, seg:], x2[:, seg:]], dim=1))
+        a1, a2 = _rows_raw(cat.float(), None, 0, wc, M, 4*seg, 4*seg*10, 10, transposed, split_out=True)
+        b1, b2 = _rows_raw(cat, None, 0, wc, M, 4*seg, 4*seg*10, 10, transposed, split_out=True)
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+
+
+@pytest.mark.parametrize('case', WG_CASES, ids=lambda c: 'B%d_A%d_C%d_H%d_W%d' % c)
+def test_rows_weight_gradient_on_bf16_images_is_bit_identical(case):
+    from brever_amd.models.dccrn import _cconv_wgrad
+    dev = _cuda()
+    B, A, C, Hs, Ws = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    small = torch.randn(B, A, Hs, Ws, generator=g).to(dev).to(torch.bfloat16)
+    big = torch.randn(B, C, 2*Hs, Ws + 1, generator=g).to(dev).to(torch.bfloat16)
+    assert torch.equal(_cconv_wgrad(small.float(), big.float()), _cconv_wgrad(small, big))
+    if A % 4 == 0 and A >= 8:       # the two-source form
+        seg = A//4
+        s1, s2 = small[:, :2*seg].contiguous(), small[:, 2*seg:].contiguous()
+        assert torch.equal(_cconv_wgrad(s1.float(), big.float(), small2=s2.float()), _cconv_wgrad(s1, big, small2=s2))
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 8, 10), (3, 16, 4, 125), (1, 5, 2, 2)], ids=lambda c: 'B%d_C%d_H%d_W%d' % c)
+@pytest.mark.parametrize('act', [True, False])
+def test_batch_norm_passes_with_bf16_output(shape, act):
+    """brv_batchnorm2d_forward_bf16 / _backward_bf16: the fp32 passes' element-wise outputs rounded to bf16, identical
+    statistics and parameter gradients, and the channel sums of the unrounded dx."""
+    from brever_amd import hip
+    lib = hip.lib()
+    dev = _cuda()
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    dy = torch.randn(B, C, H, W, generator=g).to(dev)
+    gamma = (1 + 0.1*torch.randn(C, generator=g)).to(dev)
+    beta = (0.1*torch.randn(C, generator=g)).to(dev)
+    slope = torch.tensor([0.25], device=dev) if act else None
+    outs = {}
+    for lowp in (False, True):
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        y = torch.empty(B, C, H, W, dtype=torch.bfloat16 if lowp else torch.float32, device=dev)
+        fn = lib.brv_batchnorm2d_forward_bf16 if lowp else lib.brv_batchnorm2d_forward
+        hip.check(fn(hip.ptr(x), hip.ptr(gamma), hip.ptr(beta), hip.ptr(rm), hip.ptr(rv), hip.ptr(slope), hip.ptr(y),
+                     hip.ptr(mean), hip.ptr(invstd), B, C, H*W, 1e-5, 0.1, 1, hip.stream()), 'bn forward')
+        dx = torch.empty_like(y)
+        dgamma, dbeta, dsl, sums = (torch.empty(C, device=dev) for _ in range(4))
+        args = (hip.ptr(x), hip.ptr(dy), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(slope),
+                hip.ptr(dx), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl))
+        if lowp:
+            hip.check(lib.brv_batchnorm2d_backward_bf16(*args, hip.ptr(sums), B, C, H*W, hip.stream()), 'bn backward')
+        else:
+            hip.check(lib.brv_batchnorm2d_backward(*args, B, C, H*W, hip.stream()), 'bn backward')
+        outs[lowp] = (y, dx, mean, invstd, rm, rv, dgamma, dbeta, dsl, sums)
+    f, h = outs[False], outs[True]
+    assert torch.equal(f[0].to(torch.bfloat16), h[0]) and torch.equal(f[1].to(torch.bfloat16), h[1])
+    for k in range(2, 9):
+        assert torch.equal(f[k], h[k]), k
+    ref = f[1].double().sum(dim=(0, 2, 3))
+    assert float((h[9].double() - ref).abs().max()) <= 1e-5*float(f[1].double().abs().sum(dim=(0, 2, 3)).max()) + 1e-7
+
+
+def test_batch_norm_bf16_output_refuses_planes_off_the_16_byte_form():
+    from brever_amd import hip
+    lib = hip.lib()
+    dev = _cuda()
+    x = torch.randn(1, 2, 3, 3, device=dev)
+    t = torch.empty(2, device=dev)
+    y = torch.empty(1, 2, 3, 3, dtype=torch.bfloat16, device=dev)
+    rc = lib.brv_batchnorm2d_forward_bf16(hip.ptr(x), hip.ptr(t), hip.ptr(t), None, None, None, hip.ptr(y), hip.ptr(t),
+                                          hip.ptr(t), 1, 2, 9, 1e-5, 0.1, 1, hip.stream())
+    assert rc == -1
+
+
+@pytest.mark.parametrize('channels', [[8, 16, 32], [16, 32, 64, 128, 128, 128]], ids=['small', 'default'])
+def test_bf16_activations_between_the_blocks_change_no_product(channels):
+    """use_amp DCCRN with the activations between the blocks stored as bf16 (``_BlockFunction``) against the round-5
+    path that keeps them fp32 and rounds inside the kernels (BRV_DCCRN_BF16_ACT=0): the same rounding points and the
+    same products (the kernel-level tests above: bit-identical). Two runs of ONE path are not bitwise equal (the
+    recurrent block's products add their split reductions with atomics, and a last-bit difference flips bf16 roundings
+    downstream), so the yardstick is measured: the round-5 path run twice. The bf16 path may differ from it by three
+    times that spread (+ 1e-5 of the norm); the biases in front of a batch norm have gradients of pure rounding noise
+    and are held to the top gradient norm."""
+    import brever_amd.models.dccrn as D
+    dev = _cuda()
+    n = 16000
+    batch = 0.1*torch.randn(2, 2, n, generator=torch.Generator().manual_seed(4)).to(dev)
+    lengths = torch.tensor([n, n - 3000], device=dev)
+    out = []
+    try:
+        for lowp in (False, False, True):
+            D._BF16_ACT = lowp
+            torch.manual_seed(3)
+            model = D.DCCRN(channels=channels, lstm_channels=32 if len(channels) == 3 else 128).to(dev)
+            with torch.no_grad():
+                enh = model._enhance(batch[:, 0:1].repeat(1, 2, 1), True)
+            loss = model.loss(batch, lengths, True)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, enh,
+                        {k: b.detach().clone() for k, b in model.named_buffers()}))
+    finally:
+        D._BF16_ACT = True
+    ref, again, new = out
+
+    def dist(a, b):
+        return float((a.double() - b.double()).norm())
+    assert abs(new[0] - ref[0]) <= 3*abs(again[0] - ref[0]) + 1e-5*abs(ref[0]), (new[0], again[0], ref[0])
+    assert dist(new[2], ref[2]) <= 3*dist(again[2], ref[2]) + 1e-5*float(ref[2].norm())
+    for k in ref[3]:
+        assert dist(new[3][k], ref[3][k]) <= 3*dist(again[3][k], ref[3][k]) + 1e-5*float(ref[3][k].double().norm()) + 1e-9, k
+    # gradients: every tensor of 64 elements or more (the scalar PReLU slopes are sums with heavy cancellation: 3e-2 to
+    # 2e-1 apart between two runs of one path -- they count in the global bound), and all of them together
+    top = max(float(g.double().norm()) for g in ref[1].values())
+    for k in ref[1]:
+        if ref[1][k].numel() >= 64:
+            assert dist(new[1][k], ref[1][k]) <= 3*dist(again[1][k], ref[1][k]) + 2e-3*float(ref[1][k].double().norm()) + 1e-6*top, \
+                (k, dist(new[1][k], ref[1][k]), dist(again[1][k], ref[1][k]), float(ref[1][k].double().norm()))
+    tot = sum(float(g.double().norm())**2 for g in ref[1].values())**0.5
+    d_new = sum(dist(new[1][k], ref[1][k])**2 for k in ref[1])**0.5
+    d_again = sum(dist(again[1][k], ref[1][k])**2 for k in ref[1])**0.5
+    assert d_new <= 3*d_again + 1e-3*tot, (d_new, d_again, tot)
