@@ -376,10 +376,14 @@ int64_t brv_cconv_wgrad_workspace_bytes(int64_t B, int64_t A, int64_t C, int64_t
 int brv_cconv_wgrad(const float* small, const float* small2, const float* big, float* out, void* workspace,
                     int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream);
 /* The same two products with the IMAGES stored as bf16 (in / in2; small / small2 / big -- all alike): the values the
- * fp32 forms round their operands to on the way into LDS, read at half the bytes (these kernels are bound by what a
- * CU takes in per cycle). Results are bit-identical to the fp32 forms given images that hold bf16-representable
- * values. Producers: brv_batchnorm2d_forward_bf16 / brv_batchnorm2d_backward_bf16 below; reference: what
- * torch.autocast holds between the layers of brever/models/dccrn/dccrn.py:238-292. Outputs stay fp32. */
+ * fp32 forms round their operands to on the way into LDS. Results are bit-identical to the fp32 forms given images
+ * that hold bf16-representable values. Producers: brv_batchnorm2d_forward_bf16 / brv_batchnorm2d_backward_bf16
+ * below; reference: what torch.autocast holds between the layers of brever/models/dccrn/dccrn.py:238-292. Outputs
+ * stay fp32. bf16 images need no conversion on the way into LDS: brv_cconv_rows_bf16 stages them by LDS-DMA
+ * (csrc/cconv_dma.cuh) wherever C is a multiple of 8, and that path fetches whole 16-byte pieces around a row's ends
+ * through range-checked descriptors that reach 16 bytes in front of and behind the tensor.
+ * CONTRACT: `in` and `in2` of brv_cconv_rows_bf16 must have 16 READABLE bytes on both sides (allocate 8 elements
+ * more at each end; their contents do not matter). brv_cconv_wgrad_bf16 has no such requirement. */
 int brv_cconv_rows_bf16(const void* in, const void* in2, int64_t in_seg, const void* wp, const float* bias, float* out,
                         float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
                         int32_t transposed, brv_stream_t stream);

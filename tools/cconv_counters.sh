@@ -10,14 +10,13 @@ cd /tmp && export TMPDIR=/tmp
 export LAYER
 [ -n "$LIB" ] && export BRV_LIB_PATH=$LIB
 N=0
+# (SQ counters only: a pass with TA_* / TCP_* counters never returned on this pool and ran into gpurun's limit; every
+# pass is bounded by its own timeout)
 for SET in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" \
-           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
-           "TA_TA_BUSY_sum TA_BUFFER_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
-           "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
-           "TD_TD_BUSY_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TOTAL_ACCESSES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"; do
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   N=$((N + 1))
   rm -rf /tmp/cc_$N
-  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d /tmp/cc_$N -o p -- python3 $REPO/tools/cconv_bench.py bf16 > /tmp/cc_$N.log 2>&1
+  timeout 150 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d /tmp/cc_$N -o p -- python3 $REPO/tools/cconv_bench.py bf16 > /tmp/cc_$N.log 2>&1
   f=$(find /tmp/cc_$N -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then cp $f $OUT/${LAYER}_pass$N.csv; else echo "pass $N failed: $(tail -2 /tmp/cc_$N.log | cut -c1-200)"; fi
 done
