@@ -840,6 +840,7 @@ __global__ __launch_bounds__(256) void cconv_wgrad_reduce_kernel(const float* pa
 }
 
 #include "cconv_dma.cuh"
+#include "cconv_wgrad_dma.cuh"
 
 // which tile function a launch shape runs (measured per layer, tools/dccrn_conv_bench.py): the lean loader for
 // two-source inputs / split outputs and for M <= 64; the pair form of the transposed convolution for M <= 128
@@ -1012,6 +1013,11 @@ static int cconv_wgrad_any(const void* small, const void* small2, const void* bi
   cconv_wgrad_plan(B, A, C, Hs, p.atiles, p.ctiles, nsplit, p.pairs_per);
   p.npairs = (int)(B*Hs); p.nstage = (p.Wb + WG_F - 1)/WG_F; p.ldo = (int)(10*C);
   hipStream_t st = (hipStream_t)stream;
+  // bf16 images: staged by LDS-DMA (cconv_wgrad_dma.cuh) when a unit of 8 rows never straddles two sources
+  if (sizeof(T) == 2 && CC_DMA && (seg == 0 || seg % 8 == 0) && B*p.small_bs < (1LL << 29) && B*p.big_bs < (1LL << 29))
+    hipLaunchKernelGGL(cconv_wgrad_dma_kernel, dim3((unsigned)(p.atiles*p.ctiles), (unsigned)nsplit), dim3(WG_THREADS), 0,
+                       st, p);
+  else
   hipLaunchKernelGGL(cconv_wgrad_kernel<T>, dim3((unsigned)(p.atiles*p.ctiles), (unsigned)nsplit), dim3(WG_THREADS), 0,
                      st, p);
   const long long n = 10*A*C;

@@ -68,7 +68,7 @@ __device__ __forceinline__ void cconv_tile_dma(const CConvParams& p, unsigned ch
   constexpr int U = NSLOT;                   // DMAs per wave and chunk
   static_assert(WM*WN == 8 && NT % 128 == 0, "8 waves, whole images");
   static_assert(U*(R - 1) < 64, "vmcnt field");
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar for the compiler)
   const int wm = wid / WN, wn = wid % WN;
   const int f0 = ftile*NT;
   const int plane = p.Hin*p.Win;

@@ -382,8 +382,10 @@ int brv_cconv_wgrad(const float* small, const float* small2, const float* big, f
  * stay fp32. bf16 images need no conversion on the way into LDS: brv_cconv_rows_bf16 stages them by LDS-DMA
  * (csrc/cconv_dma.cuh) wherever C is a multiple of 8, and that path fetches whole 16-byte pieces around a row's ends
  * through range-checked descriptors that reach 16 bytes in front of and behind the tensor.
- * CONTRACT: `in` and `in2` of brv_cconv_rows_bf16 must have 16 READABLE bytes on both sides (allocate 8 elements
- * more at each end; their contents do not matter). brv_cconv_wgrad_bf16 has no such requirement. */
+ * brv_cconv_wgrad_bf16 does the same (csrc/cconv_wgrad_dma.cuh) unless its two-source segments are not whole
+ * groups of 8 channels.
+ * CONTRACT: every bf16 image handed to these two functions (in, in2; small, small2, big) must have 16 READABLE bytes
+ * on both sides (allocate 8 elements more at each end; their contents do not matter). */
 int brv_cconv_rows_bf16(const void* in, const void* in2, int64_t in_seg, const void* wp, const float* bias, float* out,
                         float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
                         int32_t transposed, brv_stream_t stream);
