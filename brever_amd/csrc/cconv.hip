@@ -45,7 +45,9 @@ constexpr int CC_KH = 5;
 
 struct CConvParams {
   const void* in; const void* in2;   // fp32 or bf16 elements (the kernel's TI)
-  const uint4* wp; const float* bias; float* out; float* out2;
+  const uint4* wp; const float* bias;
+  void* out; void* out2;       // fp32, or bf16 with out_bf16 (the block's batch norm reads it: brv_batchnorm2d_*_bf16io)
+  int out_bf16;
   int in_seg, out_seg;         // > 0: channels = [t[:seg] | t2[:seg] | t[seg:] | t2[seg:]] of two (B, 2 seg, H, W) tensors
   int B, C, M, Hin, Win, Hout, Wout;
   long long in_bs, out_bs;
@@ -322,8 +324,9 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
   }
 
   // ---- D[m][frame] -> out[b][m][r][frame] (+ bias)
-  float* out_b = p.out + (long long)b*p.out_bs;
-  float* out2_b = SEG && p.out_seg > 0 ? p.out2 + (long long)b*p.out_bs : nullptr;
+  const int oes = p.out_bf16 ? 2 : 4;        // bytes per output element
+  char* out_b = static_cast<char*>(p.out) + (long long)b*p.out_bs*oes;
+  char* out2_b = SEG && p.out_seg > 0 ? static_cast<char*>(p.out2) + (long long)b*p.out_bs*oes : nullptr;
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
@@ -335,14 +338,16 @@ __device__ __forceinline__ void cconv_tile(const CConvParams& p, unsigned char* 
         if (m < p.M && w < p.Wout) {
           float v = acc[mf][nf][i];
           if (p.bias) v += p.bias[m];
-          float* dst = out_b;
+          char* dst = out_b;
           int mc = m;
           if (SEG && p.out_seg > 0) {
             const int sg = (m >= p.out_seg) + (m >= 2*p.out_seg) + (m >= 3*p.out_seg);
             mc -= ((sg + 1) >> 1)*p.out_seg;
             if (sg & 1) dst = out2_b;
           }
-          dst[((long long)mc*p.Hout + r)*p.Wout + w] = v;
+          const long long idx = ((long long)mc*p.Hout + r)*p.Wout + w;
+            if (p.out_bf16) *reinterpret_cast<bf16_t*>(dst + idx*2) = f2bf(v);
+            else *reinterpret_cast<float*>(dst + idx*4) = v;
         }
       }
     }
@@ -551,8 +556,9 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
   }
 
   // ---- D[m][frame] -> out[b][m][row][frame] (+ bias)
-  float* out_b = p.out + (long long)b*p.out_bs;
-  float* out2_b = SEG && p.out_seg > 0 ? p.out2 + (long long)b*p.out_bs : nullptr;
+  const int oes = p.out_bf16 ? 2 : 4;        // bytes per output element
+  char* out_b = static_cast<char*>(p.out) + (long long)b*p.out_bs*oes;
+  char* out2_b = SEG && p.out_seg > 0 ? static_cast<char*>(p.out2) + (long long)b*p.out_bs*oes : nullptr;
 #pragma unroll
   for (int set = 0; set < NSET; ++set) {
     const int orow = PAIR ? 2*r + set : r;
@@ -567,14 +573,16 @@ __device__ __forceinline__ void cconv_tile_lean(const CConvParams& p, unsigned c
           if (m < p.M && w < p.Wout && (!(CC_ABL & 8) || acc[set][mf][nf][i] == 1234.5f)) {
             float v = acc[set][mf][nf][i];
             if (p.bias) v += p.bias[m];
-            float* dst = out_b;
+            char* dst = out_b;
             int mc = m;
             if (SEG && p.out_seg > 0) {
               const int sg = (m >= p.out_seg) + (m >= 2*p.out_seg) + (m >= 3*p.out_seg);
               mc -= ((sg + 1) >> 1)*p.out_seg;
               if (sg & 1) dst = out2_b;
             }
-            dst[((long long)mc*p.Hout + orow)*p.Wout + w] = v;
+            const long long idx = ((long long)mc*p.Hout + orow)*p.Wout + w;
+            if (p.out_bf16) *reinterpret_cast<bf16_t*>(dst + idx*2) = f2bf(v);
+            else *reinterpret_cast<float*>(dst + idx*4) = v;
           }
         }
       }
@@ -888,15 +896,15 @@ static void cconv_launch(CConvParams& p, int64_t B, int64_t M, bool transposed, 
 }
 
 template <typename TI>
-static int cconv_rows_any(const void* in, const void* in2, int64_t in_seg, const void* wp, const float* bias, float* out,
-                          float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
-                          int32_t transposed, brv_stream_t stream) {
+static int cconv_rows_any(const void* in, const void* in2, int64_t in_seg, const void* wp, const float* bias, void* out,
+                          void* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
+                          int32_t transposed, brv_stream_t stream, int out_bf16 = 0) {
   if (!in || !wp || !out || B < 1 || C < 1 || M < 1 || Hin < 1 || Win < 1) return -1;
   if (!transposed && ((Hin & 1) || Win < 2)) return -1;
   if (in_seg < 0 || (in_seg > 0 && (!in2 || C != 4*in_seg || (in_seg & 7)))) return -1;
   if (out_seg < 0 || (out_seg > 0 && (!out2 || M != 4*out_seg))) return -1;
   CConvParams p;
-  p.in = in; p.in2 = in2; p.wp = (const uint4*)wp; p.bias = bias; p.out = out; p.out2 = out2;
+  p.in = in; p.in2 = in2; p.wp = (const uint4*)wp; p.bias = bias; p.out = out; p.out2 = out2; p.out_bf16 = out_bf16;
   p.in_seg = (int)in_seg; p.out_seg = (int)out_seg;
   p.B = (int)B; p.C = (int)C; p.M = (int)M; p.Hin = (int)Hin; p.Win = (int)Win;
   p.Hout = transposed ? (int)(2*Hin) : (int)(Hin/2);
@@ -978,6 +986,15 @@ int brv_cconv_rows_bf16(const void* in, const void* in2, int64_t in_seg, const v
                         float* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
                         int32_t transposed, brv_stream_t stream) {
   return cconv_rows_any<bf16_t>(in, in2, in_seg, wp, bias, out, out2, out_seg, B, C, M, Hin, Win, transposed, stream);
+}
+
+int brv_cconv_rows_ex(const void* in, const void* in2, int64_t in_seg, const void* wp, const float* bias, void* out,
+                      void* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
+                      int32_t transposed, int32_t in_bf16, int32_t out_bf16, brv_stream_t stream) {
+  if (in_bf16) return cconv_rows_any<bf16_t>(in, in2, in_seg, wp, bias, out, out2, out_seg, B, C, M, Hin, Win, transposed,
+                                             stream, out_bf16 != 0);
+  return cconv_rows_any<float>(in, in2, in_seg, wp, bias, out, out2, out_seg, B, C, M, Hin, Win, transposed, stream,
+                               out_bf16 != 0);
 }
 
 static void cconv_wgrad_plan(int64_t B, int64_t A, int64_t C, int64_t Hs, int& atiles, int& ctiles, int& nsplit,

@@ -257,8 +257,9 @@ __device__ __forceinline__ void cconv_tile_dma(const CConvParams& p, unsigned ch
   dma::wait_vm<0>();                               // (the bursts past the end)
 
   // ---- D[m][frame] -> out[b][m][row][frame] (+ bias)
-  float* out_b = p.out + (long long)b*p.out_bs;
-  float* out2_b = SEG && p.out_seg > 0 ? p.out2 + (long long)b*p.out_bs : nullptr;
+  const int oes = p.out_bf16 ? 2 : 4;        // bytes per output element
+  char* out_b = static_cast<char*>(p.out) + (long long)b*p.out_bs*oes;
+  char* out2_b = SEG && p.out_seg > 0 ? static_cast<char*>(p.out2) + (long long)b*p.out_bs*oes : nullptr;
 #pragma unroll
   for (int set = 0; set < NSET; ++set) {
     const int orow = PAIR ? 2*r + set : r;
@@ -273,14 +274,16 @@ __device__ __forceinline__ void cconv_tile_dma(const CConvParams& p, unsigned ch
           if (m < p.M && w < p.Wout && (!(CC_ABL & 8) || acc[set][mf][nf][i] == 1234.5f)) {
             float v = acc[set][mf][nf][i];
             if (p.bias) v += p.bias[m];
-            float* dst = out_b;
+            char* dst = out_b;
             int mc = m;
             if (SEG && p.out_seg > 0) {
               const int sg = (m >= p.out_seg) + (m >= 2*p.out_seg) + (m >= 3*p.out_seg);
               mc -= ((sg + 1) >> 1)*p.out_seg;
               if (sg & 1) dst = out2_b;
             }
-            dst[((long long)mc*p.Hout + orow)*p.Wout + w] = v;
+            const long long idx = ((long long)mc*p.Hout + orow)*p.Wout + w;
+            if (p.out_bf16) *reinterpret_cast<bf16_t*>(dst + idx*2) = f2bf(v);
+            else *reinterpret_cast<float*>(dst + idx*4) = v;
           }
         }
       }

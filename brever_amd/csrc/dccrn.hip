@@ -102,6 +102,18 @@ __global__ __launch_bounds__(256) void conv_transpose2d_fwd_kernel(const float* 
 // Per-channel reductions over (B, HW) run as gridDim.y slices per channel whose fp64 partial
 // sums land in a scratch (C, slices, K) and are combined in a fixed order by a finishing
 // kernel: deterministic, and C = 16..512 channels alone would leave most of the chip idle.
+// (TO = bf16_t: the output as the bf16 values the use_amp row convolutions round it to anyway -- its only readers on
+// that path, csrc/cconv.hip -- at half the bytes)
+__device__ __forceinline__ float4 load4(const float* base, long long i) { return reinterpret_cast<const float4*>(base)[i]; }
+__device__ __forceinline__ float4 load4(const bf16_t* base, long long i) {
+  const uint2 q = reinterpret_cast<const uint2*>(base)[i];
+  return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                     __uint_as_float(q.y & 0xffff0000u));
+}
+__device__ __forceinline__ void store4(float* base, long long i, float4 v) { reinterpret_cast<float4*>(base)[i] = v; }
+__device__ __forceinline__ void store4(bf16_t* base, long long i, float4 v) {
+  reinterpret_cast<uint2*>(base)[i] = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+}
 constexpr int kRedSlices = 64;
 __device__ __forceinline__ void slice_range(long long n, long long& lo, long long& hi) {
   const long long per = (n + gridDim.y - 1)/gridDim.y;
@@ -130,16 +142,17 @@ __global__ __launch_bounds__(256) void bn_stats_part_kernel(const float* x, int 
 // the same sums when HW % 4 == 0 (every DCCRN shape): blockIdx.y = (batch item, piece of the plane) so that a block
 // reads one contiguous run with 16-byte loads -- no 64-bit division per element; four elements meet in fp32, then
 // join the fp64 sum (44 -> 27 us on a 131 MB tensor)
-__global__ __launch_bounds__(256) void bn_stats_part4_kernel(const float* x, int C, long long HW, int pieces,
+template <typename TI>
+__global__ __launch_bounds__(256) void bn_stats_part4_kernel(const TI* x, int C, long long HW, int pieces,
                                                              double* part) {
   __shared__ double scr[8];
   const int c = blockIdx.x, b = blockIdx.y / pieces, pc = blockIdx.y % pieces;
   const long long n4 = HW >> 2, per = (n4 + pieces - 1)/pieces;
   const long long lo = pc*per, hi = lo + per < n4 ? lo + per : n4;
-  const float4* src = reinterpret_cast<const float4*>(x + ((long long)b*C + c)*HW);
+  const TI* src = x + ((long long)b*C + c)*HW;
   double s = 0.0, q = 0.0;
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    const float4 v = src[i];
+    const float4 v = load4(src, i);
     s += (double)((v.x + v.y) + (v.z + v.w));
     q += (double)((v.x*v.x + v.y*v.y) + (v.z*v.z + v.w*v.w));
   }
@@ -189,23 +202,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const flo
 }
 // the two element-wise passes when HW % 4 == 0: blockIdx = (piece of the plane, channel, batch item): the channel
 // scalars are loaded once per block, the plane is walked with 16-byte accesses, no division per element
-// (TO = bf16_t: the output as the bf16 values the use_amp row convolutions round it to anyway -- its only readers on
-// that path, csrc/cconv.hip -- at half the bytes)
-__device__ __forceinline__ void store4(float* base, long long i, float4 v) { reinterpret_cast<float4*>(base)[i] = v; }
-__device__ __forceinline__ void store4(bf16_t* base, long long i, float4 v) {
-  reinterpret_cast<uint2*>(base)[i] = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
-}
-template <typename TO>
-__global__ __launch_bounds__(256) void bn_apply4_kernel(const float* x, const float* mean, const float* invstd,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const TI* x, const float* mean, const float* invstd,
                                                         const float* gamma, const float* beta, const float* slope,
                                                         TO* y, int C, long long HW) {
   const int c = blockIdx.y, b = blockIdx.z;
   const float a = slope ? *slope : 1.f;
   const long long n4 = HW >> 2, base = ((long long)b*C + c)*HW;
-  const float4* src = reinterpret_cast<const float4*>(x + base);
+  const TI* src = x + base;
   TO* dst = y + base;
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n4; i += (long long)gridDim.x*256) {
-    float4 v = src[i];
+    float4 v = load4(src, i);
     // (x - mean)*invstd*gamma + beta with the reference's rounding order kept: two multiplies, then the add
     v.x = (v.x - mean[c])*invstd[c]*gamma[c] + beta[c]; v.y = (v.y - mean[c])*invstd[c]*gamma[c] + beta[c];
     v.z = (v.z - mean[c])*invstd[c]*gamma[c] + beta[c]; v.w = (v.w - mean[c])*invstd[c]*gamma[c] + beta[c];
@@ -1109,7 +1116,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
     o[0] = s1; o[1] = s2; o[2] = sa;
   }
 }
-__global__ __launch_bounds__(256) void bn_bwd_stats4_kernel(const float* x, const float* dy,
+template <typename TI>
+__global__ __launch_bounds__(256) void bn_bwd_stats4_kernel(const TI* x, const float* dy,
                                                             const float* mean, const float* invstd,
                                                             const float* gamma, const float* beta,
                                                             const float* slope, int C, long long HW,
@@ -1120,11 +1128,11 @@ __global__ __launch_bounds__(256) void bn_bwd_stats4_kernel(const float* x, cons
   const float mu = mean[c], is = invstd[c], gm = gamma[c], bt = beta[c];
   const long long n4 = HW >> 2, per = (n4 + pieces - 1)/pieces;
   const long long lo = pc*per, hi = lo + per < n4 ? lo + per : n4;
-  const float4* xs = reinterpret_cast<const float4*>(x + ((long long)b*C + c)*HW);
+  const TI* xs = x + ((long long)b*C + c)*HW;
   const float4* ds = reinterpret_cast<const float4*>(dy + ((long long)b*C + c)*HW);
   double s1 = 0.0, s2 = 0.0, sa = 0.0;
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    const float4 xv = xs[i], dv = ds[i];
+    const float4 xv = load4(xs, i), dv = ds[i];
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
     float de[4] = {dv.x, dv.y, dv.z, dv.w};
     float t1 = 0.f, t2 = 0.f, ta = 0.f;
@@ -1180,8 +1188,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
 // (TO = bf16_t: dx as bf16 -- the gradient with respect to a row convolution's output, which its data and weight
 // gradient kernels round to bf16 anyway; `sums`: per-block sums of the UNROUNDED dx, what the convolution's bias
 // gradient is made of: [channel][batch item x gridDim.x] partials, added up by row_sum_final-style bn_dxsum_kernel)
-template <typename TO>
-__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* x, const float* dy, const float* mean,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const TI* x, const float* dy, const float* mean,
                                                             const float* invstd, const float* gamma,
                                                             const float* beta, const float* slope,
                                                             const float* dgamma, const float* dbeta, TO* dx,
@@ -1191,12 +1199,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* x, cons
   const float a = slope ? *slope : 1.f;
   const float mu = mean[c], is = invstd[c], gm = gamma[c], bt = beta[c], db = dbeta[c]*inv_n, dg = dgamma[c]*inv_n;
   const long long n4 = HW >> 2, base = ((long long)b*C + c)*HW;
-  const float4* xs = reinterpret_cast<const float4*>(x + base);
+  const TI* xs = x + base;
   const float4* ds = reinterpret_cast<const float4*>(dy + base);
   TO* dst = dx + base;
   double tot = 0.0;
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n4; i += (long long)gridDim.x*256) {
-    const float4 xv = xs[i], dv = ds[i];
+    const float4 xv = load4(xs, i), dv = ds[i];
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
     float o[4];
 #pragma unroll
@@ -1365,16 +1373,16 @@ int brv_conv_transpose2d_forward(const float* x, const float* w, const float* bi
 
 }  // extern "C"
 
-template <typename TO>
-static int bn_forward_any(const float* x, const float* gamma, const float* beta,
+template <typename TI, typename TO>
+static int bn_forward_any(const TI* x, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, const float* prelu_slope,
                             TO* y, float* save_mean, float* save_invstd, int64_t B, int64_t C,
                             int64_t HW, float eps, float momentum, int training,
                             brv_stream_t stream) {
   if (B < 1 || C < 1 || HW < 1) return -1;
-  constexpr bool kF32 = sizeof(TO) == 4;
-  if (!kF32 && ((HW & 3) || C > 65535 || B > 65535 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)))
-    return -1;                                  // the bf16 output exists in the 16-byte form only
+  constexpr bool kF32 = sizeof(TO) == 4 && sizeof(TI) == 4;
+  if (!kF32 && ((HW & 3) || C > 65535 || B > 1024 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)))
+    return -1;                                  // bf16 input / output exist in the four-elements-per-access form only
   hipStream_t st = (hipStream_t)stream;
   if (training) {
     const bool vec = (HW & 3) == 0 && B <= 1024 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
@@ -1382,9 +1390,9 @@ static int bn_forward_any(const float* x, const float* gamma, const float* beta,
     const int slices = vec ? (int)B*pieces : red_slices(B*HW);
     double* part = nullptr;
     DC_OK(hipMallocAsync((void**)&part, (size_t)C*slices*2*sizeof(double), st));
-    if (vec) hipLaunchKernelGGL(bn_stats_part4_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st,
+    if (vec) hipLaunchKernelGGL(bn_stats_part4_kernel<TI>, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st,
                                 x, (int)C, (long long)HW, pieces, part);
-    else hipLaunchKernelGGL(bn_stats_part_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st,
+    else if constexpr (kF32) hipLaunchKernelGGL(bn_stats_part_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st,
                        x, (int)B, (int)C, (long long)HW, part);
     hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((C + 255)/256)), dim3(256), 0, st, part,
                        slices, (int)B, (int)C, (long long)HW, save_mean, save_invstd, running_mean,
@@ -1399,7 +1407,7 @@ static int bn_forward_any(const float* x, const float* gamma, const float* beta,
   if ((HW & 3) == 0 && C <= 65535 && B <= 65535 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
     long long gx = (HW/4 + 1023)/1024;                 // four 16-byte accesses per thread
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(bn_apply4_kernel<TO>, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, save_mean,
+    hipLaunchKernelGGL((bn_apply4_kernel<TI, TO>), dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, save_mean,
                        save_invstd, gamma, beta, prelu_slope, y, (int)C, (long long)HW);
   } else if constexpr (kF32)
   hipLaunchKernelGGL(bn_apply_kernel, flat_grid(total), dim3(256), 0, st, x, save_mean,
@@ -1415,8 +1423,8 @@ int brv_batchnorm2d_forward(const float* x, const float* gamma, const float* bet
                             float* y, float* save_mean, float* save_invstd, int64_t B, int64_t C,
                             int64_t HW, float eps, float momentum, int training,
                             brv_stream_t stream) {
-  return bn_forward_any<float>(x, gamma, beta, running_mean, running_var, prelu_slope, y, save_mean, save_invstd, B, C,
-                               HW, eps, momentum, training, stream);
+  return bn_forward_any<float, float>(x, gamma, beta, running_mean, running_var, prelu_slope, y, save_mean, save_invstd, B, C,
+                                      HW, eps, momentum, training, stream);
 }
 
 int brv_batchnorm2d_forward_bf16(const float* x, const float* gamma, const float* beta,
@@ -1424,8 +1432,17 @@ int brv_batchnorm2d_forward_bf16(const float* x, const float* gamma, const float
                                  void* y16, float* save_mean, float* save_invstd, int64_t B, int64_t C,
                                  int64_t HW, float eps, float momentum, int training,
                                  brv_stream_t stream) {
-  return bn_forward_any<bf16_t>(x, gamma, beta, running_mean, running_var, prelu_slope, (bf16_t*)y16, save_mean,
-                                save_invstd, B, C, HW, eps, momentum, training, stream);
+  return bn_forward_any<float, bf16_t>(x, gamma, beta, running_mean, running_var, prelu_slope, (bf16_t*)y16, save_mean,
+                                       save_invstd, B, C, HW, eps, momentum, training, stream);
+}
+
+int brv_batchnorm2d_forward_bf16io(const void* x16, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, const float* prelu_slope,
+                                   void* y16, float* save_mean, float* save_invstd, int64_t B, int64_t C,
+                                   int64_t HW, float eps, float momentum, int training,
+                                   brv_stream_t stream) {
+  return bn_forward_any<bf16_t, bf16_t>((const bf16_t*)x16, gamma, beta, running_mean, running_var, prelu_slope,
+                                        (bf16_t*)y16, save_mean, save_invstd, B, C, HW, eps, momentum, training, stream);
 }
 
 int brv_lstm_recurrent_forward(const float* gates_in, const float* w_hh, const float* bias,
@@ -1533,15 +1550,15 @@ int brv_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, i
 
 }  // extern "C"
 
-template <typename TO>
-static int bn_backward_any(const float* x, const float* dy, const float* save_mean,
+template <typename TI, typename TO>
+static int bn_backward_any(const TI* x, const float* dy, const float* save_mean,
                              const float* save_invstd, const float* gamma, const float* beta,
                              const float* prelu_slope, TO* dx, float* dgamma, float* dbeta,
                              float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
                              brv_stream_t stream) {
   if (B < 1 || C < 1 || HW < 1) return -1;
-  constexpr bool kF32 = sizeof(TO) == 4;
-  if ((!kF32 || dx_sums) && ((HW & 3) || C > 65535 || B > 65535 ||
+  constexpr bool kF32 = sizeof(TO) == 4 && sizeof(TI) == 4;
+  if ((!kF32 || dx_sums) && ((HW & 3) || C > 65535 || B > (kF32 ? 65535 : 1024) ||
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15)))
     return -1;                                  // bf16 output / dx sums: the 16-byte form only
   hipStream_t st = (hipStream_t)stream;
@@ -1550,10 +1567,10 @@ static int bn_backward_any(const float* x, const float* dy, const float* save_me
   const int slices = vec ? (int)B*pieces : red_slices(B*HW);
   double* part = nullptr;
   DC_OK(hipMallocAsync((void**)&part, (size_t)C*slices*3*sizeof(double), st));
-  if (vec) hipLaunchKernelGGL(bn_bwd_stats4_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st, x,
+  if (vec) hipLaunchKernelGGL(bn_bwd_stats4_kernel<TI>, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st, x,
                               dy, save_mean, save_invstd, gamma, beta, prelu_slope, (int)C, (long long)HW,
                               pieces, part);
-  else hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st, x,
+  else if constexpr (kF32) hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st, x,
                      dy, save_mean, save_invstd, gamma, beta, prelu_slope, (int)B, (int)C,
                      (long long)HW, part);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)((C + 255)/256)), dim3(256), 0, st, part,
@@ -1566,7 +1583,7 @@ static int bn_backward_any(const float* x, const float* dy, const float* save_me
     if (gx < 1) gx = 1;
     double* sums = nullptr;
     if (dx_sums) DC_OK(hipMallocAsync((void**)&sums, (size_t)C*B*gx*sizeof(double), st));
-    hipLaunchKernelGGL(bn_bwd_apply4_kernel<TO>, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, dy,
+    hipLaunchKernelGGL((bn_bwd_apply4_kernel<TI, TO>), dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, dy,
                        save_mean, save_invstd, gamma, beta, prelu_slope, dgamma, dbeta, dx, (int)C, (long long)HW,
                        1.f/(float)(B*HW), sums);
     if (dx_sums) {
@@ -1589,7 +1606,7 @@ int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_
                              const float* prelu_slope, float* dx, float* dgamma, float* dbeta,
                              float* dslope_partial, int64_t B, int64_t C, int64_t HW,
                              brv_stream_t stream) {
-  return bn_backward_any<float>(x, dy, save_mean, save_invstd, gamma, beta, prelu_slope, dx, dgamma, dbeta,
+  return bn_backward_any<float, float>(x, dy, save_mean, save_invstd, gamma, beta, prelu_slope, dx, dgamma, dbeta,
                                 dslope_partial, nullptr, B, C, HW, stream);
 }
 
@@ -1598,8 +1615,17 @@ int brv_batchnorm2d_backward_bf16(const float* x, const float* dy, const float* 
                                   const float* prelu_slope, void* dx16, float* dgamma, float* dbeta,
                                   float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
                                   brv_stream_t stream) {
-  return bn_backward_any<bf16_t>(x, dy, save_mean, save_invstd, gamma, beta, prelu_slope, (bf16_t*)dx16, dgamma, dbeta,
-                                 dslope_partial, dx_sums, B, C, HW, stream);
+  return bn_backward_any<float, bf16_t>(x, dy, save_mean, save_invstd, gamma, beta, prelu_slope, (bf16_t*)dx16, dgamma, dbeta,
+                                        dslope_partial, dx_sums, B, C, HW, stream);
+}
+
+int brv_batchnorm2d_backward_bf16io(const void* x16, const float* dy, const float* save_mean,
+                                    const float* save_invstd, const float* gamma, const float* beta,
+                                    const float* prelu_slope, void* dx16, float* dgamma, float* dbeta,
+                                    float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
+                                    brv_stream_t stream) {
+  return bn_backward_any<bf16_t, bf16_t>((const bf16_t*)x16, dy, save_mean, save_invstd, gamma, beta, prelu_slope,
+                                         (bf16_t*)dx16, dgamma, dbeta, dslope_partial, dx_sums, B, C, HW, stream);
 }
 
 int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* w_hh,

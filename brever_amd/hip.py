@@ -278,6 +278,11 @@ SIGNATURES = {
     'brv_cconv_rows_bf16': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_i64]*6
                             + [ctypes.c_int32, _c_ptr]),
     'brv_cconv_wgrad_bf16': (ctypes.c_int, [_c_ptr]*5 + [_c_i64]*6 + [_c_ptr]),
+    'brv_cconv_rows_ex': (ctypes.c_int, [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_i64]*6
+                          + [ctypes.c_int32]*3 + [_c_ptr]),
+    'brv_batchnorm2d_forward_bf16io': (ctypes.c_int, [_c_ptr]*9 + [_c_i64]*3
+                                       + [_c_f32, _c_f32, ctypes.c_int, _c_ptr]),
+    'brv_batchnorm2d_backward_bf16io': (ctypes.c_int, [_c_ptr]*12 + [_c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_batchnorm2d_forward_bf16': (ctypes.c_int, [_c_ptr]*9 + [_c_i64]*3
                                      + [_c_f32, _c_f32, ctypes.c_int, _c_ptr]),
     'brv_batchnorm2d_backward_bf16': (ctypes.c_int, [_c_ptr]*12 + [_c_i64, _c_i64, _c_i64, _c_ptr]),

@@ -606,6 +606,10 @@ class _BatchNormActFunction(torch.autograd.Function):
 # so the products are bit-identical; what changes is the bytes: the convolutions and their weight gradients are bound
 # by what a CU takes in per cycle (DESIGN.md 5b "Round 6, DCCRN"). BRV_DCCRN_BF16_ACT=0: fp32 tensors, round-5 path.
 _BF16_ACT = os.environ.get('BRV_DCCRN_BF16_ACT', '1') != '0'
+# ... and so does the convolution output of a block whose batch norm writes bf16 (every block with a norm but the first
+# and the last encoder block): what torch.autocast makes of a convolution in the reference; a rounding point the fp32-
+# output form does not have -- oracle/dccrn.py emulates it (ComplexWrapper.round_output). BRV_DCCRN_BF16_Y=0: fp32.
+_BF16_Y = os.environ.get('BRV_DCCRN_BF16_Y', '1') != '0'
 
 
 def _token(shape, device):
@@ -668,11 +672,11 @@ class _BlockFunction(torch.autograd.Function):
         bwd = ((Cin2, 2*Cout, 2*Cw, khw) if transpose else (Cin2, 2*Cout, khw, 2*Cw)) if need_dx else None
         wc, bias, wp_fwd, ctx.wp_bwd = _pack_complex_layer(wr, wi, br, bi, -1.0 if transpose else 1.0, fwd, bwd)
         Ho, Wo = (2*H, W + 1) if transpose else (H//2, W - 1)
-        y = torch.empty(B, 2*Cout, Ho, Wo, dtype=torch.float32, device=dev)
-        rows = lib.brv_cconv_rows if first else lib.brv_cconv_rows_bf16
-        hip.check(rows(hip.ptr(x16), hip.ptr(skip16), seg, hip.ptr(wp_fwd), hip.ptr(bias),
-                       hip.ptr(y), None, 0, B, Cin2, 2*Cout, H, W, int(transpose), hip.stream()),
-                  'brv_cconv_rows' if first else 'brv_cconv_rows_bf16')
+        y16 = ctx.y16 = bool(_BF16_Y and norm is not None and out_bf16 and not first)
+        y = torch.empty(B, 2*Cout, Ho, Wo, dtype=torch.bfloat16 if y16 else torch.float32, device=dev)
+        hip.check(lib.brv_cconv_rows_ex(hip.ptr(x16), hip.ptr(skip16), seg, hip.ptr(wp_fwd), hip.ptr(bias),
+                                        hip.ptr(y), None, 0, B, Cin2, 2*Cout, H, W, int(transpose), int(not first),
+                                        int(y16), hip.stream()), 'brv_cconv_rows_ex')
         ctx.cfg = (geom4, transpose, (H, W), (Ho, Wo), Cin2, Cout, R, Cw, wr.shape, seg, two)
         ctx.has_norm = norm is not None
         ctx.training = training
@@ -688,7 +692,8 @@ class _BlockFunction(torch.autograd.Function):
                 int(training), hip.stream())
         if out_bf16:
             a16 = _bf16_empty((B, 2*Cout, Ho, Wo), dev)
-            hip.check(lib.brv_batchnorm2d_forward_bf16(*args, hip.ptr(a16), *tail), 'brv_batchnorm2d_forward_bf16')
+            fwd_fn = lib.brv_batchnorm2d_forward_bf16io if y16 else lib.brv_batchnorm2d_forward_bf16
+            hip.check(fwd_fn(*args, hip.ptr(a16), *tail), 'brv_batchnorm2d_forward_bf16[io]')
             out = (_token(y.shape, dev), a16)
             ctx.mark_non_differentiable(a16)
         else:
@@ -733,9 +738,9 @@ class _BlockFunction(torch.autograd.Function):
             else:
                 dy = None
                 dy16 = _bf16_empty(y.shape, dev)
-                hip.check(lib.brv_batchnorm2d_backward_bf16(*args, hip.ptr(dy16), hip.ptr(dgamma), hip.ptr(dbeta),
-                                                            hip.ptr(dsl), hip.ptr(sums), B, 2*Cout, Ho*Wo,
-                                                            hip.stream()), 'brv_batchnorm2d_backward_bf16')
+                bwd_fn = lib.brv_batchnorm2d_backward_bf16io if ctx.y16 else lib.brv_batchnorm2d_backward_bf16
+                hip.check(bwd_fn(*args, hip.ptr(dy16), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl), hip.ptr(sums),
+                                 B, 2*Cout, Ho*Wo, hip.stream()), 'brv_batchnorm2d_backward_bf16[io]')
             if ctx.has_slope:
                 dslope = torch.empty(1, dtype=torch.float32, device=dev)
                 hip.check(lib.brv_row_sum(hip.ptr(dsl), hip.ptr(dslope), 1, 1, 2*Cout, hip.stream()), 'brv_row_sum')

@@ -391,6 +391,12 @@ int brv_cconv_rows_bf16(const void* in, const void* in2, int64_t in_seg, const v
                         int32_t transposed, brv_stream_t stream);
 int brv_cconv_wgrad_bf16(const void* small, const void* small2, const void* big, float* out, void* workspace,
                          int64_t B, int64_t A, int64_t C, int64_t Hs, int64_t Ws, int64_t seg, brv_stream_t stream);
+/* brv_cconv_rows / brv_cconv_rows_bf16 with the element types as arguments: in_bf16 selects the image type (0: fp32,
+ * 1: bf16 -- with the readable-slack contract above), out_bf16 the type out / out2 are written in (1: rounded to bf16:
+ * what torch.autocast makes of a convolution output; read by brv_batchnorm2d_forward_bf16io / _backward_bf16io). */
+int brv_cconv_rows_ex(const void* in, const void* in2, int64_t in_seg, const void* wp, const float* bias, void* out,
+                      void* out2, int64_t out_seg, int64_t B, int64_t C, int64_t M, int64_t Hin, int64_t Win,
+                      int32_t transposed, int32_t in_bf16, int32_t out_bf16, brv_stream_t stream);
 /* brv_gemm_bf16 with bf16 tensors in memory: flags bit 0: b holds bf16 elements, bit 2: a does, bit 1:
  * d is written as bf16 (no accumulate, no split reduction); strides count elements. Used with
  * brv_im2col_bf16 / brv_col2im_bf16 (same arguments as brv_im2col / brv_col2im, the column matrix
@@ -517,6 +523,18 @@ int brv_batchnorm2d_backward_bf16(const float* x, const float* dy, const float* 
                                   const float* prelu_slope, void* dx16, float* dgamma, float* dbeta,
                                   float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
                                   brv_stream_t stream);
+/* ... and with the norm's INPUT x stored as bf16 too (the convolution output as brv_cconv_rows_ex(out_bf16 = 1) writes
+ * it): the same arithmetic on the widened values. */
+int brv_batchnorm2d_forward_bf16io(const void* x16, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, const float* prelu_slope,
+                                   void* y16, float* save_mean, float* save_invstd, int64_t B, int64_t C,
+                                   int64_t HW, float eps, float momentum, int training,
+                                   brv_stream_t stream);
+int brv_batchnorm2d_backward_bf16io(const void* x16, const float* dy, const float* save_mean,
+                                    const float* save_invstd, const float* gamma, const float* beta,
+                                    const float* prelu_slope, void* dx16, float* dgamma, float* dbeta,
+                                    float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
+                                    brv_stream_t stream);
 int brv_lstm_recurrent_backward(const float* act, const float* cs, const float* w_hh,
                                 const float* dy, float* dgates, int64_t B, int64_t T, int64_t H,
                                 int64_t groups, brv_stream_t stream);

@@ -68,6 +68,8 @@ _qf, _qb = _RoundForward.apply, _RoundBackward.apply
 
 class ComplexWrapper(nn.Module):                                   # dccrn.py:221-231
     emulate_bf16 = False
+    round_output = False        # emulation: the product + bias is stored as bf16 (round 6: the blocks whose batch norm reads
+                                # a bf16 convolution output on the HIP path -- what torch.autocast makes of a convolution)
 
     def __init__(self, module_cls, *args, **kwargs):
         super().__init__()
@@ -88,7 +90,7 @@ class ComplexWrapper(nn.Module):                                   # dccrn.py:22
                 return F.conv2d(t, w, None, mr.stride, mr.padding)
         prod = _qb(torch.cat([f(xr, wr) - f(xi, wi), f(xi, wr) + f(xr, wi)], dim=1))
         bias = torch.cat([mr.bias - mi.bias, mr.bias + mi.bias]).view(1, -1, 1, 1)
-        return prod + bias
+        return _qf(prod + bias) if self.round_output else prod + bias
 
     def forward(self, x):
         if self.emulate_bf16:
@@ -287,6 +289,14 @@ class OracleDCCRN(nn.Module):
         for m in self.modules():
             if isinstance(m, ComplexWrapper):
                 m.emulate_bf16 = self.emulate_bf16
+        # the HIP path (brever_amd/models/dccrn.py: _BlockFunction) stores the convolution output of a block as bf16 where
+        # the block's batch norm writes bf16 too: every block with a norm but the first encoder block (its fp32 output
+        # feeds the column-matrix weight gradient) and the last encoder block (fp32 for the recurrent block)
+        enc, dec = self.mask_net.encoder, self.mask_net.decoder
+        for k, blk in enumerate(enc):
+            blk.conv.round_output = bool(self.emulate_bf16) and 0 < k < len(enc) - 1
+        for blk in dec:
+            blk.conv.round_output = bool(self.emulate_bf16) and getattr(blk, 'norm', None) is not None
         length = x.shape[-1]
         x = _stft(x, self.n, self.hop)[..., 1:, :]
         x = torch.stack([x.real, x.imag], dim=1)

@@ -339,7 +339,9 @@ def test_bf16_activations_between_the_blocks_change_no_product(channels):
     batch = 0.1*torch.randn(2, 2, n, generator=torch.Generator().manual_seed(4)).to(dev)
     lengths = torch.tensor([n, n - 3000], device=dev)
     out = []
+    y16 = D._BF16_Y
     try:
+        D._BF16_Y = False           # (the bf16 convolution OUTPUT is a rounding point of its own: tested against the oracle)
         for lowp in (False, False, True):
             D._BF16_ACT = lowp
             torch.manual_seed(3)
@@ -353,6 +355,7 @@ def test_bf16_activations_between_the_blocks_change_no_product(channels):
                         {k: b.detach().clone() for k, b in model.named_buffers()}))
     finally:
         D._BF16_ACT = True
+        D._BF16_Y = y16
     ref, again, new = out
 
     def dist(a, b):
@@ -374,3 +377,71 @@ def test_bf16_activations_between_the_blocks_change_no_product(channels):
     d_new = sum(dist(new[1][k], ref[1][k])**2 for k in ref[1])**0.5
     d_again = sum(dist(again[1][k], ref[1][k])**2 for k in ref[1])**0.5
     assert d_new <= 3*d_again + 5e-3*tot, (d_new, d_again, tot)
+
+
+@pytest.mark.parametrize('case', [(2, 32, 64, 8, 129, 0), (2, 64, 128, 8, 300, 1), (1, 128, 256, 4, 257, 0),
+                                  (16, 24, 256, 8, 131, 1), (2, 2, 32, 16, 37, 0)],
+                         ids=lambda c: 'B%d_C%d_M%d_H%d_W%d_t%d' % c)
+def test_rows_convolution_with_bf16_output(case):
+    """brv_cconv_rows_ex(out_bf16 = 1): the fp32 output rounded to bf16, for fp32 and bf16 images, one and two targets."""
+    from brever_amd import hip
+    lib = hip.lib()
+    dev = _cuda()
+    B, C, M, H, W, transposed = case
+    g = torch.Generator().manual_seed(sum(case))
+    x16 = _as_bf16(torch.randn(B, C, H, W, generator=g).to(dev))
+    wc = (torch.randn(M, C*10, generator=g)/(C*10)**0.5).to(dev)
+    bias = torch.randn(M, generator=g).to(dev)
+    wp = torch.empty(lib.brv_cconv_packed_bytes(M, C), dtype=torch.uint8, device=dev)
+    hip.check(lib.brv_cconv_pack(hip.ptr(wc), hip.ptr(wp), M, C, C*10, 10, hip.stream()), 'brv_cconv_pack')
+    shape = (B, M) + ((2*H, W + 1) if transposed else (H//2, W - 1))
+    for split in (False, True):
+        if split and M % 4:
+            continue
+        oshape = (B, M//2) + shape[2:] if split else shape
+        for in_bf16 in (0, 1):
+            xin = x16 if in_bf16 else x16.float()
+            outs = {}
+            for ob in (0, 1):
+                o1 = torch.empty(oshape, dtype=torch.bfloat16 if ob else torch.float32, device=dev)
+                o2 = torch.empty_like(o1) if split else None
+                hip.check(lib.brv_cconv_rows_ex(hip.ptr(xin), None, 0, hip.ptr(wp), hip.ptr(bias), hip.ptr(o1), hip.ptr(o2),
+                                                M//4 if split else 0, B, C, M, H, W, transposed, in_bf16, ob, hip.stream()),
+                          'brv_cconv_rows_ex')
+                outs[ob] = (o1, o2)
+            assert torch.equal(outs[0][0].to(torch.bfloat16), outs[1][0])
+            if split:
+                assert torch.equal(outs[0][1].to(torch.bfloat16), outs[1][1])
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 8, 10), (3, 16, 4, 125)], ids=lambda c: 'B%d_C%d_H%d_W%d' % c)
+def test_batch_norm_passes_with_bf16_input_and_output(shape):
+    """brv_batchnorm2d_forward_bf16io / _backward_bf16io on a bf16 x: the bf16-output passes on the widened values."""
+    from brever_amd import hip
+    lib = hip.lib()
+    dev = _cuda()
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x16 = torch.randn(B, C, H, W, generator=g).to(dev).to(torch.bfloat16)
+    dy = torch.randn(B, C, H, W, generator=g).to(dev)
+    gamma = (1 + 0.1*torch.randn(C, generator=g)).to(dev)
+    beta = (0.1*torch.randn(C, generator=g)).to(dev)
+    slope = torch.tensor([0.25], device=dev)
+    outs = {}
+    for io in (False, True):
+        x = x16 if io else x16.float()
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        y = torch.empty(B, C, H, W, dtype=torch.bfloat16, device=dev)
+        fwd = lib.brv_batchnorm2d_forward_bf16io if io else lib.brv_batchnorm2d_forward_bf16
+        hip.check(fwd(hip.ptr(x), hip.ptr(gamma), hip.ptr(beta), hip.ptr(rm), hip.ptr(rv), hip.ptr(slope), hip.ptr(y),
+                      hip.ptr(mean), hip.ptr(invstd), B, C, H*W, 1e-5, 0.1, 1, hip.stream()), 'bn forward')
+        dx = torch.empty_like(y)
+        dgamma, dbeta, dsl, sums = (torch.empty(C, device=dev) for _ in range(4))
+        bwd = lib.brv_batchnorm2d_backward_bf16io if io else lib.brv_batchnorm2d_backward_bf16
+        hip.check(bwd(hip.ptr(x), hip.ptr(dy), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(slope),
+                      hip.ptr(dx), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl), hip.ptr(sums), B, C, H*W, hip.stream()),
+                  'bn backward')
+        outs[io] = (y, dx, mean, invstd, rm, rv, dgamma, dbeta, dsl, sums)
+    for k in range(10):
+        assert torch.equal(outs[False][k], outs[True][k]), k
