@@ -610,6 +610,8 @@ _BF16_ACT = os.environ.get('BRV_DCCRN_BF16_ACT', '1') != '0'
 # and the last encoder block): what torch.autocast makes of a convolution in the reference; a rounding point the fp32-
 # output form does not have -- oracle/dccrn.py emulates it (ComplexWrapper.round_output). BRV_DCCRN_BF16_Y=0: fp32.
 _BF16_Y = os.environ.get('BRV_DCCRN_BF16_Y', '1') != '0'
+# use_amp: the output projections of the recurrent block on the bf16 MFMA (BRV_DCCRN_LINEAR_LOWP=0: exact-fp32 products)
+_LINEAR_LOWP = os.environ.get('BRV_DCCRN_LINEAR_LOWP', '1') != '0'
 
 
 def _token(shape, device):
@@ -996,6 +998,38 @@ class _LSTMFunction(torch.autograd.Function):
         return dx, dw_ih, dw_hh, db, db.clone()
 
 
+class _LinearLowpFunction(torch.autograd.Function):
+    """``ffnn._LinearFunction`` (nn.Linear on the feature axis of (B, features, frames): LSTMBlock.linear_r / linear_i,
+    dccrn.py:293-311) with the three products on bf16-rounded operands, fp32 accumulation: what torch.autocast makes of
+    nn.Linear; ``use_amp`` only (oracle/dccrn.py: _LSTMBlock._linear emulates it)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, I, T = x.shape
+        O = weight.shape[0]
+        x = x.contiguous()
+        y = torch.empty(B, O, T, dtype=torch.float32, device=x.device)
+        _gemm(weight, x, y, B, O, T, I, I, T, T, 0, I*T, O*T, bias=bias, lowp=True)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, I, T = x.shape
+        O = weight.shape[0]
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)                       # W^T (I, O) @ dy[b] (O, T)
+            _gemm(weight, dy, dx, B, I, T, O, I, T, T, 0, O*T, I*T, trans_a=1, lowp=True)
+        dw = torch.empty_like(weight)                      # sum_b dy[b] (O, T) @ x[b]^T (T, I)
+        _gemm(dy, x, dw, 1, O, I, T, T, T, I, 0, 0, 0, trans_b=1, kbatch=B, a_kbs=O*T, b_kbs=I*T, lowp=True)
+        db = torch.empty(O, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().brv_row_sum(hip.ptr(dy), hip.ptr(db), B, O, T, hip.stream()), 'brv_row_sum')
+        return dx, dw, db
+
+
 class _ApplyMaskFunction(torch.autograd.Function):
     """DCCRN.apply_mask (dccrn.py:96-109): x, mask (B, 2, Fq, T) -> complex (B, 1, Fq, T)."""
 
@@ -1094,10 +1128,9 @@ class DCCRN(BreverBaseModel):
             real, imag = _CombineFunction.apply(rr, ii, -1.0), _CombineFunction.apply(ri, ir, 1.0)
         # Linear applied on the feature axis of (B, features, T): the output is already in the
         # (channels*freqs, frames) layout of the decoder input
-        out_r = _LinearFunction.apply(real.transpose(1, 2).contiguous(), blk.linear_r.weight,
-                                      blk.linear_r.bias)
-        out_i = _LinearFunction.apply(imag.transpose(1, 2).contiguous(), blk.linear_i.weight,
-                                      blk.linear_i.bias)
+        linear = _LinearLowpFunction if (_AMP['on'] and _LINEAR_LOWP) else _LinearFunction
+        out_r = linear.apply(real.transpose(1, 2).contiguous(), blk.linear_r.weight, blk.linear_r.bias)
+        out_i = linear.apply(imag.transpose(1, 2).contiguous(), blk.linear_i.weight, blk.linear_i.bias)
         return torch.cat([out_r, out_i], dim=1).view(B, C2, Fq, T)
 
     def _blocks_ok(self, x):

@@ -220,11 +220,19 @@ class _LSTMBlock(nn.Module):                                       # dccrn.py:29
         self.linear_r = nn.Linear(hidden_size, input_size)
         self.linear_i = nn.Linear(hidden_size, input_size)
 
+    emulate_bf16 = False        # the two output projections on bf16-rounded operands (round 6: the HIP path runs them on
+                                # the bf16 MFMA under use_amp, as torch.autocast runs nn.Linear)
+
+    def _linear(self, m, x):
+        if not self.emulate_bf16:
+            return m(x)
+        return _qb(_qf(x) @ _qf(m.weight).t()) + m.bias
+
     def forward(self, x):
         real, imag = torch.chunk(x, 2, dim=-1)
         for layer in self.lstm.layers:
             real, imag = layer(real, imag)
-        return torch.cat([self.linear_r(real), self.linear_i(imag)], dim=-1)
+        return torch.cat([self._linear(self.linear_r, real), self._linear(self.linear_i, imag)], dim=-1)
 
 
 class _MaskNet(nn.Module):                                         # dccrn.py:145-218
@@ -292,6 +300,7 @@ class OracleDCCRN(nn.Module):
         # the HIP path (brever_amd/models/dccrn.py: _BlockFunction) stores the convolution output of a block as bf16 where
         # the block's batch norm writes bf16 too: every block with a norm but the first encoder block (its fp32 output
         # feeds the column-matrix weight gradient) and the last encoder block (fp32 for the recurrent block)
+        self.mask_net.lstm.emulate_bf16 = bool(self.emulate_bf16)
         enc, dec = self.mask_net.encoder, self.mask_net.decoder
         for k, blk in enumerate(enc):
             blk.conv.round_output = bool(self.emulate_bf16) and 0 < k < len(enc) - 1
