@@ -612,6 +612,7 @@ _BF16_ACT = os.environ.get('BRV_DCCRN_BF16_ACT', '1') != '0'
 _BF16_Y = os.environ.get('BRV_DCCRN_BF16_Y', '1') != '0'
 # use_amp: the output projections of the recurrent block on the bf16 MFMA (BRV_DCCRN_LINEAR_LOWP=0: exact-fp32 products)
 _LINEAR_LOWP = os.environ.get('BRV_DCCRN_LINEAR_LOWP', '1') != '0'
+_TWO_TOKENS = os.environ.get('BRV_DCCRN_TWO_TOKENS', '1') != '0'     # (0: the two gradients of an encoder output summed by a pass)
 
 
 def _token(shape, device):
@@ -647,7 +648,10 @@ class _BlockFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x16, skip, skip16, wr, br, wi, bi, gamma, beta, slope, norm, training, geom4, transpose,
-                out_bf16):
+                out_bf16, two_out=False):
+        """``two_out``: a second token for the block's second consumer (an encoder output feeds the next block AND the
+        decoder's skip input, dccrn.py:205-217): the two gradients arrive separately and the norm's backward pass adds
+        them on the fly (``brv_batchnorm2d_backward_ex``: no pass that sums them)."""
         lib = hip.lib()
         (kh, kw) = geom4[0]
         khw = kh*kw
@@ -696,7 +700,7 @@ class _BlockFunction(torch.autograd.Function):
             a16 = _bf16_empty((B, 2*Cout, Ho, Wo), dev)
             fwd_fn = lib.brv_batchnorm2d_forward_bf16io if y16 else lib.brv_batchnorm2d_forward_bf16
             hip.check(fwd_fn(*args, hip.ptr(a16), *tail), 'brv_batchnorm2d_forward_bf16[io]')
-            out = (_token(y.shape, dev), a16)
+            out = (_token(y.shape, dev), a16) + ((_token(y.shape, dev),) if two_out else ())
             ctx.mark_non_differentiable(a16)
         else:
             a = torch.empty_like(y)
@@ -710,8 +714,10 @@ class _BlockFunction(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, g, _g16=None):
+    def backward(ctx, g, _g16=None, g2=None):
         lib = hip.lib()
+        if g is None:
+            g, g2 = g2, None
         geom4, transpose, (H, W), (Ho, Wo), Cin2, Cout, R, Cw, wshape, seg, two = ctx.cfg
         saved = list(ctx.saved_tensors)
         x16, wc = saved[:2]
@@ -720,6 +726,7 @@ class _BlockFunction(torch.autograd.Function):
         khw = geom4[0][0]*geom4[0][1]
         dev = g.device
         g = g.contiguous()
+        g2 = g2.contiguous() if g2 is not None else None
         B = x16.shape[0]
         small_cin = ctx.x_f32 is not None
         dgamma = dbeta = dslope = None
@@ -730,19 +737,13 @@ class _BlockFunction(torch.autograd.Function):
             y, gamma, beta, mean, invstd = rest[:5]
             slope = rest[5] if ctx.has_slope else None
             dgamma, dbeta, dsl = (torch.empty(2*Cout, dtype=torch.float32, device=dev) for _ in range(3))
-            args = (hip.ptr(y), hip.ptr(g), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta),
-                    hip.ptr(slope))
-            if small_cin:
-                dy = torch.empty_like(y)
-                hip.check(lib.brv_batchnorm2d_backward(*args, hip.ptr(dy), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl),
-                                                       B, 2*Cout, Ho*Wo, hip.stream()), 'brv_batchnorm2d_backward')
-                dy16 = None
-            else:
-                dy = None
-                dy16 = _bf16_empty(y.shape, dev)
-                bwd_fn = lib.brv_batchnorm2d_backward_bf16io if ctx.y16 else lib.brv_batchnorm2d_backward_bf16
-                hip.check(bwd_fn(*args, hip.ptr(dy16), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl), hip.ptr(sums),
-                                 B, 2*Cout, Ho*Wo, hip.stream()), 'brv_batchnorm2d_backward_bf16[io]')
+            dy = torch.empty_like(y) if small_cin else None
+            dy16 = None if small_cin else _bf16_empty(y.shape, dev)
+            hip.check(lib.brv_batchnorm2d_backward_ex(
+                hip.ptr(y), int(ctx.y16), hip.ptr(g), hip.ptr(g2), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma),
+                hip.ptr(beta), hip.ptr(slope), hip.ptr(dy if small_cin else dy16), int(not small_cin), hip.ptr(dgamma),
+                hip.ptr(dbeta), hip.ptr(dsl), None if small_cin else hip.ptr(sums), B, 2*Cout, Ho*Wo, hip.stream()),
+                'brv_batchnorm2d_backward_ex')
             if ctx.has_slope:
                 dslope = torch.empty(1, dtype=torch.float32, device=dev)
                 hip.check(lib.brv_row_sum(hip.ptr(dsl), hip.ptr(dslope), 1, 1, 2*Cout, hip.stream()), 'brv_row_sum')
@@ -800,7 +801,7 @@ class _BlockFunction(torch.autograd.Function):
             if not _side['pending'].get(dev.index):
                 _side['pending'][dev.index] = True
                 torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev))
-        return (dx, None, dskip, None, dwr, dbr, dwi, dbi, dgamma, dbeta, dslope, None, None, None, None, None)
+        return (dx, None, dskip, None, dwr, dbr, dwi, dbi, dgamma, dbeta, dslope, None, None, None, None, None, None)
 
 
 class _CplxMomentsFunction(torch.autograd.Function):
@@ -1152,14 +1153,14 @@ class DCCRN(BreverBaseModel):
                 return False
         return net.decoder[-1].norm is None       # (the mask leaves the network as fp32 data)
 
-    def _block(self, x, x16, skip, skip16, blk, transpose, out_bf16):
+    def _block(self, x, x16, skip, skip16, blk, transpose, out_bf16, two_out=False):
         mr, mi = blk.conv.module_real, blk.conv.module_imag
         norm, act = blk.norm, blk.activation
         training = norm is not None and norm.training and norm.track_running_stats
         return _BlockFunction.apply(x, x16, skip, skip16, mr.weight, mr.bias, mi.weight, mi.bias,
                                     norm.weight if norm is not None else None, norm.bias if norm is not None else None,
                                     act.weight if act is not None else None, norm, training, self.mask_net.geom,
-                                    transpose, out_bf16)
+                                    transpose, out_bf16, two_out)
 
     def _mask_net_blocks(self, x):
         """``_mask_net`` with bf16 activations between the blocks: every block returns (token, data) -- ``_token``."""
@@ -1169,11 +1170,13 @@ class DCCRN(BreverBaseModel):
         tok, a16 = x, None
         skips = []
         for k, blk in enumerate(net.encoder):
-            # (the last encoder output feeds the recurrent block: fp32)
-            tok, a16 = self._block(tok, a16, None, None, blk, False, k + 1 < len(net.encoder))
-            s_tok = tok
-            if tok.requires_grad:
-                tok, s_tok = _ForkFunction.apply(tok)
+            if k + 1 < len(net.encoder) and _TWO_TOKENS:     # bf16 output, one token per consumer (next block, decoder's skip input)
+                tok, a16, s_tok = self._block(tok, a16, None, None, blk, False, True, two_out=True)
+            else:                            # the last encoder output feeds the recurrent block: fp32 data, forked
+                tok, a16 = self._block(tok, a16, None, None, blk, False, k + 1 < len(net.encoder))
+                s_tok = tok
+                if tok.requires_grad:
+                    tok, s_tok = _ForkFunction.apply(tok)
             skips.append((s_tok, a16))
         tok, a16 = self._lstm_block(tok), None
         for blk, (s_tok, s16) in zip(net.decoder, reversed(skips)):

@@ -443,5 +443,41 @@ def test_batch_norm_passes_with_bf16_input_and_output(shape):
                       hip.ptr(dx), hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl), hip.ptr(sums), B, C, H*W, hip.stream()),
                   'bn backward')
         outs[io] = (y, dx, mean, invstd, rm, rv, dgamma, dbeta, dsl, sums)
-    for k in range(10):
+    for k in range(6):
         assert torch.equal(outs[False][k], outs[True][k]), k
+    for k in range(6, 10):      # (reductions: the two instantiations may contract their multiply-adds differently)
+        a, b = outs[False][k].double(), outs[True][k].double()
+        assert float((a - b).abs().max()) <= 1e-5*float(b.abs().max()) + 1e-6, k
+
+
+@pytest.mark.parametrize('types', [(0, 0), (0, 1), (1, 1)], ids=['f32_f32', 'f32_bf16', 'bf16_bf16'])
+def test_batch_norm_backward_adds_a_second_gradient_on_the_fly(types):
+    """brv_batchnorm2d_backward_ex(dy, dy2) == the same pass on dy + dy2 (an encoder block's two consumers)."""
+    from brever_amd import hip
+    lib = hip.lib()
+    dev = _cuda()
+    x_bf16, dx_bf16 = types
+    B, C, H, W = 3, 16, 4, 125
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    x = x.to(torch.bfloat16) if x_bf16 else x
+    dy, dy2 = torch.randn(B, C, H, W, generator=g).to(dev), torch.randn(B, C, H, W, generator=g).to(dev)
+    gamma = (1 + 0.1*torch.randn(C, generator=g)).to(dev)
+    beta = (0.1*torch.randn(C, generator=g)).to(dev)
+    slope = torch.tensor([0.25], device=dev)
+    xf = x.float()
+    mean = xf.mean(dim=(0, 2, 3)).contiguous()
+    invstd = (xf.var(dim=(0, 2, 3), unbiased=False) + 1e-5).rsqrt().contiguous()
+    outs = []
+    for a, b in ((dy + dy2, None), (dy, dy2)):
+        dx = torch.empty(B, C, H, W, dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=dev)
+        dgamma, dbeta, dsl, sums = (torch.empty(C, device=dev) for _ in range(4))
+        hip.check(lib.brv_batchnorm2d_backward_ex(hip.ptr(x), x_bf16, hip.ptr(a), hip.ptr(b), hip.ptr(mean), hip.ptr(invstd),
+                                                  hip.ptr(gamma), hip.ptr(beta), hip.ptr(slope), hip.ptr(dx), dx_bf16,
+                                                  hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl), hip.ptr(sums), B, C, H*W,
+                                                  hip.stream()), 'brv_batchnorm2d_backward_ex')
+        outs.append((dx, dgamma, dbeta, dsl, sums))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in range(1, 5):
+        a, b = outs[0][k].double(), outs[1][k].double()
+        assert float((a - b).abs().max()) <= 1e-5*float(b.abs().max()) + 1e-6, k
