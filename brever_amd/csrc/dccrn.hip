@@ -918,6 +918,26 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* a, const floa
   GRID_STRIDE(i, n) out[i] = a[i] + sign*b[i];
 }
 
+// The complex combination behind a ComplexLSTM layer (dccrn.py:330-358): o = (2 modules, 2 halves, n) holds module m on
+// input half h at o[m][h]; real = real(real) - imag(imag) = o[0][0] - o[1][1], imag = real(imag) + imag(real) =
+// o[0][1] + o[1][0]. One launch each way instead of two selects, two chunks and two combines (and, backwards, their
+// zero-filled select gradients, two concatenations, two scalings and an accumulation).
+__global__ __launch_bounds__(256) void complex_mix_fwd_kernel(const float4* o, float4* real, float4* imag, long long n4) {
+  GRID_STRIDE(i, n4) {
+    const float4 rr = o[i], ri = o[n4 + i], ir = o[2*n4 + i], ii = o[3*n4 + i];
+    real[i] = make_float4(rr.x - ii.x, rr.y - ii.y, rr.z - ii.z, rr.w - ii.w);
+    imag[i] = make_float4(ri.x + ir.x, ri.y + ir.y, ri.z + ir.z, ri.w + ir.w);
+  }
+}
+__global__ __launch_bounds__(256) void complex_mix_bwd_kernel(const float4* greal, const float4* gimag, float4* dout,
+                                                              long long n4) {
+  GRID_STRIDE(i, n4) {
+    const float4 a = greal[i], b = gimag[i];
+    dout[i] = a; dout[n4 + i] = b; dout[2*n4 + i] = b;
+    dout[3*n4 + i] = make_float4(-a.x, -a.y, -a.z, -a.w);
+  }
+}
+
 // DCCRN.apply_mask (dccrn.py:96-109): polar product with a tanh-bounded mask magnitude
 __global__ __launch_bounds__(256) void dccrn_mask_kernel(const float* xr, const float* xi,
                                                          const float* mr, const float* mi,
@@ -1511,6 +1531,24 @@ int brv_combine(const float* a, const float* b, float* out, int64_t n, float sig
   if (n < 1) return -1;
   hipLaunchKernelGGL(combine_kernel, flat_grid(n), dim3(256), 0, (hipStream_t)stream, a, b, out,
                      (long long)n, sign);
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_complex_mix_forward(const float* o, float* real, float* imag, int64_t n, brv_stream_t stream) {
+  if (!o || !real || !imag || n < 4 || (n & 3) ||
+      ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(real) | reinterpret_cast<uintptr_t>(imag)) & 15)) return -1;
+  hipLaunchKernelGGL(complex_mix_fwd_kernel, flat_grid(n/4), dim3(256), 0, (hipStream_t)stream, (const float4*)o,
+                     (float4*)real, (float4*)imag, (long long)(n/4));
+  DC_OK(hipGetLastError());
+  return 0;
+}
+
+int brv_complex_mix_backward(const float* greal, const float* gimag, float* dout, int64_t n, brv_stream_t stream) {
+  if (!greal || !gimag || !dout || n < 4 || (n & 3) ||
+      ((reinterpret_cast<uintptr_t>(greal) | reinterpret_cast<uintptr_t>(gimag) | reinterpret_cast<uintptr_t>(dout)) & 15)) return -1;
+  hipLaunchKernelGGL(complex_mix_bwd_kernel, flat_grid(n/4), dim3(256), 0, (hipStream_t)stream, (const float4*)greal,
+                     (const float4*)gimag, (float4*)dout, (long long)(n/4));
   DC_OK(hipGetLastError());
   return 0;
 }

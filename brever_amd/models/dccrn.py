@@ -526,6 +526,31 @@ class _CombineFunction(torch.autograd.Function):
         return g, ctx.sign*g if ctx.sign != 1.0 else g, None
 
 
+class _ComplexMixFunction(torch.autograd.Function):
+    """(2 modules, 2 B, T, H) outputs of the two single-layer LSTMs of a ComplexLSTM layer on [real; imag] ->
+    (real, imag) = (real(real) - imag(imag), real(imag) + imag(real)) (dccrn.py:330-358): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, out):
+        out = out.contiguous()
+        G, B2, T, H = out.shape
+        assert G == 2 and B2 % 2 == 0
+        real = torch.empty(B2//2, T, H, dtype=torch.float32, device=out.device)
+        imag = torch.empty_like(real)
+        hip.check(hip.lib().brv_complex_mix_forward(hip.ptr(out), hip.ptr(real), hip.ptr(imag), real.numel(),
+                                                    hip.stream()), 'brv_complex_mix_forward')
+        ctx.shape = out.shape
+        return real, imag
+
+    @staticmethod
+    def backward(ctx, greal, gimag):
+        greal, gimag = greal.contiguous(), gimag.contiguous()
+        dout = torch.empty(ctx.shape, dtype=torch.float32, device=greal.device)
+        hip.check(hip.lib().brv_complex_mix_backward(hip.ptr(greal), hip.ptr(gimag), hip.ptr(dout), greal.numel(),
+                                                     hip.stream()), 'brv_complex_mix_backward')
+        return dout
+
+
 class _ForkFunction(torch.autograd.Function):
     """One tensor, two consumers (an encoder output feeds the next block AND the decoder's skip input,
     dccrn.py:205-217): the two gradients are summed by ``brv_combine`` instead of the autograd engine's
@@ -656,6 +681,9 @@ class _BlockFunction(torch.autograd.Function):
         (kh, kw) = geom4[0]
         khw = kh*kw
         dev = x.device
+        # (the engine would hand backward a dense tensor of zeros for every output without a gradient -- the bf16 data
+        # output of each block, 131 MB at the first levels: 0.27 ms of fills per step)
+        ctx.set_materialize_grads(False)
         ctx.side_ok = _side_allowed((wr, br, wi, bi))
         B, C2, H, W = x.shape
         ctx.x_f32 = None
@@ -718,6 +746,8 @@ class _BlockFunction(torch.autograd.Function):
         lib = hip.lib()
         if g is None:
             g, g2 = g2, None
+        if g is None:                       # nothing downstream asked for a gradient
+            return (None,)*17
         geom4, transpose, (H, W), (Ho, Wo), Cin2, Cout, R, Cw, wshape, seg, two = ctx.cfg
         saved = list(ctx.saved_tensors)
         x16, wc = saved[:2]
@@ -1125,8 +1155,11 @@ class DCCRN(BreverBaseModel):
             # each module sees both halves; both modules run in one set of launches (4B chains)
             # (round 5: ONE concatenation [real; imag] shared by both modules instead of two concatenations and a stack)
             out = self._lstm((layer.module_real, layer.module_imag), torch.cat([real, imag], dim=0).unsqueeze(0))
-            (rr, ri), (ir, ii) = out[0].chunk(2, dim=0), out[1].chunk(2, dim=0)
-            real, imag = _CombineFunction.apply(rr, ii, -1.0), _CombineFunction.apply(ri, ir, 1.0)
+            if out.is_cuda and out.numel() % 16 == 0:          # (each of the four parts in whole 16-byte pieces)
+                real, imag = _ComplexMixFunction.apply(out)
+            else:
+                (rr, ri), (ir, ii) = out[0].chunk(2, dim=0), out[1].chunk(2, dim=0)
+                real, imag = _CombineFunction.apply(rr, ii, -1.0), _CombineFunction.apply(ri, ir, 1.0)
         # Linear applied on the feature axis of (B, features, T): the output is already in the
         # (channels*freqs, frames) layout of the decoder input
         linear = _LinearLowpFunction if (_AMP['on'] and _LINEAR_LOWP) else _LinearFunction

@@ -569,6 +569,11 @@ int brv_dccrn_apply_mask_backward_batched(const float* x, const float* mask, con
 int brv_istft_env_divide(const float* dy, const float* window, float* out, int64_t rows,
                          int64_t length, int64_t frame_length, int64_t hop_length, int64_t frames,
                          brv_stream_t stream);
+/* The complex combination of a ComplexLSTM layer (brever/models/dccrn/dccrn.py:330-358): o (2, 2, n) = module m on input
+ * half h; real = o[0][0] - o[1][1], imag = o[0][1] + o[1][0]; backward: dout from the two gradients. n a multiple of 4,
+ * 16-byte aligned pointers. */
+int brv_complex_mix_forward(const float* o, float* real, float* imag, int64_t n, brv_stream_t stream);
+int brv_complex_mix_backward(const float* greal, const float* gimag, float* dout, int64_t n, brv_stream_t stream);
 int brv_combine(const float* a, const float* b, float* out, int64_t n, float sign,
                 brv_stream_t stream);
 int brv_dccrn_apply_mask(const float* xr, const float* xi, const float* mr, const float* mi,
