@@ -672,3 +672,16 @@ def test_all_reduce_mean_grads_packs_every_parameter_in_a_fixed_order():
     assert torch.equal(a.grad, torch.tensor([0.5, 1.0]))
     assert torch.equal(b.grad, torch.full((3,), 2.))          # missing here, present elsewhere: receives the mean
     assert torch.equal(c.grad, torch.full((4,), 0.5))
+
+
+def test_dccrn_bf16_images_carry_readable_slack_and_tokens_own_one_element():
+    """`_bf16_empty`: 16 readable bytes on both sides of a bf16 image (the LDS-DMA row kernels' contract,
+    include/brever_hip.h); `_token`: the fp32 stand-in autograd tracks for a bf16 activation owns one element."""
+    import torch
+    from brever_amd.models.dccrn import _bf16_empty, _token
+    t = _bf16_empty((2, 3, 4, 5), torch.device('cpu'))
+    assert t.dtype == torch.bfloat16 and t.shape == (2, 3, 4, 5) and t.is_contiguous()
+    assert t.storage_offset() == 8 and t.untyped_storage().nbytes() >= (t.numel() + 16)*2
+    k = _token((2, 3, 4, 5), torch.device('cpu'))
+    assert k.dtype == torch.float32 and k.shape == (2, 3, 4, 5) and k.stride() == (0, 0, 0, 0)
+    assert k.untyped_storage().nbytes() == 4
