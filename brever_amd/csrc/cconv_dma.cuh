@@ -294,7 +294,13 @@ __device__ __forceinline__ void cconv_tile_dma(const CConvParams& p, unsigned ch
 template <int MF, int NF, int WM, int WN, bool SEG, int MODE>
 __global__ __launch_bounds__(CC_THREADS) void cconv_rows_dma_kernel(const CConvParams p) {
   constexpr int NT = 32*NF*WN;
-  constexpr int R = MODE == 0 ? 3 : 4;
+#ifndef CC_RING1
+#define CC_RING1 4       // ring slots of the three- / two-tap forms (diagnostic builds: 2 = 48 KB of LDS, several workgroups per CU)
+#endif
+#ifndef CC_RING0
+#define CC_RING0 3       // ... of the five-tap form
+#endif
+  constexpr int R = MODE == 0 ? CC_RING0 : CC_RING1;
   constexpr int NSLOT = MODE == 0 ? 5 : 3;
   __shared__ __attribute__((aligned(256))) unsigned char lds[R*NSLOT*(NT/128)*4096];
   int ftile = blockIdx.x, r = blockIdx.y, bz = blockIdx.z;     // XCD-aware order: as cconv_rows_kernel
