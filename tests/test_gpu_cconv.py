@@ -481,3 +481,40 @@ def test_batch_norm_backward_adds_a_second_gradient_on_the_fly(types):
     for k in range(1, 5):
         a, b = outs[0][k].double(), outs[1][k].double()
         assert float((a - b).abs().max()) <= 1e-5*float(b.abs().max()) + 1e-6, k
+
+
+def test_bf16_block_path_in_eval_mode_follows_the_emulating_oracle():
+    """``enhance`` under use_amp (batch norms on their running statistics, the bf16-in / bf16-out norm pass with
+    ``training = 0``) after a few training steps, against OracleDCCRN(emulate_bf16=True) in eval mode at the same
+    parameters and running statistics; and the gradient of an eval-mode norm stays refused."""
+    import brever_amd.models.dccrn as D
+    from oracle.dccrn import OracleDCCRN
+    dev = _cuda()
+    torch.manual_seed(11)
+    kw = dict(channels=[8, 16, 32], lstm_channels=32)
+    net = D.DCCRN(**kw).to(dev)
+    n = 16000
+    batch = 0.1*torch.randn(2, 2, n, generator=torch.Generator().manual_seed(12)).to(dev)
+    lengths = torch.tensor([n, n - 2000], device=dev)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    for _ in range(3):                                  # running statistics away from their initial values
+        net.train_step(batch, lengths, True, scaler)
+    oracle = OracleDCCRN(**kw, emulate_bf16=True)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items() if k.startswith('mask_net.')}
+    missing, unexpected = oracle.load_state_dict(sd, strict=False)
+    assert not unexpected and all('mask_net' not in k or 'num_batches' in k for k in missing), (missing, unexpected)
+    oracle.eval()
+    net.eval()
+    x = batch[:, 0].cpu()
+    with torch.no_grad():
+        want = oracle(x)
+        got = net._enhance(batch[:, 0:1].repeat(1, 2, 1), True).cpu()
+        plain = OracleDCCRN(**kw)
+        plain.load_state_dict(oracle.state_dict())
+        plain.eval()
+        ref32 = plain(x)
+    err, emu = float((got - want).norm()/want.norm()), float((want - ref32).norm()/ref32.norm())
+    print(f'eval-mode use_amp enhance: HIP vs emulating oracle {err:.3e}; emulation vs fp32 oracle {emu:.3e}')
+    assert err <= 0.5*emu + 2e-3, (err, emu)
+    with pytest.raises(NotImplementedError):
+        net.loss(batch, lengths, True).backward()
