@@ -300,7 +300,10 @@ __global__ __launch_bounds__(CC_THREADS) void cconv_rows_dma_kernel(const CConvP
 #ifndef CC_RING0
 #define CC_RING0 3       // ... of the five-tap form
 #endif
-  constexpr int R = MODE == 0 ? CC_RING0 : CC_RING1;
+  // (the 32-row tile keeps 74 - 106 registers: with two ring slots = 48 KB of LDS two or three of its workgroups share a
+  // CU, which pays more than the deeper ring there -- 157 -> 127, 140 -> 118, 89 -> 76 us on its three launch shapes;
+  // the larger tiles lose as much: profiles/r06_cconv_ablation.txt, section 8)
+  constexpr int R = MODE == 0 ? CC_RING0 : (MF == 1 ? 2 : CC_RING1);
   constexpr int NSLOT = MODE == 0 ? 5 : 3;
   __shared__ __attribute__((aligned(256))) unsigned char lds[R*NSLOT*(NT/128)*4096];
   int ftile = blockIdx.x, r = blockIdx.y, bz = blockIdx.z;     // XCD-aware order: as cconv_rows_kernel
