@@ -637,6 +637,7 @@ _BF16_ACT = os.environ.get('BRV_DCCRN_BF16_ACT', '1') != '0'
 _BF16_Y = os.environ.get('BRV_DCCRN_BF16_Y', '1') != '0'
 # use_amp: the output projections of the recurrent block on the bf16 MFMA (BRV_DCCRN_LINEAR_LOWP=0: exact-fp32 products)
 _LINEAR_LOWP = os.environ.get('BRV_DCCRN_LINEAR_LOWP', '1') != '0'
+_LINEAR_FUSED = os.environ.get('BRV_DCCRN_LINEAR_FUSED', '1') != '0'   # (0: two linear nodes between transposed copies and a concatenation)
 _TWO_TOKENS = os.environ.get('BRV_DCCRN_TWO_TOKENS', '1') != '0'     # (0: the two gradients of an encoder output summed by a pass)
 
 
@@ -1061,6 +1062,44 @@ class _LinearLowpFunction(torch.autograd.Function):
         return dx, dw, db
 
 
+class _ComplexLinearFunction(torch.autograd.Function):
+    """LSTMBlock.linear_r / linear_i (dccrn.py:293-311) on the recurrent block's (B, T, H) outputs, written straight into
+    the two halves of the (B, 2 F, T) decoder input: the products read their operands transposed in place (no
+    ``transpose().contiguous()`` copies in front, no concatenation behind, none of their gradients' copies)."""
+
+    @staticmethod
+    def forward(ctx, real, imag, wr, br, wi, bi, lowp):
+        real, imag = real.contiguous(), imag.contiguous()
+        B, T, H = real.shape
+        F_ = wr.shape[0]
+        out = torch.empty(B, 2*F_, T, dtype=torch.float32, device=real.device)
+        for k, (x, w, b) in enumerate(((real, wr, br), (imag, wi, bi))):
+            # out[b][k F : (k + 1) F] (F x T) = W (F x H) @ x[b]^T (H x T)
+            _gemm(w, x, out[:, k*F_:], B, F_, T, H, H, H, T, 0, T*H, 2*F_*T, trans_b=1, bias=b, lowp=lowp)
+        ctx.save_for_backward(real, imag, wr, wi)
+        ctx.lowp = lowp
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        real, imag, wr, wi = ctx.saved_tensors
+        B, T, H = real.shape
+        F_ = wr.shape[0]
+        dy = dy.contiguous()
+        lowp = ctx.lowp
+        grads = []
+        for k, (x, w) in enumerate(((real, wr), (imag, wi))):
+            d = dy[:, k*F_:]                                   # (B, F, T) view: rows T apart, items 2 F T apart
+            dx = torch.empty_like(x)                           # dx[b] (T x H) = d[b]^T (T x F) @ W (F x H)
+            _gemm(d, w, dx, B, T, H, F_, T, H, H, 2*F_*T, 0, T*H, trans_a=1, lowp=lowp)
+            dw = torch.empty_like(w)                           # sum_b d[b] (F x T) @ x[b] (T x H)
+            _gemm(d, x, dw, 1, F_, H, T, T, H, H, 0, 0, 0, kbatch=B, a_kbs=2*F_*T, b_kbs=T*H, lowp=lowp)
+            grads.append((dx, dw))
+        sums = torch.empty(2*F_, dtype=torch.float32, device=dy.device)
+        hip.check(hip.lib().brv_row_sum(hip.ptr(dy), hip.ptr(sums), B, 2*F_, T, hip.stream()), 'brv_row_sum')
+        return grads[0][0], grads[1][0], grads[0][1], sums[:F_], grads[1][1], sums[F_:], None
+
+
 class _ApplyMaskFunction(torch.autograd.Function):
     """DCCRN.apply_mask (dccrn.py:96-109): x, mask (B, 2, Fq, T) -> complex (B, 1, Fq, T)."""
 
@@ -1162,6 +1201,10 @@ class DCCRN(BreverBaseModel):
                 real, imag = _CombineFunction.apply(rr, ii, -1.0), _CombineFunction.apply(ri, ir, 1.0)
         # Linear applied on the feature axis of (B, features, T): the output is already in the
         # (channels*freqs, frames) layout of the decoder input
+        if _LINEAR_FUSED and real.is_cuda:
+            out = _ComplexLinearFunction.apply(real, imag, blk.linear_r.weight, blk.linear_r.bias, blk.linear_i.weight,
+                                               blk.linear_i.bias, bool(_AMP['on'] and _LINEAR_LOWP))
+            return out.view(B, C2, Fq, T)
         linear = _LinearLowpFunction if (_AMP['on'] and _LINEAR_LOWP) else _LinearFunction
         out_r = linear.apply(real.transpose(1, 2).contiguous(), blk.linear_r.weight, blk.linear_r.bias)
         out_i = linear.apply(imag.transpose(1, 2).contiguous(), blk.linear_i.weight, blk.linear_i.bias)
