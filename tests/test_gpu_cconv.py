@@ -518,3 +518,32 @@ def test_bf16_block_path_in_eval_mode_follows_the_emulating_oracle():
     assert err <= 0.5*emu + 2e-3, (err, emu)
     with pytest.raises(NotImplementedError):
         net.loss(batch, lengths, True).backward()
+
+
+@pytest.mark.parametrize('flag,tol', [('_TWO_TOKENS', 5e-3), ('_LINEAR_FUSED', 5e-3), ('_LINEAR_LOWP', 5e-2), ('_BF16_Y', 5e-2),
+                                      ('_BF16_ACT', 5e-2), ('_WGRAD_SIDE', 5e-3)])
+def test_every_host_side_switch_of_the_use_amp_path_still_runs_and_agrees(flag, tol):
+    """The A/B switches of models/dccrn.py are code paths of their own: each one turned off gives the
+    loss and the gradients of the default path -- to the run-to-run spread where only the data movement differs, to the
+    bf16 rounding it adds or removes otherwise (global relative gradient distance)."""
+    import brever_amd.models.dccrn as D
+    dev = _cuda()
+    n = 12000
+    batch = 0.1*torch.randn(3, 2, n, generator=torch.Generator().manual_seed(21)).to(dev)
+    lengths = torch.tensor([n, n - 1000, n - 4000], device=dev)
+    out = {}
+    old = getattr(D, flag)
+    try:
+        for value in (True, False):
+            setattr(D, flag, value)
+            torch.manual_seed(5)
+            model = D.DCCRN(channels=[8, 16, 32, 32], lstm_channels=32).to(dev)
+            loss = model.loss(batch, lengths, True)
+            loss.backward()
+            torch.cuda.synchronize()
+            out[value] = (float(loss.detach()), torch.cat([p.grad.reshape(-1) for p in model.parameters()]).double())
+    finally:
+        setattr(D, flag, old)
+    assert abs(out[True][0] - out[False][0]) <= tol*abs(out[True][0]) + 1e-4, (out[True][0], out[False][0])
+    d = float((out[True][1] - out[False][1]).norm()/out[True][1].norm())
+    assert d <= tol + 3e-3, d
