@@ -921,7 +921,10 @@ static int cconv_rows_any(const void* in, const void* in2, int64_t in_seg, const
                        dim3(CC_THREADS), 0, st, p);
   } else if (M > 128) {
     const long long wgs = (long long)((p.Wout + 255)/256)*p.Hout*B*((M + 255)/256);
-    if (wgs < 256) CC_LAUNCH(2, 2, 4, 2); else CC_LAUNCH(2, 4, 4, 2);
+    // (strided launches on bf16 images with up to 256 output rows: two passes of the 128-row LDS-DMA tile beat the
+    // 256-row register tile -- 150 -> 137, 92 -> 61, 209 -> 198 us; with 512 rows they do not: profiles/r06_cconv_ablation.txt)
+    if (CC_DMA && sizeof(TI) == 2 && !transposed && C % 8 == 0 && M <= 256) CC_LAUNCH(2, 2, 2, 4);
+    else if (wgs < 256) CC_LAUNCH(2, 2, 4, 2); else CC_LAUNCH(2, 4, 4, 2);
   } else if (M > 64) CC_LAUNCH(2, 2, 2, 4);
   else if (M > 32) CC_LAUNCH(2, 1, 1, 8);
   else CC_LAUNCH(1, 1, 1, 8);
