@@ -26,6 +26,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn(worker, make_args, nprocs):
+    """mp.spawn with a fresh rendezvous port per attempt: the port `_free_port` found can be taken again before rank 0
+    listens on it (seen once in a full run: 'failed to listen on any local network address', EADDRINUSE)."""
+    import torch.multiprocessing as mp
+    for attempt in range(3):
+        try:
+            mp.spawn(worker, args=make_args(_free_port()), nprocs=nprocs, join=True)
+            return
+        except Exception as e:       # noqa: BLE001 (ProcessRaisedException carries the child's traceback as text)
+            if attempt == 2 or not any(k in str(e) for k in ('failed to listen', 'EADDRINUSE', 'Address already in use')):
+                raise
+
+
 def _build(kind, dev, hooks):
     if kind == 'dccrn':
         from brever_amd.models.dccrn import DCCRN
@@ -102,8 +115,7 @@ def test_two_ranks_equal_the_mean_of_the_half_batch_gradients(tmp_path, kind, am
     """VERDICT r4 item 2 / ADVICE r4 (high). DCCRN `use_amp` runs with its weight gradients on the side stream; the
     `hooks` case is the same model WITHOUT a flat buffer (per-parameter all-reduce from inside backward): the side
     stream must switch itself off there."""
-    import torch.multiprocessing as mp
-    mp.spawn(_rank_worker, args=(2, _free_port(), str(tmp_path), kind, amp, hooks), nprocs=2, join=True)
+    _spawn(_rank_worker, lambda port: (2, port, str(tmp_path), kind, amp, hooks), 2)
     r0, r1 = torch.load(tmp_path/'r0.pt'), torch.load(tmp_path/'r1.pt')
     assert torch.equal(r0['params'], r1['params'])              # the ranks stay in lock-step
     if hooks:
