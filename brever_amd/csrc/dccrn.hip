@@ -1138,8 +1138,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* x, const
 }
 // (dy2: a second gradient with respect to the output, added on the fly -- an encoder block's output feeds the next block
 // AND the decoder's skip input: no pass that sums the two)
-template <typename TI>
-__global__ __launch_bounds__(256) void bn_bwd_stats4_kernel(const TI* x, const float* dy, const float* dy2,
+template <typename TI, typename TG>
+__global__ __launch_bounds__(256) void bn_bwd_stats4_kernel(const TI* x, const TG* dy, const TG* dy2,
                                                             const float* mean, const float* invstd,
                                                             const float* gamma, const float* beta,
                                                             const float* slope, int C, long long HW,
@@ -1151,13 +1151,13 @@ __global__ __launch_bounds__(256) void bn_bwd_stats4_kernel(const TI* x, const f
   const long long n4 = HW >> 2, per = (n4 + pieces - 1)/pieces;
   const long long lo = pc*per, hi = lo + per < n4 ? lo + per : n4;
   const TI* xs = x + ((long long)b*C + c)*HW;
-  const float4* ds = reinterpret_cast<const float4*>(dy + ((long long)b*C + c)*HW);
-  const float4* ds2 = dy2 ? reinterpret_cast<const float4*>(dy2 + ((long long)b*C + c)*HW) : nullptr;
+  const TG* ds = dy + ((long long)b*C + c)*HW;
+  const TG* ds2 = dy2 ? dy2 + ((long long)b*C + c)*HW : nullptr;
   double s1 = 0.0, s2 = 0.0, sa = 0.0;
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const float4 xv = load4(xs, i);
-    float4 dv = ds[i];
-    if (ds2) { const float4 e = ds2[i]; dv.x += e.x; dv.y += e.y; dv.z += e.z; dv.w += e.w; }
+    float4 dv = load4(ds, i);
+    if (ds2) { const float4 e = load4(ds2, i); dv.x += e.x; dv.y += e.y; dv.z += e.z; dv.w += e.w; }
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
     float de[4] = {dv.x, dv.y, dv.z, dv.w};
     float t1 = 0.f, t2 = 0.f, ta = 0.f;
@@ -1213,8 +1213,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, const
 // (TO = bf16_t: dx as bf16 -- the gradient with respect to a row convolution's output, which its data and weight
 // gradient kernels round to bf16 anyway; `sums`: per-block sums of the UNROUNDED dx, what the convolution's bias
 // gradient is made of: [channel][batch item x gridDim.x] partials, added up by row_sum_final-style bn_dxsum_kernel)
-template <typename TI, typename TO>
-__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const TI* x, const float* dy, const float* dy2, const float* mean,
+template <typename TI, typename TG, typename TO>
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const TI* x, const TG* dy, const TG* dy2, const float* mean,
                                                             const float* invstd, const float* gamma,
                                                             const float* beta, const float* slope,
                                                             const float* dgamma, const float* dbeta, TO* dx,
@@ -1225,14 +1225,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const TI* x, const f
   const float mu = mean[c], is = invstd[c], gm = gamma[c], bt = beta[c], db = dbeta[c]*inv_n, dg = dgamma[c]*inv_n;
   const long long n4 = HW >> 2, base = ((long long)b*C + c)*HW;
   const TI* xs = x + base;
-  const float4* ds = reinterpret_cast<const float4*>(dy + base);
-  const float4* ds2 = dy2 ? reinterpret_cast<const float4*>(dy2 + base) : nullptr;
+  const TG* ds = dy + base;
+  const TG* ds2 = dy2 ? dy2 + base : nullptr;
   TO* dst = dx + base;
   double tot = 0.0;
   for (long long i = (long long)blockIdx.x*256 + threadIdx.x; i < n4; i += (long long)gridDim.x*256) {
     const float4 xv = load4(xs, i);
-    float4 dv = ds[i];
-    if (ds2) { const float4 e = ds2[i]; dv.x += e.x; dv.y += e.y; dv.z += e.z; dv.w += e.w; }
+    float4 dv = load4(ds, i);
+    if (ds2) { const float4 e = load4(ds2, i); dv.x += e.x; dv.y += e.y; dv.z += e.z; dv.w += e.w; }
     const float xe[4] = {xv.x, xv.y, xv.z, xv.w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
     float o[4];
 #pragma unroll
@@ -1596,14 +1596,14 @@ int brv_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, i
 
 }  // extern "C"
 
-template <typename TI, typename TO>
-static int bn_backward_any(const TI* x, const float* dy, const float* dy2, const float* save_mean,
+template <typename TI, typename TO, typename TG = float>
+static int bn_backward_any(const TI* x, const TG* dy, const TG* dy2, const float* save_mean,
                              const float* save_invstd, const float* gamma, const float* beta,
                              const float* prelu_slope, TO* dx, float* dgamma, float* dbeta,
                              float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
                              brv_stream_t stream) {
   if (B < 1 || C < 1 || HW < 1) return -1;
-  constexpr bool kF32 = sizeof(TO) == 4 && sizeof(TI) == 4;
+  constexpr bool kF32 = sizeof(TO) == 4 && sizeof(TI) == 4 && sizeof(TG) == 4;
   if (dy2 && ((HW & 3) || B > 1024 || (reinterpret_cast<uintptr_t>(dy2) & 15))) return -1;     // (the vector kernels only)
   if ((!kF32 || dx_sums || dy2) && ((HW & 3) || C > 65535 || B > (kF32 ? 65535 : 1024) ||
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15)))
@@ -1614,7 +1614,7 @@ static int bn_backward_any(const TI* x, const float* dy, const float* dy2, const
   const int slices = vec ? (int)B*pieces : red_slices(B*HW);
   double* part = nullptr;
   DC_OK(hipMallocAsync((void**)&part, (size_t)C*slices*3*sizeof(double), st));
-  if (vec) hipLaunchKernelGGL(bn_bwd_stats4_kernel<TI>, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st, x,
+  if (vec) hipLaunchKernelGGL((bn_bwd_stats4_kernel<TI, TG>), dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st, x,
                               dy, dy2, save_mean, save_invstd, gamma, beta, prelu_slope, (int)C, (long long)HW,
                               pieces, part);
   else if constexpr (kF32) hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)C, (unsigned)slices), dim3(256), 0, st, x,
@@ -1630,7 +1630,7 @@ static int bn_backward_any(const TI* x, const float* dy, const float* dy2, const
     if (gx < 1) gx = 1;
     double* sums = nullptr;
     if (dx_sums) DC_OK(hipMallocAsync((void**)&sums, (size_t)C*B*gx*sizeof(double), st));
-    hipLaunchKernelGGL((bn_bwd_apply4_kernel<TI, TO>), dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, dy, dy2,
+    hipLaunchKernelGGL((bn_bwd_apply4_kernel<TI, TG, TO>), dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st, x, dy, dy2,
                        save_mean, save_invstd, gamma, beta, prelu_slope, dgamma, dbeta, dx, (int)C, (long long)HW,
                        1.f/(float)(B*HW), sums);
     if (dx_sums) {
@@ -1653,7 +1653,7 @@ int brv_batchnorm2d_backward(const float* x, const float* dy, const float* save_
                              const float* prelu_slope, float* dx, float* dgamma, float* dbeta,
                              float* dslope_partial, int64_t B, int64_t C, int64_t HW,
                              brv_stream_t stream) {
-  return bn_backward_any<float, float>(x, dy, nullptr, save_mean, save_invstd, gamma, beta, prelu_slope, dx, dgamma, dbeta,
+  return bn_backward_any<float, float, float>(x, dy, nullptr, save_mean, save_invstd, gamma, beta, prelu_slope, dx, dgamma, dbeta,
                                 dslope_partial, nullptr, B, C, HW, stream);
 }
 
@@ -1662,7 +1662,7 @@ int brv_batchnorm2d_backward_bf16(const float* x, const float* dy, const float* 
                                   const float* prelu_slope, void* dx16, float* dgamma, float* dbeta,
                                   float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
                                   brv_stream_t stream) {
-  return bn_backward_any<float, bf16_t>(x, dy, nullptr, save_mean, save_invstd, gamma, beta, prelu_slope, (bf16_t*)dx16, dgamma, dbeta,
+  return bn_backward_any<float, bf16_t, float>(x, dy, nullptr, save_mean, save_invstd, gamma, beta, prelu_slope, (bf16_t*)dx16, dgamma, dbeta,
                                         dslope_partial, dx_sums, B, C, HW, stream);
 }
 
@@ -1671,16 +1671,29 @@ int brv_batchnorm2d_backward_bf16io(const void* x16, const float* dy, const floa
                                     const float* prelu_slope, void* dx16, float* dgamma, float* dbeta,
                                     float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
                                     brv_stream_t stream) {
-  return bn_backward_any<bf16_t, bf16_t>((const bf16_t*)x16, dy, nullptr, save_mean, save_invstd, gamma, beta, prelu_slope,
+  return bn_backward_any<bf16_t, bf16_t, float>((const bf16_t*)x16, dy, nullptr, save_mean, save_invstd, gamma, beta, prelu_slope,
                                          (bf16_t*)dx16, dgamma, dbeta, dslope_partial, dx_sums, B, C, HW, stream);
 }
 
-int brv_batchnorm2d_backward_ex(const void* x, int32_t x_bf16, const float* dy, const float* dy2, const float* save_mean,
+int brv_batchnorm2d_backward_ex(const void* x, int32_t x_bf16, const void* dy_, const void* dy2_, int32_t dy_bf16,
+                                const float* save_mean,
                                 const float* save_invstd, const float* gamma, const float* beta,
                                 const float* prelu_slope, void* dx, int32_t dx_bf16, float* dgamma, float* dbeta,
                                 float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,
                                 brv_stream_t stream) {
   if (x_bf16 && !dx_bf16) return -1;
+  if (dy_bf16) {           // the gradients with respect to the output as bf16 (what autocast hands a bf16 activation)
+    const bf16_t* g = (const bf16_t*)dy_; const bf16_t* g2 = (const bf16_t*)dy2_;
+    if (x_bf16) return bn_backward_any<bf16_t, bf16_t, bf16_t>((const bf16_t*)x, g, g2, save_mean, save_invstd, gamma, beta,
+                                                               prelu_slope, (bf16_t*)dx, dgamma, dbeta, dslope_partial,
+                                                               dx_sums, B, C, HW, stream);
+    if (dx_bf16) return bn_backward_any<float, bf16_t, bf16_t>((const float*)x, g, g2, save_mean, save_invstd, gamma, beta,
+                                                               prelu_slope, (bf16_t*)dx, dgamma, dbeta, dslope_partial,
+                                                               dx_sums, B, C, HW, stream);
+    return bn_backward_any<float, float, bf16_t>((const float*)x, g, g2, save_mean, save_invstd, gamma, beta, prelu_slope,
+                                                 (float*)dx, dgamma, dbeta, dslope_partial, dx_sums, B, C, HW, stream);
+  }
+  const float* dy = (const float*)dy_; const float* dy2 = (const float*)dy2_;
   if (x_bf16) return bn_backward_any<bf16_t, bf16_t>((const bf16_t*)x, dy, dy2, save_mean, save_invstd, gamma, beta,
                                                      prelu_slope, (bf16_t*)dx, dgamma, dbeta, dslope_partial, dx_sums, B, C,
                                                      HW, stream);

@@ -285,8 +285,8 @@ SIGNATURES = {
     'brv_batchnorm2d_backward_bf16io': (ctypes.c_int, [_c_ptr]*12 + [_c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_complex_mix_forward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
     'brv_complex_mix_backward': (ctypes.c_int, [_c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr]),
-    'brv_batchnorm2d_backward_ex': (ctypes.c_int, [_c_ptr, ctypes.c_int32] + [_c_ptr]*8 + [ctypes.c_int32] + [_c_ptr]*4
-                                    + [_c_i64, _c_i64, _c_i64, _c_ptr]),
+    'brv_batchnorm2d_backward_ex': (ctypes.c_int, [_c_ptr, ctypes.c_int32, _c_ptr, _c_ptr, ctypes.c_int32] + [_c_ptr]*6
+                                    + [ctypes.c_int32] + [_c_ptr]*4 + [_c_i64, _c_i64, _c_i64, _c_ptr]),
     'brv_batchnorm2d_forward_bf16': (ctypes.c_int, [_c_ptr]*9 + [_c_i64]*3
                                      + [_c_f32, _c_f32, ctypes.c_int, _c_ptr]),
     'brv_batchnorm2d_backward_bf16': (ctypes.c_int, [_c_ptr]*12 + [_c_i64, _c_i64, _c_i64, _c_ptr]),

@@ -637,16 +637,20 @@ _BF16_ACT = os.environ.get('BRV_DCCRN_BF16_ACT', '1') != '0'
 _BF16_Y = os.environ.get('BRV_DCCRN_BF16_Y', '1') != '0'
 # use_amp: the output projections of the recurrent block on the bf16 MFMA (BRV_DCCRN_LINEAR_LOWP=0: exact-fp32 products)
 _LINEAR_LOWP = os.environ.get('BRV_DCCRN_LINEAR_LOWP', '1') != '0'
+# the gradient with respect to a bf16 activation is bf16 as well (what autocast hands backward; halves the bytes of the
+# norm's backward passes and of the data-gradient kernels' stores): the token of a bf16 output is a bf16 tensor, so the
+# engine expects -- and the consuming block returns -- a bf16 gradient. BRV_DCCRN_BF16_GRAD=0: fp32 gradients.
+_BF16_GRAD = os.environ.get('BRV_DCCRN_BF16_GRAD', '1') != '0'
 _LINEAR_FUSED = os.environ.get('BRV_DCCRN_LINEAR_FUSED', '1') != '0'   # (0: two linear nodes between transposed copies and a concatenation)
 _TWO_TOKENS = os.environ.get('BRV_DCCRN_TWO_TOKENS', '1') != '0'     # (0: the two gradients of an encoder output summed by a pass)
 
 
-def _token(shape, device):
+def _token(shape, device, dtype=torch.float32):
     """What autograd tracks in place of a bf16 activation: an fp32 tensor of the logical shape that owns ONE element
     (stride 0). The engine checks gradients against the dtype and shape of the forward tensor -- a bf16 output would
     have its fp32 gradient cast to bf16 -- so every block returns (token, bf16 data) and reads its inputs' data from
     the second member; only gradients travel along the first."""
-    return torch.empty(1, dtype=torch.float32, device=device).expand(shape)
+    return torch.empty(1, dtype=dtype, device=device).expand(shape)
 
 
 def _bf16_empty(shape, device):
@@ -712,6 +716,8 @@ class _BlockFunction(torch.autograd.Function):
         hip.check(lib.brv_cconv_rows_ex(hip.ptr(x16), hip.ptr(skip16), seg, hip.ptr(wp_fwd), hip.ptr(bias),
                                         hip.ptr(y), None, 0, B, Cin2, 2*Cout, H, W, int(transpose), int(not first),
                                         int(y16), hip.stream()), 'brv_cconv_rows_ex')
+        ctx.dx_bf16 = x.dtype == torch.bfloat16          # (the input is the bf16 token of a block: its gradient is bf16)
+        assert not two or skip.dtype == x.dtype
         ctx.cfg = (geom4, transpose, (H, W), (Ho, Wo), Cin2, Cout, R, Cw, wr.shape, seg, two)
         ctx.has_norm = norm is not None
         ctx.training = training
@@ -729,7 +735,10 @@ class _BlockFunction(torch.autograd.Function):
             a16 = _bf16_empty((B, 2*Cout, Ho, Wo), dev)
             fwd_fn = lib.brv_batchnorm2d_forward_bf16io if y16 else lib.brv_batchnorm2d_forward_bf16
             hip.check(fwd_fn(*args, hip.ptr(a16), *tail), 'brv_batchnorm2d_forward_bf16[io]')
-            out = (_token(y.shape, dev), a16) + ((_token(y.shape, dev),) if two_out else ())
+            # (bf16 gradients need every encoder output to hand out one token per consumer: a forked token's two
+            # gradients are summed by an fp32 pass)
+            tdt = torch.bfloat16 if (_BF16_GRAD and _TWO_TOKENS) else torch.float32
+            out = (_token(y.shape, dev, tdt), a16) + ((_token(y.shape, dev, tdt),) if two_out else ())
             ctx.mark_non_differentiable(a16)
         else:
             a = torch.empty_like(y)
@@ -770,8 +779,10 @@ class _BlockFunction(torch.autograd.Function):
             dgamma, dbeta, dsl = (torch.empty(2*Cout, dtype=torch.float32, device=dev) for _ in range(3))
             dy = torch.empty_like(y) if small_cin else None
             dy16 = None if small_cin else _bf16_empty(y.shape, dev)
+            assert g2 is None or g2.dtype == g.dtype
             hip.check(lib.brv_batchnorm2d_backward_ex(
-                hip.ptr(y), int(ctx.y16), hip.ptr(g), hip.ptr(g2), hip.ptr(mean), hip.ptr(invstd), hip.ptr(gamma),
+                hip.ptr(y), int(ctx.y16), hip.ptr(g), hip.ptr(g2), int(g.dtype == torch.bfloat16), hip.ptr(mean),
+                hip.ptr(invstd), hip.ptr(gamma),
                 hip.ptr(beta), hip.ptr(slope), hip.ptr(dy if small_cin else dy16), int(not small_cin), hip.ptr(dgamma),
                 hip.ptr(dbeta), hip.ptr(dsl), None if small_cin else hip.ptr(sums), B, 2*Cout, Ho*Wo, hip.stream()),
                 'brv_batchnorm2d_backward_ex')
@@ -815,12 +826,12 @@ class _BlockFunction(torch.autograd.Function):
             src = dy16 if dy16 is not None else _as_bf16(dy)
             M = Cin2
             shape = (B, M//2 if two else M) + ((H, W))
-            dx = torch.empty(shape, dtype=torch.float32, device=dev)
+            dx = torch.empty(shape, dtype=torch.bfloat16 if ctx.dx_bf16 else torch.float32, device=dev)
             dskip = torch.empty_like(dx) if two else None
             # the data gradient of a (transposed) convolution is the other form with the same weights
-            hip.check(lib.brv_cconv_rows_bf16(hip.ptr(src), None, 0, hip.ptr(ctx.wp_bwd), None, hip.ptr(dx),
-                                              hip.ptr(dskip), M//4 if two else 0, B, 2*Cout, M, Ho, Wo,
-                                              int(not transpose), hip.stream()), 'brv_cconv_rows_bf16')
+            hip.check(lib.brv_cconv_rows_ex(hip.ptr(src), None, 0, hip.ptr(ctx.wp_bwd), None, hip.ptr(dx),
+                                            hip.ptr(dskip), M//4 if two else 0, B, 2*Cout, M, Ho, Wo,
+                                            int(not transpose), 1, int(ctx.dx_bf16), hip.stream()), 'brv_cconv_rows_ex')
         if side is None:
             dwr, dwi, dbr, dbi = param_grads()
         else:

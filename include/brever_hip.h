@@ -537,8 +537,10 @@ int brv_batchnorm2d_backward_bf16io(const void* x16, const float* dy, const floa
                                     brv_stream_t stream);
 /* The backward pass with the element types as arguments and an optional SECOND gradient dy2 with respect to the output,
  * added on the fly (an encoder block's output feeds the next block and the decoder's skip input, dccrn.py:205-217: no
- * pass that sums the two gradients). HW a multiple of 4 whenever dy2, dx_sums or a bf16 type is used. */
-int brv_batchnorm2d_backward_ex(const void* x, int32_t x_bf16, const float* dy, const float* dy2, const float* save_mean,
+ * pass that sums the two gradients); dy_bf16: dy / dy2 hold bf16 elements (the gradient of a bf16 activation as
+ * torch.autocast hands it over). HW a multiple of 4 whenever dy2, dx_sums or a bf16 type is used. */
+int brv_batchnorm2d_backward_ex(const void* x, int32_t x_bf16, const void* dy, const void* dy2, int32_t dy_bf16,
+                                const float* save_mean,
                                 const float* save_invstd, const float* gamma, const float* beta,
                                 const float* prelu_slope, void* dx, int32_t dx_bf16, float* dgamma, float* dbeta,
                                 float* dslope_partial, float* dx_sums, int64_t B, int64_t C, int64_t HW,

@@ -254,15 +254,20 @@ class _MaskNet(nn.Module):                                         # dccrn.py:14
             dim = (dim + 2*padding[0] - kernel_size[0])//stride[0] + 1
         self.lstm = _LSTMBlock(channels[-1]*dim, lstm_channels, lstm_layers)
 
+    round_grads = False     # emulation: the gradient with respect to a bf16 activation is bf16 at each of its consumers (round 6)
+
     def forward(self, x):
+        q = _qb if self.round_grads else (lambda t: t)
         outs = []
-        for blk in self.encoder:
-            x = blk(x)
+        for k, blk in enumerate(self.encoder):
+            x = blk(q(x) if k > 0 else x)          # (the inputs of encoder blocks 2.. are bf16 activations)
             outs.append(x)
         x = x.permute(0, x.ndim - 1, *range(1, x.ndim - 1))
         x = self.lstm(x.reshape(*x.shape[:2], -1)).reshape(*x.shape)
         x = x.permute(0, *range(2, x.ndim), 1)
-        for blk, enc in zip(self.decoder, reversed(outs)):
+        for k, (blk, enc) in enumerate(zip(self.decoder, reversed(outs))):
+            if k > 0:                               # (the first decoder block reads fp32 tensors: the recurrent block's
+                x, enc = q(x), q(enc)               # output and the last encoder block's)
             real, imag = x.chunk(2, dim=1)
             sr, si = enc.chunk(2, dim=1)
             x = blk(torch.cat([real, sr, imag, si], dim=1))
@@ -301,6 +306,7 @@ class OracleDCCRN(nn.Module):
         # the block's batch norm writes bf16 too: every block with a norm but the first encoder block (its fp32 output
         # feeds the column-matrix weight gradient) and the last encoder block (fp32 for the recurrent block)
         self.mask_net.lstm.emulate_bf16 = bool(self.emulate_bf16)
+        self.mask_net.round_grads = bool(self.emulate_bf16)
         enc, dec = self.mask_net.encoder, self.mask_net.decoder
         for k, blk in enumerate(enc):
             blk.conv.round_output = bool(self.emulate_bf16) and 0 < k < len(enc) - 1

@@ -342,6 +342,7 @@ def test_bf16_activations_between_the_blocks_change_no_product(channels):
     y16 = D._BF16_Y
     try:
         D._BF16_Y = False           # (the bf16 convolution OUTPUT is a rounding point of its own: tested against the oracle)
+        g16, D._BF16_GRAD = D._BF16_GRAD, False       # (and so are the bf16 gradients between the blocks)
         for lowp in (False, False, True):
             D._BF16_ACT = lowp
             torch.manual_seed(3)
@@ -356,6 +357,7 @@ def test_bf16_activations_between_the_blocks_change_no_product(channels):
     finally:
         D._BF16_ACT = True
         D._BF16_Y = y16
+        D._BF16_GRAD = g16
     ref, again, new = out
 
     def dist(a, b):
@@ -472,7 +474,7 @@ def test_batch_norm_backward_adds_a_second_gradient_on_the_fly(types):
     for a, b in ((dy + dy2, None), (dy, dy2)):
         dx = torch.empty(B, C, H, W, dtype=torch.bfloat16 if dx_bf16 else torch.float32, device=dev)
         dgamma, dbeta, dsl, sums = (torch.empty(C, device=dev) for _ in range(4))
-        hip.check(lib.brv_batchnorm2d_backward_ex(hip.ptr(x), x_bf16, hip.ptr(a), hip.ptr(b), hip.ptr(mean), hip.ptr(invstd),
+        hip.check(lib.brv_batchnorm2d_backward_ex(hip.ptr(x), x_bf16, hip.ptr(a), hip.ptr(b), 0, hip.ptr(mean), hip.ptr(invstd),
                                                   hip.ptr(gamma), hip.ptr(beta), hip.ptr(slope), hip.ptr(dx), dx_bf16,
                                                   hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl), hip.ptr(sums), B, C, H*W,
                                                   hip.stream()), 'brv_batchnorm2d_backward_ex')
@@ -520,7 +522,8 @@ def test_bf16_block_path_in_eval_mode_follows_the_emulating_oracle():
         net.loss(batch, lengths, True).backward()
 
 
-@pytest.mark.parametrize('flag,tol', [('_TWO_TOKENS', 5e-3), ('_LINEAR_FUSED', 5e-3), ('_LINEAR_LOWP', 5e-2), ('_BF16_Y', 5e-2),
+@pytest.mark.parametrize('flag,tol', [('_TWO_TOKENS', 5e-2), ('_LINEAR_FUSED', 5e-3), ('_LINEAR_LOWP', 5e-2), ('_BF16_Y', 5e-2),
+                                      ('_BF16_GRAD', 5e-2),
                                       ('_BF16_ACT', 5e-2), ('_WGRAD_SIDE', 5e-3)])
 def test_every_host_side_switch_of_the_use_amp_path_still_runs_and_agrees(flag, tol):
     """The A/B switches of models/dccrn.py are code paths of their own: each one turned off gives the
@@ -547,3 +550,36 @@ def test_every_host_side_switch_of_the_use_amp_path_still_runs_and_agrees(flag, 
     assert abs(out[True][0] - out[False][0]) <= tol*abs(out[True][0]) + 1e-4, (out[True][0], out[False][0])
     d = float((out[True][1] - out[False][1]).norm()/out[True][1].norm())
     assert d <= tol + 3e-3, d
+
+
+def test_batch_norm_backward_reads_bf16_gradients():
+    """brv_batchnorm2d_backward_ex(dy_bf16 = 1) == the same pass on the widened gradients (one and two of them)."""
+    from brever_amd import hip
+    lib = hip.lib()
+    dev = _cuda()
+    B, C, H, W = 3, 16, 4, 125
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, C, H, W, generator=g).to(dev).to(torch.bfloat16)
+    dy, dy2 = (torch.randn(B, C, H, W, generator=g).to(dev).to(torch.bfloat16) for _ in range(2))
+    gamma = (1 + 0.1*torch.randn(C, generator=g)).to(dev)
+    beta = (0.1*torch.randn(C, generator=g)).to(dev)
+    slope = torch.tensor([0.25], device=dev)
+    xf = x.float()
+    mean = xf.mean(dim=(0, 2, 3)).contiguous()
+    invstd = (xf.var(dim=(0, 2, 3), unbiased=False) + 1e-5).rsqrt().contiguous()
+    for second in (None, dy2):
+        outs = []
+        for lowp in (0, 1):
+            a = dy if lowp else dy.float()
+            b = None if second is None else (second if lowp else second.float())
+            dx = torch.empty(B, C, H, W, dtype=torch.bfloat16, device=dev)
+            dgamma, dbeta, dsl, sums = (torch.empty(C, device=dev) for _ in range(4))
+            hip.check(lib.brv_batchnorm2d_backward_ex(hip.ptr(x), 1, hip.ptr(a), hip.ptr(b), lowp, hip.ptr(mean),
+                                                      hip.ptr(invstd), hip.ptr(gamma), hip.ptr(beta), hip.ptr(slope),
+                                                      hip.ptr(dx), 1, hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dsl),
+                                                      hip.ptr(sums), B, C, H*W, hip.stream()), 'brv_batchnorm2d_backward_ex')
+            outs.append((dx, dgamma, dbeta, dsl, sums))
+        assert torch.equal(outs[0][0], outs[1][0])
+        for k in range(1, 5):
+            p, q = outs[0][k].double(), outs[1][k].double()
+            assert float((p - q).abs().max()) <= 1e-5*float(q.abs().max()) + 1e-6, k
