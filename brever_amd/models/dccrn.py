@@ -226,6 +226,8 @@ def _cconv_wgrad(small, big, small2=None):
     ws = torch.empty(hip.lib().brv_cconv_wgrad_workspace_bytes(B, A, C, Hs), dtype=torch.uint8, device=big.device)
     lowp = big.dtype == torch.bfloat16          # (all three images alike: _BlockFunction)
     assert small.dtype == big.dtype and (small2 is None or small2.dtype == big.dtype)
+    # (the LDS-DMA kernel fetches whole 16-byte pieces around the images' ends: include/brever_hip.h)
+    assert not lowp or all(_has_slack(t) for t in (small, small2, big) if t is not None), 'bf16 image without slack'
     fn, name = (hip.lib().brv_cconv_wgrad_bf16, 'brv_cconv_wgrad_bf16') if lowp else \
         (hip.lib().brv_cconv_wgrad, 'brv_cconv_wgrad')
     hip.check(fn(hip.ptr(small), hip.ptr(small2), hip.ptr(big), hip.ptr(out), hip.ptr(ws),
@@ -662,6 +664,11 @@ def _bf16_empty(shape, device):
     return torch.empty(n + 16, dtype=torch.bfloat16, device=device)[8:8 + n].view(shape)
 
 
+def _has_slack(t):
+    """``t`` (bf16) sits at least 8 elements inside its storage on both sides (``_bf16_empty``)."""
+    return t.storage_offset() >= 8 and t.untyped_storage().nbytes()//2 >= t.storage_offset() + t.numel() + 8
+
+
 def _as_bf16(t):
     with torch.no_grad():
         out = _bf16_empty(t.shape, t.device)
@@ -716,6 +723,7 @@ class _BlockFunction(torch.autograd.Function):
         hip.check(lib.brv_cconv_rows_ex(hip.ptr(x16), hip.ptr(skip16), seg, hip.ptr(wp_fwd), hip.ptr(bias),
                                         hip.ptr(y), None, 0, B, Cin2, 2*Cout, H, W, int(transpose), int(not first),
                                         int(y16), hip.stream()), 'brv_cconv_rows_ex')
+        assert first or (_has_slack(x16) and (skip16 is None or _has_slack(skip16))), 'bf16 image without slack'
         ctx.dx_bf16 = x.dtype == torch.bfloat16          # (the input is the bf16 token of a block: its gradient is bf16)
         assert not two or skip.dtype == x.dtype
         ctx.cfg = (geom4, transpose, (H, W), (Ho, Wo), Cin2, Cout, R, Cw, wr.shape, seg, two)
@@ -824,6 +832,7 @@ class _BlockFunction(torch.autograd.Function):
         dx = dskip = None
         if need_dx:
             src = dy16 if dy16 is not None else _as_bf16(dy)
+            assert _has_slack(src), 'bf16 image without slack'
             M = Cin2
             shape = (B, M//2 if two else M) + ((H, W))
             dx = torch.empty(shape, dtype=torch.bfloat16 if ctx.dx_bf16 else torch.float32, device=dev)
